@@ -1,0 +1,681 @@
+"""CPU oracle for the S-VolSDF volume-rendering hot path (numpy, float32).
+
+TEST INFRASTRUCTURE ONLY.  This module is a restatement, written from scratch, of
+the algorithm of the reference (cvlab-stonybrook/s-volsdf, file:line cited on every
+function, paths relative to the reference root).  Only `tests/`, `__graft_entry__.smoke()`
+and `bench.py`'s `cpu_baseline` leg may import it; the product path
+(`s-volsdf_amd/`) never does and fails loudly when the HIP library is missing.
+
+Parity status: PINNED.  Every function here is checked in tests/test_oracle_golden.py
+against golden arrays produced by importing the reference itself on CPU
+(tests/golden/make_fixtures.py, run in the build container; the reference has no
+tests or golden vectors of its own -- SURVEY.md section 4).
+
+Numeric contract (what "bit-exact" means for the sampler), also in DESIGN.md:
+  * every elementary op (+ - * / sqrt, compare) is an IEEE float32 op in the
+    reference's order, with no fused multiply-add;
+  * exp / expm1 are `det_exp` / `det_expm1` below: evaluated in float64 by a fixed
+    Cody-Waite + degree-13 Horner recipe that uses only IEEE add/mul (no fma, no
+    libm), then rounded once to float32.  They agree with torch's float32
+    exp/expm1 to <= 1 ulp and are reproducible bit for bit on any IEEE machine,
+    which is what lets the HIP sampler be compared bit-exactly with this file;
+  * cumsum / row sums accumulate in float64 and round each prefix to float32
+    (what torch-CPU cumsum does) in the CANONICAL BLOCKED ORDER of
+    `canon_cumsum` (64 contiguous chunks, sequential inside a chunk, Kogge-Stone
+    across chunks) -- the order a 64-lane wavefront scan produces.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+F32 = np.float32
+F64 = np.float64
+
+# ----------------------------------------------------------------------------------------
+# deterministic transcendental functions
+# ----------------------------------------------------------------------------------------
+_LOG2E = 1.4426950408889634
+_LN2_HI = 6.93147180369123816490e-01   # 0x3fe62e42fee00000
+_LN2_LO = 1.90821492927058770002e-10   # 0x3dea39ef35793c76
+# 1/n! for n = 0..13, nearest doubles
+_EXP_C = (
+    1.0, 1.0, 0.5, 1.6666666666666666e-01, 4.1666666666666664e-02, 8.3333333333333332e-03,
+    1.3888888888888889e-03, 1.9841269841269841e-04, 2.4801587301587302e-05,
+    2.7557319223985893e-06, 2.7557319223985888e-07, 2.5052108385441720e-08,
+    2.0876756987868100e-09, 1.6059043836821613e-10,
+)
+_EXP_HI = 88.72283935546875     # above this float32 exp overflows to +inf
+_EXP_LO = -104.0                # below this the float32 result is 0
+
+
+def _exp64(x: np.ndarray) -> np.ndarray:
+    """float64 exp by the fixed recipe (input already float64, finite, in [_EXP_LO,_EXP_HI])."""
+    k = np.rint(x * _LOG2E)
+    r = (x - k * _LN2_HI) - k * _LN2_LO
+    p = np.full_like(r, _EXP_C[13])
+    for c in _EXP_C[12::-1]:
+        p = p * r + c
+    return p * np.ldexp(1.0, k.astype(np.int64))
+
+
+def det_exp(x) -> np.ndarray:
+    """float32 -> float32 exp, reproducible bit for bit (see module docstring)."""
+    x = np.asarray(x, dtype=F32)
+    xd = x.astype(F64)
+    with np.errstate(all="ignore"):
+        inner = _exp64(np.clip(np.nan_to_num(xd, nan=0.0), _EXP_LO, _EXP_HI))
+        y = inner.astype(F32)
+    y = np.where(xd > _EXP_HI, F32(np.inf), y)
+    y = np.where(xd < _EXP_LO, F32(0.0), y)
+    y = np.where(np.isnan(xd), F32(np.nan), y)
+    return y.astype(F32)
+
+
+def det_expm1(x) -> np.ndarray:
+    """float32 -> float32 expm1: |x| < 2^-20 -> x + x*x/2, else exp64(x) - 1 (float64), rounded once."""
+    x = np.asarray(x, dtype=F32)
+    xd = x.astype(F64)
+    with np.errstate(all="ignore"):
+        xc = np.clip(np.nan_to_num(xd, nan=0.0), _EXP_LO, _EXP_HI)
+        big = _exp64(xc) - 1.0
+        small = xd + (xd * xd) * 0.5
+        y = np.where(np.abs(xd) < 9.5367431640625e-07, small, big).astype(F32)
+    y = np.where(xd > _EXP_HI, F32(np.inf), y)
+    y = np.where(xd < _EXP_LO, F32(-1.0), y)
+    y = np.where(np.isnan(xd), F32(np.nan), y)
+    return y.astype(F32)
+
+
+# ----------------------------------------------------------------------------------------
+# canonical scans
+# ----------------------------------------------------------------------------------------
+def canon_cumsum64(x) -> np.ndarray:
+    """Inclusive cumsum along the last axis, float64 accumulation in the canonical blocked order.
+
+    Lane i of 64 owns the contiguous chunk [i*c, (i+1)*c), c = ceil(m/64); prefixes are
+    sequential inside a chunk; chunk totals are combined by a Kogge-Stone inclusive scan
+    (d = 1,2,4,8,16,32: t[i] += t[i-d]); result[i*c+j] = offset_i + local_i[j].
+    Returns float64 (callers round to float32).
+    """
+    x = np.asarray(x)
+    m = x.shape[-1]
+    c = max(1, -(-m // 64))
+    pad = 64 * c - m
+    xd = x.astype(F64)
+    if pad:
+        xd = np.concatenate([xd, np.zeros(x.shape[:-1] + (pad,), F64)], -1)
+    xd = xd.reshape(x.shape[:-1] + (64, c))
+    local = np.empty_like(xd)
+    acc = np.zeros(xd.shape[:-1], F64)
+    for j in range(c):
+        acc = acc + xd[..., j]
+        local[..., j] = acc
+    tot = local[..., c - 1].copy()
+    for d in (1, 2, 4, 8, 16, 32):
+        nxt = tot.copy()
+        nxt[..., d:] = tot[..., d:] + tot[..., :-d]
+        tot = nxt
+    off = np.concatenate([np.zeros(tot.shape[:-1] + (1,), F64), tot[..., :-1]], -1)
+    out = off[..., None] + local
+    return out.reshape(x.shape[:-1] + (64 * c,))[..., :m]
+
+
+def canon_cumsum(x) -> np.ndarray:
+    """torch.cumsum(float32) restatement: float64 accumulate, each prefix rounded to float32."""
+    return canon_cumsum64(x).astype(F32)
+
+
+def canon_sum(x) -> np.ndarray:
+    """Row sum = last prefix of canon_cumsum (float32), keepdims."""
+    return canon_cumsum64(x)[..., -1:].astype(F32)
+
+
+# ----------------------------------------------------------------------------------------
+# a1  rays      volsdf/utils/rend_util.py:60-95 (get_camera_params), :143-156 (lift)
+# ----------------------------------------------------------------------------------------
+def _normalize(v, eps=1e-12):
+    n = np.sqrt((v * v).sum(-1, keepdims=True, dtype=F32)).astype(F32)
+    return (v / np.maximum(n, F32(eps))).astype(F32)
+
+
+def lift(x, y, z, K):
+    """rend_util.py:143-156.  K (4,4); x,y,z (N,)."""
+    fx, fy, cx, cy, sk = (F32(K[0, 0]), F32(K[1, 1]), F32(K[0, 2]), F32(K[1, 2]), F32(K[0, 1]))
+    x_l = (x - cx + cy * sk / fy - sk * y / fy) / fx * z
+    y_l = (y - cy) / fy * z
+    return np.stack([x_l, y_l, z], -1).astype(F32)
+
+
+def rays_from_uv(uv, pose, K):
+    """rend_util.py:60-95 + volsdf/model/network.py:213-217.
+
+    uv (R,2) pixel coords (x=col, y=row), pose (4,4) cam-to-world, K (4,4).
+    Returns ray_dirs (R,3) unit, cam_loc (3,), depth_scale (R,1) = z of the unit ray in the camera frame.
+    """
+    uv = np.asarray(uv, F32)
+    pose = np.asarray(pose, F32)
+    K = np.asarray(K, F32)
+    p_cam = lift(uv[:, 0], uv[:, 1], np.ones(uv.shape[0], F32), K)          # (R,3)
+    world = (p_cam @ pose[:3, :3].T).astype(F32) + pose[:3, 3]
+    dirs = _normalize(world - pose[:3, 3])
+    depth_scale = _normalize(p_cam.copy())[:, 2:3]     # identity pose: dirs_cam = normalize(p_cam)
+    return dirs, pose[:3, 3].copy(), depth_scale
+
+
+def sphere_intersections(cam_loc, dirs, r):
+    """rend_util.py:200-216.  cam_loc (R,3), dirs (R,3) -> (R,2) near/far, clamped >= 0."""
+    dot = (dirs * cam_loc).sum(-1, keepdims=True, dtype=F32)
+    under = dot ** 2 - ((cam_loc * cam_loc).sum(-1, keepdims=True, dtype=F32) - F32(r * r))
+    if (under <= 0).any():
+        raise ValueError("BOUNDING SPHERE PROBLEM")       # the reference calls exit() here
+    s = np.sqrt(under).astype(F32)
+    return np.maximum(np.concatenate([-s - dot, s - dot], -1), F32(0)).astype(F32)
+
+
+# ----------------------------------------------------------------------------------------
+# a4/A2  positional encoding     volsdf/model/embedder.py:10-36
+# ----------------------------------------------------------------------------------------
+def posenc(x, L):
+    """[x, sin(2^0 x), cos(2^0 x), sin(2^1 x), ...]; x (P,d) -> (P, d*(1+2L))."""
+    x = np.asarray(x, F32)
+    out = [x]
+    for k in range(L):
+        f = F32(2.0 ** k)
+        out.append(np.sin(x * f, dtype=F32))
+        out.append(np.cos(x * f, dtype=F32))
+    return np.concatenate(out, -1).astype(F32)
+
+
+# ----------------------------------------------------------------------------------------
+# a5  SDF MLP      volsdf/model/network.py:71-131
+# ----------------------------------------------------------------------------------------
+def weightnorm(g, v):
+    """nn.utils.weight_norm(dim=0): w = g * v / ||v||_row   (network.py:64-65)."""
+    v = np.asarray(v, F32)
+    nrm = np.sqrt((v.astype(F64) ** 2).sum(1, keepdims=True)).astype(F32)
+    return (np.asarray(g, F32).reshape(-1, 1) * (v / nrm)).astype(F32)
+
+
+def effective_weights(params, prefix, n_layers):
+    """params: dict name -> array with torch state_dict names. Returns [(W,b)] effective per layer."""
+    out = []
+    for l in range(n_layers):
+        b = np.asarray(params[f"{prefix}.lin{l}.bias"], F32)
+        if f"{prefix}.lin{l}.weight_g" in params:
+            W = weightnorm(params[f"{prefix}.lin{l}.weight_g"], params[f"{prefix}.lin{l}.weight_v"])
+        else:
+            W = np.asarray(params[f"{prefix}.lin{l}.weight"], F32)
+        out.append((W, b))
+    return out
+
+
+def softplus100(a):
+    """nn.Softplus(beta=100), threshold 20 (network.py:69): a if 100a > 20 else log1p(exp(100a))/100."""
+    a = np.asarray(a, F32)
+    t = a * F32(100.0)
+    with np.errstate(over="ignore"):
+        soft = (np.log1p(np.exp(np.minimum(t, F32(30.0)), dtype=F32), dtype=F32) / F32(100.0)).astype(F32)
+    return np.where(t > F32(20.0), a, soft).astype(F32)
+
+
+def sigmoid100(a):
+    """d softplus100 / da = sigmoid(100 a) (1 above the threshold)."""
+    t = np.asarray(a, F32).astype(F64) * 100.0
+    s = 1.0 / (1.0 + np.exp(-np.clip(t, -700, 700)))
+    return np.where(t > 20.0, 1.0, s).astype(F32)
+
+
+INV_SQRT2 = F32(1.0 / np.sqrt(2.0))
+
+
+def sdf_mlp_forward(layers, x, multires=6, skip_in=(4,), return_cache=False):
+    """ImplicitNetwork.forward, network.py:71-88.  layers = [(W,b)]*9; x (P,d_in) -> (P, 1+feat)."""
+    x = np.asarray(x, F32)
+    inp = posenc(x, multires) if multires > 0 else x
+    h = inp
+    cache = []
+    n = len(layers)
+    for l, (W, b) in enumerate(layers):
+        if l in skip_in:
+            h = (np.concatenate([h, inp], 1) / F32(np.sqrt(2.0))).astype(F32)
+        a = (h @ W.T + b).astype(F32)
+        cache.append((h, a))
+        h = softplus100(a) if l < n - 1 else a
+    if return_cache:
+        return h, inp, cache
+    return h
+
+
+def sdf_clamp(sdf, x, sdf_bounding_sphere, sphere_scale):
+    """network.py:110-112 / :128-130: min(sdf, scale*(R - |x|)) when sdf_bounding_sphere > 0."""
+    if sdf_bounding_sphere > 0.0:
+        nrm = np.sqrt((x * x).sum(1, keepdims=True, dtype=F32)).astype(F32)
+        sphere = (F32(sphere_scale) * (F32(sdf_bounding_sphere) - nrm)).astype(F32)
+        return np.minimum(sdf, sphere), sphere
+    return sdf, None
+
+
+def sdf_vals(layers, x, sdf_bounding_sphere=3.0, sphere_scale=20.0, multires=6):
+    """ImplicitNetwork.get_sdf_vals, network.py:125-131 -> (P,1)."""
+    out = sdf_mlp_forward(layers, x, multires)
+    return sdf_clamp(out[:, :1], np.asarray(x, F32), sdf_bounding_sphere, sphere_scale)[0]
+
+
+def posenc_vjp(x, g_pe, L):
+    """d/dx of posenc contracted with g_pe (P, d*(1+2L)) -> (P,d)."""
+    d = x.shape[1]
+    gx = g_pe[:, :d].astype(F64).copy()
+    xd = x.astype(F64)
+    for k in range(L):
+        f = 2.0 ** k
+        gs = g_pe[:, d * (1 + 2 * k): d * (2 + 2 * k)].astype(F64)
+        gc = g_pe[:, d * (2 + 2 * k): d * (3 + 2 * k)].astype(F64)
+        gx += f * (np.cos(xd * f) * gs - np.sin(xd * f) * gc)
+    return gx.astype(F32)
+
+
+def sdf_outputs(layers, x, sdf_bounding_sphere=3.0, sphere_scale=20.0, multires=6, skip_in=(4,),
+                clamp=True):
+    """ImplicitNetwork.get_outputs, network.py:105-123 -> sdf (P,1), feature (P,256), d sdf/dx (P,3).
+
+    The gradient is the reverse-mode derivative of (clamped) sdf w.r.t. x, written out by hand
+    (the reference gets it from torch.autograd.grad, :115-121).  `clamp=False` gives
+    ImplicitNetwork.gradient (:90-103), which differentiates the raw output column 0.
+    """
+    x = np.asarray(x, F32)
+    out, inp, cache = sdf_mlp_forward(layers, x, multires, skip_in, return_cache=True)
+    n = len(layers)
+    d_pe = inp.shape[1]
+    g = np.zeros_like(out)
+    g[:, 0] = 1.0                                  # d sdf / d a_8
+    g_inp = np.zeros_like(inp)
+    for l in range(n - 1, -1, -1):
+        W, _ = layers[l]
+        h, a = cache[l]
+        if l < n - 1:
+            g = (g * sigmoid100(a)).astype(F32)
+        g = (g @ W).astype(F32)                    # grad wrt this layer's input
+        if l in skip_in:
+            g = (g / F32(np.sqrt(2.0))).astype(F32)
+            g_inp += g[:, -d_pe:]
+            g = g[:, :-d_pe]
+    g_inp += g
+    grad = posenc_vjp(x, g_inp, multires) if multires > 0 else g_inp
+    sdf = out[:, :1]
+    if clamp and sdf_bounding_sphere > 0.0:
+        sdf_c, sphere = sdf_clamp(sdf, x, sdf_bounding_sphere, sphere_scale)
+        nrm = np.sqrt((x * x).sum(1, keepdims=True, dtype=F32)).astype(F32)
+        use_sphere = sphere < sdf                  # torch.minimum: ties keep grad of both halves /2; measure-zero
+        grad = np.where(use_sphere, (-F32(sphere_scale) * x / nrm).astype(F32), grad)
+        sdf = sdf_c
+    return sdf.astype(F32), out[:, 1:].astype(F32), grad.astype(F32)
+
+
+# ----------------------------------------------------------------------------------------
+# a6  radiance MLP     volsdf/model/network.py:170-190
+# ----------------------------------------------------------------------------------------
+def rgb_mlp_forward(layers, points, normals, view_dirs, feat, mode="idr", multires_view=1):
+    vd = posenc(view_dirs, multires_view) if multires_view > 0 else np.asarray(view_dirs, F32)
+    if mode == "idr":
+        h = np.concatenate([points, vd, normals, feat], -1).astype(F32)
+    else:
+        h = np.concatenate([vd, feat], -1).astype(F32)
+    n = len(layers)
+    for l, (W, b) in enumerate(layers):
+        h = (h @ W.T + b).astype(F32)
+        if l < n - 1:
+            h = np.maximum(h, F32(0))
+    return (1.0 / (1.0 + np.exp(-h.astype(F64)))).astype(F32)
+
+
+# ----------------------------------------------------------------------------------------
+# a7  Laplace density     volsdf/model/density.py:21-30
+# ----------------------------------------------------------------------------------------
+def get_beta(beta_param, beta_min=1e-4):
+    return F32(abs(F32(beta_param)) + F32(beta_min))
+
+
+def laplace_density(sdf, beta):
+    """alpha*(0.5 + 0.5*sign(s)*expm1(-|s|/beta)), alpha = 1/beta; beta scalar or broadcastable."""
+    sdf = np.asarray(sdf, F32)
+    beta = np.asarray(beta, F32)
+    alpha = (F32(1.0) / beta).astype(F32)
+    e = det_expm1((-np.abs(sdf) / beta).astype(F32))
+    return (alpha * (F32(0.5) + F32(0.5) * np.sign(sdf).astype(F32) * e)).astype(F32)
+
+
+# ----------------------------------------------------------------------------------------
+# a2  uniform sampler     volsdf/model/ray_sampler.py:22-43
+# ----------------------------------------------------------------------------------------
+def _fma32(a, b, c):
+    """float32 fused multiply-add (one rounding), emulated exactly in float64."""
+    return (np.asarray(a, F32).astype(F64) * np.asarray(b, F32).astype(F64) + np.asarray(c, F32).astype(F64)).astype(F32)
+
+
+def linspace32(start, end, n):
+    """torch.linspace(start,end,n) in float32: step=(end-start)/(n-1) (float32);
+    fma(step, i, start) for i < n/2, fma(-step, n-1-i, end) otherwise (ATen RangeFactories)."""
+    step = (F32(end) - F32(start)) / F32(n - 1)
+    i = np.arange(n)
+    lo = _fma32(step, i.astype(F32), F32(start))
+    hi = _fma32(-step, (n - 1 - i).astype(F32), F32(end))
+    return np.where(i < n // 2, lo, hi).astype(F32)
+
+
+def linspace01(n):
+    return linspace32(0.0, 1.0, n)
+
+
+def uniform_z(near, far, n_samples, t_rand=None):
+    """near (R,1)/scalar, far (R,1)/scalar; t_rand (R,n) in train mode (the torch.rand draw of :39)."""
+    t = linspace01(n_samples)[None, :]
+    near = np.asarray(near, F32).reshape(-1, 1)
+    far = np.asarray(far, F32).reshape(-1, 1)
+    z = (near * (F32(1.0) - t) + far * t).astype(F32)
+    if t_rand is not None:
+        if z.shape[0] == 1:
+            z = np.repeat(z, t_rand.shape[0], 0)
+        mids = (F32(0.5) * (z[:, 1:] + z[:, :-1])).astype(F32)
+        upper = np.concatenate([mids, z[:, -1:]], -1)
+        lower = np.concatenate([z[:, :1], mids], -1)
+        z = (lower + (upper - lower) * np.asarray(t_rand, F32)).astype(F32)
+    return z
+
+
+# ----------------------------------------------------------------------------------------
+# a3/a4  error-bounded sampler     volsdf/model/ray_sampler.py:67-229
+# ----------------------------------------------------------------------------------------
+def d_star_bound(z, sdf):
+    """ray_sampler.py:97-111.  z, sdf (R,n) -> dists (R,n-1), d_star (R,n-1)."""
+    dists = (z[:, 1:] - z[:, :-1]).astype(F32)
+    a, b, c = dists, np.abs(sdf[:, :-1]), np.abs(sdf[:, 1:])
+    a2, b2, c2 = (a * a).astype(F32), (b * b).astype(F32), (c * c).astype(F32)
+    first = (a2 + b2).astype(F32) <= c2
+    second = (a2 + c2).astype(F32) <= b2
+    d_star = np.zeros_like(dists)
+    d_star[first] = b[first]
+    d_star[second] = c[second]
+    s = ((a + b + c).astype(F32) / F32(2.0)).astype(F32)
+    area = (((s * (s - a)).astype(F32) * (s - b)).astype(F32) * (s - c)).astype(F32)
+    mask = ~first & ~second & ((b + c).astype(F32) - a > 0)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        tri = ((F32(2.0) * np.sqrt(area).astype(F32)).astype(F32) / a).astype(F32)
+    d_star[mask] = tri[mask]
+    same_sign = (np.sign(sdf[:, 1:]) * np.sign(sdf[:, :-1])) == 1
+    return dists, (same_sign.astype(F32) * d_star).astype(F32)
+
+
+def error_bound(beta, sdf, dists, d_star):
+    """ErrorBoundSampler.get_error_bound, ray_sampler.py:221-229.  beta scalar or (R,1). -> (R,)"""
+    beta = np.asarray(beta, F32)
+    density = laplace_density(sdf, beta)
+    sfe = np.concatenate([np.zeros((dists.shape[0], 1), F32), (dists * density[:, :-1]).astype(F32)], -1)
+    integral = canon_cumsum(sfe)
+    with np.errstate(over="ignore", invalid="ignore"):
+        eps_sec = ((det_exp((-d_star / beta).astype(F32)) * (dists * dists).astype(F32)).astype(F32)
+                   / (F32(4.0) * (beta * beta).astype(F32)).astype(F32)).astype(F32)
+        err_int = canon_cumsum(eps_sec)
+        bound = ((np.minimum(det_exp(err_int), F32(1.0e6)) - F32(1.0)).astype(F32)
+                 * det_exp(-integral[:, :-1])).astype(F32)
+    return bound.max(-1)
+
+
+def ray_weights(z, sdf, beta, last_dist=1e10):
+    """ray_sampler.py:126-132 / network.py:281-295: density -> free energy -> alpha, T, weights."""
+    density = laplace_density(sdf, beta)
+    dists = np.concatenate([(z[:, 1:] - z[:, :-1]).astype(F32),
+                            np.full((z.shape[0], 1), last_dist, F32)], -1)
+    fe = (dists * density).astype(F32)
+    sfe = np.concatenate([np.zeros((z.shape[0], 1), F32), fe[:, :-1]], -1)
+    alpha = (F32(1.0) - det_exp(-fe)).astype(F32)
+    trans = det_exp(-canon_cumsum(sfe))
+    return (alpha * trans).astype(F32), trans, dists
+
+
+def searchsorted_right(cdf, u):
+    """torch.searchsorted(cdf, u, right=True) rowwise: number of cdf entries <= u."""
+    return (cdf[:, None, :] <= u[:, :, None]).sum(-1).astype(np.int64)
+
+
+def inverse_cdf(cdf, bins, u):
+    """ray_sampler.py:173-185 -> samples (R,N), inds (R,N) int64."""
+    n = cdf.shape[-1]
+    inds = searchsorted_right(cdf, u)
+    below = np.maximum(inds - 1, 0)
+    above = np.minimum(inds, n - 1)
+    cdf_b = np.take_along_axis(cdf, below, 1)
+    cdf_a = np.take_along_axis(cdf, above, 1)
+    bin_b = np.take_along_axis(bins, below, 1)
+    bin_a = np.take_along_axis(bins, above, 1)
+    denom = (cdf_a - cdf_b).astype(F32)
+    denom = np.where(denom < F32(1e-5), F32(1.0), denom)
+    t = ((u - cdf_b).astype(F32) / denom).astype(F32)
+    return (bin_b + (t * (bin_a - bin_b).astype(F32)).astype(F32)).astype(F32), inds
+
+
+def stable_merge(z, samples):
+    """torch.sort(cat[z, samples]) values + indices with ties resolved to the lower index."""
+    cat = np.concatenate([z, samples], -1)
+    idx = np.argsort(cat, axis=-1, kind="stable")
+    return np.take_along_axis(cat, idx, -1), idx.astype(np.int64)
+
+
+def extras_index_eval(n, n_extra):
+    """torch.linspace(0, n-1, n_extra).long()  (ray_sampler.py:203), float32 linspace then truncation."""
+    return linspace32(0.0, float(n - 1), n_extra).astype(np.int64)
+
+
+def sampler_round(z, sdf, beta_in, beta0, *, upsample_allowed, training=False, u_final=None,
+                  N_samples=64, N_samples_eval=128, eps=0.1, beta_iters=10, add_tiny=0.0):
+    """One pass of the `while` body of ErrorBoundSampler.get_z_vals after the sdf merge
+    (ray_sampler.py:96-190): d*, beta line search, weights, convergence test, pdf/cdf, inverse CDF and,
+    when up-sampling, the merge-sort.
+
+    z, sdf (R,n): current bins and their sdf; beta_in (R,): beta carried over from the previous round
+    (the Lemma-2 bound on the first); upsample_allowed = (total_iters + 1 < max_total_iters).
+    Returns a dict (see keys below); 'z_next'/'samples_idx' only when up-sampling.
+    """
+    R = z.shape[0]
+    beta0 = F32(beta0)
+    dists, d_star = d_star_bound(z, sdf)
+
+    curr = error_bound(beta0, sdf, dists, d_star)
+    beta = np.asarray(beta_in, F32).copy()
+    beta[curr <= F32(eps)] = beta0
+    beta_min, beta_max = np.full(R, beta0, F32), beta
+    for _ in range(beta_iters):
+        mid = ((beta_min + beta_max) / F32(2.0)).astype(F32)
+        curr = error_bound(mid[:, None], sdf, dists, d_star)
+        beta_max = np.where(curr <= F32(eps), mid, beta_max).astype(F32)
+        beta_min = np.where(curr > F32(eps), mid, beta_min).astype(F32)
+    beta = beta_max
+
+    weights, trans, _ = ray_weights(z, sdf, beta[:, None])
+
+    not_converge = bool(beta.max() > beta0)          # batch-global, ray_sampler.py:136
+    upsample = not_converge and upsample_allowed
+    if upsample:
+        N = N_samples_eval
+        with np.errstate(over="ignore", invalid="ignore"):
+            b = beta[:, None]
+            eps_sec = ((det_exp((-d_star / b).astype(F32)) * (dists * dists).astype(F32)).astype(F32)
+                       / (F32(4.0) * (b * b).astype(F32)).astype(F32)).astype(F32)
+            err_int = canon_cumsum(eps_sec)
+            bound_op = ((np.minimum(det_exp(err_int), F32(1.0e6)) - F32(1.0)).astype(F32)
+                        * trans[:, :-1]).astype(F32)
+        pdf = (bound_op + F32(add_tiny)).astype(F32)
+    else:
+        N = N_samples
+        pdf = (weights[:, :-1] + F32(1e-5)).astype(F32)
+    pdf = (pdf / canon_sum(pdf)).astype(F32)
+    cdf = np.concatenate([np.zeros((R, 1), F32), canon_cumsum(pdf)], -1)
+
+    if upsample or not training:
+        u = np.repeat(linspace01(N)[None], R, 0)
+    else:
+        u = np.asarray(u_final, F32)
+    samples, inds = inverse_cdf(cdf, z, u)
+
+    rec = dict(n=z.shape[1], z=z, sdf=sdf, d_star=d_star, beta=beta, weights=weights, pdf=pdf, cdf=cdf, u=u,
+               inds=inds, samples=samples, upsample=upsample, not_converge=not_converge)
+    if upsample:
+        rec["z_next"], rec["samples_idx"] = stable_merge(z, samples)
+    return rec
+
+
+def error_bound_sampler(sdf_fn, ray_dirs, cam_loc, beta0, *, near=1e-4, scene_bounding_sphere=3.0,
+                        N_samples=64, N_samples_eval=128, N_samples_extra=32, eps=0.1, beta_iters=10,
+                        max_total_iters=5, fast=-1, training=False, inverse_sphere_bg=False,
+                        N_samples_inverse_sphere=0, add_tiny=0.0, rng=None, inv_4log=None, trace=None,
+                        sdf_override=None):
+    """ErrorBoundSampler.get_z_vals, ray_sampler.py:67-219.
+
+    sdf_fn(points (P,3)) -> (P,1) is `model.implicit_network.get_sdf_vals`.
+    rng: dict of the train-mode draws (SURVEY note R): 'jitter' (R,128), 'u' (R,64),
+         'perm' (n,) randperm of the final bin count, 'eik_idx' (R,), ['jitter_bg' (R,32)].
+    inv_4log: float32 1/(4*log(1+eps)) as computed by the host (torch.log in float32, :77).
+    sdf_override: optional list of per-round (R*128,1) sdf arrays used INSTEAD of sdf_fn, so the
+         sampler can be replayed on fixed sdf inputs (bit-exact index tests).
+    trace: optional list that receives one dict per round (see sampler_round).
+    Returns z_vals (R, N_samples+N_samples_extra+2) [BG: (z_vals, z_bg)], z_samples_eik (R,1).
+    """
+    ray_dirs = np.asarray(ray_dirs, F32)
+    cam_loc = np.asarray(cam_loc, F32)
+    if cam_loc.ndim == 1:
+        cam_loc = np.repeat(cam_loc[None], ray_dirs.shape[0], 0)
+    R = ray_dirs.shape[0]
+    rng = rng or {}
+    beta0 = F32(beta0)
+    far_default = F32(2.0 * scene_bounding_sphere)
+    max_iters = fast if fast >= 0 else max_total_iters
+
+    if inverse_sphere_bg:
+        far_u = sphere_intersections(cam_loc, ray_dirs, scene_bounding_sphere)[:, 1:]
+    else:
+        far_u = far_default
+    z = uniform_z(F32(near), far_u, N_samples_eval, rng.get("jitter") if training else None)
+    if z.shape[0] == 1:
+        z = np.repeat(z, R, 0)
+    samples, samples_idx = z, None
+
+    dists = (z[:, 1:] - z[:, :-1]).astype(F32)
+    if inv_4log is None:
+        inv_4log = F32(1.0) / (F32(4.0) * F32(math.log(F32(eps) + F32(1.0))))
+    bound = (F32(inv_4log) * canon_sum((dists * dists).astype(F32))[:, 0]).astype(F32)
+    beta = np.sqrt(bound).astype(F32)
+
+    total_iters, not_converge = 0, True
+    sdf = None
+    while not_converge and total_iters < max_iters:
+        points = (cam_loc[:, None, :] + samples[:, :, None] * ray_dirs[:, None, :]).astype(F32)
+        if sdf_override is not None:
+            samples_sdf = np.asarray(sdf_override[total_iters], F32).reshape(-1, 1)
+        else:
+            samples_sdf = np.asarray(sdf_fn(points.reshape(-1, 3)), F32)
+        if samples_idx is not None:
+            sdf_merge = np.concatenate([sdf.reshape(R, z.shape[1] - samples.shape[1]),
+                                        samples_sdf.reshape(R, samples.shape[1])], -1)
+            sdf = np.take_along_axis(sdf_merge, samples_idx, 1)
+        else:
+            sdf = samples_sdf.reshape(R, -1)
+
+        total_iters += 1
+        rec = sampler_round(z, sdf, beta, beta0, upsample_allowed=total_iters < max_iters, training=training,
+                            u_final=rng.get("u"), N_samples=N_samples, N_samples_eval=N_samples_eval, eps=eps,
+                            beta_iters=beta_iters, add_tiny=add_tiny)
+        beta, samples, not_converge = rec["beta"], rec["samples"], rec["not_converge"]
+        if rec["upsample"]:
+            z, samples_idx = rec["z_next"], rec["samples_idx"]
+        if trace is not None:
+            trace.append(rec)
+
+    z_final, z_eik = sampler_finalize(z, samples, near=near, far=far_default, N_samples_extra=N_samples_extra,
+                                      training=training, rng=rng,
+                                      far_rays=(sphere_intersections(cam_loc, ray_dirs, scene_bounding_sphere)[:, 1:]
+                                                if inverse_sphere_bg else None))
+    if inverse_sphere_bg:
+        z_bg = uniform_z(F32(0.0), F32(1.0), N_samples_inverse_sphere,
+                         rng.get("jitter_bg") if training else None)
+        if z_bg.shape[0] == 1:
+            z_bg = np.repeat(z_bg, R, 0)
+        z_bg = (z_bg * F32(1.0 / scene_bounding_sphere)).astype(F32)
+        return (z_final, z_bg), z_eik
+    return z_final, z_eik
+
+
+def sampler_finalize(z, z_samples, *, near, far, N_samples_extra=32, training=False, rng=None, far_rays=None):
+    """ray_sampler.py:192-212: extras (near, far, N_samples_extra bins), final sort, eikonal sample pick."""
+    R = z.shape[0]
+    rng = rng or {}
+    near_c = np.full((R, 1), near, F32)
+    far_c = np.full((R, 1), far, F32) if far_rays is None else np.asarray(far_rays, F32)
+    if N_samples_extra > 0:
+        if training:
+            sampling_idx = np.asarray(rng["perm"])[:N_samples_extra]
+        else:
+            sampling_idx = extras_index_eval(z.shape[1], N_samples_extra)
+        z_extra = np.concatenate([near_c, far_c, z[:, sampling_idx]], -1)
+    else:
+        z_extra = np.concatenate([near_c, far_c], -1)
+    z_final = np.sort(np.concatenate([z_samples, z_extra], -1), -1).astype(F32)
+    if training and "eik_idx" in rng:
+        idx = np.asarray(rng["eik_idx"]).reshape(-1, 1)
+    else:
+        idx = np.zeros((R, 1), np.int64)      # the eval-mode draw is unused downstream (network.py:258)
+    return z_final, np.take_along_axis(z_final, idx, 1)
+
+
+# ----------------------------------------------------------------------------------------
+# a8  compositing    volsdf/model/network.py:281-295 and the reductions :237-256,270-276
+# ----------------------------------------------------------------------------------------
+def composite(z, sdf, rgb, beta, depth_scale, normals=None):
+    """z (R,S), sdf (R,S), rgb (R,S,3), beta scalar, depth_scale (R,1)."""
+    weights, _, _ = ray_weights(z, sdf, F32(beta))
+    out = {"weights": weights}
+    out["rgb_values"] = (weights[:, :, None] * rgb).sum(1, dtype=F32)
+    wsum = weights.sum(1, keepdims=True, dtype=F32)
+    out["depth_values"] = (depth_scale * ((weights * z).sum(1, keepdims=True, dtype=F32)
+                                          / (wsum + F32(1e-8)))).astype(F32)
+    out["depth_vals"] = (z * depth_scale).astype(F32)
+    if normals is not None:
+        nrm = np.sqrt((normals * normals).sum(-1, keepdims=True, dtype=F32)).astype(F32)
+        out["normal_map"] = (weights[:, :, None] * (normals / nrm)).sum(1, dtype=F32)
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# a9  VolSDFNetwork.forward    volsdf/model/network.py:206-279
+# ----------------------------------------------------------------------------------------
+def render_forward(params, uv, pose, K, *, beta_param, fast=-1, training=False, rng=None,
+                   sampler_conf=None, scene_bounding_sphere=3.0, sphere_scale=20.0, trace=None):
+    """Full forward of the fg-only DTU model.  params: state-dict-named arrays.  Returns dict like the reference."""
+    sampler_conf = dict(sampler_conf or {})
+    sdf_layers = effective_weights(params, "implicit_network", 9)
+    rgb_layers = effective_weights(params, "rendering_network", 5)
+    beta = get_beta(beta_param)
+    dirs, cam, depth_scale = rays_from_uv(uv, pose, K)
+    R = dirs.shape[0]
+    cam_r = np.repeat(cam[None], R, 0)
+    sdf_fn = lambda p: sdf_vals(sdf_layers, p, scene_bounding_sphere, sphere_scale)
+    z, z_eik = error_bound_sampler(sdf_fn, dirs, cam_r, beta, fast=fast, training=training, rng=rng,
+                                   scene_bounding_sphere=scene_bounding_sphere, trace=trace, **sampler_conf)
+    S = z.shape[1]
+    points = (cam_r[:, None, :] + z[:, :, None] * dirs[:, None, :]).astype(F32)
+    pf = points.reshape(-1, 3)
+    sdf, feat, grad = sdf_outputs(sdf_layers, pf, scene_bounding_sphere, sphere_scale)
+    dirs_flat = np.repeat(dirs[:, None, :], S, 1).reshape(-1, 3)
+    rgb = rgb_mlp_forward(rgb_layers, pf, grad, dirs_flat, feat).reshape(R, S, 3)
+    out = composite(z, sdf.reshape(R, S), rgb, beta, depth_scale,
+                    normals=None if training else grad.reshape(R, S, 3))
+    out["xyz"] = points
+    out["z_vals"] = z
+    out["sdf"] = sdf.reshape(R, S)
+    out["gradients"] = grad.reshape(R, S, 3)
+    if training:
+        eik_uniform = np.asarray(rng["eik_points"], F32)
+        eik_near = (cam_r[:, None, :] + z_eik[:, :, None] * dirs[:, None, :]).reshape(-1, 3).astype(F32)
+        eik = np.concatenate([eik_uniform, eik_near], 0)
+        out["grad_theta"] = sdf_outputs(sdf_layers, eik, scene_bounding_sphere, sphere_scale, clamp=False)[2]
+    return out

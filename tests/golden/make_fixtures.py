@@ -1,0 +1,276 @@
+"""Golden-vector generator: imports the REFERENCE (read-only, /root/reference) on CPU in the build
+container and stores arrays only (inputs + the reference's outputs) as small .npz fixtures.
+
+Run:  python tests/golden/make_fixtures.py [name ...]
+The reference cannot travel to the GPU box; the fixtures can.  No reference source is stored.
+"""
+import contextlib
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_shim  # noqa: E402
+import synth     # noqa: E402
+
+ref_shim.install()
+import torch  # noqa: E402
+
+torch.set_num_threads(4)
+F32 = np.float32
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def build_model(params, beta=None, near=1e-4, bg=False):
+    from volsdf.model.network import VolSDFNetwork
+    m = VolSDFNetwork(ref_shim.dtu_model_conf(near=near))
+    sd = {k: T(v).clone() for k, v in params.items()}
+    if beta is not None:
+        sd["density.beta"] = torch.tensor(beta, dtype=torch.float32)
+    missing = m.load_state_dict(sd, strict=True)
+    return m
+
+
+@contextlib.contextmanager
+def capture_sampler():
+    """Record searchsorted / sort results and per-round sdf while the reference sampler runs."""
+    rec = SimpleNamespace(inds=[], sort_vals=[], sort_idx=[], cdf=[], u=[])
+    o_ss, o_sort = torch.searchsorted, torch.sort
+
+    def ss(cdf, u, right=False, **kw):
+        r = o_ss(cdf, u, right=right, **kw)
+        rec.inds.append(r.numpy().copy()); rec.cdf.append(cdf.detach().numpy().copy()); rec.u.append(u.numpy().copy())
+        return r
+
+    def srt(x, *a, **kw):
+        r = o_sort(x, *a, **kw)
+        rec.sort_vals.append(r[0].detach().numpy().copy()); rec.sort_idx.append(r[1].numpy().copy())
+        return r
+
+    torch.searchsorted, torch.sort = ss, srt
+    try:
+        yield rec
+    finally:
+        torch.searchsorted, torch.sort = o_ss, o_sort
+
+
+@contextlib.contextmanager
+def inject_rng(draws):
+    """Feed the reference's CPU RNG calls from explicit arrays (SURVEY note R order)."""
+    o_rand, o_perm, o_randint, o_uniform = torch.rand, torch.randperm, torch.randint, torch.Tensor.uniform_
+    q_rand = [draws["jitter"], draws["u"]] + ([draws["jitter_bg"]] if "jitter_bg" in draws else [])
+
+    def rand(*shape, **kw):
+        a = q_rand.pop(0)
+        shp = tuple(shape[0]) if len(shape) == 1 and not isinstance(shape[0], int) else tuple(shape)
+        assert tuple(a.shape) == shp, (a.shape, shp)
+        return T(a).clone()
+
+    def randperm(n, **kw):
+        assert n == len(draws["perm"])
+        return T(draws["perm"]).clone()
+
+    def randint(high, size, **kw):
+        return T(draws["eik_idx"]).clone()
+
+    def uniform_(self, a, b):
+        self.copy_(T(draws["eik_points"]))
+        return self
+
+    torch.rand, torch.randperm, torch.randint, torch.Tensor.uniform_ = rand, randperm, randint, uniform_
+    try:
+        yield
+    finally:
+        torch.rand, torch.randperm, torch.randint, torch.Tensor.uniform_ = o_rand, o_perm, o_randint, o_uniform
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print(f"  wrote {name}.npz  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+# ------------------------------------------------------------------------------------------
+def fx_rays():
+    from volsdf.utils import rend_util
+    out = {}
+    for tag, skew, tilt in (("a", 0.0, 0.0), ("b", 3.5, 0.3)):
+        K, pose = synth.make_camera(skew=skew, tilt=tilt, center=(0.3, -0.2, -2.5))
+        uv = synth.make_uv(32, seed=1)
+        dirs, cam = rend_util.get_camera_params(T(uv)[None], T(pose)[None], T(K)[None])
+        tmp, _ = rend_util.get_camera_params(T(uv)[None], torch.eye(4)[None], T(K)[None])
+        out.update({f"{tag}_K": K, f"{tag}_pose": pose, f"{tag}_uv": uv, f"{tag}_dirs": dirs[0].numpy(),
+                    f"{tag}_cam": cam[0].numpy(), f"{tag}_depth_scale": tmp[0, :, 2:].numpy()})
+    save("rays", **out)
+
+
+def sample_points(n, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(-1.2, 1.2, (n, 3))
+    x[: n // 8] *= 3.0                      # some outside the r=3 sphere clamp region
+    x[n // 8: n // 4] *= 0.05               # near the origin
+    return x.astype(F32)
+
+
+def fx_sdf_mlp():
+    params = synth.make_params(seed=0)
+    m = build_model(params)
+    x = sample_points(96, 3)
+    net = m.implicit_network
+    with torch.no_grad():
+        out = net(T(x)).numpy()
+        sdfv = net.get_sdf_vals(T(x)).numpy()
+    sdf, feat, grad = net.get_outputs(T(x).clone())
+    g2 = net.gradient(T(x).clone())
+    save("sdf_mlp", seed=0, x=x, out=out, sdf_vals=sdfv, sdf=sdf.detach().numpy(), feat=feat.detach().numpy(),
+         grad=grad.detach().numpy(), grad_raw=g2.detach().numpy())
+
+
+def fx_rgb_mlp():
+    params = synth.make_params(seed=0)
+    m = build_model(params)
+    rng = np.random.default_rng(5)
+    P = 64
+    pts = sample_points(P, 7)
+    nrm = rng.normal(0, 1, (P, 3)).astype(F32)
+    d = rng.normal(0, 1, (P, 3)); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(F32)
+    feat = rng.normal(0, 0.5, (P, 256)).astype(F32)
+    with torch.no_grad():
+        rgb = m.rendering_network(T(pts), T(nrm), T(d), T(feat)).numpy()
+    save("rgb_mlp", seed=0, points=pts, normals=nrm, dirs=d, feat=feat, rgb=rgb)
+
+
+def fx_density():
+    from volsdf.model.density import LaplaceDensity
+    rng = np.random.default_rng(9)
+    sdf = np.concatenate([rng.normal(0, 0.3, 200), [0.0, 1e-8, -1e-8, 1e-3, -1e-3, 5.0, -5.0]]).astype(F32)
+    out = {"sdf": sdf}
+    for i, b in enumerate((0.1, 0.01, 0.001)):
+        dn = LaplaceDensity(params_init={"beta": b})
+        with torch.no_grad():
+            out[f"sigma_{i}"] = dn(T(sdf)).numpy()
+            out[f"beta_{i}"] = dn.get_beta().numpy()
+    dn = LaplaceDensity(params_init={"beta": 0.1})
+    br = rng.uniform(0.002, 0.2, (23, 1)).astype(F32)
+    s2 = rng.normal(0, 0.2, (23, 9)).astype(F32)
+    with torch.no_grad():
+        out["sigma_ray"] = dn(T(s2), beta=T(br)).numpy()
+    out["beta_ray"], out["sdf_ray"] = br, s2
+    save("density", **out)
+
+
+def run_sampler(m, dirs, cam, fast, training, draws=None):
+    sdfs = []
+    orig = m.implicit_network.get_sdf_vals
+    betas = []
+    orig_density = m.density.forward
+
+    def density_fwd(sdf, beta=None):
+        # the per-ray call at ray_sampler.py:126 ("Upsample more points") sees the round's final beta
+        if beta is not None and beta.dim() == 2 and sdf.dim() == 2:
+            betas.append(beta.detach().numpy().copy()[:, 0])
+        return orig_density(sdf, beta=beta)
+
+    m.density.forward = density_fwd
+
+    def wrapped(p):
+        r = orig(p)
+        sdfs.append(r.detach().numpy().copy())
+        return r
+
+    m.implicit_network.get_sdf_vals = wrapped
+    m.train(training)
+    ctx = inject_rng(draws) if training else contextlib.nullcontext()
+    with capture_sampler() as rec, ctx:
+        z, z_eik = m.ray_sampler.get_z_vals(T(dirs), T(cam), m, fast=fast)
+    m.implicit_network.get_sdf_vals = orig
+    m.density.forward = orig_density
+    # 11 per-ray density calls per round (10 bisection + the final one): keep the final one
+    rec.betas = betas[10::11]
+    return z, z_eik, rec, sdfs
+
+
+def fx_sampler():
+    params = synth.make_params(seed=0)
+    K, pose = synth.make_camera(center=(0.1, 0.05, -2.5), tilt=0.1)
+    R = 12
+    uv = synth.make_uv(R, seed=2, margin=0.1)
+    import oracle_path  # noqa
+    from svs_oracle import rays_from_uv
+    dirs, cam, _ = rays_from_uv(uv, pose, K)
+    cam_r = np.repeat(cam[None], R, 0).astype(F32)
+    for beta in (0.1, 0.01, 0.001):
+        for fast in (-1, 0, 1, 2):
+            if beta != 0.01 and fast in (0, 2):
+                continue
+            m = build_model(params, beta=beta)
+            z, z_eik, rec, sdfs = run_sampler(m, dirs, cam_r, fast, False)
+            arr = dict(dirs=dirs, cam=cam_r, beta_param=F32(beta), fast=fast, z=z.numpy(), n_rounds=len(sdfs),
+                       inv_4log=(1.0 / (4.0 * torch.log(torch.tensor(0.1 + 1.0)))).numpy())
+            for i, s in enumerate(sdfs):
+                arr[f"sdf_{i}"] = s
+                arr[f"beta_{i}"] = rec.betas[i]
+            for i, a in enumerate(rec.inds):
+                arr[f"inds_{i}"] = a; arr[f"cdf_{i}"] = rec.cdf[i]
+            n_merge = len(rec.sort_idx) - 1
+            for i in range(n_merge):
+                arr[f"samples_idx_{i}"] = rec.sort_idx[i]; arr[f"zmerged_{i}"] = rec.sort_vals[i]
+            save(f"sampler_eval_b{beta}_f{fast}", **arr)
+    # train mode
+    m = build_model(params, beta=0.05)
+    draws = synth.make_train_rng(R, seed=4)
+    z, z_eik, rec, sdfs = run_sampler(m, dirs, cam_r, 1, True, draws)
+    save("sampler_train", dirs=dirs, cam=cam_r, beta_param=F32(0.05), z=z.numpy(), z_eik=z_eik.numpy(),
+         sdf_0=sdfs[0], inds_0=rec.inds[0], cdf_0=rec.cdf[0], beta_0=rec.betas[0],
+         inv_4log=(1.0 / (4.0 * torch.log(torch.tensor(0.1 + 1.0)))).numpy())
+
+
+def fx_composite():
+    params = synth.make_params(seed=0)
+    m = build_model(params, beta=0.03)
+    rng = np.random.default_rng(11)
+    R, S = 16, 98
+    z = np.sort(rng.uniform(0.5, 5.5, (R, S)), -1).astype(F32)
+    z[:, 5] = z[:, 4]                         # duplicate sample -> zero-length interval
+    sdf = (rng.normal(0.3, 0.5, (R, S)) - np.linspace(0, 1.0, S)[None]).astype(F32)
+    rgb = rng.uniform(0, 1, (R, S, 3)).astype(F32)
+    with torch.no_grad():
+        w, dists = m.volume_rendering(T(z), T(sdf).reshape(-1, 1))
+    save("composite", z=z, sdf=sdf, rgb=rgb, beta_param=F32(0.03), weights=w.numpy(), dists=dists.numpy())
+
+
+def fx_forward():
+    params = synth.make_params(seed=0)
+    K, pose = synth.make_camera(center=(0.1, 0.05, -2.5), tilt=0.1, skew=0.7)
+    R = 12
+    uv = synth.make_uv(R, seed=3, margin=0.1)
+    inp = {"intrinsics": T(K)[None], "uv": T(uv)[None], "pose": T(pose)[None]}
+    for tag, beta, fast in (("eval_b0.1", 0.1, -1), ("eval_b0.01", 0.01, -1), ("eval_b0.01_f1", 0.01, 1)):
+        m = build_model(params, beta=beta)
+        m.eval()
+        out = m(inp, fast=fast)
+        save(f"forward_{tag}", K=K, pose=pose, uv=uv, beta_param=F32(beta), fast=fast,
+             **{k: v.detach().numpy() for k, v in out.items()})
+    m = build_model(params, beta=0.05)
+    m.train()
+    draws = synth.make_train_rng(R, seed=6)
+    with inject_rng(draws):
+        out = m(inp, fast=1)
+    save("forward_train", K=K, pose=pose, uv=uv, beta_param=F32(0.05), fast=1, rng_seed=6,
+         **{k: v.detach().numpy() for k, v in out.items()})
+
+
+ALL = dict(rays=fx_rays, sdf_mlp=fx_sdf_mlp, rgb_mlp=fx_rgb_mlp, density=fx_density, sampler=fx_sampler,
+           composite=fx_composite, forward=fx_forward)
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(ALL)
+    for n in names:
+        print(f"[{n}]")
+        ALL[n]()
