@@ -585,6 +585,8 @@ def error_bound_sampler(sdf_fn, ray_dirs, cam_loc, beta0, *, near=1e-4, scene_bo
         rec = sampler_round(z, sdf, beta, beta0, upsample_allowed=total_iters < max_iters, training=training,
                             u_final=rng.get("u"), N_samples=N_samples, N_samples_eval=N_samples_eval, eps=eps,
                             beta_iters=beta_iters, add_tiny=add_tiny)
+        rec["samples_sdf"] = samples_sdf.reshape(R, -1)      # sdf of this round's new samples (sdf_fn output)
+        rec["beta_in"] = beta
         beta, samples, not_converge = rec["beta"], rec["samples"], rec["not_converge"]
         if rec["upsample"]:
             z, samples_idx = rec["z_next"], rec["samples_idx"]

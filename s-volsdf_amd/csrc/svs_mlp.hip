@@ -1,0 +1,627 @@
+// Fused SDF ("implicit") and radiance ("rendering") MLP kernels for gfx950.
+//
+// Reference semantics: volsdf/model/network.py:71-131 (ImplicitNetwork) and :170-190
+// (RenderingNetwork) of cvlab-stonybrook/s-volsdf; positional encoding volsdf/model/embedder.py:10-36.
+//
+// Design (DESIGN.md "MLP kernels"):
+//   * activations live TRANSPOSED in registers: a wave owns 32 points (MFMA columns = lane & 31) and the
+//     256 features of a layer are the rows of eight 32x32 accumulator tiles (8 x 16 = 128 VGPRs/lane).
+//     The accumulator layout of v_mfma_f32_32x32x2_f32 (row = (r&3)+8(r>>2)+4(lane>>5)) is exactly the
+//     B-operand layout of the next layer's MFMAs once the K order of the weights is permuted to match,
+//     so a layer's output feeds the next layer with no LDS round trip and no cross-lane traffic;
+//   * weights are pre-packed (svs_mlp_pack) in the order the MFMAs consume them, as 36 KiB "chunks"
+//     (one output tile = 32 output features x K = 256), streamed global -> LDS by LDS-DMA
+//     (global_load_lds_dwordx4) into a double buffer shared by the 4 waves of a workgroup, and read back
+//     with conflict-free ds_read_b128;
+//   * exact float32 MFMA (v_mfma_f32_32x32x2_f32): the 1e-4 parity bound of the path rules out bf16.
+#include "svs_common.h"
+#include "svs_mlp_layout.h"
+
+namespace svs {
+namespace mlp {
+
+// ------------------------------------------------------------------------------------------------------
+// weight stream
+// ------------------------------------------------------------------------------------------------------
+// LDS-DMA copy of N16 float4 (N16 % 64 == 0) from global to LDS, issued by the whole workgroup.
+template <int N16>
+__device__ __forceinline__ void chunk_issue(const f32x4* __restrict__ g, f32x4* lds) {
+  static_assert(N16 % 64 == 0, "chunk must be a whole number of wave-instructions");
+  const int tid = threadIdx.x;
+  const int wave_base = tid & ~63;
+#pragma unroll
+  for (int i = 0; i < (N16 + kThreads - 1) / kThreads; ++i) {
+    const int idx = i * kThreads + wave_base;  // wave-uniform
+    if (idx < N16) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + idx + (tid & 63)),
+                                       (__attribute__((address_space(3))) void*)(lds + idx), 16, 0, 0);
+    }
+  }
+}
+
+struct Stream {
+  const f32x4* g;  // next chunk to fetch
+  f32x4* buf;      // LDS: two buffers of kChunkF4
+  int cur;         // buffer holding the chunk being consumed
+
+  __device__ __forceinline__ const f32x4* cur_buf() const { return buf + cur * kChunkF4; }
+  template <int N16>
+  __device__ __forceinline__ void prefetch() {
+    chunk_issue<N16>(g, buf + (cur ^ 1) * kChunkF4);
+    g += N16;
+  }
+  // the chunk fetched by prefetch() becomes current: own loads landed, then everyone's
+  __device__ __forceinline__ void advance() {
+    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) lgkmcnt(0) expcnt(0)
+    __syncthreads();
+    cur ^= 1;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------------
+// element-wise pieces
+// ------------------------------------------------------------------------------------------------------
+// softplus(beta=100) = max(a,0) + log1p(exp(-|100 a|))/100 through the hardware exp2/log2: the absolute
+// error is < 1e-9 (the reference switches to the identity above 100a > 20, where the two differ by 2e-11).
+__device__ __forceinline__ float softplus100(float a) {
+  const float e = __builtin_amdgcn_exp2f(__builtin_fabsf(a) * (-100.0f * 1.44269504088896341f));
+  return __builtin_fmaxf(a, 0.0f) + (0.69314718055994531f / 100.0f) * __builtin_amdgcn_logf(1.0f + e);
+}
+// d softplus100 / da as a function of h = softplus100(a):  sigmoid(100 a) = 1 - exp(-100 h)
+__device__ __forceinline__ float dsoftplus_from_h(float h) {
+  return 1.0f - __builtin_amdgcn_exp2f(h * (-100.0f * 1.44269504088896341f));
+}
+
+// Positional encoding of one 3-D point, all 39 entries + a zero pad, in the reference's order
+// [x, sin(2^0 x), cos(2^0 x), ..., sin(2^5 x), cos(2^5 x)] (embedder.py:10-36).
+struct PosEnc {
+  float v[40];
+  __device__ __forceinline__ void compute(float x0, float x1, float x2) {
+    v[0] = x0; v[1] = x1; v[2] = x2;
+    const float xs[3] = {x0, x1, x2};
+#pragma unroll
+    for (int f = 0; f < 6; ++f) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float s, co;
+        sincosf(xs[c] * (float)(1 << f), &s, &co);
+        v[3 + 6 * f + c] = s;
+        v[6 + 6 * f + c] = co;
+      }
+    }
+    v[39] = 0.0f;
+  }
+};
+
+struct PointSrc {
+  const float* pts;   // (P,3) explicit points, or nullptr
+  const float* cam;   // ray mode: camera centre(s)
+  const float* dirs;  // ray mode: (R,3)
+  const float* z;     // ray mode: (R,S)
+  int cam_stride;     // 0: one camera for all rays, 3: per ray
+  int S;              // samples per ray (ray mode)
+  int P;              // number of points
+};
+
+__device__ __forceinline__ void load_point(const PointSrc& src, int p, float& x0, float& x1, float& x2) {
+  if (p >= src.P) p = src.P - 1;
+  if (src.pts) {
+    x0 = src.pts[3 * p + 0]; x1 = src.pts[3 * p + 1]; x2 = src.pts[3 * p + 2];
+  } else {
+    const int r = p / src.S;
+    const float zz = src.z[p];
+    const float* o = src.cam + (size_t)r * src.cam_stride;
+    // cam_loc + z * ray_dir as two rounded float32 ops (network.py:226, ray_sampler.py:84)
+    x0 = __fadd_rn(o[0], __fmul_rn(zz, src.dirs[3 * r + 0]));
+    x1 = __fadd_rn(o[1], __fmul_rn(zz, src.dirs[3 * r + 1]));
+    x2 = __fadd_rn(o[2], __fmul_rn(zz, src.dirs[3 * r + 2]));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// one output tile:  acc(32 x 32 points) = hdr(bias) + sum_k A[:, k] x[k, :]
+// ------------------------------------------------------------------------------------------------------
+template <int KS>  // number of k-steps (2 input rows each); x holds KS/16 tiles (last may be partial)
+__device__ __forceinline__ f32x16 tile_mma(const f32x4* __restrict__ chunk, const f32x16* x, int lane) {
+  f32x16 acc;
+#pragma unroll
+  for (int r4 = 0; r4 < 4; ++r4) {
+    const f32x4 b = chunk[r4 * 64 + lane];
+    acc[4 * r4 + 0] = b[0]; acc[4 * r4 + 1] = b[1]; acc[4 * r4 + 2] = b[2]; acc[4 * r4 + 3] = b[3];
+  }
+  const f32x4* a_ptr = chunk + kHdrF4 + lane;
+#pragma unroll
+  for (int s4 = 0; s4 < KS / 4; ++s4) {
+    const f32x4 a = a_ptr[s4 * 64];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int s = 4 * s4 + j;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], x[s / 16][s % 16], acc, 0, 0, 0);
+    }
+  }
+  return acc;
+}
+
+// layer 0: the B operand of k-step s is PE row 2s (lanes 0-31) / 2s+1 (lanes 32-63)
+__device__ __forceinline__ f32x16 tile_mma_pe(const f32x4* __restrict__ chunk, const PosEnc& pe, int lane, int half) {
+  f32x16 acc;
+#pragma unroll
+  for (int r4 = 0; r4 < 4; ++r4) {
+    const f32x4 b = chunk[r4 * 64 + lane];
+    acc[4 * r4 + 0] = b[0]; acc[4 * r4 + 1] = b[1]; acc[4 * r4 + 2] = b[2]; acc[4 * r4 + 3] = b[3];
+  }
+  const f32x4* a_ptr = chunk + kHdrF4 + lane;
+#pragma unroll
+  for (int s4 = 0; s4 < 5; ++s4) {
+    const f32x4 a = a_ptr[s4 * 64];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int s = 4 * s4 + j;
+      const float b = half ? pe.v[2 * s + 1] : pe.v[2 * s];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b, acc, 0, 0, 0);
+    }
+  }
+  return acc;
+}
+
+// PE rows spliced into the layer-4 input (skip connection, network.py:80-81): accumulator rows 217..223
+// carry PE[32..38] and rows 224..255 carry PE[0..31]; the 1/sqrt(2) is folded into the packed W4.
+__device__ __forceinline__ void splice_skip(f32x16* y, const PosEnc& pe, int half) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row0 = rho(r), row1 = rho(r) + 4;  // local rows for half 0 / 1
+    y[7][r] = half ? pe.v[row1] : pe.v[row0];
+    const int l0 = row0 - 25, l1 = row1 - 25;     // tile 6: local rows 25..31 -> PE[32..38]
+    if (l0 >= 0 || l1 >= 0) {
+      const float v0 = l0 >= 0 ? pe.v[32 + (l0 >= 0 ? l0 : 0)] : y[6][r];
+      const float v1 = l1 >= 0 ? pe.v[32 + (l1 >= 0 ? l1 : 0)] : y[6][r];
+      y[6][r] = half ? v1 : v0;
+    }
+  }
+}
+
+// A wave's 256 x 32 activation block in global memory: float4 index (i/4)*64 + lane holds accumulator
+// registers i..i+3 (i = 16*tile + r) of that lane -- every wave-instruction moves 1 KiB contiguously.
+__device__ __forceinline__ void store_tile_regs(float* __restrict__ dst, const f32x16* x, int lane) {
+  f32x4* d = reinterpret_cast<f32x4*>(dst) + lane;
+#pragma unroll
+  for (int i4 = 0; i4 < 32; ++i4) {
+    f32x4 v;
+    v[0] = x[i4 / 4][4 * (i4 % 4) + 0]; v[1] = x[i4 / 4][4 * (i4 % 4) + 1];
+    v[2] = x[i4 / 4][4 * (i4 % 4) + 2]; v[3] = x[i4 / 4][4 * (i4 % 4) + 3];
+    d[i4 * 64] = v;
+  }
+}
+__device__ __forceinline__ void load_tile_regs(const float* __restrict__ src, f32x16* x, int lane) {
+  const f32x4* d = reinterpret_cast<const f32x4*>(src) + lane;
+#pragma unroll
+  for (int i4 = 0; i4 < 32; ++i4) {
+    const f32x4 v = d[i4 * 64];
+    x[i4 / 4][4 * (i4 % 4) + 0] = v[0]; x[i4 / 4][4 * (i4 % 4) + 1] = v[1];
+    x[i4 / 4][4 * (i4 % 4) + 2] = v[2]; x[i4 / 4][4 * (i4 % 4) + 3] = v[3];
+  }
+}
+
+// Forward through layers 0..7; on return x holds h_8 (the input of lin8).  When HBUF, every layer's
+// activations (h_1..h_8) are also stored to this wave's scratch tile (reverse pass / training backward).
+template <bool HBUF>
+__device__ __forceinline__ void forward_trunk(Stream& st, f32x16* x, f32x16* y, const PosEnc& pe, int lane, int half,
+                                              float* __restrict__ hbuf) {
+  // ---- layer 0 : 39(40) -> 256
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    if (t < 7) st.prefetch<kChunk0F4>(); else st.prefetch<kChunkF4>();
+    const f32x16 acc = tile_mma_pe(st.cur_buf(), pe, lane, half);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[t][r] = softplus100(acc[r]);
+    st.advance();
+  }
+  if (HBUF) store_tile_regs(hbuf, x, lane);
+  // ---- layers 1..7 : 256 -> 256 (layer 3 emits 217 rows + the skip splice)
+  for (int l = 1; l < 8; ++l) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      if (t == 7 && l == 3) break;  // lin3 has 217 outputs = 7 tiles; tile 7 is the PE splice
+      st.prefetch<kChunkF4>();
+      const f32x16 acc = tile_mma<128>(st.cur_buf(), x, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) y[t][r] = softplus100(acc[r]);
+      st.advance();
+    }
+    if (l == 3) splice_skip(y, pe, half);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x[t] = y[t];
+    if (HBUF) store_tile_regs(hbuf + (size_t)l * 128 * 64, x, lane);
+  }
+}
+
+// sdf = b8[0] + W8[0,:] . h8 from the VEC chunk (both halves end up with the full sum)
+__device__ __forceinline__ float sdf_head(const f32x4* __restrict__ chunk, const f32x16* x, int lane) {
+  float acc = 0.0f;
+  const f32x4* w_ptr = chunk + kHdrF4 + lane;
+#pragma unroll
+  for (int s4 = 0; s4 < 32; ++s4) {
+    const f32x4 w = w_ptr[s4 * 64];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int s = 4 * s4 + j;
+      acc = __builtin_fmaf(w[j], x[s / 16][s % 16], acc);
+    }
+  }
+  acc += __shfl_xor(acc, 32);
+  return acc + chunk[lane][0];
+}
+
+struct SdfOnlyArgs {
+  PointSrc src;
+  const f32x4* stream;   // packed forward stream
+  float* sdf;            // (P)
+  float sphere_radius;   // <= 0: no clamp (network.py:128)
+  float sphere_scale;
+  const int* gate;       // optional device flag: the launch is a no-op when *gate == 0 (sampler rounds)
+};
+
+// ImplicitNetwork.get_sdf_vals (network.py:125-131), no grad: the sampler's evaluation.
+__global__ __launch_bounds__(kThreads, 1) void sdf_only_kernel(SdfOnlyArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (a.gate && *a.gate == 0) return;
+  Stream st;
+  st.g = a.stream;
+  st.buf = reinterpret_cast<f32x4*>(smem);
+  st.cur = 1;
+  const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
+  const int p = (blockIdx.x * kWaves + wave) * kTilePts + (lane & 31);
+
+  st.prefetch<kChunk0F4>();   // chunk 0 -> buffer 0 (overlaps the positional encoding below)
+  float x0, x1, x2;
+  load_point(a.src, p, x0, x1, x2);
+  PosEnc pe;
+  pe.compute(x0, x1, x2);
+  st.advance();
+
+  f32x16 x[8], y[8];
+  forward_trunk<false>(st, x, y, pe, lane, half, nullptr);
+  // the VEC chunk was prefetched by the last tile of layer 7
+  float sdf = sdf_head(st.cur_buf(), x, lane);
+  if (a.sphere_radius > 0.0f) {
+    const float nrm = __builtin_sqrtf(x0 * x0 + x1 * x1 + x2 * x2);
+    sdf = __builtin_fminf(sdf, a.sphere_scale * (a.sphere_radius - nrm));
+  }
+  if (half == 0 && p < a.src.P) a.sdf[p] = sdf;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// ImplicitNetwork.get_outputs (network.py:105-123): sdf, feature vector and d sdf / d x in one launch.
+// The input gradient is the reverse-mode product through the same MLP (the reference's autograd.grad,
+// :115-121): g(h_8) = W8[0,:], g(a_l) = g(h_{l+1}) * softplus'(a_l), g(h_l) = W_l^T g(a_l).
+// ------------------------------------------------------------------------------------------------------
+struct SdfFullArgs {
+  PointSrc src;
+  const f32x4* stream;   // full stream
+  float* sdf;            // (P)
+  float* grad;           // (P,3)
+  float* feat_tiles;     // [wave tiles][128*64] or nullptr
+  float* hbuf;           // [wave tiles][8][128*64] activations h_1..h_8
+  float sphere_radius;   // > 0: min(sdf, scale*(R-|x|)) inside the differentiated graph (network.py:110-112)
+  float sphere_scale;
+};
+
+__global__ __launch_bounds__(kThreads, 1) void sdf_full_kernel(SdfFullArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Stream st;
+  st.g = a.stream;
+  st.buf = reinterpret_cast<f32x4*>(smem);
+  st.cur = 1;
+  const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
+  const int wtile = blockIdx.x * kWaves + wave;
+  const int p = wtile * kTilePts + (lane & 31);
+
+  st.prefetch<kChunk0F4>();
+  float x0, x1, x2;
+  load_point(a.src, p, x0, x1, x2);
+  PosEnc pe;
+  pe.compute(x0, x1, x2);
+  st.advance();
+
+  float* hb = a.hbuf + (size_t)wtile * 8 * 128 * 64;
+  f32x16 x[8], y[8];
+  forward_trunk<true>(st, x, y, pe, lane, half, hb);
+
+  // ---- head: current chunk = VEC (W8 row 0 in C-layout order, b8[0])
+  st.prefetch<kChunkF4>();                       // FEAT tile 0
+  float sdf = sdf_head(st.cur_buf(), x, lane);
+  {
+    const f32x4* w_ptr = st.cur_buf() + kHdrF4 + lane;
+#pragma unroll
+    for (int s4 = 0; s4 < 32; ++s4) {
+      const f32x4 w = w_ptr[s4 * 64];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[s4 / 4][4 * (s4 % 4) + j] = w[j];   // g(h_8)
+    }
+  }
+  st.advance();
+  // ---- feature vector = rows 1..256 of lin8
+  float* ft = a.feat_tiles ? a.feat_tiles + (size_t)wtile * 128 * 64 : nullptr;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    st.prefetch<kChunkF4>();                     // FEAT t+1, or reverse L7 tile 0
+    const f32x16 acc = tile_mma<128>(st.cur_buf(), x, lane);
+    if (ft) {
+      f32x4* d = reinterpret_cast<f32x4*>(ft) + lane;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v; v[0] = acc[4 * q]; v[1] = acc[4 * q + 1]; v[2] = acc[4 * q + 2]; v[3] = acc[4 * q + 3];
+        d[(4 * t + q) * 64] = v;
+      }
+    }
+    st.advance();
+  }
+  // g(a_7) = g(h_8) * softplus'(a_7), h_8 still in x
+#pragma unroll
+  for (int i = 0; i < 128; ++i) y[i / 16][i % 16] *= dsoftplus_from_h(x[i / 16][i % 16]);
+
+  // ---- reverse layers 7..1
+  f32x16 skip7;          // g(PE[0..31]) from the skip connection (tile 7 of g(h_4 spliced))
+  f32x16 skip6;          // tile 6; only local rows 25..31 are PE[32..38]
+  for (int l = 7; l >= 1; --l) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      st.prefetch<kChunkF4>();                     // next reverse chunk (the last one prefetches REV0 tile 0)
+      x[t] = tile_mma<128>(st.cur_buf(), y, lane);   // g(h_l) rows 32t..32t+31
+      st.advance();
+    }
+    if (l == 4) { skip7 = x[7]; skip6 = x[6]; }
+    // g(a_{l-1}) = g(h_l) * softplus'(a_{l-1}),  softplus' from the stored h_l
+    const f32x4* hsrc = reinterpret_cast<const f32x4*>(hb + (size_t)(l - 1) * 128 * 64) + lane;
+#pragma unroll
+    for (int i4 = 0; i4 < 32; ++i4) {
+      const f32x4 h = hsrc[i4 * 64];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[i4 / 4][4 * (i4 % 4) + j] = x[i4 / 4][4 * (i4 % 4) + j] * dsoftplus_from_h(h[j]);
+    }
+    if (l == 4) {
+      // rows >= 217 of h_4 are the PE splice, not softplus outputs: they do not flow into lin3
+      y[7] = (f32x16)(0.0f);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row0 = rho(r), row1 = rho(r) + 4;
+        if (row0 >= 25 || row1 >= 25) {
+          const bool z0 = row0 >= 25, z1 = row1 >= 25;
+          if (half ? z1 : z0) y[6][r] = 0.0f;
+        }
+      }
+    }
+  }
+  // ---- reverse layer 0: g(PE) = W0^T g(a_0) (+ skip), 2 tiles
+  st.prefetch<kChunkF4>();
+  f32x16 gpe0 = tile_mma<128>(st.cur_buf(), y, lane);
+  st.advance();
+  f32x16 gpe1 = tile_mma<128>(st.cur_buf(), y, lane);
+  gpe0 += skip7;
+  gpe1 += skip6;
+
+  // ---- d/dx of the positional encoding
+  float dx0 = 0.0f, dx1 = 0.0f, dx2 = 0.0f;
+  // PE entry q: q<3 identity; else f=(q-3)/6, w=(q-3)%6: w<3 sin(2^f x_w) else cos(2^f x_{w-3})
+  auto accum = [&](int q, float g, bool active) {
+    if (q < 0 || q >= kPeDim) return;
+    float coef = 1.0f;
+    int c = q;
+    if (q >= 3) {
+      const int f = (q - 3) / 6, w = (q - 3) % 6;
+      const float sc = (float)(1 << f);
+      c = w < 3 ? w : w - 3;
+      coef = w < 3 ? sc * pe.v[q + 3] : -sc * pe.v[q - 3];
+    }
+    const float term = active ? coef * g : 0.0f;
+    if (c == 0) dx0 += term; else if (c == 1) dx1 += term; else dx2 += term;
+  };
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    accum(rho(r), gpe0[r], half == 0);
+    accum(rho(r) + 4, gpe0[r], half == 1);
+    accum(rho(r) >= 25 ? 32 + rho(r) - 25 : -1, gpe1[r], half == 0);
+    accum(rho(r) + 4 >= 25 ? 32 + rho(r) + 4 - 25 : -1, gpe1[r], half == 1);
+  }
+  dx0 += __shfl_xor(dx0, 32); dx1 += __shfl_xor(dx1, 32); dx2 += __shfl_xor(dx2, 32);
+
+  if (a.sphere_radius > 0.0f) {
+    const float nrm = __builtin_sqrtf(x0 * x0 + x1 * x1 + x2 * x2);
+    const float sphere = a.sphere_scale * (a.sphere_radius - nrm);
+    if (sphere < sdf) {
+      sdf = sphere;
+      const float k = -a.sphere_scale / nrm;
+      dx0 = k * x0; dx1 = k * x1; dx2 = k * x2;
+    }
+  }
+  if (half == 0 && p < a.src.P) {
+    a.sdf[p] = sdf;
+    a.grad[3 * p + 0] = dx0; a.grad[3 * p + 1] = dx1; a.grad[3 * p + 2] = dx2;
+  }
+}
+
+// wave-tile layout -> row-major (P, 256)
+__global__ void tiles_to_rows_kernel(const float* __restrict__ tiles, int P, float* __restrict__ rows) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over P*256
+  if (idx >= (size_t)P * 256) return;
+  const int p = (int)(idx / 256), f = (int)(idx % 256);
+  const int wtile = p / 32, col = p % 32;
+  const int t = f / 32, local = f % 32;
+  const int half = (local >> 2) & 1, r = (local & 3) + 4 * (local >> 3);
+  const int i = 16 * t + r, lane = col + 32 * half;
+  rows[idx] = tiles[(size_t)wtile * 128 * 64 + ((size_t)(i / 4) * 64 + lane) * 4 + (i % 4)];
+}
+
+// ------------------------------------------------------------------------------------------------------
+// RenderingNetwork.forward, mode 'idr' (network.py:170-190): cat[x, PE1(view), normal, feature] -> 4 x 256 ReLU -> 3, sigmoid
+// ------------------------------------------------------------------------------------------------------
+struct RgbArgs {
+  PointSrc src;            // sample positions (same source as the SDF kernel)
+  const float* normals;    // (P,3) = d sdf / dx, not normalised (network.py:234)
+  const float* view;       // view directions, (R,3) if view_S > 0 (one per ray) else (P,3)
+  int view_S;
+  const float* feat_tiles; // [wave tiles][128*64]
+  const f32x4* stream;
+  float* rgb;              // (P,3)
+};
+
+constexpr int kRgbBufF4 = kRgbChunk0F4;   // LDS buffer size for the radiance kernel (38 KiB)
+
+struct RgbStream {
+  const f32x4* g; f32x4* buf; int cur;
+  __device__ __forceinline__ const f32x4* cur_buf() const { return buf + cur * kRgbBufF4; }
+  template <int N16> __device__ __forceinline__ void prefetch() { chunk_issue<N16>(g, buf + (cur ^ 1) * kRgbBufF4); g += N16; }
+  __device__ __forceinline__ void advance() { __builtin_amdgcn_s_waitcnt(0); __syncthreads(); cur ^= 1; }
+};
+
+__global__ __launch_bounds__(kThreads, 1) void rgb_kernel(RgbArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  RgbStream st;
+  st.g = a.stream; st.buf = reinterpret_cast<f32x4*>(smem); st.cur = 1;
+  const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
+  const int wtile = blockIdx.x * kWaves + wave;
+  const int p = wtile * kTilePts + (lane & 31);
+  const int pc = p < a.src.P ? p : a.src.P - 1;
+
+  st.prefetch<kRgbChunk0F4>();
+  float x0, x1, x2;
+  load_point(a.src, p, x0, x1, x2);
+  const float* vd = a.view + 3 * (size_t)(a.view_S > 0 ? pc / a.view_S : pc);
+  const float d0 = vd[0], d1 = vd[1], d2 = vd[2];
+  // extra rows: [x(3), d(3), sin d(3), cos d(3), n(3), 0]
+  float ex[16];
+  ex[0] = x0; ex[1] = x1; ex[2] = x2; ex[3] = d0; ex[4] = d1; ex[5] = d2;
+  ex[6] = sinf(d0); ex[7] = sinf(d1); ex[8] = sinf(d2); ex[9] = cosf(d0); ex[10] = cosf(d1); ex[11] = cosf(d2);
+  ex[12] = a.normals[3 * pc]; ex[13] = a.normals[3 * pc + 1]; ex[14] = a.normals[3 * pc + 2]; ex[15] = 0.0f;
+  float eb[8];   // B operands of k-steps 128..135: rows rho(r) / rho(r)+4 of the 16 extra rows
+#pragma unroll
+  for (int r = 0; r < 8; ++r) eb[r] = half ? ex[rho(r) + 4] : ex[rho(r)];
+
+  f32x16 x[8], y[8];
+  load_tile_regs(a.feat_tiles + (size_t)wtile * 128 * 64, x, lane);
+  st.advance();
+
+  // ---- layer 0: 271 -> 256
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    if (t < 7) st.prefetch<kRgbChunk0F4>(); else st.prefetch<kChunkF4>();
+    const f32x4* chunk = st.cur_buf();
+    f32x16 acc = tile_mma<128>(chunk, x, lane);
+    const f32x4* a_ptr = chunk + kHdrF4 + 2048 + lane;
+#pragma unroll
+    for (int s4 = 0; s4 < 2; ++s4) {
+      const f32x4 w = a_ptr[s4 * 64];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j], eb[4 * s4 + j], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) y[t][r] = __builtin_fmaxf(acc[r], 0.0f);
+    st.advance();
+  }
+  // ---- layers 1..3
+  for (int l = 1; l < 4; ++l) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x[t] = y[t];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      st.prefetch<kChunkF4>();
+      const f32x16 acc = tile_mma<128>(st.cur_buf(), x, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) y[t][r] = __builtin_fmaxf(acc[r], 0.0f);
+      st.advance();
+    }
+  }
+  // ---- layer 4: 256 -> 3 as one tile (rows 0..2 live in registers 0..2 of lanes 0..31), sigmoid
+  const f32x16 acc = tile_mma<128>(st.cur_buf(), y, lane);
+  if (half == 0 && p < a.src.P) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a.rgb[3 * p + c] = 1.0f / (1.0f + __expf(-acc[c]));
+  }
+}
+
+}  // namespace mlp
+}  // namespace svs
+
+using namespace svs;
+using namespace svs::mlp;
+
+namespace {
+int fill_src(PointSrc& src, const float* points, const float* cam, int cam_stride, const float* dirs, const float* z,
+             int S, int n_points, const char* who) {
+  if (n_points <= 0) { set_error("%s: n_points must be positive", who); return SVS_ESHAPE; }
+  if (!points && !(cam && dirs && z && S > 0 && (cam_stride == 0 || cam_stride == 3) && n_points % S == 0)) {
+    set_error("%s: give either points, or cam/dirs/z with S > 0 dividing n_points and cam_stride in {0,3}", who);
+    return SVS_EINVAL;
+  }
+  src.pts = points; src.cam = cam; src.dirs = dirs; src.z = z; src.cam_stride = cam_stride; src.S = S > 0 ? S : 1;
+  src.P = n_points;
+  return SVS_OK;
+}
+int wave_tiles(int n_points) { return (n_points + kWgPts - 1) / kWgPts * kWaves; }
+
+template <typename K>
+int set_lds(K kernel, int bytes, const char* who) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e)); return (int)e; }
+  return SVS_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int svs_sdf_vals(const float* points, const float* cam, int cam_stride, const float* dirs, const float* z, int S,
+                 int n_points, const float* stream, float sphere_radius, float sphere_scale, float* sdf,
+                 const int* gate, void* hip_stream) {
+  SdfOnlyArgs a;
+  if (int rc = fill_src(a.src, points, cam, cam_stride, dirs, z, S, n_points, "svs_sdf_vals")) return rc;
+  if (!stream || !sdf) { set_error("svs_sdf_vals: null stream/sdf"); return SVS_EINVAL; }
+  a.stream = reinterpret_cast<const f32x4*>(stream); a.sdf = sdf;
+  a.sphere_radius = sphere_radius; a.sphere_scale = sphere_scale; a.gate = gate;
+  static int once = set_lds(sdf_only_kernel, kLdsBytes, "svs_sdf_vals");
+  if (once) return once;
+  sdf_only_kernel<<<(n_points + kWgPts - 1) / kWgPts, kThreads, kLdsBytes, (hipStream_t)hip_stream>>>(a);
+  return check_launch("svs_sdf_vals");
+}
+
+size_t svs_sdf_hbuf_bytes(int n_points) { return (size_t)wave_tiles(n_points) * 8 * 128 * 64 * sizeof(float); }
+size_t svs_feat_tiles_bytes(int n_points) { return (size_t)wave_tiles(n_points) * 128 * 64 * sizeof(float); }
+
+int svs_sdf_outputs(const float* points, const float* cam, int cam_stride, const float* dirs, const float* z, int S,
+                    int n_points, const float* stream, float sphere_radius, float sphere_scale, float* sdf,
+                    float* grad, float* feat_tiles, float* hbuf, void* hip_stream) {
+  SdfFullArgs a;
+  if (int rc = fill_src(a.src, points, cam, cam_stride, dirs, z, S, n_points, "svs_sdf_outputs")) return rc;
+  if (!stream || !sdf || !grad || !hbuf) { set_error("svs_sdf_outputs: null stream/sdf/grad/hbuf"); return SVS_EINVAL; }
+  a.stream = reinterpret_cast<const f32x4*>(stream); a.sdf = sdf; a.grad = grad; a.feat_tiles = feat_tiles; a.hbuf = hbuf;
+  a.sphere_radius = sphere_radius; a.sphere_scale = sphere_scale;
+  static int once = set_lds(sdf_full_kernel, kLdsBytes, "svs_sdf_outputs");
+  if (once) return once;
+  sdf_full_kernel<<<(n_points + kWgPts - 1) / kWgPts, kThreads, kLdsBytes, (hipStream_t)hip_stream>>>(a);
+  return check_launch("svs_sdf_outputs");
+}
+
+int svs_tiles_to_rows(const float* tiles, int n_points, float* rows, void* hip_stream) {
+  if (!tiles || !rows || n_points <= 0) { set_error("svs_tiles_to_rows: bad argument"); return SVS_EINVAL; }
+  const size_t n = (size_t)n_points * 256;
+  tiles_to_rows_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)hip_stream>>>(tiles, n_points, rows);
+  return check_launch("svs_tiles_to_rows");
+}
+
+int svs_rgb_eval(const float* points, const float* cam, int cam_stride, const float* dirs, const float* z, int S,
+                 int n_points, const float* normals, const float* view_dirs, int view_S, const float* feat_tiles,
+                 const float* stream, float* rgb, void* hip_stream) {
+  RgbArgs a;
+  if (int rc = fill_src(a.src, points, cam, cam_stride, dirs, z, S, n_points, "svs_rgb_eval")) return rc;
+  if (!normals || !view_dirs || !feat_tiles || !stream || !rgb || view_S < 0 || (view_S > 0 && n_points % view_S)) {
+    set_error("svs_rgb_eval: bad argument"); return SVS_EINVAL;
+  }
+  a.normals = normals; a.view = view_dirs; a.view_S = view_S; a.feat_tiles = feat_tiles;
+  a.stream = reinterpret_cast<const f32x4*>(stream); a.rgb = rgb;
+  constexpr int lds = 2 * kRgbBufF4 * 16;
+  static int once = set_lds(rgb_kernel, lds, "svs_rgb_eval");
+  if (once) return once;
+  rgb_kernel<<<(n_points + kWgPts - 1) / kWgPts, kThreads, lds, (hipStream_t)hip_stream>>>(a);
+  return check_launch("svs_rgb_eval");
+}
+
+}  // extern "C"

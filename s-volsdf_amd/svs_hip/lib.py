@@ -1,0 +1,71 @@
+"""ctypes binding of libsvolsdf_hip.so (the C-ABI declared in include/svolsdf_hip.h).
+
+The product path has NO CPU fallback: if the library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsvolsdf_hip.so")
+
+_lib = None
+
+
+class SvsError(RuntimeError):
+    pass
+
+
+_P = c_void_p   # every device pointer crosses the boundary as a plain address
+_PP = POINTER(c_void_p)
+
+# name -> (restype, argtypes); mirrors include/svolsdf_hip.h one to one
+SIGNATURES = {
+    "svs_version": (c_int, []),
+    "svs_last_error_string": (c_char_p, []),
+    "svs_rays_from_uv": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P]),
+    "svs_sdf_stream_bytes": (c_size_t, [c_int]),
+    "svs_rgb_stream_bytes": (c_size_t, []),
+    "svs_pack_workspace_bytes": (c_size_t, []),
+    "svs_sdf_pack": (c_int, [_PP, _PP, _PP, _P, _P, c_int, _P]),
+    "svs_rgb_pack": (c_int, [_PP, _PP, _PP, _P, _P, _P]),
+    "svs_sdf_vals": (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, _P, c_float, c_float, _P, _P, _P]),
+    "svs_sdf_hbuf_bytes": (c_size_t, [c_int]),
+    "svs_feat_tiles_bytes": (c_size_t, [c_int]),
+    "svs_sdf_outputs": (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, _P, c_float, c_float, _P, _P, _P, _P, _P]),
+    "svs_tiles_to_rows": (c_int, [_P, c_int, _P, _P]),
+    "svs_rgb_eval": (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, _P, _P, c_int, _P, _P, _P, _P]),
+    "svs_sampler_ctl_bytes": (c_size_t, []),
+    "svs_sampler_cap": (c_int, []),
+    "svs_sampler_max_new": (c_int, []),
+    "svs_sampler_init": (c_int, [_P, c_int, _P, c_int, c_int, c_float, c_float, c_int, c_float, _P, c_float, c_int,
+                                 _P, _P, _P, _P, _P, _P]),
+    "svs_sampler_round": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_float,
+                                  c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "svs_composite": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P]),
+    "svs_selftest_exp": (c_int, [_P, _P, _P, c_int, _P]),
+    "svs_selftest_arith": (c_int, [_P, _P, _P, _P, c_int, _P]),
+    "svs_selftest_cumsum": (c_int, [_P, _P, _P, c_int, c_int, _P]),
+}
+
+
+def load():
+    """Load the shared library once; raises SvsError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SvsError(f"{LIB_PATH} not found: run `python s-volsdf_amd/build.py` (there is no CPU fallback)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the header and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().svs_last_error_string()
+        raise SvsError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

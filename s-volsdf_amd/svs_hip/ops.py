@@ -1,0 +1,256 @@
+"""torch-tensor wrappers over the C-ABI (device pointers + the current HIP stream).
+
+PyTorch is used only for device memory and streams; every computation is a hand-written HIP kernel.
+Shapes/semantics follow the reference functions named in each docstring (paths relative to the
+reference root).
+"""
+import ctypes
+
+import torch
+
+from . import lib as _lib
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensors only"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t):
+    return t.detach().to(dtype=torch.float32).contiguous()
+
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr() if t is not None else None
+    return arr
+
+
+# ---------------------------------------------------------------------------------------------------
+def rays_from_uv(uv, pose, intrinsics):
+    """rend_util.get_camera_params (volsdf/utils/rend_util.py:60-95) + the depth_scale of network.py:216-217.
+
+    uv (R,2), pose (4,4), intrinsics (4,4) -> ray_dirs (R,3), cam_loc (3,), depth_scale (R,1)
+    """
+    L = _lib.load()
+    uv, pose, K = _f32(uv), _f32(pose), _f32(intrinsics)
+    R = uv.shape[0]
+    dirs = torch.empty(R, 3, device=uv.device)
+    cam = torch.empty(3, device=uv.device)
+    ds = torch.empty(R, 1, device=uv.device)
+    _lib.check(L.svs_rays_from_uv(_ptr(uv), _ptr(pose), _ptr(K), R, _ptr(dirs), _ptr(cam), _ptr(ds), _stream()),
+               "svs_rays_from_uv")
+    return dirs, cam, ds
+
+
+class PackedMlp:
+    """Packed weight streams of one ImplicitNetwork / RenderingNetwork pair (rebuilt after every optimiser step)."""
+
+    def __init__(self, device):
+        L = _lib.load()
+        self.device = device
+        self.sdf_stream = torch.empty(L.svs_sdf_stream_bytes(1) // 4, device=device)
+        self.rgb_stream = torch.empty(L.svs_rgb_stream_bytes() // 4, device=device)
+        self._ws = torch.empty(L.svs_pack_workspace_bytes() // 4, device=device)
+
+    def pack_sdf(self, weight_v, weight_g, bias):
+        """weight_v/bias: 9 tensors; weight_g: 9 tensors or None (no weight-norm). network.py:64-65."""
+        L = _lib.load()
+        v = [_f32(t) for t in weight_v]
+        b = [_f32(t) for t in bias]
+        g = [_f32(t) for t in weight_g] if weight_g is not None else None
+        self._keep = (v, b, g)
+        _lib.check(L.svs_sdf_pack(_ptr_array(v), _ptr_array(g) if g else None, _ptr_array(b), _ptr(self._ws),
+                                  _ptr(self.sdf_stream), 1, _stream()), "svs_sdf_pack")
+
+    def pack_rgb(self, weight_v, weight_g, bias):
+        L = _lib.load()
+        v = [_f32(t) for t in weight_v]
+        b = [_f32(t) for t in bias]
+        g = [_f32(t) for t in weight_g] if weight_g is not None else None
+        self._keep_rgb = (v, b, g)
+        _lib.check(L.svs_rgb_pack(_ptr_array(v), _ptr_array(g) if g else None, _ptr_array(b), _ptr(self._ws),
+                                  _ptr(self.rgb_stream), _stream()), "svs_rgb_pack")
+
+
+class PointSource:
+    """Where the MLP kernels take sample positions from: explicit points (P,3) or rays cam + z * dir."""
+
+    def __init__(self, points=None, cam=None, dirs=None, z=None):
+        if points is not None:
+            self.points = _f32(points)
+            self.n = self.points.shape[0]
+            self.cam = self.dirs = self.z = None
+            self.S, self.cam_stride = 0, 0
+        else:
+            self.points = None
+            self.cam, self.dirs, self.z = _f32(cam), _f32(dirs), _f32(z)
+            self.S = self.z.shape[1]
+            self.n = self.z.numel()
+            self.cam_stride = 0 if self.cam.numel() == 3 else 3
+
+    def args(self):
+        return (_ptr(self.points), _ptr(self.cam), self.cam_stride, _ptr(self.dirs), _ptr(self.z), self.S, self.n)
+
+    @property
+    def device(self):
+        return (self.points if self.points is not None else self.z).device
+
+
+def sdf_vals(packed, src, sphere_radius, sphere_scale, out=None, gate=None):
+    """ImplicitNetwork.get_sdf_vals (network.py:125-131) -> (P,1).  gate: optional device int (skip when 0)."""
+    L = _lib.load()
+    sdf = out if out is not None else torch.empty(src.n, 1, device=src.device)
+    _lib.check(L.svs_sdf_vals(*src.args(), _ptr(packed.sdf_stream), float(sphere_radius), float(sphere_scale),
+                              _ptr(sdf), ctypes.c_void_p(gate) if gate else None, _stream()), "svs_sdf_vals")
+    return sdf
+
+
+def sdf_outputs(packed, src, sphere_radius, sphere_scale, want_feature_rows=False):
+    """ImplicitNetwork.get_outputs (network.py:105-123): sdf (P,1), d sdf/dx (P,3), feature tiles, hbuf.
+
+    sphere_radius <= 0 differentiates the raw output (ImplicitNetwork.gradient, :90-103).
+    """
+    L = _lib.load()
+    dev = src.device
+    sdf = torch.empty(src.n, 1, device=dev)
+    grad = torch.empty(src.n, 3, device=dev)
+    feat = torch.empty(L.svs_feat_tiles_bytes(src.n) // 4, device=dev)
+    hbuf = torch.empty(L.svs_sdf_hbuf_bytes(src.n) // 4, device=dev)
+    _lib.check(L.svs_sdf_outputs(*src.args(), _ptr(packed.sdf_stream), float(sphere_radius), float(sphere_scale),
+                                 _ptr(sdf), _ptr(grad), _ptr(feat), _ptr(hbuf), _stream()), "svs_sdf_outputs")
+    rows = None
+    if want_feature_rows:
+        rows = torch.empty(src.n, 256, device=dev)
+        _lib.check(L.svs_tiles_to_rows(_ptr(feat), src.n, _ptr(rows), _stream()), "svs_tiles_to_rows")
+    return sdf, grad, feat, hbuf, rows
+
+
+def rgb_eval(packed, src, normals, view_dirs, feat_tiles):
+    """RenderingNetwork.forward, mode 'idr' (network.py:170-190) -> (P,3).
+    view_dirs: (R,3) with src in ray mode (one direction per ray), or (P,3)."""
+    L = _lib.load()
+    normals, view_dirs = _f32(normals), _f32(view_dirs)
+    view_S = src.S if (src.points is None and view_dirs.shape[0] * src.S == src.n) else 0
+    if view_S == 0:
+        assert view_dirs.shape[0] == src.n
+    rgb = torch.empty(src.n, 3, device=src.device)
+    _lib.check(L.svs_rgb_eval(*src.args(), _ptr(normals), _ptr(view_dirs), view_S, _ptr(feat_tiles),
+                              _ptr(packed.rgb_stream), _ptr(rgb), _stream()), "svs_rgb_eval")
+    return rgb
+
+
+def composite(z, sdf, rgb, depth_scale, beta_param, beta_min, normals=None):
+    """VolSDFNetwork.volume_rendering + reductions (network.py:281-295, :237-256, :270-276)."""
+    L = _lib.load()
+    z = _f32(z)
+    R, S = z.shape
+    dev = z.device
+    sdf, rgb, depth_scale = _f32(sdf), _f32(rgb), _f32(depth_scale)
+    beta_param = _f32(beta_param).reshape(1)
+    weights = torch.empty(R, S, device=dev)
+    rgb_values = torch.empty(R, 3, device=dev)
+    depth_values = torch.empty(R, 1, device=dev)
+    depth_vals = torch.empty(R, S, device=dev)
+    normal_map = torch.empty(R, 3, device=dev) if normals is not None else None
+    nrm = _f32(normals) if normals is not None else None
+    _lib.check(L.svs_composite(R, S, _ptr(z), _ptr(sdf), _ptr(rgb), _ptr(nrm), _ptr(depth_scale), _ptr(beta_param),
+                               float(beta_min), _ptr(weights), _ptr(rgb_values), _ptr(depth_values), _ptr(depth_vals),
+                               _ptr(normal_map), _stream()), "svs_composite")
+    return dict(weights=weights, rgb_values=rgb_values, depth_values=depth_values, depth_vals=depth_vals,
+                normal_map=normal_map)
+
+
+class SamplerWorkspace:
+    """Device buffers of the error-bounded sampler for R rays (allocated once, reused every step)."""
+
+    def __init__(self, R, device):
+        L = _lib.load()
+        self.R = R
+        self.cap, self.max_new = L.svs_sampler_cap(), L.svs_sampler_max_new()
+        f = lambda *s: torch.empty(*s, device=device)
+        self.z, self.sdf = f(R, self.cap), f(R, self.cap)
+        self.beta, self.far = f(R), f(R)
+        self.samples, self.samples_sdf = f(R, self.max_new), f(R, self.max_new)
+        self.ctl = torch.zeros(L.svs_sampler_ctl_bytes() // 4, dtype=torch.int32, device=device)
+        self.err = torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def sample_rays(packed, cam, dirs, beta0, *, near, scene_bounding_sphere, sphere_scale, sdf_clamp_radius,
+                N_samples=64, N_samples_eval=128, N_samples_extra=32, eps=0.1, beta_iters=10, max_total_iters=5,
+                fast=-1, training=False, inverse_sphere_bg=False, add_tiny=0.0, inv_4log=None, rng=None,
+                workspace=None, debug=None, sdf_override=None):
+    """ErrorBoundSampler.get_z_vals (volsdf/model/ray_sampler.py:67-219) without host synchronisation.
+
+    cam (3,) or (R,3), dirs (R,3); beta0: python float (density.get_beta()).
+    rng: dict of device tensors for train mode: 'jitter' (R,N_eval), 'u' (R,N_samples), 'perm' (int32, >= N_extra),
+         'eik_idx' (int32, R).   debug: optional dict that receives per-round index/cdf tensors.
+    sdf_override: optional list of per-round (R, N_eval) tensors used instead of the MLP (parity tests).
+    Returns z_vals (R, N_samples + N_samples_extra + 2) and z_samples_eik (R,1).
+    """
+    L = _lib.load()
+    cam, dirs = _f32(cam), _f32(dirs)
+    R = dirs.shape[0]
+    dev = dirs.device
+    ws = workspace or SamplerWorkspace(R, dev)
+    assert ws.R == R
+    rng = rng or {}
+    max_iters = fast if fast >= 0 else max_total_iters
+    if training and max_iters > 1 and "perm" in rng:
+        raise NotImplementedError("train-mode extras for more than one round need the bin count on the host")
+    if inv_4log is None:
+        inv_4log = float(1.0 / (4.0 * torch.log(torch.tensor(eps + 1.0))))     # float32, ray_sampler.py:77
+    cam_stride = 0 if cam.numel() == 3 else 3
+    far = 2.0 * scene_bounding_sphere
+    jitter = _f32(rng["jitter"]) if training and "jitter" in rng else None
+    _lib.check(L.svs_sampler_init(_ptr(cam), cam_stride, _ptr(dirs), R, N_samples_eval, float(near), float(far),
+                                  int(inverse_sphere_bg), float(scene_bounding_sphere), _ptr(jitter), float(inv_4log),
+                                  max_iters, _ptr(ws.samples), _ptr(ws.beta), _ptr(ws.far), _ptr(ws.ctl), _ptr(ws.err),
+                                  _stream()), "svs_sampler_init")
+    n_out = (N_samples if max_iters > 0 else N_samples_eval) + N_samples_extra + 2
+    z_final = torch.empty(R, n_out, device=dev)
+    z_eik = torch.empty(R, 1, device=dev)
+    u_final = _f32(rng["u"]) if training and "u" in rng else None
+    extra_idx = rng["perm"].to(torch.int32).contiguous() if training and "perm" in rng else None
+    eik_idx = rng["eik_idx"].to(torch.int32).contiguous() if training and "eik_idx" in rng else None
+
+    def call(phase, i, dbg):
+        _lib.check(L.svs_sampler_round(phase, R, i, max_iters, N_samples_eval, N_samples, N_samples_extra, float(beta0),
+                                       float(eps), beta_iters, float(add_tiny), float(near), _ptr(ws.far), _ptr(ws.z),
+                                       _ptr(ws.sdf), _ptr(ws.beta), _ptr(ws.samples), _ptr(ws.samples_sdf), _ptr(ws.ctl),
+                                       _ptr(u_final), _ptr(extra_idx), _ptr(eik_idx), _ptr(z_final), _ptr(z_eik),
+                                       _ptr(dbg.get("samples_idx")), _ptr(dbg.get("inds")), _ptr(dbg.get("cdf")),
+                                       _ptr(dbg.get("weights")), _stream()), "svs_sampler_round")
+
+    if max_iters == 0:
+        call(2, 0, {})
+        return z_final, z_eik
+    src = PointSource(cam=cam, dirs=dirs, z=ws.samples[:, :N_samples_eval]) if N_samples_eval == ws.max_new else None
+    for i in range(max_iters):
+        dbg = {}
+        if debug is not None:
+            dbg = dict(samples_idx=torch.full((R, ws.cap), -1, dtype=torch.int32, device=dev),
+                       inds=torch.full((R, ws.max_new), -1, dtype=torch.int32, device=dev),
+                       cdf=torch.zeros(R, ws.cap, device=dev), weights=torch.zeros(R, ws.cap, device=dev))
+            debug.setdefault("rounds", []).append(dbg)
+        if sdf_override is not None:
+            if i < len(sdf_override):
+                ws.samples_sdf[:, :N_samples_eval].copy_(sdf_override[i])
+        else:
+            if src is None:
+                raise NotImplementedError("N_samples_eval must equal the kernel's row stride (128)")
+            gate = ws.ctl.data_ptr() + 4 * (8 + i)          # Ctl.active[i]
+            sdf_vals(packed, src, sdf_clamp_radius, sphere_scale, out=ws.samples_sdf, gate=gate)
+        call(0, i, dbg)
+        call(1, i, dbg)
+        if debug is not None:
+            dbg["z"] = ws.z.clone(); dbg["sdf"] = ws.sdf.clone(); dbg["beta"] = ws.beta.clone()
+            dbg["samples"] = ws.samples.clone(); dbg["ctl"] = ws.ctl.clone()
+    return z_final, z_eik
