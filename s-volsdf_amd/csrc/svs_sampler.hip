@@ -193,7 +193,8 @@ __global__ __launch_bounds__(64) void init_kernel(InitArgs a) {
 struct RoundArgs {
   int R, round, max_iters;
   int n_eval, n_final, n_extra;
-  float beta0, eps; int beta_iters; float add_tiny;
+  const float* beta_param; float beta_min;   // beta0 = |*beta_param| + beta_min (density.py:28-30), read on the device
+  float eps; int beta_iters; float add_tiny;
   float near;
   const float* far;            // (R)
   float* z;                    // (R, kCap) bins
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(64) void round_a_kernel(RoundArgs a) {
   __syncthreads();
 
   float beta = a.beta[r];
-  const float beta0 = a.beta0;
+  const float beta0 = __builtin_fabsf(*a.beta_param) + a.beta_min;
   float err = error_bound(L, n, beta0, lane);
   if (err <= a.eps) beta = beta0;
   float bmin = beta0, bmax = beta;
@@ -436,17 +437,18 @@ int svs_sampler_init(const float* cam, int cam_stride, const float* dirs, int n_
 
 // phase: 0 = round A, 1 = round B, 2 = finalize for max_iters == 0
 int svs_sampler_round(int phase, int n_rays, int round, int max_iters, int n_eval, int n_final, int n_extra,
-                      float beta0, float eps, int beta_iters, float add_tiny, float near_, const float* far_,
+                      const float* beta_param, float beta_min, float eps, int beta_iters, float add_tiny, float near_,
+                      const float* far_,
                       float* z, float* sdf, float* beta, float* samples, const float* samples_sdf, void* ctl,
                       const float* u_final, const int* extra_idx, const int* eik_idx, float* z_final, float* z_eik,
                       int* dbg_samples_idx, int* dbg_inds, float* dbg_cdf, float* dbg_weights, void* hip_stream) {
-  if (!far_ || !z || !sdf || !beta || !samples || !ctl || !z_final || !z_eik || n_rays <= 0 || round < 0 || round > 6) {
+  if (!beta_param || !far_ || !z || !sdf || !beta || !samples || !ctl || !z_final || !z_eik || n_rays <= 0 || round < 0 || round > 6) {
     set_error("svs_sampler_round: null/invalid argument"); return SVS_EINVAL;
   }
   if (n_final > kMaxNew || n_final + n_extra + 2 > kCap || n_eval + n_extra + 2 > kCap) {
     set_error("svs_sampler_round: sample counts exceed kernel limits"); return SVS_ESHAPE;
   }
-  RoundArgs a{n_rays, round, max_iters, n_eval, n_final, n_extra, beta0, eps, beta_iters, add_tiny, near_, far_,
+  RoundArgs a{n_rays, round, max_iters, n_eval, n_final, n_extra, beta_param, beta_min, eps, beta_iters, add_tiny, near_, far_,
               z, sdf, beta, samples, samples_sdf, (Ctl*)ctl, u_final, extra_idx, eik_idx, z_final, z_eik,
               dbg_samples_idx, dbg_inds, dbg_cdf, dbg_weights};
   hipStream_t s = (hipStream_t)hip_stream;

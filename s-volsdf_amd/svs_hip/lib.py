@@ -40,7 +40,7 @@ SIGNATURES = {
     "svs_sampler_max_new": (c_int, []),
     "svs_sampler_init": (c_int, [_P, c_int, _P, c_int, c_int, c_float, c_float, c_int, c_float, _P, c_float, c_int,
                                  _P, _P, _P, _P, _P, _P]),
-    "svs_sampler_round": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_float,
+    "svs_sampler_round": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_float, c_float, c_int, c_float,
                                   c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "svs_composite": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P]),
     "svs_selftest_exp": (c_int, [_P, _P, _P, c_int, _P]),

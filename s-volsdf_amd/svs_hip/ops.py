@@ -183,13 +183,14 @@ class SamplerWorkspace:
         self.err = torch.zeros(1, dtype=torch.int32, device=device)
 
 
-def sample_rays(packed, cam, dirs, beta0, *, near, scene_bounding_sphere, sphere_scale, sdf_clamp_radius,
+def sample_rays(packed, cam, dirs, beta_param, *, beta_min=1e-4, near, scene_bounding_sphere, sphere_scale, sdf_clamp_radius,
                 N_samples=64, N_samples_eval=128, N_samples_extra=32, eps=0.1, beta_iters=10, max_total_iters=5,
                 fast=-1, training=False, inverse_sphere_bg=False, add_tiny=0.0, inv_4log=None, rng=None,
                 workspace=None, debug=None, sdf_override=None):
     """ErrorBoundSampler.get_z_vals (volsdf/model/ray_sampler.py:67-219) without host synchronisation.
 
-    cam (3,) or (R,3), dirs (R,3); beta0: python float (density.get_beta()).
+    cam (3,) or (R,3), dirs (R,3); beta_param: the `density.beta` parameter (device scalar tensor or float);
+    beta0 = |beta_param| + beta_min is formed on the device (density.py:28-30), so a step needs no host sync.
     rng: dict of device tensors for train mode: 'jitter' (R,N_eval), 'u' (R,N_samples), 'perm' (int32, >= N_extra),
          'eik_idx' (int32, R).   debug: optional dict that receives per-round index/cdf tensors.
     sdf_override: optional list of per-round (R, N_eval) tensors used instead of the MLP (parity tests).
@@ -202,6 +203,9 @@ def sample_rays(packed, cam, dirs, beta0, *, near, scene_bounding_sphere, sphere
     ws = workspace or SamplerWorkspace(R, dev)
     assert ws.R == R
     rng = rng or {}
+    if not torch.is_tensor(beta_param):
+        beta_param = torch.tensor(float(beta_param), device=dev)
+    beta_param = _f32(beta_param).reshape(1)
     max_iters = fast if fast >= 0 else max_total_iters
     if training and max_iters > 1 and "perm" in rng:
         raise NotImplementedError("train-mode extras for more than one round need the bin count on the host")
@@ -222,8 +226,8 @@ def sample_rays(packed, cam, dirs, beta0, *, near, scene_bounding_sphere, sphere
     eik_idx = rng["eik_idx"].to(torch.int32).contiguous() if training and "eik_idx" in rng else None
 
     def call(phase, i, dbg):
-        _lib.check(L.svs_sampler_round(phase, R, i, max_iters, N_samples_eval, N_samples, N_samples_extra, float(beta0),
-                                       float(eps), beta_iters, float(add_tiny), float(near), _ptr(ws.far), _ptr(ws.z),
+        _lib.check(L.svs_sampler_round(phase, R, i, max_iters, N_samples_eval, N_samples, N_samples_extra, _ptr(beta_param),
+                                       float(beta_min), float(eps), beta_iters, float(add_tiny), float(near), _ptr(ws.far), _ptr(ws.z),
                                        _ptr(ws.sdf), _ptr(ws.beta), _ptr(ws.samples), _ptr(ws.samples_sdf), _ptr(ws.ctl),
                                        _ptr(u_final), _ptr(extra_idx), _ptr(eik_idx), _ptr(z_final), _ptr(z_eik),
                                        _ptr(dbg.get("samples_idx")), _ptr(dbg.get("inds")), _ptr(dbg.get("cdf")),

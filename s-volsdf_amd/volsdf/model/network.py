@@ -1,0 +1,209 @@
+"""VolSDF networks with the reference's class names, constructor arguments, state-dict keys and
+forward() contract (volsdf/model/network.py), evaluated by the fused HIP kernels of svs_mlp.hip.
+
+`train.model_class: volsdf.model.network.VolSDFNetwork` (config/vol/dtu.yaml:4) resolves to this module
+when s-volsdf_amd/ precedes the reference on sys.path; checkpoints interchange with the reference
+(`implicit_network.lin{0..8}.{weight_g,weight_v,bias}`, `rendering_network.lin{0..4}.*`, `density.beta`).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from svs_hip import ops
+from volsdf.model.density import LaplaceDensity
+from volsdf.model.embedder import get_embedder
+from volsdf.model.ray_sampler import ErrorBoundSampler
+from volsdf.utils import rend_util
+
+
+def _dev(module):
+    return next(module.parameters()).device
+
+
+class ImplicitNetwork(nn.Module):
+    """SDF MLP, network.py:10-131.  Parameters are created exactly as the reference creates them (nn.Linear +
+    geometric initialisation + weight_norm), so seeds and checkpoints carry over; evaluation is the fused
+    kernel, which is specialised to the 8 x 256 / skip-4 / PE-6 / 256-feature architecture of every config."""
+
+    def __init__(self, feature_vector_size, sdf_bounding_sphere, d_in, d_out, dims, geometric_init=True, bias=1.0,
+                 skip_in=(), weight_norm=True, multires=0, sphere_scale=1.0):
+        super().__init__()
+        self.sdf_bounding_sphere, self.sphere_scale = sdf_bounding_sphere, sphere_scale
+        dims = [d_in] + list(dims) + [d_out + feature_vector_size]
+        self.embed_fn = None
+        if multires > 0:
+            self.embed_fn, dims[0] = get_embedder(multires, input_dims=d_in)
+        self.num_layers = len(dims)
+        self.skip_in = tuple(skip_in)
+        self.weight_norm = weight_norm
+        self._supported = (d_in == 3 and d_out == 1 and feature_vector_size == 256 and multires == 6 and
+                           list(dims[1:-1]) == [256] * 8 and self.skip_in == (4,))
+        for l in range(self.num_layers - 1):
+            out_dim = dims[l + 1] - dims[0] if l + 1 in self.skip_in else dims[l + 1]
+            lin = nn.Linear(dims[l], out_dim)
+            if geometric_init:
+                if l == self.num_layers - 2:
+                    torch.nn.init.normal_(lin.weight, mean=np.sqrt(np.pi) / np.sqrt(dims[l]), std=0.0001)
+                    torch.nn.init.constant_(lin.bias, -bias)
+                elif multires > 0 and l == 0:
+                    torch.nn.init.constant_(lin.bias, 0.0)
+                    torch.nn.init.constant_(lin.weight[:, 3:], 0.0)
+                    torch.nn.init.normal_(lin.weight[:, :3], 0.0, np.sqrt(2) / np.sqrt(out_dim))
+                elif multires > 0 and l in self.skip_in:
+                    torch.nn.init.constant_(lin.bias, 0.0)
+                    torch.nn.init.normal_(lin.weight, 0.0, np.sqrt(2) / np.sqrt(out_dim))
+                    torch.nn.init.constant_(lin.weight[:, -(dims[0] - 3):], 0.0)
+                else:
+                    torch.nn.init.constant_(lin.bias, 0.0)
+                    torch.nn.init.normal_(lin.weight, 0.0, np.sqrt(2) / np.sqrt(out_dim))
+            if weight_norm:
+                lin = nn.utils.weight_norm(lin)
+            setattr(self, "lin" + str(l), lin)
+        self._packed, self._packed_key = None, None
+
+    # ---- packed weights ----------------------------------------------------------------------------
+    def _layer_tensors(self):
+        n = self.num_layers - 1
+        lins = [getattr(self, f"lin{l}") for l in range(n)]
+        if self.weight_norm:
+            return [m.weight_v for m in lins], [m.weight_g for m in lins], [m.bias for m in lins]
+        return [m.weight for m in lins], None, [m.bias for m in lins]
+
+    def packed(self, owner=None):
+        if not self._supported:
+            raise NotImplementedError("the fused SDF kernel is built for d_in=3, 8x256, skip_in=[4], multires=6, 256 features")
+        v, g, b = self._layer_tensors()
+        key = tuple((t.data_ptr(), t._version) for t in v + (g or []) + b)
+        pk = owner if owner is not None else self._packed
+        if pk is None:
+            pk = self._packed = ops.PackedMlp(v[0].device)
+        if self._packed_key != key or getattr(pk, "_sdf_key", None) != key:
+            pk.pack_sdf(v, g, b)
+            pk._sdf_key = self._packed_key = key
+        return pk
+
+    # ---- reference call surface (inference; gradients w.r.t. parameters arrive with the backward kernels) ----
+    def forward(self, input):
+        """(P,3) -> (P,257) = [sdf (unclamped), feature]."""
+        sdf, _, _, _, rows = ops.sdf_outputs(self.packed(), ops.PointSource(points=input), 0.0, self.sphere_scale,
+                                             want_feature_rows=True)
+        return torch.cat([sdf, rows], 1)
+
+    def gradient(self, x, with_sdf=False):
+        sdf, grad, _, _, _ = ops.sdf_outputs(self.packed(), ops.PointSource(points=x), 0.0, self.sphere_scale)
+        return (grad, sdf) if with_sdf else grad
+
+    def get_outputs(self, x):
+        sdf, grad, _, _, rows = ops.sdf_outputs(self.packed(), ops.PointSource(points=x), self.sdf_bounding_sphere,
+                                                self.sphere_scale, want_feature_rows=True)
+        return sdf, rows, grad
+
+    def get_sdf_vals(self, x):
+        return ops.sdf_vals(self.packed(), ops.PointSource(points=x), self.sdf_bounding_sphere, self.sphere_scale)
+
+
+class RenderingNetwork(nn.Module):
+    """Radiance MLP, network.py:134-190 (mode 'idr', 4 x 256, PE-1 view directions)."""
+
+    def __init__(self, feature_vector_size, mode, d_in, d_out, dims, weight_norm=True, multires_view=0):
+        super().__init__()
+        self.mode = mode
+        dims = [d_in + feature_vector_size] + list(dims) + [d_out]
+        self.embedview_fn = None
+        if multires_view > 0:
+            self.embedview_fn, input_ch = get_embedder(multires_view)
+            dims[0] += input_ch - 3
+        self.num_layers = len(dims)
+        self.weight_norm = weight_norm
+        self._supported = (mode == "idr" and dims == [271, 256, 256, 256, 256, 3])
+        for l in range(self.num_layers - 1):
+            lin = nn.Linear(dims[l], dims[l + 1])
+            if weight_norm:
+                lin = nn.utils.weight_norm(lin)
+            setattr(self, "lin" + str(l), lin)
+        self._packed_key = None
+
+    def pack_into(self, pk):
+        if not self._supported:
+            raise NotImplementedError("the fused radiance kernel is built for mode='idr', 271->4x256->3")
+        lins = [getattr(self, f"lin{l}") for l in range(self.num_layers - 1)]
+        if self.weight_norm:
+            v, g, b = [m.weight_v for m in lins], [m.weight_g for m in lins], [m.bias for m in lins]
+        else:
+            v, g, b = [m.weight for m in lins], None, [m.bias for m in lins]
+        key = tuple((t.data_ptr(), t._version) for t in v + (g or []) + b)
+        if getattr(pk, "_rgb_key", None) != key:
+            pk.pack_rgb(v, g, b)
+            pk._rgb_key = key
+        return pk
+
+
+class VolSDFNetwork(nn.Module):
+    """network.py:192-295.  forward(input, fast) -> dict with the reference's keys."""
+
+    def __init__(self, conf):
+        super().__init__()
+        self.feature_vector_size = conf.get_int('feature_vector_size')
+        self.scene_bounding_sphere = conf.get_float('scene_bounding_sphere', default=1.0)
+        self.white_bkgd = conf.get_bool('white_bkgd', default=False)
+        self.register_buffer("bg_color", torch.tensor(conf.get_list("bg_color", default=[1.0, 1.0, 1.0])).float(),
+                             persistent=False)
+        self.implicit_network = ImplicitNetwork(self.feature_vector_size,
+                                                0.0 if self.white_bkgd else self.scene_bounding_sphere,
+                                                **conf.get_config('implicit_network'))
+        self.rendering_network = RenderingNetwork(self.feature_vector_size, **conf.get_config('rendering_network'))
+        self.density = LaplaceDensity(**conf.get_config('density'))
+        self.ray_sampler = ErrorBoundSampler(self.scene_bounding_sphere, **conf.get_config('ray_sampler'))
+        self._pk = None
+
+    def packed_mlp(self):
+        """Packed weight streams (re-packed only when a parameter changed)."""
+        if self._pk is None or self._pk.device != _dev(self):
+            self._pk = ops.PackedMlp(_dev(self))
+        self.implicit_network.packed(owner=self._pk)
+        self.rendering_network.pack_into(self._pk)
+        return self._pk
+
+    def forward(self, input, fast=-1):
+        intrinsics, uv, pose = input["intrinsics"], input["uv"], input["pose"]
+        if uv.shape[0] != 1:
+            raise NotImplementedError("batch_size 1 only (runner.py:166)")
+        net = self.implicit_network
+        pk = self.packed_mlp()
+        ray_dirs, cam_loc, depth_scale = ops.rays_from_uv(uv[0], pose[0], intrinsics[0])       # network.py:213-217
+        num_pixels = ray_dirs.shape[0]
+
+        z_vals, z_samples_eik = self.ray_sampler.get_z_vals(ray_dirs, cam_loc, self, fast=fast,
+                                                            iter_step=input.get("iter_step", 1))
+        N_samples = z_vals.shape[1]
+        src = ops.PointSource(cam=cam_loc, dirs=ray_dirs, z=z_vals)
+        sdf, gradients, feat_tiles, _, _ = ops.sdf_outputs(pk, src, net.sdf_bounding_sphere, net.sphere_scale)
+        rgb_flat = ops.rgb_eval(pk, src, gradients, ray_dirs, feat_tiles)
+        comp = ops.composite(z_vals, sdf, rgb_flat, depth_scale, self.density.beta, float(self.density.beta_min),
+                             normals=None if self.training else gradients)
+        rgb_values = comp["rgb_values"]
+        if self.white_bkgd:
+            acc_map = torch.sum(comp["weights"], -1)
+            rgb_values = rgb_values + (1. - acc_map[..., None]) * self.bg_color.unsqueeze(0)
+        points = cam_loc.view(1, 1, 3) + z_vals.unsqueeze(2) * ray_dirs.unsqueeze(1)
+        output = {'rgb_values': rgb_values, 'depth_values': comp["depth_values"], 'depth_vals': comp["depth_vals"],
+                  'weights': comp["weights"], 'xyz': points}
+        if self.training:
+            n_eik = num_pixels
+            eikonal_points = torch.empty(n_eik, 3).uniform_(-self.scene_bounding_sphere,
+                                                            self.scene_bounding_sphere).to(ray_dirs.device)
+            eik_near = cam_loc.view(1, 3) + z_samples_eik * ray_dirs
+            eikonal_points = torch.cat([eikonal_points, eik_near], 0)
+            output['grad_theta'] = net.gradient(eikonal_points)
+        else:
+            output['normal_map'] = comp["normal_map"]
+        return output
+
+    def volume_rendering(self, z_vals, sdf):
+        """network.py:281-295 -> (weights, dists)."""
+        R = z_vals.shape[0]
+        dev = z_vals.device
+        comp = ops.composite(z_vals, sdf, torch.zeros(z_vals.numel(), 3, device=dev), torch.ones(R, 1, device=dev),
+                             self.density.beta, float(self.density.beta_min))
+        dists = torch.cat([z_vals[:, 1:] - z_vals[:, :-1], torch.full((R, 1), 1e10, device=dev)], -1)
+        return comp["weights"], dists

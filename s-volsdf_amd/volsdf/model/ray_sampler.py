@@ -1,0 +1,107 @@
+"""Ray samplers with the reference's class names and call surface (volsdf/model/ray_sampler.py).
+
+`ErrorBoundSampler.get_z_vals` enqueues the HIP sampler (svs_sampler.hip) with the gated fused SDF-MLP
+launches between rounds; no host synchronisation happens inside a call.  All randomness is drawn from
+torch's CPU generator in the reference's order (ray_sampler.py:39,170,201,211) and handed to the kernels.
+"""
+import abc
+
+import torch
+
+from svs_hip import ops
+
+
+class RaySampler(metaclass=abc.ABCMeta):
+    def __init__(self, near, far):
+        self.near, self.far = near, far
+
+    @abc.abstractmethod
+    def get_z_vals(self, ray_dirs, cam_loc, model):
+        pass
+
+
+class UniformSampler(RaySampler):
+    """ray_sampler.py:15-43.  Kept as host glue (tiny); the error-bounded sampler's own uniform
+    initialisation runs inside its init kernel."""
+
+    def __init__(self, scene_bounding_sphere, near, N_samples, take_sphere_intersection=False, far=-1):
+        super().__init__(near, 2.0 * scene_bounding_sphere if far == -1 else far)
+        self.N_samples = N_samples
+        self.scene_bounding_sphere = scene_bounding_sphere
+        self.take_sphere_intersection = take_sphere_intersection
+
+    def get_z_vals(self, ray_dirs, cam_loc, model, iter_step=None):
+        from volsdf.utils import rend_util
+        dev = ray_dirs.device
+        n = ray_dirs.shape[0]
+        near = self.near * torch.ones(n, 1, device=dev)
+        if not self.take_sphere_intersection:
+            far = self.far * torch.ones(n, 1, device=dev)
+        else:
+            far = rend_util.get_sphere_intersections(cam_loc, ray_dirs, r=self.scene_bounding_sphere)[:, 1:]
+        t_vals = torch.linspace(0., 1., steps=self.N_samples).to(dev)
+        z_vals = near * (1. - t_vals) + far * t_vals
+        if model.training:
+            mids = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
+            upper = torch.cat([mids, z_vals[..., -1:]], -1)
+            lower = torch.cat([z_vals[..., :1], mids], -1)
+            t_rand = torch.rand(z_vals.shape).to(dev)
+            z_vals = lower + (upper - lower) * t_rand
+        return z_vals
+
+
+class ErrorBoundSampler(RaySampler):
+    def __init__(self, scene_bounding_sphere, near, N_samples, N_samples_eval, N_samples_extra, eps, beta_iters,
+                 max_total_iters, inverse_sphere_bg=False, N_samples_inverse_sphere=0, add_tiny=0.0):
+        super().__init__(near, 2.0 * scene_bounding_sphere)
+        self.N_samples, self.N_samples_eval, self.N_samples_extra = N_samples, N_samples_eval, N_samples_extra
+        self.uniform_sampler = UniformSampler(scene_bounding_sphere, near, N_samples_eval,
+                                              take_sphere_intersection=inverse_sphere_bg)
+        self.eps, self.beta_iters, self.max_total_iters = eps, beta_iters, max_total_iters
+        self.scene_bounding_sphere = scene_bounding_sphere
+        self.add_tiny = add_tiny
+        self.inverse_sphere_bg = inverse_sphere_bg
+        if inverse_sphere_bg:
+            self.inverse_sphere_sampler = UniformSampler(1.0, 0.0, N_samples_inverse_sphere, False, far=1.0)
+        # float32 constant of ray_sampler.py:77, computed the way the reference computes it
+        self._inv_4log = float(1.0 / (4.0 * torch.log(torch.tensor(self.eps + 1.0))))
+        self._ws = None
+
+    def get_z_vals(self, ray_dirs, cam_loc, model, fast=-1, iter_step=None):
+        """ray_dirs (R,3), cam_loc (R,3) or (3,) -> z_vals (R, N_samples+N_samples_extra+2), z_samples_eik (R,1)."""
+        dev = ray_dirs.device
+        R = ray_dirs.shape[0]
+        max_iters = fast if fast >= 0 else self.max_total_iters
+        rng = None
+        if model.training:
+            if max_iters != 1:
+                raise NotImplementedError("train-mode sampling is implemented for fast=1 (what VolOpt.train_step uses)")
+            # same draws, same order as the reference (CPU generator, then copied to the device)
+            n_out = self.N_samples + self.N_samples_extra + 2
+            rng = dict(jitter=torch.rand(R, self.N_samples_eval).to(dev),
+                       u=torch.rand(R, self.N_samples).to(dev),
+                       perm=torch.randperm(self.N_samples_eval)[:self.N_samples_extra].to(torch.int32).to(dev),
+                       eik_idx=torch.randint(n_out, (R,)).to(torch.int32).to(dev))
+        if self._ws is None or self._ws.R != R or self._ws.z.device != dev:
+            self._ws = ops.SamplerWorkspace(R, dev)
+        net = model.implicit_network
+        z, z_eik = ops.sample_rays(model.packed_mlp(), cam_loc, ray_dirs, model.density.beta, beta_min=float(model.density.beta_min), near=self.near,
+                                   scene_bounding_sphere=self.scene_bounding_sphere, sphere_scale=net.sphere_scale,
+                                   sdf_clamp_radius=net.sdf_bounding_sphere, N_samples=self.N_samples,
+                                   N_samples_eval=self.N_samples_eval, N_samples_extra=self.N_samples_extra, eps=self.eps,
+                                   beta_iters=self.beta_iters, max_total_iters=self.max_total_iters, fast=fast,
+                                   training=model.training, inverse_sphere_bg=self.inverse_sphere_bg,
+                                   add_tiny=self.add_tiny, inv_4log=self._inv_4log, rng=rng, workspace=self._ws)
+        if self.inverse_sphere_bg:
+            z_bg = self.inverse_sphere_sampler.get_z_vals(ray_dirs, cam_loc, model) * (1. / self.scene_bounding_sphere)
+            z = (z, z_bg)
+        return z, z_eik
+
+    def get_error_bound(self, beta, model, sdf, z_vals, dists, d_star):
+        """ray_sampler.py:221-229 on tensors (host glue for analysis; the sampler kernels evaluate it in LDS)."""
+        density = model.density(sdf.reshape(z_vals.shape), beta=beta)
+        sfe = torch.cat([torch.zeros(dists.shape[0], 1, device=dists.device), dists * density[:, :-1]], dim=-1)
+        integral = torch.cumsum(sfe, dim=-1)
+        err_int = torch.cumsum(torch.exp(-d_star / beta) * (dists ** 2.) / (4 * beta ** 2), dim=-1)
+        bound = (torch.clamp(torch.exp(err_int), max=1.e6) - 1.0) * torch.exp(-integral[:, :-1])
+        return bound.max(-1)[0]
