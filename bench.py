@@ -81,7 +81,7 @@ def main():
         e0.record()
         out = orig(pk, src, *a, **k)
         e1.record()
-        ev.append((e0, e1, src.n))
+        ev.append((e0, e1, src.n, src.S))
         return out
 
     ev_on = [False]
@@ -113,9 +113,9 @@ def main():
 
     if rank == 0:
         n_pts = ev[0][2]
-        k_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in ev]))
+        k_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
         achieved = n_pts * 2 * F_SDF / (k_ms * 1e-3)
-        S = n_pts // R
+        S = ev[0][3]
         flop_per_ray = 128 * F_SDF + S * (2 * F_SDF + F_RGB) + 2 * (2 * F_SDF)
         line = {
             "metric": "rendered rays/sec (1024-ray batch, 128 samples)",

@@ -93,20 +93,24 @@ struct PosEnc {
   }
 };
 
+// Sample positions of one launch: first the ray samples cam + z * dir (n_ray = R*S of them, may be 0),
+// then n_pts explicit points (may be 0).  P = n_ray + n_pts.
 struct PointSrc {
-  const float* pts;   // (P,3) explicit points, or nullptr
-  const float* cam;   // ray mode: camera centre(s)
-  const float* dirs;  // ray mode: (R,3)
-  const float* z;     // ray mode: (R,S)
+  const float* pts;   // (n_pts,3) explicit points
+  const float* cam;   // ray part: camera centre(s)
+  const float* dirs;  // ray part: (R,3)
+  const float* z;     // ray part: (R,S)
   int cam_stride;     // 0: one camera for all rays, 3: per ray
-  int S;              // samples per ray (ray mode)
-  int P;              // number of points
+  int S;              // samples per ray
+  int n_ray;          // R * S
+  int P;              // total number of points
 };
 
 __device__ __forceinline__ void load_point(const PointSrc& src, int p, float& x0, float& x1, float& x2) {
   if (p >= src.P) p = src.P - 1;
-  if (src.pts) {
-    x0 = src.pts[3 * p + 0]; x1 = src.pts[3 * p + 1]; x2 = src.pts[3 * p + 2];
+  if (p >= src.n_ray) {
+    const int q = p - src.n_ray;
+    x0 = src.pts[3 * q + 0]; x1 = src.pts[3 * q + 1]; x2 = src.pts[3 * q + 2];
   } else {
     const int r = p / src.S;
     const float zz = src.z[p];
@@ -258,6 +262,7 @@ struct SdfOnlyArgs {
   float* sdf;            // (P)
   float sphere_radius;   // <= 0: no clamp (network.py:128)
   float sphere_scale;
+  int clamp_n;           // the clamp applies to points [0, clamp_n)
   const int* gate;       // optional device flag: the launch is a no-op when *gate == 0 (sampler rounds)
 };
 
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_only_kernel(SdfOnlyArgs a) {
   forward_trunk<false>(st, x, y, pe, lane, half, nullptr);
   // the VEC chunk was prefetched by the last tile of layer 7
   float sdf = sdf_head(st.cur_buf(), x, lane);
-  if (a.sphere_radius > 0.0f) {
+  if (a.sphere_radius > 0.0f && p < a.clamp_n) {
     const float nrm = __builtin_sqrtf(x0 * x0 + x1 * x1 + x2 * x2);
     sdf = __builtin_fminf(sdf, a.sphere_scale * (a.sphere_radius - nrm));
   }
@@ -304,6 +309,7 @@ struct SdfFullArgs {
   float* hbuf;           // [wave tiles][8][128*64] activations h_1..h_8
   float sphere_radius;   // > 0: min(sdf, scale*(R-|x|)) inside the differentiated graph (network.py:110-112)
   float sphere_scale;
+  int clamp_n;           // ... for points [0, clamp_n); the rest differentiate the raw output (network.py:90-103)
 };
 
 __global__ __launch_bounds__(kThreads, 1) void sdf_full_kernel(SdfFullArgs a) {
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_kernel(SdfFullArgs a) {
   }
   dx0 += __shfl_xor(dx0, 32); dx1 += __shfl_xor(dx1, 32); dx2 += __shfl_xor(dx2, 32);
 
-  if (a.sphere_radius > 0.0f) {
+  if (a.sphere_radius > 0.0f && p < a.clamp_n) {
     const float nrm = __builtin_sqrtf(x0 * x0 + x1 * x1 + x2 * x2);
     const float sphere = a.sphere_scale * (a.sphere_radius - nrm);
     if (sphere < sdf) {
@@ -546,15 +552,17 @@ using namespace svs;
 using namespace svs::mlp;
 
 namespace {
-int fill_src(PointSrc& src, const float* points, const float* cam, int cam_stride, const float* dirs, const float* z,
-             int S, int n_points, const char* who) {
-  if (n_points <= 0) { set_error("%s: n_points must be positive", who); return SVS_ESHAPE; }
-  if (!points && !(cam && dirs && z && S > 0 && (cam_stride == 0 || cam_stride == 3) && n_points % S == 0)) {
-    set_error("%s: give either points, or cam/dirs/z with S > 0 dividing n_points and cam_stride in {0,3}", who);
-    return SVS_EINVAL;
+int fill_src(PointSrc& src, const float* points, int n_points, const float* cam, int cam_stride, const float* dirs,
+             const float* z, int S, int n_rays, const char* who) {
+  if (n_points < 0 || n_rays < 0 || (n_points == 0 && n_rays == 0)) { set_error("%s: no points", who); return SVS_ESHAPE; }
+  if (n_points > 0 && !points) { set_error("%s: n_points > 0 but points is null", who); return SVS_EINVAL; }
+  if (n_rays > 0 && !(cam && dirs && z && S > 0 && (cam_stride == 0 || cam_stride == 3))) {
+    set_error("%s: the ray part needs cam/dirs/z, S > 0 and cam_stride in {0,3}", who); return SVS_EINVAL;
   }
+  if ((long long)n_rays * S + n_points > 0x7fffffffLL) { set_error("%s: too many points", who); return SVS_ESHAPE; }
   src.pts = points; src.cam = cam; src.dirs = dirs; src.z = z; src.cam_stride = cam_stride; src.S = S > 0 ? S : 1;
-  src.P = n_points;
+  src.n_ray = n_rays * (S > 0 ? S : 0);
+  src.P = src.n_ray + n_points;
   return SVS_OK;
 }
 int wave_tiles(int n_points) { return (n_points + kWgPts - 1) / kWgPts * kWaves; }
@@ -569,34 +577,36 @@ int set_lds(K kernel, int bytes, const char* who) {
 
 extern "C" {
 
-int svs_sdf_vals(const float* points, const float* cam, int cam_stride, const float* dirs, const float* z, int S,
-                 int n_points, const float* stream, float sphere_radius, float sphere_scale, float* sdf,
-                 const int* gate, void* hip_stream) {
+int svs_sdf_vals(const float* points, int n_points, const float* cam, int cam_stride, const float* dirs, const float* z,
+                 int S, int n_rays, const float* stream, float sphere_radius, float sphere_scale, int clamp_n,
+                 float* sdf, const int* gate, void* hip_stream) {
   SdfOnlyArgs a;
-  if (int rc = fill_src(a.src, points, cam, cam_stride, dirs, z, S, n_points, "svs_sdf_vals")) return rc;
+  if (int rc = fill_src(a.src, points, n_points, cam, cam_stride, dirs, z, S, n_rays, "svs_sdf_vals")) return rc;
   if (!stream || !sdf) { set_error("svs_sdf_vals: null stream/sdf"); return SVS_EINVAL; }
   a.stream = reinterpret_cast<const f32x4*>(stream); a.sdf = sdf;
   a.sphere_radius = sphere_radius; a.sphere_scale = sphere_scale; a.gate = gate;
+  a.clamp_n = clamp_n < 0 ? a.src.P : clamp_n;
   static int once = set_lds(sdf_only_kernel, kLdsBytes, "svs_sdf_vals");
   if (once) return once;
-  sdf_only_kernel<<<(n_points + kWgPts - 1) / kWgPts, kThreads, kLdsBytes, (hipStream_t)hip_stream>>>(a);
+  sdf_only_kernel<<<(a.src.P + kWgPts - 1) / kWgPts, kThreads, kLdsBytes, (hipStream_t)hip_stream>>>(a);
   return check_launch("svs_sdf_vals");
 }
 
 size_t svs_sdf_hbuf_bytes(int n_points) { return (size_t)wave_tiles(n_points) * 8 * 128 * 64 * sizeof(float); }
 size_t svs_feat_tiles_bytes(int n_points) { return (size_t)wave_tiles(n_points) * 128 * 64 * sizeof(float); }
 
-int svs_sdf_outputs(const float* points, const float* cam, int cam_stride, const float* dirs, const float* z, int S,
-                    int n_points, const float* stream, float sphere_radius, float sphere_scale, float* sdf,
-                    float* grad, float* feat_tiles, float* hbuf, void* hip_stream) {
+int svs_sdf_outputs(const float* points, int n_points, const float* cam, int cam_stride, const float* dirs,
+                    const float* z, int S, int n_rays, const float* stream, float sphere_radius, float sphere_scale,
+                    int clamp_n, float* sdf, float* grad, float* feat_tiles, float* hbuf, void* hip_stream) {
   SdfFullArgs a;
-  if (int rc = fill_src(a.src, points, cam, cam_stride, dirs, z, S, n_points, "svs_sdf_outputs")) return rc;
+  if (int rc = fill_src(a.src, points, n_points, cam, cam_stride, dirs, z, S, n_rays, "svs_sdf_outputs")) return rc;
   if (!stream || !sdf || !grad || !hbuf) { set_error("svs_sdf_outputs: null stream/sdf/grad/hbuf"); return SVS_EINVAL; }
   a.stream = reinterpret_cast<const f32x4*>(stream); a.sdf = sdf; a.grad = grad; a.feat_tiles = feat_tiles; a.hbuf = hbuf;
   a.sphere_radius = sphere_radius; a.sphere_scale = sphere_scale;
+  a.clamp_n = clamp_n < 0 ? a.src.P : clamp_n;
   static int once = set_lds(sdf_full_kernel, kLdsBytes, "svs_sdf_outputs");
   if (once) return once;
-  sdf_full_kernel<<<(n_points + kWgPts - 1) / kWgPts, kThreads, kLdsBytes, (hipStream_t)hip_stream>>>(a);
+  sdf_full_kernel<<<(a.src.P + kWgPts - 1) / kWgPts, kThreads, kLdsBytes, (hipStream_t)hip_stream>>>(a);
   return check_launch("svs_sdf_outputs");
 }
 
@@ -607,12 +617,12 @@ int svs_tiles_to_rows(const float* tiles, int n_points, float* rows, void* hip_s
   return check_launch("svs_tiles_to_rows");
 }
 
-int svs_rgb_eval(const float* points, const float* cam, int cam_stride, const float* dirs, const float* z, int S,
-                 int n_points, const float* normals, const float* view_dirs, int view_S, const float* feat_tiles,
+int svs_rgb_eval(const float* points, int n_points, const float* cam, int cam_stride, const float* dirs, const float* z,
+                 int S, int n_rays, const float* normals, const float* view_dirs, int view_S, const float* feat_tiles,
                  const float* stream, float* rgb, void* hip_stream) {
   RgbArgs a;
-  if (int rc = fill_src(a.src, points, cam, cam_stride, dirs, z, S, n_points, "svs_rgb_eval")) return rc;
-  if (!normals || !view_dirs || !feat_tiles || !stream || !rgb || view_S < 0 || (view_S > 0 && n_points % view_S)) {
+  if (int rc = fill_src(a.src, points, n_points, cam, cam_stride, dirs, z, S, n_rays, "svs_rgb_eval")) return rc;
+  if (!normals || !view_dirs || !feat_tiles || !stream || !rgb || view_S < 0 || (view_S > 0 && a.src.P % view_S)) {
     set_error("svs_rgb_eval: bad argument"); return SVS_EINVAL;
   }
   a.normals = normals; a.view = view_dirs; a.view_S = view_S; a.feat_tiles = feat_tiles;
@@ -620,7 +630,7 @@ int svs_rgb_eval(const float* points, const float* cam, int cam_stride, const fl
   constexpr int lds = 2 * kRgbBufF4 * 16;
   static int once = set_lds(rgb_kernel, lds, "svs_rgb_eval");
   if (once) return once;
-  rgb_kernel<<<(n_points + kWgPts - 1) / kWgPts, kThreads, lds, (hipStream_t)hip_stream>>>(a);
+  rgb_kernel<<<(a.src.P + kWgPts - 1) / kWgPts, kThreads, lds, (hipStream_t)hip_stream>>>(a);
   return check_launch("svs_rgb_eval");
 }
 

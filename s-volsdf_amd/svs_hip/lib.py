@@ -29,12 +29,13 @@ SIGNATURES = {
     "svs_pack_workspace_bytes": (c_size_t, []),
     "svs_sdf_pack": (c_int, [_PP, _PP, _PP, _P, _P, c_int, _P]),
     "svs_rgb_pack": (c_int, [_PP, _PP, _PP, _P, _P, _P]),
-    "svs_sdf_vals": (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, _P, c_float, c_float, _P, _P, _P]),
+    "svs_sdf_vals": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, _P, c_float, c_float, c_int, _P, _P, _P]),
     "svs_sdf_hbuf_bytes": (c_size_t, [c_int]),
     "svs_feat_tiles_bytes": (c_size_t, [c_int]),
-    "svs_sdf_outputs": (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, _P, c_float, c_float, _P, _P, _P, _P, _P]),
+    "svs_sdf_outputs": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, _P, c_float, c_float, c_int, _P, _P, _P,
+                                _P, _P]),
     "svs_tiles_to_rows": (c_int, [_P, c_int, _P, _P]),
-    "svs_rgb_eval": (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, _P, _P, c_int, _P, _P, _P, _P]),
+    "svs_rgb_eval": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, _P, _P, c_int, _P, _P, _P, _P]),
     "svs_sampler_ctl_bytes": (c_size_t, []),
     "svs_sampler_cap": (c_int, []),
     "svs_sampler_max_new": (c_int, []),
@@ -54,6 +55,7 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    import torch  # noqa: F401  -- first, so that the HIP runtime torch ships is the one this library binds to
     if not os.path.exists(LIB_PATH):
         raise SvsError(f"{LIB_PATH} not found: run `python s-volsdf_amd/build.py` (there is no CPU fallback)")
     lib = ctypes.CDLL(LIB_PATH)

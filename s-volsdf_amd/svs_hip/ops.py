@@ -81,42 +81,45 @@ class PackedMlp:
 
 
 class PointSource:
-    """Where the MLP kernels take sample positions from: explicit points (P,3) or rays cam + z * dir."""
+    """Sample positions of one MLP launch: ray samples cam + z * dir (R*S of them) followed by explicit points.
+    Either part may be absent."""
 
     def __init__(self, points=None, cam=None, dirs=None, z=None):
-        if points is not None:
-            self.points = _f32(points)
-            self.n = self.points.shape[0]
-            self.cam = self.dirs = self.z = None
-            self.S, self.cam_stride = 0, 0
-        else:
-            self.points = None
+        self.points = _f32(points) if points is not None else None
+        self.n_points = self.points.shape[0] if points is not None else 0
+        if z is not None:
             self.cam, self.dirs, self.z = _f32(cam), _f32(dirs), _f32(z)
-            self.S = self.z.shape[1]
-            self.n = self.z.numel()
+            self.n_rays, self.S = self.z.shape
             self.cam_stride = 0 if self.cam.numel() == 3 else 3
+        else:
+            self.cam = self.dirs = self.z = None
+            self.n_rays, self.S, self.cam_stride = 0, 0, 0
+        self.n_ray_points = self.n_rays * self.S
+        self.n = self.n_ray_points + self.n_points
 
     def args(self):
-        return (_ptr(self.points), _ptr(self.cam), self.cam_stride, _ptr(self.dirs), _ptr(self.z), self.S, self.n)
+        return (_ptr(self.points), self.n_points, _ptr(self.cam), self.cam_stride, _ptr(self.dirs), _ptr(self.z),
+                self.S, self.n_rays)
 
     @property
     def device(self):
         return (self.points if self.points is not None else self.z).device
 
 
-def sdf_vals(packed, src, sphere_radius, sphere_scale, out=None, gate=None):
+def sdf_vals(packed, src, sphere_radius, sphere_scale, out=None, gate=None, clamp_n=-1):
     """ImplicitNetwork.get_sdf_vals (network.py:125-131) -> (P,1).  gate: optional device int (skip when 0)."""
     L = _lib.load()
     sdf = out if out is not None else torch.empty(src.n, 1, device=src.device)
     _lib.check(L.svs_sdf_vals(*src.args(), _ptr(packed.sdf_stream), float(sphere_radius), float(sphere_scale),
-                              _ptr(sdf), ctypes.c_void_p(gate) if gate else None, _stream()), "svs_sdf_vals")
+                              int(clamp_n), _ptr(sdf), ctypes.c_void_p(gate) if gate else None, _stream()), "svs_sdf_vals")
     return sdf
 
 
-def sdf_outputs(packed, src, sphere_radius, sphere_scale, want_feature_rows=False):
+def sdf_outputs(packed, src, sphere_radius, sphere_scale, want_feature_rows=False, clamp_n=-1):
     """ImplicitNetwork.get_outputs (network.py:105-123): sdf (P,1), d sdf/dx (P,3), feature tiles, hbuf.
 
-    sphere_radius <= 0 differentiates the raw output (ImplicitNetwork.gradient, :90-103).
+    The sphere clamp (network.py:110-112) applies to the first clamp_n points (-1: all); the others, and all
+    of them when sphere_radius <= 0, differentiate the raw output (ImplicitNetwork.gradient, :90-103).
     """
     L = _lib.load()
     dev = src.device
@@ -125,7 +128,8 @@ def sdf_outputs(packed, src, sphere_radius, sphere_scale, want_feature_rows=Fals
     feat = torch.empty(L.svs_feat_tiles_bytes(src.n) // 4, device=dev)
     hbuf = torch.empty(L.svs_sdf_hbuf_bytes(src.n) // 4, device=dev)
     _lib.check(L.svs_sdf_outputs(*src.args(), _ptr(packed.sdf_stream), float(sphere_radius), float(sphere_scale),
-                                 _ptr(sdf), _ptr(grad), _ptr(feat), _ptr(hbuf), _stream()), "svs_sdf_outputs")
+                                 int(clamp_n), _ptr(sdf), _ptr(grad), _ptr(feat), _ptr(hbuf), _stream()),
+               "svs_sdf_outputs")
     rows = None
     if want_feature_rows:
         rows = torch.empty(src.n, 256, device=dev)
@@ -138,7 +142,7 @@ def rgb_eval(packed, src, normals, view_dirs, feat_tiles):
     view_dirs: (R,3) with src in ray mode (one direction per ray), or (P,3)."""
     L = _lib.load()
     normals, view_dirs = _f32(normals), _f32(view_dirs)
-    view_S = src.S if (src.points is None and view_dirs.shape[0] * src.S == src.n) else 0
+    view_S = src.S if (src.n_points == 0 and view_dirs.shape[0] * src.S == src.n) else 0
     if view_S == 0:
         assert view_dirs.shape[0] == src.n
     rgb = torch.empty(src.n, 3, device=src.device)

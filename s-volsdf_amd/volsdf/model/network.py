@@ -176,9 +176,22 @@ class VolSDFNetwork(nn.Module):
         z_vals, z_samples_eik = self.ray_sampler.get_z_vals(ray_dirs, cam_loc, self, fast=fast,
                                                             iter_step=input.get("iter_step", 1))
         N_samples = z_vals.shape[1]
-        src = ops.PointSource(cam=cam_loc, dirs=ray_dirs, z=z_vals)
-        sdf, gradients, feat_tiles, _, _ = ops.sdf_outputs(pk, src, net.sdf_bounding_sphere, net.sphere_scale)
-        rgb_flat = ops.rgb_eval(pk, src, gradients, ray_dirs, feat_tiles)
+        n_main = num_pixels * N_samples
+        eikonal_points = None
+        if self.training:
+            # eikonal samples (network.py:258-266) ride in the same launch as the ray samples; they
+            # differentiate the raw network output (ImplicitNetwork.gradient), the ray samples the clamped sdf
+            eikonal_points = torch.empty(num_pixels, 3).uniform_(-self.scene_bounding_sphere,
+                                                                 self.scene_bounding_sphere).to(ray_dirs.device)
+            eik_near = cam_loc.view(1, 3) + z_samples_eik * ray_dirs
+            eikonal_points = torch.cat([eikonal_points, eik_near], 0)
+        src = ops.PointSource(points=eikonal_points, cam=cam_loc, dirs=ray_dirs, z=z_vals)
+        sdf, gradients, feat_tiles, _, _ = ops.sdf_outputs(pk, src, net.sdf_bounding_sphere, net.sphere_scale,
+                                                           clamp_n=n_main)
+        grad_theta = gradients[n_main:]
+        sdf, gradients = sdf[:n_main], gradients[:n_main]
+        src_main = ops.PointSource(cam=cam_loc, dirs=ray_dirs, z=z_vals)
+        rgb_flat = ops.rgb_eval(pk, src_main, gradients, ray_dirs, feat_tiles)
         comp = ops.composite(z_vals, sdf, rgb_flat, depth_scale, self.density.beta, float(self.density.beta_min),
                              normals=None if self.training else gradients)
         rgb_values = comp["rgb_values"]
@@ -189,12 +202,7 @@ class VolSDFNetwork(nn.Module):
         output = {'rgb_values': rgb_values, 'depth_values': comp["depth_values"], 'depth_vals': comp["depth_vals"],
                   'weights': comp["weights"], 'xyz': points}
         if self.training:
-            n_eik = num_pixels
-            eikonal_points = torch.empty(n_eik, 3).uniform_(-self.scene_bounding_sphere,
-                                                            self.scene_bounding_sphere).to(ray_dirs.device)
-            eik_near = cam_loc.view(1, 3) + z_samples_eik * ray_dirs
-            eikonal_points = torch.cat([eikonal_points, eik_near], 0)
-            output['grad_theta'] = net.gradient(eikonal_points)
+            output['grad_theta'] = grad_theta
         else:
             output['normal_map'] = comp["normal_map"]
         return output
