@@ -1,0 +1,117 @@
+/* libsvolsdf_hip.so -- C-ABI of the MI355X-native S-VolSDF volume-rendering hot path.
+ *
+ * The reference (cvlab-stonybrook/s-volsdf) is pure Python: it has no FFI of its own, so each entry point
+ * below names the reference function (file:line, relative to the reference root) whose arithmetic it
+ * replaces.  The binding a maintainer adds on the reference side is the ctypes stub shown in INTEGRATION.md
+ * (s-volsdf_amd/svs_hip/lib.py is that stub, s-volsdf_amd/volsdf/ the drop-in classes that call it).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to float32 / int32 data unless stated otherwise; tensors are
+ *     contiguous row-major; `hip_stream` is a hipStream_t (NULL = default stream);
+ *   - calls are asynchronous (stream-ordered); none allocates, frees or synchronises; all outputs and
+ *     workspaces are caller-allocated (size queries: *_bytes);
+ *   - return 0 on success, < 0 for an argument/shape error, > 0 = hipError_t of a failed launch;
+ *     svs_last_error_string() describes the last failure on the calling thread.
+ */
+#ifndef SVOLSDF_HIP_H
+#define SVOLSDF_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int svs_version(void);
+const char* svs_last_error_string(void);
+
+/* ---- a1  rays ---------------------------------------------------------------------------------------
+ * rend_util.get_camera_params + lift (volsdf/utils/rend_util.py:60-95,143-156) and the depth_scale of
+ * VolSDFNetwork.forward (volsdf/model/network.py:213-217).
+ * uv (n_rays,2) pixel (x,y); pose (4,4) camera-to-world; intrinsics (4,4).
+ * -> ray_dirs (n_rays,3) unit, cam_loc (3), depth_scale (n_rays) */
+int svs_rays_from_uv(const float* uv, const float* pose, const float* intrinsics, int n_rays, float* ray_dirs,
+                     float* cam_loc, float* depth_scale, void* hip_stream);
+
+/* ---- a5/a6  weight packing --------------------------------------------------------------------------
+ * Weight-norm materialisation w = g*v/||v|| (nn.utils.weight_norm, volsdf/model/network.py:64-65) and the
+ * permutation into the MFMA consumption order.  weight_v/weight_g/bias: HOST arrays of 9 (SDF) / 5 (radiance)
+ * device pointers in layer order, shapes as in the checkpoint (`implicit_network.lin{l}.weight_v` ...);
+ * weight_g == NULL for networks without weight-norm.  workspace: svs_pack_workspace_bytes().
+ * full != 0 also packs the feature head and the transposed weights used by the input-gradient pass. */
+size_t svs_sdf_stream_bytes(int full);
+size_t svs_rgb_stream_bytes(void);
+size_t svs_pack_workspace_bytes(void);
+int svs_sdf_pack(const float* const* weight_v, const float* const* weight_g, const float* const* bias,
+                 float* workspace, float* stream_out, int full, void* hip_stream);
+int svs_rgb_pack(const float* const* weight_v, const float* const* weight_g, const float* const* bias,
+                 float* workspace, float* stream_out, void* hip_stream);
+
+/* ---- a5  SDF MLP ------------------------------------------------------------------------------------
+ * Sample positions of a launch = the ray samples cam + z*dir (n_rays x S, row-major, may be 0 rays) followed by
+ * n_points explicit points (may be 0).  cam_stride 0 = one camera centre, 3 = one per ray.
+ *
+ * svs_sdf_vals: ImplicitNetwork.get_sdf_vals (volsdf/model/network.py:125-131) -> sdf (P).
+ *   sphere clamp min(sdf, scale*(radius-|x|)) on points [0, clamp_n) (clamp_n < 0: all) when radius > 0.
+ *   gate: optional device int; the launch does nothing when *gate == 0 (sampler rounds). */
+int svs_sdf_vals(const float* points, int n_points, const float* cam, int cam_stride, const float* dirs, const float* z,
+                 int S, int n_rays, const float* stream, float sphere_radius, float sphere_scale, int clamp_n,
+                 float* sdf, const int* gate, void* hip_stream);
+/* svs_sdf_outputs: ImplicitNetwork.get_outputs (network.py:105-123) and .gradient (:90-103):
+ *   sdf (P), grad = d sdf/dx (P,3), feat_tiles (svs_feat_tiles_bytes; wave-tile layout, may be NULL),
+ *   hbuf (svs_sdf_hbuf_bytes): the activations h_1..h_8 kept for the gradient pass / training backward. */
+size_t svs_sdf_hbuf_bytes(int n_points_total);
+size_t svs_feat_tiles_bytes(int n_points_total);
+int svs_sdf_outputs(const float* points, int n_points, const float* cam, int cam_stride, const float* dirs,
+                    const float* z, int S, int n_rays, const float* stream, float sphere_radius, float sphere_scale,
+                    int clamp_n, float* sdf, float* grad, float* feat_tiles, float* hbuf, void* hip_stream);
+/* feature vectors in row-major (P,256), for callers outside the fused pipeline */
+int svs_tiles_to_rows(const float* tiles, int n_points, float* rows, void* hip_stream);
+
+/* ---- a6  radiance MLP -------------------------------------------------------------------------------
+ * RenderingNetwork.forward, mode 'idr' (volsdf/model/network.py:170-190): rgb (P,3) =
+ * sigmoid(MLP(cat[x, PE1(view), normal, feature])).  view_dirs: (n_rays,3) when view_S == S, (P,3) when 0. */
+int svs_rgb_eval(const float* points, int n_points, const float* cam, int cam_stride, const float* dirs, const float* z,
+                 int S, int n_rays, const float* normals, const float* view_dirs, int view_S, const float* feat_tiles,
+                 const float* stream, float* rgb, void* hip_stream);
+
+/* ---- a2/a3/a4  error-bounded sampler ------------------------------------------------------------------
+ * ErrorBoundSampler.get_z_vals / get_error_bound, UniformSampler.get_z_vals
+ * (volsdf/model/ray_sampler.py:22-43, 67-219, 221-229).  One call sequence per batch:
+ *   svs_sampler_init;  for round i < max_iters: svs_sdf_vals(samples -> samples_sdf, gate = ctl.active[i]),
+ *   svs_sampler_round(phase 0), svs_sampler_round(phase 1);   max_iters == 0: svs_sampler_round(phase 2).
+ * Buffers: z, sdf (n_rays, svs_sampler_cap()); samples, samples_sdf (n_rays, svs_sampler_max_new());
+ * beta, far (n_rays); ctl (svs_sampler_ctl_bytes(): int conv_flag[8], active[8], final_round); err_flag (1 int,
+ * set on a bounding-sphere miss).  Random draws (train mode) are inputs: jitter (n_rays,n_eval),
+ * u_final (n_rays,n_final), extra_idx (n_extra int), eik_idx (n_rays int); NULL = eval mode.
+ * beta0 = |*beta_param| + beta_min is read on the device (volsdf/model/density.py:28-30). */
+size_t svs_sampler_ctl_bytes(void);
+int svs_sampler_cap(void);
+int svs_sampler_max_new(void);
+int svs_sampler_init(const float* cam, int cam_stride, const float* dirs, int n_rays, int n_eval, float near_, float far_,
+                     int sphere_far, float sphere_radius, const float* jitter, float inv_4log, int max_iters,
+                     float* samples, float* beta, float* far_out, void* ctl, int* err_flag, void* hip_stream);
+int svs_sampler_round(int phase, int n_rays, int round, int max_iters, int n_eval, int n_final, int n_extra,
+                      const float* beta_param, float beta_min, float eps, int beta_iters, float add_tiny, float near_,
+                      const float* far_, float* z, float* sdf, float* beta, float* samples, const float* samples_sdf,
+                      void* ctl, const float* u_final, const int* extra_idx, const int* eik_idx, float* z_final,
+                      float* z_eik, int* dbg_samples_idx, int* dbg_inds, float* dbg_cdf, float* dbg_weights,
+                      void* hip_stream);
+
+/* ---- a8  alpha compositing ----------------------------------------------------------------------------
+ * VolSDFNetwork.volume_rendering (volsdf/model/network.py:281-295) and the reductions of :237-256,270-276.
+ * z (R,S), sdf (R*S), rgb (R*S,3), normals (R*S,3) or NULL, depth_scale (R) -> weights (R,S), rgb_values (R,3),
+ * depth_values (R), depth_vals (R,S), normal_map (R,3) or NULL. */
+int svs_composite(int n_rays, int n_samples, const float* z, const float* sdf, const float* rgb, const float* normals,
+                  const float* depth_scale, const float* beta_param, float beta_min, float* weights, float* rgb_values,
+                  float* depth_values, float* depth_vals, float* normal_map, void* hip_stream);
+
+/* ---- numeric-contract self tests (used by tests/test_gpu_parity.py) --------------------------------------- */
+int svs_selftest_exp(const float* x, float* y_exp, float* y_expm1, int n, void* hip_stream);
+int svs_selftest_arith(const float* a, const float* b, float* quotient, float* sqrt_abs_a, int n, void* hip_stream);
+int svs_selftest_cumsum(const float* x, float* y, float* total, int rows, int m, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVOLSDF_HIP_H */

@@ -1,0 +1,63 @@
+"""CPU-side checks of the C-ABI: the library builds for gfx950, loads, and exports exactly what
+include/svolsdf_hip.h declares with the argument counts the ctypes table uses (no compute calls)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("svs_build", os.path.join(ROOT, "s-volsdf_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.build(verbose=False)
+    from svs_hip import lib as L
+    return L
+
+
+def _header_decls():
+    src = open(os.path.join(ROOT, "include", "svolsdf_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    decls = {}
+    for m in re.finditer(r"\b(?:int|size_t|const char\*)\s+(svs_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        args = m.group(2).strip()
+        decls[m.group(1)] = 0 if args in ("void", "") else len([a for a in args.split(",") if a.strip()])
+    return decls
+
+
+def test_header_matches_library_and_ctypes_table(lib):
+    decls = _header_decls()
+    L = lib.load()
+    assert set(decls) == set(lib.SIGNATURES), set(decls) ^ set(lib.SIGNATURES)
+    for name, nargs in decls.items():
+        assert hasattr(L, name), f"{name} declared in the header but not exported"
+        assert len(lib.SIGNATURES[name][1]) == nargs, name
+    assert L.svs_version() >= 100
+
+
+def test_size_queries(lib):
+    L = lib.load()
+    assert L.svs_sdf_stream_bytes(1) > L.svs_sdf_stream_bytes(0) > 1 << 20
+    assert L.svs_rgb_stream_bytes() > 1 << 20
+    assert L.svs_sampler_cap() >= 640 and L.svs_sampler_max_new() == 128
+    assert L.svs_sdf_hbuf_bytes(128) == 4 * 8 * 128 * 64 * 4
+    assert L.svs_feat_tiles_bytes(129) == 8 * 128 * 64 * 4
+
+
+def test_argument_errors_are_reported(lib):
+    L = lib.load()
+    rc = L.svs_rays_from_uv(None, None, None, 0, None, None, None, None)
+    assert rc < 0 and b"svs_rays_from_uv" in L.svs_last_error_string()
+    rc = L.svs_composite(4, 1000, None, None, None, None, None, None, 0.0, None, None, None, None, None, None)
+    assert rc < 0
+
+
+def test_missing_library_fails_loudly(lib, monkeypatch):
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libsvolsdf_hip.so")
+    with pytest.raises(lib.SvsError):
+        lib.load()
