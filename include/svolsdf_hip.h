@@ -106,6 +106,28 @@ int svs_composite(int n_rays, int n_samples, const float* z, const float* sdf, c
                   const float* depth_scale, const float* beta_param, float beta_min, float* weights, float* rgb_values,
                   float* depth_values, float* depth_vals, float* normal_map, void* hip_stream);
 
+/* ---- a10  MVS prior lookup ----------------------------------------------------------------------------
+ * VolOpt.cost_mapping (volsdf/vsdf.py:382-452).  Points: xyz (n_points,3) or, when xyz == NULL, cam + z*dir with
+ * z (n_points/S, S).  view_params: HOST float array, 17 per view: fx, fy, cx, cy, sk, c2w rows (3x4).
+ * cost / z_near / z_far: HOST arrays of device pointers per view: probability volume (D,H,W), depth hypotheses
+ * [0] and [-1] (H,W); dims: HOST int array D,H,W per view.  same_view: index of the rendered view (-> pi).
+ * img_w, img_h: SceneDataset resolution used for the normalisation (vsdf.py:397,414-415).
+ * -> pj (n_points), pi (n_points), valid (n_points, uint8) */
+int svs_cost_lookup(const float* xyz, const float* cam, const float* dirs, const float* z, int S, int n_points,
+                    int n_views, int same_view, int inverse_depth, float img_w, float img_h, const float* view_params,
+                    const float* const* cost, const float* const* z_near, const float* const* z_far, const int* dims,
+                    float* pj, float* pi, unsigned char* valid, void* hip_stream);
+
+/* ---- a11  loss ----------------------------------------------------------------------------------------
+ * VolSDFLoss.forward (volsdf/model/loss.py:80-114) and the gradient of the total w.r.t. the model outputs.
+ * rgb_target = ground_truth['rgb'], or 'rgb_smooth' with annealed = 1 (loss.py:103-105); pi/pj NULL = no MVS terms.
+ * losses[5] = rgb, eikonal, mvs, sparse, total. */
+int svs_loss(int n_rays, int n_samples, int n_eik, const float* rgb_values, const float* rgb_target,
+             const float* grad_theta, const float* weights, const float* pi, const float* pj, const float* depth_values,
+             float rgb_weight, float eikonal_weight, float mvs_weight, float sparse_weight, float gce, float confi,
+             int annealed, float anneal_sparse, float* losses, float* d_rgb_values, float* d_grad_theta,
+             float* d_weights, float* d_depth_values, void* hip_stream);
+
 /* ---- numeric-contract self tests (used by tests/test_gpu_parity.py) --------------------------------------- */
 int svs_selftest_exp(const float* x, float* y_exp, float* y_expm1, int n, void* hip_stream);
 int svs_selftest_arith(const float* a, const float* b, float* quotient, float* sqrt_abs_a, int n, void* hip_stream);

@@ -681,3 +681,129 @@ def render_forward(params, uv, pose, K, *, beta_param, fast=-1, training=False, 
         eik = np.concatenate([eik_uniform, eik_near], 0)
         out["grad_theta"] = sdf_outputs(sdf_layers, eik, scene_bounding_sphere, sphere_scale, clamp=False)[2]
     return out
+
+
+# ----------------------------------------------------------------------------------------
+# a10  MVS prior lookup     volsdf/vsdf.py:382-452 (VolOpt.cost_mapping)
+# ----------------------------------------------------------------------------------------
+def _grid_sample_zeros(vol, coords):
+    """F.grid_sample(mode='bilinear', padding_mode='zeros', align_corners=True) for one channel.
+    vol: (H,W) or (D,H,W); coords: (...,2) as (x,y) or (...,3) as (x,y,z), normalised to [-1,1]."""
+    nd = vol.ndim
+    sizes = vol.shape[::-1]                       # (W,H[,D]) matches coord order x,y[,z]
+    pix = [((coords[..., a] + F32(1.0)) / F32(2.0) * F32(sizes[a] - 1)).astype(F32) for a in range(nd)]
+    base = [np.floor(p) for p in pix]
+    frac = [(p - b).astype(F32) for p, b in zip(pix, base)]
+    out = np.zeros(coords.shape[:-1], F32)
+    for corner in range(1 << nd):
+        w = np.ones(coords.shape[:-1], F32)
+        idx = []
+        ok = np.ones(coords.shape[:-1], bool)
+        for a in range(nd):
+            hi = (corner >> a) & 1
+            ia = base[a] + hi
+            w = (w * (frac[a] if hi else (F32(1.0) - frac[a]))).astype(F32)
+            ok &= (ia >= 0) & (ia <= sizes[a] - 1)
+            idx.append(np.clip(np.nan_to_num(ia, nan=0.0, posinf=0.0, neginf=0.0), 0, sizes[a] - 1).astype(np.int64))
+        vals = vol[tuple(idx[::-1])]
+        out += np.where(ok, w * vals, F32(0.0)).astype(F32)
+    return out
+
+
+def cost_mapping(xyz, view_index, views, img_res, inverse_depth=False):
+    """VolOpt.cost_mapping, vsdf.py:382-452.
+
+    xyz (R,S,3) world points; view_index: which entry of `views` the batch was rendered from;
+    views: list of dicts(K (4,4), c2w (4,4), cost (D,Hc,Wc) probability volume, z_mvs (D,Hc,Wc) depth hypotheses);
+    img_res (H,W) of the SceneDataset.  Returns pj (R,S), pi (R,S), valid (R,S) bool.
+    """
+    R, S, _ = xyz.shape
+    _h, _w = img_res
+    pj = np.zeros((R, S), F32)
+    pi = np.zeros((R, S), F32)
+    valid = np.zeros((R, S), bool)
+    with np.errstate(all="ignore"):
+        for i, v in enumerate(views):
+            K, c2w = np.asarray(v["K"], F32), np.asarray(v["c2w"], F32)[:3]
+            fx, fy, cx, cy, sk = K[0, 0], K[1, 1], K[0, 2], K[1, 2], K[0, 1]
+            p = (xyz - c2w[:, 3].reshape(1, 1, 3)).astype(F32)
+            p = (p @ c2w[:, :3]).astype(F32)
+            z = p[..., 2]
+            x = (p[..., 0] / z).astype(F32)
+            y = (p[..., 1] / z).astype(F32)
+            y = (y * fy + cy).astype(F32)
+            x = (x * fx + cx + (y - cy) * sk / fy).astype(F32)
+            x = (x / F32((_w - 1) / 2) - F32(1.0)).astype(F32)
+            y = (y / F32((_h - 1) / 2) - F32(1.0)).astype(F32)
+            inval = (z < 1e-5) | (x > 1.001) | (x < -1.001) | (y > 1.001) | (y < -1.001)
+            x = np.where(inval, F32(-99.0), x)
+            y = np.where(inval, F32(-99.0), y)
+            z = np.where(inval, F32(-99.0), z)
+            xy = np.stack([x, y], -1)
+            near = _grid_sample_zeros(np.asarray(v["z_mvs"][0], F32), xy)
+            far = _grid_sample_zeros(np.asarray(v["z_mvs"][-1], F32), xy)
+            if inverse_depth:
+                far = np.where(inval, F32(1e-8), far)
+                zn = (F32(2.0) * (F32(1.0) - near / z) / (F32(1.0) - near / far) - F32(1.0)).astype(F32)
+            else:
+                zn = (F32(2.0) * (z - near) / (far - near) - F32(1.0)).astype(F32)
+            inval = (near < 1e-5) | (far < 1e-5) | (zn > 1.01) | (zn < -1.01) | inval
+            x = np.where(inval, F32(-99.0), x)
+            y = np.where(inval, F32(-99.0), y)
+            zn = np.where(inval, F32(-99.0), zn)
+            cost = _grid_sample_zeros(np.asarray(v["cost"], F32), np.stack([x, y, zn], -1))
+            if i == view_index:
+                pi = cost
+            else:
+                pj = (pj + cost).astype(F32)
+                valid |= ~inval
+    pi = np.where(valid, pi, F32(0.0)).astype(F32)
+    return pj, pi, valid
+
+
+# ----------------------------------------------------------------------------------------
+# a11  loss     volsdf/model/loss.py:80-114 (VolSDFLoss.forward)
+# ----------------------------------------------------------------------------------------
+def volsdf_loss(out, rgb_gt, rgb_smooth, iter_step, *, eikonal_weight=0.1, rgb_weight=1.0, mvs_weight=1.0,
+                sparse_weight=1.0, anneal_rgb=200, gce=0.5, confi=1e-3):
+    """Returns dict(rgb_loss, eikonal_loss, mvs_loss, sparse_loss, loss) as float32 scalars.
+    out: dict with rgb_values (R,3), grad_theta (2R,3) [optional], weights, pi, pj (R,S) [optional], depth_values (R,1)."""
+    res = {}
+    rgb_gt = np.asarray(rgb_gt, F32).reshape(-1, 3)
+    res["rgb_loss"] = np.abs(out["rgb_values"] - rgb_gt).mean(dtype=F64).astype(F32)
+    if "grad_theta" in out:
+        nrm = np.sqrt((out["grad_theta"].astype(F64) ** 2).sum(1))
+        res["eikonal_loss"] = (((nrm - 1.0) ** 2).mean()).astype(F32)
+    else:
+        res["eikonal_loss"] = F32(0.0)
+    has_mvs = "pi" in out
+    if has_mvs and mvs_weight > 0:
+        pw = (out["pi"] * out["pj"]).astype(F64)
+        w = out["weights"].astype(F64)
+        if gce == 1:
+            l = -pw * w
+        elif gce == 0:
+            l = -pw * np.log(w + 1e-8)
+        else:
+            l = -pw * w ** gce * np.log(w + 1e-8)
+        l = l.sum(1) * (pw.sum(1) > confi)
+        res["mvs_loss"] = l.mean().astype(F32)
+    else:
+        res["mvs_loss"] = F32(0.0)
+    anneal_on = sparse_weight > 0 and anneal_rgb > 0 and iter_step < anneal_rgb
+    if has_mvs and anneal_on:
+        conf = (out["pi"] * out["pj"]).astype(F64).sum(-1)
+        dep = out.get("depth_values_all", out["depth_values"]).astype(F64).reshape(-1)
+        res["sparse_loss"] = ((1.0 / (dep + 1e-3)) * (conf < confi)).mean().astype(F32)
+    else:
+        res["sparse_loss"] = F32(0.0)
+    anneal_sparse = 0.0
+    if anneal_on:
+        t = iter_step / anneal_rgb
+        anneal_sparse = 0.0 if t >= 1 else (1.0 if t <= 0 else 1.0 + (0.0 - 1.0) * min(t, 1.0))
+        conf = (out["pi"] * out["pj"]).astype(F64).sum(-1)
+        l = np.abs(out["rgb_values"] - np.asarray(rgb_smooth, F32).reshape(-1, 3)).astype(F64).mean(-1)
+        res["rgb_loss"] = (l * (conf < 1e-8)).mean().astype(F32)
+    res["loss"] = F32(rgb_weight * res["rgb_loss"] + eikonal_weight * res["eikonal_loss"] +
+                      mvs_weight * res["mvs_loss"] + sparse_weight * anneal_sparse * res["sparse_loss"])
+    return res

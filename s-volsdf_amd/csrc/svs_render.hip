@@ -121,6 +121,198 @@ __global__ __launch_bounds__(64) void composite_kernel(CompositeArgs a) {
   }
 }
 
+// ---- a10: MVS prior lookup (VolOpt.cost_mapping, volsdf/vsdf.py:382-452) --------------------------------
+struct LookupView {
+  float fx, fy, cx, cy, sk;
+  float c2w[12];            // rows of the 3x4 camera-to-world matrix
+  const float* cost;        // probability volume (D,H,W)
+  const float* z_near;      // depth hypotheses[0]   (H,W)
+  const float* z_far;       // depth hypotheses[-1]  (H,W)
+  int D, H, W;
+};
+constexpr int kMaxViews = 4;
+struct LookupArgs {
+  const float* xyz;         // (P,3) explicit world points, or nullptr -> cam + z*dir
+  const float* cam; const float* dirs; const float* z; int S;
+  int P, n_views, same_view, inverse_depth;
+  float half_w, half_h;     // (W_img-1)/2, (H_img-1)/2 of the SceneDataset resolution (vsdf.py:397,414-415)
+  LookupView v[kMaxViews];
+  float* pj; float* pi; unsigned char* valid;
+};
+
+// F.grid_sample(bilinear, zeros, align_corners=True), one channel
+__device__ __forceinline__ float sample2d(const float* __restrict__ img, int H, int W, float gx, float gy) {
+  const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1), iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
+  const float fx0 = __builtin_floorf(ix), fy0 = __builtin_floorf(iy);
+  const float tx = ix - fx0, ty = iy - fy0;
+  float acc = 0.0f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float xx = fx0 + (float)(c & 1), yy = fy0 + (float)(c >> 1);
+    if (xx >= 0.0f && xx <= (float)(W - 1) && yy >= 0.0f && yy <= (float)(H - 1)) {
+      const float w = ((c & 1) ? tx : 1.0f - tx) * ((c >> 1) ? ty : 1.0f - ty);
+      acc += w * img[(int)yy * W + (int)xx];
+    }
+  }
+  return acc;
+}
+__device__ __forceinline__ float sample3d(const float* __restrict__ vol, int D, int H, int W, float gx, float gy, float gz) {
+  const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1), iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1),
+              iz = ((gz + 1.0f) / 2.0f) * (float)(D - 1);
+  const float fx0 = __builtin_floorf(ix), fy0 = __builtin_floorf(iy), fz0 = __builtin_floorf(iz);
+  const float tx = ix - fx0, ty = iy - fy0, tz = iz - fz0;
+  float acc = 0.0f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const float xx = fx0 + (float)(c & 1), yy = fy0 + (float)((c >> 1) & 1), zz = fz0 + (float)(c >> 2);
+    if (xx >= 0.0f && xx <= (float)(W - 1) && yy >= 0.0f && yy <= (float)(H - 1) && zz >= 0.0f && zz <= (float)(D - 1)) {
+      const float w = (((c & 1) ? tx : 1.0f - tx) * (((c >> 1) & 1) ? ty : 1.0f - ty)) * ((c >> 2) ? tz : 1.0f - tz);
+      acc += w * vol[((size_t)(int)zz * H + (int)yy) * W + (int)xx];
+    }
+  }
+  return acc;
+}
+
+__global__ void cost_lookup_kernel(LookupArgs a) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= a.P) return;
+  float X, Y, Z;
+  if (a.xyz) { X = a.xyz[3 * p]; Y = a.xyz[3 * p + 1]; Z = a.xyz[3 * p + 2]; }
+  else {
+    const int r = p / a.S;
+    const float zz = a.z[p];
+    X = a.cam[0] + zz * a.dirs[3 * r]; Y = a.cam[1] + zz * a.dirs[3 * r + 1]; Z = a.cam[2] + zz * a.dirs[3 * r + 2];
+  }
+  float pj = 0.0f, pi = 0.0f;
+  bool valid = false;
+  for (int j = 0; j < a.n_views; ++j) {
+    const LookupView& v = a.v[j];
+    // xyz_j = (xyz - t) @ R   (row vector times the c2w rotation = world -> camera), vsdf.py:402-403
+    const float dx = X - v.c2w[3], dy = Y - v.c2w[7], dz = Z - v.c2w[11];
+    const float px = (dx * v.c2w[0] + dy * v.c2w[4]) + dz * v.c2w[8];
+    const float py = (dx * v.c2w[1] + dy * v.c2w[5]) + dz * v.c2w[9];
+    float pz = (dx * v.c2w[2] + dy * v.c2w[6]) + dz * v.c2w[10];
+    float y = (py / pz) * v.fy + v.cy;
+    float x = ((px / pz) * v.fx + v.cx) + ((y - v.cy) * v.sk) / v.fy;
+    x = x / a.half_w - 1.0f;
+    y = y / a.half_h - 1.0f;
+    bool inval = (pz < 1e-5f) || (x > 1.001f) || (x < -1.001f) || (y > 1.001f) || (y < -1.001f);
+    if (inval) { x = -99.0f; y = -99.0f; pz = -99.0f; }
+    const float nearv = sample2d(v.z_near, v.H, v.W, x, y);
+    float farv = sample2d(v.z_far, v.H, v.W, x, y);
+    float zn;
+    if (a.inverse_depth) {
+      if (inval) farv = 1e-8f;
+      zn = (2.0f * (1.0f - nearv / pz)) / (1.0f - nearv / farv) - 1.0f;
+    } else {
+      zn = (2.0f * (pz - nearv)) / (farv - nearv) - 1.0f;
+    }
+    inval = (nearv < 1e-5f) || (farv < 1e-5f) || (zn > 1.01f) || (zn < -1.01f) || inval;
+    if (inval) { x = -99.0f; y = -99.0f; zn = -99.0f; }
+    const float c = sample3d(v.cost, v.D, v.H, v.W, x, y, zn);
+    if (j == a.same_view) pi = c;
+    else { pj += c; valid = valid || !inval; }
+  }
+  a.pj[p] = pj;
+  a.pi[p] = valid ? pi : 0.0f;
+  a.valid[p] = valid ? 1 : 0;
+}
+
+// ---- a11: VolSDFLoss.forward (volsdf/model/loss.py:80-114) + its gradient w.r.t. the model outputs ---------
+struct LossArgs {
+  int R, S, n_eik;
+  const float* rgb_values;   // (R,3)
+  const float* rgb_gt;       // (R,3) the target of the rgb term (rgb, or rgb_smooth in the annealed phase)
+  const float* grad_theta;   // (n_eik,3) or nullptr
+  const float* weights;      // (R,S)
+  const float* pi; const float* pj;   // (R,S) or nullptr
+  const float* depth_values; // (R)
+  float rgb_weight, eikonal_weight, mvs_weight, sparse_weight;
+  float gce, confi, anneal_sparse;    // anneal_sparse > 0 <=> annealed phase (masked rgb + sparse term)
+  int annealed;
+  float* losses;             // out[5]: rgb, eikonal, mvs, sparse, total
+  float* d_rgb_values;       // (R,3)   d total / d rgb_values
+  float* d_grad_theta;       // (n_eik,3)
+  float* d_weights;          // (R,S)
+  float* d_depth_values;     // (R)
+};
+
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int i = 0; i < nw; ++i) t += sh[i];
+  return t;
+}
+
+__global__ __launch_bounds__(1024) void loss_kernel(LossArgs a) {
+  __shared__ double sh[16];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const bool has_mvs = a.pi != nullptr;
+  double s_rgb = 0.0, s_eik = 0.0, s_mvs = 0.0, s_sparse = 0.0;
+  for (int r = tid; r < a.R; r += nt) {
+    double conf = 0.0, lm = 0.0;
+    if (has_mvs) {
+      for (int s = 0; s < a.S; ++s) {
+        const size_t p = (size_t)r * a.S + s;
+        const float pw = a.pi[p] * a.pj[p];
+        const float w = a.weights[p];
+        conf += (double)pw;
+        float l, dl;
+        if (a.gce == 1.0f) { l = -pw * w; dl = -pw; }
+        else if (a.gce == 0.0f) { l = -pw * __logf(w + 1e-8f); dl = -pw / (w + 1e-8f); }
+        else { const float wq = __powf(w, a.gce); l = (-pw * wq) * __logf(w + 1e-8f); dl = (-pw * wq) / (w + 1e-8f); }
+        lm += (double)l;
+        a.d_weights[p] = dl;           // scaled below once the ray's mask is known
+      }
+    }
+    const bool mvs_on = has_mvs && a.mvs_weight > 0.0f && conf > (double)a.confi;
+    if (has_mvs) {
+      const float sc = mvs_on ? a.mvs_weight / (float)a.R : 0.0f;
+      for (int s = 0; s < a.S; ++s) a.d_weights[(size_t)r * a.S + s] *= sc;
+    } else {
+      for (int s = 0; s < a.S; ++s) a.d_weights[(size_t)r * a.S + s] = 0.0f;
+    }
+    if (mvs_on) s_mvs += lm;
+    // rgb term
+    const bool masked = a.annealed && has_mvs;
+    const bool rgb_on = !masked || conf < 1e-8;
+    double l1 = 0.0;
+    for (int c = 0; c < 3; ++c) {
+      const float d = a.rgb_values[3 * r + c] - a.rgb_gt[3 * r + c];
+      l1 += (double)__builtin_fabsf(d);
+      const float sg = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+      a.d_rgb_values[3 * r + c] = rgb_on ? a.rgb_weight * sg / (3.0f * (float)a.R) : 0.0f;
+    }
+    if (rgb_on) s_rgb += l1 / 3.0;
+    // sparsity term (annealed phase only)
+    float dd = 0.0f;
+    if (masked && conf < (double)a.confi) {
+      const float dep = a.depth_values[r] + 1e-3f;
+      s_sparse += 1.0 / (double)dep;
+      dd = -(a.sparse_weight * a.anneal_sparse) / (dep * dep) / (float)a.R;
+    }
+    a.d_depth_values[r] = dd;
+  }
+  for (int i = tid; i < a.n_eik; i += nt) {
+    const float g0 = a.grad_theta[3 * i], g1 = a.grad_theta[3 * i + 1], g2 = a.grad_theta[3 * i + 2];
+    const float n = __builtin_sqrtf((g0 * g0 + g1 * g1) + g2 * g2);
+    s_eik += (double)(n - 1.0f) * (double)(n - 1.0f);
+    const float k = n > 0.0f ? a.eikonal_weight * 2.0f * (n - 1.0f) / (n * (float)a.n_eik) : 0.0f;
+    a.d_grad_theta[3 * i] = k * g0; a.d_grad_theta[3 * i + 1] = k * g1; a.d_grad_theta[3 * i + 2] = k * g2;
+  }
+  s_rgb = block_sum(s_rgb, sh); s_eik = block_sum(s_eik, sh); s_mvs = block_sum(s_mvs, sh); s_sparse = block_sum(s_sparse, sh);
+  if (tid == 0) {
+    const float rgb = (float)(s_rgb / a.R), eik = a.n_eik ? (float)(s_eik / a.n_eik) : 0.0f;
+    const float mvs = (float)(s_mvs / a.R), sp = (float)(s_sparse / a.R);
+    a.losses[0] = rgb; a.losses[1] = eik; a.losses[2] = mvs; a.losses[3] = sp;
+    a.losses[4] = a.rgb_weight * rgb + a.eikonal_weight * eik + a.mvs_weight * mvs + (a.sparse_weight * a.anneal_sparse) * sp;
+  }
+}
+
 }  // namespace render
 }  // namespace svs
 
@@ -152,6 +344,47 @@ int svs_composite(int n_rays, int n_samples, const float* z, const float* sdf, c
                   depth_values, depth_vals, normal_map};
   composite_kernel<<<n_rays, 64, 0, (hipStream_t)hip_stream>>>(a);
   return check_launch("svs_composite");
+}
+
+int svs_cost_lookup(const float* xyz, const float* cam, const float* dirs, const float* z, int S, int n_points,
+                    int n_views, int same_view, int inverse_depth, float img_w, float img_h, const float* view_params,
+                    const float* const* cost, const float* const* z_near, const float* const* z_far, const int* dims,
+                    float* pj, float* pi, unsigned char* valid, void* hip_stream) {
+  if ((!xyz && !(cam && dirs && z && S > 0)) || !view_params || !cost || !z_near || !z_far || !dims || !pj || !pi ||
+      !valid || n_points <= 0) { set_error("svs_cost_lookup: null/invalid argument"); return SVS_EINVAL; }
+  if (n_views < 1 || n_views > kMaxViews) { set_error("svs_cost_lookup: 1..%d views", kMaxViews); return SVS_ESHAPE; }
+  LookupArgs a;
+  a.xyz = xyz; a.cam = cam; a.dirs = dirs; a.z = z; a.S = S > 0 ? S : 1; a.P = n_points; a.n_views = n_views;
+  a.same_view = same_view; a.inverse_depth = inverse_depth;
+  a.half_w = (img_w - 1.0f) / 2.0f; a.half_h = (img_h - 1.0f) / 2.0f;
+  for (int j = 0; j < n_views; ++j) {
+    const float* vp = view_params + 17 * j;   // HOST array: fx, fy, cx, cy, sk, c2w[12]
+    a.v[j].fx = vp[0]; a.v[j].fy = vp[1]; a.v[j].cx = vp[2]; a.v[j].cy = vp[3]; a.v[j].sk = vp[4];
+    for (int k = 0; k < 12; ++k) a.v[j].c2w[k] = vp[5 + k];
+    a.v[j].cost = cost[j]; a.v[j].z_near = z_near[j]; a.v[j].z_far = z_far[j];
+    a.v[j].D = dims[3 * j]; a.v[j].H = dims[3 * j + 1]; a.v[j].W = dims[3 * j + 2];
+    if (!a.v[j].cost || !a.v[j].z_near || !a.v[j].z_far || a.v[j].D < 1 || a.v[j].H < 1 || a.v[j].W < 1) {
+      set_error("svs_cost_lookup: bad view %d", j); return SVS_EINVAL;
+    }
+  }
+  cost_lookup_kernel<<<(n_points + 255) / 256, 256, 0, (hipStream_t)hip_stream>>>(a);
+  return check_launch("svs_cost_lookup");
+}
+
+int svs_loss(int n_rays, int n_samples, int n_eik, const float* rgb_values, const float* rgb_target,
+             const float* grad_theta, const float* weights, const float* pi, const float* pj, const float* depth_values,
+             float rgb_weight, float eikonal_weight, float mvs_weight, float sparse_weight, float gce, float confi,
+             int annealed, float anneal_sparse, float* losses, float* d_rgb_values, float* d_grad_theta,
+             float* d_weights, float* d_depth_values, void* hip_stream) {
+  if (!rgb_values || !rgb_target || !weights || !depth_values || !losses || !d_rgb_values || !d_weights ||
+      !d_depth_values || n_rays <= 0 || n_samples <= 0 || (n_eik > 0 && (!grad_theta || !d_grad_theta)) || (!pi != !pj)) {
+    set_error("svs_loss: null/invalid argument"); return SVS_EINVAL;
+  }
+  LossArgs a{n_rays, n_samples, n_eik, rgb_values, rgb_target, grad_theta, weights, pi, pj, depth_values, rgb_weight,
+             eikonal_weight, mvs_weight, sparse_weight, gce, confi, anneal_sparse, annealed, losses, d_rgb_values,
+             d_grad_theta, d_weights, d_depth_values};
+  loss_kernel<<<1, 1024, 0, (hipStream_t)hip_stream>>>(a);
+  return check_launch("svs_loss");
 }
 
 }  // extern "C"

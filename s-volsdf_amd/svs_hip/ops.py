@@ -172,6 +172,76 @@ def composite(z, sdf, rgb, depth_scale, beta_param, beta_min, normals=None):
                 normal_map=normal_map)
 
 
+def cost_lookup(views, same_view, img_res, *, xyz=None, cam=None, dirs=None, z=None, inverse_depth=False):
+    """VolOpt.cost_mapping (volsdf/vsdf.py:382-452).
+
+    views: list of dict(K (4,4) host/any tensor, c2w (4,4), cost (D,H,W) device, z_mvs (D,H,W) device or
+    (z_near, z_far) (H,W) device).  Points: xyz (R,S,3), or cam (3,), dirs (R,3), z (R,S).
+    Returns pj (R,S), pi (R,S), valid (R,S) bool.
+    """
+    L = _lib.load()
+    if xyz is not None:
+        xyz = _f32(xyz)
+        R, S = xyz.shape[:2]
+        dev = xyz.device
+    else:
+        cam, dirs, z = _f32(cam).reshape(3), _f32(dirs), _f32(z)
+        R, S = z.shape
+        dev = z.device
+    V = len(views)
+    vp = (ctypes.c_float * (17 * V))()
+    dims = (ctypes.c_int * (3 * V))()
+    keep, cost_p, near_p, far_p = [], [], [], []
+    for j, v in enumerate(views):
+        K = torch.as_tensor(v["K"], dtype=torch.float32).cpu()
+        c2w = torch.as_tensor(v["c2w"], dtype=torch.float32).cpu()
+        vals = [K[0, 0], K[1, 1], K[0, 2], K[1, 2], K[0, 1]] + [c2w[i, k] for i in range(3) for k in range(4)]
+        for k, x in enumerate(vals):
+            vp[17 * j + k] = float(x)
+        cost = _f32(v["cost"]).reshape(v["cost"].shape[-3:])
+        if "z_mvs" in v:
+            zm = v["z_mvs"].reshape(v["z_mvs"].shape[-3:])
+            zn, zf = _f32(zm[0]), _f32(zm[-1])
+        else:
+            zn, zf = _f32(v["z_near"]), _f32(v["z_far"])
+        keep += [cost, zn, zf]
+        cost_p.append(cost); near_p.append(zn); far_p.append(zf)
+        dims[3 * j], dims[3 * j + 1], dims[3 * j + 2] = cost.shape
+    pj = torch.empty(R, S, device=dev)
+    pi = torch.empty(R, S, device=dev)
+    valid = torch.empty(R, S, dtype=torch.uint8, device=dev)
+    _lib.check(L.svs_cost_lookup(_ptr(xyz), _ptr(cam), _ptr(dirs), _ptr(z), S, R * S, V, int(same_view),
+                                 int(bool(inverse_depth)), float(img_res[1]), float(img_res[0]), vp,
+                                 _ptr_array(cost_p), _ptr_array(near_p), _ptr_array(far_p), dims, _ptr(pj), _ptr(pi),
+                                 _ptr(valid), _stream()), "svs_cost_lookup")
+    return pj, pi, valid.bool()
+
+
+def loss_fwd_bwd(rgb_values, rgb_target, weights, depth_values, grad_theta=None, pi=None, pj=None, *, rgb_weight=1.0,
+                 eikonal_weight=0.1, mvs_weight=0.0, sparse_weight=0.0, gce=1.0, confi=0.0, annealed=False,
+                 anneal_sparse=0.0):
+    """VolSDFLoss.forward (volsdf/model/loss.py:80-114) and d(total)/d(model outputs) in one launch.
+    Returns (losses[5] = rgb, eikonal, mvs, sparse, total; dict of gradients)."""
+    L = _lib.load()
+    rgb_values, rgb_target = _f32(rgb_values).reshape(-1, 3), _f32(rgb_target).reshape(-1, 3)
+    weights, depth_values = _f32(weights), _f32(depth_values).reshape(-1)
+    R, S = weights.shape
+    dev = weights.device
+    gt = _f32(grad_theta) if grad_theta is not None else None
+    n_eik = gt.shape[0] if gt is not None else 0
+    pi_, pj_ = (_f32(pi), _f32(pj)) if pi is not None else (None, None)
+    losses = torch.empty(5, device=dev)
+    d_rgb = torch.empty(R, 3, device=dev)
+    d_gt = torch.empty(n_eik, 3, device=dev) if n_eik else None
+    d_w = torch.empty(R, S, device=dev)
+    d_dep = torch.empty(R, 1, device=dev)
+    _lib.check(L.svs_loss(R, S, n_eik, _ptr(rgb_values), _ptr(rgb_target), _ptr(gt), _ptr(weights), _ptr(pi_), _ptr(pj_),
+                          _ptr(depth_values), float(rgb_weight), float(eikonal_weight), float(mvs_weight),
+                          float(sparse_weight), float(gce), float(confi), int(bool(annealed)), float(anneal_sparse),
+                          _ptr(losses), _ptr(d_rgb), _ptr(d_gt), _ptr(d_w), _ptr(d_dep), _stream()), "svs_loss")
+    return losses, dict(rgb_values=d_rgb, grad_theta=d_gt, weights=d_w, depth_values=d_dep)
+
+
 class SamplerWorkspace:
     """Device buffers of the error-bounded sampler for R rays (allocated once, reused every step)."""
 

@@ -266,8 +266,53 @@ def fx_forward():
          **{k: v.detach().numpy() for k, v in out.items()})
 
 
+def fx_cost_mapping():
+    from volsdf.vsdf import VolOpt
+    rng = np.random.default_rng(21)
+    R, S = 24, 98
+    views = synth.make_mvs_views(5)
+    K, pose = views[0]["K"], views[0]["c2w"]
+    import oracle_path  # noqa
+    from svs_oracle import rays_from_uv
+    uv = synth.make_uv(R, seed=8, margin=0.02)
+    dirs, cam, _ = rays_from_uv(uv, pose, K)
+    z = np.sort(rng.uniform(0.2, 5.5, (R, S)), -1).astype(F32)
+    xyz = (cam[None, None] + z[:, :, None] * dirs[:, None, :]).astype(F32)
+    ids = [25, 22, 28]
+    for inv in (False, True):
+        for vi in (0, 2):
+            ds = SimpleNamespace(img_res=[576, 768], intrinsics_all={ids[j]: T(views[j]["K"]) for j in range(3)},
+                                 pose_all={ids[j]: T(views[j]["c2w"]) for j in range(3)})
+            me = SimpleNamespace(trains_i=ids, costs={j: T(views[j]["cost"])[None] for j in range(3)},
+                                 z_mvs={j: T(views[j]["z_mvs"])[None] for j in range(3)}, train_dataset=ds,
+                                 hparams=SimpleNamespace(inverse_depth=inv), stg=0)
+            pj, pi, valid = VolOpt.cost_mapping(me, z_vals=T(z), ts=torch.tensor([ids[vi]]), xyz_raw=T(xyz))
+            save(f"cost_mapping_inv{int(inv)}_v{vi}", xyz=xyz, view_index=vi, inverse_depth=inv, seed=5,
+                 pj=pj.numpy(), pi=pi.numpy(), valid=valid.numpy())
+
+
+def fx_loss():
+    from volsdf.model.loss import VolSDFLoss
+    rng = np.random.default_rng(31)
+    R, S = 32, 98
+    out = dict(rgb_values=rng.uniform(0, 1, (R, 3)).astype(F32), grad_theta=rng.normal(0, 1, (2 * R, 3)).astype(F32),
+               weights=(rng.uniform(0, 1, (R, S)) ** 4).astype(F32), pi=(rng.uniform(0, 0.2, (R, S)) ** 2).astype(F32),
+               pj=(rng.uniform(0, 0.3, (R, S)) ** 2).astype(F32), depth_values=rng.uniform(0.5, 4, (R, 1)).astype(F32))
+    out["pi"][:6] = 0.0
+    gt = dict(rgb=rng.uniform(0, 1, (1, R, 3)).astype(F32), rgb_smooth=rng.uniform(0, 1, (1, R, 3)).astype(F32))
+    arr = dict(**out, rgb=gt["rgb"], rgb_smooth=gt["rgb_smooth"])
+    loss = VolSDFLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, rgb_weight=1.0, mvs_weight=1.0, sparse_weight=1.0,
+                      anneal_rgb=200, gce=0.5, confi=1e-3)
+    for it in (0, 100, 250):
+        loss.iter_step = it
+        res = loss({k: T(v) for k, v in out.items()}, {k: T(v) for k, v in gt.items()})
+        for k, v in res.items():
+            arr[f"it{it}_{k}"] = np.asarray(float(v), F32)
+    save("loss", **arr)
+
+
 ALL = dict(rays=fx_rays, sdf_mlp=fx_sdf_mlp, rgb_mlp=fx_rgb_mlp, density=fx_density, sampler=fx_sampler,
-           composite=fx_composite, forward=fx_forward)
+           composite=fx_composite, forward=fx_forward, cost_mapping=fx_cost_mapping, loss=fx_loss)
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(ALL)

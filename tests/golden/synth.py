@@ -95,3 +95,19 @@ def make_train_rng(R, seed=0, n_bins=128, n_final=98):
         "eik_idx": rng.integers(0, n_final, size=R).astype(np.int64),
         "eik_points": rng.uniform(-3.0, 3.0, (R, 3)).astype(F32),
     }
+
+
+def make_mvs_views(seed, D=48, Hc=36, Wc=48, n_views=3):
+    """Synthetic MVS prior: softmax(N(0,1)) probability volumes, per-pixel depth hypotheses,
+    three cameras with x offsets 0, +-0.3 looking at the origin."""
+    rng = np.random.default_rng(seed)
+    views = []
+    for j, dx in enumerate((0.0, 0.3, -0.3)[:n_views]):
+        K, pose = make_camera(center=(dx, 0.02 * j, -2.5), tilt=-0.12 * dx / 0.3, skew=0.4 * j)
+        logits = rng.normal(0, 1, (D, Hc, Wc))
+        prob = np.exp(logits) / np.exp(logits).sum(0, keepdims=True)
+        base = np.linspace(1.5, 3.5, D)[:, None, None] * (1.0 + 0.05 * rng.uniform(-1, 1, (1, Hc, Wc)))
+        if j == 2:
+            base[:, :4, :] = 0.0            # a band of invalid hypotheses (near < 1e-5)
+        views.append(dict(K=K, c2w=pose, cost=prob.astype(F32), z_mvs=base.astype(F32)))
+    return views

@@ -288,3 +288,79 @@ def test_model_forward_vs_oracle_1024(dev):
     assert same.mean() > 0.95
     np.testing.assert_allclose(out["rgb_values"].cpu().numpy()[same], ref["rgb_values"][same], atol=1e-4)
     np.testing.assert_allclose(out["depth_values"].cpu().numpy()[same], ref["depth_values"][same], atol=2e-4)
+
+
+# ------------------------------------------------------------------------------------------------------
+# a10 / a11
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["cost_mapping_inv0_v0", "cost_mapping_inv0_v2", "cost_mapping_inv1_v0",
+                                  "cost_mapping_inv1_v2"])
+def test_cost_lookup_golden(dev, ops, golden_dir, name):
+    g = dict(np.load(os.path.join(golden_dir, name + ".npz")))
+    views = synth.make_mvs_views(int(g["seed"]))
+    dv = [dict(K=v["K"], c2w=v["c2w"], cost=G(v["cost"], dev), z_mvs=G(v["z_mvs"], dev)) for v in views]
+    pj, pi, valid = ops.cost_lookup(dv, int(g["view_index"]), (576, 768), xyz=G(g["xyz"], dev),
+                                    inverse_depth=bool(g["inverse_depth"]))
+    assert np.array_equal(valid.cpu().numpy(), g["valid"])
+    np.testing.assert_allclose(pj.cpu().numpy(), g["pj"], atol=3e-6)
+    np.testing.assert_allclose(pi.cpu().numpy(), g["pi"], atol=3e-6)
+
+
+def test_cost_lookup_ray_mode_full_size(dev, ops):
+    """1024 x 98 points against the oracle; ray-parametrised input (cam + z*dir formed in the kernel)."""
+    views = synth.make_mvs_views(9, D=192, Hc=72, Wc=96)
+    K, pose = views[1]["K"], views[1]["c2w"]
+    uv = synth.make_uv(1024, seed=41, margin=0.02)
+    dirs, cam, _ = orc.rays_from_uv(uv, pose, K)
+    z = np.sort(np.random.default_rng(2).uniform(0.2, 5.5, (1024, 98)), -1).astype(F32)
+    xyz = (cam[None, None] + z[:, :, None] * dirs[:, None, :]).astype(F32)
+    pj_r, pi_r, valid_r = orc.cost_mapping(xyz, 1, views, (576, 768))
+    dv = [dict(K=v["K"], c2w=v["c2w"], cost=G(v["cost"], dev), z_mvs=G(v["z_mvs"], dev)) for v in views]
+    pj, pi, valid = ops.cost_lookup(dv, 1, (576, 768), cam=G(cam, dev), dirs=G(dirs, dev), z=G(z, dev))
+    agree = valid.cpu().numpy() == valid_r
+    assert agree.mean() > 0.9999          # a point exactly on a frustum bound may fall either side
+    np.testing.assert_allclose(pj.cpu().numpy()[agree], pj_r[agree], atol=3e-6)
+    np.testing.assert_allclose(pi.cpu().numpy()[agree], pi_r[agree], atol=3e-6)
+
+
+def _torch_loss(out, rgb, rgb_smooth, it, **kw):
+    """plain torch float32 restatement of loss.py:80-114 (autograd reference for the fused loss kernel)."""
+    eik_w, rgb_w, mvs_w, sp_w = kw["eikonal_weight"], kw["rgb_weight"], kw["mvs_weight"], kw["sparse_weight"]
+    gce, confi, anneal_rgb = kw["gce"], kw["confi"], kw["anneal_rgb"]
+    rgb_loss = (out["rgb_values"] - rgb).abs().mean()
+    eik = ((out["grad_theta"].norm(2, dim=1) - 1) ** 2).mean()
+    pw = out["pi"] * out["pj"]
+    w = out["weights"]
+    l = (-pw * w.detach() ** gce * torch.log(w + 1e-8)).sum(1)
+    mvs = (1. * (pw.sum(1) > confi) * l).mean()
+    on = sp_w > 0 and anneal_rgb > 0 and it < anneal_rgb
+    sparse = torch.zeros(())
+    anneal = 0.0
+    if on:
+        conf = pw.sum(-1)
+        sparse = ((1. / (out["depth_values"].squeeze() + 1e-3)) * (conf < confi)).mean()
+        anneal = 1.0 - it / anneal_rgb
+        rgb_loss = ((out["rgb_values"] - rgb_smooth).abs().mean(-1) * (conf < 1e-8)).mean()
+    return rgb_w * rgb_loss + eik_w * eik + mvs_w * mvs + sp_w * anneal * sparse
+
+
+@pytest.mark.parametrize("it", [0, 100, 250])
+def test_loss_kernel(dev, ops, golden_dir, it):
+    g = dict(np.load(os.path.join(golden_dir, "loss.npz")))
+    kw = dict(eikonal_weight=0.1, rgb_weight=1.0, mvs_weight=1.0, sparse_weight=1.0, gce=0.5, confi=1e-3, anneal_rgb=200)
+    annealed = it < 200
+    anneal = 1.0 - it / 200 if annealed else 0.0
+    target = g["rgb_smooth"] if annealed else g["rgb"]
+    losses, grads = ops.loss_fwd_bwd(G(g["rgb_values"], dev), G(target, dev), G(g["weights"], dev),
+                                     G(g["depth_values"], dev), grad_theta=G(g["grad_theta"], dev), pi=G(g["pi"], dev),
+                                     pj=G(g["pj"], dev), rgb_weight=1.0, eikonal_weight=0.1, mvs_weight=1.0,
+                                     sparse_weight=1.0, gce=0.5, confi=1e-3, annealed=annealed, anneal_sparse=anneal)
+    l = losses.cpu().numpy()
+    for i, k in enumerate(("rgb_loss", "eikonal_loss", "mvs_loss", "sparse_loss", "loss")):
+        np.testing.assert_allclose(l[i], g[f"it{it}_{k}"], rtol=3e-6, atol=1e-7, err_msg=k)
+    t = {k: torch.tensor(g[k], requires_grad=k in ("rgb_values", "grad_theta", "weights", "depth_values"))
+         for k in ("rgb_values", "grad_theta", "weights", "pi", "pj", "depth_values")}
+    _torch_loss(t, torch.tensor(g["rgb"]).reshape(-1, 3), torch.tensor(g["rgb_smooth"]).reshape(-1, 3), it, **kw).backward()
+    for k in ("rgb_values", "grad_theta", "weights", "depth_values"):
+        ref = t[k].grad.numpy() if t[k].grad is not None else np.zeros_like(g[k])
+        np.testing.assert_allclose(grads[k].cpu().numpy().reshape(ref.shape), ref, rtol=2e-5, atol=1e-8, err_msg=k)

@@ -221,3 +221,24 @@ def test_forward(golden_dir, tag):
     else:
         np.testing.assert_allclose(out["normal_map"], g["normal_map"], atol=2e-3)
         np.testing.assert_allclose(out["normal_map"][same], g["normal_map"][same], atol=2e-4)
+
+
+@pytest.mark.parametrize("name", ["cost_mapping_inv0_v0", "cost_mapping_inv0_v2", "cost_mapping_inv1_v0",
+                                  "cost_mapping_inv1_v2"])
+def test_cost_mapping(golden_dir, name):
+    g = load(golden_dir, name)
+    views = synth.make_mvs_views(int(g["seed"]))
+    pj, pi, valid = orc.cost_mapping(g["xyz"], int(g["view_index"]), views, (576, 768), bool(g["inverse_depth"]))
+    assert np.array_equal(valid, g["valid"])
+    assert 0.05 < valid.mean() < 0.95, "fixture must mix valid and invalid samples"
+    np.testing.assert_allclose(pj, g["pj"], atol=2e-6)
+    np.testing.assert_allclose(pi, g["pi"], atol=2e-6)
+
+
+def test_loss(golden_dir):
+    g = load(golden_dir, "loss")
+    out = {k: g[k] for k in ("rgb_values", "grad_theta", "weights", "pi", "pj", "depth_values")}
+    for it in (0, 100, 250):
+        res = orc.volsdf_loss(out, g["rgb"], g["rgb_smooth"], it)
+        for k, v in res.items():
+            np.testing.assert_allclose(v, g[f"it{it}_{k}"], rtol=2e-6, atol=1e-7, err_msg=f"it{it} {k}")
