@@ -357,6 +357,7 @@ int svs_cost_lookup(const float* xyz, const float* cam, const float* dirs, const
   a.xyz = xyz; a.cam = cam; a.dirs = dirs; a.z = z; a.S = S > 0 ? S : 1; a.P = n_points; a.n_views = n_views;
   a.same_view = same_view; a.inverse_depth = inverse_depth;
   a.half_w = (img_w - 1.0f) / 2.0f; a.half_h = (img_h - 1.0f) / 2.0f;
+  a.pj = pj; a.pi = pi; a.valid = valid;
   for (int j = 0; j < n_views; ++j) {
     const float* vp = view_params + 17 * j;   // HOST array: fx, fy, cx, cy, sk, c2w[12]
     a.v[j].fx = vp[0]; a.v[j].fy = vp[1]; a.v[j].cx = vp[2]; a.v[j].cy = vp[3]; a.v[j].sk = vp[4];

@@ -319,8 +319,10 @@ def test_cost_lookup_ray_mode_full_size(dev, ops):
     pj, pi, valid = ops.cost_lookup(dv, 1, (576, 768), cam=G(cam, dev), dirs=G(dirs, dev), z=G(z, dev))
     agree = valid.cpu().numpy() == valid_r
     assert agree.mean() > 0.9999          # a point exactly on a frustum bound may fall either side
-    np.testing.assert_allclose(pj.cpu().numpy()[agree], pj_r[agree], atol=3e-6)
-    np.testing.assert_allclose(pi.cpu().numpy()[agree], pi_r[agree], atol=3e-6)
+    # D = 192: one float32 ulp of the normalised depth moves the trilinear weight by ~1e-5
+    np.testing.assert_allclose(pj.cpu().numpy()[agree], pj_r[agree], atol=5e-5)
+    np.testing.assert_allclose(pi.cpu().numpy()[agree], pi_r[agree], atol=5e-5)
+    assert np.abs(pj.cpu().numpy()[agree] - pj_r[agree]).mean() < 1e-7
 
 
 def _torch_loss(out, rgb, rgb_smooth, it, **kw):
