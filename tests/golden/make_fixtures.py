@@ -311,8 +311,94 @@ def fx_loss():
     save("loss", **arr)
 
 
+def _load_costreg(model, stage, params):
+    sd = {k: T(v) for k, v in params.items()}
+    model.cost_regularization[stage].load_state_dict(sd, strict=True)
+
+
+def fx_casmvs():
+    from models.CasMVSNet import CascadeMVSNet, homo_warping
+    import oracle_path  # noqa
+    # ---- homo_warping alone: per-pixel hypotheses, off-image and behind-camera projections
+    rng = np.random.default_rng(3)
+    C, H, W, D = 8, 12, 16, 6
+    src = rng.normal(0, 1, (C, H, W)).astype(F32)
+    Kc = np.eye(4, dtype=F32); Kc[0, 0] = Kc[1, 1] = 20.0; Kc[0, 2], Kc[1, 2] = 8.0, 6.0
+    def P(tx, ang):
+        E = np.eye(4, dtype=F32)
+        E[:3, :3] = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], F32)
+        E[0, 3] = tx
+        out = E.copy(); out[:3, :4] = Kc[:3, :3] @ E[:3, :4]
+        return out
+    ref_p, src_p = P(0.0, 0.0), P(1.5, 0.35)
+    dv = (rng.uniform(1.0, 12.0, (D, H, W))).astype(F32)
+    dv[0, :3, :3] = 0.2                                 # close points -> projection behind/near the src camera
+    warped = homo_warping(T(src)[None], T(src_p)[None], T(ref_p)[None], T(dv)[None])[0].numpy()
+    save("homo_warp", src=src, src_proj=src_p, ref_proj=ref_p, depth_values=dv, warped=warped)
+
+    # ---- DepthNet / CascadeMVSNet, 3 stages on a 64x96 image
+    feats, proj, depth_values = synth.make_mvs_sample(7, img_hw=(64, 96))
+    ndepths = [48, 32, 8]
+    model = CascadeMVSNet(refine=False, ndepths=ndepths, depth_interals_ratio=[1.0, 0.5, 0.5], share_cr=False,
+                          cr_base_chs=[8, 8, 8], grad_method="detach")
+    model.eval()
+    for st, cin in enumerate((32, 16, 8)):
+        _load_costreg(model, st, synth.make_costreg_params(100 + st, cin))
+    sample = dict(imgs=torch.zeros(1, 3, 3, 64, 96), depth_values=T(depth_values)[None],
+                  proj_matrices={k: T(v)[None] for k, v in proj.items()})
+    features = [{k: T(v)[None] for k, v in f.items()} for f in feats]
+    outputs = None
+    arr = {}
+    for st in range(3):
+        cap = {}
+        cr = model.cost_regularization[st]
+        orig = cr.forward
+        def wrapped(x, _o=orig, _c=cap):
+            _c["variance"] = x.detach().numpy().copy()
+            y = _o(x)
+            _c["reg"] = y.detach().numpy().copy()
+            return y
+        cr.forward = wrapped
+        outputs, _ = model(st, sample, features=features, extra=None, outputs=outputs,
+                           int_r=model.depth_interals_ratio[st])
+        cr.forward = orig
+        if st == 0:
+            # what runner.py:240-243 does: the rendered depth replaces the MVS depth that seeds stage 2
+            smooth = outputs["depth"] * 0.98 + 4.0
+            outputs["stage1"]["depth"] = smooth
+            outputs["depth"] = smooth
+            arr["stage1_depth_override"] = smooth[0].numpy()
+        o = outputs[f"stage{st + 1}"]
+        var = cap["variance"][0]
+        pick = np.random.default_rng(50 + st).choice(var.size, 4000, replace=False)
+        arr[f"s{st}_variance_idx"] = pick                    # the full volume is MBs: pin 4000 random voxels
+        arr[f"s{st}_variance_val"] = var.reshape(-1)[pick]
+        arr[f"s{st}_reg"] = cap["reg"][0, 0]
+        arr[f"s{st}_depth"] = o["depth"][0].numpy() if st else None
+        arr[f"s{st}_conf"] = o["photometric_confidence"][0].numpy()
+        if st == 0:
+            arr[f"s{st}_prob"] = o["prob_volume"][0].numpy()
+        arr[f"s{st}_depth_values"] = o["depth_values"][0].numpy()
+    # stage-1 depth before the override
+    arr["s0_depth"] = (arr["stage1_depth_override"] - 4.0) / 0.98
+    save("casmvs_3stage", seed=7, ndepths=np.asarray(ndepths), **{k: v for k, v in arr.items() if v is not None})
+    # one D = 192 case on a tiny map (depth regression / confidence window at full depth count)
+    rng = np.random.default_rng(12)
+    reg = rng.normal(0, 2, (192, 9, 12)).astype(F32)
+    dv = np.broadcast_to((425 + 2.65 * np.arange(192, dtype=F32)).reshape(-1, 1, 1), reg.shape).astype(F32).copy()
+    import torch.nn.functional as Fn
+    from models.CasMVSNet import depth_regression
+    prob = Fn.softmax(T(reg)[None], dim=1)
+    depth = depth_regression(prob, depth_values=T(dv)[None])
+    s4 = 4 * Fn.avg_pool3d(Fn.pad(prob.unsqueeze(1), pad=(0, 0, 0, 0, 1, 2)), (4, 1, 1), stride=1, padding=0).squeeze(1)
+    di = depth_regression(prob, depth_values=torch.arange(192, dtype=torch.float)).long().clamp(min=0, max=191)
+    conf = torch.gather(s4, 1, di.unsqueeze(1)).squeeze(1)
+    save("depthnet_tail_d192", reg=reg, depth_values=dv, prob=prob[0].numpy(), depth=depth[0].numpy(),
+         conf=conf[0].numpy(), idx=di[0].numpy())
+
+
 ALL = dict(rays=fx_rays, sdf_mlp=fx_sdf_mlp, rgb_mlp=fx_rgb_mlp, density=fx_density, sampler=fx_sampler,
-           composite=fx_composite, forward=fx_forward, cost_mapping=fx_cost_mapping, loss=fx_loss)
+           composite=fx_composite, forward=fx_forward, cost_mapping=fx_cost_mapping, loss=fx_loss, casmvs=fx_casmvs)
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(ALL)

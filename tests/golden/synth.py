@@ -111,3 +111,71 @@ def make_mvs_views(seed, D=48, Hc=36, Wc=48, n_views=3):
             base[:, :4, :] = 0.0            # a band of invalid hypotheses (near < 1e-5)
         views.append(dict(K=K, c2w=pose, cost=prob.astype(F32), z_mvs=base.astype(F32)))
     return views
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CasMVSNet cost-volume inputs (SURVEY.md 8d "C3"), scaled down for fixtures
+# ---------------------------------------------------------------------------------------------------------
+COSTREG_LAYERS = [("conv0", None, 1), ("conv1", 1, 2), ("conv2", 2, 2), ("conv3", 2, 4), ("conv4", 4, 4),
+                  ("conv5", 4, 8), ("conv6", 8, 8)]      # (name, in multiple of base (None = in_channels), out multiple)
+COSTREG_DECONV = [("conv7", 8, 4), ("conv9", 4, 2), ("conv11", 2, 1)]
+
+
+def make_costreg_params(seed, in_channels, base=8):
+    """State-dict-named float32 arrays of one CostRegNet (models/CasMVSNet.py:441-472), BN in eval form."""
+    rng = np.random.default_rng(seed)
+    p = {}
+
+    def bn(name, c):
+        p[f"{name}.bn.weight"] = rng.uniform(0.6, 1.4, c).astype(F32)
+        p[f"{name}.bn.bias"] = rng.normal(0, 0.1, c).astype(F32)
+        p[f"{name}.bn.running_mean"] = rng.normal(0, 0.1, c).astype(F32)
+        p[f"{name}.bn.running_var"] = rng.uniform(0.5, 1.5, c).astype(F32)
+        p[f"{name}.bn.num_batches_tracked"] = np.asarray(1, np.int64)
+
+    for name, ci, co in COSTREG_LAYERS:
+        cin = in_channels if ci is None else ci * base
+        cout = co * base
+        p[f"{name}.conv.weight"] = rng.normal(0, np.sqrt(2.0 / (27 * cin)), (cout, cin, 3, 3, 3)).astype(F32)
+        bn(name, cout)
+    for name, ci, co in COSTREG_DECONV:
+        cin, cout = ci * base, co * base
+        p[f"{name}.conv.weight"] = rng.normal(0, np.sqrt(2.0 / (27 * cin / 8)), (cin, cout, 3, 3, 3)).astype(F32)
+        bn(name, cout)
+    p["prob.weight"] = rng.normal(0, np.sqrt(2.0 / (27 * base)), (1, base, 3, 3, 3)).astype(F32)
+    return p
+
+
+def make_mvs_sample(seed, img_hw=(64, 96), n_views=3, numdepth=192):
+    """Synthetic MVSDataset item (datasets/general_eval.py:178-273 layout): per-stage features, projection
+    matrices (V,2,4,4) per stage ([v,0] = extrinsic, [v,1,:3,:3] = stage intrinsics) and depth_values (numdepth,)."""
+    rng = np.random.default_rng(seed)
+    H, W = img_hw
+    feats = []
+    chans = {1: 32, 2: 16, 3: 8}
+    for v in range(n_views):
+        f = {}
+        for st, sc in ((1, 4), (2, 2), (3, 1)):
+            h, w = H // sc, W // sc
+            yy, xx = np.meshgrid(np.arange(h) / h, np.arange(w) / w, indexing="ij")
+            base = np.stack([np.sin(2 * np.pi * (k % 5 + 1) * xx + k + 0.3 * v) * np.cos(2 * np.pi * (k % 3 + 1) * yy - k)
+                             for k in range(chans[st])], 0)
+            f[f"stage{st}"] = (base + 0.2 * rng.normal(0, 1, base.shape)).astype(F32)
+        feats.append(f)
+    proj = {}
+    for st, sc in ((1, 4), (2, 2), (3, 1)):
+        P = np.zeros((n_views, 2, 4, 4), F32)
+        for v, tx in enumerate((0.0, 30.0, -30.0)[:n_views]):
+            ext = np.eye(4, dtype=F32)
+            ang = 0.02 * v
+            ext[:3, :3] = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], F32)
+            ext[0, 3] = tx
+            ext[1, 3] = 3.0 * v
+            Kst = np.eye(4, dtype=F32)
+            f_img = 300.0 * (W / 160.0) * 4.0
+            Kst[0, 0] = Kst[1, 1] = f_img / sc
+            Kst[0, 2], Kst[1, 2] = (W / 2.0) / sc, (H / 2.0) / sc
+            P[v, 0], P[v, 1] = ext, Kst
+        proj[f"stage{st}"] = P
+    depth_values = (425.0 + 2.5 * 1.06 * np.arange(numdepth)).astype(F32)
+    return feats, proj, depth_values

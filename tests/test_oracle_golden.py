@@ -242,3 +242,49 @@ def test_loss(golden_dir):
         res = orc.volsdf_loss(out, g["rgb"], g["rgb_smooth"], it)
         for k, v in res.items():
             np.testing.assert_allclose(v, g[f"it{it}_{k}"], rtol=2e-6, atol=1e-7, err_msg=f"it{it} {k}")
+
+
+# ------------------------------------------------------------------------------------------------------
+# CasMVSNet cost volume (a13-a16)
+# ------------------------------------------------------------------------------------------------------
+import casmvs_oracle as corc   # noqa: E402
+
+
+def test_homo_warp(golden_dir):
+    g = load(golden_dir, "homo_warp")
+    w = corc.homo_warp(g["src"], g["src_proj"], g["ref_proj"], g["depth_values"])
+    assert (g["warped"] == 0).mean() > 0.02, "fixture must contain off-image samples"
+    np.testing.assert_allclose(w, g["warped"], atol=2e-4)
+    assert np.abs(w - g["warped"]).mean() < 2e-6
+
+
+def test_depthnet_tail_d192(golden_dir):
+    g = load(golden_dir, "depthnet_tail_d192")
+    prob, depth, conf, idx = corc.depthnet_tail(g["reg"], g["depth_values"])
+    np.testing.assert_allclose(prob, g["prob"], rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(depth, g["depth"], rtol=2e-6)
+    assert np.array_equal(idx, g["idx"])
+    np.testing.assert_allclose(conf, g["conf"], atol=3e-7)
+
+
+def test_casmvs_three_stages(golden_dir):
+    g = load(golden_dir, "casmvs_3stage")
+    feats, proj, depth_values = synth.make_mvs_sample(int(g["seed"]), img_hw=(64, 96))
+    ndepths = [int(x) for x in g["ndepths"]]
+    int_r = [1.0, 0.5, 0.5]
+    prev = None
+    for st in range(3):
+        key = f"stage{st + 1}"
+        dv = corc.depth_hypotheses(st, depth_values, (64, 96), ndepths[st], (4, 2, 1)[st], int_r[st], prev_depth=prev)
+        np.testing.assert_allclose(dv, g[f"s{st}_depth_values"], rtol=3e-6, err_msg=f"depth hypotheses {key}")
+        out = corc.depthnet_forward([f[key] for f in feats], list(proj[key]), g[f"s{st}_depth_values"],
+                                    synth.make_costreg_params(100 + st, (32, 16, 8)[st]))
+        np.testing.assert_allclose(out["variance"].reshape(-1)[g[f"s{st}_variance_idx"]], g[f"s{st}_variance_val"],
+                                   atol=2e-4, err_msg=f"variance {key}")
+        np.testing.assert_allclose(out["reg"], g[f"s{st}_reg"], atol=2e-3, err_msg=f"reg {key}")
+        assert np.abs(out["reg"] - g[f"s{st}_reg"]).mean() < 5e-5
+        # the tail is pinned on the reference's own regularised volume (argmax-like index is discontinuous)
+        prob, depth, conf, idx = corc.depthnet_tail(g[f"s{st}_reg"], g[f"s{st}_depth_values"])
+        np.testing.assert_allclose(depth, g[f"s{st}_depth"], rtol=3e-6, err_msg=f"depth {key}")
+        np.testing.assert_allclose(conf, g[f"s{st}_conf"], atol=5e-7, err_msg=f"conf {key}")
+        prev = g["stage1_depth_override"] if st == 0 else g[f"s{st}_depth"]
