@@ -128,6 +128,36 @@ int svs_loss(int n_rays, int n_samples, int n_eik, const float* rgb_values, cons
              int annealed, float anneal_sparse, float* losses, float* d_rgb_values, float* d_grad_theta,
              float* d_weights, float* d_depth_values, void* hip_stream);
 
+/* ---- a13/a14  homography warp + variance --------------------------------------------------------------------
+ * homo_warping (models/CasMVSNet.py:280-315) for every source view fused with the variance aggregation of
+ * DepthNet.forward (:611-642): variance (C,D,H,W) = sum(f^2)/V - (sum(f)/V)^2 over the reference feature (C,H,W)
+ * and the n_src warped source features.  Source features are passed channel-last (H,W,C) -- svs_chw_to_hwc.
+ * rot_trans: HOST float array, 12 per source view: rows of (src_proj @ inv(ref_proj))[:3,:3], then [:3,3], with
+ * proj = K[:3,:3] @ E[:3,:4] (:622-625).  depth_values (D,H,W) per-pixel hypotheses.  C in {8,16,32}.
+ * raw_warp != 0: write the warped volume of source 0 instead (homo_warping on its own). */
+int svs_chw_to_hwc(const float* in, float* out, int C, int H, int W, void* hip_stream);
+int svs_warp_variance(const float* ref_feature, const float* const* src_features_hwc, const float* rot_trans, int n_src,
+                      int C, int D, int H, int W, const float* depth_values, float* variance, int raw_warp,
+                      void* hip_stream);
+
+/* ---- a15  3-D regularisation blocks ----------------------------------------------------------------------------
+ * Conv3d / Deconv3d blocks of CostRegNet (models/CasMVSNet.py:107-186,441-472) with BatchNorm(eval) folded:
+ * out = [skip +] relu?(conv(in, weight) + bias).  weight: [Cin][27][Cout], tap = (kd*3+kh)*3+kw, BN scale folded
+ * in; bias: BN shift (NULL for the final `prob` conv).  transposed: ConvTranspose3d(k3,s2,p1,output_padding 1). */
+int svs_conv3d(const float* in, const float* weight, const float* bias, const float* skip, float* out, int Cin, int Cout,
+               int Di, int Hi, int Wi, int stride, int transposed, int relu, void* hip_stream);
+
+/* ---- a14 tail  softmax over D, depth regression, photometric confidence (models/CasMVSNet.py:648-663) ---------
+ * reg, depth_values (D,H,W) -> prob (D,H,W), depth (H,W), conf (H,W), index (H,W int, may be NULL). */
+int svs_prob_depth_conf(const float* reg, const float* depth_values, int D, int H, int W, float* prob, float* depth,
+                        float* conf, int* index, void* hip_stream);
+
+/* ---- a16  depth hypotheses (models/CasMVSNet.py:519-595,733-751) -------------------------------------------------
+ * prev_depth == NULL: D planes dmin..dmax (inverse != 0: uniform in 1/depth); else the previous stage's depth
+ * (Hp,Wp) -> +-(D/2)*pix_interval around its bilinear resize to the image, resized to (D, H_img/scale, W_img/scale). */
+int svs_depth_hypotheses(const float* prev_depth, int Hp, int Wp, int H_img, int W_img, int D, int scale, float dmin,
+                         float dmax, float pix_interval, int inverse, float* out, void* hip_stream);
+
 /* ---- numeric-contract self tests (used by tests/test_gpu_parity.py) --------------------------------------- */
 int svs_selftest_exp(const float* x, float* y_exp, float* y_expm1, int n, void* hip_stream);
 int svs_selftest_arith(const float* a, const float* b, float* quotient, float* sqrt_abs_a, int n, void* hip_stream);

@@ -24,6 +24,7 @@ UNITS = {
     "svs_mlp.hip": [],
     "svs_sampler.hip": ["-ffp-contract=off"],
     "svs_render.hip": ["-ffp-contract=off"],
+    "svs_costvol.hip": ["-ffp-contract=off"],
 }
 BASE_FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
               "-x", "hip"]

@@ -1,0 +1,434 @@
+// CasMVSNet cost-volume build for gfx950: fused homography warp + variance, 3-D U-Net convolutions with folded
+// BatchNorm, and the softmax / depth-regression / confidence tail.
+//
+// Reference: models/CasMVSNet.py:280-315 (homo_warping), :601-663 (DepthNet.forward), :441-472 (CostRegNet),
+// :107-186 (Conv3d / Deconv3d blocks), :519-595 and :733-751 (depth hypotheses).
+//
+// Warp + variance is HBM-bound: the reference materialises one (C,D,H,W) warped volume per source view and keeps
+// three volumes live; here every output voxel is produced once -- sum and sum of squares stay in registers and
+// only the variance is written (algorithmic bytes: write C*D*H*W*4 + read D*H*W*4 + V*C*H*W*4).
+#include "svs_common.h"
+
+namespace svs {
+namespace costvol {
+
+// ---- (C,H,W) -> (H,W,C): a source view's feature map in channel-last order, so that one bilinear corner is one
+// contiguous C-vector -------------------------------------------------------------------------------------------
+__global__ void chw_to_hwc_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int HW) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)C * HW) return;
+  const int c = (int)(idx % C);
+  const size_t p = idx / C;
+  out[idx] = in[(size_t)c * HW + p];
+}
+
+constexpr int kMaxSrc = 4;
+struct WarpArgs {
+  const float* ref;              // (C,H,W) reference-view feature
+  const float* src_hwc[kMaxSrc]; // (H,W,C) source-view features
+  float rot[kMaxSrc][9];         // src_proj @ inv(ref_proj), rows
+  float trans[kMaxSrc][3];
+  const float* depth_values;     // (D,H,W)
+  float* variance;               // (C,D,H,W)
+  int n_src, D, H, W;
+  int raw_warp;                  // 1: write the warped volume of source 0 instead of the variance (homo_warping alone)
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void warp_variance_kernel(WarpArgs a) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y, d = blockIdx.z;
+  if (x >= a.W) return;
+  const int H = a.H, W = a.W;
+  const size_t pix = (size_t)y * W + x;
+  const float depth = a.depth_values[((size_t)d * H + y) * W + x];
+  float sum[C], sq[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const float r = a.ref[(size_t)c * H * W + pix];
+    sum[c] = r; sq[c] = r * r;
+  }
+  const float fx = (float)x, fy = (float)y;
+  for (int v = 0; v < a.n_src; ++v) {
+    const float* R = a.rot[v];
+    // rot @ [x,y,1] * depth + trans   (CasMVSNet.py:300-303)
+    const float qx = ((R[0] * fx + R[1] * fy) + R[2]) * depth + a.trans[v][0];
+    const float qy = ((R[3] * fx + R[4] * fy) + R[5]) * depth + a.trans[v][1];
+    const float qz = ((R[6] * fx + R[7] * fy) + R[8]) * depth + a.trans[v][2];
+    const float px = qx / qz, py = qy / qz;
+    // normalised with the (W-1)/2 formula, sampled with align_corners=False (:305-312)
+    const float gx = px / ((float)(W - 1) / 2.0f) - 1.0f, gy = py / ((float)(H - 1) / 2.0f) - 1.0f;
+    const float ix = ((gx + 1.0f) * (float)W - 1.0f) / 2.0f, iy = ((gy + 1.0f) * (float)H - 1.0f) / 2.0f;
+    const float x0 = __builtin_floorf(ix), y0 = __builtin_floorf(iy);
+    const float tx = ix - x0, ty = iy - y0;
+    float warped[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) warped[c] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float xx = x0 + (float)(k & 1), yy = y0 + (float)(k >> 1);
+      if (xx >= 0.0f && xx <= (float)(W - 1) && yy >= 0.0f && yy <= (float)(H - 1)) {
+        const float w = ((k & 1) ? tx : 1.0f - tx) * ((k >> 1) ? ty : 1.0f - ty);
+        const f32x4* s = reinterpret_cast<const f32x4*>(a.src_hwc[v] + ((size_t)(int)yy * W + (int)xx) * C);
+#pragma unroll
+        for (int c4 = 0; c4 < C / 4; ++c4) {
+          const f32x4 f = s[c4];
+          warped[4 * c4] += w * f[0]; warped[4 * c4 + 1] += w * f[1];
+          warped[4 * c4 + 2] += w * f[2]; warped[4 * c4 + 3] += w * f[3];
+        }
+      }
+    }
+    if (a.raw_warp) {
+      const size_t vox0 = ((size_t)d * H + y) * W + x;
+      const size_t cs0 = (size_t)a.D * H * W;
+#pragma unroll
+      for (int c = 0; c < C; ++c) a.variance[c * cs0 + vox0] = warped[c];
+      return;
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) { sum[c] += warped[c]; sq[c] += warped[c] * warped[c]; }
+  }
+  const float nv = (float)(a.n_src + 1);
+  const size_t vox = ((size_t)d * H + y) * W + x;
+  const size_t cs = (size_t)a.D * H * W;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const float m = sum[c] / nv;
+    a.variance[c * cs + vox] = sq[c] / nv - m * m;
+  }
+}
+
+// ---- 3x3x3 convolution, padding 1, stride 1/2, folded BN (scale in the weights, shift as bias), optional ReLU ----
+// weights: [Cin][27][Cout] (tap = (kd*3+kh)*3+kw).  One thread: VX consecutive x outputs x CT output channels.
+constexpr int kConvThreads = 256;
+constexpr int kCinChunk = 8;
+
+struct ConvArgs {
+  const float* in;     // (Cin, Di, Hi, Wi)
+  const float* w;      // [Cin][27][Cout]
+  const float* bias;   // [Cout] or nullptr
+  const float* skip;   // (Cout, Do, Ho, Wo) added AFTER the ReLU (CasMVSNet.py:468-470) or nullptr
+  float* out;          // (Cout, Do, Ho, Wo)
+  int Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, stride, relu;
+};
+
+template <int CT, int VX>
+__global__ __launch_bounds__(kConvThreads) void conv3d_kernel(ConvArgs a) {
+  __shared__ float wl[kCinChunk * 27 * CT];
+  const int co0 = blockIdx.y * CT;
+  const int wg = (a.Wo + VX - 1) / VX;
+  const long long total = (long long)a.Do * a.Ho * wg;
+  const long long t = (long long)blockIdx.x * kConvThreads + threadIdx.x;
+  const bool live = t < total;
+  const long long tt = live ? t : 0;
+  const int xo0 = (int)(tt % wg) * VX;
+  const int yo = (int)((tt / wg) % a.Ho), zo = (int)(tt / ((long long)wg * a.Ho));
+  float acc[CT][VX];
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int v = 0; v < VX; ++v) acc[c][v] = 0.0f;
+  const int s = a.stride;
+  constexpr int NX = (VX - 1) * 2 + 3;   // input columns touched (stride <= 2)
+  for (int ci0 = 0; ci0 < a.Cin; ci0 += kCinChunk) {
+    const int nci = a.Cin - ci0 < kCinChunk ? a.Cin - ci0 : kCinChunk;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nci * 27 * CT; i += kConvThreads) {
+      const int c = i % CT, rest = i / CT;
+      wl[i] = (co0 + c < a.Cout) ? a.w[((size_t)(ci0 * 27 + rest)) * a.Cout + co0 + c] : 0.0f;
+    }
+    __syncthreads();
+    if (!live) continue;
+    for (int ci = 0; ci < nci; ++ci) {
+      const float* inc = a.in + (size_t)(ci0 + ci) * a.Di * a.Hi * a.Wi;
+#pragma unroll
+      for (int kd = 0; kd < 3; ++kd) {
+        const int zi = zo * s + kd - 1;
+        if (zi < 0 || zi >= a.Di) continue;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int yi = yo * s + kh - 1;
+          if (yi < 0 || yi >= a.Hi) continue;
+          const float* row = inc + ((size_t)zi * a.Hi + yi) * a.Wi;
+          float xin[NX];
+          const int xi0 = xo0 * s - 1;
+#pragma unroll
+          for (int j = 0; j < NX; ++j) {
+            const int xi = xi0 + j;
+            xin[j] = (j < (VX - 1) * s + 3 && xi >= 0 && xi < a.Wi) ? row[xi] : 0.0f;
+          }
+          const float* wrow = wl + (ci * 27 + (kd * 3 + kh) * 3) * CT;
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+              const float wv = wrow[kw * CT + c];
+#pragma unroll
+              for (int v = 0; v < VX; ++v) {
+                const float xv = s == 1 ? xin[v + kw] : xin[2 * v + kw];
+                acc[c][v] = __builtin_fmaf(wv, xv, acc[c][v]);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  if (!live) return;
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    if (co0 + c >= a.Cout) break;
+    const float b = a.bias ? a.bias[co0 + c] : 0.0f;
+#pragma unroll
+    for (int v = 0; v < VX; ++v) {
+      const int xo = xo0 + v;
+      if (xo >= a.Wo) break;
+      const size_t o = (((size_t)(co0 + c) * a.Do + zo) * a.Ho + yo) * a.Wo + xo;
+      float r = acc[c][v] + b;
+      if (a.relu) r = __builtin_fmaxf(r, 0.0f);
+      if (a.skip) r += a.skip[o];
+      a.out[o] = r;
+    }
+  }
+}
+
+// ---- ConvTranspose3d(k=3, stride=2, padding=1, output_padding=1): out[o] += in[(o+1-t)/2] * w[ci][co][t] for the taps
+// t whose (o+1-t) is even and in range.  weights: [Cin][27][Cout] (same layout, tap order of the torch kernel).
+template <int CT>
+__global__ __launch_bounds__(kConvThreads) void deconv3d_kernel(ConvArgs a) {
+  __shared__ float wl[kCinChunk * 27 * CT];
+  const int co0 = blockIdx.y * CT;
+  const long long total = (long long)a.Do * a.Ho * a.Wo;
+  const long long t = (long long)blockIdx.x * kConvThreads + threadIdx.x;
+  const bool live = t < total;
+  const long long tt = live ? t : 0;
+  const int xo = (int)(tt % a.Wo), yo = (int)((tt / a.Wo) % a.Ho), zo = (int)(tt / ((long long)a.Wo * a.Ho));
+  float acc[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) acc[c] = 0.0f;
+  // valid taps per dimension: o even -> t=1 (i=o/2); o odd -> t=0 (i=(o+1)/2) and t=2 (i=(o-1)/2)
+  int tz[2], iz[2], nz = 0, ty_[2], iy_[2], ny = 0, tx_[2], ix_[2], nx = 0;
+  auto taps = [](int o, int n_in, int* tt_, int* ii_, int& n) {
+    n = 0;
+    for (int k = 0; k < 3; ++k) {
+      const int num = o + 1 - k;
+      if (num >= 0 && (num & 1) == 0 && (num >> 1) < n_in) { tt_[n] = k; ii_[n] = num >> 1; ++n; }
+    }
+  };
+  taps(zo, a.Di, tz, iz, nz); taps(yo, a.Hi, ty_, iy_, ny); taps(xo, a.Wi, tx_, ix_, nx);
+  for (int ci0 = 0; ci0 < a.Cin; ci0 += kCinChunk) {
+    const int nci = a.Cin - ci0 < kCinChunk ? a.Cin - ci0 : kCinChunk;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nci * 27 * CT; i += kConvThreads) {
+      const int c = i % CT, rest = i / CT;
+      wl[i] = (co0 + c < a.Cout) ? a.w[((size_t)(ci0 * 27 + rest)) * a.Cout + co0 + c] : 0.0f;
+    }
+    __syncthreads();
+    if (!live) continue;
+    for (int ci = 0; ci < nci; ++ci) {
+      const float* inc = a.in + (size_t)(ci0 + ci) * a.Di * a.Hi * a.Wi;
+      for (int p = 0; p < nz; ++p)
+        for (int q = 0; q < ny; ++q)
+          for (int r = 0; r < nx; ++r) {
+            const float xv = inc[((size_t)iz[p] * a.Hi + iy_[q]) * a.Wi + ix_[r]];
+            const float* wrow = wl + (ci * 27 + (tz[p] * 3 + ty_[q]) * 3 + tx_[r]) * CT;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc[c] = __builtin_fmaf(wrow[c], xv, acc[c]);
+          }
+    }
+  }
+  if (!live) return;
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    if (co0 + c >= a.Cout) break;
+    const size_t o = (((size_t)(co0 + c) * a.Do + zo) * a.Ho + yo) * a.Wo + xo;
+    float r = acc[c] + (a.bias ? a.bias[co0 + c] : 0.0f);
+    if (a.relu) r = __builtin_fmaxf(r, 0.0f);
+    if (a.skip) r += a.skip[o];
+    a.out[o] = r;
+  }
+}
+
+// ---- softmax over D, depth regression, photometric confidence (CasMVSNet.py:648-663) ----------------------------
+__global__ void prob_depth_conf_kernel(const float* __restrict__ reg, const float* __restrict__ depth_values, int D, int HW,
+                                       float* __restrict__ prob, float* __restrict__ depth, float* __restrict__ conf,
+                                       int* __restrict__ index) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= HW) return;
+  float m = -__builtin_inff();
+  for (int d = 0; d < D; ++d) m = __builtin_fmaxf(m, reg[(size_t)d * HW + p]);
+  float s = 0.0f;
+  for (int d = 0; d < D; ++d) s += __expf(reg[(size_t)d * HW + p] - m);
+  const float inv = 1.0f / s;
+  float dep = 0.0f, idxf = 0.0f;
+  for (int d = 0; d < D; ++d) {
+    const float pr = __expf(reg[(size_t)d * HW + p] - m) * inv;
+    prob[(size_t)d * HW + p] = pr;
+    dep += pr * depth_values[(size_t)d * HW + p];
+    idxf += pr * (float)d;
+  }
+  int idx = (int)idxf;                       // .long() truncation
+  idx = idx < 0 ? 0 : (idx > D - 1 ? D - 1 : idx);
+  float c = 0.0f;                            // p[idx-1] + p[idx] + p[idx+1] + p[idx+2], zero padded
+  for (int k = idx - 1; k <= idx + 2; ++k)
+    if (k >= 0 && k < D) c += __expf(reg[(size_t)k * HW + p] - m) * inv;
+  depth[p] = dep;
+  conf[p] = c;
+  if (index) index[p] = idx;
+}
+
+// ---- depth hypotheses (CasMVSNet.py:519-595, 733-751) -------------------------------------------------------------
+// stage 1: D planes from dmin..dmax (or inverse-depth), identical for every pixel.
+// stage >= 2: previous depth bilinearly resized to the image (align_corners=False), +-(D/2)*pixel_interval around it,
+// then the trilinear resize of :747-749 to (D, H/s, W/s), which for the integer scales used is evaluated directly.
+struct HypoArgs {
+  const float* prev_depth;   // (Hp,Wp) previous stage depth or nullptr
+  int Hp, Wp, H_img, W_img, D, Hs, Ws;   // Hs = H_img/scale
+  float dmin, dmax, pix_interval;
+  int inverse;
+  float* out;                // (D,Hs,Ws)
+};
+
+__device__ __forceinline__ void lin_src(int o, int n_in, int n_out, int& i0, int& i1, float& t) {
+  const float scale = (float)n_in / (float)n_out;
+  float src = ((float)o + 0.5f) * scale - 0.5f;
+  src = src < 0.0f ? 0.0f : src;
+  i0 = (int)src; if (i0 > n_in - 1) i0 = n_in - 1;
+  i1 = i0 + 1 < n_in ? i0 + 1 : n_in - 1;
+  t = src - (float)i0;
+}
+
+__device__ __forceinline__ float upsampled_prev(const HypoArgs& a, int yi, int xi) {
+  int y0, y1, x0, x1; float ty, tx;
+  lin_src(yi, a.Hp, a.H_img, y0, y1, ty);
+  lin_src(xi, a.Wp, a.W_img, x0, x1, tx);
+  const float* p = a.prev_depth;
+  const float top = (1.0f - tx) * p[y0 * a.Wp + x0] + tx * p[y0 * a.Wp + x1];
+  const float bot = (1.0f - tx) * p[y1 * a.Wp + x0] + tx * p[y1 * a.Wp + x1];
+  return (1.0f - ty) * top + ty * bot;
+}
+
+__global__ void depth_hypotheses_kernel(HypoArgs a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.D * a.Hs * a.Ws) return;
+  const int x = idx % a.Ws, y = (idx / a.Ws) % a.Hs, d = idx / (a.Ws * a.Hs);
+  if (!a.prev_depth) {
+    float v;
+    if (a.inverse) {
+      const float step = 1.0f / (float)(a.D - 1);
+      const float t = d < a.D / 2 ? __builtin_fmaf(step, (float)d, 0.0f) : __builtin_fmaf(-step, (float)(a.D - 1 - d), 1.0f);
+      v = 1.0f / (1.0f / a.dmin * (1.0f - t) + 1.0f / a.dmax * t);
+    } else {
+      v = a.dmin + (float)d * ((a.dmax - a.dmin) / (float)(a.D - 1));
+    }
+    a.out[idx] = v;
+    return;
+  }
+  // trilinear resize (D,H_img,W_img) -> (D,Hs,Ws): depth axis is an identity, the spatial axes interpolate
+  int y0, y1, x0, x1; float ty, tx;
+  lin_src(y, a.H_img, a.Hs, y0, y1, ty);
+  lin_src(x, a.W_img, a.Ws, x0, x1, tx);
+  auto hyp = [&](int yi, int xi) {
+    const float cur = upsampled_prev(a, yi, xi);
+    const float half = (float)a.D / 2.0f * a.pix_interval;
+    const float cmin = cur - half, cmax = cur + half;
+    return cmin + (float)d * ((cmax - cmin) / (float)(a.D - 1));
+  };
+  const float top = (1.0f - tx) * hyp(y0, x0) + tx * hyp(y0, x1);
+  const float bot = (1.0f - tx) * hyp(y1, x0) + tx * hyp(y1, x1);
+  a.out[idx] = (1.0f - ty) * top + ty * bot;
+}
+
+}  // namespace costvol
+}  // namespace svs
+
+using namespace svs;
+using namespace svs::costvol;
+
+extern "C" {
+
+int svs_chw_to_hwc(const float* in, float* out, int C, int H, int W, void* hip_stream) {
+  if (!in || !out || C < 1 || H < 1 || W < 1) { set_error("svs_chw_to_hwc: bad argument"); return SVS_EINVAL; }
+  const size_t n = (size_t)C * H * W;
+  chw_to_hwc_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)hip_stream>>>(in, out, C, H * W);
+  return check_launch("svs_chw_to_hwc");
+}
+
+int svs_warp_variance(const float* ref_feature, const float* const* src_features_hwc, const float* rot_trans, int n_src,
+                      int C, int D, int H, int W, const float* depth_values, float* variance, int raw_warp,
+                      void* hip_stream) {
+  if (!ref_feature || !src_features_hwc || !rot_trans || !depth_values || !variance) {
+    set_error("svs_warp_variance: null argument"); return SVS_EINVAL;
+  }
+  if (n_src < 1 || n_src > kMaxSrc || D < 1 || H < 2 || W < 2) { set_error("svs_warp_variance: bad sizes"); return SVS_ESHAPE; }
+  WarpArgs a;
+  a.ref = ref_feature; a.depth_values = depth_values; a.variance = variance; a.n_src = n_src; a.D = D; a.H = H; a.W = W;
+  a.raw_warp = raw_warp;
+  for (int v = 0; v < n_src; ++v) {
+    if (!src_features_hwc[v]) { set_error("svs_warp_variance: null source %d", v); return SVS_EINVAL; }
+    a.src_hwc[v] = src_features_hwc[v];
+    for (int k = 0; k < 9; ++k) a.rot[v][k] = rot_trans[12 * v + k];      // HOST array: 9 rot + 3 trans per source
+    for (int k = 0; k < 3; ++k) a.trans[v][k] = rot_trans[12 * v + 9 + k];
+  }
+  dim3 grid((W + 255) / 256, H, D), block(256);
+  if (W <= 64) { block.x = 64; grid.x = (W + 63) / 64; } else if (W <= 128) { block.x = 128; grid.x = (W + 127) / 128; }
+  hipStream_t s = (hipStream_t)hip_stream;
+  if (C == 8) warp_variance_kernel<8><<<grid, block, 0, s>>>(a);
+  else if (C == 16) warp_variance_kernel<16><<<grid, block, 0, s>>>(a);
+  else if (C == 32) warp_variance_kernel<32><<<grid, block, 0, s>>>(a);
+  else { set_error("svs_warp_variance: C must be 8, 16 or 32 (FeatureNet outputs)"); return SVS_ESHAPE; }
+  return check_launch("svs_warp_variance");
+}
+
+// transposed != 0: ConvTranspose3d(k3,s2,p1,op1) (Do = 2*Di); else Conv3d(k3,p1,stride)
+int svs_conv3d(const float* in, const float* weight, const float* bias, const float* skip, float* out, int Cin, int Cout,
+               int Di, int Hi, int Wi, int stride, int transposed, int relu, void* hip_stream) {
+  if (!in || !weight || !out || Cin < 1 || Cout < 1 || Di < 1 || Hi < 1 || Wi < 1 || (stride != 1 && stride != 2)) {
+    set_error("svs_conv3d: bad argument"); return SVS_EINVAL;
+  }
+  ConvArgs a;
+  a.in = in; a.w = weight; a.bias = bias; a.skip = skip; a.out = out; a.Cin = Cin; a.Cout = Cout;
+  a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.stride = stride; a.relu = relu;
+  hipStream_t s = (hipStream_t)hip_stream;
+  if (transposed) {
+    a.Do = 2 * Di; a.Ho = 2 * Hi; a.Wo = 2 * Wi;
+    const long long total = (long long)a.Do * a.Ho * a.Wo;
+    dim3 grid((unsigned)((total + kConvThreads - 1) / kConvThreads), (Cout + 7) / 8);
+    deconv3d_kernel<8><<<grid, kConvThreads, 0, s>>>(a);
+  } else {
+    a.Do = (Di - 1) / stride + 1; a.Ho = (Hi - 1) / stride + 1; a.Wo = (Wi - 1) / stride + 1;
+    constexpr int VX = 4;
+    const long long total = (long long)a.Do * a.Ho * ((a.Wo + VX - 1) / VX);
+    if (Cout <= 8) {
+      dim3 grid((unsigned)((total + kConvThreads - 1) / kConvThreads), (Cout + 7) / 8);
+      conv3d_kernel<8, VX><<<grid, kConvThreads, 0, s>>>(a);
+    } else {
+      dim3 grid((unsigned)((total + kConvThreads - 1) / kConvThreads), (Cout + 15) / 16);
+      conv3d_kernel<16, VX><<<grid, kConvThreads, 0, s>>>(a);
+    }
+  }
+  return check_launch("svs_conv3d");
+}
+
+int svs_prob_depth_conf(const float* reg, const float* depth_values, int D, int H, int W, float* prob, float* depth,
+                        float* conf, int* index, void* hip_stream) {
+  if (!reg || !depth_values || !prob || !depth || !conf || D < 1 || H < 1 || W < 1) {
+    set_error("svs_prob_depth_conf: bad argument"); return SVS_EINVAL;
+  }
+  prob_depth_conf_kernel<<<(H * W + 255) / 256, 256, 0, (hipStream_t)hip_stream>>>(reg, depth_values, D, H * W, prob,
+                                                                                  depth, conf, index);
+  return check_launch("svs_prob_depth_conf");
+}
+
+int svs_depth_hypotheses(const float* prev_depth, int Hp, int Wp, int H_img, int W_img, int D, int scale, float dmin,
+                         float dmax, float pix_interval, int inverse, float* out, void* hip_stream) {
+  if (!out || D < 2 || scale < 1 || H_img % scale || W_img % scale || (prev_depth && (Hp < 1 || Wp < 1))) {
+    set_error("svs_depth_hypotheses: bad argument"); return SVS_EINVAL;
+  }
+  HypoArgs a{prev_depth, Hp, Wp, H_img, W_img, D, H_img / scale, W_img / scale, dmin, dmax, pix_interval, inverse, out};
+  const int n = D * a.Hs * a.Ws;
+  depth_hypotheses_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)hip_stream>>>(a);
+  return check_launch("svs_depth_hypotheses");
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+"""torch-tensor wrappers for the CasMVSNet cost-volume kernels (csrc/svs_costvol.hip)."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from .ops import _f32, _ptr, _ptr_array, _stream
+
+
+def relative_projection(src_proj, ref_proj):
+    """models/CasMVSNet.py:622-625 and :290-292 on the host, in float64: proj (2,4,4) tensors ->
+    12 floats: rows of (src @ inv(ref))[:3,:3] then [:3,3]."""
+    def comb(P):
+        P = np.asarray(P.detach().cpu(), np.float64)
+        out = P[0].copy()
+        out[:3, :4] = P[1][:3, :3] @ P[0][:3, :4]
+        return out
+    rel = comb(src_proj) @ np.linalg.inv(comb(ref_proj))
+    return list(rel[:3, :3].reshape(-1)) + list(rel[:3, 3])
+
+
+def warp_variance(features, proj_matrices, depth_values):
+    """DepthNet.forward step 2 (models/CasMVSNet.py:611-642).  features: list of (1,C,H,W) (reference first),
+    proj_matrices: (1,V,2,4,4), depth_values (1,D,H,W) -> variance (1,C,D,H,W)."""
+    L = _lib.load()
+    ref = _f32(features[0][0])
+    C, H, W = ref.shape
+    D = depth_values.shape[1]
+    dev = ref.device
+    n_src = len(features) - 1
+    hwc = []
+    for f in features[1:]:
+        o = torch.empty(H, W, C, device=dev)
+        _lib.check(L.svs_chw_to_hwc(_ptr(_f32(f[0])), _ptr(o), C, H, W, _stream()), "svs_chw_to_hwc")
+        hwc.append(o)
+    rt = (ctypes.c_float * (12 * n_src))()
+    for v in range(n_src):
+        for k, x in enumerate(relative_projection(proj_matrices[0, v + 1], proj_matrices[0, 0])):
+            rt[12 * v + k] = float(x)
+    var = torch.empty(1, C, D, H, W, device=dev)
+    dv = _f32(depth_values[0])
+    _lib.check(L.svs_warp_variance(_ptr(ref), _ptr_array(hwc), rt, n_src, C, D, H, W, _ptr(dv), _ptr(var), 0, _stream()),
+               "svs_warp_variance")
+    return var
+
+
+def homo_warp(src_fea, src_rel, depth_values):
+    """homo_warping alone (models/CasMVSNet.py:280-315).  src_fea (C,H,W), src_rel: 12 floats
+    (rows of (src_proj @ inv(ref_proj))[:3,:3], then [:3,3]), depth_values (D,H,W) -> (C,D,H,W)."""
+    L = _lib.load()
+    src = _f32(src_fea)
+    C, H, W = src.shape
+    dv = _f32(depth_values)
+    D = dv.shape[0]
+    hwc = torch.empty(H, W, C, device=src.device)
+    _lib.check(L.svs_chw_to_hwc(_ptr(src), _ptr(hwc), C, H, W, _stream()), "svs_chw_to_hwc")
+    rt = (ctypes.c_float * 12)(*[float(x) for x in src_rel])
+    out = torch.empty(C, D, H, W, device=src.device)
+    _lib.check(L.svs_warp_variance(_ptr(src), _ptr_array([hwc]), rt, 1, C, D, H, W, _ptr(dv), _ptr(out), 1, _stream()),
+               "svs_warp_variance")
+    return out
+
+
+def conv3d(x, weight, bias=None, skip=None, stride=1, transposed=False, relu=True):
+    """x (Cin,D,H,W); weight [Cin][27][Cout] folded; -> (Cout,Do,Ho,Wo)."""
+    L = _lib.load()
+    x = _f32(x)
+    Cin, D, H, W = x.shape
+    Cout = weight.shape[2]
+    if transposed:
+        shp = (Cout, 2 * D, 2 * H, 2 * W)
+    else:
+        shp = (Cout, (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1)
+    out = torch.empty(shp, device=x.device)
+    _lib.check(L.svs_conv3d(_ptr(x), _ptr(weight), _ptr(bias), _ptr(skip), _ptr(out), Cin, Cout, D, H, W, stride,
+                            int(transposed), int(relu), _stream()), "svs_conv3d")
+    return out
+
+
+def prob_depth_conf(reg, depth_values):
+    """reg (D,H,W), depth_values (D,H,W) -> prob (D,H,W), depth (H,W), conf (H,W), index (H,W int32)."""
+    L = _lib.load()
+    reg, dv = _f32(reg), _f32(depth_values)
+    D, H, W = reg.shape
+    dev = reg.device
+    prob = torch.empty(D, H, W, device=dev)
+    depth = torch.empty(H, W, device=dev)
+    conf = torch.empty(H, W, device=dev)
+    idx = torch.empty(H, W, dtype=torch.int32, device=dev)
+    _lib.check(L.svs_prob_depth_conf(_ptr(reg), _ptr(dv), D, H, W, _ptr(prob), _ptr(depth), _ptr(conf), _ptr(idx),
+                                     _stream()), "svs_prob_depth_conf")
+    return prob, depth, conf, idx
+
+
+def depth_hypotheses(prev_depth, img_hw, ndepth, scale, dmin, dmax, pix_interval, inverse, device):
+    """models/CasMVSNet.py:733-751 -> (D, H/scale, W/scale)."""
+    L = _lib.load()
+    H, W = img_hw
+    out = torch.empty(ndepth, H // scale, W // scale, device=device)
+    pd = _f32(prev_depth) if prev_depth is not None else None
+    Hp, Wp = (pd.shape[-2], pd.shape[-1]) if pd is not None else (0, 0)
+    _lib.check(L.svs_depth_hypotheses(_ptr(pd), Hp, Wp, H, W, ndepth, scale, float(dmin), float(dmax),
+                                      float(pix_interval), int(bool(inverse)), _ptr(out), _stream()),
+               "svs_depth_hypotheses")
+    return out

@@ -48,6 +48,12 @@ SIGNATURES = {
                                 _PP, _PP, _PP, POINTER(c_int), _P, _P, _P, _P]),
     "svs_loss": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float,
                          c_float, c_int, c_float, _P, _P, _P, _P, _P, _P]),
+    "svs_chw_to_hwc": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "svs_warp_variance": (c_int, [_P, _PP, POINTER(c_float), c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P]),
+    "svs_conv3d": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "svs_prob_depth_conf": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    "svs_depth_hypotheses": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_int,
+                                     _P, _P]),
     "svs_selftest_exp": (c_int, [_P, _P, _P, c_int, _P]),
     "svs_selftest_arith": (c_int, [_P, _P, _P, _P, c_int, _P]),
     "svs_selftest_cumsum": (c_int, [_P, _P, _P, c_int, c_int, _P]),

@@ -1,0 +1,134 @@
+"""GPU parity of the CasMVSNet cost-volume kernels against the oracle and
+the reference-generated fixtures.  Tolerances: 2e-4 abs on warped features / variance (bilinear sampling at
+|coordinate| ~ 1e2 px), 2e-3 abs / 5e-5 mean on the 11-layer 3-D U-Net output, exact regression index."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import casmvs_oracle as corc
+import synth
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def G(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name + ".npz")))
+
+
+def test_homo_warping_golden(dev, golden_dir):
+    from models.CasMVSNet import homo_warping
+    g = load(golden_dir, "homo_warp")
+    w = homo_warping(G(g["src"], dev)[None], G(g["src_proj"], dev)[None], G(g["ref_proj"], dev)[None],
+                     G(g["depth_values"], dev)[None])[0].cpu().numpy()
+    np.testing.assert_allclose(w, g["warped"], atol=2e-4)
+    assert np.abs(w - g["warped"]).mean() < 2e-6
+    assert np.array_equal(w == 0, g["warped"] == 0)           # same off-image / behind-camera voxels
+
+
+def test_tail_d192_golden(dev, golden_dir):
+    from svs_hip import costvol
+    g = load(golden_dir, "depthnet_tail_d192")
+    prob, depth, conf, idx = costvol.prob_depth_conf(G(g["reg"], dev), G(g["depth_values"], dev))
+    np.testing.assert_allclose(prob.cpu().numpy(), g["prob"], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(depth.cpu().numpy(), g["depth"], rtol=3e-6)
+    assert np.array_equal(idx.cpu().numpy(), g["idx"])
+    np.testing.assert_allclose(conf.cpu().numpy(), g["conf"], atol=1e-6)
+
+
+def _model(dev, ndepths):
+    from models.CasMVSNet import CascadeMVSNet
+    m = CascadeMVSNet(refine=False, ndepths=ndepths, depth_interals_ratio=[1.0, 0.5, 0.5], share_cr=False,
+                      cr_base_chs=[8, 8, 8], grad_method="detach")
+    for st, cin in enumerate((32, 16, 8)):
+        sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_costreg_params(100 + st, cin).items()}
+        m.cost_regularization[st].load_state_dict(sd, strict=True)
+    return m.to(dev).eval()
+
+
+def test_three_stage_forward_golden(dev, golden_dir):
+    """CascadeMVSNet.forward x 3 stages through the reference's call surface, stage-1 depth overridden as in
+    runner.py:240-243."""
+    g = load(golden_dir, "casmvs_3stage")
+    feats, proj, depth_values = synth.make_mvs_sample(int(g["seed"]), img_hw=(64, 96))
+    m = _model(dev, [int(x) for x in g["ndepths"]])
+    sample = dict(imgs=torch.zeros(1, 3, 3, 64, 96, device=dev), depth_values=G(depth_values, dev)[None],
+                  proj_matrices={k: G(v, dev)[None] for k, v in proj.items()})
+    features = [{k: G(v, dev)[None] for k, v in f.items()} for f in feats]
+    outputs = None
+    for st in range(3):
+        cr = m.cost_regularization[st]
+        cap = {}
+        orig = cr.forward
+        cr.forward = lambda x, _o=orig, _c=cap: _c.setdefault("reg", _o(_c.setdefault("var", x)))
+        outputs, _ = m(st, sample, features=features, extra=None, outputs=outputs, int_r=m.depth_interals_ratio[st])
+        cr.forward = orig
+        o = outputs[f"stage{st + 1}"]
+        np.testing.assert_allclose(o["depth_values"][0].cpu().numpy(), g[f"s{st}_depth_values"], rtol=5e-6,
+                                   err_msg=f"hypotheses stage {st + 1}")
+        var = cap["var"][0].cpu().numpy().reshape(-1)
+        np.testing.assert_allclose(var[g[f"s{st}_variance_idx"]], g[f"s{st}_variance_val"], atol=2e-4)
+        reg = cap["reg"][0, 0].cpu().numpy()
+        np.testing.assert_allclose(reg, g[f"s{st}_reg"], atol=2e-3, err_msg=f"reg stage {st + 1}")
+        assert np.abs(reg - g[f"s{st}_reg"]).mean() < 5e-5
+        # depth / confidence: continuous in reg except where the truncated index flips
+        np.testing.assert_allclose(o["depth"][0].cpu().numpy(), g[f"s{st}_depth"], rtol=2e-5)
+        dconf = np.abs(o["photometric_confidence"][0].cpu().numpy() - g[f"s{st}_conf"])
+        assert (dconf > 1e-4).mean() < 0.01
+        if st == 0:
+            np.testing.assert_allclose(o["prob_volume"][0].cpu().numpy(), g["s0_prob"], atol=2e-5)
+            ov = G(g["stage1_depth_override"], dev)[None]
+            outputs["stage1"]["depth"] = ov
+            outputs["depth"] = ov
+
+
+@pytest.mark.parametrize("cin,shape", [(32, (16, 16, 24)), (16, (8, 24, 16)), (8, (8, 8, 8))])
+def test_costreg_vs_torch_reference(dev, cin, shape):
+    """3-D U-Net on random volumes (incl. non-cubic shapes) against the plain torch float32 reference."""
+    from models.CasMVSNet import CostRegNet
+    params = synth.make_costreg_params(7 + cin, cin)
+    net = CostRegNet(cin, 8)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in params.items()}, strict=True)
+    net.to(dev).eval()
+    x = np.random.default_rng(cin).normal(0, 1, (cin,) + shape).astype(F32)
+    y = net(G(x, dev)[None])[0, 0].cpu().numpy()
+    ref = corc.cost_reg_net_torch(params, x)
+    np.testing.assert_allclose(y, ref, atol=2e-3)
+    assert np.abs(y - ref).mean() < 5e-5
+
+
+def test_config3_sizes_run(dev):
+    """BASELINE config 3 geometry (640x512 image, D = 192/32/8): shapes, finiteness and linearity of the fused
+    warp+variance in the feature scale (size-independent property)."""
+    from svs_hip import costvol
+    feats, proj, depth_values = synth.make_mvs_sample(3, img_hw=(512, 640))
+    m = _model(dev, [192, 32, 8])
+    sample = dict(imgs=torch.zeros(1, 3, 3, 512, 640, device=dev), depth_values=G(depth_values, dev)[None],
+                  proj_matrices={k: G(v, dev)[None] for k, v in proj.items()})
+    features = [{k: G(v, dev)[None] for k, v in f.items()} for f in feats]
+    outputs = None
+    for st in range(3):
+        outputs, _ = m(st, sample, features=features, extra=None, outputs=outputs, int_r=m.depth_interals_ratio[st])
+        o = outputs[f"stage{st + 1}"]
+        s = (4, 2, 1)[st]
+        assert o["depth"].shape == (1, 512 // s, 640 // s)
+        assert o["prob_volume"].shape == (1, [192, 32, 8][st], 512 // s, 640 // s)
+        assert torch.isfinite(o["depth"]).all() and torch.isfinite(o["photometric_confidence"]).all()
+        np.testing.assert_allclose(o["prob_volume"].sum(1).cpu().numpy(), 1.0, atol=1e-5)
+    f1 = [f["stage1"] for f in features]
+    dv = outputs["stage1"]["depth_values"]
+    v1 = costvol.warp_variance(f1, sample["proj_matrices"]["stage1"], dv)
+    v2 = costvol.warp_variance([2.0 * f for f in f1], sample["proj_matrices"]["stage1"], dv)
+    np.testing.assert_allclose(v2.cpu().numpy(), 4.0 * v1.cpu().numpy(), rtol=1e-5, atol=1e-6)
