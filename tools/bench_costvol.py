@@ -1,0 +1,62 @@
+"""Secondary measurement (not the driver's bench line): CasMVSNet cost-volume build at BASELINE config 3
+(640x512 image, D = 192/32/8, 3 views) on one MI355X.  Prints one JSON object with per-stage times and the
+HBM roofline of the fused warp+variance kernel (algorithmic bytes: SURVEY.md section 8d)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "tests", "golden"), os.path.join(ROOT, "s-volsdf_amd")):
+    sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import synth  # noqa: E402
+from models.CasMVSNet import CascadeMVSNet  # noqa: E402
+from svs_hip import costvol  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda:0")
+    H, W = 512, 640
+    feats, proj, depth_values = synth.make_mvs_sample(3, img_hw=(H, W))
+    m = CascadeMVSNet(refine=False, ndepths=[192, 32, 8], depth_interals_ratio=[1.0, 0.5, 0.5], share_cr=False,
+                      cr_base_chs=[8, 8, 8], grad_method="detach")
+    for st, cin in enumerate((32, 16, 8)):
+        m.cost_regularization[st].load_state_dict(
+            {k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_costreg_params(100 + st, cin).items()})
+    m.to(dev).eval()
+    G = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    sample = dict(imgs=torch.zeros(1, 3, 3, H, W, device=dev), depth_values=G(depth_values)[None],
+                  proj_matrices={k: G(v)[None] for k, v in proj.items()})
+    features = [{k: G(v)[None] for k, v in f.items()} for f in feats]
+    res = {}
+    macs = {0: 10152, 1: 6696, 2: 4968}
+    for rep in range(3):
+        outputs = None
+        for st in range(3):
+            key = f"stage{st + 1}"
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            e[0].record()
+            outputs, _ = m(st, sample, features=features, extra=None, outputs=outputs, int_r=m.depth_interals_ratio[st])
+            e[1].record()
+            torch.cuda.synchronize()
+            res[key + "_ms"] = e[0].elapsed_time(e[1])
+            dv = outputs[key]["depth_values"]
+            fs = [f[key] for f in features]
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            e[0].record()
+            costvol.warp_variance(fs, sample["proj_matrices"][key], dv)
+            e[1].record()
+            torch.cuda.synchronize()
+            C, D, h, w = fs[0].shape[1], dv.shape[1], dv.shape[2], dv.shape[3]
+            bytes_ = 4 * (C * D * h * w + D * h * w + 3 * C * h * w)
+            t = e[0].elapsed_time(e[1]) * 1e-3
+            res[key + "_warp_ms"] = t * 1e3
+            res[key + "_warp_GBps"] = bytes_ / t / 1e9
+            res[key + "_unet_TFLOPs"] = 2 * macs[st] * D * h * w / ((res[key + "_ms"] * 1e-3 - t)) / 1e12
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
