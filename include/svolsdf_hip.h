@@ -106,6 +106,14 @@ int svs_composite(int n_rays, int n_samples, const float* z, const float* sdf, c
                   const float* depth_scale, const float* beta_param, float beta_min, float* weights, float* rgb_values,
                   float* depth_values, float* depth_vals, float* normal_map, void* hip_stream);
 
+/* a8 backward: gradients of a scalar loss through the compositing (hand-derived reverse pass of network.py:281-295
+ * and :237-243).  d_weights / d_depth_values may be NULL.  -> d_sdf (R*S), d_rgb (R*S,3), d_beta_param (1) =
+ * d loss / d density.beta; d_beta_ray (R) is workspace. */
+int svs_composite_bwd(int n_rays, int n_samples, const float* z, const float* sdf, const float* rgb,
+                      const float* depth_scale, const float* beta_param, float beta_min, const float* d_rgb_values,
+                      const float* d_weights, const float* d_depth_values, float* d_sdf, float* d_rgb,
+                      float* d_beta_ray, float* d_beta_param, void* hip_stream);
+
 /* ---- a10  MVS prior lookup ----------------------------------------------------------------------------
  * VolOpt.cost_mapping (volsdf/vsdf.py:382-452).  Points: xyz (n_points,3) or, when xyz == NULL, cam + z*dir with
  * z (n_points/S, S).  view_params: HOST float array, 17 per view: fx, fy, cx, cy, sk, c2w rows (3x4).

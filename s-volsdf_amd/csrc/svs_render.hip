@@ -121,6 +121,107 @@ __global__ __launch_bounds__(64) void composite_kernel(CompositeArgs a) {
   }
 }
 
+// ---- a8 backward: d(loss)/d(sdf, rgb, beta) from d(loss)/d(rgb_values, weights, depth_values) -----------------
+// Forward (network.py:281-295): fe_i = dist_i * sigma(sdf_i, beta), w_i = (1 - exp(-fe_i)) * exp(-sum_{j<i} fe_j);
+// rgb_values = sum w_i c_i, depth_values = ds * sum(w_i z_i) / (sum w_i + 1e-8).  Hand-derived reverse pass:
+//   dL/dfe_k = dw_k * T_k * exp(-fe_k) - sum_{i>k} dw_i * w_i
+//   dsigma/dsdf = -exp(-|s|/beta) / (2 beta^2),  dsigma/dbeta = -sigma/beta + sgn(s) exp(-|s|/beta) |s| / (2 beta^3)
+struct CompositeBwdArgs {
+  int R, S;
+  const float* z; const float* sdf; const float* rgb; const float* depth_scale;
+  const float* beta_param; float beta_min;
+  const float* d_rgb_values;   // (R,3)
+  const float* d_weights;      // (R,S) or nullptr
+  const float* d_depth_values; // (R) or nullptr
+  float* d_sdf;                // (R*S)
+  float* d_rgb;                // (R*S,3)
+  float* d_beta_ray;           // (R): per-ray d loss / d beta (summed by beta_reduce_kernel)
+};
+
+__global__ __launch_bounds__(64) void composite_bwd_kernel(CompositeBwdArgs a) {
+  __shared__ float zs[kMaxS], fe[kMaxS], tr[kMaxS], dw[kMaxS], pre[kMaxS];
+  const int r = blockIdx.x, lane = threadIdx.x, S = a.S;
+  const float beta = __builtin_fabsf(*a.beta_param) + a.beta_min;
+  for (int i = lane; i < S; i += 64) zs[i] = a.z[(size_t)r * S + i];
+  __syncthreads();
+  for (int i = lane; i < S; i += 64) {
+    const float dist = i < S - 1 ? zs[i + 1] - zs[i] : 1e10f;
+    fe[i] = dist * laplace_density(a.sdf[(size_t)r * S + i], beta);
+  }
+  __syncthreads();
+  for (int i = lane; i < S; i += 64) tr[i] = i == 0 ? 0.0f : fe[i - 1];
+  __syncthreads();
+  wave_cumsum_excl_out(tr, tr, S, lane);
+  __syncthreads();
+  float sw = 0.0f, swz = 0.0f;
+  for (int i = lane; i < S; i += 64) {
+    const float T = det_exp(-tr[i]);
+    tr[i] = T;
+    const float w = (1.0f - det_exp(-fe[i])) * T;
+    pre[i] = w;                         // weights, reused below
+    sw += w; swz += w * zs[i];
+  }
+  sw = wave_sum(sw); swz = wave_sum(swz);
+  __syncthreads();
+  const float ds = a.depth_scale[r];
+  const float g0 = a.d_rgb_values[3 * r], g1 = a.d_rgb_values[3 * r + 1], g2 = a.d_rgb_values[3 * r + 2];
+  const float gd = a.d_depth_values ? a.d_depth_values[r] * ds : 0.0f;
+  const float den = sw + 1e-8f;
+  for (int i = lane; i < S; i += 64) {
+    const size_t p = (size_t)r * S + i;
+    const float w = pre[i];
+    const float c0 = a.rgb[3 * p], c1 = a.rgb[3 * p + 1], c2 = a.rgb[3 * p + 2];
+    a.d_rgb[3 * p] = w * g0; a.d_rgb[3 * p + 1] = w * g1; a.d_rgb[3 * p + 2] = w * g2;
+    float d = (c0 * g0 + c1 * g1) + c2 * g2;
+    if (a.d_weights) d += a.d_weights[p];
+    d += gd * (zs[i] * den - swz) / (den * den);
+    dw[i] = d;
+    pre[i] = d * w;                     // summand of the suffix sums
+  }
+  __syncthreads();
+  const float tot = wave_cumsum_excl_out(pre, pre, S, lane);   // inclusive prefix of dw_i * w_i
+  __syncthreads();
+  float dbeta = 0.0f;
+  for (int i = lane; i < S; i += 64) {
+    const size_t p = (size_t)r * S + i;
+    const float suffix = tot - pre[i];                          // sum_{j>i} dw_j w_j
+    const float dfe = dw[i] * tr[i] * det_exp(-fe[i]) - suffix;
+    const float dist = i < S - 1 ? zs[i + 1] - zs[i] : 1e10f;
+    const float dsig = dfe * dist;
+    const float s = a.sdf[p];
+    const float as = __builtin_fabsf(s);
+    const float e = det_exp(-as / beta);
+    const float sgn = s > 0.0f ? 1.0f : (s < 0.0f ? -1.0f : 0.0f);
+    const float sigma = (1.0f / beta) * (0.5f + 0.5f * sgn * (e - 1.0f));
+    // sign(0) = 0 in the reference's density: its gradient w.r.t. sdf vanishes there as well
+    a.d_sdf[p] = (s != 0.0f) ? dsig * (-0.5f * e / (beta * beta)) : 0.0f;
+    const float dsig_dbeta = -sigma / beta + 0.5f * sgn * e * as / (beta * beta * beta);
+    // exp(-fe) underflows long before dist = 1e10 matters; guard the 0 * inf of the last sample
+    if (dfe != 0.0f) dbeta += dsig * dsig_dbeta;
+  }
+  dbeta = wave_sum(dbeta);
+  if (lane == 0) a.d_beta_ray[r] = dbeta;
+}
+
+// d loss / d density.beta = sign(beta_param) * sum over rays (float64, fixed order -> reproducible)
+__global__ __launch_bounds__(256) void beta_reduce_kernel(const float* __restrict__ d_beta_ray, int R,
+                                                          const float* __restrict__ beta_param, float* __restrict__ out,
+                                                          int accumulate) {
+  __shared__ double sh[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < R; i += 256) acc += (double)d_beta_ray[i];
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double t = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    const float bp = *beta_param;
+    const float sg = bp > 0.0f ? 1.0f : (bp < 0.0f ? -1.0f : 0.0f);
+    const float v = sg * (float)t;
+    out[0] = accumulate ? out[0] + v : v;
+  }
+}
+
 // ---- a10: MVS prior lookup (VolOpt.cost_mapping, volsdf/vsdf.py:382-452) --------------------------------
 struct LookupView {
   float fx, fy, cx, cy, sk;
@@ -344,6 +445,21 @@ int svs_composite(int n_rays, int n_samples, const float* z, const float* sdf, c
                   depth_values, depth_vals, normal_map};
   composite_kernel<<<n_rays, 64, 0, (hipStream_t)hip_stream>>>(a);
   return check_launch("svs_composite");
+}
+
+int svs_composite_bwd(int n_rays, int n_samples, const float* z, const float* sdf, const float* rgb,
+                      const float* depth_scale, const float* beta_param, float beta_min, const float* d_rgb_values,
+                      const float* d_weights, const float* d_depth_values, float* d_sdf, float* d_rgb,
+                      float* d_beta_ray, float* d_beta_param, void* hip_stream) {
+  if (!z || !sdf || !rgb || !depth_scale || !beta_param || !d_rgb_values || !d_sdf || !d_rgb || !d_beta_ray ||
+      !d_beta_param || n_rays <= 0) { set_error("svs_composite_bwd: null/invalid argument"); return SVS_EINVAL; }
+  if (n_samples < 2 || n_samples > kMaxS) { set_error("svs_composite_bwd: n_samples must be in [2,%d]", kMaxS); return SVS_ESHAPE; }
+  CompositeBwdArgs a{n_rays, n_samples, z, sdf, rgb, depth_scale, beta_param, beta_min, d_rgb_values, d_weights,
+                     d_depth_values, d_sdf, d_rgb, d_beta_ray};
+  hipStream_t s = (hipStream_t)hip_stream;
+  composite_bwd_kernel<<<n_rays, 64, 0, s>>>(a);
+  beta_reduce_kernel<<<1, 256, 0, s>>>(d_beta_ray, n_rays, beta_param, d_beta_param, 0);
+  return check_launch("svs_composite_bwd");
 }
 
 int svs_cost_lookup(const float* xyz, const float* cam, const float* dirs, const float* z, int S, int n_points,

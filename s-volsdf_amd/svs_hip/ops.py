@@ -172,6 +172,27 @@ def composite(z, sdf, rgb, depth_scale, beta_param, beta_min, normals=None):
                 normal_map=normal_map)
 
 
+def composite_bwd(z, sdf, rgb, depth_scale, beta_param, beta_min, d_rgb_values, d_weights=None, d_depth_values=None):
+    """Reverse pass of `composite`: -> d_sdf (R*S,1), d_rgb (R*S,3), d_beta_param (1,)."""
+    L = _lib.load()
+    z = _f32(z)
+    R, S = z.shape
+    dev = z.device
+    sdf, rgb, depth_scale = _f32(sdf), _f32(rgb), _f32(depth_scale)
+    beta_param = _f32(beta_param).reshape(1)
+    g_rgb = _f32(d_rgb_values)
+    g_w = _f32(d_weights) if d_weights is not None else None
+    g_d = _f32(d_depth_values).reshape(-1) if d_depth_values is not None else None
+    d_sdf = torch.empty(R * S, 1, device=dev)
+    d_rgb = torch.empty(R * S, 3, device=dev)
+    ws = torch.empty(R, device=dev)
+    d_beta = torch.empty(1, device=dev)
+    _lib.check(L.svs_composite_bwd(R, S, _ptr(z), _ptr(sdf), _ptr(rgb), _ptr(depth_scale), _ptr(beta_param),
+                                   float(beta_min), _ptr(g_rgb), _ptr(g_w), _ptr(g_d), _ptr(d_sdf), _ptr(d_rgb),
+                                   _ptr(ws), _ptr(d_beta), _stream()), "svs_composite_bwd")
+    return d_sdf, d_rgb, d_beta
+
+
 def cost_lookup(views, same_view, img_res, *, xyz=None, cam=None, dirs=None, z=None, inverse_depth=False):
     """VolOpt.cost_mapping (volsdf/vsdf.py:382-452).
 
