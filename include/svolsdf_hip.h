@@ -114,6 +114,16 @@ int svs_composite_bwd(int n_rays, int n_samples, const float* z, const float* sd
                       const float* d_weights, const float* d_depth_values, float* d_sdf, float* d_rgb,
                       float* d_beta_ray, float* d_beta_param, void* hip_stream);
 
+/* ---- a12  weight-gradient contraction of the training backward ---------------------------------------------------
+ * dW[256][ldw] += sum over points of A(:,p) B(:,p)^T for one or two operand pairs stored as wave-tile activation
+ * blocks (128*64 floats per 32 points; s* = floats between consecutive blocks).  a*_h (optional): A is multiplied
+ * by softplus'(.) = 1 - exp(-100 h) of that block.  b_extra: optional 16 extra B rows per block (dW columns
+ * 256..271, ldw >= 272: the radiance MLP's first layer).  db[256] += row sums of pair 0's A (bias gradient).
+ * dW / db are accumulated with float atomics: the caller zeroes them. */
+int svs_wgrad(const float* a0, const float* a0_h, const float* b0, long long sa0, long long sh0, long long sb0,
+              const float* a1, const float* a1_h, const float* b1, long long sa1, long long sh1, long long sb1,
+              const float* b_extra, long long s_extra, int n_points, float* dW, int ldw, float* db, void* hip_stream);
+
 /* ---- a10  MVS prior lookup ----------------------------------------------------------------------------
  * VolOpt.cost_mapping (volsdf/vsdf.py:382-452).  Points: xyz (n_points,3) or, when xyz == NULL, cam + z*dir with
  * z (n_points/S, S).  view_params: HOST float array, 17 per view: fx, fy, cx, cy, sk, c2w rows (3x4).

@@ -25,6 +25,7 @@ UNITS = {
     "svs_sampler.hip": ["-ffp-contract=off"],
     "svs_render.hip": ["-ffp-contract=off"],
     "svs_costvol.hip": ["-ffp-contract=off"],
+    "svs_wgrad.hip": [],
 }
 BASE_FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
               "-x", "hip"]

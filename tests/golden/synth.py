@@ -179,3 +179,23 @@ def make_mvs_sample(seed, img_hw=(64, 96), n_views=3, numdepth=192):
         proj[f"stage{st}"] = P
     depth_values = (425.0 + 2.5 * 1.06 * np.arange(numdepth)).astype(F32)
     return feats, proj, depth_values
+
+
+def rows_to_tiles(x):
+    """(P, F) row-major features -> wave-tile activation blocks (ceil(P/32), 128*64): the layout of
+    svs_mlp.hip (block float index ((i//4)*64 + lane)*4 + i%4, i = 16*tile + r, feature = 32*tile + rho(r) + 4*half,
+    lane = point%32 + 32*half).  F <= 256; missing rows / points are zero."""
+    P, Fdim = x.shape
+    nt = (P + 31) // 32
+    out = np.zeros((nt, 128 * 64), F32)
+    f = np.arange(Fdim)
+    t, local = f // 32, f % 32
+    half = (local >> 2) & 1
+    r = (local & 3) + 4 * (local >> 3)
+    i = 16 * t + r
+    p = np.arange(P)
+    wt, col = p // 32, p % 32
+    lane = col[:, None] + 32 * half[None, :]
+    idx = ((i[None, :] // 4) * 64 + lane) * 4 + (i[None, :] % 4)
+    out[wt[:, None].repeat(Fdim, 1), idx] = x
+    return out
