@@ -39,6 +39,12 @@ int svs_rays_from_uv(const float* uv, const float* pose, const float* intrinsics
  * device pointers in layer order, shapes as in the checkpoint (`implicit_network.lin{l}.weight_v` ...);
  * weight_g == NULL for networks without weight-norm.  workspace: svs_pack_workspace_bytes().
  * full != 0 also packs the feature head and the transposed weights used by the input-gradient pass. */
+/* which: 0 SDF forward, 1 SDF full (forward + feature head + input-gradient pass), 2 SDF training backward,
+ *        3 radiance forward, 4 radiance backward.  The first svs_pack_stream call per `which` uploads a 2 KiB chunk
+ * table (one hipMalloc + hipMemcpy; make that call outside graph capture). */
+size_t svs_stream_bytes(int which);
+int svs_pack_stream(int which, const float* const* weight_v, const float* const* weight_g, const float* const* bias,
+                    float* workspace, float* stream_out, void* hip_stream);
 size_t svs_sdf_stream_bytes(int full);
 size_t svs_rgb_stream_bytes(void);
 size_t svs_pack_workspace_bytes(void);
@@ -59,12 +65,15 @@ int svs_sdf_vals(const float* points, int n_points, const float* cam, int cam_st
                  float* sdf, const int* gate, void* hip_stream);
 /* svs_sdf_outputs: ImplicitNetwork.get_outputs (network.py:105-123) and .gradient (:90-103):
  *   sdf (P), grad = d sdf/dx (P,3), feat_tiles (svs_feat_tiles_bytes; wave-tile layout, may be NULL),
- *   hbuf (svs_sdf_hbuf_bytes): the activations h_1..h_8 kept for the gradient pass / training backward. */
+ *   hbuf (svs_sdf_hbuf_bytes): the activations h_1..h_8 kept for the gradient pass / training backward;
+ *   gbuf (same size, may be NULL): g(h_1)..g(h_8) of the gradient pass; clamp_mask (P bytes, may be NULL): 1 where
+ *   the sphere clamp is active -- both are only needed by the training backward. */
 size_t svs_sdf_hbuf_bytes(int n_points_total);
 size_t svs_feat_tiles_bytes(int n_points_total);
 int svs_sdf_outputs(const float* points, int n_points, const float* cam, int cam_stride, const float* dirs,
                     const float* z, int S, int n_rays, const float* stream, float sphere_radius, float sphere_scale,
-                    int clamp_n, float* sdf, float* grad, float* feat_tiles, float* hbuf, void* hip_stream);
+                    int clamp_n, float* sdf, float* grad, float* feat_tiles, float* hbuf, float* gbuf,
+                    unsigned char* clamp_mask, void* hip_stream);
 /* feature vectors in row-major (P,256), for callers outside the fused pipeline */
 int svs_tiles_to_rows(const float* tiles, int n_points, float* rows, void* hip_stream);
 
@@ -73,7 +82,9 @@ int svs_tiles_to_rows(const float* tiles, int n_points, float* rows, void* hip_s
  * sigmoid(MLP(cat[x, PE1(view), normal, feature])).  view_dirs: (n_rays,3) when view_S == S, (P,3) when 0. */
 int svs_rgb_eval(const float* points, int n_points, const float* cam, int cam_stride, const float* dirs, const float* z,
                  int S, int n_rays, const float* normals, const float* view_dirs, int view_S, const float* feat_tiles,
-                 const float* stream, float* rgb, void* hip_stream);
+                 const float* stream, float* rgb, float* rbuf, void* hip_stream);
+/* rbuf (svs_rgb_rbuf_bytes, may be NULL): post-ReLU activations + the 16 extra input rows, kept for svs_rgb_bwd */
+size_t svs_rgb_rbuf_bytes(int n_points_total);
 
 /* ---- a2/a3/a4  error-bounded sampler ------------------------------------------------------------------
  * ErrorBoundSampler.get_z_vals / get_error_bound, UniformSampler.get_z_vals
@@ -123,6 +134,37 @@ int svs_composite_bwd(int n_rays, int n_samples, const float* z, const float* sd
 int svs_wgrad(const float* a0, const float* a0_h, const float* b0, long long sa0, long long sh0, long long sb0,
               const float* a1, const float* a1_h, const float* b1, long long sa1, long long sh1, long long sb1,
               const float* b_extra, long long s_extra, int n_points, float* dW, int ldw, float* db, void* hip_stream);
+
+/* ---- a12  training backward of the fused MLPs (hand-written reverse mode; the reference uses torch.autograd,
+ * loss.backward() at volsdf/vsdf.py:215, incl. the double backward through network.py:115-121) -------------------
+ * Buffers are wave-tile activation blocks; svs_block_bytes(n_points, k) = bytes of k blocks per 32-point tile.
+ *   svs_rgb_bwd : d_rgb (P,3), rgb (P,3), rbuf, radiance backward stream (svs_pack_stream which=4)
+ *                 -> zbuf (5 blocks/tile, ZERO-INITIALISED by the caller once), feat_bar (1 block/tile), d_normals (P,3)
+ *   svs_sdf_bwd_a: second-order sweep.  points/rays as in svs_sdf_outputs; d_grad (P,3) = dL/d(d sdf/dx);
+ *                 hbuf, gbuf from svs_sdf_outputs; stream = SDF training stream (which=2)
+ *                 -> ubuf (9 blocks/tile), a2buf (8), pebuf (1)
+ *   svs_sdf_bwd_b: backprop.  d_sdf (P) or NULL, feat_bar for the first n_feat_points points (multiple of 32)
+ *                 -> abuf (8 blocks/tile), sbar_out (32 floats per tile)
+ *   svs_lin8_row0_grad: out257[0..255] += dL/dW8[0,:], out257[256] += dL/db8[0] (caller zeroes)
+ *   svs_unpack_wgrad: kernel-order dW (from svs_wgrad) -> parameter gradients incl. weight-norm backward
+ *                 (w = g v/|v|, network.py:64-65).  map: 0 identity, 1 SDF lin4 (skip splice, 1/sqrt2),
+ *                 2 radiance lin0.  row_off: first parameter row covered by dWk (SDF lin8: 1, with row0 = out257). */
+size_t svs_block_bytes(int n_points, int blocks_per_tile);
+size_t svs_rgb_zbuf_bytes(int n_points);
+size_t svs_sdf_ubuf_bytes(int n_points);
+int svs_rgb_bwd(int n_points, const float* d_rgb, const float* rgb, const float* rbuf, const float* stream, float* zbuf,
+                float* feat_bar, float* d_normals, void* hip_stream);
+int svs_sdf_bwd_a(const float* points, int n_points, const float* cam, int cam_stride, const float* dirs, const float* z,
+                  int S, int n_rays, const float* d_grad, const unsigned char* clamp_mask, const float* hbuf,
+                  const float* gbuf, const float* stream, float* ubuf, float* a2buf, float* pebuf, void* hip_stream);
+int svs_sdf_bwd_b(int n_points, const float* d_sdf, const unsigned char* clamp_mask, const float* feat_bar,
+                  int n_feat_points, const float* hbuf, const float* gbuf, const float* a2buf, const float* stream,
+                  float* abuf, float* sbar_out, void* hip_stream);
+int svs_lin8_row0_grad(const float* hbuf, const float* ubuf, const float* sbar, int n_points, float* out257,
+                       void* hip_stream);
+int svs_unpack_wgrad(const float* dWk, const float* dbk, int ldw, int map, int rows, int cols, int row_off,
+                     const float* weight_v, const float* weight_g, const float* row0, float* grad_v, float* grad_g,
+                     float* grad_b, void* hip_stream);
 
 /* ---- a10  MVS prior lookup ----------------------------------------------------------------------------
  * VolOpt.cost_mapping (volsdf/vsdf.py:382-452).  Points: xyz (n_points,3) or, when xyz == NULL, cam + z*dir with

@@ -26,6 +26,7 @@ UNITS = {
     "svs_render.hip": ["-ffp-contract=off"],
     "svs_costvol.hip": ["-ffp-contract=off"],
     "svs_wgrad.hip": [],
+    "svs_mlp_bwd.hip": [],
 }
 BASE_FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
               "-x", "hip"]

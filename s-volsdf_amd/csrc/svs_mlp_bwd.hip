@@ -1,0 +1,505 @@
+// Training backward of the fused MLPs (reverse-mode derivative of svs_mlp.hip, written by hand).
+//
+// The reference obtains these gradients from torch.autograd (loss.backward() at volsdf/vsdf.py:215), including the
+// double-backward through `gradients = autograd.grad(sdf, x, create_graph=True)` (volsdf/model/network.py:115-121):
+// the normals feed the radiance MLP and the eikonal loss, so d loss / d theta needs the derivative of a
+// quantity that is itself a backward pass.
+//
+// Notation: h_{l+1} = softplus(a_l), a_l = W_l h_l + b_l (l = 0..7), sdf = a_8[0], feat = a_8[1:];
+// gradient pass: g(h_8) = W_8[0,:], ghat_l = g(h_{l+1}) * s'(a_l), g(h_l) = W_l^T ghat_l, n = J_PE^T g(h_0).
+// Given sbar = dL/dsdf, fbar = dL/dfeat, nbar = dL/dn:
+//   pass A (bottom-up, "second-order sweep"):  u_0 = J_PE nbar;  v_l = W_l u_l;  u_{l+1} = v_l * s'(a_l);
+//                                              a2_l = v_l * g(h_{l+1}) * s''(a_l)
+//   pass B (top-down, ordinary backprop):      hbar_8 = sbar W_8[0,:] + W_8[1:,:]^T fbar;
+//                                              abar_l = hbar_{l+1} * s'(a_l) + a2_l;  hbar_l = W_l^T abar_l
+//   weights (svs_wgrad):                       dW_l = abar_l h_l^T + ghat_l u_l^T,  db_l = sum abar_l
+// with s' = 1 - exp(-100 h), s'' = 100 s' (1 - s').  Both passes reuse the forward machinery (transposed
+// activations in registers, LDS-DMA weight streaming, float32 MFMA) with bias-free / transposed weight streams.
+#include "svs_mlp_dev.h"
+
+namespace svs {
+namespace mlp {
+
+__device__ __forceinline__ f32x16 load_tile(const float* __restrict__ block, int t, int lane) {
+  const f32x4* d = reinterpret_cast<const f32x4*>(block) + lane;
+  f32x16 v;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 f = d[(4 * t + q) * 64];
+    v[4 * q] = f[0]; v[4 * q + 1] = f[1]; v[4 * q + 2] = f[2]; v[4 * q + 3] = f[3];
+  }
+  return v;
+}
+__device__ __forceinline__ void store_tile(float* __restrict__ block, int t, int lane, const f32x16& v) {
+  f32x4* d = reinterpret_cast<f32x4*>(block) + lane;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 f; f[0] = v[4 * q]; f[1] = v[4 * q + 1]; f[2] = v[4 * q + 2]; f[3] = v[4 * q + 3];
+    d[(4 * t + q) * 64] = f;
+  }
+}
+
+// zero the accumulator rows >= 217 of tile 6 (local rows 25..31): the PE splice, not network outputs
+__device__ __forceinline__ void zero_splice_rows_tile6(f32x16& v, int half) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const bool z0 = rho(r) >= 25, z1 = rho(r) + 4 >= 25;
+    if (z0 || z1) { if (half ? z1 : z0) v[r] = 0.0f; }
+  }
+}
+
+// ==============================================================================================================
+// radiance MLP backward
+// ==============================================================================================================
+struct RgbBwdArgs {
+  int P;
+  const float* d_rgb;      // (P,3) d loss / d rgb (after the sigmoid)
+  const float* rgb;        // (P,3) forward output
+  const float* rbuf;       // forward activations [wave tiles][kRbufF]
+  const f32x4* stream;     // radiance backward stream
+  float* zbuf;             // out [wave tiles][5][kBlockF]: zbar_0..zbar_3, zbar_4 (first tile only; rest stays zero)
+  float* feat_bar;         // out [wave tiles][kBlockF]: d loss / d feature vector
+  float* d_normals;        // out (P,3): d loss / d normals (the rendering network's normal input)
+};
+constexpr int kRbufFb = 4 * kBlockF + 1024;
+
+__global__ __launch_bounds__(kThreads, 1) void rgb_bwd_kernel(RgbBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Stream st;
+  st.g = a.stream; st.buf = reinterpret_cast<f32x4*>(smem); st.cur = 1;
+  const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
+  const int wtile = blockIdx.x * kWaves + wave;
+  const int p = wtile * kTilePts + (lane & 31);
+  const bool livep = p < a.P;
+  const int pc = livep ? p : a.P - 1;
+  const float* rb = a.rbuf + (size_t)wtile * kRbufFb;
+  float* zb = a.zbuf + (size_t)wtile * 5 * kBlockF;
+
+  st.prefetch<kW4TF4>();
+  float dz[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float o = a.rgb[3 * pc + c];
+    dz[c] = (livep && half == 0) ? a.d_rgb[3 * pc + c] * o * (1.0f - o) : 0.0f;   // through the sigmoid (network.py:189)
+  }
+  {  // zbar_4: rows 0..2 live in registers 0..2 of half 0, tile 0
+    f32x16 z4 = (f32x16)(0.0f);
+    z4[0] = dz[0]; z4[1] = dz[1]; z4[2] = dz[2];
+    store_tile(zb + 4 * (size_t)kBlockF, 0, lane, z4);
+  }
+  st.advance();
+  f32x16 x[8], y[8];
+  // rbar_4 = W_4^T zbar_4
+  st.prefetch<kChunkF4>();
+  {
+    const f32x4* c = st.cur_buf();
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const f32x4 w = c[t * 64 + lane];
+      f32x16 acc = (f32x16)(0.0f);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], dz[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1], dz[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2], dz[2], acc, 0, 0, 0);
+      x[t] = acc;
+    }
+  }
+  st.advance();
+  // layers 3..1: zbar_l = rbar_{l+1} * [r_{l+1} > 0];  rbar_l = W_l^T zbar_l
+  for (int l = 3; l >= 1; --l) {
+    const float* rblk = rb + (size_t)l * kBlockF;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const f32x16 r = load_tile(rblk, t, lane);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) y[t][i] = r[i] > 0.0f ? x[t][i] : 0.0f;
+    }
+    store_tile_regs(zb + (size_t)l * kBlockF, y, lane);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      st.prefetch<kChunkF4>();
+      x[t] = tile_mma<128>(st.cur_buf(), y, lane);
+      st.advance();
+    }
+  }
+  // layer 0: zbar_0, then the input gradients (feature rows: tiles 0..7, extras: tile 8)
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const f32x16 r = load_tile(rb, t, lane);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) y[t][i] = r[i] > 0.0f ? x[t][i] : 0.0f;
+  }
+  store_tile_regs(zb, y, lane);
+  float* fb = a.feat_bar + (size_t)wtile * kBlockF;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    if (t < 8) st.prefetch<kChunkF4>();
+    const f32x16 acc = tile_mma<128>(st.cur_buf(), y, lane);
+    if (t < 8) { store_tile(fb, t, lane, acc); st.advance(); }
+    else if (half == 1 && livep) {
+      // extra rows 12,13,14 (normals, network.py:175) = local rows rho(4..6)+4 of the extras tile
+      a.d_normals[3 * p] = acc[4]; a.d_normals[3 * p + 1] = acc[5]; a.d_normals[3 * p + 2] = acc[6];
+    }
+  }
+}
+
+// ==============================================================================================================
+// SDF MLP backward, pass A
+// ==============================================================================================================
+struct SdfBwdAArgs {
+  PointSrc src;
+  const float* d_grad;        // (P,3) nbar = d loss / d (d sdf/dx)
+  const unsigned char* clamp_mask;  // (P) or nullptr: clamped points contribute no nbar
+  const float* hbuf;          // [wave tiles][8][kBlockF] forward activations
+  const float* gbuf;          // [wave tiles][8][kBlockF] g(h_{l+1})
+  const f32x4* stream;        // SDF training stream (pass A part at offset 0)
+  float* ubuf;                // out [wave tiles][9][kBlockF]: block 0 = u_0 (PE order, first 2 tiles), blocks 1..8 = u_1..u_8
+  float* a2buf;               // out [wave tiles][8][kBlockF]
+  float* pebuf;               // out [wave tiles][kBlockF]: h_0 = PE(x) in PE order (first 2 tiles), B operand of dW_0
+};
+
+// a 39-vector in PE order as a 2-tile accumulator-layout block (rows q = 32*tile + rho(r) + 4*half)
+__device__ __forceinline__ void store_pe_block(float* __restrict__ block, const float* vec40, int lane, int half) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    f32x16 v;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int q0 = 32 * t + rho(r), q1 = q0 + 4;
+      const float a0 = q0 < kPeDim ? vec40[q0 < 40 ? q0 : 39] : 0.0f;
+      const float a1 = q1 < kPeDim ? vec40[q1 < 40 ? q1 : 39] : 0.0f;
+      v[r] = half ? a1 : a0;
+    }
+    store_tile(block, t, lane, v);
+  }
+}
+
+__global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_kernel(SdfBwdAArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Stream st;
+  st.g = a.stream; st.buf = reinterpret_cast<f32x4*>(smem); st.cur = 1;
+  const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
+  const int wtile = blockIdx.x * kWaves + wave;
+  const int p = wtile * kTilePts + (lane & 31);
+  const int pc = p < a.src.P ? p : a.src.P - 1;
+
+  st.prefetch<kChunk0F4>();
+  float x0, x1, x2;
+  load_point(a.src, p, x0, x1, x2);
+  PosEnc pe;
+  pe.compute(x0, x1, x2);
+  float nb[3] = {a.d_grad[3 * pc], a.d_grad[3 * pc + 1], a.d_grad[3 * pc + 2]};
+  if (p >= a.src.P || (a.clamp_mask && a.clamp_mask[pc])) { nb[0] = nb[1] = nb[2] = 0.0f; }
+  // u_0[q] = d PE_q / d x_{c(q)} * nbar_{c(q)}
+  PosEnc u0;
+#pragma unroll
+  for (int q = 0; q < 40; ++q) {
+    float coef = 1.0f; int c = q;
+    if (q >= 3 && q < kPeDim) {
+      const int f = (q - 3) / 6, w = (q - 3) % 6;
+      const float sc = (float)(1 << f);
+      c = w < 3 ? w : w - 3;
+      coef = w < 3 ? sc * pe.v[q + 3] : -sc * pe.v[q - 3];
+    }
+    u0.v[q] = q < kPeDim ? coef * nb[c < 3 ? c : 0] : 0.0f;
+  }
+  const float* hb = a.hbuf + (size_t)wtile * 8 * kBlockF;
+  const float* gb = a.gbuf + (size_t)wtile * 8 * kBlockF;
+  float* ub = a.ubuf + (size_t)wtile * 9 * kBlockF;
+  float* a2 = a.a2buf + (size_t)wtile * 8 * kBlockF;
+  store_pe_block(ub, u0.v, lane, half);
+  store_pe_block(a.pebuf + (size_t)wtile * kBlockF, pe.v, lane, half);
+  st.advance();
+
+  f32x16 x[8], y[8];
+  auto epilogue = [&](int l, int t, const f32x16& v, f32x16& u_next) {
+    const f32x16 h = load_tile(hb + (size_t)l * kBlockF, t, lane);
+    const f32x16 g = load_tile(gb + (size_t)l * kBlockF, t, lane);
+    f32x16 a2v;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float s1 = dsoftplus_from_h(h[i]);
+      u_next[i] = v[i] * s1;
+      a2v[i] = v[i] * g[i] * (100.0f * s1 * (1.0f - s1));
+    }
+    if (l == 3 && t == 6) zero_splice_rows_tile6(a2v, half);
+    store_tile(a2 + (size_t)l * kBlockF, t, lane, a2v);
+  };
+  // layer 0
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    if (t < 7) st.prefetch<kChunk0F4>(); else st.prefetch<kChunkF4>();
+    const f32x16 v = tile_mma_pe(st.cur_buf(), u0, lane, half);
+    epilogue(0, t, v, x[t]);
+    st.advance();
+  }
+  store_tile_regs(ub + 1 * (size_t)kBlockF, x, lane);
+  for (int l = 1; l < 8; ++l) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      if (t == 7 && l == 3) break;
+      if (!(l == 7 && t == 7)) st.prefetch<kChunkF4>();
+      const f32x16 v = tile_mma<128>(st.cur_buf(), x, lane);
+      epilogue(l, t, v, y[t]);
+      if (!(l == 7 && t == 7)) st.advance();
+    }
+    if (l == 3) {
+      splice_skip(y, u0, half);                       // u_4 rows >= 217 carry u_0 (skip connection)
+      store_tile(a2 + 3 * (size_t)kBlockF, 7, lane, (f32x16)(0.0f));
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x[t] = y[t];
+    store_tile_regs(ub + (size_t)(l + 1) * kBlockF, x, lane);
+  }
+}
+
+// ==============================================================================================================
+// SDF MLP backward, pass B
+// ==============================================================================================================
+struct SdfBwdBArgs {
+  int P;
+  const float* d_sdf;         // (P) sbar, or nullptr
+  const unsigned char* clamp_mask;
+  const float* feat_bar;      // [wave tiles][kBlockF] fbar (or nullptr: zero)
+  int n_feat_tiles;           // wave tiles that have a feat_bar block (ray samples); later tiles (eikonal points) have none
+  const float* hbuf; const float* gbuf; const float* a2buf;
+  const f32x4* stream;        // SDF training stream, pass B part
+  float* abuf;                // out [wave tiles][8][kBlockF] abar_0..abar_7
+  float* sbar_out;            // out (padded P): the effective sbar (clamp applied), for the lin8 row-0 gradient
+};
+
+__global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_kernel(SdfBwdBArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Stream st;
+  st.g = a.stream; st.buf = reinterpret_cast<f32x4*>(smem); st.cur = 1;
+  const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
+  const int wtile = blockIdx.x * kWaves + wave;
+  const int p = wtile * kTilePts + (lane & 31);
+  const int pc = p < a.P ? p : a.P - 1;
+  st.prefetch<kChunkF4>();
+  float sbar = (a.d_sdf && p < a.P) ? a.d_sdf[pc] : 0.0f;
+  if (a.clamp_mask && a.clamp_mask[pc]) sbar = 0.0f;
+  if (half == 0) a.sbar_out[p] = sbar;
+  const float* hb = a.hbuf + (size_t)wtile * 8 * kBlockF;
+  const float* gb = a.gbuf + (size_t)wtile * 8 * kBlockF;
+  const float* a2 = a.a2buf + (size_t)wtile * 8 * kBlockF;
+  float* ab = a.abuf + (size_t)wtile * 8 * kBlockF;
+  const bool has_f = a.feat_bar && wtile < a.n_feat_tiles;
+  f32x16 x[8], y[8];
+  if (has_f) load_tile_regs(a.feat_bar + (size_t)wtile * kBlockF, y, lane);
+  else {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) y[t] = (f32x16)(0.0f);
+  }
+  st.advance();
+  // hbar_8 = W8[1:,:]^T fbar + sbar * W8[0,:]   (W8[0,:] in accumulator layout = gbuf block 7)
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    st.prefetch<kChunkF4>();
+    f32x16 acc = tile_mma<128>(st.cur_buf(), y, lane);
+    const f32x16 w0 = load_tile(gb + 7 * (size_t)kBlockF, t, lane);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] += sbar * w0[i];
+    x[t] = acc;
+    st.advance();
+  }
+  for (int l = 7; l >= 0; --l) {
+    // abar_l = hbar_{l+1} * s'(a_l) + a2_l
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const f32x16 h = load_tile(hb + (size_t)l * kBlockF, t, lane);
+      const f32x16 s2 = load_tile(a2 + (size_t)l * kBlockF, t, lane);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) y[t][i] = x[t][i] * dsoftplus_from_h(h[i]) + s2[i];
+    }
+    if (l == 3) { y[7] = (f32x16)(0.0f); zero_splice_rows_tile6(y[6], half); }
+    store_tile_regs(ab + (size_t)l * kBlockF, y, lane);
+    if (l == 0) break;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      if (!(l == 1 && t == 7)) st.prefetch<kChunkF4>();
+      x[t] = tile_mma<128>(st.cur_buf(), y, lane);      // hbar_l
+      if (!(l == 1 && t == 7)) st.advance();
+    }
+  }
+}
+
+// d loss / d W_8[0,:] = sum_p (sbar_p h_8[:,p] + u_8[:,p]);  d loss / d b_8[0] = sum_p sbar_p.   One wave per tile
+// range, float atomics into out[257] (index 256 = the bias).
+__global__ __launch_bounds__(256) void lin8_row0_kernel(const float* __restrict__ hbuf, const float* __restrict__ ubuf,
+                                                        const float* __restrict__ sbar, int n_tiles, int P,
+                                                        float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave_global = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+  float acc[128];
+#pragma unroll
+  for (int i = 0; i < 128; ++i) acc[i] = 0.0f;
+  float bsum = 0.0f;
+  for (int t = wave_global; t < n_tiles; t += n_waves) {
+    const int p = t * 32 + (lane & 31);
+    const float sb = p < P ? sbar[p] : 0.0f;
+    const float live = p < P ? 1.0f : 0.0f;
+    const f32x4* h = reinterpret_cast<const f32x4*>(hbuf + ((size_t)t * 8 + 7) * kBlockF) + lane;
+    const f32x4* u = reinterpret_cast<const f32x4*>(ubuf + ((size_t)t * 9 + 8) * kBlockF) + lane;
+#pragma unroll
+    for (int i4 = 0; i4 < 32; ++i4) {
+      const f32x4 hv = h[i4 * 64], uv = u[i4 * 64];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[4 * i4 + j] += sb * hv[j] + live * uv[j];
+    }
+    if (lane < 32) bsum += sb;
+  }
+  // reduce over the 32 points of each half, then one atomic per row
+#pragma unroll
+  for (int i = 0; i < 128; ++i) {
+    float v = acc[i];
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    if ((lane & 31) == 0) {
+      const int row = 32 * (i / 16) + rho(i % 16) + 4 * (lane >> 5);
+      atomicAdd(&out[row], v);
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) bsum += __shfl_xor(bsum, d);
+  if (lane == 0) atomicAdd(&out[256], bsum);
+}
+
+// ==============================================================================================================
+// kernel-order weight gradients -> parameter gradients (incl. the weight-norm backward, network.py:64-65)
+// ==============================================================================================================
+struct UnpackArgs {
+  const float* dWk;    // [256][ldw] kernel-order gradient of the EFFECTIVE weight
+  const float* dbk;    // [256] or nullptr
+  int ldw;
+  int map;             // 0 identity, 1 SDF lin4 (skip splice, 1/sqrt2), 2 radiance lin0 (extras first)
+  int rows, cols, row_off;   // parameter shape; row_off: first parameter row covered (SDF lin8: 1)
+  const float* v; const float* g;     // weight_v (or plain weight), weight_g or nullptr
+  float* grad_v; float* grad_g; float* grad_b;
+  const float* row0;   // SDF lin8: [257] gradient of row 0 (+ bias at [256]) or nullptr
+};
+
+__device__ __forceinline__ int kernel_col(int map, int c) {
+  if (map == 1) return c < 217 ? c : (c < 249 ? 224 + (c - 217) : 217 + (c - 249));
+  if (map == 2) return c < 15 ? 256 + c : c - 15;
+  return c;
+}
+
+// one wave per parameter row
+__global__ __launch_bounds__(256) void unpack_wgrad_kernel(UnpackArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (o >= a.rows) return;
+  const float fac = a.map == 1 ? 0.70710678118654752f : 1.0f;
+  const bool is_row0 = a.row0 && o == 0;
+  const int ko = o - a.row_off;
+  auto dweff = [&](int c) -> float {
+    if (is_row0) return a.row0[c];
+    return a.dWk[(size_t)ko * a.ldw + kernel_col(a.map, c)] * fac;
+  };
+  if (lane == 0 && a.grad_b) a.grad_b[o] = is_row0 ? a.row0[256] : (a.dbk ? a.dbk[ko] : 0.0f);
+  if (!a.g) {
+    for (int c = lane; c < a.cols; c += 64) a.grad_v[(size_t)o * a.cols + c] = dweff(c);
+    return;
+  }
+  double nn = 0.0, dot = 0.0;
+  for (int c = lane; c < a.cols; c += 64) {
+    const double vv = (double)a.v[(size_t)o * a.cols + c];
+    nn += vv * vv; dot += vv * (double)dweff(c);
+  }
+  for (int d = 32; d >= 1; d >>= 1) { nn += __shfl_xor(nn, d); dot += __shfl_xor(dot, d); }
+  const double nrm = __builtin_sqrt(nn);
+  const float gg = a.g[o];
+  const float k1 = (float)((double)gg / nrm), k2 = (float)((double)gg * dot / (nrm * nn));
+  if (lane == 0) a.grad_g[o] = (float)(dot / nrm);
+  for (int c = lane; c < a.cols; c += 64)
+    a.grad_v[(size_t)o * a.cols + c] = k1 * dweff(c) - k2 * a.v[(size_t)o * a.cols + c];
+}
+
+}  // namespace mlp
+}  // namespace svs
+
+using namespace svs;
+using namespace svs::mlp;
+
+namespace {
+int tiles_of(int n_points) { return (n_points + kWgPts - 1) / kWgPts * kWaves; }
+template <typename K>
+int set_lds_b(K kernel, int bytes, const char* who) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e)); return (int)e; }
+  return SVS_OK;
+}
+}  // namespace
+
+extern "C" {
+
+size_t svs_rgb_zbuf_bytes(int n_points) { return (size_t)tiles_of(n_points) * 5 * kBlockF * sizeof(float); }
+size_t svs_sdf_ubuf_bytes(int n_points) { return (size_t)tiles_of(n_points) * 9 * kBlockF * sizeof(float); }
+size_t svs_block_bytes(int n_points, int blocks_per_tile) {
+  return (size_t)tiles_of(n_points) * blocks_per_tile * kBlockF * sizeof(float);
+}
+
+int svs_rgb_bwd(int n_points, const float* d_rgb, const float* rgb, const float* rbuf, const float* stream, float* zbuf,
+                float* feat_bar, float* d_normals, void* hip_stream) {
+  if (!d_rgb || !rgb || !rbuf || !stream || !zbuf || !feat_bar || !d_normals || n_points <= 0) {
+    set_error("svs_rgb_bwd: null/invalid argument"); return SVS_EINVAL;
+  }
+  RgbBwdArgs a{n_points, d_rgb, rgb, rbuf, reinterpret_cast<const f32x4*>(stream), zbuf, feat_bar, d_normals};
+  static int once = set_lds_b(rgb_bwd_kernel, kLdsBytes, "svs_rgb_bwd");
+  if (once) return once;
+  rgb_bwd_kernel<<<(n_points + kWgPts - 1) / kWgPts, kThreads, kLdsBytes, (hipStream_t)hip_stream>>>(a);
+  return check_launch("svs_rgb_bwd");
+}
+
+int svs_sdf_bwd_a(const float* points, int n_points, const float* cam, int cam_stride, const float* dirs, const float* z,
+                  int S, int n_rays, const float* d_grad, const unsigned char* clamp_mask, const float* hbuf,
+                  const float* gbuf, const float* stream, float* ubuf, float* a2buf, float* pebuf, void* hip_stream) {
+  SdfBwdAArgs a;
+  if (n_points < 0 || n_rays < 0 || (n_points == 0 && n_rays == 0) || (n_points > 0 && !points) ||
+      (n_rays > 0 && !(cam && dirs && z && S > 0)) || !d_grad || !hbuf || !gbuf || !stream || !ubuf || !a2buf || !pebuf) {
+    set_error("svs_sdf_bwd_a: null/invalid argument"); return SVS_EINVAL;
+  }
+  a.src.pts = points; a.src.cam = cam; a.src.dirs = dirs; a.src.z = z; a.src.cam_stride = cam_stride;
+  a.src.S = S > 0 ? S : 1; a.src.n_ray = n_rays * (S > 0 ? S : 0); a.src.P = a.src.n_ray + n_points;
+  a.d_grad = d_grad; a.clamp_mask = clamp_mask; a.hbuf = hbuf; a.gbuf = gbuf;
+  a.stream = reinterpret_cast<const f32x4*>(stream); a.ubuf = ubuf; a.a2buf = a2buf; a.pebuf = pebuf;
+  static int once = set_lds_b(sdf_bwd_a_kernel, kLdsBytes, "svs_sdf_bwd_a");
+  if (once) return once;
+  sdf_bwd_a_kernel<<<(a.src.P + kWgPts - 1) / kWgPts, kThreads, kLdsBytes, (hipStream_t)hip_stream>>>(a);
+  return check_launch("svs_sdf_bwd_a");
+}
+
+int svs_sdf_bwd_b(int n_points, const float* d_sdf, const unsigned char* clamp_mask, const float* feat_bar,
+                  int n_feat_points, const float* hbuf, const float* gbuf, const float* a2buf, const float* stream,
+                  float* abuf, float* sbar_out, void* hip_stream) {
+  if (!hbuf || !gbuf || !a2buf || !stream || !abuf || !sbar_out || n_points <= 0 || n_feat_points % 32) {
+    set_error("svs_sdf_bwd_b: null/invalid argument (n_feat_points must be a multiple of 32)"); return SVS_EINVAL;
+  }
+  SdfBwdBArgs a{n_points, d_sdf, clamp_mask, feat_bar, n_feat_points / 32, hbuf, gbuf, a2buf,
+                reinterpret_cast<const f32x4*>(stream) + kSdfTrainPassBF4, abuf, sbar_out};
+  static int once = set_lds_b(sdf_bwd_b_kernel, kLdsBytes, "svs_sdf_bwd_b");
+  if (once) return once;
+  sdf_bwd_b_kernel<<<(n_points + kWgPts - 1) / kWgPts, kThreads, kLdsBytes, (hipStream_t)hip_stream>>>(a);
+  return check_launch("svs_sdf_bwd_b");
+}
+
+int svs_lin8_row0_grad(const float* hbuf, const float* ubuf, const float* sbar, int n_points, float* out257,
+                       void* hip_stream) {
+  if (!hbuf || !ubuf || !sbar || !out257 || n_points <= 0) { set_error("svs_lin8_row0_grad: bad argument"); return SVS_EINVAL; }
+  const int n_tiles = (n_points + 31) / 32;
+  const int grid = n_tiles < 4 * 64 ? (n_tiles + 3) / 4 : 64;
+  lin8_row0_kernel<<<grid, 256, 0, (hipStream_t)hip_stream>>>(hbuf, ubuf, sbar, n_tiles, n_points, out257);
+  return check_launch("svs_lin8_row0_grad");
+}
+
+int svs_unpack_wgrad(const float* dWk, const float* dbk, int ldw, int map, int rows, int cols, int row_off,
+                     const float* weight_v, const float* weight_g, const float* row0, float* grad_v, float* grad_g,
+                     float* grad_b, void* hip_stream) {
+  if (!dWk || !weight_v || !grad_v || rows < 1 || cols < 1 || map < 0 || map > 2 || (weight_g && !grad_g)) {
+    set_error("svs_unpack_wgrad: bad argument"); return SVS_EINVAL;
+  }
+  UnpackArgs a{dWk, dbk, ldw, map, rows, cols, row_off, weight_v, weight_g, grad_v, grad_g, grad_b, row0};
+  unpack_wgrad_kernel<<<(rows + 3) / 4, 256, 0, (hipStream_t)hip_stream>>>(a);
+  return check_launch("svs_unpack_wgrad");
+}
+
+}  // extern "C"

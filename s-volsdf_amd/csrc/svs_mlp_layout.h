@@ -1,4 +1,4 @@
-// Packed weight-stream layout shared by the pack kernels and the MLP kernels (see svs_mlp.hip).
+// Packed weight-stream layout shared by the pack kernel and the MLP kernels (see svs_mlp.hip).
 #pragma once
 #include "svs_common.h"
 
@@ -15,20 +15,36 @@ constexpr int kChunkF4 = kHdrF4 + kBodyF4;  // 36 KiB
 constexpr int kPeDim = 39;                // 3 * (1 + 2 * 6), embedder.py:38-50 with multires = 6
 constexpr int kChunk0F4 = kHdrF4 + 320;   // SDF layer-0 chunk: header + 20 k-steps (K = 39 -> 40)
 constexpr int kLdsBytes = 2 * kChunkF4 * 16;  // double buffer = 72 KiB
-
-// chunk kinds of the SDF-MLP stream, in stream order
-//   forward : 8 x FWD0 | L1,L2: 8 x FWD | L3: 7 x FWD | L4..L7: 8 x FWD | VEC
-//   full    : forward | 8 x FEAT | L7..L1 reverse: 8 x REV each | 2 x REV0
-constexpr int kSdfFwdChunks = 8 + 7 * 8 - 1 + 1;                    // 64
-constexpr size_t kSdfFwdF4 = 8 * (size_t)kChunk0F4 + (size_t)(kSdfFwdChunks - 8) * kChunkF4;
-constexpr int kSdfFullChunks = kSdfFwdChunks + 8 + 7 * 8 + 2;       // 130
-constexpr size_t kSdfFullF4 = kSdfFwdF4 + (size_t)(kSdfFullChunks - kSdfFwdChunks) * kChunkF4;
-
-// radiance stream: L0: 8 chunks of (hdr + 136 k-steps: 256 feature rows + 16 extra rows) | L1..L3: 8 x FWD | L4: 1 x FWD
-constexpr int kRgbL0BodyF4 = 136 * 16;    // 2176
+constexpr int kRgbL0BodyF4 = 136 * 16;    // radiance layer 0: 128 feature k-steps + 8 k-steps of the 16 extra rows
 constexpr int kRgbChunk0F4 = kHdrF4 + kRgbL0BodyF4;
-constexpr int kRgbChunks = 8 + 3 * 8 + 1;
-constexpr size_t kRgbF4 = 8 * (size_t)kRgbChunk0F4 + 25 * (size_t)kChunkF4;   // last chunk: lin4 (3 rows) as one tile
+constexpr int kW4TF4 = 8 * 64;            // radiance lin4 transposed: 8 tiles x 64 lanes x 4 k-steps
+constexpr int kBlockF = 128 * 64;         // floats of one wave-tile activation block (256 rows x 32 points)
+
+// chunk kinds (svs_pack.hip packs them, the kernels consume them in stream order)
+enum ChunkKind {
+  kSdfFwd0 = 0,   // SDF layer 0, output tile t (K = PE rows)
+  kSdfFwd,        // SDF layer l, output tile t (K = C-layout rows of the layer input; lin4: skip splice, 1/sqrt2)
+  kSdfVec,        // lin8 row 0 (sdf head) as a vector + b8[0]
+  kSdfFeat,       // lin8 rows 1..256 (feature head), tile t
+  kSdfRev,        // W_l^T: output = layer-input rows, K = layer-output rows (gradient pass / backward)
+  kSdfRev0,       // W_0^T onto the PE rows (2 tiles, splice arrangement)
+  kSdfFeatT,      // lin8[1:,:]^T: output = h_8 rows, K = feature-vector index
+  kRgbFwd0,       // radiance layer 0 (K = 256 feature rows + 16 extra rows)
+  kRgbFwd,        // radiance layers 1..4
+  kRgbRev,        // radiance W_l^T, l = 1..3
+  kRgbRev0,       // radiance W_0^T (9 tiles: 8 feature tiles + the extras tile)
+  kRgbW4T,        // radiance lin4^T (3 output rows), short chunk
+};
+constexpr int kNoBias = 0x100;            // flag: zero header
+
+__host__ __device__ constexpr int chunk_f4(int kind) {
+  return kind == kSdfFwd0 ? kChunk0F4 : (kind == kRgbFwd0 ? kRgbChunk0F4 : (kind == kRgbW4T ? kW4TF4 : kChunkF4));
+}
+
+// streams
+enum StreamKind { kStreamSdfFwd = 0, kStreamSdfFull, kStreamSdfTrain, kStreamRgbFwd, kStreamRgbBwd, kNumStreams };
+// offsets inside the SDF training stream (float4): pass A starts at 0, pass B after the 63 forward chunks
+constexpr size_t kSdfTrainPassBF4 = 8 * (size_t)kChunk0F4 + 55 * (size_t)kChunkF4;
 
 }  // namespace mlp
 }  // namespace svs

@@ -1,8 +1,12 @@
 // Weight packing for the fused MLP kernels: weight-norm materialisation (w = g * v / ||v||_row,
 // volsdf/model/network.py:64-65) and the permutation of every layer into the order in which the MFMA
-// k-loops of svs_mlp.hip consume it (chunk format: svs_mlp_layout.h).  Runs once per optimisation step.
+// k-loops of svs_mlp.hip / svs_mlp_bwd.hip consume it (chunk format: svs_mlp_layout.h).  Runs once per
+// optimisation step.  Streams are described by a table of chunk descriptors, so forward, gradient-pass and
+// training-backward streams share one pack kernel.
 #include "svs_common.h"
 #include "svs_mlp_layout.h"
+
+#include <vector>
 
 namespace svs {
 namespace mlp {
@@ -48,139 +52,156 @@ __device__ __forceinline__ float weff(const LayerPtrs& w, const float* scale, in
 
 // column of lin4's weight that multiplies accumulator row i of the spliced layer-4 input
 // (rows 0..216 = h, 217..223 = PE[32..38], 224..255 = PE[0..31]; reference order is cat[h(217), PE(39)])
-__device__ __forceinline__ int l4_col(int i) { return i < 217 ? i : (i < 224 ? 217 + 32 + (i - 217) : 217 + (i - 224)); }
+__device__ __host__ inline int l4_col(int i) { return i < 217 ? i : (i < 224 ? 217 + 32 + (i - 217) : 217 + (i - 224)); }
 
 // PE index carried by output row (tile, local) of the reverse layer-0 product (matches the splice layout)
 __device__ __forceinline__ int rev0_pe(int tile, int local) {
-  if (tile == 0) return local;             // PE[0..31]
+  if (tile == 0) return local;                  // PE[0..31]
   return local >= 25 ? 32 + (local - 25) : -1;  // tile 1: local rows 25..31 -> PE[32..38]
 }
 
-__global__ void pack_sdf_kernel(LayerPtrs w, const float* __restrict__ scale, float* __restrict__ out, int full) {
-  const size_t total = (full ? kSdfFullF4 : kSdfFwdF4) * 4;
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
+struct ChunkDesc { int kind, layer, tile, off_f4; };   // off_f4: offset of the chunk in the stream, in float4
+
+// one workgroup per chunk
+__global__ __launch_bounds__(256) void pack_stream_kernel(LayerPtrs w, const float* __restrict__ scale,
+                                                          const ChunkDesc* __restrict__ table, float* __restrict__ out) {
+  const ChunkDesc d = table[blockIdx.x];
+  const int kind = d.kind & 0xff;
+  const bool nobias = (d.kind & kNoBias) != 0;
+  const int l = d.layer, t = d.tile;
   const float inv_sqrt2 = 0.70710678118654752f;
-  const size_t base1 = 8 * (size_t)kChunk0F4 * 4;
-  float val = 0.0f;
-  if (idx < base1) {
-    // ---- layer 0, tile t
-    const int t = (int)(idx / (kChunk0F4 * 4));
-    const int wi = (int)(idx % (kChunk0F4 * 4));
-    if (wi < kHdrF4 * 4) {
-      const int r = 4 * (wi / 256) + (wi & 3), lane = (wi & 255) >> 2;
-      val = w.b[0][32 * t + rho(r) + 4 * (lane >> 5)];
-    } else {
-      const int wb = wi - kHdrF4 * 4;
-      const int s = 4 * (wb / 256) + (wb & 3), lane = (wb & 255) >> 2;
-      const int q = 2 * s + (lane >> 5);
-      if (q < 39) val = weff(w, scale, 0, 32 * t + (lane & 31), q, 39);
+  float* dst = out + (size_t)d.off_f4 * 4;
+  const int n = chunk_f4(kind) * 4;
+  for (int wi = threadIdx.x; wi < n; wi += 256) {
+    float val = 0.0f;
+    if (kind == kRgbW4T) {
+      // [tile 8][lane 64][4 k-steps]: A = W4^T rows (input feature 32*tile + lane&31), k = rho(s) + 4*half < 3
+      const int tt = wi / 256, lane = (wi & 255) >> 2, s = wi & 3;
+      const int k = rho(s) + 4 * (lane >> 5);
+      if (k < 3) val = weff(w, scale, 4, k, 32 * tt + (lane & 31), 256);
+      dst[wi] = val;
+      continue;
     }
-    out[idx] = val;
-    return;
-  }
-  const size_t rel = idx - base1;
-  const int j = (int)(rel / (kChunkF4 * 4));
-  const int wi = (int)(rel % (kChunkF4 * 4));
-  const bool hdr = wi < kHdrF4 * 4;
-  const int wb = hdr ? wi : wi - kHdrF4 * 4;
-  const int lane = (wb & 255) >> 2, half = lane >> 5, col32 = lane & 31;
-  const int sr = 4 * (wb / 256) + (wb & 3);              // hdr: accumulator register r; body: k-step s
-  const int crow = 32 * (sr / 16) + rho(sr % 16) + 4 * half;  // body: C-layout row addressed by k-step s
-
-  // decode chunk j
-  int kind, l, t;  // kind 0 FWD, 1 VEC, 2 FEAT, 3 REV, 4 REV0
-  if (j < 55) {
-    kind = 0;
-    if (j < 16) { l = 1 + j / 8; t = j % 8; }
-    else if (j < 23) { l = 3; t = j - 16; }
-    else { l = 4 + (j - 23) / 8; t = (j - 23) % 8; }
-  } else if (j == 55) { kind = 1; l = 8; t = 0; }
-  else if (j < 64) { kind = 2; l = 8; t = j - 56; }
-  else if (j < 120) { kind = 3; l = 7 - (j - 64) / 8; t = (j - 64) % 8; }
-  else { kind = 4; l = 0; t = j - 120; }
-
-  if (kind == 0 || kind == 2) {
-    const int rows = sdf_rows(l);
-    if (hdr) {
-      const int o = (kind == 2 ? 1 : 0) + 32 * t + rho(sr) + 4 * half;
-      if (o < rows) val = w.b[l][o];
-    } else {
-      const int o = (kind == 2 ? 1 : 0) + 32 * t + col32;
-      if (o < rows) {
-        if (l == 4) val = weff(w, scale, 4, o, l4_col(crow), 256) * inv_sqrt2;
-        else val = weff(w, scale, l, o, crow, 256);
+    const bool hdr = wi < kHdrF4 * 4;
+    const int wb = hdr ? wi : wi - kHdrF4 * 4;
+    const int lane = (wb & 255) >> 2, half = lane >> 5, col32 = lane & 31;
+    const int sr = 4 * (wb / 256) + (wb & 3);                   // hdr: accumulator register r; body: k-step s
+    const int crow = 32 * (sr / 16) + rho(sr % 16) + 4 * half;  // body: C-layout row addressed by k-step s
+    switch (kind) {
+      case kSdfFwd0:
+        if (hdr) { if (!nobias) val = w.b[0][32 * t + rho(sr) + 4 * half]; }
+        else { const int q = 2 * sr + half; if (q < 39) val = weff(w, scale, 0, 32 * t + col32, q, 39); }
+        break;
+      case kSdfFwd:
+      case kSdfFeat: {
+        const int rows = sdf_rows(l), off = kind == kSdfFeat ? 1 : 0;
+        if (hdr) { const int o = off + 32 * t + rho(sr) + 4 * half; if (o < rows && !nobias) val = w.b[l][o]; }
+        else {
+          const int o = off + 32 * t + col32;
+          if (o < rows) val = l == 4 ? weff(w, scale, 4, o, l4_col(crow), 256) * inv_sqrt2 : weff(w, scale, l, o, crow, 256);
+        }
+        break;
       }
-    }
-  } else if (kind == 1) {
-    if (hdr) val = w.b[8][0];
-    else val = weff(w, scale, 8, 0, crow, 256);
-  } else if (kind == 3) {
-    // reverse of layer l: out row = input feature i_out (C-layout row of the layer's input), k = output feature
-    if (!hdr) {
-      const int i_out = 32 * t + col32;
-      const int k = crow;
-      if (k < sdf_rows(l)) {
-        if (l == 4) val = weff(w, scale, 4, k, l4_col(i_out), 256) * inv_sqrt2;
-        else val = weff(w, scale, l, k, i_out, 256);
+      case kSdfVec:
+        val = hdr ? w.b[8][0] : weff(w, scale, 8, 0, crow, 256);
+        break;
+      case kSdfRev:
+        // reverse of layer l: out row = input feature i_out (C-layout row of the layer's input), k = output feature
+        if (!hdr && crow < sdf_rows(l)) {
+          const int i_out = 32 * t + col32;
+          val = l == 4 ? weff(w, scale, 4, crow, l4_col(i_out), 256) * inv_sqrt2 : weff(w, scale, l, crow, i_out, 256);
+        }
+        break;
+      case kSdfRev0:
+        if (!hdr) { const int q = rev0_pe(t, col32); if (q >= 0) val = weff(w, scale, 0, crow, q, 39); }
+        break;
+      case kSdfFeatT:
+        // h_bar_8 += W8[1:,:]^T f_bar : out row = h_8 feature (32t+col), k = feature-vector index
+        if (!hdr) val = weff(w, scale, 8, 1 + crow, 32 * t + col32, 256);
+        break;
+      case kRgbFwd0:
+        if (hdr) { if (!nobias) val = w.b[0][32 * t + rho(sr) + 4 * half]; }
+        else {
+          const int o = 32 * t + col32;
+          if (sr < 128) val = weff(w, scale, 0, o, 15 + crow, 271);
+          else { const int e = rho(sr - 128) + 4 * half; if (e < 15) val = weff(w, scale, 0, o, e, 271); }
+        }
+        break;
+      case kRgbFwd: {
+        const int rows = rgb_rows(l);
+        if (hdr) { const int o = 32 * t + rho(sr) + 4 * half; if (o < rows && !nobias) val = w.b[l][o]; }
+        else { const int o = 32 * t + col32; if (o < rows) val = weff(w, scale, l, o, crow, 256); }
+        break;
       }
+      case kRgbRev:
+        if (!hdr) val = weff(w, scale, l, crow, 32 * t + col32, 256);
+        break;
+      case kRgbRev0:
+        // out row = layer-0 input in kernel order: tiles 0..7 feature rows (param col 15+row), tile 8 the 16 extras
+        if (!hdr) {
+          const int pc = t < 8 ? 15 + 32 * t + col32 : (col32 < 15 ? col32 : -1);
+          if (pc >= 0) val = weff(w, scale, 0, crow, pc, 271);
+        }
+        break;
+      default: break;
     }
-  } else {
-    if (!hdr) {
-      const int q = rev0_pe(t, col32);
-      if (q >= 0) val = weff(w, scale, 0, crow, q, 39);
-    }
+    dst[wi] = val;
   }
-  out[idx] = val;
 }
 
-// radiance stream (mode 'idr', network.py:174-176: cat[points(3), PE1(view)(9), normals(3), feature(256)])
-__global__ void pack_rgb_kernel(LayerPtrs w, const float* __restrict__ scale, float* __restrict__ out) {
-  const size_t total = kRgbF4 * 4;
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
-  const size_t base1 = 8 * (size_t)kRgbChunk0F4 * 4;
-  float val = 0.0f;
-  if (idx < base1) {
-    const int t = (int)(idx / (kRgbChunk0F4 * 4));
-    const int wi = (int)(idx % (kRgbChunk0F4 * 4));
-    if (wi < kHdrF4 * 4) {
-      const int r = 4 * (wi / 256) + (wi & 3), lane = (wi & 255) >> 2;
-      val = w.b[0][32 * t + rho(r) + 4 * (lane >> 5)];
-    } else {
-      const int wb = wi - kHdrF4 * 4;
-      const int s = 4 * (wb / 256) + (wb & 3), lane = (wb & 255) >> 2, half = lane >> 5;
-      const int o = 32 * t + (lane & 31);
-      if (s < 128) {
-        const int crow = 32 * (s / 16) + rho(s % 16) + 4 * half;   // feature row
-        val = weff(w, scale, 0, o, 15 + crow, 271);
-      } else {
-        const int e = rho(s - 128) + 4 * half;                     // extra row 0..15
-        if (e < 15) val = weff(w, scale, 0, o, e, 271);
+// ------------------------------------------------------------------------------------------------------------
+// stream tables (host)
+// ------------------------------------------------------------------------------------------------------------
+struct StreamTable {
+  std::vector<ChunkDesc> host;
+  ChunkDesc* dev = nullptr;
+  size_t total_f4 = 0;
+  void add(int kind, int layer, int tile) {
+    host.push_back(ChunkDesc{kind, layer, tile, (int)total_f4});
+    total_f4 += chunk_f4(kind & 0xff);
+  }
+};
+
+static void sdf_forward_part(StreamTable& t, int flags) {
+  for (int i = 0; i < 8; ++i) t.add(kSdfFwd0 | flags, 0, i);
+  for (int l = 1; l < 8; ++l)
+    for (int i = 0; i < (l == 3 ? 7 : 8); ++i) t.add(kSdfFwd | flags, l, i);
+}
+
+static StreamTable& table_for(int which) {
+  static StreamTable tabs[kNumStreams];
+  StreamTable& t = tabs[which];
+  if (!t.host.empty()) return t;
+  switch (which) {
+    case kStreamSdfFwd:
+    case kStreamSdfFull:
+      sdf_forward_part(t, 0);
+      t.add(kSdfVec, 8, 0);
+      if (which == kStreamSdfFull) {
+        for (int i = 0; i < 8; ++i) t.add(kSdfFeat, 8, i);
+        for (int l = 7; l >= 1; --l) for (int i = 0; i < 8; ++i) t.add(kSdfRev, l, i);
+        for (int i = 0; i < 2; ++i) t.add(kSdfRev0, 0, i);
       }
-    }
-    out[idx] = val;
-    return;
+      break;
+    case kStreamSdfTrain:
+      // pass A (second-order sweep): the forward trunk without biases; pass B: transposed feature head, then the
+      // transposed trunk
+      sdf_forward_part(t, kNoBias);
+      for (int i = 0; i < 8; ++i) t.add(kSdfFeatT, 8, i);
+      for (int l = 7; l >= 1; --l) for (int i = 0; i < 8; ++i) t.add(kSdfRev, l, i);
+      break;
+    case kStreamRgbFwd:
+      for (int i = 0; i < 8; ++i) t.add(kRgbFwd0, 0, i);
+      for (int l = 1; l < 4; ++l) for (int i = 0; i < 8; ++i) t.add(kRgbFwd, l, i);
+      t.add(kRgbFwd, 4, 0);
+      break;
+    case kStreamRgbBwd:
+      t.add(kRgbW4T, 4, 0);
+      for (int l = 3; l >= 1; --l) for (int i = 0; i < 8; ++i) t.add(kRgbRev, l, i);
+      for (int i = 0; i < 9; ++i) t.add(kRgbRev0, 0, i);
+      break;
   }
-  const size_t rel = idx - base1;
-  const int j = (int)(rel / (kChunkF4 * 4));
-  const int wi = (int)(rel % (kChunkF4 * 4));
-  const bool hdr = wi < kHdrF4 * 4;
-  const int wb = hdr ? wi : wi - kHdrF4 * 4;
-  const int lane = (wb & 255) >> 2, half = lane >> 5, col32 = lane & 31;
-  const int sr = 4 * (wb / 256) + (wb & 3);
-  const int crow = 32 * (sr / 16) + rho(sr % 16) + 4 * half;
-  const int l = j < 24 ? 1 + j / 8 : 4;
-  const int t = j < 24 ? j % 8 : 0;
-  const int rows = rgb_rows(l);
-  if (hdr) {
-    const int o = 32 * t + rho(sr) + 4 * half;
-    if (o < rows) val = w.b[l][o];
-  } else {
-    const int o = 32 * t + col32;
-    if (o < rows) val = weff(w, scale, l, o, crow, 256);
-  }
-  out[idx] = val;
+  return t;
 }
 
 }  // namespace mlp
@@ -191,37 +212,48 @@ using namespace svs::mlp;
 
 extern "C" {
 
-size_t svs_sdf_stream_bytes(int full) { return (full ? kSdfFullF4 : kSdfFwdF4) * 16 ; }
-size_t svs_rgb_stream_bytes(void) { return kRgbF4 * 16; }
+// which: 0 SDF forward, 1 SDF full (forward + feature head + gradient pass), 2 SDF training backward,
+//        3 radiance forward, 4 radiance backward
+size_t svs_stream_bytes(int which) {
+  if (which < 0 || which >= kNumStreams) return 0;
+  return table_for(which).total_f4 * 16;
+}
+size_t svs_sdf_stream_bytes(int full) { return svs_stream_bytes(full ? kStreamSdfFull : kStreamSdfFwd); }
+size_t svs_rgb_stream_bytes(void) { return svs_stream_bytes(kStreamRgbFwd); }
 size_t svs_pack_workspace_bytes(void) { return 9 * kScaleStride * sizeof(float); }
+
+// weight_v / weight_g / bias: HOST arrays of 9 (SDF) or 5 (radiance) device pointers; weight_g may be NULL.
+int svs_pack_stream(int which, const float* const* weight_v, const float* const* weight_g, const float* const* bias,
+                    float* workspace, float* stream_out, void* hip_stream) {
+  if (which < 0 || which >= kNumStreams || !weight_v || !bias || !workspace || !stream_out) {
+    set_error("svs_pack_stream: bad argument"); return SVS_EINVAL;
+  }
+  const bool is_rgb = which >= kStreamRgbFwd;
+  const int nl = is_rgb ? 5 : 9;
+  LayerPtrs w = {};
+  for (int l = 0; l < nl; ++l) {
+    w.v[l] = weight_v[l]; w.g[l] = weight_g ? weight_g[l] : nullptr; w.b[l] = bias[l];
+    if (!w.v[l] || !w.b[l]) { set_error("svs_pack_stream: null layer %d", l); return SVS_EINVAL; }
+  }
+  StreamTable& t = table_for(which);
+  if (!t.dev) {
+    hipError_t e = hipMalloc(&t.dev, t.host.size() * sizeof(ChunkDesc));
+    if (e == hipSuccess) e = hipMemcpy(t.dev, t.host.data(), t.host.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { set_error("svs_pack_stream: table upload: %s", hipGetErrorString(e)); t.dev = nullptr; return (int)e; }
+  }
+  hipStream_t s = (hipStream_t)hip_stream;
+  rownorm_kernel<<<(nl * kScaleStride + 3) / 4, 256, 0, s>>>(w, nl, is_rgb ? 1 : 0, workspace);
+  pack_stream_kernel<<<(unsigned)t.host.size(), 256, 0, s>>>(w, workspace, t.dev, stream_out);
+  return check_launch("svs_pack_stream");
+}
 
 int svs_sdf_pack(const float* const* weight_v, const float* const* weight_g, const float* const* bias,
                  float* workspace, float* stream_out, int full, void* hip_stream) {
-  if (!weight_v || !bias || !workspace || !stream_out) { set_error("svs_sdf_pack: null argument"); return SVS_EINVAL; }
-  LayerPtrs w;
-  for (int l = 0; l < 9; ++l) {
-    w.v[l] = weight_v[l]; w.g[l] = weight_g ? weight_g[l] : nullptr; w.b[l] = bias[l];
-    if (!w.v[l] || !w.b[l]) { set_error("svs_sdf_pack: null layer %d", l); return SVS_EINVAL; }
-  }
-  hipStream_t s = (hipStream_t)hip_stream;
-  rownorm_kernel<<<(9 * kScaleStride + 3) / 4, 256, 0, s>>>(w, 9, 0, workspace);
-  const size_t total = (full ? kSdfFullF4 : kSdfFwdF4) * 4;
-  pack_sdf_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(w, workspace, stream_out, full);
-  return check_launch("svs_sdf_pack");
+  return svs_pack_stream(full ? kStreamSdfFull : kStreamSdfFwd, weight_v, weight_g, bias, workspace, stream_out, hip_stream);
 }
-
 int svs_rgb_pack(const float* const* weight_v, const float* const* weight_g, const float* const* bias,
                  float* workspace, float* stream_out, void* hip_stream) {
-  if (!weight_v || !bias || !workspace || !stream_out) { set_error("svs_rgb_pack: null argument"); return SVS_EINVAL; }
-  LayerPtrs w = {};
-  for (int l = 0; l < 5; ++l) {
-    w.v[l] = weight_v[l]; w.g[l] = weight_g ? weight_g[l] : nullptr; w.b[l] = bias[l];
-    if (!w.v[l] || !w.b[l]) { set_error("svs_rgb_pack: null layer %d", l); return SVS_EINVAL; }
-  }
-  hipStream_t s = (hipStream_t)hip_stream;
-  rownorm_kernel<<<(5 * kScaleStride + 3) / 4, 256, 0, s>>>(w, 5, 1, workspace);
-  pack_rgb_kernel<<<(unsigned)((kRgbF4 * 4 + 255) / 256), 256, 0, s>>>(w, workspace, stream_out);
-  return check_launch("svs_rgb_pack");
+  return svs_pack_stream(kStreamRgbFwd, weight_v, weight_g, bias, workspace, stream_out, hip_stream);
 }
 
 }  // extern "C"

@@ -15,7 +15,6 @@ namespace svs {
 namespace wgrad {
 
 constexpr int kPitch = 33;
-constexpr int kBlockF = 128 * 64;     // floats per wave-tile block
 
 struct Pair {
   const float* a;        // blocks [n_tiles][block_stride_a]: A rows (output features / gradients)

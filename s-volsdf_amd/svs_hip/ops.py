@@ -115,7 +115,7 @@ def sdf_vals(packed, src, sphere_radius, sphere_scale, out=None, gate=None, clam
     return sdf
 
 
-def sdf_outputs(packed, src, sphere_radius, sphere_scale, want_feature_rows=False, clamp_n=-1):
+def sdf_outputs(packed, src, sphere_radius, sphere_scale, want_feature_rows=False, clamp_n=-1, keep=None):
     """ImplicitNetwork.get_outputs (network.py:105-123): sdf (P,1), d sdf/dx (P,3), feature tiles, hbuf.
 
     The sphere clamp (network.py:110-112) applies to the first clamp_n points (-1: all); the others, and all
@@ -127,9 +127,14 @@ def sdf_outputs(packed, src, sphere_radius, sphere_scale, want_feature_rows=Fals
     grad = torch.empty(src.n, 3, device=dev)
     feat = torch.empty(L.svs_feat_tiles_bytes(src.n) // 4, device=dev)
     hbuf = torch.empty(L.svs_sdf_hbuf_bytes(src.n) // 4, device=dev)
+    gbuf = mask = None
+    if keep is not None:          # training: keep the gradient-pass state for the backward kernels
+        gbuf = torch.empty(L.svs_sdf_hbuf_bytes(src.n) // 4, device=dev)
+        mask = torch.empty(src.n, dtype=torch.uint8, device=dev)
+        keep.update(hbuf=hbuf, gbuf=gbuf, clamp_mask=mask, src=src)
     _lib.check(L.svs_sdf_outputs(*src.args(), _ptr(packed.sdf_stream), float(sphere_radius), float(sphere_scale),
-                                 int(clamp_n), _ptr(sdf), _ptr(grad), _ptr(feat), _ptr(hbuf), _stream()),
-               "svs_sdf_outputs")
+                                 int(clamp_n), _ptr(sdf), _ptr(grad), _ptr(feat), _ptr(hbuf), _ptr(gbuf), _ptr(mask),
+                                 _stream()), "svs_sdf_outputs")
     rows = None
     if want_feature_rows:
         rows = torch.empty(src.n, 256, device=dev)
@@ -137,7 +142,7 @@ def sdf_outputs(packed, src, sphere_radius, sphere_scale, want_feature_rows=Fals
     return sdf, grad, feat, hbuf, rows
 
 
-def rgb_eval(packed, src, normals, view_dirs, feat_tiles):
+def rgb_eval(packed, src, normals, view_dirs, feat_tiles, keep=None):
     """RenderingNetwork.forward, mode 'idr' (network.py:170-190) -> (P,3).
     view_dirs: (R,3) with src in ray mode (one direction per ray), or (P,3)."""
     L = _lib.load()
@@ -146,8 +151,12 @@ def rgb_eval(packed, src, normals, view_dirs, feat_tiles):
     if view_S == 0:
         assert view_dirs.shape[0] == src.n
     rgb = torch.empty(src.n, 3, device=src.device)
+    rbuf = None
+    if keep is not None:
+        rbuf = torch.empty(L.svs_rgb_rbuf_bytes(src.n) // 4, device=src.device)
+        keep.update(rbuf=rbuf, feat_tiles=feat_tiles, rgb=rgb)
     _lib.check(L.svs_rgb_eval(*src.args(), _ptr(normals), _ptr(view_dirs), view_S, _ptr(feat_tiles),
-                              _ptr(packed.rgb_stream), _ptr(rgb), _stream()), "svs_rgb_eval")
+                              _ptr(packed.rgb_stream), _ptr(rgb), _ptr(rbuf), _stream()), "svs_rgb_eval")
     return rgb
 
 

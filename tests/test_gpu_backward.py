@@ -88,3 +88,111 @@ def test_wgrad_gemm(dev, P):
     ref = A0.astype(np.float64).T @ B0 + (A1 * (1 - np.exp(-100.0 * H1.astype(np.float64)))).T @ B1
     assert rel_err(dW.cpu().numpy(), ref) < 2e-5
     assert rel_err(db.cpu().numpy(), A0.astype(np.float64).sum(0)) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------------
+# full MLP backward (double backward through the normals) against torch autograd in float64
+# ------------------------------------------------------------------------------------------------------
+def _t64(params, requires_grad=True):
+    return {k: torch.tensor(np.asarray(v, np.float64), requires_grad=requires_grad and k != "density.beta")
+            for k, v in params.items()}
+
+
+def _wn(p, prefix, l):
+    v, g = p[f"{prefix}.lin{l}.weight_v"], p[f"{prefix}.lin{l}.weight_g"]
+    return g * v / v.norm(dim=1, keepdim=True)
+
+
+def _pe(x, L):
+    out = [x]
+    for k in range(L):
+        out += [torch.sin(x * 2.0 ** k), torch.cos(x * 2.0 ** k)]
+    return torch.cat(out, -1)
+
+
+def _sdf_mlp(p, x):
+    inp = _pe(x, 6)
+    h = inp
+    for l in range(9):
+        if l == 4:
+            h = torch.cat([h, inp], 1) / np.sqrt(2)
+        h = h @ _wn(p, "implicit_network", l).T + p[f"implicit_network.lin{l}.bias"]
+        if l < 8:
+            h = torch.nn.functional.softplus(h, beta=100)
+    return h
+
+
+def _rgb_mlp(p, x, n, d, feat):
+    h = torch.cat([x, _pe(d, 1), n, feat], -1)
+    for l in range(5):
+        h = h @ _wn(p, "rendering_network", l).T + p[f"rendering_network.lin{l}.bias"]
+        if l < 4:
+            h = torch.relu(h)
+    return torch.sigmoid(h)
+
+
+def test_mlp_backward_vs_autograd(dev, ops):
+    from svs_hip.train import MlpBackward
+    params = synth.make_params(0)
+    rng = np.random.default_rng(77)
+    K, pose = synth.make_camera()
+    R, S, NE = 8, 32, 96
+    uv = synth.make_uv(R, seed=3)
+    dirs, cam, _ = orc.rays_from_uv(uv, pose, K)
+    z = np.sort(rng.uniform(0.3, 5.9, (R, S)), -1).astype(F32)      # far samples leave the r=3 sphere -> clamp
+    x_main = (cam[None, None] + z[:, :, None] * dirs[:, None, :]).astype(F32).reshape(-1, 3)
+    x_eik = rng.uniform(-1.5, 1.5, (NE, 3)).astype(F32)
+    Wr = rng.normal(0, 1, (R * S, 3)).astype(F32)
+    ws = rng.normal(0, 1, (R * S, 1)).astype(F32)
+    Wg = rng.normal(0, 0.1, (NE, 3)).astype(F32)
+
+    # ---- torch float64 reference
+    p = _t64(params)
+    xm = torch.tensor(x_main.astype(np.float64), requires_grad=True)
+    out = _sdf_mlp(p, xm)
+    sphere = 20.0 * (3.0 - xm.norm(2, 1, keepdim=True))
+    sdf_c = torch.minimum(out[:, :1], sphere)
+    grad = torch.autograd.grad(sdf_c.sum(), xm, create_graph=True)[0]
+    dflat = torch.tensor(np.repeat(dirs[:, None, :], S, 1).reshape(-1, 3).astype(np.float64))
+    rgb = _rgb_mlp(p, xm, grad, dflat, out[:, 1:])
+    xe = torch.tensor(x_eik.astype(np.float64), requires_grad=True)
+    gt = torch.autograd.grad(_sdf_mlp(p, xe)[:, :1].sum(), xe, create_graph=True)[0]
+    loss = (rgb * torch.tensor(Wr, dtype=torch.float64)).sum() + (sdf_c * torch.tensor(ws, dtype=torch.float64)).sum() \
+        + (gt * torch.tensor(Wg, dtype=torch.float64)).sum()
+    loss.backward()
+    assert (sphere < out[:, :1]).any() and (sphere > out[:, :1]).any()
+
+    # ---- HIP
+    pk = ops.PackedMlp(dev)
+    t = lambda k: G(params[k], dev)
+    sdf_p = ([t(f"implicit_network.lin{l}.weight_v") for l in range(9)], [t(f"implicit_network.lin{l}.weight_g") for l in range(9)],
+             [t(f"implicit_network.lin{l}.bias") for l in range(9)])
+    rgb_p = ([t(f"rendering_network.lin{l}.weight_v") for l in range(5)], [t(f"rendering_network.lin{l}.weight_g") for l in range(5)],
+             [t(f"rendering_network.lin{l}.bias") for l in range(5)])
+    pk.pack_sdf(*sdf_p)
+    pk.pack_rgb(*rgb_p)
+    keep = {}
+    src = ops.PointSource(points=G(x_eik, dev), cam=G(cam, dev), dirs=G(dirs, dev), z=G(z, dev))
+    sdf, gradients, feat_tiles, _, _ = ops.sdf_outputs(pk, src, 3.0, 20.0, clamp_n=R * S, keep=keep)
+    np.testing.assert_allclose(sdf[:R * S].cpu().numpy(), sdf_c.detach().numpy(), atol=1e-4)
+    np.testing.assert_allclose(gradients[R * S:].cpu().numpy(), gt.detach().numpy(), atol=2e-4)
+    src_main = ops.PointSource(cam=G(cam, dev), dirs=G(dirs, dev), z=G(z, dev))
+    rgb_h = ops.rgb_eval(pk, src_main, gradients[:R * S], G(dirs, dev), feat_tiles, keep=keep)
+    np.testing.assert_allclose(rgb_h.cpu().numpy(), rgb.detach().numpy(), atol=1e-4)
+    bw = MlpBackward(dev)
+    sdf_g, rgb_g = bw.run(sdf_p, rgb_p, keep, G(Wr, dev), G(ws, dev), G(Wg, dev))
+    torch.cuda.synchronize()
+    worst = 0.0
+    for l in range(5):
+        for name, got in zip(("weight_v", "weight_g", "bias"), rgb_g[l]):
+            ref = p[f"rendering_network.lin{l}.{name}"].grad.numpy()
+            e = rel_err(got.cpu().numpy().reshape(ref.shape), ref)
+            worst = max(worst, e)
+            assert e < 2e-3, (f"rendering lin{l}.{name}", e)
+    for l in range(9):
+        for name, got in zip(("weight_v", "weight_g", "bias"), sdf_g[l]):
+            ref = p[f"implicit_network.lin{l}.{name}"].grad.numpy()
+            e = rel_err(got.cpu().numpy().reshape(ref.shape), ref)
+            worst = max(worst, e)
+            assert e < 2e-3, (f"implicit lin{l}.{name}", e)
+    print("worst relative gradient error", worst)
