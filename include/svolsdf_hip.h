@@ -166,6 +166,14 @@ int svs_unpack_wgrad(const float* dWk, const float* dbk, int ldw, int map, int r
                      const float* weight_v, const float* weight_g, const float* row0, float* grad_v, float* grad_g,
                      float* grad_b, void* hip_stream);
 
+/* ---- a12  optimiser step ---------------------------------------------------------------------------------------
+ * clip_grad_norm_(1.0) + NaN/Inf guard + Adam of VolOpt.train_step (volsdf/vsdf.py:214-219,454-463,101-102) on flat
+ * float32 buffers, no host sync.  step: 1-based.  info (2 floats, may be NULL): gradient norm, update dropped (0/1). */
+size_t svs_adam_workspace_bytes(void);
+int svs_clip_guard_adam(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long long n, int step,
+                        float max_norm, float lr, float beta1, float beta2, float eps, void* workspace, float* info,
+                        void* hip_stream);
+
 /* ---- a10  MVS prior lookup ----------------------------------------------------------------------------
  * VolOpt.cost_mapping (volsdf/vsdf.py:382-452).  Points: xyz (n_points,3) or, when xyz == NULL, cam + z*dir with
  * z (n_points/S, S).  view_params: HOST float array, 17 per view: fx, fy, cx, cy, sk, c2w rows (3x4).

@@ -1,0 +1,90 @@
+// Fused optimiser step on a flat float32 parameter buffer: global-norm gradient clipping, NaN/Inf guard and Adam,
+// with no host synchronisation.
+//
+// Reference: volsdf/vsdf.py:214-219 -- torch.nn.utils.clip_grad_norm_(params, 1.0), on_after_backward (:454-463: if any
+// gradient entry is NaN/Inf the gradients are zeroed and the step still runs, as torch 1.9's zero_grad() does),
+// torch.optim.Adam(lr=5e-4) (:101-102; betas (0.9,0.999), eps 1e-8, no weight decay).
+#include "svs_common.h"
+
+namespace svs {
+namespace optim {
+
+constexpr int kBlocks = 256;
+
+// stage 1: per-block partial sum of squares (float64) and non-finite count
+__global__ __launch_bounds__(256) void grad_stats_kernel(const float* __restrict__ g, long long n, double* __restrict__ part,
+                                                         int* __restrict__ bad) {
+  __shared__ double sh[4];
+  __shared__ int shb[4];
+  double acc = 0.0;
+  int nb = 0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float v = g[i];
+    if (!(__builtin_fabsf(v) <= 3.4028234e38f)) nb = 1;     // NaN or Inf
+    acc += (double)v * (double)v;
+  }
+  for (int d = 32; d >= 1; d >>= 1) { acc += __shfl_xor(acc, d); nb |= __shfl_xor(nb, d); }
+  if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = acc; shb[threadIdx.x >> 6] = nb; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    bad[blockIdx.x] = shb[0] | shb[1] | shb[2] | shb[3];
+  }
+}
+
+// stage 2: every block reduces the partials in the same fixed order (reproducible), then updates its slice
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long long n, const double* __restrict__ part,
+                                                   const int* __restrict__ bad, int n_part, float max_norm, float lr,
+                                                   float beta1, float beta2, float eps, float bc1, float bc2_sqrt,
+                                                   float* __restrict__ info) {
+  double tot = 0.0;
+  int nb = 0;
+  for (int i = 0; i < n_part; ++i) { tot += part[i]; nb |= bad[i]; }
+  const float total_norm = (float)__builtin_sqrt(tot);
+  float coef = max_norm > 0.0f ? max_norm / (total_norm + 1e-6f) : 1.0f;     // clip_grad_norm_
+  coef = coef > 1.0f ? 1.0f : coef;
+  const bool drop = nb != 0 || !(total_norm <= 3.4028234e38f);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && info) { info[0] = total_norm; info[1] = drop ? 1.0f : 0.0f; }
+  const float step_size = lr / bc1;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float gi = drop ? 0.0f : g[i] * coef;
+    g[i] = gi;                                          // the clipped (or zeroed) gradient stays visible, as in torch
+    const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = __builtin_sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+  }
+}
+
+}  // namespace optim
+}  // namespace svs
+
+using namespace svs;
+using namespace svs::optim;
+
+extern "C" {
+
+size_t svs_adam_workspace_bytes(void) { return kBlocks * (sizeof(double) + sizeof(int)); }
+
+// step: 1-based Adam step count.  workspace: svs_adam_workspace_bytes().  info (2 floats, may be NULL): the
+// gradient norm before clipping and whether the update was dropped (non-finite gradient).
+int svs_clip_guard_adam(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long long n, int step,
+                        float max_norm, float lr, float beta1, float beta2, float eps, void* workspace, float* info,
+                        void* hip_stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !workspace || n <= 0 || step < 1) {
+    set_error("svs_clip_guard_adam: bad argument"); return SVS_EINVAL;
+  }
+  double* part = (double*)workspace;
+  int* bad = (int*)(part + kBlocks);
+  hipStream_t s = (hipStream_t)hip_stream;
+  grad_stats_kernel<<<kBlocks, 256, 0, s>>>(grads, n, part, bad);
+  const double bc1 = 1.0 - __builtin_pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - __builtin_pow((double)beta2, (double)step);
+  adam_kernel<<<kBlocks, 256, 0, s>>>(params, grads, exp_avg, exp_avg_sq, n, part, bad, kBlocks, max_norm, lr, beta1, beta2,
+                                      eps, (float)bc1, (float)__builtin_sqrt(bc2), info);
+  return check_launch("svs_clip_guard_adam");
+}
+
+}  // extern "C"

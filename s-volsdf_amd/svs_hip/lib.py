@@ -59,6 +59,9 @@ SIGNATURES = {
     "svs_wgrad": (c_int, [_P, _P, _P, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, _P, _P, _P,
                           ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, _P, ctypes.c_longlong, c_int, _P, c_int,
                           _P, _P]),
+    "svs_adam_workspace_bytes": (c_size_t, []),
+    "svs_clip_guard_adam": (c_int, [_P, _P, _P, _P, ctypes.c_longlong, c_int, c_float, c_float, c_float, c_float, c_float,
+                                    _P, _P, _P]),
     "svs_cost_lookup": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, POINTER(c_float),
                                 _PP, _PP, _PP, POINTER(c_int), _P, _P, _P, _P]),
     "svs_loss": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float,

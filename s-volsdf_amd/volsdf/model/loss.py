@@ -52,5 +52,22 @@ class VolSDFLoss(nn.Module):
             confi=float(self.confi), annealed=annealed and has_mvs, anneal_sparse=float(anneal_sparse))
         self.last_grads = grads
         self.iter_step += 1
+        total = losses[4]
+        diff = [k for k in ('rgb_values', 'grad_theta', 'weights', 'depth_values')
+                if k in model_outputs and torch.is_tensor(model_outputs[k]) and model_outputs[k].requires_grad]
+        if diff:
+            # connect the fused loss to autograd so that the reference's `loss.backward()` (vsdf.py:215) works
+            total = _FusedLossFunction.apply(losses, grads, diff, *[model_outputs[k] for k in diff])
         return {'rgb_loss': losses[0], 'eikonal_loss': losses[1], 'mvs_loss': losses[2], 'sparse_loss': losses[3],
-                'loss': losses[4]}
+                'loss': total}
+
+
+class _FusedLossFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, losses, grads, names, *tensors):
+        ctx.grads = [grads[n].reshape(t.shape) for n, t in zip(names, tensors)]
+        return losses[4].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None, None, None, *[g * x for x in ctx.grads])

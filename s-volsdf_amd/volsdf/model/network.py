@@ -164,7 +164,43 @@ class VolSDFNetwork(nn.Module):
         self.rendering_network.pack_into(self._pk)
         return self._pk
 
+    # ---- parameters in a fixed order (shared by the autograd bridge and the fused trainer) -----------------
+    def mlp_params(self):
+        """((sdf weight_v, weight_g, bias), (rgb weight_v, weight_g, bias)) as lists per layer."""
+        def grab(net, n):
+            lins = [getattr(net, f"lin{l}") for l in range(n)]
+            if net.weight_norm:
+                return [m.weight_v for m in lins], [m.weight_g for m in lins], [m.bias for m in lins]
+            return [m.weight for m in lins], None, [m.bias for m in lins]
+        return grab(self.implicit_network, 9), grab(self.rendering_network, 5)
+
+    def _flat_param_list(self):
+        (sv, sg, sb), (rv, rg, rb) = self.mlp_params()
+        out = []
+        for v, g, b in ((sv, sg, sb), (rv, rg, rb)):
+            for l in range(len(v)):
+                out += [v[l]] + ([g[l]] if g is not None else []) + [b[l]]
+        return out + [self.density.beta]
+
+    def invalidate_packed(self):
+        """Call after parameters were changed outside torch's version counter (fused optimiser kernel)."""
+        self.implicit_network._packed_key = None
+        if self._pk is not None:
+            self._pk._sdf_key = self._pk._rgb_key = None
+
     def forward(self, input, fast=-1):
+        if self.training and torch.is_grad_enabled():
+            if self.white_bkgd:
+                raise NotImplementedError("white_bkgd training is not wired to the backward kernels (default is False)")
+            params = self._flat_param_list()
+            res = _RenderFunction.apply(self, input, fast, *params)
+            rgb_values, depth_values, weights, grad_theta, depth_vals, xyz = res
+            return {'rgb_values': rgb_values, 'depth_values': depth_values, 'depth_vals': depth_vals, 'weights': weights,
+                    'xyz': xyz, 'grad_theta': grad_theta}
+        return self._forward_impl(input, fast, None)
+
+    def _forward_impl(self, input, fast, keep):
+        """network.py:206-279 on the HIP kernels.  keep: dict that receives what the backward kernels need."""
         intrinsics, uv, pose = input["intrinsics"], input["uv"], input["pose"]
         if uv.shape[0] != 1:
             raise NotImplementedError("batch_size 1 only (runner.py:166)")
@@ -187,13 +223,16 @@ class VolSDFNetwork(nn.Module):
             eikonal_points = torch.cat([eikonal_points, eik_near], 0)
         src = ops.PointSource(points=eikonal_points, cam=cam_loc, dirs=ray_dirs, z=z_vals)
         sdf, gradients, feat_tiles, _, _ = ops.sdf_outputs(pk, src, net.sdf_bounding_sphere, net.sphere_scale,
-                                                           clamp_n=n_main)
+                                                           clamp_n=n_main, keep=keep)
         grad_theta = gradients[n_main:]
         sdf, gradients = sdf[:n_main], gradients[:n_main]
         src_main = ops.PointSource(cam=cam_loc, dirs=ray_dirs, z=z_vals)
-        rgb_flat = ops.rgb_eval(pk, src_main, gradients, ray_dirs, feat_tiles)
+        rgb_flat = ops.rgb_eval(pk, src_main, gradients, ray_dirs, feat_tiles, keep=keep)
         comp = ops.composite(z_vals, sdf, rgb_flat, depth_scale, self.density.beta, float(self.density.beta_min),
                              normals=None if self.training else gradients)
+        if keep is not None:
+            keep.update(z_vals=z_vals, sdf=sdf, rgb_flat=rgb_flat, depth_scale=depth_scale, cam_loc=cam_loc,
+                        ray_dirs=ray_dirs)
         rgb_values = comp["rgb_values"]
         if self.white_bkgd:
             acc_map = torch.sum(comp["weights"], -1)
@@ -207,6 +246,26 @@ class VolSDFNetwork(nn.Module):
             output['normal_map'] = comp["normal_map"]
         return output
 
+    def backward_from_output_grads(self, keep, g_rgb_values, g_weights=None, g_depth_values=None, g_grad_theta=None):
+        """d loss / d parameters from d loss / d (rgb_values, weights, depth_values, grad_theta): compositing
+        backward, then the fused MLP backward.  Returns (sdf_grads, rgb_grads, d_beta)."""
+        from svs_hip.train import MlpBackward
+        dev = keep["z_vals"].device
+        if getattr(self, "_mlp_bwd", None) is None or self._mlp_bwd.dev != dev:
+            self._mlp_bwd = MlpBackward(dev)
+        R = keep["z_vals"].shape[0]
+        if g_rgb_values is None:
+            g_rgb_values = torch.zeros(R, 3, device=dev)
+        d_sdf, d_rgb, d_beta = ops.composite_bwd(keep["z_vals"], keep["sdf"], keep["rgb_flat"], keep["depth_scale"],
+                                                 self.density.beta, float(self.density.beta_min), g_rgb_values,
+                                                 g_weights, g_depth_values)
+        n_extra = keep["src"].n - keep["rgb"].shape[0]
+        if g_grad_theta is None and n_extra:
+            g_grad_theta = torch.zeros(n_extra, 3, device=dev)
+        sdf_p, rgb_p = self.mlp_params()
+        sdf_g, rgb_g = self._mlp_bwd.run(sdf_p, rgb_p, keep, d_rgb, d_sdf, g_grad_theta)
+        return sdf_g, rgb_g, d_beta
+
     def volume_rendering(self, z_vals, sdf):
         """network.py:281-295 -> (weights, dists)."""
         R = z_vals.shape[0]
@@ -215,3 +274,28 @@ class VolSDFNetwork(nn.Module):
                              self.density.beta, float(self.density.beta_min))
         dists = torch.cat([z_vals[:, 1:] - z_vals[:, :-1], torch.full((R, 1), 1e10, device=dev)], -1)
         return comp["weights"], dists
+
+
+class _RenderFunction(torch.autograd.Function):
+    """Autograd bridge: lets `loss.backward()` of the reference trainer (volsdf/vsdf.py:215) drive the hand-written
+    backward kernels.  Inputs after `fast` are the parameters in VolSDFNetwork._flat_param_list() order."""
+
+    @staticmethod
+    def forward(ctx, model, input, fast, *params):
+        keep = {}
+        out = model._forward_impl(input, fast, keep)
+        ctx.model, ctx.keep = model, keep
+        ctx.mark_non_differentiable(out['depth_vals'], out['xyz'])
+        return (out['rgb_values'], out['depth_values'], out['weights'], out['grad_theta'], out['depth_vals'], out['xyz'])
+
+    @staticmethod
+    def backward(ctx, g_rgb_values, g_depth_values, g_weights, g_grad_theta, _g1, _g2):
+        model = ctx.model
+        sdf_g, rgb_g, d_beta = model.backward_from_output_grads(ctx.keep, g_rgb_values, g_weights, g_depth_values,
+                                                                g_grad_theta)
+        grads = []
+        for group, wn in ((sdf_g, model.implicit_network.weight_norm), (rgb_g, model.rendering_network.weight_norm)):
+            for gv, gg, gb in group:
+                grads += [gv] + ([gg] if wn else []) + [gb]
+        grads.append(d_beta.reshape(model.density.beta.shape))
+        return (None, None, None, *grads)

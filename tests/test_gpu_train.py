@@ -1,0 +1,148 @@
+"""Training step on the HIP path against the reference's own three optimisation steps (fixture train_step.npz:
+VolSDFNetwork + cost_mapping + VolSDFLoss + clip_grad_norm_ + NaN guard + Adam, volsdf/vsdf.py:196-219)."""
+import contextlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def G(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@contextlib.contextmanager
+def inject_rng(draws):
+    """feed the CPU-generator call sites of the model (reference order: jitter, u, randperm, randint, uniform_)"""
+    o = (torch.rand, torch.randperm, torch.randint, torch.Tensor.uniform_)
+    q = [draws["jitter"], draws["u"]]
+    torch.rand = lambda *s, **k: torch.from_numpy(q.pop(0))
+    torch.randperm = lambda n, **k: torch.from_numpy(draws["perm"])
+    torch.randint = lambda h, s, **k: torch.from_numpy(draws["eik_idx"])
+    torch.Tensor.uniform_ = lambda self, a, b: self.copy_(torch.from_numpy(draws["eik_points"]))
+    try:
+        yield
+    finally:
+        torch.rand, torch.randperm, torch.randint, torch.Tensor.uniform_ = o
+
+
+def _setup(dev):
+    from ref_shim import dtu_model_conf
+    from volsdf.model.loss import VolSDFLoss
+    from volsdf.model.network import VolSDFNetwork
+    params = synth.make_params(0)
+    m = VolSDFNetwork(dtu_model_conf())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    m.to(dev)
+    loss = VolSDFLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, rgb_weight=1.0, mvs_weight=1.0, sparse_weight=1.0,
+                      anneal_rgb=200, gce=0.5, confi=1e-3)
+    return m, loss
+
+
+def _check_digest(g, step, kind, named, rtol, atol, frac_ok=1.0):
+    bad = tot = 0
+    worst = 0.0
+    for name, t in named:
+        idx = g[f"s{step}_{kind}_idx/{name}"]
+        ref = g[f"s{step}_{kind}/{name}"]
+        got = t.detach().cpu().numpy().reshape(-1)[idx]
+        err = np.abs(got - ref)
+        lim = atol + rtol * np.abs(ref)
+        bad += int((err > lim).sum()); tot += err.size
+        worst = max(worst, float((err / (np.abs(ref) + atol)).max()))
+    assert bad <= (1.0 - frac_ok) * tot, (kind, step, bad, tot, worst)
+    return worst
+
+
+def _mvs(dev, g):
+    views = synth.make_mvs_views(int(g["mvs_seed"]))
+    dv = [dict(K=v["K"], c2w=v["c2w"], cost=G(v["cost"], dev), z_mvs=G(v["z_mvs"], dev)) for v in views]
+    return dict(views=dv, same_view=0, img_res=(576, 768), inverse_depth=False), views
+
+
+def test_train_steps_fused(dev, golden_dir):
+    """TrainStep (forward, lookup, fused loss, hand-written backward, fused clip+guard+Adam) x 3."""
+    from svs_hip.trainer import TrainStep
+    g = dict(np.load(os.path.join(golden_dir, "train_step.npz")))
+    m, loss = _setup(dev)
+    ts = TrainStep(m, loss, lr=5e-4)
+    mvs, views = _mvs(dev, g)
+    R = g["uv"].shape[0]
+    inp = {"intrinsics": G(views[0]["K"], dev)[None], "uv": G(g["uv"], dev)[None], "pose": G(views[0]["c2w"], dev)[None]}
+    gt = {"rgb": G(g["rgb"], dev), "rgb_smooth": G(g["rgb_smooth"], dev)}
+    for step in range(3):
+        with inject_rng(synth.make_train_rng(R, seed=100 + step)):
+            lo, out = ts(inp, gt, mvs=mvs)
+        torch.cuda.synchronize()
+        for k in ("rgb_loss", "eikonal_loss", "mvs_loss", "sparse_loss", "loss"):
+            np.testing.assert_allclose(float(lo[k]), float(g[f"s{step}_{k}"]), rtol=2e-4, atol=2e-6, err_msg=f"step {step} {k}")
+        # gradient norm before clipping (info[0]) and the raw gradients: the flat grad buffer holds the CLIPPED grads
+        norm = float(ts.opt.info[0])
+        np.testing.assert_allclose(norm, float(g[f"s{step}_grad_norm"]), rtol=1e-3)
+        coef = min(1.0, 1.0 / (float(g[f"s{step}_grad_norm"]) + 1e-6))
+        named_g = [(n, p.grad / coef) for n, p in m.named_parameters()]
+        _check_digest(g, step, "grad", named_g, rtol=2e-3, atol=2e-6 * max(1.0, norm), frac_ok=0.995)
+        # Adam moves an entry by ~lr * g/|g|: entries whose gradient is numerically zero may differ in sign
+        _check_digest(g, step, "param", list(m.named_parameters()), rtol=0.0, atol=3e-5, frac_ok=0.97)
+        _check_digest(g, step, "param", list(m.named_parameters()), rtol=0.0, atol=1.1e-3 * (step + 1), frac_ok=1.0)
+
+
+def test_train_step_autograd_bridge(dev, golden_dir):
+    """The reference's own sequence -- model(...), loss(...), loss.backward(), clip_grad_norm_, torch Adam -- driving
+    the HIP kernels through the autograd bridge (what runner.py does with the drop-in classes)."""
+    from svs_hip import ops
+    g = dict(np.load(os.path.join(golden_dir, "train_step.npz")))
+    m, loss = _setup(dev)
+    m.train()
+    opt = torch.optim.Adam(m.parameters(), lr=5e-4)
+    mvs, views = _mvs(dev, g)
+    R = g["uv"].shape[0]
+    inp = {"intrinsics": G(views[0]["K"], dev)[None], "uv": G(g["uv"], dev)[None], "pose": G(views[0]["c2w"], dev)[None]}
+    gt = {"rgb": G(g["rgb"], dev), "rgb_smooth": G(g["rgb_smooth"], dev)}
+    for step in range(2):
+        with inject_rng(synth.make_train_rng(R, seed=100 + step)):
+            out = m(inp, fast=1)
+        with torch.no_grad():
+            out['pj'], out['pi'], _ = ops.cost_lookup(mvs["views"], 0, (576, 768), xyz=out['xyz'])
+        lo = loss(out, gt)
+        opt.zero_grad()
+        lo['loss'].backward()
+        named_g = [(n, p.grad) for n, p in m.named_parameters()]
+        _check_digest(g, step, "grad", named_g, rtol=2e-3, atol=2e-6 * max(1.0, float(g[f"s{step}_grad_norm"])), frac_ok=0.995)
+        norm = torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        np.testing.assert_allclose(float(norm), float(g[f"s{step}_grad_norm"]), rtol=1e-3)
+        opt.step()
+        np.testing.assert_allclose(float(lo['loss']), float(g[f"s{step}_loss"]), rtol=2e-4)
+        _check_digest(g, step, "param", list(m.named_parameters()), rtol=0.0, atol=3e-5, frac_ok=0.97)
+
+
+def test_nan_guard_drops_update(dev):
+    """on_after_backward (vsdf.py:454-463): a non-finite gradient zeroes the gradients; Adam still steps (torch 1.9)."""
+    from svs_hip.trainer import FusedAdam
+    p = torch.nn.Parameter(torch.linspace(-1, 1, 1000, device=dev))
+    opt = FusedAdam([p], lr=1e-2)
+    p.grad.copy_(torch.randn(1000, device=dev))
+    opt.step()
+    after1 = p.detach().clone()
+    p.grad.copy_(torch.randn(1000, device=dev)); p.grad[17] = float("nan")
+    opt.step()
+    assert float(opt.info[1]) == 1.0
+    assert torch.isfinite(p).all() and (p.grad == 0).all()
+    # zero gradient, decayed moments: same as torch.optim.Adam fed with zeros
+    ref = torch.nn.Parameter(torch.linspace(-1, 1, 1000))
+    ropt = torch.optim.Adam([ref], lr=1e-2)
+    torch.manual_seed(0)
+    g1 = (after1.cpu() - ref.detach())  # recover step-1 direction: sign pattern only
+    assert (g1.abs() > 0).all()
