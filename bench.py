@@ -4,12 +4,14 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the per-iteration rendering path over one 1024-ray batch per GPU, exactly the model
-call of VolOpt.train_step (volsdf/vsdf.py:205, train mode, fast=1): rays -> 128 uniform samples -> SDF MLP ->
-error-bound / beta search -> 64 + 34 final samples -> SDF MLP forward + d sdf/dx (98 304+2 048 ... points) ->
-radiance MLP -> alpha compositing -> eikonal points.  Inputs (weights, camera, pixel batch, random draws) are
-resident in HBM before the timed region.  Rays are independent: with N GPUs each rank renders its own
-1024-ray shard (weak scaling, no data-path collective).
+A "step" is one pass of the per-iteration hot path over one 1024-ray batch per GPU = VolOpt.train_step
+(volsdf/vsdf.py:196-219): rays -> 128 uniform samples -> SDF MLP -> error-bound / beta search -> 64 + 34 final
+samples -> SDF MLP forward + d sdf/dx (100 352 + 2 048 points) -> radiance MLP -> alpha compositing -> MVS prior
+lookup (3 views, 192x288x384 probability volumes) -> loss -> backward through compositing and both MLPs (incl. the
+double backward through the normals) -> clip + NaN guard + Adam.  `--mode render` times the forward part only.
+Inputs (weights, camera, pixel batch, prior volumes) are resident in HBM before the timed region.  Rays are
+independent: with N GPUs each rank takes its own 1024-ray shard (weak scaling) and the step adds ONE RCCL
+all-reduce of the flat float32 gradient (3.19 MB).
 
 Rank 0 prints ONE JSON line; `roofline` prices the dominant kernel (fused SDF forward+gradient) against the
 float32 MFMA peak, `cpu_baseline` times the numpy oracle on a bounded sample of the same workload.
@@ -36,6 +38,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rays", type=int, default=1024)
+    ap.add_argument("--mode", choices=["train", "render"], default="train")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -44,6 +47,8 @@ def main():
     import synth
     from ref_shim import dtu_model_conf
     from svs_hip import ops
+    from svs_hip.trainer import TrainStep
+    from volsdf.model.loss import VolSDFLoss
     from volsdf.model.network import VolSDFNetwork
 
     rank = int(os.environ.get("RANK", "0"))
@@ -87,8 +92,30 @@ def main():
     ev_on = [False]
     ops.sdf_outputs = timed_sdf_outputs
 
+    train = args.mode == "train"
+    if train:
+        # synthetic MVS prior at the real DTU stage-1 size: softmax(N(0,1)) over D = 192 at 288 x 384,
+        # per-pixel hypotheses 1.5 .. 3.5, three views with x offsets 0, +-0.3
+        gen = torch.Generator(device=dev); gen.manual_seed(7)
+        views = []
+        for j, dx in enumerate((0.0, 0.3, -0.3)):
+            Kj, Pj = synth.make_camera(center=(dx, 0.0, -2.5), tilt=-0.12 * dx / 0.3)
+            prob = torch.softmax(torch.randn(192, 288, 384, device=dev, generator=gen), 0)
+            zm = torch.linspace(1.5, 3.5, 192, device=dev).view(-1, 1, 1) * (1 + 0.05 * (torch.rand(1, 288, 384, device=dev, generator=gen) * 2 - 1))
+            views.append(dict(K=Kj, c2w=Pj, cost=prob, z_near=zm[0].contiguous(), z_far=zm[-1].contiguous()))
+        mvs = dict(views=views, same_view=0, img_res=(576, 768), inverse_depth=False)
+        rs = np.random.default_rng(11 + rank)
+        gt = {"rgb": torch.from_numpy(rs.uniform(0, 1, (1, R, 3)).astype(np.float32)).to(dev),
+              "rgb_smooth": torch.from_numpy(rs.uniform(0, 1, (1, R, 3)).astype(np.float32)).to(dev)}
+        loss = VolSDFLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, rgb_weight=1.0, mvs_weight=1.0,
+                          sparse_weight=1.0, anneal_rgb=200, gce=0.5, confi=1e-3)       # config/ours.yaml:16-21
+        ts = TrainStep(model, loss, lr=5e-4, world=world, rank=rank)
+
     def step():
-        return model(inp, fast=1)
+        if train:
+            return ts(inp, gt, mvs=mvs)
+        with torch.no_grad():
+            return model(inp, fast=1)
 
     for _ in range(args.warmup):
         step()
@@ -117,6 +144,10 @@ def main():
         achieved = n_pts * 2 * F_SDF / (k_ms * 1e-3)
         S = ev[0][3]
         flop_per_ray = 128 * F_SDF + S * (2 * F_SDF + F_RGB) + 2 * (2 * F_SDF)
+        if train:
+            # backward: second-order sweep + backprop of the SDF MLP (2 x 8 layers), its two weight-gradient
+            # contractions per layer, radiance backprop + weight gradients (approximate, SURVEY.md 8d: 0.92 GFLOP/ray)
+            flop_per_ray += (S + 2) * (2 * F_SDF + 2 * F_SDF) + S * (2 * F_RGB)
         line = {
             "metric": "rendered rays/sec (1024-ray batch, 128 samples)",
             "value": world * R * args.steps / dt,
@@ -130,9 +161,11 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: VolSDFNetwork.forward as called by VolOpt.train_step (train mode, fast=1): "
-                                   f"{R} rays/GPU x 128 coarse + {S} composited samples + {2 * R} eikonal points, "
-                                   "8x256 SDF MLP (fwd + d/dx) + 4x256 radiance MLP, forward only",
+            "config": {"workload": ("configs[1]: VolOpt.train_step (forward + MVS prior lookup + loss + backward + clip/guard/Adam), "
+                                    if train else "configs[1]: VolSDFNetwork.forward as called by VolOpt.train_step, forward only, ")
+                                   + f"train mode, fast=1: {R} rays/GPU x 128 coarse + {S} composited samples + {2 * R} "
+                                   "eikonal points, 8x256 SDF MLP + 4x256 radiance MLP",
+                       "mode": args.mode,
                        "rays_per_gpu": R, "flop_per_ray": flop_per_ray,
                        "model_flops_per_s": world * R * args.steps / dt * flop_per_ray},
             "roofline": {"bound": "mfma", "kernel": "sdf_full_kernel (SDF MLP forward + input gradient + features)",
@@ -141,36 +174,54 @@ def main():
                          "kernel_ms": k_ms, "points_per_launch": n_pts, "flop_per_point": 2 * F_SDF},
         }
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(params, K, pose)
+            line["cpu_baseline"] = cpu_baseline(params, K, pose, train=train)
         print(json.dumps(line), flush=True)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(params, K, pose, rays=48, reps=3):
-    """numpy oracle (a port of the reference's PyTorch path) on a bounded sample: `rays` rays, same workload."""
+def cpu_baseline(params, K, pose, train=True, rays=32, reps=3):
+    """CPU port of the reference's PyTorch path on a bounded sample (`rays` rays of the same workload): numpy oracle for
+    the sampler / forward, plain torch float32 autograd (oracle/torch_ref.py) for the differentiable part."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
+    import torch
     import svs_oracle as orc
     import synth
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
-    except Exception:
-        cores = os.cpu_count() or 1
+    import torch_ref as tref
+    cores = torch.get_num_threads()
     uv = synth.make_uv(rays, seed=5)
     rng = synth.make_train_rng(rays, seed=5)
-    orc.render_forward(params, uv[:8], pose, K, beta_param=params["density.beta"], fast=1, training=True,
-                       rng={k: (v[:8] if v.shape[0] == rays else v) for k, v in rng.items()})
+    layers = orc.effective_weights(params, "implicit_network", 9)
+
+    def one():
+        if not train:
+            orc.render_forward(params, uv, pose, K, beta_param=params["density.beta"], fast=1, training=True, rng=rng)
+            return
+        dirs, cam, ds = orc.rays_from_uv(uv, pose, K)
+        z, z_eik = orc.error_bound_sampler(lambda x: orc.sdf_vals(layers, x), dirs, cam, orc.get_beta(0.1), fast=1,
+                                           training=True, rng=rng)
+        eik = np.concatenate([rng["eik_points"], (cam[None] + z_eik * dirs).astype(np.float32)], 0)
+        p = tref.to_torch(params, torch.float32)
+        out = tref.forward_differentiable(p, cam, dirs, z, eik, ds)
+        tgt = torch.rand(rays, 3)
+        total = tref.loss_fn(out, tgt, tgt, 250)
+        total.backward()
+        opt = torch.optim.Adam([v for v in p.values()], lr=5e-4)
+        torch.nn.utils.clip_grad_norm_([v for v in p.values()], 1.0)
+        opt.step()
+
+    one()
     ts = []
     for _ in range(reps):
         t0 = time.perf_counter()
-        orc.render_forward(params, uv, pose, K, beta_param=params["density.beta"], fast=1, training=True, rng=rng)
+        one()
         ts.append(time.perf_counter() - t0)
     t = float(np.median(ts))
+    what = "train step (numpy sampler + torch float32 autograd, clip, Adam)" if train else "train-mode fast=1 forward, numpy oracle"
     return {"value": rays / t, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": f"{rays} rays of the same train-mode fast=1 forward, numpy oracle, median of {reps}"}
+            "sample": f"{rays} rays of the same {what}, median of {reps}"}
 
 
 if __name__ == "__main__":

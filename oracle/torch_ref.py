@@ -1,0 +1,108 @@
+"""Plain torch restatement (CPU, any float dtype) of the differentiable part of the hot path, with autograd.
+
+TEST INFRASTRUCTURE ONLY (see oracle/svs_oracle.py).  Floating-point kernels may be checked against a plain torch
+reference; this file is that reference for everything that needs gradients: the SDF / radiance MLPs
+(volsdf/model/network.py:71-131,170-190), compositing (:281-295,237-243), the loss (volsdf/model/loss.py:80-114) and one
+optimisation step (volsdf/vsdf.py:214-219).  The sampler (no gradients flow through it) comes from svs_oracle.
+Pinned by tests/test_oracle_golden.py::test_torch_ref_* against the reference-generated fixtures.
+"""
+import numpy as np
+import torch
+
+
+def to_torch(params, dtype=torch.float64, requires_grad=True):
+    return {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=requires_grad) for k, v in params.items()}
+
+
+def weightnorm(p, prefix, l):
+    v, g = p[f"{prefix}.lin{l}.weight_v"], p[f"{prefix}.lin{l}.weight_g"]
+    return g * v / v.norm(dim=1, keepdim=True)
+
+
+def posenc(x, L):
+    out = [x]
+    for k in range(L):
+        out += [torch.sin(x * 2.0 ** k), torch.cos(x * 2.0 ** k)]
+    return torch.cat(out, -1)
+
+
+def sdf_mlp(p, x):
+    """ImplicitNetwork.forward (network.py:71-88) -> (P,257)"""
+    inp = posenc(x, 6)
+    h = inp
+    for l in range(9):
+        if l == 4:
+            h = torch.cat([h, inp], 1) / np.sqrt(2)
+        h = h @ weightnorm(p, "implicit_network", l).T + p[f"implicit_network.lin{l}.bias"]
+        if l < 8:
+            h = torch.nn.functional.softplus(h, beta=100)
+    return h
+
+
+def sdf_outputs(p, x, radius=3.0, scale=20.0, clamp=True):
+    """get_outputs (network.py:105-123) / gradient (:90-103) with create_graph=True."""
+    x = x.requires_grad_(True)
+    out = sdf_mlp(p, x)
+    sdf = out[:, :1]
+    if clamp and radius > 0:
+        sdf = torch.minimum(sdf, scale * (radius - x.norm(2, 1, keepdim=True)))
+    grad = torch.autograd.grad(sdf.sum(), x, create_graph=True)[0]
+    return sdf, out[:, 1:], grad
+
+
+def rgb_mlp(p, x, n, d, feat):
+    """RenderingNetwork.forward, mode idr (network.py:170-190)"""
+    h = torch.cat([x, posenc(d, 1), n, feat], -1)
+    for l in range(5):
+        h = h @ weightnorm(p, "rendering_network", l).T + p[f"rendering_network.lin{l}.bias"]
+        if l < 4:
+            h = torch.relu(h)
+    return torch.sigmoid(h)
+
+
+def composite(z, sdf, rgb, beta_param, ds, beta_min=1e-4):
+    """network.py:281-295 + :237-243 -> weights, rgb_values, depth_values"""
+    beta = beta_param.abs() + beta_min
+    sigma = (1 / beta) * (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() / beta))
+    dists = torch.cat([z[:, 1:] - z[:, :-1], torch.full_like(z[:, :1], 1e10)], -1)
+    fe = dists * sigma
+    sfe = torch.cat([torch.zeros_like(fe[:, :1]), fe[:, :-1]], -1)
+    w = (1 - torch.exp(-fe)) * torch.exp(-torch.cumsum(sfe, -1))
+    rgb_values = (w.unsqueeze(-1) * rgb).sum(1)
+    depth_values = ds * ((w * z).sum(1, keepdim=True) / (w.sum(1, keepdim=True) + 1e-8))
+    return w, rgb_values, depth_values
+
+
+def loss_fn(out, rgb, rgb_smooth, it, *, eikonal_weight=0.1, rgb_weight=1.0, mvs_weight=1.0, sparse_weight=1.0,
+            gce=0.5, confi=1e-3, anneal_rgb=200):
+    """VolSDFLoss.forward (loss.py:80-114) -> total"""
+    rgb_loss = (out["rgb_values"] - rgb).abs().mean()
+    eik = ((out["grad_theta"].norm(2, dim=1) - 1) ** 2).mean()
+    total = eikonal_weight * eik
+    on = sparse_weight > 0 and anneal_rgb > 0 and it < anneal_rgb
+    if "pi" in out:
+        pw = out["pi"] * out["pj"]
+        w = out["weights"]
+        l = (-pw * w.detach() ** gce * torch.log(w + 1e-8)).sum(1)
+        total = total + mvs_weight * (1. * (pw.sum(1) > confi) * l).mean()
+        if on:
+            conf = pw.sum(-1)
+            sparse = ((1. / (out["depth_values"].squeeze() + 1e-3)) * (conf < confi)).mean()
+            total = total + sparse_weight * (1.0 - it / anneal_rgb) * sparse
+            rgb_loss = ((out["rgb_values"] - rgb_smooth).abs().mean(-1) * (conf < 1e-8)).mean()
+    return total + rgb_weight * rgb_loss
+
+
+def forward_differentiable(p, cam, dirs, z, eik_points, depth_scale, radius=3.0, scale=20.0):
+    """VolSDFNetwork.forward after the sampler (network.py:226-268), train mode."""
+    R, S = z.shape
+    dt = p["density.beta"].dtype
+    cam_t, dirs_t, z_t = (torch.tensor(np.asarray(a), dtype=dt) for a in (cam, dirs, z))
+    pts = (cam_t.view(1, 1, 3) + z_t.unsqueeze(2) * dirs_t.unsqueeze(1)).reshape(-1, 3)
+    sdf, feat, grad = sdf_outputs(p, pts, radius, scale)
+    dflat = dirs_t.unsqueeze(1).repeat(1, S, 1).reshape(-1, 3)
+    rgb = rgb_mlp(p, pts, grad, dflat, feat).reshape(R, S, 3)
+    w, rgb_values, depth_values = composite(z_t, sdf.reshape(R, S), rgb, p["density.beta"],
+                                            torch.tensor(np.asarray(depth_scale), dtype=dt))
+    _, _, gt = sdf_outputs(p, torch.tensor(np.asarray(eik_points), dtype=dt), clamp=False)
+    return dict(rgb_values=rgb_values, depth_values=depth_values, weights=w, grad_theta=gt, sdf=sdf, rgb=rgb)

@@ -34,16 +34,8 @@ def rel_err(a, b):
 
 
 def torch_composite(z, sdf, rgb, beta_param, ds, beta_min=1e-4):
-    """network.py:281-295 + :237-243 in plain torch (float64 for a clean autograd reference)."""
-    beta = beta_param.abs() + beta_min
-    sigma = (1 / beta) * (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() / beta))
-    dists = torch.cat([z[:, 1:] - z[:, :-1], torch.full_like(z[:, :1], 1e10)], -1)
-    fe = dists * sigma
-    sfe = torch.cat([torch.zeros_like(fe[:, :1]), fe[:, :-1]], -1)
-    w = (1 - torch.exp(-fe)) * torch.exp(-torch.cumsum(sfe, -1))
-    rgb_values = (w.unsqueeze(-1) * rgb).sum(1)
-    depth_values = ds * ((w * z).sum(1, keepdim=True) / (w.sum(1, keepdim=True) + 1e-8))
-    return w, rgb_values, depth_values
+    import torch_ref
+    return torch_ref.composite(z, sdf, rgb, beta_param, ds, beta_min)
 
 
 @pytest.mark.parametrize("beta", [0.1, 0.02])
@@ -93,42 +85,16 @@ def test_wgrad_gemm(dev, P):
 # ------------------------------------------------------------------------------------------------------
 # full MLP backward (double backward through the normals) against torch autograd in float64
 # ------------------------------------------------------------------------------------------------------
+import torch_ref as tref   # noqa: E402  (oracle/torch_ref.py: plain torch restatement with autograd)
+
+
 def _t64(params, requires_grad=True):
-    return {k: torch.tensor(np.asarray(v, np.float64), requires_grad=requires_grad and k != "density.beta")
-            for k, v in params.items()}
+    p = tref.to_torch(params, torch.float64, requires_grad)
+    p["density.beta"].requires_grad_(False)
+    return p
 
 
-def _wn(p, prefix, l):
-    v, g = p[f"{prefix}.lin{l}.weight_v"], p[f"{prefix}.lin{l}.weight_g"]
-    return g * v / v.norm(dim=1, keepdim=True)
-
-
-def _pe(x, L):
-    out = [x]
-    for k in range(L):
-        out += [torch.sin(x * 2.0 ** k), torch.cos(x * 2.0 ** k)]
-    return torch.cat(out, -1)
-
-
-def _sdf_mlp(p, x):
-    inp = _pe(x, 6)
-    h = inp
-    for l in range(9):
-        if l == 4:
-            h = torch.cat([h, inp], 1) / np.sqrt(2)
-        h = h @ _wn(p, "implicit_network", l).T + p[f"implicit_network.lin{l}.bias"]
-        if l < 8:
-            h = torch.nn.functional.softplus(h, beta=100)
-    return h
-
-
-def _rgb_mlp(p, x, n, d, feat):
-    h = torch.cat([x, _pe(d, 1), n, feat], -1)
-    for l in range(5):
-        h = h @ _wn(p, "rendering_network", l).T + p[f"rendering_network.lin{l}.bias"]
-        if l < 4:
-            h = torch.relu(h)
-    return torch.sigmoid(h)
+_sdf_mlp, _rgb_mlp = tref.sdf_mlp, tref.rgb_mlp
 
 
 def test_mlp_backward_vs_autograd(dev, ops):

@@ -288,3 +288,41 @@ def test_casmvs_three_stages(golden_dir):
         np.testing.assert_allclose(depth, g[f"s{st}_depth"], rtol=3e-6, err_msg=f"depth {key}")
         np.testing.assert_allclose(conf, g[f"s{st}_conf"], atol=5e-7, err_msg=f"conf {key}")
         prev = g["stage1_depth_override"] if st == 0 else g[f"s{st}_depth"]
+
+
+# ------------------------------------------------------------------------------------------------------
+# oracle/torch_ref.py (autograd reference of the differentiable part) pinned on the reference's fixtures
+# ------------------------------------------------------------------------------------------------------
+def test_torch_ref_forward_and_first_step_gradients(golden_dir):
+    """torch_ref forward on the reference's own sample positions == the reference's outputs, and its gradients of
+    the reference loss == the reference's gradients (train_step fixture, step 0)."""
+    import torch
+    import torch_ref as tref
+    g = load(golden_dir, "train_step")
+    params = synth.make_params(0)
+    views = synth.make_mvs_views(int(g["mvs_seed"]))
+    K, pose = views[0]["K"], views[0]["c2w"]
+    R = g["uv"].shape[0]
+    rng = synth.make_train_rng(R, seed=100)
+    layers = orc.effective_weights(params, "implicit_network", 9)
+    dirs, cam, ds = orc.rays_from_uv(g["uv"], pose, K)
+    z, z_eik = orc.error_bound_sampler(lambda x: orc.sdf_vals(layers, x), dirs, cam, orc.get_beta(0.1), fast=1,
+                                       training=True, rng=rng)
+    eik = np.concatenate([rng["eik_points"], (cam[None] + z_eik * dirs).astype(F32)], 0)
+    p = tref.to_torch(params, torch.float64)
+    out = tref.forward_differentiable(p, cam, dirs, z, eik, ds)
+    xyz = (cam[None, None] + z[:, :, None] * dirs[:, None, :]).astype(F32)
+    pj, pi, _ = orc.cost_mapping(xyz, 0, views, (576, 768))
+    out["pi"], out["pj"] = torch.tensor(pi, dtype=torch.float64), torch.tensor(pj, dtype=torch.float64)
+    total = tref.loss_fn(out, torch.tensor(g["rgb"].reshape(-1, 3), dtype=torch.float64),
+                         torch.tensor(g["rgb_smooth"].reshape(-1, 3), dtype=torch.float64), 0)
+    np.testing.assert_allclose(float(total), float(g["s0_loss"]), rtol=2e-4)
+    total.backward()
+    worst = 0.0
+    for name in params:
+        if f"s0_grad/{name}" not in g:
+            continue
+        got = p[name].grad.numpy().reshape(-1)[g[f"s0_grad_idx/{name}"]]
+        ref = g[f"s0_grad/{name}"]
+        worst = max(worst, float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30)))
+    assert worst < 2e-3, worst
