@@ -194,7 +194,8 @@ int svs_loss(int n_rays, int n_samples, int n_eik, const float* rgb_values, cons
              const float* grad_theta, const float* weights, const float* pi, const float* pj, const float* depth_values,
              float rgb_weight, float eikonal_weight, float mvs_weight, float sparse_weight, float gce, float confi,
              int annealed, float anneal_sparse, float* losses, float* d_rgb_values, float* d_grad_theta,
-             float* d_weights, float* d_depth_values, void* hip_stream);
+             float* d_weights, float* d_depth_values, double* workspace, void* hip_stream);
+size_t svs_loss_workspace_bytes(int n_rays, int n_eik);
 
 /* ---- a13/a14  homography warp + variance --------------------------------------------------------------------
  * homo_warping (models/CasMVSNet.py:280-315) for every source view fused with the variance aggregation of

@@ -486,7 +486,7 @@ int svs_lin8_row0_grad(const float* hbuf, const float* ubuf, const float* sbar, 
                        void* hip_stream) {
   if (!hbuf || !ubuf || !sbar || !out257 || n_points <= 0) { set_error("svs_lin8_row0_grad: bad argument"); return SVS_EINVAL; }
   const int n_tiles = (n_points + 31) / 32;
-  const int grid = n_tiles < 4 * 64 ? (n_tiles + 3) / 4 : 64;
+  const int grid = n_tiles < 4 * 256 ? (n_tiles + 3) / 4 : 256;
   lin8_row0_kernel<<<grid, 256, 0, (hipStream_t)hip_stream>>>(hbuf, ubuf, sbar, n_tiles, n_points, out257);
   return check_launch("svs_lin8_row0_grad");
 }

@@ -338,26 +338,19 @@ struct LossArgs {
   float* d_depth_values;     // (R)
 };
 
-__device__ __forceinline__ double block_sum(double v, double* sh) {
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) sh[w] = v;
-  __syncthreads();
-  double t = 0.0;
-  for (int i = 0; i < nw; ++i) t += sh[i];
-  return t;
-}
-
-__global__ __launch_bounds__(1024) void loss_kernel(LossArgs a) {
-  __shared__ double sh[16];
-  const int tid = threadIdx.x, nt = blockDim.x;
+// one wave per ray (coalesced over the samples); per-ray partial sums go to `partial` and a single-block second
+// kernel adds them in a fixed order (reproducible)
+__global__ __launch_bounds__(256) void loss_rays_kernel(LossArgs a, double* __restrict__ partial) {
+  const int lane = threadIdx.x & 63;
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);      // rays first, then groups of 64 eikonal points
   const bool has_mvs = a.pi != nullptr;
-  double s_rgb = 0.0, s_eik = 0.0, s_mvs = 0.0, s_sparse = 0.0;
-  for (int r = tid; r < a.R; r += nt) {
+  if (unit < a.R) {
+    const int r = unit;
     double conf = 0.0, lm = 0.0;
+    float dls[4];                                              // S <= 256: up to 4 samples per lane
     if (has_mvs) {
-      for (int s = 0; s < a.S; ++s) {
+      int k = 0;
+      for (int s = lane; s < a.S; s += 64, ++k) {
         const size_t p = (size_t)r * a.S + s;
         const float pw = a.pi[p] * a.pj[p];
         const float w = a.weights[p];
@@ -367,48 +360,67 @@ __global__ __launch_bounds__(1024) void loss_kernel(LossArgs a) {
         else if (a.gce == 0.0f) { l = -pw * __logf(w + 1e-8f); dl = -pw / (w + 1e-8f); }
         else { const float wq = __powf(w, a.gce); l = (-pw * wq) * __logf(w + 1e-8f); dl = (-pw * wq) / (w + 1e-8f); }
         lm += (double)l;
-        a.d_weights[p] = dl;           // scaled below once the ray's mask is known
+        dls[k & 3] = dl;
       }
+      for (int d = 32; d >= 1; d >>= 1) { conf += __shfl_xor(conf, d); lm += __shfl_xor(lm, d); }
     }
     const bool mvs_on = has_mvs && a.mvs_weight > 0.0f && conf > (double)a.confi;
-    if (has_mvs) {
+    {
       const float sc = mvs_on ? a.mvs_weight / (float)a.R : 0.0f;
-      for (int s = 0; s < a.S; ++s) a.d_weights[(size_t)r * a.S + s] *= sc;
-    } else {
-      for (int s = 0; s < a.S; ++s) a.d_weights[(size_t)r * a.S + s] = 0.0f;
+      int k = 0;
+      for (int s = lane; s < a.S; s += 64, ++k) a.d_weights[(size_t)r * a.S + s] = has_mvs ? dls[k & 3] * sc : 0.0f;
     }
-    if (mvs_on) s_mvs += lm;
-    // rgb term
-    const bool masked = a.annealed && has_mvs;
-    const bool rgb_on = !masked || conf < 1e-8;
-    double l1 = 0.0;
-    for (int c = 0; c < 3; ++c) {
-      const float d = a.rgb_values[3 * r + c] - a.rgb_gt[3 * r + c];
-      l1 += (double)__builtin_fabsf(d);
-      const float sg = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
-      a.d_rgb_values[3 * r + c] = rgb_on ? a.rgb_weight * sg / (3.0f * (float)a.R) : 0.0f;
+    if (lane == 0) {
+      const bool masked = a.annealed && has_mvs;
+      const bool rgb_on = !masked || conf < 1e-8;
+      double l1 = 0.0;
+      for (int c = 0; c < 3; ++c) {
+        const float d = a.rgb_values[3 * r + c] - a.rgb_gt[3 * r + c];
+        l1 += (double)__builtin_fabsf(d);
+        const float sg = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+        a.d_rgb_values[3 * r + c] = rgb_on ? a.rgb_weight * sg / (3.0f * (float)a.R) : 0.0f;
+      }
+      float dd = 0.0f;
+      double sp = 0.0;
+      if (masked && conf < (double)a.confi) {
+        const float dep = a.depth_values[r] + 1e-3f;
+        sp = 1.0 / (double)dep;
+        dd = -(a.sparse_weight * a.anneal_sparse) / (dep * dep) / (float)a.R;
+      }
+      a.d_depth_values[r] = dd;
+      double* o = partial + (size_t)unit * 4;
+      o[0] = rgb_on ? l1 / 3.0 : 0.0; o[1] = 0.0; o[2] = mvs_on ? lm : 0.0; o[3] = sp;
     }
-    if (rgb_on) s_rgb += l1 / 3.0;
-    // sparsity term (annealed phase only)
-    float dd = 0.0f;
-    if (masked && conf < (double)a.confi) {
-      const float dep = a.depth_values[r] + 1e-3f;
-      s_sparse += 1.0 / (double)dep;
-      dd = -(a.sparse_weight * a.anneal_sparse) / (dep * dep) / (float)a.R;
+  } else {
+    const int i = (unit - a.R) * 64 + lane;
+    double e = 0.0;
+    if (i < a.n_eik) {
+      const float g0 = a.grad_theta[3 * i], g1 = a.grad_theta[3 * i + 1], g2 = a.grad_theta[3 * i + 2];
+      const float n = __builtin_sqrtf((g0 * g0 + g1 * g1) + g2 * g2);
+      e = (double)(n - 1.0f) * (double)(n - 1.0f);
+      const float k = n > 0.0f ? a.eikonal_weight * 2.0f * (n - 1.0f) / (n * (float)a.n_eik) : 0.0f;
+      a.d_grad_theta[3 * i] = k * g0; a.d_grad_theta[3 * i + 1] = k * g1; a.d_grad_theta[3 * i + 2] = k * g2;
     }
-    a.d_depth_values[r] = dd;
+    for (int d = 32; d >= 1; d >>= 1) e += __shfl_xor(e, d);
+    if (lane == 0) { double* o = partial + (size_t)unit * 4; o[0] = 0.0; o[1] = e; o[2] = 0.0; o[3] = 0.0; }
   }
-  for (int i = tid; i < a.n_eik; i += nt) {
-    const float g0 = a.grad_theta[3 * i], g1 = a.grad_theta[3 * i + 1], g2 = a.grad_theta[3 * i + 2];
-    const float n = __builtin_sqrtf((g0 * g0 + g1 * g1) + g2 * g2);
-    s_eik += (double)(n - 1.0f) * (double)(n - 1.0f);
-    const float k = n > 0.0f ? a.eikonal_weight * 2.0f * (n - 1.0f) / (n * (float)a.n_eik) : 0.0f;
-    a.d_grad_theta[3 * i] = k * g0; a.d_grad_theta[3 * i + 1] = k * g1; a.d_grad_theta[3 * i + 2] = k * g2;
+}
+
+__global__ __launch_bounds__(256) void loss_reduce_kernel(LossArgs a, const double* __restrict__ partial, int n_units) {
+  __shared__ double sh[4][4];
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int u = threadIdx.x; u < n_units; u += 256)
+    for (int k = 0; k < 4; ++k) acc[k] += partial[(size_t)u * 4 + k];
+  for (int k = 0; k < 4; ++k) {
+    for (int d = 32; d >= 1; d >>= 1) acc[k] += __shfl_xor(acc[k], d);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][k] = acc[k];
   }
-  s_rgb = block_sum(s_rgb, sh); s_eik = block_sum(s_eik, sh); s_mvs = block_sum(s_mvs, sh); s_sparse = block_sum(s_sparse, sh);
-  if (tid == 0) {
-    const float rgb = (float)(s_rgb / a.R), eik = a.n_eik ? (float)(s_eik / a.n_eik) : 0.0f;
-    const float mvs = (float)(s_mvs / a.R), sp = (float)(s_sparse / a.R);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t[4];
+    for (int k = 0; k < 4; ++k) t[k] = (sh[0][k] + sh[1][k]) + (sh[2][k] + sh[3][k]);
+    const float rgb = (float)(t[0] / a.R), eik = a.n_eik ? (float)(t[1] / a.n_eik) : 0.0f;
+    const float mvs = (float)(t[2] / a.R), sp = (float)(t[3] / a.R);
     a.losses[0] = rgb; a.losses[1] = eik; a.losses[2] = mvs; a.losses[3] = sp;
     a.losses[4] = a.rgb_weight * rgb + a.eikonal_weight * eik + a.mvs_weight * mvs + (a.sparse_weight * a.anneal_sparse) * sp;
   }
@@ -421,6 +433,8 @@ using namespace svs;
 using namespace svs::render;
 
 extern "C" {
+
+size_t svs_loss_workspace_bytes(int n_rays, int n_eik) { return (size_t)(n_rays + (n_eik + 63) / 64 + 4) * 4 * sizeof(double); }
 
 int svs_rays_from_uv(const float* uv, const float* pose, const float* intrinsics, int n_rays, float* ray_dirs,
                      float* cam_loc, float* depth_scale, void* hip_stream) {
@@ -492,15 +506,17 @@ int svs_loss(int n_rays, int n_samples, int n_eik, const float* rgb_values, cons
              const float* grad_theta, const float* weights, const float* pi, const float* pj, const float* depth_values,
              float rgb_weight, float eikonal_weight, float mvs_weight, float sparse_weight, float gce, float confi,
              int annealed, float anneal_sparse, float* losses, float* d_rgb_values, float* d_grad_theta,
-             float* d_weights, float* d_depth_values, void* hip_stream) {
+             float* d_weights, float* d_depth_values, double* workspace, void* hip_stream) {
   if (!rgb_values || !rgb_target || !weights || !depth_values || !losses || !d_rgb_values || !d_weights ||
-      !d_depth_values || n_rays <= 0 || n_samples <= 0 || (n_eik > 0 && (!grad_theta || !d_grad_theta)) || (!pi != !pj)) {
+      !d_depth_values || !workspace || n_rays <= 0 || n_samples <= 0 || n_samples > 256 || (n_eik > 0 && (!grad_theta || !d_grad_theta)) || (!pi != !pj)) {
     set_error("svs_loss: null/invalid argument"); return SVS_EINVAL;
   }
   LossArgs a{n_rays, n_samples, n_eik, rgb_values, rgb_target, grad_theta, weights, pi, pj, depth_values, rgb_weight,
              eikonal_weight, mvs_weight, sparse_weight, gce, confi, anneal_sparse, annealed, losses, d_rgb_values,
              d_grad_theta, d_weights, d_depth_values};
-  loss_kernel<<<1, 1024, 0, (hipStream_t)hip_stream>>>(a);
+  const int n_units = n_rays + (n_eik + 63) / 64;
+  loss_rays_kernel<<<(n_units + 3) / 4, 256, 0, (hipStream_t)hip_stream>>>(a, workspace);
+  loss_reduce_kernel<<<1, 256, 0, (hipStream_t)hip_stream>>>(a, workspace, n_units);
   return check_launch("svs_loss");
 }
 

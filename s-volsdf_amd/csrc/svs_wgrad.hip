@@ -135,7 +135,7 @@ extern "C" {
 int svs_wgrad(const float* a0, const float* a0_h, const float* b0, long long sa0, long long sh0, long long sb0,
               const float* a1, const float* a1_h, const float* b1, long long sa1, long long sh1, long long sb1,
               const float* b_extra, long long s_extra, int n_points, float* dW, int ldw, float* db, void* hip_stream) {
-  if (!a0 || !b0 || !dW || n_points <= 0 || ldw < 32 || ldw > 288) { set_error("svs_wgrad: bad argument"); return SVS_EINVAL; }
+  if (!a0 || !b0 || !dW || n_points <= 0 || ldw < 256 || ldw > 288 || (b_extra && ldw < 288)) { set_error("svs_wgrad: bad argument"); return SVS_EINVAL; }
   Args a;
   a.p[0] = Pair{a0, a0_h, b0, (size_t)sa0, (size_t)sh0, (size_t)sb0, 0};
   a.n_pairs = 1;
@@ -150,7 +150,7 @@ int svs_wgrad(const float* a0, const float* a0_h, const float* b0, long long sa0
   a.dW = dW; a.ldw = ldw; a.db = db;
   hipStream_t s = (hipStream_t)hip_stream;
   const int grid = a.n_tiles < 256 ? a.n_tiles : 256;
-  if (ldw > 256) {
+  if (b_extra) {
     constexpr int lds = (256 + 288) * kPitch * 4;
     static hipError_t e9 = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<9>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);

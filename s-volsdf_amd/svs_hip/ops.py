@@ -265,10 +265,11 @@ def loss_fwd_bwd(rgb_values, rgb_target, weights, depth_values, grad_theta=None,
     d_gt = torch.empty(n_eik, 3, device=dev) if n_eik else None
     d_w = torch.empty(R, S, device=dev)
     d_dep = torch.empty(R, 1, device=dev)
+    ws = torch.empty(L.svs_loss_workspace_bytes(R, n_eik) // 8, dtype=torch.float64, device=dev)
     _lib.check(L.svs_loss(R, S, n_eik, _ptr(rgb_values), _ptr(rgb_target), _ptr(gt), _ptr(weights), _ptr(pi_), _ptr(pj_),
                           _ptr(depth_values), float(rgb_weight), float(eikonal_weight), float(mvs_weight),
                           float(sparse_weight), float(gce), float(confi), int(bool(annealed)), float(anneal_sparse),
-                          _ptr(losses), _ptr(d_rgb), _ptr(d_gt), _ptr(d_w), _ptr(d_dep), _stream()), "svs_loss")
+                          _ptr(losses), _ptr(d_rgb), _ptr(d_gt), _ptr(d_w), _ptr(d_dep), _ptr(ws), _stream()), "svs_loss")
     return losses, dict(rgb_values=d_rgb, grad_theta=d_gt, weights=d_w, depth_values=d_dep)
 
 

@@ -1,0 +1,83 @@
+"""world_size-2 gloo test (CPU) of the data-parallel host logic: ray sharding, loss scaling by 1/world, flat parameter /
+gradient buffers and the single all-reduce of the flat gradient (what bench.py --gpus N / TrainStep do over RCCL)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _toy_model():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Linear(2, 16), torch.nn.Softplus(beta=100), torch.nn.Linear(16, 3))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "s-volsdf_amd"))
+    import torch.distributed as dist
+    from svs_hip.trainer import FlatParams, allreduce_flat_grad, shard_rays
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = _toy_model()
+    fp = FlatParams(list(model.parameters()))
+    uv = torch.arange(64, dtype=torch.float32).reshape(1, 32, 2) / 10.0           # the same global batch on every rank
+    gt = torch.linspace(0, 1, 96).reshape(32, 3)
+    k = 32 // world
+    mine = shard_rays(uv, rank, world)
+    assert mine.shape == (1, k, 2)
+    fp.grad.zero_()
+    out = model(mine[0])
+    # each rank's mean is over its shard; dividing by world makes the all-reduced sum the global-batch mean
+    loss = (out - gt[rank * k:(rank + 1) * k]).abs().mean() / world
+    loss.backward()
+    assert all(p.grad.data_ptr() >= fp.grad.data_ptr() for p in model.parameters()), "grads live in the flat buffer"
+    allreduce_flat_grad(fp.grad, world)
+    q.put((rank, fp.grad.clone().numpy(), fp.flat.clone().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_gradient_equals_full_batch():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference on the whole batch
+    model = _toy_model()
+    uv = torch.arange(64, dtype=torch.float32).reshape(1, 32, 2) / 10.0
+    gt = torch.linspace(0, 1, 96).reshape(32, 3)
+    (model(uv[0]) - gt).abs().mean().backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).numpy()
+    for rank, grad, flat in res:
+        np.testing.assert_allclose(grad, ref, rtol=1e-5, atol=1e-7)
+    np.testing.assert_array_equal(res[0][2], res[1][2])       # replicas stay identical
+
+
+def test_shard_rays_rejects_ragged():
+    sys.path.insert(0, os.path.join(ROOT, "s-volsdf_amd"))
+    from svs_hip.trainer import shard_rays
+    with pytest.raises(ValueError):
+        shard_rays(torch.zeros(1, 10, 2), 0, 4)
+    full = torch.arange(16.).reshape(1, 8, 2)
+    parts = [shard_rays(full, r, 4) for r in range(4)]
+    assert torch.equal(torch.cat(parts, 1), full)
