@@ -111,14 +111,21 @@ def main():
                           sparse_weight=1.0, anneal_rgb=200, gce=0.5, confi=1e-3)       # config/ours.yaml:16-21
         ts = TrainStep(model, loss, lr=5e-4, world=world, rank=rank)
 
+    wg_ev = []
+
     def step():
         if train:
-            return ts(inp, gt, mvs=mvs)
+            r = ts(inp, gt, mvs=mvs)
+            if ev_on[0] and model._mlp_bwd.timer_events:
+                wg_ev.append(model._mlp_bwd.timer_events)
+            return r
         with torch.no_grad():
             return model(inp, fast=1)
 
     for _ in range(args.warmup):
         step()
+    if train:
+        model._mlp_bwd.time_wgrad = True
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -148,6 +155,21 @@ def main():
             # backward: second-order sweep + backprop of the SDF MLP (2 x 8 layers), its two weight-gradient
             # contractions per layer, radiance backprop + weight gradients (approximate, SURVEY.md 8d: 0.92 GFLOP/ray)
             flop_per_ray += (S + 2) * (2 * F_SDF + 2 * F_SDF) + S * (2 * F_RGB)
+        roof_full = {"bound": "mfma", "kernel": "sdf_full_kernel (SDF MLP forward + input gradient + features)",
+                     "achieved": achieved / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_F32_MFMA, "traffic": None, "kernel_ms": k_ms, "launches_per_step": 1,
+                     "points_per_launch": n_pts, "flop_per_point": 2 * F_SDF}
+        roofline = roof_full
+        if train and wg_ev:
+            # 9 launches of wgrad_kernel<8> per step: dW_l = abar_l h_l^T + ghat_l u_l^T (l = 0..7) and the feature head
+            w_ms = float(np.mean([a.elapsed_time(b) for a, b in wg_ev]))
+            w_flop = (2 * 2 * (F_SDF // 2 - 257 * 256) + 2 * 256 * 256) * n_pts      # algorithmic: 2 pairs x 2 x rows x cols
+            roof_w = {"bound": "mfma", "kernel": "wgrad_kernel<8> (SDF weight gradients, 9 launches per step)",
+                      "achieved": w_flop / (w_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
+                      "frac": w_flop / (w_ms * 1e-3) / PEAK_F32_MFMA, "traffic": None, "kernel_ms": w_ms / 9,
+                      "launches_per_step": 9, "flop_per_step": w_flop}
+            # the dominant kernel is the one with the larger total time per step
+            roofline = dict(roof_w, other=roof_full) if w_ms > k_ms else dict(roof_full, other=roof_w)
         line = {
             "metric": "rendered rays/sec (1024-ray batch, 128 samples)",
             "value": world * R * args.steps / dt,
@@ -168,10 +190,7 @@ def main():
                        "mode": args.mode,
                        "rays_per_gpu": R, "flop_per_ray": flop_per_ray,
                        "model_flops_per_s": world * R * args.steps / dt * flop_per_ray},
-            "roofline": {"bound": "mfma", "kernel": "sdf_full_kernel (SDF MLP forward + input gradient + features)",
-                         "achieved": achieved / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA, "traffic": None,
-                         "kernel_ms": k_ms, "points_per_launch": n_pts, "flop_per_point": 2 * F_SDF},
+            "roofline": roofline,
         }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(params, K, pose, train=train)

@@ -103,6 +103,17 @@ class TrainStep:
         self.opt = FusedAdam(self.fp, lr=lr, max_norm=1.0 if grad_clip else 0.0)
         self.world, self.rank = world, rank
         self.grad_views = self.fp.views(self.fp.grad)
+        # the unpack kernels write straight into the flat gradient buffer: (grad_v, grad_g, grad_b) views per layer
+        it = iter(self.grad_views)
+        self.grad_out = []
+        for net, n in ((model.implicit_network, 9), (model.rendering_network, 5)):
+            group = []
+            for _ in range(n):
+                gv = next(it)
+                gg = next(it) if net.weight_norm else None
+                group.append((gv, gg, next(it)))
+            self.grad_out.append(group)
+        self.beta_grad = next(it)
 
     def __call__(self, model_input, ground_truth, mvs=None, fast=1):
         """mvs: optional dict(views=[...], same_view=int, img_res=(H,W), inverse_depth=bool) for cost_mapping."""
@@ -117,18 +128,10 @@ class TrainStep:
         loss_out = self.loss(out, ground_truth)
         g = self.loss.last_grads
         scale = 1.0 / self.world       # each rank's means are over its own shard
-        sdf_g, rgb_g, d_beta = m.backward_from_output_grads(keep, g["rgb_values"] * scale, g["weights"] * scale,
-                                                            g["depth_values"] * scale,
-                                                            g["grad_theta"] * scale if g["grad_theta"] is not None else None)
-        # write into the flat gradient buffer in _flat_param_list() order
-        it = iter(self.grad_views)
-        for group, wn in ((sdf_g, m.implicit_network.weight_norm), (rgb_g, m.rendering_network.weight_norm)):
-            for gv, gg, gb in group:
-                next(it).copy_(gv)
-                if wn:
-                    next(it).copy_(gg)
-                next(it).copy_(gb)
-        next(it).copy_(d_beta.reshape(()))
+        sc = (lambda t: t if (scale == 1.0 or t is None) else t * scale)
+        _, _, d_beta = m.backward_from_output_grads(keep, sc(g["rgb_values"]), sc(g["weights"]), sc(g["depth_values"]),
+                                                    sc(g["grad_theta"]), out=self.grad_out)
+        self.beta_grad.copy_(d_beta.reshape(()))
         allreduce_flat_grad(self.fp.grad, self.world)
         self.opt.step()
         m.invalidate_packed()          # the fused kernel bypasses torch's version counters

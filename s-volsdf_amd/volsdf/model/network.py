@@ -246,7 +246,8 @@ class VolSDFNetwork(nn.Module):
             output['normal_map'] = comp["normal_map"]
         return output
 
-    def backward_from_output_grads(self, keep, g_rgb_values, g_weights=None, g_depth_values=None, g_grad_theta=None):
+    def backward_from_output_grads(self, keep, g_rgb_values, g_weights=None, g_depth_values=None, g_grad_theta=None,
+                                   out=None):
         """d loss / d parameters from d loss / d (rgb_values, weights, depth_values, grad_theta): compositing
         backward, then the fused MLP backward.  Returns (sdf_grads, rgb_grads, d_beta)."""
         from svs_hip.train import MlpBackward
@@ -263,7 +264,7 @@ class VolSDFNetwork(nn.Module):
         if g_grad_theta is None and n_extra:
             g_grad_theta = torch.zeros(n_extra, 3, device=dev)
         sdf_p, rgb_p = self.mlp_params()
-        sdf_g, rgb_g = self._mlp_bwd.run(sdf_p, rgb_p, keep, d_rgb, d_sdf, g_grad_theta)
+        sdf_g, rgb_g = self._mlp_bwd.run(sdf_p, rgb_p, keep, d_rgb, d_sdf, g_grad_theta, out=out)
         return sdf_g, rgb_g, d_beta
 
     def volume_rendering(self, z_vals, sdf):
