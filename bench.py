@@ -159,6 +159,18 @@ def main():
                      "achieved": achieved / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_F32_MFMA, "traffic": None, "kernel_ms": k_ms, "launches_per_step": 1,
                      "points_per_launch": n_pts, "flop_per_point": 2 * F_SDF}
+        # HBM traffic per launch: PMC counters of the committed profile of this same command (profiles/, see
+        # tools/summarize_profiles.py); the bench itself cannot run the counters
+        try:
+            prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
+            pk = json.load(open(os.path.join(ROOT, "profiles", prof[-1])))["kernels"]
+            traffic = {"sdf_full": pk["svs::mlp::sdf_full_kernel"]["hbm_bytes"],
+                       "wgrad8": pk.get("svs::wgrad::wgrad_kernel<8>", {}).get("hbm_bytes")}
+            src_prof = prof[-1]
+        except Exception:
+            traffic, src_prof = {"sdf_full": None, "wgrad8": None}, None
+        roof_full["traffic"] = traffic["sdf_full"]
+        roof_full["traffic_source"] = src_prof
         roofline = roof_full
         if train and wg_ev:
             # 9 launches of wgrad_kernel<8> per step: dW_l = abar_l h_l^T + ghat_l u_l^T (l = 0..7) and the feature head
@@ -168,6 +180,7 @@ def main():
                       "achieved": w_flop / (w_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
                       "frac": w_flop / (w_ms * 1e-3) / PEAK_F32_MFMA, "traffic": None, "kernel_ms": w_ms / 9,
                       "launches_per_step": 9, "flop_per_step": w_flop}
+            roof_w["traffic"], roof_w["traffic_source"] = traffic["wgrad8"], src_prof
             # the dominant kernel is the one with the larger total time per step
             roofline = dict(roof_w, other=roof_full) if w_ms > k_ms else dict(roof_full, other=roof_w)
         line = {
