@@ -41,7 +41,8 @@ __device__ __forceinline__ float dsoftplus_from_h(float h) {
 }
 
 struct Staging {
-  f32x4 a[8], b[8], x;
+  f32x4 a[8], b[8], h[8], x;
+  bool has_h;
 };
 
 template <int NTB>
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(Args a) {
   const int my_tiles = a.n_tiles > (int)blockIdx.x ? (a.n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
   const int n_items = my_tiles * a.n_pairs;
   Staging st;
+  int st_live = 32;
 
   auto issue = [&](int item) {
     const int t = blockIdx.x + (item / a.n_pairs) * gridDim.x, pi = item % a.n_pairs;
@@ -69,29 +71,33 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(Args a) {
     const f32x4* gb = reinterpret_cast<const f32x4*>(p.b + (size_t)t * p.stride_b);
 #pragma unroll
     for (int k = 0; k < 8; ++k) { st.a[k] = ga[k * 256 + tid]; st.b[k] = gb[k * 256 + tid]; }
-    if (p.a_h) {
+    st.has_h = p.a_h != nullptr;
+    if (st.has_h) {       // the softplus' factor is applied at commit time, so that these loads stay in flight
       const f32x4* gh = reinterpret_cast<const f32x4*>(p.a_h + (size_t)t * p.stride_h);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const f32x4 h = gh[k * 256 + tid];
-        st.a[k][0] *= dsoftplus_from_h(h[0]); st.a[k][1] *= dsoftplus_from_h(h[1]);
-        st.a[k][2] *= dsoftplus_from_h(h[2]); st.a[k][3] *= dsoftplus_from_h(h[3]);
-      }
+      for (int k = 0; k < 8; ++k) st.h[k] = gh[k * 256 + tid];
     }
     if (NTB == 9) {
       st.x = (a.b_extra && pi == 0) ? reinterpret_cast<const f32x4*>(a.b_extra + (size_t)t * a.stride_extra)[tid]
                                     : (f32x4)(0.0f);
     }
-    const int live = a.n_valid_points - t * 32;
-    if (live < 32) {
-      // ragged last tile: points beyond the batch contribute nothing
-#pragma unroll
-      for (int k = 0; k < 8; ++k) if ((tid & 31) >= live) st.a[k] = (f32x4)(0.0f);
-    }
+    st_live = a.n_valid_points - t * 32;
   };
   auto commit = [&](int buf) {
     float* la = smem + buf * BUF;
     float* lb = la + 32 * PA;
+    if (st.has_h) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        st.a[k][0] *= dsoftplus_from_h(st.h[k][0]); st.a[k][1] *= dsoftplus_from_h(st.h[k][1]);
+        st.a[k][2] *= dsoftplus_from_h(st.h[k][2]); st.a[k][3] *= dsoftplus_from_h(st.h[k][3]);
+      }
+    }
+    if (st_live < 32) {
+      // ragged last tile: points beyond the batch contribute nothing
+#pragma unroll
+      for (int k = 0; k < 8; ++k) if ((tid & 31) >= st_live) st.a[k] = (f32x4)(0.0f);
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int q = k * 256 + tid, i4 = q >> 6, ln = q & 63;
