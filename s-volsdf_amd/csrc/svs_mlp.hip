@@ -137,34 +137,27 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_kernel(SdfFullArgs a) {
   f32x16 skip7;          // g(PE[0..31]) from the skip connection (tile 7 of g(h_4 spliced))
   f32x16 skip6;          // tile 6; only local rows 25..31 are PE[32..38]
   for (int l = 7; l >= 1; --l) {
+    const float* hblk = hb + (size_t)(l - 1) * kBlockF;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
+      const f32x16 h = load_tile(hblk, t, lane);   // issued before the MFMAs: arrives while they run
       st.prefetch<kChunkF4>();                     // next reverse chunk (the last one prefetches REV0 tile 0)
-      x[t] = tile_mma<128>(st.cur_buf(), y, lane);   // g(h_l) rows 32t..32t+31
+      const f32x16 acc = tile_mma<128>(st.cur_buf(), y, lane);   // g(h_l) rows 32t..32t+31
+      if (gb) store_tile(gb + (size_t)(l - 1) * kBlockF, t, lane, acc);
+      if (l == 4 && t == 7) skip7 = acc;
+      if (l == 4 && t == 6) skip6 = acc;
+      // g(a_{l-1}) = g(h_l) * softplus'(a_{l-1}),  softplus' from the stored h_l
+#pragma unroll
+      for (int i = 0; i < 16; ++i) x[t][i] = acc[i] * dsoftplus_from_h(h[i]);
       st.advance();
-    }
-    if (l == 4) { skip7 = x[7]; skip6 = x[6]; }
-    if (gb) store_tile_regs(gb + (size_t)(l - 1) * kBlockF, x, lane);   // g(h_l)
-    // g(a_{l-1}) = g(h_l) * softplus'(a_{l-1}),  softplus' from the stored h_l
-    const f32x4* hsrc = reinterpret_cast<const f32x4*>(hb + (size_t)(l - 1) * 128 * 64) + lane;
-#pragma unroll
-    for (int i4 = 0; i4 < 32; ++i4) {
-      const f32x4 h = hsrc[i4 * 64];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) y[i4 / 4][4 * (i4 % 4) + j] = x[i4 / 4][4 * (i4 % 4) + j] * dsoftplus_from_h(h[j]);
     }
     if (l == 4) {
       // rows >= 217 of h_4 are the PE splice, not softplus outputs: they do not flow into lin3
-      y[7] = (f32x16)(0.0f);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row0 = rho(r), row1 = rho(r) + 4;
-        if (row0 >= 25 || row1 >= 25) {
-          const bool z0 = row0 >= 25, z1 = row1 >= 25;
-          if (half ? z1 : z0) y[6][r] = 0.0f;
-        }
-      }
+      x[7] = (f32x16)(0.0f);
+      zero_splice_rows_tile6(x[6], half);
     }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) y[t] = x[t];
   }
   // ---- reverse layer 0: g(PE) = W0^T g(a_0) (+ skip), 2 tiles
   st.prefetch<kChunkF4>();

@@ -20,34 +20,6 @@
 namespace svs {
 namespace mlp {
 
-__device__ __forceinline__ f32x16 load_tile(const float* __restrict__ block, int t, int lane) {
-  const f32x4* d = reinterpret_cast<const f32x4*>(block) + lane;
-  f32x16 v;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const f32x4 f = d[(4 * t + q) * 64];
-    v[4 * q] = f[0]; v[4 * q + 1] = f[1]; v[4 * q + 2] = f[2]; v[4 * q + 3] = f[3];
-  }
-  return v;
-}
-__device__ __forceinline__ void store_tile(float* __restrict__ block, int t, int lane, const f32x16& v) {
-  f32x4* d = reinterpret_cast<f32x4*>(block) + lane;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    f32x4 f; f[0] = v[4 * q]; f[1] = v[4 * q + 1]; f[2] = v[4 * q + 2]; f[3] = v[4 * q + 3];
-    d[(4 * t + q) * 64] = f;
-  }
-}
-
-// zero the accumulator rows >= 217 of tile 6 (local rows 25..31): the PE splice, not network outputs
-__device__ __forceinline__ void zero_splice_rows_tile6(f32x16& v, int half) {
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const bool z0 = rho(r) >= 25, z1 = rho(r) + 4 >= 25;
-    if (z0 || z1) { if (half ? z1 : z0) v[r] = 0.0f; }
-  }
-}
-
 // ==============================================================================================================
 // radiance MLP backward
 // ==============================================================================================================
@@ -211,9 +183,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_kernel(SdfBwdAArgs a) {
   st.advance();
 
   f32x16 x[8], y[8];
-  auto epilogue = [&](int l, int t, const f32x16& v, f32x16& u_next) {
-    const f32x16 h = load_tile(hb + (size_t)l * kBlockF, t, lane);
-    const f32x16 g = load_tile(gb + (size_t)l * kBlockF, t, lane);
+  auto epilogue = [&](int l, int t, const f32x16& v, const f32x16& h, const f32x16& g, f32x16& u_next) {
     f32x16 a2v;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -227,9 +197,10 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_kernel(SdfBwdAArgs a) {
   // layer 0
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
+    const f32x16 h = load_tile(hb, t, lane), g = load_tile(gb, t, lane);   // in flight during the MFMAs
     if (t < 7) st.prefetch<kChunk0F4>(); else st.prefetch<kChunkF4>();
     const f32x16 v = tile_mma_pe(st.cur_buf(), u0, lane, half);
-    epilogue(0, t, v, x[t]);
+    epilogue(0, t, v, h, g, x[t]);
     st.advance();
   }
   store_tile_regs(ub + 1 * (size_t)kBlockF, x, lane);
@@ -237,9 +208,10 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_kernel(SdfBwdAArgs a) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       if (t == 7 && l == 3) break;
+      const f32x16 h = load_tile(hb + (size_t)l * kBlockF, t, lane), g = load_tile(gb + (size_t)l * kBlockF, t, lane);
       if (!(l == 7 && t == 7)) st.prefetch<kChunkF4>();
       const f32x16 v = tile_mma<128>(st.cur_buf(), x, lane);
-      epilogue(l, t, v, y[t]);
+      epilogue(l, t, v, h, g, y[t]);
       if (!(l == 7 && t == 7)) st.advance();
     }
     if (l == 3) {
@@ -291,35 +263,37 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_kernel(SdfBwdBArgs a) {
     for (int t = 0; t < 8; ++t) y[t] = (f32x16)(0.0f);
   }
   st.advance();
-  // hbar_8 = W8[1:,:]^T fbar + sbar * W8[0,:]   (W8[0,:] in accumulator layout = gbuf block 7)
+  // hbar_8 = W8[1:,:]^T fbar + sbar * W8[0,:]   (W8[0,:] in accumulator layout = gbuf block 7), fused with
+  // abar_7 = hbar_8 * s'(a_7) + a2_7; the tiles of h_8 / a2_7 / W8[0,:] are requested before the MFMAs of the tile
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
-    st.prefetch<kChunkF4>();
-    f32x16 acc = tile_mma<128>(st.cur_buf(), y, lane);
     const f32x16 w0 = load_tile(gb + 7 * (size_t)kBlockF, t, lane);
+    const f32x16 h = load_tile(hb + 7 * (size_t)kBlockF, t, lane);
+    const f32x16 s2 = load_tile(a2 + 7 * (size_t)kBlockF, t, lane);
+    st.prefetch<kChunkF4>();
+    const f32x16 acc = tile_mma<128>(st.cur_buf(), y, lane);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] += sbar * w0[i];
-    x[t] = acc;
+    for (int i = 0; i < 16; ++i) x[t][i] = (acc[i] + sbar * w0[i]) * dsoftplus_from_h(h[i]) + s2[i];
+    store_tile(ab + 7 * (size_t)kBlockF, t, lane, x[t]);
     st.advance();
   }
-  for (int l = 7; l >= 0; --l) {
-    // abar_l = hbar_{l+1} * s'(a_l) + a2_l
+  for (int l = 7; l >= 1; --l) {
+    // x = abar_l; hbar_l = W_l^T abar_l, fused with abar_{l-1} = hbar_l * s'(a_{l-1}) + a2_{l-1}
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      const f32x16 h = load_tile(hb + (size_t)l * kBlockF, t, lane);
-      const f32x16 s2 = load_tile(a2 + (size_t)l * kBlockF, t, lane);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) y[t][i] = x[t][i] * dsoftplus_from_h(h[i]) + s2[i];
-    }
-    if (l == 3) { y[7] = (f32x16)(0.0f); zero_splice_rows_tile6(y[6], half); }
-    store_tile_regs(ab + (size_t)l * kBlockF, y, lane);
-    if (l == 0) break;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
+      const f32x16 h = load_tile(hb + (size_t)(l - 1) * kBlockF, t, lane);
+      const f32x16 s2 = load_tile(a2 + (size_t)(l - 1) * kBlockF, t, lane);
       if (!(l == 1 && t == 7)) st.prefetch<kChunkF4>();
-      x[t] = tile_mma<128>(st.cur_buf(), y, lane);      // hbar_l
+      const f32x16 acc = tile_mma<128>(st.cur_buf(), x, lane);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) y[t][i] = acc[i] * dsoftplus_from_h(h[i]) + s2[i];
+      if (l == 4 && t == 7) y[7] = (f32x16)(0.0f);          // abar_3 rows >= 217: the PE splice rows of h_4
+      if (l == 4 && t == 6) zero_splice_rows_tile6(y[6], half);
+      store_tile(ab + (size_t)(l - 1) * kBlockF, t, lane, y[t]);
       if (!(l == 1 && t == 7)) st.advance();
     }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x[t] = y[t];
   }
 }
 

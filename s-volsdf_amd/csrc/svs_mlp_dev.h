@@ -193,6 +193,34 @@ __device__ __forceinline__ void load_tile_regs(const float* __restrict__ src, f3
   }
 }
 
+__device__ __forceinline__ f32x16 load_tile(const float* __restrict__ block, int t, int lane) {
+  const f32x4* d = reinterpret_cast<const f32x4*>(block) + lane;
+  f32x16 v;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 f = d[(4 * t + q) * 64];
+    v[4 * q] = f[0]; v[4 * q + 1] = f[1]; v[4 * q + 2] = f[2]; v[4 * q + 3] = f[3];
+  }
+  return v;
+}
+__device__ __forceinline__ void store_tile(float* __restrict__ block, int t, int lane, const f32x16& v) {
+  f32x4* d = reinterpret_cast<f32x4*>(block) + lane;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 f; f[0] = v[4 * q]; f[1] = v[4 * q + 1]; f[2] = v[4 * q + 2]; f[3] = v[4 * q + 3];
+    d[(4 * t + q) * 64] = f;
+  }
+}
+
+// zero the accumulator rows >= 217 of tile 6 (local rows 25..31): the PE splice, not network outputs
+__device__ __forceinline__ void zero_splice_rows_tile6(f32x16& v, int half) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const bool z0 = rho(r) >= 25, z1 = rho(r) + 4 >= 25;
+    if (z0 || z1) { if (half ? z1 : z0) v[r] = 0.0f; }
+  }
+}
+
 // Forward through layers 0..7; on return x holds h_8 (the input of lin8).  When HBUF, every layer's
 // activations (h_1..h_8) are also stored to this wave's scratch tile (reverse pass / training backward).
 template <bool HBUF>
