@@ -115,19 +115,16 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_kernel(SdfFullArgs a) {
   if (gb) store_tile_regs(gb + 7 * (size_t)kBlockF, y, lane);       // g(h_8) = W8[0,:]
   // ---- feature vector = rows 1..256 of lin8
   float* ft = a.feat_tiles ? a.feat_tiles + (size_t)wtile * 128 * 64 : nullptr;
+  {
+    f32x16 pend;
 #pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    st.prefetch<kChunkF4>();                     // FEAT t+1, or reverse L7 tile 0
-    const f32x16 acc = tile_mma<128>(st.cur_buf(), x, lane);
-    if (ft) {
-      f32x4* d = reinterpret_cast<f32x4*>(ft) + lane;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        f32x4 v; v[0] = acc[4 * q]; v[1] = acc[4 * q + 1]; v[2] = acc[4 * q + 2]; v[3] = acc[4 * q + 3];
-        d[(4 * t + q) * 64] = v;
-      }
+    for (int t = 0; t < 8; ++t) {
+      if (ft && t > 0) store_tile(ft, t - 1, lane, pend);   // deferred store (see forward_trunk)
+      st.prefetch<kChunkF4>();                                // FEAT t+1, or reverse L7 tile 0
+      pend = tile_mma<128>(st.cur_buf(), x, lane);
+      st.advance();
     }
-    st.advance();
+    if (ft) store_tile(ft, 7, lane, pend);
   }
   // g(a_7) = g(h_8) * softplus'(a_7), h_8 still in x
 #pragma unroll
@@ -138,12 +135,15 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_kernel(SdfFullArgs a) {
   f32x16 skip6;          // tile 6; only local rows 25..31 are PE[32..38]
   for (int l = 7; l >= 1; --l) {
     const float* hblk = hb + (size_t)(l - 1) * kBlockF;
+    float* gblk = gb ? gb + (size_t)(l - 1) * kBlockF : nullptr;
+    f32x16 pend;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
+      if (gblk && t > 0) store_tile(gblk, t - 1, lane, pend);   // g(h_l) tile t-1, deferred store
       const f32x16 h = load_tile(hblk, t, lane);   // issued before the MFMAs: arrives while they run
       st.prefetch<kChunkF4>();                     // next reverse chunk (the last one prefetches REV0 tile 0)
       const f32x16 acc = tile_mma<128>(st.cur_buf(), y, lane);   // g(h_l) rows 32t..32t+31
-      if (gb) store_tile(gb + (size_t)(l - 1) * kBlockF, t, lane, acc);
+      pend = acc;
       if (l == 4 && t == 7) skip7 = acc;
       if (l == 4 && t == 6) skip6 = acc;
       // g(a_{l-1}) = g(h_l) * softplus'(a_{l-1}),  softplus' from the stored h_l
@@ -151,6 +151,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_kernel(SdfFullArgs a) {
       for (int i = 0; i < 16; ++i) x[t][i] = acc[i] * dsoftplus_from_h(h[i]);
       st.advance();
     }
+    if (gblk) store_tile(gblk, 7, lane, pend);
     if (l == 4) {
       // rows >= 217 of h_4 are the PE splice, not softplus outputs: they do not flow into lin3
       x[7] = (f32x16)(0.0f);
@@ -282,6 +283,7 @@ __global__ __launch_bounds__(kThreads, 1) void rgb_kernel(RgbArgs a) {
   // ---- layer 0: 271 -> 256
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
+    if (rb && t > 0) store_tile(rb, t - 1, lane, y[t - 1]);     // deferred store (see forward_trunk)
     if (t < 7) st.prefetch<kRgbChunk0F4>(); else st.prefetch<kChunkF4>();
     const f32x4* chunk = st.cur_buf();
     f32x16 acc = tile_mma<128>(chunk, x, lane);
@@ -296,20 +298,21 @@ __global__ __launch_bounds__(kThreads, 1) void rgb_kernel(RgbArgs a) {
     for (int r = 0; r < 16; ++r) y[t][r] = __builtin_fmaxf(acc[r], 0.0f);
     st.advance();
   }
-  if (rb) store_tile_regs(rb, y, lane);
+  if (rb) store_tile(rb, 7, lane, y[7]);
   // ---- layers 1..3
   for (int l = 1; l < 4; ++l) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) x[t] = y[t];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
+      if (rb && t > 0) store_tile(rb + (size_t)l * kBlockF, t - 1, lane, y[t - 1]);
       st.prefetch<kChunkF4>();
       const f32x16 acc = tile_mma<128>(st.cur_buf(), x, lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) y[t][r] = __builtin_fmaxf(acc[r], 0.0f);
       st.advance();
     }
-    if (rb) store_tile_regs(rb + (size_t)l * kBlockF, y, lane);
+    if (rb) store_tile(rb + (size_t)l * kBlockF, 7, lane, y[7]);
   }
   // ---- layer 4: 256 -> 3 as one tile (rows 0..2 live in registers 0..2 of lanes 0..31), sigmoid
   const f32x16 acc = tile_mma<128>(st.cur_buf(), y, lane);

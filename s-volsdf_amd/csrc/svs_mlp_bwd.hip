@@ -102,11 +102,13 @@ __global__ __launch_bounds__(kThreads, 1) void rgb_bwd_kernel(RgbBwdArgs a) {
   }
   store_tile_regs(zb, y, lane);
   float* fb = a.feat_bar + (size_t)wtile * kBlockF;
+  f32x16 pend;
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
+    if (t > 0) store_tile(fb, t - 1, lane, pend);        // deferred store of the previous feature-gradient tile
     if (t < 8) st.prefetch<kChunkF4>();
     const f32x16 acc = tile_mma<128>(st.cur_buf(), y, lane);
-    if (t < 8) { store_tile(fb, t, lane, acc); st.advance(); }
+    if (t < 8) { pend = acc; st.advance(); }
     else if (half == 1 && livep) {
       // extra rows 12,13,14 (normals, network.py:175) = local rows rho(4..6)+4 of the extras tile
       a.d_normals[3 * p] = acc[4]; a.d_normals[3 * p + 1] = acc[5]; a.d_normals[3 * p + 2] = acc[6];
@@ -183,8 +185,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_kernel(SdfBwdAArgs a) {
   st.advance();
 
   f32x16 x[8], y[8];
-  auto epilogue = [&](int l, int t, const f32x16& v, const f32x16& h, const f32x16& g, f32x16& u_next) {
-    f32x16 a2v;
+  auto epilogue = [&](int l, int t, const f32x16& v, const f32x16& h, const f32x16& g, f32x16& u_next, f32x16& a2v) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const float s1 = dsoftplus_from_h(h[i]);
@@ -192,35 +193,49 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_kernel(SdfBwdAArgs a) {
       a2v[i] = v[i] * g[i] * (100.0f * s1 * (1.0f - s1));
     }
     if (l == 3 && t == 6) zero_splice_rows_tile6(a2v, half);
-    store_tile(a2 + (size_t)l * kBlockF, t, lane, a2v);
   };
+  // Stores of tile t-1 (a2 and u) are issued at the top of tile t, before its loads and weight prefetch.
+  f32x16 pend_a2;
   // layer 0
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
+    if (t > 0) { store_tile(a2, t - 1, lane, pend_a2); store_tile(ub + (size_t)kBlockF, t - 1, lane, x[t - 1]); }
     const f32x16 h = load_tile(hb, t, lane), g = load_tile(gb, t, lane);   // in flight during the MFMAs
     if (t < 7) st.prefetch<kChunk0F4>(); else st.prefetch<kChunkF4>();
     const f32x16 v = tile_mma_pe(st.cur_buf(), u0, lane, half);
-    epilogue(0, t, v, h, g, x[t]);
+    epilogue(0, t, v, h, g, x[t], pend_a2);
     st.advance();
   }
-  store_tile_regs(ub + 1 * (size_t)kBlockF, x, lane);
+  store_tile(a2, 7, lane, pend_a2);
+  store_tile(ub + (size_t)kBlockF, 7, lane, x[7]);
   for (int l = 1; l < 8; ++l) {
+    float* a2l = a2 + (size_t)l * kBlockF;
+    float* ul = ub + (size_t)(l + 1) * kBlockF;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       if (t == 7 && l == 3) break;
+      if (t > 0) {
+        store_tile(a2l, t - 1, lane, pend_a2);
+        if (!(l == 3 && t - 1 == 6)) store_tile(ul, t - 1, lane, y[t - 1]);
+      }
       const f32x16 h = load_tile(hb + (size_t)l * kBlockF, t, lane), g = load_tile(gb + (size_t)l * kBlockF, t, lane);
       if (!(l == 7 && t == 7)) st.prefetch<kChunkF4>();
       const f32x16 v = tile_mma<128>(st.cur_buf(), x, lane);
-      epilogue(l, t, v, h, g, y[t]);
+      epilogue(l, t, v, h, g, y[t], pend_a2);
       if (!(l == 7 && t == 7)) st.advance();
     }
     if (l == 3) {
       splice_skip(y, u0, half);                       // u_4 rows >= 217 carry u_0 (skip connection)
-      store_tile(a2 + 3 * (size_t)kBlockF, 7, lane, (f32x16)(0.0f));
+      store_tile(a2l, 6, lane, pend_a2);
+      store_tile(a2l, 7, lane, (f32x16)(0.0f));
+      store_tile(ul, 6, lane, y[6]);
+      store_tile(ul, 7, lane, y[7]);
+    } else {
+      store_tile(a2l, 7, lane, pend_a2);
+      store_tile(ul, 7, lane, y[7]);
     }
 #pragma unroll
     for (int t = 0; t < 8; ++t) x[t] = y[t];
-    store_tile_regs(ub + (size_t)(l + 1) * kBlockF, x, lane);
   }
 }
 
@@ -267,6 +282,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_kernel(SdfBwdBArgs a) {
   // abar_7 = hbar_8 * s'(a_7) + a2_7; the tiles of h_8 / a2_7 / W8[0,:] are requested before the MFMAs of the tile
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
+    if (t > 0) store_tile(ab + 7 * (size_t)kBlockF, t - 1, lane, x[t - 1]);    // deferred store
     const f32x16 w0 = load_tile(gb + 7 * (size_t)kBlockF, t, lane);
     const f32x16 h = load_tile(hb + 7 * (size_t)kBlockF, t, lane);
     const f32x16 s2 = load_tile(a2 + 7 * (size_t)kBlockF, t, lane);
@@ -274,13 +290,14 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_kernel(SdfBwdBArgs a) {
     const f32x16 acc = tile_mma<128>(st.cur_buf(), y, lane);
 #pragma unroll
     for (int i = 0; i < 16; ++i) x[t][i] = (acc[i] + sbar * w0[i]) * dsoftplus_from_h(h[i]) + s2[i];
-    store_tile(ab + 7 * (size_t)kBlockF, t, lane, x[t]);
     st.advance();
   }
+  store_tile(ab + 7 * (size_t)kBlockF, 7, lane, x[7]);
   for (int l = 7; l >= 1; --l) {
     // x = abar_l; hbar_l = W_l^T abar_l, fused with abar_{l-1} = hbar_l * s'(a_{l-1}) + a2_{l-1}
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
+      if (t > 0) store_tile(ab + (size_t)(l - 1) * kBlockF, t - 1, lane, y[t - 1]);   // deferred store
       const f32x16 h = load_tile(hb + (size_t)(l - 1) * kBlockF, t, lane);
       const f32x16 s2 = load_tile(a2 + (size_t)(l - 1) * kBlockF, t, lane);
       if (!(l == 1 && t == 7)) st.prefetch<kChunkF4>();
@@ -289,9 +306,9 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_kernel(SdfBwdBArgs a) {
       for (int i = 0; i < 16; ++i) y[t][i] = acc[i] * dsoftplus_from_h(h[i]) + s2[i];
       if (l == 4 && t == 7) y[7] = (f32x16)(0.0f);          // abar_3 rows >= 217: the PE splice rows of h_4
       if (l == 4 && t == 6) zero_splice_rows_tile6(y[6], half);
-      store_tile(ab + (size_t)(l - 1) * kBlockF, t, lane, y[t]);
       if (!(l == 1 && t == 7)) st.advance();
     }
+    store_tile(ab + (size_t)(l - 1) * kBlockF, 7, lane, y[7]);
 #pragma unroll
     for (int t = 0; t < 8; ++t) x[t] = y[t];
   }

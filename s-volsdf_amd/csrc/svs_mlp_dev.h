@@ -226,31 +226,40 @@ __device__ __forceinline__ void zero_splice_rows_tile6(f32x16& v, int half) {
 template <bool HBUF>
 __device__ __forceinline__ void forward_trunk(Stream& st, f32x16* x, f32x16* y, const PosEnc& pe, int lane, int half,
                                               float* __restrict__ hbuf) {
+  // Stores of a finished tile are issued at the top of the NEXT tile (before its weight prefetch), so that the
+  // vmcnt(0) of Stream::advance() never waits on a store that was issued a few cycles earlier.
   // ---- layer 0 : 39(40) -> 256
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
+    if (HBUF && t > 0) store_tile(hbuf, t - 1, lane, x[t - 1]);
     if (t < 7) st.prefetch<kChunk0F4>(); else st.prefetch<kChunkF4>();
     const f32x16 acc = tile_mma_pe(st.cur_buf(), pe, lane, half);
 #pragma unroll
     for (int r = 0; r < 16; ++r) x[t][r] = softplus100(acc[r]);
     st.advance();
   }
-  if (HBUF) store_tile_regs(hbuf, x, lane);
+  if (HBUF) store_tile(hbuf, 7, lane, x[7]);
   // ---- layers 1..7 : 256 -> 256 (layer 3 emits 217 rows + the skip splice)
   for (int l = 1; l < 8; ++l) {
+    float* hb = hbuf + (size_t)l * kBlockF;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       if (t == 7 && l == 3) break;  // lin3 has 217 outputs = 7 tiles; tile 7 is the PE splice
+      if (HBUF && t > 0) store_tile(hb, t - 1, lane, y[t - 1]);
       st.prefetch<kChunkF4>();
       const f32x16 acc = tile_mma<128>(st.cur_buf(), x, lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) y[t][r] = softplus100(acc[r]);
       st.advance();
     }
-    if (l == 3) splice_skip(y, pe, half);
+    if (l == 3) {
+      splice_skip(y, pe, half);
+      if (HBUF) { store_tile(hb, 6, lane, y[6]); store_tile(hb, 7, lane, y[7]); }   // tile 5 went out in the loop
+    } else if (HBUF) {
+      store_tile(hb, 7, lane, y[7]);
+    }
 #pragma unroll
     for (int t = 0; t < 8; ++t) x[t] = y[t];
-    if (HBUF) store_tile_regs(hbuf + (size_t)l * 128 * 64, x, lane);
   }
 }
 
