@@ -143,6 +143,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_kernel(SdfFullArgs a) {
       const f32x16 h = load_tile(hblk, t, lane);   // issued before the MFMAs: arrives while they run
       st.prefetch<kChunkF4>();                     // next reverse chunk (the last one prefetches REV0 tile 0)
       const f32x16 acc = tile_mma<128>(st.cur_buf(), y, lane);   // g(h_l) rows 32t..32t+31
+      __builtin_amdgcn_sched_barrier(0);   // keep the epilogue (and its vmcnt wait) behind the MFMAs
       pend = acc;
       if (l == 4 && t == 7) skip7 = acc;
       if (l == 4 && t == 6) skip6 = acc;

@@ -203,6 +203,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_kernel(SdfBwdAArgs a) {
     const f32x16 h = load_tile(hb, t, lane), g = load_tile(gb, t, lane);   // in flight during the MFMAs
     if (t < 7) st.prefetch<kChunk0F4>(); else st.prefetch<kChunkF4>();
     const f32x16 v = tile_mma_pe(st.cur_buf(), u0, lane, half);
+    __builtin_amdgcn_sched_barrier(0);   // keep the epilogue (and its vmcnt wait) behind the MFMAs, see Stream
     epilogue(0, t, v, h, g, x[t], pend_a2);
     st.advance();
   }
@@ -221,6 +222,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_kernel(SdfBwdAArgs a) {
       const f32x16 h = load_tile(hb + (size_t)l * kBlockF, t, lane), g = load_tile(gb + (size_t)l * kBlockF, t, lane);
       if (!(l == 7 && t == 7)) st.prefetch<kChunkF4>();
       const f32x16 v = tile_mma<128>(st.cur_buf(), x, lane);
+      __builtin_amdgcn_sched_barrier(0);
       epilogue(l, t, v, h, g, y[t], pend_a2);
       if (!(l == 7 && t == 7)) st.advance();
     }
@@ -288,6 +290,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_kernel(SdfBwdBArgs a) {
     const f32x16 s2 = load_tile(a2 + 7 * (size_t)kBlockF, t, lane);
     st.prefetch<kChunkF4>();
     const f32x16 acc = tile_mma<128>(st.cur_buf(), y, lane);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 16; ++i) x[t][i] = (acc[i] + sbar * w0[i]) * dsoftplus_from_h(h[i]) + s2[i];
     st.advance();
@@ -302,6 +305,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_kernel(SdfBwdBArgs a) {
       const f32x16 s2 = load_tile(a2 + (size_t)(l - 1) * kBlockF, t, lane);
       if (!(l == 1 && t == 7)) st.prefetch<kChunkF4>();
       const f32x16 acc = tile_mma<128>(st.cur_buf(), x, lane);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 16; ++i) y[t][i] = acc[i] * dsoftplus_from_h(h[i]) + s2[i];
       if (l == 4 && t == 7) y[7] = (f32x16)(0.0f);          // abar_3 rows >= 217: the PE splice rows of h_4
