@@ -61,8 +61,9 @@ __global__ __launch_bounds__(kThreads, 1) void rgb_bwd_kernel(RgbBwdArgs a) {
   }
   st.advance();
   f32x16 x[8], y[8];
-  // rbar_4 = W_4^T zbar_4
+  // rbar_4 = W_4^T zbar_4 (3 k-steps per tile), masked by r_4 > 0 -> zbar_3.  All of r_4 is requested up front.
   st.prefetch<kChunkF4>();
+  load_tile_regs(rb + 3 * (size_t)kBlockF, y, lane);
   {
     const f32x4* c = st.cur_buf();
 #pragma unroll
@@ -75,32 +76,34 @@ __global__ __launch_bounds__(kThreads, 1) void rgb_bwd_kernel(RgbBwdArgs a) {
       x[t] = acc;
     }
   }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) y[t][i] = y[t][i] > 0.0f ? x[t][i] : 0.0f;
+  store_tile_regs(zb + 3 * (size_t)kBlockF, y, lane);
   st.advance();
-  // layers 3..1: zbar_l = rbar_{l+1} * [r_{l+1} > 0];  rbar_l = W_l^T zbar_l
+  // layers 3..1: rbar_l = W_l^T zbar_l, fused per tile with zbar_{l-1} = rbar_l * [r_l > 0]; the r_l tile is requested
+  // before the tile's MFMAs and the zbar tile is stored at the top of the next tile
   for (int l = 3; l >= 1; --l) {
-    const float* rblk = rb + (size_t)l * kBlockF;
+    const float* rblk = rb + (size_t)(l - 1) * kBlockF;
+    float* zblk = zb + (size_t)(l - 1) * kBlockF;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
+      if (t > 0) store_tile(zblk, t - 1, lane, x[t - 1]);
       const f32x16 r = load_tile(rblk, t, lane);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) y[t][i] = r[i] > 0.0f ? x[t][i] : 0.0f;
-    }
-    store_tile_regs(zb + (size_t)l * kBlockF, y, lane);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
       st.prefetch<kChunkF4>();
-      x[t] = tile_mma<128>(st.cur_buf(), y, lane);
+      const f32x16 acc = tile_mma<128>(st.cur_buf(), y, lane);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) x[t][i] = r[i] > 0.0f ? acc[i] : 0.0f;
       st.advance();
     }
-  }
-  // layer 0: zbar_0, then the input gradients (feature rows: tiles 0..7, extras: tile 8)
+    store_tile(zblk, 7, lane, x[7]);
 #pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    const f32x16 r = load_tile(rb, t, lane);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) y[t][i] = r[i] > 0.0f ? x[t][i] : 0.0f;
+    for (int t = 0; t < 8; ++t) y[t] = x[t];
   }
-  store_tile_regs(zb, y, lane);
+  // layer 0: the input gradients from zbar_0 (feature rows: tiles 0..7, extras: tile 8)
   float* fb = a.feat_bar + (size_t)wtile * kBlockF;
   f32x16 pend;
 #pragma unroll
