@@ -80,7 +80,7 @@ def main():
     orig = ops.sdf_outputs
 
     def timed_sdf_outputs(pk, src, *a, **k):
-        if src.n < R * 90 or not ev_on[0]:
+        if src.n < R * 80 or not ev_on[0]:
             return orig(pk, src, *a, **k)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -116,8 +116,8 @@ def main():
     def step():
         if train:
             r = ts(inp, gt, mvs=mvs)
-            if ev_on[0] and model._mlp_bwd.timer_events:
-                wg_ev.append(model._mlp_bwd.timer_events)
+            if ev_on[0] and ts.bwd[0].timer_events:
+                wg_ev.append(ts.bwd[0].timer_events)
             return r
         with torch.no_grad():
             return model(inp, fast=1)
@@ -125,7 +125,7 @@ def main():
     for _ in range(args.warmup):
         step()
     if train:
-        model._mlp_bwd.time_wgrad = True
+        ts.bwd[0].time_wgrad = True
     torch.cuda.synchronize()
     if dist:
         dist.barrier()

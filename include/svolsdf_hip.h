@@ -189,12 +189,13 @@ int svs_cost_lookup(const float* xyz, const float* cam, const float* dirs, const
 /* ---- a11  loss ----------------------------------------------------------------------------------------
  * VolSDFLoss.forward (volsdf/model/loss.py:80-114) and the gradient of the total w.r.t. the model outputs.
  * rgb_target = ground_truth['rgb'], or 'rgb_smooth' with annealed = 1 (loss.py:103-105); pi/pj NULL = no MVS terms.
- * losses[5] = rgb, eikonal, mvs, sparse, total. */
+ * losses[5] = rgb, eikonal, mvs, sparse, total.  n_rays_norm / n_eik_norm (0 = n_rays / n_eik): denominators of the
+ * means when a batch is processed in several ray groups (the groups' losses and gradients then simply add). */
 int svs_loss(int n_rays, int n_samples, int n_eik, const float* rgb_values, const float* rgb_target,
              const float* grad_theta, const float* weights, const float* pi, const float* pj, const float* depth_values,
              float rgb_weight, float eikonal_weight, float mvs_weight, float sparse_weight, float gce, float confi,
-             int annealed, float anneal_sparse, float* losses, float* d_rgb_values, float* d_grad_theta,
-             float* d_weights, float* d_depth_values, double* workspace, void* hip_stream);
+             int annealed, float anneal_sparse, int n_rays_norm, int n_eik_norm, float* losses, float* d_rgb_values,
+             float* d_grad_theta, float* d_weights, float* d_depth_values, double* workspace, void* hip_stream);
 size_t svs_loss_workspace_bytes(int n_rays, int n_eik);
 
 /* ---- a13/a14  homography warp + variance --------------------------------------------------------------------

@@ -322,6 +322,7 @@ __global__ void cost_lookup_kernel(LookupArgs a) {
 // ---- a11: VolSDFLoss.forward (volsdf/model/loss.py:80-114) + its gradient w.r.t. the model outputs ---------
 struct LossArgs {
   int R, S, n_eik;
+  int R_norm, n_eik_norm;    // denominators of the means (>= R, n_eik when the batch is processed in several groups)
   const float* rgb_values;   // (R,3)
   const float* rgb_gt;       // (R,3) the target of the rgb term (rgb, or rgb_smooth in the annealed phase)
   const float* grad_theta;   // (n_eik,3) or nullptr
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(256) void loss_rays_kernel(LossArgs a, double* __re
     }
     const bool mvs_on = has_mvs && a.mvs_weight > 0.0f && conf > (double)a.confi;
     {
-      const float sc = mvs_on ? a.mvs_weight / (float)a.R : 0.0f;
+      const float sc = mvs_on ? a.mvs_weight / (float)a.R_norm : 0.0f;
       int k = 0;
       for (int s = lane; s < a.S; s += 64, ++k) a.d_weights[(size_t)r * a.S + s] = has_mvs ? dls[k & 3] * sc : 0.0f;
     }
@@ -378,14 +379,14 @@ __global__ __launch_bounds__(256) void loss_rays_kernel(LossArgs a, double* __re
         const float d = a.rgb_values[3 * r + c] - a.rgb_gt[3 * r + c];
         l1 += (double)__builtin_fabsf(d);
         const float sg = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
-        a.d_rgb_values[3 * r + c] = rgb_on ? a.rgb_weight * sg / (3.0f * (float)a.R) : 0.0f;
+        a.d_rgb_values[3 * r + c] = rgb_on ? a.rgb_weight * sg / (3.0f * (float)a.R_norm) : 0.0f;
       }
       float dd = 0.0f;
       double sp = 0.0;
       if (masked && conf < (double)a.confi) {
         const float dep = a.depth_values[r] + 1e-3f;
         sp = 1.0 / (double)dep;
-        dd = -(a.sparse_weight * a.anneal_sparse) / (dep * dep) / (float)a.R;
+        dd = -(a.sparse_weight * a.anneal_sparse) / (dep * dep) / (float)a.R_norm;
       }
       a.d_depth_values[r] = dd;
       double* o = partial + (size_t)unit * 4;
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(256) void loss_rays_kernel(LossArgs a, double* __re
       const float g0 = a.grad_theta[3 * i], g1 = a.grad_theta[3 * i + 1], g2 = a.grad_theta[3 * i + 2];
       const float n = __builtin_sqrtf((g0 * g0 + g1 * g1) + g2 * g2);
       e = (double)(n - 1.0f) * (double)(n - 1.0f);
-      const float k = n > 0.0f ? a.eikonal_weight * 2.0f * (n - 1.0f) / (n * (float)a.n_eik) : 0.0f;
+      const float k = n > 0.0f ? a.eikonal_weight * 2.0f * (n - 1.0f) / (n * (float)a.n_eik_norm) : 0.0f;
       a.d_grad_theta[3 * i] = k * g0; a.d_grad_theta[3 * i + 1] = k * g1; a.d_grad_theta[3 * i + 2] = k * g2;
     }
     for (int d = 32; d >= 1; d >>= 1) e += __shfl_xor(e, d);
@@ -419,8 +420,8 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(LossArgs a, const doub
   if (threadIdx.x == 0) {
     double t[4];
     for (int k = 0; k < 4; ++k) t[k] = (sh[0][k] + sh[1][k]) + (sh[2][k] + sh[3][k]);
-    const float rgb = (float)(t[0] / a.R), eik = a.n_eik ? (float)(t[1] / a.n_eik) : 0.0f;
-    const float mvs = (float)(t[2] / a.R), sp = (float)(t[3] / a.R);
+    const float rgb = (float)(t[0] / a.R_norm), eik = a.n_eik_norm ? (float)(t[1] / a.n_eik_norm) : 0.0f;
+    const float mvs = (float)(t[2] / a.R_norm), sp = (float)(t[3] / a.R_norm);
     a.losses[0] = rgb; a.losses[1] = eik; a.losses[2] = mvs; a.losses[3] = sp;
     a.losses[4] = a.rgb_weight * rgb + a.eikonal_weight * eik + a.mvs_weight * mvs + (a.sparse_weight * a.anneal_sparse) * sp;
   }
@@ -505,13 +506,13 @@ int svs_cost_lookup(const float* xyz, const float* cam, const float* dirs, const
 int svs_loss(int n_rays, int n_samples, int n_eik, const float* rgb_values, const float* rgb_target,
              const float* grad_theta, const float* weights, const float* pi, const float* pj, const float* depth_values,
              float rgb_weight, float eikonal_weight, float mvs_weight, float sparse_weight, float gce, float confi,
-             int annealed, float anneal_sparse, float* losses, float* d_rgb_values, float* d_grad_theta,
-             float* d_weights, float* d_depth_values, double* workspace, void* hip_stream) {
+             int annealed, float anneal_sparse, int n_rays_norm, int n_eik_norm, float* losses, float* d_rgb_values,
+             float* d_grad_theta, float* d_weights, float* d_depth_values, double* workspace, void* hip_stream) {
   if (!rgb_values || !rgb_target || !weights || !depth_values || !losses || !d_rgb_values || !d_weights ||
       !d_depth_values || !workspace || n_rays <= 0 || n_samples <= 0 || n_samples > 256 || (n_eik > 0 && (!grad_theta || !d_grad_theta)) || (!pi != !pj)) {
     set_error("svs_loss: null/invalid argument"); return SVS_EINVAL;
   }
-  LossArgs a{n_rays, n_samples, n_eik, rgb_values, rgb_target, grad_theta, weights, pi, pj, depth_values, rgb_weight,
+  LossArgs a{n_rays, n_samples, n_eik, n_rays_norm > 0 ? n_rays_norm : n_rays, n_eik_norm > 0 ? n_eik_norm : n_eik, rgb_values, rgb_target, grad_theta, weights, pi, pj, depth_values, rgb_weight,
              eikonal_weight, mvs_weight, sparse_weight, gce, confi, anneal_sparse, annealed, losses, d_rgb_values,
              d_grad_theta, d_weights, d_depth_values};
   const int n_units = n_rays + (n_eik + 63) / 64;

@@ -65,7 +65,7 @@ SIGNATURES = {
     "svs_cost_lookup": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, POINTER(c_float),
                                 _PP, _PP, _PP, POINTER(c_int), _P, _P, _P, _P]),
     "svs_loss": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float,
-                         c_float, c_int, c_float, _P, _P, _P, _P, _P, _P, _P]),
+                         c_float, c_int, c_float, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "svs_loss_workspace_bytes": (c_size_t, [c_int, c_int]),
     "svs_chw_to_hwc": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "svs_warp_variance": (c_int, [_P, _PP, POINTER(c_float), c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P]),

@@ -249,8 +249,9 @@ def cost_lookup(views, same_view, img_res, *, xyz=None, cam=None, dirs=None, z=N
 
 def loss_fwd_bwd(rgb_values, rgb_target, weights, depth_values, grad_theta=None, pi=None, pj=None, *, rgb_weight=1.0,
                  eikonal_weight=0.1, mvs_weight=0.0, sparse_weight=0.0, gce=1.0, confi=0.0, annealed=False,
-                 anneal_sparse=0.0):
+                 anneal_sparse=0.0, norm=None):
     """VolSDFLoss.forward (volsdf/model/loss.py:80-114) and d(total)/d(model outputs) in one launch.
+    norm = (R_total, n_eik_total): denominators of the means when the batch is processed in ray groups.
     Returns (losses[5] = rgb, eikonal, mvs, sparse, total; dict of gradients)."""
     L = _lib.load()
     rgb_values, rgb_target = _f32(rgb_values).reshape(-1, 3), _f32(rgb_target).reshape(-1, 3)
@@ -269,7 +270,7 @@ def loss_fwd_bwd(rgb_values, rgb_target, weights, depth_values, grad_theta=None,
     _lib.check(L.svs_loss(R, S, n_eik, _ptr(rgb_values), _ptr(rgb_target), _ptr(gt), _ptr(weights), _ptr(pi_), _ptr(pj_),
                           _ptr(depth_values), float(rgb_weight), float(eikonal_weight), float(mvs_weight),
                           float(sparse_weight), float(gce), float(confi), int(bool(annealed)), float(anneal_sparse),
-                          _ptr(losses), _ptr(d_rgb), _ptr(d_gt), _ptr(d_w), _ptr(d_dep), _ptr(ws), _stream()), "svs_loss")
+                          int(norm[0]) if norm else 0, int(norm[1]) if norm else 0, _ptr(losses), _ptr(d_rgb), _ptr(d_gt), _ptr(d_w), _ptr(d_dep), _ptr(ws), _stream()), "svs_loss")
     return losses, dict(rgb_values=d_rgb, grad_theta=d_gt, weights=d_w, depth_values=d_dep)
 
 

@@ -1,8 +1,14 @@
 """Orchestration of the training backward through the fused MLPs (csrc/svs_mlp_bwd.hip, svs_wgrad.hip).
 
-Host code only sequences kernel launches on the current stream and owns the scratch buffers; every
-arithmetic step is a HIP kernel.  The reference gets these gradients from torch.autograd
-(volsdf/vsdf.py:215), including the double backward through network.py:115-121.
+Host code only sequences kernel launches on HIP streams and owns the scratch buffers; every arithmetic step is
+a HIP kernel.  The reference gets these gradients from torch.autograd (volsdf/vsdf.py:215), including the
+double backward through network.py:115-121.
+
+Structure (so that a batch can be processed in several ray groups on concurrent streams, see trainer.TrainStep):
+  TrainStreams   packed training weight streams, rebuilt once per optimiser step, shared by all groups
+  WGradAccum     kernel-order weight-gradient accumulators (float atomics), zeroed once per step, shared
+  MlpBackward    per-group scratch + the launches: radiance backward, SDF pass A / pass B, weight-gradient GEMMs
+  finalize()     kernel order -> parameter gradients (weight-norm backward), once per step
 """
 import ctypes
 
@@ -13,6 +19,7 @@ from .ops import _f32, _ptr, _ptr_array, _stream
 
 KBLOCK = 128 * 64           # floats per wave-tile activation block
 RBUF = 4 * KBLOCK + 1024    # radiance forward activations per tile
+LDW = 288
 
 
 def _off(t, n_floats):
@@ -20,16 +27,76 @@ def _off(t, n_floats):
     return ctypes.c_void_p(t.data_ptr() + 4 * n_floats)
 
 
-class MlpBackward:
-    """Scratch + packed training streams for one (ImplicitNetwork, RenderingNetwork) pair."""
-
+class TrainStreams:
     def __init__(self, device):
         L = _lib.load()
-        self.dev = device
-        self.sdf_stream = torch.empty(L.svs_stream_bytes(2) // 4, device=device)
-        self.rgb_stream = torch.empty(L.svs_stream_bytes(4) // 4, device=device)
+        self.sdf = torch.empty(L.svs_stream_bytes(2) // 4, device=device)
+        self.rgb = torch.empty(L.svs_stream_bytes(4) // 4, device=device)
         self.ws = torch.empty(L.svs_pack_workspace_bytes() // 4, device=device)
+
+    def pack(self, sdf_params, rgb_params):
+        L = _lib.load()
+        sv, sg, sb = [[_f32(t) for t in x] if x is not None else None for x in sdf_params]
+        rv, rg, rb = [[_f32(t) for t in x] if x is not None else None for x in rgb_params]
+        self._keep = (sv, sg, sb, rv, rg, rb)
+        st = _stream()
+        _lib.check(L.svs_pack_stream(2, _ptr_array(sv), _ptr_array(sg) if sg else None, _ptr_array(sb), _ptr(self.ws),
+                                     _ptr(self.sdf), st), "svs_pack_stream(sdf train)")
+        _lib.check(L.svs_pack_stream(4, _ptr_array(rv), _ptr_array(rg) if rg else None, _ptr_array(rb), _ptr(self.ws),
+                                     _ptr(self.rgb), st), "svs_pack_stream(rgb bwd)")
+
+
+class WGradAccum:
+    def __init__(self, device):
+        self.dWk = torch.zeros(14, 256, LDW, device=device)
+        self.dbk = torch.zeros(14, 256, device=device)
+        self.row0 = torch.zeros(257, device=device)
+
+    def zero(self):
+        self.dWk.zero_(); self.dbk.zero_(); self.row0.zero_()
+
+
+def finalize(accum, sdf_params, rgb_params, out=None):
+    """kernel-order accumulators -> (sdf_grads, rgb_grads): lists of (grad_v, grad_g, grad_b) per layer; `out`
+    optionally names the destination tensors (views of a flat gradient buffer)."""
+    L = _lib.load()
+    dev = accum.dWk.device
+    st = _stream()
+    res = []
+    for gi, (params, base, n) in enumerate(((sdf_params, 0, 9), (rgb_params, 9, 5))):
+        v, g, _ = params
+        group = []
+        for l in range(n):
+            rows, cols = v[l].shape
+            if out is not None:
+                gv, gg, gb = out[gi][l]
+            else:
+                gv = torch.empty(rows, cols, device=dev)
+                gg = torch.empty(rows, 1, device=dev) if g is not None else None
+                gb = torch.empty(rows, device=dev)
+            is_sdf = gi == 0
+            mp = 1 if (is_sdf and l == 4) else (2 if (not is_sdf and l == 0) else 0)
+            row_off = 1 if (is_sdf and l == 8) else 0
+            row0 = _ptr(accum.row0) if (is_sdf and l == 8) else None
+            _lib.check(L.svs_unpack_wgrad(_off(accum.dWk, (base + l) * 256 * LDW), _off(accum.dbk, (base + l) * 256), LDW,
+                                          mp, rows, cols, row_off, _ptr(_f32(v[l])), _ptr(_f32(g[l])) if g is not None else None,
+                                          row0, _ptr(gv), _ptr(gg), _ptr(gb), st), "svs_unpack_wgrad")
+            group.append((gv, gg, gb))
+        res.append(group)
+    return res[0], res[1]
+
+
+class MlpBackward:
+    """Per-group scratch and launches of the MLP backward."""
+
+    def __init__(self, device, streams=None, accum=None):
+        self.dev = device
+        self.streams = streams or TrainStreams(device)
+        self.accum = accum or WGradAccum(device)
         self._n = None
+        self._side = None
+        self.time_wgrad = False
+        self.timer_events = None
 
     def _alloc(self, n_total, n_main):
         if self._n == (n_total, n_main):
@@ -43,105 +110,62 @@ class MlpBackward:
         self.abuf = z(L.svs_block_bytes(n_total, 8))
         self.pebuf = z(L.svs_block_bytes(n_total, 1))
         self.sbar = z(L.svs_block_bytes(n_total, 1) // (128 * 2))  # 32 floats per tile
-        self.dWk = torch.empty(14, 256, 288, device=self.dev)
-        self.dbk = torch.empty(14, 256, device=self.dev)
-        self.row0 = torch.empty(257, device=self.dev)
         self._n = (n_total, n_main)
 
-    def run(self, sdf_params, rgb_params, keep, d_rgb, d_sdf, d_grad_extra, out=None):
-        """sdf_params / rgb_params: (weight_v list, weight_g list or None, bias list) of the two MLPs.
+    def accumulate(self, keep, d_rgb, d_sdf, d_grad_extra):
+        """Launches the backward of one ray group on the current stream (+ a side stream for the radiance weight
+        gradients) and adds its weight gradients into self.accum.
         keep: dict filled by ops.sdf_outputs / ops.rgb_eval (hbuf, gbuf, clamp_mask, src, rbuf, feat_tiles, rgb).
-        d_rgb (n_main,3): dL/d rgb of the ray samples; d_sdf (n_main,1) or None; d_grad_extra (n_extra,3) or None:
-        dL/d(d sdf/dx) of the extra (eikonal) points that follow the ray samples in the launch.
-        out: optional (sdf_out, rgb_out) lists of (grad_v, grad_g, grad_b) tensors to write into (e.g. views of a flat
-        gradient buffer) instead of allocating.
-        Returns (sdf_grads, rgb_grads): lists of (grad_v, grad_g, grad_b) per layer."""
+        d_rgb (n_main,3); d_sdf (n_main,1) or None; d_grad_extra (n_extra,3) or None: dL/d(d sdf/dx) of the extra
+        (eikonal) points that follow the ray samples in the launch."""
         L = _lib.load()
         src = keep["src"]
         n_total, n_main = src.n, keep["rgb"].shape[0]
         if n_main % 32:
-            raise NotImplementedError("rays*samples must be a multiple of 32 (1024 x 98 is)")
+            raise NotImplementedError("rays*samples of a group must be a multiple of 32")
         self._alloc(n_total, n_main)
-        dev = self.dev
-        sv, sg, sb = [[_f32(t) for t in x] if x is not None else None for x in sdf_params]
-        rv, rg, rb = [[_f32(t) for t in x] if x is not None else None for x in rgb_params]
-        st = _stream()
-        _lib.check(L.svs_pack_stream(2, _ptr_array(sv), _ptr_array(sg) if sg else None, _ptr_array(sb), _ptr(self.ws),
-                                     _ptr(self.sdf_stream), st), "svs_pack_stream(sdf train)")
-        sdf_scale_ws = self.ws       # (pack workspace is reused; scales are recomputed inside unpack)
-        _lib.check(L.svs_pack_stream(4, _ptr_array(rv), _ptr_array(rg) if rg else None, _ptr_array(rb), _ptr(self.ws),
-                                     _ptr(self.rgb_stream), st), "svs_pack_stream(rgb bwd)")
-        del sdf_scale_ws
+        dev, acc, S = self.dev, self.accum, self.streams
+        H8, U9, A8 = 8 * KBLOCK, 9 * KBLOCK, 8 * KBLOCK
+        hbuf, gbuf, mask = keep["hbuf"], keep["gbuf"], keep["clamp_mask"]
+        rbuf, feat = keep["rbuf"], keep["feat_tiles"]
+
+        def wgrad(slot, n_pts, a0, sa0, b0, sb0, a1=None, a1h=None, sa1=0, sh1=0, b1=None, sb1=0, extra=None, sx=0):
+            _lib.check(L.svs_wgrad(a0, None, b0, sa0, 0, sb0, a1, a1h, b1, sa1, sh1, sb1, extra, sx, n_pts,
+                                   _off(acc.dWk, slot * 256 * LDW), LDW, _off(acc.dbk, slot * 256), _stream()), "svs_wgrad")
+
         # ---- radiance MLP: input gradients
         d_rgb = _f32(d_rgb)
         d_normals = torch.empty(n_main, 3, device=dev)
-        _lib.check(L.svs_rgb_bwd(n_main, _ptr(d_rgb), _ptr(keep["rgb"]), _ptr(keep["rbuf"]), _ptr(self.rgb_stream),
-                                 _ptr(self.zbuf), _ptr(self.feat_bar), _ptr(d_normals), st), "svs_rgb_bwd")
-        # ---- SDF MLP: pass A (needs nbar), pass B (needs sbar, fbar)
+        _lib.check(L.svs_rgb_bwd(n_main, _ptr(d_rgb), _ptr(keep["rgb"]), _ptr(rbuf), _ptr(S.rgb), _ptr(self.zbuf),
+                                 _ptr(self.feat_bar), _ptr(d_normals), _stream()), "svs_rgb_bwd")
         d_grad = d_normals if d_grad_extra is None else torch.cat([d_normals, _f32(d_grad_extra)], 0)
         if d_grad.shape[0] != n_total:
             raise ValueError("d_grad_extra must cover the points that follow the ray samples")
         d_sdf_full = torch.zeros(n_total, device=dev)
         if d_sdf is not None:
             d_sdf_full[:n_main] = _f32(d_sdf).reshape(-1)
-        hbuf, gbuf, mask = keep["hbuf"], keep["gbuf"], keep["clamp_mask"]
-        # ---- weight gradients (kernel order), one GEMM over the points per layer.  The radiance GEMMs only need
-        # rgb_bwd's outputs: they run on a side stream and fill the CUs the SDF sweeps leave idle in their tail round.
-        H8, U9, A8 = 8 * KBLOCK, 9 * KBLOCK, 8 * KBLOCK
-        rbuf, feat = keep["rbuf"], keep["feat_tiles"]
-
-        def wgrad(slot, n_pts, a0, sa0, b0, sb0, a1=None, a1h=None, sa1=0, sh1=0, b1=None, sb1=0, extra=None, sx=0):
-            _lib.check(L.svs_wgrad(a0, None, b0, sa0, 0, sb0, a1, a1h, b1, sa1, sh1, sb1, extra, sx, n_pts,
-                                   _off(self.dWk, slot * 256 * 288), 288, _off(self.dbk, slot * 256), _stream()),
-                       "svs_wgrad")
-
-        def unpack(slot, mp, rows, cols, row_off, v, g, row0=None, dst=None):
-            if dst is not None:
-                gv, gg, gb = dst
-            else:
-                gv = torch.empty(rows, cols, device=dev)
-                gg = torch.empty(rows, 1, device=dev) if g is not None else None
-                gb = torch.empty(rows, device=dev)
-            _lib.check(L.svs_unpack_wgrad(_off(self.dWk, slot * 256 * 288), _off(self.dbk, slot * 256), 288, mp, rows,
-                                          cols, row_off, _ptr(v), _ptr(g), row0, _ptr(gv), _ptr(gg), _ptr(gb), _stream()),
-                       "svs_unpack_wgrad")
-            return gv, gg, gb
-
-        return_rgb = []
-
-        def radiance_side():
-            wgrad(9, n_main, _off(self.zbuf, 0), 5 * KBLOCK, _ptr(feat), KBLOCK, extra=_off(rbuf, 4 * KBLOCK), sx=RBUF)
-            for l in range(1, 5):
-                wgrad(9 + l, n_main, _off(self.zbuf, l * KBLOCK), 5 * KBLOCK, _off(rbuf, (l - 1) * KBLOCK), RBUF)
-            for l in range(5):
-                rows, cols = rv[l].shape
-                return_rgb.append(unpack(9 + l, 2 if l == 0 else 0, rows, cols, 0, rv[l], rg[l] if rg else None,
-                                         dst=out[1][l] if out else None))
-
-        return self._finish(L, keep, src, n_total, n_main, d_grad, d_sdf_full, hbuf, gbuf, mask, wgrad, unpack,
-                            radiance_side, return_rgb, sv, sg, out, H8, U9, A8)
-
-    def _finish(self, L, keep, src, n_total, n_main, d_grad, d_sdf_full, hbuf, gbuf, mask, wgrad, unpack, radiance_side,
-                return_rgb, sv, sg, out, H8, U9, A8):
+        # ---- the radiance weight-gradient GEMMs only need rgb_bwd's outputs: they run on a side stream and fill the
+        # CUs the SDF sweeps leave idle in their tail round
         main = torch.cuda.current_stream()
-        if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.dev)
-        self.dWk.zero_(); self.dbk.zero_(); self.row0.zero_()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
         fork = torch.cuda.Event(); fork.record(main)
         with torch.cuda.stream(self._side):
             self._side.wait_event(fork)
-            radiance_side()
+            wgrad(9, n_main, _off(self.zbuf, 0), 5 * KBLOCK, _ptr(feat), KBLOCK, extra=_off(rbuf, 4 * KBLOCK), sx=RBUF)
+            for l in range(1, 5):
+                wgrad(9 + l, n_main, _off(self.zbuf, l * KBLOCK), 5 * KBLOCK, _off(rbuf, (l - 1) * KBLOCK), RBUF)
             join = torch.cuda.Event(); join.record(self._side)
+        # ---- SDF MLP: pass A (needs nbar), pass B (needs sbar, fbar), then its weight gradients
         st = _stream()
-        _lib.check(L.svs_sdf_bwd_a(*src.args(), _ptr(d_grad), _ptr(mask), _ptr(hbuf), _ptr(gbuf), _ptr(self.sdf_stream),
+        _lib.check(L.svs_sdf_bwd_a(*src.args(), _ptr(d_grad), _ptr(mask), _ptr(hbuf), _ptr(gbuf), _ptr(S.sdf),
                                    _ptr(self.ubuf), _ptr(self.a2buf), _ptr(self.pebuf), st), "svs_sdf_bwd_a")
         _lib.check(L.svs_sdf_bwd_b(n_total, _ptr(d_sdf_full), _ptr(mask), _ptr(self.feat_bar), n_main, _ptr(hbuf),
-                                   _ptr(gbuf), _ptr(self.a2buf), _ptr(self.sdf_stream), _ptr(self.abuf), _ptr(self.sbar),
-                                   st), "svs_sdf_bwd_b")
-        _lib.check(L.svs_lin8_row0_grad(_ptr(hbuf), _ptr(self.ubuf), _ptr(self.sbar), n_total, _ptr(self.row0), st),
+                                   _ptr(gbuf), _ptr(self.a2buf), _ptr(S.sdf), _ptr(self.abuf), _ptr(self.sbar), st),
+                   "svs_sdf_bwd_b")
+        _lib.check(L.svs_lin8_row0_grad(_ptr(hbuf), _ptr(self.ubuf), _ptr(self.sbar), n_total, _ptr(acc.row0), st),
                    "svs_lin8_row0_grad")
-        ev = self.timer_events = ([torch.cuda.Event(enable_timing=True) for _ in range(2)]
-                                  if getattr(self, "time_wgrad", False) else None)
+        ev = self.timer_events = ([torch.cuda.Event(enable_timing=True) for _ in range(2)] if self.time_wgrad else None)
         if ev:
             ev[0].record()
         wgrad(0, n_total, _off(self.abuf, 0), A8, _ptr(self.pebuf), KBLOCK,
@@ -152,10 +176,12 @@ class MlpBackward:
         wgrad(8, n_main, _ptr(self.feat_bar), KBLOCK, _off(hbuf, 7 * KBLOCK), H8)
         if ev:
             ev[1].record()
-        sdf_grads = []
-        for l in range(9):
-            rows, cols = sv[l].shape
-            sdf_grads.append(unpack(l, 1 if l == 4 else 0, rows, cols, 1 if l == 8 else 0, sv[l], sg[l] if sg else None,
-                                    _ptr(self.row0) if l == 8 else None, dst=out[0][l] if out else None))
         main.wait_event(join)
-        return sdf_grads, return_rgb
+        self._hold = (d_grad, d_sdf_full, d_normals, d_rgb)      # keep inputs alive until the streams are joined
+
+    def run(self, sdf_params, rgb_params, keep, d_rgb, d_sdf, d_grad_extra, out=None):
+        """Whole backward of a single group: pack, zero, accumulate, finalize.  Returns (sdf_grads, rgb_grads)."""
+        self.streams.pack(sdf_params, rgb_params)
+        self.accum.zero()
+        self.accumulate(keep, d_rgb, d_sdf, d_grad_extra)
+        return finalize(self.accum, sdf_params, rgb_params, out)

@@ -95,9 +95,16 @@ def allreduce_flat_grad(flat_grad, world):
 class TrainStep:
     """VolOpt.train_step (volsdf/vsdf.py:196-235) for one batch, on the HIP path end to end:
     forward -> MVS prior lookup -> fused loss (+ output gradients) -> compositing / MLP backward ->
-    [gradient all-reduce] -> fused clip + guard + Adam."""
+    [gradient all-reduce] -> fused clip + guard + Adam.
 
-    def __init__(self, model, loss, lr=5e-4, grad_clip=True, world=1, rank=0):
+    Ray groups.  Every stage before the weight-gradient reduction is local to a ray, so the batch is processed as
+    several ray groups on concurrent HIP streams: the first group is sized so that each of its fused-MLP launches
+    fills the 256 CUs a whole number of times, the rest rides along on a second stream and fills what would
+    otherwise be the idle tail of every launch.  Results do not depend on the grouping (same random draws per ray,
+    loss means over the whole batch; only the float-atomic summation order of the weight gradients varies)."""
+
+    def __init__(self, model, loss, lr=5e-4, grad_clip=True, world=1, rank=0, groups="auto"):
+        from .train import MlpBackward, TrainStreams, WGradAccum
         self.model, self.loss = model, loss
         self.fp = FlatParams(model._flat_param_list())
         self.opt = FusedAdam(self.fp, lr=lr, max_norm=1.0 if grad_clip else 0.0)
@@ -114,25 +121,83 @@ class TrainStep:
                 group.append((gv, gg, next(it)))
             self.grad_out.append(group)
         self.beta_grad = next(it)
+        dev = self.fp.flat.device
+        self.groups = groups
+        self.tstreams = TrainStreams(dev)
+        self.accum = WGradAccum(dev)
+        self.bwd = [MlpBackward(dev, self.tstreams, self.accum) for _ in range(2)]
+        self.side = torch.cuda.Stream(device=dev)
+        self.d_beta = torch.zeros(2, device=dev)
+
+    @staticmethod
+    def split_rays(R, S, n_cu=256, wg_points=128):
+        """[(lo,hi)] ray ranges: the first group's (S+2) points per ray (ray samples + 2 eikonal points) fill a whole
+        number of rounds of n_cu workgroups; group sizes keep rays*S a multiple of 32."""
+        per_ray = S + 2
+        rounds = (R * per_ray) // (n_cu * wg_points)
+        if rounds < 1:
+            return [(0, R)]
+        r1 = (rounds * n_cu * wg_points) // per_ray
+        while r1 > 0 and ((r1 * S) % 32 or ((R - r1) * S) % 32):
+            r1 -= 1
+        if r1 <= 0 or r1 >= R:
+            return [(0, R)]
+        return [(0, r1), (r1, R)]
 
     def __call__(self, model_input, ground_truth, mvs=None, fast=1):
         """mvs: optional dict(views=[...], same_view=int, img_res=(H,W), inverse_depth=bool) for cost_mapping."""
+        from .train import finalize
         m = self.model
         m.train()
-        keep = {}
-        out = m._forward_impl(model_input, fast, keep)
-        if mvs is not None:
-            out['pj'], out['pi'], _ = ops.cost_lookup(mvs["views"], mvs["same_view"], mvs["img_res"], cam=keep["cam_loc"],
-                                                      dirs=keep["ray_dirs"], z=keep["z_vals"],
-                                                      inverse_depth=mvs.get("inverse_depth", False))
-        loss_out = self.loss(out, ground_truth)
-        g = self.loss.last_grads
-        scale = 1.0 / self.world       # each rank's means are over its own shard
-        sc = (lambda t: t if (scale == 1.0 or t is None) else t * scale)
-        _, _, d_beta = m.backward_from_output_grads(keep, sc(g["rgb_values"]), sc(g["weights"]), sc(g["depth_values"]),
-                                                    sc(g["grad_theta"]), out=self.grad_out)
-        self.beta_grad.copy_(d_beta.reshape(()))
+        uv = model_input["uv"]
+        R = uv.shape[1]
+        dev = uv.device
+        S = m.ray_sampler.N_samples + m.ray_sampler.N_samples_extra + 2
+        groups = self.split_rays(R, S) if self.groups == "auto" else (self.groups or [(0, R)])
+        rng = m.draw_train_rng(R, dev)
+        m.packed_mlp()                                   # pack once, before the streams fork
+        sdf_p, rgb_p = m.mlp_params()
+        self.tstreams.pack(sdf_p, rgb_p)
+        self.accum.zero()
+        self.d_beta.zero_()
+        main = torch.cuda.current_stream()
+        fork = torch.cuda.Event(); fork.record(main)
+        scale = 1.0 / self.world                         # each rank's means are over its own shard
+        gt_rgb, gt_smooth = ground_truth["rgb"].reshape(-1, 3), ground_truth["rgb_smooth"].reshape(-1, 3)
+        results, joins, holds = [], [], []
+        for gi, (lo, hi) in enumerate(groups):
+            stream = main if gi == 0 else self.side
+            with torch.cuda.stream(stream):
+                if gi:
+                    stream.wait_event(fork)
+                inp = dict(model_input)
+                inp["uv"] = uv[:, lo:hi].contiguous()
+                keep = {}
+                out = m._forward_impl(inp, fast, keep, rng=m.slice_rng(rng, lo, hi))
+                if mvs is not None:
+                    out['pj'], out['pi'], _ = ops.cost_lookup(mvs["views"], mvs["same_view"], mvs["img_res"],
+                                                              cam=keep["cam_loc"], dirs=keep["ray_dirs"], z=keep["z_vals"],
+                                                              inverse_depth=mvs.get("inverse_depth", False))
+                gt = {"rgb": gt_rgb[lo:hi], "rgb_smooth": gt_smooth[lo:hi]}
+                lo_out = self.loss(out, gt, norm=(R * self.world, 2 * R * self.world), advance=(gi == len(groups) - 1))
+                g = self.loss.last_grads
+                d_sdf, d_rgb, d_beta = ops.composite_bwd(keep["z_vals"], keep["sdf"], keep["rgb_flat"], keep["depth_scale"],
+                                                         m.density.beta, float(m.density.beta_min), g["rgb_values"],
+                                                         g["weights"], g["depth_values"])
+                self.d_beta[gi:gi + 1].copy_(d_beta)
+                self.bwd[min(gi, 1)].accumulate(keep, d_rgb, d_sdf, g["grad_theta"])
+                results.append((lo_out, out))
+                holds.append((keep, g, d_sdf, d_rgb, inp, gt))
+                if gi:
+                    ev = torch.cuda.Event(); ev.record(stream); joins.append(ev)
+        for ev in joins:
+            main.wait_event(ev)
+        finalize(self.accum, sdf_p, rgb_p, out=self.grad_out)
+        self.beta_grad.copy_(self.d_beta.sum())
+        del scale
         allreduce_flat_grad(self.fp.grad, self.world)
         self.opt.step()
         m.invalidate_packed()          # the fused kernel bypasses torch's version counters
-        return loss_out, out
+        self._hold = holds
+        loss_out = {k: sum(r[0][k] for r in results) for k in results[0][0]}
+        return loss_out, results[0][1]

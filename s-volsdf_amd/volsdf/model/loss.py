@@ -37,7 +37,7 @@ class VolSDFLoss(nn.Module):
             self.sparse_weight = 0
             raise NotImplementedError
 
-    def forward(self, model_outputs, ground_truth):
+    def forward(self, model_outputs, ground_truth, norm=None, advance=True):
         dev = model_outputs['rgb_values'].device
         annealed = self.sparse_weight > 0 and self.anneal_rgb > 0 and self.iter_step < self.anneal_rgb
         has_mvs = 'pi' in model_outputs
@@ -49,9 +49,10 @@ class VolSDFLoss(nn.Module):
             grad_theta=model_outputs.get('grad_theta'), pi=model_outputs.get('pi'), pj=model_outputs.get('pj'),
             rgb_weight=self.rgb_weight, eikonal_weight=self.eikonal_weight,
             mvs_weight=self.mvs_weight if has_mvs else 0.0, sparse_weight=self.sparse_weight, gce=float(self.gce),
-            confi=float(self.confi), annealed=annealed and has_mvs, anneal_sparse=float(anneal_sparse))
+            confi=float(self.confi), annealed=annealed and has_mvs, anneal_sparse=float(anneal_sparse), norm=norm)
         self.last_grads = grads
-        self.iter_step += 1
+        if advance:
+            self.iter_step += 1
         total = losses[4]
         diff = [k for k in ('rgb_values', 'grad_theta', 'weights', 'depth_values')
                 if k in model_outputs and torch.is_tensor(model_outputs[k]) and model_outputs[k].requires_grad]

@@ -199,8 +199,20 @@ class VolSDFNetwork(nn.Module):
                     'xyz': xyz, 'grad_theta': grad_theta}
         return self._forward_impl(input, fast, None)
 
-    def _forward_impl(self, input, fast, keep):
-        """network.py:206-279 on the HIP kernels.  keep: dict that receives what the backward kernels need."""
+    def draw_train_rng(self, R, dev):
+        """All train-mode random draws of one forward for R rays, in the reference's order (sampler draws, then the
+        uniform eikonal points of network.py:261).  Slices of it can be handed to _forward_impl per ray group."""
+        rng = self.ray_sampler.draw_train_rng(R, dev)
+        rng["eik_points"] = torch.empty(R, 3).uniform_(-self.scene_bounding_sphere, self.scene_bounding_sphere).to(dev)
+        return rng
+
+    @staticmethod
+    def slice_rng(rng, lo, hi):
+        return {k: (v if k == "perm" else v[lo:hi].contiguous()) for k, v in rng.items()}
+
+    def _forward_impl(self, input, fast, keep, rng=None):
+        """network.py:206-279 on the HIP kernels.  keep: dict that receives what the backward kernels need.
+        rng: optional pre-drawn random draws for exactly these rays (train mode)."""
         intrinsics, uv, pose = input["intrinsics"], input["uv"], input["pose"]
         if uv.shape[0] != 1:
             raise NotImplementedError("batch_size 1 only (runner.py:166)")
@@ -209,16 +221,17 @@ class VolSDFNetwork(nn.Module):
         ray_dirs, cam_loc, depth_scale = ops.rays_from_uv(uv[0], pose[0], intrinsics[0])       # network.py:213-217
         num_pixels = ray_dirs.shape[0]
 
+        if self.training and rng is None:
+            rng = self.draw_train_rng(num_pixels, ray_dirs.device)
         z_vals, z_samples_eik = self.ray_sampler.get_z_vals(ray_dirs, cam_loc, self, fast=fast,
-                                                            iter_step=input.get("iter_step", 1))
+                                                            iter_step=input.get("iter_step", 1), rng=rng)
         N_samples = z_vals.shape[1]
         n_main = num_pixels * N_samples
         eikonal_points = None
         if self.training:
             # eikonal samples (network.py:258-266) ride in the same launch as the ray samples; they
             # differentiate the raw network output (ImplicitNetwork.gradient), the ray samples the clamped sdf
-            eikonal_points = torch.empty(num_pixels, 3).uniform_(-self.scene_bounding_sphere,
-                                                                 self.scene_bounding_sphere).to(ray_dirs.device)
+            eikonal_points = rng["eik_points"]
             eik_near = cam_loc.view(1, 3) + z_samples_eik * ray_dirs
             eikonal_points = torch.cat([eikonal_points, eik_near], 0)
         src = ops.PointSource(points=eikonal_points, cam=cam_loc, dirs=ray_dirs, z=z_vals)

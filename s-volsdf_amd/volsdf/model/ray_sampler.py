@@ -67,23 +67,34 @@ class ErrorBoundSampler(RaySampler):
         self._inv_4log = float(1.0 / (4.0 * torch.log(torch.tensor(self.eps + 1.0))))
         self._ws = None
 
-    def get_z_vals(self, ray_dirs, cam_loc, model, fast=-1, iter_step=None):
-        """ray_dirs (R,3), cam_loc (R,3) or (3,) -> z_vals (R, N_samples+N_samples_extra+2), z_samples_eik (R,1)."""
+    def draw_train_rng(self, R, dev):
+        """The sampler's train-mode draws for R rays: same calls, same order as the reference
+        (ray_sampler.py:39,170,201,211; CPU generator, then copied to the device)."""
+        n_out = self.N_samples + self.N_samples_extra + 2
+        return dict(jitter=torch.rand(R, self.N_samples_eval).to(dev),
+                    u=torch.rand(R, self.N_samples).to(dev),
+                    perm=torch.randperm(self.N_samples_eval)[:self.N_samples_extra].to(torch.int32).to(dev),
+                    eik_idx=torch.randint(n_out, (R,)).to(torch.int32).to(dev))
+
+    def get_z_vals(self, ray_dirs, cam_loc, model, fast=-1, iter_step=None, rng=None):
+        """ray_dirs (R,3), cam_loc (R,3) or (3,) -> z_vals (R, N_samples+N_samples_extra+2), z_samples_eik (R,1).
+        rng: optional pre-drawn train-mode draws for exactly these rays (a slice of draw_train_rng's output)."""
         dev = ray_dirs.device
         R = ray_dirs.shape[0]
         max_iters = fast if fast >= 0 else self.max_total_iters
-        rng = None
         if model.training:
             if max_iters != 1:
                 raise NotImplementedError("train-mode sampling is implemented for fast=1 (what VolOpt.train_step uses)")
-            # same draws, same order as the reference (CPU generator, then copied to the device)
-            n_out = self.N_samples + self.N_samples_extra + 2
-            rng = dict(jitter=torch.rand(R, self.N_samples_eval).to(dev),
-                       u=torch.rand(R, self.N_samples).to(dev),
-                       perm=torch.randperm(self.N_samples_eval)[:self.N_samples_extra].to(torch.int32).to(dev),
-                       eik_idx=torch.randint(n_out, (R,)).to(torch.int32).to(dev))
-        if self._ws is None or self._ws.R != R or self._ws.z.device != dev:
-            self._ws = ops.SamplerWorkspace(R, dev)
+            if rng is None:
+                rng = self.draw_train_rng(R, dev)
+        else:
+            rng = None
+        if not hasattr(self, "_ws_by_R"):
+            self._ws_by_R = {}
+        key = (R, str(dev), torch.cuda.current_stream().cuda_stream)
+        if key not in self._ws_by_R:
+            self._ws_by_R[key] = ops.SamplerWorkspace(R, dev)
+        self._ws = self._ws_by_R[key]
         net = model.implicit_network
         z, z_eik = ops.sample_rays(model.packed_mlp(), cam_loc, ray_dirs, model.density.beta, beta_min=float(model.density.beta_min), near=self.near,
                                    scene_bounding_sphere=self.scene_bounding_sphere, sphere_scale=net.sphere_scale,
