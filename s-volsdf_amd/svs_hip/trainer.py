@@ -182,7 +182,7 @@ class TrainStep:
                 lo_out = self.loss(out, gt, norm=(R * self.world, 2 * R * self.world), advance=(gi == len(groups) - 1))
                 g = self.loss.last_grads
                 d_sdf, d_rgb, d_beta = ops.composite_bwd(keep["z_vals"], keep["sdf"], keep["rgb_flat"], keep["depth_scale"],
-                                                         m.density.beta, float(m.density.beta_min), g["rgb_values"],
+                                                         m.density.beta, m.density.beta_min_value, g["rgb_values"],
                                                          g["weights"], g["depth_values"])
                 self.d_beta[gi:gi + 1].copy_(d_beta)
                 self.bwd[min(gi, 1)].accumulate(keep, d_rgb, d_sdf, g["grad_theta"])

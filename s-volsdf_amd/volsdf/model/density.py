@@ -22,6 +22,7 @@ class LaplaceDensity(Density):
     def __init__(self, params_init={}, beta_min=0.0001):
         super().__init__(params_init=params_init)
         self.register_buffer("beta_min", torch.tensor(beta_min), persistent=False)
+        self.beta_min_value = float(beta_min)     # host copy: kernels take it by value, no device read-back per step
 
     def density_func(self, sdf, beta=None):
         if beta is None:

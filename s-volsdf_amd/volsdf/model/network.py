@@ -202,8 +202,15 @@ class VolSDFNetwork(nn.Module):
     def draw_train_rng(self, R, dev):
         """All train-mode random draws of one forward for R rays, in the reference's order (sampler draws, then the
         uniform eikonal points of network.py:261).  Slices of it can be handed to _forward_impl per ray group."""
-        rng = self.ray_sampler.draw_train_rng(R, dev)
-        rng["eik_points"] = torch.empty(R, 3).uniform_(-self.scene_bounding_sphere, self.scene_bounding_sphere).to(dev)
+        from volsdf.model.ray_sampler import HostStage
+        if getattr(self, "_stage", None) is None or self._stage.dev != dev:
+            self._stage = HostStage(dev)
+        st = self._stage
+        st.begin()
+        rng = self.ray_sampler.draw_train_rng(R, dev, stage=st)
+        rng["eik_points"] = st.upload("eik_points", torch.empty(R, 3).uniform_(-self.scene_bounding_sphere,
+                                                                               self.scene_bounding_sphere))
+        st.end()
         return rng
 
     @staticmethod
@@ -241,7 +248,7 @@ class VolSDFNetwork(nn.Module):
         sdf, gradients = sdf[:n_main], gradients[:n_main]
         src_main = ops.PointSource(cam=cam_loc, dirs=ray_dirs, z=z_vals)
         rgb_flat = ops.rgb_eval(pk, src_main, gradients, ray_dirs, feat_tiles, keep=keep)
-        comp = ops.composite(z_vals, sdf, rgb_flat, depth_scale, self.density.beta, float(self.density.beta_min),
+        comp = ops.composite(z_vals, sdf, rgb_flat, depth_scale, self.density.beta, self.density.beta_min_value,
                              normals=None if self.training else gradients)
         if keep is not None:
             keep.update(z_vals=z_vals, sdf=sdf, rgb_flat=rgb_flat, depth_scale=depth_scale, cam_loc=cam_loc,
@@ -271,7 +278,7 @@ class VolSDFNetwork(nn.Module):
         if g_rgb_values is None:
             g_rgb_values = torch.zeros(R, 3, device=dev)
         d_sdf, d_rgb, d_beta = ops.composite_bwd(keep["z_vals"], keep["sdf"], keep["rgb_flat"], keep["depth_scale"],
-                                                 self.density.beta, float(self.density.beta_min), g_rgb_values,
+                                                 self.density.beta, self.density.beta_min_value, g_rgb_values,
                                                  g_weights, g_depth_values)
         n_extra = keep["src"].n - keep["rgb"].shape[0]
         if g_grad_theta is None and n_extra:
@@ -285,7 +292,7 @@ class VolSDFNetwork(nn.Module):
         R = z_vals.shape[0]
         dev = z_vals.device
         comp = ops.composite(z_vals, sdf, torch.zeros(z_vals.numel(), 3, device=dev), torch.ones(R, 1, device=dev),
-                             self.density.beta, float(self.density.beta_min))
+                             self.density.beta, self.density.beta_min_value)
         dists = torch.cat([z_vals[:, 1:] - z_vals[:, :-1], torch.full((R, 1), 1e10, device=dev)], -1)
         return comp["weights"], dists
 
