@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rays", type=int, default=1024)
     ap.add_argument("--mode", choices=["train", "render"], default="train")
+    ap.add_argument("--groups", choices=["auto", "none"], default="auto", help="ray groups on concurrent streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -109,7 +110,7 @@ def main():
               "rgb_smooth": torch.from_numpy(rs.uniform(0, 1, (1, R, 3)).astype(np.float32)).to(dev)}
         loss = VolSDFLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, rgb_weight=1.0, mvs_weight=1.0,
                           sparse_weight=1.0, anneal_rgb=200, gce=0.5, confi=1e-3)       # config/ours.yaml:16-21
-        ts = TrainStep(model, loss, lr=5e-4, world=world, rank=rank)
+        ts = TrainStep(model, loss, lr=5e-4, world=world, rank=rank, groups=None if args.groups == "none" else "auto")
 
     wg_ev = []
 

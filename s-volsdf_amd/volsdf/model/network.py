@@ -202,15 +202,8 @@ class VolSDFNetwork(nn.Module):
     def draw_train_rng(self, R, dev):
         """All train-mode random draws of one forward for R rays, in the reference's order (sampler draws, then the
         uniform eikonal points of network.py:261).  Slices of it can be handed to _forward_impl per ray group."""
-        from volsdf.model.ray_sampler import HostStage
-        if getattr(self, "_stage", None) is None or self._stage.dev != dev:
-            self._stage = HostStage(dev)
-        st = self._stage
-        st.begin()
-        rng = self.ray_sampler.draw_train_rng(R, dev, stage=st)
-        rng["eik_points"] = st.upload("eik_points", torch.empty(R, 3).uniform_(-self.scene_bounding_sphere,
-                                                                               self.scene_bounding_sphere))
-        st.end()
+        rng = self.ray_sampler.draw_train_rng(R, dev)
+        rng["eik_points"] = torch.empty(R, 3).uniform_(-self.scene_bounding_sphere, self.scene_bounding_sphere).to(dev)
         return rng
 
     @staticmethod

@@ -50,38 +50,6 @@ class UniformSampler(RaySampler):
         return z_vals
 
 
-class HostStage:
-    """Pinned host staging for the per-step random draws: copy into one of two pinned slots, then an asynchronous
-    copy into a persistent device buffer on the current stream.  The slot is reused two steps later, guarded by an
-    event, so the host never waits for the GPU in steady state."""
-
-    def __init__(self, dev):
-        self.dev = dev
-        self.slots = [{}, {}]
-        self.events = [None, None]
-        self.dev_bufs = [{}, {}]
-        self.k = 0
-
-    def begin(self):
-        self.k ^= 1
-        if self.events[self.k] is not None:
-            self.events[self.k].synchronize()        # the copies issued two steps ago (long done)
-
-    def upload(self, name, t):
-        slot, dbuf = self.slots[self.k], self.dev_bufs[self.k]
-        if name not in slot or slot[name].shape != t.shape or slot[name].dtype != t.dtype:
-            slot[name] = torch.empty(t.shape, dtype=t.dtype).pin_memory()
-            dbuf[name] = torch.empty(t.shape, dtype=t.dtype, device=self.dev)
-        slot[name].copy_(t)
-        dbuf[name].copy_(slot[name], non_blocking=True)
-        return dbuf[name]
-
-    def end(self):
-        ev = torch.cuda.Event()
-        ev.record()
-        self.events[self.k] = ev
-
-
 class ErrorBoundSampler(RaySampler):
     def __init__(self, scene_bounding_sphere, near, N_samples, N_samples_eval, N_samples_extra, eps, beta_iters,
                  max_total_iters, inverse_sphere_bg=False, N_samples_inverse_sphere=0, add_tiny=0.0):
@@ -99,12 +67,12 @@ class ErrorBoundSampler(RaySampler):
         self._inv_4log = float(1.0 / (4.0 * torch.log(torch.tensor(self.eps + 1.0))))
         self._ws = None
 
-    def draw_train_rng(self, R, dev, stage=None):
+    def draw_train_rng(self, R, dev):
         """The sampler's train-mode draws for R rays: same calls, same order as the reference
-        (ray_sampler.py:39,170,201,211; CPU generator, then copied to the device).
-        stage: optional HostStage (pinned double buffers + asynchronous H2D copies, no host blocking)."""
+        (ray_sampler.py:39,170,201,211; CPU generator, then copied to the device).  The pageable H2D copies are
+        stream-ordered: the host simply runs one step ahead of the GPU (measured: pinned staging is slower here)."""
         n_out = self.N_samples + self.N_samples_extra + 2
-        up = stage.upload if stage is not None else (lambda name, t: t.to(dev))
+        up = lambda name, t: t.to(dev)
         return dict(jitter=up("jitter", torch.rand(R, self.N_samples_eval)),
                     u=up("u", torch.rand(R, self.N_samples)),
                     perm=up("perm", torch.randperm(self.N_samples_eval)[:self.N_samples_extra].to(torch.int32)),
