@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rays", type=int, default=1024)
     ap.add_argument("--mode", choices=["train", "render"], default="train")
-    ap.add_argument("--groups", choices=["auto", "none"], default="auto", help="ray groups on concurrent streams")
+    ap.add_argument("--groups", choices=["auto", "none"], default="none", help="ray groups on concurrent streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

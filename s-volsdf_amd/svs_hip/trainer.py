@@ -97,13 +97,15 @@ class TrainStep:
     forward -> MVS prior lookup -> fused loss (+ output gradients) -> compositing / MLP backward ->
     [gradient all-reduce] -> fused clip + guard + Adam.
 
-    Ray groups.  Every stage before the weight-gradient reduction is local to a ray, so the batch is processed as
-    several ray groups on concurrent HIP streams: the first group is sized so that each of its fused-MLP launches
-    fills the 256 CUs a whole number of times, the rest rides along on a second stream and fills what would
-    otherwise be the idle tail of every launch.  Results do not depend on the grouping (same random draws per ray,
-    loss means over the whole batch; only the float-atomic summation order of the weight gradients varies)."""
+    Ray groups (groups="auto", off by default).  Every stage before the weight-gradient reduction is local to a ray,
+    so the batch can be processed as ray groups on concurrent HIP streams: the first group sized so that each of
+    its fused-MLP launches fills the 256 CUs a whole number of times, the rest on a second stream.  Results do not
+    depend on the grouping (same random draws per ray, loss means over the whole batch; only the float-atomic
+    summation order of the weight gradients varies).  Measured on MI355X (tools/ab_groups.py, interleaved A/B):
+    10.97 ms/step ungrouped vs 11.10 ms grouped -- the dispatcher does not back-fill the tail round across queues,
+    so the default stays ungrouped; the tail needs a finer work unit instead."""
 
-    def __init__(self, model, loss, lr=5e-4, grad_clip=True, world=1, rank=0, groups="auto"):
+    def __init__(self, model, loss, lr=5e-4, grad_clip=True, world=1, rank=0, groups=None):
         from .train import MlpBackward, TrainStreams, WGradAccum
         self.model, self.loss = model, loss
         self.fp = FlatParams(model._flat_param_list())

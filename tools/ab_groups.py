@@ -1,0 +1,42 @@
+"""Interleaved A/B (one process, alternating rounds) of TrainStep configurations in the bench.py train workload."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "tests", "golden"), os.path.join(ROOT, "s-volsdf_amd")):
+    sys.path.insert(0, p)
+import numpy as np, torch, synth
+from ref_shim import dtu_model_conf
+from svs_hip.trainer import TrainStep
+from volsdf.model.loss import VolSDFLoss
+from volsdf.model.network import VolSDFNetwork
+
+dev = torch.device("cuda:0")
+R = 1024
+K, pose = synth.make_camera()
+inp = {"intrinsics": torch.from_numpy(K)[None].to(dev), "uv": torch.from_numpy(synth.make_uv(R, seed=1))[None].to(dev), "pose": torch.from_numpy(pose)[None].to(dev)}
+gt = {"rgb": torch.rand(1, R, 3, device=dev), "rgb_smooth": torch.rand(1, R, 3, device=dev)}
+views = []
+for j, dx in enumerate((0.0, 0.3, -0.3)):
+    Kj, Pj = synth.make_camera(center=(dx, 0.0, -2.5), tilt=-0.12 * dx / 0.3)
+    prob = torch.softmax(torch.randn(192, 288, 384, device=dev), 0)
+    zm = torch.linspace(1.5, 3.5, 192, device=dev).view(-1, 1, 1) * (1 + 0.05 * (torch.rand(1, 288, 384, device=dev) * 2 - 1))
+    views.append(dict(K=Kj, c2w=Pj, cost=prob, z_near=zm[0].contiguous(), z_far=zm[-1].contiguous()))
+mvs = dict(views=views, same_view=0, img_res=(576, 768), inverse_depth=False)
+cfgs = {}
+for name, groups in (("none", None), ("auto", "auto")):
+    m = VolSDFNetwork(dtu_model_conf()); m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_params(0).items()}); m.to(dev).train()
+    loss = VolSDFLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, rgb_weight=1.0, mvs_weight=1.0, sparse_weight=1.0, anneal_rgb=200, gce=0.5, confi=1e-3)
+    cfgs[name] = TrainStep(m, loss, groups=groups)
+for ts in cfgs.values():
+    for _ in range(5):
+        ts(inp, gt, mvs=mvs)
+torch.cuda.synchronize()
+res = {k: [] for k in cfgs}
+for rnd in range(5):
+    for name, ts in cfgs.items():
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(25):
+            ts(inp, gt, mvs=mvs)
+        torch.cuda.synchronize()
+        res[name].append(1e3 * (time.perf_counter() - t0) / 25)
+for k, v in res.items():
+    print(k, "ms/step per round:", [round(x, 2) for x in v], "median", round(float(np.median(v)), 3))
