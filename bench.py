@@ -61,7 +61,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("SVS_FORCE_DIST") == "1":      # the env switch exercises the RCCL path on one GPU
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 

@@ -86,8 +86,8 @@ def shard_rays(uv, rank, world):
 def allreduce_flat_grad(flat_grad, world):
     """The one collective of a data-parallel step: sum the flat float32 gradient over ranks (RCCL over xGMI on the GPU
     box, gloo in the CPU tests).  The loss of each rank is already divided by the GLOBAL ray count."""
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if world > 1 or (dist.is_available() and dist.is_initialized()):
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
     return flat_grad
 
