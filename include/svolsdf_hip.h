@@ -38,20 +38,19 @@ int svs_rays_from_uv(const float* uv, const float* pose, const float* intrinsics
  * permutation into the MFMA consumption order.  weight_v/weight_g/bias: HOST arrays of 9 (SDF) / 5 (radiance)
  * device pointers in layer order, shapes as in the checkpoint (`implicit_network.lin{l}.weight_v` ...);
  * weight_g == NULL for networks without weight-norm.  workspace: svs_pack_workspace_bytes().
- * full != 0 also packs the feature head and the transposed weights used by the input-gradient pass. */
-/* which: 0 SDF forward, 1 SDF full (forward + feature head + input-gradient pass), 2 SDF training backward,
+ * which: 0 SDF forward, 1 SDF full (forward + feature head + input-gradient pass), 2 SDF training backward,
  *        3 radiance forward, 4 radiance backward.  The first svs_pack_stream call per `which` uploads a 2 KiB chunk
- * table (one hipMalloc + hipMemcpy; make that call outside graph capture). */
+ * table (one hipMalloc + hipMemcpy; make that call outside graph capture).
+ * precision: how the kernels that consume the stream evaluate the layer products (the same value is passed to them):
+ *   SVS_MMA_F32   v_mfma_f32_32x32x2_f32 on float32 operands (exact float32 products);
+ *   SVS_MMA_F16X2 v_mfma_f32_32x32x16_f16 on operands split into two fp16 pieces, a = hi + mid, three products
+ *                 per term (22-bit significands, float32 accumulation: float32-class accuracy at 2.8x the speed;
+ *                 operands must stay below 65504).  Stream sizes do not depend on the precision. */
+enum { SVS_MMA_F32 = 0, SVS_MMA_F16X2 = 1 };
 size_t svs_stream_bytes(int which);
-int svs_pack_stream(int which, const float* const* weight_v, const float* const* weight_g, const float* const* bias,
-                    float* workspace, float* stream_out, void* hip_stream);
-size_t svs_sdf_stream_bytes(int full);
-size_t svs_rgb_stream_bytes(void);
+int svs_pack_stream(int which, int precision, const float* const* weight_v, const float* const* weight_g,
+                    const float* const* bias, float* workspace, float* stream_out, void* hip_stream);
 size_t svs_pack_workspace_bytes(void);
-int svs_sdf_pack(const float* const* weight_v, const float* const* weight_g, const float* const* bias,
-                 float* workspace, float* stream_out, int full, void* hip_stream);
-int svs_rgb_pack(const float* const* weight_v, const float* const* weight_g, const float* const* bias,
-                 float* workspace, float* stream_out, void* hip_stream);
 
 /* ---- a5  SDF MLP ------------------------------------------------------------------------------------
  * Sample positions of a launch = the ray samples cam + z*dir (n_rays x S, row-major, may be 0 rays) followed by
@@ -61,8 +60,8 @@ int svs_rgb_pack(const float* const* weight_v, const float* const* weight_g, con
  *   sphere clamp min(sdf, scale*(radius-|x|)) on points [0, clamp_n) (clamp_n < 0: all) when radius > 0.
  *   gate: optional device int; the launch does nothing when *gate == 0 (sampler rounds). */
 int svs_sdf_vals(const float* points, int n_points, const float* cam, int cam_stride, const float* dirs, const float* z,
-                 int S, int n_rays, const float* stream, float sphere_radius, float sphere_scale, int clamp_n,
-                 float* sdf, const int* gate, void* hip_stream);
+                 int S, int n_rays, const float* stream, int precision, float sphere_radius, float sphere_scale,
+                 int clamp_n, float* sdf, const int* gate, void* hip_stream);
 /* svs_sdf_outputs: ImplicitNetwork.get_outputs (network.py:105-123) and .gradient (:90-103):
  *   sdf (P), grad = d sdf/dx (P,3), feat_tiles (svs_feat_tiles_bytes; wave-tile layout, may be NULL),
  *   hbuf (svs_sdf_hbuf_bytes): the activations h_1..h_8 kept for the gradient pass / training backward;
@@ -71,9 +70,9 @@ int svs_sdf_vals(const float* points, int n_points, const float* cam, int cam_st
 size_t svs_sdf_hbuf_bytes(int n_points_total);
 size_t svs_feat_tiles_bytes(int n_points_total);
 int svs_sdf_outputs(const float* points, int n_points, const float* cam, int cam_stride, const float* dirs,
-                    const float* z, int S, int n_rays, const float* stream, float sphere_radius, float sphere_scale,
-                    int clamp_n, float* sdf, float* grad, float* feat_tiles, float* hbuf, float* gbuf,
-                    unsigned char* clamp_mask, void* hip_stream);
+                    const float* z, int S, int n_rays, const float* stream, int precision, float sphere_radius,
+                    float sphere_scale, int clamp_n, float* sdf, float* grad, float* feat_tiles, float* hbuf,
+                    float* gbuf, unsigned char* clamp_mask, void* hip_stream);
 /* feature vectors in row-major (P,256), for callers outside the fused pipeline */
 int svs_tiles_to_rows(const float* tiles, int n_points, float* rows, void* hip_stream);
 
@@ -82,7 +81,7 @@ int svs_tiles_to_rows(const float* tiles, int n_points, float* rows, void* hip_s
  * sigmoid(MLP(cat[x, PE1(view), normal, feature])).  view_dirs: (n_rays,3) when view_S == S, (P,3) when 0. */
 int svs_rgb_eval(const float* points, int n_points, const float* cam, int cam_stride, const float* dirs, const float* z,
                  int S, int n_rays, const float* normals, const float* view_dirs, int view_S, const float* feat_tiles,
-                 const float* stream, float* rgb, float* rbuf, void* hip_stream);
+                 const float* stream, int precision, float* rgb, float* rbuf, void* hip_stream);
 /* rbuf (svs_rgb_rbuf_bytes, may be NULL): post-ReLU activations + the 16 extra input rows, kept for svs_rgb_bwd */
 size_t svs_rgb_rbuf_bytes(int n_points_total);
 

@@ -14,20 +14,12 @@
 //     (global_load_lds_dwordx4) into a double buffer shared by the 4 waves of a workgroup, and read back
 //     with conflict-free ds_read_b128;
 //   * exact float32 MFMA (v_mfma_f32_32x32x2_f32): the 1e-4 parity bound of the path rules out bf16.
-#include "svs_mlp_dev.h"
+#include "svs_mlp_host.h"
+#include "svs_mlp_args.h"
 
 namespace svs {
 namespace mlp {
 
-struct SdfOnlyArgs {
-  PointSrc src;
-  const f32x4* stream;   // packed forward stream
-  float* sdf;            // (P)
-  float sphere_radius;   // <= 0: no clamp (network.py:128)
-  float sphere_scale;
-  int clamp_n;           // the clamp applies to points [0, clamp_n)
-  const int* gate;       // optional device flag: the launch is a no-op when *gate == 0 (sampler rounds)
-};
 
 // ImplicitNetwork.get_sdf_vals (network.py:125-131), no grad: the sampler's evaluation.
 __global__ __launch_bounds__(kThreads, 1) void sdf_only_kernel(SdfOnlyArgs a) {
@@ -63,19 +55,6 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_only_kernel(SdfOnlyArgs a) {
 // The input gradient is the reverse-mode product through the same MLP (the reference's autograd.grad,
 // :115-121): g(h_8) = W8[0,:], g(a_l) = g(h_{l+1}) * softplus'(a_l), g(h_l) = W_l^T g(a_l).
 // ------------------------------------------------------------------------------------------------------
-struct SdfFullArgs {
-  PointSrc src;
-  const f32x4* stream;   // full stream
-  float* sdf;            // (P)
-  float* grad;           // (P,3)
-  float* feat_tiles;     // [wave tiles][128*64] or nullptr
-  float* hbuf;           // [wave tiles][8][128*64] activations h_1..h_8
-  float* gbuf;           // optional [wave tiles][8][128*64]: g(h_{l+1}) of the gradient pass, l = 0..7 (training)
-  unsigned char* clamp_mask;  // optional (P): 1 where the sphere term of the clamp is active (training)
-  float sphere_radius;   // > 0: min(sdf, scale*(R-|x|)) inside the differentiated graph (network.py:110-112)
-  float sphere_scale;
-  int clamp_n;           // ... for points [0, clamp_n); the rest differentiate the raw output (network.py:90-103)
-};
 
 __global__ __launch_bounds__(kThreads, 1) void sdf_full_kernel(SdfFullArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -227,26 +206,6 @@ __global__ void tiles_to_rows_kernel(const float* __restrict__ tiles, int P, flo
 // ------------------------------------------------------------------------------------------------------
 // RenderingNetwork.forward, mode 'idr' (network.py:170-190): cat[x, PE1(view), normal, feature] -> 4 x 256 ReLU -> 3, sigmoid
 // ------------------------------------------------------------------------------------------------------
-struct RgbArgs {
-  PointSrc src;            // sample positions (same source as the SDF kernel)
-  const float* normals;    // (P,3) = d sdf / dx, not normalised (network.py:234)
-  const float* view;       // view directions, (R,3) if view_S > 0 (one per ray) else (P,3)
-  int view_S;
-  const float* feat_tiles; // [wave tiles][128*64]
-  const f32x4* stream;
-  float* rgb;              // (P,3)
-  float* rbuf;             // optional [wave tiles][4*8192 + 1024]: r_1..r_4 (post-ReLU) and the 16 extra input rows (training)
-};
-constexpr int kRbufF = 4 * kBlockF + 1024;
-
-constexpr int kRgbBufF4 = kRgbChunk0F4;   // LDS buffer size for the radiance kernel (38 KiB)
-
-struct RgbStream {
-  const f32x4* g; f32x4* buf; int cur;
-  __device__ __forceinline__ const f32x4* cur_buf() const { return buf + cur * kRgbBufF4; }
-  template <int N16> __device__ __forceinline__ void prefetch() { chunk_issue<N16>(g, buf + (cur ^ 1) * kRgbBufF4); g += N16; }
-  __device__ __forceinline__ void advance() { __builtin_amdgcn_s_waitcnt(0); __syncthreads(); cur ^= 1; }
-};
 
 __global__ __launch_bounds__(kThreads, 1) void rgb_kernel(RgbArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -329,41 +288,20 @@ __global__ __launch_bounds__(kThreads, 1) void rgb_kernel(RgbArgs a) {
 using namespace svs;
 using namespace svs::mlp;
 
-namespace {
-int fill_src(PointSrc& src, const float* points, int n_points, const float* cam, int cam_stride, const float* dirs,
-             const float* z, int S, int n_rays, const char* who) {
-  if (n_points < 0 || n_rays < 0 || (n_points == 0 && n_rays == 0)) { set_error("%s: no points", who); return SVS_ESHAPE; }
-  if (n_points > 0 && !points) { set_error("%s: n_points > 0 but points is null", who); return SVS_EINVAL; }
-  if (n_rays > 0 && !(cam && dirs && z && S > 0 && (cam_stride == 0 || cam_stride == 3))) {
-    set_error("%s: the ray part needs cam/dirs/z, S > 0 and cam_stride in {0,3}", who); return SVS_EINVAL;
-  }
-  if ((long long)n_rays * S + n_points > 0x7fffffffLL) { set_error("%s: too many points", who); return SVS_ESHAPE; }
-  src.pts = points; src.cam = cam; src.dirs = dirs; src.z = z; src.cam_stride = cam_stride; src.S = S > 0 ? S : 1;
-  src.n_ray = n_rays * (S > 0 ? S : 0);
-  src.P = src.n_ray + n_points;
-  return SVS_OK;
-}
-int wave_tiles(int n_points) { return (n_points + kWgPts - 1) / kWgPts * kWaves; }
-
-template <typename K>
-int set_lds(K kernel, int bytes, const char* who) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e)); return (int)e; }
-  return SVS_OK;
-}
-}  // namespace
 
 extern "C" {
 
 int svs_sdf_vals(const float* points, int n_points, const float* cam, int cam_stride, const float* dirs, const float* z,
-                 int S, int n_rays, const float* stream, float sphere_radius, float sphere_scale, int clamp_n,
-                 float* sdf, const int* gate, void* hip_stream) {
+                 int S, int n_rays, const float* stream, int precision, float sphere_radius, float sphere_scale,
+                 int clamp_n, float* sdf, const int* gate, void* hip_stream) {
   SdfOnlyArgs a;
   if (int rc = fill_src(a.src, points, n_points, cam, cam_stride, dirs, z, S, n_rays, "svs_sdf_vals")) return rc;
   if (!stream || !sdf) { set_error("svs_sdf_vals: null stream/sdf"); return SVS_EINVAL; }
   a.stream = reinterpret_cast<const f32x4*>(stream); a.sdf = sdf;
   a.sphere_radius = sphere_radius; a.sphere_scale = sphere_scale; a.gate = gate;
   a.clamp_n = clamp_n < 0 ? a.src.P : clamp_n;
+  if (precision == kFmtF16x2) return launch_sdf_only_h2(a, (hipStream_t)hip_stream);
+  if (precision != kFmtF32) { set_error("svs_sdf_vals: unknown precision %d", precision); return SVS_EINVAL; }
   static int once = set_lds(sdf_only_kernel, kLdsBytes, "svs_sdf_vals");
   if (once) return once;
   sdf_only_kernel<<<(a.src.P + kWgPts - 1) / kWgPts, kThreads, kLdsBytes, (hipStream_t)hip_stream>>>(a);
@@ -375,9 +313,9 @@ size_t svs_feat_tiles_bytes(int n_points) { return (size_t)wave_tiles(n_points) 
 size_t svs_rgb_rbuf_bytes(int n_points) { return (size_t)wave_tiles(n_points) * kRbufF * sizeof(float); }
 
 int svs_sdf_outputs(const float* points, int n_points, const float* cam, int cam_stride, const float* dirs,
-                    const float* z, int S, int n_rays, const float* stream, float sphere_radius, float sphere_scale,
-                    int clamp_n, float* sdf, float* grad, float* feat_tiles, float* hbuf, float* gbuf,
-                    unsigned char* clamp_mask, void* hip_stream) {
+                    const float* z, int S, int n_rays, const float* stream, int precision, float sphere_radius,
+                    float sphere_scale, int clamp_n, float* sdf, float* grad, float* feat_tiles, float* hbuf,
+                    float* gbuf, unsigned char* clamp_mask, void* hip_stream) {
   SdfFullArgs a;
   if (int rc = fill_src(a.src, points, n_points, cam, cam_stride, dirs, z, S, n_rays, "svs_sdf_outputs")) return rc;
   if (!stream || !sdf || !grad || !hbuf) { set_error("svs_sdf_outputs: null stream/sdf/grad/hbuf"); return SVS_EINVAL; }
@@ -385,6 +323,8 @@ int svs_sdf_outputs(const float* points, int n_points, const float* cam, int cam
   a.gbuf = gbuf; a.clamp_mask = clamp_mask;
   a.sphere_radius = sphere_radius; a.sphere_scale = sphere_scale;
   a.clamp_n = clamp_n < 0 ? a.src.P : clamp_n;
+  if (precision == kFmtF16x2) return launch_sdf_full_h2(a, (hipStream_t)hip_stream);
+  if (precision != kFmtF32) { set_error("svs_sdf_outputs: unknown precision %d", precision); return SVS_EINVAL; }
   static int once = set_lds(sdf_full_kernel, kLdsBytes, "svs_sdf_outputs");
   if (once) return once;
   sdf_full_kernel<<<(a.src.P + kWgPts - 1) / kWgPts, kThreads, kLdsBytes, (hipStream_t)hip_stream>>>(a);
@@ -400,7 +340,7 @@ int svs_tiles_to_rows(const float* tiles, int n_points, float* rows, void* hip_s
 
 int svs_rgb_eval(const float* points, int n_points, const float* cam, int cam_stride, const float* dirs, const float* z,
                  int S, int n_rays, const float* normals, const float* view_dirs, int view_S, const float* feat_tiles,
-                 const float* stream, float* rgb, float* rbuf, void* hip_stream) {
+                 const float* stream, int precision, float* rgb, float* rbuf, void* hip_stream) {
   RgbArgs a;
   if (int rc = fill_src(a.src, points, n_points, cam, cam_stride, dirs, z, S, n_rays, "svs_rgb_eval")) return rc;
   if (!normals || !view_dirs || !feat_tiles || !stream || !rgb || view_S < 0 || (view_S > 0 && a.src.P % view_S)) {
@@ -408,6 +348,8 @@ int svs_rgb_eval(const float* points, int n_points, const float* cam, int cam_st
   }
   a.normals = normals; a.view = view_dirs; a.view_S = view_S; a.feat_tiles = feat_tiles;
   a.stream = reinterpret_cast<const f32x4*>(stream); a.rgb = rgb; a.rbuf = rbuf;
+  if (precision == kFmtF16x2) return launch_rgb_h2(a, (hipStream_t)hip_stream);
+  if (precision != kFmtF32) { set_error("svs_rgb_eval: unknown precision %d", precision); return SVS_EINVAL; }
   constexpr int lds = 2 * kRgbBufF4 * 16;
   static int once = set_lds(rgb_kernel, lds, "svs_rgb_eval");
   if (once) return once;

@@ -1,0 +1,59 @@
+// Kernel argument blocks shared by the float32 (svs_mlp.hip) and fp16x2 (svs_mlp_h2.hip) MLP kernels.
+#pragma once
+#include "svs_mlp_dev.h"
+
+namespace svs {
+namespace mlp {
+
+struct SdfOnlyArgs {
+  PointSrc src;
+  const f32x4* stream;   // packed forward stream
+  float* sdf;            // (P)
+  float sphere_radius;   // <= 0: no clamp (network.py:128)
+  float sphere_scale;
+  int clamp_n;           // the clamp applies to points [0, clamp_n)
+  const int* gate;       // optional device flag: the launch is a no-op when *gate == 0 (sampler rounds)
+};
+
+struct SdfFullArgs {
+  PointSrc src;
+  const f32x4* stream;   // full stream
+  float* sdf;            // (P)
+  float* grad;           // (P,3)
+  float* feat_tiles;     // [wave tiles][128*64] or nullptr
+  float* hbuf;           // [wave tiles][8][128*64] activations h_1..h_8
+  float* gbuf;           // optional [wave tiles][8][128*64]: g(h_{l+1}) of the gradient pass, l = 0..7 (training)
+  unsigned char* clamp_mask;  // optional (P): 1 where the sphere term of the clamp is active (training)
+  float sphere_radius;   // > 0: min(sdf, scale*(R-|x|)) inside the differentiated graph (network.py:110-112)
+  float sphere_scale;
+  int clamp_n;           // ... for points [0, clamp_n); the rest differentiate the raw output (network.py:90-103)
+};
+
+struct RgbArgs {
+  PointSrc src;            // sample positions (same source as the SDF kernel)
+  const float* normals;    // (P,3) = d sdf / dx, not normalised (network.py:234)
+  const float* view;       // view directions, (R,3) if view_S > 0 (one per ray) else (P,3)
+  int view_S;
+  const float* feat_tiles; // [wave tiles][128*64]
+  const f32x4* stream;
+  float* rgb;              // (P,3)
+  float* rbuf;             // optional [wave tiles][4*8192 + 1024]: r_1..r_4 (post-ReLU) and the 16 extra input rows (training)
+};
+constexpr int kRbufF = 4 * kBlockF + 1024;
+
+constexpr int kRgbBufF4 = kRgbChunk0F4;   // LDS buffer size for the radiance kernel (38 KiB)
+
+struct RgbStream {
+  const f32x4* g; f32x4* buf; int cur;
+  __device__ __forceinline__ const f32x4* cur_buf() const { return buf + cur * kRgbBufF4; }
+  template <int N16> __device__ __forceinline__ void prefetch() { chunk_issue<N16>(g, buf + (cur ^ 1) * kRgbBufF4); g += N16; }
+  __device__ __forceinline__ void advance() { __builtin_amdgcn_s_waitcnt(0); __syncthreads(); cur ^= 1; }
+};
+
+// fp16x2 launches (svs_mlp_h2.hip)
+int launch_sdf_only_h2(const SdfOnlyArgs& a, hipStream_t s);
+int launch_sdf_full_h2(const SdfFullArgs& a, hipStream_t s);
+int launch_rgb_h2(const RgbArgs& a, hipStream_t s);
+
+}  // namespace mlp
+}  // namespace svs

@@ -1,0 +1,471 @@
+// fp16x2 variants of the fused SDF ("implicit") and radiance ("rendering") MLP kernels of svs_mlp.hip: the same
+// networks, the same transposed register-resident activations and LDS-DMA weight stream, with every layer product
+// evaluated by v_mfma_f32_32x32x16_f16 on two-piece fp16 operands (svs_mlp_h2_dev.h) and the previous tile's
+// epilogue (activation, operand split, stores) interleaved with the current tile's MFMAs.
+//
+// Reference semantics: volsdf/model/network.py:71-131 (ImplicitNetwork), :170-190 (RenderingNetwork).
+#include "svs_mlp_h2_dev.h"
+#include "svs_mlp_host.h"
+#include "svs_mlp_args.h"
+
+namespace svs {
+namespace mlp {
+
+// --------------------------------------------------------------------------------------------------------------
+// SDF trunk, layers 0..7
+// --------------------------------------------------------------------------------------------------------------
+// Epilogue of one trunk tile, in slices: softplus of accumulator register r of `prev`, the skip splice (layer 3),
+// the float32 store to hbuf (HBUF) and either the split into the next layer's operand (xn) or the float32 copy y8
+// (last layer).
+template <bool HBUF, bool LAST>
+struct TrunkEpi {
+  f32x16 prev;
+  SoftplusA sa;
+  float v8[8];
+  f32x4 q4;
+  Pieces2* xn;
+  f32x16* y8;
+  const PosEnc* pe;
+  float* hb;        // this layer's block of the wave's hbuf tile
+  int lane, half;
+  bool splice;      // layer 3: rows >= 217 of the output are the PE splice (network.py:80-81)
+
+  __device__ __forceinline__ void a(int r) {
+    sa = softplus100_a(prev[r]);
+    pin(sa.mx); pin(sa.lg);
+  }
+  __device__ __forceinline__ void b(int tp, int r) {
+    float v = softplus100_b(sa);
+    if (tp == 6 && splice) {
+      const int l0 = rho(r) - 25, l1 = rho(r) + 4 - 25;   // local rows 25..31 of tile 6 carry PE[32..38]
+      if (l0 >= 0 || l1 >= 0) {
+        const float v0 = l0 >= 0 ? pe->v[32 + (l0 >= 0 ? l0 : 0)] : v;
+        const float v1 = l1 >= 0 ? pe->v[32 + (l1 >= 0 ? l1 : 0)] : v;
+        v = half ? v1 : v0;
+      }
+    }
+    pin(v);
+    emit(tp, r, v);
+  }
+  __device__ __forceinline__ void emit(int tp, int r, float v) {
+    if (LAST) y8[tp][r] = v;
+    if (HBUF) {
+      q4[r & 3] = v;
+      if ((r & 3) == 3) reinterpret_cast<f32x4*>(hb)[(4 * tp + (r >> 2)) * 64 + lane] = q4;
+    }
+    if (!LAST) {
+      v8[r & 7] = v;
+      if ((r & 7) == 7) {
+        split8(v8, xn->h[2 * tp + (r >> 3)], xn->m[2 * tp + (r >> 3)]);
+        pin(xn->h[2 * tp + (r >> 3)], xn->m[2 * tp + (r >> 3)]);
+      }
+    }
+  }
+  __device__ __forceinline__ void all(int tp) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a(r); b(tp, r); }
+  }
+  // layer 3, tile 7 = PE[0..31] (no MFMA)
+  __device__ __forceinline__ void splice_tile7() {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) emit(7, r, half ? pe->v[rho(r) + 4] : pe->v[rho(r)]);
+  }
+};
+
+// one 256 -> 256 trunk layer (l >= 1).  On entry the layer's first chunk is current; on return the next layer's is.
+template <bool HBUF, bool LAST>
+__device__ __forceinline__ void trunk_layer_h2(Stream& st, const Pieces2& x, TrunkEpi<HBUF, LAST>& ep, int lane) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    if (t == 7 && ep.splice) break;   // lin3 has 217 outputs = 7 tiles; tile 7 is the PE splice
+    st.prefetch<kChunkF4>();
+    f32x16 acc;
+    if (t == 0) acc = tile_mma_h2<16>(st.cur_buf(), x, lane);
+    else acc = tile_mma_h2<16>(st.cur_buf(), x, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.b(t - 1, s); });
+    ep.prev = acc;
+    st.advance();
+  }
+  if (ep.splice) { ep.all(6); ep.splice_tile7(); }
+  else ep.all(7);
+}
+
+// Forward through layers 0..7.  x: scratch operand; on return y8 holds h_8 in float32 (the input of lin8) and the
+// current chunk is the one that follows the trunk in the stream.  HBUF: h_1..h_8 are also stored to hbuf.
+template <bool HBUF>
+__device__ __forceinline__ void forward_trunk_h2(Stream& st, Pieces2& x, Pieces2& xn, f32x16* y8, const PosEnc& pe,
+                                                 int lane, int half, float* __restrict__ hbuf) {
+  split_pe(pe, half, x);
+  st.advance();        // chunk 0 (prefetched by the caller before the positional encoding)
+  {
+    // ---- layer 0 : 39(48) -> 256, three k-steps per tile: the epilogue of tile t-1 follows tile t's MFMAs
+    TrunkEpi<HBUF, false> ep;
+    ep.xn = &xn; ep.y8 = nullptr; ep.pe = &pe; ep.hb = hbuf; ep.lane = lane; ep.half = half; ep.splice = false;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      if (t < 7) st.prefetch<kChunk0F4>(); else st.prefetch<kChunkF4>();
+      const f32x16 acc = tile_mma_h2<3>(st.cur_buf(), x, lane);
+      if (t > 0) ep.all(t - 1);
+      ep.prev = acc;
+      st.advance();
+    }
+    ep.all(7);
+  }
+  // ---- layers 1..6 (layer 3 emits 217 rows + the skip splice), operands ping-pong between x and xn
+  for (int l = 1; l < 7; ++l) {
+    TrunkEpi<HBUF, false> ep;
+    ep.y8 = nullptr; ep.pe = &pe; ep.hb = hbuf + (size_t)l * kBlockF; ep.lane = lane; ep.half = half; ep.splice = l == 3;
+    if (l & 1) { ep.xn = &x; trunk_layer_h2<HBUF, false>(st, xn, ep, lane); }
+    else { ep.xn = &xn; trunk_layer_h2<HBUF, false>(st, x, ep, lane); }
+  }
+  // ---- layer 7: input in xn (layer 6 wrote it), output kept in float32
+  TrunkEpi<HBUF, true> ep;
+  ep.xn = nullptr; ep.y8 = y8; ep.pe = &pe; ep.hb = hbuf + (size_t)7 * kBlockF; ep.lane = lane; ep.half = half; ep.splice = false;
+  trunk_layer_h2<HBUF, true>(st, xn, ep, lane);
+}
+
+// ImplicitNetwork.get_sdf_vals (network.py:125-131), no grad: the sampler's evaluation.
+__global__ __launch_bounds__(kThreads, 1) void sdf_only_h2_kernel(SdfOnlyArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (a.gate && *a.gate == 0) return;
+  Stream st;
+  st.g = a.stream;
+  st.buf = reinterpret_cast<f32x4*>(smem);
+  st.cur = 1;
+  const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
+  const int p = (blockIdx.x * kWaves + wave) * kTilePts + (lane & 31);
+
+  st.prefetch<kChunk0F4>();   // chunk 0 -> buffer 0 (overlaps the positional encoding below)
+  float x0, x1, x2;
+  load_point(a.src, p, x0, x1, x2);
+  PosEnc pe;
+  pe.compute(x0, x1, x2);
+
+  Pieces2 x, xn;
+  f32x16 y8[8];
+  forward_trunk_h2<false>(st, x, xn, y8, pe, lane, half, nullptr);
+  // the VEC chunk was prefetched by the last tile of layer 7
+  float sdf = sdf_head(st.cur_buf(), y8, lane);
+  if (a.sphere_radius > 0.0f && p < a.clamp_n) {
+    const float nrm = __builtin_sqrtf(x0 * x0 + x1 * x1 + x2 * x2);
+    sdf = __builtin_fminf(sdf, a.sphere_scale * (a.sphere_radius - nrm));
+  }
+  if (half == 0 && p < a.src.P) a.sdf[p] = sdf;
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// ImplicitNetwork.get_outputs (network.py:105-123): sdf, feature vector and d sdf / d x in one launch (see
+// sdf_full_kernel in svs_mlp.hip for the algebra of the gradient pass).
+// --------------------------------------------------------------------------------------------------------------
+// Epilogue of one tile of the gradient pass: g(h_l) tile -> gbuf (training), g(a_{l-1}) = g(h_l) * softplus'(a_{l-1})
+// (softplus' from the stored h_l tile `h`), split into the next operand.
+struct RevEpi {
+  f32x16 prev, h;
+  float d;            // softplus' of the current slice
+  float v8[8];
+  f32x4 q4;
+  Pieces2* out;
+  float* gblk;        // g(h_l) block of gbuf or nullptr
+  int lane, half;
+  bool l4;            // l == 4: rows >= 217 of h_4 are the PE splice, they do not flow into lin3
+
+  __device__ __forceinline__ void a(int r) {
+    d = dsoftplus_from_h(h[r]);
+    pin(d);
+  }
+  __device__ __forceinline__ void b(int tp, int r) {
+    float v = prev[r] * d;
+    if (l4 && tp == 7) v = 0.0f;
+    if (l4 && tp == 6) {
+      const bool z0 = rho(r) >= 25, z1 = rho(r) + 4 >= 25;
+      if (z0 || z1) { if (half ? z1 : z0) v = 0.0f; }
+    }
+    pin(v);
+    if (gblk) {
+      q4[r & 3] = prev[r];
+      if ((r & 3) == 3) reinterpret_cast<f32x4*>(gblk)[(4 * tp + (r >> 2)) * 64 + lane] = q4;
+    }
+    v8[r & 7] = v;
+    if ((r & 7) == 7) {
+      split8(v8, out->h[2 * tp + (r >> 3)], out->m[2 * tp + (r >> 3)]);
+      pin(out->h[2 * tp + (r >> 3)], out->m[2 * tp + (r >> 3)]);
+    }
+  }
+  __device__ __forceinline__ void all(int tp) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a(r); b(tp, r); }
+  }
+};
+
+// reverse of trunk layer l (7..1): in = g(a_l) pieces, out = g(a_{l-1}) pieces
+__device__ __forceinline__ void reverse_layer_h2(Stream& st, const Pieces2& in, Pieces2& out, int l, const float* hb,
+                                                 float* gb, f32x16& skip6, f32x16& skip7, int lane, int half) {
+  RevEpi ep;
+  ep.out = &out; ep.lane = lane; ep.half = half; ep.l4 = l == 4;
+  ep.gblk = gb ? gb + (size_t)(l - 1) * kBlockF : nullptr;
+  const float* hblk = hb + (size_t)(l - 1) * kBlockF;
+  f32x16 hnext = load_tile(hblk, 0, lane);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const f32x16 hcur = hnext;
+    if (t < 7) hnext = load_tile(hblk, t + 1, lane);   // arrives while this tile's MFMAs run
+    st.prefetch<kChunkF4>();                           // next reverse chunk (the last one prefetches REV0 tile 0)
+    f32x16 acc;
+    if (t == 0) acc = tile_mma_h2<16>(st.cur_buf(), in, lane);
+    else acc = tile_mma_h2<16>(st.cur_buf(), in, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.b(t - 1, s); });
+    if (l == 4 && t == 7) skip7 = acc;
+    if (l == 4 && t == 6) skip6 = acc;
+    ep.prev = acc;
+    ep.h = hcur;
+    st.advance();
+  }
+  ep.all(7);
+}
+
+__global__ __launch_bounds__(kThreads, 1) void sdf_full_h2_kernel(SdfFullArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Stream st;
+  st.g = a.stream;
+  st.buf = reinterpret_cast<f32x4*>(smem);
+  st.cur = 1;
+  const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
+  const int wtile = blockIdx.x * kWaves + wave;
+  const int p = wtile * kTilePts + (lane & 31);
+
+  st.prefetch<kChunk0F4>();
+  float x0, x1, x2;
+  load_point(a.src, p, x0, x1, x2);
+  PosEnc pe;
+  pe.compute(x0, x1, x2);
+
+  float* hb = a.hbuf + (size_t)wtile * 8 * kBlockF;
+  float* gb = a.gbuf ? a.gbuf + (size_t)wtile * 8 * kBlockF : nullptr;
+  Pieces2 x, xn;
+  float sdf;
+  {
+    f32x16 y8[8];
+    forward_trunk_h2<true>(st, x, xn, y8, pe, lane, half, hb);
+    // ---- head: current chunk = VEC (W8 row 0 in C-layout order as float32, b8[0])
+    st.prefetch<kChunkF4>();                       // FEAT tile 0
+    sdf = sdf_head(st.cur_buf(), y8, lane);
+    // x = h_8 (input of the feature head), xn = g(a_7) = W8[0,:] * softplus'(a_7): the VEC chunk's buffer is
+    // overwritten two prefetches from now, so its weights are consumed here
+    const f32x4* w_ptr = st.cur_buf() + kHdrF4 + lane;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      f32x16 g;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 w = w_ptr[(4 * t + q) * 64];
+        if (gb) reinterpret_cast<f32x4*>(gb + 7 * (size_t)kBlockF)[(4 * t + q) * 64 + lane] = w;   // g(h_8) = W8[0,:]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[4 * q + j] = w[j] * dsoftplus_from_h(y8[t][4 * q + j]);
+      }
+      split_tile(g, t, xn);
+      split_tile(y8[t], t, x);
+    }
+    st.advance();
+  }
+  // ---- feature vector = rows 1..256 of lin8 (no activation); tile t-1 is stored while tile t's MFMAs run
+  float* ft = a.feat_tiles ? a.feat_tiles + (size_t)wtile * kBlockF : nullptr;
+  {
+    f32x16 prev;
+    f32x4 q4;
+    auto store_slice = [&](int tp, int r) {
+      q4[r & 3] = prev[r];
+      if ((r & 3) == 3 && ft) reinterpret_cast<f32x4*>(ft)[(4 * tp + (r >> 2)) * 64 + lane] = q4;
+    };
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      st.prefetch<kChunkF4>();                      // FEAT t+1, or reverse L7 tile 0
+      f32x16 acc;
+      if (t == 0) acc = tile_mma_h2<16>(st.cur_buf(), x, lane);
+      else acc = tile_mma_h2<16>(st.cur_buf(), x, lane, NoEpi(), [&](int s) { store_slice(t - 1, s); });
+      prev = acc;
+      st.advance();
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) store_slice(7, r);
+  }
+  // ---- reverse layers 7..1, operands ping-pong between xn and x
+  f32x16 skip7 = (f32x16)(0.0f);   // g(PE[0..31]) from the skip connection (tile 7 of g(h_4 spliced))
+  f32x16 skip6 = (f32x16)(0.0f);   // tile 6; only local rows 25..31 are PE[32..38]
+  for (int l = 7; l >= 1; l -= 2) {
+    reverse_layer_h2(st, xn, x, l, hb, gb, skip6, skip7, lane, half);
+    if (l > 1) reverse_layer_h2(st, x, xn, l - 1, hb, gb, skip6, skip7, lane, half);
+  }
+  // ---- reverse layer 0: g(PE) = W0^T g(a_0) (+ skip), 2 tiles; g(a_0) is in x
+  st.prefetch<kChunkF4>();
+  f32x16 gpe0 = tile_mma_h2<16>(st.cur_buf(), x, lane);
+  st.advance();
+  f32x16 gpe1 = tile_mma_h2<16>(st.cur_buf(), x, lane);
+  gpe0 += skip7;
+  gpe1 += skip6;
+
+  // ---- d/dx of the positional encoding
+  float dx0 = 0.0f, dx1 = 0.0f, dx2 = 0.0f;
+  // PE entry q: q<3 identity; else f=(q-3)/6, w=(q-3)%6: w<3 sin(2^f x_w) else cos(2^f x_{w-3})
+  auto accum = [&](int q, float g, bool active) {
+    if (q < 0 || q >= kPeDim) return;
+    float coef = 1.0f;
+    int c = q;
+    if (q >= 3) {
+      const int f = (q - 3) / 6, w = (q - 3) % 6;
+      const float sc = (float)(1 << f);
+      c = w < 3 ? w : w - 3;
+      coef = w < 3 ? sc * pe.v[q + 3] : -sc * pe.v[q - 3];
+    }
+    const float term = active ? coef * g : 0.0f;
+    if (c == 0) dx0 += term; else if (c == 1) dx1 += term; else dx2 += term;
+  };
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    accum(rho(r), gpe0[r], half == 0);
+    accum(rho(r) + 4, gpe0[r], half == 1);
+    accum(rho(r) >= 25 ? 32 + rho(r) - 25 : -1, gpe1[r], half == 0);
+    accum(rho(r) + 4 >= 25 ? 32 + rho(r) + 4 - 25 : -1, gpe1[r], half == 1);
+  }
+  dx0 += __shfl_xor(dx0, 32); dx1 += __shfl_xor(dx1, 32); dx2 += __shfl_xor(dx2, 32);
+
+  bool clamped = false;
+  if (a.sphere_radius > 0.0f && p < a.clamp_n) {
+    const float nrm = __builtin_sqrtf(x0 * x0 + x1 * x1 + x2 * x2);
+    const float sphere = a.sphere_scale * (a.sphere_radius - nrm);
+    if (sphere < sdf) {
+      sdf = sphere;
+      const float k = -a.sphere_scale / nrm;
+      dx0 = k * x0; dx1 = k * x1; dx2 = k * x2;
+      clamped = true;
+    }
+  }
+  if (half == 0 && p < a.src.P && a.clamp_mask) a.clamp_mask[p] = clamped ? 1 : 0;
+  if (half == 0 && p < a.src.P) {
+    a.sdf[p] = sdf;
+    a.grad[3 * p + 0] = dx0; a.grad[3 * p + 1] = dx1; a.grad[3 * p + 2] = dx2;
+  }
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// RenderingNetwork.forward, mode 'idr' (network.py:170-190)
+// --------------------------------------------------------------------------------------------------------------
+struct RgbEpi {
+  f32x16 prev;
+  float v8[8];
+  f32x4 q4;
+  Pieces2* out;
+  float* rblk;       // this layer's block of rbuf or nullptr
+  int lane;
+  __device__ __forceinline__ void b(int tp, int r) {
+    float v = __builtin_fmaxf(prev[r], 0.0f);
+    pin(v);
+    if (rblk) {
+      q4[r & 3] = v;
+      if ((r & 3) == 3) reinterpret_cast<f32x4*>(rblk)[(4 * tp + (r >> 2)) * 64 + lane] = q4;
+    }
+    v8[r & 7] = v;
+    if ((r & 7) == 7) {
+      split8(v8, out->h[2 * tp + (r >> 3)], out->m[2 * tp + (r >> 3)]);
+      pin(out->h[2 * tp + (r >> 3)], out->m[2 * tp + (r >> 3)]);
+    }
+  }
+  __device__ __forceinline__ void all(int tp) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) b(tp, r);
+  }
+};
+
+template <int KS, int N16NEXT_LAST>
+__device__ __forceinline__ void rgb_layer_h2(RgbStream& st, const Pieces2& in, Pieces2& out, float* rblk, int lane) {
+  RgbEpi ep;
+  ep.out = &out; ep.rblk = rblk; ep.lane = lane;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    if (t < 7) st.prefetch<KS == 17 ? kRgbChunk0F4 : kChunkF4>(); else st.prefetch<N16NEXT_LAST>();
+    f32x16 acc;
+    if (t == 0) acc = tile_mma_h2<KS>(st.cur_buf(), in, lane);
+    else acc = tile_mma_h2<KS>(st.cur_buf(), in, lane, NoEpi(), [&](int s) { if (s < 16) ep.b(t - 1, s); });
+    ep.prev = acc;
+    st.advance();
+  }
+  ep.all(7);
+}
+
+__global__ __launch_bounds__(kThreads, 1) void rgb_h2_kernel(RgbArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  RgbStream st;
+  st.g = a.stream; st.buf = reinterpret_cast<f32x4*>(smem); st.cur = 1;
+  const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
+  const int wtile = blockIdx.x * kWaves + wave;
+  const int p = wtile * kTilePts + (lane & 31);
+  const int pc = p < a.src.P ? p : a.src.P - 1;
+
+  st.prefetch<kRgbChunk0F4>();
+  float x0, x1, x2;
+  load_point(a.src, p, x0, x1, x2);
+  const float* vd = a.view + 3 * (size_t)(a.view_S > 0 ? pc / a.view_S : pc);
+  const float d0 = vd[0], d1 = vd[1], d2 = vd[2];
+  // extra rows: [x(3), d(3), sin d(3), cos d(3), n(3), 0]
+  float ex[16];
+  ex[0] = x0; ex[1] = x1; ex[2] = x2; ex[3] = d0; ex[4] = d1; ex[5] = d2;
+  ex[6] = sinf(d0); ex[7] = sinf(d1); ex[8] = sinf(d2); ex[9] = cosf(d0); ex[10] = cosf(d1); ex[11] = cosf(d2);
+  ex[12] = a.normals[3 * pc]; ex[13] = a.normals[3 * pc + 1]; ex[14] = a.normals[3 * pc + 2]; ex[15] = 0.0f;
+  float eb[8];   // fragment of k-step 16: rows rho(j) / rho(j)+4 of the 16 extra rows
+#pragma unroll
+  for (int r = 0; r < 8; ++r) eb[r] = half ? ex[rho(r) + 4] : ex[rho(r)];
+
+  Pieces2 x, xn;
+  split8(eb, x.h[16], x.m[16]);
+  {
+    const float* ft = a.feat_tiles + (size_t)wtile * kBlockF;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) split_tile(load_tile(ft, t, lane), t, x);
+  }
+  float* rb = a.rbuf ? a.rbuf + (size_t)wtile * kRbufF : nullptr;
+  if (rb) {
+    f32x4* d = reinterpret_cast<f32x4*>(rb + 4 * (size_t)kBlockF) + lane;
+    f32x4 v0, v1; v0[0] = eb[0]; v0[1] = eb[1]; v0[2] = eb[2]; v0[3] = eb[3]; v1[0] = eb[4]; v1[1] = eb[5]; v1[2] = eb[6]; v1[3] = eb[7];
+    d[0] = v0; d[64] = v1; d[128] = (f32x4)(0.0f); d[192] = (f32x4)(0.0f);
+  }
+  st.advance();
+
+  // ---- layer 0: 271 -> 256; layers 1..3; every output r_l (post-ReLU) optionally kept in rbuf
+  rgb_layer_h2<17, kChunkF4>(st, x, xn, rb, lane);
+  rgb_layer_h2<16, kChunkF4>(st, xn, x, rb ? rb + 1 * (size_t)kBlockF : nullptr, lane);
+  rgb_layer_h2<16, kChunkF4>(st, x, xn, rb ? rb + 2 * (size_t)kBlockF : nullptr, lane);
+  rgb_layer_h2<16, kChunkF4>(st, xn, x, rb ? rb + 3 * (size_t)kBlockF : nullptr, lane);   // prefetches lin4's chunk
+  // ---- layer 4: 256 -> 3 as one tile (rows 0..2 live in registers 0..2 of lanes 0..31), sigmoid
+  const f32x16 acc = tile_mma_h2<16>(st.cur_buf(), x, lane);
+  if (half == 0 && p < a.src.P) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a.rgb[3 * p + c] = 1.0f / (1.0f + __expf(-acc[c]));
+  }
+}
+
+}  // namespace mlp
+}  // namespace svs
+
+using namespace svs;
+using namespace svs::mlp;
+
+namespace svs {
+namespace mlp {
+int launch_sdf_only_h2(const SdfOnlyArgs& a, hipStream_t s) {
+  static int once = set_lds(sdf_only_h2_kernel, kLdsBytes, "svs_sdf_vals");
+  if (once) return once;
+  sdf_only_h2_kernel<<<(a.src.P + kWgPts - 1) / kWgPts, kThreads, kLdsBytes, s>>>(a);
+  return check_launch("svs_sdf_vals");
+}
+int launch_sdf_full_h2(const SdfFullArgs& a, hipStream_t s) {
+  static int once = set_lds(sdf_full_h2_kernel, kLdsBytes, "svs_sdf_outputs");
+  if (once) return once;
+  sdf_full_h2_kernel<<<(a.src.P + kWgPts - 1) / kWgPts, kThreads, kLdsBytes, s>>>(a);
+  return check_launch("svs_sdf_outputs");
+}
+int launch_rgb_h2(const RgbArgs& a, hipStream_t s) {
+  constexpr int lds = 2 * kRgbBufF4 * 16;
+  static int once = set_lds(rgb_h2_kernel, lds, "svs_rgb_eval");
+  if (once) return once;
+  rgb_h2_kernel<<<(a.src.P + kWgPts - 1) / kWgPts, kThreads, lds, s>>>(a);
+  return check_launch("svs_rgb_eval");
+}
+}  // namespace mlp
+}  // namespace svs

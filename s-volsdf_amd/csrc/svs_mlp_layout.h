@@ -13,7 +13,8 @@ constexpr int kHdrF4 = 256;               // chunk header: 16 accumulator regs x
 constexpr int kBodyF4 = 2048;             // 128 k-steps x 64 lanes floats
 constexpr int kChunkF4 = kHdrF4 + kBodyF4;  // 36 KiB
 constexpr int kPeDim = 39;                // 3 * (1 + 2 * 6), embedder.py:38-50 with multires = 6
-constexpr int kChunk0F4 = kHdrF4 + 320;   // SDF layer-0 chunk: header + 20 k-steps (K = 39 -> 40)
+constexpr int kChunk0F4 = kHdrF4 + 384;   // SDF layer-0 chunk: header + 20 float32 k-steps (K = 39 -> 40; 320 float4
+                                          // used) or 3 fp16x2 k-steps (K -> 48; 384 float4)
 constexpr int kLdsBytes = 2 * kChunkF4 * 16;  // double buffer = 72 KiB
 constexpr int kRgbL0BodyF4 = 136 * 16;    // radiance layer 0: 128 feature k-steps + 8 k-steps of the 16 extra rows
 constexpr int kRgbChunk0F4 = kHdrF4 + kRgbL0BodyF4;
@@ -36,6 +37,12 @@ enum ChunkKind {
   kRgbW4T,        // radiance lin4^T (3 output rows), short chunk
 };
 constexpr int kNoBias = 0x100;            // flag: zero header
+
+// Body encodings of the MFMA chunks (every kind except kSdfVec and kRgbW4T, which are always float32):
+//   kFmtF32   k-step = 2 input rows, one float per lane, [k-step/4][lane][4]     (v_mfma_f32_32x32x2_f32)
+//   kFmtF16x2 k-step = 16 input rows, per k-step 64 lanes x 8 fp16 of the hi piece, then of the mid piece
+//             (v_mfma_f32_32x32x16_f16, svs_mlp_h2_dev.h).  Same bytes per chunk as kFmtF32.
+enum BodyFormat { kFmtF32 = 0, kFmtF16x2 = 1 };
 
 __host__ __device__ constexpr int chunk_f4(int kind) {
   return kind == kSdfFwd0 ? kChunk0F4 : (kind == kRgbFwd0 ? kRgbChunk0F4 : (kind == kRgbW4T ? kW4TF4 : kChunkF4));

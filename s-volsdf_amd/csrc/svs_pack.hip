@@ -62,90 +62,122 @@ __device__ __forceinline__ int rev0_pe(int tile, int local) {
 
 struct ChunkDesc { int kind, layer, tile, off_f4; };   // off_f4: offset of the chunk in the stream, in float4
 
+// Weight that multiplies input row `crow` (C-layout row of the layer input) in output row 32*t + col32 of a chunk.
+// q0: PE index of the element (SDF layer 0); e: index into the 16 extra input rows (radiance layer 0) or -1.
+__device__ __forceinline__ float body_value(const LayerPtrs& w, const float* scale, int kind, int l, int t, int col32,
+                                            int crow, int q0, int e) {
+  const float inv_sqrt2 = 0.70710678118654752f;
+  switch (kind) {
+    case kSdfFwd0:
+      return q0 < 39 ? weff(w, scale, 0, 32 * t + col32, q0, 39) : 0.0f;
+    case kSdfFwd:
+    case kSdfFeat: {
+      const int o = (kind == kSdfFeat ? 1 : 0) + 32 * t + col32;
+      if (o >= sdf_rows(l)) return 0.0f;
+      return l == 4 ? weff(w, scale, 4, o, l4_col(crow), 256) * inv_sqrt2 : weff(w, scale, l, o, crow, 256);
+    }
+    case kSdfVec:
+      return weff(w, scale, 8, 0, crow, 256);
+    case kSdfRev: {
+      // reverse of layer l: out row = input feature i_out (C-layout row of the layer's input), k = output feature
+      if (crow >= sdf_rows(l)) return 0.0f;
+      const int i_out = 32 * t + col32;
+      return l == 4 ? weff(w, scale, 4, crow, l4_col(i_out), 256) * inv_sqrt2 : weff(w, scale, l, crow, i_out, 256);
+    }
+    case kSdfRev0: {
+      const int q = rev0_pe(t, col32);
+      return q >= 0 ? weff(w, scale, 0, crow, q, 39) : 0.0f;
+    }
+    case kSdfFeatT:
+      // h_bar_8 += W8[1:,:]^T f_bar : out row = h_8 feature (32t+col), k = feature-vector index
+      return weff(w, scale, 8, 1 + crow, 32 * t + col32, 256);
+    case kRgbFwd0: {
+      const int o = 32 * t + col32;
+      if (e < 0) return weff(w, scale, 0, o, 15 + crow, 271);
+      return e < 15 ? weff(w, scale, 0, o, e, 271) : 0.0f;
+    }
+    case kRgbFwd: {
+      const int o = 32 * t + col32;
+      return o < rgb_rows(l) ? weff(w, scale, l, o, crow, 256) : 0.0f;
+    }
+    case kRgbRev:
+      return weff(w, scale, l, crow, 32 * t + col32, 256);
+    case kRgbRev0: {
+      // out row = layer-0 input in kernel order: tiles 0..7 feature rows (param col 15+row), tile 8 the 16 extras
+      const int pc = t < 8 ? 15 + 32 * t + col32 : (col32 < 15 ? col32 : -1);
+      return pc >= 0 ? weff(w, scale, 0, crow, pc, 271) : 0.0f;
+    }
+    default:
+      return 0.0f;
+  }
+}
+
+// bias of output row o_local = rho(r) + 4*half of tile t (header register r)
+__device__ __forceinline__ float header_value(const LayerPtrs& w, int kind, int l, int t, int o_local) {
+  switch (kind) {
+    case kSdfFwd0: return w.b[0][32 * t + o_local];
+    case kSdfFwd: { const int o = 32 * t + o_local; return o < sdf_rows(l) ? w.b[l][o] : 0.0f; }
+    case kSdfFeat: { const int o = 1 + 32 * t + o_local; return o < sdf_rows(l) ? w.b[l][o] : 0.0f; }
+    case kSdfVec: return w.b[8][0];
+    case kRgbFwd0: return w.b[0][32 * t + o_local];
+    case kRgbFwd: { const int o = 32 * t + o_local; return o < rgb_rows(l) ? w.b[l][o] : 0.0f; }
+    default: return 0.0f;     // transposed (backward) chunks carry no bias
+  }
+}
+
 // one workgroup per chunk
 __global__ __launch_bounds__(256) void pack_stream_kernel(LayerPtrs w, const float* __restrict__ scale,
-                                                          const ChunkDesc* __restrict__ table, float* __restrict__ out) {
+                                                          const ChunkDesc* __restrict__ table, int fmt,
+                                                          float* __restrict__ out) {
   const ChunkDesc d = table[blockIdx.x];
   const int kind = d.kind & 0xff;
   const bool nobias = (d.kind & kNoBias) != 0;
   const int l = d.layer, t = d.tile;
-  const float inv_sqrt2 = 0.70710678118654752f;
   float* dst = out + (size_t)d.off_f4 * 4;
-  const int n = chunk_f4(kind) * 4;
-  for (int wi = threadIdx.x; wi < n; wi += 256) {
-    float val = 0.0f;
-    if (kind == kRgbW4T) {
-      // [tile 8][lane 64][4 k-steps]: A = W4^T rows (input feature 32*tile + lane&31), k = rho(s) + 4*half < 3
+  if (kind == kRgbW4T) {
+    // [tile 8][lane 64][4 k-steps]: A = W4^T rows (input feature 32*tile + lane&31), k = rho(s) + 4*half < 3
+    for (int wi = threadIdx.x; wi < kW4TF4 * 4; wi += 256) {
       const int tt = wi / 256, lane = (wi & 255) >> 2, s = wi & 3;
       const int k = rho(s) + 4 * (lane >> 5);
-      if (k < 3) val = weff(w, scale, 4, k, 32 * tt + (lane & 31), 256);
-      dst[wi] = val;
-      continue;
+      dst[wi] = k < 3 ? weff(w, scale, 4, k, 32 * tt + (lane & 31), 256) : 0.0f;
     }
-    const bool hdr = wi < kHdrF4 * 4;
-    const int wb = hdr ? wi : wi - kHdrF4 * 4;
-    const int lane = (wb & 255) >> 2, half = lane >> 5, col32 = lane & 31;
-    const int sr = 4 * (wb / 256) + (wb & 3);                   // hdr: accumulator register r; body: k-step s
-    const int crow = 32 * (sr / 16) + rho(sr % 16) + 4 * half;  // body: C-layout row addressed by k-step s
-    switch (kind) {
-      case kSdfFwd0:
-        if (hdr) { if (!nobias) val = w.b[0][32 * t + rho(sr) + 4 * half]; }
-        else { const int q = 2 * sr + half; if (q < 39) val = weff(w, scale, 0, 32 * t + col32, q, 39); }
-        break;
-      case kSdfFwd:
-      case kSdfFeat: {
-        const int rows = sdf_rows(l), off = kind == kSdfFeat ? 1 : 0;
-        if (hdr) { const int o = off + 32 * t + rho(sr) + 4 * half; if (o < rows && !nobias) val = w.b[l][o]; }
-        else {
-          const int o = off + 32 * t + col32;
-          if (o < rows) val = l == 4 ? weff(w, scale, 4, o, l4_col(crow), 256) * inv_sqrt2 : weff(w, scale, l, o, crow, 256);
-        }
-        break;
-      }
-      case kSdfVec:
-        val = hdr ? w.b[8][0] : weff(w, scale, 8, 0, crow, 256);
-        break;
-      case kSdfRev:
-        // reverse of layer l: out row = input feature i_out (C-layout row of the layer's input), k = output feature
-        if (!hdr && crow < sdf_rows(l)) {
-          const int i_out = 32 * t + col32;
-          val = l == 4 ? weff(w, scale, 4, crow, l4_col(i_out), 256) * inv_sqrt2 : weff(w, scale, l, crow, i_out, 256);
-        }
-        break;
-      case kSdfRev0:
-        if (!hdr) { const int q = rev0_pe(t, col32); if (q >= 0) val = weff(w, scale, 0, crow, q, 39); }
-        break;
-      case kSdfFeatT:
-        // h_bar_8 += W8[1:,:]^T f_bar : out row = h_8 feature (32t+col), k = feature-vector index
-        if (!hdr) val = weff(w, scale, 8, 1 + crow, 32 * t + col32, 256);
-        break;
-      case kRgbFwd0:
-        if (hdr) { if (!nobias) val = w.b[0][32 * t + rho(sr) + 4 * half]; }
-        else {
-          const int o = 32 * t + col32;
-          if (sr < 128) val = weff(w, scale, 0, o, 15 + crow, 271);
-          else { const int e = rho(sr - 128) + 4 * half; if (e < 15) val = weff(w, scale, 0, o, e, 271); }
-        }
-        break;
-      case kRgbFwd: {
-        const int rows = rgb_rows(l);
-        if (hdr) { const int o = 32 * t + rho(sr) + 4 * half; if (o < rows && !nobias) val = w.b[l][o]; }
-        else { const int o = 32 * t + col32; if (o < rows) val = weff(w, scale, l, o, crow, 256); }
-        break;
-      }
-      case kRgbRev:
-        if (!hdr) val = weff(w, scale, l, crow, 32 * t + col32, 256);
-        break;
-      case kRgbRev0:
-        // out row = layer-0 input in kernel order: tiles 0..7 feature rows (param col 15+row), tile 8 the 16 extras
-        if (!hdr) {
-          const int pc = t < 8 ? 15 + 32 * t + col32 : (col32 < 15 ? col32 : -1);
-          if (pc >= 0) val = weff(w, scale, 0, crow, pc, 271);
-        }
-        break;
-      default: break;
+    return;
+  }
+  // ---- header: [r/4][lane][4] bias block in accumulator layout
+  for (int wi = threadIdx.x; wi < kHdrF4 * 4; wi += 256) {
+    const int lane = (wi & 255) >> 2, r = 4 * (wi / 256) + (wi & 3);
+    dst[wi] = nobias ? 0.0f : header_value(w, kind, l, t, rho(r) + 4 * (lane >> 5));
+  }
+  float* body = dst + kHdrF4 * 4;
+  const int body_f4 = chunk_f4(kind) - kHdrF4;
+  if (fmt == kFmtF32 || kind == kSdfVec) {
+    for (int wb = threadIdx.x; wb < body_f4 * 4; wb += 256) {
+      const int lane = (wb & 255) >> 2, half = lane >> 5, col32 = lane & 31;
+      const int sr = 4 * (wb / 256) + (wb & 3);                   // k-step: input rows 2*sr, 2*sr+1 in K order
+      const int crow = 32 * (sr / 16) + rho(sr % 16) + 4 * half;  // C-layout row addressed by k-step sr
+      const int e = sr >= 128 ? rho(sr - 128) + 4 * half : -1;
+      body[wb] = body_value(w, scale, kind, l, t, col32, crow, 2 * sr + half, e);
     }
-    dst[wi] = val;
+    return;
+  }
+  // ---- fp16x2: one 16-byte fragment per (k-step, piece, lane)
+  uint4* frag = reinterpret_cast<uint4*>(body);
+  for (int f = threadIdx.x; f < body_f4; f += 256) {
+    const int s = f >> 7, piece = (f >> 6) & 1, lane = f & 63, half = lane >> 5, col32 = lane & 31;
+    unsigned short ebits[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int crow = 32 * (s >> 1) + rho(8 * (s & 1) + j) + 4 * half;
+      const int e = s >= 16 ? rho(j) + 4 * half : -1;
+      const float wv = body_value(w, scale, kind, l, t, col32, crow, 16 * s + 8 * half + j, e);
+      const _Float16 hi = (_Float16)wv;
+      const _Float16 mid = (_Float16)(wv - (float)hi);
+      ebits[j] = __builtin_bit_cast(unsigned short, piece == 0 ? hi : mid);
+    }
+    uint4 v;
+    v.x = ebits[0] | ((unsigned)ebits[1] << 16); v.y = ebits[2] | ((unsigned)ebits[3] << 16);
+    v.z = ebits[4] | ((unsigned)ebits[5] << 16); v.w = ebits[6] | ((unsigned)ebits[7] << 16);
+    frag[f] = v;
   }
 }
 
@@ -213,19 +245,19 @@ using namespace svs::mlp;
 extern "C" {
 
 // which: 0 SDF forward, 1 SDF full (forward + feature head + gradient pass), 2 SDF training backward,
-//        3 radiance forward, 4 radiance backward
+//        3 radiance forward, 4 radiance backward.  precision: body encoding of the MFMA chunks, 0 float32, 1 fp16x2.
+// Stream sizes do not depend on the precision.
 size_t svs_stream_bytes(int which) {
   if (which < 0 || which >= kNumStreams) return 0;
   return table_for(which).total_f4 * 16;
 }
-size_t svs_sdf_stream_bytes(int full) { return svs_stream_bytes(full ? kStreamSdfFull : kStreamSdfFwd); }
-size_t svs_rgb_stream_bytes(void) { return svs_stream_bytes(kStreamRgbFwd); }
 size_t svs_pack_workspace_bytes(void) { return 9 * kScaleStride * sizeof(float); }
 
 // weight_v / weight_g / bias: HOST arrays of 9 (SDF) or 5 (radiance) device pointers; weight_g may be NULL.
-int svs_pack_stream(int which, const float* const* weight_v, const float* const* weight_g, const float* const* bias,
-                    float* workspace, float* stream_out, void* hip_stream) {
-  if (which < 0 || which >= kNumStreams || !weight_v || !bias || !workspace || !stream_out) {
+int svs_pack_stream(int which, int precision, const float* const* weight_v, const float* const* weight_g,
+                    const float* const* bias, float* workspace, float* stream_out, void* hip_stream) {
+  if (which < 0 || which >= kNumStreams || !weight_v || !bias || !workspace || !stream_out ||
+      (precision != kFmtF32 && precision != kFmtF16x2)) {
     set_error("svs_pack_stream: bad argument"); return SVS_EINVAL;
   }
   const bool is_rgb = which >= kStreamRgbFwd;
@@ -243,17 +275,8 @@ int svs_pack_stream(int which, const float* const* weight_v, const float* const*
   }
   hipStream_t s = (hipStream_t)hip_stream;
   rownorm_kernel<<<(nl * kScaleStride + 3) / 4, 256, 0, s>>>(w, nl, is_rgb ? 1 : 0, workspace);
-  pack_stream_kernel<<<(unsigned)t.host.size(), 256, 0, s>>>(w, workspace, t.dev, stream_out);
+  pack_stream_kernel<<<(unsigned)t.host.size(), 256, 0, s>>>(w, workspace, t.dev, precision, stream_out);
   return check_launch("svs_pack_stream");
-}
-
-int svs_sdf_pack(const float* const* weight_v, const float* const* weight_g, const float* const* bias,
-                 float* workspace, float* stream_out, int full, void* hip_stream) {
-  return svs_pack_stream(full ? kStreamSdfFull : kStreamSdfFwd, weight_v, weight_g, bias, workspace, stream_out, hip_stream);
-}
-int svs_rgb_pack(const float* const* weight_v, const float* const* weight_g, const float* const* bias,
-                 float* workspace, float* stream_out, void* hip_stream) {
-  return svs_pack_stream(kStreamRgbFwd, weight_v, weight_g, bias, workspace, stream_out, hip_stream);
 }
 
 }  // extern "C"

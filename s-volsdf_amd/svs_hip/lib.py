@@ -25,19 +25,15 @@ SIGNATURES = {
     "svs_last_error_string": (c_char_p, []),
     "svs_rays_from_uv": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P]),
     "svs_stream_bytes": (c_size_t, [c_int]),
-    "svs_pack_stream": (c_int, [c_int, _PP, _PP, _PP, _P, _P, _P]),
-    "svs_sdf_stream_bytes": (c_size_t, [c_int]),
-    "svs_rgb_stream_bytes": (c_size_t, []),
+    "svs_pack_stream": (c_int, [c_int, c_int, _PP, _PP, _PP, _P, _P, _P]),
     "svs_pack_workspace_bytes": (c_size_t, []),
-    "svs_sdf_pack": (c_int, [_PP, _PP, _PP, _P, _P, c_int, _P]),
-    "svs_rgb_pack": (c_int, [_PP, _PP, _PP, _P, _P, _P]),
-    "svs_sdf_vals": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, _P, c_float, c_float, c_int, _P, _P, _P]),
+    "svs_sdf_vals": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, _P, c_int, c_float, c_float, c_int, _P, _P, _P]),
     "svs_sdf_hbuf_bytes": (c_size_t, [c_int]),
     "svs_feat_tiles_bytes": (c_size_t, [c_int]),
-    "svs_sdf_outputs": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, _P, c_float, c_float, c_int, _P, _P, _P,
-                                _P, _P, _P, _P]),
+    "svs_sdf_outputs": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, _P, c_int, c_float, c_float, c_int, _P, _P,
+                                _P, _P, _P, _P, _P]),
     "svs_tiles_to_rows": (c_int, [_P, c_int, _P, _P]),
-    "svs_rgb_eval": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, _P, _P, c_int, _P, _P, _P, _P, _P]),
+    "svs_rgb_eval": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, _P, _P, c_int, _P, _P, c_int, _P, _P, _P]),
     "svs_rgb_rbuf_bytes": (c_size_t, [c_int]),
     "svs_block_bytes": (c_size_t, [c_int, c_int]),
     "svs_rgb_zbuf_bytes": (c_size_t, [c_int]),

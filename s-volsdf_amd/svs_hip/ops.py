@@ -50,14 +50,27 @@ def rays_from_uv(uv, pose, intrinsics):
     return dirs, cam, ds
 
 
+F32, F16X2 = 0, 1          # MFMA precision of the MLP kernels (include/svolsdf_hip.h: SVS_MMA_F32 / SVS_MMA_F16X2)
+
+
+def default_precision():
+    """fp16x2 (two-piece fp16 operands, float32-class accuracy, 2.8x faster) unless SVS_MLP_PRECISION=f32."""
+    import os
+    v = os.environ.get("SVS_MLP_PRECISION", "f16x2").lower()
+    if v not in ("f32", "f16x2"):
+        raise ValueError(f"SVS_MLP_PRECISION must be f32 or f16x2, not {v!r}")
+    return F32 if v == "f32" else F16X2
+
+
 class PackedMlp:
     """Packed weight streams of one ImplicitNetwork / RenderingNetwork pair (rebuilt after every optimiser step)."""
 
-    def __init__(self, device):
+    def __init__(self, device, precision=None):
         L = _lib.load()
         self.device = device
-        self.sdf_stream = torch.empty(L.svs_sdf_stream_bytes(1) // 4, device=device)
-        self.rgb_stream = torch.empty(L.svs_rgb_stream_bytes() // 4, device=device)
+        self.precision = default_precision() if precision is None else int(precision)
+        self.sdf_stream = torch.empty(L.svs_stream_bytes(1) // 4, device=device)
+        self.rgb_stream = torch.empty(L.svs_stream_bytes(3) // 4, device=device)
         self._ws = torch.empty(L.svs_pack_workspace_bytes() // 4, device=device)
 
     def pack_sdf(self, weight_v, weight_g, bias):
@@ -67,8 +80,8 @@ class PackedMlp:
         b = [_f32(t) for t in bias]
         g = [_f32(t) for t in weight_g] if weight_g is not None else None
         self._keep = (v, b, g)
-        _lib.check(L.svs_sdf_pack(_ptr_array(v), _ptr_array(g) if g else None, _ptr_array(b), _ptr(self._ws),
-                                  _ptr(self.sdf_stream), 1, _stream()), "svs_sdf_pack")
+        _lib.check(L.svs_pack_stream(1, self.precision, _ptr_array(v), _ptr_array(g) if g else None, _ptr_array(b),
+                                     _ptr(self._ws), _ptr(self.sdf_stream), _stream()), "svs_pack_stream(sdf)")
 
     def pack_rgb(self, weight_v, weight_g, bias):
         L = _lib.load()
@@ -76,8 +89,8 @@ class PackedMlp:
         b = [_f32(t) for t in bias]
         g = [_f32(t) for t in weight_g] if weight_g is not None else None
         self._keep_rgb = (v, b, g)
-        _lib.check(L.svs_rgb_pack(_ptr_array(v), _ptr_array(g) if g else None, _ptr_array(b), _ptr(self._ws),
-                                  _ptr(self.rgb_stream), _stream()), "svs_rgb_pack")
+        _lib.check(L.svs_pack_stream(3, self.precision, _ptr_array(v), _ptr_array(g) if g else None, _ptr_array(b),
+                                     _ptr(self._ws), _ptr(self.rgb_stream), _stream()), "svs_pack_stream(rgb)")
 
 
 class PointSource:
@@ -110,7 +123,7 @@ def sdf_vals(packed, src, sphere_radius, sphere_scale, out=None, gate=None, clam
     """ImplicitNetwork.get_sdf_vals (network.py:125-131) -> (P,1).  gate: optional device int (skip when 0)."""
     L = _lib.load()
     sdf = out if out is not None else torch.empty(src.n, 1, device=src.device)
-    _lib.check(L.svs_sdf_vals(*src.args(), _ptr(packed.sdf_stream), float(sphere_radius), float(sphere_scale),
+    _lib.check(L.svs_sdf_vals(*src.args(), _ptr(packed.sdf_stream), packed.precision, float(sphere_radius), float(sphere_scale),
                               int(clamp_n), _ptr(sdf), ctypes.c_void_p(gate) if gate else None, _stream()), "svs_sdf_vals")
     return sdf
 
@@ -132,7 +145,7 @@ def sdf_outputs(packed, src, sphere_radius, sphere_scale, want_feature_rows=Fals
         gbuf = torch.empty(L.svs_sdf_hbuf_bytes(src.n) // 4, device=dev)
         mask = torch.empty(src.n, dtype=torch.uint8, device=dev)
         keep.update(hbuf=hbuf, gbuf=gbuf, clamp_mask=mask, src=src)
-    _lib.check(L.svs_sdf_outputs(*src.args(), _ptr(packed.sdf_stream), float(sphere_radius), float(sphere_scale),
+    _lib.check(L.svs_sdf_outputs(*src.args(), _ptr(packed.sdf_stream), packed.precision, float(sphere_radius), float(sphere_scale),
                                  int(clamp_n), _ptr(sdf), _ptr(grad), _ptr(feat), _ptr(hbuf), _ptr(gbuf), _ptr(mask),
                                  _stream()), "svs_sdf_outputs")
     rows = None
@@ -156,7 +169,7 @@ def rgb_eval(packed, src, normals, view_dirs, feat_tiles, keep=None):
         rbuf = torch.empty(L.svs_rgb_rbuf_bytes(src.n) // 4, device=src.device)
         keep.update(rbuf=rbuf, feat_tiles=feat_tiles, rgb=rgb)
     _lib.check(L.svs_rgb_eval(*src.args(), _ptr(normals), _ptr(view_dirs), view_S, _ptr(feat_tiles),
-                              _ptr(packed.rgb_stream), _ptr(rgb), _ptr(rbuf), _stream()), "svs_rgb_eval")
+                              _ptr(packed.rgb_stream), packed.precision, _ptr(rgb), _ptr(rbuf), _stream()), "svs_rgb_eval")
     return rgb
 
 

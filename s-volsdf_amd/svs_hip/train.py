@@ -40,9 +40,9 @@ class TrainStreams:
         rv, rg, rb = [[_f32(t) for t in x] if x is not None else None for x in rgb_params]
         self._keep = (sv, sg, sb, rv, rg, rb)
         st = _stream()
-        _lib.check(L.svs_pack_stream(2, _ptr_array(sv), _ptr_array(sg) if sg else None, _ptr_array(sb), _ptr(self.ws),
+        _lib.check(L.svs_pack_stream(2, 0, _ptr_array(sv), _ptr_array(sg) if sg else None, _ptr_array(sb), _ptr(self.ws),
                                      _ptr(self.sdf), st), "svs_pack_stream(sdf train)")
-        _lib.check(L.svs_pack_stream(4, _ptr_array(rv), _ptr_array(rg) if rg else None, _ptr_array(rb), _ptr(self.ws),
+        _lib.check(L.svs_pack_stream(4, 0, _ptr_array(rv), _ptr_array(rg) if rg else None, _ptr_array(rb), _ptr(self.ws),
                                      _ptr(self.rgb), st), "svs_pack_stream(rgb bwd)")
 
 

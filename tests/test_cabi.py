@@ -41,8 +41,8 @@ def test_header_matches_library_and_ctypes_table(lib):
 
 def test_size_queries(lib):
     L = lib.load()
-    assert L.svs_sdf_stream_bytes(1) > L.svs_sdf_stream_bytes(0) > 1 << 20
-    assert L.svs_rgb_stream_bytes() > 1 << 20
+    assert L.svs_stream_bytes(1) > L.svs_stream_bytes(0) > 1 << 20
+    assert L.svs_stream_bytes(3) > 1 << 20
     assert L.svs_sampler_cap() >= 640 and L.svs_sampler_max_new() == 128
     assert L.svs_sdf_hbuf_bytes(128) == 4 * 8 * 128 * 64 * 4
     assert L.svs_feat_tiles_bytes(129) == 8 * 128 * 64 * 4
