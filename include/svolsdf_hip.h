@@ -129,10 +129,13 @@ int svs_composite_bwd(int n_rays, int n_samples, const float* z, const float* sd
  * blocks (128*64 floats per 32 points; s* = floats between consecutive blocks).  a*_h (optional): A is multiplied
  * by softplus'(.) = 1 - exp(-100 h) of that block.  b_extra: optional 16 extra B rows per block (dW columns
  * 256..271, ldw >= 272: the radiance MLP's first layer).  db[256] += row sums of pair 0's A (bias gradient).
- * dW / db are accumulated with float atomics: the caller zeroes them. */
+ * dW / db are accumulated with float atomics: the caller zeroes them.
+ * precision SVS_MMA_F16X2: the gradient-like operands (A of pair 0, B of pair 1) are scaled by a power of two derived
+ * from *absmax (device float: their maximum magnitude, published by the fp16x2 sweeps below; NULL = no scaling). */
 int svs_wgrad(const float* a0, const float* a0_h, const float* b0, long long sa0, long long sh0, long long sb0,
               const float* a1, const float* a1_h, const float* b1, long long sa1, long long sh1, long long sb1,
-              const float* b_extra, long long s_extra, int n_points, float* dW, int ldw, float* db, void* hip_stream);
+              const float* b_extra, long long s_extra, int n_points, int precision, const float* absmax, float* dW,
+              int ldw, float* db, void* hip_stream);
 
 /* ---- a12  training backward of the fused MLPs (hand-written reverse mode; the reference uses torch.autograd,
  * loss.backward() at volsdf/vsdf.py:215, incl. the double backward through network.py:115-121) -------------------
@@ -145,20 +148,26 @@ int svs_wgrad(const float* a0, const float* a0_h, const float* b0, long long sa0
  *   svs_sdf_bwd_b: backprop.  d_sdf (P) or NULL, feat_bar for the first n_feat_points points (multiple of 32)
  *                 -> abuf (8 blocks/tile), sbar_out (32 floats per tile)
  *   svs_lin8_row0_grad: out257[0..255] += dL/dW8[0,:], out257[256] += dL/db8[0] (caller zeroes)
+ *   precision SVS_MMA_F16X2 (streams packed with the same precision): every point carries its own power-of-two
+ *                 scale through the sweeps (gradients are far below fp16's range); all buffers hold true float32
+ *                 values.  Extra arguments, NULL for SVS_MMA_F32: absmax (3 floats, caller zeroes once per step:
+ *                 [0] max |abar|,|u|, [1] max |zbar|, [2] max |feat_bar| -- the scales of svs_wgrad), a2max (padded
+ *                 n_points floats, pass A -> pass B).
  *   svs_unpack_wgrad: kernel-order dW (from svs_wgrad) -> parameter gradients incl. weight-norm backward
  *                 (w = g v/|v|, network.py:64-65).  map: 0 identity, 1 SDF lin4 (skip splice, 1/sqrt2),
  *                 2 radiance lin0.  row_off: first parameter row covered by dWk (SDF lin8: 1, with row0 = out257). */
 size_t svs_block_bytes(int n_points, int blocks_per_tile);
 size_t svs_rgb_zbuf_bytes(int n_points);
 size_t svs_sdf_ubuf_bytes(int n_points);
-int svs_rgb_bwd(int n_points, const float* d_rgb, const float* rgb, const float* rbuf, const float* stream, float* zbuf,
-                float* feat_bar, float* d_normals, void* hip_stream);
+int svs_rgb_bwd(int n_points, const float* d_rgb, const float* rgb, const float* rbuf, const float* stream, int precision,
+                float* zbuf, float* feat_bar, float* d_normals, float* absmax, void* hip_stream);
 int svs_sdf_bwd_a(const float* points, int n_points, const float* cam, int cam_stride, const float* dirs, const float* z,
                   int S, int n_rays, const float* d_grad, const unsigned char* clamp_mask, const float* hbuf,
-                  const float* gbuf, const float* stream, float* ubuf, float* a2buf, float* pebuf, void* hip_stream);
+                  const float* gbuf, const float* stream, int precision, float* ubuf, float* a2buf, float* pebuf,
+                  float* absmax, float* a2max, void* hip_stream);
 int svs_sdf_bwd_b(int n_points, const float* d_sdf, const unsigned char* clamp_mask, const float* feat_bar,
                   int n_feat_points, const float* hbuf, const float* gbuf, const float* a2buf, const float* stream,
-                  float* abuf, float* sbar_out, void* hip_stream);
+                  int precision, float* abuf, float* sbar_out, float* absmax, const float* a2max, void* hip_stream);
 int svs_lin8_row0_grad(const float* hbuf, const float* ubuf, const float* sbar, int n_points, float* out257,
                        void* hip_stream);
 int svs_unpack_wgrad(const float* dWk, const float* dbk, int ldw, int map, int rows, int cols, int row_off,

@@ -16,6 +16,7 @@
 // with s' = 1 - exp(-100 h), s'' = 100 s' (1 - s').  Both passes reuse the forward machinery (transposed
 // activations in registers, LDS-DMA weight streaming, float32 MFMA) with bias-free / transposed weight streams.
 #include "svs_mlp_dev.h"
+#include "svs_mlp_bwd_args.h"
 
 namespace svs {
 namespace mlp {
@@ -23,17 +24,6 @@ namespace mlp {
 // ==============================================================================================================
 // radiance MLP backward
 // ==============================================================================================================
-struct RgbBwdArgs {
-  int P;
-  const float* d_rgb;      // (P,3) d loss / d rgb (after the sigmoid)
-  const float* rgb;        // (P,3) forward output
-  const float* rbuf;       // forward activations [wave tiles][kRbufF]
-  const f32x4* stream;     // radiance backward stream
-  float* zbuf;             // out [wave tiles][5][kBlockF]: zbar_0..zbar_3, zbar_4 (first tile only; rest stays zero)
-  float* feat_bar;         // out [wave tiles][kBlockF]: d loss / d feature vector
-  float* d_normals;        // out (P,3): d loss / d normals (the rendering network's normal input)
-};
-constexpr int kRbufFb = 4 * kBlockF + 1024;
 
 __global__ __launch_bounds__(kThreads, 1) void rgb_bwd_kernel(RgbBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -122,17 +112,6 @@ __global__ __launch_bounds__(kThreads, 1) void rgb_bwd_kernel(RgbBwdArgs a) {
 // ==============================================================================================================
 // SDF MLP backward, pass A
 // ==============================================================================================================
-struct SdfBwdAArgs {
-  PointSrc src;
-  const float* d_grad;        // (P,3) nbar = d loss / d (d sdf/dx)
-  const unsigned char* clamp_mask;  // (P) or nullptr: clamped points contribute no nbar
-  const float* hbuf;          // [wave tiles][8][kBlockF] forward activations
-  const float* gbuf;          // [wave tiles][8][kBlockF] g(h_{l+1})
-  const f32x4* stream;        // SDF training stream (pass A part at offset 0)
-  float* ubuf;                // out [wave tiles][9][kBlockF]: block 0 = u_0 (PE order, first 2 tiles), blocks 1..8 = u_1..u_8
-  float* a2buf;               // out [wave tiles][8][kBlockF]
-  float* pebuf;               // out [wave tiles][kBlockF]: h_0 = PE(x) in PE order (first 2 tiles), B operand of dW_0
-};
 
 // a 39-vector in PE order as a 2-tile accumulator-layout block (rows q = 32*tile + rho(r) + 4*half)
 __device__ __forceinline__ void store_pe_block(float* __restrict__ block, const float* vec40, int lane, int half) {
@@ -247,17 +226,6 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_kernel(SdfBwdAArgs a) {
 // ==============================================================================================================
 // SDF MLP backward, pass B
 // ==============================================================================================================
-struct SdfBwdBArgs {
-  int P;
-  const float* d_sdf;         // (P) sbar, or nullptr
-  const unsigned char* clamp_mask;
-  const float* feat_bar;      // [wave tiles][kBlockF] fbar (or nullptr: zero)
-  int n_feat_tiles;           // wave tiles that have a feat_bar block (ray samples); later tiles (eikonal points) have none
-  const float* hbuf; const float* gbuf; const float* a2buf;
-  const f32x4* stream;        // SDF training stream, pass B part
-  float* abuf;                // out [wave tiles][8][kBlockF] abar_0..abar_7
-  float* sbar_out;            // out (padded P): the effective sbar (clamp applied), for the lin8 row-0 gradient
-};
 
 __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_kernel(SdfBwdBArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -270,7 +238,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_kernel(SdfBwdBArgs a) {
   st.prefetch<kChunkF4>();
   float sbar = (a.d_sdf && p < a.P) ? a.d_sdf[pc] : 0.0f;
   if (a.clamp_mask && a.clamp_mask[pc]) sbar = 0.0f;
-  if (half == 0) a.sbar_out[p] = sbar;
+  if (half == 0 && a.sbar_out) a.sbar_out[p] = sbar;
   const float* hb = a.hbuf + (size_t)wtile * 8 * kBlockF;
   const float* gb = a.gbuf + (size_t)wtile * 8 * kBlockF;
   const float* a2 = a.a2buf + (size_t)wtile * 8 * kBlockF;
@@ -436,12 +404,17 @@ size_t svs_block_bytes(int n_points, int blocks_per_tile) {
   return (size_t)tiles_of(n_points) * blocks_per_tile * kBlockF * sizeof(float);
 }
 
-int svs_rgb_bwd(int n_points, const float* d_rgb, const float* rgb, const float* rbuf, const float* stream, float* zbuf,
-                float* feat_bar, float* d_normals, void* hip_stream) {
+int svs_rgb_bwd(int n_points, const float* d_rgb, const float* rgb, const float* rbuf, const float* stream, int precision,
+                float* zbuf, float* feat_bar, float* d_normals, float* absmax, void* hip_stream) {
   if (!d_rgb || !rgb || !rbuf || !stream || !zbuf || !feat_bar || !d_normals || n_points <= 0) {
     set_error("svs_rgb_bwd: null/invalid argument"); return SVS_EINVAL;
   }
-  RgbBwdArgs a{n_points, d_rgb, rgb, rbuf, reinterpret_cast<const f32x4*>(stream), zbuf, feat_bar, d_normals};
+  RgbBwdArgs a{n_points, d_rgb, rgb, rbuf, reinterpret_cast<const f32x4*>(stream), zbuf, feat_bar, d_normals, absmax};
+  if (precision == kFmtF16x2) {
+    if (!absmax) { set_error("svs_rgb_bwd: fp16x2 needs absmax"); return SVS_EINVAL; }
+    return launch_rgb_bwd_h2(a, (hipStream_t)hip_stream);
+  }
+  if (precision != kFmtF32) { set_error("svs_rgb_bwd: unknown precision %d", precision); return SVS_EINVAL; }
   static int once = set_lds_b(rgb_bwd_kernel, kLdsBytes, "svs_rgb_bwd");
   if (once) return once;
   rgb_bwd_kernel<<<(n_points + kWgPts - 1) / kWgPts, kThreads, kLdsBytes, (hipStream_t)hip_stream>>>(a);
@@ -450,7 +423,8 @@ int svs_rgb_bwd(int n_points, const float* d_rgb, const float* rgb, const float*
 
 int svs_sdf_bwd_a(const float* points, int n_points, const float* cam, int cam_stride, const float* dirs, const float* z,
                   int S, int n_rays, const float* d_grad, const unsigned char* clamp_mask, const float* hbuf,
-                  const float* gbuf, const float* stream, float* ubuf, float* a2buf, float* pebuf, void* hip_stream) {
+                  const float* gbuf, const float* stream, int precision, float* ubuf, float* a2buf, float* pebuf,
+                  float* absmax, float* a2max, void* hip_stream) {
   SdfBwdAArgs a;
   if (n_points < 0 || n_rays < 0 || (n_points == 0 && n_rays == 0) || (n_points > 0 && !points) ||
       (n_rays > 0 && !(cam && dirs && z && S > 0)) || !d_grad || !hbuf || !gbuf || !stream || !ubuf || !a2buf || !pebuf) {
@@ -460,6 +434,12 @@ int svs_sdf_bwd_a(const float* points, int n_points, const float* cam, int cam_s
   a.src.S = S > 0 ? S : 1; a.src.n_ray = n_rays * (S > 0 ? S : 0); a.src.P = a.src.n_ray + n_points;
   a.d_grad = d_grad; a.clamp_mask = clamp_mask; a.hbuf = hbuf; a.gbuf = gbuf;
   a.stream = reinterpret_cast<const f32x4*>(stream); a.ubuf = ubuf; a.a2buf = a2buf; a.pebuf = pebuf;
+  a.absmax = absmax; a.a2max = a2max;
+  if (precision == kFmtF16x2) {
+    if (!absmax || !a2max) { set_error("svs_sdf_bwd_a: fp16x2 needs absmax and a2max"); return SVS_EINVAL; }
+    return launch_sdf_bwd_a_h2(a, (hipStream_t)hip_stream);
+  }
+  if (precision != kFmtF32) { set_error("svs_sdf_bwd_a: unknown precision %d", precision); return SVS_EINVAL; }
   static int once = set_lds_b(sdf_bwd_a_kernel, kLdsBytes, "svs_sdf_bwd_a");
   if (once) return once;
   sdf_bwd_a_kernel<<<(a.src.P + kWgPts - 1) / kWgPts, kThreads, kLdsBytes, (hipStream_t)hip_stream>>>(a);
@@ -468,12 +448,17 @@ int svs_sdf_bwd_a(const float* points, int n_points, const float* cam, int cam_s
 
 int svs_sdf_bwd_b(int n_points, const float* d_sdf, const unsigned char* clamp_mask, const float* feat_bar,
                   int n_feat_points, const float* hbuf, const float* gbuf, const float* a2buf, const float* stream,
-                  float* abuf, float* sbar_out, void* hip_stream) {
+                  int precision, float* abuf, float* sbar_out, float* absmax, const float* a2max, void* hip_stream) {
   if (!hbuf || !gbuf || !a2buf || !stream || !abuf || !sbar_out || n_points <= 0 || n_feat_points % 32) {
     set_error("svs_sdf_bwd_b: null/invalid argument (n_feat_points must be a multiple of 32)"); return SVS_EINVAL;
   }
   SdfBwdBArgs a{n_points, d_sdf, clamp_mask, feat_bar, n_feat_points / 32, hbuf, gbuf, a2buf,
-                reinterpret_cast<const f32x4*>(stream) + kSdfTrainPassBF4, abuf, sbar_out};
+                reinterpret_cast<const f32x4*>(stream) + kSdfTrainPassBF4, abuf, sbar_out, absmax, a2max};
+  if (precision == kFmtF16x2) {
+    if (!absmax || !a2max) { set_error("svs_sdf_bwd_b: fp16x2 needs absmax and a2max"); return SVS_EINVAL; }
+    return launch_sdf_bwd_b_h2(a, (hipStream_t)hip_stream);
+  }
+  if (precision != kFmtF32) { set_error("svs_sdf_bwd_b: unknown precision %d", precision); return SVS_EINVAL; }
   static int once = set_lds_b(sdf_bwd_b_kernel, kLdsBytes, "svs_sdf_bwd_b");
   if (once) return once;
   sdf_bwd_b_kernel<<<(n_points + kWgPts - 1) / kWgPts, kThreads, kLdsBytes, (hipStream_t)hip_stream>>>(a);

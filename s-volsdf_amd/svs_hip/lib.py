@@ -38,9 +38,10 @@ SIGNATURES = {
     "svs_block_bytes": (c_size_t, [c_int, c_int]),
     "svs_rgb_zbuf_bytes": (c_size_t, [c_int]),
     "svs_sdf_ubuf_bytes": (c_size_t, [c_int]),
-    "svs_rgb_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "svs_sdf_bwd_a": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "svs_sdf_bwd_b": (c_int, [c_int, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "svs_rgb_bwd": (c_int, [c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P]),
+    "svs_sdf_bwd_a": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P, _P, _P,
+                              _P, _P, _P]),
+    "svs_sdf_bwd_b": (c_int, [c_int, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P]),
     "svs_lin8_row0_grad": (c_int, [_P, _P, _P, c_int, _P, _P]),
     "svs_unpack_wgrad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "svs_sampler_ctl_bytes": (c_size_t, []),
@@ -53,8 +54,8 @@ SIGNATURES = {
     "svs_composite": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P]),
     "svs_composite_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
     "svs_wgrad": (c_int, [_P, _P, _P, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, _P, _P, _P,
-                          ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, _P, ctypes.c_longlong, c_int, _P, c_int,
-                          _P, _P]),
+                          ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, _P, ctypes.c_longlong, c_int, c_int, _P,
+                          _P, c_int, _P, _P]),
     "svs_adam_workspace_bytes": (c_size_t, []),
     "svs_clip_guard_adam": (c_int, [_P, _P, _P, _P, ctypes.c_longlong, c_int, c_float, c_float, c_float, c_float, c_float,
                                     _P, _P, _P]),

@@ -15,7 +15,7 @@ import ctypes
 import torch
 
 from . import lib as _lib
-from .ops import _f32, _ptr, _ptr_array, _stream
+from .ops import _f32, _ptr, _ptr_array, _stream, default_precision, F16X2
 
 KBLOCK = 128 * 64           # floats per wave-tile activation block
 RBUF = 4 * KBLOCK + 1024    # radiance forward activations per tile
@@ -28,8 +28,9 @@ def _off(t, n_floats):
 
 
 class TrainStreams:
-    def __init__(self, device):
+    def __init__(self, device, precision=None):
         L = _lib.load()
+        self.precision = default_precision() if precision is None else int(precision)
         self.sdf = torch.empty(L.svs_stream_bytes(2) // 4, device=device)
         self.rgb = torch.empty(L.svs_stream_bytes(4) // 4, device=device)
         self.ws = torch.empty(L.svs_pack_workspace_bytes() // 4, device=device)
@@ -40,9 +41,9 @@ class TrainStreams:
         rv, rg, rb = [[_f32(t) for t in x] if x is not None else None for x in rgb_params]
         self._keep = (sv, sg, sb, rv, rg, rb)
         st = _stream()
-        _lib.check(L.svs_pack_stream(2, 0, _ptr_array(sv), _ptr_array(sg) if sg else None, _ptr_array(sb), _ptr(self.ws),
+        _lib.check(L.svs_pack_stream(2, self.precision, _ptr_array(sv), _ptr_array(sg) if sg else None, _ptr_array(sb), _ptr(self.ws),
                                      _ptr(self.sdf), st), "svs_pack_stream(sdf train)")
-        _lib.check(L.svs_pack_stream(4, 0, _ptr_array(rv), _ptr_array(rg) if rg else None, _ptr_array(rb), _ptr(self.ws),
+        _lib.check(L.svs_pack_stream(4, self.precision, _ptr_array(rv), _ptr_array(rg) if rg else None, _ptr_array(rb), _ptr(self.ws),
                                      _ptr(self.rgb), st), "svs_pack_stream(rgb bwd)")
 
 
@@ -51,9 +52,12 @@ class WGradAccum:
         self.dWk = torch.zeros(14, 256, LDW, device=device)
         self.dbk = torch.zeros(14, 256, device=device)
         self.row0 = torch.zeros(257, device=device)
+        # fp16x2: maxima of the gradient-like GEMM operands, published by the sweeps: [0] SDF abar / u,
+        # [1] radiance zbar, [2] feature-vector gradient
+        self.absmax = torch.zeros(4, device=device)
 
     def zero(self):
-        self.dWk.zero_(); self.dbk.zero_(); self.row0.zero_()
+        self.dWk.zero_(); self.dbk.zero_(); self.row0.zero_(); self.absmax.zero_()
 
 
 def finalize(accum, sdf_params, rgb_params, out=None):
@@ -110,6 +114,7 @@ class MlpBackward:
         self.abuf = z(L.svs_block_bytes(n_total, 8))
         self.pebuf = z(L.svs_block_bytes(n_total, 1))
         self.sbar = z(L.svs_block_bytes(n_total, 1) // (128 * 2))  # 32 floats per tile
+        self.a2max = z(L.svs_block_bytes(n_total, 1) // (128 * 2))
         self._n = (n_total, n_main)
 
     def accumulate(self, keep, d_rgb, d_sdf, d_grad_extra):
@@ -129,15 +134,20 @@ class MlpBackward:
         hbuf, gbuf, mask = keep["hbuf"], keep["gbuf"], keep["clamp_mask"]
         rbuf, feat = keep["rbuf"], keep["feat_tiles"]
 
-        def wgrad(slot, n_pts, a0, sa0, b0, sb0, a1=None, a1h=None, sa1=0, sh1=0, b1=None, sb1=0, extra=None, sx=0):
-            _lib.check(L.svs_wgrad(a0, None, b0, sa0, 0, sb0, a1, a1h, b1, sa1, sh1, sb1, extra, sx, n_pts,
+        prec = S.precision
+        h2 = prec == F16X2
+
+        def wgrad(slot, n_pts, amax, a0, sa0, b0, sb0, a1=None, a1h=None, sa1=0, sh1=0, b1=None, sb1=0, extra=None, sx=0):
+            _lib.check(L.svs_wgrad(a0, None, b0, sa0, 0, sb0, a1, a1h, b1, sa1, sh1, sb1, extra, sx, n_pts, prec,
+                                   _off(acc.absmax, amax) if h2 else None,
                                    _off(acc.dWk, slot * 256 * LDW), LDW, _off(acc.dbk, slot * 256), _stream()), "svs_wgrad")
 
         # ---- radiance MLP: input gradients
         d_rgb = _f32(d_rgb)
         d_normals = torch.empty(n_main, 3, device=dev)
-        _lib.check(L.svs_rgb_bwd(n_main, _ptr(d_rgb), _ptr(keep["rgb"]), _ptr(rbuf), _ptr(S.rgb), _ptr(self.zbuf),
-                                 _ptr(self.feat_bar), _ptr(d_normals), _stream()), "svs_rgb_bwd")
+        _lib.check(L.svs_rgb_bwd(n_main, _ptr(d_rgb), _ptr(keep["rgb"]), _ptr(rbuf), _ptr(S.rgb), prec, _ptr(self.zbuf),
+                                 _ptr(self.feat_bar), _ptr(d_normals), _ptr(acc.absmax) if h2 else None, _stream()),
+                   "svs_rgb_bwd")
         d_grad = d_normals if d_grad_extra is None else torch.cat([d_normals, _f32(d_grad_extra)], 0)
         if d_grad.shape[0] != n_total:
             raise ValueError("d_grad_extra must cover the points that follow the ray samples")
@@ -152,28 +162,30 @@ class MlpBackward:
         fork = torch.cuda.Event(); fork.record(main)
         with torch.cuda.stream(self._side):
             self._side.wait_event(fork)
-            wgrad(9, n_main, _off(self.zbuf, 0), 5 * KBLOCK, _ptr(feat), KBLOCK, extra=_off(rbuf, 4 * KBLOCK), sx=RBUF)
+            wgrad(9, n_main, 1, _off(self.zbuf, 0), 5 * KBLOCK, _ptr(feat), KBLOCK, extra=_off(rbuf, 4 * KBLOCK), sx=RBUF)
             for l in range(1, 5):
-                wgrad(9 + l, n_main, _off(self.zbuf, l * KBLOCK), 5 * KBLOCK, _off(rbuf, (l - 1) * KBLOCK), RBUF)
+                wgrad(9 + l, n_main, 1, _off(self.zbuf, l * KBLOCK), 5 * KBLOCK, _off(rbuf, (l - 1) * KBLOCK), RBUF)
             join = torch.cuda.Event(); join.record(self._side)
         # ---- SDF MLP: pass A (needs nbar), pass B (needs sbar, fbar), then its weight gradients
         st = _stream()
-        _lib.check(L.svs_sdf_bwd_a(*src.args(), _ptr(d_grad), _ptr(mask), _ptr(hbuf), _ptr(gbuf), _ptr(S.sdf),
-                                   _ptr(self.ubuf), _ptr(self.a2buf), _ptr(self.pebuf), st), "svs_sdf_bwd_a")
+        _lib.check(L.svs_sdf_bwd_a(*src.args(), _ptr(d_grad), _ptr(mask), _ptr(hbuf), _ptr(gbuf), _ptr(S.sdf), prec,
+                                   _ptr(self.ubuf), _ptr(self.a2buf), _ptr(self.pebuf),
+                                   _ptr(acc.absmax) if h2 else None, _ptr(self.a2max) if h2 else None, st), "svs_sdf_bwd_a")
         _lib.check(L.svs_sdf_bwd_b(n_total, _ptr(d_sdf_full), _ptr(mask), _ptr(self.feat_bar), n_main, _ptr(hbuf),
-                                   _ptr(gbuf), _ptr(self.a2buf), _ptr(S.sdf), _ptr(self.abuf), _ptr(self.sbar), st),
+                                   _ptr(gbuf), _ptr(self.a2buf), _ptr(S.sdf), prec, _ptr(self.abuf), _ptr(self.sbar),
+                                   _ptr(acc.absmax) if h2 else None, _ptr(self.a2max) if h2 else None, st),
                    "svs_sdf_bwd_b")
         _lib.check(L.svs_lin8_row0_grad(_ptr(hbuf), _ptr(self.ubuf), _ptr(self.sbar), n_total, _ptr(acc.row0), st),
                    "svs_lin8_row0_grad")
         ev = self.timer_events = ([torch.cuda.Event(enable_timing=True) for _ in range(2)] if self.time_wgrad else None)
         if ev:
             ev[0].record()
-        wgrad(0, n_total, _off(self.abuf, 0), A8, _ptr(self.pebuf), KBLOCK,
+        wgrad(0, n_total, 0, _off(self.abuf, 0), A8, _ptr(self.pebuf), KBLOCK,
               _off(gbuf, 0), _off(hbuf, 0), H8, H8, _off(self.ubuf, 0), U9)
         for l in range(1, 8):
-            wgrad(l, n_total, _off(self.abuf, l * KBLOCK), A8, _off(hbuf, (l - 1) * KBLOCK), H8,
+            wgrad(l, n_total, 0, _off(self.abuf, l * KBLOCK), A8, _off(hbuf, (l - 1) * KBLOCK), H8,
                   _off(gbuf, l * KBLOCK), _off(hbuf, l * KBLOCK), H8, H8, _off(self.ubuf, l * KBLOCK), U9)
-        wgrad(8, n_main, _ptr(self.feat_bar), KBLOCK, _off(hbuf, 7 * KBLOCK), H8)
+        wgrad(8, n_main, 2, _ptr(self.feat_bar), KBLOCK, _off(hbuf, 7 * KBLOCK), H8)
         if ev:
             ev[1].record()
         main.wait_event(join)

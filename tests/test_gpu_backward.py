@@ -60,23 +60,30 @@ def test_composite_backward(dev, ops, beta):
     assert abs(float(d_beta) - float(tb.grad)) / abs(float(tb.grad)) < 2e-5
 
 
+@pytest.mark.parametrize("precision,gscale", [(0, 1.0), (1, 1.0), (1, 3e-9), (1, 7e4)])
 @pytest.mark.parametrize("P", [32, 1000, 5000])
-def test_wgrad_gemm(dev, P):
-    """dW = A B^T over points, with the optional softplus' factor and the second operand pair."""
+def test_wgrad_gemm(dev, P, precision, gscale):
+    """dW = A B^T over points, with the optional softplus' factor and the second operand pair.  fp16x2: the
+    gradient-like operands (A of pair 0, B of pair 1) at magnitudes far outside fp16's range."""
     import ctypes
     from svs_hip import lib
     L = lib.load()
     rng = np.random.default_rng(P)
-    A0, B0 = rng.normal(0, 1, (P, 256)).astype(F32), rng.normal(0, 1, (P, 256)).astype(F32)
-    A1, B1 = rng.normal(0, 1, (P, 256)).astype(F32), rng.normal(0, 1, (P, 256)).astype(F32)
+    A0, B0 = (gscale * rng.normal(0, 1, (P, 256))).astype(F32), rng.normal(0, 1, (P, 256)).astype(F32)
+    A1, B1 = rng.normal(0, 1, (P, 256)).astype(F32), (gscale * rng.normal(0, 1, (P, 256))).astype(F32)
+    # a heavy tail: a few points carry gradients 1000x the typical ones
+    A0[:: 97] *= 1000.0
+    B1[:: 89] *= 1000.0
     H1 = rng.uniform(0, 0.05, (P, 256)).astype(F32)
+    absmax = torch.tensor([max(np.abs(A0).max(), np.abs(B1).max())], dtype=torch.float32, device=dev)
     ta0, tb0, ta1, tb1, th1 = (G(synth.rows_to_tiles(x), dev) for x in (A0, B0, A1, B1, H1))
     dW = torch.zeros(256, 256, device=dev)
     db = torch.zeros(256, device=dev)
     ptr = lambda t: ctypes.c_void_p(t.data_ptr())
     st = 128 * 64
     lib.check(L.svs_wgrad(ptr(ta0), None, ptr(tb0), st, 0, st, ptr(ta1), ptr(th1), ptr(tb1), st, st, st, None, 0, P,
-                          ptr(dW), 256, ptr(db), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+                          precision, ptr(absmax) if precision else None, ptr(dW), 256, ptr(db),
+                          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
     ref = A0.astype(np.float64).T @ B0 + (A1 * (1 - np.exp(-100.0 * H1.astype(np.float64)))).T @ B1
     assert rel_err(dW.cpu().numpy(), ref) < 2e-5
     assert rel_err(db.cpu().numpy(), A0.astype(np.float64).sum(0)) < 2e-5

@@ -66,30 +66,35 @@ def main():
     P = lambda x: ctypes.c_void_p(x.data_ptr())
     st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     dn = torch.empty(n_main, 3, device=dev)
-    t = timeit(lambda: lib.check(L.svs_rgb_bwd(n_main, P(d_rgb), P(keep["rgb"]), P(keep["rbuf"]), P(bw.rgb_stream), P(bw.zbuf),
-                                               P(bw.feat_bar), P(dn), st())))
+    prec = bw.streams.precision
+    h2 = prec == 1
+    am = bw.accum.absmax
+    N = lambda x: P(x) if h2 else None
+    t = timeit(lambda: lib.check(L.svs_rgb_bwd(n_main, P(d_rgb), P(keep["rgb"]), P(keep["rbuf"]), P(bw.streams.rgb), prec,
+                                               P(bw.zbuf), P(bw.feat_bar), P(dn), N(am), st())))
     res["rgb_bwd"] = dict(ms=t, tflops=n_main * F_RGB / t / 1e9)
     d_grad = torch.cat([dn, d_gt], 0)
     hbuf, gbuf, mask = keep["hbuf"], keep["gbuf"], keep["clamp_mask"]
-    t = timeit(lambda: lib.check(L.svs_sdf_bwd_a(*src.args(), P(d_grad), P(mask), P(hbuf), P(gbuf), P(bw.sdf_stream), P(bw.ubuf),
-                                                 P(bw.a2buf), P(bw.pebuf), st())))
-    res["sdf_bwd_a"] = dict(ms=t, tflops=n_total * 0.9 * F_SDF / t / 1e9)
     dsf = torch.zeros(n_total, device=dev)
+    row0 = torch.zeros(257, device=dev)
+    t = timeit(lambda: lib.check(L.svs_sdf_bwd_a(*src.args(), P(d_grad), P(mask), P(hbuf), P(gbuf), P(bw.streams.sdf), prec,
+                                                 P(bw.ubuf), P(bw.a2buf), P(bw.pebuf), N(am), N(bw.a2max), st())))
+    res["sdf_bwd_a"] = dict(ms=t, tflops=n_total * 0.9 * F_SDF / t / 1e9)
     t = timeit(lambda: lib.check(L.svs_sdf_bwd_b(n_total, P(dsf), P(mask), P(bw.feat_bar), n_main, P(hbuf), P(gbuf), P(bw.a2buf),
-                                                 P(bw.sdf_stream), P(bw.abuf), P(bw.sbar), st())))
+                                                 P(bw.streams.sdf), prec, P(bw.abuf), P(bw.sbar), N(am), N(bw.a2max), st())))
     res["sdf_bwd_b"] = dict(ms=t, tflops=n_total * F_SDF / t / 1e9)
     H8, U9, A8 = 8 * KBLOCK, 9 * KBLOCK, 8 * KBLOCK
     dW = torch.zeros(256, 288, device=dev); db = torch.zeros(256, device=dev)
     l = 2
     t = timeit(lambda: lib.check(L.svs_wgrad(_off(bw.abuf, l * KBLOCK), None, _off(hbuf, (l - 1) * KBLOCK), A8, 0, H8,
                                              _off(gbuf, l * KBLOCK), _off(hbuf, l * KBLOCK), _off(bw.ubuf, l * KBLOCK), H8, H8, U9,
-                                             None, 0, n_total, P(dW), 288, P(db), st())))
+                                             None, 0, n_total, prec, N(am), P(dW), 288, P(db), st())))
     res["wgrad_2pair"] = dict(ms=t, tflops=2 * 2 * 256 * 256 * n_total / t / 1e9)
     t = timeit(lambda: lib.check(L.svs_wgrad(P(bw.feat_bar), None, _off(hbuf, 7 * KBLOCK), KBLOCK, 0, H8, None, None, None, 0, 0, 0,
-                                             None, 0, n_main, P(dW), 288, P(db), st())))
+                                             None, 0, n_main, prec, _off(am, 2) if h2 else None, P(dW), 288, P(db), st())))
     res["wgrad_1pair"] = dict(ms=t, tflops=2 * 256 * 256 * n_main / t / 1e9)
-    row0 = torch.zeros(257, device=dev)
-    res["lin8_row0"] = dict(ms=timeit(lambda: lib.check(L.svs_lin8_row0_grad(P(hbuf), P(bw.ubuf), P(bw.sbar), n_total, P(row0), st()))))
+    if True:
+        res["lin8_row0"] = dict(ms=timeit(lambda: lib.check(L.svs_lin8_row0_grad(P(hbuf), P(bw.ubuf), P(bw.sbar), n_total, P(row0), st()))))
     print(json.dumps({k: {a: round(b, 3) for a, b in v.items()} for k, v in res.items()}))
 
 
