@@ -65,7 +65,7 @@ int svs_sdf_vals(const float* points, int n_points, const float* cam, int cam_st
 /* svs_sdf_outputs: ImplicitNetwork.get_outputs (network.py:105-123) and .gradient (:90-103):
  *   sdf (P), grad = d sdf/dx (P,3), feat_tiles (svs_feat_tiles_bytes; wave-tile layout, may be NULL),
  *   hbuf (svs_sdf_hbuf_bytes): the activations h_1..h_8 kept for the gradient pass / training backward;
- *   gbuf (same size, may be NULL): g(h_1)..g(h_8) of the gradient pass; clamp_mask (P bytes, may be NULL): 1 where
+ *   gbuf (same size, may be NULL): ghat_l = g(h_{l+1}) * softplus'(a_l), l = 0..7, of the gradient pass; clamp_mask (P bytes, may be NULL): 1 where
  *   the sphere clamp is active -- both are only needed by the training backward. */
 size_t svs_sdf_hbuf_bytes(int n_points_total);
 size_t svs_feat_tiles_bytes(int n_points_total);
@@ -126,16 +126,28 @@ int svs_composite_bwd(int n_rays, int n_samples, const float* z, const float* sd
 
 /* ---- a12  weight-gradient contraction of the training backward ---------------------------------------------------
  * dW[256][ldw] += sum over points of A(:,p) B(:,p)^T for one or two operand pairs stored as wave-tile activation
- * blocks (128*64 floats per 32 points; s* = floats between consecutive blocks).  a*_h (optional): A is multiplied
- * by softplus'(.) = 1 - exp(-100 h) of that block.  b_extra: optional 16 extra B rows per block (dW columns
+ * blocks (128*64 floats per 32 points; s* = floats between consecutive blocks).  b_extra: optional 16 extra B rows
+ * per block (dW columns
  * 256..271, ldw >= 272: the radiance MLP's first layer).  db[256] += row sums of pair 0's A (bias gradient).
  * dW / db are accumulated with float atomics: the caller zeroes them.
  * precision SVS_MMA_F16X2: the gradient-like operands (A of pair 0, B of pair 1) are scaled by a power of two derived
  * from *absmax (device float: their maximum magnitude, published by the fp16x2 sweeps below; NULL = no scaling). */
-int svs_wgrad(const float* a0, const float* a0_h, const float* b0, long long sa0, long long sh0, long long sb0,
-              const float* a1, const float* a1_h, const float* b1, long long sa1, long long sh1, long long sb1,
-              const float* b_extra, long long s_extra, int n_points, int precision, const float* absmax, float* dW,
-              int ldw, float* db, void* hip_stream);
+typedef struct svs_wgrad_job {
+  const float *a0, *b0; long long sa0, sb0;   /* pair 0 */
+  const float *a1, *b1; long long sa1, sb1;   /* pair 1, a1 == NULL: one pair */
+  const float* b_extra; long long s_extra;    /* optional 16 extra B rows of pair 0 (1024 floats per tile) */
+  int n_points, ldw;
+  float *dW, *db;                             /* db may be NULL */
+  const float* absmax;                        /* fp16x2 scaling, may be NULL */
+} svs_wgrad_job;
+/* The weight gradients of several layers (<= 20 jobs, one with b_extra counts twice) in one call.  SVS_MMA_F16X2: ONE
+ * launch, ~one workgroup per CU in total, split between the jobs in proportion to their work (so each layer flushes
+ * ~256/n_jobs partial sums instead of 256); SVS_MMA_F32: one launch per job. */
+int svs_wgrad_multi(const svs_wgrad_job* jobs, int n_jobs, int precision, void* hip_stream);
+/* single job */
+int svs_wgrad(const float* a0, const float* b0, long long sa0, long long sb0, const float* a1, const float* b1,
+              long long sa1, long long sb1, const float* b_extra, long long s_extra, int n_points, int precision,
+              const float* absmax, float* dW, int ldw, float* db, void* hip_stream);
 
 /* ---- a12  training backward of the fused MLPs (hand-written reverse mode; the reference uses torch.autograd,
  * loss.backward() at volsdf/vsdf.py:215, incl. the double backward through network.py:115-121) -------------------

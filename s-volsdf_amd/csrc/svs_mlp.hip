@@ -91,7 +91,6 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_kernel(SdfFullArgs a) {
   }
   st.advance();
   float* gb = a.gbuf ? a.gbuf + (size_t)wtile * 8 * kBlockF : nullptr;
-  if (gb) store_tile_regs(gb + 7 * (size_t)kBlockF, y, lane);       // g(h_8) = W8[0,:]
   // ---- feature vector = rows 1..256 of lin8
   float* ft = a.feat_tiles ? a.feat_tiles + (size_t)wtile * 128 * 64 : nullptr;
   {
@@ -108,6 +107,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_kernel(SdfFullArgs a) {
   // g(a_7) = g(h_8) * softplus'(a_7), h_8 still in x
 #pragma unroll
   for (int i = 0; i < 128; ++i) y[i / 16][i % 16] *= dsoftplus_from_h(x[i / 16][i % 16]);
+  if (gb) store_tile_regs(gb + 7 * (size_t)kBlockF, y, lane);       // ghat_7 = W8[0,:] * softplus'(a_7)
 
   // ---- reverse layers 7..1
   f32x16 skip7;          // g(PE[0..31]) from the skip connection (tile 7 of g(h_4 spliced))
@@ -118,17 +118,17 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_kernel(SdfFullArgs a) {
     f32x16 pend;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      if (gblk && t > 0) store_tile(gblk, t - 1, lane, pend);   // g(h_l) tile t-1, deferred store
+      if (gblk && t > 0) store_tile(gblk, t - 1, lane, pend);   // ghat_{l-1} tile t-1, deferred store
       const f32x16 h = load_tile(hblk, t, lane);   // issued before the MFMAs: arrives while they run
       st.prefetch<kChunkF4>();                     // next reverse chunk (the last one prefetches REV0 tile 0)
       const f32x16 acc = tile_mma<128>(st.cur_buf(), y, lane);   // g(h_l) rows 32t..32t+31
       __builtin_amdgcn_sched_barrier(0);   // keep the epilogue (and its vmcnt wait) behind the MFMAs
-      pend = acc;
       if (l == 4 && t == 7) skip7 = acc;
       if (l == 4 && t == 6) skip6 = acc;
       // g(a_{l-1}) = g(h_l) * softplus'(a_{l-1}),  softplus' from the stored h_l
 #pragma unroll
       for (int i = 0; i < 16; ++i) x[t][i] = acc[i] * dsoftplus_from_h(h[i]);
+      pend = x[t];
       st.advance();
     }
     if (gblk) store_tile(gblk, 7, lane, pend);

@@ -22,7 +22,8 @@ struct SdfFullArgs {
   float* grad;           // (P,3)
   float* feat_tiles;     // [wave tiles][128*64] or nullptr
   float* hbuf;           // [wave tiles][8][128*64] activations h_1..h_8
-  float* gbuf;           // optional [wave tiles][8][128*64]: g(h_{l+1}) of the gradient pass, l = 0..7 (training)
+  float* gbuf;           // optional [wave tiles][8][128*64]: ghat_l = g(h_{l+1}) * softplus'(a_l) of the gradient pass,
+                         // l = 0..7 (training; rows >= 217 of block 3 are not meaningful)
   unsigned char* clamp_mask;  // optional (P): 1 where the sphere term of the clamp is active (training)
   float sphere_radius;   // > 0: min(sdf, scale*(R-|x|)) inside the differentiated graph (network.py:110-112)
   float sphere_scale;

@@ -9,7 +9,7 @@
 // gradient pass: g(h_8) = W_8[0,:], ghat_l = g(h_{l+1}) * s'(a_l), g(h_l) = W_l^T ghat_l, n = J_PE^T g(h_0).
 // Given sbar = dL/dsdf, fbar = dL/dfeat, nbar = dL/dn:
 //   pass A (bottom-up, "second-order sweep"):  u_0 = J_PE nbar;  v_l = W_l u_l;  u_{l+1} = v_l * s'(a_l);
-//                                              a2_l = v_l * g(h_{l+1}) * s''(a_l)
+//                                              a2_l = v_l * g(h_{l+1}) * s''(a_l) = v_l * ghat_l * 100 (1 - s'(a_l))
 //   pass B (top-down, ordinary backprop):      hbar_8 = sbar W_8[0,:] + W_8[1:,:]^T fbar;
 //                                              abar_l = hbar_{l+1} * s'(a_l) + a2_l;  hbar_l = W_l^T abar_l
 //   weights (svs_wgrad):                       dW_l = abar_l h_l^T + ghat_l u_l^T,  db_l = sum abar_l
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_kernel(SdfBwdAArgs a) {
     for (int i = 0; i < 16; ++i) {
       const float s1 = dsoftplus_from_h(h[i]);
       u_next[i] = v[i] * s1;
-      a2v[i] = v[i] * g[i] * (100.0f * s1 * (1.0f - s1));
+      a2v[i] = v[i] * g[i] * (100.0f * (1.0f - s1));      // g = ghat = g(h_{l+1}) s', and s'' = 100 s' (1 - s')
     }
     if (l == 3 && t == 6) zero_splice_rows_tile6(a2v, half);
   };
@@ -251,8 +251,8 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_kernel(SdfBwdBArgs a) {
     for (int t = 0; t < 8; ++t) y[t] = (f32x16)(0.0f);
   }
   st.advance();
-  // hbar_8 = W8[1:,:]^T fbar + sbar * W8[0,:]   (W8[0,:] in accumulator layout = gbuf block 7), fused with
-  // abar_7 = hbar_8 * s'(a_7) + a2_7; the tiles of h_8 / a2_7 / W8[0,:] are requested before the MFMAs of the tile
+  // hbar_8 = W8[1:,:]^T fbar + sbar * W8[0,:], fused with abar_7 = hbar_8 * s'(a_7) + a2_7 (gbuf block 7 holds
+  // ghat_7 = W8[0,:] * s'(a_7)); the tiles of h_8 / a2_7 / ghat_7 are requested before the MFMAs of the tile
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     if (t > 0) store_tile(ab + 7 * (size_t)kBlockF, t - 1, lane, x[t - 1]);    // deferred store
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_kernel(SdfBwdBArgs a) {
     const f32x16 acc = tile_mma<128>(st.cur_buf(), y, lane);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) x[t][i] = (acc[i] + sbar * w0[i]) * dsoftplus_from_h(h[i]) + s2[i];
+    for (int i = 0; i < 16; ++i) x[t][i] = acc[i] * dsoftplus_from_h(h[i]) + sbar * w0[i] + s2[i];
     st.advance();
   }
   store_tile(ab + 7 * (size_t)kBlockF, 7, lane, x[7]);
@@ -289,44 +289,51 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_kernel(SdfBwdBArgs a) {
   }
 }
 
-// d loss / d W_8[0,:] = sum_p (sbar_p h_8[:,p] + u_8[:,p]);  d loss / d b_8[0] = sum_p sbar_p.   One wave per tile
-// range, float atomics into out[257] (index 256 = the bias).
+// d loss / d W_8[0,:] = sum_p (sbar_p h_8[:,p] + u_8[:,p]);  d loss / d b_8[0] = sum_p sbar_p.
+// HBM-bound (two activation blocks per tile are read once).  A wave owns a quarter of the 256 rows (8 float4 per lane
+// and block) and grid-strides over the tiles, with the 16 loads of a tile in flight together; the sum over the 32
+// points of a lane half goes through LDS once per workgroup, then float atomics into out[257] (index 256 = bias).
 __global__ __launch_bounds__(256) void lin8_row0_kernel(const float* __restrict__ hbuf, const float* __restrict__ ubuf,
                                                         const float* __restrict__ sbar, int n_tiles, int P,
                                                         float* __restrict__ out) {
-  const int lane = threadIdx.x & 63, wave_global = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
-  float acc[128];
+  __shared__ float red[4][32][65];
+  const int lane = threadIdx.x & 63, quarter = threadIdx.x >> 6;
+  float acc[32];
 #pragma unroll
-  for (int i = 0; i < 128; ++i) acc[i] = 0.0f;
+  for (int i = 0; i < 32; ++i) acc[i] = 0.0f;
   float bsum = 0.0f;
-  for (int t = wave_global; t < n_tiles; t += n_waves) {
+  for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
     const int p = t * 32 + (lane & 31);
     const float sb = p < P ? sbar[p] : 0.0f;
     const float live = p < P ? 1.0f : 0.0f;
-    const f32x4* h = reinterpret_cast<const f32x4*>(hbuf + ((size_t)t * 8 + 7) * kBlockF) + lane;
-    const f32x4* u = reinterpret_cast<const f32x4*>(ubuf + ((size_t)t * 9 + 8) * kBlockF) + lane;
+    const f32x4* h = reinterpret_cast<const f32x4*>(hbuf + ((size_t)t * 8 + 7) * kBlockF) + quarter * 8 * 64 + lane;
+    const f32x4* u = reinterpret_cast<const f32x4*>(ubuf + ((size_t)t * 9 + 8) * kBlockF) + quarter * 8 * 64 + lane;
+    f32x4 hv[8], uv[8];
 #pragma unroll
-    for (int i4 = 0; i4 < 32; ++i4) {
-      const f32x4 hv = h[i4 * 64], uv = u[i4 * 64];
+    for (int i4 = 0; i4 < 8; ++i4) { hv[i4] = h[i4 * 64]; uv[i4] = u[i4 * 64]; }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[4 * i4 + j] += sb * hv[j] + live * uv[j];
-    }
-    if (lane < 32) bsum += sb;
-  }
-  // reduce over the 32 points of each half, then one atomic per row
+    for (int i4 = 0; i4 < 8; ++i4)
 #pragma unroll
-  for (int i = 0; i < 128; ++i) {
-    float v = acc[i];
-#pragma unroll
-    for (int d = 16; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-    if ((lane & 31) == 0) {
-      const int row = 32 * (i / 16) + rho(i % 16) + 4 * (lane >> 5);
-      atomicAdd(&out[row], v);
-    }
+      for (int j = 0; j < 4; ++j) acc[4 * i4 + j] += sb * hv[i4][j] + live * uv[i4][j];
+    if (quarter == 0 && lane < 32) bsum += sb;
   }
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) bsum += __shfl_xor(bsum, d);
-  if (lane == 0) atomicAdd(&out[256], bsum);
+  for (int i = 0; i < 32; ++i) red[quarter][i][lane] = acc[i];
+  __syncthreads();
+  // thread -> (quarter, register i, half): sum its 32 points
+  {
+    const int q = threadIdx.x >> 6, i = (threadIdx.x >> 1) & 31, hf = threadIdx.x & 1;
+    float v = 0.0f;
+#pragma unroll 8
+    for (int c = 0; c < 32; ++c) v += red[q][i][32 * hf + c];
+    const int ii = 32 * q + i;                       // accumulator register index 0..127 of the block
+    atomicAdd(&out[32 * (ii / 16) + rho(ii % 16) + 4 * hf], v);
+  }
+  if (quarter == 0) {
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) bsum += __shfl_xor(bsum, d);
+    if (lane == 0) atomicAdd(&out[256], bsum);
+  }
 }
 
 // ==============================================================================================================
@@ -469,7 +476,7 @@ int svs_lin8_row0_grad(const float* hbuf, const float* ubuf, const float* sbar, 
                        void* hip_stream) {
   if (!hbuf || !ubuf || !sbar || !out257 || n_points <= 0) { set_error("svs_lin8_row0_grad: bad argument"); return SVS_EINVAL; }
   const int n_tiles = (n_points + 31) / 32;
-  const int grid = n_tiles < 4 * 256 ? (n_tiles + 3) / 4 : 256;
+  const int grid = n_tiles < 1024 ? n_tiles : 1024;
   lin8_row0_kernel<<<grid, 256, 0, (hipStream_t)hip_stream>>>(hbuf, ubuf, sbar, n_tiles, n_points, out257);
   return check_launch("svs_lin8_row0_grad");
 }

@@ -23,7 +23,7 @@ struct SdfBwdAArgs {
   const float* d_grad;        // (P,3) nbar = d loss / d (d sdf/dx)
   const unsigned char* clamp_mask;  // (P) or nullptr: clamped points contribute no nbar
   const float* hbuf;          // [wave tiles][8][kBlockF] forward activations
-  const float* gbuf;          // [wave tiles][8][kBlockF] g(h_{l+1})
+  const float* gbuf;          // [wave tiles][8][kBlockF] ghat_l = g(h_{l+1}) * s'(a_l) (svs_sdf_outputs)
   const f32x4* stream;        // SDF training stream (pass A part at offset 0)
   float* ubuf;                // out [wave tiles][9][kBlockF]: block 0 = u_0 (PE order, first 2 tiles), blocks 1..8 = u_1..u_8
   float* a2buf;               // out [wave tiles][8][kBlockF]

@@ -225,7 +225,7 @@ struct PassAEpi {
   }
   __device__ __forceinline__ void b(int tp, int r) {
     float u = v * s1;
-    float a2 = v * g[r] * (100.0f * s1 * (1.0f - s1));
+    float a2 = v * g[r] * (100.0f * (1.0f - s1));     // g = ghat_l = g(h_{l+1}) s'(a_l); s'' = 100 s' (1 - s')
     if (tp == 6 && r >= 12 && l3) {
       // local rows 25..31 of tile 6 (registers 13..15 of half 0, 12..15 of half 1) carry u_0[32..38]
       const bool sp = half == 1 || r >= 13;
@@ -416,12 +416,12 @@ struct PassBEpi {
   bool l4;            // producing abar_3: rows >= 217 of h_4 are the PE splice
   __device__ __forceinline__ void a(int r) {
     v = prev[r] * ps->inv_in;
-    if (FIRST) v += sbar * w0[r];
     s1 = dsoftplus_from_h(h[r]);
     pin(v); pin(s1);
   }
   __device__ __forceinline__ void b(int tp, int r) {
     float o = v * s1 + a2[r];
+    if (FIRST) o += sbar * w0[r];      // w0 = ghat_7 = W8[0,:] s'(a_7)
     if (l4 && tp == 7) o = 0.0f;
     if (l4 && tp == 6) {
       const bool z0 = rho(r) >= 25, z1 = rho(r) + 4 >= 25;
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_h2_kernel(SdfBwdBArgs a
   }
   st.advance();
   {
-    // hbar_8 (W8[0,:] in accumulator layout = gbuf block 7) fused with abar_7
+    // hbar_8 fused with abar_7 (gbuf block 7 = ghat_7 = W8[0,:] s'(a_7) in accumulator layout)
     PassBEpi<true, true> ep;
     ep.out = &pb; ep.ablk = ab + 7 * (size_t)kBlockF; ep.ps = &ps; ep.sbar = sbar; ep.lane = lane; ep.half = half; ep.l4 = false;
     pass_b_stage_h2<true, true, false>(st, pa, ep, hb + 7 * (size_t)kBlockF, a2 + 7 * (size_t)kBlockF, gb + 7 * (size_t)kBlockF, lane);

@@ -156,15 +156,15 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_only_h2_kernel(SdfOnlyArgs a)
 // ImplicitNetwork.get_outputs (network.py:105-123): sdf, feature vector and d sdf / d x in one launch (see
 // sdf_full_kernel in svs_mlp.hip for the algebra of the gradient pass).
 // --------------------------------------------------------------------------------------------------------------
-// Epilogue of one tile of the gradient pass: g(h_l) tile -> gbuf (training), g(a_{l-1}) = g(h_l) * softplus'(a_{l-1})
-// (softplus' from the stored h_l tile `h`), split into the next operand.
+// Epilogue of one tile of the gradient pass: ghat_{l-1} = g(a_{l-1}) = g(h_l) * softplus'(a_{l-1}) (softplus' from the
+// stored h_l tile `h`) -> gbuf (training), split into the next operand.
 struct RevEpi {
   f32x16 prev, h;
   float d;            // softplus' of the current slice
   float v8[8];
   f32x4 q4;
   Pieces2* out;
-  float* gblk;        // g(h_l) block of gbuf or nullptr
+  float* gblk;        // ghat_{l-1} block of gbuf or nullptr
   int lane, half;
   bool l4;            // l == 4: rows >= 217 of h_4 are the PE splice, they do not flow into lin3
 
@@ -181,7 +181,7 @@ struct RevEpi {
     }
     pin(v);
     if (gblk) {
-      q4[r & 3] = prev[r];
+      q4[r & 3] = v;
       if ((r & 3) == 3) reinterpret_cast<f32x4*>(gblk)[(4 * tp + (r >> 2)) * 64 + lane] = q4;
     }
     v8[r & 7] = v;
@@ -256,10 +256,10 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_h2_kernel(SdfFullArgs a)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const f32x4 w = w_ptr[(4 * t + q) * 64];
-        if (gb) reinterpret_cast<f32x4*>(gb + 7 * (size_t)kBlockF)[(4 * t + q) * 64 + lane] = w;   // g(h_8) = W8[0,:]
 #pragma unroll
         for (int j = 0; j < 4; ++j) g[4 * q + j] = w[j] * dsoftplus_from_h(y8[t][4 * q + j]);
       }
+      if (gb) store_tile(gb + 7 * (size_t)kBlockF, t, lane, g);   // ghat_7 = W8[0,:] * softplus'(a_7)
       split_tile(g, t, xn);
       split_tile(y8[t], t, x);
     }

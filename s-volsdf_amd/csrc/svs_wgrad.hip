@@ -20,9 +20,8 @@ namespace wgrad {
 
 struct Pair {
   const float* a;        // blocks [n_tiles][stride_a]: A rows (gradients w.r.t. layer outputs)
-  const float* a_h;      // optional: A is multiplied by softplus'(.) = 1 - exp(-100 h) of this block (same layout)
   const float* b;        // blocks: B rows (layer inputs)
-  size_t stride_a, stride_h, stride_b;   // floats between consecutive point tiles
+  size_t stride_a, stride_b;   // floats between consecutive point tiles
 };
 
 struct Args {
@@ -37,13 +36,8 @@ struct Args {
   float* db;             // [256] row sums of A of pair 0 (bias gradient) or nullptr
 };
 
-__device__ __forceinline__ float dsoftplus_from_h(float h) {
-  return 1.0f - __builtin_amdgcn_exp2f(h * (-100.0f * 1.44269504088896341f));
-}
-
 struct Staging {
-  f32x4 a[8], b[8], h[8], x;
-  bool has_h;
+  f32x4 a[8], b[8], x;
 };
 
 template <int NTB>
@@ -72,12 +66,6 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(Args a) {
     const f32x4* gb = reinterpret_cast<const f32x4*>(p.b + (size_t)t * p.stride_b);
 #pragma unroll
     for (int k = 0; k < 8; ++k) { st.a[k] = ga[k * 256 + tid]; st.b[k] = gb[k * 256 + tid]; }
-    st.has_h = p.a_h != nullptr;
-    if (st.has_h) {       // the softplus' factor is applied at commit time, so that these loads stay in flight
-      const f32x4* gh = reinterpret_cast<const f32x4*>(p.a_h + (size_t)t * p.stride_h);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) st.h[k] = gh[k * 256 + tid];
-    }
     if (NTB == 9) {
       st.x = (a.b_extra && pi == 0) ? reinterpret_cast<const f32x4*>(a.b_extra + (size_t)t * a.stride_extra)[tid]
                                     : (f32x4)(0.0f);
@@ -87,13 +75,6 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(Args a) {
   auto commit = [&](int buf) {
     float* la = smem + buf * BUF;
     float* lb = la + 32 * PA;
-    if (st.has_h) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        st.a[k][0] *= dsoftplus_from_h(st.h[k][0]); st.a[k][1] *= dsoftplus_from_h(st.h[k][1]);
-        st.a[k][2] *= dsoftplus_from_h(st.h[k][2]); st.a[k][3] *= dsoftplus_from_h(st.h[k][3]);
-      }
-    }
     if (st_live < 32) {
       // ragged last tile: points beyond the batch contribute nothing
 #pragma unroll
@@ -182,7 +163,6 @@ constexpr int kSub = 32 * 256;         // bytes of one [32 points][128 features]
 constexpr int kPiece = 2 * kSub;       // 256 features
 constexpr int kOperand = 2 * kPiece;   // hi piece, mid piece
 constexpr int kExtraPiece = 32 * 64;   // 9th B tile: [32 points][32 features], 64-byte rows
-__host__ __device__ constexpr int buf_bytes(int ntb) { return 2 * kOperand + (ntb == 9 ? 2 * kExtraPiece : 0); }
 
 __device__ __forceinline__ f16x8 tr_frag(const unsigned char* lds, int a0, int a1) {
   struct Pair { s16x4 lo, hi; } v;
@@ -201,66 +181,91 @@ __device__ __forceinline__ void scale_from_absmax(const float* absmax, float& s,
   inv_s = __uint_as_float((unsigned)(e - 10) << 23);
 }
 
-template <int NTB, int dbg = 0>
-__global__ __launch_bounds__(256, 1) void wgrad_h2_kernel(Args a, const float* __restrict__ absmax) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_h2[];
-  constexpr int BUF = buf_bytes(NTB);
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  float s_grad, inv_s;
-  scale_from_absmax(absmax, s_grad, inv_s);
+// One launch covers a list of jobs (the weight gradients of several layers): each job gets a contiguous range of
+// workgroups, proportional to its work, which split its point tiles among themselves -- about one workgroup per CU
+// in total, so the number of partial sums flushed with atomics per layer is ~256 / n_jobs instead of 256.
+struct Job {
+  Pair p[2];
+  int n_pairs;
+  int n_tiles;           // point tiles (32 points each)
+  int n_valid_points;    // points beyond this index contribute nothing (ragged last tile)
+  int b_tiles;           // 8: B blocks are 256-row activation blocks; 1: B blocks are single 32-row tiles (1024 floats)
+  int col0;              // first dW column of B tile 0
+  float* dW;             // [256][ldw] accumulated with atomics (caller zeroes)
+  int ldw;
+  float* db;             // [256] row sums of A of pair 0 (bias gradient) or nullptr
+  const float* absmax;   // device float: max magnitude of the gradient-like operands, or nullptr (no scaling)
+  int wg_begin, wg_count;
+};
+constexpr int kMaxJobs = 20;
+struct MultiArgs { Job job[kMaxJobs]; int n_jobs; };
 
-  f32x16 acc[2][NTB];
-  f32x16 accb[2];
+constexpr int kThreadsW = 512;          // 8 waves: wave w owns output tile w (32 rows) x all B tiles
+constexpr int kBufBytes = 2 * kOperand; // A image + B image (the single-tile B image of a narrow job fits in it)
+
+// a wave-uniform global pointer, kept in scalar registers (global_load with an SGPR base + 32-bit lane offset)
+typedef const __attribute__((address_space(1))) f32x4* gptr_f4;
+__device__ __forceinline__ gptr_f4 uniform_f4(const float* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<gptr_f4>(((unsigned long long)hi << 32) | lo);
+}
+
+struct Staging4 {
+  f32x4 a[4], b[4];
+};
+
+__global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs ma) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_h2[];
+  int jj = 0;
+  for (int q = 1; q < ma.n_jobs; ++q) if ((int)blockIdx.x >= ma.job[q].wg_begin) jj = q;
+  const Job& a = ma.job[jj];
+  const int wg = (int)blockIdx.x - a.wg_begin, nwg = a.wg_count;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const bool narrow = a.b_tiles == 1;
+  float s_grad, inv_s;
+  scale_from_absmax(a.absmax, s_grad, inv_s);
+
+  f32x16 acc[8];
 #pragma unroll
-  for (int o = 0; o < 2; ++o) {
-    accb[o] = (f32x16)(0.0f);
-#pragma unroll
-    for (int i = 0; i < NTB; ++i) acc[o][i] = (f32x16)(0.0f);
-  }
+  for (int i = 0; i < 8; ++i) acc[i] = (f32x16)(0.0f);
+  float bsum = 0.0f;     // bias gradient: this lane's row (lane & 31 of the wave's output tile) over its half's points
 
   // ---- reader addresses (bytes inside an operand piece), see the layout notes above
   const int ri = lane & 15, rg = (lane >> 4) & 1, rh = lane >> 5, rq = ri >> 2, rp = ri & 3;
-  int rbase[2], rt[4], rx[2];
+  int rbase[2], rt[4], rx[2], aaddr[2];
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     rbase[e] = 256 * (8 * rh + 4 * e + rq) + 16 * ((2 * rg + (rp >> 1)) ^ ((2 * rh + e) & 3)) + 8 * (rp & 1);
     rx[e] = 64 * (8 * rh + 4 * e + rq) + 32 * rg + 8 * rp;
+    aaddr[e] = (wave >> 2) * kSub + rbase[e] + 64 * ((wave & 3) ^ rq);
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) rt[j] = 64 * (j ^ rq);
-  int aaddr[2][2];   // A operand: output tiles 2*wave, 2*wave+1
-#pragma unroll
-  for (int o = 0; o < 2; ++o) {
-    const int ft = 2 * wave + o;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) aaddr[o][e] = (ft >> 2) * kSub + rbase[e] + 64 * ((ft & 3) ^ rq);
-  }
-  // ---- writer addresses
+  // ---- writer addresses: float4 k*512 + tid of a block = registers of tile 2k + (wave>>2), quarter wave&3
   const int wp = lane & 31, whf = lane >> 5;
-  const int wbase = 256 * wp + 16 * (wave ^ ((wp >> 2) & 3)) + 8 * whf;
-  const int wxoff = 64 * wp + 16 * wave + 8 * whf;
+  int wbase[2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+    wbase[x] = 256 * wp + 64 * ((2 * x + (wave >> 2)) ^ (wp & 3)) + 16 * ((wave & 3) ^ ((wp >> 2) & 3)) + 8 * whf;
+  const int wxoff = 64 * wp + 16 * (wave & 3) + 8 * whf;   // narrow B image (threads 0..255)
 
-  const int my_tiles = a.n_tiles > (int)blockIdx.x ? (a.n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  const int my_tiles = a.n_tiles > wg ? (a.n_tiles - 1 - wg) / nwg + 1 : 0;
   const int n_items = my_tiles * a.n_pairs;
-  Staging st;
+  Staging4 st;
   int st_live = 32, st_pair = 0;
 
   auto issue = [&](int item) {
-    const int t = blockIdx.x + (item / a.n_pairs) * gridDim.x, pi = item % a.n_pairs;
+    const int t = wg + (item / a.n_pairs) * nwg, pi = item % a.n_pairs;
     const Pair& p = a.p[pi];
-    const f32x4* ga = reinterpret_cast<const f32x4*>(p.a + (size_t)t * p.stride_a);
-    const f32x4* gb = reinterpret_cast<const f32x4*>(p.b + (size_t)t * p.stride_b);
+    gptr_f4 ga = uniform_f4(p.a + (size_t)t * p.stride_a);
+    gptr_f4 gb = uniform_f4(p.b + (size_t)t * p.stride_b);
+    // branch-free: registers defined on one side of a branch only would be merged by copies that wait for the loads.
+    // A narrow B block has 256 float4: every load of a narrow job re-reads float4 tid & 255 (only b[0] is used).
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { st.a[k] = ga[k * 256 + tid]; st.b[k] = gb[k * 256 + tid]; }
-    st.has_h = p.a_h != nullptr;
-    if (st.has_h) {
-      const f32x4* gh = reinterpret_cast<const f32x4*>(p.a_h + (size_t)t * p.stride_h);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) st.h[k] = gh[k * 256 + tid];
-    }
-    if (NTB == 9) {
-      st.x = (a.b_extra && pi == 0) ? reinterpret_cast<const f32x4*>(a.b_extra + (size_t)t * a.stride_extra)[tid]
-                                    : (f32x4)(0.0f);
+    for (int k = 0; k < 4; ++k) {
+      st.a[k] = ga[k * kThreadsW + tid];
+      st.b[k] = gb[narrow ? (tid & 255) : k * kThreadsW + tid];
     }
     st_live = a.n_valid_points - t * 32;
     st_pair = pi;
@@ -277,106 +282,84 @@ __global__ __launch_bounds__(256, 1) void wgrad_h2_kernel(Args a, const float* _
     *SVS_LDS(f16x4, piece_mid + off) = mid;
   };
   auto commit = [&](int buf) {
-    unsigned char* la = smem_h2 + buf * BUF;
+    unsigned char* la = smem_h2 + buf * kBufBytes;
     unsigned char* lb = la + kOperand;
     const float sa = st_pair == 0 ? s_grad : 1.0f, sb = st_pair == 0 ? 1.0f : s_grad;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 4; ++k) {
       f32x4 va = st.a[k];
-      if (st.has_h) {
-        va[0] *= dsoftplus_from_h(st.h[k][0]); va[1] *= dsoftplus_from_h(st.h[k][1]);
-        va[2] *= dsoftplus_from_h(st.h[k][2]); va[3] *= dsoftplus_from_h(st.h[k][3]);
-      }
       if (wp >= st_live) va = (f32x4)(0.0f);     // ragged last tile: points beyond the batch contribute nothing
-      const int off = (k >> 2) * kSub + wbase + 64 * ((k & 3) ^ (wp & 3));
+      const int off = (k >> 1) * kSub + wbase[k & 1];
       put(la, la + kPiece, off, va * sa);
-      put(lb, lb + kPiece, off, st.b[k] * sb);
+      if (!narrow) put(lb, lb + kPiece, off, st.b[k] * sb);
     }
-    if (NTB == 9) {
-      unsigned char* lx = la + 2 * kOperand;
-      put(lx, lx + kExtraPiece, wxoff, st.x * sb);
-    }
+    if (narrow && tid < 256) put(lb, lb + kExtraPiece, wxoff, st.b[0] * sb);
   };
 
-  f16x8 ones;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) ones[j] = (_Float16)1.0f;
+  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+  const f16x2 one2 = {(_Float16)1.0f, (_Float16)1.0f};
 
   if (n_items > 0) { issue(0); commit(0); }
   __syncthreads();
   for (int item = 0; item < n_items; ++item) {
     const int buf = item & 1;
     const bool more = item + 1 < n_items;
-    if (more && dbg != 3) issue(item + 1);
-    const unsigned char* la = smem_h2 + buf * BUF;
+    if (more) issue(item + 1);
+    const unsigned char* la = smem_h2 + buf * kBufBytes;
     const unsigned char* lb = la + kOperand;
-    const unsigned char* lx = la + 2 * kOperand;
     const bool want_bias = a.db && (item % a.n_pairs) == 0;
-    if (dbg != 1)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      f16x8 ah[2], am[2];
-#pragma unroll
-      for (int o = 0; o < 2; ++o) {
-        ah[o] = tr_frag(la + ks * 4096, aaddr[o][0], aaddr[o][1]);
-        am[o] = tr_frag(la + kPiece + ks * 4096, aaddr[o][0], aaddr[o][1]);
-      }
+      const f16x8 ah = tr_frag(la + ks * 4096, aaddr[0], aaddr[1]);
+      const f16x8 am = tr_frag(la + kPiece + ks * 4096, aaddr[0], aaddr[1]);
       auto bfrag = [&](int i, f16x8& bh, f16x8& bm) {
-        if (i < 8) {
+        if (!narrow) {
           const unsigned char* base = lb + (i >> 2) * kSub + ks * 4096;
           bh = tr_frag(base, rbase[0] + rt[i & 3], rbase[1] + rt[i & 3]);
           bm = tr_frag(base + kPiece, rbase[0] + rt[i & 3], rbase[1] + rt[i & 3]);
         } else {
-          bh = tr_frag(lx + ks * 1024, rx[0], rx[1]);
-          bm = tr_frag(lx + kExtraPiece + ks * 1024, rx[0], rx[1]);
+          bh = tr_frag(lb + ks * 1024, rx[0], rx[1]);
+          bm = tr_frag(lb + kExtraPiece + ks * 1024, rx[0], rx[1]);
         }
       };
-      f16x8 bh, bm;
-      bfrag(0, bh, bm);
       if (want_bias) {
+        // row sums of A: the fragment holds 8 points of row lane & 31 (the other lane half holds the other 8)
 #pragma unroll
-        for (int o = 0; o < 2; ++o) {
-          accb[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am[o], ones, accb[o], 0, 0, 0);
-          accb[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[o], ones, accb[o], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) {
+          const f16x2 h2v = {ah[2 * j], ah[2 * j + 1]}, m2v = {am[2 * j], am[2 * j + 1]};
+          bsum = __builtin_amdgcn_fdot2(h2v, one2, bsum, false);
+          bsum = __builtin_amdgcn_fdot2(m2v, one2, bsum, false);
         }
       }
+      // the two waves of a SIMD cover each other's LDS latency: no software pipelining of the B fragments
 #pragma unroll
-      for (int i = 0; i < NTB; ++i) {
-        f16x8 nh, nm;
-        __builtin_amdgcn_sched_barrier(0);
-        acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am[0], bh, acc[0][i], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (i + 1 < NTB) bfrag(i + 1, nh, nm);       // next B tile: behind one MFMA, ahead of five
-        __builtin_amdgcn_sched_barrier(0);
-        acc[1][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am[1], bh, acc[1][i], 0, 0, 0);
-        acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0], bm, acc[0][i], 0, 0, 0);
-        acc[1][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1], bm, acc[1][i], 0, 0, 0);
-        acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0], bh, acc[0][i], 0, 0, 0);
-        acc[1][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1], bh, acc[1][i], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (i + 1 < NTB) { bh = nh; bm = nm; }
+      for (int i = 0; i < 8; ++i) {
+        if (i > 0 && narrow) break;
+        f16x8 bh, bm;
+        bfrag(i, bh, bm);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, bh, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bm, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i], 0, 0, 0);
       }
     }
-    if (more && dbg != 2) commit(buf ^ 1);
+    if (more) commit(buf ^ 1);
     __syncthreads();
   }
   // flush: C[row = rho(r) + 4*half][col]; two 128-byte row segments per wave-instruction
   const int half = lane >> 5, col = lane & 31;
 #pragma unroll
-  for (int o = 0; o < 2; ++o)
+  for (int i = 0; i < 8; ++i) {
+    if (i > 0 && narrow) break;
 #pragma unroll
-    for (int i = 0; i < NTB; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = 32 * (2 * wave + o) + rho(r) + 4 * half;
-        const int c = 32 * i + col;
-        if (c < a.ldw) atomicAdd(&a.dW[(size_t)row * a.ldw + c], acc[o][i][r] * inv_s);
-      }
-  if (a.db && col == 0) {
-#pragma unroll
-    for (int o = 0; o < 2; ++o)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) atomicAdd(&a.db[32 * (2 * wave + o) + rho(r) + 4 * half], accb[o][r] * inv_s);
+    for (int r = 0; r < 16; ++r) {
+      const int row = 32 * wave + rho(r) + 4 * half;
+      const int c = a.col0 + 32 * i + col;
+      if (c < a.ldw) atomicAdd(&a.dW[(size_t)row * a.ldw + c], acc[i][r] * inv_s);
+    }
+  }
+  if (a.db) {
+    bsum += __shfl_xor(bsum, 32);
+    if (half == 0) atomicAdd(&a.db[32 * wave + col], bsum * inv_s);
   }
 }
 
@@ -391,71 +374,109 @@ namespace h2 = svs::wgrad::h2;
 
 extern "C" {
 
-// dW[256][ldw] += sum_p A(p) B(p)^T over n_pairs (<= 2) operand pairs; db[256] += row sums of A of pair 0.
-// a/b/a_h: wave-tile blocks with the given strides (floats between point tiles); a_h optional (A *= softplus'(h)).
-// b_extra: optional 16 extra B rows per tile (columns 256..271 of dW; ldw >= 288).
-int svs_wgrad(const float* a0, const float* a0_h, const float* b0, long long sa0, long long sh0, long long sb0,
-              const float* a1, const float* a1_h, const float* b1, long long sa1, long long sh1, long long sb1,
-              const float* b_extra, long long s_extra, int n_points, int precision, const float* absmax, float* dW,
-              int ldw, float* db, void* hip_stream) {
-  if (!a0 || !b0 || !dW || n_points <= 0 || ldw < 256 || ldw > 288 || (b_extra && ldw < 288)) {
-    set_error("svs_wgrad: bad argument"); return SVS_EINVAL;
+// the C-ABI job record (include/svolsdf_hip.h)
+struct svs_wgrad_job {
+  const float *a0, *b0; long long sa0, sb0;
+  const float *a1, *b1; long long sa1, sb1;
+  const float* b_extra; long long s_extra;
+  int n_points, ldw;
+  float *dW, *db;
+  const float* absmax;
+};
+
+// Weight gradients of several layers in one call.  Per job: dW[256][ldw] += sum_p A(p) B(p)^T over one or two
+// operand pairs; db[256] += row sums of A of pair 0.  fp16x2: one launch for all jobs; float32: one launch per job.
+int svs_wgrad_multi(const svs_wgrad_job* jobs, int n_jobs, int precision, void* hip_stream) {
+  if (!jobs || n_jobs < 1) { set_error("svs_wgrad_multi: no jobs"); return SVS_EINVAL; }
+  int n_expanded = 0;
+  for (int j = 0; j < n_jobs; ++j) n_expanded += jobs[j].b_extra ? 2 : 1;
+  if (n_expanded > h2::kMaxJobs) { set_error("svs_wgrad_multi: at most %d jobs (b_extra counts twice)", h2::kMaxJobs); return SVS_EINVAL; }
+  for (int j = 0; j < n_jobs; ++j) {
+    const svs_wgrad_job& q = jobs[j];
+    if (!q.a0 || !q.b0 || !q.dW || q.n_points <= 0 || q.ldw < 256 || q.ldw > 288 || (q.b_extra && q.ldw < 288) || (q.a1 && !q.b1)) {
+      set_error("svs_wgrad_multi: bad argument in job %d", j); return SVS_EINVAL;
+    }
   }
-  Args a;
-  a.p[0] = Pair{a0, a0_h, b0, (size_t)sa0, (size_t)sh0, (size_t)sb0};
-  a.n_pairs = 1;
-  if (a1) {
-    if (!b1) { set_error("svs_wgrad: second pair needs b1"); return SVS_EINVAL; }
-    a.p[1] = Pair{a1, a1_h, b1, (size_t)sa1, (size_t)sh1, (size_t)sb1};
-    a.n_pairs = 2;
-  }
-  a.n_tiles = (n_points + 31) / 32;
-  a.n_valid_points = n_points;
-  a.b_extra = b_extra; a.stride_extra = (size_t)s_extra;
-  a.dW = dW; a.ldw = ldw; a.db = db;
   hipStream_t s = (hipStream_t)hip_stream;
-  const int grid = a.n_tiles < 256 ? a.n_tiles : 256;
   if (precision == mlp::kFmtF16x2) {
-    if (b_extra) {
-      constexpr int lds = 2 * h2::buf_bytes(9);
-      static hipError_t e9 = hipFuncSetAttribute(reinterpret_cast<const void*>(h2::wgrad_h2_kernel<9>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      if (e9 != hipSuccess) { set_error("svs_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e9)); return (int)e9; }
-      h2::wgrad_h2_kernel<9><<<grid, 256, lds, s>>>(a, absmax);
-    } else {
-      constexpr int lds = 2 * h2::buf_bytes(8);
-      static hipError_t e8 = hipFuncSetAttribute(reinterpret_cast<const void*>(h2::wgrad_h2_kernel<8>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      if (e8 != hipSuccess) { set_error("svs_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e8)); return (int)e8; }
-      {
-        const char* m = getenv("SVS_WG_MODE"); const int mode = m ? atoi(m) : 0;
-        static hipError_t ee = (hipFuncSetAttribute(reinterpret_cast<const void*>(h2::wgrad_h2_kernel<8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
-                                hipFuncSetAttribute(reinterpret_cast<const void*>(h2::wgrad_h2_kernel<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
-                                hipFuncSetAttribute(reinterpret_cast<const void*>(h2::wgrad_h2_kernel<8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        (void)ee;
-        if (mode == 1) h2::wgrad_h2_kernel<8, 1><<<grid, 256, lds, s>>>(a, absmax);
-        else if (mode == 2) h2::wgrad_h2_kernel<8, 2><<<grid, 256, lds, s>>>(a, absmax);
-        else if (mode == 3) h2::wgrad_h2_kernel<8, 3><<<grid, 256, lds, s>>>(a, absmax);
-        else h2::wgrad_h2_kernel<8><<<grid, 256, lds, s>>>(a, absmax);
+    h2::MultiArgs ma;
+    int n = 0;
+    long long work[h2::kMaxJobs], total = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+      const svs_wgrad_job& q = jobs[j];
+      h2::Job& J = ma.job[n];
+      J.p[0] = Pair{q.a0, q.b0, (size_t)q.sa0, (size_t)q.sb0};
+      J.n_pairs = 1;
+      if (q.a1) { J.p[1] = Pair{q.a1, q.b1, (size_t)q.sa1, (size_t)q.sb1}; J.n_pairs = 2; }
+      else J.p[1] = J.p[0];
+      J.n_tiles = (q.n_points + 31) / 32; J.n_valid_points = q.n_points;
+      J.b_tiles = 8; J.col0 = 0; J.dW = q.dW; J.ldw = q.ldw; J.db = q.db; J.absmax = q.absmax;
+      work[n] = (long long)J.n_tiles * J.n_pairs * 10;
+      total += work[n++];
+      if (q.b_extra) {
+        // the 16 extra B rows (dW columns 256..271) as a narrow job of its own: same A, one 32-row B tile
+        h2::Job& X = ma.job[n];
+        X = J;
+        X.p[0].b = q.b_extra; X.p[0].stride_b = (size_t)q.s_extra; X.n_pairs = 1;
+        X.b_tiles = 1; X.col0 = 256; X.db = nullptr;
+        work[n] = (long long)X.n_tiles * 4;
+        total += work[n++];
       }
     }
-    return check_launch("svs_wgrad");
+    ma.n_jobs = n;
+    // ~one workgroup per CU in total, split in proportion to the work, at least one each and no more than tiles
+    const int n_wg_total = 256;
+    int begin = 0;
+    for (int j = 0; j < n; ++j) {
+      long long c = (work[j] * n_wg_total + total / 2) / total;
+      if (c < 1) c = 1;
+      if (c > ma.job[j].n_tiles) c = ma.job[j].n_tiles;
+      ma.job[j].wg_begin = begin; ma.job[j].wg_count = (int)c;
+      begin += (int)c;
+    }
+    constexpr int lds = 2 * h2::kBufBytes;
+    static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(h2::wgrad_h2_multi_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) { set_error("svs_wgrad_multi: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    h2::wgrad_h2_multi_kernel<<<begin, h2::kThreadsW, lds, s>>>(ma);
+    return check_launch("svs_wgrad_multi");
   }
-  if (precision != mlp::kFmtF32) { set_error("svs_wgrad: unknown precision %d", precision); return SVS_EINVAL; }
-  if (b_extra) {
-    constexpr int lds = 2 * 32 * (260 + 292) * 4;
-    static hipError_t e9 = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<9>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e9 != hipSuccess) { set_error("svs_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e9)); return (int)e9; }
-    wgrad_kernel<9><<<grid, 256, lds, s>>>(a);
-  } else {
-    constexpr int lds = 2 * 32 * (260 + 260) * 4;
-    static hipError_t e8 = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<8>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e8 != hipSuccess) { set_error("svs_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e8)); return (int)e8; }
-    wgrad_kernel<8><<<grid, 256, lds, s>>>(a);
+  if (precision != mlp::kFmtF32) { set_error("svs_wgrad_multi: unknown precision %d", precision); return SVS_EINVAL; }
+  for (int j = 0; j < n_jobs; ++j) {
+    const svs_wgrad_job& q = jobs[j];
+    Args a;
+    a.p[0] = Pair{q.a0, q.b0, (size_t)q.sa0, (size_t)q.sb0};
+    a.n_pairs = 1;
+    if (q.a1) { a.p[1] = Pair{q.a1, q.b1, (size_t)q.sa1, (size_t)q.sb1}; a.n_pairs = 2; }
+    a.n_tiles = (q.n_points + 31) / 32;
+    a.n_valid_points = q.n_points;
+    a.b_extra = q.b_extra; a.stride_extra = (size_t)q.s_extra;
+    a.dW = q.dW; a.ldw = q.ldw; a.db = q.db;
+    const int grid = a.n_tiles < 256 ? a.n_tiles : 256;
+    if (q.b_extra) {
+      constexpr int lds = 2 * 32 * (260 + 292) * 4;
+      static hipError_t e9 = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<9>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e9 != hipSuccess) { set_error("svs_wgrad_multi: hipFuncSetAttribute: %s", hipGetErrorString(e9)); return (int)e9; }
+      wgrad_kernel<9><<<grid, 256, lds, s>>>(a);
+    } else {
+      constexpr int lds = 2 * 32 * (260 + 260) * 4;
+      static hipError_t e8 = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<8>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e8 != hipSuccess) { set_error("svs_wgrad_multi: hipFuncSetAttribute: %s", hipGetErrorString(e8)); return (int)e8; }
+      wgrad_kernel<8><<<grid, 256, lds, s>>>(a);
+    }
+    if (int rc = check_launch("svs_wgrad_multi")) return rc;
   }
-  return check_launch("svs_wgrad");
+  return SVS_OK;
+}
+
+// single job (see svs_wgrad_multi)
+int svs_wgrad(const float* a0, const float* b0, long long sa0, long long sb0, const float* a1, const float* b1,
+              long long sa1, long long sb1, const float* b_extra, long long s_extra, int n_points, int precision,
+              const float* absmax, float* dW, int ldw, float* db, void* hip_stream) {
+  svs_wgrad_job q{a0, b0, sa0, sb0, a1, b1, sa1, sb1, b_extra, s_extra, n_points, ldw, dW, db, absmax};
+  return svs_wgrad_multi(&q, 1, precision, hip_stream);
 }
 
 }  // extern "C"

@@ -20,6 +20,15 @@ _P = c_void_p   # every device pointer crosses the boundary as a plain address
 _PP = POINTER(c_void_p)
 
 # name -> (restype, argtypes); mirrors include/svolsdf_hip.h one to one
+class WGradJob(ctypes.Structure):
+    """svs_wgrad_job of include/svolsdf_hip.h"""
+    _fields_ = [("a0", ctypes.c_void_p), ("b0", ctypes.c_void_p), ("sa0", ctypes.c_longlong), ("sb0", ctypes.c_longlong),
+                ("a1", ctypes.c_void_p), ("b1", ctypes.c_void_p), ("sa1", ctypes.c_longlong), ("sb1", ctypes.c_longlong),
+                ("b_extra", ctypes.c_void_p), ("s_extra", ctypes.c_longlong),
+                ("n_points", ctypes.c_int), ("ldw", ctypes.c_int),
+                ("dW", ctypes.c_void_p), ("db", ctypes.c_void_p), ("absmax", ctypes.c_void_p)]
+
+
 SIGNATURES = {
     "svs_version": (c_int, []),
     "svs_last_error_string": (c_char_p, []),
@@ -53,9 +62,9 @@ SIGNATURES = {
                                   c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "svs_composite": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P]),
     "svs_composite_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "svs_wgrad": (c_int, [_P, _P, _P, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, _P, _P, _P,
-                          ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, _P, ctypes.c_longlong, c_int, c_int, _P,
-                          _P, c_int, _P, _P]),
+    "svs_wgrad": (c_int, [_P, _P, ctypes.c_longlong, ctypes.c_longlong, _P, _P, ctypes.c_longlong, ctypes.c_longlong,
+                          _P, ctypes.c_longlong, c_int, c_int, _P, _P, c_int, _P, _P]),
+    "svs_wgrad_multi": (c_int, [_P, c_int, c_int, _P]),
     "svs_adam_workspace_bytes": (c_size_t, []),
     "svs_clip_guard_adam": (c_int, [_P, _P, _P, _P, ctypes.c_longlong, c_int, c_float, c_float, c_float, c_float, c_float,
                                     _P, _P, _P]),

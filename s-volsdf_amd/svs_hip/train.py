@@ -137,10 +137,17 @@ class MlpBackward:
         prec = S.precision
         h2 = prec == F16X2
 
-        def wgrad(slot, n_pts, amax, a0, sa0, b0, sb0, a1=None, a1h=None, sa1=0, sh1=0, b1=None, sb1=0, extra=None, sx=0):
-            _lib.check(L.svs_wgrad(a0, None, b0, sa0, 0, sb0, a1, a1h, b1, sa1, sh1, sb1, extra, sx, n_pts, prec,
-                                   _off(acc.absmax, amax) if h2 else None,
-                                   _off(acc.dWk, slot * 256 * LDW), LDW, _off(acc.dbk, slot * 256), _stream()), "svs_wgrad")
+        def addr(x):
+            return x.value if isinstance(x, ctypes.c_void_p) else x
+
+        def job(slot, n_pts, amax, a0, sa0, b0, sb0, a1=None, sa1=0, b1=None, sb1=0, extra=None, sx=0):
+            return _lib.WGradJob(addr(a0), addr(b0), sa0, sb0, addr(a1), addr(b1), sa1, sb1,
+                                 addr(extra), sx, n_pts, LDW, addr(_off(acc.dWk, slot * 256 * LDW)),
+                                 addr(_off(acc.dbk, slot * 256)), addr(_off(acc.absmax, amax)) if h2 else None)
+
+        def wgrad_multi(jobs):
+            arr = (_lib.WGradJob * len(jobs))(*jobs)
+            _lib.check(L.svs_wgrad_multi(ctypes.cast(arr, ctypes.c_void_p), len(jobs), prec, _stream()), "svs_wgrad_multi")
 
         # ---- radiance MLP: input gradients
         d_rgb = _f32(d_rgb)
@@ -162,9 +169,10 @@ class MlpBackward:
         fork = torch.cuda.Event(); fork.record(main)
         with torch.cuda.stream(self._side):
             self._side.wait_event(fork)
-            wgrad(9, n_main, 1, _off(self.zbuf, 0), 5 * KBLOCK, _ptr(feat), KBLOCK, extra=_off(rbuf, 4 * KBLOCK), sx=RBUF)
+            jobs = [job(9, n_main, 1, _off(self.zbuf, 0), 5 * KBLOCK, _ptr(feat), KBLOCK, extra=_off(rbuf, 4 * KBLOCK), sx=RBUF)]
             for l in range(1, 5):
-                wgrad(9 + l, n_main, 1, _off(self.zbuf, l * KBLOCK), 5 * KBLOCK, _off(rbuf, (l - 1) * KBLOCK), RBUF)
+                jobs.append(job(9 + l, n_main, 1, _off(self.zbuf, l * KBLOCK), 5 * KBLOCK, _off(rbuf, (l - 1) * KBLOCK), RBUF))
+            wgrad_multi(jobs)
             join = torch.cuda.Event(); join.record(self._side)
         # ---- SDF MLP: pass A (needs nbar), pass B (needs sbar, fbar), then its weight gradients
         st = _stream()
@@ -180,12 +188,13 @@ class MlpBackward:
         ev = self.timer_events = ([torch.cuda.Event(enable_timing=True) for _ in range(2)] if self.time_wgrad else None)
         if ev:
             ev[0].record()
-        wgrad(0, n_total, 0, _off(self.abuf, 0), A8, _ptr(self.pebuf), KBLOCK,
-              _off(gbuf, 0), _off(hbuf, 0), H8, H8, _off(self.ubuf, 0), U9)
+        jobs = [job(0, n_total, 0, _off(self.abuf, 0), A8, _ptr(self.pebuf), KBLOCK,
+                    _off(gbuf, 0), H8, _off(self.ubuf, 0), U9)]
         for l in range(1, 8):
-            wgrad(l, n_total, 0, _off(self.abuf, l * KBLOCK), A8, _off(hbuf, (l - 1) * KBLOCK), H8,
-                  _off(gbuf, l * KBLOCK), _off(hbuf, l * KBLOCK), H8, H8, _off(self.ubuf, l * KBLOCK), U9)
-        wgrad(8, n_main, 2, _ptr(self.feat_bar), KBLOCK, _off(hbuf, 7 * KBLOCK), H8)
+            jobs.append(job(l, n_total, 0, _off(self.abuf, l * KBLOCK), A8, _off(hbuf, (l - 1) * KBLOCK), H8,
+                            _off(gbuf, l * KBLOCK), H8, _off(self.ubuf, l * KBLOCK), U9))
+        jobs.append(job(8, n_main, 2, _ptr(self.feat_bar), KBLOCK, _off(hbuf, 7 * KBLOCK), H8))
+        wgrad_multi(jobs)
         if ev:
             ev[1].record()
         main.wait_event(join)

@@ -76,17 +76,55 @@ def test_wgrad_gemm(dev, P, precision, gscale):
     B1[:: 89] *= 1000.0
     H1 = rng.uniform(0, 0.05, (P, 256)).astype(F32)
     absmax = torch.tensor([max(np.abs(A0).max(), np.abs(B1).max())], dtype=torch.float32, device=dev)
-    ta0, tb0, ta1, tb1, th1 = (G(synth.rows_to_tiles(x), dev) for x in (A0, B0, A1, B1, H1))
+    A1 = (A1 * (1 - np.exp(-100.0 * H1.astype(np.float64)))).astype(F32)
+    ta0, tb0, ta1, tb1 = (G(synth.rows_to_tiles(x), dev) for x in (A0, B0, A1, B1))
     dW = torch.zeros(256, 256, device=dev)
     db = torch.zeros(256, device=dev)
     ptr = lambda t: ctypes.c_void_p(t.data_ptr())
     st = 128 * 64
-    lib.check(L.svs_wgrad(ptr(ta0), None, ptr(tb0), st, 0, st, ptr(ta1), ptr(th1), ptr(tb1), st, st, st, None, 0, P,
+    lib.check(L.svs_wgrad(ptr(ta0), ptr(tb0), st, st, ptr(ta1), ptr(tb1), st, st, None, 0, P,
                           precision, ptr(absmax) if precision else None, ptr(dW), 256, ptr(db),
                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
-    ref = A0.astype(np.float64).T @ B0 + (A1 * (1 - np.exp(-100.0 * H1.astype(np.float64)))).T @ B1
+    ref = A0.astype(np.float64).T @ B0 + A1.astype(np.float64).T @ B1
     assert rel_err(dW.cpu().numpy(), ref) < 2e-5
     assert rel_err(db.cpu().numpy(), A0.astype(np.float64).sum(0)) < 2e-5
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_wgrad_multi(dev, precision):
+    """Several layers in one call, incl. the 16 extra B rows of the radiance network's first layer and a ragged tile."""
+    import ctypes
+    from svs_hip import lib
+    L = lib.load()
+    rng = np.random.default_rng(5)
+    st = 128 * 64
+    jobs, refs, outs, keep = [], [], [], []
+    for j, (P, extra, two) in enumerate([(4000, True, False), (2500, False, True), (37, False, False)]):
+        A0, B0 = (1e-6 * rng.normal(0, 1, (P, 256))).astype(F32), rng.normal(0, 1, (P, 256)).astype(F32)
+        A1, B1 = rng.normal(0, 1, (P, 256)).astype(F32), (1e-6 * rng.normal(0, 1, (P, 256))).astype(F32)
+        X = rng.normal(0, 1, (P, 32)).astype(F32); X[:, 16:] = 0
+        ta0, tb0, ta1, tb1 = (G(synth.rows_to_tiles(x), dev) for x in (A0, B0, A1, B1))
+        # the extras block: one 32-row tile (16 registers x 64 lanes) per 32 points
+        xt = synth.rows_to_tiles(np.concatenate([X, np.zeros((P, 224), F32)], 1)).reshape(-1, 128 * 64)[:, :1024].copy()
+        tx = G(xt, dev)
+        dW = torch.zeros(256, 288, device=dev); db = torch.zeros(256, device=dev)
+        am = torch.tensor([max(np.abs(A0).max(), np.abs(B1).max() if two else 0.0)], dtype=torch.float32, device=dev)
+        keep += [ta0, tb0, ta1, tb1, tx, am]
+        p = lambda t: t.data_ptr()
+        jobs.append(lib.WGradJob(p(ta0), p(tb0), st, st, p(ta1) if two else None, p(tb1) if two else None, st, st,
+                                 p(tx) if extra else None, 1024, P, 288, p(dW), p(db), p(am) if precision else None))
+        ref = A0.astype(np.float64).T @ B0 + (A1.astype(np.float64).T @ B1 if two else 0.0)
+        refx = A0.astype(np.float64).T @ X[:, :16] if extra else None
+        refs.append((ref, refx, A0.astype(np.float64).sum(0))); outs.append((dW, db))
+    arr = (lib.WGradJob * len(jobs))(*jobs)
+    lib.check(L.svs_wgrad_multi(ctypes.cast(arr, ctypes.c_void_p), len(jobs), precision,
+                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    for (ref, refx, refb), (dW, db) in zip(refs, outs):
+        got = dW.cpu().numpy()
+        assert rel_err(got[:, :256], ref) < 2e-5
+        if refx is not None:
+            assert rel_err(got[:, 256:272], refx) < 2e-5
+        assert rel_err(db.cpu().numpy(), refb) < 2e-5
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -86,11 +86,11 @@ def main():
     H8, U9, A8 = 8 * KBLOCK, 9 * KBLOCK, 8 * KBLOCK
     dW = torch.zeros(256, 288, device=dev); db = torch.zeros(256, device=dev)
     l = 2
-    t = timeit(lambda: lib.check(L.svs_wgrad(_off(bw.abuf, l * KBLOCK), None, _off(hbuf, (l - 1) * KBLOCK), A8, 0, H8,
-                                             _off(gbuf, l * KBLOCK), _off(hbuf, l * KBLOCK), _off(bw.ubuf, l * KBLOCK), H8, H8, U9,
+    t = timeit(lambda: lib.check(L.svs_wgrad(_off(bw.abuf, l * KBLOCK), _off(hbuf, (l - 1) * KBLOCK), A8, H8,
+                                             _off(gbuf, l * KBLOCK), _off(bw.ubuf, l * KBLOCK), H8, U9,
                                              None, 0, n_total, prec, N(am), P(dW), 288, P(db), st())))
     res["wgrad_2pair"] = dict(ms=t, tflops=2 * 2 * 256 * 256 * n_total / t / 1e9)
-    t = timeit(lambda: lib.check(L.svs_wgrad(P(bw.feat_bar), None, _off(hbuf, 7 * KBLOCK), KBLOCK, 0, H8, None, None, None, 0, 0, 0,
+    t = timeit(lambda: lib.check(L.svs_wgrad(P(bw.feat_bar), _off(hbuf, 7 * KBLOCK), KBLOCK, H8, None, None, 0, 0,
                                              None, 0, n_main, prec, _off(am, 2) if h2 else None, P(dW), 288, P(db), st())))
     res["wgrad_1pair"] = dict(ms=t, tflops=2 * 256 * 256 * n_main / t / 1e9)
     if True:
