@@ -13,8 +13,10 @@ Inputs (weights, camera, pixel batch, prior volumes) are resident in HBM before 
 independent: with N GPUs each rank takes its own 1024-ray shard (weak scaling) and the step adds ONE RCCL
 all-reduce of the flat float32 gradient (3.19 MB).
 
-Rank 0 prints ONE JSON line; `roofline` prices the dominant kernel (fused SDF forward+gradient) against the
-float32 MFMA peak, `cpu_baseline` times the numpy oracle on a bounded sample of the same workload.
+Rank 0 prints ONE JSON line; `roofline` prices the dominant kernel (fused SDF forward + input gradient) against the
+matrix-core peak of the precision it runs in and, under "other", the weight-gradient GEMM launch against HBM;
+`cpu_baseline` times the CPU port on a bounded sample of the same workload.  SVS_MLP_PRECISION=f32 selects the
+float32-MFMA kernels instead of the default fp16x2 split-operand ones (same accuracy class).
 """
 import argparse
 import json
@@ -30,13 +32,15 @@ for p in (os.path.join(ROOT, "tests", "golden"), os.path.join(ROOT, "s-volsdf_am
 F_SDF = 1_049_088          # FLOP per point per SDF-MLP forward
 F_RGB = 533_504            # FLOP per point per radiance forward
 PEAK_F32_MFMA = 157.3e12   # MI355X dense float32 MFMA peak (MI355X_MICROARCH.md)
+PEAK_F16_MFMA = 2.5e15     # dense fp16/bf16 MFMA peak; an fp16x2 product costs three fp16 MFMA products
+PEAK_HBM = 8.0e12          # HBM3E bytes/s
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rays", type=int, default=1024)
     ap.add_argument("--mode", choices=["train", "render"], default="train")
     ap.add_argument("--groups", choices=["auto", "none"], default="none", help="ray groups on concurrent streams")
@@ -156,32 +160,46 @@ def main():
             # backward: second-order sweep + backprop of the SDF MLP (2 x 8 layers), its two weight-gradient
             # contractions per layer, radiance backprop + weight gradients (approximate, SURVEY.md 8d: 0.92 GFLOP/ray)
             flop_per_ray += (S + 2) * (2 * F_SDF + 2 * F_SDF) + S * (2 * F_RGB)
-        roof_full = {"bound": "mfma", "kernel": "sdf_full_kernel (SDF MLP forward + input gradient + features)",
-                     "achieved": achieved / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_F32_MFMA, "traffic": None, "kernel_ms": k_ms, "launches_per_step": 1,
-                     "points_per_launch": n_pts, "flop_per_point": 2 * F_SDF}
+        h2 = ops.default_precision() == ops.F16X2
+        peak = PEAK_F16_MFMA / 3 if h2 else PEAK_F32_MFMA
+        kname = "svs::mlp::sdf_full_h2_kernel" if h2 else "svs::mlp::sdf_full_kernel"
+        roof_full = {"bound": "mfma", "kernel": kname + " (SDF MLP forward + input gradient + features)",
+                     "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
+                     "frac": achieved / peak, "traffic": None, "kernel_ms": k_ms, "launches_per_step": 1,
+                     "points_per_launch": n_pts, "flop_per_point": 2 * F_SDF,
+                     "peak_note": ("algorithmic float32 FLOP; fp16x2 evaluates each product as three fp16 MFMA products: "
+                                   "peak = 2500 / 3 TFLOP/s" if h2 else "dense float32 MFMA peak")}
         # HBM traffic per launch: PMC counters of the committed profile of this same command (profiles/, see
         # tools/summarize_profiles.py); the bench itself cannot run the counters
+        wname = "svs::wgrad::h2::wgrad_h2_multi_kernel" if h2 else "svs::wgrad::wgrad_kernel<8>"
         try:
             prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
             pk = json.load(open(os.path.join(ROOT, "profiles", prof[-1])))["kernels"]
-            traffic = {"sdf_full": pk["svs::mlp::sdf_full_kernel"]["hbm_bytes"],
-                       "wgrad8": pk.get("svs::wgrad::wgrad_kernel<8>", {}).get("hbm_bytes")}
+            traffic = {"sdf_full": pk.get(kname, {}).get("hbm_bytes"), "wgrad": pk.get(wname, {}).get("hbm_bytes")}
             src_prof = prof[-1]
         except Exception:
-            traffic, src_prof = {"sdf_full": None, "wgrad8": None}, None
+            traffic, src_prof = {"sdf_full": None, "wgrad": None}, None
         roof_full["traffic"] = traffic["sdf_full"]
         roof_full["traffic_source"] = src_prof
         roofline = roof_full
         if train and wg_ev:
-            # 9 launches of wgrad_kernel<8> per step: dW_l = abar_l h_l^T + ghat_l u_l^T (l = 0..7) and the feature head
+            # the SDF weight gradients dW_l = abar_l h_l^T + ghat_l u_l^T (l = 0..7) and the feature head.  fp16x2: ONE
+            # launch, HBM-bound: every operand block (32 KiB per 32 points) is read once; float32: 9 launches, MFMA-bound
             w_ms = float(np.mean([a.elapsed_time(b) for a, b in wg_ev]))
+            n_tiles, n_main_tiles = (n_pts + 31) // 32, R * S // 32
+            w_bytes = (8 * 4 * n_tiles + 2 * n_main_tiles) * 32768
             w_flop = (2 * 2 * (F_SDF // 2 - 257 * 256) + 2 * 256 * 256) * n_pts      # algorithmic: 2 pairs x 2 x rows x cols
-            roof_w = {"bound": "mfma", "kernel": "wgrad_kernel<8> (SDF weight gradients, 9 launches per step)",
-                      "achieved": w_flop / (w_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
-                      "frac": w_flop / (w_ms * 1e-3) / PEAK_F32_MFMA, "traffic": None, "kernel_ms": w_ms / 9,
-                      "launches_per_step": 9, "flop_per_step": w_flop}
-            roof_w["traffic"], roof_w["traffic_source"] = traffic["wgrad8"], src_prof
+            if h2:
+                roof_w = {"bound": "hbm", "kernel": wname + " (all SDF weight gradients, 1 launch per step)",
+                          "achieved": w_bytes / (w_ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                          "frac": w_bytes / (w_ms * 1e-3) / PEAK_HBM, "traffic": traffic["wgrad"], "kernel_ms": w_ms,
+                          "launches_per_step": 1, "bytes_per_launch": w_bytes, "flop_per_launch": w_flop}
+            else:
+                roof_w = {"bound": "mfma", "kernel": wname + " (SDF weight gradients, 9 launches per step)",
+                          "achieved": w_flop / (w_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
+                          "frac": w_flop / (w_ms * 1e-3) / PEAK_F32_MFMA, "traffic": traffic["wgrad"], "kernel_ms": w_ms / 9,
+                          "launches_per_step": 9, "flop_per_step": w_flop}
+            roof_w["traffic_source"] = src_prof
             # the dominant kernel is the one with the larger total time per step
             roofline = dict(roof_w, other=roof_full) if w_ms > k_ms else dict(roof_full, other=roof_w)
         line = {
@@ -202,6 +220,8 @@ def main():
                                    + f"train mode, fast=1: {R} rays/GPU x 128 coarse + {S} composited samples + {2 * R} "
                                    "eikonal points, 8x256 SDF MLP + 4x256 radiance MLP",
                        "mode": args.mode,
+                       "mlp_precision": ("fp16x2: two-piece fp16 operands on v_mfma_f32_32x32x16_f16, float32 accumulation "
+                                         "(float32-class accuracy, same parity bounds)" if h2 else "float32 MFMA"),
                        "rays_per_gpu": R, "flop_per_ray": flop_per_ray,
                        "model_flops_per_s": world * R * args.steps / dt * flop_per_ray},
             "roofline": roofline,
