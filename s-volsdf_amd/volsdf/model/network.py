@@ -202,9 +202,18 @@ class VolSDFNetwork(nn.Module):
     def draw_train_rng(self, R, dev):
         """All train-mode random draws of one forward for R rays, in the reference's order (sampler draws, then the
         uniform eikonal points of network.py:261).  Slices of it can be handed to _forward_impl per ray group."""
-        rng = self.ray_sampler.draw_train_rng(R, dev)
-        rng["eik_points"] = torch.empty(R, 3).uniform_(-self.scene_bounding_sphere, self.scene_bounding_sphere).to(dev)
-        return rng
+        rb = self.scene_bounding_sphere
+
+        def eik(slot, n):
+            if n is None:       # CPU tensors (no device)
+                slot["eik_points"] = torch.empty(R, 3).uniform_(-rb, rb)
+                return ["eik_points"]
+            if "eik_points" not in slot:
+                slot["eik_points"] = torch.empty(R, 3).pin_memory()
+            slot["eik_points"].uniform_(-rb, rb)
+            return ["eik_points"]
+
+        return self.ray_sampler.draw_train_rng(R, dev, extra=eik)
 
     @staticmethod
     def slice_rng(rng, lo, hi):

@@ -5,7 +5,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-for p in (GOLDEN, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "s-volsdf_amd"), ROOT):
+for p in (GOLDEN, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "s-volsdf_amd"), os.path.join(ROOT, "tests"), ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 

@@ -249,16 +249,9 @@ def test_model_forward_golden(dev, golden_dir, tag):
     if training:
         # feed the fixture's draws through torch's CPU RNG call sites, in the reference's order
         draws = synth.make_train_rng(R, seed=int(g["rng_seed"]))
-        q = [draws["jitter"], draws["u"]]
-        o = (torch.rand, torch.randperm, torch.randint, torch.Tensor.uniform_)
-        torch.rand = lambda *s, **k: torch.from_numpy(q.pop(0))
-        torch.randperm = lambda n, **k: torch.from_numpy(draws["perm"])
-        torch.randint = lambda h, s, **k: torch.from_numpy(draws["eik_idx"])
-        torch.Tensor.uniform_ = lambda self, a, b: self.copy_(torch.from_numpy(draws["eik_points"]))
-        try:
+        from rng_inject import inject_rng
+        with inject_rng(draws):
             out = m(inp, fast=int(g["fast"]))
-        finally:
-            torch.rand, torch.randperm, torch.randint, torch.Tensor.uniform_ = o
     else:
         out = m(inp, fast=int(g["fast"]))
     out = {k: v.detach().cpu().numpy() for k, v in out.items()}

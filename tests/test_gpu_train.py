@@ -23,19 +23,7 @@ def G(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
-@contextlib.contextmanager
-def inject_rng(draws):
-    """feed the CPU-generator call sites of the model (reference order: jitter, u, randperm, randint, uniform_)"""
-    o = (torch.rand, torch.randperm, torch.randint, torch.Tensor.uniform_)
-    q = [draws["jitter"], draws["u"]]
-    torch.rand = lambda *s, **k: torch.from_numpy(q.pop(0))
-    torch.randperm = lambda n, **k: torch.from_numpy(draws["perm"])
-    torch.randint = lambda h, s, **k: torch.from_numpy(draws["eik_idx"])
-    torch.Tensor.uniform_ = lambda self, a, b: self.copy_(torch.from_numpy(draws["eik_points"]))
-    try:
-        yield
-    finally:
-        torch.rand, torch.randperm, torch.randint, torch.Tensor.uniform_ = o
+from rng_inject import inject_rng   # noqa: E402
 
 
 def _setup(dev):
