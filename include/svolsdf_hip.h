@@ -58,10 +58,12 @@ size_t svs_pack_workspace_bytes(void);
  *
  * svs_sdf_vals: ImplicitNetwork.get_sdf_vals (volsdf/model/network.py:125-131) -> sdf (P).
  *   sphere clamp min(sdf, scale*(radius-|x|)) on points [0, clamp_n) (clamp_n < 0: all) when radius > 0.
- *   gate: optional device int; the launch does nothing when *gate == 0 (sampler rounds). */
+ *   gate: optional device flags, one per group of gate_points points (a multiple of 128; <= 0: one group), gate_stride
+ *   ints apart: the points of a group are skipped when its flag is 0 (sampler rounds, one flag per convergence
+ *   group of rays). */
 int svs_sdf_vals(const float* points, int n_points, const float* cam, int cam_stride, const float* dirs, const float* z,
                  int S, int n_rays, const float* stream, int precision, float sphere_radius, float sphere_scale,
-                 int clamp_n, float* sdf, const int* gate, void* hip_stream);
+                 int clamp_n, float* sdf, const int* gate, int gate_points, int gate_stride, void* hip_stream);
 /* svs_sdf_outputs: ImplicitNetwork.get_outputs (network.py:105-123) and .gradient (:90-103):
  *   sdf (P), grad = d sdf/dx (P,3), feat_tiles (svs_feat_tiles_bytes; wave-tile layout, may be NULL),
  *   hbuf (svs_sdf_hbuf_bytes): the activations h_1..h_8 kept for the gradient pass / training backward;
@@ -91,20 +93,24 @@ size_t svs_rgb_rbuf_bytes(int n_points_total);
  *   svs_sampler_init;  for round i < max_iters: svs_sdf_vals(samples -> samples_sdf, gate = ctl.active[i]),
  *   svs_sampler_round(phase 0), svs_sampler_round(phase 1);   max_iters == 0: svs_sampler_round(phase 2).
  * Buffers: z, sdf (n_rays, svs_sampler_cap()); samples, samples_sdf (n_rays, svs_sampler_max_new());
- * beta, far (n_rays); ctl (svs_sampler_ctl_bytes(): int conv_flag[8], active[8], final_round); err_flag (1 int,
+ * beta, far (n_rays); ctl (svs_sampler_ctl_bytes(n_rays, group_rays): per convergence group of group_rays rays
+ * (<= 0: all rays form one group) int conv_flag[8], active[8], final_round -- the reference tests convergence per
+ * forward call, i.e. per chunk of split_n_pixels rays; one launch can cover many chunks); err_flag (1 int,
  * set on a bounding-sphere miss).  Random draws (train mode) are inputs: jitter (n_rays,n_eval),
  * u_final (n_rays,n_final), extra_idx (n_extra int), eik_idx (n_rays int); NULL = eval mode.
  * beta0 = |*beta_param| + beta_min is read on the device (volsdf/model/density.py:28-30). */
-size_t svs_sampler_ctl_bytes(void);
+size_t svs_sampler_ctl_bytes(int n_rays, int group_rays);
+int svs_sampler_ctl_stride(void);   /* ints per group record; active[i] is int 8 + i of a record */
 int svs_sampler_cap(void);
 int svs_sampler_max_new(void);
 int svs_sampler_init(const float* cam, int cam_stride, const float* dirs, int n_rays, int n_eval, float near_, float far_,
                      int sphere_far, float sphere_radius, const float* jitter, float inv_4log, int max_iters,
-                     float* samples, float* beta, float* far_out, void* ctl, int* err_flag, void* hip_stream);
+                     float* samples, float* beta, float* far_out, void* ctl, int group_rays, int* err_flag,
+                     void* hip_stream);
 int svs_sampler_round(int phase, int n_rays, int round, int max_iters, int n_eval, int n_final, int n_extra,
                       const float* beta_param, float beta_min, float eps, int beta_iters, float add_tiny, float near_,
                       const float* far_, float* z, float* sdf, float* beta, float* samples, const float* samples_sdf,
-                      void* ctl, const float* u_final, const int* extra_idx, const int* eik_idx, float* z_final,
+                      void* ctl, int group_rays, const float* u_final, const int* extra_idx, const int* eik_idx, float* z_final,
                       float* z_eik, int* dbg_samples_idx, int* dbg_inds, float* dbg_cdf, float* dbg_weights,
                       void* hip_stream);
 

@@ -24,7 +24,7 @@ namespace mlp {
 // ImplicitNetwork.get_sdf_vals (network.py:125-131), no grad: the sampler's evaluation.
 __global__ __launch_bounds__(kThreads, 1) void sdf_only_kernel(SdfOnlyArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  if (a.gate && *a.gate == 0) return;
+  if (a.gate && a.gate[(size_t)(blockIdx.x * kWgPts / a.gate_points) * a.gate_stride] == 0) return;
   Stream st;
   st.g = a.stream;
   st.buf = reinterpret_cast<f32x4*>(smem);
@@ -293,12 +293,14 @@ extern "C" {
 
 int svs_sdf_vals(const float* points, int n_points, const float* cam, int cam_stride, const float* dirs, const float* z,
                  int S, int n_rays, const float* stream, int precision, float sphere_radius, float sphere_scale,
-                 int clamp_n, float* sdf, const int* gate, void* hip_stream) {
+                 int clamp_n, float* sdf, const int* gate, int gate_points, int gate_stride, void* hip_stream) {
   SdfOnlyArgs a;
   if (int rc = fill_src(a.src, points, n_points, cam, cam_stride, dirs, z, S, n_rays, "svs_sdf_vals")) return rc;
   if (!stream || !sdf) { set_error("svs_sdf_vals: null stream/sdf"); return SVS_EINVAL; }
   a.stream = reinterpret_cast<const f32x4*>(stream); a.sdf = sdf;
   a.sphere_radius = sphere_radius; a.sphere_scale = sphere_scale; a.gate = gate;
+  a.gate_points = gate_points > 0 ? gate_points : 0x7fffff80; a.gate_stride = gate_stride;
+  if (gate && a.gate_points % kWgPts) { set_error("svs_sdf_vals: gate_points must be a multiple of %d", kWgPts); return SVS_EINVAL; }
   a.clamp_n = clamp_n < 0 ? a.src.P : clamp_n;
   if (precision == kFmtF16x2) return launch_sdf_only_h2(a, (hipStream_t)hip_stream);
   if (precision != kFmtF32) { set_error("svs_sdf_vals: unknown precision %d", precision); return SVS_EINVAL; }

@@ -12,7 +12,10 @@ struct SdfOnlyArgs {
   float sphere_radius;   // <= 0: no clamp (network.py:128)
   float sphere_scale;
   int clamp_n;           // the clamp applies to points [0, clamp_n)
-  const int* gate;       // optional device flag: the launch is a no-op when *gate == 0 (sampler rounds)
+  const int* gate;       // optional device flags: the workgroup is a no-op when gate[(its first point / gate_points) *
+                         // gate_stride] == 0 (sampler rounds; one flag per convergence group of rays)
+  int gate_points;       // points per gate group (a multiple of the 128 points of a workgroup)
+  int gate_stride;       // ints between the flags of consecutive groups
 };
 
 struct SdfFullArgs {

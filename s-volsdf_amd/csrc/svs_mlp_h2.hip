@@ -126,7 +126,7 @@ __device__ __forceinline__ void forward_trunk_h2(Stream& st, Pieces2& x, Pieces2
 // ImplicitNetwork.get_sdf_vals (network.py:125-131), no grad: the sampler's evaluation.
 __global__ __launch_bounds__(kThreads, 1) void sdf_only_h2_kernel(SdfOnlyArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  if (a.gate && *a.gate == 0) return;
+  if (a.gate && a.gate[(size_t)(blockIdx.x * kWgPts / a.gate_points) * a.gate_stride] == 0) return;
   Stream st;
   st.g = a.stream;
   st.buf = reinterpret_cast<f32x4*>(smem);

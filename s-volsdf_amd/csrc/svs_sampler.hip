@@ -20,7 +20,8 @@ namespace sampler {
 constexpr int kCap = 768;     // max bins held per ray (N_samples_eval * (max_total_iters + 1) <= kCap)
 constexpr int kMaxNew = 128;  // max new samples per round (N_samples_eval)
 
-struct Ctl {            // device-side control block
+struct Ctl {            // device-side control block, one per group of rays (the reference decides "converged" per
+                        // forward call = per chunk of split_n_pixels rays; a launch can cover many such groups)
   int conv_flag[8];     // OR over rays of (beta > beta0) in round i
   int active[8];        // round i runs (0/1)
   int final_round;      // round whose B kernel produced the final samples (-1: none yet)
@@ -137,7 +138,8 @@ struct InitArgs {
   float* samples;             // out (R, kMaxNew): the uniform z (round-0 samples)
   float* beta;                // out (R): Lemma-2 bound
   float* far_out;             // out (R): far per ray (finalize needs it)
-  Ctl* ctl;
+  Ctl* ctl;                   // [ceil(R / group_rays)]
+  int group_rays;             // rays per convergence group
   int max_iters;
   int* err;                   // set to 1 on a bounding-sphere miss (the reference calls exit())
 };
@@ -146,10 +148,11 @@ __global__ __launch_bounds__(64) void init_kernel(InitArgs a) {
   __shared__ float zs[kMaxNew];
   __shared__ float ds[kMaxNew];
   const int r = blockIdx.x, lane = threadIdx.x;
-  if (r == 0 && lane < 8) {
-    a.ctl->conv_flag[lane] = 0;
-    a.ctl->active[lane] = (lane == 0 && a.max_iters > 0) ? 1 : 0;
-    if (lane == 0) a.ctl->final_round = -1;
+  if (r % a.group_rays == 0 && lane < 8) {
+    Ctl* c = a.ctl + r / a.group_rays;
+    c->conv_flag[lane] = 0;
+    c->active[lane] = (lane == 0 && a.max_iters > 0) ? 1 : 0;
+    if (lane == 0) c->final_round = -1;
   }
   float far = a.far;
   if (a.sphere_far) {
@@ -202,7 +205,8 @@ struct RoundArgs {
   float* beta;                 // (R)
   float* samples;              // (R, kMaxNew) new sample positions (in: round A; out: round B when up-sampling)
   const float* samples_sdf;    // (R, kMaxNew) sdf of `samples` (round A)
-  Ctl* ctl;
+  Ctl* ctl;                    // [ceil(R / group_rays)]
+  int group_rays;
   // final sampling
   const float* u_final;        // (R, n_final) train-mode draws or nullptr (linspace)
   const int* extra_idx;        // (n_extra) train-mode bins (randperm[:n_extra]) or nullptr (linspace idx)
@@ -221,7 +225,8 @@ struct RoundArgs {
 __global__ __launch_bounds__(64) void round_a_kernel(RoundArgs a) {
   __shared__ RayLds L;
   const int r = blockIdx.x, lane = threadIdx.x, i_round = a.round;
-  if (!a.ctl->active[i_round]) return;
+  Ctl* ctl = a.ctl + r / a.group_rays;
+  if (!ctl->active[i_round]) return;
   const int n_old = a.n_eval * i_round, n_new = a.n_eval, n = n_old + n_new;
   float* zrow = a.z + (size_t)r * kCap;
   float* srow = a.sdf + (size_t)r * kCap;
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(64) void round_a_kernel(RoundArgs a) {
   beta = bmax;
   if (lane == 0) {
     a.beta[r] = beta;
-    if (beta > beta0) atomicOr(&a.ctl->conv_flag[i_round], 1);
+    if (beta > beta0) atomicOr(&ctl->conv_flag[i_round], 1);
   }
 }
 
@@ -310,11 +315,12 @@ __device__ __forceinline__ void finalize(const RoundArgs& a, RayLds& L, int r, i
 __global__ __launch_bounds__(64) void round_b_kernel(RoundArgs a) {
   __shared__ RayLds L;
   const int r = blockIdx.x, lane = threadIdx.x, i_round = a.round;
-  if (!a.ctl->active[i_round]) return;
-  const bool upsample = a.ctl->conv_flag[i_round] != 0 && (i_round + 1 < a.max_iters);
-  if (r == 0 && lane == 0) {
-    a.ctl->active[i_round + 1] = upsample ? 1 : 0;
-    if (!upsample) a.ctl->final_round = i_round;
+  Ctl* ctl = a.ctl + r / a.group_rays;
+  if (!ctl->active[i_round]) return;
+  const bool upsample = ctl->conv_flag[i_round] != 0 && (i_round + 1 < a.max_iters);
+  if (r % a.group_rays == 0 && lane == 0) {
+    ctl->active[i_round + 1] = upsample ? 1 : 0;
+    if (!upsample) ctl->final_round = i_round;
   }
   const int n = a.n_eval * (i_round + 1);
   const float* zrow = a.z + (size_t)r * kCap;
@@ -415,13 +421,19 @@ using namespace svs::sampler;
 
 extern "C" {
 
-size_t svs_sampler_ctl_bytes(void) { return sizeof(Ctl); }
+size_t svs_sampler_ctl_bytes(int n_rays, int group_rays) {
+  const int g = group_rays > 0 ? group_rays : (n_rays > 0 ? n_rays : 1);
+  return (size_t)((n_rays + g - 1) / g) * sizeof(Ctl);
+}
+int svs_sampler_ctl_stride(void) { return (int)(sizeof(Ctl) / sizeof(int)); }
 int svs_sampler_cap(void) { return kCap; }
 int svs_sampler_max_new(void) { return kMaxNew; }
 
 int svs_sampler_init(const float* cam, int cam_stride, const float* dirs, int n_rays, int n_eval, float near_, float far_,
                      int sphere_far, float sphere_radius, const float* jitter, float inv_4log, int max_iters,
-                     float* samples, float* beta, float* far_out, void* ctl, int* err_flag, void* hip_stream) {
+                     float* samples, float* beta, float* far_out, void* ctl, int group_rays, int* err_flag,
+                     void* hip_stream) {
+  if (group_rays <= 0) group_rays = n_rays;
   if (!cam || !dirs || !samples || !beta || !far_out || !ctl || !err_flag || n_rays <= 0) {
     set_error("svs_sampler_init: null/invalid argument"); return SVS_EINVAL;
   }
@@ -430,7 +442,7 @@ int svs_sampler_init(const float* cam, int cam_stride, const float* dirs, int n_
     return SVS_ESHAPE;
   }
   InitArgs a{cam, cam_stride, dirs, n_rays, n_eval, near_, far_, sphere_far, sphere_radius, jitter, inv_4log,
-             samples, beta, far_out, (Ctl*)ctl, max_iters, err_flag};
+             samples, beta, far_out, (Ctl*)ctl, group_rays, max_iters, err_flag};
   init_kernel<<<n_rays, 64, 0, (hipStream_t)hip_stream>>>(a);
   return check_launch("svs_sampler_init");
 }
@@ -440,16 +452,17 @@ int svs_sampler_round(int phase, int n_rays, int round, int max_iters, int n_eva
                       const float* beta_param, float beta_min, float eps, int beta_iters, float add_tiny, float near_,
                       const float* far_,
                       float* z, float* sdf, float* beta, float* samples, const float* samples_sdf, void* ctl,
-                      const float* u_final, const int* extra_idx, const int* eik_idx, float* z_final, float* z_eik,
+                      int group_rays, const float* u_final, const int* extra_idx, const int* eik_idx, float* z_final, float* z_eik,
                       int* dbg_samples_idx, int* dbg_inds, float* dbg_cdf, float* dbg_weights, void* hip_stream) {
   if (!beta_param || !far_ || !z || !sdf || !beta || !samples || !ctl || !z_final || !z_eik || n_rays <= 0 || round < 0 || round > 6) {
     set_error("svs_sampler_round: null/invalid argument"); return SVS_EINVAL;
   }
+  if (group_rays <= 0) group_rays = n_rays;
   if (n_final > kMaxNew || n_final + n_extra + 2 > kCap || n_eval + n_extra + 2 > kCap) {
     set_error("svs_sampler_round: sample counts exceed kernel limits"); return SVS_ESHAPE;
   }
   RoundArgs a{n_rays, round, max_iters, n_eval, n_final, n_extra, beta_param, beta_min, eps, beta_iters, add_tiny, near_, far_,
-              z, sdf, beta, samples, samples_sdf, (Ctl*)ctl, u_final, extra_idx, eik_idx, z_final, z_eik,
+              z, sdf, beta, samples, samples_sdf, (Ctl*)ctl, group_rays, u_final, extra_idx, eik_idx, z_final, z_eik,
               dbg_samples_idx, dbg_inds, dbg_cdf, dbg_weights};
   hipStream_t s = (hipStream_t)hip_stream;
   if (phase == 0) {

@@ -36,7 +36,8 @@ SIGNATURES = {
     "svs_stream_bytes": (c_size_t, [c_int]),
     "svs_pack_stream": (c_int, [c_int, c_int, _PP, _PP, _PP, _P, _P, _P]),
     "svs_pack_workspace_bytes": (c_size_t, []),
-    "svs_sdf_vals": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, _P, c_int, c_float, c_float, c_int, _P, _P, _P]),
+    "svs_sdf_vals": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, _P, c_int, c_float, c_float, c_int, _P, _P,
+                             c_int, c_int, _P]),
     "svs_sdf_hbuf_bytes": (c_size_t, [c_int]),
     "svs_feat_tiles_bytes": (c_size_t, [c_int]),
     "svs_sdf_outputs": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, _P, c_int, c_float, c_float, c_int, _P, _P,
@@ -53,13 +54,14 @@ SIGNATURES = {
     "svs_sdf_bwd_b": (c_int, [c_int, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P]),
     "svs_lin8_row0_grad": (c_int, [_P, _P, _P, c_int, _P, _P]),
     "svs_unpack_wgrad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
-    "svs_sampler_ctl_bytes": (c_size_t, []),
+    "svs_sampler_ctl_bytes": (c_size_t, [c_int, c_int]),
+    "svs_sampler_ctl_stride": (c_int, []),
     "svs_sampler_cap": (c_int, []),
     "svs_sampler_max_new": (c_int, []),
     "svs_sampler_init": (c_int, [_P, c_int, _P, c_int, c_int, c_float, c_float, c_int, c_float, _P, c_float, c_int,
-                                 _P, _P, _P, _P, _P, _P]),
+                                 _P, _P, _P, _P, c_int, _P, _P]),
     "svs_sampler_round": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_float, c_float, c_int, c_float,
-                                  c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+                                  c_float, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "svs_composite": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P]),
     "svs_composite_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
     "svs_wgrad": (c_int, [_P, _P, ctypes.c_longlong, ctypes.c_longlong, _P, _P, ctypes.c_longlong, ctypes.c_longlong,

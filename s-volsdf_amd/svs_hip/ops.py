@@ -119,12 +119,14 @@ class PointSource:
         return (self.points if self.points is not None else self.z).device
 
 
-def sdf_vals(packed, src, sphere_radius, sphere_scale, out=None, gate=None, clamp_n=-1):
-    """ImplicitNetwork.get_sdf_vals (network.py:125-131) -> (P,1).  gate: optional device int (skip when 0)."""
+def sdf_vals(packed, src, sphere_radius, sphere_scale, out=None, gate=None, clamp_n=-1, gate_points=0, gate_stride=0):
+    """ImplicitNetwork.get_sdf_vals (network.py:125-131) -> (P,1).  gate: optional address of device int flags, one
+    per group of gate_points points (0: one group), gate_stride ints apart: groups whose flag is 0 are skipped."""
     L = _lib.load()
     sdf = out if out is not None else torch.empty(src.n, 1, device=src.device)
     _lib.check(L.svs_sdf_vals(*src.args(), _ptr(packed.sdf_stream), packed.precision, float(sphere_radius), float(sphere_scale),
-                              int(clamp_n), _ptr(sdf), ctypes.c_void_p(gate) if gate else None, _stream()), "svs_sdf_vals")
+                              int(clamp_n), _ptr(sdf), ctypes.c_void_p(gate) if gate else None, int(gate_points),
+                              int(gate_stride), _stream()), "svs_sdf_vals")
     return sdf
 
 
@@ -288,17 +290,20 @@ def loss_fwd_bwd(rgb_values, rgb_target, weights, depth_values, grad_theta=None,
 
 
 class SamplerWorkspace:
-    """Device buffers of the error-bounded sampler for R rays (allocated once, reused every step)."""
+    """Device buffers of the error-bounded sampler for R rays (allocated once, reused every step).
+    group_rays: rays per convergence group (None: the whole batch, what one reference forward call does)."""
 
-    def __init__(self, R, device):
+    def __init__(self, R, device, group_rays=None):
         L = _lib.load()
         self.R = R
+        self.group_rays = int(group_rays) if group_rays else R
         self.cap, self.max_new = L.svs_sampler_cap(), L.svs_sampler_max_new()
         f = lambda *s: torch.empty(*s, device=device)
         self.z, self.sdf = f(R, self.cap), f(R, self.cap)
         self.beta, self.far = f(R), f(R)
         self.samples, self.samples_sdf = f(R, self.max_new), f(R, self.max_new)
-        self.ctl = torch.zeros(L.svs_sampler_ctl_bytes() // 4, dtype=torch.int32, device=device)
+        self.ctl = torch.zeros(L.svs_sampler_ctl_bytes(R, self.group_rays) // 4, dtype=torch.int32, device=device)
+        self.ctl_stride = L.svs_sampler_ctl_stride()
         self.err = torch.zeros(1, dtype=torch.int32, device=device)
 
 
@@ -335,8 +340,8 @@ def sample_rays(packed, cam, dirs, beta_param, *, beta_min=1e-4, near, scene_bou
     jitter = _f32(rng["jitter"]) if training and "jitter" in rng else None
     _lib.check(L.svs_sampler_init(_ptr(cam), cam_stride, _ptr(dirs), R, N_samples_eval, float(near), float(far),
                                   int(inverse_sphere_bg), float(scene_bounding_sphere), _ptr(jitter), float(inv_4log),
-                                  max_iters, _ptr(ws.samples), _ptr(ws.beta), _ptr(ws.far), _ptr(ws.ctl), _ptr(ws.err),
-                                  _stream()), "svs_sampler_init")
+                                  max_iters, _ptr(ws.samples), _ptr(ws.beta), _ptr(ws.far), _ptr(ws.ctl), ws.group_rays,
+                                  _ptr(ws.err), _stream()), "svs_sampler_init")
     n_out = (N_samples if max_iters > 0 else N_samples_eval) + N_samples_extra + 2
     z_final = torch.empty(R, n_out, device=dev)
     z_eik = torch.empty(R, 1, device=dev)
@@ -348,7 +353,7 @@ def sample_rays(packed, cam, dirs, beta_param, *, beta_min=1e-4, near, scene_bou
         _lib.check(L.svs_sampler_round(phase, R, i, max_iters, N_samples_eval, N_samples, N_samples_extra, _ptr(beta_param),
                                        float(beta_min), float(eps), beta_iters, float(add_tiny), float(near), _ptr(ws.far), _ptr(ws.z),
                                        _ptr(ws.sdf), _ptr(ws.beta), _ptr(ws.samples), _ptr(ws.samples_sdf), _ptr(ws.ctl),
-                                       _ptr(u_final), _ptr(extra_idx), _ptr(eik_idx), _ptr(z_final), _ptr(z_eik),
+                                       ws.group_rays, _ptr(u_final), _ptr(extra_idx), _ptr(eik_idx), _ptr(z_final), _ptr(z_eik),
                                        _ptr(dbg.get("samples_idx")), _ptr(dbg.get("inds")), _ptr(dbg.get("cdf")),
                                        _ptr(dbg.get("weights")), _stream()), "svs_sampler_round")
 
@@ -369,8 +374,9 @@ def sample_rays(packed, cam, dirs, beta_param, *, beta_min=1e-4, near, scene_bou
         else:
             if src is None:
                 raise NotImplementedError("N_samples_eval must equal the kernel's row stride (128)")
-            gate = ws.ctl.data_ptr() + 4 * (8 + i)          # Ctl.active[i]
-            sdf_vals(packed, src, sdf_clamp_radius, sphere_scale, out=ws.samples_sdf, gate=gate)
+            gate = ws.ctl.data_ptr() + 4 * (8 + i)          # Ctl.active[i] of group 0
+            sdf_vals(packed, src, sdf_clamp_radius, sphere_scale, out=ws.samples_sdf, gate=gate,
+                     gate_points=ws.group_rays * N_samples_eval, gate_stride=ws.ctl_stride)
         call(0, i, dbg)
         call(1, i, dbg)
         if debug is not None:

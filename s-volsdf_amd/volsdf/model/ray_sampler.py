@@ -127,9 +127,12 @@ class ErrorBoundSampler(RaySampler):
             rng = None
         if not hasattr(self, "_ws_by_R"):
             self._ws_by_R = {}
-        key = (R, str(dev), torch.cuda.current_stream().cuda_stream)
+        # group_rays: rays per convergence group (None: the batch of this call, as in the reference; the image
+        # renderer sets it to split_n_pixels so that one large launch reproduces the reference's per-chunk decisions)
+        group = getattr(self, "group_rays", None)
+        key = (R, str(dev), torch.cuda.current_stream().cuda_stream, group)
         if key not in self._ws_by_R:
-            self._ws_by_R[key] = ops.SamplerWorkspace(R, dev)
+            self._ws_by_R[key] = ops.SamplerWorkspace(R, dev, group_rays=group)
         self._ws = self._ws_by_R[key]
         net = model.implicit_network
         z, z_eik = ops.sample_rays(model.packed_mlp(), cam_loc, ray_dirs, model.density.beta, beta_min=model.density.beta_min_value, near=self.near,
