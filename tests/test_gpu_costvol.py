@@ -132,3 +132,36 @@ def test_config3_sizes_run(dev):
     v1 = costvol.warp_variance(f1, sample["proj_matrices"]["stage1"], dv)
     v2 = costvol.warp_variance([2.0 * f for f in f1], sample["proj_matrices"]["stage1"], dv)
     np.testing.assert_allclose(v2.cpu().numpy(), 4.0 * v1.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_stage_loop_feature_cache(dev):
+    """runner.py:178-243 through svs_hip.stage_loop.StageLoop: three reference views x three stages with the images'
+    features extracted once each (3 calls instead of 27), identical outputs to the uncached loop, and the depth
+    hand-off between stages."""
+    from svs_hip.stage_loop import StageLoop
+    torch.manual_seed(0)
+    m = _model(dev, [16, 8, 8])
+    H, W = 64, 96
+    rng = np.random.default_rng(3)
+    images = [torch.from_numpy(rng.uniform(0, 1, (1, 3, H, W)).astype(F32)).to(dev) for _ in range(3)]
+    _, proj, depth_values = synth.make_mvs_sample(11, img_hw=(H, W))
+    samples = []
+    for ref in range(3):
+        order = [ref] + [v for v in range(3) if v != ref]
+        # fresh tensors every time, as a data loader would hand them out
+        samples.append(dict(imgs=torch.stack([images[v].clone() for v in order], 1), depth_values=G(depth_values, dev)[None],
+                            proj_matrices={k: G(v, dev)[None] for k, v in proj.items()}))
+    results = {}
+    for cached in (True, False):
+        loop = StageLoop(m, cache_features=cached)
+        outs = [None] * 3
+        for st in range(3):
+            outs, _ = loop.cost_volumes(st, samples, outs)
+            depths = [o[f"stage{st + 1}"]["depth"] * 1.01 for o in outs]      # stands in for the rendered depths
+            outs = StageLoop.hand_off_depth(outs, st, depths)
+            assert all(o["depth"] is d for o, d in zip(outs, depths))
+        results[cached] = (loop.feature_calls, [o["stage3"]["depth"].cpu().numpy() for o in outs],
+                           [o["stage3"]["photometric_confidence"].cpu().numpy() for o in outs])
+    assert results[True][0] == 3 and results[False][0] == 27
+    for a, b in zip(results[True][1] + results[True][2], results[False][1] + results[False][2]):
+        assert np.array_equal(a, b)
