@@ -684,6 +684,118 @@ def render_forward(params, uv, pose, K, *, beta_param, fast=-1, training=False, 
 
 
 # ----------------------------------------------------------------------------------------
+# a9 (BG)  VolSDFNetworkBG.forward    volsdf/model/network_bg.py:37-214
+# ----------------------------------------------------------------------------------------
+def depth2pts_outside(ray_o, ray_d, depth, r):
+    """network_bg.py:182-214 (NeRF++ inverted sphere): ray_o, ray_d (..., 3), depth (...) = 1 / distance to the
+    origin in [0, 1/r]  ->  pts (..., 4) = (unit direction of the point, depth), depth_real (...)."""
+    ray_o, ray_d, depth = np.asarray(ray_o, F32), np.asarray(ray_d, F32), np.asarray(depth, F32)
+    o_dot_d = (ray_d * ray_o).sum(-1, dtype=F32)
+    under_sqrt = (o_dot_d ** 2 - ((ray_o ** 2).sum(-1, dtype=F32) - F32(r) ** 2)).astype(F32)
+    d_sphere = (np.sqrt(under_sqrt) - o_dot_d).astype(F32)
+    p_sphere = (ray_o + d_sphere[..., None] * ray_d).astype(F32)
+    p_mid = (ray_o - o_dot_d[..., None] * ray_d).astype(F32)
+    p_mid_norm = np.sqrt((p_mid * p_mid).sum(-1, dtype=F32)).astype(F32)
+    rot_axis = np.cross(ray_o, p_sphere).astype(F32)
+    rot_axis = (rot_axis / np.sqrt((rot_axis * rot_axis).sum(-1, keepdims=True, dtype=F32))).astype(F32)
+    phi = np.arcsin(p_mid_norm / F32(r)).astype(F32)
+    theta = np.arcsin(p_mid_norm * depth).astype(F32)
+    rot_angle = (phi - theta)[..., None].astype(F32)
+    c, sn = np.cos(rot_angle).astype(F32), np.sin(rot_angle).astype(F32)
+    p_new = (p_sphere * c + np.cross(rot_axis, p_sphere).astype(F32) * sn
+             + rot_axis * (rot_axis * p_sphere).sum(-1, keepdims=True, dtype=F32) * (F32(1.0) - c)).astype(F32)
+    p_new = (p_new / np.sqrt((p_new * p_new).sum(-1, keepdims=True, dtype=F32))).astype(F32)
+    pts = np.concatenate([p_new, depth[..., None]], -1).astype(F32)
+    d1 = (-o_dot_d / (ray_d * ray_d).sum(-1, dtype=F32)).astype(F32)
+    ray_d_cos = (F32(1.0) / np.sqrt((ray_d * ray_d).sum(-1, dtype=F32))).astype(F32)
+    depth_real = (F32(1.0) / (depth + F32(1e-6)) * np.cos(theta).astype(F32) * ray_d_cos + d1).astype(F32)
+    return pts, depth_real
+
+
+def fg_weights_bg_model(z, z_max, sdf, beta):
+    """VolSDFNetworkBG.volume_rendering, network_bg.py:147-164: the last interval ends at the sphere exit z_max;
+    returns weights (R,S), bg_transmittance (R,) = transmittance behind the last sample."""
+    sigma = laplace_density(sdf, F32(beta))
+    dists = np.concatenate([z[:, 1:] - z[:, :-1], z_max[:, None] - z[:, -1:]], -1).astype(F32)
+    free = (dists * sigma).astype(F32)
+    shifted = np.concatenate([np.zeros((z.shape[0], 1), F32), free], -1)
+    alpha = (F32(1.0) - det_exp(-free)).astype(F32)
+    trans = det_exp(-canon_cumsum(shifted))
+    return (alpha * trans[:, :-1]).astype(F32), trans[:, -1].astype(F32), dists
+
+
+def bg_weights(z_bg, bg_sigma):
+    """bg_volume_rendering, network_bg.py:166-180; z_bg (R,N) descending inverse depths, bg_sigma (R,N) = |sdf|."""
+    dists = np.concatenate([z_bg[:, :-1] - z_bg[:, 1:], np.full((z_bg.shape[0], 1), 1e10, F32)], -1).astype(F32)
+    free = (dists * bg_sigma).astype(F32)
+    shifted = np.concatenate([np.zeros((z_bg.shape[0], 1), F32), free[:, :-1]], -1)
+    alpha = (F32(1.0) - det_exp(-free)).astype(F32)
+    trans = det_exp(-canon_cumsum(shifted))
+    return (alpha * trans).astype(F32)
+
+
+def render_forward_bg(params, uv, pose, K, *, beta_param, fast=-1, training=False, rng=None, near_pose=None,
+                      scene_bounding_sphere=3.0, trace=None):
+    """VolSDFNetworkBG.forward (network_bg.py:37-145) with the bmvs.yaml configuration."""
+    r = scene_bounding_sphere
+    sdf_layers = effective_weights(params, "implicit_network", 9)
+    rgb_layers = effective_weights(params, "rendering_network", 5)
+    bg_sdf_layers = effective_weights(params, "bg_implicit_network", 9)
+    bg_rgb_layers = effective_weights(params, "bg_rendering_network", 2)
+    beta = get_beta(beta_param)
+    dirs, cam, depth_scale = rays_from_uv(uv, pose, K)
+    R = dirs.shape[0]
+    cam_r = np.repeat(cam[None], R, 0)
+    sdf_fn = lambda p: sdf_vals(sdf_layers, p, 0.0, 1.0)
+    (z_all, z_bg), z_eik = error_bound_sampler(sdf_fn, dirs, cam_r, beta, near=0.0, scene_bounding_sphere=r, fast=fast,
+                                               training=training, rng=rng, inverse_sphere_bg=True,
+                                               N_samples_inverse_sphere=32, add_tiny=1e-6, trace=trace)
+    z_max, z = z_all[:, -1], z_all[:, :-1]
+    S = z.shape[1]
+    points = (cam_r[:, None, :] + z[:, :, None] * dirs[:, None, :]).astype(F32)
+    pf = points.reshape(-1, 3)
+    sdf, feat, grad = sdf_outputs(sdf_layers, pf, 0.0, 1.0)
+    view = dirs
+    if not training:
+        view = rays_from_uv(uv, near_pose, K)[0]
+    rgb = rgb_mlp_forward(rgb_layers, pf, grad, np.repeat(view[:, None, :], S, 1).reshape(-1, 3), feat).reshape(R, S, 3)
+    weights, bg_trans, _ = fg_weights_bg_model(z, z_max, sdf.reshape(R, S), beta)
+    fg_rgb = (weights[:, :, None] * rgb).sum(1, dtype=F32)
+    # background
+    z_bg = z_bg[:, ::-1].copy()                      # 1 -> 0
+    Nb = z_bg.shape[1]
+    bg_pts, bg_depth = depth2pts_outside(np.repeat(cam_r[:, None, :], Nb, 1), np.repeat(dirs[:, None, :], Nb, 1), z_bg, r)
+    bg_out = sdf_mlp_forward(bg_sdf_layers, bg_pts.reshape(-1, 4), multires=10)
+    bg_sigma = np.abs(bg_out[:, :1]).astype(F32)
+    bg_rgb = rgb_mlp_forward(bg_rgb_layers, None, None, np.repeat(view[:, None, :], Nb, 1).reshape(-1, 3), bg_out[:, 1:],
+                             mode="nerf", multires_view=4).reshape(R, Nb, 3)
+    bw = bg_weights(z_bg, bg_sigma.reshape(R, Nb))
+    bg_rgb_values = (bw[:, :, None] * bg_rgb).sum(1, dtype=F32)
+    weights_all = np.concatenate([weights, bg_trans[:, None] * bw], 1).astype(F32)
+    depth_vals_all = (depth_scale * np.concatenate([z, bg_depth], 1)).astype(F32)
+    out = {
+        "rgb_values": (fg_rgb + bg_trans[:, None] * bg_rgb_values).astype(F32),
+        "depth_values_all": ((weights_all * depth_vals_all).sum(1, keepdims=True, dtype=F32)
+                             / (weights_all.sum(1, keepdims=True, dtype=F32) + F32(1e-8))).astype(F32),
+        "depth_vals": (z * depth_scale).astype(F32),
+        "weights": weights,
+        "xyz": points,
+    }
+    out["depth_values"] = ((weights * out["depth_vals"]).sum(1, keepdims=True, dtype=F32)
+                           / (weights.sum(1, keepdims=True, dtype=F32) + F32(1e-8))).astype(F32)
+    out.update(z_vals=z, z_max=z_max, z_bg=z_bg, bg_points=bg_pts, bg_depth=bg_depth, bg_sigma=bg_sigma.reshape(R, Nb),
+               bg_rgb=bg_rgb, bg_weights=bw, bg_transmittance=bg_trans, sdf=sdf.reshape(R, S))
+    if training:
+        eik_near = (cam_r[:, None, :] + z_eik[:, :, None] * dirs[:, None, :]).reshape(-1, 3).astype(F32)
+        eik = np.concatenate([np.asarray(rng["eik_points"], F32), eik_near], 0)
+        out["grad_theta"] = sdf_outputs(sdf_layers, eik, 0.0, 1.0, clamp=False)[2]
+    else:
+        nrm = np.sqrt((grad * grad).sum(-1, keepdims=True, dtype=F32)).astype(F32)
+        out["normal_map"] = (weights[:, :, None] * (grad / nrm).reshape(R, S, 3)).sum(1, dtype=F32)
+    return out
+
+
+# ----------------------------------------------------------------------------------------
 # a10  MVS prior lookup     volsdf/vsdf.py:382-452 (VolOpt.cost_mapping)
 # ----------------------------------------------------------------------------------------
 def _grid_sample_zeros(vol, coords):

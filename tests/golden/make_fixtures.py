@@ -266,6 +266,53 @@ def fx_forward():
          **{k: v.detach().numpy() for k, v in out.items()})
 
 
+def build_bg_model(params, beta):
+    from volsdf.model.network_bg import VolSDFNetworkBG
+    m = VolSDFNetworkBG(ref_shim.bmvs_model_conf())
+    sd = {k: T(v).clone() for k, v in params.items()}
+    sd["density.beta"] = torch.tensor(beta, dtype=torch.float32)
+    m.load_state_dict(sd, strict=True)
+    return m
+
+
+def fx_forward_bg():
+    """VolSDFNetworkBG.forward (config 4: fg + inverted-sphere bg), eval (with near_pose) and train mode, with the
+    intermediate background quantities captured."""
+    params = dict(synth.make_params(seed=0))
+    params.update(synth.make_bg_params(seed=0))
+    K, pose = synth.make_camera(center=(0.1, 0.05, -2.5), tilt=0.1, skew=0.7)
+    _, near_pose = synth.make_camera(center=(0.25, 0.0, -2.45), tilt=0.05)
+    R = 12
+    uv = synth.make_uv(R, seed=3, margin=0.1)
+    for tag, beta, fast, training in (("eval_b0.1", 0.1, -1, False), ("eval_b0.01", 0.01, -1, False), ("train", 0.05, 1, True)):
+        m = build_bg_model(params, beta)
+        m.train(training)
+        cap = {}
+        o_d2p, o_bgvr, o_vr = m.depth2pts_outside, m.bg_volume_rendering, m.volume_rendering
+
+        def d2p(o, d, depth):
+            r = o_d2p(o, d, depth); cap["z_bg"] = depth.detach().numpy().copy()
+            cap["bg_points"], cap["bg_depth"] = r[0].detach().numpy().copy(), r[1].detach().numpy().copy(); return r
+
+        def bgvr(z, s):
+            r = o_bgvr(z, s); cap["bg_sdf"] = s.detach().numpy().copy(); cap["bg_weights"] = r.detach().numpy().copy(); return r
+
+        def vr(z, zmax, sdf):
+            r = o_vr(z, zmax, sdf); cap["z_vals"], cap["z_max"] = z.detach().numpy().copy(), zmax.detach().numpy().copy()
+            cap["bg_transmittance"] = r[1].detach().numpy().copy(); return r
+
+        m.depth2pts_outside, m.bg_volume_rendering, m.volume_rendering = d2p, bgvr, vr
+        inp = {"intrinsics": T(K)[None], "uv": T(uv)[None], "pose": T(pose)[None], "near_pose": T(near_pose)[None]}
+        if training:
+            draws = synth.make_train_rng(R, seed=6, n_final=98, bg=True)
+            with inject_rng(draws):
+                out = m(inp, fast=fast)
+        else:
+            out = m(inp, fast=fast)
+        save(f"forward_bg_{tag}", K=K, pose=pose, near_pose=near_pose, uv=uv, beta_param=F32(beta), fast=fast, rng_seed=6,
+             **{k: v.detach().numpy() for k, v in out.items()}, **cap)
+
+
 def fx_cost_mapping():
     from volsdf.vsdf import VolOpt
     rng = np.random.default_rng(21)
@@ -457,7 +504,7 @@ def fx_train_step():
 
 
 ALL = dict(rays=fx_rays, sdf_mlp=fx_sdf_mlp, rgb_mlp=fx_rgb_mlp, density=fx_density, sampler=fx_sampler,
-           composite=fx_composite, forward=fx_forward, cost_mapping=fx_cost_mapping, loss=fx_loss, casmvs=fx_casmvs, train_step=fx_train_step)
+           composite=fx_composite, forward=fx_forward, forward_bg=fx_forward_bg, cost_mapping=fx_cost_mapping, loss=fx_loss, casmvs=fx_casmvs, train_step=fx_train_step)
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(ALL)

@@ -87,3 +87,23 @@ def dtu_model_conf(near=1e-4, beta=0.1):
         ray_sampler=dict(near=near, N_samples=64, N_samples_eval=128, N_samples_extra=32,
                          eps=0.1, beta_iters=10, max_total_iters=5),
     )
+
+
+def bmvs_model_conf(beta=0.1):
+    """Values of config/vol/bmvs.yaml:26-77 (the fg + inverted-sphere bg model, VolSDFNetworkBG)."""
+    return DictConf(
+        feature_vector_size=256,
+        scene_bounding_sphere=3.0,
+        implicit_network=dict(d_in=3, d_out=1, dims=[256] * 8, geometric_init=True, bias=0.6,
+                              skip_in=[4], weight_norm=True, multires=6),
+        rendering_network=dict(mode="idr", d_in=9, d_out=3, dims=[256] * 4, weight_norm=True, multires_view=1),
+        density=dict(params_init=dict(beta=beta), beta_min=0.0001),
+        ray_sampler=dict(near=0.0, N_samples=64, N_samples_eval=128, N_samples_extra=32, eps=0.1, beta_iters=10,
+                         max_total_iters=5, N_samples_inverse_sphere=32, add_tiny=1.0e-6),
+        bg_network=dict(
+            feature_vector_size=256,
+            implicit_network=dict(d_in=4, d_out=1, dims=[256] * 8, geometric_init=False, bias=0.0, skip_in=[4],
+                                  weight_norm=False, multires=10),
+            rendering_network=dict(mode="nerf", d_in=3, d_out=3, dims=[128], weight_norm=False, multires_view=4),
+        ),
+    )

@@ -58,6 +58,30 @@ def make_params(seed=0, trained=True):
     return p
 
 
+BG_SDF_DIMS = [84, 256, 256, 256, 256, 256, 256, 256, 256, 257]     # lin3 emits 256 - 84 = 172 rows (skip at 4)
+
+
+def make_bg_params(seed=0):
+    """State-dict-named float32 arrays of the inverted-sphere background networks of VolSDFNetworkBG (563 504
+    parameters): bg_implicit_network (4-D points, PE-10, no weight-norm, no geometric init) and
+    bg_rendering_network (mode 'nerf': PE-4 view dirs + feature -> 128 -> 3).  nn.Linear's default initialisation
+    (uniform +-1/sqrt(fan_in)), with the last implicit layer scaled up so that densities and features are O(1)."""
+    rng = np.random.default_rng(seed + 77)
+    p = {}
+    for l in range(9):
+        d_in = BG_SDF_DIMS[l]
+        d_out = BG_SDF_DIMS[l + 1] - (84 if l + 1 == 4 else 0)
+        k = 1.0 / np.sqrt(d_in)
+        gain = np.sqrt(6.0) if l < 8 else 4.0
+        p[f"bg_implicit_network.lin{l}.weight"] = (gain * rng.uniform(-k, k, (d_out, d_in))).astype(F32)
+        p[f"bg_implicit_network.lin{l}.bias"] = rng.uniform(-k, k, d_out).astype(F32)
+    for l, (d_in, d_out) in enumerate(((283, 128), (128, 3))):
+        k = 1.0 / np.sqrt(d_in)
+        p[f"bg_rendering_network.lin{l}.weight"] = (np.sqrt(3.0) * rng.uniform(-k, k, (d_out, d_in))).astype(F32)
+        p[f"bg_rendering_network.lin{l}.bias"] = rng.uniform(-k, k, d_out).astype(F32)
+    return p
+
+
 def make_camera(res_hw=(576, 768), skew=0.0, center=(0.0, 0.0, -2.5), tilt=0.0):
     """Pin-hole K (4,4) and camera-to-world pose (4,4) looking at the origin."""
     h, w = res_hw
@@ -85,9 +109,17 @@ def make_uv(n, seed=0, res_hw=(576, 768), margin=0.25):
     return uv[:n].astype(F32)
 
 
-def make_train_rng(R, seed=0, n_bins=128, n_final=98):
-    """The train-mode random draws of SURVEY.md note R as explicit arrays (numpy, seeded)."""
+def make_train_rng(R, seed=0, n_bins=128, n_final=98, bg=False):
+    """The train-mode random draws of SURVEY.md note R as explicit arrays (numpy, seeded).  bg: adds the jitter of the
+    inverse-sphere sampler (rand(R,32), drawn after the eikonal-sample pick, ray_sampler.py:215)."""
     rng = np.random.default_rng(seed + 2000)
+    d = _train_rng(rng, R, n_bins, n_final)
+    if bg:
+        d["jitter_bg"] = rng.random((R, 32), dtype=F32)
+    return d
+
+
+def _train_rng(rng, R, n_bins, n_final):
     return {
         "jitter": rng.random((R, 128), dtype=F32),
         "u": rng.random((R, 64), dtype=F32),

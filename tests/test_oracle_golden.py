@@ -223,6 +223,46 @@ def test_forward(golden_dir, tag):
         np.testing.assert_allclose(out["normal_map"][same], g["normal_map"][same], atol=2e-4)
 
 
+@pytest.mark.parametrize("tag", ["eval_b0.1", "eval_b0.01", "train"])
+def test_forward_bg(golden_dir, tag):
+    """VolSDFNetworkBG.forward (fg + inverted-sphere background, config 4) of the reference against the oracle:
+    the background pieces on the reference's own inputs, then the whole forward."""
+    g = load(golden_dir, "forward_bg_" + tag)
+    params = dict(synth.make_params(0)); params.update(synth.make_bg_params(0))
+    training = tag == "train"
+    R = g["uv"].shape[0]
+    # background pieces on the fixture's inverse depths
+    dirs, cam, _ = orc.rays_from_uv(g["uv"], g["pose"], g["K"])
+    Nb = g["z_bg"].shape[1]
+    pts, dreal = orc.depth2pts_outside(np.repeat(cam[None, None], R, 0).repeat(Nb, 1), np.repeat(dirs[:, None], Nb, 1),
+                                       g["z_bg"], 3.0)
+    np.testing.assert_allclose(pts, g["bg_points"], atol=2e-6)
+    np.testing.assert_allclose(dreal, g["bg_depth"], rtol=2e-5)
+    bg_out = orc.sdf_mlp_forward(orc.effective_weights(params, "bg_implicit_network", 9), g["bg_points"].reshape(-1, 4),
+                                 multires=10)
+    np.testing.assert_allclose(bg_out[:, :1], g["bg_sdf"], atol=2e-5)
+    bw = orc.bg_weights(g["z_bg"], np.abs(g["bg_sdf"]).reshape(R, Nb))
+    np.testing.assert_allclose(bw, g["bg_weights"], atol=2e-6)
+    # whole forward
+    rng = synth.make_train_rng(R, seed=int(g["rng_seed"]), bg=True) if training else None
+    out = orc.render_forward_bg(params, g["uv"], g["pose"], g["K"], beta_param=g["beta_param"], fast=int(g["fast"]),
+                                training=training, rng=rng, near_pose=g["near_pose"])
+    np.testing.assert_allclose(out["z_bg"], g["z_bg"], atol=1e-7)
+    np.testing.assert_allclose(out["z_max"], g["z_max"], atol=2e-6)
+    same = np.abs(out["depth_vals"] - g["depth_vals"]).max(-1) < 3e-4
+    assert same.mean() >= 0.75, same
+    np.testing.assert_allclose(out["weights"][same], g["weights"][same], atol=2e-3)
+    np.testing.assert_allclose(out["bg_transmittance"][same], g["bg_transmittance"][same], atol=2e-4)
+    np.testing.assert_allclose(out["rgb_values"], g["rgb_values"], atol=3e-4)
+    np.testing.assert_allclose(out["depth_values"][same], g["depth_values"][same], atol=2e-4)
+    # the background depths reach 1e6 (1 / (depth + 1e-6)): small weight differences move this mean visibly
+    np.testing.assert_allclose(out["depth_values_all"][same], g["depth_values_all"][same], rtol=3e-3)
+    if training:
+        np.testing.assert_allclose(out["grad_theta"][:R], g["grad_theta"][:R], atol=1e-4)
+    else:
+        np.testing.assert_allclose(out["normal_map"][same], g["normal_map"][same], atol=2e-4)
+
+
 @pytest.mark.parametrize("name", ["cost_mapping_inv0_v0", "cost_mapping_inv0_v2", "cost_mapping_inv1_v0",
                                   "cost_mapping_inv1_v2"])
 def test_cost_mapping(golden_dir, name):
