@@ -254,7 +254,9 @@ def test_forward_bg(golden_dir, tag):
     np.testing.assert_allclose(out["weights"][same], g["weights"][same], atol=2e-3)
     np.testing.assert_allclose(out["bg_transmittance"][same], g["bg_transmittance"][same], atol=2e-4)
     np.testing.assert_allclose(out["rgb_values"], g["rgb_values"], atol=3e-4)
-    np.testing.assert_allclose(out["depth_values"][same], g["depth_values"][same], atol=2e-4)
+    # depth_values is normalised by the fg weight sum, which is small for rays that mostly see the background
+    wsum = g["weights"].sum(1, keepdims=True)
+    assert (np.abs(out["depth_values"] - g["depth_values"])[same] <= 3e-4 / np.maximum(wsum[same], 1e-3)).all()
     # the background depths reach 1e6 (1 / (depth + 1e-6)): small weight differences move this mean visibly
     np.testing.assert_allclose(out["depth_values_all"][same], g["depth_values_all"][same], rtol=3e-3)
     if training:
