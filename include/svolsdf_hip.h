@@ -39,7 +39,7 @@ int svs_rays_from_uv(const float* uv, const float* pose, const float* intrinsics
  * device pointers in layer order, shapes as in the checkpoint (`implicit_network.lin{l}.weight_v` ...);
  * weight_g == NULL for networks without weight-norm.  workspace: svs_pack_workspace_bytes().
  * which: 0 SDF forward, 1 SDF full (forward + feature head + input-gradient pass), 2 SDF training backward,
- *        3 radiance forward, 4 radiance backward.  The first svs_pack_stream call per `which` uploads a 2 KiB chunk
+ *        3 radiance forward, 4 radiance backward (5..8: the background networks, see below).  The first svs_pack_stream call per `which` uploads a 2 KiB chunk
  * table (one hipMalloc + hipMemcpy; make that call outside graph capture).
  * precision: how the kernels that consume the stream evaluate the layer products (the same value is passed to them):
  *   SVS_MMA_F32   v_mfma_f32_32x32x2_f32 on float32 operands (exact float32 products);
@@ -129,6 +129,30 @@ int svs_composite_bwd(int n_rays, int n_samples, const float* z, const float* sd
                       const float* depth_scale, const float* beta_param, float beta_min, const float* d_rgb_values,
                       const float* d_weights, const float* d_depth_values, float* d_sdf, float* d_rgb,
                       float* d_beta_ray, float* d_beta_param, void* hip_stream);
+
+/* ---- a9 (config 4)  inverted-sphere background model, VolSDFNetworkBG (volsdf/model/network_bg.py) -----------
+ * fp16x2 only.  Streams: svs_pack_stream which = 5 (bg implicit forward), 6 (bg implicit backward), 7 (bg radiance
+ * forward), 8 (bg radiance backward); weight arrays of 9 / 2 device pointers, weight_g = NULL (no weight-norm).
+ *   svs_bg_points     UniformSampler(1,0,n_bg,far=1) * (1/radius), flipped (ray_sampler.py:22-43,215-216;
+ *                     network_bg.py:79-82) + depth2pts_outside (:182-214): jitter (n_rays,n_bg) train draws or NULL
+ *                     -> z_bg (n_rays,n_bg), pts (n_rays*n_bg,4), depth_real (n_rays,n_bg)
+ *   svs_bg_sdf_eval   bg_implicit_network (:85-88): pts (P,4) -> out0 (P) = output[:,0] (density = |out0|),
+ *                     feat_tiles; training: hbuf (svs_sdf_hbuf_bytes) + ghat7 (svs_block_bytes(P,1)), both or neither
+ *   svs_bg_rgb_eval   bg_rendering_network, mode 'nerf' (:91-93): view_dirs (n_rays,3) with view_S points per ray
+ *                     (or (P,3) with view_S = 0) -> rgb (P,3); rbuf (svs_bg_rbuf_bytes, training) or NULL
+ *   svs_composite_bg  volume_rendering / bg_volume_rendering and the composition (:76-125,147-180) */
+int svs_bg_points(const float* cam, int cam_stride, const float* dirs, int n_rays, int n_bg, const float* jitter,
+                  float radius, float* z_bg, float* pts, float* depth_real, void* hip_stream);
+int svs_bg_sdf_eval(const float* pts, int n_points, const float* stream, float* out0, float* feat_tiles, float* hbuf,
+                    float* ghat7, void* hip_stream);
+size_t svs_bg_rbuf_bytes(int n_points);
+int svs_bg_rgb_eval(int n_points, const float* view_dirs, int view_S, const float* feat_tiles, const float* stream,
+                    float* rgb, float* rbuf, void* hip_stream);
+int svs_composite_bg(int n_rays, int n_samples, int n_bg, const float* z, const float* z_max, const float* sdf,
+                     const float* rgb, const float* normals, const float* depth_scale, const float* beta_param,
+                     float beta_min, const float* z_bg, const float* bg_out0, const float* bg_rgb, const float* bg_depth,
+                     float* weights, float* bg_trans, float* bg_weights, float* rgb_values, float* depth_values,
+                     float* depth_values_all, float* depth_vals, float* normal_map, void* hip_stream);
 
 /* ---- a12  weight-gradient contraction of the training backward ---------------------------------------------------
  * dW[256][ldw] += sum over points of A(:,p) B(:,p)^T for one or two operand pairs stored as wave-tile activation

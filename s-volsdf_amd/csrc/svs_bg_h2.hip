@@ -1,0 +1,246 @@
+// The inverted-sphere background networks of VolSDFNetworkBG (volsdf/model/network_bg.py:31-35, 85-103) on fp16x2
+// MFMAs: bg_implicit_network (4-D points, PE-10 = 84 inputs, 8 x 256 softplus, skip at 4, no weight-norm; output =
+// [density logit, 256 features]) and bg_rendering_network (mode 'nerf': cat[PE4(view)(27), feature(256)] -> 128 ReLU
+// -> 3 sigmoid).  Same machinery as svs_mlp_h2.hip (shared trunk: svs_mlp_h2_trunk.h with the NetBg geometry).
+#include "svs_mlp_h2_trunk.h"
+#include "svs_mlp_host.h"
+
+namespace svs {
+namespace mlp {
+
+struct BgSdfArgs {
+  const float* pts;      // (P,4) inverted-sphere points (unit direction, 1/r)
+  int P;
+  const f32x4* stream;   // kStreamBgFwd
+  float* out0;           // (P) raw output[:, 0] (the density is its absolute value, AbsDensity)
+  float* feat_tiles;     // [wave tiles][kBlockF]
+  float* hbuf;           // training: [wave tiles][8][kBlockF] h_1..h_8, else nullptr
+  float* ghat7;          // training: [wave tiles][kBlockF] W8[0,:] * softplus'(a_7) (pass B's seed), else nullptr
+};
+
+template <bool TRAIN>
+__global__ __launch_bounds__(kThreads, 1) void bg_sdf_h2_kernel(BgSdfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Stream st;
+  st.g = a.stream;
+  st.buf = reinterpret_cast<f32x4*>(smem);
+  st.cur = 1;
+  const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
+  const int wtile = blockIdx.x * kWaves + wave;
+  const int p = wtile * kTilePts + (lane & 31);
+  const int pc = p < a.P ? p : a.P - 1;
+
+  st.prefetch<kBgChunk0F4>();
+  PosEncBg pe;
+  {
+    const f32x4 x = reinterpret_cast<const f32x4*>(a.pts)[pc];
+    pe.compute(x[0], x[1], x[2], x[3]);
+  }
+  float* hb = TRAIN ? a.hbuf + (size_t)wtile * 8 * kBlockF : nullptr;
+  Pieces2 x, xn;
+  f32x16 y8[8];
+  forward_trunk_h2<TRAIN, NetBg>(st, x, xn, y8, pe, lane, half, hb);
+  // ---- head: current chunk = VEC (W8 row 0 in C-layout order as float32, b8[0])
+  st.prefetch<kChunkF4>();                       // FEAT tile 0
+  const float out0 = sdf_head(st.cur_buf(), y8, lane);
+  if (TRAIN) {
+    const f32x4* w_ptr = st.cur_buf() + kHdrF4 + lane;
+    float* g7 = a.ghat7 + (size_t)wtile * kBlockF;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      f32x16 g;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 w = w_ptr[(4 * t + q) * 64];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[4 * q + j] = w[j] * dsoftplus_from_h(y8[t][4 * q + j]);
+      }
+      store_tile(g7, t, lane, g);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) split_tile(y8[t], t, x);
+  st.advance();
+  if (half == 0 && p < a.P) a.out0[p] = out0;
+  // ---- feature vector = rows 1..256 of lin8 (no activation); tile t-1 is stored while tile t's MFMAs run
+  float* ft = a.feat_tiles + (size_t)wtile * kBlockF;
+  f32x16 prev;
+  f32x4 q4;
+  auto store_slice = [&](int tp, int r) {
+    q4[r & 3] = prev[r];
+    if ((r & 3) == 3) reinterpret_cast<f32x4*>(ft)[(4 * tp + (r >> 2)) * 64 + lane] = q4;
+  };
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    if (t < 7) st.prefetch<kChunkF4>();
+    f32x16 acc;
+    if (t == 0) acc = tile_mma_h2<16>(st.cur_buf(), x, lane);
+    else acc = tile_mma_h2<16>(st.cur_buf(), x, lane, NoEpi(), [&](int s) { store_slice(t - 1, s); });
+    prev = acc;
+    if (t < 7) st.advance();
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) store_slice(7, r);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// bg_rendering_network, mode 'nerf' (network.py:170-190 with bmvs.yaml:70-77)
+// ------------------------------------------------------------------------------------------------------------
+struct BgRgbArgs {
+  int P;
+  const float* view;       // view directions: (R,3) if view_S > 0 (one per ray) else (P,3)
+  int view_S;
+  const float* feat_tiles; // [wave tiles][kBlockF]
+  const f32x4* stream;     // kStreamBgRgbFwd
+  float* rgb;              // (P,3)
+  float* rbuf;             // training: [wave tiles][kBgRbufF]: r_1 (post-ReLU, tiles 0..3) and the 32 view-PE rows, else nullptr
+};
+constexpr int kBgRbufF = kBlockF + 2048;
+constexpr int kBgRgbBufF4 = kBgRgbChunk0F4;
+
+struct BgRgbStream {
+  const f32x4* g; f32x4* buf; int cur;
+  __device__ __forceinline__ const f32x4* cur_buf() const { return buf + cur * kBgRgbBufF4; }
+  template <int N16> __device__ __forceinline__ void prefetch() { chunk_issue<N16>(g, buf + (cur ^ 1) * kBgRgbBufF4); g += N16; }
+  __device__ __forceinline__ void advance() { __builtin_amdgcn_s_waitcnt(0); __syncthreads(); cur ^= 1; }
+};
+
+__global__ __launch_bounds__(kThreads, 1) void bg_rgb_h2_kernel(BgRgbArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  BgRgbStream st;
+  st.g = a.stream; st.buf = reinterpret_cast<f32x4*>(smem); st.cur = 1;
+  const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
+  const int wtile = blockIdx.x * kWaves + wave;
+  const int p = wtile * kTilePts + (lane & 31);
+  const int pc = p < a.P ? p : a.P - 1;
+
+  st.prefetch<kBgRgbChunk0F4>();
+  const float* vd = a.view + 3 * (size_t)(a.view_S > 0 ? pc / a.view_S : pc);
+  // PE-4 of the view direction: [d(3), sin(2^f d)(3), cos(2^f d)(3), f = 0..3] = 27 entries, padded to 32
+  float ex[32];
+  {
+    const float d[3] = {vd[0], vd[1], vd[2]};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ex[c] = d[c];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float s, co;
+        sincosf(d[c] * (float)(1 << f), &s, &co);
+        ex[3 + 6 * f + c] = s;
+        ex[6 + 6 * f + c] = co;
+      }
+#pragma unroll
+    for (int q = 27; q < 32; ++q) ex[q] = 0.0f;
+  }
+  Pieces2 x, xn;
+  float eb[16];   // fragments of k-steps 16, 17: rows 16 s' + rho(j) (+4) of the 32 extra rows
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) eb[8 * s + j] = half ? ex[16 * s + rho(j) + 4] : ex[16 * s + rho(j)];
+    split8(eb + 8 * s, x.h[16 + s], x.m[16 + s]);
+  }
+  {
+    const float* ft = a.feat_tiles + (size_t)wtile * kBlockF;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) split_tile(load_tile(ft, t, lane), t, x);
+  }
+  float* rb = a.rbuf ? a.rbuf + (size_t)wtile * kBgRbufF : nullptr;
+  if (rb) {
+    // the extras as a 32-row accumulator-layout tile pair: registers 0..7 of "tile" s hold rows 16 s + rho(j) (+4)
+    f32x4* d = reinterpret_cast<f32x4*>(rb + (size_t)kBlockF) + lane;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      f32x4 v0, v1;
+      v0[0] = eb[8 * s]; v0[1] = eb[8 * s + 1]; v0[2] = eb[8 * s + 2]; v0[3] = eb[8 * s + 3];
+      v1[0] = eb[8 * s + 4]; v1[1] = eb[8 * s + 5]; v1[2] = eb[8 * s + 6]; v1[3] = eb[8 * s + 7];
+      d[(4 * s) * 64] = v0; d[(4 * s + 1) * 64] = v1; d[(4 * s + 2) * 64] = (f32x4)(0.0f); d[(4 * s + 3) * 64] = (f32x4)(0.0f);
+    }
+  }
+  st.advance();
+  // ---- layer 0: 283 -> 128 (4 tiles), ReLU
+  {
+    f32x16 prev;
+    float v8[8];
+    f32x4 q4;
+    auto slice = [&](int tp, int r) {
+      float v = __builtin_fmaxf(prev[r], 0.0f);
+      pin(v);
+      if (rb) {
+        q4[r & 3] = v;
+        if ((r & 3) == 3) reinterpret_cast<f32x4*>(rb)[(4 * tp + (r >> 2)) * 64 + lane] = q4;
+      }
+      v8[r & 7] = v;
+      if ((r & 7) == 7) {
+        split8(v8, xn.h[2 * tp + (r >> 3)], xn.m[2 * tp + (r >> 3)]);
+        pin(xn.h[2 * tp + (r >> 3)], xn.m[2 * tp + (r >> 3)]);
+      }
+    };
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t < 3) st.prefetch<kBgRgbChunk0F4>(); else st.prefetch<kChunkF4>();
+      f32x16 acc;
+      if (t == 0) acc = tile_mma_h2<18>(st.cur_buf(), x, lane);
+      else acc = tile_mma_h2<18>(st.cur_buf(), x, lane, NoEpi(), [&](int s) { if (s < 16) slice(t - 1, s); });
+      prev = acc;
+      st.advance();
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) slice(3, r);
+    if (rb) {
+      // tiles 4..7 of the r_1 block stay zero (the weight-gradient GEMM reads whole 256-row blocks)
+#pragma unroll
+      for (int t = 4; t < 8; ++t) store_tile(rb, t, lane, (f32x16)(0.0f));
+    }
+  }
+  // ---- layer 1: 128 -> 3 as one tile (rows 0..2 live in registers 0..2 of lanes 0..31), sigmoid
+  const f32x16 acc = tile_mma_h2<8>(st.cur_buf(), xn, lane);
+  if (half == 0 && p < a.P) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a.rgb[3 * p + c] = 1.0f / (1.0f + __expf(-acc[c]));
+  }
+}
+
+}  // namespace mlp
+}  // namespace svs
+
+using namespace svs;
+using namespace svs::mlp;
+
+extern "C" {
+
+size_t svs_bg_rbuf_bytes(int n_points) { return (size_t)wave_tiles(n_points) * kBgRbufF * sizeof(float); }
+
+// bg_implicit_network (network_bg.py:85-88): pts (P,4) -> out0 (P) = output[:,0], feat_tiles (svs_feat_tiles_bytes);
+// training: hbuf (svs_sdf_hbuf_bytes) and ghat7 (svs_block_bytes(P,1)) for the backward, both or neither.
+int svs_bg_sdf_eval(const float* pts, int n_points, const float* stream, float* out0, float* feat_tiles, float* hbuf,
+                    float* ghat7, void* hip_stream) {
+  if (!pts || n_points <= 0 || !stream || !out0 || !feat_tiles || (!hbuf != !ghat7)) {
+    set_error("svs_bg_sdf_eval: null/invalid argument"); return SVS_EINVAL;
+  }
+  BgSdfArgs a{pts, n_points, reinterpret_cast<const f32x4*>(stream), out0, feat_tiles, hbuf, ghat7};
+  static int once = set_lds(bg_sdf_h2_kernel<false>, kLdsBytes, "svs_bg_sdf_eval") | set_lds(bg_sdf_h2_kernel<true>, kLdsBytes, "svs_bg_sdf_eval");
+  if (once) return once;
+  const dim3 grid((n_points + kWgPts - 1) / kWgPts);
+  if (hbuf) bg_sdf_h2_kernel<true><<<grid, kThreads, kLdsBytes, (hipStream_t)hip_stream>>>(a);
+  else bg_sdf_h2_kernel<false><<<grid, kThreads, kLdsBytes, (hipStream_t)hip_stream>>>(a);
+  return check_launch("svs_bg_sdf_eval");
+}
+
+// bg_rendering_network (network_bg.py:91-93): view_dirs (n_rays,3) when view_S > 0 (points per ray) else (P,3)
+int svs_bg_rgb_eval(int n_points, const float* view_dirs, int view_S, const float* feat_tiles, const float* stream,
+                    float* rgb, float* rbuf, void* hip_stream) {
+  if (n_points <= 0 || !view_dirs || !feat_tiles || !stream || !rgb || view_S < 0 || (view_S > 0 && n_points % view_S)) {
+    set_error("svs_bg_rgb_eval: null/invalid argument"); return SVS_EINVAL;
+  }
+  BgRgbArgs a{n_points, view_dirs, view_S, feat_tiles, reinterpret_cast<const f32x4*>(stream), rgb, rbuf};
+  constexpr int lds = 2 * kBgRgbBufF4 * 16;
+  static int once = set_lds(bg_rgb_h2_kernel, lds, "svs_bg_rgb_eval");
+  if (once) return once;
+  bg_rgb_h2_kernel<<<(n_points + kWgPts - 1) / kWgPts, kThreads, lds, (hipStream_t)hip_stream>>>(a);
+  return check_launch("svs_bg_rgb_eval");
+}
+
+}  // extern "C"

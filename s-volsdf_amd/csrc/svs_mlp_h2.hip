@@ -7,121 +7,10 @@
 #include "svs_mlp_h2_dev.h"
 #include "svs_mlp_host.h"
 #include "svs_mlp_args.h"
+#include "svs_mlp_h2_trunk.h"
 
 namespace svs {
 namespace mlp {
-
-// --------------------------------------------------------------------------------------------------------------
-// SDF trunk, layers 0..7
-// --------------------------------------------------------------------------------------------------------------
-// Epilogue of one trunk tile, in slices: softplus of accumulator register r of `prev`, the skip splice (layer 3),
-// the float32 store to hbuf (HBUF) and either the split into the next layer's operand (xn) or the float32 copy y8
-// (last layer).
-template <bool HBUF, bool LAST>
-struct TrunkEpi {
-  f32x16 prev;
-  SoftplusA sa;
-  float v8[8];
-  f32x4 q4;
-  Pieces2* xn;
-  f32x16* y8;
-  const PosEnc* pe;
-  float* hb;        // this layer's block of the wave's hbuf tile
-  int lane, half;
-  bool splice;      // layer 3: rows >= 217 of the output are the PE splice (network.py:80-81)
-
-  __device__ __forceinline__ void a(int r) {
-    sa = softplus100_a(prev[r]);
-    pin(sa.mx); pin(sa.lg);
-  }
-  __device__ __forceinline__ void b(int tp, int r) {
-    float v = softplus100_b(sa);
-    if (tp == 6 && splice) {
-      const int l0 = rho(r) - 25, l1 = rho(r) + 4 - 25;   // local rows 25..31 of tile 6 carry PE[32..38]
-      if (l0 >= 0 || l1 >= 0) {
-        const float v0 = l0 >= 0 ? pe->v[32 + (l0 >= 0 ? l0 : 0)] : v;
-        const float v1 = l1 >= 0 ? pe->v[32 + (l1 >= 0 ? l1 : 0)] : v;
-        v = half ? v1 : v0;
-      }
-    }
-    pin(v);
-    emit(tp, r, v);
-  }
-  __device__ __forceinline__ void emit(int tp, int r, float v) {
-    if (LAST) y8[tp][r] = v;
-    if (HBUF) {
-      q4[r & 3] = v;
-      if ((r & 3) == 3) reinterpret_cast<f32x4*>(hb)[(4 * tp + (r >> 2)) * 64 + lane] = q4;
-    }
-    if (!LAST) {
-      v8[r & 7] = v;
-      if ((r & 7) == 7) {
-        split8(v8, xn->h[2 * tp + (r >> 3)], xn->m[2 * tp + (r >> 3)]);
-        pin(xn->h[2 * tp + (r >> 3)], xn->m[2 * tp + (r >> 3)]);
-      }
-    }
-  }
-  __device__ __forceinline__ void all(int tp) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { a(r); b(tp, r); }
-  }
-  // layer 3, tile 7 = PE[0..31] (no MFMA)
-  __device__ __forceinline__ void splice_tile7() {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) emit(7, r, half ? pe->v[rho(r) + 4] : pe->v[rho(r)]);
-  }
-};
-
-// one 256 -> 256 trunk layer (l >= 1).  On entry the layer's first chunk is current; on return the next layer's is.
-template <bool HBUF, bool LAST>
-__device__ __forceinline__ void trunk_layer_h2(Stream& st, const Pieces2& x, TrunkEpi<HBUF, LAST>& ep, int lane) {
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    if (t == 7 && ep.splice) break;   // lin3 has 217 outputs = 7 tiles; tile 7 is the PE splice
-    st.prefetch<kChunkF4>();
-    f32x16 acc;
-    if (t == 0) acc = tile_mma_h2<16>(st.cur_buf(), x, lane);
-    else acc = tile_mma_h2<16>(st.cur_buf(), x, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.b(t - 1, s); });
-    ep.prev = acc;
-    st.advance();
-  }
-  if (ep.splice) { ep.all(6); ep.splice_tile7(); }
-  else ep.all(7);
-}
-
-// Forward through layers 0..7.  x: scratch operand; on return y8 holds h_8 in float32 (the input of lin8) and the
-// current chunk is the one that follows the trunk in the stream.  HBUF: h_1..h_8 are also stored to hbuf.
-template <bool HBUF>
-__device__ __forceinline__ void forward_trunk_h2(Stream& st, Pieces2& x, Pieces2& xn, f32x16* y8, const PosEnc& pe,
-                                                 int lane, int half, float* __restrict__ hbuf) {
-  split_pe(pe, half, x);
-  st.advance();        // chunk 0 (prefetched by the caller before the positional encoding)
-  {
-    // ---- layer 0 : 39(48) -> 256, three k-steps per tile: the epilogue of tile t-1 follows tile t's MFMAs
-    TrunkEpi<HBUF, false> ep;
-    ep.xn = &xn; ep.y8 = nullptr; ep.pe = &pe; ep.hb = hbuf; ep.lane = lane; ep.half = half; ep.splice = false;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      if (t < 7) st.prefetch<kChunk0F4>(); else st.prefetch<kChunkF4>();
-      const f32x16 acc = tile_mma_h2<3>(st.cur_buf(), x, lane);
-      if (t > 0) ep.all(t - 1);
-      ep.prev = acc;
-      st.advance();
-    }
-    ep.all(7);
-  }
-  // ---- layers 1..6 (layer 3 emits 217 rows + the skip splice), operands ping-pong between x and xn
-  for (int l = 1; l < 7; ++l) {
-    TrunkEpi<HBUF, false> ep;
-    ep.y8 = nullptr; ep.pe = &pe; ep.hb = hbuf + (size_t)l * kBlockF; ep.lane = lane; ep.half = half; ep.splice = l == 3;
-    if (l & 1) { ep.xn = &x; trunk_layer_h2<HBUF, false>(st, xn, ep, lane); }
-    else { ep.xn = &xn; trunk_layer_h2<HBUF, false>(st, x, ep, lane); }
-  }
-  // ---- layer 7: input in xn (layer 6 wrote it), output kept in float32
-  TrunkEpi<HBUF, true> ep;
-  ep.xn = nullptr; ep.y8 = y8; ep.pe = &pe; ep.hb = hbuf + (size_t)7 * kBlockF; ep.lane = lane; ep.half = half; ep.splice = false;
-  trunk_layer_h2<HBUF, true>(st, xn, ep, lane);
-}
 
 // ImplicitNetwork.get_sdf_vals (network.py:125-131), no grad: the sampler's evaluation.
 __global__ __launch_bounds__(kThreads, 1) void sdf_only_h2_kernel(SdfOnlyArgs a) {

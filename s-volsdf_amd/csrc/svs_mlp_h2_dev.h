@@ -21,10 +21,10 @@ namespace mlp {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-// one layer input as MFMA B fragments: 16 k-steps (K = 256) x {hi, mid} = 128 VGPRs; k-step 16 holds the 16 extra
-// input rows of the radiance network's first layer (unused elsewhere: costs no registers)
+// one layer input as MFMA B fragments: 16 k-steps (K = 256) x {hi, mid} = 128 VGPRs; k-steps 16, 17 hold the extra
+// input rows of the radiance networks' first layer (16 fg / 27 bg; unused elsewhere: they cost no registers)
 struct Pieces2 {
-  f16x8 h[17], m[17];
+  f16x8 h[18], m[18];
 };
 
 __device__ __forceinline__ void split8(const float* v, f16x8& h, f16x8& m) {
@@ -52,21 +52,23 @@ __device__ __forceinline__ void split_tile(const f32x16& y, int t, Pieces2& p) {
   }
 }
 
-// SDF layer-0 input: k-step s (0..2), element j of lane half h is PE[16 s + 8 h + j] (zero beyond 38)
-__device__ __forceinline__ void split_pe(const PosEnc& pe, int half, Pieces2& p) {
+// layer-0 input: k-step s (0..KS-1), element j of lane half h is PE[16 s + 8 h + j] (zero beyond the PAD entries)
+template <int KS, int PAD>
+__device__ __forceinline__ void split_pe(const float* pev, int half, Pieces2& p) {
 #pragma unroll
-  for (int s = 0; s < 3; ++s) {
+  for (int s = 0; s < KS; ++s) {
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int q0 = 16 * s + j, q1 = 16 * s + 8 + j;
-      const float a0 = q0 < 40 ? pe.v[q0 < 40 ? q0 : 0] : 0.0f;
-      const float a1 = q1 < 40 ? pe.v[q1 < 40 ? q1 : 0] : 0.0f;
+      const float a0 = q0 < PAD ? pev[q0 < PAD ? q0 : 0] : 0.0f;
+      const float a1 = q1 < PAD ? pev[q1 < PAD ? q1 : 0] : 0.0f;
       v[j] = half ? a1 : a0;
     }
     split8(v, p.h[s], p.m[s]);
   }
 }
+__device__ __forceinline__ void split_pe(const PosEnc& pe, int half, Pieces2& p) { split_pe<3, 40>(pe.v, half, p); }
 
 __device__ __forceinline__ f32x16 tile_bias(const f32x4* __restrict__ chunk, int lane) {
   f32x16 acc;

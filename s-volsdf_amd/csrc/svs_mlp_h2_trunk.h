@@ -1,0 +1,160 @@
+// The trunk (layers 0..7) of the implicit networks on fp16x2 MFMAs, shared by the foreground SDF network
+// (svs_mlp_h2.hip) and the inverted-sphere background network (svs_bg_h2.hip).
+#pragma once
+#include "svs_mlp_h2_dev.h"
+
+namespace svs {
+namespace mlp {
+
+// Positional encoding of the background network's 4-D points (unit direction, 1/r): PE-10, 84 entries in the
+// reference's order [x(4), sin(2^0 x)(4), cos(2^0 x)(4), ...] (embedder.py:10-36), padded with zeros to 96.
+struct PosEncBg {
+  float v[96];
+  __device__ __forceinline__ void compute(float x0, float x1, float x2, float x3) {
+    const float xs[4] = {x0, x1, x2, x3};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = xs[c];
+#pragma unroll
+    for (int f = 0; f < 10; ++f) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float s, co;
+        sincosf(xs[c] * (float)(1 << f), &s, &co);
+        v[4 + 8 * f + c] = s;
+        v[8 + 8 * f + c] = co;
+      }
+    }
+#pragma unroll
+    for (int q = 84; q < 96; ++q) v[q] = 0.0f;
+  }
+};
+
+// geometry of the two implicit networks (network.py:31-62 with dtu.yaml / bmvs.yaml)
+struct NetFg {   // d_in 3, PE-6: 39 inputs; lin3 emits 217 rows, rows 217..255 of lin4's input are the PE splice
+  typedef PosEnc Pe;
+  static constexpr int kSteps0 = 3, kPePad = 40, kChunk0 = kChunk0F4, kSpliceTile = 6, kSpliceLocal = 25;
+};
+struct NetBg {   // d_in 4, PE-10: 84 inputs; lin3 emits 172 rows, rows 172..255 of lin4's input are the PE splice
+  typedef PosEncBg Pe;
+  static constexpr int kSteps0 = 6, kPePad = 96, kChunk0 = kBgChunk0F4, kSpliceTile = 5, kSpliceLocal = 12;
+};
+
+// --------------------------------------------------------------------------------------------------------------
+// SDF trunk, layers 0..7
+// --------------------------------------------------------------------------------------------------------------
+// Epilogue of one trunk tile, in slices: softplus of accumulator register r of `prev`, the skip splice (layer 3),
+// the float32 store to hbuf (HBUF) and either the split into the next layer's operand (xn) or the float32 copy y8
+// (last layer).
+template <bool HBUF, bool LAST, typename Net = NetFg>
+struct TrunkEpi {
+  f32x16 prev;
+  SoftplusA sa;
+  float v8[8];
+  f32x4 q4;
+  Pieces2* xn;
+  f32x16* y8;
+  const typename Net::Pe* pe;
+  float* hb;        // this layer's block of the wave's hbuf tile
+  int lane, half;
+  bool splice;      // layer 3: rows >= 217 of the output are the PE splice (network.py:80-81)
+
+  __device__ __forceinline__ void a(int r) {
+    sa = softplus100_a(prev[r]);
+    pin(sa.mx); pin(sa.lg);
+  }
+  __device__ __forceinline__ void b(int tp, int r) {
+    float v = softplus100_b(sa);
+    if (tp == Net::kSpliceTile && splice) {
+      // the partial tile: local rows >= kSpliceLocal carry PE[32 * (7 - tile) + local - kSpliceLocal]
+      constexpr int base = 32 * (7 - Net::kSpliceTile);
+      const int l0 = rho(r) - Net::kSpliceLocal, l1 = rho(r) + 4 - Net::kSpliceLocal;
+      if (l0 >= 0 || l1 >= 0) {
+        const float v0 = l0 >= 0 ? pe->v[base + (l0 >= 0 ? l0 : 0)] : v;
+        const float v1 = l1 >= 0 ? pe->v[base + (l1 >= 0 ? l1 : 0)] : v;
+        v = half ? v1 : v0;
+      }
+    }
+    pin(v);
+    emit(tp, r, v);
+  }
+  __device__ __forceinline__ void emit(int tp, int r, float v) {
+    if (LAST) y8[tp][r] = v;
+    if (HBUF) {
+      q4[r & 3] = v;
+      if ((r & 3) == 3) reinterpret_cast<f32x4*>(hb)[(4 * tp + (r >> 2)) * 64 + lane] = q4;
+    }
+    if (!LAST) {
+      v8[r & 7] = v;
+      if ((r & 7) == 7) {
+        split8(v8, xn->h[2 * tp + (r >> 3)], xn->m[2 * tp + (r >> 3)]);
+        pin(xn->h[2 * tp + (r >> 3)], xn->m[2 * tp + (r >> 3)]);
+      }
+    }
+  }
+  __device__ __forceinline__ void all(int tp) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a(r); b(tp, r); }
+  }
+  // layer 3, the tiles behind the partial one are pure PE (no MFMA): tile tp = PE[32 * (7 - tp) + local]
+  __device__ __forceinline__ void splice_full_tiles() {
+#pragma unroll
+    for (int tp = Net::kSpliceTile + 1; tp < 8; ++tp)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) emit(tp, r, half ? pe->v[32 * (7 - tp) + rho(r) + 4] : pe->v[32 * (7 - tp) + rho(r)]);
+  }
+};
+
+// one 256 -> 256 trunk layer (l >= 1).  On entry the layer's first chunk is current; on return the next layer's is.
+template <bool HBUF, bool LAST, typename Net = NetFg>
+__device__ __forceinline__ void trunk_layer_h2(Stream& st, const Pieces2& x, TrunkEpi<HBUF, LAST, Net>& ep, int lane) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    if (t == Net::kSpliceTile + 1 && ep.splice) break;   // lin3 has 217 (bg: 172) outputs; the tiles behind are the PE splice
+    st.prefetch<kChunkF4>();
+    f32x16 acc;
+    if (t == 0) acc = tile_mma_h2<16>(st.cur_buf(), x, lane);
+    else acc = tile_mma_h2<16>(st.cur_buf(), x, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.b(t - 1, s); });
+    ep.prev = acc;
+    st.advance();
+  }
+  if (ep.splice) { ep.all(Net::kSpliceTile); ep.splice_full_tiles(); }
+  else ep.all(7);
+}
+
+// Forward through layers 0..7.  x: scratch operand; on return y8 holds h_8 in float32 (the input of lin8) and the
+// current chunk is the one that follows the trunk in the stream.  HBUF: h_1..h_8 are also stored to hbuf.
+template <bool HBUF, typename Net = NetFg>
+__device__ __forceinline__ void forward_trunk_h2(Stream& st, Pieces2& x, Pieces2& xn, f32x16* y8, const typename Net::Pe& pe,
+                                                 int lane, int half, float* __restrict__ hbuf) {
+  split_pe<Net::kSteps0, Net::kPePad>(pe.v, half, x);
+  st.advance();        // chunk 0 (prefetched by the caller before the positional encoding)
+  {
+    // ---- layer 0 : 39(48) -> 256, three k-steps per tile: the epilogue of tile t-1 follows tile t's MFMAs
+    TrunkEpi<HBUF, false, Net> ep;
+    ep.xn = &xn; ep.y8 = nullptr; ep.pe = &pe; ep.hb = hbuf; ep.lane = lane; ep.half = half; ep.splice = false;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      if (t < 7) st.prefetch<Net::kChunk0>(); else st.prefetch<kChunkF4>();
+      const f32x16 acc = tile_mma_h2<Net::kSteps0>(st.cur_buf(), x, lane);
+      if (t > 0) ep.all(t - 1);
+      ep.prev = acc;
+      st.advance();
+    }
+    ep.all(7);
+  }
+  // ---- layers 1..6 (layer 3 emits 217 rows + the skip splice), operands ping-pong between x and xn
+  for (int l = 1; l < 7; ++l) {
+    TrunkEpi<HBUF, false, Net> ep;
+    ep.y8 = nullptr; ep.pe = &pe; ep.hb = hbuf + (size_t)l * kBlockF; ep.lane = lane; ep.half = half; ep.splice = l == 3;
+    if (l & 1) { ep.xn = &x; trunk_layer_h2<HBUF, false, Net>(st, xn, ep, lane); }
+    else { ep.xn = &xn; trunk_layer_h2<HBUF, false, Net>(st, x, ep, lane); }
+  }
+  // ---- layer 7: input in xn (layer 6 wrote it), output kept in float32
+  TrunkEpi<HBUF, true, Net> ep;
+  ep.xn = nullptr; ep.y8 = y8; ep.pe = &pe; ep.hb = hbuf + (size_t)7 * kBlockF; ep.lane = lane; ep.half = half; ep.splice = false;
+  trunk_layer_h2<HBUF, true, Net>(st, xn, ep, lane);
+}
+
+
+}  // namespace mlp
+}  // namespace svs

@@ -20,6 +20,10 @@ constexpr int kRgbL0BodyF4 = 136 * 16;    // radiance layer 0: 128 feature k-ste
 constexpr int kRgbChunk0F4 = kHdrF4 + kRgbL0BodyF4;
 constexpr int kW4TF4 = 8 * 64;            // radiance lin4 transposed: 8 tiles x 64 lanes x 4 k-steps
 constexpr int kBlockF = 128 * 64;         // floats of one wave-tile activation block (256 rows x 32 points)
+constexpr int kBgPeDim = 84;              // 4 * (1 + 2 * 10): PE-10 of the 4-D inverted-sphere points
+constexpr int kBgChunk0F4 = kHdrF4 + 6 * 128;   // bg implicit layer 0: 6 fp16x2 k-steps
+constexpr int kW1TF4 = 4 * 64;            // bg radiance lin1 transposed: 4 tiles x 64 lanes x 4 k-steps
+constexpr int kBgRgbChunk0F4 = kHdrF4 + 18 * 128;   // bg radiance layer 0: 16 feature k-steps + 2 k-steps of view-PE rows
 
 // chunk kinds (svs_pack.hip packs them, the kernels consume them in stream order)
 enum ChunkKind {
@@ -35,6 +39,13 @@ enum ChunkKind {
   kRgbRev,        // radiance W_l^T, l = 1..3
   kRgbRev0,       // radiance W_0^T (9 tiles: 8 feature tiles + the extras tile)
   kRgbW4T,        // radiance lin4^T (3 output rows), short chunk
+  // inverted-sphere background networks (VolSDFNetworkBG, network_bg.py): the implicit network reuses kSdfFwd /
+  // kSdfVec / kSdfFeat / kSdfFeatT / kSdfRev with the bg geometry (84 PE rows, lin3 emits 172 rows)
+  kBgFwd0,        // bg implicit layer 0 (K = 84 -> 96 = 6 fp16x2 k-steps)
+  kBgRgbFwd0,     // bg radiance layer 0: 128 rows, K = 256 feature rows + 32 extra rows (27 view-PE entries)
+  kBgRgbFwd1,     // bg radiance layer 1: 3 rows, K = 128
+  kBgRgbW1T,      // bg radiance lin1^T (3 output rows), short chunk (4 tiles)
+  kBgRgbRev0,     // bg radiance lin0^T onto the 256 feature rows, K = 128
 };
 constexpr int kNoBias = 0x100;            // flag: zero header
 
@@ -45,11 +56,24 @@ constexpr int kNoBias = 0x100;            // flag: zero header
 enum BodyFormat { kFmtF32 = 0, kFmtF16x2 = 1 };
 
 __host__ __device__ constexpr int chunk_f4(int kind) {
-  return kind == kSdfFwd0 ? kChunk0F4 : (kind == kRgbFwd0 ? kRgbChunk0F4 : (kind == kRgbW4T ? kW4TF4 : kChunkF4));
+  return kind == kSdfFwd0 ? kChunk0F4
+       : kind == kRgbFwd0 ? kRgbChunk0F4
+       : kind == kRgbW4T ? kW4TF4
+       : kind == kBgFwd0 ? kBgChunk0F4
+       : kind == kBgRgbFwd0 ? kBgRgbChunk0F4
+       : kind == kBgRgbW1T ? kW1TF4
+       : kChunkF4;
 }
 
 // streams
-enum StreamKind { kStreamSdfFwd = 0, kStreamSdfFull, kStreamSdfTrain, kStreamRgbFwd, kStreamRgbBwd, kNumStreams };
+enum StreamKind {
+  kStreamSdfFwd = 0, kStreamSdfFull, kStreamSdfTrain, kStreamRgbFwd, kStreamRgbBwd,
+  kStreamBgFwd,      // bg implicit network: trunk + head vector + feature head
+  kStreamBgTrain,    // bg implicit network backward: transposed feature head + transposed trunk
+  kStreamBgRgbFwd, kStreamBgRgbBwd,
+  kNumStreams
+};
+constexpr bool stream_is_bg(int which) { return which >= kStreamBgFwd; }
 // offsets inside the SDF training stream (float4): pass A starts at 0, pass B after the 63 forward chunks
 constexpr size_t kSdfTrainPassBF4 = 8 * (size_t)kChunk0F4 + 55 * (size_t)kChunkF4;
 

@@ -19,19 +19,20 @@ struct LayerPtrs {
 
 constexpr int kScaleStride = 264;
 
-__device__ __host__ constexpr int sdf_rows(int l) { return l == 3 ? 217 : (l == 8 ? 257 : 256); }
-__device__ __host__ constexpr int sdf_cols(int l) { return l == 0 ? 39 : 256; }
-__device__ __host__ constexpr int rgb_rows(int l) { return l == 4 ? 3 : 256; }
-__device__ __host__ constexpr int rgb_cols(int l) { return l == 0 ? 271 : 256; }
+// layer shapes; net: 0 = foreground networks, 1 = inverted-sphere background networks (network_bg.py:31-35)
+__device__ __host__ constexpr int sdf_rows(int l, int net = 0) { return l == 3 ? (net ? 172 : 217) : (l == 8 ? 257 : 256); }
+__device__ __host__ constexpr int sdf_cols(int l, int net = 0) { return l == 0 ? (net ? 84 : 39) : 256; }
+__device__ __host__ constexpr int rgb_rows(int l, int net = 0) { return net ? (l == 0 ? 128 : 3) : (l == 4 ? 3 : 256); }
+__device__ __host__ constexpr int rgb_cols(int l, int net = 0) { return net ? (l == 0 ? 283 : 128) : (l == 0 ? 271 : 256); }
 
 // scale[l][o] = g[o] / ||v[o,:]||  (1 when the layer has no weight-norm); one wave per row
-__global__ void rownorm_kernel(LayerPtrs w, int n_layers, int is_rgb, float* __restrict__ scale) {
+__global__ void rownorm_kernel(LayerPtrs w, int n_layers, int is_rgb, int net, float* __restrict__ scale) {
   const int lane = threadIdx.x & 63;
   const int row_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int l = row_global / kScaleStride, o = row_global % kScaleStride;
   if (l >= n_layers) return;
-  const int rows = is_rgb ? rgb_rows(l) : sdf_rows(l);
-  const int cols = is_rgb ? rgb_cols(l) : sdf_cols(l);
+  const int rows = is_rgb ? rgb_rows(l, net) : sdf_rows(l, net);
+  const int cols = is_rgb ? rgb_cols(l, net) : sdf_cols(l, net);
   if (o >= rows) return;
   float s = 1.0f;
   if (w.g[l]) {
@@ -52,7 +53,11 @@ __device__ __forceinline__ float weff(const LayerPtrs& w, const float* scale, in
 
 // column of lin4's weight that multiplies accumulator row i of the spliced layer-4 input
 // (rows 0..216 = h, 217..223 = PE[32..38], 224..255 = PE[0..31]; reference order is cat[h(217), PE(39)])
-__device__ __host__ inline int l4_col(int i) { return i < 217 ? i : (i < 224 ? 217 + 32 + (i - 217) : 217 + (i - 224)); }
+__device__ __host__ inline int l4_col(int i, int net = 0) {
+  if (net == 0) return i < 217 ? i : (i < 224 ? 217 + 32 + (i - 217) : 217 + (i - 224));
+  // bg: rows 0..171 = h, 172..191 = PE[64..83], 192..223 = PE[32..63], 224..255 = PE[0..31]; reference order cat[h(172), PE(84)]
+  return i < 172 ? i : (i < 192 ? 172 + 64 + (i - 172) : (i < 224 ? 172 + 32 + (i - 192) : 172 + (i - 224)));
+}
 
 // PE index carried by output row (tile, local) of the reverse layer-0 product (matches the splice layout)
 __device__ __forceinline__ int rev0_pe(int tile, int local) {
@@ -65,24 +70,39 @@ struct ChunkDesc { int kind, layer, tile, off_f4; };   // off_f4: offset of the 
 // Weight that multiplies input row `crow` (C-layout row of the layer input) in output row 32*t + col32 of a chunk.
 // q0: PE index of the element (SDF layer 0); e: index into the 16 extra input rows (radiance layer 0) or -1.
 __device__ __forceinline__ float body_value(const LayerPtrs& w, const float* scale, int kind, int l, int t, int col32,
-                                            int crow, int q0, int e) {
+                                            int crow, int q0, int e, int net) {
   const float inv_sqrt2 = 0.70710678118654752f;
   switch (kind) {
     case kSdfFwd0:
       return q0 < 39 ? weff(w, scale, 0, 32 * t + col32, q0, 39) : 0.0f;
+    case kBgFwd0:
+      return q0 < kBgPeDim ? weff(w, scale, 0, 32 * t + col32, q0, kBgPeDim) : 0.0f;
+    case kBgRgbFwd0: {
+      // nerf mode (network.py:176): input = cat[PE4(view)(27), feature(256)]
+      const int o = 32 * t + col32;
+      if (o >= 128) return 0.0f;
+      if (e < 0) return weff(w, scale, 0, o, 27 + crow, 283);
+      return e < 27 ? weff(w, scale, 0, o, e, 283) : 0.0f;
+    }
+    case kBgRgbFwd1: {
+      const int o = 32 * t + col32;
+      return (o < 3 && crow < 128) ? weff(w, scale, 1, o, crow, 128) : 0.0f;
+    }
+    case kBgRgbRev0:
+      return crow < 128 ? weff(w, scale, 0, crow, 27 + 32 * t + col32, 283) : 0.0f;
     case kSdfFwd:
     case kSdfFeat: {
       const int o = (kind == kSdfFeat ? 1 : 0) + 32 * t + col32;
-      if (o >= sdf_rows(l)) return 0.0f;
-      return l == 4 ? weff(w, scale, 4, o, l4_col(crow), 256) * inv_sqrt2 : weff(w, scale, l, o, crow, 256);
+      if (o >= sdf_rows(l, net)) return 0.0f;
+      return l == 4 ? weff(w, scale, 4, o, l4_col(crow, net), 256) * inv_sqrt2 : weff(w, scale, l, o, crow, 256);
     }
     case kSdfVec:
       return weff(w, scale, 8, 0, crow, 256);
     case kSdfRev: {
       // reverse of layer l: out row = input feature i_out (C-layout row of the layer's input), k = output feature
-      if (crow >= sdf_rows(l)) return 0.0f;
+      if (crow >= sdf_rows(l, net)) return 0.0f;
       const int i_out = 32 * t + col32;
-      return l == 4 ? weff(w, scale, 4, crow, l4_col(i_out), 256) * inv_sqrt2 : weff(w, scale, l, crow, i_out, 256);
+      return l == 4 ? weff(w, scale, 4, crow, l4_col(i_out, net), 256) * inv_sqrt2 : weff(w, scale, l, crow, i_out, 256);
     }
     case kSdfRev0: {
       const int q = rev0_pe(t, col32);
@@ -113,10 +133,12 @@ __device__ __forceinline__ float body_value(const LayerPtrs& w, const float* sca
 }
 
 // bias of output row o_local = rho(r) + 4*half of tile t (header register r)
-__device__ __forceinline__ float header_value(const LayerPtrs& w, int kind, int l, int t, int o_local) {
+__device__ __forceinline__ float header_value(const LayerPtrs& w, int kind, int l, int t, int o_local, int net) {
   switch (kind) {
-    case kSdfFwd0: return w.b[0][32 * t + o_local];
-    case kSdfFwd: { const int o = 32 * t + o_local; return o < sdf_rows(l) ? w.b[l][o] : 0.0f; }
+    case kSdfFwd0: case kBgFwd0: return w.b[0][32 * t + o_local];
+    case kBgRgbFwd0: { const int o = 32 * t + o_local; return o < 128 ? w.b[0][o] : 0.0f; }
+    case kBgRgbFwd1: { const int o = 32 * t + o_local; return o < 3 ? w.b[1][o] : 0.0f; }
+    case kSdfFwd: { const int o = 32 * t + o_local; return o < sdf_rows(l, net) ? w.b[l][o] : 0.0f; }
     case kSdfFeat: { const int o = 1 + 32 * t + o_local; return o < sdf_rows(l) ? w.b[l][o] : 0.0f; }
     case kSdfVec: return w.b[8][0];
     case kRgbFwd0: return w.b[0][32 * t + o_local];
@@ -127,7 +149,7 @@ __device__ __forceinline__ float header_value(const LayerPtrs& w, int kind, int 
 
 // one workgroup per chunk
 __global__ __launch_bounds__(256) void pack_stream_kernel(LayerPtrs w, const float* __restrict__ scale,
-                                                          const ChunkDesc* __restrict__ table, int fmt,
+                                                          const ChunkDesc* __restrict__ table, int fmt, int net,
                                                           float* __restrict__ out) {
   const ChunkDesc d = table[blockIdx.x];
   const int kind = d.kind & 0xff;
@@ -143,10 +165,19 @@ __global__ __launch_bounds__(256) void pack_stream_kernel(LayerPtrs w, const flo
     }
     return;
   }
+  if (kind == kBgRgbW1T) {
+    // [tile 4][lane 64][4 k-steps]: A = W1^T rows (hidden unit 32*tile + lane&31), k = rho(s) + 4*half < 3
+    for (int wi = threadIdx.x; wi < kW1TF4 * 4; wi += 256) {
+      const int tt = wi / 256, lane = (wi & 255) >> 2, s = wi & 3;
+      const int k = rho(s) + 4 * (lane >> 5);
+      dst[wi] = k < 3 ? weff(w, scale, 1, k, 32 * tt + (lane & 31), 128) : 0.0f;
+    }
+    return;
+  }
   // ---- header: [r/4][lane][4] bias block in accumulator layout
   for (int wi = threadIdx.x; wi < kHdrF4 * 4; wi += 256) {
     const int lane = (wi & 255) >> 2, r = 4 * (wi / 256) + (wi & 3);
-    dst[wi] = nobias ? 0.0f : header_value(w, kind, l, t, rho(r) + 4 * (lane >> 5));
+    dst[wi] = nobias ? 0.0f : header_value(w, kind, l, t, rho(r) + 4 * (lane >> 5), net);
   }
   float* body = dst + kHdrF4 * 4;
   const int body_f4 = chunk_f4(kind) - kHdrF4;
@@ -156,7 +187,7 @@ __global__ __launch_bounds__(256) void pack_stream_kernel(LayerPtrs w, const flo
       const int sr = 4 * (wb / 256) + (wb & 3);                   // k-step: input rows 2*sr, 2*sr+1 in K order
       const int crow = 32 * (sr / 16) + rho(sr % 16) + 4 * half;  // C-layout row addressed by k-step sr
       const int e = sr >= 128 ? rho(sr - 128) + 4 * half : -1;
-      body[wb] = body_value(w, scale, kind, l, t, col32, crow, 2 * sr + half, e);
+      body[wb] = body_value(w, scale, kind, l, t, col32, crow, 2 * sr + half, e, net);
     }
     return;
   }
@@ -168,8 +199,8 @@ __global__ __launch_bounds__(256) void pack_stream_kernel(LayerPtrs w, const flo
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int crow = 32 * (s >> 1) + rho(8 * (s & 1) + j) + 4 * half;
-      const int e = s >= 16 ? rho(j) + 4 * half : -1;
-      const float wv = body_value(w, scale, kind, l, t, col32, crow, 16 * s + 8 * half + j, e);
+      const int e = s >= 16 ? 16 * (s - 16) + rho(j) + 4 * half : -1;
+      const float wv = body_value(w, scale, kind, l, t, col32, crow, 16 * s + 8 * half + j, e, net);
       const _Float16 hi = (_Float16)wv;
       const _Float16 mid = (_Float16)(wv - (float)hi);
       ebits[j] = __builtin_bit_cast(unsigned short, piece == 0 ? hi : mid);
@@ -232,6 +263,25 @@ static StreamTable& table_for(int which) {
       for (int l = 3; l >= 1; --l) for (int i = 0; i < 8; ++i) t.add(kRgbRev, l, i);
       for (int i = 0; i < 9; ++i) t.add(kRgbRev0, 0, i);
       break;
+    case kStreamBgFwd:
+      for (int i = 0; i < 8; ++i) t.add(kBgFwd0, 0, i);
+      for (int l = 1; l < 8; ++l)
+        for (int i = 0; i < (l == 3 ? 6 : 8); ++i) t.add(kSdfFwd, l, i);     // lin3: 172 rows = 6 tiles
+      t.add(kSdfVec, 8, 0);
+      for (int i = 0; i < 8; ++i) t.add(kSdfFeat, 8, i);
+      break;
+    case kStreamBgTrain:
+      for (int i = 0; i < 8; ++i) t.add(kSdfFeatT, 8, i);
+      for (int l = 7; l >= 1; --l) for (int i = 0; i < 8; ++i) t.add(kSdfRev, l, i);
+      break;
+    case kStreamBgRgbFwd:
+      for (int i = 0; i < 4; ++i) t.add(kBgRgbFwd0, 0, i);
+      t.add(kBgRgbFwd1, 1, 0);
+      break;
+    case kStreamBgRgbBwd:
+      t.add(kBgRgbW1T, 1, 0);
+      for (int i = 0; i < 8; ++i) t.add(kBgRgbRev0, 0, i);
+      break;
   }
   return t;
 }
@@ -245,7 +295,8 @@ using namespace svs::mlp;
 extern "C" {
 
 // which: 0 SDF forward, 1 SDF full (forward + feature head + gradient pass), 2 SDF training backward,
-//        3 radiance forward, 4 radiance backward.  precision: body encoding of the MFMA chunks, 0 float32, 1 fp16x2.
+//        3 radiance forward, 4 radiance backward; background networks (fp16x2 only): 5 bg implicit forward,
+//        6 bg implicit backward, 7 bg radiance forward, 8 bg radiance backward.  precision: body encoding of the MFMA chunks, 0 float32, 1 fp16x2.
 // Stream sizes do not depend on the precision.
 size_t svs_stream_bytes(int which) {
   if (which < 0 || which >= kNumStreams) return 0;
@@ -260,8 +311,10 @@ int svs_pack_stream(int which, int precision, const float* const* weight_v, cons
       (precision != kFmtF32 && precision != kFmtF16x2)) {
     set_error("svs_pack_stream: bad argument"); return SVS_EINVAL;
   }
-  const bool is_rgb = which >= kStreamRgbFwd;
-  const int nl = is_rgb ? 5 : 9;
+  const bool is_rgb = which == kStreamRgbFwd || which == kStreamRgbBwd || which == kStreamBgRgbFwd || which == kStreamBgRgbBwd;
+  const int net = stream_is_bg(which) ? 1 : 0;
+  const int nl = is_rgb ? (net ? 2 : 5) : 9;
+  if (net && precision != kFmtF16x2) { set_error("svs_pack_stream: the background networks are fp16x2 only"); return SVS_EINVAL; }
   LayerPtrs w = {};
   for (int l = 0; l < nl; ++l) {
     w.v[l] = weight_v[l]; w.g[l] = weight_g ? weight_g[l] : nullptr; w.b[l] = bias[l];
@@ -274,8 +327,8 @@ int svs_pack_stream(int which, int precision, const float* const* weight_v, cons
     if (e != hipSuccess) { set_error("svs_pack_stream: table upload: %s", hipGetErrorString(e)); t.dev = nullptr; return (int)e; }
   }
   hipStream_t s = (hipStream_t)hip_stream;
-  rownorm_kernel<<<(nl * kScaleStride + 3) / 4, 256, 0, s>>>(w, nl, is_rgb ? 1 : 0, workspace);
-  pack_stream_kernel<<<(unsigned)t.host.size(), 256, 0, s>>>(w, workspace, t.dev, precision, stream_out);
+  rownorm_kernel<<<(nl * kScaleStride + 3) / 4, 256, 0, s>>>(w, nl, is_rgb ? 1 : 0, net, workspace);
+  pack_stream_kernel<<<(unsigned)t.host.size(), 256, 0, s>>>(w, workspace, t.dev, precision, net, stream_out);
   return check_launch("svs_pack_stream");
 }
 

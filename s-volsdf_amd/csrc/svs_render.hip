@@ -427,6 +427,156 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(LossArgs a, const doub
   }
 }
 
+// ---- a9 (BG model): inverted-sphere samples and fg/bg compositing (volsdf/model/network_bg.py) --------------------
+// torch.linspace(start,end,n)[i] in float32 (see svs_sampler.hip)
+__device__ __forceinline__ float linspace_at_r(float start, float end, int n, int i) {
+  const float step = (end - start) / (float)(n - 1);
+  return i < n / 2 ? __builtin_fmaf(step, (float)i, start) : __builtin_fmaf(-step, (float)(n - 1 - i), end);
+}
+
+struct BgPointsArgs {
+  int R, N;                 // rays, inverse-sphere samples per ray (32)
+  const float* cam; int cam_stride;
+  const float* dirs;        // (R,3)
+  const float* jitter;      // (R,N) uniform draws in train mode or nullptr
+  float radius;             // scene_bounding_sphere
+  float* z_bg;              // (R,N) inverse depths, descending (1/r -> 0), as flipped at network_bg.py:82
+  float* pts;               // (R*N,4)
+  float* depth_real;        // (R,N)
+};
+
+// UniformSampler(1, 0, N, far=1) (ray_sampler.py:22-43 via :215-216) + depth2pts_outside (network_bg.py:182-214).
+// One thread per (ray, sample).
+__global__ void bg_points_kernel(BgPointsArgs a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.R * a.N) return;
+  const int r = idx / a.N, k = idx % a.N;
+  const int i = a.N - 1 - k;                              // position before the flip
+  auto zu = [&](int j) { const float t = linspace_at_r(0.0f, 1.0f, a.N, j); return 0.0f * (1.0f - t) + 1.0f * t; };
+  float z = zu(i);
+  if (a.jitter) {
+    const float upper = i < a.N - 1 ? 0.5f * (zu(i + 1) + zu(i)) : zu(a.N - 1);
+    const float lower = i > 0 ? 0.5f * (zu(i) + zu(i - 1)) : zu(0);
+    z = lower + (upper - lower) * a.jitter[(size_t)r * a.N + i];
+  }
+  const float depth = z * (float)(1.0 / (double)a.radius);
+  a.z_bg[idx] = depth;
+  const float* o = a.cam + (size_t)r * a.cam_stride;
+  const float* d = a.dirs + 3 * (size_t)r;
+  const float o_dot_d = (d[0] * o[0] + d[1] * o[1]) + d[2] * o[2];
+  const float under = o_dot_d * o_dot_d - (((o[0] * o[0] + o[1] * o[1]) + o[2] * o[2]) - a.radius * a.radius);
+  const float d_sphere = __builtin_sqrtf(under) - o_dot_d;
+  float ps[3], pm[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { ps[c] = o[c] + d_sphere * d[c]; pm[c] = o[c] - o_dot_d * d[c]; }
+  const float pm_norm = __builtin_sqrtf((pm[0] * pm[0] + pm[1] * pm[1]) + pm[2] * pm[2]);
+  float ax[3] = {o[1] * ps[2] - o[2] * ps[1], o[2] * ps[0] - o[0] * ps[2], o[0] * ps[1] - o[1] * ps[0]};
+  const float axn = __builtin_sqrtf((ax[0] * ax[0] + ax[1] * ax[1]) + ax[2] * ax[2]);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) ax[c] = ax[c] / axn;
+  const float phi = asinf(pm_norm / a.radius);
+  const float theta = asinf(pm_norm * depth);
+  const float ang = phi - theta;
+  const float ca = cosf(ang), sa = sinf(ang);
+  const float cr[3] = {ax[1] * ps[2] - ax[2] * ps[1], ax[2] * ps[0] - ax[0] * ps[2], ax[0] * ps[1] - ax[1] * ps[0]};
+  const float adp = (ax[0] * ps[0] + ax[1] * ps[1]) + ax[2] * ps[2];
+  float pn[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) pn[c] = (ps[c] * ca + cr[c] * sa) + (ax[c] * adp) * (1.0f - ca);
+  const float pnn = __builtin_sqrtf((pn[0] * pn[0] + pn[1] * pn[1]) + pn[2] * pn[2]);
+  a.pts[4 * (size_t)idx] = pn[0] / pnn; a.pts[4 * (size_t)idx + 1] = pn[1] / pnn; a.pts[4 * (size_t)idx + 2] = pn[2] / pnn;
+  a.pts[4 * (size_t)idx + 3] = depth;
+  const float dd = (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2];
+  const float d1 = -o_dot_d / dd;
+  const float ray_d_cos = 1.0f / __builtin_sqrtf(dd);
+  a.depth_real[idx] = ((1.0f / (depth + 1e-6f)) * cosf(theta)) * ray_d_cos + d1;
+}
+
+struct CompositeBgArgs {
+  int R, S, Nb;              // rays, fg samples (97), bg samples (32)
+  const float* z;            // (R,S) fg sample distances
+  const float* z_max;        // (R) sphere exit
+  const float* sdf;          // (R*S)
+  const float* rgb;          // (R*S,3)
+  const float* normals;      // (R*S,3) or nullptr
+  const float* depth_scale;  // (R)
+  const float* beta_param; float beta_min;
+  const float* z_bg;         // (R,Nb) descending inverse depths
+  const float* bg_out0;      // (R*Nb) raw bg output[:,0]; density = |.|
+  const float* bg_rgb;       // (R*Nb,3)
+  const float* bg_depth;     // (R,Nb) conventional depths of the bg samples
+  float* weights;            // (R,S)
+  float* bg_trans;           // (R) transmittance behind the last fg sample
+  float* bg_weights;         // (R,Nb)
+  float* rgb_values;         // (R,3)
+  float* depth_values;       // (R)
+  float* depth_values_all;   // (R)
+  float* depth_vals;         // (R,S)
+  float* normal_map;         // (R,3) or nullptr
+};
+
+// VolSDFNetworkBG.volume_rendering / bg_volume_rendering and the composition (network_bg.py:76-125, 147-180)
+__global__ __launch_bounds__(64) void composite_bg_kernel(CompositeBgArgs a) {
+  __shared__ float zs[kMaxS], fe[kMaxS], sfe[kMaxS], bfe[64], bsf[64];
+  const int r = blockIdx.x, lane = threadIdx.x, S = a.S, Nb = a.Nb;
+  const float beta = __builtin_fabsf(*a.beta_param) + a.beta_min;
+  for (int i = lane; i < S; i += 64) zs[i] = a.z[(size_t)r * S + i];
+  for (int i = lane; i < Nb; i += 64) bsf[i] = a.z_bg[(size_t)r * Nb + i];
+  __syncthreads();
+  for (int i = lane; i < S; i += 64) {
+    const float dist = i < S - 1 ? zs[i + 1] - zs[i] : a.z_max[r] - zs[i];
+    fe[i] = dist * laplace_density(a.sdf[(size_t)r * S + i], beta);
+  }
+  for (int i = lane; i < Nb; i += 64) {
+    const float dist = i < Nb - 1 ? bsf[i] - bsf[i + 1] : 1e10f;
+    bfe[i] = dist * __builtin_fabsf(a.bg_out0[(size_t)r * Nb + i]);
+  }
+  __syncthreads();
+  for (int i = lane; i <= S; i += 64) sfe[i] = i == 0 ? 0.0f : fe[i - 1];      // S + 1 entries: the last is the total
+  for (int i = lane; i < Nb; i += 64) bsf[i] = i == 0 ? 0.0f : bfe[i - 1];
+  __syncthreads();
+  wave_cumsum_excl_out(sfe, sfe, S + 1, lane);
+  __syncthreads();
+  wave_cumsum_excl_out(bsf, bsf, Nb, lane);
+  __syncthreads();
+  const float tbg = det_exp(-sfe[S]);
+  const float ds = a.depth_scale[r];
+  float sw = 0.0f, swz = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, n0 = 0.0f, n1 = 0.0f, n2 = 0.0f, swa = 0.0f, swd = 0.0f;
+  for (int i = lane; i < S; i += 64) {
+    const size_t p = (size_t)r * S + i;
+    const float w = (1.0f - det_exp(-fe[i])) * det_exp(-sfe[i]);
+    a.weights[p] = w;
+    const float dv = zs[i] * ds;
+    a.depth_vals[p] = dv;
+    sw += w; swz += w * dv; swa += w; swd += w * (ds * zs[i]);
+    c0 += w * a.rgb[3 * p]; c1 += w * a.rgb[3 * p + 1]; c2 += w * a.rgb[3 * p + 2];
+    if (a.normal_map) {
+      const float g0 = a.normals[3 * p], g1 = a.normals[3 * p + 1], g2 = a.normals[3 * p + 2];
+      const float nn = __builtin_sqrtf((g0 * g0 + g1 * g1) + g2 * g2);
+      n0 += w * (g0 / nn); n1 += w * (g1 / nn); n2 += w * (g2 / nn);
+    }
+  }
+  float b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
+  for (int i = lane; i < Nb; i += 64) {
+    const size_t p = (size_t)r * Nb + i;
+    const float bw = (1.0f - det_exp(-bfe[i])) * det_exp(-bsf[i]);
+    a.bg_weights[p] = bw;
+    b0 += bw * a.bg_rgb[3 * p]; b1 += bw * a.bg_rgb[3 * p + 1]; b2 += bw * a.bg_rgb[3 * p + 2];
+    const float wa = tbg * bw;
+    swa += wa; swd += wa * (ds * a.bg_depth[p]);
+  }
+  sw = wave_sum(sw); swz = wave_sum(swz); c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2);
+  b0 = wave_sum(b0); b1 = wave_sum(b1); b2 = wave_sum(b2); swa = wave_sum(swa); swd = wave_sum(swd);
+  if (a.normal_map) { n0 = wave_sum(n0); n1 = wave_sum(n1); n2 = wave_sum(n2); }
+  if (lane == 0) {
+    a.bg_trans[r] = tbg;
+    a.rgb_values[3 * r] = c0 + tbg * b0; a.rgb_values[3 * r + 1] = c1 + tbg * b1; a.rgb_values[3 * r + 2] = c2 + tbg * b2;
+    a.depth_values[r] = swz / (sw + 1e-8f);
+    a.depth_values_all[r] = swd / (swa + 1e-8f);
+    if (a.normal_map) { a.normal_map[3 * r] = n0; a.normal_map[3 * r + 1] = n1; a.normal_map[3 * r + 2] = n2; }
+  }
+}
+
 }  // namespace render
 }  // namespace svs
 
@@ -460,6 +610,39 @@ int svs_composite(int n_rays, int n_samples, const float* z, const float* sdf, c
                   depth_values, depth_vals, normal_map};
   composite_kernel<<<n_rays, 64, 0, (hipStream_t)hip_stream>>>(a);
   return check_launch("svs_composite");
+}
+
+// BG model: inverse-sphere samples of a batch of rays (ray_sampler.py:215-216, network_bg.py:79-86).
+// jitter: (n_rays, n_bg) uniform draws in train mode or NULL.  -> z_bg (n_rays,n_bg) descending, pts (n_rays*n_bg,4),
+// depth_real (n_rays,n_bg).
+int svs_bg_points(const float* cam, int cam_stride, const float* dirs, int n_rays, int n_bg, const float* jitter,
+                  float radius, float* z_bg, float* pts, float* depth_real, void* hip_stream) {
+  if (!cam || !dirs || !z_bg || !pts || !depth_real || n_rays <= 0 || n_bg < 2 || n_bg > 64 || (cam_stride != 0 && cam_stride != 3)) {
+    set_error("svs_bg_points: null/invalid argument"); return SVS_EINVAL;
+  }
+  BgPointsArgs a{n_rays, n_bg, cam, cam_stride, dirs, jitter, radius, z_bg, pts, depth_real};
+  const int n = n_rays * n_bg;
+  bg_points_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)hip_stream>>>(a);
+  return check_launch("svs_bg_points");
+}
+
+// BG model: fg weights with the sphere exit as the last interval end, bg weights, composition (network_bg.py:76-125)
+int svs_composite_bg(int n_rays, int n_samples, int n_bg, const float* z, const float* z_max, const float* sdf,
+                     const float* rgb, const float* normals, const float* depth_scale, const float* beta_param,
+                     float beta_min, const float* z_bg, const float* bg_out0, const float* bg_rgb, const float* bg_depth,
+                     float* weights, float* bg_trans, float* bg_weights, float* rgb_values, float* depth_values,
+                     float* depth_values_all, float* depth_vals, float* normal_map, void* hip_stream) {
+  if (!z || !z_max || !sdf || !rgb || !depth_scale || !beta_param || !z_bg || !bg_out0 || !bg_rgb || !bg_depth || !weights ||
+      !bg_trans || !bg_weights || !rgb_values || !depth_values || !depth_values_all || !depth_vals || n_rays <= 0) {
+    set_error("svs_composite_bg: null/invalid argument"); return SVS_EINVAL;
+  }
+  if (n_samples < 2 || n_samples + 1 > kMaxS || n_bg < 2 || n_bg > 64) { set_error("svs_composite_bg: sample counts out of range"); return SVS_ESHAPE; }
+  if (normal_map && !normals) { set_error("svs_composite_bg: normal_map needs normals"); return SVS_EINVAL; }
+  CompositeBgArgs a{n_rays, n_samples, n_bg, z, z_max, sdf, rgb, normals, depth_scale, beta_param, beta_min, z_bg, bg_out0,
+                    bg_rgb, bg_depth, weights, bg_trans, bg_weights, rgb_values, depth_values, depth_values_all, depth_vals,
+                    normal_map};
+  composite_bg_kernel<<<n_rays, 64, 0, (hipStream_t)hip_stream>>>(a);
+  return check_launch("svs_composite_bg");
 }
 
 int svs_composite_bwd(int n_rays, int n_samples, const float* z, const float* sdf, const float* rgb,

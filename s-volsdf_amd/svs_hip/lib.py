@@ -67,6 +67,12 @@ SIGNATURES = {
     "svs_wgrad": (c_int, [_P, _P, ctypes.c_longlong, ctypes.c_longlong, _P, _P, ctypes.c_longlong, ctypes.c_longlong,
                           _P, ctypes.c_longlong, c_int, c_int, _P, _P, c_int, _P, _P]),
     "svs_wgrad_multi": (c_int, [_P, c_int, c_int, _P]),
+    "svs_bg_points": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_float, _P, _P, _P, _P]),
+    "svs_bg_sdf_eval": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P]),
+    "svs_bg_rbuf_bytes": (c_size_t, [c_int]),
+    "svs_bg_rgb_eval": (c_int, [c_int, _P, c_int, _P, _P, _P, _P, _P]),
+    "svs_composite_bg": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P,
+                                 _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "svs_adam_workspace_bytes": (c_size_t, []),
     "svs_clip_guard_adam": (c_int, [_P, _P, _P, _P, ctypes.c_longlong, c_int, c_float, c_float, c_float, c_float, c_float,
                                     _P, _P, _P]),

@@ -196,6 +196,99 @@ def composite(z, sdf, rgb, depth_scale, beta_param, beta_min, normals=None):
                 normal_map=normal_map)
 
 
+# ---------------------------------------------------------------------------------------------------
+# inverted-sphere background model (volsdf/model/network_bg.py), fp16x2 kernels of svs_bg_h2.hip
+# ---------------------------------------------------------------------------------------------------
+class PackedBg:
+    """Packed weight streams of bg_implicit_network / bg_rendering_network (no weight-norm)."""
+
+    def __init__(self, device):
+        L = _lib.load()
+        self.device = device
+        self.sdf_stream = torch.empty(L.svs_stream_bytes(5) // 4, device=device)
+        self.rgb_stream = torch.empty(L.svs_stream_bytes(7) // 4, device=device)
+        self._ws = torch.empty(L.svs_pack_workspace_bytes() // 4, device=device)
+
+    def pack(self, sdf_wb, rgb_wb):
+        """sdf_wb / rgb_wb: (weights, biases) lists of 9 / 2 tensors."""
+        L = _lib.load()
+        self._keep = []
+        for which, (w, b), stream in ((5, sdf_wb, self.sdf_stream), (7, rgb_wb, self.rgb_stream)):
+            w, b = [_f32(t) for t in w], [_f32(t) for t in b]
+            self._keep += [w, b]
+            _lib.check(L.svs_pack_stream(which, F16X2, _ptr_array(w), None, _ptr_array(b), _ptr(self._ws), _ptr(stream),
+                                         _stream()), "svs_pack_stream(bg)")
+
+
+def bg_points(cam, dirs, n_bg, radius, jitter=None):
+    """Inverse-sphere samples (ray_sampler.py:215-216, flipped as network_bg.py:82) and depth2pts_outside
+    (network_bg.py:182-214) -> z_bg (R,n_bg) descending, pts (R*n_bg,4), depth_real (R,n_bg)."""
+    L = _lib.load()
+    cam, dirs = _f32(cam), _f32(dirs)
+    R, dev = dirs.shape[0], dirs.device
+    z_bg = torch.empty(R, n_bg, device=dev)
+    pts = torch.empty(R * n_bg, 4, device=dev)
+    depth = torch.empty(R, n_bg, device=dev)
+    jitter = _f32(jitter) if jitter is not None else None
+    _lib.check(L.svs_bg_points(_ptr(cam), 0 if cam.numel() == 3 else 3, _ptr(dirs), R, n_bg, _ptr(jitter), float(radius),
+                               _ptr(z_bg), _ptr(pts), _ptr(depth), _stream()), "svs_bg_points")
+    return z_bg, pts, depth
+
+
+def bg_sdf_eval(packed, pts, keep=None):
+    """bg_implicit_network (network_bg.py:85-88): pts (P,4) -> out0 (P,1) = output[:, :1], feature tiles."""
+    L = _lib.load()
+    pts = _f32(pts)
+    P, dev = pts.shape[0], pts.device
+    out0 = torch.empty(P, 1, device=dev)
+    feat = torch.empty(L.svs_feat_tiles_bytes(P) // 4, device=dev)
+    hbuf = ghat7 = None
+    if keep is not None:
+        hbuf = torch.empty(L.svs_sdf_hbuf_bytes(P) // 4, device=dev)
+        ghat7 = torch.empty(L.svs_block_bytes(P, 1) // 4, device=dev)
+        keep.update(bg_hbuf=hbuf, bg_ghat7=ghat7, bg_pts=pts)
+    _lib.check(L.svs_bg_sdf_eval(_ptr(pts), P, _ptr(packed.sdf_stream), _ptr(out0), _ptr(feat), _ptr(hbuf), _ptr(ghat7),
+                                 _stream()), "svs_bg_sdf_eval")
+    return out0, feat
+
+
+def bg_rgb_eval(packed, view_dirs, n_bg, feat_tiles, n_points, keep=None):
+    """bg_rendering_network, mode 'nerf' (network_bg.py:91-93): one view direction per ray -> rgb (P,3)."""
+    L = _lib.load()
+    view_dirs = _f32(view_dirs)
+    dev = view_dirs.device
+    rgb = torch.empty(n_points, 3, device=dev)
+    rbuf = None
+    if keep is not None:
+        rbuf = torch.empty(L.svs_bg_rbuf_bytes(n_points) // 4, device=dev)
+        keep.update(bg_rbuf=rbuf, bg_feat=feat_tiles, bg_rgb=rgb)
+    _lib.check(L.svs_bg_rgb_eval(n_points, _ptr(view_dirs), n_bg, _ptr(feat_tiles), _ptr(packed.rgb_stream), _ptr(rgb),
+                                 _ptr(rbuf), _stream()), "svs_bg_rgb_eval")
+    return rgb
+
+
+def composite_bg(z, z_max, sdf, rgb, depth_scale, beta_param, beta_min, z_bg, bg_out0, bg_rgb, bg_depth, normals=None):
+    """volume_rendering / bg_volume_rendering and the composition of VolSDFNetworkBG.forward (network_bg.py:76-125)."""
+    L = _lib.load()
+    z = _f32(z)
+    R, S = z.shape
+    Nb = z_bg.shape[1]
+    dev = z.device
+    beta_param = _f32(beta_param).reshape(1)
+    f = lambda *s: torch.empty(*s, device=dev)
+    weights, bg_trans, bg_w = f(R, S), f(R), f(R, Nb)
+    rgb_values, depth_values, depth_all, depth_vals = f(R, 3), f(R, 1), f(R, 1), f(R, S)
+    normal_map = f(R, 3) if normals is not None else None
+    _lib.check(L.svs_composite_bg(R, S, Nb, _ptr(z), _ptr(_f32(z_max)), _ptr(_f32(sdf)), _ptr(_f32(rgb)),
+                                  _ptr(_f32(normals)) if normals is not None else None, _ptr(_f32(depth_scale)),
+                                  _ptr(beta_param), float(beta_min), _ptr(_f32(z_bg)), _ptr(_f32(bg_out0)), _ptr(_f32(bg_rgb)),
+                                  _ptr(_f32(bg_depth)), _ptr(weights), _ptr(bg_trans), _ptr(bg_w), _ptr(rgb_values),
+                                  _ptr(depth_values), _ptr(depth_all), _ptr(depth_vals), _ptr(normal_map), _stream()),
+               "svs_composite_bg")
+    return dict(weights=weights, bg_transmittance=bg_trans, bg_weights=bg_w, rgb_values=rgb_values,
+                depth_values=depth_values, depth_values_all=depth_all, depth_vals=depth_vals, normal_map=normal_map)
+
+
 def composite_bwd(z, sdf, rgb, depth_scale, beta_param, beta_min, d_rgb_values, d_weights=None, d_depth_values=None):
     """Reverse pass of `composite`: -> d_sdf (R*S,1), d_rgb (R*S,3), d_beta_param (1,)."""
     L = _lib.load()

@@ -1,0 +1,143 @@
+"""VolSDFNetworkBG with the reference's class name, constructor, state-dict keys and forward() contract
+(volsdf/model/network_bg.py): the foreground VolSDF model plus the NeRF++ inverted-sphere background, evaluated by
+the fused HIP kernels (svs_mlp_h2.hip for the foreground networks, svs_bg_h2.hip for the background networks,
+svs_render.hip for the inverse-sphere points and the fg/bg compositing).
+
+`train.model_class: volsdf.model.network_bg.VolSDFNetworkBG` (config/vol/bmvs.yaml:4).  Checkpoint keys:
+`implicit_network.*`, `rendering_network.*`, `density.beta`, `bg_implicit_network.lin{0..8}.{weight,bias}`,
+`bg_rendering_network.lin{0,1}.{weight,bias}`.
+"""
+import torch
+import torch.nn as nn
+
+from svs_hip import ops
+from volsdf.model.density import AbsDensity, LaplaceDensity
+from volsdf.model.network import ImplicitNetwork, RenderingNetwork, _dev
+from volsdf.model.ray_sampler import ErrorBoundSampler
+
+
+class VolSDFNetworkBG(nn.Module):
+    def __init__(self, conf):
+        super().__init__()
+        self.feature_vector_size = conf.get_int('feature_vector_size')
+        self.scene_bounding_sphere = conf.get_float('scene_bounding_sphere', default=1.0)
+        # foreground object's networks (no sphere clamp: network_bg.py:25)
+        self.implicit_network = ImplicitNetwork(self.feature_vector_size, 0.0, **conf.get_config('implicit_network'))
+        self.rendering_network = RenderingNetwork(self.feature_vector_size, **conf.get_config('rendering_network'))
+        self.density = LaplaceDensity(**conf.get_config('density'))
+        self.ray_sampler = ErrorBoundSampler(self.scene_bounding_sphere, inverse_sphere_bg=True,
+                                             **conf.get_config('ray_sampler'))
+        # background's networks
+        bg_feature_vector_size = conf.get_int('bg_network.feature_vector_size')
+        self.bg_implicit_network = ImplicitNetwork(bg_feature_vector_size, 0.0, **conf.get_config('bg_network.implicit_network'))
+        self.bg_rendering_network = RenderingNetwork(bg_feature_vector_size, **conf.get_config('bg_network.rendering_network'))
+        self.bg_density = AbsDensity(**conf.get_config('bg_network.density', default={}))
+        bi, br = self.bg_implicit_network, self.bg_rendering_network
+        if not (bi.num_layers == 10 and not bi.weight_norm and bi.lin0.weight.shape == (256, 84) and
+                bi.lin3.weight.shape == (172, 256) and bi.lin8.weight.shape == (257, 256) and br.mode == "nerf" and
+                not br.weight_norm and br.num_layers == 3 and br.lin0.weight.shape == (128, 283)):
+            raise NotImplementedError("the background kernels are built for bmvs.yaml's bg_network (4-D PE-10 8x256 "
+                                      "skip-4 implicit network, 283->128->3 'nerf' radiance network, no weight-norm)")
+        self._pk = self._pk_bg = None
+        self._bg_key = None
+
+    # ---- packed weights -------------------------------------------------------------------------------------
+    def packed_mlp(self):
+        if self._pk is None or self._pk.device != _dev(self):
+            self._pk = ops.PackedMlp(_dev(self))
+        self.implicit_network.packed(owner=self._pk)
+        self.rendering_network.pack_into(self._pk)
+        return self._pk
+
+    def bg_params(self):
+        bi, br = self.bg_implicit_network, self.bg_rendering_network
+        sw = [getattr(bi, f"lin{l}").weight for l in range(9)], [getattr(bi, f"lin{l}").bias for l in range(9)]
+        rw = [getattr(br, f"lin{l}").weight for l in range(2)], [getattr(br, f"lin{l}").bias for l in range(2)]
+        return sw, rw
+
+    def packed_bg(self):
+        if self._pk_bg is None or self._pk_bg.device != _dev(self):
+            self._pk_bg, self._bg_key = ops.PackedBg(_dev(self)), None
+        sw, rw = self.bg_params()
+        key = tuple((t.data_ptr(), t._version) for t in sw[0] + sw[1] + rw[0] + rw[1])
+        if key != self._bg_key:
+            self._pk_bg.pack(sw, rw)
+            self._bg_key = key
+        return self._pk_bg
+
+    def invalidate_packed(self):
+        self.implicit_network._packed_key = None
+        if self._pk is not None:
+            self._pk._sdf_key = self._pk._rgb_key = None
+        self._bg_key = None
+
+    # ---- forward --------------------------------------------------------------------------------------------
+    def draw_train_rng(self, R, dev):
+        rb = self.scene_bounding_sphere
+
+        def eik(slot, n):
+            if n is None:
+                slot["eik_points"] = torch.empty(R, 3).uniform_(-rb, rb)
+                return ["eik_points"]
+            if "eik_points" not in slot:
+                slot["eik_points"] = torch.empty(R, 3).pin_memory()
+            slot["eik_points"].uniform_(-rb, rb)
+            return ["eik_points"]
+
+        return self.ray_sampler.draw_train_rng(R, dev, extra=eik)
+
+    def forward(self, input, fast=-1):
+        if self.training and torch.is_grad_enabled():
+            raise NotImplementedError("training of VolSDFNetworkBG goes through svs_hip.trainer (fused backward); "
+                                      "wrap evaluation in torch.no_grad()")
+        return self._forward_impl(input, fast, None)
+
+    def _forward_impl(self, input, fast, keep, rng=None):
+        """network_bg.py:37-145 on the HIP kernels."""
+        intrinsics, uv, pose = input["intrinsics"], input["uv"], input["pose"]
+        if uv.shape[0] != 1:
+            raise NotImplementedError("batch_size 1 only (runner.py:166)")
+        net = self.implicit_network
+        pk, pkb = self.packed_mlp(), self.packed_bg()
+        ray_dirs, cam_loc, depth_scale = ops.rays_from_uv(uv[0], pose[0], intrinsics[0])
+        R = ray_dirs.shape[0]
+        if self.training and rng is None:
+            rng = self.draw_train_rng(R, ray_dirs.device)
+        (z_all, _), z_samples_eik = self.ray_sampler.get_z_vals(ray_dirs, cam_loc, self, fast=fast,
+                                                                iter_step=input.get("iter_step", 1), rng=rng)
+        z_bg, bg_pts, bg_depth = self.ray_sampler._bg_last
+        z_max = z_all[:, -1].contiguous()
+        z_vals = z_all[:, :-1].contiguous()
+        S, Nb = z_vals.shape[1], z_bg.shape[1]
+        n_main = R * S
+        eikonal_points = None
+        if self.training:
+            eik_near = cam_loc.view(1, 3) + z_samples_eik * ray_dirs
+            eikonal_points = torch.cat([rng["eik_points"], eik_near], 0)
+        src = ops.PointSource(points=eikonal_points, cam=cam_loc, dirs=ray_dirs, z=z_vals)
+        sdf, gradients, feat_tiles, _, _ = ops.sdf_outputs(pk, src, 0.0, net.sphere_scale, clamp_n=n_main, keep=keep)
+        grad_theta = gradients[n_main:]
+        sdf, gradients = sdf[:n_main], gradients[:n_main]
+        view_dirs = ray_dirs
+        if not self.training:
+            # nearest training view's directions (network_bg.py:69-74)
+            view_dirs, _, _ = ops.rays_from_uv(uv[0], input["near_pose"][0].to(uv.device), intrinsics[0])
+        src_main = ops.PointSource(cam=cam_loc, dirs=ray_dirs, z=z_vals)
+        rgb_flat = ops.rgb_eval(pk, src_main, gradients, view_dirs, feat_tiles, keep=keep)
+        # background (network_bg.py:78-100)
+        bg_out0, bg_feat = ops.bg_sdf_eval(pkb, bg_pts, keep=keep)
+        bg_rgb = ops.bg_rgb_eval(pkb, view_dirs, Nb, bg_feat, R * Nb, keep=keep)
+        comp = ops.composite_bg(z_vals, z_max, sdf, rgb_flat, depth_scale, self.density.beta, self.density.beta_min_value,
+                                z_bg, bg_out0, bg_rgb, bg_depth, normals=None if self.training else gradients)
+        if keep is not None:
+            keep.update(z_vals=z_vals, z_max=z_max, sdf=sdf, rgb_flat=rgb_flat, depth_scale=depth_scale, cam_loc=cam_loc,
+                        ray_dirs=ray_dirs, z_bg=z_bg, bg_out0=bg_out0, bg_depth=bg_depth, comp=comp)
+        points = cam_loc.view(1, 1, 3) + z_vals.unsqueeze(2) * ray_dirs.unsqueeze(1)
+        output = {'rgb_values': comp["rgb_values"], 'depth_values_all': comp["depth_values_all"],
+                  'depth_values': comp["depth_values"], 'depth_vals': comp["depth_vals"], 'weights': comp["weights"],
+                  'xyz': points}
+        if self.training:
+            output['grad_theta'] = grad_theta
+        else:
+            output['normal_map'] = comp["normal_map"]
+        return output

@@ -81,6 +81,8 @@ class ErrorBoundSampler(RaySampler):
             host = dict(jitter=torch.rand(R, self.N_samples_eval), u=torch.rand(R, self.N_samples),
                         perm=torch.randperm(self.N_samples_eval)[:self.N_samples_extra].to(torch.int32),
                         eik_idx=torch.randint(n_out, (R,)).to(torch.int32))
+            if self.inverse_sphere_bg:
+                host["jitter_bg"] = torch.rand(R, self.inverse_sphere_sampler.N_samples)
             if extra is not None:
                 extra(host, None)
             return host
@@ -103,6 +105,12 @@ class ErrorBoundSampler(RaySampler):
         torch.randint(n_out, (R,), out=slot["eik64"])
         slot["eik_idx"].copy_(slot["eik64"])
         names = ["jitter", "u", "perm", "eik_idx"]
+        if self.inverse_sphere_bg:
+            # the inverse-sphere sampler jitters too, after the eikonal pick (ray_sampler.py:215 -> :39)
+            if "jitter_bg" not in slot:
+                slot["jitter_bg"] = torch.empty(R, self.inverse_sphere_sampler.N_samples).pin_memory()
+            torch.rand(R, self.inverse_sphere_sampler.N_samples, out=slot["jitter_bg"])
+            names.append("jitter_bg")
         if extra is not None:
             names += extra(slot, R)
         out = {k: torch.empty(slot[k].shape, dtype=slot[k].dtype, device=dev) for k in names}
@@ -143,8 +151,12 @@ class ErrorBoundSampler(RaySampler):
                                    training=model.training, inverse_sphere_bg=self.inverse_sphere_bg,
                                    add_tiny=self.add_tiny, inv_4log=self._inv_4log, rng=rng, workspace=self._ws)
         if self.inverse_sphere_bg:
-            z_bg = self.inverse_sphere_sampler.get_z_vals(ray_dirs, cam_loc, model) * (1. / self.scene_bounding_sphere)
-            z = (z, z_bg)
+            # inverse-sphere samples + their 4-D points in one small kernel; the model picks the points up from
+            # _bg_last (z_bg descending, points, conventional depths); the reference returns z_bg ascending
+            jit = rng.get("jitter_bg") if (model.training and rng) else None
+            self._bg_last = ops.bg_points(cam_loc, ray_dirs, self.inverse_sphere_sampler.N_samples,
+                                          self.scene_bounding_sphere, jitter=jit)
+            z = (z, torch.flip(self._bg_last[0], dims=[-1]))
         return z, z_eik
 
     def get_error_bound(self, beta, model, sdf, z_vals, dists, d_star):

@@ -10,7 +10,7 @@ def inject_rng(draws):
     """Replaces the CPU-generator call sites of the model (reference order: jitter, u, randperm, randint, uniform_)
     so that they return the given draws; honours the out= form used by the pinned staging of the draws."""
     o = (torch.rand, torch.randperm, torch.randint, torch.Tensor.uniform_)
-    q = [draws["jitter"], draws["u"]]
+    q = [draws["jitter"], draws["u"]] + ([draws["jitter_bg"]] if "jitter_bg" in draws else [])
 
     def give(v, k):
         t = torch.from_numpy(np.ascontiguousarray(v))

@@ -1,0 +1,124 @@
+"""The fg + inverted-sphere background model (VolSDFNetworkBG, config 4) on the HIP kernels against the reference's
+fixtures (tests/golden/forward_bg_*.npz) and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import svs_oracle as orc
+import synth
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def golden_dir():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def G(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _params():
+    p = dict(synth.make_params(0))
+    p.update(synth.make_bg_params(0))
+    return p
+
+
+def _model(dev, beta):
+    from ref_shim import bmvs_model_conf
+    from volsdf.model.network_bg import VolSDFNetworkBG
+    m = VolSDFNetworkBG(bmvs_model_conf())
+    sd = {k: torch.from_numpy(v) for k, v in _params().items()}
+    sd["density.beta"] = torch.tensor(beta, dtype=torch.float32)
+    m.load_state_dict(sd, strict=True)
+    return m.to(dev)
+
+
+@pytest.mark.parametrize("tag", ["eval_b0.1", "train"])
+def test_bg_pieces(dev, golden_dir, tag):
+    """inverse-sphere points, bg implicit / radiance networks and the fg/bg compositing, each on the reference's inputs"""
+    from svs_hip import ops
+    g = dict(np.load(os.path.join(golden_dir, "forward_bg_" + tag + ".npz")))
+    params = _params()
+    R, Nb = g["z_bg"].shape
+    dirs, cam, ds = orc.rays_from_uv(g["uv"], g["pose"], g["K"])
+    jit = synth.make_train_rng(R, seed=int(g["rng_seed"]), bg=True)["jitter_bg"] if tag == "train" else None
+    z_bg, pts, depth = ops.bg_points(G(cam, dev), G(dirs, dev), Nb, 3.0, jitter=G(jit, dev) if jit is not None else None)
+    np.testing.assert_allclose(z_bg.cpu().numpy(), g["z_bg"], atol=3e-8)
+    np.testing.assert_allclose(pts.cpu().numpy().reshape(R, Nb, 4), g["bg_points"], atol=3e-6)
+    np.testing.assert_allclose(depth.cpu().numpy(), g["bg_depth"], rtol=3e-5)
+    m = _model(dev, float(g["beta_param"]))
+    pkb = m.packed_bg()
+    out0, feat = ops.bg_sdf_eval(pkb, G(g["bg_points"].reshape(-1, 4), dev))
+    np.testing.assert_allclose(out0.cpu().numpy(), g["bg_sdf"], atol=1e-4)
+    ref_out = orc.sdf_mlp_forward(orc.effective_weights(params, "bg_implicit_network", 9), g["bg_points"].reshape(-1, 4), multires=10)
+    rows = torch.empty(R * Nb, 256, device=dev)
+    from svs_hip import lib
+    import ctypes
+    lib.check(lib.load().svs_tiles_to_rows(ctypes.c_void_p(feat.data_ptr()), R * Nb, ctypes.c_void_p(rows.data_ptr()),
+                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    np.testing.assert_allclose(rows.cpu().numpy(), ref_out[:, 1:], atol=1e-4)
+    view = orc.rays_from_uv(g["uv"], g["near_pose"], g["K"])[0] if tag != "train" else dirs
+    rgb = ops.bg_rgb_eval(pkb, G(view, dev), Nb, feat, R * Nb)
+    ref_rgb = orc.rgb_mlp_forward(orc.effective_weights(params, "bg_rendering_network", 2), None, None,
+                                  np.repeat(view[:, None], Nb, 1).reshape(-1, 3), ref_out[:, 1:], mode="nerf", multires_view=4)
+    np.testing.assert_allclose(rgb.cpu().numpy(), ref_rgb, atol=1e-4)
+    # compositing on the fixture's arrays
+    S = g["z_vals"].shape[1]
+    rs = np.random.default_rng(1)
+    sdf = rs.normal(0, 0.2, (R, S)).astype(F32)
+    frgb = rs.uniform(0, 1, (R, S, 3)).astype(F32)
+    beta = orc.get_beta(g["beta_param"])
+    w_ref, t_ref, _ = orc.fg_weights_bg_model(g["z_vals"], g["z_max"], sdf, beta)
+    bw_ref = orc.bg_weights(g["z_bg"], np.abs(g["bg_sdf"]).reshape(R, Nb))
+    comp = ops.composite_bg(G(g["z_vals"], dev), G(g["z_max"], dev), G(sdf.reshape(-1, 1), dev), G(frgb.reshape(-1, 3), dev),
+                            G(ds, dev), G(g["beta_param"], dev), 1e-4, G(g["z_bg"], dev), G(g["bg_sdf"], dev),
+                            G(ref_rgb, dev), G(g["bg_depth"], dev))
+    np.testing.assert_array_equal(comp["weights"].cpu().numpy(), w_ref)
+    np.testing.assert_array_equal(comp["bg_transmittance"].cpu().numpy(), t_ref)
+    np.testing.assert_array_equal(comp["bg_weights"].cpu().numpy(), bw_ref)
+    rgb_ref = (w_ref[:, :, None] * frgb).sum(1) + t_ref[:, None] * (bw_ref[:, :, None] * ref_rgb.reshape(R, Nb, 3)).sum(1)
+    np.testing.assert_allclose(comp["rgb_values"].cpu().numpy(), rgb_ref, atol=2e-6)
+
+
+@pytest.mark.parametrize("tag", ["eval_b0.1", "eval_b0.01", "train"])
+def test_bg_model_forward_golden(dev, golden_dir, tag):
+    """VolSDFNetworkBG.forward (HIP) against the reference's outputs."""
+    from rng_inject import inject_rng
+    g = dict(np.load(os.path.join(golden_dir, "forward_bg_" + tag + ".npz")))
+    m = _model(dev, float(g["beta_param"]))
+    training = tag == "train"
+    m.train(training)
+    R = g["uv"].shape[0]
+    inp = {"intrinsics": G(g["K"], dev)[None], "uv": G(g["uv"], dev)[None], "pose": G(g["pose"], dev)[None],
+           "near_pose": G(g["near_pose"], dev)[None]}
+    with torch.no_grad():
+        if training:
+            with inject_rng(synth.make_train_rng(R, seed=int(g["rng_seed"]), bg=True)):
+                out = m(inp, fast=int(g["fast"]))
+        else:
+            out = m(inp, fast=int(g["fast"]))
+    out = {k: v.detach().cpu().numpy() for k, v in out.items()}
+    same = np.abs(out["depth_vals"] - g["depth_vals"]).max(-1) < 3e-4
+    assert same.mean() >= 0.75, same
+    np.testing.assert_allclose(out["xyz"][same], g["xyz"][same], atol=3e-4)
+    np.testing.assert_allclose(out["rgb_values"][same], g["rgb_values"][same], atol=1e-4)
+    np.testing.assert_allclose(out["rgb_values"], g["rgb_values"], atol=5e-4)
+    assert np.abs(out["weights"][same] - g["weights"][same]).mean() < 2e-5
+    wsum = g["weights"].sum(1, keepdims=True)
+    assert (np.abs(out["depth_values"] - g["depth_values"])[same] <= 3e-4 / np.maximum(wsum[same], 1e-3)).all()
+    np.testing.assert_allclose(out["depth_values_all"][same], g["depth_values_all"][same], rtol=3e-3)
+    if training:
+        np.testing.assert_allclose(out["grad_theta"][:R], g["grad_theta"][:R], atol=2e-4)
+    else:
+        np.testing.assert_allclose(out["normal_map"][same], g["normal_map"][same], atol=2e-4)
