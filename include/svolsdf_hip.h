@@ -153,6 +153,12 @@ int svs_composite_bg(int n_rays, int n_samples, int n_bg, const float* z, const 
                      float beta_min, const float* z_bg, const float* bg_out0, const float* bg_rgb, const float* bg_depth,
                      float* weights, float* bg_trans, float* bg_weights, float* rgb_values, float* depth_values,
                      float* depth_values_all, float* depth_vals, float* normal_map, void* hip_stream);
+/* backward of svs_composite_bg: d_weights / d_depth_values may be NULL; d_beta_ray (n_rays) is workspace */
+int svs_composite_bg_bwd(int n_rays, int n_samples, int n_bg, const float* z, const float* z_max, const float* sdf,
+                         const float* rgb, const float* depth_scale, const float* beta_param, float beta_min,
+                         const float* z_bg, const float* bg_out0, const float* bg_rgb, const float* d_rgb_values,
+                         const float* d_weights, const float* d_depth_values, float* d_sdf, float* d_rgb,
+                         float* d_bg_out0, float* d_bg_rgb, float* d_beta_ray, float* d_beta_param, void* hip_stream);
 
 /* ---- a12  weight-gradient contraction of the training backward ---------------------------------------------------
  * dW[256][ldw] += sum over points of A(:,p) B(:,p)^T for one or two operand pairs stored as wave-tile activation

@@ -106,3 +106,65 @@ def forward_differentiable(p, cam, dirs, z, eik_points, depth_scale, radius=3.0,
                                             torch.tensor(np.asarray(depth_scale), dtype=dt))
     _, _, gt = sdf_outputs(p, torch.tensor(np.asarray(eik_points), dtype=dt), clamp=False)
     return dict(rgb_values=rgb_values, depth_values=depth_values, weights=w, grad_theta=gt, sdf=sdf, rgb=rgb)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# VolSDFNetworkBG (volsdf/model/network_bg.py), train mode, after the sampler
+# ---------------------------------------------------------------------------------------------------------
+def bg_sdf_mlp(p, x):
+    """bg_implicit_network: ImplicitNetwork with d_in 4, multires 10, no weight-norm (network.py:71-88) -> (P,257)"""
+    inp = posenc(x, 10)
+    h = inp
+    for l in range(9):
+        if l == 4:
+            h = torch.cat([h, inp], 1) / np.sqrt(2)
+        h = h @ p[f"bg_implicit_network.lin{l}.weight"].T + p[f"bg_implicit_network.lin{l}.bias"]
+        if l < 8:
+            h = torch.nn.functional.softplus(h, beta=100)
+    return h
+
+
+def bg_rgb_mlp(p, d, feat):
+    """bg_rendering_network, mode nerf (network.py:176): cat[PE4(view), feature] -> 128 -> 3"""
+    h = torch.cat([posenc(d, 4), feat], -1)
+    h = torch.relu(h @ p["bg_rendering_network.lin0.weight"].T + p["bg_rendering_network.lin0.bias"])
+    return torch.sigmoid(h @ p["bg_rendering_network.lin1.weight"].T + p["bg_rendering_network.lin1.bias"])
+
+
+def composite_bg(z, z_max, sdf, rgb, beta_param, ds, z_bg, bg_out0, bg_rgb, beta_min=1e-4):
+    """network_bg.py:76-125,147-180 -> weights, bg_transmittance, rgb_values, depth_values"""
+    beta = beta_param.abs() + beta_min
+    sigma = (1 / beta) * (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() / beta))
+    dists = torch.cat([z[:, 1:] - z[:, :-1], z_max.unsqueeze(-1) - z[:, -1:]], -1)
+    fe = dists * sigma
+    sfe = torch.cat([torch.zeros_like(fe[:, :1]), fe], -1)
+    trans = torch.exp(-torch.cumsum(sfe, -1))
+    w = (1 - torch.exp(-fe)) * trans[:, :-1]
+    t_bg = trans[:, -1]
+    bdists = torch.cat([z_bg[:, :-1] - z_bg[:, 1:], torch.full_like(z_bg[:, :1], 1e10)], -1)
+    bfe = bdists * bg_out0.abs()
+    bsfe = torch.cat([torch.zeros_like(bfe[:, :1]), bfe[:, :-1]], -1)
+    bw = (1 - torch.exp(-bfe)) * torch.exp(-torch.cumsum(bsfe, -1))
+    rgb_values = (w.unsqueeze(-1) * rgb).sum(1) + t_bg.unsqueeze(-1) * (bw.unsqueeze(-1) * bg_rgb).sum(1)
+    dv = z * ds
+    depth_values = (w * dv).sum(1, keepdim=True) / (w.sum(1, keepdim=True) + 1e-8)
+    return w, t_bg, rgb_values, depth_values
+
+
+def forward_differentiable_bg(p, cam, dirs, z, z_max, eik_points, depth_scale, z_bg, bg_pts):
+    """VolSDFNetworkBG.forward after the sampler and depth2pts_outside, train mode (network_bg.py:60-134)."""
+    R, S = z.shape
+    Nb = z_bg.shape[1]
+    dt = p["density.beta"].dtype
+    T = lambda a: torch.tensor(np.asarray(a), dtype=dt)
+    cam_t, dirs_t, z_t = T(cam), T(dirs), T(z)
+    pts = (cam_t.view(1, 1, 3) + z_t.unsqueeze(2) * dirs_t.unsqueeze(1)).reshape(-1, 3)
+    sdf, feat, grad = sdf_outputs(p, pts, 0.0, 1.0)
+    rgb = rgb_mlp(p, pts, grad, dirs_t.unsqueeze(1).repeat(1, S, 1).reshape(-1, 3), feat).reshape(R, S, 3)
+    bg_out = bg_sdf_mlp(p, T(bg_pts).reshape(-1, 4))
+    bg_rgb = bg_rgb_mlp(p, dirs_t.unsqueeze(1).repeat(1, Nb, 1).reshape(-1, 3), bg_out[:, 1:]).reshape(R, Nb, 3)
+    w, t_bg, rgb_values, depth_values = composite_bg(z_t, T(z_max), sdf.reshape(R, S), rgb, p["density.beta"], T(depth_scale),
+                                                     T(z_bg), bg_out[:, 0].reshape(R, Nb), bg_rgb)
+    _, _, gt = sdf_outputs(p, T(eik_points), clamp=False)
+    return dict(rgb_values=rgb_values, depth_values=depth_values, weights=w, grad_theta=gt, sdf=sdf, rgb=rgb,
+                bg_out0=bg_out[:, :1], bg_rgb=bg_rgb, bg_transmittance=t_bg)

@@ -577,6 +577,124 @@ __global__ __launch_bounds__(64) void composite_bg_kernel(CompositeBgArgs a) {
   }
 }
 
+struct CompositeBgBwdArgs {
+  int R, S, Nb;
+  const float* z; const float* z_max; const float* sdf; const float* rgb; const float* depth_scale;
+  const float* beta_param; float beta_min;
+  const float* z_bg; const float* bg_out0; const float* bg_rgb;
+  const float* d_rgb_values;   // (R,3)
+  const float* d_weights;      // (R,S) or nullptr
+  const float* d_depth_values; // (R) or nullptr (the fg depth of network_bg.py:111-112)
+  float* d_sdf;                // (R*S)
+  float* d_rgb;                // (R*S,3)
+  float* d_bg_out0;            // (R*Nb)
+  float* d_bg_rgb;             // (R*Nb,3)
+  float* d_beta_ray;           // (R)
+};
+
+// backward of composite_bg_kernel with respect to sdf, rgb, beta, the bg density logits and the bg colours
+__global__ __launch_bounds__(64) void composite_bg_bwd_kernel(CompositeBgBwdArgs a) {
+  __shared__ float zs[kMaxS], fe[kMaxS], tr[kMaxS], dw[kMaxS], pre[kMaxS], bz[64], bfe[64], btr[64], bdw[64], bpre[64];
+  const int r = blockIdx.x, lane = threadIdx.x, S = a.S, Nb = a.Nb;
+  const float beta = __builtin_fabsf(*a.beta_param) + a.beta_min;
+  for (int i = lane; i < S; i += 64) zs[i] = a.z[(size_t)r * S + i];
+  for (int i = lane; i < Nb; i += 64) bz[i] = a.z_bg[(size_t)r * Nb + i];
+  __syncthreads();
+  const float zmax = a.z_max[r];
+  for (int i = lane; i < S; i += 64) {
+    const float dist = i < S - 1 ? zs[i + 1] - zs[i] : zmax - zs[i];
+    fe[i] = dist * laplace_density(a.sdf[(size_t)r * S + i], beta);
+  }
+  for (int i = lane; i < Nb; i += 64) {
+    const float dist = i < Nb - 1 ? bz[i] - bz[i + 1] : 1e10f;
+    bfe[i] = dist * __builtin_fabsf(a.bg_out0[(size_t)r * Nb + i]);
+  }
+  __syncthreads();
+  for (int i = lane; i <= S; i += 64) tr[i] = i == 0 ? 0.0f : fe[i - 1];
+  for (int i = lane; i < Nb; i += 64) btr[i] = i == 0 ? 0.0f : bfe[i - 1];
+  __syncthreads();
+  wave_cumsum_excl_out(tr, tr, S + 1, lane);
+  __syncthreads();
+  wave_cumsum_excl_out(btr, btr, Nb, lane);
+  __syncthreads();
+  const float tbg = det_exp(-tr[S]);
+  const float ds = a.depth_scale[r];
+  const float g0 = a.d_rgb_values[3 * r], g1 = a.d_rgb_values[3 * r + 1], g2 = a.d_rgb_values[3 * r + 2];
+  // background: weights, colour sums
+  float bdot = 0.0f;       // sum_c g_c * sum_k bw_k cb_kc
+  for (int i = lane; i < Nb; i += 64) {
+    const size_t p = (size_t)r * Nb + i;
+    const float T = det_exp(-btr[i]);
+    btr[i] = T;
+    const float bw = (1.0f - det_exp(-bfe[i])) * T;
+    const float c0 = a.bg_rgb[3 * p], c1 = a.bg_rgb[3 * p + 1], c2 = a.bg_rgb[3 * p + 2];
+    a.d_bg_rgb[3 * p] = (tbg * bw) * g0; a.d_bg_rgb[3 * p + 1] = (tbg * bw) * g1; a.d_bg_rgb[3 * p + 2] = (tbg * bw) * g2;
+    const float cg = (c0 * g0 + c1 * g1) + c2 * g2;
+    bdot += bw * cg;
+    bdw[i] = tbg * cg;                 // d loss / d bw_i
+    bpre[i] = bdw[i] * bw;
+  }
+  bdot = wave_sum(bdot);
+  // foreground: weights and their sums
+  float sw = 0.0f, swz = 0.0f;
+  for (int i = lane; i < S; i += 64) {
+    const float T = det_exp(-tr[i]);
+    tr[i] = T;
+    const float w = (1.0f - det_exp(-fe[i])) * T;
+    pre[i] = w;
+    sw += w; swz += w * (zs[i] * ds);
+  }
+  sw = wave_sum(sw); swz = wave_sum(swz);
+  __syncthreads();
+  const float gd = a.d_depth_values ? a.d_depth_values[r] : 0.0f;
+  const float den = sw + 1e-8f;
+  for (int i = lane; i < S; i += 64) {
+    const size_t p = (size_t)r * S + i;
+    const float w = pre[i];
+    const float c0 = a.rgb[3 * p], c1 = a.rgb[3 * p + 1], c2 = a.rgb[3 * p + 2];
+    a.d_rgb[3 * p] = w * g0; a.d_rgb[3 * p + 1] = w * g1; a.d_rgb[3 * p + 2] = w * g2;
+    float d = (c0 * g0 + c1 * g1) + c2 * g2;
+    if (a.d_weights) d += a.d_weights[p];
+    d += gd * ((zs[i] * ds) * den - swz) / (den * den);
+    dw[i] = d;
+    pre[i] = d * w;
+  }
+  __syncthreads();
+  const float tot = wave_cumsum_excl_out(pre, pre, S, lane);
+  __syncthreads();
+  const float btot = wave_cumsum_excl_out(bpre, bpre, Nb, lane);
+  __syncthreads();
+  float dbeta = 0.0f;
+  for (int i = lane; i < S; i += 64) {
+    const size_t p = (size_t)r * S + i;
+    const float suffix = tot - pre[i];
+    // every free energy also attenuates the background term: d (tbg * B) / d fe_i = -tbg * B
+    const float dfe = (dw[i] * tr[i] * det_exp(-fe[i]) - suffix) - tbg * bdot;
+    const float dist = i < S - 1 ? zs[i + 1] - zs[i] : zmax - zs[i];
+    const float dsig = dfe * dist;
+    const float s = a.sdf[p];
+    const float as = __builtin_fabsf(s);
+    const float e = det_exp(-as / beta);
+    const float sgn = s > 0.0f ? 1.0f : (s < 0.0f ? -1.0f : 0.0f);
+    const float sigma = (1.0f / beta) * (0.5f + 0.5f * sgn * (e - 1.0f));
+    a.d_sdf[p] = (s != 0.0f) ? dsig * (-0.5f * e / (beta * beta)) : 0.0f;
+    const float dsig_dbeta = -sigma / beta + 0.5f * sgn * e * as / (beta * beta * beta);
+    dbeta += dsig * dsig_dbeta;
+  }
+  for (int i = lane; i < Nb; i += 64) {
+    const size_t p = (size_t)r * Nb + i;
+    const float suffix = btot - bpre[i];
+    const float dfe = bdw[i] * btr[i] * det_exp(-bfe[i]) - suffix;
+    const float dist = i < Nb - 1 ? bz[i] - bz[i + 1] : 1e10f;
+    const float o = a.bg_out0[p];
+    const float sg = o > 0.0f ? 1.0f : (o < 0.0f ? -1.0f : 0.0f);
+    // exp(-fe) underflows long before dist = 1e10 matters; guard the 0 * inf of the last sample
+    a.d_bg_out0[p] = dfe != 0.0f ? (dfe * dist) * sg : 0.0f;
+  }
+  dbeta = wave_sum(dbeta);
+  if (lane == 0) a.d_beta_ray[r] = dbeta;
+}
+
 }  // namespace render
 }  // namespace svs
 
@@ -643,6 +761,26 @@ int svs_composite_bg(int n_rays, int n_samples, int n_bg, const float* z, const 
                     normal_map};
   composite_bg_kernel<<<n_rays, 64, 0, (hipStream_t)hip_stream>>>(a);
   return check_launch("svs_composite_bg");
+}
+
+// backward of svs_composite_bg with respect to sdf, rgb, density.beta, the bg density logits and the bg colours
+// (d_weights, d_depth_values may be NULL); d_beta_ray (n_rays) is workspace, *d_beta_param receives the sum.
+int svs_composite_bg_bwd(int n_rays, int n_samples, int n_bg, const float* z, const float* z_max, const float* sdf,
+                         const float* rgb, const float* depth_scale, const float* beta_param, float beta_min,
+                         const float* z_bg, const float* bg_out0, const float* bg_rgb, const float* d_rgb_values,
+                         const float* d_weights, const float* d_depth_values, float* d_sdf, float* d_rgb,
+                         float* d_bg_out0, float* d_bg_rgb, float* d_beta_ray, float* d_beta_param, void* hip_stream) {
+  if (!z || !z_max || !sdf || !rgb || !depth_scale || !beta_param || !z_bg || !bg_out0 || !bg_rgb || !d_rgb_values || !d_sdf ||
+      !d_rgb || !d_bg_out0 || !d_bg_rgb || !d_beta_ray || !d_beta_param || n_rays <= 0) {
+    set_error("svs_composite_bg_bwd: null/invalid argument"); return SVS_EINVAL;
+  }
+  if (n_samples < 2 || n_samples + 1 > kMaxS || n_bg < 2 || n_bg > 64) { set_error("svs_composite_bg_bwd: sample counts out of range"); return SVS_ESHAPE; }
+  CompositeBgBwdArgs a{n_rays, n_samples, n_bg, z, z_max, sdf, rgb, depth_scale, beta_param, beta_min, z_bg, bg_out0, bg_rgb,
+                       d_rgb_values, d_weights, d_depth_values, d_sdf, d_rgb, d_bg_out0, d_bg_rgb, d_beta_ray};
+  hipStream_t s = (hipStream_t)hip_stream;
+  composite_bg_bwd_kernel<<<n_rays, 64, 0, s>>>(a);
+  beta_reduce_kernel<<<1, 256, 0, s>>>(d_beta_ray, n_rays, beta_param, d_beta_param, 0);
+  return check_launch("svs_composite_bg_bwd");
 }
 
 int svs_composite_bwd(int n_rays, int n_samples, const float* z, const float* sdf, const float* rgb,

@@ -289,6 +289,26 @@ def composite_bg(z, z_max, sdf, rgb, depth_scale, beta_param, beta_min, z_bg, bg
                 depth_values=depth_values, depth_values_all=depth_all, depth_vals=depth_vals, normal_map=normal_map)
 
 
+def composite_bg_bwd(z, z_max, sdf, rgb, depth_scale, beta_param, beta_min, z_bg, bg_out0, bg_rgb, d_rgb_values,
+                     d_weights=None, d_depth_values=None):
+    """backward of composite_bg -> d_sdf (R*S,1), d_rgb (R*S,3), d_bg_out0 (R*Nb,1), d_bg_rgb (R*Nb,3), d_beta (1,)"""
+    L = _lib.load()
+    z = _f32(z)
+    R, S = z.shape
+    Nb = z_bg.shape[1]
+    dev = z.device
+    f = lambda *s: torch.empty(*s, device=dev)
+    d_sdf, d_rgb, d_bo, d_brgb = f(R * S, 1), f(R * S, 3), f(R * Nb, 1), f(R * Nb, 3)
+    d_beta_ray, d_beta = f(R), f(1)
+    opt = lambda t: _ptr(_f32(t)) if t is not None else None
+    _lib.check(L.svs_composite_bg_bwd(R, S, Nb, _ptr(z), _ptr(_f32(z_max)), _ptr(_f32(sdf)), _ptr(_f32(rgb)),
+                                      _ptr(_f32(depth_scale)), _ptr(_f32(beta_param).reshape(1)), float(beta_min),
+                                      _ptr(_f32(z_bg)), _ptr(_f32(bg_out0)), _ptr(_f32(bg_rgb)), _ptr(_f32(d_rgb_values)),
+                                      opt(d_weights), opt(d_depth_values), _ptr(d_sdf), _ptr(d_rgb), _ptr(d_bo), _ptr(d_brgb),
+                                      _ptr(d_beta_ray), _ptr(d_beta), _stream()), "svs_composite_bg_bwd")
+    return d_sdf, d_rgb, d_bo, d_brgb, d_beta
+
+
 def composite_bwd(z, sdf, rgb, depth_scale, beta_param, beta_min, d_rgb_values, d_weights=None, d_depth_values=None):
     """Reverse pass of `composite`: -> d_sdf (R*S,1), d_rgb (R*S,3), d_beta_param (1,)."""
     L = _lib.load()

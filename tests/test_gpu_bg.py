@@ -122,3 +122,40 @@ def test_bg_model_forward_golden(dev, golden_dir, tag):
         np.testing.assert_allclose(out["grad_theta"][:R], g["grad_theta"][:R], atol=2e-4)
     else:
         np.testing.assert_allclose(out["normal_map"][same], g["normal_map"][same], atol=2e-4)
+
+
+def _rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / (np.abs(np.asarray(b, np.float64)).max() + 1e-30))
+
+
+def test_composite_bg_backward(dev):
+    """svs_composite_bg_bwd against float64 autograd of oracle/torch_ref.composite_bg"""
+    import torch_ref as tref
+    from svs_hip import ops
+    rs = np.random.default_rng(4)
+    R, S, Nb = 40, 97, 32
+    z = np.sort(rs.uniform(0.2, 5.0, (R, S)), -1).astype(F32)
+    z_max = (z[:, -1] + rs.uniform(0.05, 0.5, R)).astype(F32)
+    sdf = rs.normal(0.05, 0.15, (R, S)).astype(F32)
+    rgb = rs.uniform(0, 1, (R, S, 3)).astype(F32)
+    ds = rs.uniform(0.8, 1.0, (R, 1)).astype(F32)
+    z_bg = np.sort(rs.uniform(0, 1 / 3, (R, Nb)), -1)[:, ::-1].astype(F32).copy()
+    bo = rs.normal(0, 2.0, (R, Nb)).astype(F32)
+    brgb = rs.uniform(0, 1, (R, Nb, 3)).astype(F32)
+    g_rgb, g_w, g_d = rs.normal(0, 1, (R, 3)).astype(F32), rs.normal(0, 0.1, (R, S)).astype(F32), rs.normal(0, 0.5, (R, 1)).astype(F32)
+    beta = 0.07
+    T = lambda a: torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    tz, tsdf, trgb, tbo, tbrgb, tb = torch.tensor(z, dtype=torch.float64), T(sdf), T(rgb), T(bo), T(brgb), T(np.asarray(beta))
+    w, tbg, rv, dv = tref.composite_bg(tz, torch.tensor(z_max, dtype=torch.float64), tsdf, trgb, tb, torch.tensor(ds, dtype=torch.float64),
+                                       torch.tensor(z_bg, dtype=torch.float64), tbo, tbrgb)
+    loss = (rv * torch.tensor(g_rgb)).sum() + (w * torch.tensor(g_w)).sum() + (dv * torch.tensor(g_d)).sum()
+    loss.backward()
+    d_sdf, d_rgb, d_bo, d_brgb, d_beta = ops.composite_bg_bwd(G(z, dev), G(z_max, dev), G(sdf.reshape(-1, 1), dev), G(rgb.reshape(-1, 3), dev),
+                                                              G(ds, dev), torch.tensor(beta, device=dev), 1e-4, G(z_bg, dev),
+                                                              G(bo.reshape(-1, 1), dev), G(brgb.reshape(-1, 3), dev), G(g_rgb, dev),
+                                                              G(g_w, dev), G(g_d, dev))
+    assert _rel(d_sdf.cpu().numpy().reshape(R, S), tsdf.grad.numpy()) < 2e-5
+    assert _rel(d_rgb.cpu().numpy().reshape(R, S, 3), trgb.grad.numpy()) < 2e-5
+    assert _rel(d_bo.cpu().numpy().reshape(R, Nb), tbo.grad.numpy()) < 2e-5
+    assert _rel(d_brgb.cpu().numpy().reshape(R, Nb, 3), tbrgb.grad.numpy()) < 2e-5
+    assert abs(float(d_beta) - float(tb.grad)) / abs(float(tb.grad)) < 5e-5
