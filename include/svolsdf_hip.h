@@ -137,17 +137,30 @@ int svs_composite_bwd(int n_rays, int n_samples, const float* z, const float* sd
  *                     network_bg.py:79-82) + depth2pts_outside (:182-214): jitter (n_rays,n_bg) train draws or NULL
  *                     -> z_bg (n_rays,n_bg), pts (n_rays*n_bg,4), depth_real (n_rays,n_bg)
  *   svs_bg_sdf_eval   bg_implicit_network (:85-88): pts (P,4) -> out0 (P) = output[:,0] (density = |out0|),
- *                     feat_tiles; training: hbuf (svs_sdf_hbuf_bytes) + ghat7 (svs_block_bytes(P,1)), both or neither
+ *                     feat_tiles; training: hbuf (svs_sdf_hbuf_bytes) + ghat7 + pebuf (svs_block_bytes(P,1) each), all
+ *                     or none
  *   svs_bg_rgb_eval   bg_rendering_network, mode 'nerf' (:91-93): view_dirs (n_rays,3) with view_S points per ray
  *                     (or (P,3) with view_S = 0) -> rgb (P,3); rbuf (svs_bg_rbuf_bytes, training) or NULL
  *   svs_composite_bg  volume_rendering / bg_volume_rendering and the composition (:76-125,147-180) */
 int svs_bg_points(const float* cam, int cam_stride, const float* dirs, int n_rays, int n_bg, const float* jitter,
                   float radius, float* z_bg, float* pts, float* depth_real, void* hip_stream);
 int svs_bg_sdf_eval(const float* pts, int n_points, const float* stream, float* out0, float* feat_tiles, float* hbuf,
-                    float* ghat7, void* hip_stream);
+                    float* ghat7, float* pebuf, void* hip_stream);
 size_t svs_bg_rbuf_bytes(int n_points);
 int svs_bg_rgb_eval(int n_points, const float* view_dirs, int view_S, const float* feat_tiles, const float* stream,
                     float* rgb, float* rbuf, void* hip_stream);
+/* training backward of the background networks (per-point scaling as in the fg sweeps; absmax: 3 floats, caller
+ * zeroes once per step: [0] max |abar|, [1] max |zbar|, [2] max |feat_bar|):
+ *   svs_bg_rgb_bwd  d_rgb (P,3), rgb (P,3), rbuf, stream (which = 8) -> zbuf (2 blocks/tile: zbar_0, zbar_1;
+ *                   ZERO-INITIALISED by the caller once), feat_bar (1 block/tile)
+ *   svs_bg_sdf_bwd  d_out0 (P), feat_bar, hbuf, ghat7, stream (which = 6) -> abuf (8 blocks/tile), sbar_out (padded P);
+ *                   n_points must be a multiple of 32 (n_rays * 32 is)
+ * Weight gradients: svs_wgrad_multi with A = abuf / feat_bar / zbuf blocks and B = pebuf / hbuf / rbuf blocks;
+ * svs_lin8_row0_grad with ubuf = NULL; svs_unpack_wgrad maps 3 (bg lin4) and 4 (bg radiance lin0). */
+int svs_bg_rgb_bwd(int n_points, const float* d_rgb, const float* rgb, const float* rbuf, const float* stream, float* zbuf,
+                   float* feat_bar, float* absmax, void* hip_stream);
+int svs_bg_sdf_bwd(int n_points, const float* d_out0, const float* feat_bar, const float* hbuf, const float* ghat7,
+                   const float* stream, float* abuf, float* sbar_out, float* absmax, void* hip_stream);
 int svs_composite_bg(int n_rays, int n_samples, int n_bg, const float* z, const float* z_max, const float* sdf,
                      const float* rgb, const float* normals, const float* depth_scale, const float* beta_param,
                      float beta_min, const float* z_bg, const float* bg_out0, const float* bg_rgb, const float* bg_depth,
@@ -203,7 +216,7 @@ int svs_wgrad(const float* a0, const float* b0, long long sa0, long long sb0, co
  *                 n_points floats, pass A -> pass B).
  *   svs_unpack_wgrad: kernel-order dW (from svs_wgrad) -> parameter gradients incl. weight-norm backward
  *                 (w = g v/|v|, network.py:64-65).  map: 0 identity, 1 SDF lin4 (skip splice, 1/sqrt2),
- *                 2 radiance lin0.  row_off: first parameter row covered by dWk (SDF lin8: 1, with row0 = out257). */
+ *                 2 radiance lin0, 3 bg lin4, 4 bg radiance lin0.  row_off: first parameter row covered by dWk (SDF lin8: 1, with row0 = out257). */
 size_t svs_block_bytes(int n_points, int blocks_per_tile);
 size_t svs_rgb_zbuf_bytes(int n_points);
 size_t svs_sdf_ubuf_bytes(int n_points);

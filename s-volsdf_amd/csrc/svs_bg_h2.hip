@@ -4,6 +4,8 @@
 // -> 3 sigmoid).  Same machinery as svs_mlp_h2.hip (shared trunk: svs_mlp_h2_trunk.h with the NetBg geometry).
 #include "svs_mlp_h2_trunk.h"
 #include "svs_mlp_host.h"
+#include "svs_mlp_bwd_args.h"
+#include "svs_mlp_bwd_h2_dev.h"
 
 namespace svs {
 namespace mlp {
@@ -16,6 +18,7 @@ struct BgSdfArgs {
   float* feat_tiles;     // [wave tiles][kBlockF]
   float* hbuf;           // training: [wave tiles][8][kBlockF] h_1..h_8, else nullptr
   float* ghat7;          // training: [wave tiles][kBlockF] W8[0,:] * softplus'(a_7) (pass B's seed), else nullptr
+  float* pebuf;          // training: [wave tiles][kBlockF] the 84 PE inputs in PE order (first 3 tiles), B operand of dW_0
 };
 
 template <bool TRAIN>
@@ -37,6 +40,18 @@ __global__ __launch_bounds__(kThreads, 1) void bg_sdf_h2_kernel(BgSdfArgs a) {
     pe.compute(x[0], x[1], x[2], x[3]);
   }
   float* hb = TRAIN ? a.hbuf + (size_t)wtile * 8 * kBlockF : nullptr;
+  if (TRAIN) {
+    float* pb = a.pebuf + (size_t)wtile * kBlockF;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      f32x16 v;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = half ? pe.v[32 * t + rho(r) + 4] : pe.v[32 * t + rho(r)];
+      store_tile(pb, t, lane, v);
+    }
+#pragma unroll
+    for (int t = 3; t < 8; ++t) store_tile(pb, t, lane, (f32x16)(0.0f));
+  }
   Pieces2 x, xn;
   f32x16 y8[8];
   forward_trunk_h2<TRAIN, NetBg>(st, x, xn, y8, pe, lane, half, hb);
@@ -95,7 +110,7 @@ struct BgRgbArgs {
   float* rgb;              // (P,3)
   float* rbuf;             // training: [wave tiles][kBgRbufF]: r_1 (post-ReLU, tiles 0..3) and the 32 view-PE rows, else nullptr
 };
-constexpr int kBgRbufF = kBlockF + 2048;
+constexpr int kBgRbufF = kBlockF + 1024;
 constexpr int kBgRgbBufF4 = kBgRgbChunk0F4;
 
 struct BgRgbStream {
@@ -149,14 +164,14 @@ __global__ __launch_bounds__(kThreads, 1) void bg_rgb_h2_kernel(BgRgbArgs a) {
   }
   float* rb = a.rbuf ? a.rbuf + (size_t)wtile * kBgRbufF : nullptr;
   if (rb) {
-    // the extras as a 32-row accumulator-layout tile pair: registers 0..7 of "tile" s hold rows 16 s + rho(j) (+4)
+    // the 32 extra rows as ONE accumulator-layout tile (register r = 8 s + j holds row 16 s + rho(j) (+4) = rho(r) (+4)):
+    // the single-tile B operand of the weight-gradient GEMM's narrow job
     f32x4* d = reinterpret_cast<f32x4*>(rb + (size_t)kBlockF) + lane;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      f32x4 v0, v1;
-      v0[0] = eb[8 * s]; v0[1] = eb[8 * s + 1]; v0[2] = eb[8 * s + 2]; v0[3] = eb[8 * s + 3];
-      v1[0] = eb[8 * s + 4]; v1[1] = eb[8 * s + 5]; v1[2] = eb[8 * s + 6]; v1[3] = eb[8 * s + 7];
-      d[(4 * s) * 64] = v0; d[(4 * s + 1) * 64] = v1; d[(4 * s + 2) * 64] = (f32x4)(0.0f); d[(4 * s + 3) * 64] = (f32x4)(0.0f);
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v;
+      v[0] = eb[4 * q]; v[1] = eb[4 * q + 1]; v[2] = eb[4 * q + 2]; v[3] = eb[4 * q + 3];
+      d[q * 64] = v;
     }
   }
   st.advance();
@@ -203,6 +218,101 @@ __global__ __launch_bounds__(kThreads, 1) void bg_rgb_h2_kernel(BgRgbArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// bg_rendering_network backward: zbar_1 = d_rgb * sigmoid', zbar_0 = (W1^T zbar_1) * [r_1 > 0],
+// fbar = W0[:, 27:]^T zbar_0 (the view directions get no gradient).  Per-point scaling as in svs_mlp_bwd_h2.hip.
+// ------------------------------------------------------------------------------------------------------------
+struct BgRgbBwdArgs {
+  int P;
+  const float* d_rgb;      // (P,3)
+  const float* rgb;        // (P,3) forward output
+  const float* rbuf;       // forward activations [wave tiles][kBgRbufF]
+  const f32x4* stream;     // kStreamBgRgbBwd
+  float* zbuf;             // out [wave tiles][2][kBlockF]: zbar_0 (tiles 0..3), zbar_1 (rows 0..2 of tile 0); the other
+                           // tiles stay zero (ZERO-INITIALISED by the caller once)
+  float* feat_bar;         // out [wave tiles][kBlockF]
+  float* absmax;           // [3]: [1] = max |zbar|, [2] = max |feat_bar|
+};
+
+__global__ __launch_bounds__(kThreads, 1) void bg_rgb_bwd_h2_kernel(BgRgbBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Stream st;
+  st.g = a.stream; st.buf = reinterpret_cast<f32x4*>(smem); st.cur = 1;
+  const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
+  const int wtile = blockIdx.x * kWaves + wave;
+  const int p = wtile * kTilePts + (lane & 31);
+  const bool livep = p < a.P;
+  const int pc = livep ? p : a.P - 1;
+  const float* rb = a.rbuf + (size_t)wtile * kBgRbufF;
+  float* zb = a.zbuf + (size_t)wtile * 2 * kBlockF;
+
+  st.prefetch<kW1TF4>();
+  float dz[3];
+  float m0 = 0.0f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float o = a.rgb[3 * pc + c];
+    dz[c] = (livep && half == 0) ? a.d_rgb[3 * pc + c] * o * (1.0f - o) : 0.0f;
+    m0 = __builtin_fmaxf(m0, __builtin_fabsf(dz[c]));
+  }
+  m0 = __builtin_fmaxf(m0, __shfl_xor(m0, 32));
+  PointScale ps;
+  ps.start(m0, 0.0f);
+  {
+    f32x16 z1 = (f32x16)(0.0f);
+    z1[0] = dz[0]; z1[1] = dz[1]; z1[2] = dz[2];
+    store_tile(zb + (size_t)kBlockF, 0, lane, z1);
+  }
+  st.advance();
+  Pieces2 pz;
+  st.prefetch<kChunkF4>();
+  {
+    // rbar_1 = W_1^T zbar_1 (K = 3: float32 MFMA from the short W1T chunk), masked by r_1 > 0 -> zbar_0 (4 tiles)
+    const f32x4* c = st.cur_buf();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x16 r = load_tile(rb, t, lane);
+      const f32x4 w = c[t * 64 + lane];
+      f32x16 acc = (f32x16)(0.0f);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], dz[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1], dz[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2], dz[2], acc, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { acc[i] = r[i] > 0.0f ? acc[i] : 0.0f; ps.track(acc[i]); }
+      store_tile(zb, t, lane, acc);
+      split_tile_scaled(acc, t, pz, ps.s_out);
+    }
+  }
+  ps.next();
+  st.advance();
+  // fbar: 8 tiles of feature rows, K = 128 (8 k-steps)
+  float* fb = a.feat_bar + (size_t)wtile * kBlockF;
+  float fmax = 0.0f;
+  f32x16 prev;
+  f32x4 q4;
+  auto slice = [&](int tp, int r) {
+    const float v = prev[r] * ps.inv_in;
+    fmax = __builtin_fmaxf(fmax, __builtin_fabsf(v));
+    q4[r & 3] = v;
+    if ((r & 3) == 3) reinterpret_cast<f32x4*>(fb)[(4 * tp + (r >> 2)) * 64 + lane] = q4;
+  };
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    if (t < 7) st.prefetch<kChunkF4>();
+    const f32x16 acc = tile_mma_h2<8>(st.cur_buf(), pz, lane);
+    if (t > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) slice(t - 1, r);
+    }
+    prev = acc;
+    if (t < 7) st.advance();
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) slice(7, r);
+  publish_max(a.absmax + 1, ps.gmax);
+  publish_max(a.absmax + 2, fmax);
+}
+
 }  // namespace mlp
 }  // namespace svs
 
@@ -216,11 +326,11 @@ size_t svs_bg_rbuf_bytes(int n_points) { return (size_t)wave_tiles(n_points) * k
 // bg_implicit_network (network_bg.py:85-88): pts (P,4) -> out0 (P) = output[:,0], feat_tiles (svs_feat_tiles_bytes);
 // training: hbuf (svs_sdf_hbuf_bytes) and ghat7 (svs_block_bytes(P,1)) for the backward, both or neither.
 int svs_bg_sdf_eval(const float* pts, int n_points, const float* stream, float* out0, float* feat_tiles, float* hbuf,
-                    float* ghat7, void* hip_stream) {
-  if (!pts || n_points <= 0 || !stream || !out0 || !feat_tiles || (!hbuf != !ghat7)) {
+                    float* ghat7, float* pebuf, void* hip_stream) {
+  if (!pts || n_points <= 0 || !stream || !out0 || !feat_tiles || (!hbuf != !ghat7) || (!hbuf != !pebuf)) {
     set_error("svs_bg_sdf_eval: null/invalid argument"); return SVS_EINVAL;
   }
-  BgSdfArgs a{pts, n_points, reinterpret_cast<const f32x4*>(stream), out0, feat_tiles, hbuf, ghat7};
+  BgSdfArgs a{pts, n_points, reinterpret_cast<const f32x4*>(stream), out0, feat_tiles, hbuf, ghat7, pebuf};
   static int once = set_lds(bg_sdf_h2_kernel<false>, kLdsBytes, "svs_bg_sdf_eval") | set_lds(bg_sdf_h2_kernel<true>, kLdsBytes, "svs_bg_sdf_eval");
   if (once) return once;
   const dim3 grid((n_points + kWgPts - 1) / kWgPts);
@@ -241,6 +351,31 @@ int svs_bg_rgb_eval(int n_points, const float* view_dirs, int view_S, const floa
   if (once) return once;
   bg_rgb_h2_kernel<<<(n_points + kWgPts - 1) / kWgPts, kThreads, lds, (hipStream_t)hip_stream>>>(a);
   return check_launch("svs_bg_rgb_eval");
+}
+
+// bg_rendering_network backward (stream: which = 8): zbuf = 2 blocks per tile, ZERO-INITIALISED by the caller once
+int svs_bg_rgb_bwd(int n_points, const float* d_rgb, const float* rgb, const float* rbuf, const float* stream, float* zbuf,
+                   float* feat_bar, float* absmax, void* hip_stream) {
+  if (n_points <= 0 || !d_rgb || !rgb || !rbuf || !stream || !zbuf || !feat_bar || !absmax) {
+    set_error("svs_bg_rgb_bwd: null/invalid argument"); return SVS_EINVAL;
+  }
+  BgRgbBwdArgs a{n_points, d_rgb, rgb, rbuf, reinterpret_cast<const f32x4*>(stream), zbuf, feat_bar, absmax};
+  static int once = set_lds(bg_rgb_bwd_h2_kernel, kLdsBytes, "svs_bg_rgb_bwd");
+  if (once) return once;
+  bg_rgb_bwd_h2_kernel<<<(n_points + kWgPts - 1) / kWgPts, kThreads, kLdsBytes, (hipStream_t)hip_stream>>>(a);
+  return check_launch("svs_bg_rgb_bwd");
+}
+
+// bg_implicit_network backward (stream: which = 6): d_out0 (P) = d loss / d output[:,0], feat_bar (1 block per tile),
+// hbuf / ghat7 from svs_bg_sdf_eval -> abuf (8 blocks per tile: abar_0..abar_7), sbar_out (padded P)
+int svs_bg_sdf_bwd(int n_points, const float* d_out0, const float* feat_bar, const float* hbuf, const float* ghat7,
+                   const float* stream, float* abuf, float* sbar_out, float* absmax, void* hip_stream) {
+  if (n_points <= 0 || n_points % 32 || !d_out0 || !feat_bar || !hbuf || !ghat7 || !stream || !abuf || !sbar_out || !absmax) {
+    set_error("svs_bg_sdf_bwd: null/invalid argument (n_points must be a multiple of 32)"); return SVS_EINVAL;
+  }
+  SdfBwdBArgs a{n_points, d_out0, nullptr, feat_bar, n_points / 32, hbuf, nullptr, nullptr,
+                reinterpret_cast<const f32x4*>(stream), abuf, sbar_out, absmax, nullptr, ghat7, (size_t)kBlockF};
+  return launch_bg_bwd_b_h2(a, (hipStream_t)hip_stream);
 }
 
 }  // extern "C"

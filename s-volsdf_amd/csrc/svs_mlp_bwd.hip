@@ -307,10 +307,17 @@ __global__ __launch_bounds__(256) void lin8_row0_kernel(const float* __restrict_
     const float sb = p < P ? sbar[p] : 0.0f;
     const float live = p < P ? 1.0f : 0.0f;
     const f32x4* h = reinterpret_cast<const f32x4*>(hbuf + ((size_t)t * 8 + 7) * kBlockF) + quarter * 8 * 64 + lane;
-    const f32x4* u = reinterpret_cast<const f32x4*>(ubuf + ((size_t)t * 9 + 8) * kBlockF) + quarter * 8 * 64 + lane;
     f32x4 hv[8], uv[8];
+    if (ubuf) {
+      const f32x4* u = reinterpret_cast<const f32x4*>(ubuf + ((size_t)t * 9 + 8) * kBlockF) + quarter * 8 * 64 + lane;
 #pragma unroll
-    for (int i4 = 0; i4 < 8; ++i4) { hv[i4] = h[i4 * 64]; uv[i4] = u[i4 * 64]; }
+      for (int i4 = 0; i4 < 8; ++i4) uv[i4] = u[i4 * 64];
+    } else {
+#pragma unroll
+      for (int i4 = 0; i4 < 8; ++i4) uv[i4] = (f32x4)(0.0f);
+    }
+#pragma unroll
+    for (int i4 = 0; i4 < 8; ++i4) hv[i4] = h[i4 * 64];
 #pragma unroll
     for (int i4 = 0; i4 < 8; ++i4)
 #pragma unroll
@@ -353,6 +360,12 @@ struct UnpackArgs {
 __device__ __forceinline__ int kernel_col(int map, int c) {
   if (map == 1) return c < 217 ? c : (c < 249 ? 224 + (c - 217) : 217 + (c - 249));
   if (map == 2) return c < 15 ? 256 + c : c - 15;
+  if (map == 3) {     // bg lin4: cat[h(172), PE(84)] -> rows 224.. = PE[0..31], 192.. = PE[32..63], 172..191 = PE[64..83]
+    if (c < 172) return c;
+    const int e = c - 172;
+    return e < 32 ? 224 + e : (e < 64 ? 192 + (e - 32) : 172 + (e - 64));
+  }
+  if (map == 4) return c < 27 ? 256 + c : c - 27;     // bg radiance lin0: cat[PE4(view)(27), feature(256)]
   return c;
 }
 
@@ -361,7 +374,7 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(UnpackArgs a) {
   const int lane = threadIdx.x & 63;
   const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (o >= a.rows) return;
-  const float fac = a.map == 1 ? 0.70710678118654752f : 1.0f;
+  const float fac = (a.map == 1 || a.map == 3) ? 0.70710678118654752f : 1.0f;
   const bool is_row0 = a.row0 && o == 0;
   const int ko = o - a.row_off;
   auto dweff = [&](int c) -> float {
@@ -460,7 +473,8 @@ int svs_sdf_bwd_b(int n_points, const float* d_sdf, const unsigned char* clamp_m
     set_error("svs_sdf_bwd_b: null/invalid argument (n_feat_points must be a multiple of 32)"); return SVS_EINVAL;
   }
   SdfBwdBArgs a{n_points, d_sdf, clamp_mask, feat_bar, n_feat_points / 32, hbuf, gbuf, a2buf,
-                reinterpret_cast<const f32x4*>(stream) + kSdfTrainPassBF4, abuf, sbar_out, absmax, a2max};
+                reinterpret_cast<const f32x4*>(stream) + kSdfTrainPassBF4, abuf, sbar_out, absmax, a2max,
+                gbuf + 7 * (size_t)kBlockF, 8 * (size_t)kBlockF};
   if (precision == kFmtF16x2) {
     if (!absmax || !a2max) { set_error("svs_sdf_bwd_b: fp16x2 needs absmax and a2max"); return SVS_EINVAL; }
     return launch_sdf_bwd_b_h2(a, (hipStream_t)hip_stream);
@@ -474,7 +488,7 @@ int svs_sdf_bwd_b(int n_points, const float* d_sdf, const unsigned char* clamp_m
 
 int svs_lin8_row0_grad(const float* hbuf, const float* ubuf, const float* sbar, int n_points, float* out257,
                        void* hip_stream) {
-  if (!hbuf || !ubuf || !sbar || !out257 || n_points <= 0) { set_error("svs_lin8_row0_grad: bad argument"); return SVS_EINVAL; }
+  if (!hbuf || !sbar || !out257 || n_points <= 0) { set_error("svs_lin8_row0_grad: bad argument"); return SVS_EINVAL; }
   const int n_tiles = (n_points + 31) / 32;
   const int grid = n_tiles < 1024 ? n_tiles : 1024;
   lin8_row0_kernel<<<grid, 256, 0, (hipStream_t)hip_stream>>>(hbuf, ubuf, sbar, n_tiles, n_points, out257);
@@ -484,7 +498,7 @@ int svs_lin8_row0_grad(const float* hbuf, const float* ubuf, const float* sbar, 
 int svs_unpack_wgrad(const float* dWk, const float* dbk, int ldw, int map, int rows, int cols, int row_off,
                      const float* weight_v, const float* weight_g, const float* row0, float* grad_v, float* grad_g,
                      float* grad_b, void* hip_stream) {
-  if (!dWk || !weight_v || !grad_v || rows < 1 || cols < 1 || map < 0 || map > 2 || (weight_g && !grad_g)) {
+  if (!dWk || !weight_v || !grad_v || rows < 1 || cols < 1 || map < 0 || map > 4 || (weight_g && !grad_g)) {
     set_error("svs_unpack_wgrad: bad argument"); return SVS_EINVAL;
   }
   UnpackArgs a{dWk, dbk, ldw, map, rows, cols, row_off, weight_v, weight_g, grad_v, grad_g, grad_b, row0};

@@ -46,7 +46,10 @@ struct SdfBwdBArgs {
   // fp16x2 only:
   float* absmax;              // [3]: [0] = max |abar| (atomic max)
   const float* a2max;         // (padded P) from pass A
+  // the block holding ghat_7 = W8[0,:] s'(a_7) of a tile is w0 + tile * w0_stride (fg: gbuf block 7, stride 8 blocks)
+  const float* w0; size_t w0_stride;
 };
+int launch_bg_bwd_b_h2(const SdfBwdBArgs& a, hipStream_t s);   // background implicit network: no a2, bg splice rows
 
 int launch_rgb_bwd_h2(const RgbBwdArgs& a, hipStream_t s);
 int launch_sdf_bwd_a_h2(const SdfBwdAArgs& a, hipStream_t s);

@@ -13,53 +13,11 @@
 #include "svs_mlp_h2_dev.h"
 #include "svs_mlp_host.h"
 #include "svs_mlp_bwd_args.h"
+#include "svs_mlp_h2_trunk.h"
+#include "svs_mlp_bwd_h2_dev.h"
 
 namespace svs {
 namespace mlp {
-
-struct PointScale {
-  float s_in, inv_in;   // the operand being consumed holds true * s_in
-  float s_out;          // the operand being produced is split as true * s_out
-  float m;              // running max |true| of the operand being produced (this lane's rows)
-  float floor_m;        // lower bound of the maxima
-  float gmax;           // max over everything tracked so far
-
-  // s * mx in [2^4, 2^5)
-  static __device__ __forceinline__ float pow2_for(float mx) {
-    int e = (int)((__float_as_uint(mx) >> 23) & 0xff);
-    e = e < 24 ? 24 : (e > 230 ? 230 : e);
-    return __uint_as_float((unsigned)(258 - e) << 23);
-  }
-  static __device__ __forceinline__ float inv_pow2(float s) { return __uint_as_float((254u << 23) - __float_as_uint(s)); }
-  // m0: max |true| of the first operand over the whole column (both lane halves)
-  __device__ __forceinline__ void start(float m0, float fl) {
-    floor_m = fl; gmax = m0;
-    s_in = pow2_for(__builtin_fmaxf(m0, fl)); inv_in = inv_pow2(s_in);
-    s_out = s_in; m = 0.0f;
-  }
-  __device__ __forceinline__ void track(float v) { m = __builtin_fmaxf(m, __builtin_fabsf(v)); }
-  // the operand just produced becomes the one consumed
-  __device__ __forceinline__ void next() {
-    m = __builtin_fmaxf(m, __shfl_xor(m, 32));
-    gmax = __builtin_fmaxf(gmax, m);
-    s_in = s_out; inv_in = inv_pow2(s_in);
-    s_out = pow2_for(__builtin_fmaxf(m, floor_m));
-    m = 0.0f;
-  }
-};
-
-__device__ __forceinline__ void publish_max(float* slot, float v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, d));
-  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(slot), __float_as_uint(v));
-}
-
-__device__ __forceinline__ void split_tile_scaled(const f32x16& y, int t, Pieces2& p, float s) {
-  f32x16 v;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) v[r] = y[r] * s;
-  split_tile(v, t, p);
-}
 
 // ==============================================================================================================
 // radiance MLP backward
@@ -402,7 +360,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_h2_kernel(SdfBwdAArgs a
 // SDF MLP backward, pass B: hbar_8 = sbar W_8[0,:] + W_8[1:,:]^T fbar;  abar_l = hbar_{l+1} s'(a_l) + a2_l;
 //                           hbar_l = W_l^T abar_l
 // ==============================================================================================================
-template <bool FIRST, bool SPLIT>
+template <bool FIRST, bool SPLIT, typename Net = NetFg, bool A2 = true>
 struct PassBEpi {
   f32x16 prev, h, a2, w0;
   float v, s1;
@@ -420,11 +378,12 @@ struct PassBEpi {
     pin(v); pin(s1);
   }
   __device__ __forceinline__ void b(int tp, int r) {
-    float o = v * s1 + a2[r];
+    float o = v * s1;
+    if (A2) o += a2[r];
     if (FIRST) o += sbar * w0[r];      // w0 = ghat_7 = W8[0,:] s'(a_7)
-    if (l4 && tp == 7) o = 0.0f;
-    if (l4 && tp == 6) {
-      const bool z0 = rho(r) >= 25, z1 = rho(r) + 4 >= 25;
+    if (l4 && tp > Net::kSpliceTile) o = 0.0f;
+    if (l4 && tp == Net::kSpliceTile) {
+      const bool z0 = rho(r) >= Net::kSpliceLocal, z1 = rho(r) + 4 >= Net::kSpliceLocal;
       if (z0 || z1) { if (half ? z1 : z0) o = 0.0f; }
     }
     pin(o);
@@ -446,20 +405,23 @@ struct PassBEpi {
 };
 
 // one stage of pass B: in -> (W^T in) fused with abar of block `blk` (h, a2 from blocks blk; FIRST: + sbar W8[0,:])
-template <bool FIRST, bool SPLIT, bool LAST_STAGE>
-__device__ __forceinline__ void pass_b_stage_h2(Stream& st, const Pieces2& in, PassBEpi<FIRST, SPLIT>& ep, const float* hblk,
+template <bool FIRST, bool SPLIT, bool LAST_STAGE, typename Net = NetFg, bool A2 = true>
+__device__ __forceinline__ void pass_b_stage_h2(Stream& st, const Pieces2& in, PassBEpi<FIRST, SPLIT, Net, A2>& ep, const float* hblk,
                                                 const float* a2blk, const float* w0blk, int lane) {
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     // the side tiles of tile t are requested one tile before its epilogue runs (during tile t+1's MFMAs)
-    const f32x16 hload = load_tile(hblk, t, lane), aload = load_tile(a2blk, t, lane);
+    const f32x16 hload = load_tile(hblk, t, lane);
+    f32x16 aload;
+    if (A2) aload = load_tile(a2blk, t, lane);
     f32x16 wload;
     if (FIRST) wload = load_tile(w0blk, t, lane);
     if (!(LAST_STAGE && t == 7)) st.prefetch<kChunkF4>();
     f32x16 acc;
     if (t == 0) acc = tile_mma_h2<16>(st.cur_buf(), in, lane);
     else acc = tile_mma_h2<16>(st.cur_buf(), in, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.b(t - 1, s); });
-    ep.prev = acc; ep.h = hload; ep.a2 = aload;
+    ep.prev = acc; ep.h = hload;
+    if (A2) ep.a2 = aload;
     if (FIRST) ep.w0 = wload;
     if (!(LAST_STAGE && t == 7)) st.advance();
   }
@@ -467,6 +429,7 @@ __device__ __forceinline__ void pass_b_stage_h2(Stream& st, const Pieces2& in, P
   ep.ps->next();
 }
 
+template <typename Net, bool A2>
 __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_h2_kernel(SdfBwdBArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Stream st;
@@ -480,8 +443,8 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_h2_kernel(SdfBwdBArgs a
   if (a.clamp_mask && a.clamp_mask[pc]) sbar = 0.0f;
   if (half == 0 && a.sbar_out) a.sbar_out[p] = sbar;
   const float* hb = a.hbuf + (size_t)wtile * 8 * kBlockF;
-  const float* gb = a.gbuf + (size_t)wtile * 8 * kBlockF;
-  const float* a2 = a.a2buf + (size_t)wtile * 8 * kBlockF;
+  const float* w0 = a.w0 + (size_t)wtile * a.w0_stride;
+  const float* a2 = A2 ? a.a2buf + (size_t)wtile * 8 * kBlockF : nullptr;
   float* ab = a.abuf + (size_t)wtile * 8 * kBlockF;
   const bool has_f = a.feat_bar && wtile < a.n_feat_tiles;
   PointScale ps;
@@ -499,7 +462,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_h2_kernel(SdfBwdBArgs a
 #pragma unroll
       for (int t = 0; t < 8; ++t) f[t] = (f32x16)(0.0f);
     }
-    ps.start(m0, __builtin_fmaxf(a.a2max[p], __builtin_fabsf(sbar)));
+    ps.start(m0, __builtin_fmaxf(A2 ? a.a2max[p] : 0.0f, __builtin_fabsf(sbar)));
     ps.gmax = 0.0f;      // fbar is not an operand of the SDF weight-gradient GEMMs (rgb_bwd publishes its maximum)
 #pragma unroll
     for (int t = 0; t < 8; ++t) split_tile_scaled(f[t], t, pa, ps.s_in);
@@ -507,23 +470,23 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_h2_kernel(SdfBwdBArgs a
   st.advance();
   {
     // hbar_8 fused with abar_7 (gbuf block 7 = ghat_7 = W8[0,:] s'(a_7) in accumulator layout)
-    PassBEpi<true, true> ep;
+    PassBEpi<true, true, Net, A2> ep;
     ep.out = &pb; ep.ablk = ab + 7 * (size_t)kBlockF; ep.ps = &ps; ep.sbar = sbar; ep.lane = lane; ep.half = half; ep.l4 = false;
-    pass_b_stage_h2<true, true, false>(st, pa, ep, hb + 7 * (size_t)kBlockF, a2 + 7 * (size_t)kBlockF, gb + 7 * (size_t)kBlockF, lane);
+    pass_b_stage_h2<true, true, false, Net, A2>(st, pa, ep, hb + 7 * (size_t)kBlockF, A2 ? a2 + 7 * (size_t)kBlockF : nullptr, w0, lane);
   }
   // layers 7..2: in = abar_l (pb), out = abar_{l-1} (pa, copied back: one code body for all layers)
   for (int l = 7; l >= 2; --l) {
-    PassBEpi<false, true> ep;
+    PassBEpi<false, true, Net, A2> ep;
     ep.out = &pa; ep.ablk = ab + (size_t)(l - 1) * kBlockF; ep.ps = &ps; ep.sbar = 0.0f; ep.lane = lane; ep.half = half; ep.l4 = l == 4;
-    pass_b_stage_h2<false, true, false>(st, pb, ep, hb + (size_t)(l - 1) * kBlockF, a2 + (size_t)(l - 1) * kBlockF, nullptr, lane);
+    pass_b_stage_h2<false, true, false, Net, A2>(st, pb, ep, hb + (size_t)(l - 1) * kBlockF, A2 ? a2 + (size_t)(l - 1) * kBlockF : nullptr, nullptr, lane);
 #pragma unroll
     for (int s = 0; s < 16; ++s) { pb.h[s] = pa.h[s]; pb.m[s] = pa.m[s]; }
   }
   {
     // layer 1: abar_1 (in pb) -> abar_0, stored only
-    PassBEpi<false, false> ep;
+    PassBEpi<false, false, Net, A2> ep;
     ep.out = nullptr; ep.ablk = ab; ep.ps = &ps; ep.sbar = 0.0f; ep.lane = lane; ep.half = half; ep.l4 = false;
-    pass_b_stage_h2<false, false, true>(st, pb, ep, hb, a2, nullptr, lane);
+    pass_b_stage_h2<false, false, true, Net, A2>(st, pb, ep, hb, a2, nullptr, lane);
   }
   publish_max(a.absmax, ps.gmax);
 }
@@ -542,10 +505,16 @@ int launch_sdf_bwd_a_h2(const SdfBwdAArgs& a, hipStream_t s) {
   return check_launch("svs_sdf_bwd_a");
 }
 int launch_sdf_bwd_b_h2(const SdfBwdBArgs& a, hipStream_t s) {
-  static int once = set_lds(sdf_bwd_b_h2_kernel, kLdsBytes, "svs_sdf_bwd_b");
+  static int once = set_lds(sdf_bwd_b_h2_kernel<NetFg, true>, kLdsBytes, "svs_sdf_bwd_b");
   if (once) return once;
-  sdf_bwd_b_h2_kernel<<<(a.P + kWgPts - 1) / kWgPts, kThreads, kLdsBytes, s>>>(a);
+  sdf_bwd_b_h2_kernel<NetFg, true><<<(a.P + kWgPts - 1) / kWgPts, kThreads, kLdsBytes, s>>>(a);
   return check_launch("svs_sdf_bwd_b");
+}
+int launch_bg_bwd_b_h2(const SdfBwdBArgs& a, hipStream_t s) {
+  static int once = set_lds(sdf_bwd_b_h2_kernel<NetBg, false>, kLdsBytes, "svs_bg_sdf_bwd");
+  if (once) return once;
+  sdf_bwd_b_h2_kernel<NetBg, false><<<(a.P + kWgPts - 1) / kWgPts, kThreads, kLdsBytes, s>>>(a);
+  return check_launch("svs_bg_sdf_bwd");
 }
 
 }  // namespace mlp

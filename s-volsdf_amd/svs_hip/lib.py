@@ -68,7 +68,9 @@ SIGNATURES = {
                           _P, ctypes.c_longlong, c_int, c_int, _P, _P, c_int, _P, _P]),
     "svs_wgrad_multi": (c_int, [_P, c_int, c_int, _P]),
     "svs_bg_points": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_float, _P, _P, _P, _P]),
-    "svs_bg_sdf_eval": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P]),
+    "svs_bg_sdf_eval": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "svs_bg_rgb_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "svs_bg_sdf_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "svs_bg_rbuf_bytes": (c_size_t, [c_int]),
     "svs_bg_rgb_eval": (c_int, [c_int, _P, c_int, _P, _P, _P, _P, _P]),
     "svs_composite_bg_bwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P,

@@ -242,13 +242,14 @@ def bg_sdf_eval(packed, pts, keep=None):
     P, dev = pts.shape[0], pts.device
     out0 = torch.empty(P, 1, device=dev)
     feat = torch.empty(L.svs_feat_tiles_bytes(P) // 4, device=dev)
-    hbuf = ghat7 = None
+    hbuf = ghat7 = pebuf = None
     if keep is not None:
         hbuf = torch.empty(L.svs_sdf_hbuf_bytes(P) // 4, device=dev)
         ghat7 = torch.empty(L.svs_block_bytes(P, 1) // 4, device=dev)
-        keep.update(bg_hbuf=hbuf, bg_ghat7=ghat7, bg_pts=pts)
+        pebuf = torch.empty(L.svs_block_bytes(P, 1) // 4, device=dev)
+        keep.update(bg_hbuf=hbuf, bg_ghat7=ghat7, bg_pebuf=pebuf, bg_pts=pts)
     _lib.check(L.svs_bg_sdf_eval(_ptr(pts), P, _ptr(packed.sdf_stream), _ptr(out0), _ptr(feat), _ptr(hbuf), _ptr(ghat7),
-                                 _stream()), "svs_bg_sdf_eval")
+                                 _ptr(pebuf), _stream()), "svs_bg_sdf_eval")
     return out0, feat
 
 

@@ -206,3 +206,99 @@ class MlpBackward:
         self.accum.zero()
         self.accumulate(keep, d_rgb, d_sdf, d_grad_extra)
         return finalize(self.accum, sdf_params, rgb_params, out)
+
+
+class BgBackward:
+    """Training backward of the background networks of VolSDFNetworkBG (bg_implicit_network: ordinary backprop, no
+    second-order sweep because its input gradient is never used; bg_rendering_network), fp16x2 kernels of
+    csrc/svs_bg_h2.hip + the shared pass-B sweep and weight-gradient GEMM."""
+    BGRBUF = KBLOCK + 1024
+
+    def __init__(self, device):
+        L = _lib.load()
+        self.dev = device
+        self.sdf_stream = torch.empty(L.svs_stream_bytes(6) // 4, device=device)
+        self.rgb_stream = torch.empty(L.svs_stream_bytes(8) // 4, device=device)
+        self.ws = torch.empty(L.svs_pack_workspace_bytes() // 4, device=device)
+        self.dWk = torch.zeros(11, 256, LDW, device=device)      # 0..8 implicit layers, 9..10 radiance layers
+        self.dbk = torch.zeros(11, 256, device=device)
+        self.row0 = torch.zeros(257, device=device)
+        self.absmax = torch.zeros(4, device=device)
+        self._n = None
+
+    def pack(self, sdf_wb, rgb_wb):
+        L = _lib.load()
+        self._keep = []
+        for which, (w, b), stream in ((6, sdf_wb, self.sdf_stream), (8, rgb_wb, self.rgb_stream)):
+            w, b = [_f32(t) for t in w], [_f32(t) for t in b]
+            self._keep += [w, b]
+            _lib.check(L.svs_pack_stream(which, F16X2, _ptr_array(w), None, _ptr_array(b), _ptr(self.ws), _ptr(stream),
+                                         _stream()), "svs_pack_stream(bg backward)")
+
+    def zero(self):
+        self.dWk.zero_(); self.dbk.zero_(); self.row0.zero_(); self.absmax.zero_()
+
+    def _alloc(self, n):
+        if self._n == n:
+            return
+        L = _lib.load()
+        z = lambda nbytes: torch.zeros(nbytes // 4, device=self.dev)
+        self.zbuf = z(L.svs_block_bytes(n, 2))          # zero-initialised once: only 4 + 1 tiles are ever written
+        self.feat_bar = z(L.svs_block_bytes(n, 1))
+        self.abuf = z(L.svs_block_bytes(n, 8))
+        self.sbar = z(L.svs_block_bytes(n, 1) // (128 * 2))
+        self._n = n
+
+    def accumulate(self, keep, d_bg_rgb, d_bg_out0):
+        """keep: what ops.bg_sdf_eval / ops.bg_rgb_eval stored; d_bg_rgb (P,3), d_bg_out0 (P,1)."""
+        L = _lib.load()
+        P = keep["bg_rgb"].shape[0]
+        self._alloc(P)
+        st = _stream()
+        hbuf, ghat7, pebuf, rbuf, feat = keep["bg_hbuf"], keep["bg_ghat7"], keep["bg_pebuf"], keep["bg_rbuf"], keep["bg_feat"]
+        d_bg_rgb, d_bg_out0 = _f32(d_bg_rgb), _f32(d_bg_out0)
+        _lib.check(L.svs_bg_rgb_bwd(P, _ptr(d_bg_rgb), _ptr(keep["bg_rgb"]), _ptr(rbuf), _ptr(self.rgb_stream), _ptr(self.zbuf),
+                                    _ptr(self.feat_bar), _ptr(self.absmax), st), "svs_bg_rgb_bwd")
+        _lib.check(L.svs_bg_sdf_bwd(P, _ptr(d_bg_out0), _ptr(self.feat_bar), _ptr(hbuf), _ptr(ghat7), _ptr(self.sdf_stream),
+                                    _ptr(self.abuf), _ptr(self.sbar), _ptr(self.absmax), st), "svs_bg_sdf_bwd")
+        _lib.check(L.svs_lin8_row0_grad(_ptr(hbuf), None, _ptr(self.sbar), P, _ptr(self.row0), st), "svs_lin8_row0_grad")
+        H8, A8, Z2 = 8 * KBLOCK, 8 * KBLOCK, 2 * KBLOCK
+
+        def addr(x):
+            return x.value if isinstance(x, ctypes.c_void_p) else x
+
+        def job(slot, amax, a0, sa0, b0, sb0, extra=None, sx=0):
+            return _lib.WGradJob(addr(a0), addr(b0), sa0, sb0, None, None, 0, 0, addr(extra), sx, P, LDW,
+                                 addr(_off(self.dWk, slot * 256 * LDW)), addr(_off(self.dbk, slot * 256)),
+                                 addr(_off(self.absmax, amax)))
+
+        jobs = [job(0, 0, _off(self.abuf, 0), A8, _ptr(pebuf), KBLOCK)]
+        for l in range(1, 8):
+            jobs.append(job(l, 0, _off(self.abuf, l * KBLOCK), A8, _off(hbuf, (l - 1) * KBLOCK), H8))
+        jobs.append(job(8, 2, _ptr(self.feat_bar), KBLOCK, _off(hbuf, 7 * KBLOCK), H8))
+        jobs.append(job(9, 1, _off(self.zbuf, 0), Z2, _ptr(feat), KBLOCK, extra=_off(rbuf, KBLOCK), sx=self.BGRBUF))
+        jobs.append(job(10, 1, _off(self.zbuf, KBLOCK), Z2, _ptr(rbuf), self.BGRBUF))
+        arr = (_lib.WGradJob * len(jobs))(*jobs)
+        _lib.check(L.svs_wgrad_multi(ctypes.cast(arr, ctypes.c_void_p), len(jobs), F16X2, st), "svs_wgrad_multi(bg)")
+        self._hold = (d_bg_rgb, d_bg_out0)
+
+    def finalize(self, sdf_wb, rgb_wb, out=None):
+        """kernel-order accumulators -> ([(grad_w, grad_b)] * 9, [(grad_w, grad_b)] * 2)"""
+        L = _lib.load()
+        st = _stream()
+        res = []
+        for gi, ((w, b), base) in enumerate(((sdf_wb, 0), (rgb_wb, 9))):
+            group = []
+            for l in range(len(w)):
+                rows, cols = w[l].shape
+                gw, gb = out[gi][l] if out is not None else (torch.empty(rows, cols, device=self.dev), torch.empty(rows, device=self.dev))
+                is_sdf = gi == 0
+                mp = 3 if (is_sdf and l == 4) else (4 if (not is_sdf and l == 0) else 0)
+                row_off = 1 if (is_sdf and l == 8) else 0
+                row0 = _ptr(self.row0) if (is_sdf and l == 8) else None
+                _lib.check(L.svs_unpack_wgrad(_off(self.dWk, (base + l) * 256 * LDW), _off(self.dbk, (base + l) * 256), LDW, mp,
+                                              rows, cols, row_off, _ptr(_f32(w[l])), None, row0, _ptr(gw), None, _ptr(gb), st),
+                           "svs_unpack_wgrad(bg)")
+                group.append((gw, gb))
+            res.append(group)
+        return res[0], res[1]

@@ -124,6 +124,11 @@ class TrainStep:
             self.grad_out.append(group)
         self.beta_grad = next(it)
         dev = self.fp.flat.device
+        self.is_bg = hasattr(model, "bg_implicit_network")      # VolSDFNetworkBG: fg + inverted-sphere background
+        if self.is_bg:
+            from .train import BgBackward
+            self.bg_grad_out = [[(next(it), next(it)) for _ in range(n)] for n in (9, 2)]
+            self.bg_bwd = BgBackward(dev)
         self.groups = groups
         self.tstreams = TrainStreams(dev)
         self.accum = WGradAccum(dev)
@@ -154,12 +159,18 @@ class TrainStep:
         uv = model_input["uv"]
         R = uv.shape[1]
         dev = uv.device
-        S = m.ray_sampler.N_samples + m.ray_sampler.N_samples_extra + 2
+        S = m.ray_sampler.N_samples + m.ray_sampler.N_samples_extra + 2 - (1 if self.is_bg else 0)
         groups = self.split_rays(R, S) if self.groups == "auto" else (self.groups or [(0, R)])
         rng = m.draw_train_rng(R, dev)
         m.packed_mlp()                                   # pack once, before the streams fork
         sdf_p, rgb_p = m.mlp_params()
         self.tstreams.pack(sdf_p, rgb_p)
+        if self.is_bg:
+            if len(groups) > 1:
+                raise NotImplementedError("ray groups are not wired for the background model")
+            bg_sdf_wb, bg_rgb_wb = m.bg_params()
+            self.bg_bwd.pack(bg_sdf_wb, bg_rgb_wb)
+            self.bg_bwd.zero()
         self.accum.zero()
         self.d_beta.zero_()
         main = torch.cuda.current_stream()
@@ -183,9 +194,16 @@ class TrainStep:
                 gt = {"rgb": gt_rgb[lo:hi], "rgb_smooth": gt_smooth[lo:hi]}
                 lo_out = self.loss(out, gt, norm=(R * self.world, 2 * R * self.world), advance=(gi == len(groups) - 1))
                 g = self.loss.last_grads
-                d_sdf, d_rgb, d_beta = ops.composite_bwd(keep["z_vals"], keep["sdf"], keep["rgb_flat"], keep["depth_scale"],
-                                                         m.density.beta, m.density.beta_min_value, g["rgb_values"],
-                                                         g["weights"], g["depth_values"])
+                if self.is_bg:
+                    d_sdf, d_rgb, d_bo, d_brgb, d_beta = ops.composite_bg_bwd(
+                        keep["z_vals"], keep["z_max"], keep["sdf"], keep["rgb_flat"], keep["depth_scale"], m.density.beta,
+                        m.density.beta_min_value, keep["z_bg"], keep["bg_out0"], keep["bg_rgb"], g["rgb_values"],
+                        g["weights"], g["depth_values"])
+                    self.bg_bwd.accumulate(keep, d_brgb, d_bo)
+                else:
+                    d_sdf, d_rgb, d_beta = ops.composite_bwd(keep["z_vals"], keep["sdf"], keep["rgb_flat"], keep["depth_scale"],
+                                                             m.density.beta, m.density.beta_min_value, g["rgb_values"],
+                                                             g["weights"], g["depth_values"])
                 self.d_beta[gi:gi + 1].copy_(d_beta)
                 self.bwd[min(gi, 1)].accumulate(keep, d_rgb, d_sdf, g["grad_theta"])
                 results.append((lo_out, out))
@@ -195,6 +213,8 @@ class TrainStep:
         for ev in joins:
             main.wait_event(ev)
         finalize(self.accum, sdf_p, rgb_p, out=self.grad_out)
+        if self.is_bg:
+            self.bg_bwd.finalize(bg_sdf_wb, bg_rgb_wb, out=self.bg_grad_out)
         self.beta_grad.copy_(self.d_beta.sum())
         del scale
         allreduce_flat_grad(self.fp.grad, self.world)

@@ -65,6 +65,25 @@ class VolSDFNetworkBG(nn.Module):
             self._bg_key = key
         return self._pk_bg
 
+    def mlp_params(self):
+        """((sdf weight_v, weight_g, bias), (rgb weight_v, weight_g, bias)) of the foreground networks"""
+        def grab(net, n):
+            lins = [getattr(net, f"lin{l}") for l in range(n)]
+            return [m.weight_v for m in lins], [m.weight_g for m in lins], [m.bias for m in lins]
+        return grab(self.implicit_network, 9), grab(self.rendering_network, 5)
+
+    def _flat_param_list(self):
+        (sv, sg, sb), (rv, rg, rb) = self.mlp_params()
+        out = []
+        for v, g, b in ((sv, sg, sb), (rv, rg, rb)):
+            for l in range(len(v)):
+                out += [v[l], g[l], b[l]]
+        out.append(self.density.beta)
+        for w, b in self.bg_params():
+            for l in range(len(w)):
+                out += [w[l], b[l]]
+        return out
+
     def invalidate_packed(self):
         self.implicit_network._packed_key = None
         if self._pk is not None:
@@ -85,6 +104,10 @@ class VolSDFNetworkBG(nn.Module):
             return ["eik_points"]
 
         return self.ray_sampler.draw_train_rng(R, dev, extra=eik)
+
+    @staticmethod
+    def slice_rng(rng, lo, hi):
+        return {k: (v if k == "perm" else v[lo:hi].contiguous()) for k, v in rng.items()}
 
     def forward(self, input, fast=-1):
         if self.training and torch.is_grad_enabled():

@@ -503,8 +503,57 @@ def fx_train_step():
     save("train_step", **arr)
 
 
+def fx_train_step_bg():
+    """Two optimisation steps of the reference with the fg + background model (VolSDFNetworkBG, config 4): forward,
+    cost_mapping, VolSDFLoss, clip, Adam (volsdf/vsdf.py:196-219); 32 rays (32 x 97 fg + 32 x 32 bg samples)."""
+    from volsdf.vsdf import VolOpt
+    from volsdf.model.loss import VolSDFLoss
+    params = dict(synth.make_params(seed=0)); params.update(synth.make_bg_params(seed=0))
+    m = build_bg_model(params, beta=0.1)
+    m.train()
+    R = 32
+    views = synth.make_mvs_views(5)
+    K, pose = views[0]["K"], views[0]["c2w"]
+    uv = synth.make_uv(R, seed=12, margin=0.2)
+    rng = np.random.default_rng(3)
+    gt = dict(rgb=rng.uniform(0, 1, (1, R, 3)).astype(F32), rgb_smooth=rng.uniform(0, 1, (1, R, 3)).astype(F32))
+    ids = [25, 22, 28]
+    ds = SimpleNamespace(img_res=[576, 768], intrinsics_all={ids[j]: T(views[j]["K"]) for j in range(3)},
+                         pose_all={ids[j]: T(views[j]["c2w"]) for j in range(3)})
+    me = SimpleNamespace(trains_i=ids, costs={j: T(views[j]["cost"])[None] for j in range(3)},
+                         z_mvs={j: T(views[j]["z_mvs"])[None] for j in range(3)}, train_dataset=ds,
+                         hparams=SimpleNamespace(inverse_depth=False), stg=0)
+    loss = VolSDFLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, rgb_weight=1.0, mvs_weight=1.0, sparse_weight=1.0,
+                      anneal_rgb=200, gce=0.5, confi=1e-3)
+    loss.iter_step = 250        # past the rgb annealing: the plain L1 colour term is active and reaches the background
+    opt = torch.optim.Adam(m.parameters(), lr=5e-4)
+    inp = {"intrinsics": T(K)[None], "uv": T(uv)[None], "pose": T(pose)[None]}
+    arr = dict(uv=uv, rgb=gt["rgb"], rgb_smooth=gt["rgb_smooth"], mvs_seed=5, loss_iter_step=250)
+    for step in range(2):
+        draws = synth.make_train_rng(R, seed=100 + step, bg=True)
+        with inject_rng(draws):
+            out = m(inp, fast=1)
+        out['pj'], out['pi'], _ = VolOpt.cost_mapping(me, z_vals=out['depth_vals'], ts=torch.tensor([ids[0]]),
+                                                      xyz_raw=out['xyz'])
+        lo = loss(out, {k: T(v) for k, v in gt.items()})
+        opt.zero_grad()
+        lo['loss'].backward()
+        raw = param_digest([(n, p.grad.detach().numpy()) for n, p in m.named_parameters()], seed=step)
+        norm = torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        opt.step()
+        for k, v in lo.items():
+            arr[f"s{step}_{k}"] = np.asarray(float(v), F32)
+        arr[f"s{step}_grad_norm"] = np.asarray(float(norm), F32)
+        for n, (idx, val) in raw.items():
+            arr[f"s{step}_grad_idx/{n}"] = idx.astype(np.int32); arr[f"s{step}_grad/{n}"] = val
+        for n, (idx, val) in param_digest([(n, p.detach().numpy()) for n, p in m.named_parameters()], seed=10 + step).items():
+            arr[f"s{step}_param_idx/{n}"] = idx.astype(np.int32); arr[f"s{step}_param/{n}"] = val
+    save("train_step_bg", **arr)
+
+
 ALL = dict(rays=fx_rays, sdf_mlp=fx_sdf_mlp, rgb_mlp=fx_rgb_mlp, density=fx_density, sampler=fx_sampler,
-           composite=fx_composite, forward=fx_forward, forward_bg=fx_forward_bg, cost_mapping=fx_cost_mapping, loss=fx_loss, casmvs=fx_casmvs, train_step=fx_train_step)
+           composite=fx_composite, forward=fx_forward, forward_bg=fx_forward_bg, cost_mapping=fx_cost_mapping, loss=fx_loss, casmvs=fx_casmvs, train_step=fx_train_step,
+           train_step_bg=fx_train_step_bg)
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(ALL)

@@ -159,3 +159,52 @@ def test_composite_bg_backward(dev):
     assert _rel(d_bo.cpu().numpy().reshape(R, Nb), tbo.grad.numpy()) < 2e-5
     assert _rel(d_brgb.cpu().numpy().reshape(R, Nb, 3), tbrgb.grad.numpy()) < 2e-5
     assert abs(float(d_beta) - float(tb.grad)) / abs(float(tb.grad)) < 5e-5
+
+
+def test_bg_train_steps_fused(dev, golden_dir):
+    """TrainStep with VolSDFNetworkBG (forward incl. background, lookup, loss, fg + bg backward, clip + Adam) x 2
+    against the reference's optimisation steps (tests/golden/train_step_bg.npz)."""
+    from rng_inject import inject_rng
+    from svs_hip.trainer import TrainStep
+    from volsdf.model.loss import VolSDFLoss
+    g = dict(np.load(os.path.join(golden_dir, "train_step_bg.npz")))
+    m = _model(dev, 0.1)
+    loss = VolSDFLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, rgb_weight=1.0, mvs_weight=1.0, sparse_weight=1.0,
+                      anneal_rgb=200, gce=0.5, confi=1e-3)
+    loss.iter_step = int(g["loss_iter_step"])
+    ts = TrainStep(m, loss, lr=5e-4)
+    views = synth.make_mvs_views(int(g["mvs_seed"]))
+    dv = [dict(K=v["K"], c2w=v["c2w"], cost=G(v["cost"], dev), z_mvs=G(v["z_mvs"], dev)) for v in views]
+    mvs = dict(views=dv, same_view=0, img_res=(576, 768), inverse_depth=False)
+    R = g["uv"].shape[0]
+    inp = {"intrinsics": G(views[0]["K"], dev)[None], "uv": G(g["uv"], dev)[None], "pose": G(views[0]["c2w"], dev)[None]}
+    gt = {"rgb": G(g["rgb"], dev), "rgb_smooth": G(g["rgb_smooth"], dev)}
+
+    def tensor_rel(step, kind, named):
+        out = {}
+        for name, t in named:
+            idx, ref = g[f"s{step}_{kind}_idx/{name}"], g[f"s{step}_{kind}/{name}"]
+            got = t.detach().cpu().numpy().reshape(-1)[idx]
+            out[name] = float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30))
+        return out
+
+    for step in range(2):
+        with inject_rng(synth.make_train_rng(R, seed=100 + step, bg=True)):
+            lo, out = ts(inp, gt, mvs=mvs)
+        torch.cuda.synchronize()
+        for k in ("rgb_loss", "eikonal_loss", "mvs_loss", "sparse_loss", "loss"):
+            print(f"step {step} {k}: {float(lo[k]):.7f} ref {float(g[f's{step}_{k}']):.7f}")
+            np.testing.assert_allclose(float(lo[k]), float(g[f"s{step}_{k}"]), rtol=3e-4 if step == 0 else 5e-3, atol=2e-6,
+                                       err_msg=f"step {step} {k}")
+        norm = float(ts.opt.info[0])
+        np.testing.assert_allclose(norm, float(g[f"s{step}_grad_norm"]), rtol=2e-3)
+        coef = min(1.0, 1.0 / (float(g[f"s{step}_grad_norm"]) + 1e-6))
+        rel = tensor_rel(step, "grad", [(n, p.grad / coef) for n, p in m.named_parameters()])
+        worst = max(rel, key=rel.get)
+        print(f"step {step}: worst per-tensor gradient error {rel[worst]:.3e} {worst}")
+        bg_rel = {k: v for k, v in rel.items() if k.startswith("bg_")}
+        print(f"step {step}: worst background-tensor gradient error {max(bg_rel.values()):.3e}")
+        assert all(np.abs(g[f"s{step}_grad/{k}"]).max() > 0 for k in bg_rel), "the fixture must exercise the background nets"
+        assert max(rel.values()) < (3e-3 if step == 0 else 3e-2), rel
+        prel = tensor_rel(step, "param", list(m.named_parameters()))
+        assert max(prel.values()) < 2e-2, prel
