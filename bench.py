@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rays", type=int, default=1024)
     ap.add_argument("--mode", choices=["train", "render"], default="train")
+    ap.add_argument("--model", choices=["dtu", "bmvs"], default="dtu",
+                    help="dtu: VolSDFNetwork (configs[1], the headline metric); bmvs: VolSDFNetworkBG, fg + inverted-sphere "
+                         "background (config 4), train mode only")
     ap.add_argument("--groups", choices=["auto", "none"], default="none", help="ray groups on concurrent streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -71,7 +74,15 @@ def main():
 
     R = args.rays
     params = synth.make_params(0)
-    model = VolSDFNetwork(dtu_model_conf())
+    if args.model == "bmvs":
+        from ref_shim import bmvs_model_conf
+        from volsdf.model.network_bg import VolSDFNetworkBG
+        params = dict(params); params.update(synth.make_bg_params(0))
+        model = VolSDFNetworkBG(bmvs_model_conf())
+        if args.mode != "train":
+            raise SystemExit("--model bmvs is benchmarked in train mode")
+    else:
+        model = VolSDFNetwork(dtu_model_conf())
     model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
     model.to(dev).train()
     K, pose = synth.make_camera()
@@ -218,7 +229,9 @@ def main():
             "config": {"workload": ("configs[1]: VolOpt.train_step (forward + MVS prior lookup + loss + backward + clip/guard/Adam), "
                                     if train else "configs[1]: VolSDFNetwork.forward as called by VolOpt.train_step, forward only, ")
                                    + f"train mode, fast=1: {R} rays/GPU x 128 coarse + {S} composited samples + {2 * R} "
-                                   "eikonal points, 8x256 SDF MLP + 4x256 radiance MLP",
+                                   "eikonal points, 8x256 SDF MLP + 4x256 radiance MLP"
+                                   + (" + 32 inverted-sphere background samples per ray (8x256 bg implicit MLP + 128-wide bg "
+                                      "radiance MLP): config 4, VolSDFNetworkBG" if args.model == "bmvs" else ""),
                        "mode": args.mode,
                        "mlp_precision": ("fp16x2: two-piece fp16 operands on v_mfma_f32_32x32x16_f16, float32 accumulation "
                                          "(float32-class accuracy, same parity bounds)" if h2 else "float32 MFMA"),
@@ -226,7 +239,7 @@ def main():
                        "model_flops_per_s": world * R * args.steps / dt * flop_per_ray},
             "roofline": roofline,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and args.model == "dtu":
             line["cpu_baseline"] = cpu_baseline(params, K, pose, train=train)
         print(json.dumps(line), flush=True)
     if dist:
