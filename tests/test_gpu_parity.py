@@ -359,3 +359,34 @@ def test_loss_kernel(dev, ops, golden_dir, it):
     for k in ("rgb_values", "grad_theta", "weights", "depth_values"):
         ref = t[k].grad.numpy() if t[k].grad is not None else np.zeros_like(g[k])
         np.testing.assert_allclose(grads[k].cpu().numpy().reshape(ref.shape), ref, rtol=2e-5, atol=1e-8, err_msg=k)
+
+
+def test_fp16x2_accuracy_class(dev):
+    """The fp16x2 MLP kernels (two-piece fp16 operands on the 16-bit matrix cores, float32 accumulation) are in the
+    accuracy class of the float32-MFMA kernels: on 16 384 random points inside the bounding sphere, the error of sdf,
+    d sdf/dx and the feature vector against a float64 evaluation is within 2.5x (5x for the input gradient, whose
+    small intermediate values sit on fp16's absolute floor of 2^-25) of the float32 kernels' error and far inside the
+    1e-4 / 2e-4 parity bounds.  Measured: sdf 1.8e-6 vs 1.6e-6, gradient 1.0e-5 vs 2.9e-6, feature 2.5e-6 vs 3.0e-6."""
+    import torch_ref as tref
+    from svs_hip import ops
+    params = synth.make_params(0)
+    lay = lambda k: [G(params[f"implicit_network.lin{l}.{k}"], dev) for l in range(9)]
+    v, g, b = lay("weight_v"), [t.reshape(-1) for t in lay("weight_g")], lay("bias")
+    rs = np.random.default_rng(8)
+    P = 16384
+    x = rs.uniform(-1.5, 1.5, (P, 3)).astype(F32)
+    p64 = tref.to_torch(params, torch.float64, requires_grad=False)
+    xt = torch.tensor(x, dtype=torch.float64)
+    sdf64, feat64, grad64 = tref.sdf_outputs(p64, xt, 3.0, 20.0)
+    sdf64, feat64, grad64 = sdf64.detach().numpy(), feat64.detach().numpy(), grad64.detach().numpy()
+    err = {}
+    for prec in (ops.F32, ops.F16X2):
+        pk = ops.PackedMlp(dev, precision=prec)
+        pk.pack_sdf(v, g, b)
+        sdf, grad, _, _, rows = ops.sdf_outputs(pk, ops.PointSource(points=G(x, dev)), 3.0, 20.0, want_feature_rows=True)
+        only = ops.sdf_vals(pk, ops.PointSource(points=G(x, dev)), 3.0, 20.0)
+        err[prec] = (np.abs(sdf.cpu().numpy() - sdf64).max(), np.abs(grad.cpu().numpy() - grad64).max(),
+                     np.abs(rows.cpu().numpy() - feat64).max(), np.abs(only.cpu().numpy() - sdf64).max())
+    print("max |err| vs float64 (sdf, grad, feature, sdf_only): float32 MFMA", err[ops.F32], " fp16x2", err[ops.F16X2])
+    for e32, e16, bound, fac in zip(err[ops.F32], err[ops.F16X2], (1e-4, 2e-4, 1e-4, 1e-4), (2.5, 5.0, 2.5, 2.5)):
+        assert e16 < bound and e16 < fac * e32 + 1e-6, (e32, e16)
