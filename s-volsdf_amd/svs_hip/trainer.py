@@ -153,6 +153,9 @@ class TrainStep:
 
     def __call__(self, model_input, ground_truth, mvs=None, fast=1):
         """mvs: optional dict(views=[...], same_view=int, img_res=(H,W), inverse_depth=bool) for cost_mapping."""
+        return self._step(model_input, ground_truth, mvs, fast)
+
+    def _step(self, model_input, ground_truth, mvs=None, fast=1):
         from .train import finalize
         m = self.model
         m.train()
