@@ -285,6 +285,14 @@ int svs_warp_variance(const float* ref_feature, const float* const* src_features
  * in; bias: BN shift (NULL for the final `prob` conv).  transposed: ConvTranspose3d(k3,s2,p1,output_padding 1). */
 int svs_conv3d(const float* in, const float* weight, const float* bias, const float* skip, float* out, int Cin, int Cout,
                int Di, int Hi, int Wi, int stride, int transposed, int relu, void* hip_stream);
+/* The stride-1 convolutions with Cin in {8,16,32} and Cout <= 16 (conv0, conv2, prob: 79 % of the U-Net's MACs at
+ * stage 1) on the fp16 matrix cores with two-piece split operands (float32-class accuracy).
+ * wfrag (svs_conv3d_mfma_wfrag_bytes(Cin)): the folded weights as fp16 hi / mid A fragments of
+ * v_mfma_f32_16x16x32_f16: [k-step s][piece][lane][8]: output channel lane & 15, k = 32 s + 8 (lane >> 4) + j =
+ * tap * Cin + cin (zero for tap > 26 and channels >= Cout). */
+size_t svs_conv3d_mfma_wfrag_bytes(int Cin);
+int svs_conv3d_mfma(const float* in, const void* wfrag, const float* bias, const float* skip, float* out, int Cin,
+                    int Cout, int D, int H, int W, int relu, void* hip_stream);
 
 /* ---- a14 tail  softmax over D, depth regression, photometric confidence (models/CasMVSNet.py:648-663) ---------
  * reg, depth_values (D,H,W) -> prob (D,H,W), depth (H,W), conf (H,W), index (H,W int, may be NULL). */

@@ -27,6 +27,7 @@ UNITS = {
     "svs_sampler.hip": ["-ffp-contract=off"],
     "svs_render.hip": ["-ffp-contract=off"],
     "svs_costvol.hip": ["-ffp-contract=off"],
+    "svs_conv_mfma.hip": [],
     "svs_wgrad.hip": [],
     "svs_mlp_bwd.hip": [],
     "svs_mlp_bwd_h2.hip": [],

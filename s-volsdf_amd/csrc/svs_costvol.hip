@@ -399,7 +399,14 @@ int svs_conv3d(const float* in, const float* weight, const float* bias, const fl
     a.Do = (Di - 1) / stride + 1; a.Ho = (Hi - 1) / stride + 1; a.Wo = (Wi - 1) / stride + 1;
     constexpr int VX = 4;
     const long long total = (long long)a.Do * a.Ho * ((a.Wo + VX - 1) / VX);
-    if (Cout <= 8) {
+    const long long wgs16 = ((total + kConvThreads - 1) / kConvThreads) * ((Cout + 15) / 16);
+    if (wgs16 < 768) {
+      // small volume (the coarse U-Net levels): one output voxel x 8 channels per thread, so that the launch still
+      // has a few hundred workgroups
+      const long long total1 = (long long)a.Do * a.Ho * a.Wo;
+      dim3 grid((unsigned)((total1 + kConvThreads - 1) / kConvThreads), (Cout + 7) / 8);
+      conv3d_kernel<8, 1><<<grid, kConvThreads, 0, s>>>(a);
+    } else if (Cout <= 8) {
       dim3 grid((unsigned)((total + kConvThreads - 1) / kConvThreads), (Cout + 7) / 8);
       conv3d_kernel<8, VX><<<grid, kConvThreads, 0, s>>>(a);
     } else {

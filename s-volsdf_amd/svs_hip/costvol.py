@@ -62,12 +62,46 @@ def homo_warp(src_fea, src_rel, depth_values):
     return out
 
 
+_WFRAG_CACHE = {}
+
+
+def mfma_weight_fragments(weight):
+    """[Cin][27][Cout] folded float32 weights -> the fp16 hi / mid A fragments of svs_conv3d_mfma
+    ([k-step][piece][lane][8] fp16, see include/svolsdf_hip.h).  One-time repacking per layer (cached)."""
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape))
+    hit = _WFRAG_CACHE.get(key)
+    if hit is not None:
+        return hit[0]
+    Cin, _, Cout = weight.shape
+    dev = weight.device
+    KS = (27 * Cin + 31) // 32
+    s = torch.arange(KS, device=dev).view(KS, 1, 1)
+    lane = torch.arange(64, device=dev).view(1, 64, 1)
+    j = torch.arange(8, device=dev).view(1, 1, 8)
+    kk = 32 * s + 8 * (lane >> 4) + j
+    tap, ci, co = kk // Cin, kk % Cin, (lane & 15).expand(KS, 64, 8)
+    ok = (tap < 27) & (co < Cout)
+    w = weight[ci.clamp(max=Cin - 1), tap.clamp(max=26), co.clamp(max=Cout - 1)]
+    w = torch.where(ok, w, torch.zeros_like(w)).float()
+    hi = w.half()
+    mid = (w - hi.float()).half()
+    frag = torch.stack([hi, mid], 1).contiguous()          # (KS, 2, 64, 8) fp16
+    _WFRAG_CACHE[key] = (frag, weight)                     # keep `weight` alive: the key holds its address
+    return frag
+
+
 def conv3d(x, weight, bias=None, skip=None, stride=1, transposed=False, relu=True):
     """x (Cin,D,H,W); weight [Cin][27][Cout] folded; -> (Cout,Do,Ho,Wo)."""
     L = _lib.load()
     x = _f32(x)
     Cin, D, H, W = x.shape
     Cout = weight.shape[2]
+    if not transposed and stride == 1 and Cin in (8, 16, 32) and Cout <= 16:
+        frag = mfma_weight_fragments(weight)
+        out = torch.empty((Cout, D, H, W), device=x.device)
+        _lib.check(L.svs_conv3d_mfma(_ptr(x), _ptr(frag), _ptr(bias), _ptr(skip), _ptr(out), Cin, Cout, D, H, W,
+                                     int(relu), _stream()), "svs_conv3d_mfma")
+        return out
     if transposed:
         shp = (Cout, 2 * D, 2 * H, 2 * W)
     else:
