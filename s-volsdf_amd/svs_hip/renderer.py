@@ -14,12 +14,44 @@ the sampler's device-side control block has one record per group of split_n_pixe
 import torch
 
 
+def shard_pixels(total_pixels, split_n_pixels, rank, world):
+    """Contiguous pixel range [lo, hi) of `rank`: whole chunks of split_n_pixels rays, so that every rank makes the
+    same per-chunk sampler decisions as a single-GPU render (the chunks are independent; no exchange is needed until
+    the image is assembled).  Chunks are dealt out as evenly as possible (the first ranks take one more)."""
+    n_chunks = (total_pixels + split_n_pixels - 1) // split_n_pixels
+    base, extra = divmod(n_chunks, world)
+    c0 = rank * base + min(rank, extra)
+    c1 = c0 + base + (1 if rank < extra else 0)
+    return min(c0 * split_n_pixels, total_pixels), min(c1 * split_n_pixels, total_pixels)
+
+
+def gather_image(part, lo, hi, total_pixels, world):
+    """Assembles the full-image tensors from every rank's part (dict of (hi - lo, ...) tensors) with one all-gather per
+    key (RCCL on the GPU box, gloo in the CPU test); ranks pad to the largest part."""
+    import torch.distributed as dist
+    sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([hi - lo], dtype=torch.int64))
+    sizes = [int(s) for s in sizes]
+    m = max(sizes)
+    out = {}
+    for k, v in part.items():
+        pad = torch.zeros((m,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+        pad[:v.shape[0]] = v
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad)
+        out[k] = torch.cat([p[:n] for p, n in zip(parts, sizes)], 0)
+        assert out[k].shape[0] == total_pixels
+    return out
+
+
 @torch.no_grad()
 def render_image(model, model_input, total_pixels, split_n_pixels=500, rays_per_launch=8000, fast=-1,
-                 keys=("rgb_values", "normal_map", "depth_values", "depth_vals", "weights", "xyz")):
+                 keys=("rgb_values", "normal_map", "depth_values", "depth_vals", "weights", "xyz"), rank=0, world=1):
     """model: VolSDFNetwork in eval mode; model_input: dict(intrinsics (1,4,4), uv (1,total_pixels,2), pose (1,4,4)).
     Returns the merged outputs of VolOpt.render_step (the arrays utils.merge_output builds) as device tensors:
-    rgb_values (N,3), normal_map (N,3), depth_values (N,1), depth_vals (N,S), weights (N,S), xyz (N,S,3)."""
+    rgb_values (N,3), normal_map (N,3), depth_values (N,1), depth_vals (N,S), weights (N,S), xyz (N,S,3).
+    world > 1: every rank renders its shard_pixels() range of whole chunks and the image is assembled with
+    gather_image (one all-gather per output)."""
     if model.training:
         raise ValueError("render_image renders in eval mode (VolOpt.render_step calls model.eval())")
     uv = model_input["uv"]
@@ -29,20 +61,23 @@ def render_image(model, model_input, total_pixels, split_n_pixels=500, rays_per_
     sampler = model.ray_sampler
     prev_group = getattr(sampler, "group_rays", None)
     sampler.group_rays = split_n_pixels
+    p_lo, p_hi = shard_pixels(total_pixels, split_n_pixels, rank, world) if world > 1 else (0, total_pixels)
     out = {}
     try:
-        for lo in range(0, total_pixels, per_launch):
-            hi = min(lo + per_launch, total_pixels)
+        for lo in range(p_lo, p_hi, per_launch):
+            hi = min(lo + per_launch, p_hi)
             chunk = dict(model_input)
             chunk["uv"] = uv[:, lo:hi].contiguous()
             res = model(chunk, fast=fast)
             for k in keys:
                 v = res[k]
                 if k not in out:
-                    out[k] = torch.empty((total_pixels,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
-                out[k][lo:hi].copy_(v)
+                    out[k] = torch.empty((p_hi - p_lo,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+                out[k][lo - p_lo:hi - p_lo].copy_(v)
     finally:
         sampler.group_rays = prev_group
+    if world > 1:
+        return gather_image(out, p_lo, p_hi, total_pixels, world)
     return out
 
 

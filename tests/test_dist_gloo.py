@@ -81,3 +81,65 @@ def test_shard_rays_rejects_ragged():
     full = torch.arange(16.).reshape(1, 8, 2)
     parts = [shard_rays(full, r, 4) for r in range(4)]
     assert torch.equal(torch.cat(parts, 1), full)
+
+
+def _render_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "s-volsdf_amd"))
+    import importlib.util
+    import torch.distributed as dist
+    # renderer.py only needs torch: load it without importing the package's HIP bindings
+    spec = importlib.util.spec_from_file_location("renderer", os.path.join(ROOT, "s-volsdf_amd", "svs_hip", "renderer.py"))
+    renderer = importlib.util.module_from_spec(spec); spec.loader.exec_module(renderer)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class Sampler:
+        group_rays = None
+
+    class Toy(torch.nn.Module):
+        """stands in for VolSDFNetwork: every output is a function of the pixel alone"""
+        def __init__(self):
+            super().__init__()
+            self.ray_sampler = Sampler()
+            self.calls = []
+
+        def forward(self, inp, fast=-1):
+            uv = inp["uv"][0]
+            self.calls.append((uv.shape[0], self.ray_sampler.group_rays))
+            return {"rgb_values": torch.stack([uv[:, 0], uv[:, 1], uv.sum(1)], 1), "depth_values": uv[:, :1] * 2.0,
+                    "weights": uv[:, :1].repeat(1, 5)}
+
+    m = Toy().eval()
+    N = 2300                               # 5 chunks of 500: 3 + 2 over two ranks, ragged last chunk
+    uv = torch.stack([torch.arange(N, dtype=torch.float32), torch.arange(N, dtype=torch.float32) % 7], 1)[None]
+    lo, hi = renderer.shard_pixels(N, 500, rank, world)
+    out = renderer.render_image(m, {"uv": uv}, N, split_n_pixels=500, rays_per_launch=1000,
+                                keys=("rgb_values", "depth_values", "weights"), rank=rank, world=world)
+    q.put((rank, lo, hi, m.calls, {k: v.numpy() for k, v in out.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_image_render():
+    """render_image over 2 ranks: whole 500-ray chunks per rank, per-chunk convergence groups set on the sampler, and
+    the all-gathered image equals the single-process result."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_render_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, lo0, hi0, calls0, out0), (r1, lo1, hi1, calls1, out1) = res
+    assert (lo0, hi0, lo1, hi1) == (0, 1500, 1500, 2300)
+    assert calls0 == [(1000, 500), (500, 500)] and calls1 == [(800, 500)]
+    N = 2300
+    uv = np.stack([np.arange(N, dtype=np.float32), np.arange(N, dtype=np.float32) % 7], 1)
+    for out in (out0, out1):
+        assert np.array_equal(out["rgb_values"], np.stack([uv[:, 0], uv[:, 1], uv.sum(1)], 1))
+        assert np.array_equal(out["depth_values"], uv[:, :1] * 2.0)
+        assert out["weights"].shape == (N, 5)
