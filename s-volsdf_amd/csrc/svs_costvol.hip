@@ -34,67 +34,151 @@ struct WarpArgs {
   int raw_warp;                  // 1: write the warped volume of source 0 instead of the variance (homo_warping alone)
 };
 
-template <int C>
-__global__ __launch_bounds__(256) void warp_variance_kernel(WarpArgs a) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = blockIdx.y, d = blockIdx.z;
-  if (x >= a.W) return;
-  const int H = a.H, W = a.W;
-  const size_t pix = (size_t)y * W + x;
-  const float depth = a.depth_values[((size_t)d * H + y) * W + x];
-  float sum[C], sq[C];
+// One workgroup: kWarpPasses * (256 / (C/4)) consecutive x of one image row, `dz` depth planes.
+//  * C/4 adjacent lanes own one voxel, 4 channels each: a bilinear corner ((H,W,C) source layout) is ONE contiguous
+//    C-vector, so a wave's load instruction touches 64/(C/4) whole lines instead of 64 partial ones;
+//  * corner weights and offsets are computed once per (voxel, source) by a separate phase and handed over in LDS
+//    (otherwise every lane of a voxel repeats the projection and its divisions: the kernel was VALU-bound on that);
+//  * the blend is packed fused multiply-adds (v_pk_fma_f32);
+//  * the variance tile goes through LDS (aliased with the corner tables) so that every channel plane is written as
+//    contiguous runs of x.
+// What bounds it: the vector L1 delivers 64 B/clk/CU and every voxel pulls n_src * 4 corners * C * 4 B through it
+// (4.0 GB at stage 1 = 0.12 ms) -- more than the HBM write of the volume (0.53 GB).
+constexpr int kWarpPasses = 5;      // 5 * 32 = 160 = stage-1 width at C = 32 (and 320 / C = 16, 640 / C = 8)
+
+template <int C, int NS>
+__global__ __launch_bounds__(256, 4) void warp_variance_kernel(WarpArgs a, int dz_planes) {
+  constexpr int LPV = C / 4;                       // lanes per voxel
+  constexpr int VPP = 256 / LPV;                   // voxels per pass
+  constexpr int TW = kWarpPasses * VPP;            // tile width in x
+  constexpr int S = TW + 4;                        // LDS row stride (floats): rows stay 16-byte aligned
+  constexpr int kTileF = C * S, kTapF = NS * TW * 8;
+  // the variance tile and the corner tables are never live together
+  __shared__ __attribute__((aligned(16))) float lds[kTileF > kTapF ? kTileF : kTapF];
+  float* tile = lds;
+  f32x4* tapw = reinterpret_cast<f32x4*>(lds);               // per (source, voxel): the 4 corner weights (0: outside)
+  i32x4* tapo = reinterpret_cast<i32x4*>(lds + NS * TW * 4); //                       and offsets into the (H,W,C) map
+  const int tid = threadIdx.x;
+  const int cg = tid % LPV, vl = tid / LPV;
+  const int H = a.H, W = a.W, y = blockIdx.y;
+  const int xt = blockIdx.x * TW;
+  const size_t HW = (size_t)H * W;
+  const float inv_nv = 1.0f / (float)(NS + 1);
+
+  // reference-view feature of the tile, kept across the depth planes
+  f32x4 ref[kWarpPasses];
 #pragma unroll
-  for (int c = 0; c < C; ++c) {
-    const float r = a.ref[(size_t)c * H * W + pix];
-    sum[c] = r; sq[c] = r * r;
+  for (int p = 0; p < kWarpPasses; ++p) {
+    const int x = xt + p * VPP + vl;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ref[p][j] = (x < W && !a.raw_warp) ? a.ref[(size_t)(4 * cg + j) * HW + (size_t)y * W + x] : 0.0f;
   }
-  const float fx = (float)x, fy = (float)y;
-  for (int v = 0; v < a.n_src; ++v) {
-    const float* R = a.rot[v];
-    // rot @ [x,y,1] * depth + trans   (CasMVSNet.py:300-303)
-    const float qx = ((R[0] * fx + R[1] * fy) + R[2]) * depth + a.trans[v][0];
-    const float qy = ((R[3] * fx + R[4] * fy) + R[5]) * depth + a.trans[v][1];
-    const float qz = ((R[6] * fx + R[7] * fy) + R[8]) * depth + a.trans[v][2];
-    const float px = qx / qz, py = qy / qz;
-    // normalised with the (W-1)/2 formula, sampled with align_corners=False (:305-312)
-    const float gx = px / ((float)(W - 1) / 2.0f) - 1.0f, gy = py / ((float)(H - 1) / 2.0f) - 1.0f;
-    const float ix = ((gx + 1.0f) * (float)W - 1.0f) / 2.0f, iy = ((gy + 1.0f) * (float)H - 1.0f) / 2.0f;
-    const float x0 = __builtin_floorf(ix), y0 = __builtin_floorf(iy);
-    const float tx = ix - x0, ty = iy - y0;
-    float warped[C];
+  for (int dz = 0; dz < dz_planes; ++dz) {
+    const int d = blockIdx.z * dz_planes + dz;
+    if (d >= a.D) break;
+    f32x4 r[kWarpPasses];
+    // ---- phase A: corner weights and offsets, one (voxel, source) per thread --------------------------------------------
+    __syncthreads();
+    for (int i = tid; i < NS * TW; i += 256) {
+      const int v = i / TW, vx = i - v * TW;
+      const int x = xt + vx;
+      f32x4 w4 = {0.0f, 0.0f, 0.0f, 0.0f};
+      i32x4 o4 = {0, 0, 0, 0};
+      if (x < W) {
+        const float depth = a.depth_values[((size_t)d * H + y) * W + x];
+        const float fx = (float)x, fy = (float)y;
+        const float* R = a.rot[v];
+        // rot @ [x,y,1] * depth + trans   (CasMVSNet.py:300-303)
+        const float qx = ((R[0] * fx + R[1] * fy) + R[2]) * depth + a.trans[v][0];
+        const float qy = ((R[3] * fx + R[4] * fy) + R[5]) * depth + a.trans[v][1];
+        const float qz = ((R[6] * fx + R[7] * fy) + R[8]) * depth + a.trans[v][2];
+        // correctly rounded divisions, the reference's operation order: at |coordinate| ~ 300 px one ulp of the
+        // quotient already moves a sample by 3e-5 px (once per voxel and source: not what bounds the kernel)
+        const float px = qx / qz, py = qy / qz;
+        // normalised with the (W-1)/2 formula, sampled with align_corners=False (:305-312)
+        const float gx = px / ((float)(W - 1) / 2.0f) - 1.0f, gy = py / ((float)(H - 1) / 2.0f) - 1.0f;
+        const float ix = ((gx + 1.0f) * (float)W - 1.0f) / 2.0f, iy = ((gy + 1.0f) * (float)H - 1.0f) / 2.0f;
+        const float x0 = __builtin_floorf(ix), y0 = __builtin_floorf(iy);
+        const float tx = ix - x0, ty = iy - y0;
 #pragma unroll
-    for (int c = 0; c < C; ++c) warped[c] = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float xx = x0 + (float)(k & 1), yy = y0 + (float)(k >> 1);
-      if (xx >= 0.0f && xx <= (float)(W - 1) && yy >= 0.0f && yy <= (float)(H - 1)) {
-        const float w = ((k & 1) ? tx : 1.0f - tx) * ((k >> 1) ? ty : 1.0f - ty);
-        const f32x4* s = reinterpret_cast<const f32x4*>(a.src_hwc[v] + ((size_t)(int)yy * W + (int)xx) * C);
-#pragma unroll
-        for (int c4 = 0; c4 < C / 4; ++c4) {
-          const f32x4 f = s[c4];
-          warped[4 * c4] += w * f[0]; warped[4 * c4 + 1] += w * f[1];
-          warped[4 * c4 + 2] += w * f[2]; warped[4 * c4 + 3] += w * f[3];
+        for (int k = 0; k < 4; ++k) {
+          const float xx = x0 + (float)(k & 1), yy = y0 + (float)(k >> 1);
+          // zeros padding: a corner outside contributes nothing (NaN coordinates compare false)
+          if (xx >= 0.0f && xx <= (float)(W - 1) && yy >= 0.0f && yy <= (float)(H - 1)) {
+            w4[k] = ((k & 1) ? tx : 1.0f - tx) * ((k >> 1) ? ty : 1.0f - ty);
+            o4[k] = ((int)yy * W + (int)xx) * (C * 4);      // byte offset
+          }
         }
       }
+      tapw[i] = w4;
+      tapo[i] = o4;
     }
-    if (a.raw_warp) {
-      const size_t vox0 = ((size_t)d * H + y) * W + x;
-      const size_t cs0 = (size_t)a.D * H * W;
+    __syncthreads();
+    // ---- phase B: gather the corners of all sources, 4 channels per lane ------------------------------------------------
 #pragma unroll
-      for (int c = 0; c < C; ++c) a.variance[c * cs0 + vox0] = warped[c];
-      return;
+    for (int p = 0; p < kWarpPasses; ++p) {
+      const int vx = p * VPP + vl;
+      f32x4 f[NS][4], w4[NS];
+#pragma unroll
+      for (int v = 0; v < NS; ++v) {
+        w4[v] = tapw[v * TW + vx];
+        const i32x4 o4 = tapo[v * TW + vx];
+        const char* __restrict__ src = reinterpret_cast<const char*>(a.src_hwc[v]);   // uniform base + 32-bit offset
+#pragma unroll
+        for (int k = 0; k < 4; ++k) f[v][k] = *reinterpret_cast<const f32x4*>(src + ((unsigned)o4[k] + 16u * cg));
+      }
+      f32x4 sum = ref[p], sq = ref[p] * ref[p];
+#pragma unroll
+      for (int v = 0; v < NS; ++v) {
+        // a corner outside has weight 0 and adds +-0: the same bits as skipping it
+        f32x4 warped = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          warped = __builtin_elementwise_fma(f32x4{w4[v][k], w4[v][k], w4[v][k], w4[v][k]}, f[v][k], warped);
+        sum += warped; sq = __builtin_elementwise_fma(warped, warped, sq);
+        if (a.raw_warp) sum = warped;
+      }
+      if (a.raw_warp) r[p] = sum;
+      else { const f32x4 m = sum * inv_nv; r[p] = sq * inv_nv - m * m; }
     }
+    // ---- phase C: variance -> LDS tile -> contiguous runs of every channel plane ----------------------------------------
+    __syncthreads();
 #pragma unroll
-    for (int c = 0; c < C; ++c) { sum[c] += warped[c]; sq[c] += warped[c] * warped[c]; }
+    for (int p = 0; p < kWarpPasses; ++p) {
+      const int vx = p * VPP + vl;
+      // column swizzle (bit 3 by bit 1 of cg): with the 16-byte-aligned stride the 64 lanes of a wave would otherwise
+      // fall on 16 banks; whole groups of 4 columns move together, so rows still read back as float4
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tile[(4 * cg + j) * S + (vx ^ ((cg & 2) << 2))] = r[p][j];
+    }
+    __syncthreads();
+    const size_t cs = (size_t)a.D * HW;
+    const size_t row = ((size_t)d * H + y) * W + xt;
+    if ((W & 3) == 0) {
+      for (int i = tid; i < C * (TW / 4); i += 256) {
+        const int c = i / (TW / 4), v4 = (i - c * (TW / 4)) * 4;
+        const int vx = v4 ^ (((c >> 2) & 2) << 2);
+        if (xt + vx < W) *reinterpret_cast<f32x4*>(a.variance + c * cs + row + vx) = *reinterpret_cast<const f32x4*>(tile + c * S + v4);
+      }
+    } else {
+      for (int i = tid; i < C * TW; i += 256) {
+        const int c = i / TW, vx = i - c * TW;
+        if (xt + vx < W) a.variance[c * cs + row + vx] = tile[c * S + (vx ^ (((c >> 2) & 2) << 2))];
+      }
+    }
   }
-  const float nv = (float)(a.n_src + 1);
-  const size_t vox = ((size_t)d * H + y) * W + x;
-  const size_t cs = (size_t)a.D * H * W;
-#pragma unroll
-  for (int c = 0; c < C; ++c) {
-    const float m = sum[c] / nv;
-    a.variance[c * cs + vox] = sq[c] / nv - m * m;
+}
+
+template <int C>
+static void launch_warp(const WarpArgs& a, hipStream_t s) {
+  const int tw = kWarpPasses * (256 / (C / 4));
+  const int dz = a.D >= 64 ? 4 : 1;                // few planes: one per workgroup, so that the launch fills the chip
+  dim3 grid((a.W + tw - 1) / tw, a.H, (a.D + dz - 1) / dz), block(256);
+  switch (a.n_src) {
+    case 1: warp_variance_kernel<C, 1><<<grid, block, 0, s>>>(a, dz); break;
+    case 2: warp_variance_kernel<C, 2><<<grid, block, 0, s>>>(a, dz); break;
+    case 3: warp_variance_kernel<C, 3><<<grid, block, 0, s>>>(a, dz); break;
+    default: warp_variance_kernel<C, 4><<<grid, block, 0, s>>>(a, dz); break;
   }
 }
 
@@ -370,13 +454,11 @@ int svs_warp_variance(const float* ref_feature, const float* const* src_features
     for (int k = 0; k < 9; ++k) a.rot[v][k] = rot_trans[12 * v + k];      // HOST array: 9 rot + 3 trans per source
     for (int k = 0; k < 3; ++k) a.trans[v][k] = rot_trans[12 * v + 9 + k];
   }
-  dim3 grid((W + 255) / 256, H, D), block(256);
-  if (W <= 64) { block.x = 64; grid.x = (W + 63) / 64; } else if (W <= 128) { block.x = 128; grid.x = (W + 127) / 128; }
+  if (C != 8 && C != 16 && C != 32) { set_error("svs_warp_variance: C must be 8, 16 or 32 (FeatureNet outputs)"); return SVS_ESHAPE; }
   hipStream_t s = (hipStream_t)hip_stream;
-  if (C == 8) warp_variance_kernel<8><<<grid, block, 0, s>>>(a);
-  else if (C == 16) warp_variance_kernel<16><<<grid, block, 0, s>>>(a);
-  else if (C == 32) warp_variance_kernel<32><<<grid, block, 0, s>>>(a);
-  else { set_error("svs_warp_variance: C must be 8, 16 or 32 (FeatureNet outputs)"); return SVS_ESHAPE; }
+  if (C == 8) launch_warp<8>(a, s);
+  else if (C == 16) launch_warp<16>(a, s);
+  else launch_warp<32>(a, s);
   return check_launch("svs_warp_variance");
 }
 

@@ -204,7 +204,7 @@ class CascadeMVSNet(nn.Module):
         if depth is None:
             depth = outputs['depth'] if stage_idx > 0 else None
         outputs = {} if outputs is None else outputs
-        dv = depth_values[0].detach().float().cpu()
+        dv = costvol.host_copy(depth_values)[0]
         depth_min, depth_max = float(dv[0]), float(dv[-1])
         depth_interval = (depth_max - depth_min) / depth_values.size(1)
         H_img, W_img = imgs.shape[-2], imgs.shape[-1]

@@ -9,15 +9,43 @@ from .ops import _f32, _ptr, _ptr_array, _stream
 
 
 def relative_projection(src_proj, ref_proj):
-    """models/CasMVSNet.py:622-625 and :290-292 on the host, in float64: proj (2,4,4) tensors ->
+    """models/CasMVSNet.py:622-625 and :290-292 on the host, in float64: proj (2,4,4) arrays / tensors ->
     12 floats: rows of (src @ inv(ref))[:3,:3] then [:3,3]."""
     def comb(P):
-        P = np.asarray(P.detach().cpu(), np.float64)
+        P = np.asarray(P.detach().cpu() if torch.is_tensor(P) else P, np.float64)
         out = P[0].copy()
         out[:3, :4] = P[1][:3, :3] @ P[0][:3, :4]
         return out
     rel = comb(src_proj) @ np.linalg.inv(comb(ref_proj))
     return list(rel[:3, :3].reshape(-1)) + list(rel[:3, 3])
+
+
+_HOST_CACHE = {}
+
+
+def host_copy(t):
+    """numpy copy of a small device tensor whose VALUES are launch arguments (projection matrices, the depth range):
+    one device-to-host copy per distinct tensor, cached on storage + version -- the sample of a scan is the same
+    tensor in every stage and every stage-loop iteration, so the stage loop runs without host synchronisation."""
+    key = (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), str(t.device), t.dtype)
+    hit = _HOST_CACHE.get(key)
+    if hit is None:
+        if len(_HOST_CACHE) >= 64:
+            _HOST_CACHE.clear()
+        # the entry keeps the tensor alive: its storage cannot be handed to another tensor while the key exists
+        hit = _HOST_CACHE[key] = (t, t.detach().cpu().numpy())
+    return hit[1]
+
+
+def _rot_trans(proj_matrices):
+    """(1,V,2,4,4) projection matrices -> ctypes float[12*(V-1)] for svs_warp_variance (host launch arguments)."""
+    P = host_copy(proj_matrices)[0]
+    n_src = P.shape[0] - 1
+    rt = (ctypes.c_float * (12 * n_src))()
+    for v in range(n_src):
+        for k, x in enumerate(relative_projection(P[v + 1], P[0])):
+            rt[12 * v + k] = float(x)
+    return rt
 
 
 def warp_variance(features, proj_matrices, depth_values):
@@ -34,10 +62,7 @@ def warp_variance(features, proj_matrices, depth_values):
         o = torch.empty(H, W, C, device=dev)
         _lib.check(L.svs_chw_to_hwc(_ptr(_f32(f[0])), _ptr(o), C, H, W, _stream()), "svs_chw_to_hwc")
         hwc.append(o)
-    rt = (ctypes.c_float * (12 * n_src))()
-    for v in range(n_src):
-        for k, x in enumerate(relative_projection(proj_matrices[0, v + 1], proj_matrices[0, 0])):
-            rt[12 * v + k] = float(x)
+    rt = _rot_trans(proj_matrices)
     var = torch.empty(1, C, D, H, W, device=dev)
     dv = _f32(depth_values[0])
     _lib.check(L.svs_warp_variance(_ptr(ref), _ptr_array(hwc), rt, n_src, C, D, H, W, _ptr(dv), _ptr(var), 0, _stream()),

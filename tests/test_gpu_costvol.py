@@ -94,6 +94,38 @@ def test_three_stage_forward_golden(dev, golden_dir):
             outputs["depth"] = ov
 
 
+@pytest.mark.parametrize("C,n_views,D,hw", [(32, 3, 5, (21, 37)), (16, 2, 70, (13, 36)), (8, 5, 6, (10, 131)),
+                                             (32, 4, 9, (6, 200)), (16, 3, 3, (5, 330))])
+def test_warp_variance_ragged(dev, C, n_views, D, hw):
+    """Fused warp + variance on shapes that exercise every tail of the tiled kernel (widths that are neither a
+    multiple of 4 nor of the x tile, depth counts that do not fill the planes-per-workgroup loop, 1..4 source
+    views, several x tiles per row) against the oracle's per-view homo_warp + variance."""
+    from svs_hip import costvol
+    rng = np.random.default_rng(C + D)
+    H, W = hw
+    feats = [rng.normal(0, 1, (C, H, W)).astype(F32) for _ in range(n_views)]
+    projs = np.zeros((n_views, 2, 4, 4), F32)
+    for v in range(n_views):
+        ext = np.eye(4, dtype=F32)
+        ang = 0.03 * v
+        ext[:3, :3] = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], F32)
+        ext[0, 3], ext[1, 3] = 12.0 * v * (-1) ** v, 2.0 * v
+        K = np.eye(4, dtype=F32)
+        K[0, 0] = K[1, 1] = 1.5 * W
+        K[0, 2], K[1, 2] = W / 2.0, H / 2.0
+        projs[v, 0], projs[v, 1] = ext, K
+    dv = np.broadcast_to((400.0 + 7.0 * np.arange(D, dtype=F32))[:, None, None], (D, H, W)).copy()
+    dv += rng.uniform(0, 3, dv.shape).astype(F32)
+    got = costvol.warp_variance([G(f, dev)[None] for f in feats], G(projs, dev)[None], G(dv, dev)[None])[0].cpu().numpy()
+    ref = corc.variance_volume(feats, projs, dv)
+    # white-noise features are the worst case for the sampling position: at |coordinate| ~ 300 px the float32
+    # rounding of rot @ [x,y,1] * depth (numpy's matmul order vs the kernel's) moves a sample by ~3e-5 px and the
+    # features change by O(1) per pixel
+    np.testing.assert_allclose(got, ref, atol=5e-4)
+    assert np.abs(got - ref).mean() < 5e-6
+    assert np.abs(ref).max() > 0.1
+
+
 @pytest.mark.parametrize("cin,shape", [(32, (16, 16, 24)), (16, (8, 24, 16)), (8, (8, 8, 8))])
 def test_costreg_vs_torch_reference(dev, cin, shape):
     """3-D U-Net on random volumes (incl. non-cubic shapes) against the plain torch float32 reference."""
