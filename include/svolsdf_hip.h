@@ -17,6 +17,7 @@
 #define SVOLSDF_HIP_H
 
 #include <stddef.h>
+#include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -304,6 +305,27 @@ int svs_prob_depth_conf(const float* reg, const float* depth_values, int D, int 
  * (Hp,Wp) -> +-(D/2)*pix_interval around its bilinear resize to the image, resized to (D, H_img/scale, W_img/scale). */
 int svs_depth_hypotheses(const float* prev_depth, int Hp, int Wp, int H_img, int W_img, int D, int scale, float dmin,
                          float dmax, float pix_interval, int inverse, float* out, void* hip_stream);
+
+/* ---- f3  depth-map fusion (helpers/utils.py:75-132, runner.py:301-386) -------------------------------------------
+ * svs_fuse_view: reproject_with_depth + check_geometric_consistency of ONE reference view against n_src <= 16 source
+ * views, then the aggregation of filter_depth: geo_mask_sum, depth_est_averaged = (sum of the masked reprojected
+ * depths + ref depth) / (geo_mask_sum + 1) (float64, as numpy promotes it), photo_mask = confidence > conf,
+ * geo_mask = geo_mask_sum >= thres_view, final = photo & geo [& extra_mask].
+ * mats: DEVICE float64, svs_fuse_mats_per_src() = 68 per source view, row-major:
+ *   inv(K_ref) (9), E_src @ inv(E_ref) (16), K_src (9), inv(K_src) (9), E_ref @ inv(E_src) (16), K_ref (9)
+ *   -- formed by the host in float32 exactly as the reference forms them, then widened.
+ * The source depth is sampled like cv2.remap(INTER_LINEAR, BORDER_CONSTANT 0): 5-bit fixed-point coordinates.
+ * Optional per-source outputs (all four or none, (n_src,H,W)): the tuple check_geometric_consistency returns.
+ * svs_fuse_points: the surviving pixels in row-major order -> world xyz float32 (count,3) and, if ref_img (H,W,3
+ * float32 in [0,1]) is given, uint8 colours (count,3) = trunc(img * 255).  mats: inv(K_ref) (9), inv(E_ref) (16).
+ * offset_ws: H*W ints; xyz / rgb sized for H*W points; *count (device int) receives the number written. */
+int svs_fuse_mats_per_src(void);
+int svs_fuse_view(const float* ref_depth, const float* confidence, const float* const* src_depths, const double* mats,
+                  int n_src, int H, int W, float conf, double filter_dist, float filter_diff, int thres_view,
+                  const uint8_t* extra_mask, double* depth_avg, uint8_t* photo_mask, uint8_t* geo_mask, uint8_t* final_mask,
+                  uint8_t* src_mask, float* src_depth_reproj, float* src_x, float* src_y, void* hip_stream);
+int svs_fuse_points(const double* depth_avg, const uint8_t* final_mask, const float* ref_img, const double* mats, int H, int W,
+                    int* offset_ws, float* xyz, uint8_t* rgb, int* count, void* hip_stream);
 
 /* ---- numeric-contract self tests (used by tests/test_gpu_parity.py) --------------------------------------- */
 int svs_selftest_exp(const float* x, float* y_exp, float* y_expm1, int n, void* hip_stream);

@@ -4,7 +4,7 @@ The product path has NO CPU fallback: if the library is missing or a call fails,
 """
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsvolsdf_hip.so")
@@ -86,6 +86,10 @@ SIGNATURES = {
                          c_float, c_int, c_float, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "svs_loss_workspace_bytes": (c_size_t, [c_int, c_int]),
     "svs_chw_to_hwc": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "svs_fuse_mats_per_src": (c_int, []),
+    "svs_fuse_view": (c_int, [_P, _P, _PP, _P, c_int, c_int, c_int, c_float, c_double, c_float, c_int, _P, _P, _P, _P, _P,
+                              _P, _P, _P, _P, _P]),
+    "svs_fuse_points": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
     "svs_warp_variance": (c_int, [_P, _PP, POINTER(c_float), c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P]),
     "svs_conv3d": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "svs_conv3d_mfma_wfrag_bytes": (c_size_t, [c_int]),

@@ -551,7 +551,52 @@ def fx_train_step_bg():
     save("train_step_bg", **arr)
 
 
-ALL = dict(rays=fx_rays, sdf_mlp=fx_sdf_mlp, rgb_mlp=fx_rgb_mlp, density=fx_density, sampler=fx_sampler,
+def fx_fusion():
+    """helpers/utils.py check_geometric_consistency of the reference on a synthetic 3-view scene.  cv2 is not
+    installed: the reference's single cv2 call (cv2.remap, INTER_LINEAR) is bound to the oracle's restatement
+    `fusion_oracle.remap_linear`, so this fixture pins the reference's geometry, masks and type promotions GIVEN that
+    sampler; the sampler itself stays unpinned (oracle/fusion_oracle.py header)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle"))
+    import fusion_oracle
+    import cv2
+    cv2.INTER_LINEAR = 1
+    cv2.remap = lambda src, mx, my, interpolation: fusion_oracle.remap_linear(src, mx, my)
+    if not hasattr(np, "bool"):
+        np.bool = np.bool_
+    from helpers.utils import check_geometric_consistency
+    arr = {"seed": np.asarray(21), "hw": np.asarray((40, 56))}
+    views = synth.make_fusion_views(21, hw=(40, 56), n_views=3)
+    for ref, src in ((0, 1), (0, 2), (1, 2), (2, 0)):
+        for fd, fr in ((1, 0.01), (0.5, 0.003)):
+            m, d, x, y = check_geometric_consistency(views[ref]["depth"], views[ref]["K"], views[ref]["E"],
+                                                     views[src]["depth"], views[src]["K"], views[src]["E"], fd, fr)
+            tag = f"r{ref}s{src}_{fd}_{fr}"
+            arr[tag + "/mask"], arr[tag + "/depth"], arr[tag + "/x"], arr[tag + "/y"] = m, d, x, y
+    save("fusion_geo", **arr)
+
+
+def fx_pfm():
+    """datasets/data_io.py save_pfm / read_pfm of the reference: the bytes it writes for a grey and a colour image and
+    what it reads back."""
+    import tempfile
+    from datasets.data_io import read_pfm, save_pfm
+    rng = np.random.default_rng(4)
+    arr = {}
+    with tempfile.TemporaryDirectory() as td:
+        for tag, img, scale in (("grey", rng.normal(0, 100, (5, 7)).astype(F32), 1), ("colour", rng.uniform(0, 1, (4, 6, 3)).astype(F32), 2.5),
+                                ("hw1", rng.normal(0, 1, (3, 2, 1)).astype(F32), 1)):
+            fn = os.path.join(td, tag + ".pfm")
+            save_pfm(fn, img, scale)
+            arr[tag + "/image"] = img
+            arr[tag + "/scale"] = np.asarray(float(scale))
+            arr[tag + "/bytes"] = np.frombuffer(open(fn, "rb").read(), np.uint8)
+            if tag != "hw1":                      # the reference cannot read back its own (H,W,1) files as (H,W,1)
+                back, sc = read_pfm(fn)
+                arr[tag + "/read"], arr[tag + "/read_scale"] = np.ascontiguousarray(back), np.asarray(float(sc))
+    save("pfm_codec", **arr)
+
+
+ALL = dict(fusion=fx_fusion, pfm=fx_pfm, rays=fx_rays, sdf_mlp=fx_sdf_mlp, rgb_mlp=fx_rgb_mlp, density=fx_density, sampler=fx_sampler,
            composite=fx_composite, forward=fx_forward, forward_bg=fx_forward_bg, cost_mapping=fx_cost_mapping, loss=fx_loss, casmvs=fx_casmvs, train_step=fx_train_step,
            train_step_bg=fx_train_step_bg)
 

@@ -231,3 +231,37 @@ def rows_to_tiles(x):
     idx = ((i[None, :] // 4) * 64 + lane) * 4 + (i[None, :] % 4)
     out[wt[:, None].repeat(Fdim, 1), idx] = x
     return out
+
+
+def make_fusion_views(seed, hw=(48, 64), n_views=3, noise=2e-3):
+    """Synthetic input of the depth-fusion filter (runner.py:301-332): n_views cameras on an arc looking at a unit
+    sphere in front of a plane; per view K (3,3), E (4,4) world->camera (float32, as read_camera_parameters returns),
+    the analytic z-depth map with multiplicative noise, a few zero holes and outliers, a confidence map and an image."""
+    rng = np.random.default_rng(seed)
+    H, W = hw
+    views = {}
+    for v in range(n_views):
+        ang = 0.25 * (v - (n_views - 1) / 2.0)
+        R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], np.float64)
+        c = np.array([3.2 * np.sin(ang), 0.1 * v, -3.2 * np.cos(ang)])            # camera centre, looking at the origin
+        E = np.eye(4)
+        E[:3, :3], E[:3, 3] = R, -R @ c
+        K = np.array([[1.1 * W, 0.3, W / 2.0 + 0.5 * v], [0, 1.1 * W, H / 2.0 - 0.25 * v], [0, 0, 1]], np.float64)
+        u, w_ = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+        d_cam = np.linalg.inv(K) @ np.stack([u.ravel(), w_.ravel(), np.ones(H * W)])
+        d_w = R.T @ d_cam                                                         # (3, HW), z_cam = 1 per unit t
+        b = (d_w * c[:, None]).sum(0)
+        a = (d_w * d_w).sum(0)
+        disc = b * b - a * (c @ c - 1.0)
+        t_sph = np.where(disc > 0, (-b - np.sqrt(np.maximum(disc, 0))) / a, np.inf)
+        t_pl = (1.5 - c[2]) / d_w[2]                                              # plane z_world = 1.5 behind the sphere
+        depth = np.minimum(t_sph, t_pl).reshape(H, W)
+        depth = depth * (1.0 + noise * rng.normal(0, 1, (H, W)))
+        holes = rng.uniform(0, 1, (H, W)) < 0.02
+        depth[holes] = 0.0
+        outl = rng.uniform(0, 1, (H, W)) < 0.03
+        depth[outl] *= rng.uniform(0.8, 1.25, outl.sum())
+        views[v] = dict(K=K.astype(F32), E=E.astype(F32), depth=depth.astype(F32),
+                        confidence=rng.uniform(0, 1, (H, W)).astype(F32),
+                        img=(rng.integers(0, 256, (H, W, 3)).astype(F32) / F32(255.)))
+    return views
