@@ -327,6 +327,37 @@ int svs_fuse_view(const float* ref_depth, const float* confidence, const float* 
 int svs_fuse_points(const double* depth_avg, const uint8_t* final_mask, const float* ref_img, const double* mats, int H, int W,
                     int* offset_ws, float* xyz, uint8_t* rgb, int* count, void* hip_stream);
 
+/* ---- f4  Chamfer evaluator on point clouds (evals/eval_dtu.py:100-176) ---------------------------------------------
+ * All clouds are (n,3) float64 (what open3d hands the reference).  One structure serves both neighbour problems:
+ * points sorted by uniform-grid cell + a hash from cell to its run; grid_ws: svs_cloud_grid_bytes(n_points of the
+ * cloud the grid is built over); origin: HOST double[3], <= every coordinate of both clouds, (max - origin)/cell < 2^21.
+ * svs_cloud_nn: sklearn NearestNeighbors(n_neighbors=1).fit(ref).kneighbors(query) (:150-152,:174-175): dist
+ *   (float64, same arithmetic as the kd-tree) and idx (may be NULL).  Exact for neighbours closer than max_radius;
+ *   a result >= max_radius is an upper bound (+inf / -1 if none met) -- the protocol drops distances >= max_dist.
+ * svs_cloud_downsample_*: the greedy radius down-sampling (:104-118) = the lexicographically-first maximal
+ *   independent set of the radius graph in index order.  _begin builds the grid (cell = radius) and clears state;
+ *   every _round settles more points (state: 0 undecided, 1 kept, 2 dropped; *undecided = points still open after
+ *   the round); repeat until *undecided == 0.
+ * svs_cloud_obs_filter: bounding-box-plus-patch test and ObsMask lookup (:124-135).  bb: HOST float[6] (BB rows),
+ *   obs_mask: uint8 (d0,d1,d2) C order.  inbound[i] = inside the padded box; in_obs[i] = inbound & grid-inbound & mask.
+ * svs_cloud_plane_side: (P . [x,y,z,1]) > 0 (:165-167), plane: HOST double[4].
+ * svs_cloud_compact: rows with mask != 0, order kept; offset_ws: n ints; *count (device int).
+ * svs_cloud_mean_below: mean of dist[dist < max_dist] (:153,:176) -> mean_count[0], and the number of terms
+ *   -> mean_count[1]; deterministic two-level sum.  workspace: svs_cloud_mean_workspace_bytes(). */
+size_t svs_cloud_grid_bytes(int n_points);
+int svs_cloud_nn(const double* ref, int n_ref, const double* query, int n_query, const double* origin, double cell,
+                 double max_radius, void* grid_ws, double* dist, int* idx, void* hip_stream);
+int svs_cloud_downsample_begin(const double* pts, int n, const double* origin, double radius, void* grid_ws, uint8_t* state,
+                               void* hip_stream);
+int svs_cloud_downsample_round(const double* origin, int n, double radius, void* grid_ws, uint8_t* state, int* undecided,
+                               void* hip_stream);
+int svs_cloud_obs_filter(const double* pts, int n, const float* bb, double res, double patch, const uint8_t* obs_mask,
+                         int d0, int d1, int d2, uint8_t* inbound, uint8_t* in_obs, void* hip_stream);
+int svs_cloud_plane_side(const double* pts, int n, const double* plane, uint8_t* above, void* hip_stream);
+int svs_cloud_compact(const double* pts, const uint8_t* mask, int n, int* offset_ws, double* out, int* count, void* hip_stream);
+size_t svs_cloud_mean_workspace_bytes(void);
+int svs_cloud_mean_below(const double* dist, int n, double max_dist, double* workspace, double* mean_count, void* hip_stream);
+
 /* ---- numeric-contract self tests (used by tests/test_gpu_parity.py) --------------------------------------- */
 int svs_selftest_exp(const float* x, float* y_exp, float* y_expm1, int n, void* hip_stream);
 int svs_selftest_arith(const float* a, const float* b, float* quotient, float* sqrt_abs_a, int n, void* hip_stream);

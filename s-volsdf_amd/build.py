@@ -33,6 +33,7 @@ UNITS = {
     "svs_mlp_bwd_h2.hip": [],
     "svs_optim.hip": ["-ffp-contract=off"],
     "svs_fusion.hip": ["-ffp-contract=off"],
+    "svs_cloud.hip": ["-ffp-contract=off"],
 }
 BASE_FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
               "-x", "hip"]

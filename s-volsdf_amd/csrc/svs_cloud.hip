@@ -1,0 +1,419 @@
+// Point-cloud kernels of the Chamfer evaluator for gfx950.
+//
+// Reference: evals/eval_dtu.py:100-176 -- the DTU evaluation protocol: greedy radius down-sampling of the predicted
+// cloud, observation-mask / bounding-box filtering, and the two nearest-neighbour passes (data -> STL accuracy,
+// STL -> data completeness) that the reference runs through sklearn's kd-tree on the CPU.
+//
+// Here both neighbour problems use one structure: points sorted by the key of their cell in a uniform grid
+// (rocPRIM radix sort -- the only library call) plus an open-addressing hash from cell key to the [begin, end) run
+// in the sorted order.  Neighbour candidates are the runs of the cells around the query, scanned in float64 with
+// the kd-tree's arithmetic (dx*dx + dy*dy + dz*dz, no fused multiply-add), so distances agree with sklearn's to the
+// last bit.  This is latency / HBM-bound gather work: no matrix cores.
+#include <hipcub/hipcub.hpp>
+
+#include "svs_common.h"
+
+namespace svs {
+namespace cloud {
+
+typedef unsigned long long u64;
+constexpr u64 kEmpty = ~0ull;
+constexpr int kCellBits = 21;                     // per-axis cell index range [0, 2^21)
+
+struct Grid {
+  double ox, oy, oz, inv_h, h;                    // cell = floor((p - origin) * inv_h)
+  const double* pts;                              // (n,3) points in SORTED order
+  const unsigned* perm;                           // sorted position -> original index
+  const u64* hkey;                                // hash table (capacity = mask + 1)
+  const uint2* hrun;                              //   [begin, end) of the cell's run
+  unsigned mask;
+  int n;
+};
+
+__device__ __forceinline__ int cell_coord(double p, double o, double inv_h) {
+  const double c = __builtin_floor((p - o) * inv_h);
+  return c < 0.0 ? 0 : (c > (double)((1 << kCellBits) - 1) ? (1 << kCellBits) - 1 : (int)c);
+}
+__device__ __forceinline__ u64 cell_key(int ix, int iy, int iz) {
+  return (u64)ix | ((u64)iy << kCellBits) | ((u64)iz << (2 * kCellBits));
+}
+__device__ __forceinline__ unsigned hash_slot(u64 k, unsigned mask) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+  return (unsigned)k & mask;
+}
+__device__ __forceinline__ uint2 find_run(const Grid& g, int ix, int iy, int iz) {
+  if ((unsigned)ix >= (1u << kCellBits) || (unsigned)iy >= (1u << kCellBits) || (unsigned)iz >= (1u << kCellBits)) return make_uint2(0, 0);
+  const u64 k = cell_key(ix, iy, iz);
+  unsigned s = hash_slot(k, g.mask);
+  while (true) {
+    const u64 hk = g.hkey[s];
+    if (hk == k) return g.hrun[s];
+    if (hk == kEmpty) return make_uint2(0, 0);
+    s = (s + 1) & g.mask;
+  }
+}
+
+__global__ void keys_kernel(const double* __restrict__ pts, int n, double ox, double oy, double oz, double inv_h,
+                            u64* __restrict__ keys, unsigned* __restrict__ idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  keys[i] = cell_key(cell_coord(pts[3 * (size_t)i], ox, inv_h), cell_coord(pts[3 * (size_t)i + 1], oy, inv_h),
+                     cell_coord(pts[3 * (size_t)i + 2], oz, inv_h));
+  idx[i] = (unsigned)i;
+}
+
+__global__ void clear_hash_kernel(u64* hkey, unsigned cap) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cap) hkey[i] = kEmpty;
+}
+
+// heads of runs insert (key -> begin); gather the points into sorted order on the way
+__global__ void heads_kernel(const u64* __restrict__ skeys, const unsigned* __restrict__ sidx, const double* __restrict__ pts, int n,
+                             u64* hkey, uint2* hrun, unsigned mask, double* __restrict__ spts) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t o = 3 * (size_t)sidx[i];
+  spts[3 * (size_t)i] = pts[o]; spts[3 * (size_t)i + 1] = pts[o + 1]; spts[3 * (size_t)i + 2] = pts[o + 2];
+  const u64 k = skeys[i];
+  if (i > 0 && skeys[i - 1] == k) return;
+  unsigned s = hash_slot(k, mask);
+  while (true) {
+    const u64 prev = atomicCAS(&hkey[s], kEmpty, k);
+    if (prev == kEmpty) { hrun[s].x = (unsigned)i; return; }
+    s = (s + 1) & mask;                            // keys are distinct among heads: never prev == k
+  }
+}
+
+__global__ void tails_kernel(const u64* __restrict__ skeys, int n, const u64* __restrict__ hkey, uint2* hrun, unsigned mask) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64 k = skeys[i];
+  if (i + 1 < n && skeys[i + 1] == k) return;
+  unsigned s = hash_slot(k, mask);
+  while (hkey[s] != k) s = (s + 1) & mask;
+  hrun[s].y = (unsigned)(i + 1);
+}
+
+// ---- nearest neighbour (sklearn NearestNeighbors(n_neighbors=1).kneighbors, eval_dtu.py:150-152,174-175) -------------------
+// Rings of cells around the query's cell, outwards, until the best distance is no larger than the distance to anything
+// not yet scanned (ring * h + the margin to the query's own cell walls).  The search stops after max_ring rings: a
+// neighbour closer than max_radius is always found exactly; a result >= max_radius is only an upper bound of the true
+// distance (+inf, idx = -1 if nothing was met) -- the evaluator discards distances >= max_dist.  Ties go to the lower
+// original index.
+__global__ __launch_bounds__(256) void nn_kernel(Grid g, const double* __restrict__ q, int nq, int max_ring, double* __restrict__ dist,
+                                                 int* __restrict__ nn_idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  const double x = q[3 * (size_t)i], y = q[3 * (size_t)i + 1], z = q[3 * (size_t)i + 2];
+  const int cx = cell_coord(x, g.ox, g.inv_h), cy = cell_coord(y, g.oy, g.inv_h), cz = cell_coord(z, g.oz, g.inv_h);
+  // margin to the walls of the (clamped) home cell; negative if the query lies outside the grid's box
+  double margin = 1e300;
+  {
+    const double fx = (x - g.ox) * g.inv_h - (double)cx, fy = (y - g.oy) * g.inv_h - (double)cy, fz = (z - g.oz) * g.inv_h - (double)cz;
+    const double m[6] = {fx, 1.0 - fx, fy, 1.0 - fy, fz, 1.0 - fz};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) margin = m[k] < margin ? m[k] : margin;
+    margin *= g.h;
+  }
+  double best = 1e300;
+  unsigned best_idx = 0xffffffffu;
+  for (int r = 0; r <= max_ring; ++r) {
+    for (int dz = -r; dz <= r; ++dz)
+      for (int dy = -r; dy <= r; ++dy) {
+        const bool face = dz == -r || dz == r || dy == -r || dy == r;
+        const int step = face ? 1 : (2 * r > 0 ? 2 * r : 1);           // interior rows of the shell: only the two x ends
+        for (int dx = -r; dx <= r; dx += step) {
+          const uint2 run = find_run(g, cx + dx, cy + dy, cz + dz);
+          for (unsigned j = run.x; j < run.y; ++j) {
+            const double ex = g.pts[3 * (size_t)j] - x, ey = g.pts[3 * (size_t)j + 1] - y, ez = g.pts[3 * (size_t)j + 2] - z;
+            const double d2 = ex * ex + ey * ey + ez * ez;
+            const unsigned oj = g.perm[j];
+            if (d2 < best || (d2 == best && oj < best_idx)) { best = d2; best_idx = oj; }
+          }
+        }
+      }
+    const double safe = (double)r * g.h + margin;
+    if (best_idx != 0xffffffffu && (safe > 0.0 && best <= safe * safe)) break;
+  }
+  dist[i] = best_idx == 0xffffffffu ? __builtin_inf() : __builtin_sqrt(best);
+  if (nn_idx) nn_idx[i] = best_idx == 0xffffffffu ? -1 : (int)best_idx;
+}
+
+// ---- greedy radius down-sampling (eval_dtu.py:104-118) -------------------------------------------------------------------------
+// The reference walks the points in index order: a point still alive is kept and kills every point within the
+// radius.  That is the lexicographically-first maximal independent set of the radius graph, computed here in
+// parallel rounds: a point is KEPT once every lower-index neighbour is DROPPED, DROPPED as soon as a lower-index
+// neighbour is KEPT.  The grid's cell size is the radius, so the 27 surrounding cells hold every neighbour.
+// state: 0 undecided, 1 kept, 2 dropped (indexed by ORIGINAL index).  Reads of other points' states may be stale
+// within a round; decisions are monotone, so a stale read only postpones a decision.
+__global__ __launch_bounds__(256) void mis_round_kernel(Grid g, double r2, uint8_t* state, int* undecided) {
+  const int j0 = blockIdx.x * blockDim.x + threadIdx.x;          // sorted position
+  if (j0 >= g.n) return;
+  const unsigned me = g.perm[j0];
+  if (state[me] != 0) return;
+  const double x = g.pts[3 * (size_t)j0], y = g.pts[3 * (size_t)j0 + 1], z = g.pts[3 * (size_t)j0 + 2];
+  const int cx = cell_coord(x, g.ox, g.inv_h), cy = cell_coord(y, g.oy, g.inv_h), cz = cell_coord(z, g.oz, g.inv_h);
+  bool blocked = false;
+  for (int dz = -1; dz <= 1; ++dz)
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        const uint2 run = find_run(g, cx + dx, cy + dy, cz + dz);
+        for (unsigned j = run.x; j < run.y; ++j) {
+          const unsigned oj = g.perm[j];
+          if (oj >= me) continue;
+          const double ex = g.pts[3 * (size_t)j] - x, ey = g.pts[3 * (size_t)j + 1] - y, ez = g.pts[3 * (size_t)j + 2] - z;
+          if (ex * ex + ey * ey + ez * ez > r2) continue;
+          const uint8_t s = __atomic_load_n(&state[oj], __ATOMIC_RELAXED);
+          if (s == 1) { __atomic_store_n(&state[me], (uint8_t)2, __ATOMIC_RELAXED); return; }
+          if (s == 0) blocked = true;
+        }
+      }
+  if (blocked) { atomicAdd(undecided, 1); return; }
+  __atomic_store_n(&state[me], (uint8_t)1, __ATOMIC_RELAXED);
+}
+
+// ---- observation-mask / bounding-box / plane tests (eval_dtu.py:120-135,165-168) -------------------------------------------
+struct ObsArgs {
+  const double* pts; int n;
+  double bb_lo[3];                // BB[0] (float32 in the .mat, widened)
+  double lo_thr[3], hi_thr[3];    // BB[0] - patch, BB[1] + 2 * patch, evaluated in float32 as numpy does
+  double res;
+  const uint8_t* obs; int dims[3]; // ObsMask, C order [i][j][k]
+  uint8_t *inbound, *in_obs;
+};
+__global__ void obs_filter_kernel(ObsArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  bool in = true, gin = true;
+  int gi[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double p = a.pts[3 * (size_t)i + k];
+    in = in && p >= a.lo_thr[k] && p < a.hi_thr[k];
+    const double gr = __builtin_rint((p - a.bb_lo[k]) / a.res);          // np.around: half to even
+    gin = gin && gr >= 0.0 && gr < (double)a.dims[k];
+    gi[k] = gin ? (int)gr : 0;
+  }
+  a.inbound[i] = in ? 1 : 0;
+  a.in_obs[i] = (in && gin && a.obs[((size_t)gi[0] * a.dims[1] + gi[1]) * a.dims[2] + gi[2]] != 0) ? 1 : 0;
+}
+
+__global__ void plane_side_kernel(const double* __restrict__ pts, int n, double p0, double p1, double p2, double p3, uint8_t* above) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // (P * [x,y,z,1]).sum(-1) > 0, summed left to right
+  above[i] = (((p0 * pts[3 * (size_t)i] + p1 * pts[3 * (size_t)i + 1]) + p2 * pts[3 * (size_t)i + 2]) + p3 * 1.0) > 0.0 ? 1 : 0;
+}
+
+// ---- ordered compaction of (n,3) float64 rows ------------------------------------------------------------------------------------
+constexpr int kScanThreads = 1024;
+__global__ __launch_bounds__(kScanThreads) void rows_scan_kernel(const uint8_t* __restrict__ mask, int n, int* __restrict__ offset,
+                                                                 int* __restrict__ count) {
+  __shared__ int part[kScanThreads];
+  const int t = threadIdx.x;
+  const int per = (n + kScanThreads - 1) / kScanThreads;
+  const long long lo_ = (long long)t * per;
+  const int lo = lo_ < n ? (int)lo_ : n, hi = lo_ + per < n ? (int)(lo_ + per) : n;
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += mask[i] != 0;
+  part[t] = s;
+  __syncthreads();
+  for (int d = 1; d < kScanThreads; d <<= 1) {
+    const int v = t >= d ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - s;
+  for (int i = lo; i < hi; ++i) { offset[i] = run; run += mask[i] != 0; }
+  if (t == kScanThreads - 1) *count = part[t];
+}
+__global__ void rows_scatter_kernel(const double* __restrict__ pts, const uint8_t* __restrict__ mask, const int* __restrict__ offset,
+                                    int n, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !mask[i]) return;
+  const size_t o = 3 * (size_t)offset[i];
+  out[o] = pts[3 * (size_t)i]; out[o + 1] = pts[3 * (size_t)i + 1]; out[o + 2] = pts[3 * (size_t)i + 2];
+}
+
+// ---- mean of the distances below the cut-off (eval_dtu.py:153,176), deterministic two-level sum ---------------------------
+constexpr int kMeanBlocks = 256;
+__global__ __launch_bounds__(256) void mean_partial_kernel(const double* __restrict__ d, int n, double max_dist, double* __restrict__ part) {
+  __shared__ double ss[256], sc[256];
+  double s = 0.0, c = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)kMeanBlocks * 256) {
+    const double v = d[i];
+    if (v < max_dist) { s += v; c += 1.0; }
+  }
+  ss[threadIdx.x] = s; sc[threadIdx.x] = c;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) { ss[threadIdx.x] += ss[threadIdx.x + k]; sc[threadIdx.x] += sc[threadIdx.x + k]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part[2 * blockIdx.x] = ss[0]; part[2 * blockIdx.x + 1] = sc[0]; }
+}
+__global__ void mean_final_kernel(const double* __restrict__ part, double* __restrict__ out) {
+  double s = 0.0, c = 0.0;
+  for (int b = 0; b < kMeanBlocks; ++b) { s += part[2 * b]; c += part[2 * b + 1]; }
+  out[0] = s / c;                                  // 0/0 -> nan, numpy's mean of an empty selection
+  out[1] = c;
+}
+
+}  // namespace cloud
+}  // namespace svs
+
+using namespace svs;
+using namespace svs::cloud;
+
+namespace {
+
+struct GridLayout {            // carve-up of the caller's workspace
+  size_t keys, skeys, idx, sidx, spts, hkey, hrun, sort_tmp, total;
+  unsigned cap;
+  size_t sort_bytes;
+};
+
+unsigned pow2_at_least(size_t v) { unsigned c = 16; while (c < v) c <<= 1; return c; }
+
+GridLayout grid_layout(int n) {
+  GridLayout L;
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  L.cap = pow2_at_least(2 * (size_t)(n > 0 ? n : 1));
+  L.sort_bytes = 0;
+  hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, L.sort_bytes, (const u64*)nullptr, (u64*)nullptr, (const unsigned*)nullptr,
+                                                    (unsigned*)nullptr, n > 0 ? n : 1, 0, 3 * kCellBits, (hipStream_t)0);
+  if (e != hipSuccess) { (void)hipGetLastError(); L.sort_bytes = 0; }
+  // never below a double buffer of the pairs: the size query needs a device, this bound does not
+  const size_t floor_bytes = 16 * (size_t)(n > 0 ? n : 1) + ((size_t)1 << 20);
+  if (L.sort_bytes < floor_bytes) L.sort_bytes = floor_bytes;
+  size_t o = 0;
+  L.keys = o; o += al(sizeof(u64) * (size_t)n);
+  L.skeys = o; o += al(sizeof(u64) * (size_t)n);
+  L.idx = o; o += al(sizeof(unsigned) * (size_t)n);
+  L.sidx = o; o += al(sizeof(unsigned) * (size_t)n);
+  L.spts = o; o += al(sizeof(double) * 3 * (size_t)n);
+  L.hkey = o; o += al(sizeof(u64) * (size_t)L.cap);
+  L.hrun = o; o += al(sizeof(uint2) * (size_t)L.cap);
+  L.sort_tmp = o; o += al(L.sort_bytes);
+  L.total = o + 256;
+  return L;
+}
+
+// Builds the grid of `pts` in `ws`; returns the device-side view.
+int build_grid(const double* pts, int n, const double* origin, double h, void* ws, hipStream_t s, Grid* g) {
+  const GridLayout L = grid_layout(n);
+  char* base = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  u64* keys = (u64*)(base + L.keys); u64* skeys = (u64*)(base + L.skeys);
+  unsigned* idx = (unsigned*)(base + L.idx); unsigned* sidx = (unsigned*)(base + L.sidx);
+  double* spts = (double*)(base + L.spts);
+  u64* hkey = (u64*)(base + L.hkey); uint2* hrun = (uint2*)(base + L.hrun);
+  const int nb = (n + 255) / 256;
+  clear_hash_kernel<<<(L.cap + 255) / 256, 256, 0, s>>>(hkey, L.cap);
+  if (n > 0) {
+    keys_kernel<<<nb, 256, 0, s>>>(pts, n, origin[0], origin[1], origin[2], 1.0 / h, keys, idx);
+    size_t tmp = L.sort_bytes;
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(base + L.sort_tmp, tmp, keys, skeys, idx, sidx, n, 0, 3 * kCellBits, s);
+    if (e != hipSuccess) { set_error("cell sort: %s", hipGetErrorString(e)); return (int)e; }
+    heads_kernel<<<nb, 256, 0, s>>>(skeys, sidx, pts, n, hkey, hrun, L.cap - 1, spts);
+    tails_kernel<<<nb, 256, 0, s>>>(skeys, n, hkey, hrun, L.cap - 1);
+  }
+  g->ox = origin[0]; g->oy = origin[1]; g->oz = origin[2]; g->inv_h = 1.0 / h; g->h = h;
+  g->pts = spts; g->perm = sidx; g->hkey = hkey; g->hrun = hrun; g->mask = L.cap - 1; g->n = n;
+  return check_launch("cell grid");
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t svs_cloud_grid_bytes(int n_points) { return grid_layout(n_points).total; }
+
+int svs_cloud_nn(const double* ref, int n_ref, const double* query, int n_query, const double* origin, double cell,
+                 double max_radius, void* grid_ws, double* dist, int* idx, void* hip_stream) {
+  if (!ref || !query || !origin || !grid_ws || !dist || n_ref < 0 || n_query < 0) { set_error("svs_cloud_nn: bad argument"); return SVS_EINVAL; }
+  if (!(cell > 0.0) || !(max_radius > 0.0) || max_radius / cell > 4096.0) { set_error("svs_cloud_nn: need 0 < cell, max_radius <= 4096 cells"); return SVS_ESHAPE; }
+  hipStream_t s = (hipStream_t)hip_stream;
+  Grid g;
+  int rc = build_grid(ref, n_ref, origin, cell, grid_ws, s, &g);
+  if (rc) return rc;
+  if (n_query == 0) return SVS_OK;
+  const int max_ring = (int)__builtin_ceil(max_radius / cell) + 1;
+  nn_kernel<<<(n_query + 255) / 256, 256, 0, s>>>(g, query, n_query, max_ring, dist, idx);
+  return check_launch("svs_cloud_nn");
+}
+
+int svs_cloud_downsample_begin(const double* pts, int n, const double* origin, double radius, void* grid_ws, uint8_t* state,
+                               void* hip_stream) {
+  if (!pts || !origin || !grid_ws || !state || n < 0 || !(radius > 0.0)) { set_error("svs_cloud_downsample_begin: bad argument"); return SVS_EINVAL; }
+  hipStream_t s = (hipStream_t)hip_stream;
+  Grid g;
+  int rc = build_grid(pts, n, origin, radius, grid_ws, s, &g);
+  if (rc) return rc;
+  hipError_t e = hipMemsetAsync(state, 0, (size_t)n, s);
+  if (e != hipSuccess) { set_error("svs_cloud_downsample_begin: %s", hipGetErrorString(e)); return (int)e; }
+  return SVS_OK;
+}
+
+int svs_cloud_downsample_round(const double* origin, int n, double radius, void* grid_ws, uint8_t* state, int* undecided,
+                               void* hip_stream) {
+  if (!origin || !grid_ws || !state || !undecided || n < 0) { set_error("svs_cloud_downsample_round: bad argument"); return SVS_EINVAL; }
+  hipStream_t s = (hipStream_t)hip_stream;
+  const GridLayout L = grid_layout(n);
+  char* base = (char*)(((uintptr_t)grid_ws + 255) & ~(uintptr_t)255);
+  Grid g;
+  g.ox = origin[0]; g.oy = origin[1]; g.oz = origin[2]; g.inv_h = 1.0 / radius; g.h = radius;
+  g.pts = (const double*)(base + L.spts); g.perm = (const unsigned*)(base + L.sidx);
+  g.hkey = (const u64*)(base + L.hkey); g.hrun = (const uint2*)(base + L.hrun); g.mask = L.cap - 1; g.n = n;
+  hipError_t e = hipMemsetAsync(undecided, 0, sizeof(int), s);
+  if (e != hipSuccess) { set_error("svs_cloud_downsample_round: %s", hipGetErrorString(e)); return (int)e; }
+  if (n == 0) return SVS_OK;
+  mis_round_kernel<<<(n + 255) / 256, 256, 0, s>>>(g, radius * radius, state, undecided);
+  return check_launch("svs_cloud_downsample_round");
+}
+
+int svs_cloud_obs_filter(const double* pts, int n, const float* bb, double res, double patch, const uint8_t* obs_mask,
+                         int d0, int d1, int d2, uint8_t* inbound, uint8_t* in_obs, void* hip_stream) {
+  if (!pts || !bb || !obs_mask || !inbound || !in_obs || n < 0 || d0 < 1 || d1 < 1 || d2 < 1 || !(res > 0.0)) {
+    set_error("svs_cloud_obs_filter: bad argument"); return SVS_EINVAL;
+  }
+  if (n == 0) return SVS_OK;
+  ObsArgs a;
+  a.pts = pts; a.n = n; a.res = res; a.obs = obs_mask; a.dims[0] = d0; a.dims[1] = d1; a.dims[2] = d2;
+  for (int k = 0; k < 3; ++k) {                    // bb: HOST array, 2 rows of 3
+    a.bb_lo[k] = (double)bb[k];
+    // float32 array -/+ python float stays float32 in numpy (eval_dtu.py:126)
+    volatile float lo = bb[k] - (float)patch, hi = bb[3 + k] + (float)(patch * 2.0);
+    a.lo_thr[k] = (double)lo; a.hi_thr[k] = (double)hi;
+  }
+  a.inbound = inbound; a.in_obs = in_obs;
+  obs_filter_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)hip_stream>>>(a);
+  return check_launch("svs_cloud_obs_filter");
+}
+
+int svs_cloud_plane_side(const double* pts, int n, const double* plane, uint8_t* above, void* hip_stream) {
+  if (!pts || !plane || !above || n < 0) { set_error("svs_cloud_plane_side: bad argument"); return SVS_EINVAL; }
+  if (n == 0) return SVS_OK;
+  plane_side_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)hip_stream>>>(pts, n, plane[0], plane[1], plane[2], plane[3], above);
+  return check_launch("svs_cloud_plane_side");
+}
+
+int svs_cloud_compact(const double* pts, const uint8_t* mask, int n, int* offset_ws, double* out, int* count, void* hip_stream) {
+  if (!pts || !mask || !offset_ws || !out || !count || n < 0) { set_error("svs_cloud_compact: bad argument"); return SVS_EINVAL; }
+  hipStream_t s = (hipStream_t)hip_stream;
+  rows_scan_kernel<<<1, kScanThreads, 0, s>>>(mask, n, offset_ws, count);
+  if (n > 0) rows_scatter_kernel<<<(n + 255) / 256, 256, 0, s>>>(pts, mask, offset_ws, n, out);
+  return check_launch("svs_cloud_compact");
+}
+
+size_t svs_cloud_mean_workspace_bytes(void) { return sizeof(double) * 2 * kMeanBlocks; }
+
+int svs_cloud_mean_below(const double* dist, int n, double max_dist, double* workspace, double* mean_count, void* hip_stream) {
+  if (!dist || !workspace || !mean_count || n < 0) { set_error("svs_cloud_mean_below: bad argument"); return SVS_EINVAL; }
+  hipStream_t s = (hipStream_t)hip_stream;
+  mean_partial_kernel<<<kMeanBlocks, 256, 0, s>>>(dist, n, max_dist, workspace);
+  mean_final_kernel<<<1, 1, 0, s>>>(workspace, mean_count);
+  return check_launch("svs_cloud_mean_below");
+}
+
+}  // extern "C"

@@ -87,6 +87,15 @@ SIGNATURES = {
     "svs_loss_workspace_bytes": (c_size_t, [c_int, c_int]),
     "svs_chw_to_hwc": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "svs_fuse_mats_per_src": (c_int, []),
+    "svs_cloud_grid_bytes": (c_size_t, [c_int]),
+    "svs_cloud_nn": (c_int, [_P, c_int, _P, c_int, POINTER(c_double), c_double, c_double, _P, _P, _P, _P]),
+    "svs_cloud_downsample_begin": (c_int, [_P, c_int, POINTER(c_double), c_double, _P, _P, _P]),
+    "svs_cloud_downsample_round": (c_int, [POINTER(c_double), c_int, c_double, _P, _P, _P, _P]),
+    "svs_cloud_obs_filter": (c_int, [_P, c_int, POINTER(c_float), c_double, c_double, _P, c_int, c_int, c_int, _P, _P, _P]),
+    "svs_cloud_plane_side": (c_int, [_P, c_int, POINTER(c_double), _P, _P]),
+    "svs_cloud_compact": (c_int, [_P, _P, c_int, _P, _P, _P, _P]),
+    "svs_cloud_mean_workspace_bytes": (c_size_t, []),
+    "svs_cloud_mean_below": (c_int, [_P, c_int, c_double, _P, _P, _P]),
     "svs_fuse_view": (c_int, [_P, _P, _PP, _P, c_int, c_int, c_int, c_float, c_double, c_float, c_int, _P, _P, _P, _P, _P,
                               _P, _P, _P, _P, _P]),
     "svs_fuse_points": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),

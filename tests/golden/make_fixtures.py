@@ -596,7 +596,60 @@ def fx_pfm():
     save("pfm_codec", **arr)
 
 
-ALL = dict(fusion=fx_fusion, pfm=fx_pfm, rays=fx_rays, sdf_mlp=fx_sdf_mlp, rgb_mlp=fx_rgb_mlp, density=fx_density, sampler=fx_sampler,
+def fx_chamfer():
+    """The reference's evaluation script itself (evals/eval_dtu.py, run as __main__ through runpy) on a synthetic
+    scan laid out in the DTU directory structure.  Two substitutions, neither in the algorithm: open3d (not
+    installed) is a stub whose read_point_cloud parses the binary PLYs written below with numpy, and the script's
+    unseeded np.random.default_rng() is seeded so that the shuffled order can be stored."""
+    import runpy
+    import tempfile
+    import types
+    from scipy.io import savemat
+    scan = 24
+    sc = synth.make_dtu_scan(31)
+
+    def write_ply(fn, pts):
+        with open(fn, "wb") as f:
+            f.write(("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty double x\nproperty double y\n"
+                     "property double z\nend_header\n" % len(pts)).encode())
+            np.ascontiguousarray(pts, "<f8").tofile(f)
+
+    def read_point_cloud(fn):
+        with open(fn, "rb") as f:
+            while f.readline().strip() != b"end_header":
+                pass
+            pts = np.fromfile(f, "<f8").reshape(-1, 3)
+        return types.SimpleNamespace(points=pts)
+
+    o3d = types.ModuleType("open3d")
+    o3d.io = types.SimpleNamespace(read_point_cloud=read_point_cloud)
+    sys.modules["open3d"] = o3d
+    real_rng = np.random.default_rng
+    with tempfile.TemporaryDirectory() as td:
+        ds = os.path.join(td, "root", "DTU", "DTU_MVS_Data")
+        os.makedirs(os.path.join(ds, "ObsMask")); os.makedirs(os.path.join(ds, "Points", "stl")); os.makedirs(os.path.join(td, "pred"))
+        savemat(os.path.join(ds, "ObsMask", f"ObsMask{scan}_10.mat"), dict(ObsMask=sc["ObsMask"], BB=sc["BB"], Res=sc["Res"]))
+        savemat(os.path.join(ds, "ObsMask", f"Plane{scan}.mat"), dict(P=sc["P"]))
+        write_ply(os.path.join(ds, "Points", "stl", f"stl{scan:03}_total.ply"), sc["stl"])
+        write_ply(os.path.join(td, "pred", f"mvsnet{scan:03}_l3.ply"), sc["data_pcd"])
+        argv = sys.argv
+        sys.argv = ["eval_dtu.py", "--data_dir_root", os.path.join(td, "root"), "--datadir", os.path.join(td, "pred"), "--scan", str(scan)]
+        np.random.default_rng = lambda *a: real_rng(*a) if a else real_rng(77)
+        try:
+            g = runpy.run_path(os.path.join(ref_shim.REFERENCE_ROOT, "evals", "eval_dtu.py"), run_name="__main__")
+        finally:
+            np.random.default_rng = real_rng
+            sys.argv = argv
+    save("chamfer_ref", seed=np.asarray(31), shuffle_seed=np.asarray(77), data_pcd_shuffled_head=g["data_pcd"][:64],
+         keep=np.packbits(g["mask"]), n_down=np.asarray(len(g["data_down"])), n_in=np.asarray(len(g["data_in"])),
+         n_in_obs=np.asarray(len(g["data_in_obs"])), n_stl_above=np.asarray(len(g["stl_above"])),
+         dist_d2s=g["dist_d2s"][:, 0], dist_s2d=g["dist_s2d"][:, 0], mean_d2s=np.asarray(g["mean_d2s"]),
+         mean_s2d=np.asarray(g["mean_s2d"]), over_all=np.asarray(g["over_all"]))
+    print("   acc %.4f comp %.4f, kept %d of %d, in_obs %d" % (g["mean_d2s"], g["mean_s2d"], len(g["data_down"]), len(g["data_pcd"]),
+                                                            len(g["data_in_obs"])))
+
+
+ALL = dict(fusion=fx_fusion, pfm=fx_pfm, chamfer=fx_chamfer, rays=fx_rays, sdf_mlp=fx_sdf_mlp, rgb_mlp=fx_rgb_mlp, density=fx_density, sampler=fx_sampler,
            composite=fx_composite, forward=fx_forward, forward_bg=fx_forward_bg, cost_mapping=fx_cost_mapping, loss=fx_loss, casmvs=fx_casmvs, train_step=fx_train_step,
            train_step_bg=fx_train_step_bg)
 

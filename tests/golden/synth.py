@@ -265,3 +265,37 @@ def make_fusion_views(seed, hw=(48, 64), n_views=3, noise=2e-3):
                         confidence=rng.uniform(0, 1, (H, W)).astype(F32),
                         img=(rng.integers(0, 256, (H, W, 3)).astype(F32) / F32(255.)))
     return views
+
+
+def make_dtu_scan(seed, n_pred=12000, n_stl=10000):
+    """Synthetic stand-in for one DTU evaluation scan (evals/eval_dtu.py inputs, millimetres): a ground-truth cloud on
+    a bumpy sphere, a predicted cloud covering part of it with noise, near-duplicate clusters (so that the 0.2 mm
+    down-sampling has work to do), far outliers and points outside the padded bounding box; ObsMask / BB / Res as in
+    ObsMask*_10.mat and the ground plane of Plane*.mat."""
+    rng = np.random.default_rng(seed)
+    c = np.array([5.0, -3.0, 2.0])
+
+    def surface(n):
+        d = rng.normal(0, 1, (n, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        r = 40.0 + 1.5 * np.sin(5 * d[:, :1]) * np.cos(4 * d[:, 1:2])
+        return c + r * d, d
+
+    stl, _ = surface(n_stl)
+    n_base = n_pred * 6 // 10
+    base, nrm = surface(n_base)
+    vis = nrm[:, 2] > -0.3                                       # the prediction misses the bottom cap
+    base, nrm = base[vis], nrm[vis]
+    base = base + nrm * rng.normal(0, 0.3, (len(base), 1))
+    n_dup = n_pred * 3 // 10
+    dup = base[rng.integers(0, len(base), n_dup)] + rng.normal(0, 0.06, (n_dup, 3))
+    n_out = n_pred - len(base) - n_dup
+    far = c + rng.normal(0, 1, (n_out, 3)) * rng.uniform(45, 140, (n_out, 1))
+    data_pcd = np.concatenate([base, dup, far], 0)
+    BB = np.array([[-45.3, -50.1, -40.7], [55.2, 45.9, 45.4]], F32)
+    Res = np.array([[2.0]])
+    dims = tuple(int(v) for v in np.ceil((BB[1] - BB[0]) / 2.0).astype(int) + 1)
+    ObsMask = (rng.uniform(0, 1, dims) > 0.1).astype(np.uint8)
+    ObsMask[:, :, :4] = 0
+    P = np.array([[0.05, -0.02, 1.0, 25.0]])
+    return dict(data_pcd=data_pcd, stl=stl, ObsMask=ObsMask, BB=BB, Res=Res, P=P)
