@@ -1,0 +1,336 @@
+"""`VolOpt` with the reference's call surface (volsdf/vsdf.py:18-463): constructor keywords `args, batch_size,
+is_continue, timestamp, checkpoint, scan`; attributes `trains_i`, `train_dataset`, `stg`, `loss`, `plots_dir`,
+`iter_step`; methods `gen_dataset(stg)`, `get_mvs_input(outs)`, `run(opt_stepN) -> epoch`, `render_mvs(id_k, epoch) ->
+(depth (H,W) on the device, None)`, `train_step`, `render_step`, `cost_mapping`, `save_checkpoints`,
+`load_from_dir` -- what runner.py:164-243 drives.
+
+Everything per ray runs on the HIP path: `train_step` is one `svs_hip.trainer.TrainStep` (forward, MVS prior lookup,
+fused loss, hand-written backward, fused clip + NaN guard + Adam), `render_step` is `svs_hip.renderer.render_image`
+(8000-ray launches, per-chunk convergence on the device, no per-chunk device-to-host copies), `cost_mapping` is the
+lookup kernel.  Around it stays host plumbing only: experiment folders, checkpoints in the reference's layout and key
+names, the DataLoader, optional TensorBoard / plot hooks.  The dataset class is resolved from `train.dataset_class`
+like the reference does (its `volsdf/datasets/` is outside this path: keep the reference checkout importable, see
+INTEGRATION.md), or injected with the `dataset_class=` keyword.
+"""
+import copy
+import itertools
+import os
+from datetime import datetime
+
+import torch
+
+import volsdf.utils.general as utils
+from svs_hip import ops, renderer
+from svs_hip.trainer import TrainStep
+from volsdf.utils.conf import Conf, attr_view, to_plain
+
+
+class _NoWriter:
+    def add_scalar(self, *a, **k):
+        pass
+
+    def add_images(self, *a, **k):
+        pass
+
+
+def _summary_writer(log_dir):
+    try:
+        from torch.utils.tensorboard import SummaryWriter
+        return SummaryWriter(log_dir=log_dir)
+    except Exception:                                    # tensorboard is optional host tooling
+        return _NoWriter()
+
+
+class AdamStateView:
+    """`torch.optim.Adam`-layout `state_dict()` / `load_state_dict()` over the fused optimiser's flat moment buffers, so
+    that OptimizerParameters/*.pth written by either implementation resumes in the other (vsdf.py:143-145,181-195)."""
+
+    def __init__(self, fused):
+        self.fused = fused
+
+    def zero_grad(self, set_to_none=False):
+        self.fused.zero_grad()
+
+    def state_dict(self):
+        f = self.fused
+        state = {}
+        if f.step_count > 0:
+            for i, (m, v) in enumerate(zip(f.fp.views(f.exp_avg), f.fp.views(f.exp_avg_sq))):
+                state[i] = {"step": torch.tensor(float(f.step_count)), "exp_avg": m.clone(), "exp_avg_sq": v.clone()}
+        group = dict(lr=f.lr, betas=tuple(f.betas), eps=f.eps, weight_decay=0, amsgrad=False, maximize=False, foreach=None,
+                     capturable=False, differentiable=False, fused=None, params=list(range(len(f.fp.params))))
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        f = self.fused
+        steps = {int(s["step"]) for s in sd["state"].values()}
+        if len(steps) > 1:
+            raise ValueError("per-parameter step counts differ: not a state the fused Adam can represent")
+        f.step_count = steps.pop() if steps else 0
+        f.exp_avg.zero_(); f.exp_avg_sq.zero_()
+        for i, (m, v) in enumerate(zip(f.fp.views(f.exp_avg), f.fp.views(f.exp_avg_sq))):
+            if i in sd["state"]:
+                m.copy_(sd["state"][i]["exp_avg"]); v.copy_(sd["state"][i]["exp_avg_sq"])
+        if sd.get("param_groups"):
+            f.lr = float(sd["param_groups"][0].get("lr", f.lr))
+
+
+class VolOpt():
+    def __init__(self, **kwargs):
+        torch.set_default_dtype(torch.float32)
+        torch.set_num_threads(1)
+
+        # get configs
+        self.hparams = attr_view(copy.deepcopy(kwargs['args']))
+        self.conf = Conf(to_plain(self.hparams['vol']))
+        self.batch_size = kwargs['batch_size']
+        if self.batch_size != 1:
+            raise NotImplementedError("the fused step takes one view per batch (runner.py:165 passes batch_size=1)")
+        self.exps_folder_name = self.hparams.exps_folder
+
+        root = './'
+        self.expname = self.conf.get_string('train.expname')
+        kwargs_scan_id = int(kwargs['scan'][4:])
+        scan_id = kwargs_scan_id if kwargs_scan_id != -1 else self.conf.get_int('dataset.scan_id', default=-1)
+        self.scan_id = scan_id
+        if scan_id != -1:
+            self.expname = self.expname + '_{0}'.format(scan_id)
+
+        is_continue, timestamp = kwargs['is_continue'], kwargs['timestamp']
+        if is_continue and timestamp == 'latest':
+            runs = os.path.join(root, self.exps_folder_name, self.expname)
+            stamps = sorted(os.listdir(runs)) if os.path.exists(runs) else []
+            is_continue, timestamp = (True, stamps[-1]) if stamps else (False, None)
+
+        # experiment / checkpoint folders (the reference's layout)
+        self.expdir = os.path.join(root, self.exps_folder_name, self.expname)
+        self.timestamp = '{:%Y_%m_%d_%H_%M_%S}'.format(datetime.now())
+        self.plots_dir = os.path.join(self.expdir, self.timestamp, 'plots')
+        self.checkpoints_path = os.path.join(self.expdir, self.timestamp, 'checkpoints')
+        self.model_params_subdir = "ModelParameters"
+        self.optimizer_params_subdir = "OptimizerParameters"
+        for d in (self.plots_dir, os.path.join(self.checkpoints_path, self.model_params_subdir),
+                  os.path.join(self.checkpoints_path, self.optimizer_params_subdir)):
+            os.makedirs(d, exist_ok=True)
+        self._save_run_config(os.path.join(self.expdir, self.timestamp, 'run.yaml'), kwargs['args'])
+
+        # dataset config
+        dataset_conf = dict(self.conf.get_config('dataset'))
+        if kwargs_scan_id != -1:
+            dataset_conf['scan_id'] = kwargs_scan_id
+        dataset_conf['data_dir_root'] = self.hparams.data_dir_root
+        assert [self.hparams.max_h, self.hparams.max_w] == list(dataset_conf['img_res'])
+        self._dataset_class = kwargs.get('dataset_class') or utils.get_class(self.conf.get_string('train.dataset_class'))
+
+        # generate dataset
+        self.data_confs = [copy.deepcopy(dataset_conf) for _ in range(3)]
+        self.gen_dataset(stg=2)          # full resolution
+        self.gen_plot_dataset()
+        self.stg = 2
+        self.ds_len = len(self.train_dataset)
+
+        # model, loss, fused optimiser step
+        self.model = utils.get_class(self.conf.get_string('train.model_class'))(conf=self.conf.get_config('model'))
+        self.model.cuda()
+        self.loss = utils.get_class(self.conf.get_string('train.loss_class'))(**self.conf.get_config('loss'))
+        self.lr = self.conf.get_float('train.learning_rate')
+        self.step_fn = TrainStep(self.model, self.loss, lr=self.lr, grad_clip=bool(self.hparams.grad_clip))
+        self.optimizer = AdamStateView(self.step_fn.opt)
+
+        # load ckpt
+        self.start_epoch = 0
+        self.iter_step, self.total_step = 0, 0
+        ckpt_dir = self.conf.get_string('train.ckpt_dir', '')
+        if is_continue:
+            self.load_from_dir(dir=os.path.join(self.expdir, timestamp), checkpoint=kwargs['checkpoint'])
+        elif ckpt_dir != '':
+            self.load_from_dir(dir=ckpt_dir, checkpoint='latest')
+
+        # some parameters
+        self.num_pixels = self.conf.get_int('train.num_pixels')
+        self.plot_freq = self.conf.get_int('train.plot_freq')
+        self.render_freq = self.conf.get_int('train.render_freq')
+        self.checkpoint_freq = self.conf.get_int('train.checkpoint_freq', default=100)
+        self.split_n_pixels = self.conf.get_int('train.split_n_pixels', default=10000)
+        self.plot_conf = self.conf.get_config('plot')
+
+        self.writer = _summary_writer(os.path.join(self.plots_dir, 'logs'))
+        self.model.hparams = self.hparams
+        self.loss.hparams = self.hparams
+
+    @staticmethod
+    def _save_run_config(path, args):
+        try:
+            from omegaconf import OmegaConf
+            with open(path, "w") as f:
+                OmegaConf.save(args, f)
+        except Exception:
+            import yaml
+            with open(path, "w") as f:
+                yaml.safe_dump(to_plain(args), f)
+
+    # ---- checkpoints: the reference's files and keys (vsdf.py:128-195) ---------------------------------------------------
+    def load_from_dir(self, dir, checkpoint='latest'):
+        old = os.path.join(dir, 'checkpoints')
+        saved = torch.load(os.path.join(old, 'ModelParameters', str(checkpoint) + ".pth"), map_location="cuda")
+        self.model.load_state_dict(saved["model_state_dict"])
+        self.model.invalidate_packed()
+        self.start_epoch = saved['epoch']
+        self.iter_step = saved['iter_step']
+        data = torch.load(os.path.join(old, 'OptimizerParameters', str(checkpoint) + ".pth"), map_location="cuda")
+        self.optimizer.load_state_dict(data["optimizer_state_dict"])
+
+    def save_checkpoints(self, epoch, latest_only=False):
+        for name in ("latest",) + (() if latest_only else (str(epoch),)):
+            torch.save({"epoch": epoch, "model_state_dict": self.model.state_dict(), "iter_step": self.iter_step},
+                       os.path.join(self.checkpoints_path, self.model_params_subdir, name + ".pth"))
+            torch.save({"epoch": epoch, "optimizer_state_dict": self.optimizer.state_dict()},
+                       os.path.join(self.checkpoints_path, self.optimizer_params_subdir, name + ".pth"))
+        return 0
+
+    # ---- datasets (host plumbing, vsdf.py:147-178) -------------------------------------------------------------------------
+    def gen_plot_dataset(self):
+        data_conf = copy.deepcopy(dict(self.conf.get_config('dataset')))
+        data_conf['img_res'] = [int(_ / 4.) for _ in data_conf['img_res']]
+        data_conf.setdefault('data_dir_root', self.hparams.data_dir_root)
+        self.plot_dataset = self._dataset_class(**data_conf)
+        self.plot_dataloader = torch.utils.data.DataLoader(self.plot_dataset, batch_size=self.conf.get_int('plot.plot_nimgs'),
+                                                           shuffle=False, collate_fn=self.plot_dataset.collate_fn)
+
+    def gen_dataset(self, stg):
+        self.train_dataset = self._dataset_class(**self.data_confs[stg])
+        self.train_dataloader = torch.utils.data.DataLoader(self.train_dataset, batch_size=self.batch_size, shuffle=True,
+                                                            collate_fn=self.train_dataset.collate_fn)
+        self.eval_dataloader = torch.utils.data.DataLoader(self.train_dataset, batch_size=1, shuffle=False,
+                                                           collate_fn=self.train_dataset.collate_fn)
+        self.total_pixels = self.train_dataset.total_pixels
+        self.img_res = self.train_dataset.img_res
+        self.scale_factor = self.train_dataset.scale_factor
+        self.n_batches = len(self.train_dataloader)
+
+    # ---- one optimisation step (vsdf.py:196-235) ----------------------------------------------------------------------------
+    def _mvs_views(self, ts):
+        views, same = [], -1
+        for i, id_k in enumerate(self.trains_i):
+            if int(ts[0]) == int(id_k):
+                same = i
+            z = self.z_mvs[i]
+            views.append(dict(K=self.train_dataset.intrinsics_all[id_k], c2w=self.train_dataset.pose_all[id_k],
+                              cost=self.costs[i], z_near=z[0, 0].contiguous(), z_far=z[0, -1].contiguous()))
+        return dict(views=views, same_view=same, img_res=tuple(self.train_dataset.img_res),
+                    inverse_depth=bool(self.hparams.inverse_depth) and self.stg == 0)
+
+    def train_step(self, batch, use_mvs=False):
+        indices, model_input, ground_truth = batch
+        model_input = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in model_input.items()}
+        model_input['iter_step'] = self.iter_step
+        if use_mvs and bool(self.hparams.inverse_depth) and self.stg >= 1:
+            raise NotImplementedError                                      # vsdf.py:429-430
+        gt = {k: ground_truth[k].cuda() for k in ("rgb", "rgb_smooth")}
+        loss_output, model_outputs = self.step_fn(model_input, gt, mvs=self._mvs_views(indices) if use_mvs else None, fast=1)
+        if self.total_step % 50 == 0:
+            for k, v in loss_output.items():
+                self.writer.add_scalar('t/' + k, v, self.total_step)
+            beta = self.model.density.get_beta().item()
+            mse = torch.mean((model_outputs['rgb_values'] - gt['rgb'].reshape(-1, 3)) ** 2)
+            self.writer.add_scalar('t/beta', beta, self.total_step)
+            self.writer.add_scalar('t/alpha', 1. / beta, self.total_step)
+            self.writer.add_scalar('t/psnr', (-10. * torch.log10(mse)).item(), self.total_step)
+        self.train_dataset.change_sampling_idx(self.num_pixels)
+        self.iter_step += 1
+        self.total_step += 1
+        return loss_output
+
+    # ---- whole-image rendering (vsdf.py:237-287) ----------------------------------------------------------------------------------
+    def render_step(self, batch, epoch, dataset, fast=-1):
+        self.model.eval()
+        indices, model_input, ground_truth = batch
+        model_input = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in model_input.items()}
+        model_input['iter_step'] = self.iter_step
+        model_outputs = renderer.render_image(self.model, model_input, dataset.total_pixels, split_n_pixels=self.split_n_pixels,
+                                              fast=fast)
+        depth_cuda = renderer.depth_image(model_outputs, dataset.img_res, self.scale_factor)
+        mask_bin = ground_truth['mask'].reshape(-1, 3).cuda() == 1.
+        mse = torch.mean((model_outputs['rgb_values'] - ground_truth['rgb'].reshape(-1, 3).cuda())[mask_bin] ** 2)
+        self.last_val_psnr = -10. * torch.log10(mse)
+        self.writer.add_scalar('val/psnr', self.last_val_psnr.item(), self.total_step)
+        self._plot(indices, model_input, model_outputs, ground_truth, epoch, dataset, mask_bin)
+        self.total_step += 1
+        return depth_cuda, None
+
+    def get_plot_data(self, model_input, model_outputs, pose, rgb_gt):
+        batch_size, num_samples, _ = rgb_gt.shape
+        return {'rgb_gt': rgb_gt, 'pose': pose,
+                'rgb_eval': model_outputs['rgb_values'].reshape(batch_size, num_samples, 3),
+                'normal_map': (model_outputs['normal_map'].reshape(batch_size, num_samples, 3) + 1.) / 2.,
+                'depth_map': model_outputs['depth_values'].reshape(batch_size, num_samples),
+                'acc': model_outputs['weights'].sum(1).reshape(batch_size, num_samples)}
+
+    def _plot(self, indices, model_input, model_outputs, ground_truth, epoch, dataset, mask_bin):
+        """The reference's image dumps (volsdf/utils/plots.py, out of the path) if that module is importable."""
+        try:
+            import volsdf.utils.plots as plt
+        except Exception:
+            return
+        cpu = {k: v.detach().cpu() for k, v in model_outputs.items()}
+        plot_data = self.get_plot_data(model_input, cpu, model_input['pose'].cpu(), ground_truth['rgb'])
+        stack = plt.stacked_plot(indices, plot_data, self.plots_dir, epoch, dataset.img_res, **self.plot_conf)
+        stack[0][~mask_bin.cpu().reshape(list(dataset.img_res) + [3, ]).permute(2, 0, 1)] = 0
+        self.writer.add_images('val/vis', torch.stack(stack, dim=0), self.total_step)
+
+    def render_mvs(self, id_k, epoch):
+        self.train_dataset.mode = 'test'
+        self.train_dataset.change_sampling_idx(-1)
+        batch = next(itertools.islice(self.eval_dataloader, id_k, None))
+        depth_cuda, depth_confi = self.render_step(batch, epoch, self.train_dataset, fast=-1)
+        self.train_dataset.mode = 'train'
+        return depth_cuda, depth_confi
+
+    # ---- optimisation loop (vsdf.py:321-367) ----------------------------------------------------------------------------------------
+    def run(self, opt_stepN=1e8):
+        start_iter_step = self.iter_step
+        epoch = self.start_epoch
+        while True:
+            if epoch % self.checkpoint_freq == 0:
+                self.save_checkpoints(epoch)
+            early_render = (self.iter_step - start_iter_step <= 120 * 50) and epoch % max(20 * 50 // self.ds_len, 1) == 0
+            if epoch % self.render_freq == 0 or early_render:
+                self.plot_dataset.change_sampling_idx(-1)
+                self.plot_dataset.mode = 'plot'
+                batch = next(iter(self.plot_dataloader))
+                self.plot_dataset.mode = 'train'
+                self.render_step(batch, epoch, self.plot_dataset, fast=-1)
+                self.save_checkpoints(epoch, latest_only=True)
+            self.train_dataset.change_sampling_idx(self.num_pixels)
+            for data_index, batch in enumerate(self.train_dataloader):
+                self.train_step(batch, self.hparams.use_mvs)
+            if self.iter_step - start_iter_step > opt_stepN:
+                break
+            epoch += 1
+        self.save_checkpoints(epoch)
+        self.start_epoch = epoch
+        return epoch
+
+    # ---- MVS prior (vsdf.py:369-452) ---------------------------------------------------------------------------------------------------
+    def get_mvs_input(self, outs_samples):
+        self.costs, self.z_mvs, self.bd_mvs = dict(), dict(), dict()
+        sphere = self.conf.get_float('model.scene_bounding_sphere')
+        for i in range(len(outs_samples)):
+            prob_volume = outs_samples[i]['prob_volume']
+            depth_values = outs_samples[i]['depth_values'] / self.scale_factor
+            self.costs[i] = prob_volume.cuda()
+            self.z_mvs[i] = depth_values.cuda()
+            bd = depth_values[:, [0, -1], :, :]
+            bd[:, 0, :, :] = torch.minimum(bd[:, 0, :, :], torch.ones_like(bd[:, 0, :, :]) * sphere)
+            self.bd_mvs[i] = bd
+
+    @torch.no_grad()
+    def cost_mapping(self, z_vals, ts, xyz_raw):
+        """-> (results_cost_j, results_cost_mvs, valid_mask), each (N_rays, N_samples)."""
+        m = self._mvs_views(ts)
+        return ops.cost_lookup(m["views"], m["same_view"], m["img_res"], xyz=xyz_raw, inverse_depth=m["inverse_depth"])
+
+    def on_after_backward(self) -> None:
+        """The NaN / Inf guard of vsdf.py:454-463 lives inside the fused clip + Adam launch (svs_clip_guard_adam): a
+        step whose gradient is not finite leaves parameters and moments untouched."""
+        return None

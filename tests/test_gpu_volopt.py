@@ -1,0 +1,137 @@
+"""`volsdf.vsdf.VolOpt` (SURVEY.md section 8 rows a12 / b): the reference's driver surface on the HIP path, exercised the
+way runner.py:164-243 drives it -- construct, run a few optimisation steps, feed MVS priors, render a view for the MVS
+stage, resume from the checkpoints -- on an in-memory dataset with the SceneDataset interface."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+MODEL = dict(feature_vector_size=256, scene_bounding_sphere=3.0,
+             implicit_network=dict(d_in=3, d_out=1, dims=[256] * 8, geometric_init=True, bias=0.6, skip_in=[4], weight_norm=True,
+                                   multires=6, sphere_scale=20.0),
+             rendering_network=dict(mode="idr", d_in=9, d_out=3, dims=[256] * 4, weight_norm=True, multires_view=1),
+             density=dict(params_init=dict(beta=0.1), beta_min=0.0001),
+             ray_sampler=dict(near=1e-4, N_samples=64, N_samples_eval=128, N_samples_extra=32, eps=0.1, beta_iters=10,
+                              max_total_iters=5))
+
+
+def make_args(use_mvs=False):
+    vol = dict(train=dict(expname="ours", dataset_class="synthetic_scene.SyntheticSceneDataset",
+                          model_class="volsdf.model.network.VolSDFNetwork", loss_class="volsdf.model.loss.VolSDFLoss",
+                          learning_rate=5.0e-4, num_pixels=512, plot_freq=100, render_freq=1000, checkpoint_freq=100,
+                          split_n_pixels=500, ckpt_dir=""),
+               plot=dict(plot_nimgs=1, resolution=100, grid_boundary=[-1.5, 1.5]),
+               loss=dict(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, rgb_weight=1.0, mvs_weight=1.0, sparse_weight=1.0,
+                         anneal_rgb=200, gce=0.5, confi=1e-3),
+               dataset=dict(data_dir="DTU", img_res=[24, 32], scan_id=24, num_views=3),
+               model=copy.deepcopy(MODEL))
+    return dict(vol=vol, exps_folder="exps", data_dir_root="unused", max_h=24, max_w=32, grad_clip=True, use_mvs=use_mvs,
+                inverse_depth=False)
+
+
+def build(args, **kw):
+    from volsdf.vsdf import VolOpt
+    opts = dict(args=args, batch_size=1, is_continue=False, timestamp="latest", checkpoint="latest", scan="scan24")
+    opts.update(kw)
+    v = VolOpt(**opts)
+    v.trains_i = v.train_dataset.trains_ids()            # runner.py:170
+    return v
+
+
+def mvs_outputs(v, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    outs = []
+    for _ in v.trains_i:
+        prob = torch.softmax(torch.randn(1, 8, 12, 16, generator=g), 1)
+        z = torch.linspace(1.2, 3.8, 8).view(1, 8, 1, 1) * (1 + 0.03 * torch.rand(1, 1, 12, 16, generator=g)) * v.scale_factor
+        outs.append(dict(prob_volume=prob.cuda(), depth_values=z.cuda()))
+    return outs
+
+
+def test_volopt_run_render_resume(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    torch.manual_seed(0)
+    v = build(make_args())
+    assert v.stg == 2 and v.ds_len == 5 and v.total_pixels == 24 * 32 and os.path.isdir(v.plots_dir)
+    assert os.path.exists(os.path.join(v.expdir, v.timestamp, "run.yaml"))
+    p0 = {k: t.clone() for k, t in v.model.state_dict().items()}
+    epoch = v.run(opt_stepN=7)
+    assert epoch == 1 and v.iter_step == 10 and v.start_epoch == 1
+    moved = [k for k, t in v.model.state_dict().items() if not torch.equal(t, p0[k])]
+    assert len(moved) == len(p0)                                           # every parameter took Adam steps
+    assert all(torch.isfinite(t).all() for t in v.model.state_dict().values())
+    for sub, key in (("ModelParameters", "model_state_dict"), ("OptimizerParameters", "optimizer_state_dict")):
+        for name in ("latest", "0", "1"):
+            ck = torch.load(os.path.join(v.checkpoints_path, sub, name + ".pth"))
+            assert key in ck and "epoch" in ck
+    ck = torch.load(os.path.join(v.checkpoints_path, "ModelParameters", "latest.pth"))
+    assert ck["iter_step"] == 10 and set(ck["model_state_dict"]) == set(p0)
+
+    # MVS priors: get_mvs_input + a step with the prior lookup and the MVS / sparse terms
+    v.get_mvs_input(mvs_outputs(v))
+    assert set(v.costs) == {0, 1, 2} and v.bd_mvs[0].shape == (1, 2, 12, 16) and float(v.bd_mvs[0][:, 0].max()) <= 3.0
+    v.train_dataset.change_sampling_idx(v.num_pixels)
+    batch = next(iter(v.train_dataloader))
+    lo = v.train_step(batch, use_mvs=True)
+    assert float(lo["mvs_loss"]) > 0 and np.isfinite(float(lo["loss"])) and v.iter_step == 11
+    # cost_mapping keeps the reference's signature and returns (pj, pi, valid)
+    v.model.eval()
+    inp = {k: t.cuda() for k, t in batch[1].items()}
+    out = v.model(inp, fast=1)
+    pj, pi, valid = v.cost_mapping(z_vals=out["depth_vals"], ts=batch[0], xyz_raw=out["xyz"])
+    assert pj.shape == out["depth_vals"].shape == pi.shape and valid.dtype == torch.bool and bool(valid.any())
+    assert float(pi[~valid].abs().max()) == 0.0
+
+    # render a training view for the MVS stage (runner.py:224-236)
+    depth, confi = v.render_mvs(0, epoch)
+    assert confi is None and depth.shape == (24, 32) and depth.is_cuda and bool(torch.isfinite(depth).all())
+    assert v.train_dataset.mode == "train" and float(depth.max()) > 0
+
+    # resume: a second VolOpt picks the latest run folder and continues from its checkpoints
+    v.save_checkpoints(epoch)
+    v2 = build(make_args(), is_continue=True)
+    assert v2.iter_step == v.iter_step and v2.start_epoch == epoch
+    for k, t in v.model.state_dict().items():
+        assert torch.equal(t, v2.model.state_dict()[k]), k
+    assert torch.equal(v.step_fn.opt.exp_avg, v2.step_fn.opt.exp_avg) and v2.step_fn.opt.step_count == v.step_fn.opt.step_count
+    # both continue identically (same RNG state, same data order)
+    for w in (v, v2):
+        torch.manual_seed(5)
+        import random
+        random.seed(5)
+        w.train_dataset.change_sampling_idx(w.num_pixels)
+        w.train_step(next(iter(w.eval_dataloader)), use_mvs=False)
+    for k, t in v.model.state_dict().items():
+        assert torch.allclose(t, v2.model.state_dict()[k], rtol=0, atol=1e-6), k
+
+
+def test_optimizer_state_is_torch_adam_compatible(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    v = build(make_args())
+    v.train_dataset.change_sampling_idx(v.num_pixels)
+    v.train_step(next(iter(v.train_dataloader)))
+    sd = v.optimizer.state_dict()
+    params = v.model._flat_param_list()
+    ref = torch.optim.Adam(params, lr=1e-3)
+    ref.load_state_dict(sd)                                               # the reference's optimiser accepts it
+    st = ref.state_dict()["state"]
+    assert len(st) == len(params) and float(st[0]["step"]) == 1.0 and st[3]["exp_avg"].shape == params[3].shape
+    assert ref.param_groups[0]["lr"] == pytest.approx(5e-4)
+    v.optimizer.load_state_dict(ref.state_dict())                         # and the other way round
+    assert v.step_fn.opt.step_count == 1
+
+
+def test_volopt_config_errors(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    bad = make_args(); bad["max_h"] = 25
+    with pytest.raises(AssertionError):
+        build(bad)
+    with pytest.raises(NotImplementedError):
+        build(make_args(), batch_size=2)
+    bad = make_args(); del bad["vol"]["train"]["num_pixels"]
+    with pytest.raises(KeyError):
+        build(bad)
