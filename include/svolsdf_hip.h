@@ -295,6 +295,18 @@ size_t svs_conv3d_mfma_wfrag_bytes(int Cin);
 int svs_conv3d_mfma(const float* in, const void* wfrag, const float* bias, const float* skip, float* out, int Cin,
                     int Cout, int D, int H, int W, int relu, void* hip_stream);
 
+/* Every other 3x3x3 layer of the U-Net (stride 2, transposed, the 32/64-channel levels) as an implicit GEMM on the
+ * same matrix-core instruction with both operands split: Cin in {8,16,32,64}, Cout <= 64
+ * (svs_conv3d_gemm_supported).  One wave = 16 output voxels along x times all output channels; the transposed form
+ * runs as 8 GEMMs, one per output parity class, over only the taps that class uses.
+ * wfrag: svs_conv3d_gemm_wfrag_bytes(Cin, Cout, transposed), filled once per layer by svs_conv3d_gemm_pack from the
+ * folded [Cin][27][Cout] weights (layout [class][k-step][m-tile][hi,mid][lane][8 fp16], k = tap-in-class * Cin + cin). */
+int svs_conv3d_gemm_supported(int Cin, int Cout);
+size_t svs_conv3d_gemm_wfrag_bytes(int Cin, int Cout, int transposed);
+int svs_conv3d_gemm_pack(const float* weight, int Cin, int Cout, int transposed, void* wfrag, void* hip_stream);
+int svs_conv3d_gemm(const float* in, const void* wfrag, const float* bias, const float* skip, float* out, int Cin, int Cout,
+                    int Di, int Hi, int Wi, int stride, int transposed, int relu, void* hip_stream);
+
 /* ---- a14 tail  softmax over D, depth regression, photometric confidence (models/CasMVSNet.py:648-663) ---------
  * reg, depth_values (D,H,W) -> prob (D,H,W), depth (H,W), conf (H,W), index (H,W int, may be NULL). */
 int svs_prob_depth_conf(const float* reg, const float* depth_values, int D, int H, int W, float* prob, float* depth,

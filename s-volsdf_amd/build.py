@@ -28,6 +28,7 @@ UNITS = {
     "svs_render.hip": ["-ffp-contract=off"],
     "svs_costvol.hip": ["-ffp-contract=off"],
     "svs_conv_mfma.hip": [],
+    "svs_conv_gemm.hip": [],
     "svs_wgrad.hip": [],
     "svs_mlp_bwd.hip": [],
     "svs_mlp_bwd_h2.hip": [],

@@ -1,0 +1,237 @@
+// 3x3x3 convolutions of the cost-regularisation U-Net as implicit GEMMs on the fp16 matrix cores, general form:
+// stride 1 or 2, and ConvTranspose3d(k3, s2, p1, op1), Cin in {8,16,32,64}, Cout <= 64.
+//
+// Reference: models/CasMVSNet.py:107-186 (Conv3d / Deconv3d blocks, BatchNorm folded by the caller), :441-472.
+// svs_conv_mfma.hip covers the three big stride-1 layers with a register-resident weight set and an LDS ring; this
+// kernel covers the rest: the stride-2 and transposed layers and the coarse levels, whose volumes are small
+// (2-8 MB, cache-resident) and which were bound by per-thread latency as direct convolutions (one output voxel and a
+// 1728-term serial sum per thread at the 64-channel level).
+//
+// One wave = one tile of 16 output voxels along x times all output channels:
+//   v_mfma_f32_16x16x32_f16, M = 16 output channels per M-tile, N = 16 voxels, K = 32 of the (tap, cin) axis.
+// Both operands are split a = hi + mid into fp16 pieces (hi*hi + hi*mid + mid*hi, float32 accumulation: float32-class
+// accuracy).  The weights arrive pre-split as A fragments (svs_conv3d_gemm_pack); the B fragment
+// of a lane is 8 consecutive input channels of one tap of its voxel, read straight from the channel-first volume
+// (16 consecutive x per load instruction) and split in registers, one k-step ahead of the MFMAs that use it.
+// The transposed convolution is 8 independent GEMMs, one per output parity class (pz,py,px): a class uses
+// (1+pz)(1+py)(1+px) of the 27 taps, so no multiplications by the zeros of the up-sampled input are issued.
+#include "svs_common.h"
+
+namespace svs {
+namespace convgemm {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct Args {
+  const float* in;      // (Cin, Di, Hi, Wi)
+  const f16x8* wfrag;   // [class][k-step][m-tile][piece][lane]
+  const float* bias;    // [Cout] or nullptr
+  const float* skip;    // (Cout, Do, Ho, Wo), added after the ReLU, or nullptr
+  float* out;           // (Cout, Do, Ho, Wo)
+  int Cout, Di, Hi, Wi, Do, Ho, Wo, stride, relu;
+  int xtiles, rows;     // tiles per output row (per class row for the transposed form), rows = Dz * Hy
+};
+
+// taps of class (pz,py,px) of the transposed convolution, per dimension: parity 0 -> kernel index 1, input offset 0;
+// parity 1 -> kernel index 0 with input offset +1, then kernel index 2 with offset 0   (o = 2 i - 1 + k)
+__host__ __device__ inline void deconv_tap(int parity, int idx, int* k, int* d) {
+  if (parity == 0) { *k = 1; *d = 0; }
+  else if (idx == 0) { *k = 0; *d = 1; }
+  else { *k = 2; *d = 0; }
+}
+
+__host__ __device__ constexpr int ksteps(int cin, int ntaps) { return (ntaps * cin + 31) / 32; }
+__host__ __device__ constexpr int ksteps_max(int cin, bool transposed) { return ksteps(cin, transposed ? 8 : 27); }
+
+// ---- weight packing: [Cin][27][Cout] float32 -> fp16 hi / mid A fragments ------------------------------------------------------
+__global__ void pack_kernel(const float* __restrict__ w, int Cin, int Cout, int transposed, int MT, f16x8* __restrict__ frag) {
+  const int KS = ksteps_max(Cin, transposed);
+  const int n_class = transposed ? 8 : 1;
+  const long long total = (long long)n_class * KS * MT * 64;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int lane = (int)(i % 64), mt = (int)((i / 64) % MT), s = (int)((i / (64 * MT)) % KS), c = (int)(i / ((long long)64 * MT * KS));
+  const int co = 16 * mt + (lane & 15);
+  const int k0 = 32 * s + 8 * (lane >> 4);
+  const int t = k0 / Cin, ci0 = k0 % Cin;
+  int tap = -1;
+  if (!transposed) {
+    if (t < 27) tap = t;
+  } else {
+    const int pz = (c >> 2) & 1, py = (c >> 1) & 1, px = c & 1;
+    const int nx = 1 + px, ny = 1 + py, nz = 1 + pz;
+    if (t < nx * ny * nz) {
+      int kz, ky, kx, d;
+      deconv_tap(pz, t / (nx * ny), &kz, &d); deconv_tap(py, (t / nx) % ny, &ky, &d); deconv_tap(px, t % nx, &kx, &d);
+      tap = (kz * 3 + ky) * 3 + kx;
+    }
+  }
+  f16x8 hi, mid;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = (tap >= 0 && co < Cout) ? w[((size_t)(ci0 + j) * 27 + tap) * Cout + co] : 0.0f;
+    const _Float16 h = (_Float16)v;
+    hi[j] = h; mid[j] = (_Float16)(v - (float)h);
+  }
+  const size_t o = (((size_t)c * KS + s) * MT + mt) * 2 * 64 + lane;
+  frag[o] = hi; frag[o + 64] = mid;
+}
+
+// MODE 0: convolution (stride 1 or 2); MODE 1: transposed convolution
+template <int CIN, int MT, int MODE>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(Args a) {
+  const int lane = threadIdx.x & 63;
+  long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long per_class = (long long)a.rows * a.xtiles;
+  int cls = 0;
+  if (MODE == 1) { cls = (int)(tile / per_class); tile -= (long long)cls * per_class; if (cls >= 8) return; }
+  else if (tile >= per_class) return;
+  const int xt = (int)(tile % a.xtiles), row = (int)(tile / a.xtiles);
+  const int n = lane & 15, g = lane >> 4;
+  const int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
+  // output voxel of this lane's column and the base input coordinate of tap (0,0,0)
+  int zo, yo, xo, zb, yb, xb, ntaps;
+  bool col_ok;
+  if (MODE == 0) {
+    zo = row / a.Ho; yo = row - zo * a.Ho; xo = 16 * xt + n;
+    col_ok = xo < a.Wo;
+    zb = zo * a.stride - 1; yb = yo * a.stride - 1; xb = xo * a.stride - 1;
+    ntaps = 27;
+  } else {
+    const int zi = row / a.Hi, yi = row - zi * a.Hi, xi = 16 * xt + n;
+    col_ok = xi < a.Wi;
+    zo = 2 * zi + pz; yo = 2 * yi + py; xo = 2 * xi + px;
+    zb = zi; yb = yi; xb = xi;
+    ntaps = (1 + pz) * (1 + py) * (1 + px);
+  }
+  const int KS = ksteps(CIN, ntaps);
+  const size_t chan_in = (size_t)a.Di * a.Hi * a.Wi;
+  const f16x8* __restrict__ wf = a.wfrag + (size_t)cls * ksteps_max(CIN, MODE == 1) * MT * 128 + lane;
+
+  // B operand of k-step s for this lane: 8 consecutive input channels of one tap at this lane's voxel
+  auto load_b = [&](int s, float* x) {
+    const int k0 = 32 * s + 8 * g;
+    const int t = k0 / CIN, ci0 = k0 % CIN;
+    int iz, iy, ix;
+    if (MODE == 0) {
+      const int kz = t / 9, ky = (t / 3) % 3, kx = t % 3;
+      iz = zb + kz; iy = yb + ky; ix = xb + kx;
+    } else {
+      const int nx = 1 + px, ny = 1 + py;
+      int k_, dz, dy, dx;
+      deconv_tap(pz, t / (nx * ny), &k_, &dz); deconv_tap(py, (t / nx) % ny, &k_, &dy); deconv_tap(px, t % nx, &k_, &dx);
+      iz = zb + dz; iy = yb + dy; ix = xb + dx;
+    }
+    const bool ok = col_ok && t < ntaps && (unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+    const float* p = a.in + (size_t)ci0 * chan_in + ((size_t)(ok ? iz : 0) * a.Hi + (ok ? iy : 0)) * a.Wi + (ok ? ix : 0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float v = p[(size_t)j * chan_in]; x[j] = ok ? v : 0.0f; }
+  };
+
+  f32x4 acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  float xc[8], xn[8];
+  load_b(0, xc);
+  for (int s = 0; s < KS; ++s) {
+    if (s + 1 < KS) load_b(s + 1, xn);
+    f16x8 bh, bm;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const _Float16 h = (_Float16)xc[j];
+      bh[j] = h; bm[j] = (_Float16)(xc[j] - (float)h);
+    }
+    const f16x8* ws = wf + (size_t)s * MT * 128;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const f16x8 ah = ws[m * 128], am = ws[m * 128 + 64];
+      acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am, bh, acc[m], 0, 0, 0);
+      acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bm, acc[m], 0, 0, 0);
+      acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[m], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xc[j] = xn[j];
+  }
+  if (!col_ok) return;
+  const size_t chan_out = (size_t)a.Do * a.Ho * a.Wo;
+  const size_t vox = ((size_t)zo * a.Ho + yo) * a.Wo + xo;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int co = 16 * m + 4 * g + j;           // accumulator row of v_mfma_f32_16x16x32: 4 * (lane >> 4) + j
+      if (co >= a.Cout) continue;
+      float r = acc[m][j] + (a.bias ? a.bias[co] : 0.0f);
+      if (a.relu) r = __builtin_fmaxf(r, 0.0f);
+      const size_t o = (size_t)co * chan_out + vox;
+      if (a.skip) r += a.skip[o];
+      a.out[o] = r;
+    }
+}
+
+template <int CIN, int MODE>
+static void launch_mt(const Args& a, int MT, long long tiles, hipStream_t s) {
+  const unsigned grid = (unsigned)((tiles + 3) / 4);
+  if (MT == 1) conv_gemm_kernel<CIN, 1, MODE><<<grid, 256, 0, s>>>(a);
+  else if (MT == 2) conv_gemm_kernel<CIN, 2, MODE><<<grid, 256, 0, s>>>(a);
+  else conv_gemm_kernel<CIN, 4, MODE><<<grid, 256, 0, s>>>(a);
+}
+
+template <int MODE>
+static bool launch_cin(const Args& a, int Cin, int MT, long long tiles, hipStream_t s) {
+  switch (Cin) {
+    case 8: launch_mt<8, MODE>(a, MT, tiles, s); return true;
+    case 16: launch_mt<16, MODE>(a, MT, tiles, s); return true;
+    case 32: launch_mt<32, MODE>(a, MT, tiles, s); return true;
+    case 64: launch_mt<64, MODE>(a, MT, tiles, s); return true;
+    default: return false;
+  }
+}
+
+static int m_tiles(int Cout) { return Cout <= 16 ? 1 : (Cout <= 32 ? 2 : 4); }
+
+}  // namespace convgemm
+}  // namespace svs
+
+using namespace svs;
+using namespace svs::convgemm;
+
+extern "C" {
+
+int svs_conv3d_gemm_supported(int Cin, int Cout) { return (Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64) && Cout >= 1 && Cout <= 64; }
+
+size_t svs_conv3d_gemm_wfrag_bytes(int Cin, int Cout, int transposed) {
+  if (!svs_conv3d_gemm_supported(Cin, Cout)) return 0;
+  return (size_t)(transposed ? 8 : 1) * ksteps_max(Cin, transposed != 0) * m_tiles(Cout) * 128 * sizeof(f16x8);
+}
+
+int svs_conv3d_gemm_pack(const float* weight, int Cin, int Cout, int transposed, void* wfrag, void* hip_stream) {
+  if (!weight || !wfrag || !svs_conv3d_gemm_supported(Cin, Cout)) { set_error("svs_conv3d_gemm_pack: bad argument"); return SVS_EINVAL; }
+  const int MT = m_tiles(Cout);
+  const long long total = (long long)(transposed ? 8 : 1) * ksteps_max(Cin, transposed != 0) * MT * 64;
+  pack_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)hip_stream>>>(weight, Cin, Cout, transposed != 0, MT, (f16x8*)wfrag);
+  return check_launch("svs_conv3d_gemm_pack");
+}
+
+int svs_conv3d_gemm(const float* in, const void* wfrag, const float* bias, const float* skip, float* out, int Cin, int Cout,
+                    int Di, int Hi, int Wi, int stride, int transposed, int relu, void* hip_stream) {
+  if (!in || !wfrag || !out || Di < 1 || Hi < 1 || Wi < 1 || (stride != 1 && stride != 2)) { set_error("svs_conv3d_gemm: bad argument"); return SVS_EINVAL; }
+  if (!svs_conv3d_gemm_supported(Cin, Cout)) { set_error("svs_conv3d_gemm: Cin must be 8/16/32/64 and Cout <= 64"); return SVS_ESHAPE; }
+  Args a;
+  a.in = in; a.wfrag = (const f16x8*)wfrag; a.bias = bias; a.skip = skip; a.out = out; a.Cout = Cout;
+  a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.stride = stride; a.relu = relu;
+  hipStream_t s = (hipStream_t)hip_stream;
+  const int MT = m_tiles(Cout);
+  if (transposed) {
+    a.Do = 2 * Di; a.Ho = 2 * Hi; a.Wo = 2 * Wi;
+    a.xtiles = (Wi + 15) / 16; a.rows = Di * Hi;
+    launch_cin<1>(a, Cin, MT, 8LL * a.rows * a.xtiles, s);
+  } else {
+    a.Do = (Di - 1) / stride + 1; a.Ho = (Hi - 1) / stride + 1; a.Wo = (Wi - 1) / stride + 1;
+    a.xtiles = (a.Wo + 15) / 16; a.rows = a.Do * a.Ho;
+    launch_cin<0>(a, Cin, MT, (long long)a.rows * a.xtiles, s);
+  }
+  return check_launch("svs_conv3d_gemm");
+}
+
+}  // extern "C"

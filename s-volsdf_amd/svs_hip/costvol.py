@@ -115,6 +115,32 @@ def mfma_weight_fragments(weight):
     return frag
 
 
+_GEMM_ON = [True]
+
+
+def gemm_enabled(on=None):
+    """The MFMA implicit-GEMM path for the strided / transposed / coarse layers (svs_conv3d_gemm); off = the VALU direct
+    convolutions (kept for A/B measurements and as the fall-back for channel counts the GEMM kernel does not cover)."""
+    if on is not None:
+        _GEMM_ON[0] = bool(on)
+    return _GEMM_ON[0]
+
+
+def gemm_weight_fragments(weight, transposed):
+    """[Cin][27][Cout] folded float32 weights -> the A fragments of svs_conv3d_gemm (packed on the device, cached)."""
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), bool(transposed))
+    hit = _WFRAG_CACHE.get(key)
+    if hit is not None:
+        return hit[0]
+    L = _lib.load()
+    Cin, _, Cout = weight.shape
+    w = _f32(weight)
+    frag = torch.empty(L.svs_conv3d_gemm_wfrag_bytes(Cin, Cout, int(transposed)), dtype=torch.uint8, device=weight.device)
+    _lib.check(L.svs_conv3d_gemm_pack(_ptr(w), Cin, Cout, int(transposed), _ptr(frag), _stream()), "svs_conv3d_gemm_pack")
+    _WFRAG_CACHE[key] = (frag, weight)
+    return frag
+
+
 def conv3d(x, weight, bias=None, skip=None, stride=1, transposed=False, relu=True):
     """x (Cin,D,H,W); weight [Cin][27][Cout] folded; -> (Cout,Do,Ho,Wo)."""
     L = _lib.load()
@@ -132,6 +158,11 @@ def conv3d(x, weight, bias=None, skip=None, stride=1, transposed=False, relu=Tru
     else:
         shp = (Cout, (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1)
     out = torch.empty(shp, device=x.device)
+    if gemm_enabled() and L.svs_conv3d_gemm_supported(Cin, Cout):
+        frag = gemm_weight_fragments(weight, transposed)
+        _lib.check(L.svs_conv3d_gemm(_ptr(x), _ptr(frag), _ptr(bias), _ptr(skip), _ptr(out), Cin, Cout, D, H, W, stride,
+                                     int(transposed), int(relu), _stream()), "svs_conv3d_gemm")
+        return out
     _lib.check(L.svs_conv3d(_ptr(x), _ptr(weight), _ptr(bias), _ptr(skip), _ptr(out), Cin, Cout, D, H, W, stride,
                             int(transposed), int(relu), _stream()), "svs_conv3d")
     return out

@@ -102,6 +102,10 @@ SIGNATURES = {
     "svs_warp_variance": (c_int, [_P, _PP, POINTER(c_float), c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P]),
     "svs_conv3d": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "svs_conv3d_mfma_wfrag_bytes": (c_size_t, [c_int]),
+    "svs_conv3d_gemm_supported": (c_int, [c_int, c_int]),
+    "svs_conv3d_gemm_wfrag_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "svs_conv3d_gemm_pack": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
+    "svs_conv3d_gemm": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "svs_conv3d_mfma": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "svs_prob_depth_conf": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "svs_depth_hypotheses": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_int,
