@@ -13,8 +13,11 @@
 // accuracy).  The weights arrive pre-split as A fragments (svs_conv3d_gemm_pack); the B fragment
 // of a lane is 8 consecutive input channels of one tap of its voxel, read straight from the channel-first volume
 // (16 consecutive x per load instruction) and split in registers, one k-step ahead of the MFMAs that use it.
-// The transposed convolution is 8 independent GEMMs, one per output parity class (pz,py,px): a class uses
-// (1+pz)(1+py)(1+px) of the 27 taps, so no multiplications by the zeros of the up-sampled input are issued.
+// The transposed convolution is a set of independent GEMMs, one per output parity class: a class uses only the taps
+// that meet non-zero input, so no multiplications by the zeros of the up-sampled input are issued.  With Cout <= 32
+// the two x-parities of a (pz,py) class share one GEMM: output rows [0,Cout) are the even-x outputs, rows
+// [Cout,2Cout) the odd-x ones, over the same B fragments (input voxels xi and xi+1) -- one third fewer input loads,
+// full M tiles for Cout = 8, and the even/odd outputs of a channel leave in the same store instruction.
 #include "svs_common.h"
 
 namespace svs {
@@ -44,19 +47,35 @@ __host__ __device__ constexpr int ksteps(int cin, int ntaps) { return (ntaps * c
 __host__ __device__ constexpr int ksteps_max(int cin, bool transposed) { return ksteps(cin, transposed ? 8 : 27); }
 
 // ---- weight packing: [Cin][27][Cout] float32 -> fp16 hi / mid A fragments ------------------------------------------------------
+// transposed: 0 convolution, 1 transposed (8 classes), 2 transposed with the x-parities paired (4 classes, M = 2 Cout)
 __global__ void pack_kernel(const float* __restrict__ w, int Cin, int Cout, int transposed, int MT, f16x8* __restrict__ frag) {
-  const int KS = ksteps_max(Cin, transposed);
-  const int n_class = transposed ? 8 : 1;
+  const int KS = ksteps_max(Cin, transposed != 0);
+  const int n_class = transposed == 1 ? 8 : (transposed == 2 ? 4 : 1);
   const long long total = (long long)n_class * KS * MT * 64;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int lane = (int)(i % 64), mt = (int)((i / 64) % MT), s = (int)((i / (64 * MT)) % KS), c = (int)(i / ((long long)64 * MT * KS));
-  const int co = 16 * mt + (lane & 15);
+  int co = 16 * mt + (lane & 15);
   const int k0 = 32 * s + 8 * (lane >> 4);
   const int t = k0 / Cin, ci0 = k0 % Cin;
   int tap = -1;
   if (!transposed) {
     if (t < 27) tap = t;
+  } else if (transposed == 2) {
+    // slot t = (a * ny + b) * 2 + dxs: input offset (dz(a), dy(b), dxs); row block px = co / Cout
+    const int pz = (c >> 1) & 1, py = c & 1;
+    const int ny = 1 + py, nz = 1 + pz;
+    const int px = co >= Cout ? 1 : 0;
+    co -= px * Cout;
+    if (px == 1 && co >= Cout) co = 1 << 20;                 // rows beyond 2 * Cout: zero
+    if (t < nz * ny * 2) {
+      const int dxs = t & 1, ab = t >> 1;
+      int kz, ky, d;
+      deconv_tap(pz, ab / ny, &kz, &d); deconv_tap(py, ab % ny, &ky, &d);
+      // even x (px = 0): kernel index 1 on input xi; odd x: index 2 on xi, index 0 on xi + 1
+      const int kx = px == 0 ? (dxs == 0 ? 1 : -1) : (dxs == 0 ? 2 : 0);
+      if (kx >= 0) tap = (kz * 3 + ky) * 3 + kx;
+    }
   } else {
     const int pz = (c >> 2) & 1, py = (c >> 1) & 1, px = c & 1;
     const int nx = 1 + px, ny = 1 + py, nz = 1 + pz;
@@ -77,18 +96,18 @@ __global__ void pack_kernel(const float* __restrict__ w, int Cin, int Cout, int 
   frag[o] = hi; frag[o + 64] = mid;
 }
 
-// MODE 0: convolution (stride 1 or 2); MODE 1: transposed convolution
+// MODE 0: convolution (stride 1 or 2); MODE 1: transposed convolution, 8 classes; MODE 2: transposed, x-parities paired
 template <int CIN, int MT, int MODE>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(Args a) {
   const int lane = threadIdx.x & 63;
   long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long long per_class = (long long)a.rows * a.xtiles;
   int cls = 0;
-  if (MODE == 1) { cls = (int)(tile / per_class); tile -= (long long)cls * per_class; if (cls >= 8) return; }
+  if (MODE >= 1) { cls = (int)(tile / per_class); tile -= (long long)cls * per_class; if (cls >= (MODE == 1 ? 8 : 4)) return; }
   else if (tile >= per_class) return;
   const int xt = (int)(tile % a.xtiles), row = (int)(tile / a.xtiles);
   const int n = lane & 15, g = lane >> 4;
-  const int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
+  const int pz = MODE == 2 ? (cls >> 1) & 1 : (cls >> 2) & 1, py = MODE == 2 ? cls & 1 : (cls >> 1) & 1, px = MODE == 2 ? 0 : cls & 1;
   // output voxel of this lane's column and the base input coordinate of tap (0,0,0)
   int zo, yo, xo, zb, yb, xb, ntaps;
   bool col_ok;
@@ -102,11 +121,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Args a) {
     col_ok = xi < a.Wi;
     zo = 2 * zi + pz; yo = 2 * yi + py; xo = 2 * xi + px;
     zb = zi; yb = yi; xb = xi;
-    ntaps = (1 + pz) * (1 + py) * (1 + px);
+    ntaps = MODE == 2 ? (1 + pz) * (1 + py) * 2 : (1 + pz) * (1 + py) * (1 + px);
   }
   const int KS = ksteps(CIN, ntaps);
   const size_t chan_in = (size_t)a.Di * a.Hi * a.Wi;
-  const f16x8* __restrict__ wf = a.wfrag + (size_t)cls * ksteps_max(CIN, MODE == 1) * MT * 128 + lane;
+  const f16x8* __restrict__ wf = a.wfrag + (size_t)cls * ksteps_max(CIN, MODE >= 1) * MT * 128 + lane;
 
   // B operand of k-step s for this lane: 8 consecutive input channels of one tap at this lane's voxel
   auto load_b = [&](int s, float* x) {
@@ -116,11 +135,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Args a) {
     if (MODE == 0) {
       const int kz = t / 9, ky = (t / 3) % 3, kx = t % 3;
       iz = zb + kz; iy = yb + ky; ix = xb + kx;
-    } else {
+    } else if (MODE == 1) {
       const int nx = 1 + px, ny = 1 + py;
       int k_, dz, dy, dx;
       deconv_tap(pz, t / (nx * ny), &k_, &dz); deconv_tap(py, (t / nx) % ny, &k_, &dy); deconv_tap(px, t % nx, &k_, &dx);
       iz = zb + dz; iy = yb + dy; ix = xb + dx;
+    } else {
+      const int ny = 1 + py, ab = t >> 1;
+      int k_, dz, dy;
+      deconv_tap(pz, ab / ny, &k_, &dz); deconv_tap(py, ab % ny, &k_, &dy);
+      iz = zb + dz; iy = yb + dy; ix = xb + (t & 1);
     }
     const bool ok = col_ok && t < ntaps && (unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
     const float* p = a.in + (size_t)ci0 * chan_in + ((size_t)(ok ? iz : 0) * a.Hi + (ok ? iy : 0)) * a.Wi + (ok ? ix : 0);
@@ -154,12 +178,17 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Args a) {
   }
   if (!col_ok) return;
   const size_t chan_out = (size_t)a.Do * a.Ho * a.Wo;
-  const size_t vox = ((size_t)zo * a.Ho + yo) * a.Wo + xo;
+  size_t vox = ((size_t)zo * a.Ho + yo) * a.Wo + xo;
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int co = 16 * m + 4 * g + j;           // accumulator row of v_mfma_f32_16x16x32: 4 * (lane >> 4) + j
+      int co = 16 * m + 4 * g + j;                 // accumulator row of v_mfma_f32_16x16x32: 4 * (lane >> 4) + j
+      if (MODE == 2) {                             // rows [Cout, 2 Cout): the odd-x outputs (Cout is a multiple of 4)
+        const int odd = co >= a.Cout ? 1 : 0;
+        co -= odd * a.Cout;
+        vox = ((size_t)zo * a.Ho + yo) * a.Wo + xo + odd;
+      }
       if (co >= a.Cout) continue;
       float r = acc[m][j] + (a.bias ? a.bias[co] : 0.0f);
       if (a.relu) r = __builtin_fmaxf(r, 0.0f);
@@ -188,7 +217,9 @@ static bool launch_cin(const Args& a, int Cin, int MT, long long tiles, hipStrea
   }
 }
 
-static int m_tiles(int Cout) { return Cout <= 16 ? 1 : (Cout <= 32 ? 2 : 4); }
+static int m_tiles(int rows) { return rows <= 16 ? 1 : (rows <= 32 ? 2 : 4); }
+// the transposed form pairs the x-parities when both fit the 64 output rows of a wave and rows split on lanes' groups of 4
+static int deconv_mode(int Cout) { return (Cout <= 32 && Cout % 4 == 0) ? 2 : 1; }
 
 }  // namespace convgemm
 }  // namespace svs
@@ -202,14 +233,16 @@ int svs_conv3d_gemm_supported(int Cin, int Cout) { return (Cin == 8 || Cin == 16
 
 size_t svs_conv3d_gemm_wfrag_bytes(int Cin, int Cout, int transposed) {
   if (!svs_conv3d_gemm_supported(Cin, Cout)) return 0;
-  return (size_t)(transposed ? 8 : 1) * ksteps_max(Cin, transposed != 0) * m_tiles(Cout) * 128 * sizeof(f16x8);
+  const int mode = transposed ? deconv_mode(Cout) : 0;
+  return (size_t)(mode == 1 ? 8 : (mode == 2 ? 4 : 1)) * ksteps_max(Cin, mode != 0) * m_tiles(mode == 2 ? 2 * Cout : Cout) * 128 * sizeof(f16x8);
 }
 
 int svs_conv3d_gemm_pack(const float* weight, int Cin, int Cout, int transposed, void* wfrag, void* hip_stream) {
   if (!weight || !wfrag || !svs_conv3d_gemm_supported(Cin, Cout)) { set_error("svs_conv3d_gemm_pack: bad argument"); return SVS_EINVAL; }
-  const int MT = m_tiles(Cout);
-  const long long total = (long long)(transposed ? 8 : 1) * ksteps_max(Cin, transposed != 0) * MT * 64;
-  pack_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)hip_stream>>>(weight, Cin, Cout, transposed != 0, MT, (f16x8*)wfrag);
+  const int mode = transposed ? deconv_mode(Cout) : 0;
+  const int MT = m_tiles(mode == 2 ? 2 * Cout : Cout);
+  const long long total = (long long)(mode == 1 ? 8 : (mode == 2 ? 4 : 1)) * ksteps_max(Cin, mode != 0) * MT * 64;
+  pack_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)hip_stream>>>(weight, Cin, Cout, mode, MT, (f16x8*)wfrag);
   return check_launch("svs_conv3d_gemm_pack");
 }
 
@@ -221,11 +254,12 @@ int svs_conv3d_gemm(const float* in, const void* wfrag, const float* bias, const
   a.in = in; a.wfrag = (const f16x8*)wfrag; a.bias = bias; a.skip = skip; a.out = out; a.Cout = Cout;
   a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.stride = stride; a.relu = relu;
   hipStream_t s = (hipStream_t)hip_stream;
-  const int MT = m_tiles(Cout);
+  int MT = m_tiles(Cout);
   if (transposed) {
     a.Do = 2 * Di; a.Ho = 2 * Hi; a.Wo = 2 * Wi;
     a.xtiles = (Wi + 15) / 16; a.rows = Di * Hi;
-    launch_cin<1>(a, Cin, MT, 8LL * a.rows * a.xtiles, s);
+    if (deconv_mode(Cout) == 2) { MT = m_tiles(2 * Cout); launch_cin<2>(a, Cin, MT, 4LL * a.rows * a.xtiles, s); }
+    else launch_cin<1>(a, Cin, MT, 8LL * a.rows * a.xtiles, s);
   } else {
     a.Do = (Di - 1) / stride + 1; a.Ho = (Hi - 1) / stride + 1; a.Wo = (Wi - 1) / stride + 1;
     a.xtiles = (a.Wo + 15) / 16; a.rows = a.Do * a.Ho;

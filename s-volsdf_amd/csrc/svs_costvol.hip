@@ -334,23 +334,52 @@ __global__ __launch_bounds__(kConvThreads) void deconv3d_kernel(ConvArgs a) {
 }
 
 // ---- softmax over D, depth regression, photometric confidence (CasMVSNet.py:648-663) ----------------------------
-__global__ void prob_depth_conf_kernel(const float* __restrict__ reg, const float* __restrict__ depth_values, int D, int HW,
-                                       float* __restrict__ prob, float* __restrict__ depth, float* __restrict__ conf,
-                                       int* __restrict__ index) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= HW) return;
+// 256 threads = 256/DS consecutive pixels x DS interleaved depth slices (slice sl owns d = sl, sl + DS, ...): at stage 1
+// there are only 128 x 160 pixels, one thread per pixel would leave most of the chip idle behind 3 x 192 serial loads.
+// Partial maxima / sums meet in LDS and are combined in slice order (deterministic).
+template <int DS>
+__global__ __launch_bounds__(256) void prob_depth_conf_kernel(const float* __restrict__ reg, const float* __restrict__ depth_values,
+                                                              int D, int HW, float* __restrict__ prob, float* __restrict__ depth,
+                                                              float* __restrict__ conf, int* __restrict__ index) {
+  constexpr int PX = 256 / DS;
+  __shared__ float red[3][DS][PX];
+  const int lp = threadIdx.x % PX, sl = threadIdx.x / PX;
+  const int p = blockIdx.x * PX + lp;
+  const bool live = p < HW;
   float m = -__builtin_inff();
-  for (int d = 0; d < D; ++d) m = __builtin_fmaxf(m, reg[(size_t)d * HW + p]);
+  if (live) for (int d = sl; d < D; d += DS) m = __builtin_fmaxf(m, reg[(size_t)d * HW + p]);
+  if (DS > 1) {
+    red[0][sl][lp] = m;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < DS; ++k) m = __builtin_fmaxf(m, red[0][k][lp]);
+  }
   float s = 0.0f;
-  for (int d = 0; d < D; ++d) s += __expf(reg[(size_t)d * HW + p] - m);
+  if (live) for (int d = sl; d < D; d += DS) s += __expf(reg[(size_t)d * HW + p] - m);
+  if (DS > 1) {
+    red[1][sl][lp] = s;
+    __syncthreads();
+    s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < DS; ++k) s += red[1][k][lp];
+  }
   const float inv = 1.0f / s;
   float dep = 0.0f, idxf = 0.0f;
-  for (int d = 0; d < D; ++d) {
+  if (live) for (int d = sl; d < D; d += DS) {
     const float pr = __expf(reg[(size_t)d * HW + p] - m) * inv;
     prob[(size_t)d * HW + p] = pr;
     dep += pr * depth_values[(size_t)d * HW + p];
     idxf += pr * (float)d;
   }
+  if (DS > 1) {
+    __syncthreads();                          // red[0] is read by every slice above
+    red[0][sl][lp] = dep; red[2][sl][lp] = idxf;
+    __syncthreads();
+    dep = 0.0f; idxf = 0.0f;
+#pragma unroll
+    for (int k = 0; k < DS; ++k) { dep += red[0][k][lp]; idxf += red[2][k][lp]; }
+  }
+  if (!live || sl != 0) return;
   int idx = (int)idxf;                       // .long() truncation
   idx = idx < 0 ? 0 : (idx > D - 1 ? D - 1 : idx);
   float c = 0.0f;                            // p[idx-1] + p[idx] + p[idx+1] + p[idx+2], zero padded
@@ -504,8 +533,11 @@ int svs_prob_depth_conf(const float* reg, const float* depth_values, int D, int 
   if (!reg || !depth_values || !prob || !depth || !conf || D < 1 || H < 1 || W < 1) {
     set_error("svs_prob_depth_conf: bad argument"); return SVS_EINVAL;
   }
-  prob_depth_conf_kernel<<<(H * W + 255) / 256, 256, 0, (hipStream_t)hip_stream>>>(reg, depth_values, D, H * W, prob,
-                                                                                  depth, conf, index);
+  hipStream_t s = (hipStream_t)hip_stream;
+  const int HW = H * W;
+  if (D >= 64) prob_depth_conf_kernel<8><<<(HW + 31) / 32, 256, 0, s>>>(reg, depth_values, D, HW, prob, depth, conf, index);
+  else if (D >= 16) prob_depth_conf_kernel<4><<<(HW + 63) / 64, 256, 0, s>>>(reg, depth_values, D, HW, prob, depth, conf, index);
+  else prob_depth_conf_kernel<1><<<(HW + 255) / 256, 256, 0, s>>>(reg, depth_values, D, HW, prob, depth, conf, index);
   return check_launch("svs_prob_depth_conf");
 }
 

@@ -1,4 +1,5 @@
-"""per-layer timing of the cost-regularisation U-Net at stage-1 size (C=32, 192x128x160)"""
+"""per-layer timing of the cost-regularisation U-Net at the three stage sizes of config 3
+(C=32, 192x128x160; C=16, 32x256x320; C=8, 8x512x640).  usage: python tools/bench_conv.py [stage]"""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "s-volsdf_amd"), os.path.join(ROOT, "tests", "golden")]
@@ -11,8 +12,10 @@ def t(fn, n=5):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-D, H, W = 192, 128, 160
-for name, cin, cout, (d, h, w), stride, tr in (("conv0", 32, 8, (D, H, W), 1, False), ("conv1", 8, 16, (D, H, W), 2, False),
+STAGE = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+C0, D, H, W = {1: (32, 192, 128, 160), 2: (16, 32, 256, 320), 3: (8, 8, 512, 640)}[STAGE]
+tot = 0.0
+for name, cin, cout, (d, h, w), stride, tr in (("conv0", C0, 8, (D, H, W), 1, False), ("conv1", 8, 16, (D, H, W), 2, False),
                                                 ("conv2", 16, 16, (D // 2, H // 2, W // 2), 1, False), ("conv3", 16, 32, (D // 2, H // 2, W // 2), 2, False),
                                                 ("conv4", 32, 32, (D // 4, H // 4, W // 4), 1, False), ("conv5", 32, 64, (D // 4, H // 4, W // 4), 2, False),
                                                 ("conv6", 64, 64, (D // 8, H // 8, W // 8), 1, False), ("conv7", 64, 32, (D // 8, H // 8, W // 8), 2, True),
@@ -24,4 +27,6 @@ for name, cin, cout, (d, h, w), stride, tr in (("conv0", 32, 8, (D, H, W), 1, Fa
     ms = t(lambda: costvol.conv3d(x, wt, b, stride=stride, transposed=tr))
     od = (d * 2, h * 2, w * 2) if tr else ((d - 1) // stride + 1, (h - 1) // stride + 1, (w - 1) // stride + 1)
     macs = od[0] * od[1] * od[2] * cout * cin * (27 / 8 if tr else 27)
+    tot += ms
     print(f"{name:7s} {cin:3d}->{cout:3d} {ms:7.3f} ms  {2 * macs / ms / 1e9:7.1f} TFLOP/s")
+print(f"sum {tot:.3f} ms")
