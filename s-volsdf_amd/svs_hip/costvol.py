@@ -1,5 +1,6 @@
 """torch-tensor wrappers for the CasMVSNet cost-volume kernels (csrc/svs_costvol.hip)."""
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -147,7 +148,7 @@ def conv3d(x, weight, bias=None, skip=None, stride=1, transposed=False, relu=Tru
     x = _f32(x)
     Cin, D, H, W = x.shape
     Cout = weight.shape[2]
-    if not transposed and stride == 1 and Cin in (8, 16, 32) and Cout <= 16:
+    if not transposed and stride == 1 and Cin in (8, 16, 32) and Cout <= 16 and not os.environ.get("SVS_CONV_RING_OFF"):
         frag = mfma_weight_fragments(weight)
         out = torch.empty((Cout, D, H, W), device=x.device)
         _lib.check(L.svs_conv3d_mfma(_ptr(x), _ptr(frag), _ptr(bias), _ptr(skip), _ptr(out), Cin, Cout, D, H, W,
