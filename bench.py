@@ -46,7 +46,9 @@ def main():
     ap.add_argument("--model", choices=["dtu", "bmvs"], default="dtu",
                     help="dtu: VolSDFNetwork (configs[1], the headline metric); bmvs: VolSDFNetworkBG, fg + inverted-sphere "
                          "background (config 4), train mode only")
-    ap.add_argument("--groups", choices=["auto", "none"], default="none", help="ray groups on concurrent streams")
+    ap.add_argument("--groups", choices=["auto", "none"], default="auto",
+                    help="auto: the batch runs as two ray groups on concurrent streams, the first sized to whole rounds of "
+                         "256 workgroups, so that the last partial round of every launch overlaps (results do not depend on it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -96,7 +98,7 @@ def main():
     orig = ops.sdf_outputs
 
     def timed_sdf_outputs(pk, src, *a, **k):
-        if src.n < R * 80 or not ev_on[0]:
+        if src.S < 64 or not ev_on[0]:             # the sampler's forward-only launches are not this kernel
             return orig(pk, src, *a, **k)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -132,8 +134,8 @@ def main():
     def step():
         if train:
             r = ts(inp, gt, mvs=mvs)
-            if ev_on[0] and ts.bwd[0].timer_events:
-                wg_ev.append(ts.bwd[0].timer_events)
+            if ev_on[0]:
+                wg_ev.extend(b.timer_events for b in ts.bwd if b.timer_events)
             return r
         with torch.no_grad():
             return model(inp, fast=1)
@@ -141,7 +143,8 @@ def main():
     for _ in range(args.warmup):
         step()
     if train:
-        ts.bwd[0].time_wgrad = True
+        for b in ts.bwd:
+            b.time_wgrad = True
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -162,7 +165,11 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
-        n_pts = ev[0][2]
+        # per-launch averages over ALL launches of the kernel in the timed region (what rocprofv3's kernel stats
+        # average too): with ray groups there are two launches of different size per step, on concurrent streams
+        launches = len(ev) / args.steps
+        n_pts = float(np.mean([e[2] for e in ev]))
+        pts_step = int(round(n_pts * launches))
         k_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
         achieved = n_pts * 2 * F_SDF / (k_ms * 1e-3)
         S = ev[0][3]
@@ -176,7 +183,7 @@ def main():
         kname = "svs::mlp::sdf_full_h2_kernel" if h2 else "svs::mlp::sdf_full_kernel"
         roof_full = {"bound": "mfma", "kernel": kname + " (SDF MLP forward + input gradient + features)",
                      "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
-                     "frac": achieved / peak, "traffic": None, "kernel_ms": k_ms, "launches_per_step": 1,
+                     "frac": achieved / peak, "traffic": None, "kernel_ms": k_ms, "launches_per_step": launches,
                      "points_per_launch": n_pts, "flop_per_point": 2 * F_SDF,
                      "peak_note": ("algorithmic float32 FLOP; fp16x2 evaluates each product as three fp16 MFMA products: "
                                    "peak = 2500 / 3 TFLOP/s" if h2 else "dense float32 MFMA peak")}
@@ -197,14 +204,15 @@ def main():
             # the SDF weight gradients dW_l = abar_l h_l^T + ghat_l u_l^T (l = 0..7) and the feature head.  fp16x2: ONE
             # launch, HBM-bound: every operand block (32 KiB per 32 points) is read once; float32: 9 launches, MFMA-bound
             w_ms = float(np.mean([a.elapsed_time(b) for a, b in wg_ev]))
-            n_tiles, n_main_tiles = (n_pts + 31) // 32, R * S // 32
-            w_bytes = (8 * 4 * n_tiles + 2 * n_main_tiles) * 32768
-            w_flop = (2 * 2 * (F_SDF // 2 - 257 * 256) + 2 * 256 * 256) * n_pts      # algorithmic: 2 pairs x 2 x rows x cols
+            w_launches = len(wg_ev) / args.steps
+            n_tiles, n_main_tiles = (pts_step + 31) // 32, R * S // 32
+            w_bytes = (8 * 4 * n_tiles + 2 * n_main_tiles) * 32768 / w_launches       # per launch
+            w_flop = (2 * 2 * (F_SDF // 2 - 257 * 256) + 2 * 256 * 256) * pts_step / w_launches   # algorithmic: 2 pairs x 2 x rows x cols
             if h2:
-                roof_w = {"bound": "hbm", "kernel": wname + " (all SDF weight gradients, 1 launch per step)",
+                roof_w = {"bound": "hbm", "kernel": wname + " (all SDF weight gradients of a ray group in one launch)",
                           "achieved": w_bytes / (w_ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
                           "frac": w_bytes / (w_ms * 1e-3) / PEAK_HBM, "traffic": traffic["wgrad"], "kernel_ms": w_ms,
-                          "launches_per_step": 1, "bytes_per_launch": w_bytes, "flop_per_launch": w_flop}
+                          "launches_per_step": w_launches, "bytes_per_launch": w_bytes, "flop_per_launch": w_flop}
             else:
                 roof_w = {"bound": "mfma", "kernel": wname + " (SDF weight gradients, 9 launches per step)",
                           "achieved": w_flop / (w_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
@@ -212,7 +220,7 @@ def main():
                           "launches_per_step": 9, "flop_per_step": w_flop}
             roof_w["traffic_source"] = src_prof
             # the dominant kernel is the one with the larger total time per step
-            roofline = dict(roof_w, other=roof_full) if w_ms > k_ms else dict(roof_full, other=roof_w)
+            roofline = dict(roof_w, other=roof_full) if w_ms * w_launches > k_ms * launches else dict(roof_full, other=roof_w)
         line = {
             "metric": "rendered rays/sec (1024-ray batch, 128 samples)",
             "value": world * R * args.steps / dt,
@@ -235,6 +243,8 @@ def main():
                        "mode": args.mode,
                        "mlp_precision": ("fp16x2: two-piece fp16 operands on v_mfma_f32_32x32x16_f16, float32 accumulation "
                                          "(float32-class accuracy, same parity bounds)" if h2 else "float32 MFMA"),
+                       "ray_groups": ([list(g) for g in ts.split_rays(R, S)] if (train and args.groups == "auto" and args.model == "dtu")
+                                      else [[0, R]]),
                        "rays_per_gpu": R, "flop_per_ray": flop_per_ray,
                        "model_flops_per_s": world * R * args.steps / dt * flop_per_ray},
             "roofline": roofline,

@@ -92,18 +92,40 @@ def allreduce_flat_grad(flat_grad, world):
     return flat_grad
 
 
+class _GroupedOutputs(dict):
+    """Model outputs of a step that ran as ray groups: per-ray tensors are concatenated in ray order on first access
+    (the step itself never needs the merged tensors; logging does, every 50 steps)."""
+
+    def __init__(self, results):
+        super().__init__()
+        self._parts = [r[1] for r in results]
+
+    def __missing__(self, key):
+        vals = [p[key] for p in self._parts]
+        self[key] = torch.cat(vals, 0) if torch.is_tensor(vals[0]) and vals[0].dim() > 0 else vals[0]
+        return self[key]
+
+    def __contains__(self, key):
+        return key in self._parts[0]
+
+    def keys(self):
+        return self._parts[0].keys()
+
+
 class TrainStep:
     """VolOpt.train_step (volsdf/vsdf.py:196-235) for one batch, on the HIP path end to end:
     forward -> MVS prior lookup -> fused loss (+ output gradients) -> compositing / MLP backward ->
     [gradient all-reduce] -> fused clip + guard + Adam.
 
-    Ray groups (groups="auto", off by default).  Every stage before the weight-gradient reduction is local to a ray,
-    so the batch can be processed as ray groups on concurrent HIP streams: the first group sized so that each of
-    its fused-MLP launches fills the 256 CUs a whole number of times, the rest on a second stream.  Results do not
-    depend on the grouping (same random draws per ray, loss means over the whole batch; only the float-atomic
-    summation order of the weight gradients varies).  Measured on MI355X (tools/ab_groups.py, interleaved A/B):
-    10.97 ms/step ungrouped vs 11.10 ms grouped -- the dispatcher does not back-fill the tail round across queues,
-    so the default stays ungrouped; the tail needs a finer work unit instead."""
+    Ray groups (groups="auto").  Every stage before the weight-gradient reduction is local to a ray, so the batch can
+    be processed as ray groups on concurrent HIP streams: the first group sized so that each of its fused-MLP launches
+    fills the 256 CUs a whole number of times (1024 rays x 100 points = 800 workgroups = 3.125 rounds otherwise: the last
+    round of every launch runs on 32 CUs), the rest on a second stream whose launches overlap with the first group's.
+    Results do not depend on the grouping: train mode samples with fast = 1 (one sampler iteration, no batch-global
+    convergence decision), every ray keeps its own random draws, the loss means are over the whole batch; only the
+    float-atomic summation order of the weight gradients varies, as it does between any two runs.  Measured on MI355X
+    (tools/ab_groups.py, interleaved A/B in one process): 5.05 ms/step ungrouped, 4.81 ms "auto", 4.78 ms two halves,
+    4.94 ms three streams, 5.19 ms four (more launches than the host thread can enqueue ahead)."""
 
     def __init__(self, model, loss, lr=5e-4, grad_clip=True, world=1, rank=0, groups=None):
         from .train import MlpBackward, TrainStreams, WGradAccum
@@ -132,9 +154,10 @@ class TrainStep:
         self.groups = groups
         self.tstreams = TrainStreams(dev)
         self.accum = WGradAccum(dev)
-        self.bwd = [MlpBackward(dev, self.tstreams, self.accum) for _ in range(2)]
-        self.side = torch.cuda.Stream(device=dev)
-        self.d_beta = torch.zeros(2, device=dev)
+        self._new_bwd = lambda: MlpBackward(dev, self.tstreams, self.accum)
+        self.bwd = [self._new_bwd()]                    # one scratch set and one stream per concurrent ray group
+        self.sides = []
+        self.d_beta = torch.zeros(8, device=dev)
 
     @staticmethod
     def split_rays(R, S, n_cu=256, wg_points=128):
@@ -164,6 +187,13 @@ class TrainStep:
         dev = uv.device
         S = m.ray_sampler.N_samples + m.ray_sampler.N_samples_extra + 2 - (1 if self.is_bg else 0)
         groups = self.split_rays(R, S) if self.groups == "auto" else (self.groups or [(0, R)])
+        if self.is_bg and self.groups == "auto":
+            groups = [(0, R)]
+        if len(groups) > self.d_beta.numel():
+            raise ValueError("at most %d ray groups" % self.d_beta.numel())
+        while len(self.bwd) < len(groups):
+            self.bwd.append(self._new_bwd())
+            self.sides.append(torch.cuda.Stream(device=dev))
         rng = m.draw_train_rng(R, dev)
         m.packed_mlp()                                   # pack once, before the streams fork
         sdf_p, rgb_p = m.mlp_params()
@@ -182,7 +212,7 @@ class TrainStep:
         gt_rgb, gt_smooth = ground_truth["rgb"].reshape(-1, 3), ground_truth["rgb_smooth"].reshape(-1, 3)
         results, joins, holds = [], [], []
         for gi, (lo, hi) in enumerate(groups):
-            stream = main if gi == 0 else self.side
+            stream = main if gi == 0 else self.sides[gi - 1]
             with torch.cuda.stream(stream):
                 if gi:
                     stream.wait_event(fork)
@@ -208,7 +238,7 @@ class TrainStep:
                                                              m.density.beta, m.density.beta_min_value, g["rgb_values"],
                                                              g["weights"], g["depth_values"])
                 self.d_beta[gi:gi + 1].copy_(d_beta)
-                self.bwd[min(gi, 1)].accumulate(keep, d_rgb, d_sdf, g["grad_theta"])
+                self.bwd[gi].accumulate(keep, d_rgb, d_sdf, g["grad_theta"])
                 results.append((lo_out, out))
                 holds.append((keep, g, d_sdf, d_rgb, inp, gt))
                 if gi:
@@ -224,5 +254,6 @@ class TrainStep:
         self.opt.step()
         m.invalidate_packed()          # the fused kernel bypasses torch's version counters
         self._hold = holds
+        self._results = results
         loss_out = {k: sum(r[0][k] for r in results) for k in results[0][0]}
-        return loss_out, results[0][1]
+        return loss_out, (results[0][1] if len(results) == 1 else _GroupedOutputs(results))

@@ -134,7 +134,7 @@ class VolOpt():
         self.model.cuda()
         self.loss = utils.get_class(self.conf.get_string('train.loss_class'))(**self.conf.get_config('loss'))
         self.lr = self.conf.get_float('train.learning_rate')
-        self.step_fn = TrainStep(self.model, self.loss, lr=self.lr, grad_clip=bool(self.hparams.grad_clip))
+        self.step_fn = TrainStep(self.model, self.loss, lr=self.lr, grad_clip=bool(self.hparams.grad_clip), groups="auto")
         self.optimizer = AdamStateView(self.step_fn.opt)
 
         # load ckpt

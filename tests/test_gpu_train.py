@@ -164,3 +164,48 @@ def test_nan_guard_drops_update(dev):
     torch.manual_seed(0)
     g1 = (after1.cpu() - ref.detach())  # recover step-1 direction: sign pattern only
     assert (g1.abs() > 0).all()
+
+
+@pytest.mark.parametrize("groups", ["auto", [(0, 192), (192, 512)], [(0, 96), (96, 352), (352, 512)]])
+def test_ray_groups_do_not_change_the_step(dev, groups):
+    """The step run as ray groups on concurrent streams == the ungrouped step: train mode samples with fast = 1 (no
+    batch-global sampler decision), every ray keeps its own random draws and the loss means are over the whole batch.
+    Only the float-atomic summation order of the weight gradients differs (as between any two runs)."""
+    from svs_hip.trainer import TrainStep
+    R = 512
+    K, pose = synth.make_camera()
+    inp = {"intrinsics": G(K, dev)[None], "uv": G(synth.make_uv(R, seed=3), dev)[None], "pose": G(pose, dev)[None]}
+    rs = np.random.default_rng(5)
+    gt = {"rgb": G(rs.uniform(0, 1, (1, R, 3)).astype(F32), dev), "rgb_smooth": G(rs.uniform(0, 1, (1, R, 3)).astype(F32), dev)}
+    views = synth.make_mvs_views(2)
+    mvs = dict(views=[dict(K=v["K"], c2w=v["c2w"], cost=G(v["cost"], dev), z_mvs=G(v["z_mvs"], dev)) for v in views], same_view=0,
+               img_res=(576, 768), inverse_depth=False)
+    runs = []
+    for gr in (None, groups):
+        m, loss = _setup(dev)
+        ts = TrainStep(m, loss, groups=gr)
+        if gr == "auto":
+            S = m.ray_sampler.N_samples + m.ray_sampler.N_samples_extra + 2
+            sp = ts.split_rays(1024, S)          # 1024 rays: the first group fills 3 rounds of 256 workgroups x 128 points
+            assert len(sp) == 2 and 0.98 * 3 * 256 * 128 < sp[0][1] * (S + 2) <= 3 * 256 * 128 and sp[1] == (sp[0][1], 1024)
+        torch.manual_seed(11)
+        rec = []
+        for step in range(2):
+            lo, out = ts(inp, gt, mvs=mvs)
+            rec.append(({k: float(v) for k, v in lo.items()}, ts.fp.grad.clone(), out["rgb_values"].clone(), out["weights"].clone()))
+        runs.append((rec, ts.fp.flat.clone()))
+    (a, pa), (b, pb) = runs
+    for step, ((la, ga, ra, wa), (lb, gb, rb, wb)) in enumerate(zip(a, b)):
+        for k in la:
+            assert la[k] == pytest.approx(lb[k], rel=1e-5, abs=1e-8), k
+        if step == 0:
+            assert torch.equal(ra, rb) and torch.equal(wa, wb)             # same parameters: per-ray results bit-identical
+        else:                                                              # parameters differ by the atomics' rounding
+            assert float((ra - rb).abs().max()) <= 1e-4 and float((wa - wb).abs().max()) <= 1e-4
+        # fp16x2 weight gradients: each launch scales its operands by the (power-of-two) maximum published so far, which
+        # depends on the grouping (the 16-ray reference fixture of test_train_steps_fused is too small to split: a group
+        # needs rays * samples to be a multiple of 32)
+        assert float((ga - gb).abs().max()) <= 1e-4 * float(ga.abs().max())
+    # Adam moves an entry by ~lr * g/|g|: entries whose gradient is numerically zero may take the other sign
+    d = (pa - pb).abs()
+    assert float(d.max()) <= 2.1e-3 and float((d > 1e-5).float().mean()) < 1e-3

@@ -22,12 +22,17 @@ for j, dx in enumerate((0.0, 0.3, -0.3)):
     views.append(dict(K=Kj, c2w=Pj, cost=prob, z_near=zm[0].contiguous(), z_far=zm[-1].contiguous()))
 mvs = dict(views=views, same_view=0, img_res=(576, 768), inverse_depth=False)
 cfgs = {}
-for name, groups in (("none", None), ("auto", "auto")):
+for name, groups in (("none", None), ("auto", "auto"), ("halves", [(0, 512), (512, 1024)]), ("q3+1", [(0, 768), (768, 1024)]),
+                     ("thirds", [(0, 352), (352, 704), (704, 1024)]), ("quarters", [(0, 256), (256, 512), (512, 768), (768, 1024)]),
+                     ("3/8-3/8-1/4", [(0, 384), (384, 768), (768, 1024)]), ("eighths", [(128 * i, 128 * (i + 1)) for i in range(8)])):
     m = VolSDFNetwork(dtu_model_conf()); m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_params(0).items()}); m.to(dev).train()
     loss = VolSDFLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, rgb_weight=1.0, mvs_weight=1.0, sparse_weight=1.0, anneal_rgb=200, gce=0.5, confi=1e-3)
+    if groups == "auto-rev":
+        a = TrainStep.split_rays(R, 98)
+        groups = [(0, R - a[0][1]), (R - a[0][1], R)] if len(a) == 2 else None
     cfgs[name] = TrainStep(m, loss, groups=groups)
 for ts in cfgs.values():
-    for _ in range(5):
+    for _ in range(12):
         ts(inp, gt, mvs=mvs)
 torch.cuda.synchronize()
 res = {k: [] for k in cfgs}
