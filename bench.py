@@ -243,7 +243,7 @@ def main():
                        "mode": args.mode,
                        "mlp_precision": ("fp16x2: two-piece fp16 operands on v_mfma_f32_32x32x16_f16, float32 accumulation "
                                          "(float32-class accuracy, same parity bounds)" if h2 else "float32 MFMA"),
-                       "ray_groups": ([list(g) for g in ts.split_rays(R, S)] if (train and args.groups == "auto" and args.model == "dtu")
+                       "ray_groups": ([list(g) for g in ts.split_rays(R, S)] if (train and args.groups == "auto")
                                       else [[0, R]]),
                        "rays_per_gpu": R, "flop_per_ray": flop_per_ray,
                        "model_flops_per_s": world * R * args.steps / dt * flop_per_ray},

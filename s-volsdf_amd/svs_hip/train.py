@@ -224,7 +224,7 @@ class BgBackward:
         self.dbk = torch.zeros(11, 256, device=device)
         self.row0 = torch.zeros(257, device=device)
         self.absmax = torch.zeros(4, device=device)
-        self._n = None
+        self._scratch = {}          # per concurrent ray group: (n, zbuf, feat_bar, abuf, sbar); the accumulators are shared
 
     def pack(self, sdf_wb, rgb_wb):
         L = _lib.load()
@@ -238,30 +238,31 @@ class BgBackward:
     def zero(self):
         self.dWk.zero_(); self.dbk.zero_(); self.row0.zero_(); self.absmax.zero_()
 
-    def _alloc(self, n):
-        if self._n == n:
-            return
+    def _alloc(self, n, slot):
+        cur = self._scratch.get(slot)
+        if cur is not None and cur[0] == n:
+            return cur[1:]
         L = _lib.load()
         z = lambda nbytes: torch.zeros(nbytes // 4, device=self.dev)
-        self.zbuf = z(L.svs_block_bytes(n, 2))          # zero-initialised once: only 4 + 1 tiles are ever written
-        self.feat_bar = z(L.svs_block_bytes(n, 1))
-        self.abuf = z(L.svs_block_bytes(n, 8))
-        self.sbar = z(L.svs_block_bytes(n, 1) // (128 * 2))
-        self._n = n
+        cur = (n, z(L.svs_block_bytes(n, 2)),          # zbuf: zero-initialised once, only 4 + 1 tiles are ever written
+               z(L.svs_block_bytes(n, 1)), z(L.svs_block_bytes(n, 8)), z(L.svs_block_bytes(n, 1) // (128 * 2)))
+        self._scratch[slot] = cur
+        return cur[1:]
 
-    def accumulate(self, keep, d_bg_rgb, d_bg_out0):
-        """keep: what ops.bg_sdf_eval / ops.bg_rgb_eval stored; d_bg_rgb (P,3), d_bg_out0 (P,1)."""
+    def accumulate(self, keep, d_bg_rgb, d_bg_out0, slot=0):
+        """keep: what ops.bg_sdf_eval / ops.bg_rgb_eval stored; d_bg_rgb (P,3), d_bg_out0 (P,1); slot: scratch set (one per
+        concurrent ray group)."""
         L = _lib.load()
         P = keep["bg_rgb"].shape[0]
-        self._alloc(P)
+        zbuf, feat_bar, abuf, sbar = self._alloc(P, slot)
         st = _stream()
         hbuf, ghat7, pebuf, rbuf, feat = keep["bg_hbuf"], keep["bg_ghat7"], keep["bg_pebuf"], keep["bg_rbuf"], keep["bg_feat"]
         d_bg_rgb, d_bg_out0 = _f32(d_bg_rgb), _f32(d_bg_out0)
-        _lib.check(L.svs_bg_rgb_bwd(P, _ptr(d_bg_rgb), _ptr(keep["bg_rgb"]), _ptr(rbuf), _ptr(self.rgb_stream), _ptr(self.zbuf),
-                                    _ptr(self.feat_bar), _ptr(self.absmax), st), "svs_bg_rgb_bwd")
-        _lib.check(L.svs_bg_sdf_bwd(P, _ptr(d_bg_out0), _ptr(self.feat_bar), _ptr(hbuf), _ptr(ghat7), _ptr(self.sdf_stream),
-                                    _ptr(self.abuf), _ptr(self.sbar), _ptr(self.absmax), st), "svs_bg_sdf_bwd")
-        _lib.check(L.svs_lin8_row0_grad(_ptr(hbuf), None, _ptr(self.sbar), P, _ptr(self.row0), st), "svs_lin8_row0_grad")
+        _lib.check(L.svs_bg_rgb_bwd(P, _ptr(d_bg_rgb), _ptr(keep["bg_rgb"]), _ptr(rbuf), _ptr(self.rgb_stream), _ptr(zbuf),
+                                    _ptr(feat_bar), _ptr(self.absmax), st), "svs_bg_rgb_bwd")
+        _lib.check(L.svs_bg_sdf_bwd(P, _ptr(d_bg_out0), _ptr(feat_bar), _ptr(hbuf), _ptr(ghat7), _ptr(self.sdf_stream),
+                                    _ptr(abuf), _ptr(sbar), _ptr(self.absmax), st), "svs_bg_sdf_bwd")
+        _lib.check(L.svs_lin8_row0_grad(_ptr(hbuf), None, _ptr(sbar), P, _ptr(self.row0), st), "svs_lin8_row0_grad")
         H8, A8, Z2 = 8 * KBLOCK, 8 * KBLOCK, 2 * KBLOCK
 
         def addr(x):
@@ -272,15 +273,16 @@ class BgBackward:
                                  addr(_off(self.dWk, slot * 256 * LDW)), addr(_off(self.dbk, slot * 256)),
                                  addr(_off(self.absmax, amax)))
 
-        jobs = [job(0, 0, _off(self.abuf, 0), A8, _ptr(pebuf), KBLOCK)]
+        jobs = [job(0, 0, _off(abuf, 0), A8, _ptr(pebuf), KBLOCK)]
         for l in range(1, 8):
-            jobs.append(job(l, 0, _off(self.abuf, l * KBLOCK), A8, _off(hbuf, (l - 1) * KBLOCK), H8))
-        jobs.append(job(8, 2, _ptr(self.feat_bar), KBLOCK, _off(hbuf, 7 * KBLOCK), H8))
-        jobs.append(job(9, 1, _off(self.zbuf, 0), Z2, _ptr(feat), KBLOCK, extra=_off(rbuf, KBLOCK), sx=self.BGRBUF))
-        jobs.append(job(10, 1, _off(self.zbuf, KBLOCK), Z2, _ptr(rbuf), self.BGRBUF))
+            jobs.append(job(l, 0, _off(abuf, l * KBLOCK), A8, _off(hbuf, (l - 1) * KBLOCK), H8))
+        jobs.append(job(8, 2, _ptr(feat_bar), KBLOCK, _off(hbuf, 7 * KBLOCK), H8))
+        jobs.append(job(9, 1, _off(zbuf, 0), Z2, _ptr(feat), KBLOCK, extra=_off(rbuf, KBLOCK), sx=self.BGRBUF))
+        jobs.append(job(10, 1, _off(zbuf, KBLOCK), Z2, _ptr(rbuf), self.BGRBUF))
         arr = (_lib.WGradJob * len(jobs))(*jobs)
         _lib.check(L.svs_wgrad_multi(ctypes.cast(arr, ctypes.c_void_p), len(jobs), F16X2, st), "svs_wgrad_multi(bg)")
-        self._hold = (d_bg_rgb, d_bg_out0)
+        self._hold = getattr(self, "_hold", {})
+        self._hold[slot] = (d_bg_rgb, d_bg_out0)
 
     def finalize(self, sdf_wb, rgb_wb, out=None):
         """kernel-order accumulators -> ([(grad_w, grad_b)] * 9, [(grad_w, grad_b)] * 2)"""

@@ -187,8 +187,6 @@ class TrainStep:
         dev = uv.device
         S = m.ray_sampler.N_samples + m.ray_sampler.N_samples_extra + 2 - (1 if self.is_bg else 0)
         groups = self.split_rays(R, S) if self.groups == "auto" else (self.groups or [(0, R)])
-        if self.is_bg and self.groups == "auto":
-            groups = [(0, R)]
         if len(groups) > self.d_beta.numel():
             raise ValueError("at most %d ray groups" % self.d_beta.numel())
         while len(self.bwd) < len(groups):
@@ -199,8 +197,6 @@ class TrainStep:
         sdf_p, rgb_p = m.mlp_params()
         self.tstreams.pack(sdf_p, rgb_p)
         if self.is_bg:
-            if len(groups) > 1:
-                raise NotImplementedError("ray groups are not wired for the background model")
             bg_sdf_wb, bg_rgb_wb = m.bg_params()
             self.bg_bwd.pack(bg_sdf_wb, bg_rgb_wb)
             self.bg_bwd.zero()
@@ -232,7 +228,7 @@ class TrainStep:
                         keep["z_vals"], keep["z_max"], keep["sdf"], keep["rgb_flat"], keep["depth_scale"], m.density.beta,
                         m.density.beta_min_value, keep["z_bg"], keep["bg_out0"], keep["bg_rgb"], g["rgb_values"],
                         g["weights"], g["depth_values"])
-                    self.bg_bwd.accumulate(keep, d_brgb, d_bo)
+                    self.bg_bwd.accumulate(keep, d_brgb, d_bo, slot=gi)
                 else:
                     d_sdf, d_rgb, d_beta = ops.composite_bwd(keep["z_vals"], keep["sdf"], keep["rgb_flat"], keep["depth_scale"],
                                                              m.density.beta, m.density.beta_min_value, g["rgb_values"],

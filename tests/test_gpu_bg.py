@@ -208,3 +208,34 @@ def test_bg_train_steps_fused(dev, golden_dir):
         assert max(rel.values()) < (3e-3 if step == 0 else 3e-2), rel
         prel = tensor_rel(step, "param", list(m.named_parameters()))
         assert max(prel.values()) < 2e-2, prel
+
+
+def test_bg_ray_groups_do_not_change_the_step(dev):
+    """VolSDFNetworkBG step as two ray groups on concurrent streams == the ungrouped step (first step: per-ray outputs
+    bit-identical, gradients up to the float-atomic order / per-launch operand scaling)."""
+    from svs_hip.trainer import TrainStep
+    from volsdf.model.loss import VolSDFLoss
+    R = 256
+    K, pose = synth.make_camera()
+    inp = {"intrinsics": G(K, dev)[None], "uv": G(synth.make_uv(R, seed=4), dev)[None], "pose": G(pose, dev)[None]}
+    rs = np.random.default_rng(6)
+    gt = {"rgb": G(rs.uniform(0, 1, (1, R, 3)).astype(np.float32), dev), "rgb_smooth": G(rs.uniform(0, 1, (1, R, 3)).astype(np.float32), dev)}
+    views = synth.make_mvs_views(2)
+    mvs = dict(views=[dict(K=v["K"], c2w=v["c2w"], cost=G(v["cost"], dev), z_mvs=G(v["z_mvs"], dev)) for v in views], same_view=0,
+               img_res=(576, 768), inverse_depth=False)
+    runs = []
+    for gr in (None, [(0, 160), (160, 256)]):
+        m = _model(dev, 0.1)
+        loss = VolSDFLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, rgb_weight=1.0, mvs_weight=1.0, sparse_weight=1.0,
+                          anneal_rgb=200, gce=0.5, confi=1e-3)
+        loss.iter_step = 250                                        # past the rgb annealing: the background nets get gradients
+        ts = TrainStep(m, loss, groups=gr)
+        torch.manual_seed(13)
+        lo, out = ts(inp, gt, mvs=mvs)
+        runs.append(({k: float(v) for k, v in lo.items()}, ts.fp.grad.clone(), out["rgb_values"].clone(), out["weights"].clone()))
+    (la, ga, ra, wa), (lb, gb, rb, wb) = runs
+    for k in la:
+        assert la[k] == pytest.approx(lb[k], rel=1e-5, abs=1e-8), k
+    assert torch.equal(ra, rb) and torch.equal(wa, wb)
+    assert float((ga - gb).abs().max()) <= 1e-4 * float(ga.abs().max())
+    assert float(ga.abs().max()) > 0
