@@ -55,7 +55,7 @@ def main():
     import numpy as np
     import torch
     import synth
-    from ref_shim import dtu_model_conf
+    from volsdf.utils.conf import dtu_model_conf
     from svs_hip import ops
     from svs_hip.trainer import TrainStep
     from volsdf.model.loss import VolSDFLoss
@@ -77,7 +77,7 @@ def main():
     R = args.rays
     params = synth.make_params(0)
     if args.model == "bmvs":
-        from ref_shim import bmvs_model_conf
+        from volsdf.utils.conf import bmvs_model_conf
         from volsdf.model.network_bg import VolSDFNetworkBG
         params = dict(params); params.update(synth.make_bg_params(0))
         model = VolSDFNetworkBG(bmvs_model_conf())

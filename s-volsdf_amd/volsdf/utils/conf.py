@@ -87,3 +87,33 @@ class Conf(dict):
 
     def get(self, key, default=None):
         return self._get(key, default)
+
+
+def dtu_model_conf(near=1e-4, beta=0.1):
+    """The `model` section the reference ships for DTU (config/vol/dtu.yaml:27-56 overlaid with config/ours.yaml:22-24):
+    what BASELINE configs[1] runs.  Used by bench.py, smoke() and the tests; a real run takes it from `args.vol.model`."""
+    return Conf(
+        feature_vector_size=256,
+        scene_bounding_sphere=3.0,
+        implicit_network=dict(d_in=3, d_out=1, dims=[256] * 8, geometric_init=True, bias=0.6, skip_in=[4], weight_norm=True,
+                              multires=6, sphere_scale=20.0),
+        rendering_network=dict(mode="idr", d_in=9, d_out=3, dims=[256] * 4, weight_norm=True, multires_view=1),
+        density=dict(params_init=dict(beta=beta), beta_min=0.0001),
+        ray_sampler=dict(near=near, N_samples=64, N_samples_eval=128, N_samples_extra=32, eps=0.1, beta_iters=10,
+                         max_total_iters=5),
+    )
+
+
+def bmvs_model_conf(beta=0.1):
+    """The `model` section for BlendedMVS (config/vol/bmvs.yaml:26-77): foreground + inverted-sphere background,
+    VolSDFNetworkBG (BASELINE configs[3])."""
+    conf = dtu_model_conf(near=0.0, beta=beta)
+    del conf["implicit_network"]["sphere_scale"]
+    conf["ray_sampler"].update(N_samples_inverse_sphere=32, add_tiny=1.0e-6)
+    conf["bg_network"] = dict(
+        feature_vector_size=256,
+        implicit_network=dict(d_in=4, d_out=1, dims=[256] * 8, geometric_init=False, bias=0.0, skip_in=[4], weight_norm=False,
+                              multires=10),
+        rendering_network=dict(mode="nerf", d_in=3, d_out=3, dims=[128], weight_norm=False, multires_view=4),
+    )
+    return conf

@@ -3,7 +3,9 @@
 Used ONLY by tests/golden/make_fixtures.py, in the build container, to emit golden
 arrays.  Nothing from /root/reference is copied: this file registers empty stub
 modules for third-party packages the image lacks and makes `.cuda()` an identity.
-It is never imported by the product, the tests or the bench.
+It is never imported by the product, the tests or the bench (they take the model
+configuration from volsdf.utils.conf; the copies below feed the REFERENCE's classes,
+whose `volsdf` package shadows this repository's while the fixtures are generated).
 """
 import sys
 import types

@@ -35,7 +35,7 @@ def _params():
 
 
 def _model(dev, beta):
-    from ref_shim import bmvs_model_conf
+    from volsdf.utils.conf import bmvs_model_conf
     from volsdf.model.network_bg import VolSDFNetworkBG
     m = VolSDFNetworkBG(bmvs_model_conf())
     sd = {k: torch.from_numpy(v) for k, v in _params().items()}

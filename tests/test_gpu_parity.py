@@ -226,7 +226,7 @@ def test_sampler_end_to_end(dev, ops, packed):
 # whole model through the reference's call surface
 # ------------------------------------------------------------------------------------------------------
 def _model(dev, beta):
-    from ref_shim import dtu_model_conf
+    from volsdf.utils.conf import dtu_model_conf
     from volsdf.model.network import VolSDFNetwork
     params = synth.make_params(0)
     m = VolSDFNetwork(dtu_model_conf())

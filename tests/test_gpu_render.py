@@ -15,7 +15,7 @@ def dev():
 
 
 def _model(dev, beta):
-    from ref_shim import dtu_model_conf
+    from volsdf.utils.conf import dtu_model_conf
     from volsdf.model.network import VolSDFNetwork
     params = synth.make_params(0)
     m = VolSDFNetwork(dtu_model_conf())

@@ -27,7 +27,7 @@ from rng_inject import inject_rng   # noqa: E402
 
 
 def _setup(dev):
-    from ref_shim import dtu_model_conf
+    from volsdf.utils.conf import dtu_model_conf
     from volsdf.model.loss import VolSDFLoss
     from volsdf.model.network import VolSDFNetwork
     params = synth.make_params(0)

@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (os.path.join(ROOT, "tests", "golden"), os.path.join(ROOT, "s-volsdf_amd")):
     sys.path.insert(0, p)
 import numpy as np, torch, synth
-from ref_shim import dtu_model_conf
+from volsdf.utils.conf import dtu_model_conf
 from svs_hip.trainer import TrainStep
 from volsdf.model.loss import VolSDFLoss
 from volsdf.model.network import VolSDFNetwork

@@ -11,7 +11,7 @@ for p in (os.path.join(ROOT, "tests", "golden"), os.path.join(ROOT, "s-volsdf_am
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import synth  # noqa: E402
-from ref_shim import dtu_model_conf  # noqa: E402
+from volsdf.utils.conf import dtu_model_conf  # noqa: E402
 from svs_hip import lib, ops  # noqa: E402
 from svs_hip.train import KBLOCK, MlpBackward, _off  # noqa: E402
 from volsdf.model.network import VolSDFNetwork  # noqa: E402
