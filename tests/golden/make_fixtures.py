@@ -455,15 +455,15 @@ def param_digest(named, seed=0, k=48):
     return out
 
 
-def fx_train_step():
+def fx_train_step(R=16, n_steps=3, name="train_step"):
     """Three optimisation steps of the reference: VolSDFNetwork + cost_mapping + VolSDFLoss + clip + guard + Adam
-    (volsdf/vsdf.py:196-219), 16 rays, injected random draws (seed = 100 + step)."""
+    (volsdf/vsdf.py:196-219), 16 rays, injected random draws (seed = 100 + step).  `train_step_r32`: two steps with 32
+    rays, the smallest batch that splits into two ray groups (a group needs rays * 98 samples to be a multiple of 32)."""
     from volsdf.vsdf import VolOpt
     from volsdf.model.loss import VolSDFLoss
     params = synth.make_params(seed=0)
     m = build_model(params, beta=0.1)
     m.train()
-    R = 16
     views = synth.make_mvs_views(5)
     K, pose = views[0]["K"], views[0]["c2w"]
     uv = synth.make_uv(R, seed=12, margin=0.2)
@@ -481,7 +481,7 @@ def fx_train_step():
     opt = torch.optim.Adam(m.parameters(), lr=5e-4)
     inp = {"intrinsics": T(K)[None], "uv": T(uv)[None], "pose": T(pose)[None]}
     arr = dict(uv=uv, rgb=gt["rgb"], rgb_smooth=gt["rgb_smooth"], mvs_seed=5)
-    for step in range(3):
+    for step in range(n_steps):
         draws = synth.make_train_rng(R, seed=100 + step)
         with inject_rng(draws):
             out = m(inp, fast=1)
@@ -500,7 +500,7 @@ def fx_train_step():
             arr[f"s{step}_grad_idx/{n}"] = idx.astype(np.int32); arr[f"s{step}_grad/{n}"] = val
         for n, (idx, val) in param_digest([(n, p.detach().numpy()) for n, p in m.named_parameters()], seed=10 + step).items():
             arr[f"s{step}_param_idx/{n}"] = idx.astype(np.int32); arr[f"s{step}_param/{n}"] = val
-    save("train_step", **arr)
+    save(name, **arr)
 
 
 def fx_train_step_bg():
@@ -650,7 +650,7 @@ def fx_chamfer():
 
 
 ALL = dict(fusion=fx_fusion, pfm=fx_pfm, chamfer=fx_chamfer, rays=fx_rays, sdf_mlp=fx_sdf_mlp, rgb_mlp=fx_rgb_mlp, density=fx_density, sampler=fx_sampler,
-           composite=fx_composite, forward=fx_forward, forward_bg=fx_forward_bg, cost_mapping=fx_cost_mapping, loss=fx_loss, casmvs=fx_casmvs, train_step=fx_train_step,
+           composite=fx_composite, forward=fx_forward, forward_bg=fx_forward_bg, cost_mapping=fx_cost_mapping, loss=fx_loss, casmvs=fx_casmvs, train_step=fx_train_step, train_step_r32=lambda: fx_train_step(32, 2, "train_step_r32"),
            train_step_bg=fx_train_step_bg)
 
 if __name__ == "__main__":

@@ -70,17 +70,21 @@ def _mvs(dev, g):
     return dict(views=dv, same_view=0, img_res=(576, 768), inverse_depth=False), views
 
 
-def test_train_steps_fused(dev, golden_dir):
-    """TrainStep (forward, lookup, fused loss, hand-written backward, fused clip+guard+Adam) x 3."""
+@pytest.mark.parametrize("fixture,groups", [("train_step", None), ("train_step_r32", None), ("train_step_r32", [(0, 16), (16, 32)])])
+def test_train_steps_fused(dev, golden_dir, fixture, groups):
+    """TrainStep (forward, lookup, fused loss, hand-written backward, fused clip+guard+Adam) against the reference's own
+    optimisation steps: 3 steps with 16 rays; 2 steps with 32 rays as one batch and as two ray groups on concurrent
+    streams (the default of bench.py / VolOpt at 1024 rays)."""
     from svs_hip.trainer import TrainStep
-    g = dict(np.load(os.path.join(golden_dir, "train_step.npz")))
+    g = dict(np.load(os.path.join(golden_dir, fixture + ".npz")))
     m, loss = _setup(dev)
-    ts = TrainStep(m, loss, lr=5e-4)
+    ts = TrainStep(m, loss, lr=5e-4, groups=groups)
     mvs, views = _mvs(dev, g)
     R = g["uv"].shape[0]
+    n_steps = 1 + max(int(k[1]) for k in g if k.startswith("s") and k[1].isdigit() and k[2] == "_")
     inp = {"intrinsics": G(views[0]["K"], dev)[None], "uv": G(g["uv"], dev)[None], "pose": G(views[0]["c2w"], dev)[None]}
     gt = {"rgb": G(g["rgb"], dev), "rgb_smooth": G(g["rgb_smooth"], dev)}
-    for step in range(3):
+    for step in range(n_steps):
         with inject_rng(synth.make_train_rng(R, seed=100 + step)):
             lo, out = ts(inp, gt, mvs=mvs)
         torch.cuda.synchronize()
@@ -204,7 +208,7 @@ def test_ray_groups_do_not_change_the_step(dev, groups):
             assert float((ra - rb).abs().max()) <= 1e-4 and float((wa - wb).abs().max()) <= 1e-4
         # fp16x2 weight gradients: each launch scales its operands by the (power-of-two) maximum published so far, which
         # depends on the grouping (the 16-ray reference fixture of test_train_steps_fused is too small to split: a group
-        # needs rays * samples to be a multiple of 32)
+        # needs rays * samples to be a multiple of 32; the 32-ray fixture pins the grouped step)
         assert float((ga - gb).abs().max()) <= 1e-4 * float(ga.abs().max())
     # Adam moves an entry by ~lr * g/|g|: entries whose gradient is numerically zero may take the other sign
     d = (pa - pb).abs()
