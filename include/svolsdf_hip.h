@@ -235,6 +235,14 @@ int svs_lin8_row0_grad(const float* hbuf, const float* ubuf, const float* sbar, 
 int svs_unpack_wgrad(const float* dWk, const float* dbk, int ldw, int map, int rows, int cols, int row_off,
                      const float* weight_v, const float* weight_g, const float* row0, float* grad_v, float* grad_g,
                      float* grad_b, void* hip_stream);
+/* the same for all layers of a step (<= 24 jobs) in ONE launch */
+typedef struct svs_unpack_job {
+  const float *dWk, *dbk;
+  int ldw, map, rows, cols, row_off;
+  const float *weight_v, *weight_g, *row0;
+  float *grad_v, *grad_g, *grad_b;
+} svs_unpack_job;
+int svs_unpack_wgrad_multi(const svs_unpack_job* jobs, int n_jobs, void* hip_stream);
 
 /* ---- a12  optimiser step ---------------------------------------------------------------------------------------
  * clip_grad_norm_(1.0) + NaN/Inf guard + Adam of VolOpt.train_step (volsdf/vsdf.py:214-219,454-463,101-102) on flat

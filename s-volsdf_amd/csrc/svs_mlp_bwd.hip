@@ -370,9 +370,7 @@ __device__ __forceinline__ int kernel_col(int map, int c) {
 }
 
 // one wave per parameter row
-__global__ __launch_bounds__(256) void unpack_wgrad_kernel(UnpackArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+__device__ __forceinline__ void unpack_row(const UnpackArgs& a, int o, int lane) {
   if (o >= a.rows) return;
   const float fac = (a.map == 1 || a.map == 3) ? 0.70710678118654752f : 1.0f;
   const bool is_row0 = a.row0 && o == 0;
@@ -400,6 +398,23 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(UnpackArgs a) {
     a.grad_v[(size_t)o * a.cols + c] = k1 * dweff(c) - k2 * a.v[(size_t)o * a.cols + c];
 }
 
+__global__ __launch_bounds__(256) void unpack_wgrad_kernel(UnpackArgs a) {
+  unpack_row(a, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+}
+
+// all layers of a step in one launch: block b belongs to the job whose block range contains it
+constexpr int kMaxUnpackJobs = 24;
+struct UnpackMulti {
+  UnpackArgs job[kMaxUnpackJobs];
+  int first_block[kMaxUnpackJobs + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void unpack_wgrad_multi_kernel(UnpackMulti m) {
+  int j = 0;
+  while (j + 1 < m.n && (int)blockIdx.x >= m.first_block[j + 1]) ++j;
+  unpack_row(m.job[j], ((int)blockIdx.x - m.first_block[j]) * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+}
+
 }  // namespace mlp
 }  // namespace svs
 
@@ -415,6 +430,13 @@ int set_lds_b(K kernel, int bytes, const char* who) {
   return SVS_OK;
 }
 }  // namespace
+
+struct svs_unpack_job {          // include/svolsdf_hip.h
+  const float *dWk, *dbk;
+  int ldw, map, rows, cols, row_off;
+  const float *weight_v, *weight_g, *row0;
+  float *grad_v, *grad_g, *grad_b;
+};
 
 extern "C" {
 
@@ -504,6 +526,25 @@ int svs_unpack_wgrad(const float* dWk, const float* dbk, int ldw, int map, int r
   UnpackArgs a{dWk, dbk, ldw, map, rows, cols, row_off, weight_v, weight_g, grad_v, grad_g, grad_b, row0};
   unpack_wgrad_kernel<<<(rows + 3) / 4, 256, 0, (hipStream_t)hip_stream>>>(a);
   return check_launch("svs_unpack_wgrad");
+}
+
+int svs_unpack_wgrad_multi(const svs_unpack_job* jobs, int n_jobs, void* hip_stream) {
+  if (!jobs || n_jobs < 1 || n_jobs > kMaxUnpackJobs) { set_error("svs_unpack_wgrad_multi: 1..%d jobs", kMaxUnpackJobs); return SVS_EINVAL; }
+  UnpackMulti m;
+  m.n = n_jobs;
+  int blocks = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    const svs_unpack_job& q = jobs[i];
+    if (!q.dWk || !q.weight_v || !q.grad_v || q.rows < 1 || q.cols < 1 || q.map < 0 || q.map > 4 || (q.weight_g && !q.grad_g)) {
+      set_error("svs_unpack_wgrad_multi: bad job %d", i); return SVS_EINVAL;
+    }
+    m.job[i] = UnpackArgs{q.dWk, q.dbk, q.ldw, q.map, q.rows, q.cols, q.row_off, q.weight_v, q.weight_g, q.grad_v, q.grad_g, q.grad_b, q.row0};
+    m.first_block[i] = blocks;
+    blocks += (q.rows + 3) / 4;
+  }
+  m.first_block[n_jobs] = blocks;
+  unpack_wgrad_multi_kernel<<<blocks, 256, 0, (hipStream_t)hip_stream>>>(m);
+  return check_launch("svs_unpack_wgrad_multi");
 }
 
 }  // extern "C"

@@ -29,6 +29,14 @@ class WGradJob(ctypes.Structure):
                 ("dW", ctypes.c_void_p), ("db", ctypes.c_void_p), ("absmax", ctypes.c_void_p)]
 
 
+class UnpackJob(ctypes.Structure):
+    """svs_unpack_job of include/svolsdf_hip.h"""
+    _fields_ = [("dWk", ctypes.c_void_p), ("dbk", ctypes.c_void_p), ("ldw", ctypes.c_int), ("map", ctypes.c_int),
+                ("rows", ctypes.c_int), ("cols", ctypes.c_int), ("row_off", ctypes.c_int),
+                ("weight_v", ctypes.c_void_p), ("weight_g", ctypes.c_void_p), ("row0", ctypes.c_void_p),
+                ("grad_v", ctypes.c_void_p), ("grad_g", ctypes.c_void_p), ("grad_b", ctypes.c_void_p)]
+
+
 SIGNATURES = {
     "svs_version": (c_int, []),
     "svs_last_error_string": (c_char_p, []),
@@ -54,6 +62,7 @@ SIGNATURES = {
     "svs_sdf_bwd_b": (c_int, [c_int, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P]),
     "svs_lin8_row0_grad": (c_int, [_P, _P, _P, c_int, _P, _P]),
     "svs_unpack_wgrad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "svs_unpack_wgrad_multi": (c_int, [_P, c_int, _P]),
     "svs_sampler_ctl_bytes": (c_size_t, [c_int, c_int]),
     "svs_sampler_ctl_stride": (c_int, []),
     "svs_sampler_cap": (c_int, []),

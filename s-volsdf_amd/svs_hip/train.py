@@ -60,13 +60,19 @@ class WGradAccum:
         self.dWk.zero_(); self.dbk.zero_(); self.row0.zero_(); self.absmax.zero_()
 
 
+def _unpack_all(jobs):
+    """[(dWk, dbk, ldw, map, rows, cols, row_off, v, g, row0, gv, gg, gb)] (c_void_p / None / int) -> one launch."""
+    L = _lib.load()
+    val = lambda x: x.value if isinstance(x, ctypes.c_void_p) else x
+    arr = (_lib.UnpackJob * len(jobs))(*[_lib.UnpackJob(*[val(x) for x in j]) for j in jobs])
+    _lib.check(L.svs_unpack_wgrad_multi(ctypes.cast(arr, ctypes.c_void_p), len(jobs), _stream()), "svs_unpack_wgrad_multi")
+
+
 def finalize(accum, sdf_params, rgb_params, out=None):
     """kernel-order accumulators -> (sdf_grads, rgb_grads): lists of (grad_v, grad_g, grad_b) per layer; `out`
-    optionally names the destination tensors (views of a flat gradient buffer)."""
-    L = _lib.load()
+    optionally names the destination tensors (views of a flat gradient buffer).  One launch for all 14 layers."""
     dev = accum.dWk.device
-    st = _stream()
-    res = []
+    res, jobs, keep = [], [], []
     for gi, (params, base, n) in enumerate(((sdf_params, 0, 9), (rgb_params, 9, 5))):
         v, g, _ = params
         group = []
@@ -82,11 +88,13 @@ def finalize(accum, sdf_params, rgb_params, out=None):
             mp = 1 if (is_sdf and l == 4) else (2 if (not is_sdf and l == 0) else 0)
             row_off = 1 if (is_sdf and l == 8) else 0
             row0 = _ptr(accum.row0) if (is_sdf and l == 8) else None
-            _lib.check(L.svs_unpack_wgrad(_off(accum.dWk, (base + l) * 256 * LDW), _off(accum.dbk, (base + l) * 256), LDW,
-                                          mp, rows, cols, row_off, _ptr(_f32(v[l])), _ptr(_f32(g[l])) if g is not None else None,
-                                          row0, _ptr(gv), _ptr(gg), _ptr(gb), st), "svs_unpack_wgrad")
+            vl, gl = _f32(v[l]), (_f32(g[l]) if g is not None else None)
+            keep += [vl, gl]
+            jobs.append((_off(accum.dWk, (base + l) * 256 * LDW), _off(accum.dbk, (base + l) * 256), LDW, mp, rows, cols,
+                         row_off, _ptr(vl), _ptr(gl), row0, _ptr(gv), _ptr(gg), _ptr(gb)))
             group.append((gv, gg, gb))
         res.append(group)
+    _unpack_all(jobs)
     return res[0], res[1]
 
 
@@ -285,10 +293,8 @@ class BgBackward:
         self._hold[slot] = (d_bg_rgb, d_bg_out0)
 
     def finalize(self, sdf_wb, rgb_wb, out=None):
-        """kernel-order accumulators -> ([(grad_w, grad_b)] * 9, [(grad_w, grad_b)] * 2)"""
-        L = _lib.load()
-        st = _stream()
-        res = []
+        """kernel-order accumulators -> ([(grad_w, grad_b)] * 9, [(grad_w, grad_b)] * 2); one launch"""
+        res, jobs, keep = [], [], []
         for gi, ((w, b), base) in enumerate(((sdf_wb, 0), (rgb_wb, 9))):
             group = []
             for l in range(len(w)):
@@ -298,9 +304,11 @@ class BgBackward:
                 mp = 3 if (is_sdf and l == 4) else (4 if (not is_sdf and l == 0) else 0)
                 row_off = 1 if (is_sdf and l == 8) else 0
                 row0 = _ptr(self.row0) if (is_sdf and l == 8) else None
-                _lib.check(L.svs_unpack_wgrad(_off(self.dWk, (base + l) * 256 * LDW), _off(self.dbk, (base + l) * 256), LDW, mp,
-                                              rows, cols, row_off, _ptr(_f32(w[l])), None, row0, _ptr(gw), None, _ptr(gb), st),
-                           "svs_unpack_wgrad(bg)")
+                wl = _f32(w[l])
+                keep.append(wl)
+                jobs.append((_off(self.dWk, (base + l) * 256 * LDW), _off(self.dbk, (base + l) * 256), LDW, mp, rows, cols, row_off,
+                             _ptr(wl), None, row0, _ptr(gw), None, _ptr(gb)))
                 group.append((gw, gb))
             res.append(group)
+        _unpack_all(jobs)
         return res[0], res[1]
