@@ -154,6 +154,7 @@ class TrainStep:
         self.groups = groups
         self.tstreams = TrainStreams(dev)
         self.accum = WGradAccum(dev)
+        self.prep = None
         self._new_bwd = lambda: MlpBackward(dev, self.tstreams, self.accum)
         self.bwd = [self._new_bwd()]                    # one scratch set and one stream per concurrent ray group
         self.sides = []
@@ -195,14 +196,22 @@ class TrainStep:
         rng = m.draw_train_rng(R, dev)
         m.packed_mlp()                                   # pack once, before the streams fork
         sdf_p, rgb_p = m.mlp_params()
-        self.tstreams.pack(sdf_p, rgb_p)
+        main = torch.cuda.current_stream()
+        # the weight streams of the BACKWARD kernels are packed on their own stream while the sampler and the forward
+        # run; the backward launches wait for the event
+        if self.prep is None:
+            self.prep = torch.cuda.Stream(device=dev)
+        self.prep.wait_stream(main)                      # parameters of this step are final, last step's readers are done
+        with torch.cuda.stream(self.prep):
+            self.tstreams.pack(sdf_p, rgb_p)
+            if self.is_bg:
+                bg_sdf_wb, bg_rgb_wb = m.bg_params()
+                self.bg_bwd.pack(bg_sdf_wb, bg_rgb_wb)
+            packed = torch.cuda.Event(); packed.record(self.prep)
         if self.is_bg:
-            bg_sdf_wb, bg_rgb_wb = m.bg_params()
-            self.bg_bwd.pack(bg_sdf_wb, bg_rgb_wb)
             self.bg_bwd.zero()
         self.accum.zero()
         self.d_beta.zero_()
-        main = torch.cuda.current_stream()
         fork = torch.cuda.Event(); fork.record(main)
         scale = 1.0 / self.world                         # each rank's means are over its own shard
         gt_rgb, gt_smooth = ground_truth["rgb"].reshape(-1, 3), ground_truth["rgb_smooth"].reshape(-1, 3)
@@ -223,6 +232,7 @@ class TrainStep:
                 gt = {"rgb": gt_rgb[lo:hi], "rgb_smooth": gt_smooth[lo:hi]}
                 lo_out = self.loss(out, gt, norm=(R * self.world, 2 * R * self.world), advance=(gi == len(groups) - 1))
                 g = self.loss.last_grads
+                stream.wait_event(packed)
                 if self.is_bg:
                     d_sdf, d_rgb, d_bo, d_brgb, d_beta = ops.composite_bg_bwd(
                         keep["z_vals"], keep["z_max"], keep["sdf"], keep["rgb_flat"], keep["depth_scale"], m.density.beta,
