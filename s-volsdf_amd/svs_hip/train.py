@@ -49,15 +49,19 @@ class TrainStreams:
 
 class WGradAccum:
     def __init__(self, device):
-        self.dWk = torch.zeros(14, 256, LDW, device=device)
-        self.dbk = torch.zeros(14, 256, device=device)
-        self.row0 = torch.zeros(257, device=device)
+        # one allocation, one memset per step
+        n = [14 * 256 * LDW, 14 * 256, 260, 4]
+        self.flat = torch.zeros(sum(n), device=device)
+        parts = torch.split(self.flat, n)
+        self.dWk = parts[0].view(14, 256, LDW)
+        self.dbk = parts[1].view(14, 256)
+        self.row0 = parts[2][:257]
         # fp16x2: maxima of the gradient-like GEMM operands, published by the sweeps: [0] SDF abar / u,
         # [1] radiance zbar, [2] feature-vector gradient
-        self.absmax = torch.zeros(4, device=device)
+        self.absmax = parts[3]
 
     def zero(self):
-        self.dWk.zero_(); self.dbk.zero_(); self.row0.zero_(); self.absmax.zero_()
+        self.flat.zero_()
 
 
 def _unpack_all(jobs):
