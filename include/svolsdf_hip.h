@@ -276,6 +276,14 @@ int svs_loss(int n_rays, int n_samples, int n_eik, const float* rgb_values, cons
              float* d_grad_theta, float* d_weights, float* d_depth_values, double* workspace, void* hip_stream);
 size_t svs_loss_workspace_bytes(int n_rays, int n_eik);
 
+/* ---- f1  FeatureNet convolutions (models/CasMVSNet.py:24-55,338-439) ---------------------------------------------
+ * out (Cout,Ho,Wo) = [add +] relu?(conv2d(in (Cin,H,W), weight [Cout][Cin][k][k]) + bias), k in {1,3,5}, padding k/2,
+ * stride in {1,2}; BatchNorm(eval) folded into weight / bias by the caller.  add: optional (Cout,Ho,Wo) tensor added
+ * AFTER the activation; add_upsample2 != 0: add is (Cout,Ho/2,Wo/2) and enters nearest-up-sampled by 2 (the FPN's
+ * top-down path, :413-431). */
+int svs_conv2d(const float* in, const float* weight, const float* bias, const float* add, int add_upsample2, float* out,
+               int Cin, int Cout, int H, int W, int k, int stride, int relu, void* hip_stream);
+
 /* ---- a13/a14  homography warp + variance --------------------------------------------------------------------
  * homo_warping (models/CasMVSNet.py:280-315) for every source view fused with the variance aggregation of
  * DepthNet.forward (:611-642): variance (C,D,H,W) = sum(f^2)/V - (sum(f)/V)^2 over the reference feature (C,H,W)

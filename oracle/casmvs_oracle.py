@@ -176,3 +176,28 @@ def depthnet_forward(features, projs, depth_values, costreg_params):
     prob, depth, conf, idx = depthnet_tail(reg, depth_values)
     return dict(variance=var, reg=reg, prob_volume=prob, depth=depth, photometric_confidence=conf, depth_index=idx,
                 depth_values=depth_values)
+
+
+def feature_net_torch(params, img):
+    """FeatureNet, arch_mode 'fpn' (models/CasMVSNet.py:338-439) with plain torch float32 functional ops on the CPU.
+    params: state-dict-named arrays (synth.make_featurenet_params), img (3,H,W) -> {'stage1','stage2','stage3'} arrays."""
+    import torch
+    import torch.nn.functional as F
+    P = {k: torch.from_numpy(np.asarray(v)) for k, v in params.items()}
+
+    def block(name, x, stride, pad):
+        x = F.conv2d(x, P[f"{name}.conv.weight"], None, stride=stride, padding=pad)
+        x = F.batch_norm(x, P[f"{name}.bn.running_mean"], P[f"{name}.bn.running_var"], P[f"{name}.bn.weight"], P[f"{name}.bn.bias"],
+                         training=False, eps=1e-5)
+        return F.relu(x)
+
+    x = torch.from_numpy(np.asarray(img, np.float32))[None]
+    c0 = block("conv0.1", block("conv0.0", x, 1, 1), 1, 1)
+    c1 = block("conv1.2", block("conv1.1", block("conv1.0", c0, 2, 2), 1, 1), 1, 1)
+    c2 = block("conv2.2", block("conv2.1", block("conv2.0", c1, 2, 2), 1, 1), 1, 1)
+    out = {"stage1": F.conv2d(c2, P["out1.weight"])}
+    f = F.interpolate(c2, scale_factor=2, mode="nearest") + F.conv2d(c1, P["inner1.weight"], P["inner1.bias"])
+    out["stage2"] = F.conv2d(f, P["out2.weight"], padding=1)
+    f = F.interpolate(f, scale_factor=2, mode="nearest") + F.conv2d(c0, P["inner2.weight"], P["inner2.bias"])
+    out["stage3"] = F.conv2d(f, P["out3.weight"], padding=1)
+    return {k: v[0].numpy() for k, v in out.items()}

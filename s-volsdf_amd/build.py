@@ -29,6 +29,7 @@ UNITS = {
     "svs_costvol.hip": ["-ffp-contract=off"],
     "svs_conv_mfma.hip": [],
     "svs_conv_gemm.hip": [],
+    "svs_conv2d.hip": [],
     "svs_wgrad.hip": [],
     "svs_mlp_bwd.hip": [],
     "svs_mlp_bwd_h2.hip": [],

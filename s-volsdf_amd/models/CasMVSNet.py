@@ -3,9 +3,10 @@
 fused homography warp + variance, 3-D U-Net with folded BatchNorm, softmax / depth regression / confidence,
 depth hypotheses.  Checkpoints load with strict=True (`feature.*`, `cost_regularization.{0,1,2}.*`).
 
-Scope note: the 2-D feature pyramid (`FeatureNet`) sits BEFORE the hot path and is
-not rebuilt; it is declared here with torch modules only so that the reference's checkpoint loads and
-`model.feature(img)` keeps working.  Inference only, like the reference (`@torch.no_grad()` forward).
+The 2-D feature pyramid (`FeatureNet`) keeps torch modules as parameter containers so that
+the reference's checkpoint loads; on the device in eval mode its convolutions run on csrc/svs_conv2d.hip (BatchNorm
+folded, the FPN's nearest up-sampling fused into the lateral convolutions).  Inference only, like the reference
+(`@torch.no_grad()` forward).
 """
 import torch
 import torch.nn as nn
@@ -17,20 +18,52 @@ Align_Corners_Range = False
 
 
 # ---------------------------------------------------------------------------------------------------------
-# FeatureNet (outside the hot path; parameter names of models/CasMVSNet.py:24-55,338-439, arch_mode 'fpn')
+# FeatureNet (parameter names of models/CasMVSNet.py:24-55,338-439, arch_mode 'fpn')
 # ---------------------------------------------------------------------------------------------------------
 class Conv2d(nn.Module):
+    """conv + BatchNorm2d + ReLU with the reference's parameter names (`conv.weight`, `bn.*`).  On the device, in eval
+    mode, the block is ONE launch of svs_conv2d with the BatchNorm folded into the weights."""
+
     def __init__(self, cin, cout, k, stride=1, relu=True, bn=True, **kw):
         super().__init__()
         self.conv = nn.Conv2d(cin, cout, k, stride=stride, bias=not bn, **kw)
         self.bn = nn.BatchNorm2d(cout) if bn else None
-        self.relu = relu
+        self.relu, self.stride = relu, stride
+        self._folded, self._key = None, None
+
+    def folded(self):
+        ts = [self.conv.weight] + ([self.conv.bias] if self.conv.bias is not None else [])
+        if self.bn is not None:
+            ts += [self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var]
+        key = tuple((t.data_ptr(), t._version) for t in ts)
+        if self._key != key:
+            w = self.conv.weight.detach().float()
+            b = self.conv.bias.detach().float() if self.conv.bias is not None else None
+            if self.bn is not None:
+                scale = (self.bn.weight / torch.sqrt(self.bn.running_var + self.bn.eps)).detach().float()
+                shift = (self.bn.bias - self.bn.running_mean * scale).detach().float()
+                w = w * scale.view(-1, 1, 1, 1)
+                b = shift if b is None else b * scale + shift
+            self._folded, self._key = (w.contiguous(), b.contiguous() if b is not None else None), key
+        return self._folded
 
     def forward(self, x):
+        if x.is_cuda and not self.training:
+            w, b = self.folded()
+            return torch.stack([costvol.conv2d(xi, w, b, stride=self.stride, relu=self.relu) for xi in x])
         x = self.conv(x)
         if self.bn is not None:
             x = self.bn(x)
         return F.relu(x) if self.relu else x
+
+
+def _plain_conv(conv, x, add=None, add_upsample2=False):
+    """nn.Conv2d (no norm, no activation) on the HIP kernel: (B,Cin,H,W) -> (B,Cout,H,W) [+ add]."""
+    outs = []
+    for i, xi in enumerate(x):
+        outs.append(costvol.conv2d(xi, conv.weight.detach(), conv.bias.detach() if conv.bias is not None else None,
+                                   add=None if add is None else add[i], add_upsample2=add_upsample2, stride=1, relu=False))
+    return torch.stack(outs)
 
 
 class FeatureNet(nn.Module):
@@ -56,6 +89,15 @@ class FeatureNet(nn.Module):
         c0 = self.conv0(x)
         c1 = self.conv1(c0)
         c2 = self.conv2(c1)
+        if x.is_cuda and not self.training:
+            # top-down path (models/CasMVSNet.py:413-431): the nearest x2 up-sampling is an index shift inside the
+            # lateral 1x1 convolution's epilogue, no up-sampled tensor is materialised
+            out = {"stage1": _plain_conv(self.out1, c2)}
+            f = _plain_conv(self.inner1, c1, add=c2, add_upsample2=True)
+            out["stage2"] = _plain_conv(self.out2, f)
+            f = _plain_conv(self.inner2, c0, add=f, add_upsample2=True)
+            out["stage3"] = _plain_conv(self.out3, f)
+            return out
         out = {"stage1": self.out1(c2)}
         f = F.interpolate(c2, scale_factor=2, mode="nearest") + self.inner1(c1)
         out["stage2"] = self.out2(f)

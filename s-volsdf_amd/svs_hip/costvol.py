@@ -116,6 +116,27 @@ def mfma_weight_fragments(weight):
     return frag
 
 
+def conv2d(x, weight, bias=None, add=None, add_upsample2=False, stride=1, relu=False):
+    """FeatureNet convolution (csrc/svs_conv2d.hip): x (Cin,H,W), weight (Cout,Cin,k,k) with BatchNorm folded, padding
+    k // 2 -> (Cout,Ho,Wo) = [add +] relu?(conv + bias); add_upsample2: `add` is at half resolution (nearest x2)."""
+    L = _lib.load()
+    x, weight = _f32(x), _f32(weight)
+    Cin, H, W = x.shape
+    Cout, cin_w, k, k2 = weight.shape
+    if cin_w != Cin or k != k2:
+        raise ValueError("weight shape does not match the input")
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    out = torch.empty(Cout, Ho, Wo, device=x.device)
+    bias = _f32(bias) if bias is not None else None
+    add = _f32(add) if add is not None else None
+    if add is not None and tuple(add.shape) != ((Cout, Ho // 2, Wo // 2) if add_upsample2 else (Cout, Ho, Wo)):
+        raise ValueError("addend shape does not match the output")
+    _lib.check(L.svs_conv2d(_ptr(x), _ptr(weight), _ptr(bias), _ptr(add), int(bool(add_upsample2)), _ptr(out), Cin, Cout, H, W, k,
+                            stride, int(bool(relu)), _stream()), "svs_conv2d")
+    return out
+
+
 _GEMM_ON = [True]
 
 

@@ -649,7 +649,21 @@ def fx_chamfer():
                                                             len(g["data_in_obs"])))
 
 
-ALL = dict(fusion=fx_fusion, pfm=fx_pfm, chamfer=fx_chamfer, rays=fx_rays, sdf_mlp=fx_sdf_mlp, rgb_mlp=fx_rgb_mlp, density=fx_density, sampler=fx_sampler,
+def fx_featurenet():
+    """FeatureNet (arch_mode 'fpn', base 8) of the reference on a 3 x 36 x 52 image (sizes that are multiples of 4 but
+    not of 8, so that the strided 5x5 layers see odd intermediate sizes): the three pyramid outputs."""
+    from models.CasMVSNet import FeatureNet
+    params = synth.make_featurenet_params(41)
+    net = FeatureNet(base_channels=8, stride=4, num_stage=3, arch_mode="fpn")
+    net.load_state_dict({k: T(v) for k, v in params.items()}, strict=True)
+    net.eval()
+    img = np.random.default_rng(42).uniform(0, 1, (1, 3, 36, 52)).astype(F32)
+    with torch.no_grad():
+        out = net(T(img))
+    save("featurenet", seed=np.asarray(41), img=img, **{k: v[0].numpy() for k, v in out.items()})
+
+
+ALL = dict(fusion=fx_fusion, pfm=fx_pfm, chamfer=fx_chamfer, featurenet=fx_featurenet, rays=fx_rays, sdf_mlp=fx_sdf_mlp, rgb_mlp=fx_rgb_mlp, density=fx_density, sampler=fx_sampler,
            composite=fx_composite, forward=fx_forward, forward_bg=fx_forward_bg, cost_mapping=fx_cost_mapping, loss=fx_loss, casmvs=fx_casmvs, train_step=fx_train_step, train_step_r32=lambda: fx_train_step(32, 2, "train_step_r32"),
            train_step_bg=fx_train_step_bg)
 

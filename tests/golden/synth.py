@@ -299,3 +299,29 @@ def make_dtu_scan(seed, n_pred=12000, n_stl=10000):
     ObsMask[:, :, :4] = 0
     P = np.array([[0.05, -0.02, 1.0, 25.0]])
     return dict(data_pcd=data_pcd, stl=stl, ObsMask=ObsMask, BB=BB, Res=Res, P=P)
+
+
+def make_featurenet_params(seed, base=8):
+    """State-dict-named float32 arrays of FeatureNet, arch_mode 'fpn' (models/CasMVSNet.py:338-399), BN in eval form."""
+    rng = np.random.default_rng(seed)
+    p = {}
+
+    def block(name, cin, cout, k):
+        p[f"{name}.conv.weight"] = rng.normal(0, np.sqrt(2.0 / (k * k * cin)), (cout, cin, k, k)).astype(F32)
+        p[f"{name}.bn.weight"] = rng.uniform(0.6, 1.4, cout).astype(F32)
+        p[f"{name}.bn.bias"] = rng.normal(0, 0.1, cout).astype(F32)
+        p[f"{name}.bn.running_mean"] = rng.normal(0, 0.1, cout).astype(F32)
+        p[f"{name}.bn.running_var"] = rng.uniform(0.5, 1.5, cout).astype(F32)
+        p[f"{name}.bn.num_batches_tracked"] = np.asarray(1, np.int64)
+
+    b = base
+    for name, cin, cout, k in (("conv0.0", 3, b, 3), ("conv0.1", b, b, 3), ("conv1.0", b, 2 * b, 5), ("conv1.1", 2 * b, 2 * b, 3),
+                               ("conv1.2", 2 * b, 2 * b, 3), ("conv2.0", 2 * b, 4 * b, 5), ("conv2.1", 4 * b, 4 * b, 3),
+                               ("conv2.2", 4 * b, 4 * b, 3)):
+        block(name, cin, cout, k)
+    for name, cin, cout, k, bias in (("out1", 4 * b, 4 * b, 1, False), ("inner1", 2 * b, 4 * b, 1, True), ("inner2", b, 4 * b, 1, True),
+                                     ("out2", 4 * b, 2 * b, 3, False), ("out3", 4 * b, b, 3, False)):
+        p[f"{name}.weight"] = rng.normal(0, np.sqrt(1.0 / (k * k * cin)), (cout, cin, k, k)).astype(F32)
+        if bias:
+            p[f"{name}.bias"] = rng.normal(0, 0.1, cout).astype(F32)
+    return p

@@ -197,3 +197,31 @@ def test_stage_loop_feature_cache(dev):
     assert results[True][0] == 3 and results[False][0] == 27
     for a, b in zip(results[True][1] + results[True][2], results[False][1] + results[False][2]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("hw", [None, (64, 80), (20, 12)])
+def test_feature_net_hip(dev, golden_dir, hw):
+    """FeatureNet on csrc/svs_conv2d.hip (BatchNorm folded, FPN up-sampling fused into the lateral convolutions) against
+    the reference's outputs (fixture) and the torch-functional oracle on other image sizes; batch of 2."""
+    from models.CasMVSNet import FeatureNet
+    g = dict(np.load(os.path.join(golden_dir, "featurenet.npz")))
+    params = synth.make_featurenet_params(int(g["seed"]))
+    net = FeatureNet(base_channels=8, stride=4, num_stage=3, arch_mode="fpn")
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in params.items()}, strict=True)
+    net.to(dev).eval()
+    if hw is None:
+        img, want = g["img"][0], {k: g[k] for k in ("stage1", "stage2", "stage3")}
+    else:
+        img = np.random.default_rng(hw[0]).uniform(0, 1, (3,) + hw).astype(F32)
+        want = corc.feature_net_torch(params, img)
+    x = G(np.stack([img, img[:, ::-1].copy()]), dev)                         # second batch entry: the image flipped
+    with torch.no_grad():
+        out = net(x)
+    want2 = corc.feature_net_torch(params, img[:, ::-1].copy())
+    for k in ("stage1", "stage2", "stage3"):
+        assert out[k].shape == (2,) + want[k].shape
+        np.testing.assert_allclose(out[k][0].cpu().numpy(), want[k], atol=1e-5)
+        np.testing.assert_allclose(out[k][1].cpu().numpy(), want2[k], atol=1e-5)
+    assert np.abs(want["stage3"]).max() > 0.1
+    net.train()                                                             # train mode: the torch modules (autograd), not the HIP path
+    assert net(x)["stage1"].requires_grad

@@ -368,3 +368,13 @@ def test_torch_ref_forward_and_first_step_gradients(golden_dir):
         ref = g[f"s0_grad/{name}"]
         worst = max(worst, float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30)))
     assert worst < 2e-3, worst
+
+
+def test_feature_net(golden_dir):
+    """The torch-functional restatement of FeatureNet == the reference's module (fixture featurenet.npz)."""
+    g = dict(np.load(os.path.join(golden_dir, "featurenet.npz")))
+    out = corc.feature_net_torch(synth.make_featurenet_params(int(g["seed"])), g["img"][0])
+    for k in ("stage1", "stage2", "stage3"):
+        assert out[k].shape == g[k].shape
+        np.testing.assert_allclose(out[k], g[k], atol=2e-6)
+    assert g["stage1"].shape == (32, 9, 13) and g["stage3"].shape == (8, 36, 52)
