@@ -1,7 +1,7 @@
 """`VolOpt` with the reference's call surface (volsdf/vsdf.py:18-463): constructor keywords `args, batch_size,
 is_continue, timestamp, checkpoint, scan`; attributes `trains_i`, `train_dataset`, `stg`, `loss`, `plots_dir`,
 `iter_step`; methods `gen_dataset(stg)`, `get_mvs_input(outs)`, `run(opt_stepN) -> epoch`, `render_mvs(id_k, epoch) ->
-(depth (H,W) on the device, None)`, `train_step`, `render_step`, `cost_mapping`, `save_checkpoints`,
+(depth (1,H,W) on the device, None)`, `train_step`, `render_step`, `cost_mapping`, `save_checkpoints`,
 `load_from_dir` -- what runner.py:164-243 drives.
 
 Everything per ray runs on the HIP path: `train_step` is one `svs_hip.trainer.TrainStep` (forward, MVS prior lookup,
@@ -249,7 +249,8 @@ class VolOpt():
         model_input['iter_step'] = self.iter_step
         model_outputs = renderer.render_image(self.model, model_input, dataset.total_pixels, split_n_pixels=self.split_n_pixels,
                                               fast=fast)
-        depth_cuda = renderer.depth_image(model_outputs, dataset.img_res, self.scale_factor)
+        # (1,H,W): the reference's lin2img(...)[0] keeps the channel axis, which the next MVS stage reads as the batch axis
+        depth_cuda = renderer.depth_image(model_outputs, dataset.img_res, self.scale_factor)[None]
         mask_bin = ground_truth['mask'].reshape(-1, 3).cuda() == 1.
         mse = torch.mean((model_outputs['rgb_values'] - ground_truth['rgb'].reshape(-1, 3).cuda())[mask_bin] ** 2)
         self.last_val_psnr = -10. * torch.log10(mse)

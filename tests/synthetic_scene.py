@@ -10,14 +10,14 @@ import synth
 
 
 class SyntheticSceneDataset(torch.utils.data.Dataset):
-    def __init__(self, data_dir_root=None, data_dir="DTU", img_res=(24, 32), scan_id=24, num_views=3, **_):
+    def __init__(self, data_dir_root=None, data_dir="DTU", img_res=(24, 32), scan_id=24, num_views=3, scale_factor=1.5, **_):
         self.data_dir, self.scan_id, self.num_views = data_dir, scan_id, num_views
         self.img_res = list(img_res)
         self.total_pixels = img_res[0] * img_res[1]
         self.mode, self.plot_id = 'train', 0
         self.sampling_idx = None
         self.n_images = 5
-        self.scale_factor = 1.5
+        self.scale_factor = float(scale_factor)
         rng = np.random.default_rng(scan_id)
         H, W = img_res
         self.rgb_images, self.rgb_smooth, self.masks, self.intrinsics_all, self.pose_all = [], [], [], [], []

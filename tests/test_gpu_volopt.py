@@ -88,7 +88,7 @@ def test_volopt_run_render_resume(tmp_path, monkeypatch):
 
     # render a training view for the MVS stage (runner.py:224-236)
     depth, confi = v.render_mvs(0, epoch)
-    assert confi is None and depth.shape == (24, 32) and depth.is_cuda and bool(torch.isfinite(depth).all())
+    assert confi is None and depth.shape == (1, 24, 32) and depth.is_cuda and bool(torch.isfinite(depth).all())
     assert v.train_dataset.mode == "train" and float(depth.max()) > 0
 
     # resume: a second VolOpt picks the latest run folder and continues from its checkpoints
