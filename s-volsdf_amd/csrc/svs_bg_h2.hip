@@ -83,7 +83,7 @@ __global__ __launch_bounds__(kThreads, 1) void bg_sdf_h2_kernel(BgSdfArgs a) {
   f32x4 q4;
   auto store_slice = [&](int tp, int r) {
     q4[r & 3] = prev[r];
-    if ((r & 3) == 3) reinterpret_cast<f32x4*>(ft)[(4 * tp + (r >> 2)) * 64 + lane] = q4;
+    if ((r & 3) == 3) SVS_STREAM_STORE(q4, reinterpret_cast<f32x4*>(ft) + (4 * tp + (r >> 2)) * 64 + lane);
   };
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kThreads, 1) void bg_rgb_h2_kernel(BgRgbArgs a) {
       pin(v);
       if (rb) {
         q4[r & 3] = v;
-        if ((r & 3) == 3) reinterpret_cast<f32x4*>(rb)[(4 * tp + (r >> 2)) * 64 + lane] = q4;
+        if ((r & 3) == 3) SVS_STREAM_STORE(q4, reinterpret_cast<f32x4*>(rb) + (4 * tp + (r >> 2)) * 64 + lane);
       }
       v8[r & 7] = v;
       if ((r & 7) == 7) {
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(kThreads, 1) void bg_rgb_bwd_h2_kernel(BgRgbBwdArgs
     const float v = prev[r] * ps.inv_in;
     fmax = __builtin_fmaxf(fmax, __builtin_fabsf(v));
     q4[r & 3] = v;
-    if ((r & 3) == 3) reinterpret_cast<f32x4*>(fb)[(4 * tp + (r >> 2)) * 64 + lane] = q4;
+    if ((r & 3) == 3) SVS_STREAM_STORE(q4, reinterpret_cast<f32x4*>(fb) + (4 * tp + (r >> 2)) * 64 + lane);
   };
 #pragma unroll
   for (int t = 0; t < 8; ++t) {

@@ -7,6 +7,20 @@
 #define SVS_EINVAL (-1)
 #define SVS_ESHAPE (-2)
 
+// Activation blocks are written once and read once by a later kernel: non-temporal stores keep them from evicting the
+// packed weight stream (2-4.6 MB per network, re-read by every workgroup) from the 4 MB L2 of an XCD.
+#ifdef SVS_NO_STREAM_HINTS
+#define SVS_STREAM_STORE(v, p) (*(p) = (v))
+#define SVS_STREAM_LOAD(p) (*(p))
+#else
+#define SVS_STREAM_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#ifdef SVS_NO_STREAM_LOADS
+#define SVS_STREAM_LOAD(p) (*(p))
+#else
+#define SVS_STREAM_LOAD(p) __builtin_nontemporal_load(p)
+#endif
+#endif
+
 namespace svs {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -37,7 +37,7 @@ struct RgbBwdEpi {
     pin(v);
     ps->track(v);
     q4[rr & 3] = v;
-    if ((rr & 3) == 3) reinterpret_cast<f32x4*>(zblk)[(4 * tp + (rr >> 2)) * 64 + lane] = q4;
+    if ((rr & 3) == 3) SVS_STREAM_STORE(q4, reinterpret_cast<f32x4*>(zblk) + (4 * tp + (rr >> 2)) * 64 + lane);
     v8[rr & 7] = v * ps->s_out;
     if ((rr & 7) == 7) {
       split8(v8, out->h[2 * tp + (rr >> 3)], out->m[2 * tp + (rr >> 3)]);
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kThreads, 1) void rgb_bwd_h2_kernel(RgbBwdArgs a) {
       const float v = prev[r] * ps.inv_in;
       fmax = __builtin_fmaxf(fmax, __builtin_fabsf(v));
       q4[r & 3] = v;
-      if ((r & 3) == 3) reinterpret_cast<f32x4*>(fb)[(4 * tp + (r >> 2)) * 64 + lane] = q4;
+      if ((r & 3) == 3) SVS_STREAM_STORE(q4, reinterpret_cast<f32x4*>(fb) + (4 * tp + (r >> 2)) * 64 + lane);
     };
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -198,9 +198,9 @@ struct PassAEpi {
     a2m = __builtin_fmaxf(a2m, __builtin_fabsf(a2));
     ps->track(u);
     qa[r & 3] = a2;
-    if ((r & 3) == 3) reinterpret_cast<f32x4*>(a2blk)[(4 * tp + (r >> 2)) * 64 + lane] = qa;
+    if ((r & 3) == 3) SVS_STREAM_STORE(qa, reinterpret_cast<f32x4*>(a2blk) + (4 * tp + (r >> 2)) * 64 + lane);
     qu[r & 3] = u;
-    if ((r & 3) == 3) reinterpret_cast<f32x4*>(ublk)[(4 * tp + (r >> 2)) * 64 + lane] = qu;
+    if ((r & 3) == 3) SVS_STREAM_STORE(qu, reinterpret_cast<f32x4*>(ublk) + (4 * tp + (r >> 2)) * 64 + lane);
     if (SPLIT) {
       v8[r & 7] = u * ps->s_out;
       if ((r & 7) == 7) {
@@ -389,7 +389,7 @@ struct PassBEpi {
     pin(o);
     ps->track(o);
     q4[r & 3] = o;
-    if ((r & 3) == 3) reinterpret_cast<f32x4*>(ablk)[(4 * tp + (r >> 2)) * 64 + lane] = q4;
+    if ((r & 3) == 3) SVS_STREAM_STORE(q4, reinterpret_cast<f32x4*>(ablk) + (4 * tp + (r >> 2)) * 64 + lane);
     if (SPLIT) {
       v8[r & 7] = o * ps->s_out;
       if ((r & 7) == 7) {

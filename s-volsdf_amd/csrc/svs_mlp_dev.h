@@ -43,6 +43,16 @@ struct Stream {
     __syncthreads();
     cur ^= 1;
   }
+  // The same, but the N youngest vector-memory operations of the wave -- float32 activation stores that the epilogue
+  // issued AFTER prefetch() -- stay in flight: loads, stores and LDS-DMA retire from vmcnt in issue order, so
+  // "all but the N youngest" covers the chunk.  Raw s_barrier: __syncthreads() carries a fence that hipcc lowers to
+  // vmcnt(0), which made every tile wait for its stores to reach memory (12 % of sdf_full).  N must not exceed the number
+  // of vector-memory instructions the wave really issued after prefetch().
+  template <int N>
+  __device__ __forceinline__ void advance_keep() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+    cur ^= 1;
+  }
 };
 
 // ------------------------------------------------------------------------------------------------------
@@ -198,7 +208,7 @@ __device__ __forceinline__ f32x16 load_tile(const float* __restrict__ block, int
   f32x16 v;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const f32x4 f = d[(4 * t + q) * 64];
+    const f32x4 f = SVS_STREAM_LOAD(d + (4 * t + q) * 64);
     v[4 * q] = f[0]; v[4 * q + 1] = f[1]; v[4 * q + 2] = f[2]; v[4 * q + 3] = f[3];
   }
   return v;
@@ -208,7 +218,7 @@ __device__ __forceinline__ void store_tile(float* __restrict__ block, int t, int
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     f32x4 f; f[0] = v[4 * q]; f[1] = v[4 * q + 1]; f[2] = v[4 * q + 2]; f[3] = v[4 * q + 3];
-    d[(4 * t + q) * 64] = f;
+    SVS_STREAM_STORE(f, d + (4 * t + q) * 64);   // streamed once: keep the weight stream in L2
   }
 }
 

@@ -71,7 +71,7 @@ struct RevEpi {
     pin(v);
     if (gblk) {
       q4[r & 3] = v;
-      if ((r & 3) == 3) reinterpret_cast<f32x4*>(gblk)[(4 * tp + (r >> 2)) * 64 + lane] = q4;
+      if ((r & 3) == 3) SVS_STREAM_STORE(q4, reinterpret_cast<f32x4*>(gblk) + (4 * tp + (r >> 2)) * 64 + lane);
     }
     v8[r & 7] = v;
     if ((r & 7) == 7) {
@@ -105,7 +105,8 @@ __device__ __forceinline__ void reverse_layer_h2(Stream& st, const Pieces2& in, 
     if (l == 4 && t == 6) skip6 = acc;
     ep.prev = acc;
     ep.h = hcur;
-    st.advance();
+    if (gb && t > 0) st.advance_keep<4>();            // the 4 gbuf stores of tile t-1's epilogue stay in flight
+    else st.advance();
   }
   ep.all(7);
 }
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_h2_kernel(SdfFullArgs a)
     f32x4 q4;
     auto store_slice = [&](int tp, int r) {
       q4[r & 3] = prev[r];
-      if ((r & 3) == 3 && ft) reinterpret_cast<f32x4*>(ft)[(4 * tp + (r >> 2)) * 64 + lane] = q4;
+      if ((r & 3) == 3 && ft) SVS_STREAM_STORE(q4, reinterpret_cast<f32x4*>(ft) + (4 * tp + (r >> 2)) * 64 + lane);
     };
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -248,7 +249,7 @@ struct RgbEpi {
     pin(v);
     if (rblk) {
       q4[r & 3] = v;
-      if ((r & 3) == 3) reinterpret_cast<f32x4*>(rblk)[(4 * tp + (r >> 2)) * 64 + lane] = q4;
+      if ((r & 3) == 3) SVS_STREAM_STORE(q4, reinterpret_cast<f32x4*>(rblk) + (4 * tp + (r >> 2)) * 64 + lane);
     }
     v8[r & 7] = v;
     if ((r & 7) == 7) {

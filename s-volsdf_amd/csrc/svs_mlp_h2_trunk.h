@@ -81,7 +81,7 @@ struct TrunkEpi {
     if (LAST) y8[tp][r] = v;
     if (HBUF) {
       q4[r & 3] = v;
-      if ((r & 3) == 3) reinterpret_cast<f32x4*>(hb)[(4 * tp + (r >> 2)) * 64 + lane] = q4;
+      if ((r & 3) == 3) SVS_STREAM_STORE(q4, reinterpret_cast<f32x4*>(hb) + (4 * tp + (r >> 2)) * 64 + lane);
     }
     if (!LAST) {
       v8[r & 7] = v;
@@ -115,7 +115,8 @@ __device__ __forceinline__ void trunk_layer_h2(Stream& st, const Pieces2& x, Tru
     if (t == 0) acc = tile_mma_h2<16>(st.cur_buf(), x, lane);
     else acc = tile_mma_h2<16>(st.cur_buf(), x, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.b(t - 1, s); });
     ep.prev = acc;
-    st.advance();
+    if (HBUF && t > 0) st.advance_keep<4>();      // the 4 hbuf stores of tile t-1's epilogue stay in flight
+    else st.advance();
   }
   if (ep.splice) { ep.all(Net::kSpliceTile); ep.splice_full_tiles(); }
   else ep.all(7);

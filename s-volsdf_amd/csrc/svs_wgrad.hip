@@ -264,8 +264,8 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
     // A narrow B block has 256 float4: every load of a narrow job re-reads float4 tid & 255 (only b[0] is used).
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      st.a[k] = ga[k * kThreadsW + tid];
-      st.b[k] = gb[narrow ? (tid & 255) : k * kThreadsW + tid];
+      st.a[k] = SVS_STREAM_LOAD(ga + k * kThreadsW + tid);
+      st.b[k] = SVS_STREAM_LOAD(gb + (narrow ? (tid & 255) : k * kThreadsW + tid));
     }
     st_live = a.n_valid_points - t * 32;
     st_pair = pi;
