@@ -240,9 +240,10 @@ class TrainStep:
                         g["weights"], g["depth_values"])
                     self.bg_bwd.accumulate(keep, d_brgb, d_bo, slot=gi)
                 else:
+                    gw = m.white_bkgd_weight_grad(g["rgb_values"], g["weights"], keep["z_vals"].shape[1])
                     d_sdf, d_rgb, d_beta = ops.composite_bwd(keep["z_vals"], keep["sdf"], keep["rgb_flat"], keep["depth_scale"],
                                                              m.density.beta, m.density.beta_min_value, g["rgb_values"],
-                                                             g["weights"], g["depth_values"])
+                                                             gw, g["depth_values"])
                 self.d_beta[gi:gi + 1].copy_(d_beta)
                 self.bwd[gi].accumulate(keep, d_rgb, d_sdf, g["grad_theta"])
                 results.append((lo_out, out))

@@ -190,8 +190,6 @@ class VolSDFNetwork(nn.Module):
 
     def forward(self, input, fast=-1):
         if self.training and torch.is_grad_enabled():
-            if self.white_bkgd:
-                raise NotImplementedError("white_bkgd training is not wired to the backward kernels (default is False)")
             params = self._flat_param_list()
             res = _RenderFunction.apply(self, input, fast, *params)
             rgb_values, depth_values, weights, grad_theta, depth_vals, xyz = res
@@ -279,6 +277,7 @@ class VolSDFNetwork(nn.Module):
         R = keep["z_vals"].shape[0]
         if g_rgb_values is None:
             g_rgb_values = torch.zeros(R, 3, device=dev)
+        g_weights = self.white_bkgd_weight_grad(g_rgb_values, g_weights, keep["z_vals"].shape[1])
         d_sdf, d_rgb, d_beta = ops.composite_bwd(keep["z_vals"], keep["sdf"], keep["rgb_flat"], keep["depth_scale"],
                                                  self.density.beta, self.density.beta_min_value, g_rgb_values,
                                                  g_weights, g_depth_values)
@@ -288,6 +287,14 @@ class VolSDFNetwork(nn.Module):
         sdf_p, rgb_p = self.mlp_params()
         sdf_g, rgb_g = self._mlp_bwd.run(sdf_p, rgb_p, keep, d_rgb, d_sdf, g_grad_theta, out=out)
         return sdf_g, rgb_g, d_beta
+
+    def white_bkgd_weight_grad(self, g_rgb_values, g_weights, S):
+        """white_bkgd (network.py:246-248): rgb_values += (1 - sum(weights)) * bg_color, so every weight of a ray receives
+        -(d loss / d rgb_values) . bg_color on top of its direct gradient.  No-op for the default black background."""
+        if not self.white_bkgd:
+            return g_weights
+        extra = -(g_rgb_values @ self.bg_color.to(g_rgb_values.device)).unsqueeze(1).expand(-1, S)
+        return extra.contiguous() if g_weights is None else g_weights + extra
 
     def volume_rendering(self, z_vals, sdf):
         """network.py:281-295 -> (weights, dists)."""
