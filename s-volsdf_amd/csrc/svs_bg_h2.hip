@@ -39,7 +39,7 @@ __global__ __launch_bounds__(kThreads, 1) void bg_sdf_h2_kernel(BgSdfArgs a) {
     const f32x4 x = reinterpret_cast<const f32x4*>(a.pts)[pc];
     pe.compute(x[0], x[1], x[2], x[3]);
   }
-  float* hb = TRAIN ? a.hbuf + (size_t)wtile * 8 * kBlockF : nullptr;
+  float* hb = TRAIN ? a.hbuf + (size_t)wtile * kBlockF : nullptr;
   if (TRAIN) {
     float* pb = a.pebuf + (size_t)wtile * kBlockF;
 #pragma unroll

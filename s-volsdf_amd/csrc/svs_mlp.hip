@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_kernel(SdfFullArgs a) {
   pe.compute(x0, x1, x2);
   st.advance();
 
-  float* hb = a.hbuf + (size_t)wtile * 8 * 128 * 64;
+  float* hb = a.hbuf + (size_t)wtile * kBlockF;          // block l of this tile: + l * block_stride()
   f32x16 x[8], y[8];
   forward_trunk<true>(st, x, y, pe, lane, half, hb);
 
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_kernel(SdfFullArgs a) {
     }
   }
   st.advance();
-  float* gb = a.gbuf ? a.gbuf + (size_t)wtile * 8 * kBlockF : nullptr;
+  float* gb = a.gbuf ? a.gbuf + (size_t)wtile * kBlockF : nullptr;
   // ---- feature vector = rows 1..256 of lin8
   float* ft = a.feat_tiles ? a.feat_tiles + (size_t)wtile * 128 * 64 : nullptr;
   {
@@ -107,14 +107,14 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_kernel(SdfFullArgs a) {
   // g(a_7) = g(h_8) * softplus'(a_7), h_8 still in x
 #pragma unroll
   for (int i = 0; i < 128; ++i) y[i / 16][i % 16] *= dsoftplus_from_h(x[i / 16][i % 16]);
-  if (gb) store_tile_regs(gb + 7 * (size_t)kBlockF, y, lane);       // ghat_7 = W8[0,:] * softplus'(a_7)
+  if (gb) store_tile_regs(gb + 7 * block_stride(), y, lane);       // ghat_7 = W8[0,:] * softplus'(a_7)
 
   // ---- reverse layers 7..1
   f32x16 skip7;          // g(PE[0..31]) from the skip connection (tile 7 of g(h_4 spliced))
   f32x16 skip6;          // tile 6; only local rows 25..31 are PE[32..38]
   for (int l = 7; l >= 1; --l) {
-    const float* hblk = hb + (size_t)(l - 1) * kBlockF;
-    float* gblk = gb ? gb + (size_t)(l - 1) * kBlockF : nullptr;
+    const float* hblk = hb + (size_t)(l - 1) * block_stride();
+    float* gblk = gb ? gb + (size_t)(l - 1) * block_stride() : nullptr;
     f32x16 pend;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {

@@ -158,10 +158,11 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_kernel(SdfBwdAArgs a) {
     }
     u0.v[q] = q < kPeDim ? coef * nb[c < 3 ? c : 0] : 0.0f;
   }
-  const float* hb = a.hbuf + (size_t)wtile * 8 * kBlockF;
-  const float* gb = a.gbuf + (size_t)wtile * 8 * kBlockF;
-  float* ub = a.ubuf + (size_t)wtile * 9 * kBlockF;
-  float* a2 = a.a2buf + (size_t)wtile * 8 * kBlockF;
+  const size_t LS = block_stride();
+  const float* hb = a.hbuf + (size_t)wtile * kBlockF;
+  const float* gb = a.gbuf + (size_t)wtile * kBlockF;
+  float* ub = a.ubuf + (size_t)wtile * kBlockF;
+  float* a2 = a.a2buf + (size_t)wtile * kBlockF;
   store_pe_block(ub, u0.v, lane, half);
   store_pe_block(a.pebuf + (size_t)wtile * kBlockF, pe.v, lane, half);
   st.advance();
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_kernel(SdfBwdAArgs a) {
   // layer 0
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
-    if (t > 0) { store_tile(a2, t - 1, lane, pend_a2); store_tile(ub + (size_t)kBlockF, t - 1, lane, x[t - 1]); }
+    if (t > 0) { store_tile(a2, t - 1, lane, pend_a2); store_tile(ub + LS, t - 1, lane, x[t - 1]); }
     const f32x16 h = load_tile(hb, t, lane), g = load_tile(gb, t, lane);   // in flight during the MFMAs
     if (t < 7) st.prefetch<kChunk0F4>(); else st.prefetch<kChunkF4>();
     const f32x16 v = tile_mma_pe(st.cur_buf(), u0, lane, half);
@@ -190,10 +191,10 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_kernel(SdfBwdAArgs a) {
     st.advance();
   }
   store_tile(a2, 7, lane, pend_a2);
-  store_tile(ub + (size_t)kBlockF, 7, lane, x[7]);
+  store_tile(ub + LS, 7, lane, x[7]);
   for (int l = 1; l < 8; ++l) {
-    float* a2l = a2 + (size_t)l * kBlockF;
-    float* ul = ub + (size_t)(l + 1) * kBlockF;
+    float* a2l = a2 + (size_t)l * LS;
+    float* ul = ub + (size_t)(l + 1) * LS;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       if (t == 7 && l == 3) break;
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_kernel(SdfBwdAArgs a) {
         store_tile(a2l, t - 1, lane, pend_a2);
         if (!(l == 3 && t - 1 == 6)) store_tile(ul, t - 1, lane, y[t - 1]);
       }
-      const f32x16 h = load_tile(hb + (size_t)l * kBlockF, t, lane), g = load_tile(gb + (size_t)l * kBlockF, t, lane);
+      const f32x16 h = load_tile(hb + (size_t)l * LS, t, lane), g = load_tile(gb + (size_t)l * LS, t, lane);
       if (!(l == 7 && t == 7)) st.prefetch<kChunkF4>();
       const f32x16 v = tile_mma<128>(st.cur_buf(), x, lane);
       __builtin_amdgcn_sched_barrier(0);
@@ -239,10 +240,11 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_kernel(SdfBwdBArgs a) {
   float sbar = (a.d_sdf && p < a.P) ? a.d_sdf[pc] : 0.0f;
   if (a.clamp_mask && a.clamp_mask[pc]) sbar = 0.0f;
   if (half == 0 && a.sbar_out) a.sbar_out[p] = sbar;
-  const float* hb = a.hbuf + (size_t)wtile * 8 * kBlockF;
-  const float* gb = a.gbuf + (size_t)wtile * 8 * kBlockF;
-  const float* a2 = a.a2buf + (size_t)wtile * 8 * kBlockF;
-  float* ab = a.abuf + (size_t)wtile * 8 * kBlockF;
+  const size_t LS = block_stride();
+  const float* hb = a.hbuf + (size_t)wtile * kBlockF;
+  const float* gb = a.gbuf + (size_t)wtile * kBlockF;
+  const float* a2 = a.a2buf + (size_t)wtile * kBlockF;
+  float* ab = a.abuf + (size_t)wtile * kBlockF;
   const bool has_f = a.feat_bar && wtile < a.n_feat_tiles;
   f32x16 x[8], y[8];
   if (has_f) load_tile_regs(a.feat_bar + (size_t)wtile * kBlockF, y, lane);
@@ -255,10 +257,10 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_kernel(SdfBwdBArgs a) {
   // ghat_7 = W8[0,:] * s'(a_7)); the tiles of h_8 / a2_7 / ghat_7 are requested before the MFMAs of the tile
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
-    if (t > 0) store_tile(ab + 7 * (size_t)kBlockF, t - 1, lane, x[t - 1]);    // deferred store
-    const f32x16 w0 = load_tile(gb + 7 * (size_t)kBlockF, t, lane);
-    const f32x16 h = load_tile(hb + 7 * (size_t)kBlockF, t, lane);
-    const f32x16 s2 = load_tile(a2 + 7 * (size_t)kBlockF, t, lane);
+    if (t > 0) store_tile(ab + 7 * LS, t - 1, lane, x[t - 1]);    // deferred store
+    const f32x16 w0 = load_tile(gb + 7 * LS, t, lane);
+    const f32x16 h = load_tile(hb + 7 * LS, t, lane);
+    const f32x16 s2 = load_tile(a2 + 7 * LS, t, lane);
     st.prefetch<kChunkF4>();
     const f32x16 acc = tile_mma<128>(st.cur_buf(), y, lane);
     __builtin_amdgcn_sched_barrier(0);
@@ -266,14 +268,14 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_kernel(SdfBwdBArgs a) {
     for (int i = 0; i < 16; ++i) x[t][i] = acc[i] * dsoftplus_from_h(h[i]) + sbar * w0[i] + s2[i];
     st.advance();
   }
-  store_tile(ab + 7 * (size_t)kBlockF, 7, lane, x[7]);
+  store_tile(ab + 7 * LS, 7, lane, x[7]);
   for (int l = 7; l >= 1; --l) {
     // x = abar_l; hbar_l = W_l^T abar_l, fused with abar_{l-1} = hbar_l * s'(a_{l-1}) + a2_{l-1}
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      if (t > 0) store_tile(ab + (size_t)(l - 1) * kBlockF, t - 1, lane, y[t - 1]);   // deferred store
-      const f32x16 h = load_tile(hb + (size_t)(l - 1) * kBlockF, t, lane);
-      const f32x16 s2 = load_tile(a2 + (size_t)(l - 1) * kBlockF, t, lane);
+      if (t > 0) store_tile(ab + (size_t)(l - 1) * LS, t - 1, lane, y[t - 1]);   // deferred store
+      const f32x16 h = load_tile(hb + (size_t)(l - 1) * LS, t, lane);
+      const f32x16 s2 = load_tile(a2 + (size_t)(l - 1) * LS, t, lane);
       if (!(l == 1 && t == 7)) st.prefetch<kChunkF4>();
       const f32x16 acc = tile_mma<128>(st.cur_buf(), x, lane);
       __builtin_amdgcn_sched_barrier(0);
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_kernel(SdfBwdBArgs a) {
       if (l == 4 && t == 6) zero_splice_rows_tile6(y[6], half);
       if (!(l == 1 && t == 7)) st.advance();
     }
-    store_tile(ab + (size_t)(l - 1) * kBlockF, 7, lane, y[7]);
+    store_tile(ab + (size_t)(l - 1) * LS, 7, lane, y[7]);
 #pragma unroll
     for (int t = 0; t < 8; ++t) x[t] = y[t];
   }
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_kernel(SdfBwdBArgs a) {
 // and block) and grid-strides over the tiles, with the 16 loads of a tile in flight together; the sum over the 32
 // points of a lane half goes through LDS once per workgroup, then float atomics into out[257] (index 256 = bias).
 __global__ __launch_bounds__(256) void lin8_row0_kernel(const float* __restrict__ hbuf, const float* __restrict__ ubuf,
-                                                        const float* __restrict__ sbar, int n_tiles, int P,
+                                                        const float* __restrict__ sbar, int n_tiles, int n_tiles_pad, int P,
                                                         float* __restrict__ out) {
   __shared__ float red[4][32][65];
   const int lane = threadIdx.x & 63, quarter = threadIdx.x >> 6;
@@ -306,10 +308,10 @@ __global__ __launch_bounds__(256) void lin8_row0_kernel(const float* __restrict_
     const int p = t * 32 + (lane & 31);
     const float sb = p < P ? sbar[p] : 0.0f;
     const float live = p < P ? 1.0f : 0.0f;
-    const f32x4* h = reinterpret_cast<const f32x4*>(hbuf + ((size_t)t * 8 + 7) * kBlockF) + quarter * 8 * 64 + lane;
+    const f32x4* h = reinterpret_cast<const f32x4*>(hbuf + ((size_t)7 * n_tiles_pad + t) * kBlockF) + quarter * 8 * 64 + lane;
     f32x4 hv[8], uv[8];
     if (ubuf) {
-      const f32x4* u = reinterpret_cast<const f32x4*>(ubuf + ((size_t)t * 9 + 8) * kBlockF) + quarter * 8 * 64 + lane;
+      const f32x4* u = reinterpret_cast<const f32x4*>(ubuf + ((size_t)8 * n_tiles_pad + t) * kBlockF) + quarter * 8 * 64 + lane;
 #pragma unroll
       for (int i4 = 0; i4 < 8; ++i4) uv[i4] = u[i4 * 64];
     } else {
@@ -496,7 +498,7 @@ int svs_sdf_bwd_b(int n_points, const float* d_sdf, const unsigned char* clamp_m
   }
   SdfBwdBArgs a{n_points, d_sdf, clamp_mask, feat_bar, n_feat_points / 32, hbuf, gbuf, a2buf,
                 reinterpret_cast<const f32x4*>(stream) + kSdfTrainPassBF4, abuf, sbar_out, absmax, a2max,
-                gbuf + 7 * (size_t)kBlockF, 8 * (size_t)kBlockF};
+                gbuf + 7 * (size_t)tiles_of(n_points) * kBlockF, (size_t)kBlockF};     // w0 = ghat_7: block 7 of gbuf ([block][tile])
   if (precision == kFmtF16x2) {
     if (!absmax || !a2max) { set_error("svs_sdf_bwd_b: fp16x2 needs absmax and a2max"); return SVS_EINVAL; }
     return launch_sdf_bwd_b_h2(a, (hipStream_t)hip_stream);
@@ -513,7 +515,7 @@ int svs_lin8_row0_grad(const float* hbuf, const float* ubuf, const float* sbar, 
   if (!hbuf || !sbar || !out257 || n_points <= 0) { set_error("svs_lin8_row0_grad: bad argument"); return SVS_EINVAL; }
   const int n_tiles = (n_points + 31) / 32;
   const int grid = n_tiles < 1024 ? n_tiles : 1024;
-  lin8_row0_kernel<<<grid, 256, 0, (hipStream_t)hip_stream>>>(hbuf, ubuf, sbar, n_tiles, n_points, out257);
+  lin8_row0_kernel<<<grid, 256, 0, (hipStream_t)hip_stream>>>(hbuf, ubuf, sbar, n_tiles, tiles_of(n_points), n_points, out257);
   return check_launch("svs_lin8_row0_grad");
 }
 

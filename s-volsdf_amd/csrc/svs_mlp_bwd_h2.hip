@@ -253,10 +253,11 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_h2_kernel(SdfBwdAArgs a
   st.prefetch<kChunk0F4>();
   PointScale ps;
   Pieces2 pa, pb;
-  const float* hb = a.hbuf + (size_t)wtile * 8 * kBlockF;
-  const float* gb = a.gbuf + (size_t)wtile * 8 * kBlockF;
-  float* ub = a.ubuf + (size_t)wtile * 9 * kBlockF;
-  float* a2 = a.a2buf + (size_t)wtile * 8 * kBlockF;
+  const size_t LS = block_stride();
+  const float* hb = a.hbuf + (size_t)wtile * kBlockF;
+  const float* gb = a.gbuf + (size_t)wtile * kBlockF;
+  float* ub = a.ubuf + (size_t)wtile * kBlockF;
+  float* a2 = a.a2buf + (size_t)wtile * kBlockF;
   {
     float x0, x1, x2;
     load_point(a.src, p, x0, x1, x2);
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_h2_kernel(SdfBwdAArgs a
   {
     // ---- layer 0 (three k-steps per tile: the epilogue of tile t-1 follows tile t's MFMAs)
     PassAEpi<true> ep;
-    ep.out = &pb; ep.ublk = ub + (size_t)kBlockF; ep.a2blk = a2; ep.ps = &ps; ep.splice = splice; ep.a2m = 0.0f;
+    ep.out = &pb; ep.ublk = ub + LS; ep.a2blk = a2; ep.ps = &ps; ep.splice = splice; ep.a2m = 0.0f;
     ep.lane = lane; ep.half = half; ep.l3 = false;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -336,9 +337,9 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_h2_kernel(SdfBwdAArgs a
   // ---- layers 1..6: pb -> pa, copied back (one code body for all layers)
   for (int l = 1; l < 7; ++l) {
     PassAEpi<true> ep;
-    ep.out = &pa; ep.ublk = ub + (size_t)(l + 1) * kBlockF; ep.a2blk = a2 + (size_t)l * kBlockF; ep.ps = &ps;
+    ep.out = &pa; ep.ublk = ub + (size_t)(l + 1) * LS; ep.a2blk = a2 + (size_t)l * LS; ep.ps = &ps;
     ep.splice = splice; ep.a2m = a2m; ep.lane = lane; ep.half = half; ep.l3 = l == 3;
-    pass_a_layer_h2<true, false>(st, pb, ep, hb + (size_t)l * kBlockF, gb + (size_t)l * kBlockF, lane);
+    pass_a_layer_h2<true, false>(st, pb, ep, hb + (size_t)l * LS, gb + (size_t)l * LS, lane);
     a2m = ep.a2m;
 #pragma unroll
     for (int s = 0; s < 16; ++s) { pb.h[s] = pa.h[s]; pb.m[s] = pa.m[s]; }
@@ -346,9 +347,9 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_h2_kernel(SdfBwdAArgs a
   // ---- layer 7: u_8 (only needed for the row-0 gradient of lin8) is stored, not split
   {
     PassAEpi<false> ep;
-    ep.out = nullptr; ep.ublk = ub + (size_t)8 * kBlockF; ep.a2blk = a2 + (size_t)7 * kBlockF; ep.ps = &ps;
+    ep.out = nullptr; ep.ublk = ub + (size_t)8 * LS; ep.a2blk = a2 + (size_t)7 * LS; ep.ps = &ps;
     ep.splice = splice; ep.a2m = a2m; ep.lane = lane; ep.half = half; ep.l3 = false;
-    pass_a_layer_h2<false, true>(st, pb, ep, hb + (size_t)7 * kBlockF, gb + (size_t)7 * kBlockF, lane);
+    pass_a_layer_h2<false, true>(st, pb, ep, hb + (size_t)7 * LS, gb + (size_t)7 * LS, lane);
     a2m = ep.a2m;
   }
   a2m = __builtin_fmaxf(a2m, __shfl_xor(a2m, 32));
@@ -442,10 +443,11 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_h2_kernel(SdfBwdBArgs a
   float sbar = (a.d_sdf && p < a.P) ? a.d_sdf[pc] : 0.0f;
   if (a.clamp_mask && a.clamp_mask[pc]) sbar = 0.0f;
   if (half == 0 && a.sbar_out) a.sbar_out[p] = sbar;
-  const float* hb = a.hbuf + (size_t)wtile * 8 * kBlockF;
+  const size_t LS = block_stride();
+  const float* hb = a.hbuf + (size_t)wtile * kBlockF;
   const float* w0 = a.w0 + (size_t)wtile * a.w0_stride;
-  const float* a2 = A2 ? a.a2buf + (size_t)wtile * 8 * kBlockF : nullptr;
-  float* ab = a.abuf + (size_t)wtile * 8 * kBlockF;
+  const float* a2 = A2 ? a.a2buf + (size_t)wtile * kBlockF : nullptr;
+  float* ab = a.abuf + (size_t)wtile * kBlockF;
   const bool has_f = a.feat_bar && wtile < a.n_feat_tiles;
   PointScale ps;
   Pieces2 pa, pb;
@@ -471,14 +473,14 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_h2_kernel(SdfBwdBArgs a
   {
     // hbar_8 fused with abar_7 (gbuf block 7 = ghat_7 = W8[0,:] s'(a_7) in accumulator layout)
     PassBEpi<true, true, Net, A2> ep;
-    ep.out = &pb; ep.ablk = ab + 7 * (size_t)kBlockF; ep.ps = &ps; ep.sbar = sbar; ep.lane = lane; ep.half = half; ep.l4 = false;
-    pass_b_stage_h2<true, true, false, Net, A2>(st, pa, ep, hb + 7 * (size_t)kBlockF, A2 ? a2 + 7 * (size_t)kBlockF : nullptr, w0, lane);
+    ep.out = &pb; ep.ablk = ab + 7 * LS; ep.ps = &ps; ep.sbar = sbar; ep.lane = lane; ep.half = half; ep.l4 = false;
+    pass_b_stage_h2<true, true, false, Net, A2>(st, pa, ep, hb + 7 * LS, A2 ? a2 + 7 * LS : nullptr, w0, lane);
   }
   // layers 7..2: in = abar_l (pb), out = abar_{l-1} (pa, copied back: one code body for all layers)
   for (int l = 7; l >= 2; --l) {
     PassBEpi<false, true, Net, A2> ep;
-    ep.out = &pa; ep.ablk = ab + (size_t)(l - 1) * kBlockF; ep.ps = &ps; ep.sbar = 0.0f; ep.lane = lane; ep.half = half; ep.l4 = l == 4;
-    pass_b_stage_h2<false, true, false, Net, A2>(st, pb, ep, hb + (size_t)(l - 1) * kBlockF, A2 ? a2 + (size_t)(l - 1) * kBlockF : nullptr, nullptr, lane);
+    ep.out = &pa; ep.ablk = ab + (size_t)(l - 1) * LS; ep.ps = &ps; ep.sbar = 0.0f; ep.lane = lane; ep.half = half; ep.l4 = l == 4;
+    pass_b_stage_h2<false, true, false, Net, A2>(st, pb, ep, hb + (size_t)(l - 1) * LS, A2 ? a2 + (size_t)(l - 1) * LS : nullptr, nullptr, lane);
 #pragma unroll
     for (int s = 0; s < 16; ++s) { pb.h[s] = pa.h[s]; pb.m[s] = pa.m[s]; }
   }

@@ -203,6 +203,12 @@ __device__ __forceinline__ void load_tile_regs(const float* __restrict__ src, f3
   }
 }
 
+// Multi-block activation buffers (hbuf, gbuf, ubuf, a2buf, abuf) are laid out [block][wave tile]: the blocks that all
+// workgroups of a launch touch at the same time (same layer) are contiguous, and so are the blocks one weight-gradient
+// job reads.  [wave tile][block] put concurrent accesses 256 KiB apart: 9 % less HBM throughput in a streaming
+// micro-benchmark (tools/micro/layout_bw.hip: 5.0 vs 5.5 TB/s).  Stride between a tile's consecutive blocks:
+__device__ __forceinline__ size_t block_stride() { return (size_t)gridDim.x * kWaves * kBlockF; }
+
 __device__ __forceinline__ f32x16 load_tile(const float* __restrict__ block, int t, int lane) {
   const f32x4* d = reinterpret_cast<const f32x4*>(block) + lane;
   f32x16 v;
@@ -251,7 +257,7 @@ __device__ __forceinline__ void forward_trunk(Stream& st, f32x16* x, f32x16* y, 
   if (HBUF) store_tile(hbuf, 7, lane, x[7]);
   // ---- layers 1..7 : 256 -> 256 (layer 3 emits 217 rows + the skip splice)
   for (int l = 1; l < 8; ++l) {
-    float* hb = hbuf + (size_t)l * kBlockF;
+    float* hb = hbuf + (size_t)l * block_stride();
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       if (t == 7 && l == 3) break;  // lin3 has 217 outputs = 7 tiles; tile 7 is the PE splice

@@ -90,8 +90,9 @@ __device__ __forceinline__ void reverse_layer_h2(Stream& st, const Pieces2& in, 
                                                  float* gb, f32x16& skip6, f32x16& skip7, int lane, int half) {
   RevEpi ep;
   ep.out = &out; ep.lane = lane; ep.half = half; ep.l4 = l == 4;
-  ep.gblk = gb ? gb + (size_t)(l - 1) * kBlockF : nullptr;
-  const float* hblk = hb + (size_t)(l - 1) * kBlockF;
+  const size_t LS = block_stride();
+  ep.gblk = gb ? gb + (size_t)(l - 1) * LS : nullptr;
+  const float* hblk = hb + (size_t)(l - 1) * LS;
   f32x16 hnext = load_tile(hblk, 0, lane);
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
@@ -127,8 +128,8 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_h2_kernel(SdfFullArgs a)
   PosEnc pe;
   pe.compute(x0, x1, x2);
 
-  float* hb = a.hbuf + (size_t)wtile * 8 * kBlockF;
-  float* gb = a.gbuf ? a.gbuf + (size_t)wtile * 8 * kBlockF : nullptr;
+  float* hb = a.hbuf + (size_t)wtile * kBlockF;                        // block l of this tile: + l * block_stride()
+  float* gb = a.gbuf ? a.gbuf + (size_t)wtile * kBlockF : nullptr;
   Pieces2 x, xn;
   float sdf;
   {
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_h2_kernel(SdfFullArgs a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) g[4 * q + j] = w[j] * dsoftplus_from_h(y8[t][4 * q + j]);
       }
-      if (gb) store_tile(gb + 7 * (size_t)kBlockF, t, lane, g);   // ghat_7 = W8[0,:] * softplus'(a_7)
+      if (gb) store_tile(gb + 7 * block_stride(), t, lane, g);   // ghat_7 = W8[0,:] * softplus'(a_7)
       split_tile(g, t, xn);
       split_tile(y8[t], t, x);
     }

@@ -146,7 +146,7 @@ __device__ __forceinline__ void forward_trunk_h2(Stream& st, Pieces2& x, Pieces2
   // ---- layers 1..6 (layer 3 emits 217 rows + the skip splice)
   for (int l = 1; l < 7; ++l) {
     TrunkEpi<HBUF, false, Net> ep;
-    ep.y8 = nullptr; ep.pe = &pe; ep.hb = hbuf + (size_t)l * kBlockF; ep.lane = lane; ep.half = half; ep.splice = l == 3;
+    ep.y8 = nullptr; ep.pe = &pe; ep.hb = hbuf + (size_t)l * block_stride(); ep.lane = lane; ep.half = half; ep.splice = l == 3;
     // xn -> x, copied back (128 v_mov per layer): one code body for all layers instead of two ping-pong copies
     // (same speed, 20 KB less code, no register spills in the kernels built around the trunk)
     ep.xn = &x; trunk_layer_h2<HBUF, false, Net>(st, xn, ep, lane);
@@ -157,7 +157,7 @@ __device__ __forceinline__ void forward_trunk_h2(Stream& st, Pieces2& x, Pieces2
   }
   // ---- layer 7: input in x (layer 6 wrote it), output kept in float32
   TrunkEpi<HBUF, true, Net> ep;
-  ep.xn = nullptr; ep.y8 = y8; ep.pe = &pe; ep.hb = hbuf + (size_t)7 * kBlockF; ep.lane = lane; ep.half = half; ep.splice = false;
+  ep.xn = nullptr; ep.y8 = y8; ep.pe = &pe; ep.hb = hbuf + (size_t)7 * block_stride(); ep.lane = lane; ep.half = half; ep.splice = false;
   trunk_layer_h2<HBUF, true, Net>(st, x, ep, lane);
 }
 

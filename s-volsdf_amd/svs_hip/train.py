@@ -18,6 +18,12 @@ from . import lib as _lib
 from .ops import _f32, _ptr, _ptr_array, _stream, default_precision, F16X2
 
 KBLOCK = 128 * 64           # floats per wave-tile activation block
+
+
+def block_stride(n_points):
+    """Floats between consecutive blocks of one wave tile in the multi-block activation buffers (hbuf, gbuf, ubuf, a2buf,
+    abuf), which are laid out [block][wave tile] with the tile count padded to whole workgroups (svs_mlp_dev.h)."""
+    return ((n_points + 127) // 128) * 4 * KBLOCK
 RBUF = 4 * KBLOCK + 1024    # radiance forward activations per tile
 LDW = 288
 
@@ -142,7 +148,7 @@ class MlpBackward:
             raise NotImplementedError("rays*samples of a group must be a multiple of 32")
         self._alloc(n_total, n_main)
         dev, acc, S = self.dev, self.accum, self.streams
-        H8, U9, A8 = 8 * KBLOCK, 9 * KBLOCK, 8 * KBLOCK
+        LS = block_stride(n_total)
         hbuf, gbuf, mask = keep["hbuf"], keep["gbuf"], keep["clamp_mask"]
         rbuf, feat = keep["rbuf"], keep["feat_tiles"]
 
@@ -200,12 +206,12 @@ class MlpBackward:
         ev = self.timer_events = ([torch.cuda.Event(enable_timing=True) for _ in range(2)] if self.time_wgrad else None)
         if ev:
             ev[0].record()
-        jobs = [job(0, n_total, 0, _off(self.abuf, 0), A8, _ptr(self.pebuf), KBLOCK,
-                    _off(gbuf, 0), H8, _off(self.ubuf, 0), U9)]
+        jobs = [job(0, n_total, 0, _off(self.abuf, 0), KBLOCK, _ptr(self.pebuf), KBLOCK,
+                    _off(gbuf, 0), KBLOCK, _off(self.ubuf, 0), KBLOCK)]
         for l in range(1, 8):
-            jobs.append(job(l, n_total, 0, _off(self.abuf, l * KBLOCK), A8, _off(hbuf, (l - 1) * KBLOCK), H8,
-                            _off(gbuf, l * KBLOCK), H8, _off(self.ubuf, l * KBLOCK), U9))
-        jobs.append(job(8, n_main, 2, _ptr(self.feat_bar), KBLOCK, _off(hbuf, 7 * KBLOCK), H8))
+            jobs.append(job(l, n_total, 0, _off(self.abuf, l * LS), KBLOCK, _off(hbuf, (l - 1) * LS), KBLOCK,
+                            _off(gbuf, l * LS), KBLOCK, _off(self.ubuf, l * LS), KBLOCK))
+        jobs.append(job(8, n_main, 2, _ptr(self.feat_bar), KBLOCK, _off(hbuf, 7 * LS), KBLOCK))
         wgrad_multi(jobs)
         if ev:
             ev[1].record()
@@ -275,7 +281,7 @@ class BgBackward:
         _lib.check(L.svs_bg_sdf_bwd(P, _ptr(d_bg_out0), _ptr(feat_bar), _ptr(hbuf), _ptr(ghat7), _ptr(self.sdf_stream),
                                     _ptr(abuf), _ptr(sbar), _ptr(self.absmax), st), "svs_bg_sdf_bwd")
         _lib.check(L.svs_lin8_row0_grad(_ptr(hbuf), None, _ptr(sbar), P, _ptr(self.row0), st), "svs_lin8_row0_grad")
-        H8, A8, Z2 = 8 * KBLOCK, 8 * KBLOCK, 2 * KBLOCK
+        LS, Z2 = block_stride(P), 2 * KBLOCK
 
         def addr(x):
             return x.value if isinstance(x, ctypes.c_void_p) else x
@@ -285,10 +291,10 @@ class BgBackward:
                                  addr(_off(self.dWk, slot * 256 * LDW)), addr(_off(self.dbk, slot * 256)),
                                  addr(_off(self.absmax, amax)))
 
-        jobs = [job(0, 0, _off(abuf, 0), A8, _ptr(pebuf), KBLOCK)]
+        jobs = [job(0, 0, _off(abuf, 0), KBLOCK, _ptr(pebuf), KBLOCK)]
         for l in range(1, 8):
-            jobs.append(job(l, 0, _off(abuf, l * KBLOCK), A8, _off(hbuf, (l - 1) * KBLOCK), H8))
-        jobs.append(job(8, 2, _ptr(feat_bar), KBLOCK, _off(hbuf, 7 * KBLOCK), H8))
+            jobs.append(job(l, 0, _off(abuf, l * LS), KBLOCK, _off(hbuf, (l - 1) * LS), KBLOCK))
+        jobs.append(job(8, 2, _ptr(feat_bar), KBLOCK, _off(hbuf, 7 * LS), KBLOCK))
         jobs.append(job(9, 1, _off(zbuf, 0), Z2, _ptr(feat), KBLOCK, extra=_off(rbuf, KBLOCK), sx=self.BGRBUF))
         jobs.append(job(10, 1, _off(zbuf, KBLOCK), Z2, _ptr(rbuf), self.BGRBUF))
         arr = (_lib.WGradJob * len(jobs))(*jobs)

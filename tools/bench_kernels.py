@@ -83,14 +83,15 @@ def main():
     t = timeit(lambda: lib.check(L.svs_sdf_bwd_b(n_total, P(dsf), P(mask), P(bw.feat_bar), n_main, P(hbuf), P(gbuf), P(bw.a2buf),
                                                  P(bw.streams.sdf), prec, P(bw.abuf), P(bw.sbar), N(am), N(bw.a2max), st())))
     res["sdf_bwd_b"] = dict(ms=t, tflops=n_total * F_SDF / t / 1e9)
-    H8, U9, A8 = 8 * KBLOCK, 9 * KBLOCK, 8 * KBLOCK
+    from svs_hip.train import block_stride
+    LS = block_stride(n_total)
     dW = torch.zeros(256, 288, device=dev); db = torch.zeros(256, device=dev)
     l = 2
-    t = timeit(lambda: lib.check(L.svs_wgrad(_off(bw.abuf, l * KBLOCK), _off(hbuf, (l - 1) * KBLOCK), A8, H8,
-                                             _off(gbuf, l * KBLOCK), _off(bw.ubuf, l * KBLOCK), H8, U9,
+    t = timeit(lambda: lib.check(L.svs_wgrad(_off(bw.abuf, l * LS), _off(hbuf, (l - 1) * LS), KBLOCK, KBLOCK,
+                                             _off(gbuf, l * LS), _off(bw.ubuf, l * LS), KBLOCK, KBLOCK,
                                              None, 0, n_total, prec, N(am), P(dW), 288, P(db), st())))
     res["wgrad_2pair"] = dict(ms=t, tflops=2 * 2 * 256 * 256 * n_total / t / 1e9)
-    t = timeit(lambda: lib.check(L.svs_wgrad(P(bw.feat_bar), _off(hbuf, 7 * KBLOCK), KBLOCK, H8, None, None, 0, 0,
+    t = timeit(lambda: lib.check(L.svs_wgrad(P(bw.feat_bar), _off(hbuf, 7 * LS), KBLOCK, KBLOCK, None, None, 0, 0,
                                              None, 0, n_main, prec, _off(am, 2) if h2 else None, P(dW), 288, P(db), st())))
     res["wgrad_1pair"] = dict(ms=t, tflops=2 * 256 * 256 * n_main / t / 1e9)
     if True:
