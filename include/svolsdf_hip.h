@@ -202,10 +202,12 @@ int svs_wgrad(const float* a0, const float* b0, long long sa0, long long sb0, co
 /* ---- a12  training backward of the fused MLPs (hand-written reverse mode; the reference uses torch.autograd,
  * loss.backward() at volsdf/vsdf.py:215, incl. the double backward through network.py:115-121) -------------------
  * Buffers are wave-tile activation blocks; svs_block_bytes(n_points, k) = bytes of k blocks per 32-point tile.
- * Layout of the multi-block SDF buffers (hbuf, gbuf, ubuf, a2buf, abuf): [block][wave tile][128*64 floats], the tile
+ * Layout of the multi-block buffers (hbuf, gbuf, ubuf, a2buf, abuf, rbuf, zbuf): [block][wave tile][128*64 floats], the tile
  * count T padded to whole workgroups (T = 4 * ceil(n_points / 128)): block b of tile t starts at float (b * T + t) *
  * 8192 -- what a launch touches at one time and what one weight-gradient job reads is contiguous (for svs_wgrad:
- * pointer = buffer + b * T * 8192, stride 8192).  The radiance buffers (rbuf, zbuf) keep [tile][block].
+ * pointer = buffer + b * T * 8192, stride 8192).  The radiance buffers use the same layout: rbuf = [4 blocks][tile]
+ * followed by the 1024-float extras of every tile, zbuf = [5 blocks][tile]; the background networks' two small
+ * buffers (bg rbuf, bg zbuf) are [tile][block].
  *   svs_rgb_bwd : d_rgb (P,3), rgb (P,3), rbuf, radiance backward stream (svs_pack_stream which=4)
  *                 -> zbuf (5 blocks/tile, ZERO-INITIALISED by the caller once), feat_bar (1 block/tile), d_normals (P,3)
  *   svs_sdf_bwd_a: second-order sweep.  points/rays as in svs_sdf_outputs; d_grad (P,3) = dL/d(d sdf/dx);

@@ -232,9 +232,11 @@ __global__ __launch_bounds__(kThreads, 1) void rgb_kernel(RgbArgs a) {
 
   f32x16 x[8], y[8];
   load_tile_regs(a.feat_tiles + (size_t)wtile * 128 * 64, x, lane);
-  float* rb = a.rbuf ? a.rbuf + (size_t)wtile * kRbufF : nullptr;
+  // rbuf: [block 0..3][wave tile][128*64] then the extras [wave tile][1024] (same [block][tile] layout as the SDF buffers)
+  const size_t LS = block_stride();
+  float* rb = a.rbuf ? a.rbuf + (size_t)wtile * kBlockF : nullptr;
   if (rb) {
-    f32x4* d = reinterpret_cast<f32x4*>(rb + 4 * (size_t)kBlockF) + lane;
+    f32x4* d = reinterpret_cast<f32x4*>(a.rbuf + 4 * LS + (size_t)wtile * 1024) + lane;
     f32x4 v0, v1; v0[0] = eb[0]; v0[1] = eb[1]; v0[2] = eb[2]; v0[3] = eb[3]; v1[0] = eb[4]; v1[1] = eb[5]; v1[2] = eb[6]; v1[3] = eb[7];
     d[0] = v0; d[64] = v1; d[128] = (f32x4)(0.0f); d[192] = (f32x4)(0.0f);
   }
@@ -265,14 +267,14 @@ __global__ __launch_bounds__(kThreads, 1) void rgb_kernel(RgbArgs a) {
     for (int t = 0; t < 8; ++t) x[t] = y[t];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      if (rb && t > 0) store_tile(rb + (size_t)l * kBlockF, t - 1, lane, y[t - 1]);
+      if (rb && t > 0) store_tile(rb + (size_t)l * LS, t - 1, lane, y[t - 1]);
       st.prefetch<kChunkF4>();
       const f32x16 acc = tile_mma<128>(st.cur_buf(), x, lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) y[t][r] = __builtin_fmaxf(acc[r], 0.0f);
       st.advance();
     }
-    if (rb) store_tile(rb + (size_t)l * kBlockF, 7, lane, y[7]);
+    if (rb) store_tile(rb + (size_t)l * LS, 7, lane, y[7]);
   }
   // ---- layer 4: 256 -> 3 as one tile (rows 0..2 live in registers 0..2 of lanes 0..31), sigmoid
   const f32x16 acc = tile_mma<128>(st.cur_buf(), y, lane);

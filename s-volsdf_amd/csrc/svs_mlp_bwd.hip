@@ -34,8 +34,9 @@ __global__ __launch_bounds__(kThreads, 1) void rgb_bwd_kernel(RgbBwdArgs a) {
   const int p = wtile * kTilePts + (lane & 31);
   const bool livep = p < a.P;
   const int pc = livep ? p : a.P - 1;
-  const float* rb = a.rbuf + (size_t)wtile * kRbufFb;
-  float* zb = a.zbuf + (size_t)wtile * 5 * kBlockF;
+  const size_t LS = block_stride();                    // rbuf, zbuf: [block][wave tile]
+  const float* rb = a.rbuf + (size_t)wtile * kBlockF;
+  float* zb = a.zbuf + (size_t)wtile * kBlockF;
 
   st.prefetch<kW4TF4>();
   float dz[3];
@@ -47,13 +48,13 @@ __global__ __launch_bounds__(kThreads, 1) void rgb_bwd_kernel(RgbBwdArgs a) {
   {  // zbar_4: rows 0..2 live in registers 0..2 of half 0, tile 0
     f32x16 z4 = (f32x16)(0.0f);
     z4[0] = dz[0]; z4[1] = dz[1]; z4[2] = dz[2];
-    store_tile(zb + 4 * (size_t)kBlockF, 0, lane, z4);
+    store_tile(zb + 4 * LS, 0, lane, z4);
   }
   st.advance();
   f32x16 x[8], y[8];
   // rbar_4 = W_4^T zbar_4 (3 k-steps per tile), masked by r_4 > 0 -> zbar_3.  All of r_4 is requested up front.
   st.prefetch<kChunkF4>();
-  load_tile_regs(rb + 3 * (size_t)kBlockF, y, lane);
+  load_tile_regs(rb + 3 * LS, y, lane);
   {
     const f32x4* c = st.cur_buf();
 #pragma unroll
@@ -71,13 +72,13 @@ __global__ __launch_bounds__(kThreads, 1) void rgb_bwd_kernel(RgbBwdArgs a) {
   for (int t = 0; t < 8; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) y[t][i] = y[t][i] > 0.0f ? x[t][i] : 0.0f;
-  store_tile_regs(zb + 3 * (size_t)kBlockF, y, lane);
+  store_tile_regs(zb + 3 * LS, y, lane);
   st.advance();
   // layers 3..1: rbar_l = W_l^T zbar_l, fused per tile with zbar_{l-1} = rbar_l * [r_l > 0]; the r_l tile is requested
   // before the tile's MFMAs and the zbar tile is stored at the top of the next tile
   for (int l = 3; l >= 1; --l) {
-    const float* rblk = rb + (size_t)(l - 1) * kBlockF;
-    float* zblk = zb + (size_t)(l - 1) * kBlockF;
+    const float* rblk = rb + (size_t)(l - 1) * LS;
+    float* zblk = zb + (size_t)(l - 1) * LS;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       if (t > 0) store_tile(zblk, t - 1, lane, x[t - 1]);

@@ -78,8 +78,9 @@ __global__ __launch_bounds__(kThreads, 1) void rgb_bwd_h2_kernel(RgbBwdArgs a) {
   const int p = wtile * kTilePts + (lane & 31);
   const bool livep = p < a.P;
   const int pc = livep ? p : a.P - 1;
-  const float* rb = a.rbuf + (size_t)wtile * kRbufFb;
-  float* zb = a.zbuf + (size_t)wtile * 5 * kBlockF;
+  const size_t LS = block_stride();                    // rbuf, zbuf: [block][wave tile]
+  const float* rb = a.rbuf + (size_t)wtile * kBlockF;
+  float* zb = a.zbuf + (size_t)wtile * kBlockF;
 
   st.prefetch<kW4TF4>();
   float dz[3];
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(kThreads, 1) void rgb_bwd_h2_kernel(RgbBwdArgs a) {
   {  // zbar_4: rows 0..2 live in registers 0..2 of half 0, tile 0
     f32x16 z4 = (f32x16)(0.0f);
     z4[0] = dz[0]; z4[1] = dz[1]; z4[2] = dz[2];
-    store_tile(zb + 4 * (size_t)kBlockF, 0, lane, z4);
+    store_tile(zb + 4 * LS, 0, lane, z4);
   }
   st.advance();
   Pieces2 pa, pb;
@@ -104,8 +105,8 @@ __global__ __launch_bounds__(kThreads, 1) void rgb_bwd_h2_kernel(RgbBwdArgs a) {
   st.prefetch<kChunkF4>();
   {
     const f32x4* c = st.cur_buf();
-    const float* r4 = rb + 3 * (size_t)kBlockF;
-    float* z3 = zb + 3 * (size_t)kBlockF;
+    const float* r4 = rb + 3 * LS;
+    float* z3 = zb + 3 * LS;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const f32x16 r = load_tile(r4, t, lane);
@@ -123,8 +124,8 @@ __global__ __launch_bounds__(kThreads, 1) void rgb_bwd_h2_kernel(RgbBwdArgs a) {
   ps.next();
   st.advance();
   // layers 3..1
-  rgb_bwd_layer_h2(st, pa, pb, rb + 2 * (size_t)kBlockF, zb + 2 * (size_t)kBlockF, ps, lane);
-  rgb_bwd_layer_h2(st, pb, pa, rb + 1 * (size_t)kBlockF, zb + 1 * (size_t)kBlockF, ps, lane);
+  rgb_bwd_layer_h2(st, pa, pb, rb + 2 * LS, zb + 2 * LS, ps, lane);
+  rgb_bwd_layer_h2(st, pb, pa, rb + 1 * LS, zb + 1 * LS, ps, lane);
   rgb_bwd_layer_h2(st, pa, pb, rb, zb, ps, lane);
   // layer 0: the input gradients from zbar_0 (feature rows: tiles 0..7, extras: tile 8)
   float* fb = a.feat_bar + (size_t)wtile * kBlockF;

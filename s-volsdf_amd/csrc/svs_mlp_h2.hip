@@ -310,9 +310,11 @@ __global__ __launch_bounds__(kThreads, 1) void rgb_h2_kernel(RgbArgs a) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) split_tile(load_tile(ft, t, lane), t, x);
   }
-  float* rb = a.rbuf ? a.rbuf + (size_t)wtile * kRbufF : nullptr;
+  // rbuf: [block 0..3][wave tile][128*64] then the extras [wave tile][1024] (same [block][tile] layout as the SDF buffers)
+  const size_t LS = block_stride();
+  float* rb = a.rbuf ? a.rbuf + (size_t)wtile * kBlockF : nullptr;
   if (rb) {
-    f32x4* d = reinterpret_cast<f32x4*>(rb + 4 * (size_t)kBlockF) + lane;
+    f32x4* d = reinterpret_cast<f32x4*>(a.rbuf + 4 * LS + (size_t)wtile * 1024) + lane;
     f32x4 v0, v1; v0[0] = eb[0]; v0[1] = eb[1]; v0[2] = eb[2]; v0[3] = eb[3]; v1[0] = eb[4]; v1[1] = eb[5]; v1[2] = eb[6]; v1[3] = eb[7];
     d[0] = v0; d[64] = v1; d[128] = (f32x4)(0.0f); d[192] = (f32x4)(0.0f);
   }
@@ -320,9 +322,9 @@ __global__ __launch_bounds__(kThreads, 1) void rgb_h2_kernel(RgbArgs a) {
 
   // ---- layer 0: 271 -> 256; layers 1..3; every output r_l (post-ReLU) optionally kept in rbuf
   rgb_layer_h2<17, kChunkF4>(st, x, xn, rb, lane);
-  rgb_layer_h2<16, kChunkF4>(st, xn, x, rb ? rb + 1 * (size_t)kBlockF : nullptr, lane);
-  rgb_layer_h2<16, kChunkF4>(st, x, xn, rb ? rb + 2 * (size_t)kBlockF : nullptr, lane);
-  rgb_layer_h2<16, kChunkF4>(st, xn, x, rb ? rb + 3 * (size_t)kBlockF : nullptr, lane);   // prefetches lin4's chunk
+  rgb_layer_h2<16, kChunkF4>(st, xn, x, rb ? rb + 1 * LS : nullptr, lane);
+  rgb_layer_h2<16, kChunkF4>(st, x, xn, rb ? rb + 2 * LS : nullptr, lane);
+  rgb_layer_h2<16, kChunkF4>(st, xn, x, rb ? rb + 3 * LS : nullptr, lane);   // prefetches lin4's chunk
   // ---- layer 4: 256 -> 3 as one tile (rows 0..2 live in registers 0..2 of lanes 0..31), sigmoid
   const f32x16 acc = tile_mma_h2<16>(st.cur_buf(), x, lane);
   if (half == 0 && p < a.src.P) {

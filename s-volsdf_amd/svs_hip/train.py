@@ -24,7 +24,6 @@ def block_stride(n_points):
     """Floats between consecutive blocks of one wave tile in the multi-block activation buffers (hbuf, gbuf, ubuf, a2buf,
     abuf), which are laid out [block][wave tile] with the tile count padded to whole workgroups (svs_mlp_dev.h)."""
     return ((n_points + 127) // 128) * 4 * KBLOCK
-RBUF = 4 * KBLOCK + 1024    # radiance forward activations per tile
 LDW = 288
 
 
@@ -187,9 +186,10 @@ class MlpBackward:
         fork = torch.cuda.Event(); fork.record(main)
         with torch.cuda.stream(self._side):
             self._side.wait_event(fork)
-            jobs = [job(9, n_main, 1, _off(self.zbuf, 0), 5 * KBLOCK, _ptr(feat), KBLOCK, extra=_off(rbuf, 4 * KBLOCK), sx=RBUF)]
+            LSm = block_stride(n_main)              # rbuf = [4 blocks][tile] + extras [tile][1024], zbuf = [5 blocks][tile]
+            jobs = [job(9, n_main, 1, _off(self.zbuf, 0), KBLOCK, _ptr(feat), KBLOCK, extra=_off(rbuf, 4 * LSm), sx=1024)]
             for l in range(1, 5):
-                jobs.append(job(9 + l, n_main, 1, _off(self.zbuf, l * KBLOCK), 5 * KBLOCK, _off(rbuf, (l - 1) * KBLOCK), RBUF))
+                jobs.append(job(9 + l, n_main, 1, _off(self.zbuf, l * LSm), KBLOCK, _off(rbuf, (l - 1) * LSm), KBLOCK))
             wgrad_multi(jobs)
             join = torch.cuda.Event(); join.record(self._side)
         # ---- SDF MLP: pass A (needs nbar), pass B (needs sbar, fbar), then its weight gradients
