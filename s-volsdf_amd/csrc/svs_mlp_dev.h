@@ -26,6 +26,20 @@ __device__ __forceinline__ void chunk_issue(const f32x4* __restrict__ g, f32x4* 
   }
 }
 
+// piece i (one wave-instruction, 1 KiB) of the same copy, for callers that spread the pieces over their MFMA gaps
+template <int N16>
+__device__ __forceinline__ void chunk_issue_piece(const f32x4* __restrict__ g, f32x4* lds, int i) {
+  static_assert(N16 % 64 == 0, "chunk must be a whole number of wave-instructions");
+  const int tid = threadIdx.x;
+  const int idx = i * kThreads + (tid & ~63);  // wave-uniform
+  if (idx < N16) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + idx + (tid & 63)),
+                                     (__attribute__((address_space(3))) void*)(lds + idx), 16, 0, 0);
+  }
+}
+template <int N16>
+constexpr int chunk_pieces() { return (N16 + kThreads - 1) / kThreads; }
+
 struct Stream {
   const f32x4* g;  // next chunk to fetch
   f32x4* buf;      // LDS: two buffers of kChunkF4
@@ -34,13 +48,30 @@ struct Stream {
   __device__ __forceinline__ const f32x4* cur_buf() const { return buf + cur * kChunkF4; }
   template <int N16>
   __device__ __forceinline__ void prefetch() {
+#if !(defined(SVS_ABL) && (SVS_ABL & 64))
     chunk_issue<N16>(g, buf + (cur ^ 1) * kChunkF4);
+#endif
     g += N16;
   }
+  // prefetch() in pieces: ceil(pieces / KS) of them at each of the first steps of a KS-step tile, then prefetch_done().
+  // An LDS-DMA instruction costs its wave 60+ cycles of issue; spread over the first MFMA gaps of the tile the pieces
+  // run under the matrix core instead of in front of it, and still land long before the tile ends.
+  template <int N16, int KS>
+  __device__ __forceinline__ void prefetch_step(int s) {
+#if !(defined(SVS_ABL) && (SVS_ABL & 64))
+    constexpr int np = chunk_pieces<N16>(), per = (np + KS - 1) / KS;
+#pragma unroll
+    for (int i = per * s; i < per * (s + 1) && i < np; ++i) chunk_issue_piece<N16>(g, buf + (cur ^ 1) * kChunkF4, i);
+#endif
+  }
+  template <int N16>
+  __device__ __forceinline__ void prefetch_done() { g += N16; }
   // the chunk fetched by prefetch() becomes current: own loads landed, then everyone's
   __device__ __forceinline__ void advance() {
+#if !(defined(SVS_ABL) && (SVS_ABL & 8))
     __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) lgkmcnt(0) expcnt(0)
     __syncthreads();
+#endif
     cur ^= 1;
   }
   // The same, but the N youngest vector-memory operations of the wave -- float32 activation stores that the epilogue
@@ -50,7 +81,9 @@ struct Stream {
   // of vector-memory instructions the wave really issued after prefetch().
   template <int N>
   __device__ __forceinline__ void advance_keep() {
+#if !(defined(SVS_ABL) && (SVS_ABL & 8))
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+#endif
     cur ^= 1;
   }
 };

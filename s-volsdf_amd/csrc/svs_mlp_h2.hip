@@ -22,16 +22,27 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_only_h2_kernel(SdfOnlyArgs a)
   st.cur = 1;
   const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
   const int p = (blockIdx.x * kWaves + wave) * kTilePts + (lane & 31);
+#if SVS_ABL & 16   // diagnostic: cycle stamps of wave 0 replace the first outputs of the workgroup
+  const uint64_t c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   st.prefetch<kChunk0F4>();   // chunk 0 -> buffer 0 (overlaps the positional encoding below)
   float x0, x1, x2;
   load_point(a.src, p, x0, x1, x2);
   PosEnc pe;
   pe.compute(x0, x1, x2);
+#if SVS_ABL & 16
+  asm volatile("" : "+v"(pe.v[38]));
+  const uint64_t c1 = __builtin_amdgcn_s_memtime();
+#endif
 
   Pieces2 x, xn;
   f32x16 y8[8];
   forward_trunk_h2<false>(st, x, xn, y8, pe, lane, half, nullptr);
+#if SVS_ABL & 16
+  asm volatile("" : "+v"(y8[7][15]));
+  const uint64_t c2 = __builtin_amdgcn_s_memtime();
+#endif
   // the VEC chunk was prefetched by the last tile of layer 7
   float sdf = sdf_head(st.cur_buf(), y8, lane);
   if (a.sphere_radius > 0.0f && p < a.clamp_n) {
@@ -39,6 +50,16 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_only_h2_kernel(SdfOnlyArgs a)
     sdf = __builtin_fminf(sdf, a.sphere_scale * (a.sphere_radius - nrm));
   }
   if (half == 0 && p < a.src.P) a.sdf[p] = sdf;
+#if SVS_ABL & 16
+  asm volatile("" : "+v"(sdf));
+  const uint64_t c3 = __builtin_amdgcn_s_memtime(), r3 = __builtin_amdgcn_s_memrealtime();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float* o = a.sdf + (size_t)blockIdx.x * kWgPts;
+    o[0] = (float)(c1 - c0); o[1] = (float)(c2 - c1); o[2] = (float)(c3 - c2); o[3] = (float)(c3 - c0);
+    o[4] = (float)(r3 - r0); o[5] = (float)(r0 & 0xffffff);
+  }
+#endif
 }
 
 // --------------------------------------------------------------------------------------------------------------
@@ -98,15 +119,15 @@ __device__ __forceinline__ void reverse_layer_h2(Stream& st, const Pieces2& in, 
   for (int t = 0; t < 8; ++t) {
     const f32x16 hcur = hnext;
     if (t < 7) hnext = load_tile(hblk, t + 1, lane);   // arrives while this tile's MFMAs run
-    st.prefetch<kChunkF4>();                           // next reverse chunk (the last one prefetches REV0 tile 0)
+    // the next reverse chunk (the last one: REV0 tile 0) is fetched in pieces behind k-steps 0..8
     f32x16 acc;
-    if (t == 0) acc = tile_mma_h2<16>(st.cur_buf(), in, lane);
-    else acc = tile_mma_h2<16>(st.cur_buf(), in, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.b(t - 1, s); });
+    if (t == 0) acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, NoEpi(), NoEpi());
+    else acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.b(t - 1, s); });
     if (l == 4 && t == 7) skip7 = acc;
     if (l == 4 && t == 6) skip6 = acc;
     ep.prev = acc;
     ep.h = hcur;
-    if (gb && t > 0) st.advance_keep<4>();            // the 4 gbuf stores of tile t-1's epilogue stay in flight
+    if (gb && t > 0) st.advance_keep<2>();            // the gbuf stores of k-steps 11 and 15 (younger than every piece) stay in flight
     else st.advance();
   }
   ep.all(7);
@@ -167,10 +188,9 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_h2_kernel(SdfFullArgs a)
     };
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      st.prefetch<kChunkF4>();                      // FEAT t+1, or reverse L7 tile 0
-      f32x16 acc;
-      if (t == 0) acc = tile_mma_h2<16>(st.cur_buf(), x, lane);
-      else acc = tile_mma_h2<16>(st.cur_buf(), x, lane, NoEpi(), [&](int s) { store_slice(t - 1, s); });
+      f32x16 acc;                                   // prefetching FEAT t+1, or reverse L7 tile 0
+      if (t == 0) acc = tile_mma_h2_pf<16, kChunkF4>(st, x, lane, NoEpi(), NoEpi());
+      else acc = tile_mma_h2_pf<16, kChunkF4>(st, x, lane, NoEpi(), [&](int s) { store_slice(t - 1, s); });
       prev = acc;
       st.advance();
     }
@@ -341,16 +361,18 @@ using namespace svs::mlp;
 
 namespace svs {
 namespace mlp {
+// diagnostic builds with fewer registers must not become two workgroups per CU: pad the LDS request
+constexpr int kLdsAbl = (SVS_ABL & 32) ? 0 : (SVS_ABL ? 20480 : 0);
 int launch_sdf_only_h2(const SdfOnlyArgs& a, hipStream_t s) {
-  static int once = set_lds(sdf_only_h2_kernel, kLdsBytes, "svs_sdf_vals");
+  static int once = set_lds(sdf_only_h2_kernel, kLdsBytes + kLdsAbl, "svs_sdf_vals");
   if (once) return once;
-  sdf_only_h2_kernel<<<(a.src.P + kWgPts - 1) / kWgPts, kThreads, kLdsBytes, s>>>(a);
+  sdf_only_h2_kernel<<<(a.src.P + kWgPts - 1) / kWgPts, kThreads, kLdsBytes + kLdsAbl, s>>>(a);
   return check_launch("svs_sdf_vals");
 }
 int launch_sdf_full_h2(const SdfFullArgs& a, hipStream_t s) {
-  static int once = set_lds(sdf_full_h2_kernel, kLdsBytes, "svs_sdf_outputs");
+  static int once = set_lds(sdf_full_h2_kernel, kLdsBytes + kLdsAbl, "svs_sdf_outputs");
   if (once) return once;
-  sdf_full_h2_kernel<<<(a.src.P + kWgPts - 1) / kWgPts, kThreads, kLdsBytes, s>>>(a);
+  sdf_full_h2_kernel<<<(a.src.P + kWgPts - 1) / kWgPts, kThreads, kLdsBytes + kLdsAbl, s>>>(a);
   return check_launch("svs_sdf_outputs");
 }
 int launch_rgb_h2(const RgbArgs& a, hipStream_t s) {

@@ -80,6 +80,19 @@ __device__ __forceinline__ f32x16 tile_bias(const f32x4* __restrict__ chunk, int
   return acc;
 }
 
+// Diagnostic builds (tools/ablate_fwd.sh): -DSVS_ABL=<mask> compiles parts of the forward kernels out to time the rest
+// (results are then wrong by construction).  1: identity instead of softplus, 2: no operand split, 4: no MFMAs,
+// 8: no chunk wait / barrier, 16: cycle stamps instead of results (sdf_only), 32: let the slimmer variants run two
+// workgroups per CU (otherwise their LDS request is padded to keep one).  Never defined in the product build.
+#ifndef SVS_ABL
+#define SVS_ABL 0
+#endif
+#if SVS_ABL & 4
+#define SVS_ABL_MFMA(x)
+#else
+#define SVS_ABL_MFMA(x) x
+#endif
+
 struct NoEpi { __device__ __forceinline__ void operator()(int) const {} };
 
 // One output tile: acc(32 rows x 32 points) = hdr(bias) + sum over KS k-steps of (mid*hi + hi*mid + hi*hi).
@@ -87,9 +100,10 @@ struct NoEpi { __device__ __forceinline__ void operator()(int) const {} };
 // second MFMA of k-step s, so that their VALU work runs while the matrix core is busy.  The A fragments of k-step
 // s+1 are read right after the first MFMA of k-step s: the wait hipcc places before their first use (always
 // lgkmcnt(0)) then has two MFMAs of cover.
-template <int KS, typename EpiA, typename EpiB>
+// dma(s): the slice of the next chunk's LDS-DMA issued behind the third MFMA of k-step s (Stream::prefetch_step).
+template <int KS, typename EpiA, typename EpiB, typename Dma = NoEpi>
 __device__ __forceinline__ f32x16 tile_mma_h2(const f32x4* __restrict__ chunk, const Pieces2& x, int lane, EpiA ea, EpiB eb,
-                                              int first_step = 0) {
+                                              int first_step = 0, Dma dma = Dma()) {
   f32x16 acc = tile_bias(chunk, lane);
   const f16x8* a_ptr = reinterpret_cast<const f16x8*>(chunk + kHdrF4) + lane;
   f16x8 ah = a_ptr[0], am = a_ptr[64];
@@ -97,17 +111,18 @@ __device__ __forceinline__ f32x16 tile_mma_h2(const f32x4* __restrict__ chunk, c
   for (int s = 0; s < KS; ++s) {
     f16x8 nh, nm;
     __builtin_amdgcn_sched_barrier(0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, x.h[first_step + s], acc, 0, 0, 0);
+    SVS_ABL_MFMA(acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, x.h[first_step + s], acc, 0, 0, 0));
     __builtin_amdgcn_sched_barrier(0);
     if (s + 1 < KS) { nh = a_ptr[(2 * s + 2) * 64]; nm = a_ptr[(2 * s + 3) * 64]; }
     ea(s);
     __builtin_amdgcn_sched_barrier(0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, x.m[first_step + s], acc, 0, 0, 0);
+    SVS_ABL_MFMA(acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, x.m[first_step + s], acc, 0, 0, 0));
     __builtin_amdgcn_sched_barrier(0);
     eb(s);
     __builtin_amdgcn_sched_barrier(0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, x.h[first_step + s], acc, 0, 0, 0);
+    SVS_ABL_MFMA(acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, x.h[first_step + s], acc, 0, 0, 0));
     __builtin_amdgcn_sched_barrier(0);
+    dma(s);
     if (s + 1 < KS) { ah = nh; am = nm; }
   }
   return acc;
@@ -117,13 +132,25 @@ __device__ __forceinline__ f32x16 tile_mma_h2(const f32x4* __restrict__ chunk, c
   return tile_mma_h2<KS>(chunk, x, lane, NoEpi(), NoEpi());
 }
 
+// tile_mma_h2 on the current chunk with the prefetch of the next chunk (N16 float4) spread over its k-steps
+template <int KS, int N16, typename EpiA, typename EpiB>
+__device__ __forceinline__ f32x16 tile_mma_h2_pf(Stream& st, const Pieces2& x, int lane, EpiA ea, EpiB eb) {
+  const f32x16 acc = tile_mma_h2<KS>(st.cur_buf(), x, lane, ea, eb, 0, [&](int s) { st.prefetch_step<N16, KS>(s); });
+  st.prefetch_done<N16>();
+  return acc;
+}
+
 // softplus100 in two slices (see tile_mma_h2): A = exp2 / max / log2, B = the final fma
 struct SoftplusA { float mx, lg; };
 __device__ __forceinline__ SoftplusA softplus100_a(float a) {
   SoftplusA r;
+#if SVS_ABL & 1
+  r.mx = a; r.lg = 0.0f;
+#else
   const float e = __builtin_amdgcn_exp2f(__builtin_fabsf(a) * (-100.0f * 1.44269504088896341f));
   r.mx = __builtin_fmaxf(a, 0.0f);
   r.lg = __builtin_amdgcn_logf(1.0f + e);
+#endif
   return r;
 }
 __device__ __forceinline__ float softplus100_b(const SoftplusA& r) {

@@ -83,7 +83,7 @@ struct TrunkEpi {
       q4[r & 3] = v;
       if ((r & 3) == 3) SVS_STREAM_STORE(q4, reinterpret_cast<f32x4*>(hb) + (4 * tp + (r >> 2)) * 64 + lane);
     }
-    if (!LAST) {
+    if (!LAST && !(SVS_ABL & 2)) {
       v8[r & 7] = v;
       if ((r & 7) == 7) {
         split8(v8, xn->h[2 * tp + (r >> 3)], xn->m[2 * tp + (r >> 3)]);
@@ -110,12 +110,13 @@ __device__ __forceinline__ void trunk_layer_h2(Stream& st, const Pieces2& x, Tru
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     if (t == Net::kSpliceTile + 1 && ep.splice) break;   // lin3 has 217 (bg: 172) outputs; the tiles behind are the PE splice
-    st.prefetch<kChunkF4>();
     f32x16 acc;
-    if (t == 0) acc = tile_mma_h2<16>(st.cur_buf(), x, lane);
-    else acc = tile_mma_h2<16>(st.cur_buf(), x, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.b(t - 1, s); });
+    // the next chunk's 9 LDS-DMA pieces go behind k-steps 0..8 (Stream::prefetch_step); the hbuf stores of tile t-1's
+    // epilogue are issued in k-steps 3, 7, 11, 15: the last two are younger than every piece and may stay in flight
+    if (t == 0) acc = tile_mma_h2_pf<16, kChunkF4>(st, x, lane, NoEpi(), NoEpi());
+    else acc = tile_mma_h2_pf<16, kChunkF4>(st, x, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.b(t - 1, s); });
     ep.prev = acc;
-    if (HBUF && t > 0) st.advance_keep<4>();      // the 4 hbuf stores of tile t-1's epilogue stay in flight
+    if (HBUF && t > 0) st.advance_keep<2>();
     else st.advance();
   }
   if (ep.splice) { ep.all(Net::kSpliceTile); ep.splice_full_tiles(); }
