@@ -10,32 +10,26 @@ namespace mlp {
 // ------------------------------------------------------------------------------------------------------
 // weight stream
 // ------------------------------------------------------------------------------------------------------
-// LDS-DMA copy of N16 float4 (N16 % 64 == 0) from global to LDS, issued by the whole workgroup.
-template <int N16>
-__device__ __forceinline__ void chunk_issue(const f32x4* __restrict__ g, f32x4* lds) {
-  static_assert(N16 % 64 == 0, "chunk must be a whole number of wave-instructions");
-  const int tid = threadIdx.x;
-  const int wave_base = tid & ~63;
-#pragma unroll
-  for (int i = 0; i < (N16 + kThreads - 1) / kThreads; ++i) {
-    const int idx = i * kThreads + wave_base;  // wave-uniform
-    if (idx < N16) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + idx + (tid & 63)),
-                                       (__attribute__((address_space(3))) void*)(lds + idx), 16, 0, 0);
-    }
-  }
-}
-
-// piece i (one wave-instruction, 1 KiB) of the same copy, for callers that spread the pieces over their MFMA gaps
+// LDS-DMA copy of N16 float4 (N16 % 64 == 0) from global to LDS, issued by the whole workgroup: wave w moves the
+// 1 KiB pieces w, w + 4, ...  The wave's base is made provably uniform (readfirstlane) so that hipcc addresses a piece as
+// scalar base + 32-bit lane offset and sets M0 from an SGPR; with a per-lane 64-bit pointer every piece cost five extra
+// vector instructions.
+__device__ __forceinline__ int wave_base_f4() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u)); }
 template <int N16>
 __device__ __forceinline__ void chunk_issue_piece(const f32x4* __restrict__ g, f32x4* lds, int i) {
   static_assert(N16 % 64 == 0, "chunk must be a whole number of wave-instructions");
-  const int tid = threadIdx.x;
-  const int idx = i * kThreads + (tid & ~63);  // wave-uniform
-  if (idx < N16) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + idx + (tid & 63)),
-                                     (__attribute__((address_space(3))) void*)(lds + idx), 16, 0, 0);
+  const int idx = i * kThreads + wave_base_f4();  // wave-uniform
+  const unsigned lane_bytes = (threadIdx.x & 63u) * 16u;
+  if ((i + 1) * kThreads <= N16 || idx < N16) {   // i is a constant after unrolling: whole rounds carry no branch
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(g + idx) + lane_bytes),
+        (__attribute__((address_space(3))) void*)(lds + idx), 16, 0, 0);
   }
+}
+template <int N16>
+__device__ __forceinline__ void chunk_issue(const f32x4* __restrict__ g, f32x4* lds) {
+#pragma unroll
+  for (int i = 0; i < (N16 + kThreads - 1) / kThreads; ++i) chunk_issue_piece<N16>(g, lds, i);
 }
 template <int N16>
 constexpr int chunk_pieces() { return (N16 + kThreads - 1) / kThreads; }

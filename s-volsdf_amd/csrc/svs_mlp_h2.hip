@@ -78,12 +78,17 @@ struct RevEpi {
   int lane, half;
   bool l4;            // l == 4: rows >= 217 of h_4 are the PE splice, they do not flow into lin3
 
+  // three slices, one per MFMA gap of a k-step: exp2 | 1 - e and the product | masks, store, split
   __device__ __forceinline__ void a(int r) {
-    d = dsoftplus_from_h(h[r]);
+    d = __builtin_amdgcn_exp2f(h[r] * (-100.0f * 1.44269504088896341f));
+    pin(d);
+  }
+  __device__ __forceinline__ void a2(int r) {
+    d = prev[r] * (1.0f - d);
     pin(d);
   }
   __device__ __forceinline__ void b(int tp, int r) {
-    float v = prev[r] * d;
+    float v = d;
     if (l4 && tp == 7) v = 0.0f;
     if (l4 && tp == 6) {
       const bool z0 = rho(r) >= 25, z1 = rho(r) + 4 >= 25;
@@ -102,7 +107,7 @@ struct RevEpi {
   }
   __device__ __forceinline__ void all(int tp) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { a(r); b(tp, r); }
+    for (int r = 0; r < 16; ++r) { a(r); a2(r); b(tp, r); }
   }
 };
 
@@ -122,7 +127,8 @@ __device__ __forceinline__ void reverse_layer_h2(Stream& st, const Pieces2& in, 
     // the next reverse chunk (the last one: REV0 tile 0) is fetched in pieces behind k-steps 0..8
     f32x16 acc;
     if (t == 0) acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, NoEpi(), NoEpi());
-    else acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.b(t - 1, s); });
+    else acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.a2(s); },
+                                            [&](int s) { ep.b(t - 1, s); });
     if (l == 4 && t == 7) skip7 = acc;
     if (l == 4 && t == 6) skip6 = acc;
     ep.prev = acc;

@@ -101,9 +101,9 @@ struct NoEpi { __device__ __forceinline__ void operator()(int) const {} };
 // s+1 are read right after the first MFMA of k-step s: the wait hipcc places before their first use (always
 // lgkmcnt(0)) then has two MFMAs of cover.
 // dma(s): the slice of the next chunk's LDS-DMA issued behind the third MFMA of k-step s (Stream::prefetch_step).
-template <int KS, typename EpiA, typename EpiB, typename Dma = NoEpi>
+template <int KS, typename EpiA, typename EpiB, typename Dma = NoEpi, typename EpiC = NoEpi>
 __device__ __forceinline__ f32x16 tile_mma_h2(const f32x4* __restrict__ chunk, const Pieces2& x, int lane, EpiA ea, EpiB eb,
-                                              int first_step = 0, Dma dma = Dma()) {
+                                              int first_step = 0, Dma dma = Dma(), EpiC ec = EpiC()) {
   f32x16 acc = tile_bias(chunk, lane);
   const f16x8* a_ptr = reinterpret_cast<const f16x8*>(chunk + kHdrF4) + lane;
   f16x8 ah = a_ptr[0], am = a_ptr[64];
@@ -122,6 +122,7 @@ __device__ __forceinline__ f32x16 tile_mma_h2(const f32x4* __restrict__ chunk, c
     __builtin_amdgcn_sched_barrier(0);
     SVS_ABL_MFMA(acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, x.h[first_step + s], acc, 0, 0, 0));
     __builtin_amdgcn_sched_barrier(0);
+    ec(s);
     dma(s);
     if (s + 1 < KS) { ah = nh; am = nm; }
   }
@@ -133,26 +134,15 @@ __device__ __forceinline__ f32x16 tile_mma_h2(const f32x4* __restrict__ chunk, c
 }
 
 // tile_mma_h2 on the current chunk with the prefetch of the next chunk (N16 float4) spread over its k-steps
-template <int KS, int N16, typename EpiA, typename EpiB>
-__device__ __forceinline__ f32x16 tile_mma_h2_pf(Stream& st, const Pieces2& x, int lane, EpiA ea, EpiB eb) {
-  const f32x16 acc = tile_mma_h2<KS>(st.cur_buf(), x, lane, ea, eb, 0, [&](int s) { st.prefetch_step<N16, KS>(s); });
+template <int KS, int N16, typename EpiA, typename EpiB, typename EpiC = NoEpi>
+__device__ __forceinline__ f32x16 tile_mma_h2_pf(Stream& st, const Pieces2& x, int lane, EpiA ea, EpiB eb, EpiC ec = EpiC()) {
+  const f32x16 acc = tile_mma_h2<KS>(st.cur_buf(), x, lane, ea, eb, 0, [&](int s) { st.prefetch_step<N16, KS>(s); }, ec);
   st.prefetch_done<N16>();
   return acc;
 }
 
-// softplus100 in two slices (see tile_mma_h2): A = exp2 / max / log2, B = the final fma
+// softplus100 in slices (see tile_mma_h2 and TrunkEpi): exp2 | max, log2 | the final fma
 struct SoftplusA { float mx, lg; };
-__device__ __forceinline__ SoftplusA softplus100_a(float a) {
-  SoftplusA r;
-#if SVS_ABL & 1
-  r.mx = a; r.lg = 0.0f;
-#else
-  const float e = __builtin_amdgcn_exp2f(__builtin_fabsf(a) * (-100.0f * 1.44269504088896341f));
-  r.mx = __builtin_fmaxf(a, 0.0f);
-  r.lg = __builtin_amdgcn_logf(1.0f + e);
-#endif
-  return r;
-}
 __device__ __forceinline__ float softplus100_b(const SoftplusA& r) {
   return r.mx + (0.69314718055994531f / 100.0f) * r.lg;
 }

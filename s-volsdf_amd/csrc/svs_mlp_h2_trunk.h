@@ -58,8 +58,24 @@ struct TrunkEpi {
   int lane, half;
   bool splice;      // layer 3: rows >= 217 of the output are the PE splice (network.py:80-81)
 
+  // softplus of element r in three slices, one per MFMA gap of a k-step (a gap hides about 24 cycles of vector issue,
+  // an exp2 or log2 costs 8): a = exp2, a2 = max + log2, b = the final fma and the element's share of emit()
   __device__ __forceinline__ void a(int r) {
-    sa = softplus100_a(prev[r]);
+#if SVS_ABL & 1
+    sa.lg = 0.0f;
+#else
+    sa.lg = __builtin_amdgcn_exp2f(__builtin_fabsf(prev[r]) * (-100.0f * 1.44269504088896341f));
+#endif
+    pin(sa.lg);
+  }
+  __device__ __forceinline__ void a2(int r) {
+#if SVS_ABL & 1
+    sa.mx = prev[r];
+#else
+    // max(a, 0) without the canonicalising v_max hipcc puts in front of fmaxf in IEEE mode (a is an MFMA result)
+    asm("v_max_f32 %0, 0, %1" : "=v"(sa.mx) : "v"(prev[r]));
+    sa.lg = __builtin_amdgcn_logf(1.0f + sa.lg);
+#endif
     pin(sa.mx); pin(sa.lg);
   }
   __device__ __forceinline__ void b(int tp, int r) {
@@ -93,7 +109,7 @@ struct TrunkEpi {
   }
   __device__ __forceinline__ void all(int tp) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { a(r); b(tp, r); }
+    for (int r = 0; r < 16; ++r) { a(r); a2(r); b(tp, r); }
   }
   // layer 3, the tiles behind the partial one are pure PE (no MFMA): tile tp = PE[32 * (7 - tp) + local]
   __device__ __forceinline__ void splice_full_tiles() {
@@ -114,7 +130,8 @@ __device__ __forceinline__ void trunk_layer_h2(Stream& st, const Pieces2& x, Tru
     // the next chunk's 9 LDS-DMA pieces go behind k-steps 0..8 (Stream::prefetch_step); the hbuf stores of tile t-1's
     // epilogue are issued in k-steps 3, 7, 11, 15: the last two are younger than every piece and may stay in flight
     if (t == 0) acc = tile_mma_h2_pf<16, kChunkF4>(st, x, lane, NoEpi(), NoEpi());
-    else acc = tile_mma_h2_pf<16, kChunkF4>(st, x, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.b(t - 1, s); });
+    else acc = tile_mma_h2_pf<16, kChunkF4>(st, x, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.a2(s); },
+                                            [&](int s) { ep.b(t - 1, s); });
     ep.prev = acc;
     if (HBUF && t > 0) st.advance_keep<2>();
     else st.advance();

@@ -22,18 +22,20 @@ def build(masks):
     os.makedirs(ABL, exist_ok=True)
     objs = [os.path.join(B.LIBDIR, u.rsplit(".", 1)[0] + ".o") for u in B.UNITS if u != "svs_mlp_h2.hip"]
     for m in masks:
-        obj = os.path.join(ABL, f"h2_{m}.o")
-        subprocess.check_call([B._hipcc()] + B.BASE_FLAGS + [f"-DSVS_ABL={m}", "-I", B.CSRC, "-c",
+        tag = os.environ.get("ABL_TAG", "")
+        obj = os.path.join(ABL, f"h2_{m}{tag}.o")
+        extra = [f"-D{d}" for d in os.environ.get("ABL_DEFS", "").split()]   # further -D switches under test
+        subprocess.check_call([B._hipcc()] + B.BASE_FLAGS + extra + [f"-DSVS_ABL={m}", "-I", B.CSRC, "-c",
                                                            os.path.join(B.CSRC, "svs_mlp_h2.hip"), "-o", obj])
         subprocess.check_call([B._hipcc(), "-shared", "-fPIC", f"--offload-arch={B.ARCH}", "-o",
-                               os.path.join(ABL, f"lib_{m}.so"), obj] + objs)
+                               os.path.join(ABL, f"lib_{m}{tag}.so"), obj] + objs)
         print("built", m, flush=True)
 
 
 def child(mask):
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     from svs_hip import lib
-    lib.LIB_PATH = os.path.join(ABL, f"lib_{mask}.so")
+    lib.LIB_PATH = os.path.join(ABL, f"lib_{mask}{os.environ.get('ABL_TAG', '')}.so")
     import torch
     import synth
     from svs_hip import ops
@@ -64,7 +66,7 @@ def child(mask):
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n
 
-    res = {"mask": mask}
+    res = {"mask": mask, "tag": os.environ.get("ABL_TAG", "")}
     res["sdf_only_ms"] = round(timeit(lambda: ops.sdf_vals(pk, s128, 3.0, 20.0)), 4)
     if mask & 16:   # in-kernel stamps of wave 0 of every workgroup (see sdf_only_h2_kernel)
         o = ops.sdf_vals(pk, s128, 3.0, 20.0).view(-1, 128)[:, :6].double().cpu()
