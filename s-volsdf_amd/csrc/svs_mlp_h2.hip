@@ -148,12 +148,21 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_h2_kernel(SdfFullArgs a)
   const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
   const int wtile = blockIdx.x * kWaves + wave;
   const int p = wtile * kTilePts + (lane & 31);
+#if SVS_ABL & 16   // diagnostic: cycle stamps of wave 0 replace the workgroup's first gradient outputs
+  uint64_t cs[8];
+  cs[0] = __builtin_amdgcn_s_memtime();
+  const uint64_t r0 = __builtin_amdgcn_s_memrealtime();
+#define SVS_STAMP(i, var) { asm volatile("" : "+v"(var)); cs[i] = __builtin_amdgcn_s_memtime(); }
+#else
+#define SVS_STAMP(i, var)
+#endif
 
   st.prefetch<kChunk0F4>();
   float x0, x1, x2;
   load_point(a.src, p, x0, x1, x2);
   PosEnc pe;
   pe.compute(x0, x1, x2);
+  SVS_STAMP(1, pe.v[38])
 
   float* hb = a.hbuf + (size_t)wtile * kBlockF;                        // block l of this tile: + l * block_stride()
   float* gb = a.gbuf ? a.gbuf + (size_t)wtile * kBlockF : nullptr;
@@ -162,6 +171,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_h2_kernel(SdfFullArgs a)
   {
     f32x16 y8[8];
     forward_trunk_h2<true>(st, x, xn, y8, pe, lane, half, hb);
+    SVS_STAMP(2, y8[7][15])
     // ---- head: current chunk = VEC (W8 row 0 in C-layout order as float32, b8[0])
     st.prefetch<kChunkF4>();                       // FEAT tile 0
     sdf = sdf_head(st.cur_buf(), y8, lane);
@@ -183,6 +193,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_h2_kernel(SdfFullArgs a)
     }
     st.advance();
   }
+  SVS_STAMP(3, sdf)
   // ---- feature vector = rows 1..256 of lin8 (no activation); tile t-1 is stored while tile t's MFMAs run
   float* ft = a.feat_tiles ? a.feat_tiles + (size_t)wtile * kBlockF : nullptr;
   {
@@ -203,6 +214,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_h2_kernel(SdfFullArgs a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) store_slice(7, r);
   }
+  SVS_STAMP(4, sdf)
   // ---- reverse layers 7..1, operands ping-pong between xn and x
   f32x16 skip7 = (f32x16)(0.0f);   // g(PE[0..31]) from the skip connection (tile 7 of g(h_4 spliced))
   f32x16 skip6 = (f32x16)(0.0f);   // tile 6; only local rows 25..31 are PE[32..38]
@@ -210,6 +222,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_h2_kernel(SdfFullArgs a)
     reverse_layer_h2(st, xn, x, l, hb, gb, skip6, skip7, lane, half);
     if (l > 1) reverse_layer_h2(st, x, xn, l - 1, hb, gb, skip6, skip7, lane, half);
   }
+  SVS_STAMP(5, skip7[0])
   // ---- reverse layer 0: g(PE) = W0^T g(a_0) (+ skip), 2 tiles; g(a_0) is in x
   st.prefetch<kChunkF4>();
   f32x16 gpe0 = tile_mma_h2<16>(st.cur_buf(), x, lane);
@@ -259,6 +272,16 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_h2_kernel(SdfFullArgs a)
     a.sdf[p] = sdf;
     a.grad[3 * p + 0] = dx0; a.grad[3 * p + 1] = dx1; a.grad[3 * p + 2] = dx2;
   }
+#if SVS_ABL & 16
+  SVS_STAMP(6, dx0)
+  const uint64_t r1 = __builtin_amdgcn_s_memrealtime();
+  __syncthreads();
+  if (threadIdx.x == 0) {   // pe, trunk, head, features, reverse 7..1, reverse 0 + Jacobian, total, real time
+    float* o = a.grad + (size_t)blockIdx.x * kWgPts * 3;
+    for (int i = 0; i < 6; ++i) o[i] = (float)(cs[i + 1] - cs[i]);
+    o[6] = (float)(cs[6] - cs[0]); o[7] = (float)(r1 - r0);
+  }
+#endif
 }
 
 // --------------------------------------------------------------------------------------------------------------

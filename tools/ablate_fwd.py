@@ -76,6 +76,12 @@ def child(mask):
         start = o[:, 5]
         res["wg_start_spread_us"] = round(float((start.max() - start.min()) % (1 << 24)) / 100.0, 1)
     res["sdf_full_ms"] = round(timeit(lambda: ops.sdf_outputs(pk, s100, 3.0, 20.0, clamp_n=R * 98, keep={})), 4)
+    if mask & 16:   # sdf_full_h2_kernel's stamps: pe, trunk, head, features, reverse 7..1, reverse 0 + Jacobian, total
+        o = ops.sdf_outputs(pk, s100, 3.0, 20.0, clamp_n=R * 98, keep={})
+        o = o[1].reshape(-1, 384)[:, :8].double().cpu()
+        med = o.median(0).values
+        res["full_cycles_pe_trunk_head_feat_rev_rev0_total"] = [int(v) for v in med[:7]]
+        res["full_clock_ghz"] = round(float(med[6] / med[7]) * 0.1, 3)
     print(json.dumps(res), flush=True)
 
 
