@@ -246,6 +246,11 @@ __device__ __forceinline__ f32x16 load_tile(const float* __restrict__ block, int
   }
   return v;
 }
+// quarter q (4 accumulator registers) of load_tile, for callers that spread the four loads over their MFMA gaps
+__device__ __forceinline__ void load_tile_quarter(const float* __restrict__ block, int t, int lane, int q, f32x16& v) {
+  const f32x4 f = SVS_STREAM_LOAD(reinterpret_cast<const f32x4*>(block) + lane + (4 * t + q) * 64);
+  v[4 * q] = f[0]; v[4 * q + 1] = f[1]; v[4 * q + 2] = f[2]; v[4 * q + 3] = f[3];
+}
 __device__ __forceinline__ void store_tile(float* __restrict__ block, int t, int lane, const f32x16& v) {
   f32x4* d = reinterpret_cast<f32x4*>(block) + lane;
 #pragma unroll

@@ -72,7 +72,7 @@ struct RevEpi {
   f32x16 prev, h;
   float d;            // softplus' of the current slice
   float v8[8];
-  f32x4 q4;
+  LateStore ls;
   Pieces2* out;
   float* gblk;        // ghat_{l-1} block of gbuf or nullptr
   int lane, half;
@@ -95,19 +95,19 @@ struct RevEpi {
       if (z0 || z1) { if (half ? z1 : z0) v = 0.0f; }
     }
     pin(v);
-    if (gblk) {
-      q4[r & 3] = v;
-      if ((r & 3) == 3) SVS_STREAM_STORE(q4, reinterpret_cast<f32x4*>(gblk) + (4 * tp + (r >> 2)) * 64 + lane);
-    }
+    ls.put(r, v);
     v8[r & 7] = v;
     if ((r & 7) == 7) {
       split8(v8, out->h[2 * tp + (r >> 3)], out->m[2 * tp + (r >> 3)]);
       pin(out->h[2 * tp + (r >> 3)], out->m[2 * tp + (r >> 3)]);
     }
   }
+  // the gbuf stores of tile tp: sliced (behind k-step s, see LateStore) or all four at once
+  __device__ __forceinline__ void st(int tp, int s) { if (gblk) ls.step(s, gblk, tp, lane); }
   __device__ __forceinline__ void all(int tp) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { a(r); a2(r); b(tp, r); }
+    if (gblk) ls.all(gblk, tp, lane);
   }
 };
 
@@ -119,22 +119,32 @@ __device__ __forceinline__ void reverse_layer_h2(Stream& st, const Pieces2& in, 
   const size_t LS = block_stride();
   ep.gblk = gb ? gb + (size_t)(l - 1) * LS : nullptr;
   const float* hblk = hb + (size_t)(l - 1) * LS;
+  // h tile t + 1 is requested during tile t behind k-steps 10, 12, 14, 15 -- after the last LDS-DMA piece (k-step 8), like
+  // the gbuf stores (LateStore): in flight across the tile's barrier, complete one tile later, consumed by the epilogue of
+  // tile t + 1 during tile t + 2.  (Requested in front of the tile's pieces, the barrier's vmcnt wait had to sit out
+  // their HBM latency: 700 cycles per tile.)
   f32x16 hnext = load_tile(hblk, 0, lane);
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     const f32x16 hcur = hnext;
-    if (t < 7) hnext = load_tile(hblk, t + 1, lane);   // arrives while this tile's MFMAs run
+    auto hload = [&](int s) {
+      const int q = s == 10 ? 0 : s == 12 ? 1 : s == 14 ? 2 : s == 15 ? 3 : -1;
+      if (t < 7 && q >= 0) load_tile_quarter(hblk, t + 1, lane, q, hnext);
+    };
     // the next reverse chunk (the last one: REV0 tile 0) is fetched in pieces behind k-steps 0..8
     f32x16 acc;
-    if (t == 0) acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, NoEpi(), NoEpi());
+    if (t == 0) acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, NoEpi(), NoEpi(), hload);
     else acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.a2(s); },
-                                            [&](int s) { ep.b(t - 1, s); });
+                                            [&](int s) { ep.b(t - 1, s); ep.st(t - 1, s); hload(s); });
     if (l == 4 && t == 7) skip7 = acc;
     if (l == 4 && t == 6) skip6 = acc;
     ep.prev = acc;
     ep.h = hcur;
-    if (gb && t > 0) st.advance_keep<2>();            // the gbuf stores of k-steps 11 and 15 (younger than every piece) stay in flight
-    else st.advance();
+    // in flight across the barrier: the 4 h loads (t < 7) and the 4 gbuf stores (training, t > 0) of this tile
+    const bool stores = gb && t > 0;
+    if (t == 0) st.advance_keep<4>();
+    else if (t < 7) { if (stores) st.advance_keep<8>(); else st.advance_keep<4>(); }
+    else { if (stores) st.advance_keep<4>(); else st.advance(); }
   }
   ep.all(7);
 }
@@ -198,10 +208,10 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_h2_kernel(SdfFullArgs a)
   float* ft = a.feat_tiles ? a.feat_tiles + (size_t)wtile * kBlockF : nullptr;
   {
     f32x16 prev;
-    f32x4 q4;
-    auto store_slice = [&](int tp, int r) {
-      q4[r & 3] = prev[r];
-      if ((r & 3) == 3 && ft) SVS_STREAM_STORE(q4, reinterpret_cast<f32x4*>(ft) + (4 * tp + (r >> 2)) * 64 + lane);
+    LateStore ls;
+    auto store_slice = [&](int tp, int r) {       // see LateStore
+      ls.put(r, prev[r]);
+      if (ft) ls.step(r, ft, tp, lane);
     };
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -209,10 +219,12 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_h2_kernel(SdfFullArgs a)
       if (t == 0) acc = tile_mma_h2_pf<16, kChunkF4>(st, x, lane, NoEpi(), NoEpi());
       else acc = tile_mma_h2_pf<16, kChunkF4>(st, x, lane, NoEpi(), [&](int s) { store_slice(t - 1, s); });
       prev = acc;
-      st.advance();
+      if (ft && t > 0) st.advance_keep<4>();
+      else st.advance();
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) store_slice(7, r);
+    for (int r = 0; r < 16; ++r) ls.put(r, prev[r]);
+    if (ft) ls.all(ft, 7, lane);
   }
   SVS_STAMP(4, sdf)
   // ---- reverse layers 7..1, operands ping-pong between xn and x

@@ -82,6 +82,9 @@ def child(mask):
         med = o.median(0).values
         res["full_cycles_pe_trunk_head_feat_rev_rev0_total"] = [int(v) for v in med[:7]]
         res["full_clock_ghz"] = round(float(med[6] / med[7]) * 0.1, 3)
+        o = ops.sdf_outputs(pk, s100, 3.0, 20.0, clamp_n=R * 98)      # render mode: no gbuf stores
+        o = o[1].reshape(-1, 384)[:, :8].double().cpu()
+        res["render_cycles"] = [int(v) for v in o.median(0).values[:7]]
     print(json.dumps(res), flush=True)
 
 
