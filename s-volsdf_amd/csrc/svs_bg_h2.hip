@@ -113,12 +113,7 @@ struct BgRgbArgs {
 constexpr int kBgRbufF = kBlockF + 1024;
 constexpr int kBgRgbBufF4 = kBgRgbChunk0F4;
 
-struct BgRgbStream {
-  const f32x4* g; f32x4* buf; int cur;
-  __device__ __forceinline__ const f32x4* cur_buf() const { return buf + cur * kBgRgbBufF4; }
-  template <int N16> __device__ __forceinline__ void prefetch() { chunk_issue<N16>(g, buf + (cur ^ 1) * kBgRgbBufF4); g += N16; }
-  __device__ __forceinline__ void advance() { __builtin_amdgcn_s_waitcnt(0); __syncthreads(); cur ^= 1; }
-};
+typedef StreamT<kBgRgbBufF4> BgRgbStream;
 
 __global__ __launch_bounds__(kThreads, 1) void bg_rgb_h2_kernel(BgRgbArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

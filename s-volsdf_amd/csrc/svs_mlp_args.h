@@ -47,12 +47,7 @@ constexpr int kRbufF = 4 * kBlockF + 1024;
 
 constexpr int kRgbBufF4 = kRgbChunk0F4;   // LDS buffer size for the radiance kernel (38 KiB)
 
-struct RgbStream {
-  const f32x4* g; f32x4* buf; int cur;
-  __device__ __forceinline__ const f32x4* cur_buf() const { return buf + cur * kRgbBufF4; }
-  template <int N16> __device__ __forceinline__ void prefetch() { chunk_issue<N16>(g, buf + (cur ^ 1) * kRgbBufF4); g += N16; }
-  __device__ __forceinline__ void advance() { __builtin_amdgcn_s_waitcnt(0); __syncthreads(); cur ^= 1; }
-};
+typedef StreamT<kRgbBufF4> RgbStream;
 
 // fp16x2 launches (svs_mlp_h2.hip)
 int launch_sdf_only_h2(const SdfOnlyArgs& a, hipStream_t s);

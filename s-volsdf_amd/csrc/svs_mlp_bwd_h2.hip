@@ -26,7 +26,7 @@ namespace mlp {
 struct RgbBwdEpi {
   f32x16 prev, r;
   float v8[8];
-  f32x4 q4;
+  LateStore ls;
   Pieces2* out;
   float* zblk;
   PointScale* ps;
@@ -36,8 +36,7 @@ struct RgbBwdEpi {
     v = r[rr] > 0.0f ? v : 0.0f;
     pin(v);
     ps->track(v);
-    q4[rr & 3] = v;
-    if ((rr & 3) == 3) SVS_STREAM_STORE(q4, reinterpret_cast<f32x4*>(zblk) + (4 * tp + (rr >> 2)) * 64 + lane);
+    ls.put(rr, v);
     v8[rr & 7] = v * ps->s_out;
     if ((rr & 7) == 7) {
       split8(v8, out->h[2 * tp + (rr >> 3)], out->m[2 * tp + (rr >> 3)]);
@@ -47,6 +46,7 @@ struct RgbBwdEpi {
   __device__ __forceinline__ void all(int tp) {
 #pragma unroll
     for (int rr = 0; rr < 16; ++rr) b(tp, rr);
+    ls.all(zblk, tp, lane);
   }
 };
 
@@ -55,15 +55,26 @@ __device__ __forceinline__ void rgb_bwd_layer_h2(Stream& st, const Pieces2& in, 
                                                  PointScale& ps, int lane) {
   RgbBwdEpi ep;
   ep.out = &out; ep.zblk = zblk; ep.ps = &ps; ep.lane = lane;
+  // Per tile: the next chunk's 9 LDS-DMA pieces behind k-steps 0..8 (Stream::prefetch_step), then -- younger than every
+  // piece, so that the barrier leaves them in flight (LateStore) -- the 4 zbuf stores of tile t-1's epilogue (k-steps
+  // 9, 11, 13, 15) and the 4 loads of r tile t+1 (k-steps 10, 12, 14, 15), which the epilogue of tile t+1 consumes
+  // during tile t+2.
+  f32x16 rnext = load_tile(rblk, 0, lane);
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
-    const f32x16 rcur = load_tile(rblk, t, lane);   // for the epilogue that runs during tile t+1's MFMAs
-    st.prefetch<kChunkF4>();
+    const f32x16 rcur = rnext;
+    auto rload = [&](int s) {
+      const int q = s == 10 ? 0 : s == 12 ? 1 : s == 14 ? 2 : s == 15 ? 3 : -1;
+      if (t < 7 && q >= 0) load_tile_quarter(rblk, t + 1, lane, q, rnext);
+    };
     f32x16 acc;
-    if (t == 0) acc = tile_mma_h2<16>(st.cur_buf(), in, lane);
-    else acc = tile_mma_h2<16>(st.cur_buf(), in, lane, NoEpi(), [&](int s) { ep.b(t - 1, s); });
+    if (t == 0) acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, NoEpi(), NoEpi(), rload);
+    else acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, NoEpi(), [&](int s) { ep.b(t - 1, s); },
+                                            [&](int s) { ep.ls.step(s, ep.zblk, t - 1, lane); rload(s); });
     ep.prev = acc; ep.r = rcur;
-    st.advance();
+    if (t == 0) st.advance_keep<4>();
+    else if (t < 7) st.advance_keep<8>();
+    else st.advance_keep<4>();
   }
   ep.all(7);
   ps.next();

@@ -34,16 +34,18 @@ __device__ __forceinline__ void chunk_issue(const f32x4* __restrict__ g, f32x4* 
 template <int N16>
 constexpr int chunk_pieces() { return (N16 + kThreads - 1) / kThreads; }
 
-struct Stream {
+// BUF: float4 per LDS buffer (two of them).
+template <int BUF>
+struct StreamT {
   const f32x4* g;  // next chunk to fetch
-  f32x4* buf;      // LDS: two buffers of kChunkF4
+  f32x4* buf;      // LDS: two buffers of BUF float4
   int cur;         // buffer holding the chunk being consumed
 
-  __device__ __forceinline__ const f32x4* cur_buf() const { return buf + cur * kChunkF4; }
+  __device__ __forceinline__ const f32x4* cur_buf() const { return buf + cur * BUF; }
   template <int N16>
   __device__ __forceinline__ void prefetch() {
 #if !(defined(SVS_ABL) && (SVS_ABL & 64))
-    chunk_issue<N16>(g, buf + (cur ^ 1) * kChunkF4);
+    chunk_issue<N16>(g, buf + (cur ^ 1) * BUF);
 #endif
     g += N16;
   }
@@ -55,7 +57,7 @@ struct Stream {
 #if !(defined(SVS_ABL) && (SVS_ABL & 64))
     constexpr int np = chunk_pieces<N16>(), per = (np + KS - 1) / KS;
 #pragma unroll
-    for (int i = per * s; i < per * (s + 1) && i < np; ++i) chunk_issue_piece<N16>(g, buf + (cur ^ 1) * kChunkF4, i);
+    for (int i = per * s; i < per * (s + 1) && i < np; ++i) chunk_issue_piece<N16>(g, buf + (cur ^ 1) * BUF, i);
 #endif
   }
   template <int N16>
@@ -81,6 +83,7 @@ struct Stream {
     cur ^= 1;
   }
 };
+typedef StreamT<kChunkF4> Stream;
 
 // ------------------------------------------------------------------------------------------------------
 // element-wise pieces

@@ -307,7 +307,8 @@ struct RgbEpi {
   float* rblk;       // this layer's block of rbuf or nullptr
   int lane;
   __device__ __forceinline__ void b(int tp, int r) {
-    float v = __builtin_fmaxf(prev[r], 0.0f);
+    float v;
+    asm("v_max_f32 %0, 0, %1" : "=v"(v) : "v"(prev[r]));   // ReLU without the canonicalising v_max of fmaxf (IEEE mode)
     pin(v);
     if (rblk) {
       q4[r & 3] = v;
@@ -325,18 +326,24 @@ struct RgbEpi {
   }
 };
 
+// One radiance layer.  The next chunk (N16NEXT_LAST float4 behind the layer's last tile) is fetched in pieces behind the
+// first k-steps of each tile (Stream::prefetch_step: 9 or 10 pieces, k-steps 0..9); the rbuf stores of tile t-1's
+// epilogue are issued in k-steps 3, 7, 11, 15: the last two are younger than every piece and may stay in flight.
 template <int KS, int N16NEXT_LAST>
 __device__ __forceinline__ void rgb_layer_h2(RgbStream& st, const Pieces2& in, Pieces2& out, float* rblk, int lane) {
   RgbEpi ep;
   ep.out = &out; ep.rblk = rblk; ep.lane = lane;
+  constexpr int kNext = KS == 17 ? kRgbChunk0F4 : kChunkF4;
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
-    if (t < 7) st.prefetch<KS == 17 ? kRgbChunk0F4 : kChunkF4>(); else st.prefetch<N16NEXT_LAST>();
+    auto relu = [&](int s) { if (s < 16) ep.b(t - 1, s); };
     f32x16 acc;
-    if (t == 0) acc = tile_mma_h2<KS>(st.cur_buf(), in, lane);
-    else acc = tile_mma_h2<KS>(st.cur_buf(), in, lane, NoEpi(), [&](int s) { if (s < 16) ep.b(t - 1, s); });
+    if (t == 0) acc = tile_mma_h2_pf<KS, kNext>(st, in, lane, NoEpi(), NoEpi());
+    else if (t < 7) acc = tile_mma_h2_pf<KS, kNext>(st, in, lane, NoEpi(), relu);
+    else acc = tile_mma_h2_pf<KS, N16NEXT_LAST>(st, in, lane, NoEpi(), relu);
     ep.prev = acc;
-    st.advance();
+    if (rblk && t > 0) st.template advance_keep<2>();
+    else st.advance();
   }
   ep.all(7);
 }

@@ -134,10 +134,10 @@ __device__ __forceinline__ f32x16 tile_mma_h2(const f32x4* __restrict__ chunk, c
 }
 
 // tile_mma_h2 on the current chunk with the prefetch of the next chunk (N16 float4) spread over its k-steps
-template <int KS, int N16, typename EpiA, typename EpiB, typename EpiC = NoEpi>
-__device__ __forceinline__ f32x16 tile_mma_h2_pf(Stream& st, const Pieces2& x, int lane, EpiA ea, EpiB eb, EpiC ec = EpiC()) {
-  const f32x16 acc = tile_mma_h2<KS>(st.cur_buf(), x, lane, ea, eb, 0, [&](int s) { st.prefetch_step<N16, KS>(s); }, ec);
-  st.prefetch_done<N16>();
+template <int KS, int N16, typename S, typename EpiA, typename EpiB, typename EpiC = NoEpi>
+__device__ __forceinline__ f32x16 tile_mma_h2_pf(S& st, const Pieces2& x, int lane, EpiA ea, EpiB eb, EpiC ec = EpiC()) {
+  const f32x16 acc = tile_mma_h2<KS>(st.cur_buf(), x, lane, ea, eb, 0, [&](int s) { st.template prefetch_step<N16, KS>(s); }, ec);
+  st.template prefetch_done<N16>();
   return acc;
 }
 
