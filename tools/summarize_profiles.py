@@ -1,9 +1,11 @@
 """Turns the rocprofv3 outputs under gpurun_out/<run>/ into the small summaries committed under profiles/:
   <tag>_train_kernel_stats.csv / <tag>_render_kernel_stats.csv   (rocprofv3 --kernel-trace --stats, as written)
+  <tag>_train_onegroup_kernel_stats.csv                           (the same step as ONE ray group: a launch = a batch)
+  <tag>_pmc_mfma.json      matrix-core utilisation + wave-time split from the SQ counters (one-group step)
   <tag>_pmc_traffic.json   per-kernel HBM bytes per launch from separate --pmc FETCH_SIZE / WRITE_SIZE passes,
                            corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE counts 64 B per 128-B
                            request of a wide coalesced stream: doubled; WRITE_SIZE as read; both in KiB).
-usage: python tools/summarize_profiles.py gpurun_out/r01 r01
+usage: bash tools/profile_round.sh r01 (on the GPU box), then python tools/summarize_profiles.py gpurun_out/r01 r01
 """
 import collections
 import csv
@@ -29,7 +31,7 @@ def main(src, tag):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = os.path.join(root, "profiles")
     os.makedirs(out, exist_ok=True)
-    for mode in ("train", "render"):
+    for mode in ("train", "render", "train_onegroup"):
         f = glob.glob(os.path.join(src, mode, "*", "*kernel_stats.csv"))
         if f:
             shutil.copy(f[0], os.path.join(out, f"{tag}_{mode}_kernel_stats.csv"))
@@ -46,6 +48,38 @@ def main(src, tag):
                                                               "write_bytes": wb, "hbm_bytes": fb + wb}
     json.dump(res, open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps({k: round(v["hbm_bytes"] / 1e6, 1) for k, v in res["kernels"].items()}, indent=1))
+    mfma_summary(src, out, tag)
+
+
+MFMA_COUNTERS = ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
+                 "SQ_WAIT_INST_LDS", "GRBM_GUI_ACTIVE")
+
+
+def mfma_summary(src, out, tag):
+    """<tag>_pmc_mfma.json: matrix-core utilisation and the split of wave time per kernel (one-group step)."""
+    pat = os.path.join(src, "pmc_mfma", "*", "*counter_collection.csv")
+    c = {name: agg(pat, name) for name in MFMA_COUNTERS}
+    if not c["GRBM_GUI_ACTIVE"]:
+        return
+    res = {"_note": "rocprofv3 --pmc " + " ".join(MFMA_COUNTERS) + " -- python3 bench.py --steps 3 --warmup 2 "
+           "--no-cpu-baseline --groups none; per-launch averages. kernel_cycles = GRBM_GUI_ACTIVE / 8 XCDs; mfma_util = "
+           "SQ_VALU_MFMA_BUSY_CYCLES / (kernel_cycles * 1024 SIMDs); parked / issue_stall / issuing = SQ_WAIT_ANY / "
+           "SQ_WAIT_INST_ANY / SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES", "kernels": {}}
+    mean = lambda v: sum(v) / max(1, len(v))
+    for k, gui in c["GRBM_GUI_ACTIVE"].items():
+        if not k.startswith(("svs::mlp", "void svs::mlp", "svs::wgrad", "void svs::wgrad")):
+            continue
+        cyc = mean(gui) / 8.0
+        wave = mean(c["SQ_WAVE_CYCLES"][k]) or 1.0
+        res["kernels"][k.split("(")[0].replace("void ", "")] = {
+            "launches": len(gui), "kernel_cycles": int(cyc),
+            "mfma_util": round(mean(c["SQ_VALU_MFMA_BUSY_CYCLES"][k]) / (cyc * 1024.0), 3),
+            "parked": round(mean(c["SQ_WAIT_ANY"][k]) / wave, 3),
+            "issue_stall": round(mean(c["SQ_WAIT_INST_ANY"][k]) / wave, 3),
+            "issuing": round(mean(c["SQ_ACTIVE_INST_ANY"][k]) / wave, 3),
+            "lds_issue_stall": round(mean(c["SQ_WAIT_INST_LDS"][k]) / wave, 3)}
+    json.dump(res, open(os.path.join(out, f"{tag}_pmc_mfma.json"), "w"), indent=1, sort_keys=True)
+    print(json.dumps({k: v["mfma_util"] for k, v in res["kernels"].items()}, indent=1))
 
 
 if __name__ == "__main__":
