@@ -378,7 +378,7 @@ struct PassBEpi {
   f32x16 prev, h, a2, w0;
   float v, s1;
   float v8[8];
-  f32x4 q4;
+  LateStore ls;
   Pieces2* out;
   float* ablk;
   PointScale* ps;
@@ -401,8 +401,7 @@ struct PassBEpi {
     }
     pin(o);
     ps->track(o);
-    q4[r & 3] = o;
-    if ((r & 3) == 3) SVS_STREAM_STORE(q4, reinterpret_cast<f32x4*>(ablk) + (4 * tp + (r >> 2)) * 64 + lane);
+    ls.put(r, o);
     if (SPLIT) {
       v8[r & 7] = o * ps->s_out;
       if ((r & 7) == 7) {
@@ -414,6 +413,7 @@ struct PassBEpi {
   __device__ __forceinline__ void all(int tp) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { a(r); b(tp, r); }
+    ls.all(ablk, tp, lane);
   }
 };
 
@@ -421,22 +421,40 @@ struct PassBEpi {
 template <bool FIRST, bool SPLIT, bool LAST_STAGE, typename Net = NetFg, bool A2 = true>
 __device__ __forceinline__ void pass_b_stage_h2(Stream& st, const Pieces2& in, PassBEpi<FIRST, SPLIT, Net, A2>& ep, const float* hblk,
                                                 const float* a2blk, const float* w0blk, int lane) {
+  // Per tile: the next chunk's LDS-DMA pieces behind k-steps 0..8 (Stream::prefetch_step), then -- younger than every
+  // piece, left in flight across the tile's barrier (LateStore) -- the 4 abuf stores of tile t-1's epilogue (k-steps 9,
+  // 11, 13, 15) and the loads of the side tiles h, a2 (FIRST: and ghat_7) of tile t+1, which the epilogue of tile t+1
+  // consumes during tile t+2.
+  f32x16 hnext = load_tile(hblk, 0, lane), anext, wnext;
+  if (A2) anext = load_tile(a2blk, 0, lane);
+  if (FIRST) wnext = load_tile(w0blk, 0, lane);
+  constexpr int kLoads = 4 + (A2 ? 4 : 0) + (FIRST ? 4 : 0);
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
-    // the side tiles of tile t are requested one tile before its epilogue runs (during tile t+1's MFMAs)
-    const f32x16 hload = load_tile(hblk, t, lane);
-    f32x16 aload;
-    if (A2) aload = load_tile(a2blk, t, lane);
-    f32x16 wload;
-    if (FIRST) wload = load_tile(w0blk, t, lane);
-    if (!(LAST_STAGE && t == 7)) st.prefetch<kChunkF4>();
+    const f32x16 hcur = hnext, acur = anext, wcur = wnext;
+    auto side = [&](int s) {
+      if (t == 7) return;
+      const int qh = s == 9 ? 0 : s == 11 ? 1 : s == 13 ? 2 : s == 15 ? 3 : -1;   // beside the stores
+      const int qa = s == 10 ? 0 : s == 12 ? 1 : s == 14 ? 2 : s == 15 ? 3 : -1;
+      if (qh >= 0) load_tile_quarter(hblk, t + 1, lane, qh, hnext);
+      if (A2 && qa >= 0) load_tile_quarter(a2blk, t + 1, lane, qa, anext);
+      if (FIRST && qa >= 0) load_tile_quarter(w0blk, t + 1, lane, qa, wnext);
+    };
+    const bool fetch = !(LAST_STAGE && t == 7);
     f32x16 acc;
-    if (t == 0) acc = tile_mma_h2<16>(st.cur_buf(), in, lane);
-    else acc = tile_mma_h2<16>(st.cur_buf(), in, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.b(t - 1, s); });
-    ep.prev = acc; ep.h = hload;
-    if (A2) ep.a2 = aload;
-    if (FIRST) ep.w0 = wload;
-    if (!(LAST_STAGE && t == 7)) st.advance();
+    if (!fetch) acc = tile_mma_h2<16>(st.cur_buf(), in, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.b(t - 1, s); }, 0,
+                                       [&](int s) { ep.ls.step(s, ep.ablk, t - 1, lane); });
+    else if (t == 0) acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, NoEpi(), NoEpi(), side);
+    else acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.b(t - 1, s); },
+                                            [&](int s) { ep.ls.step(s, ep.ablk, t - 1, lane); side(s); });
+    ep.prev = acc; ep.h = hcur;
+    if (A2) ep.a2 = acur;
+    if (FIRST) ep.w0 = wcur;
+    if (fetch) {
+      if (t == 0) st.advance_keep<kLoads>();
+      else if (t < 7) st.advance_keep<kLoads + 4>();
+      else st.advance_keep<4>();
+    }
   }
   ep.all(7);
   ep.ps->next();
