@@ -235,17 +235,25 @@ struct PassAEpi {
 template <bool SPLIT, bool LAST>
 __device__ __forceinline__ void pass_a_layer_h2(Stream& st, const Pieces2& in, PassAEpi<SPLIT>& ep, const float* hblk,
                                                 const float* gblk, int lane) {
+  // Per tile: the side tiles h, ghat of tile t are requested in front of it (their epilogue runs during tile t+1; a third
+  // register set for requesting them behind the pieces, as the other sweeps do, does not fit: 110 spills); the next
+  // chunk's LDS-DMA pieces go behind k-steps 0..8 (Stream::prefetch_step); the a2 / u stores of tile t-1's epilogue are
+  // issued in k-steps 3, 7, 11, 15 (two each): the last four are younger than every piece and stay in flight across the
+  // tile's barrier.
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     if (t == 7 && ep.l3) break;
-    // the side tiles of tile t are requested one tile before its epilogue runs (during tile t+1's MFMAs)
     const f32x16 hload = load_tile(hblk, t, lane), gload = load_tile(gblk, t, lane);
-    if (!(LAST && t == 7)) st.prefetch<kChunkF4>();
+    const bool fetch = !(LAST && t == 7);
     f32x16 acc;
-    if (t == 0) acc = tile_mma_h2<16>(st.cur_buf(), in, lane);
-    else acc = tile_mma_h2<16>(st.cur_buf(), in, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.b(t - 1, s); });
+    if (!fetch) acc = tile_mma_h2<16>(st.cur_buf(), in, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.b(t - 1, s); });
+    else if (t == 0) acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, NoEpi(), NoEpi());
+    else acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.b(t - 1, s); });
     ep.prev = acc; ep.h = hload; ep.g = gload;
-    if (!(LAST && t == 7)) st.advance();
+    if (fetch) {
+      if (t == 0) st.advance();
+      else st.advance_keep<4>();
+    }
   }
   if (ep.l3) { ep.all(6); ep.splice_tile7(); }
   else ep.all(7);
