@@ -73,10 +73,11 @@ struct TrunkEpi {
     sa.mx = prev[r];
 #else
     // max(a, 0) without the canonicalising v_max hipcc puts in front of fmaxf in IEEE mode (a is an MFMA result)
-    asm("v_max_f32 %0, 0, %1" : "=v"(sa.mx) : "v"(prev[r]));
+    // (volatile + first: hipcc pads an inline-asm instruction that directly precedes an MFMA with an s_nop)
+    asm volatile("v_max_f32 %0, 0, %1" : "=v"(sa.mx) : "v"(prev[r]));
     sa.lg = __builtin_amdgcn_logf(1.0f + sa.lg);
 #endif
-    pin(sa.mx); pin(sa.lg);
+    pin(sa.lg);
   }
   __device__ __forceinline__ void b(int tp, int r) {
     float v = softplus100_b(sa);
