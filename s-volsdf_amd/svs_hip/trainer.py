@@ -230,15 +230,20 @@ class TrainStep:
             self.bwd.append(self._new_bwd())
             self.sides.append(torch.cuda.Stream(device=dev))
         rng = m.draw_train_rng(R, dev)
-        m.packed_mlp()                                   # pack once, before the streams fork
         sdf_p, rgb_p = m.mlp_params()
         main = torch.cuda.current_stream()
-        # the weight streams of the BACKWARD kernels are packed on their own stream while the sampler and the forward
-        # run; the backward launches wait for the event
+        # Only the SDF forward streams are packed on the main stream (the sampler needs them first).  The radiance forward
+        # stream and the weight streams of the BACKWARD kernels are packed on their own stream meanwhile; the forward
+        # waits for the first event (recorded long before it gets there), the backward launches for the second.
         if self.prep is None:
             self.prep = torch.cuda.Stream(device=dev)
         self.prep.wait_stream(main)                      # parameters of this step are final, last step's readers are done
+        pk = m.packed_mlp(rgb=False)                     # pack once, before the streams fork
+        if self.is_bg:
+            m.packed_bg()                                # (the group streams are ordered behind `fork`, not behind each other)
         with torch.cuda.stream(self.prep):
+            m.rendering_network.pack_into(pk)
+            rgb_packed = torch.cuda.Event(); rgb_packed.record(self.prep)
             self.tstreams.pack(sdf_p, rgb_p)
             if self.is_bg:
                 bg_sdf_wb, bg_rgb_wb = m.bg_params()
@@ -248,6 +253,7 @@ class TrainStep:
             self.bg_bwd.zero()
         self.accum.zero()
         self.d_beta.zero_()
+        main.wait_event(rgb_packed)
         fork = torch.cuda.Event(); fork.record(main)
         scale = 1.0 / self.world                         # each rank's means are over its own shard
         gt_rgb, gt_smooth = ground_truth["rgb"].reshape(-1, 3), ground_truth["rgb_smooth"].reshape(-1, 3)

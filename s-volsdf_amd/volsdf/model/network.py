@@ -156,12 +156,14 @@ class VolSDFNetwork(nn.Module):
         self.ray_sampler = ErrorBoundSampler(self.scene_bounding_sphere, **conf.get_config('ray_sampler'))
         self._pk = None
 
-    def packed_mlp(self):
-        """Packed weight streams (re-packed only when a parameter changed)."""
+    def packed_mlp(self, rgb=True):
+        """Packed weight streams (re-packed only when a parameter changed).  rgb=False: the SDF streams only (the fused
+        train step packs the radiance stream on a side stream, trainer.TrainStep)."""
         if self._pk is None or self._pk.device != _dev(self):
             self._pk = ops.PackedMlp(_dev(self))
         self.implicit_network.packed(owner=self._pk)
-        self.rendering_network.pack_into(self._pk)
+        if rgb:
+            self.rendering_network.pack_into(self._pk)
         return self._pk
 
     # ---- parameters in a fixed order (shared by the autograd bridge and the fused trainer) -----------------

@@ -42,11 +42,12 @@ class VolSDFNetworkBG(nn.Module):
         self._bg_key = None
 
     # ---- packed weights -------------------------------------------------------------------------------------
-    def packed_mlp(self):
+    def packed_mlp(self, rgb=True):
         if self._pk is None or self._pk.device != _dev(self):
             self._pk = ops.PackedMlp(_dev(self))
         self.implicit_network.packed(owner=self._pk)
-        self.rendering_network.pack_into(self._pk)
+        if rgb:
+            self.rendering_network.pack_into(self._pk)
         return self._pk
 
     def bg_params(self):
