@@ -147,18 +147,22 @@ __device__ __forceinline__ float header_value(const LayerPtrs& w, int kind, int 
   }
 }
 
-// one workgroup per chunk
+// kPackParts workgroups per chunk (one per chunk left the launch latency-bound: 128 workgroups of 8 serial gather rounds,
+// 34 us on the critical path of every optimiser step)
+constexpr int kPackParts = 4;
+constexpr int kPackStride = 256 * kPackParts;
 __global__ __launch_bounds__(256) void pack_stream_kernel(LayerPtrs w, const float* __restrict__ scale,
                                                           const ChunkDesc* __restrict__ table, int fmt, int net,
                                                           float* __restrict__ out) {
-  const ChunkDesc d = table[blockIdx.x];
+  const ChunkDesc d = table[blockIdx.x / kPackParts];
+  const int tid = (blockIdx.x % kPackParts) * 256 + threadIdx.x;
   const int kind = d.kind & 0xff;
   const bool nobias = (d.kind & kNoBias) != 0;
   const int l = d.layer, t = d.tile;
   float* dst = out + (size_t)d.off_f4 * 4;
   if (kind == kRgbW4T) {
     // [tile 8][lane 64][4 k-steps]: A = W4^T rows (input feature 32*tile + lane&31), k = rho(s) + 4*half < 3
-    for (int wi = threadIdx.x; wi < kW4TF4 * 4; wi += 256) {
+    for (int wi = tid; wi < kW4TF4 * 4; wi += kPackStride) {
       const int tt = wi / 256, lane = (wi & 255) >> 2, s = wi & 3;
       const int k = rho(s) + 4 * (lane >> 5);
       dst[wi] = k < 3 ? weff(w, scale, 4, k, 32 * tt + (lane & 31), 256) : 0.0f;
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(256) void pack_stream_kernel(LayerPtrs w, const flo
   }
   if (kind == kBgRgbW1T) {
     // [tile 4][lane 64][4 k-steps]: A = W1^T rows (hidden unit 32*tile + lane&31), k = rho(s) + 4*half < 3
-    for (int wi = threadIdx.x; wi < kW1TF4 * 4; wi += 256) {
+    for (int wi = tid; wi < kW1TF4 * 4; wi += kPackStride) {
       const int tt = wi / 256, lane = (wi & 255) >> 2, s = wi & 3;
       const int k = rho(s) + 4 * (lane >> 5);
       dst[wi] = k < 3 ? weff(w, scale, 1, k, 32 * tt + (lane & 31), 128) : 0.0f;
@@ -175,14 +179,14 @@ __global__ __launch_bounds__(256) void pack_stream_kernel(LayerPtrs w, const flo
     return;
   }
   // ---- header: [r/4][lane][4] bias block in accumulator layout
-  for (int wi = threadIdx.x; wi < kHdrF4 * 4; wi += 256) {
+  for (int wi = tid; wi < kHdrF4 * 4; wi += kPackStride) {
     const int lane = (wi & 255) >> 2, r = 4 * (wi / 256) + (wi & 3);
     dst[wi] = nobias ? 0.0f : header_value(w, kind, l, t, rho(r) + 4 * (lane >> 5), net);
   }
   float* body = dst + kHdrF4 * 4;
   const int body_f4 = chunk_f4(kind) - kHdrF4;
   if (fmt == kFmtF32 || kind == kSdfVec) {
-    for (int wb = threadIdx.x; wb < body_f4 * 4; wb += 256) {
+    for (int wb = tid; wb < body_f4 * 4; wb += kPackStride) {
       const int lane = (wb & 255) >> 2, half = lane >> 5, col32 = lane & 31;
       const int sr = 4 * (wb / 256) + (wb & 3);                   // k-step: input rows 2*sr, 2*sr+1 in K order
       const int crow = 32 * (sr / 16) + rho(sr % 16) + 4 * half;  // C-layout row addressed by k-step sr
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(256) void pack_stream_kernel(LayerPtrs w, const flo
   }
   // ---- fp16x2: one 16-byte fragment per (k-step, piece, lane)
   uint4* frag = reinterpret_cast<uint4*>(body);
-  for (int f = threadIdx.x; f < body_f4; f += 256) {
+  for (int f = tid; f < body_f4; f += kPackStride) {
     const int s = f >> 7, piece = (f >> 6) & 1, lane = f & 63, half = lane >> 5, col32 = lane & 31;
     unsigned short ebits[8];
 #pragma unroll
@@ -328,7 +332,7 @@ int svs_pack_stream(int which, int precision, const float* const* weight_v, cons
   }
   hipStream_t s = (hipStream_t)hip_stream;
   rownorm_kernel<<<(nl * kScaleStride + 3) / 4, 256, 0, s>>>(w, nl, is_rgb ? 1 : 0, net, workspace);
-  pack_stream_kernel<<<(unsigned)t.host.size(), 256, 0, s>>>(w, workspace, t.dev, precision, net, stream_out);
+  pack_stream_kernel<<<(unsigned)t.host.size() * kPackParts, 256, 0, s>>>(w, workspace, t.dev, precision, net, stream_out);
   return check_launch("svs_pack_stream");
 }
 
