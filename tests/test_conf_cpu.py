@@ -31,3 +31,18 @@ def test_attr_view_and_to_plain():
     assert to_plain(ns) == {"a": 1, "b": {"c": [1, [2, 3]]}}
     assert to_plain(args)["vol"] == {"train": {"x": 1}}
     assert attr_view(ns) is ns
+
+
+def test_grouped_step_results_are_lazy_mappings():
+    """TrainStep returns lazy containers when a step ran as ray groups (trainer._GroupedLosses / _GroupedOutputs): loss
+    terms are the sum over the groups, per-ray outputs the concatenation in ray order, both formed on first access."""
+    import torch
+    from svs_hip.trainer import _GroupedLosses, _GroupedOutputs
+    res = [({"loss": torch.tensor(1.0), "rgb_loss": torch.tensor(0.5)}, {"rgb_values": torch.zeros(3, 3), "n": 4}),
+           ({"loss": torch.tensor(2.0), "rgb_loss": torch.tensor(0.25)}, {"rgb_values": torch.ones(2, 3), "n": 4})]
+    lo, out = _GroupedLosses(res), _GroupedOutputs(res)
+    assert "loss" in lo and "nope" not in lo and len(lo) == 2 and list(lo) == ["loss", "rgb_loss"]
+    assert float(lo["loss"]) == 3.0 and float(dict(lo.items())["rgb_loss"]) == 0.75
+    assert lo.get("nope", 7) == 7 and [float(v) for v in lo.values()] == [3.0, 0.75]
+    assert lo["loss"] is lo["loss"]                       # formed once
+    assert out["rgb_values"].shape == (5, 3) and float(out["rgb_values"][3:].min()) == 1.0 and out["n"] == 4
