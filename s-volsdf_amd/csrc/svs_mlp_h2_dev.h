@@ -94,6 +94,7 @@ __device__ __forceinline__ f32x16 tile_bias(const f32x4* __restrict__ chunk, int
 #endif
 
 struct NoEpi { __device__ __forceinline__ void operator()(int) const {} };
+struct NoPre { __device__ __forceinline__ void operator()() const {} };
 
 // One output tile: acc(32 rows x 32 points) = hdr(bias) + sum over KS k-steps of (mid*hi + hi*mid + hi*hi).
 // ea(s) / eb(s) are two slices of the PREVIOUS tile's epilogue (activation, split, stores) issued behind the first /
@@ -101,12 +102,16 @@ struct NoEpi { __device__ __forceinline__ void operator()(int) const {} };
 // s+1 are read right after the first MFMA of k-step s: the wait hipcc places before their first use (always
 // lgkmcnt(0)) then has two MFMAs of cover.
 // dma(s): the slice of the next chunk's LDS-DMA issued behind the third MFMA of k-step s (Stream::prefetch_step).
-template <int KS, typename EpiA, typename EpiB, typename Dma = NoEpi, typename EpiC = NoEpi>
+// pre(): vector work issued between the tile's first LDS reads (bias block, first A fragments) and its first MFMA, where
+// the wave otherwise only waits for those reads.
+template <int KS, typename EpiA, typename EpiB, typename Dma = NoEpi, typename EpiC = NoEpi, typename Pre = NoPre>
 __device__ __forceinline__ f32x16 tile_mma_h2(const f32x4* __restrict__ chunk, const Pieces2& x, int lane, EpiA ea, EpiB eb,
-                                              int first_step = 0, Dma dma = Dma(), EpiC ec = EpiC()) {
+                                              int first_step = 0, Dma dma = Dma(), EpiC ec = EpiC(), Pre pre = Pre()) {
   f32x16 acc = tile_bias(chunk, lane);
   const f16x8* a_ptr = reinterpret_cast<const f16x8*>(chunk + kHdrF4) + lane;
   f16x8 ah = a_ptr[0], am = a_ptr[64];
+  __builtin_amdgcn_sched_barrier(0);
+  pre();
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     f16x8 nh, nm;
@@ -134,9 +139,11 @@ __device__ __forceinline__ f32x16 tile_mma_h2(const f32x4* __restrict__ chunk, c
 }
 
 // tile_mma_h2 on the current chunk with the prefetch of the next chunk (N16 float4) spread over its k-steps
-template <int KS, int N16, typename S, typename EpiA, typename EpiB, typename EpiC = NoEpi>
-__device__ __forceinline__ f32x16 tile_mma_h2_pf(S& st, const Pieces2& x, int lane, EpiA ea, EpiB eb, EpiC ec = EpiC()) {
-  const f32x16 acc = tile_mma_h2<KS>(st.cur_buf(), x, lane, ea, eb, 0, [&](int s) { st.template prefetch_step<N16, KS>(s); }, ec);
+template <int KS, int N16, typename S, typename EpiA, typename EpiB, typename EpiC = NoEpi, typename Pre = NoPre>
+__device__ __forceinline__ f32x16 tile_mma_h2_pf(S& st, const Pieces2& x, int lane, EpiA ea, EpiB eb, EpiC ec = EpiC(),
+                                                 Pre pre = Pre()) {
+  const f32x16 acc = tile_mma_h2<KS>(st.cur_buf(), x, lane, ea, eb, 0, [&](int s) { st.template prefetch_step<N16, KS>(s); }, ec,
+                                     pre);
   st.template prefetch_done<N16>();
   return acc;
 }

@@ -79,6 +79,7 @@ struct TrunkEpi {
 #endif
     pin(sa.lg);
   }
+  template <bool DEFER = false>
   __device__ __forceinline__ void b(int tp, int r) {
     float v = softplus100_b(sa);
     if (tp == Net::kSpliceTile && splice) {
@@ -92,8 +93,11 @@ struct TrunkEpi {
       }
     }
     pin(v);
-    emit(tp, r, v);
+    emit<DEFER>(tp, r, v);
   }
+  // DEFER (sliced epilogues): the split of elements 8..15 -- 24 instructions that would sit in front of
+  // the tile's barrier -- is left to finish(tp), which the NEXT tile issues while it waits for its first LDS reads
+  template <bool DEFER = false>
   __device__ __forceinline__ void emit(int tp, int r, float v) {
     if (LAST) y8[tp][r] = v;
     if (HBUF) {
@@ -102,10 +106,16 @@ struct TrunkEpi {
     }
     if (!LAST && !(SVS_ABL & 2)) {
       v8[r & 7] = v;
-      if ((r & 7) == 7) {
+      if ((r & 7) == 7 && !(DEFER && r == 15)) {
         split8(v8, xn->h[2 * tp + (r >> 3)], xn->m[2 * tp + (r >> 3)]);
         pin(xn->h[2 * tp + (r >> 3)], xn->m[2 * tp + (r >> 3)]);
       }
+    }
+  }
+  __device__ __forceinline__ void finish(int tp) {
+    if (!LAST && !(SVS_ABL & 2)) {
+      split8(v8, xn->h[2 * tp + 1], xn->m[2 * tp + 1]);
+      pin(xn->h[2 * tp + 1], xn->m[2 * tp + 1]);
     }
   }
   __device__ __forceinline__ void all(int tp) {
@@ -131,14 +141,16 @@ __device__ __forceinline__ void trunk_layer_h2(Stream& st, const Pieces2& x, Tru
     // the next chunk's 9 LDS-DMA pieces go behind k-steps 0..8 (Stream::prefetch_step); the hbuf stores of tile t-1's
     // epilogue are issued in k-steps 3, 7, 11, 15: the last two are younger than every piece and may stay in flight
     if (t == 0) acc = tile_mma_h2_pf<16, kChunkF4>(st, x, lane, NoEpi(), NoEpi());
+    // (the split of tile t-2's last eight elements is issued while this tile waits for its first LDS reads)
     else acc = tile_mma_h2_pf<16, kChunkF4>(st, x, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.a2(s); },
-                                            [&](int s) { ep.b(t - 1, s); });
+                                            [&](int s) { ep.template b<true>(t - 1, s); },
+                                            [&]() { if (t >= 2) ep.finish(t - 2); });
     ep.prev = acc;
     if (HBUF && t > 0) st.advance_keep<2>();
     else st.advance();
   }
-  if (ep.splice) { ep.all(Net::kSpliceTile); ep.splice_full_tiles(); }
-  else ep.all(7);
+  if (ep.splice) { ep.finish(Net::kSpliceTile - 1); ep.all(Net::kSpliceTile); ep.splice_full_tiles(); }
+  else { ep.finish(6); ep.all(7); }
 }
 
 // Forward through layers 0..7.  x: scratch operand; on return y8 holds h_8 in float32 (the input of lin8) and the
