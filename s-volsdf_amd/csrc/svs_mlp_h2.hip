@@ -87,6 +87,7 @@ struct RevEpi {
     d = prev[r] * (1.0f - d);
     pin(d);
   }
+  template <bool DEFER = false>     // DEFER: the split of elements 8..15 is left to finish(tp) (see TrunkEpi::emit)
   __device__ __forceinline__ void b(int tp, int r) {
     float v = d;
     if (l4 && tp == 7) v = 0.0f;
@@ -97,10 +98,14 @@ struct RevEpi {
     pin(v);
     ls.put(r, v);
     v8[r & 7] = v;
-    if ((r & 7) == 7) {
+    if ((r & 7) == 7 && !(DEFER && r == 15)) {
       split8(v8, out->h[2 * tp + (r >> 3)], out->m[2 * tp + (r >> 3)]);
       pin(out->h[2 * tp + (r >> 3)], out->m[2 * tp + (r >> 3)]);
     }
+  }
+  __device__ __forceinline__ void finish(int tp) {
+    split8(v8, out->h[2 * tp + 1], out->m[2 * tp + 1]);
+    pin(out->h[2 * tp + 1], out->m[2 * tp + 1]);
   }
   // the gbuf stores of tile tp: sliced (behind k-step s, see LateStore) or all four at once
   __device__ __forceinline__ void st(int tp, int s) { if (gblk) ls.step(s, gblk, tp, lane); }
@@ -135,7 +140,8 @@ __device__ __forceinline__ void reverse_layer_h2(Stream& st, const Pieces2& in, 
     f32x16 acc;
     if (t == 0) acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, NoEpi(), NoEpi(), hload);
     else acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.a2(s); },
-                                            [&](int s) { ep.b(t - 1, s); ep.st(t - 1, s); hload(s); });
+                                            [&](int s) { ep.template b<true>(t - 1, s); ep.st(t - 1, s); hload(s); },
+                                            [&]() { if (t >= 2) ep.finish(t - 2); });
     if (l == 4 && t == 7) skip7 = acc;
     if (l == 4 && t == 6) skip6 = acc;
     ep.prev = acc;
@@ -146,6 +152,7 @@ __device__ __forceinline__ void reverse_layer_h2(Stream& st, const Pieces2& in, 
     else if (t < 7) { if (stores) st.advance_keep<8>(); else st.advance_keep<4>(); }
     else { if (stores) st.advance_keep<4>(); else st.advance(); }
   }
+  ep.finish(6);
   ep.all(7);
 }
 
