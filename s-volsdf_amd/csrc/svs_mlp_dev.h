@@ -16,9 +16,9 @@ namespace mlp {
 // vector instructions.
 __device__ __forceinline__ int wave_base_f4() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u)); }
 template <int N16>
-__device__ __forceinline__ void chunk_issue_piece(const f32x4* __restrict__ g, f32x4* lds, int i) {
+__device__ __forceinline__ void chunk_issue_piece(const f32x4* __restrict__ g, f32x4* lds, int i, int wave_base) {
   static_assert(N16 % 64 == 0, "chunk must be a whole number of wave-instructions");
-  const int idx = i * kThreads + wave_base_f4();  // wave-uniform
+  const int idx = i * kThreads + wave_base;  // wave-uniform (wave_base_f4(), read once per kernel: Stream::wb)
   const unsigned lane_bytes = (threadIdx.x & 63u) * 16u;
   if ((i + 1) * kThreads <= N16 || idx < N16) {   // i is a constant after unrolling: whole rounds carry no branch
     __builtin_amdgcn_global_load_lds(
@@ -27,9 +27,9 @@ __device__ __forceinline__ void chunk_issue_piece(const f32x4* __restrict__ g, f
   }
 }
 template <int N16>
-__device__ __forceinline__ void chunk_issue(const f32x4* __restrict__ g, f32x4* lds) {
+__device__ __forceinline__ void chunk_issue(const f32x4* __restrict__ g, f32x4* lds, int wave_base) {
 #pragma unroll
-  for (int i = 0; i < (N16 + kThreads - 1) / kThreads; ++i) chunk_issue_piece<N16>(g, lds, i);
+  for (int i = 0; i < (N16 + kThreads - 1) / kThreads; ++i) chunk_issue_piece<N16>(g, lds, i, wave_base);
 }
 template <int N16>
 constexpr int chunk_pieces() { return (N16 + kThreads - 1) / kThreads; }
@@ -40,12 +40,13 @@ struct StreamT {
   const f32x4* g;  // next chunk to fetch
   f32x4* buf;      // LDS: two buffers of BUF float4
   int cur;         // buffer holding the chunk being consumed
+  int wb = wave_base_f4();   // the wave's float4 offset within a round of pieces, in an SGPR for the whole kernel
 
   __device__ __forceinline__ const f32x4* cur_buf() const { return buf + cur * BUF; }
   template <int N16>
   __device__ __forceinline__ void prefetch() {
 #if !(defined(SVS_ABL) && (SVS_ABL & 64))
-    chunk_issue<N16>(g, buf + (cur ^ 1) * BUF);
+    chunk_issue<N16>(g, buf + (cur ^ 1) * BUF, wb);
 #endif
     g += N16;
   }
@@ -57,7 +58,7 @@ struct StreamT {
 #if !(defined(SVS_ABL) && (SVS_ABL & 64))
     constexpr int np = chunk_pieces<N16>(), per = (np + KS - 1) / KS;
 #pragma unroll
-    for (int i = per * s; i < per * (s + 1) && i < np; ++i) chunk_issue_piece<N16>(g, buf + (cur ^ 1) * BUF, i);
+    for (int i = per * s; i < per * (s + 1) && i < np; ++i) chunk_issue_piece<N16>(g, buf + (cur ^ 1) * BUF, i, wb);
 #endif
   }
   template <int N16>

@@ -29,6 +29,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_only_h2_kernel(SdfOnlyArgs a)
   st.prefetch<kChunk0F4>();   // chunk 0 -> buffer 0 (overlaps the positional encoding below)
   float x0, x1, x2;
   load_point(a.src, p, x0, x1, x2);
+  const float r2 = x0 * x0 + x1 * x1 + x2 * x2;   // for the sphere clamp at the end: one live value instead of three
   PosEnc pe;
   pe.compute(x0, x1, x2);
 #if SVS_ABL & 16
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_only_h2_kernel(SdfOnlyArgs a)
   // the VEC chunk was prefetched by the last tile of layer 7
   float sdf = sdf_head(st.cur_buf(), y8, lane);
   if (a.sphere_radius > 0.0f && p < a.clamp_n) {
-    const float nrm = __builtin_sqrtf(x0 * x0 + x1 * x1 + x2 * x2);
+    const float nrm = __builtin_sqrtf(r2);
     sdf = __builtin_fminf(sdf, a.sphere_scale * (a.sphere_radius - nrm));
   }
   if (half == 0 && p < a.src.P) a.sdf[p] = sdf;
