@@ -71,7 +71,9 @@ class PackedMlp:
         self.precision = default_precision() if precision is None else int(precision)
         self.sdf_stream = torch.empty(L.svs_stream_bytes(1) // 4, device=device)
         self.rgb_stream = torch.empty(L.svs_stream_bytes(3) // 4, device=device)
+        # one row-norm workspace per stream: the fused train step packs the two on different HIP streams at the same time
         self._ws = torch.empty(L.svs_pack_workspace_bytes() // 4, device=device)
+        self._ws_rgb = torch.empty(L.svs_pack_workspace_bytes() // 4, device=device)
 
     def pack_sdf(self, weight_v, weight_g, bias):
         """weight_v/bias: 9 tensors; weight_g: 9 tensors or None (no weight-norm). network.py:64-65."""
@@ -90,7 +92,7 @@ class PackedMlp:
         g = [_f32(t) for t in weight_g] if weight_g is not None else None
         self._keep_rgb = (v, b, g)
         _lib.check(L.svs_pack_stream(3, self.precision, _ptr_array(v), _ptr_array(g) if g else None, _ptr_array(b),
-                                     _ptr(self._ws), _ptr(self.rgb_stream), _stream()), "svs_pack_stream(rgb)")
+                                     _ptr(self._ws_rgb), _ptr(self.rgb_stream), _stream()), "svs_pack_stream(rgb)")
 
 
 class PointSource:
