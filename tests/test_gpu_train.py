@@ -209,9 +209,12 @@ def test_ray_groups_do_not_change_the_step(dev, groups):
         # fp16x2 weight gradients: each launch scales its operands by the (power-of-two) maximum published so far, which
         # depends on the grouping (the 16-ray reference fixture of test_train_steps_fused is too small to split: a group
         # needs rays * samples to be a multiple of 32; the 32-ray fixture pins the grouped step)
-        # (observed over ~100 suite runs: typically 0.5e-4, once or twice 1.1e-4 of the largest entry -- the float atomics'
-        # summation order varies from run to run on top of the operand scale)
-        assert float((ga - gb).abs().max()) <= 3e-4 * float(ga.abs().max())
+        # Step 0 (same parameters): only the float atomics' summation order and the operand scale differ: ~2e-7 of the largest
+        # entry.  Step 1: the parameters already differ by Adam's sign noise on numerically-zero gradients, which the second
+        # forward/backward amplifies: 3e-6 ... 8e-5 in 36 samples, 1.1e-4 seen twice in ~100 suite runs.
+        ratio = float((ga - gb).abs().max()) / float(ga.abs().max())
+        print(f"step {step}: grouped vs ungrouped gradient, max |diff| / max |g| = {ratio:.2e}")
+        assert ratio <= (1e-5 if step == 0 else 3e-4)
     # Adam moves an entry by ~lr * g/|g|: entries whose gradient is numerically zero may take the other sign
     d = (pa - pb).abs()
     assert float(d.max()) <= 2.1e-3 and float((d > 1e-5).float().mean()) < 1e-3
