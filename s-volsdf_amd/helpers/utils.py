@@ -1,7 +1,13 @@
 """The runner-side helpers of the reference (helpers/utils.py:11-132) that feed the depth-fusion path, with the same
 names and return conventions.  `check_geometric_consistency` runs on the HIP kernel (csrc/svs_fusion.hip); the file
-readers / writers are host-side parsing."""
+readers / writers are host-side parsing.  With a reference checkout importable every other helper of its
+helpers/utils.py (`tocuda`, `tensor2numpy`, `load_K_Rt_from_P`, `glob_imgs`, ... -- runner.py:36 star-imports them) is
+re-exported unchanged (svs_hip/refpath.py); only `check_geometric_consistency` and the readers below are replaced."""
 import numpy as np
+
+from svs_hip.refpath import overlay
+
+overlay(globals(), __name__)
 
 
 def read_camera_parameters(filename):

@@ -196,6 +196,21 @@ class TrainStep:
         self.sides = []
         self.d_beta = torch.zeros(8, device=dev)
 
+    def samples_per_ray(self):
+        rs = self.model.ray_sampler
+        return rs.N_samples + rs.N_samples_extra + 2 - (1 if self.is_bg else 0)
+
+    def check_batch(self, R):
+        """The fused MLP kernels work on 32-point wave tiles and the ray samples of a batch (R x S points) must end on a
+        tile boundary, where the eikonal points start: R x S % 32 == 0, i.e. R % 16 == 0 for the DTU model (S = 98) and
+        R % 32 == 0 for the fg + background model (S = 97).  The reference has no such constraint; its configurations
+        use 512 / 1024 / 2048 rays."""
+        S = self.samples_per_ray()
+        if R <= 0 or (R * S) % 32:
+            import math
+            raise ValueError(f"train.num_pixels = {R}: rays x samples ({R} x {S}) must be a multiple of 32 on the fused "
+                             f"path -- use a multiple of {32 // math.gcd(S, 32)} rays")
+
     @staticmethod
     def split_rays(R, S, n_cu=256, wg_points=128):
         """[(lo,hi)] ray ranges: the first group's (S+2) points per ray (ray samples + 2 eikonal points) fill a whole
@@ -222,7 +237,8 @@ class TrainStep:
         uv = model_input["uv"]
         R = uv.shape[1]
         dev = uv.device
-        S = m.ray_sampler.N_samples + m.ray_sampler.N_samples_extra + 2 - (1 if self.is_bg else 0)
+        S = self.samples_per_ray()
+        self.check_batch(R)
         groups = self.split_rays(R, S) if self.groups == "auto" else (self.groups or [(0, R)])
         if len(groups) > self.d_beta.numel():
             raise ValueError("at most %d ray groups" % self.d_beta.numel())
@@ -255,7 +271,6 @@ class TrainStep:
         self.d_beta.zero_()
         main.wait_event(rgb_packed)
         fork = torch.cuda.Event(); fork.record(main)
-        scale = 1.0 / self.world                         # each rank's means are over its own shard
         gt_rgb, gt_smooth = ground_truth["rgb"].reshape(-1, 3), ground_truth["rgb_smooth"].reshape(-1, 3)
         results, joins, holds = [], [], []
         for gi, (lo, hi) in enumerate(groups):
@@ -298,7 +313,6 @@ class TrainStep:
         if self.is_bg:
             self.bg_bwd.finalize(bg_sdf_wb, bg_rgb_wb, out=self.bg_grad_out)
         self.beta_grad.copy_(self.d_beta.sum())
-        del scale
         allreduce_flat_grad(self.fp.grad, self.world)
         self.opt.step()
         m.invalidate_packed()          # the fused kernel bypasses torch's version counters

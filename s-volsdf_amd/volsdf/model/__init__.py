@@ -1,0 +1,4 @@
+from svs_hip.refpath import extend_package_path
+
+# submodules this repository does not provide are found in the reference checkout (svs_hip/refpath.py)
+__path__ = extend_package_path(__name__, __path__)

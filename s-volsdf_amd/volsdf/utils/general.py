@@ -1,7 +1,15 @@
-"""Host glue with the reference's names (volsdf/utils/general.py:6-58): class lookup and pixel chunking."""
+"""`volsdf.utils.general` next to the hot path.  With a reference checkout importable every helper of its
+volsdf/utils/general.py (`glob_imgs`, `split_input`, `merge_output`, ...) is re-exported unchanged (svs_hip/refpath.py);
+what this repository's `VolOpt` needs itself -- the dotted-name class lookup of the config plug points
+(`train.model_class`, `train.loss_class`, `train.dataset_class`; volsdf/vsdf.py:93,98 of the reference) and the
+folder helper -- is defined here so that the path also runs without a checkout.  Whole-image chunking lives in
+svs_hip/renderer.py, not here."""
+import importlib
 import os
 
-import torch
+from svs_hip.refpath import overlay
+
+overlay(globals(), __name__)
 
 
 def mkdir_ifnotexists(directory):
@@ -9,42 +17,6 @@ def mkdir_ifnotexists(directory):
 
 
 def get_class(kls):
-    parts = kls.split(".")
-    m = __import__(".".join(parts[:-1]))
-    for comp in parts[1:]:
-        m = getattr(m, comp)
-    return m
-
-
-def split_input(model_input, total_pixels, n_pixels=10000):
-    """Chunks of n_pixels rays (the chunk size is part of the result: the sampler's convergence test is
-    chunk-global, ray_sampler.py:136)."""
-    split = []
-    dev = model_input["uv"].device
-    for indx in torch.split(torch.arange(total_pixels, device=dev), n_pixels, dim=0):
-        data = dict(model_input)
-        data["uv"] = torch.index_select(model_input["uv"], 1, indx)
-        for key in ("object_mask", "rgb"):
-            if key in data:
-                data[key] = torch.index_select(model_input[key], 1, indx)
-        split.append(data)
-    return split
-
-
-def merge_output(res, total_pixels, batch_size):
-    out = {}
-    for entry in res[0]:
-        if res[0][entry] is None:
-            continue
-        nd = res[0][entry].dim()
-        if nd == 1:
-            out[entry] = torch.cat([r[entry].reshape(batch_size, -1, 1) for r in res], 1).reshape(batch_size * total_pixels)
-        elif nd == 2:
-            out[entry] = torch.cat([r[entry].reshape(batch_size, -1, r[entry].shape[-1]) for r in res], 1).reshape(
-                batch_size * total_pixels, -1)
-        elif nd == 3:
-            out[entry] = torch.cat([r[entry].reshape(batch_size, -1, r[entry].shape[-2], r[entry].shape[-1]) for r in res],
-                                   1).reshape(batch_size * total_pixels, -1, res[0][entry].shape[-1])
-        else:
-            raise NotImplementedError
-    return out
+    """'volsdf.model.network.VolSDFNetwork' -> the class object."""
+    module, _, attr = kls.rpartition(".")
+    return getattr(importlib.import_module(module), attr)

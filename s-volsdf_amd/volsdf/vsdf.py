@@ -43,34 +43,56 @@ def _summary_writer(log_dir):
 
 class AdamStateView:
     """`torch.optim.Adam`-layout `state_dict()` / `load_state_dict()` over the fused optimiser's flat moment buffers, so
-    that OptimizerParameters/*.pth written by either implementation resumes in the other (vsdf.py:143-145,181-195)."""
+    that OptimizerParameters/*.pth written by either implementation resumes in the other (vsdf.py:143-145,181-195).
 
-    def __init__(self, fused):
+    torch numbers optimiser state by the position of a parameter in `model.parameters()` -- for a weight-normed layer
+    that is bias, weight_g, weight_v (registration order) -- while the flat buffers follow the kernels' order
+    (weight_v, weight_g, bias).  The two are matched by parameter identity; shapes are checked before anything is
+    copied."""
+
+    def __init__(self, fused, model):
         self.fused = fused
+        slot = {id(p): i for i, p in enumerate(fused.fp.params)}
+        self._torch_order = [slot[id(p)] for p in model.parameters()]        # torch index -> flat-buffer view index
+        if sorted(self._torch_order) != list(range(len(fused.fp.params))):
+            raise ValueError("the fused optimiser does not cover exactly model.parameters()")
 
     def zero_grad(self, set_to_none=False):
         self.fused.zero_grad()
+
+    def _moments(self):
+        f = self.fused
+        m, v = f.fp.views(f.exp_avg), f.fp.views(f.exp_avg_sq)
+        return [(m[k], v[k]) for k in self._torch_order]
 
     def state_dict(self):
         f = self.fused
         state = {}
         if f.step_count > 0:
-            for i, (m, v) in enumerate(zip(f.fp.views(f.exp_avg), f.fp.views(f.exp_avg_sq))):
+            for i, (m, v) in enumerate(self._moments()):
                 state[i] = {"step": torch.tensor(float(f.step_count)), "exp_avg": m.clone(), "exp_avg_sq": v.clone()}
         group = dict(lr=f.lr, betas=tuple(f.betas), eps=f.eps, weight_decay=0, amsgrad=False, maximize=False, foreach=None,
-                     capturable=False, differentiable=False, fused=None, params=list(range(len(f.fp.params))))
+                     capturable=False, differentiable=False, fused=None, params=list(range(len(self._torch_order))))
         return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
         f = self.fused
+        moments = self._moments()
+        for i, st in sd["state"].items():
+            if not 0 <= int(i) < len(moments):
+                raise ValueError(f"optimizer state for parameter {i}: the model has {len(moments)} parameters")
+            for key, dst in zip(("exp_avg", "exp_avg_sq"), moments[int(i)]):
+                if tuple(st[key].shape) != tuple(dst.shape):
+                    raise ValueError(f"optimizer state {i}.{key} has shape {tuple(st[key].shape)}, parameter {i} of "
+                                     f"model.parameters() has {tuple(dst.shape)}")
         steps = {int(s["step"]) for s in sd["state"].values()}
         if len(steps) > 1:
             raise ValueError("per-parameter step counts differ: not a state the fused Adam can represent")
         f.step_count = steps.pop() if steps else 0
         f.exp_avg.zero_(); f.exp_avg_sq.zero_()
-        for i, (m, v) in enumerate(zip(f.fp.views(f.exp_avg), f.fp.views(f.exp_avg_sq))):
-            if i in sd["state"]:
-                m.copy_(sd["state"][i]["exp_avg"]); v.copy_(sd["state"][i]["exp_avg_sq"])
+        for i, st in sd["state"].items():
+            m, v = moments[int(i)]
+            m.copy_(st["exp_avg"]); v.copy_(st["exp_avg_sq"])
         if sd.get("param_groups"):
             f.lr = float(sd["param_groups"][0].get("lr", f.lr))
 
@@ -135,7 +157,7 @@ class VolOpt():
         self.loss = utils.get_class(self.conf.get_string('train.loss_class'))(**self.conf.get_config('loss'))
         self.lr = self.conf.get_float('train.learning_rate')
         self.step_fn = TrainStep(self.model, self.loss, lr=self.lr, grad_clip=bool(self.hparams.grad_clip), groups="auto")
-        self.optimizer = AdamStateView(self.step_fn.opt)
+        self.optimizer = AdamStateView(self.step_fn.opt, self.model)
 
         # load ckpt
         self.start_epoch = 0
@@ -148,6 +170,7 @@ class VolOpt():
 
         # some parameters
         self.num_pixels = self.conf.get_int('train.num_pixels')
+        self.step_fn.check_batch(self.num_pixels)
         self.plot_freq = self.conf.get_int('train.plot_freq')
         self.render_freq = self.conf.get_int('train.render_freq')
         self.checkpoint_freq = self.conf.get_int('train.checkpoint_freq', default=100)
@@ -280,34 +303,50 @@ class VolOpt():
         self.writer.add_images('val/vis', torch.stack(stack, dim=0), self.total_step)
 
     def render_mvs(self, id_k, epoch):
-        self.train_dataset.mode = 'test'
-        self.train_dataset.change_sampling_idx(-1)
-        batch = next(itertools.islice(self.eval_dataloader, id_k, None))
-        depth_cuda, depth_confi = self.render_step(batch, epoch, self.train_dataset, fast=-1)
-        self.train_dataset.mode = 'train'
-        return depth_cuda, depth_confi
+        """Full-resolution depth of training view number `id_k` (position in the eval loader) -> ((1,H,W) on the device, None)."""
+        ds = self.train_dataset
+        ds.mode = 'test'
+        try:
+            ds.change_sampling_idx(-1)
+            batch = next(itertools.islice(self.eval_dataloader, id_k, None))
+            return self.render_step(batch, epoch, ds, fast=-1)
+        finally:
+            ds.mode = 'train'
 
     # ---- optimisation loop (vsdf.py:321-367) ----------------------------------------------------------------------------------------
+    def _epochs(self, first, opt_stepN):
+        """Epoch numbers first, first+1, ... ; stops after the epoch that carries the step count past `opt_stepN` steps
+        beyond where this call started (the reference tests `>` after a whole pass over the views, vsdf.py:357)."""
+        begin = self.iter_step
+        for epoch in itertools.count(first):
+            yield epoch, self.iter_step - begin
+            if self.iter_step - begin > opt_stepN:
+                return
+
+    def _preview(self, epoch):
+        """Low-resolution render of the first plot view + a `latest` checkpoint (vsdf.py:339-347)."""
+        ds = self.plot_dataset
+        ds.change_sampling_idx(-1)
+        ds.mode = 'plot'
+        batch = next(iter(self.plot_dataloader))
+        ds.mode = 'train'
+        self.render_step(batch, epoch, ds, fast=-1)
+        self.save_checkpoints(epoch, latest_only=True)
+
     def run(self, opt_stepN=1e8):
-        start_iter_step = self.iter_step
+        """Optimise for at least `opt_stepN` further steps in whole passes over the training views -> last epoch number.
+        Same schedule as the reference: numbered checkpoint every `checkpoint_freq` epochs and at the end, preview
+        every `render_freq` epochs and, during the first 6000 steps of the call, every 1000/len(views) epochs."""
+        early_every = max(20 * 50 // self.ds_len, 1)
         epoch = self.start_epoch
-        while True:
+        for epoch, done in self._epochs(self.start_epoch, opt_stepN):
             if epoch % self.checkpoint_freq == 0:
                 self.save_checkpoints(epoch)
-            early_render = (self.iter_step - start_iter_step <= 120 * 50) and epoch % max(20 * 50 // self.ds_len, 1) == 0
-            if epoch % self.render_freq == 0 or early_render:
-                self.plot_dataset.change_sampling_idx(-1)
-                self.plot_dataset.mode = 'plot'
-                batch = next(iter(self.plot_dataloader))
-                self.plot_dataset.mode = 'train'
-                self.render_step(batch, epoch, self.plot_dataset, fast=-1)
-                self.save_checkpoints(epoch, latest_only=True)
+            if epoch % self.render_freq == 0 or (done <= 120 * 50 and epoch % early_every == 0):
+                self._preview(epoch)
             self.train_dataset.change_sampling_idx(self.num_pixels)
-            for data_index, batch in enumerate(self.train_dataloader):
+            for batch in self.train_dataloader:
                 self.train_step(batch, self.hparams.use_mvs)
-            if self.iter_step - start_iter_step > opt_stepN:
-                break
-            epoch += 1
         self.save_checkpoints(epoch)
         self.start_epoch = epoch
         return epoch
@@ -333,5 +372,7 @@ class VolOpt():
 
     def on_after_backward(self) -> None:
         """The NaN / Inf guard of vsdf.py:454-463 lives inside the fused clip + Adam launch (svs_clip_guard_adam): a
-        step whose gradient is not finite leaves parameters and moments untouched."""
+        gradient that is not finite is ZEROED and the Adam step still runs -- moments decay, parameters move by their
+        momentum, the step count advances -- which is what the reference's `optimizer.zero_grad()` followed by
+        `optimizer.step()` does under its pinned torch 1.9 (zero_grad leaves zero tensors, not None)."""
         return None

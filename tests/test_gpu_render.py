@@ -31,7 +31,6 @@ def test_render_image_equals_chunk_loop(dev, beta):
     (split_input / merge_output, volsdf/utils/general.py:24-58), bit for bit.  The first 500 rays look at an image
     corner (background only): with beta = 0.05 the three groups stop after 1 / 4 / 3 sampler rounds."""
     from svs_hip.renderer import depth_image, render_image
-    from volsdf.utils.general import merge_output, split_input
     m = _model(dev, beta)
     K, pose = synth.make_camera()
     N = 1372       # ragged last group, ragged last launch
@@ -42,10 +41,10 @@ def test_render_image_equals_chunk_loop(dev, beta):
     keys = ("rgb_values", "normal_map", "depth_values", "depth_vals", "weights", "xyz")
     with torch.no_grad():
         res = []
-        for s in split_input(inp, N, n_pixels=500):
-            o = m(s, fast=-1)
+        for lo in range(0, N, 500):                 # the reference's chunking: consecutive 500-ray slices of uv
+            o = m(dict(inp, uv=inp["uv"][:, lo:lo + 500]), fast=-1)
             res.append({k: o[k] for k in keys})
-        ref = merge_output(res, N, 1)
+        ref = {k: torch.cat([r[k] for r in res], 0) for k in keys}
     for per_launch in (1000, 8000):
         got = render_image(m, inp, N, split_n_pixels=500, rays_per_launch=per_launch)
         for k in keys:

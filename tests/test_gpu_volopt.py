@@ -110,19 +110,36 @@ def test_volopt_run_render_resume(tmp_path, monkeypatch):
 
 
 def test_optimizer_state_is_torch_adam_compatible(tmp_path, monkeypatch):
+    """OptimizerParameters/*.pth interchange: the state a fused step leaves loads into the reference's optimiser --
+    torch.optim.Adam over `model.parameters()` (vsdf.py:101), i.e. torch's registration order bias, weight_g, weight_v
+    -- shape for shape, survives a real torch step, and comes back."""
     monkeypatch.chdir(tmp_path)
     v = build(make_args())
     v.train_dataset.change_sampling_idx(v.num_pixels)
     v.train_step(next(iter(v.train_dataloader)))
     sd = v.optimizer.state_dict()
-    params = v.model._flat_param_list()
-    ref = torch.optim.Adam(params, lr=1e-3)
+    names = [n for n, _ in v.model.named_parameters()]
+    assert names[0].endswith("bias") and names[2].endswith("weight_v")
+    clones = [p.detach().clone().requires_grad_() for p in v.model.parameters()]
+    ref = torch.optim.Adam(clones, lr=1e-3)
     ref.load_state_dict(sd)                                               # the reference's optimiser accepts it
     st = ref.state_dict()["state"]
-    assert len(st) == len(params) and float(st[0]["step"]) == 1.0 and st[3]["exp_avg"].shape == params[3].shape
-    assert ref.param_groups[0]["lr"] == pytest.approx(5e-4)
+    assert len(st) == len(clones) and ref.param_groups[0]["lr"] == pytest.approx(5e-4)
+    for i, c in enumerate(clones):
+        assert float(st[i]["step"]) == 1.0 and st[i]["exp_avg"].shape == c.shape, names[i]
+    # the moments are the fused step's: m = (1 - beta1) * clipped gradient after one step
+    gviews = dict(zip((id(p) for p in v.step_fn.fp.params), v.step_fn.fp.views(v.step_fn.fp.grad)))
+    for i, p in enumerate(v.model.parameters()):
+        assert torch.allclose(st[i]["exp_avg"], 0.1 * gviews[id(p)], rtol=1e-5, atol=1e-12), names[i]
+    for c in clones:
+        c.grad = torch.full_like(c, 1e-3)
+    ref.step()                                                            # a real torch step on top
     v.optimizer.load_state_dict(ref.state_dict())                         # and the other way round
-    assert v.step_fn.opt.step_count == 1
+    assert v.step_fn.opt.step_count == 2
+    mviews = dict(zip((id(p) for p in v.step_fn.fp.params), v.step_fn.fp.views(v.step_fn.opt.exp_avg)))
+    st = ref.state_dict()["state"]
+    for i, p in enumerate(v.model.parameters()):
+        assert torch.equal(mviews[id(p)], st[i]["exp_avg"]), names[i]
 
 
 def test_volopt_config_errors(tmp_path, monkeypatch):
