@@ -10,13 +10,18 @@ samples -> SDF MLP forward + d sdf/dx (100 352 + 2 048 points) -> radiance MLP -
 lookup (3 views, 192x288x384 probability volumes) -> loss -> backward through compositing and both MLPs (incl. the
 double backward through the normals) -> clip + NaN guard + Adam.  `--mode render` times the forward part only.
 Inputs (weights, camera, pixel batch, prior volumes) are resident in HBM before the timed region.  Rays are
-independent: with N GPUs each rank takes its own 1024-ray shard (weak scaling) and the step adds ONE RCCL
-all-reduce of the flat float32 gradient (3.19 MB).
+independent: with N GPUs each rank takes its own 1024-ray shard (`--scaling weak`, the default) or 1024/N rays of one
+1024-ray batch (`--scaling strong`), and the step adds ONE RCCL all-reduce of the flat float32 gradient (3.19 MB).
 
-Rank 0 prints ONE JSON line; `roofline` prices the dominant kernel (fused SDF forward + input gradient) against the
-matrix-core peak of the precision it runs in and, under "other", the weight-gradient GEMM launch against HBM;
-`cpu_baseline` times the CPU port on a bounded sample of the same workload.  SVS_MLP_PRECISION=f32 selects the
-float32-MFMA kernels instead of the default fp16x2 split-operand ones (same accuracy class).
+Timed region: W warm-up steps (the step's launch sequence is captured into a hipGraph during them), then untimed
+steps until `--settle` seconds of steady state have passed (clocks, allocator), then barrier + synchronize, EXACTLY K
+steps, synchronize + barrier; the maximum over ranks is reported.
+
+Rank 0 prints ONE JSON line.  `roofline` prices the kernel with the largest time per step; the per-launch durations
+come from HIP events on the launch streams (svs_hip/profiling.py) over eager steps run right AFTER the timed region in
+the same process -- events cannot be read back from inside a replayed graph -- and are listed for every fused-MLP
+kernel under `roofline.kernels`.  `cpu_baseline` times the CPU port on a bounded sample of the same workload.
+SVS_MLP_PRECISION=f32 selects the float32-MFMA kernels instead of the default fp16x2 split-operand ones.
 """
 import argparse
 import json
@@ -30,16 +35,42 @@ for p in (os.path.join(ROOT, "tests", "golden"), os.path.join(ROOT, "s-volsdf_am
         sys.path.insert(0, p)
 
 F_SDF = 1_049_088          # FLOP per point per SDF-MLP forward
+F_SDF_TRUNK = 918_016      # the same without the 256 feature rows of lin8 (the sampler's sdf-only evaluation)
 F_RGB = 533_504            # FLOP per point per radiance forward
 PEAK_F32_MFMA = 157.3e12   # MI355X dense float32 MFMA peak (MI355X_MICROARCH.md)
 PEAK_F16_MFMA = 2.5e15     # dense fp16/bf16 MFMA peak; an fp16x2 product costs three fp16 MFMA products
 PEAK_HBM = 8.0e12          # HBM3E bytes/s
+BLOCK = 1024               # bytes per point of one 256-feature float32 activation block
+
+# C-ABI entry points of the fused-MLP kernels: (kernel symbol fp16x2, symbol float32, bound, work per point, what)
+# work: FLOP per point for "mfma" rows, algorithmic HBM bytes per point for "hbm" rows (every
+# activation block a launch reads or writes once, BLOCK bytes per point each).
+MLP_KERNELS = {
+    "svs_sdf_outputs": ("svs::mlp::sdf_full_h2_kernel", "svs::mlp::sdf_full_kernel", "mfma", 2 * F_SDF,
+                        "SDF MLP forward + input gradient + features"),
+    "svs_sdf_vals": ("svs::mlp::sdf_only_h2_kernel", "svs::mlp::sdf_only_kernel", "mfma", F_SDF_TRUNK,
+                     "SDF MLP forward of the sampler"),
+    "svs_rgb_eval": ("svs::mlp::rgb_h2_kernel", "svs::mlp::rgb_kernel", "mfma", F_RGB, "radiance MLP forward"),
+    "svs_rgb_bwd": ("svs::mlp::rgb_bwd_h2_kernel", "svs::mlp::rgb_bwd_kernel", "mfma", F_RGB, "radiance MLP backward"),
+    "svs_sdf_bwd_a": ("svs::mlp::sdf_bwd_a_h2_kernel", "svs::mlp::sdf_bwd_a_kernel", "hbm", None,
+                      "SDF MLP backward, second-order sweep"),
+    "svs_sdf_bwd_b": ("svs::mlp::sdf_bwd_b_h2_kernel", "svs::mlp::sdf_bwd_b_kernel", "hbm", None,
+                      "SDF MLP backward, backprop sweep"),
+    "svs_wgrad_multi": ("svs::wgrad::h2::wgrad_h2_multi_kernel", "svs::wgrad::wgrad_kernel<8>", "hbm", None,
+                        "weight gradients of all layers of a network in one launch"),
+}
+
+
+def block_bytes():
+    """Algorithmic HBM bytes per point of the HBM-bound launches, from the library's own block-format query."""
+    from svs_hip import train
+    return train.algorithmic_bytes_per_point()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rays", type=int, default=1024)
     ap.add_argument("--mode", choices=["train", "render"], default="train")
@@ -49,6 +80,11 @@ def main():
     ap.add_argument("--groups", choices=["auto", "none"], default="auto",
                     help="auto: the batch runs as two ray groups on concurrent streams, the first sized to whole rounds of "
                          "256 workgroups, so that the last partial round of every launch overlaps (results do not depend on it)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --rays rays per GPU; strong: --rays rays in total, rays/N per GPU")
+    ap.add_argument("--settle", type=float, default=1.0, help="seconds of untimed steady-state steps before the timed region")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue every step launch by launch instead of replaying a hipGraph")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel event timing (roofline = null)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -74,43 +110,35 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    R = args.rays
-    params = synth.make_params(0)
-    if args.model == "bmvs":
-        from volsdf.utils.conf import bmvs_model_conf
-        from volsdf.model.network_bg import VolSDFNetworkBG
-        params = dict(params); params.update(synth.make_bg_params(0))
-        model = VolSDFNetworkBG(bmvs_model_conf())
-        if args.mode != "train":
-            raise SystemExit("--model bmvs is benchmarked in train mode")
-    else:
-        model = VolSDFNetwork(dtu_model_conf())
-    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
-    model.to(dev).train()
+    if args.scaling == "strong" and args.rays % world:
+        raise SystemExit(f"--scaling strong: {args.rays} rays do not shard over {world} ranks")
+    R = args.rays if args.scaling == "weak" else args.rays // world
+    train = args.mode == "train"
+    h2 = ops.default_precision() == ops.F16X2
+
+    def make_model(seed_params=0):
+        params = synth.make_params(seed_params)
+        if args.model == "bmvs":
+            from volsdf.utils.conf import bmvs_model_conf
+            from volsdf.model.network_bg import VolSDFNetworkBG
+            params = dict(params); params.update(synth.make_bg_params(0))
+            model = VolSDFNetworkBG(bmvs_model_conf())
+        else:
+            model = VolSDFNetwork(dtu_model_conf())
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+        return params, model.to(dev).train()
+
+    if args.model == "bmvs" and not train:
+        raise SystemExit("--model bmvs is benchmarked in train mode")
+    params, model = make_model()
     K, pose = synth.make_camera()
-    uv = synth.make_uv(R, seed=100 + rank)          # each rank renders its own pixel shard of the view
-    inp = {"intrinsics": torch.from_numpy(K)[None].to(dev), "uv": torch.from_numpy(uv)[None].to(dev),
+    # each rank renders its own pixel shard of the view
+    uv = synth.make_uv(R * world, seed=100)[rank * R:(rank + 1) * R] if args.scaling == "strong" else synth.make_uv(R, seed=100 + rank)
+    inp = {"intrinsics": torch.from_numpy(K)[None].to(dev), "uv": torch.from_numpy(np.ascontiguousarray(uv))[None].to(dev),
            "pose": torch.from_numpy(pose)[None].to(dev)}
     torch.manual_seed(1234 + rank)
 
-    # instrument the dominant kernel with events on the launch stream
-    ev = []
-    orig = ops.sdf_outputs
-
-    def timed_sdf_outputs(pk, src, *a, **k):
-        if src.S < 64 or not ev_on[0]:             # the sampler's forward-only launches are not this kernel
-            return orig(pk, src, *a, **k)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = orig(pk, src, *a, **k)
-        e1.record()
-        ev.append((e0, e1, src.n, src.S))
-        return out
-
-    ev_on = [False]
-    ops.sdf_outputs = timed_sdf_outputs
-
-    train = args.mode == "train"
+    mvs = gt = None
     if train:
         # synthetic MVS prior at the real DTU stage-1 size: softmax(N(0,1)) over D = 192 at 288 x 384,
         # per-pixel hypotheses 1.5 .. 3.5, three views with x offsets 0, +-0.3
@@ -125,31 +153,35 @@ def main():
         rs = np.random.default_rng(11 + rank)
         gt = {"rgb": torch.from_numpy(rs.uniform(0, 1, (1, R, 3)).astype(np.float32)).to(dev),
               "rgb_smooth": torch.from_numpy(rs.uniform(0, 1, (1, R, 3)).astype(np.float32)).to(dev)}
+
+    def make_step(mdl):
+        if not train:
+            def fwd():
+                with torch.no_grad():
+                    return mdl(inp, fast=1)
+            return None, fwd
         loss = VolSDFLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, rgb_weight=1.0, mvs_weight=1.0,
                           sparse_weight=1.0, anneal_rgb=200, gce=0.5, confi=1e-3)       # config/ours.yaml:16-21
-        ts = TrainStep(model, loss, lr=5e-4, world=world, rank=rank, groups=None if args.groups == "none" else "auto")
+        t = TrainStep(mdl, loss, lr=5e-4, world=world, rank=rank, groups=None if args.groups == "none" else "auto",
+                      graph=not args.no_graph)
+        return t, (lambda: t(inp, gt, mvs=mvs))
 
-    wg_ev = []
-
-    def step():
-        if train:
-            r = ts(inp, gt, mvs=mvs)
-            if ev_on[0]:
-                wg_ev.extend(b.timer_events for b in ts.bwd if b.timer_events)
-            return r
-        with torch.no_grad():
-            return model(inp, fast=1)
+    ts, step = make_step(model)
 
     for _ in range(args.warmup):
         step()
-    if train:
-        for b in ts.bwd:
-            b.time_wgrad = True
     torch.cuda.synchronize()
+    # steady state before the clock starts: a fresh process runs its first steps slower (module loads, allocator growth,
+    # graph capture) and the chip needs load to settle its clocks; a timed region of a few ms would measure that
+    settle_steps, t_settle = 0, time.perf_counter()
+    while time.perf_counter() - t_settle < args.settle and settle_steps < 5000:
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
+        settle_steps += 10
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
-    ev_on[0] = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -158,69 +190,22 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    ev_on[0] = False
     if dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    del out
 
     if rank == 0:
-        # per-launch averages over ALL launches of the kernel in the timed region (what rocprofv3's kernel stats
-        # average too): with ray groups there are two launches of different size per step, on concurrent streams
-        launches = len(ev) / args.steps
-        n_pts = float(np.mean([e[2] for e in ev]))
-        pts_step = int(round(n_pts * launches))
-        k_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-        achieved = n_pts * 2 * F_SDF / (k_ms * 1e-3)
-        S = ev[0][3]
+        S = model.ray_sampler.N_samples + model.ray_sampler.N_samples_extra + 2 - (1 if args.model == "bmvs" else 0)
         flop_per_ray = 128 * F_SDF + S * (2 * F_SDF + F_RGB) + 2 * (2 * F_SDF)
         if train:
             # backward: second-order sweep + backprop of the SDF MLP (2 x 8 layers), its two weight-gradient
             # contractions per layer, radiance backprop + weight gradients (approximate, SURVEY.md 8d: 0.92 GFLOP/ray)
             flop_per_ray += (S + 2) * (2 * F_SDF + 2 * F_SDF) + S * (2 * F_RGB)
-        h2 = ops.default_precision() == ops.F16X2
-        peak = PEAK_F16_MFMA / 3 if h2 else PEAK_F32_MFMA
-        kname = "svs::mlp::sdf_full_h2_kernel" if h2 else "svs::mlp::sdf_full_kernel"
-        roof_full = {"bound": "mfma", "kernel": kname + " (SDF MLP forward + input gradient + features)",
-                     "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
-                     "frac": achieved / peak, "traffic": None, "kernel_ms": k_ms, "launches_per_step": launches,
-                     "points_per_launch": n_pts, "flop_per_point": 2 * F_SDF,
-                     "peak_note": ("algorithmic float32 FLOP; fp16x2 evaluates each product as three fp16 MFMA products: "
-                                   "peak = 2500 / 3 TFLOP/s" if h2 else "dense float32 MFMA peak")}
-        # HBM traffic per launch: PMC counters of the committed profile of this same command (profiles/, see
-        # tools/summarize_profiles.py); the bench itself cannot run the counters
-        wname = "svs::wgrad::h2::wgrad_h2_multi_kernel" if h2 else "svs::wgrad::wgrad_kernel<8>"
-        try:
-            prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
-            pk = json.load(open(os.path.join(ROOT, "profiles", prof[-1])))["kernels"]
-            traffic = {"sdf_full": pk.get(kname, {}).get("hbm_bytes"), "wgrad": pk.get(wname, {}).get("hbm_bytes")}
-            src_prof = prof[-1]
-        except Exception:
-            traffic, src_prof = {"sdf_full": None, "wgrad": None}, None
-        roof_full["traffic"] = traffic["sdf_full"]
-        roof_full["traffic_source"] = src_prof
-        roofline = roof_full
-        if train and wg_ev:
-            # the SDF weight gradients dW_l = abar_l h_l^T + ghat_l u_l^T (l = 0..7) and the feature head.  fp16x2: ONE
-            # launch, HBM-bound: every operand block (32 KiB per 32 points) is read once; float32: 9 launches, MFMA-bound
-            w_ms = float(np.mean([a.elapsed_time(b) for a, b in wg_ev]))
-            w_launches = len(wg_ev) / args.steps
-            n_tiles, n_main_tiles = (pts_step + 31) // 32, R * S // 32
-            w_bytes = (8 * 4 * n_tiles + 2 * n_main_tiles) * 32768 / w_launches       # per launch
-            w_flop = (2 * 2 * (F_SDF // 2 - 257 * 256) + 2 * 256 * 256) * pts_step / w_launches   # algorithmic: 2 pairs x 2 x rows x cols
-            if h2:
-                roof_w = {"bound": "hbm", "kernel": wname + " (all SDF weight gradients of a ray group in one launch)",
-                          "achieved": w_bytes / (w_ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
-                          "frac": w_bytes / (w_ms * 1e-3) / PEAK_HBM, "traffic": traffic["wgrad"], "kernel_ms": w_ms,
-                          "launches_per_step": w_launches, "bytes_per_launch": w_bytes, "flop_per_launch": w_flop}
-            else:
-                roof_w = {"bound": "mfma", "kernel": wname + " (SDF weight gradients, 9 launches per step)",
-                          "achieved": w_flop / (w_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
-                          "frac": w_flop / (w_ms * 1e-3) / PEAK_F32_MFMA, "traffic": traffic["wgrad"], "kernel_ms": w_ms / 9,
-                          "launches_per_step": 9, "flop_per_step": w_flop}
-            roof_w["traffic_source"] = src_prof
-            # the dominant kernel is the one with the larger total time per step
-            roofline = dict(roof_w, other=roof_full) if w_ms * w_launches > k_ms * launches else dict(roof_full, other=roof_w)
+        roofline = None
+        if not args.no_kernel_timing and world == 1:
+            roofline = kernel_roofline(ts, step, R, S, h2, train)
         line = {
             "metric": "rendered rays/sec (1024-ray batch, 128 samples)",
             "value": world * R * args.steps / dt,
@@ -230,9 +215,9 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": ("f32 (fp16x2 split operands on the fp16 matrix cores, f32 accumulate)" if h2 else "f32"),
             "data": "synthetic",
             "config": {"workload": ("configs[1]: VolOpt.train_step (forward + MVS prior lookup + loss + backward + clip/guard/Adam), "
                                     if train else "configs[1]: VolSDFNetwork.forward as called by VolOpt.train_step, forward only, ")
@@ -245,10 +230,15 @@ def main():
                                          "(float32-class accuracy, same parity bounds)" if h2 else "float32 MFMA"),
                        "ray_groups": ([list(g) for g in ts.split_rays(R, S)] if (train and args.groups == "auto")
                                       else [[0, R]]),
-                       "rays_per_gpu": R, "flop_per_ray": flop_per_ray,
+                       "launch": ("hipGraph replay of the captured step + eager all-reduce / fused Adam"
+                                  if (train and ts.graph) else "eager launches"),
+                       "rays_per_gpu": R, "rays_total": R * world, "settle_steps": settle_steps,
+                       "flop_per_ray": flop_per_ray,
                        "model_flops_per_s": world * R * args.steps / dt * flop_per_ray},
             "roofline": roofline,
         }
+        if train and h2 and world == 1 and args.model == "dtu" and not args.no_kernel_timing:
+            line["exact_f32_ms_per_step"] = exact_f32_step_ms(make_model, make_step)
         if not args.no_cpu_baseline and args.model == "dtu":
             line["cpu_baseline"] = cpu_baseline(params, K, pose, train=train)
         print(json.dumps(line), flush=True)
@@ -257,21 +247,144 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(params, K, pose, train=True, rays=32, reps=3):
-    """CPU port of the reference's PyTorch path on a bounded sample (`rays` rays of the same workload): numpy oracle for
-    the sampler / forward, plain torch float32 autograd (oracle/torch_ref.py) for the differentiable part."""
+def kernel_roofline(ts, step, R, S, h2, train, n_steps=12):
+    """Per-launch durations of every fused-MLP kernel over eager steps (HIP events on the launch streams), and the
+    roofline of the one with the largest time per step."""
+    import numpy as np
+    import torch
+    from svs_hip.profiling import LaunchTimer
+    was = None
+    if ts is not None:
+        was, ts.graph = ts.graph, False
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    with LaunchTimer(list(MLP_KERNELS)) as lt:
+        for _ in range(n_steps):
+            step()
+        torch.cuda.synchronize()
+    if ts is not None:
+        ts.graph = was
+    bpp = block_bytes() if train else {}
+    rows = []
+    for name, (k_h2, k_f32, bound, work, what) in MLP_KERNELS.items():
+        ms = lt.times_ms(name)
+        if not ms:
+            continue
+        metas = lt.meta[name]
+        if name == "svs_wgrad_multi":
+            # two launches per ray group: the SDF network's layers (9 jobs; 11 with the background network's) and the
+            # radiance network's (5 jobs, side stream)
+            kinds = {}
+            for t, a in zip(ms, metas):
+                kinds.setdefault(int(a[1]), []).append(t)
+            for n_jobs, tt in kinds.items():
+                which = "radiance" if n_jobs == 5 else "sdf"
+                pts = (R * S if which == "radiance" else R * (S + 2)) * n_steps / len(tt)
+                rows.append(dict(entry=name, kernel=(k_h2 if h2 else k_f32), what=f"{what} ({which}, {n_jobs} layers)",
+                                 bound=bound, launches_per_step=len(tt) / n_steps, kernel_ms=float(np.mean(tt)),
+                                 points_per_launch=pts, work_per_point=bpp.get("wgrad_" + which)))
+            continue
+        if name in ("svs_rgb_bwd", "svs_sdf_bwd_b"):
+            pts = [int(a[0]) for a in metas]
+        else:
+            pts = [int(a[1]) + int(a[6]) * int(a[7]) for a in metas]
+        if name == "svs_sdf_vals":
+            pass
+        w = work if work is not None else bpp.get(name)
+        rows.append(dict(entry=name, kernel=(k_h2 if h2 else k_f32), what=what, bound=bound,
+                         launches_per_step=len(ms) / n_steps, kernel_ms=float(np.mean(ms)),
+                         points_per_launch=float(np.mean(pts)), work_per_point=w))
+    for r in rows:
+        r["ms_per_step"] = r["kernel_ms"] * r["launches_per_step"]
+        per_launch = (r["work_per_point"] or 0) * r["points_per_launch"]
+        rate = per_launch / (r["kernel_ms"] * 1e-3) if r["kernel_ms"] > 0 else 0.0
+        if r["bound"] == "mfma":
+            peak = PEAK_F16_MFMA / 3 if h2 else PEAK_F32_MFMA
+            r.update(achieved=rate / 1e12, peak=peak / 1e12, unit="TFLOP/s", frac=rate / peak)
+        else:
+            r.update(achieved=rate / 1e9, peak=PEAK_HBM / 1e9, unit="GB/s", frac=rate / PEAK_HBM)
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    # HBM traffic per launch: PMC counters of the committed profile of this same command (profiles/, see
+    # tools/summarize_profiles.py); the bench itself cannot run the counters
+    traffic, src_prof = {}, None
+    try:
+        prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
+        traffic = json.load(open(os.path.join(ROOT, "profiles", prof[-1])))["kernels"]
+        src_prof = prof[-1]
+    except Exception:
+        pass
+    top = dict(rows[0])
+    top["traffic"] = traffic.get(top["kernel"], {}).get("hbm_bytes")
+    top["traffic_source"] = src_prof
+    top["timing"] = (f"HIP events on the launch streams over {n_steps} eager steps after the timed region (same process; the "
+                     "timed region replays a hipGraph, whose kernels cannot be bracketed by events)")
+    top["peak_note"] = ("mfma rows: algorithmic float32 FLOP; fp16x2 evaluates each product as three fp16 MFMA products: "
+                        "peak = 2500 / 3 TFLOP/s.  hbm rows: algorithmic bytes = every activation block the launch "
+                        "reads or writes, once" if h2 else "dense float32 MFMA peak / HBM3E peak")
+    top["kernels"] = [{k: r[k] for k in ("kernel", "what", "bound", "launches_per_step", "kernel_ms", "ms_per_step",
+                                         "points_per_launch", "work_per_point", "achieved", "unit", "frac")} for r in rows]
+    return top
+
+
+def exact_f32_step_ms(make_model, make_step, n=10):
+    """ms per step of the same workload on the exact float32-MFMA kernels (SVS_MLP_PRECISION=f32), eager launches."""
+    import torch
+    old = os.environ.get("SVS_MLP_PRECISION")
+    os.environ["SVS_MLP_PRECISION"] = "f32"
+    try:
+        _, model = make_model()
+        ts, step = make_step(model)
+        ts.graph = False
+        for _ in range(4):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / n
+    finally:
+        if old is None:
+            os.environ.pop("SVS_MLP_PRECISION", None)
+        else:
+            os.environ["SVS_MLP_PRECISION"] = old
+
+
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(params, K, pose, train=True, reps=5, warm=2):
+    """CPU port of the reference's PyTorch path on a bounded sample of the same workload: numpy oracle for the sampler and
+    the MVS prior lookup, plain torch float32 autograd (oracle/torch_ref.py) for the differentiable part, clip + Adam.
+    Timed at 1 thread (what the reference's trainer forces, volsdf/vsdf.py:21), 8 threads and all host threads; the
+    sample size per thread count keeps one repetition at a few seconds."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import torch
     import svs_oracle as orc
     import synth
     import torch_ref as tref
-    cores = torch.get_num_threads()
-    uv = synth.make_uv(rays, seed=5)
-    rng = synth.make_train_rng(rays, seed=5)
+    all_threads = os.cpu_count() or torch.get_num_threads()
     layers = orc.effective_weights(params, "implicit_network", 9)
+    # a small prior (72 x 96 x 192, three views) for the lookup: its cost does not depend on the volume size
+    rs = np.random.default_rng(3)
+    views = []
+    for dx in (0.0, 0.3, -0.3):
+        Kj, Pj = synth.make_camera(center=(dx, 0.0, -2.5), tilt=-0.12 * dx / 0.3)
+        logits = rs.normal(0, 1, (192, 72, 96)).astype(np.float32)
+        prob = np.exp(logits - logits.max(0)); prob /= prob.sum(0)
+        zm = np.broadcast_to(np.linspace(1.5, 3.5, 192, dtype=np.float32)[:, None, None], (192, 72, 96)).copy()
+        views.append(dict(K=Kj, c2w=Pj, cost=prob.astype(np.float32), z_mvs=zm))
 
-    def one():
+    def one(rays, rng, uv):
         if not train:
             orc.render_forward(params, uv, pose, K, beta_param=params["density.beta"], fast=1, training=True, rng=rng)
             return
@@ -281,6 +394,9 @@ def cpu_baseline(params, K, pose, train=True, rays=32, reps=3):
         eik = np.concatenate([rng["eik_points"], (cam[None] + z_eik * dirs).astype(np.float32)], 0)
         p = tref.to_torch(params, torch.float32)
         out = tref.forward_differentiable(p, cam, dirs, z, eik, ds)
+        xyz = (cam[None, None] + z[:, :, None] * dirs[:, None, :]).astype(np.float32)
+        pj, pi, _ = orc.cost_mapping(xyz, 0, views, (576, 768))
+        out["pj"], out["pi"] = torch.from_numpy(pj), torch.from_numpy(pi)
         tgt = torch.rand(rays, 3)
         total = tref.loss_fn(out, tgt, tgt, 250)
         total.backward()
@@ -288,16 +404,32 @@ def cpu_baseline(params, K, pose, train=True, rays=32, reps=3):
         torch.nn.utils.clip_grad_norm_([v for v in p.values()], 1.0)
         opt.step()
 
-    one()
-    ts = []
-    for _ in range(reps):
-        t0 = time.perf_counter()
-        one()
-        ts.append(time.perf_counter() - t0)
-    t = float(np.median(ts))
-    what = "train step (numpy sampler + torch float32 autograd, clip, Adam)" if train else "train-mode fast=1 forward, numpy oracle"
-    return {"value": rays / t, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": f"{rays} rays of the same {what}, median of {reps}"}
+    by_threads = {}
+    saved = torch.get_num_threads()
+    for threads, rays in ((1, 64), (8, 256), (all_threads, 256)):
+        if threads in by_threads or threads > all_threads:
+            continue
+        torch.set_num_threads(threads)
+        uv = synth.make_uv(rays, seed=5)
+        rng = synth.make_train_rng(rays, seed=5)
+        for _ in range(warm):
+            one(rays, rng, uv)
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            one(rays, rng, uv)
+            ts.append(time.perf_counter() - t0)
+        by_threads[threads] = dict(rays_per_s=rays / float(np.median(ts)), rays=rays, median_s=float(np.median(ts)))
+    torch.set_num_threads(saved)
+    best = max(by_threads, key=lambda k: by_threads[k]["rays_per_s"])
+    what = ("train step (numpy sampler + MVS prior lookup, torch float32 autograd, clip, Adam)" if train
+            else "train-mode fast=1 forward, numpy oracle")
+    return {"value": by_threads[best]["rays_per_s"], "unit": "rays/s", "cores": best, "kind": "port",
+            "sample": f"{by_threads[best]['rays']} rays of the same {what}; median of {reps} after {warm} warm-ups; "
+                      f"fastest of the thread counts tried (torch intra-op threads; numpy parts are single-threaded)",
+            "single_thread_rays_per_s": by_threads[1]["rays_per_s"],
+            "by_threads": {str(k): v for k, v in by_threads.items()},
+            "host_cpu": cpu_model_name(), "host_threads": all_threads}
 
 
 if __name__ == "__main__":

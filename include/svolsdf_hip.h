@@ -252,11 +252,16 @@ int svs_unpack_wgrad_multi(const svs_unpack_job* jobs, int n_jobs, void* hip_str
 
 /* ---- a12  optimiser step ---------------------------------------------------------------------------------------
  * clip_grad_norm_(1.0) + NaN/Inf guard + Adam of VolOpt.train_step (volsdf/vsdf.py:214-219,454-463,101-102) on flat
- * float32 buffers, no host sync.  step: 1-based.  info (2 floats, may be NULL): gradient norm, update dropped (0/1). */
+ * float32 buffers, no host sync.  step: 1-based Adam step count; when step_counter (device int) is not NULL the launch
+ * increments that counter and uses the new value instead, so that a captured launch sequence (hipGraph) replays with
+ * an advancing step.  lr / betas / eps are float64 like torch's hyper-parameters (1 - beta, the bias corrections and
+ * lr / bias_correction1 are formed in float64 and rounded once, as torch does).  A non-finite gradient is zeroed and
+ * the Adam step still runs (torch 1.9 zero_grad semantics).  info (2 floats, may be NULL): gradient norm before
+ * clipping, gradient dropped (0/1). */
 size_t svs_adam_workspace_bytes(void);
 int svs_clip_guard_adam(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long long n, int step,
-                        float max_norm, float lr, float beta1, float beta2, float eps, void* workspace, float* info,
-                        void* hip_stream);
+                        int* step_counter, double max_norm, double lr, double beta1, double beta2, double eps,
+                        void* workspace, float* info, void* hip_stream);
 
 /* ---- a10  MVS prior lookup ----------------------------------------------------------------------------
  * VolOpt.cost_mapping (volsdf/vsdf.py:382-452).  Points: xyz (n_points,3) or, when xyz == NULL, cam + z*dir with
@@ -264,22 +269,27 @@ int svs_clip_guard_adam(float* params, float* grads, float* exp_avg, float* exp_
  * cost / z_near / z_far: HOST arrays of device pointers per view: probability volume (D,H,W), depth hypotheses
  * [0] and [-1] (H,W); dims: HOST int array D,H,W per view.  same_view: index of the rendered view (-> pi).
  * img_w, img_h: SceneDataset resolution used for the normalisation (vsdf.py:397,414-415).
+ * same_view_dev (device int, may be NULL): overrides same_view at run time, so that a captured launch sequence
+ * (hipGraph) can be replayed for another rendered view.
  * -> pj (n_points), pi (n_points), valid (n_points, uint8) */
 int svs_cost_lookup(const float* xyz, const float* cam, const float* dirs, const float* z, int S, int n_points,
                     int n_views, int same_view, int inverse_depth, float img_w, float img_h, const float* view_params,
                     const float* const* cost, const float* const* z_near, const float* const* z_far, const int* dims,
-                    float* pj, float* pi, unsigned char* valid, void* hip_stream);
+                    float* pj, float* pi, unsigned char* valid, const int* same_view_dev, void* hip_stream);
 
 /* ---- a11  loss ----------------------------------------------------------------------------------------
  * VolSDFLoss.forward (volsdf/model/loss.py:80-114) and the gradient of the total w.r.t. the model outputs.
  * rgb_target = ground_truth['rgb'], or 'rgb_smooth' with annealed = 1 (loss.py:103-105); pi/pj NULL = no MVS terms.
  * losses[5] = rgb, eikonal, mvs, sparse, total.  n_rays_norm / n_eik_norm (0 = n_rays / n_eik): denominators of the
- * means when a batch is processed in several ray groups (the groups' losses and gradients then simply add). */
+ * means when a batch is processed in several ray groups (the groups' losses and gradients then simply add).
+ * anneal_dev (device, 2 floats, may be NULL): {annealed, anneal_sparse} read at run time instead of the two by-value
+ * arguments (captured launch sequences replayed while the annealing advances). */
 int svs_loss(int n_rays, int n_samples, int n_eik, const float* rgb_values, const float* rgb_target,
              const float* grad_theta, const float* weights, const float* pi, const float* pj, const float* depth_values,
              float rgb_weight, float eikonal_weight, float mvs_weight, float sparse_weight, float gce, float confi,
              int annealed, float anneal_sparse, int n_rays_norm, int n_eik_norm, float* losses, float* d_rgb_values,
-             float* d_grad_theta, float* d_weights, float* d_depth_values, double* workspace, void* hip_stream);
+             float* d_grad_theta, float* d_weights, float* d_depth_values, double* workspace, const float* anneal_dev,
+             void* hip_stream);
 size_t svs_loss_workspace_bytes(int n_rays, int n_eik);
 
 /* ---- f1  FeatureNet convolutions (models/CasMVSNet.py:24-55,338-439) ---------------------------------------------

@@ -13,7 +13,8 @@ constexpr int kBlocks = 256;
 
 // stage 1: per-block partial sum of squares (float64) and non-finite count
 __global__ __launch_bounds__(256) void grad_stats_kernel(const float* __restrict__ g, long long n, double* __restrict__ part,
-                                                         int* __restrict__ bad) {
+                                                         int* __restrict__ bad, int* __restrict__ step_counter) {
+  if (step_counter && blockIdx.x == 0 && threadIdx.x == 0) *step_counter += 1;      // read by adam_kernel (next launch)
   __shared__ double sh[4];
   __shared__ int shb[4];
   double acc = 0.0;
@@ -32,28 +33,38 @@ __global__ __launch_bounds__(256) void grad_stats_kernel(const float* __restrict
   }
 }
 
-// stage 2: every block reduces the partials in the same fixed order (reproducible), then updates its slice
+// stage 2: every block reduces the partials in the same fixed order (reproducible), then updates its slice.
+// Scalars arrive as the float32 values torch's kernels receive: torch keeps lr / betas / eps as Python floats
+// (float64), forms 1 - beta, the bias corrections and lr / bias_correction1 in float64 and rounds once when the scalar
+// enters a float32 kernel.  (1.0f - 0.999f is 4.7e-5 larger than float(1 - 0.999).)
+struct AdamScalars {
+  float max_norm, beta1, omb1, beta2, omb2, eps;
+  double lr, beta1_d, beta2_d;
+};
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long long n, const double* __restrict__ part,
-                                                   const int* __restrict__ bad, int n_part, float max_norm, float lr,
-                                                   float beta1, float beta2, float eps, float bc1, float bc2_sqrt,
-                                                   float* __restrict__ info) {
+                                                   const int* __restrict__ bad, int n_part, AdamScalars sc, int step,
+                                                   const int* __restrict__ step_dev, float* __restrict__ info) {
   double tot = 0.0;
   int nb = 0;
   for (int i = 0; i < n_part; ++i) { tot += part[i]; nb |= bad[i]; }
+  if (step_dev) step = *step_dev;                      // graph replays: the counter lives on the device (grad_stats bumped it)
+  const double bc1 = 1.0 - pow(sc.beta1_d, (double)step);
+  const double bc2 = 1.0 - pow(sc.beta2_d, (double)step);
+  const float step_size = (float)(sc.lr / bc1), bc2_sqrt = (float)__builtin_sqrt(bc2);
   const float total_norm = (float)__builtin_sqrt(tot);
-  float coef = max_norm > 0.0f ? max_norm / (total_norm + 1e-6f) : 1.0f;     // clip_grad_norm_
+  float coef = sc.max_norm > 0.0f ? sc.max_norm / (total_norm + 1e-6f) : 1.0f;     // clip_grad_norm_
   coef = coef > 1.0f ? 1.0f : coef;
   const bool drop = nb != 0 || !(total_norm <= 3.4028234e38f);
   if (blockIdx.x == 0 && threadIdx.x == 0 && info) { info[0] = total_norm; info[1] = drop ? 1.0f : 0.0f; }
-  const float step_size = lr / bc1;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const float gi = drop ? 0.0f : g[i] * coef;
     g[i] = gi;                                          // the clipped (or zeroed) gradient stays visible, as in torch
-    const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
-    const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+    const float mi = sc.beta1 * m[i] + sc.omb1 * gi;
+    const float vi = sc.beta2 * v[i] + sc.omb2 * (gi * gi);      // addcmul_(grad, grad, value = 1 - beta2)
     m[i] = mi; v[i] = vi;
-    const float denom = __builtin_sqrtf(vi) / bc2_sqrt + eps;
+    const float denom = __builtin_sqrtf(vi) / bc2_sqrt + sc.eps;
     p[i] = p[i] - step_size * (mi / denom);
   }
 }
@@ -68,22 +79,24 @@ extern "C" {
 
 size_t svs_adam_workspace_bytes(void) { return kBlocks * (sizeof(double) + sizeof(int)); }
 
-// step: 1-based Adam step count.  workspace: svs_adam_workspace_bytes().  info (2 floats, may be NULL): the
-// gradient norm before clipping and whether the update was dropped (non-finite gradient).
+// step: 1-based Adam step count, or -- when step_counter (device int) is given -- ignored: the launch increments the
+// counter and uses the new value, so that a captured launch sequence (hipGraph) replays with an advancing step.
+// lr / betas / eps are float64 like torch's hyper-parameters.  workspace: svs_adam_workspace_bytes().  info (2
+// floats, may be NULL): the gradient norm before clipping and whether the gradient was dropped (non-finite).
 int svs_clip_guard_adam(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long long n, int step,
-                        float max_norm, float lr, float beta1, float beta2, float eps, void* workspace, float* info,
-                        void* hip_stream) {
-  if (!params || !grads || !exp_avg || !exp_avg_sq || !workspace || n <= 0 || step < 1) {
+                        int* step_counter, double max_norm, double lr, double beta1, double beta2, double eps,
+                        void* workspace, float* info, void* hip_stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !workspace || n <= 0 || (!step_counter && step < 1)) {
     set_error("svs_clip_guard_adam: bad argument"); return SVS_EINVAL;
   }
   double* part = (double*)workspace;
   int* bad = (int*)(part + kBlocks);
   hipStream_t s = (hipStream_t)hip_stream;
-  grad_stats_kernel<<<kBlocks, 256, 0, s>>>(grads, n, part, bad);
-  const double bc1 = 1.0 - __builtin_pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - __builtin_pow((double)beta2, (double)step);
-  adam_kernel<<<kBlocks, 256, 0, s>>>(params, grads, exp_avg, exp_avg_sq, n, part, bad, kBlocks, max_norm, lr, beta1, beta2,
-                                      eps, (float)bc1, (float)__builtin_sqrt(bc2), info);
+  grad_stats_kernel<<<kBlocks, 256, 0, s>>>(grads, n, part, bad, step_counter);
+  AdamScalars sc;
+  sc.max_norm = (float)max_norm; sc.beta1 = (float)beta1; sc.omb1 = (float)(1.0 - beta1); sc.beta2 = (float)beta2;
+  sc.omb2 = (float)(1.0 - beta2); sc.eps = (float)eps; sc.lr = lr; sc.beta1_d = beta1; sc.beta2_d = beta2;
+  adam_kernel<<<kBlocks, 256, 0, s>>>(params, grads, exp_avg, exp_avg_sq, n, part, bad, kBlocks, sc, step, step_counter, info);
   return check_launch("svs_clip_guard_adam");
 }
 

@@ -236,6 +236,7 @@ struct LookupArgs {
   const float* xyz;         // (P,3) explicit world points, or nullptr -> cam + z*dir
   const float* cam; const float* dirs; const float* z; int S;
   int P, n_views, same_view, inverse_depth;
+  const int* same_view_dev; // optional: the rendered view's index read from the device (captured launch sequences)
   float half_w, half_h;     // (W_img-1)/2, (H_img-1)/2 of the SceneDataset resolution (vsdf.py:397,414-415)
   LookupView v[kMaxViews];
   float* pj; float* pi; unsigned char* valid;
@@ -277,6 +278,7 @@ __device__ __forceinline__ float sample3d(const float* __restrict__ vol, int D, 
 __global__ void cost_lookup_kernel(LookupArgs a) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= a.P) return;
+  const int same_view = a.same_view_dev ? *a.same_view_dev : a.same_view;
   float X, Y, Z;
   if (a.xyz) { X = a.xyz[3 * p]; Y = a.xyz[3 * p + 1]; Z = a.xyz[3 * p + 2]; }
   else {
@@ -311,7 +313,7 @@ __global__ void cost_lookup_kernel(LookupArgs a) {
     inval = (nearv < 1e-5f) || (farv < 1e-5f) || (zn > 1.01f) || (zn < -1.01f) || inval;
     if (inval) { x = -99.0f; y = -99.0f; zn = -99.0f; }
     const float c = sample3d(v.cost, v.D, v.H, v.W, x, y, zn);
-    if (j == a.same_view) pi = c;
+    if (j == same_view) pi = c;
     else { pj += c; valid = valid || !inval; }
   }
   a.pj[p] = pj;
@@ -332,6 +334,7 @@ struct LossArgs {
   float rgb_weight, eikonal_weight, mvs_weight, sparse_weight;
   float gce, confi, anneal_sparse;    // anneal_sparse > 0 <=> annealed phase (masked rgb + sparse term)
   int annealed;
+  const float* anneal_dev;   // optional {annealed (0/1), anneal_sparse} on the device (captured launch sequences)
   float* losses;             // out[5]: rgb, eikonal, mvs, sparse, total
   float* d_rgb_values;       // (R,3)   d total / d rgb_values
   float* d_grad_theta;       // (n_eik,3)
@@ -372,7 +375,8 @@ __global__ __launch_bounds__(256) void loss_rays_kernel(LossArgs a, double* __re
       for (int s = lane; s < a.S; s += 64, ++k) a.d_weights[(size_t)r * a.S + s] = has_mvs ? dls[k & 3] * sc : 0.0f;
     }
     if (lane == 0) {
-      const bool masked = a.annealed && has_mvs;
+      const bool masked = (a.anneal_dev ? a.anneal_dev[0] != 0.0f : a.annealed != 0) && has_mvs;
+      const float anneal_sparse = a.anneal_dev ? a.anneal_dev[1] : a.anneal_sparse;
       const bool rgb_on = !masked || conf < 1e-8;
       double l1 = 0.0;
       for (int c = 0; c < 3; ++c) {
@@ -386,7 +390,7 @@ __global__ __launch_bounds__(256) void loss_rays_kernel(LossArgs a, double* __re
       if (masked && conf < (double)a.confi) {
         const float dep = a.depth_values[r] + 1e-3f;
         sp = 1.0 / (double)dep;
-        dd = -(a.sparse_weight * a.anneal_sparse) / (dep * dep) / (float)a.R_norm;
+        dd = -(a.sparse_weight * anneal_sparse) / (dep * dep) / (float)a.R_norm;
       }
       a.d_depth_values[r] = dd;
       double* o = partial + (size_t)unit * 4;
@@ -423,7 +427,8 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(LossArgs a, const doub
     const float rgb = (float)(t[0] / a.R_norm), eik = a.n_eik_norm ? (float)(t[1] / a.n_eik_norm) : 0.0f;
     const float mvs = (float)(t[2] / a.R_norm), sp = (float)(t[3] / a.R_norm);
     a.losses[0] = rgb; a.losses[1] = eik; a.losses[2] = mvs; a.losses[3] = sp;
-    a.losses[4] = a.rgb_weight * rgb + a.eikonal_weight * eik + a.mvs_weight * mvs + (a.sparse_weight * a.anneal_sparse) * sp;
+    const float anneal_sparse = a.anneal_dev ? a.anneal_dev[1] : a.anneal_sparse;
+    a.losses[4] = a.rgb_weight * rgb + a.eikonal_weight * eik + a.mvs_weight * mvs + (a.sparse_weight * anneal_sparse) * sp;
   }
 }
 
@@ -801,13 +806,13 @@ int svs_composite_bwd(int n_rays, int n_samples, const float* z, const float* sd
 int svs_cost_lookup(const float* xyz, const float* cam, const float* dirs, const float* z, int S, int n_points,
                     int n_views, int same_view, int inverse_depth, float img_w, float img_h, const float* view_params,
                     const float* const* cost, const float* const* z_near, const float* const* z_far, const int* dims,
-                    float* pj, float* pi, unsigned char* valid, void* hip_stream) {
+                    float* pj, float* pi, unsigned char* valid, const int* same_view_dev, void* hip_stream) {
   if ((!xyz && !(cam && dirs && z && S > 0)) || !view_params || !cost || !z_near || !z_far || !dims || !pj || !pi ||
       !valid || n_points <= 0) { set_error("svs_cost_lookup: null/invalid argument"); return SVS_EINVAL; }
   if (n_views < 1 || n_views > kMaxViews) { set_error("svs_cost_lookup: 1..%d views", kMaxViews); return SVS_ESHAPE; }
   LookupArgs a;
   a.xyz = xyz; a.cam = cam; a.dirs = dirs; a.z = z; a.S = S > 0 ? S : 1; a.P = n_points; a.n_views = n_views;
-  a.same_view = same_view; a.inverse_depth = inverse_depth;
+  a.same_view = same_view; a.same_view_dev = same_view_dev; a.inverse_depth = inverse_depth;
   a.half_w = (img_w - 1.0f) / 2.0f; a.half_h = (img_h - 1.0f) / 2.0f;
   a.pj = pj; a.pi = pi; a.valid = valid;
   for (int j = 0; j < n_views; ++j) {
@@ -828,13 +833,14 @@ int svs_loss(int n_rays, int n_samples, int n_eik, const float* rgb_values, cons
              const float* grad_theta, const float* weights, const float* pi, const float* pj, const float* depth_values,
              float rgb_weight, float eikonal_weight, float mvs_weight, float sparse_weight, float gce, float confi,
              int annealed, float anneal_sparse, int n_rays_norm, int n_eik_norm, float* losses, float* d_rgb_values,
-             float* d_grad_theta, float* d_weights, float* d_depth_values, double* workspace, void* hip_stream) {
+             float* d_grad_theta, float* d_weights, float* d_depth_values, double* workspace, const float* anneal_dev,
+             void* hip_stream) {
   if (!rgb_values || !rgb_target || !weights || !depth_values || !losses || !d_rgb_values || !d_weights ||
       !d_depth_values || !workspace || n_rays <= 0 || n_samples <= 0 || n_samples > 256 || (n_eik > 0 && (!grad_theta || !d_grad_theta)) || (!pi != !pj)) {
     set_error("svs_loss: null/invalid argument"); return SVS_EINVAL;
   }
   LossArgs a{n_rays, n_samples, n_eik, n_rays_norm > 0 ? n_rays_norm : n_rays, n_eik_norm > 0 ? n_eik_norm : n_eik, rgb_values, rgb_target, grad_theta, weights, pi, pj, depth_values, rgb_weight,
-             eikonal_weight, mvs_weight, sparse_weight, gce, confi, anneal_sparse, annealed, losses, d_rgb_values,
+             eikonal_weight, mvs_weight, sparse_weight, gce, confi, anneal_sparse, annealed, anneal_dev, losses, d_rgb_values,
              d_grad_theta, d_weights, d_depth_values};
   const int n_units = n_rays + (n_eik + 63) / 64;
   loss_rays_kernel<<<(n_units + 3) / 4, 256, 0, (hipStream_t)hip_stream>>>(a, workspace);

@@ -87,12 +87,12 @@ SIGNATURES = {
     "svs_composite_bg": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P,
                                  _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "svs_adam_workspace_bytes": (c_size_t, []),
-    "svs_clip_guard_adam": (c_int, [_P, _P, _P, _P, ctypes.c_longlong, c_int, c_float, c_float, c_float, c_float, c_float,
-                                    _P, _P, _P]),
+    "svs_clip_guard_adam": (c_int, [_P, _P, _P, _P, ctypes.c_longlong, c_int, _P, c_double, c_double, c_double, c_double,
+                                    c_double, _P, _P, _P]),
     "svs_cost_lookup": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, POINTER(c_float),
-                                _PP, _PP, _PP, POINTER(c_int), _P, _P, _P, _P]),
+                                _PP, _PP, _PP, POINTER(c_int), _P, _P, _P, _P, _P]),
     "svs_loss": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float,
-                         c_float, c_int, c_float, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+                         c_float, c_int, c_float, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "svs_loss_workspace_bytes": (c_size_t, [c_int, c_int]),
     "svs_conv2d": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "svs_chw_to_hwc": (c_int, [_P, _P, c_int, c_int, c_int, _P]),

@@ -333,11 +333,30 @@ def composite_bwd(z, sdf, rgb, depth_scale, beta_param, beta_min, d_rgb_values, 
     return d_sdf, d_rgb, d_beta
 
 
-def cost_lookup(views, same_view, img_res, *, xyz=None, cam=None, dirs=None, z=None, inverse_depth=False):
+_HOST_COPIES = {}
+
+
+def _host_f32(t):
+    """float32 host copy of a small camera matrix; copies of DEVICE tensors are cached per (address, version) so that a
+    step launches without a device-to-host synchronisation (and can be captured in a hipGraph)."""
+    if not (torch.is_tensor(t) and t.is_cuda):
+        return torch.as_tensor(t, dtype=torch.float32)
+    key = (t.data_ptr(), t._version, tuple(t.shape))
+    hit = _HOST_COPIES.get(key)
+    if hit is None:
+        if len(_HOST_COPIES) > 256:
+            _HOST_COPIES.clear()
+        hit = _HOST_COPIES[key] = t.detach().to(dtype=torch.float32).cpu()
+    return hit
+
+
+def cost_lookup(views, same_view, img_res, *, xyz=None, cam=None, dirs=None, z=None, inverse_depth=False,
+                same_view_dev=None):
     """VolOpt.cost_mapping (volsdf/vsdf.py:382-452).
 
     views: list of dict(K (4,4) host/any tensor, c2w (4,4), cost (D,H,W) device, z_mvs (D,H,W) device or
     (z_near, z_far) (H,W) device).  Points: xyz (R,S,3), or cam (3,), dirs (R,3), z (R,S).
+    same_view_dev: optional device int32 tensor overriding same_view at run time (captured launch sequences).
     Returns pj (R,S), pi (R,S), valid (R,S) bool.
     """
     L = _lib.load()
@@ -354,8 +373,7 @@ def cost_lookup(views, same_view, img_res, *, xyz=None, cam=None, dirs=None, z=N
     dims = (ctypes.c_int * (3 * V))()
     keep, cost_p, near_p, far_p = [], [], [], []
     for j, v in enumerate(views):
-        K = torch.as_tensor(v["K"], dtype=torch.float32).cpu()
-        c2w = torch.as_tensor(v["c2w"], dtype=torch.float32).cpu()
+        K, c2w = _host_f32(v["K"]), _host_f32(v["c2w"])
         vals = [K[0, 0], K[1, 1], K[0, 2], K[1, 2], K[0, 1]] + [c2w[i, k] for i in range(3) for k in range(4)]
         for k, x in enumerate(vals):
             vp[17 * j + k] = float(x)
@@ -374,15 +392,16 @@ def cost_lookup(views, same_view, img_res, *, xyz=None, cam=None, dirs=None, z=N
     _lib.check(L.svs_cost_lookup(_ptr(xyz), _ptr(cam), _ptr(dirs), _ptr(z), S, R * S, V, int(same_view),
                                  int(bool(inverse_depth)), float(img_res[1]), float(img_res[0]), vp,
                                  _ptr_array(cost_p), _ptr_array(near_p), _ptr_array(far_p), dims, _ptr(pj), _ptr(pi),
-                                 _ptr(valid), _stream()), "svs_cost_lookup")
+                                 _ptr(valid), _ptr(same_view_dev), _stream()), "svs_cost_lookup")
     return pj, pi, valid.bool()
 
 
 def loss_fwd_bwd(rgb_values, rgb_target, weights, depth_values, grad_theta=None, pi=None, pj=None, *, rgb_weight=1.0,
                  eikonal_weight=0.1, mvs_weight=0.0, sparse_weight=0.0, gce=1.0, confi=0.0, annealed=False,
-                 anneal_sparse=0.0, norm=None):
+                 anneal_sparse=0.0, norm=None, anneal_dev=None):
     """VolSDFLoss.forward (volsdf/model/loss.py:80-114) and d(total)/d(model outputs) in one launch.
     norm = (R_total, n_eik_total): denominators of the means when the batch is processed in ray groups.
+    anneal_dev: optional device float32[2] = {annealed, anneal_sparse} read at run time (captured launch sequences).
     Returns (losses[5] = rgb, eikonal, mvs, sparse, total; dict of gradients)."""
     L = _lib.load()
     rgb_values, rgb_target = _f32(rgb_values).reshape(-1, 3), _f32(rgb_target).reshape(-1, 3)
@@ -401,7 +420,8 @@ def loss_fwd_bwd(rgb_values, rgb_target, weights, depth_values, grad_theta=None,
     _lib.check(L.svs_loss(R, S, n_eik, _ptr(rgb_values), _ptr(rgb_target), _ptr(gt), _ptr(weights), _ptr(pi_), _ptr(pj_),
                           _ptr(depth_values), float(rgb_weight), float(eikonal_weight), float(mvs_weight),
                           float(sparse_weight), float(gce), float(confi), int(bool(annealed)), float(anneal_sparse),
-                          int(norm[0]) if norm else 0, int(norm[1]) if norm else 0, _ptr(losses), _ptr(d_rgb), _ptr(d_gt), _ptr(d_w), _ptr(d_dep), _ptr(ws), _stream()), "svs_loss")
+                          int(norm[0]) if norm else 0, int(norm[1]) if norm else 0, _ptr(losses), _ptr(d_rgb), _ptr(d_gt), _ptr(d_w), _ptr(d_dep), _ptr(ws),
+                          _ptr(anneal_dev), _stream()), "svs_loss")
     return losses, dict(rgb_values=d_rgb, grad_theta=d_gt, weights=d_w, depth_values=d_dep)
 
 

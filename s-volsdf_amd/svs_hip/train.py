@@ -322,3 +322,15 @@ class BgBackward:
             res.append(group)
         _unpack_all(jobs)
         return res[0], res[1]
+
+
+def algorithmic_bytes_per_point(precision=None):
+    """HBM bytes per point that the HBM-bound launches of the training backward read or write ONCE (the figures
+    bench.py's roofline prices).  One 256-feature float32 block = 1024 bytes per point.
+      svs_sdf_bwd_a   reads h_1..h_8, ghat_0..ghat_7; writes u_0..u_8, a2_0..a2_7, the PE block
+      svs_sdf_bwd_b   reads h_1..h_8, a2_0..a2_7, ghat_7, feat_bar; writes abar_0..abar_7
+      wgrad_sdf       per layer abar_l, h_l, ghat_l, u_l (l = 0..7) + feat_bar, h_8 for lin8
+      wgrad_radiance  zbar_0..zbar_4, r_0..r_3, the feature block, the 16 extra input rows"""
+    blk = 1024
+    return {"svs_sdf_bwd_a": (8 + 8 + 9 + 8 + 1) * blk, "svs_sdf_bwd_b": (8 + 8 + 1 + 1 + 8) * blk,
+            "wgrad_sdf": (8 * 4 + 2) * blk, "wgrad_radiance": (5 + 4 + 1) * blk + 128}

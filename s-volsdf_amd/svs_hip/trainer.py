@@ -54,6 +54,7 @@ class FusedAdam:
         self.ws = torch.empty(L.svs_adam_workspace_bytes() // 4, dtype=torch.int32, device=dev)
         self.info = torch.zeros(2, device=dev)
         self.step_count = 0
+        self.step_dev = None          # device step counter while the step is replayed from a hipGraph (set by the capturer)
 
     def zero_grad(self, set_to_none=False):
         self.fp.grad.zero_()
@@ -62,9 +63,9 @@ class FusedAdam:
         L = _lib.load()
         self.step_count += 1
         _lib.check(L.svs_clip_guard_adam(_ptr(self.fp.flat), _ptr(self.fp.grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
-                                         self.fp.n, self.step_count, float(self.max_norm), float(self.lr),
-                                         float(self.betas[0]), float(self.betas[1]), float(self.eps), _ptr(self.ws),
-                                         _ptr(self.info), _stream()), "svs_clip_guard_adam")
+                                         self.fp.n, self.step_count, _ptr(self.step_dev) if self.step_dev is not None else None,
+                                         float(self.max_norm), float(self.lr), float(self.betas[0]), float(self.betas[1]),
+                                         float(self.eps), _ptr(self.ws), _ptr(self.info), _stream()), "svs_clip_guard_adam")
 
     def state_dict(self):
         return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq}
@@ -148,6 +149,44 @@ class _GroupedLosses(dict):
         return self[key] if key in self else default
 
 
+class _Scratch:
+    """Everything a step launches into besides the model's own buffers: packed training weight streams, weight-gradient
+    accumulators, per-group backward scratch and the streams the groups run on.  The eager path owns one set; every
+    captured graph owns its own (a graph replays into the addresses it was captured with, so its scratch must never be
+    re-allocated by a step of another shape)."""
+
+    def __init__(self, dev, is_bg):
+        from .train import BgBackward, MlpBackward, TrainStreams, WGradAccum
+        self.dev = dev
+        self.tstreams = TrainStreams(dev)
+        self.accum = WGradAccum(dev)
+        self.prep = torch.cuda.Stream(device=dev)
+        self._new_bwd = lambda: MlpBackward(dev, self.tstreams, self.accum)
+        self.bwd = [self._new_bwd()]                    # one scratch set and one stream per concurrent ray group
+        self.sides = []
+        self.d_beta = torch.zeros(8, device=dev)
+        self.bg_bwd = BgBackward(dev) if is_bg else None
+
+    def for_groups(self, n):
+        if n > self.d_beta.numel():
+            raise ValueError("at most %d ray groups" % self.d_beta.numel())
+        while len(self.bwd) < n:
+            self.bwd.append(self._new_bwd())
+            self.sides.append(torch.cuda.Stream(device=self.dev))
+
+
+class _CapturedStep:
+    """One captured launch sequence (hipGraph) of the device part of a step, with the static tensors it reads."""
+
+    def __init__(self):
+        self.graph = None
+        self.static = {}            # name -> persistent device tensor (inputs, random draws, step-varying scalars)
+        self.scratch = None
+        self.result = None          # what the eager step would have returned: tensors inside the graph's pool
+        self.hold = None
+        self.calls = 0
+
+
 class TrainStep:
     """VolOpt.train_step (volsdf/vsdf.py:196-235) for one batch, on the HIP path end to end:
     forward -> MVS prior lookup -> fused loss (+ output gradients) -> compositing / MLP backward ->
@@ -161,10 +200,18 @@ class TrainStep:
     convergence decision), every ray keeps its own random draws, the loss means are over the whole batch; only the
     float-atomic summation order of the weight gradients varies, as it does between any two runs.  Measured on MI355X
     (tools/ab_groups.py, interleaved A/B in one process): 5.05 ms/step ungrouped, 4.81 ms "auto", 4.78 ms two halves,
-    4.94 ms three streams, 5.19 ms four (more launches than the host thread can enqueue ahead)."""
+    4.94 ms three streams, 5.19 ms four (more launches than the host thread can enqueue ahead).
 
-    def __init__(self, model, loss, lr=5e-4, grad_clip=True, world=1, rank=0, groups=None):
-        from .train import MlpBackward, TrainStreams, WGradAccum
+    Captured steps (graph=True, the default; SVS_TRAIN_GRAPH=0 turns it off).  The ~100 launches of a step cost the host
+    thread ~3 ms to enqueue -- more than the GPU needs for a 256-ray shard.  The launch sequence contains no host
+    decision, so after one eager step per configuration (ray count, ray groups, model, MVS prior on / off) it is captured
+    once into a hipGraph and replayed: per step the host uploads the inputs (pixels, targets, camera, random draws and
+    three scalars: rendered-view index, annealing state) into the graph's static tensors and launches the graph; the
+    all-reduce and the fused optimiser launch stay outside it.  What a replay returns are views into the graph's memory:
+    valid until the next step."""
+
+    def __init__(self, model, loss, lr=5e-4, grad_clip=True, world=1, rank=0, groups=None, graph=None):
+        import os
         self.model, self.loss = model, loss
         self.fp = FlatParams(model._flat_param_list())
         self.opt = FusedAdam(self.fp, lr=lr, max_norm=1.0 if grad_clip else 0.0)
@@ -184,17 +231,23 @@ class TrainStep:
         dev = self.fp.flat.device
         self.is_bg = hasattr(model, "bg_implicit_network")      # VolSDFNetworkBG: fg + inverted-sphere background
         if self.is_bg:
-            from .train import BgBackward
             self.bg_grad_out = [[(next(it), next(it)) for _ in range(n)] for n in (9, 2)]
-            self.bg_bwd = BgBackward(dev)
         self.groups = groups
-        self.tstreams = TrainStreams(dev)
-        self.accum = WGradAccum(dev)
-        self.prep = None
-        self._new_bwd = lambda: MlpBackward(dev, self.tstreams, self.accum)
-        self.bwd = [self._new_bwd()]                    # one scratch set and one stream per concurrent ray group
-        self.sides = []
-        self.d_beta = torch.zeros(8, device=dev)
+        self.scratch = _Scratch(dev, self.is_bg)
+        if graph is None:
+            graph = os.environ.get("SVS_TRAIN_GRAPH", "1") != "0"
+        self.graph = bool(graph)
+        self._captured = {}
+        self._graph_pool = None
+
+    # compatibility with code that reached into the former attributes
+    @property
+    def bwd(self):
+        return self.scratch.bwd
+
+    @property
+    def accum(self):
+        return self.scratch.accum
 
     def samples_per_ray(self):
         rs = self.model.ray_sampler
@@ -230,51 +283,75 @@ class TrainStep:
         """mvs: optional dict(views=[...], same_view=int, img_res=(H,W), inverse_depth=bool) for cost_mapping."""
         return self._step(model_input, ground_truth, mvs, fast)
 
+    def _groups_for(self, R):
+        return self.split_rays(R, self.samples_per_ray()) if self.groups == "auto" else (self.groups or [(0, R)])
+
     def _step(self, model_input, ground_truth, mvs=None, fast=1):
-        from .train import finalize
         m = self.model
         m.train()
         uv = model_input["uv"]
         R = uv.shape[1]
-        dev = uv.device
-        S = self.samples_per_ray()
         self.check_batch(R)
-        groups = self.split_rays(R, S) if self.groups == "auto" else (self.groups or [(0, R)])
-        if len(groups) > self.d_beta.numel():
-            raise ValueError("at most %d ray groups" % self.d_beta.numel())
-        while len(self.bwd) < len(groups):
-            self.bwd.append(self._new_bwd())
-            self.sides.append(torch.cuda.Stream(device=dev))
-        rng = m.draw_train_rng(R, dev)
+        if self.graph:
+            out = self._step_captured(model_input, ground_truth, mvs, fast)
+            if out is not None:
+                return self._finish(out)
+        rng = m.draw_train_rng(R, uv.device)
+        gt = {"rgb": ground_truth["rgb"].reshape(-1, 3), "rgb_smooth": ground_truth["rgb_smooth"].reshape(-1, 3)}
+        results, holds = self._device_step(self.scratch, model_input, gt, mvs, fast, rng, dyn=None)
+        self._hold = holds
+        return self._finish(results)
+
+    def _finish(self, results):
+        """What follows the gradient: the one collective of a data-parallel step, the fused optimiser, host counters."""
+        allreduce_flat_grad(self.fp.grad, self.world)
+        self.opt.step()
+        self.model.invalidate_packed()          # the fused kernel bypasses torch's version counters
+        self.loss.iter_step += 1
+        self._results = results
+        if len(results) == 1:
+            return results[0]
+        return _GroupedLosses(results), _GroupedOutputs(results)
+
+    # ---- the device part of a step: everything between the uploaded inputs and the flat gradient ---------------------------
+    def _device_step(self, sc, model_input, gt, mvs, fast, rng, dyn):
+        """Launches forward, prior lookup, loss and backward of every ray group and leaves d loss / d parameters (this
+        rank's share, before the all-reduce) in the flat gradient.  No host synchronisation, no host decision that
+        depends on device data: the sequence can be captured.  dyn: None, or dict(same_view=int32[1], anneal=float32[2])
+        device tensors that carry the step-varying scalars of a captured sequence."""
+        from .train import finalize
+        m = self.model
+        uv = model_input["uv"]
+        R = uv.shape[1]
+        dev = uv.device
+        groups = self._groups_for(R)
+        sc.for_groups(len(groups))
         sdf_p, rgb_p = m.mlp_params()
         main = torch.cuda.current_stream()
         # Only the SDF forward streams are packed on the main stream (the sampler needs them first).  The radiance forward
         # stream and the weight streams of the BACKWARD kernels are packed on their own stream meanwhile; the forward
         # waits for the first event (recorded long before it gets there), the backward launches for the second.
-        if self.prep is None:
-            self.prep = torch.cuda.Stream(device=dev)
-        self.prep.wait_stream(main)                      # parameters of this step are final, last step's readers are done
+        sc.prep.wait_stream(main)                        # parameters of this step are final, last step's readers are done
         pk = m.packed_mlp(rgb=False)                     # pack once, before the streams fork
         if self.is_bg:
             m.packed_bg()                                # (the group streams are ordered behind `fork`, not behind each other)
-        with torch.cuda.stream(self.prep):
+        with torch.cuda.stream(sc.prep):
             m.rendering_network.pack_into(pk)
-            rgb_packed = torch.cuda.Event(); rgb_packed.record(self.prep)
-            self.tstreams.pack(sdf_p, rgb_p)
+            rgb_packed = torch.cuda.Event(); rgb_packed.record(sc.prep)
+            sc.tstreams.pack(sdf_p, rgb_p)
             if self.is_bg:
                 bg_sdf_wb, bg_rgb_wb = m.bg_params()
-                self.bg_bwd.pack(bg_sdf_wb, bg_rgb_wb)
-            packed = torch.cuda.Event(); packed.record(self.prep)
+                sc.bg_bwd.pack(bg_sdf_wb, bg_rgb_wb)
+            packed = torch.cuda.Event(); packed.record(sc.prep)
         if self.is_bg:
-            self.bg_bwd.zero()
-        self.accum.zero()
-        self.d_beta.zero_()
+            sc.bg_bwd.zero()
+        sc.accum.zero()
+        sc.d_beta.zero_()
         main.wait_event(rgb_packed)
         fork = torch.cuda.Event(); fork.record(main)
-        gt_rgb, gt_smooth = ground_truth["rgb"].reshape(-1, 3), ground_truth["rgb_smooth"].reshape(-1, 3)
         results, joins, holds = [], [], []
         for gi, (lo, hi) in enumerate(groups):
-            stream = main if gi == 0 else self.sides[gi - 1]
+            stream = main if gi == 0 else sc.sides[gi - 1]
             with torch.cuda.stream(stream):
                 if gi:
                     stream.wait_event(fork)
@@ -285,9 +362,11 @@ class TrainStep:
                 if mvs is not None:
                     out['pj'], out['pi'], _ = ops.cost_lookup(mvs["views"], mvs["same_view"], mvs["img_res"],
                                                               cam=keep["cam_loc"], dirs=keep["ray_dirs"], z=keep["z_vals"],
-                                                              inverse_depth=mvs.get("inverse_depth", False))
-                gt = {"rgb": gt_rgb[lo:hi], "rgb_smooth": gt_smooth[lo:hi]}
-                lo_out = self.loss(out, gt, norm=(R * self.world, 2 * R * self.world), advance=(gi == len(groups) - 1))
+                                                              inverse_depth=mvs.get("inverse_depth", False),
+                                                              same_view_dev=dyn["same_view"] if dyn else None)
+                g_gt = {"rgb": gt["rgb"][lo:hi], "rgb_smooth": gt["rgb_smooth"][lo:hi]}
+                lo_out = self.loss(out, g_gt, norm=loss_norm(R, self.world), advance=False,
+                                   anneal_dev=dyn["anneal"] if dyn else None)
                 g = self.loss.last_grads
                 stream.wait_event(packed)
                 if self.is_bg:
@@ -295,29 +374,103 @@ class TrainStep:
                         keep["z_vals"], keep["z_max"], keep["sdf"], keep["rgb_flat"], keep["depth_scale"], m.density.beta,
                         m.density.beta_min_value, keep["z_bg"], keep["bg_out0"], keep["bg_rgb"], g["rgb_values"],
                         g["weights"], g["depth_values"])
-                    self.bg_bwd.accumulate(keep, d_brgb, d_bo, slot=gi)
+                    sc.bg_bwd.accumulate(keep, d_brgb, d_bo, slot=gi)
                 else:
                     gw = m.white_bkgd_weight_grad(g["rgb_values"], g["weights"], keep["z_vals"].shape[1])
                     d_sdf, d_rgb, d_beta = ops.composite_bwd(keep["z_vals"], keep["sdf"], keep["rgb_flat"], keep["depth_scale"],
                                                              m.density.beta, m.density.beta_min_value, g["rgb_values"],
                                                              gw, g["depth_values"])
-                self.d_beta[gi:gi + 1].copy_(d_beta)
-                self.bwd[gi].accumulate(keep, d_rgb, d_sdf, g["grad_theta"])
+                sc.d_beta[gi:gi + 1].copy_(d_beta)
+                sc.bwd[gi].accumulate(keep, d_rgb, d_sdf, g["grad_theta"])
                 results.append((lo_out, out))
-                holds.append((keep, g, d_sdf, d_rgb, inp, gt))
+                holds.append((keep, g, d_sdf, d_rgb, inp, g_gt))
                 if gi:
                     ev = torch.cuda.Event(); ev.record(stream); joins.append(ev)
         for ev in joins:
             main.wait_event(ev)
-        finalize(self.accum, sdf_p, rgb_p, out=self.grad_out)
+        finalize(sc.accum, sdf_p, rgb_p, out=self.grad_out)
         if self.is_bg:
-            self.bg_bwd.finalize(bg_sdf_wb, bg_rgb_wb, out=self.bg_grad_out)
-        self.beta_grad.copy_(self.d_beta.sum())
-        allreduce_flat_grad(self.fp.grad, self.world)
-        self.opt.step()
-        m.invalidate_packed()          # the fused kernel bypasses torch's version counters
-        self._hold = holds
-        self._results = results
-        if len(results) == 1:
-            return results[0]
-        return _GroupedLosses(results), _GroupedOutputs(results)
+            sc.bg_bwd.finalize(bg_sdf_wb, bg_rgb_wb, out=self.bg_grad_out)
+        self.beta_grad.copy_(sc.d_beta.sum())
+        return results, holds
+
+    # ---- captured steps -----------------------------------------------------------------------------------------------------
+    def _capture_key(self, model_input, mvs, fast):
+        R = model_input["uv"].shape[1]
+        mk = None
+        if mvs is not None:
+            mk = (len(mvs["views"]), tuple(mvs["img_res"]), bool(mvs.get("inverse_depth", False)),
+                  tuple(int(v["cost"].data_ptr()) for v in mvs["views"]))
+        return (R, tuple(self._groups_for(R)), fast, mk, str(model_input["uv"].device))
+
+    def _upload(self, cs, model_input, ground_truth, mvs):
+        """Host -> static tensors of a captured step, on the current stream (ordered before the graph launch)."""
+        st = cs.static
+        dev = model_input["uv"].device
+        for k in ("uv", "intrinsics", "pose"):
+            src = model_input[k]
+            if k not in st:
+                st[k] = torch.empty(src.shape, dtype=torch.float32, device=dev)
+            st[k].copy_(src, non_blocking=True)
+        annealed, anneal_sparse = self.loss.anneal_state()
+        target = ground_truth["rgb_smooth"] if annealed else ground_truth["rgb"]
+        if "target" not in st:
+            st["target"] = torch.empty(target.reshape(-1, 3).shape, dtype=torch.float32, device=dev)
+        st["target"].copy_(target.reshape(-1, 3), non_blocking=True)
+        if "scalars" not in st:
+            st["scalars"] = torch.zeros(4, dtype=torch.float32).pin_memory()
+            st["anneal"] = torch.zeros(2, dtype=torch.float32, device=dev)
+            st["same_view"] = torch.zeros(1, dtype=torch.int32, device=dev)
+            st["same_view_host"] = torch.zeros(1, dtype=torch.int32).pin_memory()
+            st["rng"] = {}
+        st["scalars"][0] = 1.0 if annealed else 0.0
+        st["scalars"][1] = float(anneal_sparse)
+        st["anneal"].copy_(st["scalars"][:2], non_blocking=True)
+        st["same_view_host"][0] = int(mvs["same_view"]) if mvs is not None else -1
+        st["same_view"].copy_(st["same_view_host"], non_blocking=True)
+        self.model.draw_train_rng(model_input["uv"].shape[1], dev, out=st["rng"])
+
+    def _step_captured(self, model_input, ground_truth, mvs, fast):
+        """-> results of the step (replayed from its graph), or None when this call has to run eagerly: the first step of
+        a configuration runs eagerly (it also performs the one-time kernel attribute set-up), the second is captured."""
+        key = self._capture_key(model_input, mvs, fast)
+        cs = self._captured.get(key)
+        if cs is None:
+            if len(self._captured) >= 4:                 # a few configurations at most (stages, render previews)
+                self._captured.pop(next(iter(self._captured)))
+            cs = self._captured[key] = _CapturedStep()
+        cs.calls += 1
+        if cs.calls == 1:
+            return None
+        m = self.model
+        # the pinned staging scalars are re-written by the host every step: wait until last step's uploads have left them
+        ev = getattr(cs, "uploaded", None)
+        if ev is not None:
+            ev.synchronize()
+        self._upload(cs, model_input, ground_truth, mvs)
+        cs.uploaded = torch.cuda.Event(); cs.uploaded.record()
+        if cs.graph is None:
+            st = cs.static
+            cs.scratch = _Scratch(model_input["uv"].device, self.is_bg)
+            inp = dict(model_input)
+            inp.update(uv=st["uv"], intrinsics=st["intrinsics"], pose=st["pose"])
+            gt = {"rgb": st["target"], "rgb_smooth": st["target"]}
+            dyn = dict(same_view=st["same_view"], anneal=st["anneal"])
+            m.invalidate_packed()                        # the capture must contain the weight packing
+            graph = torch.cuda.CUDAGraph()
+            if self._graph_pool is None:
+                self._graph_pool = torch.cuda.graph_pool_handle()
+            with torch.cuda.graph(graph, pool=self._graph_pool):
+                cs.result, cs.hold = self._device_step(cs.scratch, inp, gt, mvs, fast, st["rng"], dyn)
+            cs.graph = graph
+        cs.graph.replay()
+        return cs.result
+
+
+def loss_norm(n_rays_local, world):
+    """Denominators (rays, eikonal points) of the loss means of ONE rank when a batch of world x n_rays_local rays is
+    sharded over `world` ranks (and possibly processed as ray groups inside a rank): every rank's terms are normalised by
+    the GLOBAL counts, so that the all-reduced (summed) gradient is the gradient of the reference's batch mean
+    (volsdf/model/loss.py:43-46,50,67,78 take `.mean()` over all rays of the batch; the reference samples
+    2 eikonal points per ray, network.py:258-266)."""
+    return n_rays_local * world, 2 * n_rays_local * world

@@ -37,11 +37,18 @@ class VolSDFLoss(nn.Module):
             self.sparse_weight = 0
             raise NotImplementedError
 
-    def forward(self, model_outputs, ground_truth, norm=None, advance=True):
-        dev = model_outputs['rgb_values'].device
+    def anneal_state(self):
+        """(annealed, anneal_sparse) of the current iteration (loss.py:88-90,103-105): while `iter_step < anneal_rgb` the
+        rgb term uses `rgb_smooth` on rays without MVS support and the sparsity weight decays linearly to zero."""
         annealed = self.sparse_weight > 0 and self.anneal_rgb > 0 and self.iter_step < self.anneal_rgb
+        return annealed, (anneal_linearly(self.iter_step / self.anneal_rgb, 1.0, 0.) if annealed else 0.0)
+
+    def forward(self, model_outputs, ground_truth, norm=None, advance=True, anneal_dev=None):
+        """anneal_dev: optional device float32[2] holding anneal_state() -- the kernels then read the annealing from it
+        (a captured launch sequence stays valid while the iteration count advances; trainer.TrainStep)."""
+        dev = model_outputs['rgb_values'].device
+        annealed, anneal_sparse = self.anneal_state()
         has_mvs = 'pi' in model_outputs
-        anneal_sparse = anneal_linearly(self.iter_step / self.anneal_rgb, 1.0, 0.) if annealed else 0.0
         target = ground_truth['rgb_smooth'] if annealed else ground_truth['rgb']
         losses, grads = ops.loss_fwd_bwd(
             model_outputs['rgb_values'], target.to(dev), model_outputs['weights'], model_outputs.get(
@@ -49,7 +56,8 @@ class VolSDFLoss(nn.Module):
             grad_theta=model_outputs.get('grad_theta'), pi=model_outputs.get('pi'), pj=model_outputs.get('pj'),
             rgb_weight=self.rgb_weight, eikonal_weight=self.eikonal_weight,
             mvs_weight=self.mvs_weight if has_mvs else 0.0, sparse_weight=self.sparse_weight, gce=float(self.gce),
-            confi=float(self.confi), annealed=annealed and has_mvs, anneal_sparse=float(anneal_sparse), norm=norm)
+            confi=float(self.confi), annealed=annealed and has_mvs, anneal_sparse=float(anneal_sparse), norm=norm,
+            anneal_dev=anneal_dev)
         self.last_grads = grads
         if advance:
             self.iter_step += 1

@@ -67,7 +67,7 @@ class ErrorBoundSampler(RaySampler):
         self._inv_4log = float(1.0 / (4.0 * torch.log(torch.tensor(self.eps + 1.0))))
         self._ws = None
 
-    def draw_train_rng(self, R, dev, extra=None):
+    def draw_train_rng(self, R, dev, extra=None, out=None):
         """The sampler's train-mode draws for R rays: same calls, same order as the reference
         (ray_sampler.py:39,170,201,211; CPU generator), then uploaded to the device.
 
@@ -75,7 +75,9 @@ class ErrorBoundSampler(RaySampler):
         non-blocking copies: a pageable `.to(device)` blocks the host until all earlier work of the stream has
         finished, which kept the host from running ahead of the GPU (0.55 ms of GPU idle time at the start of every
         step).  extra: optional callable(slot_dict) drawing further tensors AFTER the sampler's (the model's
-        eikonal points, network.py:261), so the generator order of the reference is preserved."""
+        eikonal points, network.py:261), so the generator order of the reference is preserved.
+        out: optional dict of persistent device tensors to upload into (the static inputs of a captured step) instead of
+        fresh ones; missing entries are created in it."""
         n_out = self.N_samples + self.N_samples_extra + 2
         if dev.type != "cuda":
             host = dict(jitter=torch.rand(R, self.N_samples_eval), u=torch.rand(R, self.N_samples),
@@ -113,7 +115,11 @@ class ErrorBoundSampler(RaySampler):
             names.append("jitter_bg")
         if extra is not None:
             names += extra(slot, R)
-        out = {k: torch.empty(slot[k].shape, dtype=slot[k].dtype, device=dev) for k in names}
+        if out is None:
+            out = {}
+        for k in names:
+            if k not in out:
+                out[k] = torch.empty(slot[k].shape, dtype=slot[k].dtype, device=dev)
         for k in names:
             out[k].copy_(slot[k], non_blocking=True)
         slot["event"] = torch.cuda.Event()
