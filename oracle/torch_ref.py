@@ -74,22 +74,25 @@ def composite(z, sdf, rgb, beta_param, ds, beta_min=1e-4):
 
 
 def loss_fn(out, rgb, rgb_smooth, it, *, eikonal_weight=0.1, rgb_weight=1.0, mvs_weight=1.0, sparse_weight=1.0,
-            gce=0.5, confi=1e-3, anneal_rgb=200):
-    """VolSDFLoss.forward (loss.py:80-114) -> total"""
-    rgb_loss = (out["rgb_values"] - rgb).abs().mean()
-    eik = ((out["grad_theta"].norm(2, dim=1) - 1) ** 2).mean()
+            gce=0.5, confi=1e-3, anneal_rgb=200, norm=None):
+    """VolSDFLoss.forward (loss.py:80-114) -> total.  norm = (n_rays, n_eik): denominators of the means when `out` holds
+    only a shard of a larger batch (the shards' totals then add up to the batch's total); None: the sizes of `out`."""
+    n_rays, n_eik = norm if norm is not None else (out["rgb_values"].shape[0], out["grad_theta"].shape[0])
+    over_rays = lambda per_ray: per_ray.sum() / n_rays
+    rgb_loss = over_rays((out["rgb_values"] - rgb).abs().mean(-1))
+    eik = ((out["grad_theta"].norm(2, dim=1) - 1) ** 2).sum() / n_eik
     total = eikonal_weight * eik
     on = sparse_weight > 0 and anneal_rgb > 0 and it < anneal_rgb
     if "pi" in out:
         pw = out["pi"] * out["pj"]
         w = out["weights"]
         l = (-pw * w.detach() ** gce * torch.log(w + 1e-8)).sum(1)
-        total = total + mvs_weight * (1. * (pw.sum(1) > confi) * l).mean()
+        total = total + mvs_weight * over_rays(1. * (pw.sum(1) > confi) * l)
         if on:
             conf = pw.sum(-1)
-            sparse = ((1. / (out["depth_values"].squeeze() + 1e-3)) * (conf < confi)).mean()
+            sparse = over_rays((1. / (out["depth_values"].squeeze() + 1e-3)) * (conf < confi))
             total = total + sparse_weight * (1.0 - it / anneal_rgb) * sparse
-            rgb_loss = ((out["rgb_values"] - rgb_smooth).abs().mean(-1) * (conf < 1e-8)).mean()
+            rgb_loss = over_rays((out["rgb_values"] - rgb_smooth).abs().mean(-1) * (conf < 1e-8))
     return total + rgb_weight * rgb_loss
 
 

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     const float gi = drop ? 0.0f : g[i] * coef;
     g[i] = gi;                                          // the clipped (or zeroed) gradient stays visible, as in torch
     const float mi = sc.beta1 * m[i] + sc.omb1 * gi;
-    const float vi = sc.beta2 * v[i] + sc.omb2 * (gi * gi);      // addcmul_(grad, grad, value = 1 - beta2)
+    const float vi = sc.beta2 * v[i] + (sc.omb2 * gi) * gi;      // addcmul_(grad, grad, value = 1 - beta2): value * g * g
     m[i] = mi; v[i] = vi;
     const float denom = __builtin_sqrtf(vi) / bc2_sqrt + sc.eps;
     p[i] = p[i] - step_size * (mi / denom);

@@ -73,6 +73,111 @@ def test_sharded_gradient_equals_full_batch():
     np.testing.assert_array_equal(res[0][2], res[1][2])       # replicas stay identical
 
 
+# --------------------------------------------------------------------------------------------------------------
+# the step's own data-parallel arithmetic: loss normalisation by the GLOBAL ray / eikonal counts (trainer.loss_norm),
+# ray shards of the pixel batch and of the host-drawn random numbers (shard_rays, slice_rng), one all-reduce (sum) of the
+# flat gradient, identical optimiser step on every rank -- driven with the real model math (oracle/torch_ref.py
+# restates VolSDFNetwork + VolSDFLoss with autograd; the HIP kernels cannot run here)
+# --------------------------------------------------------------------------------------------------------------
+R_GLOBAL, IT = 16, 50          # iteration 50 < anneal_rgb: every loss term is live (masked rgb, eikonal, MVS, sparse)
+
+
+def _step_inputs():
+    sys.path[:0] = [os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "golden"), os.path.join(ROOT, "s-volsdf_amd")]
+    import synth
+    K, pose = synth.make_camera()
+    uv = synth.make_uv(R_GLOBAL, seed=3)
+    rng = synth.make_train_rng(R_GLOBAL, seed=5)
+    rs = np.random.default_rng(9)
+    gt = rs.uniform(0, 1, (R_GLOBAL, 3)).astype(np.float32)
+    gts = rs.uniform(0, 1, (R_GLOBAL, 3)).astype(np.float32)
+    return synth.make_params(0), K, pose, uv, rng, gt, gts, synth.make_mvs_views(2)
+
+
+def _shard_gradient(params, K, pose, uv, rng, gt, gts, views, lo, hi, norm):
+    """Flat float32 gradient of the loss of rays [lo, hi) normalised by `norm` -> (FlatParams, z of the shard)."""
+    import svs_oracle as orc
+    import torch_ref as tref
+    from svs_hip.trainer import FlatParams
+    p = tref.to_torch(params, torch.float32)
+    names = sorted(k for k in p if k != "density.beta") + ["density.beta"]
+    fp = FlatParams([p[k] for k in names])
+    dirs, cam, ds = orc.rays_from_uv(uv[lo:hi], pose, K)
+    layers = orc.effective_weights(params, "implicit_network", 9)
+    z, z_eik = orc.error_bound_sampler(lambda x: orc.sdf_vals(layers, x), dirs, cam, orc.get_beta(params["density.beta"]),
+                                       fast=1, training=True, rng=rng)
+    eik = np.concatenate([rng["eik_points"], (cam[None] + z_eik * dirs).astype(np.float32)], 0)
+    out = tref.forward_differentiable(p, cam, dirs, z, eik, ds)
+    xyz = (cam[None, None] + z[:, :, None] * dirs[:, None, :]).astype(np.float32)
+    pj, pi, _ = orc.cost_mapping(xyz, 0, views, (576, 768))
+    out["pj"], out["pi"] = torch.from_numpy(pj), torch.from_numpy(pi)
+    total = tref.loss_fn(out, torch.from_numpy(gt[lo:hi]), torch.from_numpy(gts[lo:hi]), IT, norm=norm)
+    fp.grad.zero_()
+    total.backward()
+    return fp, z, float(total.detach())
+
+
+def _step_worker(rank, world, port, q):
+    import torch.distributed as dist
+    params, K, pose, uv, rng, gt, gts, views = _step_inputs()
+    from svs_hip.trainer import allreduce_flat_grad, loss_norm, shard_rays
+    from volsdf.model.network import VolSDFNetwork
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    k = R_GLOBAL // world
+    mine = shard_rays(torch.from_numpy(uv)[None], rank, world)              # this rank's pixels ...
+    assert np.array_equal(mine[0].numpy(), uv[rank * k:(rank + 1) * k])
+    rng_t = {n: torch.from_numpy(np.ascontiguousarray(v)) for n, v in rng.items()}
+    mine_rng = {n: v.numpy() for n, v in VolSDFNetwork.slice_rng(rng_t, rank * k, (rank + 1) * k).items()}   # ... and draws
+    fp, z, total = _shard_gradient(params, K, pose, mine[0].numpy(), mine_rng, gt[rank * k:(rank + 1) * k],
+                                   gts[rank * k:(rank + 1) * k], views, 0, k, loss_norm(k, world))
+    local = fp.grad.clone()
+    allreduce_flat_grad(fp.grad, world)                                       # THE collective of the step
+    reduced = fp.grad.clone()
+    opt = torch.optim.Adam(fp.params, lr=5e-4)
+    torch.nn.utils.clip_grad_norm_(fp.params, 1.0)
+    opt.step()
+    q.put((rank, local.numpy(), reduced.numpy(), fp.flat.clone().numpy(), z, total))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_train_step_arithmetic_world2():
+    """Two ranks x 8 rays == one process x 16 rays: summed shard losses, all-reduced gradient, parameters after the step."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_step_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    params, K, pose, uv, rng, gt, gts, views = _step_inputs()
+    from svs_hip.trainer import loss_norm
+    assert loss_norm(8, 2) == (16, 32) and loss_norm(1024, 1) == (1024, 2048)
+    torch.set_num_threads(2)
+    fp, z_full, total_full = _shard_gradient(params, K, pose, uv, rng, gt, gts, views, 0, R_GLOBAL, None)
+    ref = fp.grad.clone().numpy()
+    opt = torch.optim.Adam(fp.params, lr=5e-4)
+    torch.nn.utils.clip_grad_norm_(fp.params, 1.0)
+    opt.step()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    k = R_GLOBAL // world
+    scale = np.abs(ref).max()
+    for rank, local, grad, flat, z, total in res:
+        assert np.array_equal(z, z_full[rank * k:(rank + 1) * k])            # fast = 1: sampling does not couple rays
+        np.testing.assert_allclose(grad, ref, rtol=0, atol=2e-6 * scale)     # all-reduced == full-batch gradient
+        assert np.abs(local - ref).max() > 0.05 * scale                      # (a single shard's is not)
+    assert sum(t[5] for t in res) == pytest.approx(total_full, rel=1e-5)     # the shard losses add up to the batch loss
+    np.testing.assert_array_equal(res[0][2], res[1][2])                      # same gradient bits on both ranks ...
+    np.testing.assert_array_equal(res[0][3], res[1][3])                      # ... hence identical replicas after Adam
+    d = np.abs(res[0][3] - fp.flat.numpy())
+    assert d.max() <= 1.1e-3 and (d > 1e-5).mean() < 0.01                    # and the single-process step (Adam sign noise aside)
+
+
 def test_shard_rays_rejects_ragged():
     sys.path.insert(0, os.path.join(ROOT, "s-volsdf_amd"))
     from svs_hip.trainer import shard_rays

@@ -1,0 +1,124 @@
+"""Captured steps (svs_hip/trainer.py): the device part of a train step replayed from a hipGraph must equal the same
+step enqueued launch by launch -- with the inputs, the rendered view, the annealing state and the Adam step count
+changing from step to step, which is exactly what a replay cannot see unless it reads them from device memory."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def G(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _fresh(dev, kind):
+    from volsdf.model.loss import VolSDFLoss
+    params = dict(synth.make_params(0))
+    if kind == "bmvs":
+        from volsdf.utils.conf import bmvs_model_conf
+        from volsdf.model.network_bg import VolSDFNetworkBG
+        params.update(synth.make_bg_params(0))
+        m = VolSDFNetworkBG(bmvs_model_conf())
+    else:
+        from volsdf.utils.conf import dtu_model_conf
+        from volsdf.model.network import VolSDFNetwork
+        m = VolSDFNetwork(dtu_model_conf())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    # anneal_rgb = 3: the annealed phase (rgb_smooth target, sparse term with a decaying weight) ends inside the test
+    loss = VolSDFLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, rgb_weight=1.0, mvs_weight=1.0, sparse_weight=1.0,
+                      anneal_rgb=3, gce=0.5, confi=1e-3)
+    return m.to(dev), loss
+
+
+@pytest.mark.parametrize("kind", ["dtu", "bmvs"])
+def test_captured_step_equals_eager(dev, kind):
+    from svs_hip.trainer import TrainStep
+    R, n_steps = 128, 6
+    rs = np.random.default_rng(5)
+    views = synth.make_mvs_views(2)
+    dviews = [dict(K=v["K"], c2w=v["c2w"], cost=G(v["cost"], dev), z_mvs=G(v["z_mvs"], dev)) for v in views]
+    # two different batches: other pixels, other camera (= other rendered view), other targets
+    batches = []
+    for j in range(2):
+        K, pose = views[j]["K"], views[j]["c2w"]
+        inp = {"intrinsics": G(np.asarray(K, F32), dev)[None], "uv": G(synth.make_uv(R, seed=3 + j), dev)[None],
+               "pose": G(np.asarray(pose, F32), dev)[None]}
+        gt = {"rgb": G(rs.uniform(0, 1, (1, R, 3)).astype(F32), dev), "rgb_smooth": G(rs.uniform(0, 1, (1, R, 3)).astype(F32), dev)}
+        batches.append((inp, gt, dict(views=dviews, same_view=j, img_res=(576, 768), inverse_depth=False)))
+    runs = {}
+    for graph in (False, True):
+        m, loss = _fresh(dev, kind)
+        ts = TrainStep(m, loss, groups=[(0, 64), (64, 128)], graph=graph)
+        torch.manual_seed(11)
+        rec = []
+        for step in range(n_steps):
+            inp, gt, mvs = batches[(step // 2) % 2]          # steps 0,1 eager+capture on batch 0; 2,3 batch 1; 4,5 batch 0
+            lo, out = ts(inp, gt, mvs=mvs)
+            rec.append(({k: float(lo[k]) for k in lo.keys()}, out["rgb_values"].clone(), out["weights"].clone(),
+                        ts.fp.grad.clone()))
+        if graph:
+            assert len(ts._captured) == 1 and next(iter(ts._captured.values())).graph is not None
+        else:
+            assert not ts._captured
+        assert ts.opt.step_count == n_steps and loss.iter_step == n_steps
+        runs[graph] = (rec, ts.fp.flat.clone())
+    (a, pa), (b, pb) = runs[False], runs[True]
+    for step, ((la, ra, wa, ga), (lb, rb, wb, gb)) in enumerate(zip(a, b)):
+        for k in la:
+            assert la[k] == pytest.approx(lb[k], rel=2e-4, abs=1e-7), (step, k, la[k], lb[k])
+        if step == 0:
+            assert torch.equal(ra, rb) and torch.equal(wa, wb)
+        else:
+            # from step 1 on the parameters differ by the float atomics' rounding of the step before (as between any two
+            # runs); a replay that missed an input update would be off by O(0.1)
+            assert float((ra - rb).abs().max()) <= 2e-4 and float((wa - wb).abs().max()) <= 2e-4, step
+        ratio = float((ga - gb).abs().max()) / float(ga.abs().max())
+        assert ratio <= (1e-5 if step == 0 else 1e-3), (step, ratio)
+    # the sparse term is live in the annealed phase only, and its weight decays: 1, 2/3, 1/3, then off
+    sp = [x[0]["sparse_loss"] for x in b]
+    assert sp[0] > 0 and sp[3] == 0.0 and sp[5] == 0.0, sp
+    d = (pa - pb).abs()
+    assert float(d.max()) <= 4e-3 and float((d > 1e-5).float().mean()) < 5e-3
+
+
+def test_adam_device_step_counter(dev):
+    """svs_clip_guard_adam with the step count on the device (what a captured optimiser launch would use) == the same
+    launches with the step count as an argument."""
+    from svs_hip.trainer import FusedAdam
+    g = torch.Generator().manual_seed(1)
+    grads = [torch.randn(5000, generator=g).to(dev) * s for s in (1.0, 3.0, 0.01, 2.0)]
+    outs = []
+    for on_device in (False, True):
+        p = torch.nn.Parameter(torch.linspace(-1, 1, 5000, device=dev))
+        opt = FusedAdam([p], lr=1e-2)
+        if on_device:
+            opt.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        for gr in grads:
+            p.grad.copy_(gr)
+            opt.step()
+        if on_device:
+            assert int(opt.step_dev) == len(grads)
+        outs.append((p.detach().clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone()))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    # and both equal torch.optim.Adam + clip_grad_norm_ (float64 scalar arithmetic, float32 tensors)
+    ref = torch.nn.Parameter(torch.linspace(-1, 1, 5000))
+    ropt = torch.optim.Adam([ref], lr=1e-2)
+    for gr in grads:
+        ref.grad = gr.cpu().clone()
+        torch.nn.utils.clip_grad_norm_([ref], 1.0)
+        ropt.step()
+    np.testing.assert_allclose(outs[0][0].cpu().numpy(), ref.detach().numpy(), rtol=0, atol=3e-7)
+    st = ropt.state_dict()["state"][0]
+    np.testing.assert_allclose(outs[0][1].cpu().numpy(), st["exp_avg"].numpy(), rtol=2e-6, atol=1e-10)
+    np.testing.assert_allclose(outs[0][2].cpu().numpy(), st["exp_avg_sq"].numpy(), rtol=2e-6, atol=1e-14)

@@ -172,8 +172,8 @@ def test_nan_guard_drops_update(dev):
         ropt.step()
     st = ropt.state_dict()["state"][0]
     np.testing.assert_allclose(p.detach().cpu().numpy(), ref.detach().numpy(), rtol=0, atol=2e-6)
-    np.testing.assert_allclose(opt.exp_avg.cpu().numpy(), st["exp_avg"].numpy(), rtol=1e-6, atol=1e-9)
-    np.testing.assert_allclose(opt.exp_avg_sq.cpu().numpy(), st["exp_avg_sq"].numpy(), rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(opt.exp_avg.cpu().numpy(), st["exp_avg"].numpy(), rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(opt.exp_avg_sq.cpu().numpy(), st["exp_avg_sq"].numpy(), rtol=2e-6, atol=1e-12)
     # Inf is caught the same way, and through the norm when no single element is flagged
     p.grad.fill_(3e38)
     opt.step()
