@@ -13,7 +13,7 @@ Inputs (weights, camera, pixel batch, prior volumes) are resident in HBM before 
 independent: with N GPUs each rank takes its own 1024-ray shard (`--scaling weak`, the default) or 1024/N rays of one
 1024-ray batch (`--scaling strong`), and the step adds ONE RCCL all-reduce of the flat float32 gradient (3.19 MB).
 
-Timed region: W warm-up steps (the step's launch sequence is captured into a hipGraph during them), then untimed
+Timed region: W warm-up steps (with --graph the step's launch sequence is captured into a hipGraph during them), then untimed
 steps until `--settle` seconds of steady state have passed (clocks, allocator), then barrier + synchronize, EXACTLY K
 steps, synchronize + barrier; the maximum over ranks is reported.
 
@@ -83,7 +83,9 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --rays rays per GPU; strong: --rays rays in total, rays/N per GPU")
     ap.add_argument("--settle", type=float, default=1.0, help="seconds of untimed steady-state steps before the timed region")
-    ap.add_argument("--no-graph", action="store_true", help="enqueue every step launch by launch instead of replaying a hipGraph")
+    ap.add_argument("--graph", choices=["off", "on", "linear"], default="off",
+                    help="replay the step's launch sequence from a hipGraph (on: with its stream topology; linear: as one "
+                         "chain); off (default): eager launches -- measured faster on this ROCm stack, see DESIGN.md")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel event timing (roofline = null)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -163,7 +165,7 @@ def main():
         loss = VolSDFLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, rgb_weight=1.0, mvs_weight=1.0,
                           sparse_weight=1.0, anneal_rgb=200, gce=0.5, confi=1e-3)       # config/ours.yaml:16-21
         t = TrainStep(mdl, loss, lr=5e-4, world=world, rank=rank, groups=None if args.groups == "none" else "auto",
-                      graph=not args.no_graph)
+                      graph={"off": False, "on": True, "linear": "linear"}[args.graph])
         return t, (lambda: t(inp, gt, mvs=mvs))
 
     ts, step = make_step(model)
@@ -406,7 +408,7 @@ def cpu_baseline(params, K, pose, train=True, reps=5, warm=2):
 
     by_threads = {}
     saved = torch.get_num_threads()
-    for threads, rays in ((1, 64), (8, 256), (all_threads, 256)):
+    for threads, rays in ((1, 64), (8, 256), (min(all_threads, 32), 256)):
         if threads in by_threads or threads > all_threads:
             continue
         torch.set_num_threads(threads)

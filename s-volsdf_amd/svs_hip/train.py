@@ -134,9 +134,11 @@ class MlpBackward:
         self.a2max = z(L.svs_block_bytes(n_total, 1) // (128 * 2))
         self._n = (n_total, n_main)
 
-    def accumulate(self, keep, d_rgb, d_sdf, d_grad_extra):
+    def accumulate(self, keep, d_rgb, d_sdf, d_grad_extra, wait=True, side=True):
         """Launches the backward of one ray group on the current stream (+ a side stream for the radiance weight
-        gradients) and adds its weight gradients into self.accum.
+        gradients) and adds its weight gradients into self.accum.  Returns the event that marks the end of the side
+        stream's work; wait=True also makes the current stream wait for it.  (A caller that runs groups on forked streams
+        passes wait=False and lets its ORIGIN stream wait for the event: see trainer.TrainStep._device_step.)
         keep: dict filled by ops.sdf_outputs / ops.rgb_eval (hbuf, gbuf, clamp_mask, src, rbuf, feat_tiles, rgb).
         d_rgb (n_main,3); d_sdf (n_main,1) or None; d_grad_extra (n_extra,3) or None: dL/d(d sdf/dx) of the extra
         (eikonal) points that follow the ray samples in the launch."""
@@ -183,15 +185,17 @@ class MlpBackward:
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream(device=dev)
+        side_stream = self._side if side else main          # side=False: everything on the current stream
         fork = torch.cuda.Event(); fork.record(main)
-        with torch.cuda.stream(self._side):
-            self._side.wait_event(fork)
+        with torch.cuda.stream(side_stream):
+            if side:
+                side_stream.wait_event(fork)
             LSm = block_stride(n_main)              # rbuf = [4 blocks][tile] + extras [tile][1024], zbuf = [5 blocks][tile]
             jobs = [job(9, n_main, 1, _off(self.zbuf, 0), KBLOCK, _ptr(feat), KBLOCK, extra=_off(rbuf, 4 * LSm), sx=1024)]
             for l in range(1, 5):
                 jobs.append(job(9 + l, n_main, 1, _off(self.zbuf, l * LSm), KBLOCK, _off(rbuf, (l - 1) * LSm), KBLOCK))
             wgrad_multi(jobs)
-            join = torch.cuda.Event(); join.record(self._side)
+            join = torch.cuda.Event(); join.record(side_stream)
         # ---- SDF MLP: pass A (needs nbar), pass B (needs sbar, fbar), then its weight gradients
         st = _stream()
         _lib.check(L.svs_sdf_bwd_a(*src.args(), _ptr(d_grad), _ptr(mask), _ptr(hbuf), _ptr(gbuf), _ptr(S.sdf), prec,
@@ -215,8 +219,10 @@ class MlpBackward:
         wgrad_multi(jobs)
         if ev:
             ev[1].record()
-        main.wait_event(join)
+        if wait and side:
+            main.wait_event(join)
         self._hold = (d_grad, d_sdf_full, d_normals, d_rgb)      # keep inputs alive until the streams are joined
+        return join
 
     def run(self, sdf_params, rgb_params, keep, d_rgb, d_sdf, d_grad_extra, out=None):
         """Whole backward of a single group: pack, zero, accumulate, finalize.  Returns (sdf_grads, rgb_grads)."""

@@ -235,8 +235,9 @@ class TrainStep:
         self.groups = groups
         self.scratch = _Scratch(dev, self.is_bg)
         if graph is None:
-            graph = os.environ.get("SVS_TRAIN_GRAPH", "1") != "0"
-        self.graph = bool(graph)
+            graph = os.environ.get("SVS_TRAIN_GRAPH", "0")
+            graph = {"0": False, "1": True}.get(graph, graph)
+        self.graph = graph                              # False | True (the step's stream topology) | "linear" (one chain)
         self._captured = {}
         self._graph_pool = None
 
@@ -314,7 +315,7 @@ class TrainStep:
         return _GroupedLosses(results), _GroupedOutputs(results)
 
     # ---- the device part of a step: everything between the uploaded inputs and the flat gradient ---------------------------
-    def _device_step(self, sc, model_input, gt, mvs, fast, rng, dyn):
+    def _device_step(self, sc, model_input, gt, mvs, fast, rng, dyn, serial=False):
         """Launches forward, prior lookup, loss and backward of every ray group and leaves d loss / d parameters (this
         rank's share, before the all-reduce) in the flat gradient.  No host synchronisation, no host decision that
         depends on device data: the sequence can be captured.  dyn: None, or dict(same_view=int32[1], anneal=float32[2])
@@ -324,25 +325,31 @@ class TrainStep:
         uv = model_input["uv"]
         R = uv.shape[1]
         dev = uv.device
-        groups = self._groups_for(R)
+        groups = [(0, R)] if serial else self._groups_for(R)
         sc.for_groups(len(groups))
         sdf_p, rgb_p = m.mlp_params()
         main = torch.cuda.current_stream()
+        prep = main if serial else sc.prep
         # Only the SDF forward streams are packed on the main stream (the sampler needs them first).  The radiance forward
         # stream and the weight streams of the BACKWARD kernels are packed on their own stream meanwhile; the forward
         # waits for the first event (recorded long before it gets there), the backward launches for the second.
-        sc.prep.wait_stream(main)                        # parameters of this step are final, last step's readers are done
+        # Stream topology (also what a capture records): every side stream forks from `main` or from a group stream and
+        # joins `main` DIRECTLY.  A stream forked from a forked stream that joins its parent again makes
+        # hipStreamEndCapture crash (ROCm 7.0 runtime of this torch build; tools/dbg_graph2.py), so the radiance
+        # weight-gradient stream of a group hands its completion event up to here instead of joining the group stream.
+        if not serial:
+            prep.wait_stream(main)                       # parameters of this step are final, last step's readers are done
         pk = m.packed_mlp(rgb=False)                     # pack once, before the streams fork
         if self.is_bg:
             m.packed_bg()                                # (the group streams are ordered behind `fork`, not behind each other)
-        with torch.cuda.stream(sc.prep):
+        with torch.cuda.stream(prep):
             m.rendering_network.pack_into(pk)
-            rgb_packed = torch.cuda.Event(); rgb_packed.record(sc.prep)
+            rgb_packed = torch.cuda.Event(); rgb_packed.record(prep)
             sc.tstreams.pack(sdf_p, rgb_p)
             if self.is_bg:
                 bg_sdf_wb, bg_rgb_wb = m.bg_params()
                 sc.bg_bwd.pack(bg_sdf_wb, bg_rgb_wb)
-            packed = torch.cuda.Event(); packed.record(sc.prep)
+            packed = torch.cuda.Event(); packed.record(prep)
         if self.is_bg:
             sc.bg_bwd.zero()
         sc.accum.zero()
@@ -381,7 +388,7 @@ class TrainStep:
                                                              m.density.beta, m.density.beta_min_value, g["rgb_values"],
                                                              gw, g["depth_values"])
                 sc.d_beta[gi:gi + 1].copy_(d_beta)
-                sc.bwd[gi].accumulate(keep, d_rgb, d_sdf, g["grad_theta"])
+                joins.append(sc.bwd[gi].accumulate(keep, d_rgb, d_sdf, g["grad_theta"], wait=False, side=not serial))
                 results.append((lo_out, out))
                 holds.append((keep, g, d_sdf, d_rgb, inp, g_gt))
                 if gi:
@@ -401,7 +408,7 @@ class TrainStep:
         if mvs is not None:
             mk = (len(mvs["views"]), tuple(mvs["img_res"]), bool(mvs.get("inverse_depth", False)),
                   tuple(int(v["cost"].data_ptr()) for v in mvs["views"]))
-        return (R, tuple(self._groups_for(R)), fast, mk, str(model_input["uv"].device))
+        return (R, tuple(self._groups_for(R)), fast, mk, str(model_input["uv"].device), self.graph)
 
     def _upload(self, cs, model_input, ground_truth, mvs):
         """Host -> static tensors of a captured step, on the current stream (ordered before the graph launch)."""
@@ -461,7 +468,8 @@ class TrainStep:
             if self._graph_pool is None:
                 self._graph_pool = torch.cuda.graph_pool_handle()
             with torch.cuda.graph(graph, pool=self._graph_pool):
-                cs.result, cs.hold = self._device_step(cs.scratch, inp, gt, mvs, fast, st["rng"], dyn)
+                cs.result, cs.hold = self._device_step(cs.scratch, inp, gt, mvs, fast, st["rng"], dyn,
+                                                       serial=self.graph == "linear")
             cs.graph = graph
         cs.graph.replay()
         return cs.result

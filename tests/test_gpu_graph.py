@@ -34,14 +34,15 @@ def _fresh(dev, kind):
         from volsdf.model.network import VolSDFNetwork
         m = VolSDFNetwork(dtu_model_conf())
     m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
-    # anneal_rgb = 3: the annealed phase (rgb_smooth target, sparse term with a decaying weight) ends inside the test
+    # anneal_rgb = 3: the annealed phase (rgb_smooth target, sparse term with a decaying weight) ends inside the test;
+    # confi = 1e3: no ray counts as MVS-supported, so the sparse term is live on every ray while the phase lasts
     loss = VolSDFLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, rgb_weight=1.0, mvs_weight=1.0, sparse_weight=1.0,
-                      anneal_rgb=3, gce=0.5, confi=1e-3)
+                      anneal_rgb=3, gce=0.5, confi=1e3)
     return m.to(dev), loss
 
 
-@pytest.mark.parametrize("kind", ["dtu", "bmvs"])
-def test_captured_step_equals_eager(dev, kind):
+@pytest.mark.parametrize("kind,mode", [("dtu", True), ("dtu", "linear"), ("bmvs", True)])
+def test_captured_step_equals_eager(dev, kind, mode):
     from svs_hip.trainer import TrainStep
     R, n_steps = 128, 6
     rs = np.random.default_rng(5)
@@ -56,7 +57,7 @@ def test_captured_step_equals_eager(dev, kind):
         gt = {"rgb": G(rs.uniform(0, 1, (1, R, 3)).astype(F32), dev), "rgb_smooth": G(rs.uniform(0, 1, (1, R, 3)).astype(F32), dev)}
         batches.append((inp, gt, dict(views=dviews, same_view=j, img_res=(576, 768), inverse_depth=False)))
     runs = {}
-    for graph in (False, True):
+    for graph in (False, mode):
         m, loss = _fresh(dev, kind)
         ts = TrainStep(m, loss, groups=[(0, 64), (64, 128)], graph=graph)
         torch.manual_seed(11)
@@ -72,10 +73,11 @@ def test_captured_step_equals_eager(dev, kind):
             assert not ts._captured
         assert ts.opt.step_count == n_steps and loss.iter_step == n_steps
         runs[graph] = (rec, ts.fp.flat.clone())
-    (a, pa), (b, pb) = runs[False], runs[True]
+    (a, pa), (b, pb) = runs[False], runs[mode]
     for step, ((la, ra, wa, ga), (lb, rb, wb, gb)) in enumerate(zip(a, b)):
         for k in la:
-            assert la[k] == pytest.approx(lb[k], rel=2e-4, abs=1e-7), (step, k, la[k], lb[k])
+            # (later steps: the replicas' parameters have drifted apart by Adam's sign noise on ~zero gradients)
+            assert la[k] == pytest.approx(lb[k], rel=1e-5 if step == 0 else 5e-3, abs=1e-7), (step, k, la[k], lb[k])
         if step == 0:
             assert torch.equal(ra, rb) and torch.equal(wa, wb)
         else:
@@ -86,9 +88,17 @@ def test_captured_step_equals_eager(dev, kind):
         assert ratio <= (1e-5 if step == 0 else 1e-3), (step, ratio)
     # the sparse term is live in the annealed phase only, and its weight decays: 1, 2/3, 1/3, then off
     sp = [x[0]["sparse_loss"] for x in b]
-    assert sp[0] > 0 and sp[3] == 0.0 and sp[5] == 0.0, sp
+    assert sp[0] > 0 and sp[2] > 0 and sp[3] == 0.0 and sp[5] == 0.0, sp
+    # its weight (1, 2/3, 1/3) is read from the device by the replayed launches: the totals must follow it
+    for step in (1, 2):
+        la, lb = a[step][0], b[step][0]
+        w = 1.0 - step / 3.0
+        rest = lambda l: l["loss"] - w * l["sparse_loss"]
+        assert rest(la) == pytest.approx(la["rgb_loss"] + 0.1 * la["eikonal_loss"] + la["mvs_loss"], rel=1e-4)
+        assert rest(lb) == pytest.approx(lb["rgb_loss"] + 0.1 * lb["eikonal_loss"] + lb["mvs_loss"], rel=1e-4), (step, lb)
     d = (pa - pb).abs()
-    assert float(d.max()) <= 4e-3 and float((d > 1e-5).float().mean()) < 5e-3
+    # six Adam steps: entries whose gradient is numerically zero take +-lr per step with a noise-determined sign
+    assert float(d.max()) <= 4e-3 and float((d > 1e-5).float().mean()) < 5e-2
 
 
 def test_adam_device_step_counter(dev):
@@ -120,5 +130,5 @@ def test_adam_device_step_counter(dev):
         ropt.step()
     np.testing.assert_allclose(outs[0][0].cpu().numpy(), ref.detach().numpy(), rtol=0, atol=3e-7)
     st = ropt.state_dict()["state"][0]
-    np.testing.assert_allclose(outs[0][1].cpu().numpy(), st["exp_avg"].numpy(), rtol=2e-6, atol=1e-10)
-    np.testing.assert_allclose(outs[0][2].cpu().numpy(), st["exp_avg_sq"].numpy(), rtol=2e-6, atol=1e-14)
+    np.testing.assert_allclose(outs[0][1].cpu().numpy(), st["exp_avg"].numpy(), rtol=2e-6, atol=5e-9)
+    np.testing.assert_allclose(outs[0][2].cpu().numpy(), st["exp_avg_sq"].numpy(), rtol=2e-6, atol=1e-11)
