@@ -77,7 +77,7 @@ int svs_sdf_outputs(const float* points, int n_points, const float* cam, int cam
                     float sphere_scale, int clamp_n, float* sdf, float* grad, float* feat_tiles, float* hbuf,
                     float* gbuf, unsigned char* clamp_mask, void* hip_stream);
 /* feature vectors in row-major (P,256), for callers outside the fused pipeline */
-int svs_tiles_to_rows(const float* tiles, int n_points, float* rows, void* hip_stream);
+int svs_tiles_to_rows(const float* tiles, int n_points, int precision, float* rows, void* hip_stream);
 
 /* ---- a6  radiance MLP -------------------------------------------------------------------------------
  * RenderingNetwork.forward, mode 'idr' (volsdf/model/network.py:170-190): rgb (P,3) =
@@ -236,7 +236,7 @@ int svs_sdf_bwd_a(const float* points, int n_points, const float* cam, int cam_s
 int svs_sdf_bwd_b(int n_points, const float* d_sdf, const unsigned char* clamp_mask, const float* feat_bar,
                   int n_feat_points, const float* hbuf, const float* gbuf, const float* a2buf, const float* stream,
                   int precision, float* abuf, float* sbar_out, float* absmax, const float* a2max, void* hip_stream);
-int svs_lin8_row0_grad(const float* hbuf, const float* ubuf, const float* sbar, int n_points, float* out257,
+int svs_lin8_row0_grad(const float* hbuf, const float* ubuf, const float* sbar, int n_points, int precision, float* out257,
                        void* hip_stream);
 int svs_unpack_wgrad(const float* dWk, const float* dbk, int ldw, int map, int rows, int cols, int row_off,
                      const float* weight_v, const float* weight_g, const float* row0, float* grad_v, float* grad_g,

@@ -40,19 +40,18 @@ __global__ __launch_bounds__(kThreads, 1) void bg_sdf_h2_kernel(BgSdfArgs a) {
     pe.compute(x[0], x[1], x[2], x[3]);
   }
   float* hb = TRAIN ? a.hbuf + (size_t)wtile * kBlockF : nullptr;
+  Pieces2 x, xn;
   if (TRAIN) {
+    // h_0 = PE (84 rows, 6 k-steps) as a PAIR block in PE order, the rest zero: the B operand of dW_0
     float* pb = a.pebuf + (size_t)wtile * kBlockF;
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      f32x16 v;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = half ? pe.v[32 * t + rho(r) + 4] : pe.v[32 * t + rho(r)];
-      store_tile(pb, t, lane, v);
+    for (int k = 0; k < 16; ++k) {
+      f16x8 fh = (f16x8)(_Float16)0.0f, fm = (f16x8)(_Float16)0.0f;
+      if (k < NetBg::kSteps0) block_fragment<kBgPeDim>(pe.v, k, half, 1.0f, fh, fm);
+      store_piece(pb, k, lane, fh, 0);
+      store_piece(pb, k, lane, fm, 1);
     }
-#pragma unroll
-    for (int t = 3; t < 8; ++t) store_tile(pb, t, lane, (f32x16)(0.0f));
   }
-  Pieces2 x, xn;
   f32x16 y8[8];
   forward_trunk_h2<TRAIN, NetBg>(st, x, xn, y8, pe, lane, half, hb);
   // ---- head: current chunk = VEC (W8 row 0 in C-layout order as float32, b8[0])
@@ -70,20 +69,33 @@ __global__ __launch_bounds__(kThreads, 1) void bg_sdf_h2_kernel(BgSdfArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) g[4 * q + j] = w[j] * dsoftplus_from_h(y8[t][4 * q + j]);
       }
-      store_tile(g7, t, lane, g);
+      float v8[8];
+#pragma unroll
+      for (int sh = 0; sh < 2; ++sh) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v8[j] = g[8 * sh + j];
+        store_piece(g7, 2 * t + sh, lane, hi8(v8, 1.0f));       // ghat_7: a half block, unscaled
+      }
     }
   }
+  if (!TRAIN) {     // (with TRAIN the trunk already split h_8 into x: its pieces are what hbuf stores)
 #pragma unroll
-  for (int t = 0; t < 8; ++t) split_tile(y8[t], t, x);
+    for (int t = 0; t < 8; ++t) split_tile(y8[t], t, x);
+  }
   st.advance();
   if (half == 0 && p < a.P) a.out0[p] = out0;
   // ---- feature vector = rows 1..256 of lin8 (no activation); tile t-1 is stored while tile t's MFMAs run
-  float* ft = a.feat_tiles + (size_t)wtile * kBlockF;
+  float* ft = a.feat_tiles + (size_t)wtile * kBlockF;     // a PAIR block (svs_blocks_h2.h)
   f32x16 prev;
-  f32x4 q4;
+  float v8[8];
   auto store_slice = [&](int tp, int r) {
-    q4[r & 3] = prev[r];
-    if ((r & 3) == 3) SVS_STREAM_STORE(q4, reinterpret_cast<f32x4*>(ft) + (4 * tp + (r >> 2)) * 64 + lane);
+    v8[r & 7] = prev[r];
+    if ((r & 7) == 7) {
+      f16x8 fh, fm;
+      split8(v8, fh, fm);
+      store_piece(ft, 2 * tp + (r >> 3), lane, fh, 0);
+      store_piece(ft, 2 * tp + (r >> 3), lane, fm, 1);
+    }
   };
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
@@ -153,9 +165,9 @@ __global__ __launch_bounds__(kThreads, 1) void bg_rgb_h2_kernel(BgRgbArgs a) {
     split8(eb + 8 * s, x.h[16 + s], x.m[16 + s]);
   }
   {
-    const float* ft = a.feat_tiles + (size_t)wtile * kBlockF;
+    const float* ft = a.feat_tiles + (size_t)wtile * kBlockF;    // a pair block: the operand as it is
 #pragma unroll
-    for (int t = 0; t < 8; ++t) split_tile(load_tile(ft, t, lane), t, x);
+    for (int k = 0; k < 16; ++k) { x.h[k] = load_piece(ft, k, lane, 0); x.m[k] = load_piece(ft, k, lane, 1); }
   }
   float* rb = a.rbuf ? a.rbuf + (size_t)wtile * kBgRbufF : nullptr;
   if (rb) {
@@ -174,18 +186,15 @@ __global__ __launch_bounds__(kThreads, 1) void bg_rgb_h2_kernel(BgRgbArgs a) {
   {
     f32x16 prev;
     float v8[8];
-    f32x4 q4;
     auto slice = [&](int tp, int r) {
       float v = __builtin_fmaxf(prev[r], 0.0f);
       pin(v);
-      if (rb) {
-        q4[r & 3] = v;
-        if ((r & 3) == 3) SVS_STREAM_STORE(q4, reinterpret_cast<f32x4*>(rb) + (4 * tp + (r >> 2)) * 64 + lane);
-      }
       v8[r & 7] = v;
       if ((r & 7) == 7) {
-        split8(v8, xn.h[2 * tp + (r >> 3)], xn.m[2 * tp + (r >> 3)]);
-        pin(xn.h[2 * tp + (r >> 3)], xn.m[2 * tp + (r >> 3)]);
+        const int k = 2 * tp + (r >> 3);
+        split8(v8, xn.h[k], xn.m[k]);
+        pin(xn.h[k], xn.m[k]);
+        if (rb) { store_piece(rb, k, lane, xn.h[k], 0); store_piece(rb, k, lane, xn.m[k], 1); }    // r_1: a pair block
       }
     };
 #pragma unroll
@@ -200,9 +209,12 @@ __global__ __launch_bounds__(kThreads, 1) void bg_rgb_h2_kernel(BgRgbArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) slice(3, r);
     if (rb) {
-      // tiles 4..7 of the r_1 block stay zero (the weight-gradient GEMM reads whole 256-row blocks)
+      // k-steps 8..15 (rows 128..255) of the r_1 block stay zero (the weight-gradient GEMM reads whole 256-row blocks)
 #pragma unroll
-      for (int t = 4; t < 8; ++t) store_tile(rb, t, lane, (f32x16)(0.0f));
+      for (int k = 8; k < 16; ++k) {
+        store_piece(rb, k, lane, (f16x8)(_Float16)0.0f, 0);
+        store_piece(rb, k, lane, (f16x8)(_Float16)0.0f, 1);
+      }
     }
   }
   // ---- layer 1: 128 -> 3 as one tile (rows 0..2 live in registers 0..2 of lanes 0..31), sigmoid
@@ -253,10 +265,10 @@ __global__ __launch_bounds__(kThreads, 1) void bg_rgb_bwd_h2_kernel(BgRgbBwdArgs
   m0 = __builtin_fmaxf(m0, __shfl_xor(m0, 32));
   PointScale ps;
   ps.start(m0, 0.0f);
-  {
-    f32x16 z1 = (f32x16)(0.0f);
-    z1[0] = dz[0]; z1[1] = dz[1]; z1[2] = dz[2];
-    store_tile(zb + (size_t)kBlockF, 0, lane, z1);
+  {  // zbar_1: rows 0..2 = elements 0..2 of k-step 0 of half 0 (a half block; the rest stays zero)
+    float z8[8] = {dz[0], dz[1], dz[2], 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    store_piece(zb + (size_t)kBlockF, 0, lane, hi8(z8, ps.s_in));
+    store_record(zb + (size_t)kBlockF, lane, ps.s_in, m0);
   }
   st.advance();
   Pieces2 pz;
@@ -264,32 +276,36 @@ __global__ __launch_bounds__(kThreads, 1) void bg_rgb_bwd_h2_kernel(BgRgbBwdArgs
   {
     // rbar_1 = W_1^T zbar_1 (K = 3: float32 MFMA from the short W1T chunk), masked by r_1 > 0 -> zbar_0 (4 tiles)
     const f32x4* c = st.cur_buf();
+    store_record(zb, lane, ps.s_out, 0.0f);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const f32x16 r = load_tile(rb, t, lane);
+      TilePieces r;
+      load_tile_hi(rb, t, lane, r);
       const f32x4 w = c[t * 64 + lane];
       f32x16 acc = (f32x16)(0.0f);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], dz[0], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1], dz[1], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2], dz[2], acc, 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { acc[i] = r[i] > 0.0f ? acc[i] : 0.0f; ps.track(acc[i]); }
-      store_tile(zb, t, lane, acc);
+      for (int i = 0; i < 16; ++i) { acc[i] = hi_at(r, i) > 0.0f ? acc[i] : 0.0f; ps.track(acc[i]); }
       split_tile_scaled(acc, t, pz, ps.s_out);
+      store_piece(zb, 2 * t, lane, pz.h[2 * t]);              // zbar_0: a half block under s_out
+      store_piece(zb, 2 * t + 1, lane, pz.h[2 * t + 1]);
     }
   }
   ps.next();
   st.advance();
   // fbar: 8 tiles of feature rows, K = 128 (8 k-steps)
-  float* fb = a.feat_bar + (size_t)wtile * kBlockF;
+  float* fb = a.feat_bar + (size_t)wtile * kBlockF;     // a half block under the predicted scale s_f (see rgb_bwd_h2_kernel)
   float fmax = 0.0f;
+  const float s_f = ps.s_out;
   f32x16 prev;
-  f32x4 q4;
+  float v8[8];
   auto slice = [&](int tp, int r) {
     const float v = prev[r] * ps.inv_in;
     fmax = __builtin_fmaxf(fmax, __builtin_fabsf(v));
-    q4[r & 3] = v;
-    if ((r & 3) == 3) SVS_STREAM_STORE(q4, reinterpret_cast<f32x4*>(fb) + (4 * tp + (r >> 2)) * 64 + lane);
+    v8[r & 7] = v;
+    if ((r & 7) == 7) store_piece(fb, 2 * tp + (r >> 3), lane, hi8(v8, s_f));
   };
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
@@ -304,6 +320,8 @@ __global__ __launch_bounds__(kThreads, 1) void bg_rgb_bwd_h2_kernel(BgRgbBwdArgs
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) slice(7, r);
+  fmax = __builtin_fmaxf(fmax, __shfl_xor(fmax, 32));
+  store_record(fb, lane, s_f, fmax);
   publish_max(a.absmax + 1, ps.gmax);
   publish_max(a.absmax + 2, fmax);
 }

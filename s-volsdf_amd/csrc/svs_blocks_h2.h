@@ -1,0 +1,90 @@
+// Activation blocks of the fp16x2 path in HBM (the float32-MFMA kernels keep plain float32 blocks, svs_mlp_dev.h).
+//
+// A block slot is unchanged: kBlockF floats = 32 KiB per wave tile (256 feature rows x 32 points), slots laid out
+// [block][wave tile].  What the fp16x2 kernels put INTO a slot is the operand form the matrix cores consume, so no
+// consumer converts or re-splits anything:
+//
+//   pair block   every value as its two fp16 pieces (22 significand bits, svs_mlp_h2_dev.h): the hi plane, 16 KiB =
+//                [16 k-steps][64 lanes][16 B], float4 index s * 64 + lane, then the mid plane at float4 index 1024 + ...
+//                The 16 bytes of lane L in k-step s are the MFMA B fragment of that k-step: rows 16 s + 8 (j >> 2) +
+//                4 (L >> 5) + (j & 3), j = 0..7, of point L & 31 -- registers 8 (s & 1) .. 8 (s & 1) + 7 of accumulator
+//                tile s >> 1.  Forward activations (h_l, the feature vector, the radiance network's r_l, PE(x)).
+//   half block   the hi plane only, of value * 2^k with one power of two per point and block, + a record of 64 floats at
+//                float index 4096 of the slot: [scale of point 0..31][max |value| of point 0..31].  Everything that
+//                exists only to form parameter gradients: ghat_l (stored unscaled: scale 1), u_l, a2_l, abar_l, zbar_l,
+//                fbar.  11 significand bits: tools/study/fp16_blocks_error.py measures what that costs (parameter
+//                gradients 3e-4 ... 8e-4 of a tensor's largest entry vs float64, inside the 2e-3 the parity tests
+//                allow); it halves the bytes these blocks move, and a sweep that only needs softplus' of h reads the
+//                hi plane of the pair block alone.
+//
+// Slot offsets and strides are those of the float32 blocks, so host code is format-agnostic; a half block simply leaves
+// the second half of its slot (beyond the record) untouched.
+#pragma once
+#include "svs_mlp_h2_dev.h"
+
+namespace svs {
+namespace mlp {
+
+constexpr int kPlaneF4 = 1024;          // float4 per fp16 plane of a wave tile (16 KiB)
+constexpr int kRecordF = 4096;          // float index of a half block's scale / max record
+
+__device__ __forceinline__ f32x4 as_f4(const f16x8& v) { return __builtin_bit_cast(f32x4, v); }
+__device__ __forceinline__ f16x8 as_h8(const f32x4& v) { return __builtin_bit_cast(f16x8, v); }
+
+// one fragment (k-step s) of a plane; plane 0 = hi, 1 = mid
+__device__ __forceinline__ void store_piece(float* __restrict__ blk, int s, int lane, const f16x8& v, int plane = 0) {
+  SVS_STREAM_STORE(as_f4(v), reinterpret_cast<f32x4*>(blk) + plane * kPlaneF4 + s * 64 + lane);
+}
+__device__ __forceinline__ f16x8 load_piece(const float* __restrict__ blk, int s, int lane, int plane = 0) {
+  return as_h8(SVS_STREAM_LOAD(reinterpret_cast<const f32x4*>(blk) + plane * kPlaneF4 + s * 64 + lane));
+}
+
+// accumulator-layout tile t (16 registers) back from stored fragments
+struct TilePieces {
+  f16x8 h[2], m[2];     // k-steps 2t, 2t+1
+};
+__device__ __forceinline__ void load_tile_hi(const float* __restrict__ blk, int t, int lane, TilePieces& p) {
+  p.h[0] = load_piece(blk, 2 * t, lane); p.h[1] = load_piece(blk, 2 * t + 1, lane);
+}
+__device__ __forceinline__ void load_tile_pair(const float* __restrict__ blk, int t, int lane, TilePieces& p) {
+  load_tile_hi(blk, t, lane, p);
+  p.m[0] = load_piece(blk, 2 * t, lane, 1); p.m[1] = load_piece(blk, 2 * t + 1, lane, 1);
+}
+// element r (0..15) of the tile
+__device__ __forceinline__ float hi_at(const TilePieces& p, int r) { return (float)p.h[r >> 3][r & 7]; }
+__device__ __forceinline__ float pair_at(const TilePieces& p, int r) { return (float)p.h[r >> 3][r & 7] + (float)p.m[r >> 3][r & 7]; }
+
+// the record of a half block: lane L < 32 writes the scale of its point, lane L >= 32 the maximum (both lane halves
+// hold both values)
+__device__ __forceinline__ void store_record(float* __restrict__ blk, int lane, float scale, float mx) {
+  blk[kRecordF + lane] = lane < 32 ? scale : mx;
+}
+__device__ __forceinline__ float load_scale(const float* __restrict__ blk, int lane) { return blk[kRecordF + (lane & 31)]; }
+__device__ __forceinline__ float load_max(const float* __restrict__ blk, int lane) { return blk[kRecordF + 32 + (lane & 31)]; }
+
+// Fragment of k-step s of a vector given in natural row order (vec[q], q < n, zero beyond), in the BLOCK convention
+// (row 16 s + 8 (j >> 2) + 4 half + (j & 3)) -- NOT the order split_pe() uses for the layer-0 operand (16 s + 8 half + j,
+// which the packed layer-0 weights follow): what a weight-gradient GEMM reads as its B operand must be in block order.
+template <int N>
+__device__ __forceinline__ void block_fragment(const float* vec, int s, int half, float scale, f16x8& h, f16x8& m) {
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int q0 = 16 * s + 8 * (j >> 2) + (j & 3), q1 = q0 + 4;
+    const float a0 = q0 < N ? vec[q0 < N ? q0 : 0] : 0.0f;
+    const float a1 = q1 < N ? vec[q1 < N ? q1 : 0] : 0.0f;
+    v[j] = (half ? a1 : a0) * scale;
+  }
+  split8(v, h, m);
+}
+
+// 8 float32 values -> the hi fragment of value * s (the stored form of a half block)
+__device__ __forceinline__ f16x8 hi8(const float* v, float s) {
+  f16x8 h;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) h[j] = (_Float16)(v[j] * s);
+  return h;
+}
+
+}  // namespace mlp
+}  // namespace svs

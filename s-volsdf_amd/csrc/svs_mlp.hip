@@ -191,6 +191,19 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_kernel(SdfFullArgs a) {
   }
 }
 
+// pair-block layout of the fp16x2 kernels (svs_blocks_h2.h) -> row-major (P, 256): value = hi + mid
+__global__ void pair_tiles_to_rows_kernel(const float* __restrict__ tiles, int P, float* __restrict__ rows) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over P*256
+  if (idx >= (size_t)P * 256) return;
+  const int p = (int)(idx / 256), f = (int)(idx % 256);
+  const int wtile = p / 32, col = p % 32;
+  // row f = 16 s + 8 (j >> 2) + 4 half + (j & 3)
+  const int s = f >> 4, w = f & 15, half = (w >> 2) & 1, j = (w & 3) + 4 * (w >> 3), lane = col + 32 * half;
+  const _Float16* blk = reinterpret_cast<const _Float16*>(tiles + (size_t)wtile * 128 * 64);
+  const size_t e = ((size_t)s * 64 + lane) * 8 + j;
+  rows[idx] = (float)blk[e] + (float)blk[e + 1024 * 8];
+}
+
 // wave-tile layout -> row-major (P, 256)
 __global__ void tiles_to_rows_kernel(const float* __restrict__ tiles, int P, float* __restrict__ rows) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over P*256
@@ -335,8 +348,13 @@ int svs_sdf_outputs(const float* points, int n_points, const float* cam, int cam
   return check_launch("svs_sdf_outputs");
 }
 
-int svs_tiles_to_rows(const float* tiles, int n_points, float* rows, void* hip_stream) {
+int svs_tiles_to_rows(const float* tiles, int n_points, int precision, float* rows, void* hip_stream) {
   if (!tiles || !rows || n_points <= 0) { set_error("svs_tiles_to_rows: bad argument"); return SVS_EINVAL; }
+  if (precision == kFmtF16x2) {
+    const size_t n2 = (size_t)n_points * 256;
+    pair_tiles_to_rows_kernel<<<(unsigned)((n2 + 255) / 256), 256, 0, (hipStream_t)hip_stream>>>(tiles, n_points, rows);
+    return check_launch("svs_tiles_to_rows");
+  }
   const size_t n = (size_t)n_points * 256;
   tiles_to_rows_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)hip_stream>>>(tiles, n_points, rows);
   return check_launch("svs_tiles_to_rows");

@@ -511,9 +511,11 @@ int svs_sdf_bwd_b(int n_points, const float* d_sdf, const unsigned char* clamp_m
   return check_launch("svs_sdf_bwd_b");
 }
 
-int svs_lin8_row0_grad(const float* hbuf, const float* ubuf, const float* sbar, int n_points, float* out257,
+int svs_lin8_row0_grad(const float* hbuf, const float* ubuf, const float* sbar, int n_points, int precision, float* out257,
                        void* hip_stream) {
   if (!hbuf || !sbar || !out257 || n_points <= 0) { set_error("svs_lin8_row0_grad: bad argument"); return SVS_EINVAL; }
+  if (precision == kFmtF16x2) return launch_lin8_row0_h2(hbuf, ubuf, sbar, n_points, tiles_of(n_points), out257, (hipStream_t)hip_stream);
+  if (precision != kFmtF32) { set_error("svs_lin8_row0_grad: unknown precision %d", precision); return SVS_EINVAL; }
   const int n_tiles = (n_points + 31) / 32;
   const int grid = n_tiles < 1024 ? n_tiles : 1024;
   lin8_row0_kernel<<<grid, 256, 0, (hipStream_t)hip_stream>>>(hbuf, ubuf, sbar, n_tiles, tiles_of(n_points), n_points, out257);

@@ -52,6 +52,8 @@ struct SdfBwdBArgs {
 int launch_bg_bwd_b_h2(const SdfBwdBArgs& a, hipStream_t s);   // background implicit network: no a2, bg splice rows
 
 int launch_rgb_bwd_h2(const RgbBwdArgs& a, hipStream_t s);
+int launch_lin8_row0_h2(const float* hbuf, const float* ubuf, const float* sbar, int n_points, int n_tiles_pad, float* out257,
+                        hipStream_t s);
 int launch_sdf_bwd_a_h2(const SdfBwdAArgs& a, hipStream_t s);
 int launch_sdf_bwd_b_h2(const SdfBwdBArgs& a, hipStream_t s);
 

@@ -7,8 +7,9 @@
 // largest element is ~2^4, and the accumulator is multiplied by 1/s in the epilogue (both exact).  The scale used
 // to split the operand a layer produces is derived from the maximum of the operand the layer consumed (the new
 // maximum is only known once all eight tiles are done), which leaves 2^11 of headroom for growth across one layer;
-// additive external inputs (a2 in pass B) enter through a per-point floor of the maximum.  All buffers written to
-// memory hold true (unscaled) float32 values.  The kernels also publish the global maxima of the gradient-like
+// additive external inputs (a2 in pass B) enter through a per-point floor of the maximum.  What the sweeps write to
+// memory are the hi pieces of these scaled operands (half blocks with their per-point scale, svs_blocks_h2.h); forward
+// activations are read back from pair blocks, by their hi plane where only softplus' is needed.  The kernels also publish the global maxima of the gradient-like
 // operands of the weight-gradient GEMMs (svs_wgrad.hip, fp16x2 path) with one atomic max per wave.
 #include "svs_mlp_h2_dev.h"
 #include "svs_mlp_host.h"
@@ -22,31 +23,33 @@ namespace mlp {
 // ==============================================================================================================
 // radiance MLP backward
 // ==============================================================================================================
-// zbar_{l-1} = rbar_l * [r_l > 0] for one tile: store (true units), track, split
+// zbar_{l-1} = rbar_l * [r_l > 0] for one tile: track, split; the hi pieces of the split (value * s_out) are what
+// zbuf stores (a HALF block, svs_blocks_h2.h)
 struct RgbBwdEpi {
-  f32x16 prev, r;
+  f32x16 prev;
+  TilePieces r;        // hi pieces of the stored r_l tile: only its sign is needed
   float v8[8];
-  LateStore ls;
   Pieces2* out;
   float* zblk;
   PointScale* ps;
   int lane;
   __device__ __forceinline__ void b(int tp, int rr) {
     float v = prev[rr] * ps->inv_in;
-    v = r[rr] > 0.0f ? v : 0.0f;
+    v = hi_at(r, rr) > 0.0f ? v : 0.0f;
     pin(v);
     ps->track(v);
-    ls.put(rr, v);
     v8[rr & 7] = v * ps->s_out;
     if ((rr & 7) == 7) {
       split8(v8, out->h[2 * tp + (rr >> 3)], out->m[2 * tp + (rr >> 3)]);
       pin(out->h[2 * tp + (rr >> 3)], out->m[2 * tp + (rr >> 3)]);
     }
+    // stores behind the LDS-DMA pieces: k-step 9 (the piece split at element 7) and 15
+    if (rr == 9) store_piece(zblk, 2 * tp, lane, out->h[2 * tp]);
+    if (rr == 15) store_piece(zblk, 2 * tp + 1, lane, out->h[2 * tp + 1]);
   }
   __device__ __forceinline__ void all(int tp) {
 #pragma unroll
     for (int rr = 0; rr < 16; ++rr) b(tp, rr);
-    ls.all(zblk, tp, lane);
   }
 };
 
@@ -55,26 +58,27 @@ __device__ __forceinline__ void rgb_bwd_layer_h2(Stream& st, const Pieces2& in, 
                                                  PointScale& ps, int lane) {
   RgbBwdEpi ep;
   ep.out = &out; ep.zblk = zblk; ep.ps = &ps; ep.lane = lane;
+  store_record(zblk, lane, ps.s_out, 0.0f);
   // Per tile: the next chunk's 9 LDS-DMA pieces behind k-steps 0..8 (Stream::prefetch_step), then -- younger than every
-  // piece, so that the barrier leaves them in flight (LateStore) -- the 4 zbuf stores of tile t-1's epilogue (k-steps
-  // 9, 11, 13, 15) and the 4 loads of r tile t+1 (k-steps 10, 12, 14, 15), which the epilogue of tile t+1 consumes
-  // during tile t+2.
-  f32x16 rnext = load_tile(rblk, 0, lane);
+  // piece, so that the barrier leaves them in flight -- the 2 zbuf stores of tile t-1's epilogue (k-steps 9, 15) and the
+  // 2 loads of r tile t+1 (k-steps 10, 12), which the epilogue of tile t+1 consumes during tile t+2.
+  TilePieces rnext;
+  load_tile_hi(rblk, 0, lane, rnext);
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
-    const f32x16 rcur = rnext;
+    const TilePieces rcur = rnext;
     auto rload = [&](int s) {
-      const int q = s == 10 ? 0 : s == 12 ? 1 : s == 14 ? 2 : s == 15 ? 3 : -1;
-      if (t < 7 && q >= 0) load_tile_quarter(rblk, t + 1, lane, q, rnext);
+      if (t == 7) return;
+      if (s == 10) rnext.h[0] = load_piece(rblk, 2 * (t + 1), lane);
+      if (s == 12) rnext.h[1] = load_piece(rblk, 2 * (t + 1) + 1, lane);
     };
     f32x16 acc;
     if (t == 0) acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, NoEpi(), NoEpi(), rload);
-    else acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, NoEpi(), [&](int s) { ep.b(t - 1, s); },
-                                            [&](int s) { ep.ls.step(s, ep.zblk, t - 1, lane); rload(s); });
+    else acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, NoEpi(), [&](int s) { ep.b(t - 1, s); }, rload);
     ep.prev = acc; ep.r = rcur;
-    if (t == 0) st.advance_keep<4>();
-    else if (t < 7) st.advance_keep<8>();
-    else st.advance_keep<4>();
+    if (t == 0) st.advance_keep<2>();
+    else if (t < 7) st.advance_keep<4>();
+    else st.advance_keep<2>();
   }
   ep.all(7);
   ps.next();
@@ -105,10 +109,10 @@ __global__ __launch_bounds__(kThreads, 1) void rgb_bwd_h2_kernel(RgbBwdArgs a) {
   m0 = __builtin_fmaxf(m0, __shfl_xor(m0, 32));
   PointScale ps;
   ps.start(m0, 0.0f);
-  {  // zbar_4: rows 0..2 live in registers 0..2 of half 0, tile 0
-    f32x16 z4 = (f32x16)(0.0f);
-    z4[0] = dz[0]; z4[1] = dz[1]; z4[2] = dz[2];
-    store_tile(zb + 4 * LS, 0, lane, z4);
+  {  // zbar_4: rows 0..2 = elements 0..2 of k-step 0 of half 0; the rest of the block stays zero (caller zeroes once)
+    float v8[8] = {dz[0], dz[1], dz[2], 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    store_piece(zb + 4 * LS, 0, lane, hi8(v8, ps.s_in));
+    store_record(zb + 4 * LS, lane, ps.s_in, m0);
   }
   st.advance();
   Pieces2 pa, pb;
@@ -118,18 +122,21 @@ __global__ __launch_bounds__(kThreads, 1) void rgb_bwd_h2_kernel(RgbBwdArgs a) {
     const f32x4* c = st.cur_buf();
     const float* r4 = rb + 3 * LS;
     float* z3 = zb + 3 * LS;
+    store_record(z3, lane, ps.s_out, 0.0f);
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      const f32x16 r = load_tile(r4, t, lane);
+      TilePieces r;
+      load_tile_hi(r4, t, lane, r);
       const f32x4 w = c[t * 64 + lane];
       f32x16 acc = (f32x16)(0.0f);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], dz[0], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1], dz[1], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2], dz[2], acc, 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { acc[i] = r[i] > 0.0f ? acc[i] : 0.0f; ps.track(acc[i]); }
-      store_tile(z3, t, lane, acc);
+      for (int i = 0; i < 16; ++i) { acc[i] = hi_at(r, i) > 0.0f ? acc[i] : 0.0f; ps.track(acc[i]); }
       split_tile_scaled(acc, t, pa, ps.s_out);
+      store_piece(z3, 2 * t, lane, pa.h[2 * t]);
+      store_piece(z3, 2 * t + 1, lane, pa.h[2 * t + 1]);
     }
   }
   ps.next();
@@ -138,17 +145,20 @@ __global__ __launch_bounds__(kThreads, 1) void rgb_bwd_h2_kernel(RgbBwdArgs a) {
   rgb_bwd_layer_h2(st, pa, pb, rb + 2 * LS, zb + 2 * LS, ps, lane);
   rgb_bwd_layer_h2(st, pb, pa, rb + 1 * LS, zb + 1 * LS, ps, lane);
   rgb_bwd_layer_h2(st, pa, pb, rb, zb, ps, lane);
-  // layer 0: the input gradients from zbar_0 (feature rows: tiles 0..7, extras: tile 8)
+  // layer 0: the input gradients from zbar_0 (feature rows: tiles 0..7, extras: tile 8).  fbar is stored as a HALF block
+  // under the scale predicted from zbar_0's maximum (ps.s_out, as between any two layers); its record -- pass B takes
+  // the scale and the maximum from it -- is written once the maximum is known
   float* fb = a.feat_bar + (size_t)wtile * kBlockF;
   float fmax = 0.0f;
+  const float s_f = ps.s_out;
   {
     f32x16 prev;
-    f32x4 q4;
+    float v8[8];
     auto slice = [&](int tp, int r) {
       const float v = prev[r] * ps.inv_in;
       fmax = __builtin_fmaxf(fmax, __builtin_fabsf(v));
-      q4[r & 3] = v;
-      if ((r & 3) == 3) SVS_STREAM_STORE(q4, reinterpret_cast<f32x4*>(fb) + (4 * tp + (r >> 2)) * 64 + lane);
+      v8[r & 7] = v;
+      if ((r & 7) == 7) store_piece(fb, 2 * tp + (r >> 3), lane, hi8(v8, s_f));
     };
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -164,6 +174,8 @@ __global__ __launch_bounds__(kThreads, 1) void rgb_bwd_h2_kernel(RgbBwdArgs a) {
       }
     }
   }
+  fmax = __builtin_fmaxf(fmax, __shfl_xor(fmax, 32));
+  store_record(fb, lane, s_f, fmax);
   publish_max(a.absmax + 1, ps.gmax);
   publish_max(a.absmax + 2, fmax);
 }
@@ -173,29 +185,39 @@ __global__ __launch_bounds__(kThreads, 1) void rgb_bwd_h2_kernel(RgbBwdArgs a) {
 // ==============================================================================================================
 constexpr int kSpliceF = 20;     // floats per lane kept in LDS for the skip splice of pass A (tile 7 + 4 registers of tile 6)
 
+// a2 is stored under the scale of the u it is produced with, lowered by 2^7: a2 / u = 100 g(h) (1 - s') elementwise, and
+// g(h) = d sdf / d h is O(0.1 ... 10) -- the 2^11 of headroom above the point's u maximum then cover |g| up to ~2600
+constexpr float kA2Down = 1.0f / 128.0f;
+
 template <bool SPLIT>
 struct PassAEpi {
-  f32x16 prev, h, g;
+  f32x16 prev;
+  TilePieces h, g;    // hi pieces of the stored h_{l+1} tile (softplus' only) and of ghat_l
   float v, s1;
-  float v8[8];
-  f32x4 qu, qa;
+  float v8[8], w8[8];
+  f16x8 a2p[2], up[2];
   Pieces2* out;       // u_{l+1} as the next operand (SPLIT)
-  float* ublk;        // u_{l+1} block
-  float* a2blk;
+  float* ublk;        // u_{l+1} block (HALF block: value * s_out)
+  float* a2blk;       // a2_l block (HALF block: value * s_out * kA2Down)
   PointScale* ps;
   const float* splice;  // LDS: this lane's u_0 splice values, [kSpliceF][kThreads]
   float a2m;          // running max |a2|
   int lane, half;
   bool l3;            // layer 3: the skip connection carries u_0 into rows >= 217 of u_4, a2 is zero there
 
+  __device__ __forceinline__ void begin() {      // the records of the two blocks this layer writes
+    store_record(ublk, lane, ps->s_out, 0.0f);
+    store_record(a2blk, lane, ps->s_out * kA2Down, 0.0f);
+  }
   __device__ __forceinline__ void a(int r) {
     v = prev[r] * ps->inv_in;
-    s1 = dsoftplus_from_h(h[r]);
+    s1 = dsoftplus_from_h(hi_at(h, r));
     pin(v); pin(s1);
   }
+  template <bool LATE = false>     // LATE: the stores wait for store_slot() (behind the tile's LDS-DMA pieces)
   __device__ __forceinline__ void b(int tp, int r) {
     float u = v * s1;
-    float a2 = v * g[r] * (100.0f * (1.0f - s1));     // g = ghat_l = g(h_{l+1}) s'(a_l); s'' = 100 s' (1 - s')
+    float a2 = v * hi_at(g, r) * (100.0f * (1.0f - s1));     // g = ghat_l = g(h_{l+1}) s'(a_l); s'' = 100 s' (1 - s')
     if (tp == 6 && r >= 12 && l3) {
       // local rows 25..31 of tile 6 (registers 13..15 of half 0, 12..15 of half 1) carry u_0[32..38]
       const bool sp = half == 1 || r >= 13;
@@ -204,22 +226,32 @@ struct PassAEpi {
       a2 = sp ? 0.0f : a2;
     }
     pin(u); pin(a2);
-    emit(tp, r, u, a2);
+    emit<LATE>(tp, r, u, a2);
   }
+  template <bool LATE = false>
   __device__ __forceinline__ void emit(int tp, int r, float u, float a2) {
     a2m = __builtin_fmaxf(a2m, __builtin_fabsf(a2));
     ps->track(u);
-    qa[r & 3] = a2;
-    if ((r & 3) == 3) SVS_STREAM_STORE(qa, reinterpret_cast<f32x4*>(a2blk) + (4 * tp + (r >> 2)) * 64 + lane);
-    qu[r & 3] = u;
-    if ((r & 3) == 3) SVS_STREAM_STORE(qu, reinterpret_cast<f32x4*>(ublk) + (4 * tp + (r >> 2)) * 64 + lane);
-    if (SPLIT) {
-      v8[r & 7] = u * ps->s_out;
-      if ((r & 7) == 7) {
-        split8(v8, out->h[2 * tp + (r >> 3)], out->m[2 * tp + (r >> 3)]);
-        pin(out->h[2 * tp + (r >> 3)], out->m[2 * tp + (r >> 3)]);
+    v8[r & 7] = u * ps->s_out;
+    w8[r & 7] = a2;
+    if ((r & 7) == 7) {
+      const int k = 2 * tp + (r >> 3);
+      if (SPLIT) {
+        split8(v8, out->h[k], out->m[k]);
+        pin(out->h[k], out->m[k]);
+        up[r >> 3] = out->h[k];
+      } else {
+        up[r >> 3] = hi8(v8, 1.0f);
       }
+      a2p[r >> 3] = hi8(w8, ps->s_out * kA2Down);
+      if (!LATE) { store_piece(ublk, k, lane, up[r >> 3]); store_piece(a2blk, k, lane, a2p[r >> 3]); }
     }
+  }
+  // k-step s of the tile whose MFMAs cover this epilogue: the four stores of tile tp behind the last LDS-DMA piece
+  __device__ __forceinline__ void store_slot(int tp, int s) {
+    if (s == 9) store_piece(ublk, 2 * tp, lane, up[0]);
+    if (s == 11) store_piece(a2blk, 2 * tp, lane, a2p[0]);
+    if (s == 15) { store_piece(ublk, 2 * tp + 1, lane, up[1]); store_piece(a2blk, 2 * tp + 1, lane, a2p[1]); }
   }
   __device__ __forceinline__ void all(int tp) {
 #pragma unroll
@@ -235,20 +267,23 @@ struct PassAEpi {
 template <bool SPLIT, bool LAST>
 __device__ __forceinline__ void pass_a_layer_h2(Stream& st, const Pieces2& in, PassAEpi<SPLIT>& ep, const float* hblk,
                                                 const float* gblk, int lane) {
-  // Per tile: the side tiles h, ghat of tile t are requested in front of it (their epilogue runs during tile t+1; a third
-  // register set for requesting them behind the pieces, as the other sweeps do, does not fit: 110 spills); the next
-  // chunk's LDS-DMA pieces go behind k-steps 0..8 (Stream::prefetch_step); the a2 / u stores of tile t-1's epilogue are
-  // issued in k-steps 3, 7, 11, 15 (two each): the last four are younger than every piece and stay in flight across the
-  // tile's barrier.
+  // Per tile: the side tiles h, ghat of tile t (two fragments each: their hi planes) are requested in front of it (their
+  // epilogue runs during tile t+1); the next chunk's LDS-DMA pieces go behind k-steps 0..8 (Stream::prefetch_step); the
+  // a2 / u stores of tile t-1's epilogue are issued in k-steps 9, 11, 15: younger than every piece, they stay in flight
+  // across the tile's barrier.
+  ep.begin();
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     if (t == 7 && ep.l3) break;
-    const f32x16 hload = load_tile(hblk, t, lane), gload = load_tile(gblk, t, lane);
+    TilePieces hload, gload;
+    load_tile_hi(hblk, t, lane, hload);
+    load_tile_hi(gblk, t, lane, gload);
     const bool fetch = !(LAST && t == 7);
     f32x16 acc;
     if (!fetch) acc = tile_mma_h2<16>(st.cur_buf(), in, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.b(t - 1, s); });
     else if (t == 0) acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, NoEpi(), NoEpi());
-    else acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.b(t - 1, s); });
+    else acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, [&](int s) { ep.a(s); },
+                                            [&](int s) { ep.template b<true>(t - 1, s); ep.store_slot(t - 1, s); });
     ep.prev = acc; ep.h = hload; ep.g = gload;
     if (fetch) {
       if (t == 0) st.advance();
@@ -301,23 +336,6 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_h2_kernel(SdfBwdAArgs a
       m0 = __builtin_fmaxf(m0, __builtin_fabsf(u0.v[q]));
     }
     ps.start(m0, 0.0f);
-    // u_0 / PE in PE order as 2-tile accumulator-layout blocks (rows q = 32*tile + rho(r) + 4*half)
-    auto store_pe_block = [&](float* block, const float* vec40) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        f32x16 v;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int q0 = 32 * t + rho(r), q1 = q0 + 4;
-          const float a0 = q0 < kPeDim ? vec40[q0 < 40 ? q0 : 39] : 0.0f;
-          const float a1 = q1 < kPeDim ? vec40[q1 < 40 ? q1 : 39] : 0.0f;
-          v[r] = half ? a1 : a0;
-        }
-        store_tile(block, t, lane, v);
-      }
-    };
-    store_pe_block(ub, u0.v);
-    store_pe_block(a.pebuf + (size_t)wtile * kBlockF, pe.v);
     // the skip splice of layer 3, parked in LDS: [0..15] tile 7 = u_0[rho(r) (+4)], [16..19] registers 12..15 of
     // tile 6 = u_0[32 + rho(r) (+4) - 25]
 #pragma unroll
@@ -332,6 +350,19 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_h2_kernel(SdfBwdAArgs a
 #pragma unroll
     for (int q = 0; q < 40; ++q) us.v[q] = u0.v[q] * ps.s_in;
     split_pe(us, half, pa);
+    // u_0 (HALF block, scale s_in) and h_0 = PE (PAIR block) in PE order, as block fragments: k-steps 0..2 hold the 39
+    // rows, the rest of both blocks stays zero (the caller zeroes them once): the B operands of the two products of dW_0
+    float* pbk = a.pebuf + (size_t)wtile * kBlockF;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      f16x8 fh, fm;
+      block_fragment<kPeDim>(u0.v, k, half, ps.s_in, fh, fm);
+      store_piece(ub, k, lane, fh);
+      block_fragment<kPeDim>(pe.v, k, half, 1.0f, fh, fm);
+      store_piece(pbk, k, lane, fh, 0);
+      store_piece(pbk, k, lane, fm, 1);
+    }
+    store_record(ub, lane, ps.s_in, m0);
   }
   st.advance();
 
@@ -341,9 +372,12 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_h2_kernel(SdfBwdAArgs a
     PassAEpi<true> ep;
     ep.out = &pb; ep.ublk = ub + LS; ep.a2blk = a2; ep.ps = &ps; ep.splice = splice; ep.a2m = 0.0f;
     ep.lane = lane; ep.half = half; ep.l3 = false;
+    ep.begin();
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      const f32x16 hload = load_tile(hb, t, lane), gload = load_tile(gb, t, lane);
+      TilePieces hload, gload;
+      load_tile_hi(hb, t, lane, hload);
+      load_tile_hi(gb, t, lane, gload);
       if (t < 7) st.prefetch<kChunk0F4>(); else st.prefetch<kChunkF4>();
       const f32x16 acc = tile_mma_h2<3>(st.cur_buf(), pa, lane);
       if (t > 0) ep.all(t - 1);
@@ -383,25 +417,27 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_h2_kernel(SdfBwdAArgs a
 // ==============================================================================================================
 template <bool FIRST, bool SPLIT, typename Net = NetFg, bool A2 = true>
 struct PassBEpi {
-  f32x16 prev, h, a2, w0;
+  f32x16 prev;
+  TilePieces h, a2, w0;    // hi pieces: h_{l+1} (softplus' only), a2_l (value * a2_scale), ghat_7
   float v, s1;
   float v8[8];
-  LateStore ls;
+  f16x8 ap[2];
   Pieces2* out;
-  float* ablk;
+  float* ablk;             // abar_l block (HALF block: value * s_out)
   PointScale* ps;
-  float sbar;
+  float sbar, a2_inv;      // a2_inv: 1 / (scale the a2 block was stored under)
   int lane, half;
   bool l4;            // producing abar_3: rows >= 217 of h_4 are the PE splice
   __device__ __forceinline__ void a(int r) {
     v = prev[r] * ps->inv_in;
-    s1 = dsoftplus_from_h(h[r]);
+    s1 = dsoftplus_from_h(hi_at(h, r));
     pin(v); pin(s1);
   }
+  template <bool LATE = false>
   __device__ __forceinline__ void b(int tp, int r) {
     float o = v * s1;
-    if (A2) o += a2[r];
-    if (FIRST) o += sbar * w0[r];      // w0 = ghat_7 = W8[0,:] s'(a_7)
+    if (A2) o += hi_at(a2, r) * a2_inv;
+    if (FIRST) o += sbar * hi_at(w0, r);      // w0 = ghat_7 = W8[0,:] s'(a_7)
     if (l4 && tp > Net::kSpliceTile) o = 0.0f;
     if (l4 && tp == Net::kSpliceTile) {
       const bool z0 = rho(r) >= Net::kSpliceLocal, z1 = rho(r) + 4 >= Net::kSpliceLocal;
@@ -409,19 +445,26 @@ struct PassBEpi {
     }
     pin(o);
     ps->track(o);
-    ls.put(r, o);
-    if (SPLIT) {
-      v8[r & 7] = o * ps->s_out;
-      if ((r & 7) == 7) {
-        split8(v8, out->h[2 * tp + (r >> 3)], out->m[2 * tp + (r >> 3)]);
-        pin(out->h[2 * tp + (r >> 3)], out->m[2 * tp + (r >> 3)]);
+    v8[r & 7] = o * ps->s_out;
+    if ((r & 7) == 7) {
+      const int k = 2 * tp + (r >> 3);
+      if (SPLIT) {
+        split8(v8, out->h[k], out->m[k]);
+        pin(out->h[k], out->m[k]);
+        ap[r >> 3] = out->h[k];
+      } else {
+        ap[r >> 3] = hi8(v8, 1.0f);
       }
+      if (!LATE) store_piece(ablk, k, lane, ap[r >> 3]);
     }
+  }
+  __device__ __forceinline__ void store_slot(int tp, int s) {     // behind the tile's LDS-DMA pieces
+    if (s == 9) store_piece(ablk, 2 * tp, lane, ap[0]);
+    if (s == 15) store_piece(ablk, 2 * tp + 1, lane, ap[1]);
   }
   __device__ __forceinline__ void all(int tp) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { a(r); b(tp, r); }
-    ls.all(ablk, tp, lane);
   }
 };
 
@@ -430,38 +473,41 @@ template <bool FIRST, bool SPLIT, bool LAST_STAGE, typename Net = NetFg, bool A2
 __device__ __forceinline__ void pass_b_stage_h2(Stream& st, const Pieces2& in, PassBEpi<FIRST, SPLIT, Net, A2>& ep, const float* hblk,
                                                 const float* a2blk, const float* w0blk, int lane) {
   // Per tile: the next chunk's LDS-DMA pieces behind k-steps 0..8 (Stream::prefetch_step), then -- younger than every
-  // piece, left in flight across the tile's barrier (LateStore) -- the 4 abuf stores of tile t-1's epilogue (k-steps 9,
-  // 11, 13, 15) and the loads of the side tiles h, a2 (FIRST: and ghat_7) of tile t+1, which the epilogue of tile t+1
-  // consumes during tile t+2.
-  f32x16 hnext = load_tile(hblk, 0, lane), anext, wnext;
-  if (A2) anext = load_tile(a2blk, 0, lane);
-  if (FIRST) wnext = load_tile(w0blk, 0, lane);
-  constexpr int kLoads = 4 + (A2 ? 4 : 0) + (FIRST ? 4 : 0);
+  // piece, left in flight across the tile's barrier -- the 2 abuf stores of tile t-1's epilogue (k-steps 9, 15) and the
+  // loads of the side tiles (hi planes: two fragments each) h, a2 (FIRST: and ghat_7) of tile t+1, which the epilogue of
+  // tile t+1 consumes during tile t+2.
+  store_record(ep.ablk, lane, ep.ps->s_out, 0.0f);
+  ep.a2_inv = A2 ? PointScale::inv_pow2(load_scale(a2blk, lane)) : 0.0f;
+  TilePieces hnext, anext, wnext;
+  load_tile_hi(hblk, 0, lane, hnext);
+  if (A2) load_tile_hi(a2blk, 0, lane, anext);
+  if (FIRST) load_tile_hi(w0blk, 0, lane, wnext);
+  constexpr int kLoads = 2 + (A2 ? 2 : 0) + (FIRST ? 2 : 0);
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
-    const f32x16 hcur = hnext, acur = anext, wcur = wnext;
+    const TilePieces hcur = hnext, acur = anext, wcur = wnext;
     auto side = [&](int s) {
       if (t == 7) return;
-      const int qh = s == 9 ? 0 : s == 11 ? 1 : s == 13 ? 2 : s == 15 ? 3 : -1;   // beside the stores
-      const int qa = s == 10 ? 0 : s == 12 ? 1 : s == 14 ? 2 : s == 15 ? 3 : -1;
-      if (qh >= 0) load_tile_quarter(hblk, t + 1, lane, qh, hnext);
-      if (A2 && qa >= 0) load_tile_quarter(a2blk, t + 1, lane, qa, anext);
-      if (FIRST && qa >= 0) load_tile_quarter(w0blk, t + 1, lane, qa, wnext);
+      if (s == 10) hnext.h[0] = load_piece(hblk, 2 * (t + 1), lane);
+      if (s == 11) hnext.h[1] = load_piece(hblk, 2 * (t + 1) + 1, lane);
+      if (A2 && s == 12) anext.h[0] = load_piece(a2blk, 2 * (t + 1), lane);
+      if (A2 && s == 13) anext.h[1] = load_piece(a2blk, 2 * (t + 1) + 1, lane);
+      if (FIRST && s == 14) wnext.h[0] = load_piece(w0blk, 2 * (t + 1), lane);
+      if (FIRST && s == 15) wnext.h[1] = load_piece(w0blk, 2 * (t + 1) + 1, lane);
     };
     const bool fetch = !(LAST_STAGE && t == 7);
     f32x16 acc;
-    if (!fetch) acc = tile_mma_h2<16>(st.cur_buf(), in, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.b(t - 1, s); }, 0,
-                                       [&](int s) { ep.ls.step(s, ep.ablk, t - 1, lane); });
+    if (!fetch) acc = tile_mma_h2<16>(st.cur_buf(), in, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.b(t - 1, s); });
     else if (t == 0) acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, NoEpi(), NoEpi(), side);
-    else acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.b(t - 1, s); },
-                                            [&](int s) { ep.ls.step(s, ep.ablk, t - 1, lane); side(s); });
+    else acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, [&](int s) { ep.a(s); },
+                                            [&](int s) { ep.template b<true>(t - 1, s); ep.store_slot(t - 1, s); }, side);
     ep.prev = acc; ep.h = hcur;
     if (A2) ep.a2 = acur;
     if (FIRST) ep.w0 = wcur;
     if (fetch) {
       if (t == 0) st.advance_keep<kLoads>();
-      else if (t < 7) st.advance_keep<kLoads + 4>();
-      else st.advance_keep<4>();
+      else if (t < 7) st.advance_keep<kLoads + 2>();
+      else st.advance_keep<2>();
     }
   }
   ep.all(7);
@@ -490,26 +536,24 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_h2_kernel(SdfBwdBArgs a
   PointScale ps;
   Pieces2 pa, pb;
   {
-    // fbar (true units) -> first operand; the scale floor covers the additive inputs a2 and sbar * W8[0,:]
-    f32x16 f[8];
-    float m0 = 0.0f;
+    // fbar (a HALF block under its recorded scale) is the first operand as it stands; the scale floor covers the additive
+    // inputs a2 and sbar * W8[0,:]
+    const float fl = __builtin_fmaxf(A2 ? a.a2max[p] : 0.0f, __builtin_fabsf(sbar));
     if (has_f) {
-      load_tile_regs(a.feat_bar + (size_t)wtile * kBlockF, f, lane);
+      const float* fb = a.feat_bar + (size_t)wtile * kBlockF;
 #pragma unroll
-      for (int i = 0; i < 128; ++i) m0 = __builtin_fmaxf(m0, __builtin_fabsf(f[i / 16][i % 16]));
-      m0 = __builtin_fmaxf(m0, __shfl_xor(m0, 32));
+      for (int k = 0; k < 16; ++k) { pa.h[k] = load_piece(fb, k, lane); pa.m[k] = (f16x8)(_Float16)0.0f; }
+      ps.start_stored(load_scale(fb, lane), load_max(fb, lane), fl);
     } else {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) f[t] = (f32x16)(0.0f);
+      for (int k = 0; k < 16; ++k) { pa.h[k] = (f16x8)(_Float16)0.0f; pa.m[k] = (f16x8)(_Float16)0.0f; }
+      ps.start(0.0f, fl);
     }
-    ps.start(m0, __builtin_fmaxf(A2 ? a.a2max[p] : 0.0f, __builtin_fabsf(sbar)));
     ps.gmax = 0.0f;      // fbar is not an operand of the SDF weight-gradient GEMMs (rgb_bwd publishes its maximum)
-#pragma unroll
-    for (int t = 0; t < 8; ++t) split_tile_scaled(f[t], t, pa, ps.s_in);
   }
   st.advance();
   {
-    // hbar_8 fused with abar_7 (gbuf block 7 = ghat_7 = W8[0,:] s'(a_7) in accumulator layout)
+    // hbar_8 fused with abar_7 (gbuf block 7 = ghat_7 = W8[0,:] s'(a_7), a half block)
     PassBEpi<true, true, Net, A2> ep;
     ep.out = &pb; ep.ablk = ab + 7 * LS; ep.ps = &ps; ep.sbar = sbar; ep.lane = lane; ep.half = half; ep.l4 = false;
     pass_b_stage_h2<true, true, false, Net, A2>(st, pa, ep, hb + 7 * LS, A2 ? a2 + 7 * LS : nullptr, w0, lane);
@@ -529,6 +573,68 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_h2_kernel(SdfBwdBArgs a
     pass_b_stage_h2<false, false, true, Net, A2>(st, pb, ep, hb, a2, nullptr, lane);
   }
   publish_max(a.absmax, ps.gmax);
+}
+
+// d loss / d W_8[0,:] = sum_p (sbar_p h_8[:,p] + u_8[:,p]);  d loss / d b_8[0] = sum_p sbar_p  (svs_mlp_bwd.hip) on the fp16x2
+// block forms: h_8 = pair block 7 of hbuf, u_8 = half block 8 of ubuf with its per-point scale.  Wave w of a workgroup
+// owns k-steps 4w..4w+3 (64 of the 256 rows), grid-strides over the tiles with the 12 loads of a tile in flight; the sum
+// over the 32 points of a lane half goes through LDS once per workgroup, then float atomics into out[257].
+__global__ __launch_bounds__(256) void lin8_row0_h2_kernel(const float* __restrict__ hbuf, const float* __restrict__ ubuf,
+                                                           const float* __restrict__ sbar, int n_tiles, int n_tiles_pad, int P,
+                                                           float* __restrict__ out) {
+  __shared__ float red[4][32][65];
+  const int lane = threadIdx.x & 63, quarter = threadIdx.x >> 6;
+  float acc[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) acc[i] = 0.0f;
+  float bsum = 0.0f;
+  for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const int p = t * 32 + (lane & 31);
+    const float sb = p < P ? sbar[p] : 0.0f;
+    const float* h = hbuf + ((size_t)7 * n_tiles_pad + t) * kBlockF;
+    f16x8 hh[4], hm[4], uh[4];
+    float us = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { hh[k] = load_piece(h, 4 * quarter + k, lane, 0); hm[k] = load_piece(h, 4 * quarter + k, lane, 1); }
+    if (ubuf) {
+      const float* u = ubuf + ((size_t)8 * n_tiles_pad + t) * kBlockF;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) uh[k] = load_piece(u, 4 * quarter + k, lane);
+      us = p < P ? PointScale::inv_pow2(load_scale(u, lane)) : 0.0f;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) uh[k] = (f16x8)(_Float16)0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[8 * k + j] += sb * ((float)hh[k][j] + (float)hm[k][j]) + us * (float)uh[k][j];
+    if (quarter == 0 && lane < 32) bsum += sb;
+  }
+#pragma unroll
+  for (int i = 0; i < 32; ++i) red[quarter][i][lane] = acc[i];
+  __syncthreads();
+  // thread -> (quarter, element i = 8 k + j, half): sum its 32 points; row = 16 (4 q + k) + 8 (j >> 2) + 4 half + (j & 3)
+  {
+    const int q = threadIdx.x >> 6, i = (threadIdx.x >> 1) & 31, hf = threadIdx.x & 1;
+    float v = 0.0f;
+#pragma unroll 8
+    for (int c = 0; c < 32; ++c) v += red[q][i][32 * hf + c];
+    const int k = i >> 3, j = i & 7;
+    atomicAdd(&out[16 * (4 * q + k) + 8 * (j >> 2) + 4 * hf + (j & 3)], v);
+  }
+  if (quarter == 0) {
+    for (int d = 16; d >= 1; d >>= 1) bsum += __shfl_xor(bsum, d);
+    if (lane == 0) atomicAdd(&out[256], bsum);
+  }
+}
+
+int launch_lin8_row0_h2(const float* hbuf, const float* ubuf, const float* sbar, int n_points, int n_tiles_pad, float* out257,
+                        hipStream_t s) {
+  const int n_tiles = (n_points + 31) / 32;
+  const int grid = n_tiles < 1024 ? n_tiles : 1024;
+  lin8_row0_h2_kernel<<<grid, 256, 0, s>>>(hbuf, ubuf, sbar, n_tiles, n_tiles_pad, n_points, out257);
+  return check_launch("svs_lin8_row0_grad");
 }
 
 int launch_rgb_bwd_h2(const RgbBwdArgs& a, hipStream_t s) {

@@ -2,6 +2,7 @@
 // header of svs_mlp_bwd_h2.hip.
 #pragma once
 #include "svs_mlp_h2_dev.h"
+#include "svs_blocks_h2.h"
 
 namespace svs {
 namespace mlp {
@@ -25,6 +26,12 @@ struct PointScale {
     floor_m = fl; gmax = m0;
     s_in = pow2_for(__builtin_fmaxf(m0, fl)); inv_in = inv_pow2(s_in);
     s_out = s_in; m = 0.0f;
+  }
+  // the first operand comes from a stored half block (svs_blocks_h2.h): its scale is the stored one; m0 its maximum
+  __device__ __forceinline__ void start_stored(float s_stored, float m0, float fl) {
+    floor_m = fl; gmax = m0;
+    s_in = s_stored; inv_in = inv_pow2(s_in);
+    s_out = pow2_for(__builtin_fmaxf(m0, fl)); m = 0.0f;
   }
   __device__ __forceinline__ void track(float v) { m = __builtin_fmaxf(m, __builtin_fabsf(v)); }
   // the operand just produced becomes the one consumed

@@ -8,6 +8,7 @@
 #include "svs_mlp_host.h"
 #include "svs_mlp_args.h"
 #include "svs_mlp_h2_trunk.h"
+#include "svs_blocks_h2.h"
 
 namespace svs {
 namespace mlp {
@@ -70,18 +71,18 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_only_h2_kernel(SdfOnlyArgs a)
 // Epilogue of one tile of the gradient pass: ghat_{l-1} = g(a_{l-1}) = g(h_l) * softplus'(a_{l-1}) (softplus' from the
 // stored h_l tile `h`) -> gbuf (training), split into the next operand.
 struct RevEpi {
-  f32x16 prev, h;
+  f32x16 prev;
+  TilePieces h;       // the stored h_l tile (pair block)
   float d;            // softplus' of the current slice
   float v8[8];
-  LateStore ls;
   Pieces2* out;
-  float* gblk;        // ghat_{l-1} block of gbuf or nullptr
+  float* gblk;        // ghat_{l-1} block of gbuf (a HALF block, stored unscaled: record scale 1) or nullptr
   int lane, half;
   bool l4;            // l == 4: rows >= 217 of h_4 are the PE splice, they do not flow into lin3
 
-  // three slices, one per MFMA gap of a k-step: exp2 | 1 - e and the product | masks, store, split
+  // three slices, one per MFMA gap of a k-step: exp2 | 1 - e and the product | masks, split
   __device__ __forceinline__ void a(int r) {
-    d = __builtin_amdgcn_exp2f(h[r] * (-100.0f * 1.44269504088896341f));
+    d = __builtin_amdgcn_exp2f(pair_at(h, r) * (-100.0f * 1.44269504088896341f));
     pin(d);
   }
   __device__ __forceinline__ void a2(int r) {
@@ -97,23 +98,30 @@ struct RevEpi {
       if (z0 || z1) { if (half ? z1 : z0) v = 0.0f; }
     }
     pin(v);
-    ls.put(r, v);
     v8[r & 7] = v;
     if ((r & 7) == 7 && !(DEFER && r == 15)) {
-      split8(v8, out->h[2 * tp + (r >> 3)], out->m[2 * tp + (r >> 3)]);
-      pin(out->h[2 * tp + (r >> 3)], out->m[2 * tp + (r >> 3)]);
+      const int k = 2 * tp + (r >> 3);
+      split8(v8, out->h[k], out->m[k]);
+      pin(out->h[k], out->m[k]);
+      if (gblk && !DEFER) store_piece(gblk, k, lane, out->h[k]);
     }
   }
+  template <bool STORE = false>
   __device__ __forceinline__ void finish(int tp) {
-    split8(v8, out->h[2 * tp + 1], out->m[2 * tp + 1]);
-    pin(out->h[2 * tp + 1], out->m[2 * tp + 1]);
+    const int k = 2 * tp + 1;
+    split8(v8, out->h[k], out->m[k]);
+    pin(out->h[k], out->m[k]);
+    if (gblk && STORE) store_piece(gblk, k, lane, out->h[k]);
   }
-  // the gbuf stores of tile tp: sliced (behind k-step s, see LateStore) or all four at once
-  __device__ __forceinline__ void st(int tp, int s) { if (gblk) ls.step(s, gblk, tp, lane); }
+  // the gbuf stores issued during tile t (see TrunkEpi::late_store): the hi pieces of k-steps 2(t-1) and 2(t-2)+1
+  __device__ __forceinline__ void st(int t, int s) {
+    if (!gblk) return;
+    if (s == 9) store_piece(gblk, 2 * (t - 1), lane, out->h[2 * (t - 1)]);
+    if (t >= 2 && s == 11) store_piece(gblk, 2 * (t - 2) + 1, lane, out->h[2 * (t - 2) + 1]);
+  }
   __device__ __forceinline__ void all(int tp) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { a(r); a2(r); b(tp, r); }
-    if (gblk) ls.all(gblk, tp, lane);
   }
 };
 
@@ -125,35 +133,41 @@ __device__ __forceinline__ void reverse_layer_h2(Stream& st, const Pieces2& in, 
   const size_t LS = block_stride();
   ep.gblk = gb ? gb + (size_t)(l - 1) * LS : nullptr;
   const float* hblk = hb + (size_t)(l - 1) * LS;
-  // h tile t + 1 is requested during tile t behind k-steps 10, 12, 14, 15 -- after the last LDS-DMA piece (k-step 8), like
-  // the gbuf stores (LateStore): in flight across the tile's barrier, complete one tile later, consumed by the epilogue of
-  // tile t + 1 during tile t + 2.  (Requested in front of the tile's pieces, the barrier's vmcnt wait had to sit out
-  // their HBM latency: 700 cycles per tile.)
-  f32x16 hnext = load_tile(hblk, 0, lane);
+  // h tile t + 1 (a pair: 4 fragments) is requested during tile t behind k-steps 10, 12, 14, 15 -- after the last LDS-DMA
+  // piece (k-step 8), like the gbuf stores: in flight across the tile's barrier, complete one tile later, consumed by the
+  // epilogue of tile t + 1 during tile t + 2.  (Requested in front of the tile's pieces, the barrier's vmcnt wait had to
+  // sit out their HBM latency: 700 cycles per tile.)
+  TilePieces hnext;
+  load_tile_pair(hblk, 0, lane, hnext);
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
-    const f32x16 hcur = hnext;
+    const TilePieces hcur = hnext;
     auto hload = [&](int s) {
-      const int q = s == 10 ? 0 : s == 12 ? 1 : s == 14 ? 2 : s == 15 ? 3 : -1;
-      if (t < 7 && q >= 0) load_tile_quarter(hblk, t + 1, lane, q, hnext);
+      if (t == 7) return;
+      if (s == 10) hnext.h[0] = load_piece(hblk, 2 * (t + 1), lane, 0);
+      if (s == 12) hnext.h[1] = load_piece(hblk, 2 * (t + 1) + 1, lane, 0);
+      if (s == 14) hnext.m[0] = load_piece(hblk, 2 * (t + 1), lane, 1);
+      if (s == 15) hnext.m[1] = load_piece(hblk, 2 * (t + 1) + 1, lane, 1);
     };
     // the next reverse chunk (the last one: REV0 tile 0) is fetched in pieces behind k-steps 0..8
     f32x16 acc;
     if (t == 0) acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, NoEpi(), NoEpi(), hload);
     else acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.a2(s); },
-                                            [&](int s) { ep.template b<true>(t - 1, s); ep.st(t - 1, s); hload(s); },
+                                            [&](int s) { ep.template b<true>(t - 1, s); ep.st(t, s); hload(s); },
                                             [&]() { if (t >= 2) ep.finish(t - 2); });
     if (l == 4 && t == 7) skip7 = acc;
     if (l == 4 && t == 6) skip6 = acc;
     ep.prev = acc;
     ep.h = hcur;
-    // in flight across the barrier: the 4 h loads (t < 7) and the 4 gbuf stores (training, t > 0) of this tile
-    const bool stores = gb && t > 0;
-    if (t == 0) st.advance_keep<4>();
-    else if (t < 7) { if (stores) st.advance_keep<8>(); else st.advance_keep<4>(); }
-    else { if (stores) st.advance_keep<4>(); else st.advance(); }
+    // in flight across the barrier: the 4 h loads (t < 7) and the gbuf stores (training: 1 in tile 1, then 2) of this tile
+    const int stores = !gb || t == 0 ? 0 : (t == 1 ? 1 : 2);
+    if (t < 7) {
+      if (stores == 0) st.advance_keep<4>(); else if (stores == 1) st.advance_keep<5>(); else st.advance_keep<6>();
+    } else {
+      if (stores == 0) st.advance(); else st.advance_keep<2>();
+    }
   }
-  ep.finish(6);
+  ep.template finish<true>(6);
   ep.all(7);
 }
 
@@ -193,8 +207,8 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_h2_kernel(SdfFullArgs a)
     // ---- head: current chunk = VEC (W8 row 0 in C-layout order as float32, b8[0])
     st.prefetch<kChunkF4>();                       // FEAT tile 0
     sdf = sdf_head(st.cur_buf(), y8, lane);
-    // x = h_8 (input of the feature head), xn = g(a_7) = W8[0,:] * softplus'(a_7): the VEC chunk's buffer is
-    // overwritten two prefetches from now, so its weights are consumed here
+    // x = h_8 (input of the feature head, split by the trunk), xn = g(a_7) = W8[0,:] * softplus'(a_7): the VEC chunk's
+    // buffer is overwritten two prefetches from now, so its weights are consumed here
     const f32x4* w_ptr = st.cur_buf() + kHdrF4 + lane;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -205,34 +219,43 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_h2_kernel(SdfFullArgs a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) g[4 * q + j] = w[j] * dsoftplus_from_h(y8[t][4 * q + j]);
       }
-      if (gb) store_tile(gb + 7 * block_stride(), t, lane, g);   // ghat_7 = W8[0,:] * softplus'(a_7)
+      // ghat_7 = W8[0,:] * softplus'(a_7): a half block (unscaled).  (x already holds the pieces of h_8: the trunk's
+      // last layer split and stored them.)
       split_tile(g, t, xn);
-      split_tile(y8[t], t, x);
+      if (gb) {
+        store_piece(gb + 7 * block_stride(), 2 * t, lane, xn.h[2 * t]);
+        store_piece(gb + 7 * block_stride(), 2 * t + 1, lane, xn.h[2 * t + 1]);
+      }
     }
     st.advance();
   }
   SVS_STAMP(3, sdf)
-  // ---- feature vector = rows 1..256 of lin8 (no activation); tile t-1 is stored while tile t's MFMAs run
+  // ---- feature vector = rows 1..256 of lin8 (no activation), stored as a PAIR block (the radiance network's operand
+  // and the B operand of its first weight gradient); tile t-1 is split and stored while tile t's MFMAs run
   float* ft = a.feat_tiles ? a.feat_tiles + (size_t)wtile * kBlockF : nullptr;
   {
     f32x16 prev;
-    LateStore ls;
-    auto store_slice = [&](int tp, int r) {       // see LateStore
-      ls.put(r, prev[r]);
-      if (ft) ls.step(r, ft, tp, lane);
+    float v8[8];
+    f16x8 fh[2], fm[2];
+    auto slice = [&](int tp, int r) {             // stores behind the LDS-DMA pieces (k-steps 9, 11, 15, 15)
+      v8[r & 7] = prev[r];
+      if ((r & 7) == 7) { split8(v8, fh[r >> 3], fm[r >> 3]); pin(fh[r >> 3], fm[r >> 3]); }
+      if (!ft) return;
+      if (r == 9) store_piece(ft, 2 * tp, lane, fh[0], 0);
+      if (r == 11) store_piece(ft, 2 * tp, lane, fm[0], 1);
+      if (r == 15) { store_piece(ft, 2 * tp + 1, lane, fh[1], 0); store_piece(ft, 2 * tp + 1, lane, fm[1], 1); }
     };
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       f32x16 acc;                                   // prefetching FEAT t+1, or reverse L7 tile 0
       if (t == 0) acc = tile_mma_h2_pf<16, kChunkF4>(st, x, lane, NoEpi(), NoEpi());
-      else acc = tile_mma_h2_pf<16, kChunkF4>(st, x, lane, NoEpi(), [&](int s) { store_slice(t - 1, s); });
+      else acc = tile_mma_h2_pf<16, kChunkF4>(st, x, lane, NoEpi(), [&](int s) { slice(t - 1, s); });
       prev = acc;
       if (ft && t > 0) st.advance_keep<4>();
       else st.advance();
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ls.put(r, prev[r]);
-    if (ft) ls.all(ft, 7, lane);
+    for (int r = 0; r < 16; ++r) slice(7, r);
   }
   SVS_STAMP(4, sdf)
   // ---- reverse layers 7..1, operands ping-pong between xn and x
@@ -310,22 +333,23 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_h2_kernel(SdfFullArgs a)
 struct RgbEpi {
   f32x16 prev;
   float v8[8];
-  f32x4 q4;
   Pieces2* out;
-  float* rblk;       // this layer's block of rbuf or nullptr
+  float* rblk;       // this layer's block of rbuf (a PAIR block: r_l is the next weight gradient's B operand) or nullptr
   int lane;
   __device__ __forceinline__ void b(int tp, int r) {
     float v;
     asm("v_max_f32 %0, 0, %1" : "=v"(v) : "v"(prev[r]));   // ReLU without the canonicalising v_max of fmaxf (IEEE mode)
     pin(v);
-    if (rblk) {
-      q4[r & 3] = v;
-      if ((r & 3) == 3) SVS_STREAM_STORE(q4, reinterpret_cast<f32x4*>(rblk) + (4 * tp + (r >> 2)) * 64 + lane);
-    }
     v8[r & 7] = v;
     if ((r & 7) == 7) {
       split8(v8, out->h[2 * tp + (r >> 3)], out->m[2 * tp + (r >> 3)]);
       pin(out->h[2 * tp + (r >> 3)], out->m[2 * tp + (r >> 3)]);
+    }
+    // the four stores of the tile behind the LDS-DMA pieces (k-steps 0..9): k-steps 11, 13, 15, 15
+    if (rblk) {
+      if (r == 11) store_piece(rblk, 2 * tp, lane, out->h[2 * tp], 0);
+      if (r == 13) store_piece(rblk, 2 * tp, lane, out->m[2 * tp], 1);
+      if (r == 15) { store_piece(rblk, 2 * tp + 1, lane, out->h[2 * tp + 1], 0); store_piece(rblk, 2 * tp + 1, lane, out->m[2 * tp + 1], 1); }
     }
   }
   __device__ __forceinline__ void all(int tp) {
@@ -336,7 +360,7 @@ struct RgbEpi {
 
 // One radiance layer.  The next chunk (N16NEXT_LAST float4 behind the layer's last tile) is fetched in pieces behind the
 // first k-steps of each tile (Stream::prefetch_step: 9 or 10 pieces, k-steps 0..9); the rbuf stores of tile t-1's
-// epilogue are issued in k-steps 3, 7, 11, 15: the last two are younger than every piece and may stay in flight.
+// epilogue are issued in k-steps 11, 13, 15: younger than every piece, they may stay in flight.
 template <int KS, int N16NEXT_LAST>
 __device__ __forceinline__ void rgb_layer_h2(RgbStream& st, const Pieces2& in, Pieces2& out, float* rblk, int lane) {
   RgbEpi ep;
@@ -350,7 +374,7 @@ __device__ __forceinline__ void rgb_layer_h2(RgbStream& st, const Pieces2& in, P
     else if (t < 7) acc = tile_mma_h2_pf<KS, kNext>(st, in, lane, NoEpi(), relu);
     else acc = tile_mma_h2_pf<KS, N16NEXT_LAST>(st, in, lane, NoEpi(), relu);
     ep.prev = acc;
-    if (rblk && t > 0) st.template advance_keep<2>();
+    if (rblk && t > 0) st.template advance_keep<4>();
     else st.advance();
   }
   ep.all(7);
@@ -382,9 +406,9 @@ __global__ __launch_bounds__(kThreads, 1) void rgb_h2_kernel(RgbArgs a) {
   Pieces2 x, xn;
   split8(eb, x.h[16], x.m[16]);
   {
-    const float* ft = a.feat_tiles + (size_t)wtile * kBlockF;
+    const float* ft = a.feat_tiles + (size_t)wtile * kBlockF;   // a pair block: the operand as it is
 #pragma unroll
-    for (int t = 0; t < 8; ++t) split_tile(load_tile(ft, t, lane), t, x);
+    for (int k = 0; k < 16; ++k) { x.h[k] = load_piece(ft, k, lane, 0); x.m[k] = load_piece(ft, k, lane, 1); }
   }
   // rbuf: [block 0..3][wave tile][128*64] then the extras [wave tile][1024] (same [block][tile] layout as the SDF buffers)
   const size_t LS = block_stride();

@@ -2,6 +2,7 @@
 // (svs_mlp_h2.hip) and the inverted-sphere background network (svs_bg_h2.hip).
 #pragma once
 #include "svs_mlp_h2_dev.h"
+#include "svs_blocks_h2.h"
 
 namespace svs {
 namespace mlp {
@@ -43,10 +44,13 @@ struct NetBg {   // d_in 4, PE-10: 84 inputs; lin3 emits 172 rows, rows 172..255
 // SDF trunk, layers 0..7
 // --------------------------------------------------------------------------------------------------------------
 // Epilogue of one trunk tile, in slices: softplus of accumulator register r of `prev`, the skip splice (layer 3),
-// the float32 store to hbuf (HBUF) and either the split into the next layer's operand (xn) or the float32 copy y8
-// (last layer).
+// and either the split into the next layer's operand (xn) -- whose pieces are also what hbuf stores (HBUF) -- or the
+// float32 copy y8 (last layer: the caller splits and stores h_8).
 template <bool HBUF, bool LAST, typename Net = NetFg>
 struct TrunkEpi {
+  // the last layer keeps h_8 in float32 (y8: the sdf head and ghat_7 need it); with HBUF it ALSO splits it into xn -- the
+  // feature head's operand -- since the pieces are what hbuf stores
+  static constexpr bool kSplit = !LAST || HBUF;
   f32x16 prev;
   SoftplusA sa;
   float v8[8];
@@ -96,27 +100,41 @@ struct TrunkEpi {
     emit<DEFER>(tp, r, v);
   }
   // DEFER (sliced epilogues): the split of elements 8..15 -- 24 instructions that would sit in front of
-  // the tile's barrier -- is left to finish(tp), which the NEXT tile issues while it waits for its first LDS reads
+  // the tile's barrier -- is left to finish(tp), which the NEXT tile issues while it waits for its first LDS reads.
+  // HBUF: h is stored as a PAIR block (svs_blocks_h2.h) -- the very pieces the split produces for the next layer.
+  // Sliced epilogues issue those stores from late_store() (behind the tile's last LDS-DMA piece), the others at once.
   template <bool DEFER = false>
   __device__ __forceinline__ void emit(int tp, int r, float v) {
     if (LAST) y8[tp][r] = v;
-    if (HBUF) {
-      q4[r & 3] = v;
-      if ((r & 3) == 3) SVS_STREAM_STORE(q4, reinterpret_cast<f32x4*>(hb) + (4 * tp + (r >> 2)) * 64 + lane);
-    }
-    if (!LAST && !(SVS_ABL & 2)) {
+    if (kSplit && !(SVS_ABL & 2)) {
       v8[r & 7] = v;
       if ((r & 7) == 7 && !(DEFER && r == 15)) {
-        split8(v8, xn->h[2 * tp + (r >> 3)], xn->m[2 * tp + (r >> 3)]);
-        pin(xn->h[2 * tp + (r >> 3)], xn->m[2 * tp + (r >> 3)]);
+        const int k = 2 * tp + (r >> 3);
+        split8(v8, xn->h[k], xn->m[k]);
+        pin(xn->h[k], xn->m[k]);
+        if (HBUF && !DEFER) { store_piece(hb, k, lane, xn->h[k], 0); store_piece(hb, k, lane, xn->m[k], 1); }
       }
     }
   }
+  template <bool STORE = false>
   __device__ __forceinline__ void finish(int tp) {
-    if (!LAST && !(SVS_ABL & 2)) {
-      split8(v8, xn->h[2 * tp + 1], xn->m[2 * tp + 1]);
-      pin(xn->h[2 * tp + 1], xn->m[2 * tp + 1]);
+    if (kSplit && !(SVS_ABL & 2)) {
+      const int k = 2 * tp + 1;
+      split8(v8, xn->h[k], xn->m[k]);
+      pin(xn->h[k], xn->m[k]);
+      if (HBUF && STORE) { store_piece(hb, k, lane, xn->h[k], 0); store_piece(hb, k, lane, xn->m[k], 1); }
     }
+  }
+  // k-step s of tile t (whose MFMAs cover the epilogue of tile t-1): the pair stores of the pieces that are complete by
+  // now -- k-step 2(t-1) (split in this tile's k-step 7) and k-step 2(t-2)+1 (split by finish(t-2) in front of this
+  // tile) -- behind the last LDS-DMA piece (k-step 8), so that Stream::advance_keep leaves them in flight (LateStore)
+  __device__ __forceinline__ void late_store(int t, int s) {
+    if (!HBUF) return;
+    const int k1 = 2 * (t - 1), k2 = 2 * (t - 2) + 1;
+    if (s == 9) store_piece(hb, k1, lane, xn->h[k1], 0);
+    if (s == 11) store_piece(hb, k1, lane, xn->m[k1], 1);
+    if (t >= 2 && s == 13) store_piece(hb, k2, lane, xn->h[k2], 0);
+    if (t >= 2 && s == 15) store_piece(hb, k2, lane, xn->m[k2], 1);
   }
   __device__ __forceinline__ void all(int tp) {
 #pragma unroll
@@ -138,23 +156,26 @@ __device__ __forceinline__ void trunk_layer_h2(Stream& st, const Pieces2& x, Tru
   for (int t = 0; t < 8; ++t) {
     if (t == Net::kSpliceTile + 1 && ep.splice) break;   // lin3 has 217 (bg: 172) outputs; the tiles behind are the PE splice
     f32x16 acc;
-    // the next chunk's 9 LDS-DMA pieces go behind k-steps 0..8 (Stream::prefetch_step); the hbuf stores of tile t-1's
-    // epilogue are issued in k-steps 3, 7, 11, 15: the last two are younger than every piece and may stay in flight
+    // the next chunk's 9 LDS-DMA pieces go behind k-steps 0..8 (Stream::prefetch_step); the hbuf stores (TrunkEpi::
+    // late_store) behind them, in k-steps 9, 11, 13, 15: younger than every piece, they may stay in flight
     if (t == 0) acc = tile_mma_h2_pf<16, kChunkF4>(st, x, lane, NoEpi(), NoEpi());
     // (the split of tile t-2's last eight elements is issued while this tile waits for its first LDS reads)
     else acc = tile_mma_h2_pf<16, kChunkF4>(st, x, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.a2(s); },
-                                            [&](int s) { ep.template b<true>(t - 1, s); },
+                                            [&](int s) { ep.template b<true>(t - 1, s); ep.late_store(t, s); },
                                             [&]() { if (t >= 2) ep.finish(t - 2); });
     ep.prev = acc;
-    if (HBUF && t > 0) st.advance_keep<2>();
+    if (HBUF && t > 0) { if (t >= 2) st.advance_keep<4>(); else st.advance_keep<2>(); }
     else st.advance();
   }
-  if (ep.splice) { ep.finish(Net::kSpliceTile - 1); ep.all(Net::kSpliceTile); ep.splice_full_tiles(); }
-  else { ep.finish(6); ep.all(7); }
+  // the tail: the pieces the loop has not stored yet go out at once
+  if (ep.splice) {
+    ep.template finish<true>(Net::kSpliceTile - 1); ep.all(Net::kSpliceTile); ep.splice_full_tiles();
+  } else { ep.template finish<true>(6); ep.all(7); }
 }
 
 // Forward through layers 0..7.  x: scratch operand; on return y8 holds h_8 in float32 (the input of lin8) and the
-// current chunk is the one that follows the trunk in the stream.  HBUF: h_1..h_8 are also stored to hbuf.
+// current chunk is the one that follows the trunk in the stream.  HBUF: h_1..h_8 are also stored to hbuf (pair blocks)
+// and x holds the pieces of h_8.
 template <bool HBUF, typename Net = NetFg>
 __device__ __forceinline__ void forward_trunk_h2(Stream& st, Pieces2& x, Pieces2& xn, f32x16* y8, const typename Net::Pe& pe,
                                                  int lane, int half, float* __restrict__ hbuf) {
@@ -185,9 +206,9 @@ __device__ __forceinline__ void forward_trunk_h2(Stream& st, Pieces2& x, Pieces2
     ep2.y8 = nullptr; ep2.pe = &pe; ep2.hb = hbuf + (size_t)(l + 1) * block_stride(); ep2.lane = lane; ep2.half = half; ep2.splice = false;
     ep2.xn = &xn; trunk_layer_h2<HBUF, false, Net>(st, x, ep2, lane);
   }
-  // ---- layer 7: input in xn (layer 6 wrote it), output kept in float32
+  // ---- layer 7: input in xn (layer 6 wrote it), output kept in float32 (y8) and, with HBUF, as pieces in x
   TrunkEpi<HBUF, true, Net> ep;
-  ep.xn = nullptr; ep.y8 = y8; ep.pe = &pe; ep.hb = hbuf + (size_t)7 * block_stride(); ep.lane = lane; ep.half = half; ep.splice = false;
+  ep.xn = HBUF ? &x : nullptr; ep.y8 = y8; ep.pe = &pe; ep.hb = hbuf + (size_t)7 * block_stride(); ep.lane = lane; ep.half = half; ep.splice = false;
   trunk_layer_h2<HBUF, true, Net>(st, xn, ep, lane);
 }
 

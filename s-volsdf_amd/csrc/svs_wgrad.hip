@@ -138,31 +138,40 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(Args a) {
 
 
 // --------------------------------------------------------------------------------------------------------------
-// fp16x2 variant: the same contraction on v_mfma_f32_32x32x16_f16 with two-piece fp16 operands (svs_mlp_h2_dev.h).
+// fp16x2 variant: the same contraction on v_mfma_f32_32x32x16_f16, reading the operand blocks in the forms the sweeps
+// store them in (svs_blocks_h2.h): no conversion, no split.
+//   pair 0:  A = abar_l / zbar_l / fbar  HALF block, per-point scale  (gradient-like: one piece)
+//            B = h_l / r_l / feature     PAIR block                   (activation: hi + mid)      -> 2 MFMAs per k-step
+//   pair 1:  A = ghat_l                  HALF block, unscaled
+//            B = u_l                     HALF block, per-point scale                               -> 1 MFMA per k-step
+//   narrow:  B = the 16 / 32 extra input rows of a radiance network's first layer, ONE float32 tile (converted here)
 //
-// The contraction index is the POINT, which lives on the lanes of the activation blocks, so both operands are
-// transposed through LDS: a staging thread converts its float4 (4 consecutive features of one point) into hi / mid
-// fp16 pieces and stores each as ONE ds_write_b64 into a [point][feature] image; the MFMA fragments (8 consecutive
-// points of one feature per lane) come back through ds_read_b64_tr_b16, the hardware transpose read.  Images are
-// [32 points][128 features] sub-tiles with 256-byte rows and the chunk swizzle of cdna_hip_programming.md T10 (b):
-// both the 8-byte writes and the transposed reads are conflict-free.
+// The contraction index is the POINT, which lives on the lanes of the blocks, so both operands are transposed through
+// LDS: a staging thread copies its fragment (16 B = 2 x 4 consecutive features of one point) with two ds_write_b64 into a
+// [point][feature] image; the MFMA fragments (8 consecutive points of one feature per lane) come back through
+// ds_read_b64_tr_b16, the hardware transpose read.  Images are [32 points][128 features] sub-tiles with 256-byte rows
+// and the chunk swizzle of cdna_hip_programming.md T10 (b): both the 8-byte writes and the transposed reads are
+// conflict-free.
 //
-// Gradient-like operands (A of pair 0, B of pair 1) span many orders of magnitude and can be far below fp16's range:
-// they are multiplied by a power of two s chosen from their maximum magnitude (absmax, produced on the device by the
-// kernels that write them) so that the largest element is ~2^10, and the accumulators are multiplied by 1/s before
-// the flush.  Elements below 2^-13 of the maximum keep an absolute precision of 2^-35 of it.
+// Scaled operands carry value * s_p with one power of two s_p per point (the point's largest element at ~2^4); a
+// contraction over points needs ONE scale, so the staging thread multiplies its fragment by s / s_p in fp16 (exact:
+// a power of two), with s chosen from the published maximum of the operand (absmax) so that the largest element of
+// the launch is ~2^10; the accumulators are multiplied by 1 / s before the flush.  Points whose gradients are below
+// 2^-34 of the largest one underflow to zero.
 // --------------------------------------------------------------------------------------------------------------
 namespace h2 {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
 #define SVS_LDS(T, ptr) ((__attribute__((address_space(3))) T*)(ptr))
 
 constexpr int kSub = 32 * 256;         // bytes of one [32 points][128 features] fp16 sub-image
 constexpr int kPiece = 2 * kSub;       // 256 features
-constexpr int kOperand = 2 * kPiece;   // hi piece, mid piece
-constexpr int kExtraPiece = 32 * 64;   // 9th B tile: [32 points][32 features], 64-byte rows
+constexpr int kExtraPiece = 32 * 64;   // narrow B tile: [32 points][32 features], 64-byte rows
+constexpr int kPlaneF4 = 1024;         // float4 per fp16 plane of a block (svs_blocks_h2.h)
+constexpr int kRecordF = 4096;         // float index of a half block's per-point scale record
 
 __device__ __forceinline__ f16x8 tr_frag(const unsigned char* lds, int a0, int a1) {
   struct Pair { s16x4 lo, hi; } v;
@@ -189,19 +198,20 @@ struct Job {
   int n_pairs;
   int n_tiles;           // point tiles (32 points each)
   int n_valid_points;    // points beyond this index contribute nothing (ragged last tile)
-  int b_tiles;           // 8: B blocks are 256-row activation blocks; 1: B blocks are single 32-row tiles (1024 floats)
+  int b_tiles;           // 8: B blocks are 256-row blocks; 1: B blocks are single 32-row float32 tiles (1024 floats)
   int col0;              // first dW column of B tile 0
   float* dW;             // [256][ldw] accumulated with atomics (caller zeroes)
   int ldw;
   float* db;             // [256] row sums of A of pair 0 (bias gradient) or nullptr
-  const float* absmax;   // device float: max magnitude of the gradient-like operands, or nullptr (no scaling)
+  const float* absmax;   // device float: max magnitude of the scaled operands, or nullptr (scales ignored)
   int wg_begin, wg_count;
 };
 constexpr int kMaxJobs = 20;
 struct MultiArgs { Job job[kMaxJobs]; int n_jobs; };
 
 constexpr int kThreadsW = 512;          // 8 waves: wave w owns output tile w (32 rows) x all B tiles
-constexpr int kBufBytes = 2 * kOperand; // A image + B image (the single-tile B image of a narrow job fits in it)
+// LDS per buffer: A image (one piece), B image hi, B image mid
+constexpr int kBufBytes = 3 * kPiece;
 
 // a wave-uniform global pointer, kept in scalar registers (global_load with an SGPR base + 32-bit lane offset)
 typedef const __attribute__((address_space(1))) f32x4* gptr_f4;
@@ -212,7 +222,8 @@ __device__ __forceinline__ gptr_f4 uniform_f4(const float* p) {
 }
 
 struct Staging4 {
-  f32x4 a[4], b[4];
+  f32x4 a[2], b[4];      // A hi plane (2 fragments per thread), B hi + mid planes (pair 0) / B hi plane (pair 1: b[0..1])
+  float sa, sb;          // per-point factors s / s_p of the scaled operands (1 where the operand is not scaled)
 };
 
 __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs ma) {
@@ -242,13 +253,23 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) rt[j] = 64 * (j ^ rq);
-  // ---- writer addresses: float4 k*512 + tid of a block = registers of tile 2k + (wave>>2), quarter wave&3
+  // ---- writer addresses.  Fragment (k-step s, lane L) of a plane = features 16 s + 4 (L >> 5) + {0..3} and + 8 of point
+  // L & 31: accumulator tile s >> 1, quarters 2 (s & 1) and 2 (s & 1) + 1.  Thread tid takes k-steps wave and wave + 8.
+  // image offset of (tile, quarter) for this lane: (tile >> 2) kSub + 256 pt + 64 ((tile & 3) ^ (pt & 3)) + 16 (quarter ^
+  // ((pt >> 2) & 3)) + 8 (L >> 5)
   const int wp = lane & 31, whf = lane >> 5;
-  int wbase[2];
+  int woff[2][2];        // [which of the thread's two k-steps][first / second half of the fragment]
 #pragma unroll
-  for (int x = 0; x < 2; ++x)
-    wbase[x] = 256 * wp + 64 * ((2 * x + (wave >> 2)) ^ (wp & 3)) + 16 * ((wave & 3) ^ ((wp >> 2) & 3)) + 8 * whf;
-  const int wxoff = 64 * wp + 16 * (wave & 3) + 8 * whf;   // narrow B image (threads 0..255)
+  for (int j = 0; j < 2; ++j) {
+    const int s = wave + 8 * j, tile = s >> 1;
+#pragma unroll
+    for (int hq = 0; hq < 2; ++hq) {
+      const int quarter = 2 * (s & 1) + hq;
+      woff[j][hq] = (tile >> 2) * kSub + 256 * wp + 64 * ((tile & 3) ^ (wp & 3)) + 16 * (quarter ^ ((wp >> 2) & 3)) + 8 * whf;
+    }
+  }
+  // narrow B image (threads 0..255): float4 tid of the float32 tile = registers 4 (tid >> 6) .. +3 of lane tid & 63
+  const int wxoff = 64 * wp + 16 * (wave & 3) + 8 * whf;
 
   const int my_tiles = a.n_tiles > wg ? (a.n_tiles - 1 - wg) / nwg + 1 : 0;
   const int n_items = my_tiles * a.n_pairs;
@@ -258,19 +279,49 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
   auto issue = [&](int item) {
     const int t = wg + (item / a.n_pairs) * nwg, pi = item % a.n_pairs;
     const Pair& p = a.p[pi];
-    gptr_f4 ga = uniform_f4(p.a + (size_t)t * p.stride_a);
-    gptr_f4 gb = uniform_f4(p.b + (size_t)t * p.stride_b);
+    const float* pa = p.a + (size_t)t * p.stride_a;
+    const float* pb = p.b + (size_t)t * p.stride_b;
+    gptr_f4 ga = uniform_f4(pa);
+    gptr_f4 gb = uniform_f4(pb);
     // branch-free: registers defined on one side of a branch only would be merged by copies that wait for the loads.
-    // A narrow B block has 256 float4: every load of a narrow job re-reads float4 tid & 255 (only b[0] is used).
+    // A narrow B block has 256 float4: every B load of a narrow job re-reads float4 tid & 255 (only b[0] is used); pair 1
+    // has no mid plane: its b[2], b[3] re-read the hi plane (unused).
+    const int mid = (pi == 0 && !narrow) ? kPlaneF4 : 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      st.a[k] = SVS_STREAM_LOAD(ga + k * kThreadsW + tid);
-      st.b[k] = SVS_STREAM_LOAD(gb + (narrow ? (tid & 255) : k * kThreadsW + tid));
+    for (int j = 0; j < 2; ++j) {
+      st.a[j] = SVS_STREAM_LOAD(ga + j * kThreadsW + tid);
+      st.b[j] = SVS_STREAM_LOAD(gb + (narrow ? (tid & 255) : j * kThreadsW + tid));
+      st.b[2 + j] = SVS_STREAM_LOAD(gb + (narrow ? (tid & 255) : mid + j * kThreadsW + tid));
     }
+    // per-point rescale factors of the scaled operands: pair 0 scales A (abar-like), pair 1 scales B (u)
     st_live = a.n_valid_points - t * 32;
+    float sa = 1.0f, sb = 1.0f;
+    if (a.absmax && wp < st_live) {
+      const float rec = pi == 0 ? pa[kRecordF + wp] : pb[kRecordF + wp];
+      // s / s_p: rec is a power of two in [2^-103, 2^103] (PointScale::pow2_for); anything else (a block that was
+      // never written) leaves the factor at 1
+      const unsigned eb = (__float_as_uint(rec) >> 23) & 0xff;
+      const float f = (eb >= 20 && eb <= 240) ? s_grad * __uint_as_float((254u << 23) - __float_as_uint(rec)) : 1.0f;
+      sa = pi == 0 ? f : 1.0f;
+      sb = pi == 0 ? 1.0f : f;
+    }
+    st.sa = sa; st.sb = sb;
     st_pair = pi;
   };
-  auto put = [&](unsigned char* piece_hi, unsigned char* piece_mid, int off, const f32x4& v) {
+  // frag * f in fp16, f a power of two: exact unless the product leaves fp16's range.  f itself may exceed fp16's range
+  // (a point whose scale was set by its floor, far above the values of this block): it is applied as two factors
+  auto put8 = [&](unsigned char* image, int off0, int off1, const f32x4& frag, float f, bool scaled) {
+    struct Halves { f16x4 lo, hi; } v = __builtin_bit_cast(Halves, frag);
+    if (scaled) {
+      const float f1 = __builtin_fminf(f, 32768.0f), f2 = f / f1;
+      const _Float16 h1 = (_Float16)f1, h2 = (_Float16)__builtin_fminf(f2, 32768.0f);
+      const f16x4 a4 = {h1, h1, h1, h1}, b4 = {h2, h2, h2, h2};
+      v.lo = (v.lo * a4) * b4; v.hi = (v.hi * a4) * b4;
+    }
+    *SVS_LDS(f16x4, image + off0) = v.lo;
+    *SVS_LDS(f16x4, image + off1) = v.hi;
+  };
+  auto put_f32 = [&](unsigned char* piece_hi, unsigned char* piece_mid, int off, const f32x4& v) {
     f16x4 hi, mid;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -283,20 +334,22 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
   };
   auto commit = [&](int buf) {
     unsigned char* la = smem_h2 + buf * kBufBytes;
-    unsigned char* lb = la + kOperand;
-    const float sa = st_pair == 0 ? s_grad : 1.0f, sb = st_pair == 0 ? 1.0f : s_grad;
+    unsigned char* lb = la + kPiece;
+    const bool p0 = st_pair == 0;
+    const float fa = st.sa, fb = st.sb;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      f32x4 va = st.a[k];
+    for (int j = 0; j < 2; ++j) {
+      f32x4 va = st.a[j];
       if (wp >= st_live) va = (f32x4)(0.0f);     // ragged last tile: points beyond the batch contribute nothing
-      const int off = (k >> 1) * kSub + wbase[k & 1];
-      put(la, la + kPiece, off, va * sa);
-      if (!narrow) put(lb, lb + kPiece, off, st.b[k] * sb);
+      put8(la, woff[j][0], woff[j][1], va, fa, p0 && a.absmax);
+      if (!narrow) {
+        put8(lb, woff[j][0], woff[j][1], st.b[j], fb, !p0 && a.absmax);
+        if (p0) put8(lb + kPiece, woff[j][0], woff[j][1], st.b[2 + j], fb, false);
+      }
     }
-    if (narrow && tid < 256) put(lb, lb + kExtraPiece, wxoff, st.b[0] * sb);
+    if (narrow && tid < 256) put_f32(lb, lb + kExtraPiece, wxoff, st.b[0]);
   };
 
-  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
   const f16x2 one2 = {(_Float16)1.0f, (_Float16)1.0f};
 
   if (n_items > 0) { issue(0); commit(0); }
@@ -304,41 +357,37 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
   for (int item = 0; item < n_items; ++item) {
     const int buf = item & 1;
     const bool more = item + 1 < n_items;
+    const bool p0 = (item % a.n_pairs) == 0;
     if (more) issue(item + 1);
     const unsigned char* la = smem_h2 + buf * kBufBytes;
-    const unsigned char* lb = la + kOperand;
-    const bool want_bias = a.db && (item % a.n_pairs) == 0;
+    const unsigned char* lb = la + kPiece;
+    const bool want_bias = a.db && p0;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const f16x8 ah = tr_frag(la + ks * 4096, aaddr[0], aaddr[1]);
-      const f16x8 am = tr_frag(la + kPiece + ks * 4096, aaddr[0], aaddr[1]);
-      auto bfrag = [&](int i, f16x8& bh, f16x8& bm) {
-        if (!narrow) {
-          const unsigned char* base = lb + (i >> 2) * kSub + ks * 4096;
-          bh = tr_frag(base, rbase[0] + rt[i & 3], rbase[1] + rt[i & 3]);
-          bm = tr_frag(base + kPiece, rbase[0] + rt[i & 3], rbase[1] + rt[i & 3]);
-        } else {
-          bh = tr_frag(lb + ks * 1024, rx[0], rx[1]);
-          bm = tr_frag(lb + kExtraPiece + ks * 1024, rx[0], rx[1]);
-        }
-      };
       if (want_bias) {
         // row sums of A: the fragment holds 8 points of row lane & 31 (the other lane half holds the other 8)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const f16x2 h2v = {ah[2 * j], ah[2 * j + 1]}, m2v = {am[2 * j], am[2 * j + 1]};
+          const f16x2 h2v = {ah[2 * j], ah[2 * j + 1]};
           bsum = __builtin_amdgcn_fdot2(h2v, one2, bsum, false);
-          bsum = __builtin_amdgcn_fdot2(m2v, one2, bsum, false);
         }
       }
       // the two waves of a SIMD cover each other's LDS latency: no software pipelining of the B fragments
+      const bool two = p0 || narrow;       // B has a mid piece
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         if (i > 0 && narrow) break;
         f16x8 bh, bm;
-        bfrag(i, bh, bm);
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, bh, acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bm, acc[i], 0, 0, 0);
+        if (!narrow) {
+          const unsigned char* base = lb + (i >> 2) * kSub + ks * 4096;
+          bh = tr_frag(base, rbase[0] + rt[i & 3], rbase[1] + rt[i & 3]);
+          if (two) bm = tr_frag(base + kPiece, rbase[0] + rt[i & 3], rbase[1] + rt[i & 3]);
+        } else {
+          bh = tr_frag(lb + ks * 1024, rx[0], rx[1]);
+          bm = tr_frag(lb + kExtraPiece + ks * 1024, rx[0], rx[1]);
+        }
+        if (two) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bm, acc[i], 0, 0, 0);
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i], 0, 0, 0);
       }
     }

@@ -50,7 +50,7 @@ SIGNATURES = {
     "svs_feat_tiles_bytes": (c_size_t, [c_int]),
     "svs_sdf_outputs": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, _P, c_int, c_float, c_float, c_int, _P, _P,
                                 _P, _P, _P, _P, _P]),
-    "svs_tiles_to_rows": (c_int, [_P, c_int, _P, _P]),
+    "svs_tiles_to_rows": (c_int, [_P, c_int, c_int, _P, _P]),
     "svs_rgb_eval": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, _P, _P, c_int, _P, _P, c_int, _P, _P, _P]),
     "svs_rgb_rbuf_bytes": (c_size_t, [c_int]),
     "svs_block_bytes": (c_size_t, [c_int, c_int]),
@@ -60,7 +60,7 @@ SIGNATURES = {
     "svs_sdf_bwd_a": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P, _P, _P,
                               _P, _P, _P]),
     "svs_sdf_bwd_b": (c_int, [c_int, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P]),
-    "svs_lin8_row0_grad": (c_int, [_P, _P, _P, c_int, _P, _P]),
+    "svs_lin8_row0_grad": (c_int, [_P, _P, _P, c_int, c_int, _P, _P]),
     "svs_unpack_wgrad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "svs_unpack_wgrad_multi": (c_int, [_P, c_int, _P]),
     "svs_sampler_ctl_bytes": (c_size_t, [c_int, c_int]),

@@ -155,7 +155,7 @@ def sdf_outputs(packed, src, sphere_radius, sphere_scale, want_feature_rows=Fals
     rows = None
     if want_feature_rows:
         rows = torch.empty(src.n, 256, device=dev)
-        _lib.check(L.svs_tiles_to_rows(_ptr(feat), src.n, _ptr(rows), _stream()), "svs_tiles_to_rows")
+        _lib.check(L.svs_tiles_to_rows(_ptr(feat), src.n, packed.precision, _ptr(rows), _stream()), "svs_tiles_to_rows")
     return sdf, grad, feat, hbuf, rows
 
 

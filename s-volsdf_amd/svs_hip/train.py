@@ -205,7 +205,7 @@ class MlpBackward:
                                    _ptr(gbuf), _ptr(self.a2buf), _ptr(S.sdf), prec, _ptr(self.abuf), _ptr(self.sbar),
                                    _ptr(acc.absmax) if h2 else None, _ptr(self.a2max) if h2 else None, st),
                    "svs_sdf_bwd_b")
-        _lib.check(L.svs_lin8_row0_grad(_ptr(hbuf), _ptr(self.ubuf), _ptr(self.sbar), n_total, _ptr(acc.row0), st),
+        _lib.check(L.svs_lin8_row0_grad(_ptr(hbuf), _ptr(self.ubuf), _ptr(self.sbar), n_total, prec, _ptr(acc.row0), st),
                    "svs_lin8_row0_grad")
         ev = self.timer_events = ([torch.cuda.Event(enable_timing=True) for _ in range(2)] if self.time_wgrad else None)
         if ev:
@@ -286,7 +286,7 @@ class BgBackward:
                                     _ptr(feat_bar), _ptr(self.absmax), st), "svs_bg_rgb_bwd")
         _lib.check(L.svs_bg_sdf_bwd(P, _ptr(d_bg_out0), _ptr(feat_bar), _ptr(hbuf), _ptr(ghat7), _ptr(self.sdf_stream),
                                     _ptr(abuf), _ptr(sbar), _ptr(self.absmax), st), "svs_bg_sdf_bwd")
-        _lib.check(L.svs_lin8_row0_grad(_ptr(hbuf), None, _ptr(sbar), P, _ptr(self.row0), st), "svs_lin8_row0_grad")
+        _lib.check(L.svs_lin8_row0_grad(_ptr(hbuf), None, _ptr(sbar), P, F16X2, _ptr(self.row0), st), "svs_lin8_row0_grad")
         LS, Z2 = block_stride(P), 2 * KBLOCK
 
         def addr(x):
@@ -332,11 +332,20 @@ class BgBackward:
 
 def algorithmic_bytes_per_point(precision=None):
     """HBM bytes per point that the HBM-bound launches of the training backward read or write ONCE (the figures
-    bench.py's roofline prices).  One 256-feature float32 block = 1024 bytes per point.
-      svs_sdf_bwd_a   reads h_1..h_8, ghat_0..ghat_7; writes u_0..u_8, a2_0..a2_7, the PE block
-      svs_sdf_bwd_b   reads h_1..h_8, a2_0..a2_7, ghat_7, feat_bar; writes abar_0..abar_7
-      wgrad_sdf       per layer abar_l, h_l, ghat_l, u_l (l = 0..7) + feat_bar, h_8 for lin8
-      wgrad_radiance  zbar_0..zbar_4, r_0..r_3, the feature block, the 16 extra input rows"""
+    bench.py's roofline prices).  One 256-feature block slot = 1024 bytes per point in float32
+    (precision f32); on the fp16x2 path (csrc/svs_blocks_h2.h) a PAIR block is 1024 bytes per point, its hi plane alone
+    512, a HALF block 512.
+      svs_sdf_bwd_a   reads h_1..h_8 (hi planes), ghat_0..ghat_7; writes u_0..u_8, a2_0..a2_7, the PE block
+      svs_sdf_bwd_b   reads h_1..h_8 (hi planes), a2_0..a2_7, ghat_7, fbar; writes abar_0..abar_7
+      wgrad_sdf       per layer abar_l, h_l (pair), ghat_l, u_l (l = 0..7) + fbar, h_8 (pair) for lin8
+      wgrad_radiance  zbar_0..zbar_4, r_0..r_3 (pair), the feature block (pair), the 16 extra input rows"""
+    precision = default_precision() if precision is None else precision
+    if precision == F16X2:
+        half, pair = 512, 1024
+        return {"svs_sdf_bwd_a": 8 * half + 8 * half + 9 * half + 8 * half + pair,
+                "svs_sdf_bwd_b": 8 * half + 8 * half + half + half + 8 * half,
+                "wgrad_sdf": 8 * (half + pair + half + half) + half + pair,
+                "wgrad_radiance": 5 * half + 4 * pair + pair + 128}
     blk = 1024
     return {"svs_sdf_bwd_a": (8 + 8 + 9 + 8 + 1) * blk, "svs_sdf_bwd_b": (8 + 8 + 1 + 1 + 8) * blk,
             "wgrad_sdf": (8 * 4 + 2) * blk, "wgrad_radiance": (5 + 4 + 1) * blk + 128}

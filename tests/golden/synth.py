@@ -233,6 +233,60 @@ def rows_to_tiles(x):
     return out
 
 
+def _fragment_index(Fdim):
+    """feature f -> (k-step s, element j, lane half) of the fp16 fragment layout of csrc/svs_blocks_h2.h:
+    f = 16 s + 8 (j >> 2) + 4 half + (j & 3)"""
+    f = np.arange(Fdim)
+    s, w = f // 16, f % 16
+    half = (w >> 2) & 1
+    j = (w & 3) + 4 * (w >> 3)
+    return s, j, half
+
+
+def rows_to_pair_block(x):
+    """(P, F<=256) float32 rows -> PAIR blocks of the fp16x2 kernels (csrc/svs_blocks_h2.h), (ceil(P/32), 128*64)
+    float32 words: hi plane [16 k-steps][64 lanes][8 fp16], then the mid plane, value = hi + mid."""
+    P, Fdim = x.shape
+    nt = (P + 31) // 32
+    hi = x.astype(np.float16)
+    mid = (x - hi.astype(F32)).astype(np.float16)
+    out = np.zeros((nt, 2, 16, 64, 8), np.float16)
+    s, j, half = _fragment_index(Fdim)
+    p = np.arange(P)
+    wt, lane = (p // 32)[:, None], (p % 32)[:, None] + 32 * half[None, :]
+    out[wt, 0, s[None, :], lane, j[None, :]] = hi
+    out[wt, 1, s[None, :], lane, j[None, :]] = mid
+    return out.reshape(nt, -1).view(F32)
+
+
+def rows_to_half_block(x, scaled=True):
+    """(P, F<=256) float32 rows -> HALF blocks (csrc/svs_blocks_h2.h): the hi plane of x * s_p, s_p the power of two that
+    puts the point's largest magnitude in [2^4, 2^5) (1 when not `scaled`), + the record [scale(32), max(32)] at float
+    index 4096.  Returns (blocks (ceil(P/32), 128*64) float32 words, the values the block actually holds (P, F))."""
+    P, Fdim = x.shape
+    nt = (P + 31) // 32
+    mx = np.abs(x).max(1)
+    if scaled:
+        e = np.floor(np.log2(np.maximum(mx, 2.0 ** -102)))
+        sp = (2.0 ** (4 - e)).astype(F32)
+    else:
+        sp = np.ones(P, F32)
+    hi = (x * sp[:, None]).astype(np.float16)
+    out = np.zeros((nt, 128 * 64 * 2), np.float16)
+    planes = out[:, :16 * 64 * 8].reshape(nt, 16, 64, 8)
+    s, j, half = _fragment_index(Fdim)
+    p = np.arange(P)
+    wt, lane = (p // 32)[:, None], (p % 32)[:, None] + 32 * half[None, :]
+    planes[wt, s[None, :], lane, j[None, :]] = hi
+    words = out.view(F32).reshape(nt, 128 * 64)
+    rec = np.ones((nt, 64), F32)
+    rec[:, 32:] = 0.0
+    rec.reshape(-1)[(p // 32) * 64 + p % 32] = sp
+    rec.reshape(-1)[(p // 32) * 64 + 32 + p % 32] = mx
+    words[:, 4096:4160] = rec
+    return words, hi.astype(F32) / sp[:, None]
+
+
 def make_fusion_views(seed, hw=(48, 64), n_views=3, noise=2e-3):
     """Synthetic input of the depth-fusion filter (runner.py:301-332): n_views cameras on an arc looking at a unit
     sphere in front of a plane; per view K (3,3), E (4,4) world->camera (float32, as read_camera_parameters returns),

@@ -60,11 +60,26 @@ def test_composite_backward(dev, ops, beta):
     assert abs(float(d_beta) - float(tb.grad)) / abs(float(tb.grad)) < 2e-5
 
 
+def _operands(precision, A0, B0, A1, B1, dev):
+    """Device blocks of the two operand pairs in the form the kernels of that precision read, and the values those blocks
+    really hold (fp16x2: A of pair 0 and B of pair 1 are HALF blocks under a per-point scale, A of pair 1 an unscaled
+    half block, B of pair 0 a PAIR block -- csrc/svs_blocks_h2.h)."""
+    if precision == 0:
+        return [G(synth.rows_to_tiles(x), dev) for x in (A0, B0, A1, B1)], (A0, B0, A1, B1)
+    a0, A0q = synth.rows_to_half_block(A0)
+    b0 = synth.rows_to_pair_block(B0)
+    a1, A1q = synth.rows_to_half_block(A1, scaled=False)
+    b1, B1q = synth.rows_to_half_block(B1)
+    B0q = B0.astype(np.float16).astype(F32) + (B0 - B0.astype(np.float16).astype(F32)).astype(np.float16).astype(F32)
+    return [G(x, dev) for x in (a0, b0, a1, b1)], (A0q, B0q, A1q, B1q)
+
+
 @pytest.mark.parametrize("precision,gscale", [(0, 1.0), (1, 1.0), (1, 3e-9), (1, 7e4)])
 @pytest.mark.parametrize("P", [32, 1000, 5000])
 def test_wgrad_gemm(dev, P, precision, gscale):
-    """dW = A B^T over points, with the optional softplus' factor and the second operand pair.  fp16x2: the
-    gradient-like operands (A of pair 0, B of pair 1) at magnitudes far outside fp16's range."""
+    """dW = A B^T over points, with the second operand pair.  fp16x2: the gradient-like operands (A of pair 0, B of pair 1)
+    at magnitudes far outside fp16's range; the reference is formed from the values the operand blocks hold (what the
+    block formats cost is measured at the level of the whole backward, test_mlp_backward_vs_autograd)."""
     import ctypes
     from svs_hip import lib
     L = lib.load()
@@ -77,7 +92,7 @@ def test_wgrad_gemm(dev, P, precision, gscale):
     H1 = rng.uniform(0, 0.05, (P, 256)).astype(F32)
     absmax = torch.tensor([max(np.abs(A0).max(), np.abs(B1).max())], dtype=torch.float32, device=dev)
     A1 = (A1 * (1 - np.exp(-100.0 * H1.astype(np.float64)))).astype(F32)
-    ta0, tb0, ta1, tb1 = (G(synth.rows_to_tiles(x), dev) for x in (A0, B0, A1, B1))
+    (ta0, tb0, ta1, tb1), (A0q, B0q, A1q, B1q) = _operands(precision, A0, B0, A1, B1, dev)
     dW = torch.zeros(256, 256, device=dev)
     db = torch.zeros(256, device=dev)
     ptr = lambda t: ctypes.c_void_p(t.data_ptr())
@@ -85,9 +100,12 @@ def test_wgrad_gemm(dev, P, precision, gscale):
     lib.check(L.svs_wgrad(ptr(ta0), ptr(tb0), st, st, ptr(ta1), ptr(tb1), st, st, None, 0, P,
                           precision, ptr(absmax) if precision else None, ptr(dW), 256, ptr(db),
                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
-    ref = A0.astype(np.float64).T @ B0 + A1.astype(np.float64).T @ B1
+    ref = A0q.astype(np.float64).T @ B0q + A1q.astype(np.float64).T @ B1q
     assert rel_err(dW.cpu().numpy(), ref) < 2e-5
-    assert rel_err(db.cpu().numpy(), A0.astype(np.float64).sum(0)) < 2e-5
+    assert rel_err(db.cpu().numpy(), A0q.astype(np.float64).sum(0)) < 2e-5
+    # and the block formats themselves: within fp16's 2^-11 of the float32 operands
+    exact = A0.astype(np.float64).T @ B0 + A1.astype(np.float64).T @ B1
+    assert rel_err(dW.cpu().numpy(), exact) < 1e-3
 
 
 @pytest.mark.parametrize("precision", [0, 1])
@@ -103,8 +121,8 @@ def test_wgrad_multi(dev, precision):
         A0, B0 = (1e-6 * rng.normal(0, 1, (P, 256))).astype(F32), rng.normal(0, 1, (P, 256)).astype(F32)
         A1, B1 = rng.normal(0, 1, (P, 256)).astype(F32), (1e-6 * rng.normal(0, 1, (P, 256))).astype(F32)
         X = rng.normal(0, 1, (P, 32)).astype(F32); X[:, 16:] = 0
-        ta0, tb0, ta1, tb1 = (G(synth.rows_to_tiles(x), dev) for x in (A0, B0, A1, B1))
-        # the extras block: one 32-row tile (16 registers x 64 lanes) per 32 points
+        (ta0, tb0, ta1, tb1), (A0q, B0q, A1q, B1q) = _operands(precision, A0, B0, A1, B1, dev)
+        # the extras block: one 32-row float32 tile (16 registers x 64 lanes) per 32 points, in both precisions
         xt = synth.rows_to_tiles(np.concatenate([X, np.zeros((P, 224), F32)], 1)).reshape(-1, 128 * 64)[:, :1024].copy()
         tx = G(xt, dev)
         dW = torch.zeros(256, 288, device=dev); db = torch.zeros(256, device=dev)
@@ -113,9 +131,9 @@ def test_wgrad_multi(dev, precision):
         p = lambda t: t.data_ptr()
         jobs.append(lib.WGradJob(p(ta0), p(tb0), st, st, p(ta1) if two else None, p(tb1) if two else None, st, st,
                                  p(tx) if extra else None, 1024, P, 288, p(dW), p(db), p(am) if precision else None))
-        ref = A0.astype(np.float64).T @ B0 + (A1.astype(np.float64).T @ B1 if two else 0.0)
-        refx = A0.astype(np.float64).T @ X[:, :16] if extra else None
-        refs.append((ref, refx, A0.astype(np.float64).sum(0))); outs.append((dW, db))
+        ref = A0q.astype(np.float64).T @ B0q + (A1q.astype(np.float64).T @ B1q if two else 0.0)
+        refx = A0q.astype(np.float64).T @ X[:, :16] if extra else None
+        refs.append((ref, refx, A0q.astype(np.float64).sum(0))); outs.append((dW, db))
     arr = (lib.WGradJob * len(jobs))(*jobs)
     lib.check(L.svs_wgrad_multi(ctypes.cast(arr, ctypes.c_void_p), len(jobs), precision,
                                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))

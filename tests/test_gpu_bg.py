@@ -65,8 +65,8 @@ def test_bg_pieces(dev, golden_dir, tag):
     rows = torch.empty(R * Nb, 256, device=dev)
     from svs_hip import lib
     import ctypes
-    lib.check(lib.load().svs_tiles_to_rows(ctypes.c_void_p(feat.data_ptr()), R * Nb, ctypes.c_void_p(rows.data_ptr()),
-                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    lib.check(lib.load().svs_tiles_to_rows(ctypes.c_void_p(feat.data_ptr()), R * Nb, 1, ctypes.c_void_p(rows.data_ptr()),
+                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))   # bg: fp16x2 pair block
     np.testing.assert_allclose(rows.cpu().numpy(), ref_out[:, 1:], atol=1e-4)
     view = orc.rays_from_uv(g["uv"], g["near_pose"], g["K"])[0] if tag != "train" else dirs
     rgb = ops.bg_rgb_eval(pkb, G(view, dev), Nb, feat, R * Nb)

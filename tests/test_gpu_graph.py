@@ -83,7 +83,7 @@ def test_captured_step_equals_eager(dev, kind, mode):
         else:
             # from step 1 on the parameters differ by the float atomics' rounding of the step before (as between any two
             # runs); a replay that missed an input update would be off by O(0.1)
-            assert float((ra - rb).abs().max()) <= 2e-4 and float((wa - wb).abs().max()) <= 2e-4, step
+            assert float((ra - rb).abs().max()) <= 1e-3 and float((wa - wb).abs().max()) <= 5e-3, step
         ratio = float((ga - gb).abs().max()) / float(ga.abs().max())
         assert ratio <= (1e-5 if step == 0 else 1e-3), (step, ratio)
     # the sparse term is live in the annealed phase only, and its weight decays: 1, 2/3, 1/3, then off
