@@ -42,14 +42,13 @@ __global__ __launch_bounds__(kThreads, 1) void bg_sdf_h2_kernel(BgSdfArgs a) {
   float* hb = TRAIN ? a.hbuf + (size_t)wtile * kBlockF : nullptr;
   Pieces2 x, xn;
   if (TRAIN) {
-    // h_0 = PE (84 rows, 6 k-steps) as a PAIR block in PE order, the rest zero: the B operand of dW_0
+    // h_0 = PE (84 rows, 6 k-steps) in PE order as block fragments (hi plane), the rest zero: the B operand of dW_0
     float* pb = a.pebuf + (size_t)wtile * kBlockF;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       f16x8 fh = (f16x8)(_Float16)0.0f, fm = (f16x8)(_Float16)0.0f;
       if (k < NetBg::kSteps0) block_fragment<kBgPeDim>(pe.v, k, half, 1.0f, fh, fm);
       store_piece(pb, k, lane, fh, 0);
-      store_piece(pb, k, lane, fm, 1);
     }
   }
   f32x16 y8[8];
@@ -194,7 +193,7 @@ __global__ __launch_bounds__(kThreads, 1) void bg_rgb_h2_kernel(BgRgbArgs a) {
         const int k = 2 * tp + (r >> 3);
         split8(v8, xn.h[k], xn.m[k]);
         pin(xn.h[k], xn.m[k]);
-        if (rb) { store_piece(rb, k, lane, xn.h[k], 0); store_piece(rb, k, lane, xn.m[k], 1); }    // r_1: a pair block
+        if (rb) store_piece(rb, k, lane, xn.h[k], 0);    // r_1: the hi plane (ReLU mask, weight gradient's B operand)
       }
     };
 #pragma unroll
@@ -211,10 +210,7 @@ __global__ __launch_bounds__(kThreads, 1) void bg_rgb_h2_kernel(BgRgbArgs a) {
     if (rb) {
       // k-steps 8..15 (rows 128..255) of the r_1 block stay zero (the weight-gradient GEMM reads whole 256-row blocks)
 #pragma unroll
-      for (int k = 8; k < 16; ++k) {
-        store_piece(rb, k, lane, (f16x8)(_Float16)0.0f, 0);
-        store_piece(rb, k, lane, (f16x8)(_Float16)0.0f, 1);
-      }
+      for (int k = 8; k < 16; ++k) store_piece(rb, k, lane, (f16x8)(_Float16)0.0f, 0);
     }
   }
   // ---- layer 1: 128 -> 3 as one tile (rows 0..2 live in registers 0..2 of lanes 0..31), sigmoid

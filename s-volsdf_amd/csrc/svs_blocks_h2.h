@@ -5,7 +5,7 @@
 // consumer converts or re-splits anything:
 //
 //   pair block   every value as its two fp16 pieces (22 significand bits, svs_mlp_h2_dev.h): the hi plane, 16 KiB =
-//                [16 k-steps][64 lanes][16 B], float4 index s * 64 + lane, then the mid plane at float4 index 1024 + ...
+//                [16 k-steps][64 fragments][16 B], float4 index s * 64 + piece_slot(s, lane), then the mid plane at 1024 + ...
 //                The 16 bytes of lane L in k-step s are the MFMA B fragment of that k-step: rows 16 s + 8 (j >> 2) +
 //                4 (L >> 5) + (j & 3), j = 0..7, of point L & 31 -- registers 8 (s & 1) .. 8 (s & 1) + 7 of accumulator
 //                tile s >> 1.  Forward activations (h_l, the feature vector, the radiance network's r_l, PE(x)).
@@ -31,12 +31,22 @@ constexpr int kRecordF = 4096;          // float index of a half block's scale /
 __device__ __forceinline__ f32x4 as_f4(const f16x8& v) { return __builtin_bit_cast(f32x4, v); }
 __device__ __forceinline__ f16x8 as_h8(const f32x4& v) { return __builtin_bit_cast(f16x8, v); }
 
+// Where lane L's fragment of k-step s sits inside the k-step's 1 KiB (in 16-byte slots).  A permutation of the 64 slots,
+// chosen for the one consumer that does not read whole fragments: the weight-gradient GEMM copies a plane into LDS as it
+// stands (LDS-DMA) and reads it TRANSPOSED (ds_read_b64_tr_b16: 4 points x 16 features per 16 lanes); with L = 32 b + 4 a
+// + q (b = feature half, a = group of four points, q = point in the group) the slot 16 (a >> 1) + 8 ((a & 1) ^ (s & 1)) +
+// 4 b + q makes every such read conflict-free (svs_wgrad.hip).  A wave still moves the whole 1 KiB per instruction.
+__device__ __forceinline__ int piece_slot(int s, int lane) {
+  const int b = lane >> 5, a = (lane >> 2) & 7, q = lane & 3;
+  return 16 * (a >> 1) + 8 * ((a & 1) ^ (s & 1)) + 4 * b + q;
+}
+
 // one fragment (k-step s) of a plane; plane 0 = hi, 1 = mid
 __device__ __forceinline__ void store_piece(float* __restrict__ blk, int s, int lane, const f16x8& v, int plane = 0) {
-  SVS_STREAM_STORE(as_f4(v), reinterpret_cast<f32x4*>(blk) + plane * kPlaneF4 + s * 64 + lane);
+  SVS_STREAM_STORE(as_f4(v), reinterpret_cast<f32x4*>(blk) + plane * kPlaneF4 + s * 64 + piece_slot(s, lane));
 }
 __device__ __forceinline__ f16x8 load_piece(const float* __restrict__ blk, int s, int lane, int plane = 0) {
-  return as_h8(SVS_STREAM_LOAD(reinterpret_cast<const f32x4*>(blk) + plane * kPlaneF4 + s * 64 + lane));
+  return as_h8(SVS_STREAM_LOAD(reinterpret_cast<const f32x4*>(blk) + plane * kPlaneF4 + s * 64 + piece_slot(s, lane)));
 }
 
 // accumulator-layout tile t (16 registers) back from stored fragments

@@ -200,7 +200,9 @@ __global__ void pair_tiles_to_rows_kernel(const float* __restrict__ tiles, int P
   // row f = 16 s + 8 (j >> 2) + 4 half + (j & 3)
   const int s = f >> 4, w = f & 15, half = (w >> 2) & 1, j = (w & 3) + 4 * (w >> 3), lane = col + 32 * half;
   const _Float16* blk = reinterpret_cast<const _Float16*>(tiles + (size_t)wtile * 128 * 64);
-  const size_t e = ((size_t)s * 64 + lane) * 8 + j;
+  const int b = lane >> 5, a = (lane >> 2) & 7, q = lane & 3;
+  const int slot = 16 * (a >> 1) + 8 * ((a & 1) ^ (s & 1)) + 4 * b + q;        // piece_slot() of svs_blocks_h2.h
+  const size_t e = ((size_t)s * 64 + slot) * 8 + j;
   rows[idx] = (float)blk[e] + (float)blk[e + 1024 * 8];
 }
 

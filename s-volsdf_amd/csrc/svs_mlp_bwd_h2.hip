@@ -359,8 +359,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_h2_kernel(SdfBwdAArgs a
       block_fragment<kPeDim>(u0.v, k, half, ps.s_in, fh, fm);
       store_piece(ub, k, lane, fh);
       block_fragment<kPeDim>(pe.v, k, half, 1.0f, fh, fm);
-      store_piece(pbk, k, lane, fh, 0);
-      store_piece(pbk, k, lane, fm, 1);
+      store_piece(pbk, k, lane, fh, 0);          // (the weight gradient reads hi planes only)
     }
     store_record(ub, lane, ps.s_in, m0);
   }

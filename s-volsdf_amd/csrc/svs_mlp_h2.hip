@@ -334,7 +334,7 @@ struct RgbEpi {
   f32x16 prev;
   float v8[8];
   Pieces2* out;
-  float* rblk;       // this layer's block of rbuf (a PAIR block: r_l is the next weight gradient's B operand) or nullptr
+  float* rblk;       // this layer's block of rbuf (the hi plane of a pair block) or nullptr
   int lane;
   __device__ __forceinline__ void b(int tp, int r) {
     float v;
@@ -345,11 +345,11 @@ struct RgbEpi {
       split8(v8, out->h[2 * tp + (r >> 3)], out->m[2 * tp + (r >> 3)]);
       pin(out->h[2 * tp + (r >> 3)], out->m[2 * tp + (r >> 3)]);
     }
-    // the four stores of the tile behind the LDS-DMA pieces (k-steps 0..9): k-steps 11, 13, 15, 15
+    // r_l is read back by the backward's ReLU mask and as the weight gradient's B operand, both from the hi plane: only
+    // that is stored, behind the LDS-DMA pieces (k-steps 0..9): k-steps 11 and 15
     if (rblk) {
       if (r == 11) store_piece(rblk, 2 * tp, lane, out->h[2 * tp], 0);
-      if (r == 13) store_piece(rblk, 2 * tp, lane, out->m[2 * tp], 1);
-      if (r == 15) { store_piece(rblk, 2 * tp + 1, lane, out->h[2 * tp + 1], 0); store_piece(rblk, 2 * tp + 1, lane, out->m[2 * tp + 1], 1); }
+      if (r == 15) store_piece(rblk, 2 * tp + 1, lane, out->h[2 * tp + 1], 0);
     }
   }
   __device__ __forceinline__ void all(int tp) {
@@ -360,7 +360,7 @@ struct RgbEpi {
 
 // One radiance layer.  The next chunk (N16NEXT_LAST float4 behind the layer's last tile) is fetched in pieces behind the
 // first k-steps of each tile (Stream::prefetch_step: 9 or 10 pieces, k-steps 0..9); the rbuf stores of tile t-1's
-// epilogue are issued in k-steps 11, 13, 15: younger than every piece, they may stay in flight.
+// epilogue are issued in k-steps 11, 15: younger than every piece, they may stay in flight.
 template <int KS, int N16NEXT_LAST>
 __device__ __forceinline__ void rgb_layer_h2(RgbStream& st, const Pieces2& in, Pieces2& out, float* rblk, int lane) {
   RgbEpi ep;
@@ -374,7 +374,7 @@ __device__ __forceinline__ void rgb_layer_h2(RgbStream& st, const Pieces2& in, P
     else if (t < 7) acc = tile_mma_h2_pf<KS, kNext>(st, in, lane, NoEpi(), relu);
     else acc = tile_mma_h2_pf<KS, N16NEXT_LAST>(st, in, lane, NoEpi(), relu);
     ep.prev = acc;
-    if (rblk && t > 0) st.template advance_keep<4>();
+    if (rblk && t > 0) st.template advance_keep<2>();
     else st.advance();
   }
   ep.all(7);

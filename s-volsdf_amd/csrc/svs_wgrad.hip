@@ -139,25 +139,30 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(Args a) {
 
 // --------------------------------------------------------------------------------------------------------------
 // fp16x2 variant: the same contraction on v_mfma_f32_32x32x16_f16, reading the operand blocks in the forms the sweeps
-// store them in (svs_blocks_h2.h): no conversion, no split.
+// store them in (svs_blocks_h2.h): no conversion, no split, no staging registers.
 //   pair 0:  A = abar_l / zbar_l / fbar  HALF block, per-point scale  (gradient-like: one piece)
-//            B = h_l / r_l / feature     PAIR block                   (activation: hi + mid)      -> 2 MFMAs per k-step
+//            B = h_l / r_l / feature     the HI PLANE of a pair block (the gradient's other factor has 11 bits anyway:
+//                                        tools/study/fp16_blocks_error.py, "h_wgrad_hi")
 //   pair 1:  A = ghat_l                  HALF block, unscaled
-//            B = u_l                     HALF block, per-point scale                               -> 1 MFMA per k-step
-//   narrow:  B = the 16 / 32 extra input rows of a radiance network's first layer, ONE float32 tile (converted here)
+//            B = u_l                     HALF block, per-point scale
+//   narrow:  B = the 16 / 32 extra input rows of a radiance network's first layer, ONE float32 tile (split here)
+// One MFMA per k-step and B tile; 32 KiB per item.
 //
-// The contraction index is the POINT, which lives on the lanes of the blocks, so both operands are transposed through
-// LDS: a staging thread copies its fragment (16 B = 2 x 4 consecutive features of one point) with two ds_write_b64 into a
-// [point][feature] image; the MFMA fragments (8 consecutive points of one feature per lane) come back through
-// ds_read_b64_tr_b16, the hardware transpose read.  Images are [32 points][128 features] sub-tiles with 256-byte rows
-// and the chunk swizzle of cdna_hip_programming.md T10 (b): both the 8-byte writes and the transposed reads are
-// conflict-free.
+// The contraction index is the POINT, which lives on the lanes of the fragments.  A 16-KiB plane is copied into LDS as it
+// stands by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction) into a ring of four item slots (A plane, B
+// plane), three items ahead of the one being multiplied; the MFMA fragments (8 consecutive points of one feature per
+// lane) are read TRANSPOSED out of the plane with ds_read_b64_tr_b16 -- the slot permutation of the planes
+// (piece_slot(), svs_blocks_h2.h) is what makes these reads conflict-free: for the 32 lanes of a half
+//     byte = 1024 s + 256 (a >> 1) + 128 ((a & 1) ^ (s & 1)) + 64 (p & 1) + 16 q + 8 (p >> 1)
+// with s = feature / 16 (two values per half: the two 16-lane groups), a = point / 4, q = point % 4, p = the lane's
+// column quad: 32 distinct 8-byte slots of one 256-byte line.
 //
 // Scaled operands carry value * s_p with one power of two s_p per point (the point's largest element at ~2^4); a
-// contraction over points needs ONE scale, so the staging thread multiplies its fragment by s / s_p in fp16 (exact:
-// a power of two), with s chosen from the published maximum of the operand (absmax) so that the largest element of
-// the launch is ~2^10; the accumulators are multiplied by 1 / s before the flush.  Points whose gradients are below
-// 2^-34 of the largest one underflow to zero.
+// contraction over points needs ONE scale, so every A fragment is multiplied by the factors s / s_p of its 8 points in
+// fp16 (exact: powers of two) -- for pair 1 the factors of B's points are applied to A, which is the same product -- with
+// s chosen from the published maximum of the scaled operand (absmax) so that the largest element of the launch is
+// ~2^10; the accumulators are multiplied by 1 / s before the flush.  Factors are clamped to 2^15; points beyond the
+// batch get factor 0.
 // --------------------------------------------------------------------------------------------------------------
 namespace h2 {
 
@@ -167,17 +172,36 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
 #define SVS_LDS(T, ptr) ((__attribute__((address_space(3))) T*)(ptr))
 
-constexpr int kSub = 32 * 256;         // bytes of one [32 points][128 features] fp16 sub-image
-constexpr int kPiece = 2 * kSub;       // 256 features
-constexpr int kExtraPiece = 32 * 64;   // narrow B tile: [32 points][32 features], 64-byte rows
-constexpr int kPlaneF4 = 1024;         // float4 per fp16 plane of a block (svs_blocks_h2.h)
+constexpr int kPlane = 16384;          // bytes of one fp16 plane of a block (svs_blocks_h2.h)
 constexpr int kRecordF = 4096;         // float index of a half block's per-point scale record
+constexpr int kSlot = 2 * kPlane;      // ring slot: A plane, B plane
+constexpr int kRing = 4;
+constexpr int kAhead = kRing - 1;      // items in flight beyond the one being multiplied
+constexpr int kExtraPiece = 32 * 64;   // narrow B tile: [32 points][32 features] fp16, 64-byte rows (hi, then mid)
+constexpr int kNarrowImg = 8192;       // a narrow job has no B plane: its float32 B tile lands (LDS-DMA) at the B plane's
+                                       // place, its fp16 image (hi, mid) kNarrowImg bytes further
+constexpr int kRecBytes = 8 * 256;     // per ring slot: every wave's copy of the scaled operand's record (64 floats)
+constexpr int kFactorBytes = 8 * 64;   // per ring slot: 8 waves x 32 fp16 factors
+constexpr int kSlotAll = kSlot + kRecBytes + kFactorBytes;
+constexpr int kLdsBytes = kRing * kSlotAll;
 
-__device__ __forceinline__ f16x8 tr_frag(const unsigned char* lds, int a0, int a1) {
-  struct Pair { s16x4 lo, hi; } v;
-  v.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SVS_LDS(s16x4, lds + a0));
-  v.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SVS_LDS(s16x4, lds + a1));
-  return __builtin_bit_cast(f16x8, v);
+// LDS reads of the main loop go through inline asm: hipcc's waitcnt pass makes every LDS access it can see wait for ALL
+// LDS-DMA in flight (vmcnt(0): it cannot tell the ring slots apart), which would un-pipeline the ring.  The reads are
+// ordered against the copies by the counted vmcnt waits + barriers of the loop; lds_wait() is the lgkmcnt side.
+struct Frag { s16x4 lo, hi; };
+__device__ __forceinline__ void tr_issue(Frag& v, unsigned a0, unsigned a1) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v.lo) : "v"(a0));
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v.hi) : "v"(a1));
+}
+__device__ __forceinline__ f16x8 frag_of(const Frag& v) { return __builtin_bit_cast(f16x8, v); }
+__device__ __forceinline__ void lds_read128(f32x4& v, unsigned a) { asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a)); }
+__device__ __forceinline__ void lds_read32(float& v, unsigned a) { asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(a)); }
+__device__ __forceinline__ void lds_wait() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);      // hipcc hoists register-only MFMAs above an asm wait otherwise (rule 18)
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(unsigned long long)SVS_LDS(const void, p);
 }
 
 // power-of-two scale from the maximum magnitude: s * absmax in [2^10, 2^11)
@@ -210,21 +234,8 @@ constexpr int kMaxJobs = 20;
 struct MultiArgs { Job job[kMaxJobs]; int n_jobs; };
 
 constexpr int kThreadsW = 512;          // 8 waves: wave w owns output tile w (32 rows) x all B tiles
-// LDS per buffer: A image (one piece), B image hi, B image mid
-constexpr int kBufBytes = 3 * kPiece;
 
-// a wave-uniform global pointer, kept in scalar registers (global_load with an SGPR base + 32-bit lane offset)
-typedef const __attribute__((address_space(1))) f32x4* gptr_f4;
-__device__ __forceinline__ gptr_f4 uniform_f4(const float* p) {
-  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-  return reinterpret_cast<gptr_f4>(((unsigned long long)hi << 32) | lo);
-}
-
-struct Staging4 {
-  f32x4 a[2], b[4];      // A hi plane (2 fragments per thread), B hi + mid planes (pair 0) / B hi plane (pair 1: b[0..1])
-  float sa, sb;          // per-point factors s / s_p of the scaled operands (1 where the operand is not scaled)
-};
+typedef const __attribute__((address_space(1))) void* gvoid;
 
 __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs ma) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_h2[];
@@ -232,7 +243,8 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
   for (int q = 1; q < ma.n_jobs; ++q) if ((int)blockIdx.x >= ma.job[q].wg_begin) jj = q;
   const Job& a = ma.job[jj];
   const int wg = (int)blockIdx.x - a.wg_begin, nwg = a.wg_count;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool narrow = a.b_tiles == 1;
   float s_grad, inv_s;
   scale_from_absmax(a.absmax, s_grad, inv_s);
@@ -242,129 +254,133 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
   for (int i = 0; i < 8; ++i) acc[i] = (f32x16)(0.0f);
   float bsum = 0.0f;     // bias gradient: this lane's row (lane & 31 of the wave's output tile) over its half's points
 
-  // ---- reader addresses (bytes inside an operand piece), see the layout notes above
-  const int ri = lane & 15, rg = (lane >> 4) & 1, rh = lane >> 5, rq = ri >> 2, rp = ri & 3;
-  int rbase[2], rt[4], rx[2], aaddr[2];
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    rbase[e] = 256 * (8 * rh + 4 * e + rq) + 16 * ((2 * rg + (rp >> 1)) ^ ((2 * rh + e) & 3)) + 8 * (rp & 1);
-    rx[e] = 64 * (8 * rh + 4 * e + rq) + 32 * rg + 8 * rp;
-    aaddr[e] = (wave >> 2) * kSub + rbase[e] + 64 * ((wave & 3) ^ rq);
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) rt[j] = 64 * (j ^ rq);
-  // ---- writer addresses.  Fragment (k-step s, lane L) of a plane = features 16 s + 4 (L >> 5) + {0..3} and + 8 of point
-  // L & 31: accumulator tile s >> 1, quarters 2 (s & 1) and 2 (s & 1) + 1.  Thread tid takes k-steps wave and wave + 8.
-  // image offset of (tile, quarter) for this lane: (tile >> 2) kSub + 256 pt + 64 ((tile & 3) ^ (pt & 3)) + 16 (quarter ^
-  // ((pt >> 2) & 3)) + 8 (L >> 5)
+  unsigned char* ring = smem_h2;
+
+  // ---- transposed-read addresses inside a plane (see the header): this lane is row q', column quad p' of its 16-lane
+  // group; group g of its half reads k-step (feature block) 2 tile + g; k-step ks of the contraction adds 512 bytes;
+  // the second read of a fragment (points + 4) flips bit 7
+  const int rq = (lane & 15) >> 2, rp = lane & 3, rg = (lane >> 4) & 1, rh = lane >> 5;
+  const int rd0 = 1024 * rg + 256 * rh + 128 * rg + 64 * (rp & 1) + 16 * rq + 8 * (rp >> 1);
+  const int a_rd = 2048 * wave + rd0;
+  // narrow B image reads ([32 points][32 features], 64-byte rows)
+  const int rx0 = 64 * (8 * rh + rq) + 32 * rg + 8 * rp, rx1 = rx0 + 64 * 4;
+  // narrow B image writer (threads 0..255): float4 tid of the float32 tile = registers 4 (tid >> 6) .. +3 of lane tid & 63
   const int wp = lane & 31, whf = lane >> 5;
-  int woff[2][2];        // [which of the thread's two k-steps][first / second half of the fragment]
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int s = wave + 8 * j, tile = s >> 1;
-#pragma unroll
-    for (int hq = 0; hq < 2; ++hq) {
-      const int quarter = 2 * (s & 1) + hq;
-      woff[j][hq] = (tile >> 2) * kSub + 256 * wp + 64 * ((tile & 3) ^ (wp & 3)) + 16 * (quarter ^ ((wp >> 2) & 3)) + 8 * whf;
-    }
-  }
-  // narrow B image (threads 0..255): float4 tid of the float32 tile = registers 4 (tid >> 6) .. +3 of lane tid & 63
   const int wxoff = 64 * wp + 16 * (wave & 3) + 8 * whf;
 
   const int my_tiles = a.n_tiles > wg ? (a.n_tiles - 1 - wg) / nwg + 1 : 0;
   const int n_items = my_tiles * a.n_pairs;
-  Staging4 st;
-  int st_live = 32, st_pair = 0;
 
+  // ---- issue the LDS-DMA of one item into its ring slot: wave w copies the 1-KiB fragments w, w + 8 of every plane, its
+  // own copy of the scaled operand's record, and (narrow job) quarter w & 3 of the float32 B tile.  Everything goes
+  // through LDS-DMA: with no register loads in the loop the only vmcnt waits are the counted ones below.
   auto issue = [&](int item) {
     const int t = wg + (item / a.n_pairs) * nwg, pi = item % a.n_pairs;
     const Pair& p = a.p[pi];
     const float* pa = p.a + (size_t)t * p.stride_a;
     const float* pb = p.b + (size_t)t * p.stride_b;
-    gptr_f4 ga = uniform_f4(pa);
-    gptr_f4 gb = uniform_f4(pb);
-    // branch-free: registers defined on one side of a branch only would be merged by copies that wait for the loads.
-    // A narrow B block has 256 float4: every B load of a narrow job re-reads float4 tid & 255 (only b[0] is used); pair 1
-    // has no mid plane: its b[2], b[3] re-read the hi plane (unused).
-    const int mid = (pi == 0 && !narrow) ? kPlaneF4 : 0;
+    unsigned char* slot = ring + (item % kRing) * kSlotAll;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      st.a[j] = SVS_STREAM_LOAD(ga + j * kThreadsW + tid);
-      st.b[j] = SVS_STREAM_LOAD(gb + (narrow ? (tid & 255) : j * kThreadsW + tid));
-      st.b[2 + j] = SVS_STREAM_LOAD(gb + (narrow ? (tid & 255) : mid + j * kThreadsW + tid));
+      const int piece = wave + 8 * j;
+      __builtin_amdgcn_global_load_lds((gvoid)(reinterpret_cast<const f32x4*>(pa) + piece * 64 + lane),
+                                       SVS_LDS(void, slot + piece * 1024), 16, 0, 0);
+      if (!narrow)
+        __builtin_amdgcn_global_load_lds((gvoid)(reinterpret_cast<const f32x4*>(pb) + piece * 64 + lane),
+                                         SVS_LDS(void, slot + kPlane + piece * 1024), 16, 0, 0);
     }
-    // per-point rescale factors of the scaled operands: pair 0 scales A (abar-like), pair 1 scales B (u)
-    st_live = a.n_valid_points - t * 32;
-    float sa = 1.0f, sb = 1.0f;
-    if (a.absmax && wp < st_live) {
-      const float rec = pi == 0 ? pa[kRecordF + wp] : pb[kRecordF + wp];
-      // s / s_p: rec is a power of two in [2^-103, 2^103] (PointScale::pow2_for); anything else (a block that was
-      // never written) leaves the factor at 1
+    if (narrow)
+      __builtin_amdgcn_global_load_lds((gvoid)(reinterpret_cast<const f32x4*>(pb) + (wave & 3) * 64 + lane),
+                                       SVS_LDS(void, slot + kPlane + (wave & 3) * 1024), 16, 0, 0);
+    // scale record of the scaled operand: pair 0 scales A (abar-like), pair 1 B (u); applied to A either way
+    if (a.absmax)
+      __builtin_amdgcn_global_load_lds((gvoid)((pi == 0 ? pa : pb) + kRecordF + lane),
+                                       SVS_LDS(void, slot + kSlot + wave * 256), 4, 0, 0);
+  };
+  // number of vector-memory operations issue() makes per wave and item
+  const int ops = (narrow ? 3 : 4) + (a.absmax ? 1 : 0);
+
+  // ---- per-item set-up once the wave's own copies have landed: its factor table; (narrow job) the fp16 B image -- whose
+  // float32 source quarters were copied by waves 0..3, hence after the barrier
+  auto stage_factors = [&](int item) {
+    unsigned char* slot = ring + (item % kRing) * kSlotAll;
+    const int t = wg + (item / a.n_pairs) * nwg;
+    const int live = a.n_valid_points - t * 32;
+    float f = 1.0f;
+    if (a.absmax) {
+      // s / s_p: the record is a power of two in [2^-107, 2^107] (PointScale::pow2_for); anything else (a block that
+      // was never written) leaves the factor at 1
+      float rec;
+      lds_read32(rec, lds_addr(slot + kSlot + wave * 256 + 4 * wp));
+      lds_wait();
       const unsigned eb = (__float_as_uint(rec) >> 23) & 0xff;
-      const float f = (eb >= 20 && eb <= 240) ? s_grad * __uint_as_float((254u << 23) - __float_as_uint(rec)) : 1.0f;
-      sa = pi == 0 ? f : 1.0f;
-      sb = pi == 0 ? 1.0f : f;
+      if (eb >= 20 && eb <= 240) f = __builtin_fminf(s_grad * __uint_as_float((254u << 23) - __float_as_uint(rec)), 32768.0f);
     }
-    st.sa = sa; st.sb = sb;
-    st_pair = pi;
+    if (wp >= live) f = 0.0f;
+    if (lane < 32) *SVS_LDS(_Float16, slot + kSlot + kRecBytes + wave * 64 + 2 * lane) = (_Float16)f;
   };
-  // frag * f in fp16, f a power of two: exact unless the product leaves fp16's range.  f itself may exceed fp16's range
-  // (a point whose scale was set by its floor, far above the values of this block): it is applied as two factors
-  auto put8 = [&](unsigned char* image, int off0, int off1, const f32x4& frag, float f, bool scaled) {
-    struct Halves { f16x4 lo, hi; } v = __builtin_bit_cast(Halves, frag);
-    if (scaled) {
-      const float f1 = __builtin_fminf(f, 32768.0f), f2 = f / f1;
-      const _Float16 h1 = (_Float16)f1, h2 = (_Float16)__builtin_fminf(f2, 32768.0f);
-      const f16x4 a4 = {h1, h1, h1, h1}, b4 = {h2, h2, h2, h2};
-      v.lo = (v.lo * a4) * b4; v.hi = (v.hi * a4) * b4;
-    }
-    *SVS_LDS(f16x4, image + off0) = v.lo;
-    *SVS_LDS(f16x4, image + off1) = v.hi;
-  };
-  auto put_f32 = [&](unsigned char* piece_hi, unsigned char* piece_mid, int off, const f32x4& v) {
-    f16x4 hi, mid;
+  auto stage_narrow = [&](int item) {
+    unsigned char* slot = ring + (item % kRing) * kSlotAll;
+    if (tid < 256) {
+      f32x4 v;
+      lds_read128(v, lds_addr(slot + kPlane + tid * 16));
+      lds_wait();
+      f16x4 hi, mid;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const _Float16 h = (_Float16)v[j];
-      hi[j] = h;
-      mid[j] = (_Float16)(v[j] - (float)h);
-    }
-    *SVS_LDS(f16x4, piece_hi + off) = hi;
-    *SVS_LDS(f16x4, piece_mid + off) = mid;
-  };
-  auto commit = [&](int buf) {
-    unsigned char* la = smem_h2 + buf * kBufBytes;
-    unsigned char* lb = la + kPiece;
-    const bool p0 = st_pair == 0;
-    const float fa = st.sa, fb = st.sb;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      f32x4 va = st.a[j];
-      if (wp >= st_live) va = (f32x4)(0.0f);     // ragged last tile: points beyond the batch contribute nothing
-      put8(la, woff[j][0], woff[j][1], va, fa, p0 && a.absmax);
-      if (!narrow) {
-        put8(lb, woff[j][0], woff[j][1], st.b[j], fb, !p0 && a.absmax);
-        if (p0) put8(lb + kPiece, woff[j][0], woff[j][1], st.b[2 + j], fb, false);
+      for (int j = 0; j < 4; ++j) {
+        const _Float16 h = (_Float16)v[j];
+        hi[j] = h;
+        mid[j] = (_Float16)(v[j] - (float)h);
       }
+      *SVS_LDS(f16x4, slot + kPlane + kNarrowImg + wxoff) = hi;
+      *SVS_LDS(f16x4, slot + kPlane + kNarrowImg + kExtraPiece + wxoff) = mid;
     }
-    if (narrow && tid < 256) put_f32(lb, lb + kExtraPiece, wxoff, st.b[0]);
   };
 
   const f16x2 one2 = {(_Float16)1.0f, (_Float16)1.0f};
 
-  if (n_items > 0) { issue(0); commit(0); }
-  __syncthreads();
+  // ---- prologue: kAhead items in flight
+  for (int i0 = 0; i0 < kAhead && i0 < n_items; ++i0) issue(i0);
   for (int item = 0; item < n_items; ++item) {
-    const int buf = item & 1;
-    const bool more = item + 1 < n_items;
-    const bool p0 = (item % a.n_pairs) == 0;
-    if (more) issue(item + 1);
-    const unsigned char* la = smem_h2 + buf * kBufBytes;
-    const unsigned char* lb = la + kPiece;
+    const int pi = item % a.n_pairs;
+    const bool p0 = pi == 0;
+    // the item's own operations are the oldest outstanding ones of this wave: wait until only those of the later items
+    // (up to kAhead - 1 of them) remain; then everybody's have landed after the barrier -- which also says that every wave
+    // is done with the slot of item - 1, the one item + kAhead is about to be copied into
+    {
+      const int left = n_items - 1 - item;
+      const int later = (left < kAhead - 1 ? left : kAhead - 1) * ops;        // 0, ops or 2 ops: 0, 3, 4, 5, 6, 8, 10
+      if (later == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else if (later == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (later == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (later == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else if (later == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (later == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // (raw s_barrier: __syncthreads() carries a fence that hipcc lowers to vmcnt(0), which would also wait for the
+    // next item's copies)
+    stage_factors(item);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (narrow) {
+      stage_narrow(item);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if (item + kAhead < n_items) issue(item + kAhead);
+    const unsigned la = lds_addr(ring + (item % kRing) * kSlotAll);
+    const unsigned lb = la + kPlane;
+    const unsigned ftab = la + kSlot + kRecBytes + wave * 64;
+    const unsigned nimg = lb + kNarrowImg;
     const bool want_bias = a.db && p0;
+    const bool two = narrow;             // only the narrow float32 tile is split into two pieces
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const f16x8 ah = tr_frag(la + ks * 4096, aaddr[0], aaddr[1]);
+      Frag fa;
+      f32x4 fraw;
+      tr_issue(fa, la + 512 * ks + a_rd, la + 512 * ks + (a_rd ^ 128));
+      lds_read128(fraw, ftab + 32 * ks + 16 * rh);        // the factors of the fragment's 8 points (16 ks + 8 half + 0..7)
+      lds_wait();
+      const f16x8 ah = frag_of(fa) * __builtin_bit_cast(f16x8, fraw);
       if (want_bias) {
         // row sums of A: the fragment holds 8 points of row lane & 31 (the other lane half holds the other 8)
 #pragma unroll
@@ -374,25 +390,22 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
         }
       }
       // the two waves of a SIMD cover each other's LDS latency: no software pipelining of the B fragments
-      const bool two = p0 || narrow;       // B has a mid piece
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         if (i > 0 && narrow) break;
-        f16x8 bh, bm;
+        Frag fh, fm;
         if (!narrow) {
-          const unsigned char* base = lb + (i >> 2) * kSub + ks * 4096;
-          bh = tr_frag(base, rbase[0] + rt[i & 3], rbase[1] + rt[i & 3]);
-          if (two) bm = tr_frag(base + kPiece, rbase[0] + rt[i & 3], rbase[1] + rt[i & 3]);
+          const unsigned rd = lb + 2048 * i + 512 * ks + rd0;
+          tr_issue(fh, rd, rd ^ 128);
         } else {
-          bh = tr_frag(lb + ks * 1024, rx[0], rx[1]);
-          bm = tr_frag(lb + kExtraPiece + ks * 1024, rx[0], rx[1]);
+          tr_issue(fh, nimg + ks * 1024 + rx0, nimg + ks * 1024 + rx1);
+          tr_issue(fm, nimg + kExtraPiece + ks * 1024 + rx0, nimg + kExtraPiece + ks * 1024 + rx1);
         }
-        if (two) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bm, acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i], 0, 0, 0);
+        lds_wait();
+        if (two) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, frag_of(fm), acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, frag_of(fh), acc[i], 0, 0, 0);
       }
     }
-    if (more) commit(buf ^ 1);
-    __syncthreads();
   }
   // flush: C[row = rho(r) + 4*half][col]; two 128-byte row segments per wave-instruction
   const int half = lane >> 5, col = lane & 31;
@@ -483,7 +496,7 @@ int svs_wgrad_multi(const svs_wgrad_job* jobs, int n_jobs, int precision, void* 
       ma.job[j].wg_begin = begin; ma.job[j].wg_count = (int)c;
       begin += (int)c;
     }
-    constexpr int lds = 2 * h2::kBufBytes;
+    constexpr int lds = h2::kLdsBytes;
     static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(h2::wgrad_h2_multi_kernel),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) { set_error("svs_wgrad_multi: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }

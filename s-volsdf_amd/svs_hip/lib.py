@@ -7,7 +7,8 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsvolsdf_hip.so")
+# SVS_LIB_PATH: another build of the same library (A/B timing of kernel variants on one box, tools/ab_variant.sh)
+LIB_PATH = os.environ.get("SVS_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libsvolsdf_hip.so")
 
 _lib = None
 

@@ -337,15 +337,15 @@ def algorithmic_bytes_per_point(precision=None):
     512, a HALF block 512.
       svs_sdf_bwd_a   reads h_1..h_8 (hi planes), ghat_0..ghat_7; writes u_0..u_8, a2_0..a2_7, the PE block
       svs_sdf_bwd_b   reads h_1..h_8 (hi planes), a2_0..a2_7, ghat_7, fbar; writes abar_0..abar_7
-      wgrad_sdf       per layer abar_l, h_l (pair), ghat_l, u_l (l = 0..7) + fbar, h_8 (pair) for lin8
-      wgrad_radiance  zbar_0..zbar_4, r_0..r_3 (pair), the feature block (pair), the 16 extra input rows"""
+      wgrad_sdf       per layer abar_l, h_l (hi plane), ghat_l, u_l (l = 0..7) + fbar, h_8 (hi plane) for lin8
+      wgrad_radiance  zbar_0..zbar_4, r_0..r_3 (hi planes), the feature block (hi plane), the 16 extra input rows"""
     precision = default_precision() if precision is None else precision
     if precision == F16X2:
         half, pair = 512, 1024
         return {"svs_sdf_bwd_a": 8 * half + 8 * half + 9 * half + 8 * half + pair,
                 "svs_sdf_bwd_b": 8 * half + 8 * half + half + half + 8 * half,
-                "wgrad_sdf": 8 * (half + pair + half + half) + half + pair,
-                "wgrad_radiance": 5 * half + 4 * pair + pair + 128}
+                "wgrad_sdf": 8 * (half + half + half + half) + half + half,
+                "wgrad_radiance": 5 * half + 4 * half + half + 128}
     blk = 1024
     return {"svs_sdf_bwd_a": (8 + 8 + 9 + 8 + 1) * blk, "svs_sdf_bwd_b": (8 + 8 + 1 + 1 + 8) * blk,
             "wgrad_sdf": (8 * 4 + 2) * blk, "wgrad_radiance": (5 + 4 + 1) * blk + 128}

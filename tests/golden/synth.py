@@ -243,6 +243,12 @@ def _fragment_index(Fdim):
     return s, j, half
 
 
+def _piece_slot(s, lane):
+    """piece_slot() of csrc/svs_blocks_h2.h"""
+    b, a, q = lane >> 5, (lane >> 2) & 7, lane & 3
+    return 16 * (a >> 1) + 8 * ((a & 1) ^ (s & 1)) + 4 * b + q
+
+
 def rows_to_pair_block(x):
     """(P, F<=256) float32 rows -> PAIR blocks of the fp16x2 kernels (csrc/svs_blocks_h2.h), (ceil(P/32), 128*64)
     float32 words: hi plane [16 k-steps][64 lanes][8 fp16], then the mid plane, value = hi + mid."""
@@ -254,8 +260,9 @@ def rows_to_pair_block(x):
     s, j, half = _fragment_index(Fdim)
     p = np.arange(P)
     wt, lane = (p // 32)[:, None], (p % 32)[:, None] + 32 * half[None, :]
-    out[wt, 0, s[None, :], lane, j[None, :]] = hi
-    out[wt, 1, s[None, :], lane, j[None, :]] = mid
+    slot = _piece_slot(s[None, :], lane)
+    out[wt, 0, s[None, :], slot, j[None, :]] = hi
+    out[wt, 1, s[None, :], slot, j[None, :]] = mid
     return out.reshape(nt, -1).view(F32)
 
 
@@ -277,7 +284,7 @@ def rows_to_half_block(x, scaled=True):
     s, j, half = _fragment_index(Fdim)
     p = np.arange(P)
     wt, lane = (p // 32)[:, None], (p % 32)[:, None] + 32 * half[None, :]
-    planes[wt, s[None, :], lane, j[None, :]] = hi
+    planes[wt, s[None, :], _piece_slot(s[None, :], lane), j[None, :]] = hi
     words = out.view(F32).reshape(nt, 128 * 64)
     rec = np.ones((nt, 64), F32)
     rec[:, 32:] = 0.0

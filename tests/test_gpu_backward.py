@@ -63,14 +63,14 @@ def test_composite_backward(dev, ops, beta):
 def _operands(precision, A0, B0, A1, B1, dev):
     """Device blocks of the two operand pairs in the form the kernels of that precision read, and the values those blocks
     really hold (fp16x2: A of pair 0 and B of pair 1 are HALF blocks under a per-point scale, A of pair 1 an unscaled
-    half block, B of pair 0 a PAIR block -- csrc/svs_blocks_h2.h)."""
+    half block, B of pair 0 the hi plane of a PAIR block -- csrc/svs_blocks_h2.h)."""
     if precision == 0:
         return [G(synth.rows_to_tiles(x), dev) for x in (A0, B0, A1, B1)], (A0, B0, A1, B1)
     a0, A0q = synth.rows_to_half_block(A0)
     b0 = synth.rows_to_pair_block(B0)
     a1, A1q = synth.rows_to_half_block(A1, scaled=False)
     b1, B1q = synth.rows_to_half_block(B1)
-    B0q = B0.astype(np.float16).astype(F32) + (B0 - B0.astype(np.float16).astype(F32)).astype(np.float16).astype(F32)
+    B0q = B0.astype(np.float16).astype(F32)          # the weight gradient reads the hi plane of B's pair block
     return [G(x, dev) for x in (a0, b0, a1, b1)], (A0q, B0q, A1q, B1q)
 
 

@@ -197,7 +197,8 @@ def test_bg_train_steps_fused(dev, golden_dir):
             np.testing.assert_allclose(float(lo[k]), float(g[f"s{step}_{k}"]), rtol=3e-4 if step == 0 else 5e-3, atol=2e-6,
                                        err_msg=f"step {step} {k}")
         norm = float(ts.opt.info[0])
-        np.testing.assert_allclose(norm, float(g[f"s{step}_grad_norm"]), rtol=2e-3)
+        np.testing.assert_allclose(norm, float(g[f"s{step}_grad_norm"]), rtol=3e-4 if step == 0 else 5e-3,
+                                   err_msg=f"gradient norm, step {step}")
         coef = min(1.0, 1.0 / (float(g[f"s{step}_grad_norm"]) + 1e-6))
         rel = tensor_rel(step, "grad", [(n, p.grad / coef) for n, p in m.named_parameters()])
         worst = max(rel, key=rel.get)

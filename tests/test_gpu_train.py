@@ -95,7 +95,9 @@ def test_train_steps_fused(dev, golden_dir, fixture, groups):
                                        err_msg=f"step {step} {k}")
         # gradient norm before clipping (info[0]) and the raw gradients: the flat grad buffer holds the CLIPPED grads
         norm = float(ts.opt.info[0])
-        np.testing.assert_allclose(norm, float(g[f"s{step}_grad_norm"]), rtol=1e-3)
+        # (step 0: identical parameters; later steps: parameters differ by Adam's sign noise on ~zero gradients)
+        np.testing.assert_allclose(norm, float(g[f"s{step}_grad_norm"]), rtol=2e-4 if step == 0 else 5e-3,
+                                   err_msg=f"gradient norm, step {step}")
         coef = min(1.0, 1.0 / (float(g[f"s{step}_grad_norm"]) + 1e-6))
         named_g = [(n, p.grad / coef) for n, p in m.named_parameters()]
         rel = _tensor_rel(g, step, "grad", named_g)
@@ -144,7 +146,8 @@ def test_train_step_autograd_bridge(dev, golden_dir):
                           frac_ok=0.995)
         assert max(rel.values()) < (2e-3 if step == 0 else 3e-2), rel
         norm = torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
-        np.testing.assert_allclose(float(norm), float(g[f"s{step}_grad_norm"]), rtol=1e-3)
+        np.testing.assert_allclose(float(norm), float(g[f"s{step}_grad_norm"]), rtol=2e-4 if step == 0 else 5e-3,
+                                   err_msg=f"gradient norm, step {step}")
         opt.step()
         np.testing.assert_allclose(float(lo['loss'].detach()), float(g[f"s{step}_loss"]), rtol=2e-4 if step == 0 else 5e-3)
         _check_digest(g, step, "param", list(m.named_parameters()), rtol=0.0, atol=3e-5, frac_ok=0.97 - 0.02 * step)

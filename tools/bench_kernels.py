@@ -63,6 +63,17 @@ def main():
     d_sdf = torch.randn(n_main, 1, device=dev) * 1e-3
     d_gt = torch.randn(n_total - n_main, 3, device=dev) * 1e-3
     res["backward_total"] = dict(ms=timeit(lambda: bw.run(sdf_p, rgb_p, keep, d_rgb, d_sdf, d_gt), n=5))
+    # the two multi-layer weight-gradient launches of a step, replayed alone (arguments recorded from one backward)
+    rec = []
+    orig = L.svs_wgrad_multi
+    L.svs_wgrad_multi = lambda *a: (rec.append(a), orig(*a))[1]
+    bw.run(sdf_p, rgb_p, keep, d_rgb, d_sdf, d_gt)
+    L.svs_wgrad_multi = orig
+    torch.cuda.synchronize()
+    for a in rec:
+        name = "wgrad_multi_%d_layers" % a[1]
+        t = timeit(lambda: lib.check(orig(a[0], a[1], a[2], ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))))
+        res[name] = dict(ms=t)
     P = lambda x: ctypes.c_void_p(x.data_ptr())
     st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     dn = torch.empty(n_main, 3, device=dev)
@@ -95,7 +106,7 @@ def main():
                                              None, 0, n_main, prec, _off(am, 2) if h2 else None, P(dW), 288, P(db), st())))
     res["wgrad_1pair"] = dict(ms=t, tflops=2 * 256 * 256 * n_main / t / 1e9)
     if True:
-        res["lin8_row0"] = dict(ms=timeit(lambda: lib.check(L.svs_lin8_row0_grad(P(hbuf), P(bw.ubuf), P(bw.sbar), n_total, P(row0), st()))))
+        res["lin8_row0"] = dict(ms=timeit(lambda: lib.check(L.svs_lin8_row0_grad(P(hbuf), P(bw.ubuf), P(bw.sbar), n_total, prec, P(row0), st()))))
     print(json.dumps({k: {a: round(b, 3) for a, b in v.items()} for k, v in res.items()}))
 
 

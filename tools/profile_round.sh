@@ -1,10 +1,10 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence committed under profiles/ (run on the GPU box through gpurun):
-#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/profile_round.sh r01'
-# then, back in the container:  python tools/summarize_profiles.py gpurun_out/r01 r01
+#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/profile_round.sh r02'
+# then, back in the container:  python tools/summarize_profiles.py gpurun_out/r02 r02
 # Kernel trace and counter passes are separate runs (a --pmc pass never carries a trace domain besides the kernel
 # dispatch records rocprofv3 adds by itself); the program follows "--" directly.
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 rm -rf "$O"; mkdir -p "$O"
@@ -13,10 +13,12 @@ B="python3 $R/bench.py --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats -d $O/train --output-format csv -- $B --steps 20 --warmup 10 > $O/train.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/render --output-format csv -- $B --mode render --steps 20 --warmup 10 > $O/render.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/train_onegroup --output-format csv -- $B --steps 20 --warmup 10 --groups none > $O/onegroup.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch --output-format csv -- $B --steps 3 --warmup 2 > $O/f.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write --output-format csv -- $B --steps 3 --warmup 2 > $O/w.log 2>&1
+# counter passes: few steps, no settle phase / extra passes (every dispatch is serialised under --pmc)
+C="$B --steps 3 --warmup 2 --settle 0 --no-kernel-timing"
+rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch --output-format csv -- $C > $O/f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write --output-format csv -- $C > $O/w.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE \
-  -d $O/pmc_mfma --output-format csv -- $B --steps 3 --warmup 2 --groups none > $O/m.log 2>&1
+  -d $O/pmc_mfma --output-format csv -- $C --groups none > $O/m.log 2>&1
 cd $R
 # keep what travels back small: the stats files and the counter tables only
 find $O -name '*kernel_trace.csv' -delete

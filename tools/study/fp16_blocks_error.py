@@ -86,10 +86,11 @@ def manual_backward(W, b, x, nbar, sbar, fbar, quant):
         hb = abar[l] @ W[l]
         hbar = hb[:, :217] / np.sqrt(2) if l == 4 else hb
     abar_st = [Q("abar", v) for v in abar]
-    dW = [abar_st[l].T @ hin[l] + ghat_st[l].T @ uin_st[l] for l in range(8)]
+    hin_w = [hi_piece(v) if "h_wgrad_hi" in quant else v for v in hin]       # the weight gradient's B operand
+    dW = [abar_st[l].T @ hin_w[l] + ghat_st[l].T @ uin_st[l] for l in range(8)]
     db = [abar_st[l].sum(0) for l in range(8)]
     a8bar = torch.cat([sbar, fbar], 1)
-    dW8 = a8bar.T @ h[8]
+    dW8 = a8bar.T @ hin_w[8]
     dW8[0] += (g[8][:1] * 0).sum()            # (row 0 also receives u_8 through n: added below)
     dW8[0] += u_st[8].sum(0)
     dW.append(dW8); db.append(a8bar.sum(0))
@@ -141,7 +142,7 @@ def main():
         chk = max(float((a - r).abs().max() / r.abs().max()) for a, r in zip(exact_W + exact_b, ref_W + ref_b))
         print(f"[{label}] {x.shape[0]} points; manual algebra vs float64 autograd: worst rel {chk:.2e}")
         for quant in (("abar",), ("u",), ("a2",), ("ghat",), ("ghat", "ghat_unscaled"), ("h_hi",), ("abar", "u", "a2", "ghat"),
-                      ("abar", "u", "a2", "ghat", "h_hi")):
+                      ("abar", "u", "a2", "ghat", "h_hi"), ("h_wgrad_hi",), ("abar", "u", "a2", "ghat", "h_hi", "h_wgrad_hi")):
             qW, qb = manual_backward(W, b, x, nbar, sbar, fbar, set(quant))
             relmax = [float((a - r).abs().max() / r.abs().max()) for a, r in zip(qW + qb, ref_W + ref_b)]
             rel2 = [float((a - r).norm() / r.norm()) for a, r in zip(qW + qb, ref_W + ref_b)]
