@@ -96,18 +96,20 @@ def loss_fn(out, rgb, rgb_smooth, it, *, eikonal_weight=0.1, rgb_weight=1.0, mvs
     return total + rgb_weight * rgb_loss
 
 
-def forward_differentiable(p, cam, dirs, z, eik_points, depth_scale, radius=3.0, scale=20.0):
-    """VolSDFNetwork.forward after the sampler (network.py:226-268), train mode."""
+def forward_differentiable(p, cam, dirs, z, eik_points, depth_scale, radius=3.0, scale=20.0, device=None):
+    """VolSDFNetwork.forward after the sampler (network.py:226-268), train mode.  device: where the parameters live
+    (None: CPU; inputs may then be numpy arrays or tensors)."""
     R, S = z.shape
     dt = p["density.beta"].dtype
-    cam_t, dirs_t, z_t = (torch.tensor(np.asarray(a), dtype=dt) for a in (cam, dirs, z))
+    conv = lambda a: (a.detach().to(device=device, dtype=dt) if torch.is_tensor(a)
+                      else torch.tensor(np.asarray(a), dtype=dt, device=device))
+    cam_t, dirs_t, z_t = conv(cam), conv(dirs), conv(z)
     pts = (cam_t.view(1, 1, 3) + z_t.unsqueeze(2) * dirs_t.unsqueeze(1)).reshape(-1, 3)
     sdf, feat, grad = sdf_outputs(p, pts, radius, scale)
     dflat = dirs_t.unsqueeze(1).repeat(1, S, 1).reshape(-1, 3)
     rgb = rgb_mlp(p, pts, grad, dflat, feat).reshape(R, S, 3)
-    w, rgb_values, depth_values = composite(z_t, sdf.reshape(R, S), rgb, p["density.beta"],
-                                            torch.tensor(np.asarray(depth_scale), dtype=dt))
-    _, _, gt = sdf_outputs(p, torch.tensor(np.asarray(eik_points), dtype=dt), clamp=False)
+    w, rgb_values, depth_values = composite(z_t, sdf.reshape(R, S), rgb, p["density.beta"], conv(depth_scale))
+    _, _, gt = sdf_outputs(p, conv(eik_points), clamp=False)
     return dict(rgb_values=rgb_values, depth_values=depth_values, weights=w, grad_theta=gt, sdf=sdf, rgb=rgb)
 
 

@@ -118,8 +118,8 @@ def sample_points(n, seed):
     return x.astype(F32)
 
 
-def fx_sdf_mlp():
-    params = synth.make_params(seed=0)
+def fx_sdf_mlp(wset="w0"):
+    params = synth.WEIGHT_SETS[wset]()
     m = build_model(params)
     x = sample_points(96, 3)
     net = m.implicit_network
@@ -128,7 +128,7 @@ def fx_sdf_mlp():
         sdfv = net.get_sdf_vals(T(x)).numpy()
     sdf, feat, grad = net.get_outputs(T(x).clone())
     g2 = net.gradient(T(x).clone())
-    save("sdf_mlp", seed=0, x=x, out=out, sdf_vals=sdfv, sdf=sdf.detach().numpy(), feat=feat.detach().numpy(),
+    save("sdf_mlp" if wset == "w0" else f"sdf_mlp_{wset}", seed=0, x=x, out=out, sdf_vals=sdfv, sdf=sdf.detach().numpy(), feat=feat.detach().numpy(),
          grad=grad.detach().numpy(), grad_raw=g2.detach().numpy())
 
 
@@ -243,6 +243,27 @@ def fx_composite():
     with torch.no_grad():
         w, dists = m.volume_rendering(T(z), T(sdf).reshape(-1, 1))
     save("composite", z=z, sdf=sdf, rgb=rgb, beta_param=F32(0.03), weights=w.numpy(), dists=dists.numpy())
+
+
+def fx_forward_w1():
+    """The trained-scale weight set (synth.make_trained_params): eval render with the full sampler at the set's own
+    beta = 0.005, and a train-mode forward."""
+    params = synth.WEIGHT_SETS["w1"]()
+    K, pose = synth.make_camera(center=(0.1, 0.05, -2.5), tilt=0.1, skew=0.7)
+    R = 12
+    uv = synth.make_uv(R, seed=3, margin=0.1)
+    inp = {"intrinsics": T(K)[None], "uv": T(uv)[None], "pose": T(pose)[None]}
+    m = build_model(params, beta=float(params["density.beta"]))
+    m.eval()
+    out = m(inp, fast=-1)
+    save("forward_w1_eval", K=K, pose=pose, uv=uv, beta_param=params["density.beta"], fast=-1,
+         **{k: v.detach().numpy() for k, v in out.items()})
+    m.train()
+    draws = synth.make_train_rng(R, seed=6)
+    with inject_rng(draws):
+        out = m(inp, fast=1)
+    save("forward_w1_train", K=K, pose=pose, uv=uv, beta_param=params["density.beta"], fast=1, rng_seed=6,
+         **{k: v.detach().numpy() for k, v in out.items()})
 
 
 def fx_forward():
@@ -455,14 +476,14 @@ def param_digest(named, seed=0, k=48):
     return out
 
 
-def fx_train_step(R=16, n_steps=3, name="train_step"):
+def fx_train_step(R=16, n_steps=3, name="train_step", wset="w0"):
     """Three optimisation steps of the reference: VolSDFNetwork + cost_mapping + VolSDFLoss + clip + guard + Adam
     (volsdf/vsdf.py:196-219), 16 rays, injected random draws (seed = 100 + step).  `train_step_r32`: two steps with 32
     rays, the smallest batch that splits into two ray groups (a group needs rays * 98 samples to be a multiple of 32)."""
     from volsdf.vsdf import VolOpt
     from volsdf.model.loss import VolSDFLoss
-    params = synth.make_params(seed=0)
-    m = build_model(params, beta=0.1)
+    params = synth.WEIGHT_SETS[wset]()
+    m = build_model(params, beta=float(params["density.beta"]))
     m.train()
     views = synth.make_mvs_views(5)
     K, pose = views[0]["K"], views[0]["c2w"]
@@ -665,6 +686,8 @@ def fx_featurenet():
 
 ALL = dict(fusion=fx_fusion, pfm=fx_pfm, chamfer=fx_chamfer, featurenet=fx_featurenet, rays=fx_rays, sdf_mlp=fx_sdf_mlp, rgb_mlp=fx_rgb_mlp, density=fx_density, sampler=fx_sampler,
            composite=fx_composite, forward=fx_forward, forward_bg=fx_forward_bg, cost_mapping=fx_cost_mapping, loss=fx_loss, casmvs=fx_casmvs, train_step=fx_train_step, train_step_r32=lambda: fx_train_step(32, 2, "train_step_r32"),
+           sdf_mlp_w1=lambda: fx_sdf_mlp("w1"), forward_w1=fx_forward_w1,
+           train_step_w1=lambda: fx_train_step(16, 2, "train_step_w1", "w1"),
            train_step_bg=fx_train_step_bg)
 
 if __name__ == "__main__":

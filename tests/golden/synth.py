@@ -58,6 +58,58 @@ def make_params(seed=0, trained=True):
     return p
 
 
+def make_trained_params(seed=1):
+    """A second weight set at the scale of a TRAINED network (make_params stays near the geometric initialisation):
+    log-normal spread of the weight-norm gains (up to ~3x), dense perturbations of the directions incl. the
+    positional-encoding columns of lin0, larger biases, a radiance network with 1.35x gains, beta = 0.005.  A fifth to a
+    third of the pre-activations lie beyond +-0.2 (softplus(beta=100) is the identity / zero there), activations reach
+    ~15, d sdf/dx up to ~20.  The sdf bias is re-centred so that the zero level set stays inside the scene (most rays
+    cross a surface).  Everything seeded: fixtures store only the seed."""
+    rng = np.random.default_rng(1000 + seed)
+    p = dict(make_params(seed))
+    for l in range(9):
+        v = p[f"implicit_network.lin{l}.weight_v"].astype(np.float64)
+        g = p[f"implicit_network.lin{l}.weight_g"].astype(np.float64)
+        b = p[f"implicit_network.lin{l}.bias"].astype(np.float64)
+        if l < 8:
+            v = v + rng.normal(0, 0.02, v.shape)
+            if l == 0:
+                v[:, 3:] += rng.normal(0, 0.01, v[:, 3:].shape)
+            g = g * np.exp(rng.normal(0.05, 0.2, g.shape))
+            b = b + rng.normal(0, 0.05, b.shape)
+        else:
+            v[1:] = v[1:] + rng.normal(0, 0.05, v[1:].shape)
+            g[1:] = g[1:] * np.exp(rng.normal(0, 0.3, g[1:].shape))
+            b[1:] += rng.normal(0, 0.1, b[1:].shape)
+        p[f"implicit_network.lin{l}.weight_v"] = v.astype(F32)
+        p[f"implicit_network.lin{l}.weight_g"] = g.astype(F32)
+        p[f"implicit_network.lin{l}.bias"] = b.astype(F32)
+    for l in range(5):
+        g = p[f"rendering_network.lin{l}.weight_g"].astype(np.float64)
+        p[f"rendering_network.lin{l}.weight_g"] = (g * np.exp(rng.normal(0.3, 0.3, g.shape))).astype(F32)
+    p["density.beta"] = np.asarray(0.005, F32)
+    # re-centre: sdf = 0 on average over the sphere |x| = 0.7 (float64 forward of the weight-normed network)
+    d = rng.normal(0, 1, (2048, 3))
+    x = 0.7 * d / np.linalg.norm(d, axis=1, keepdims=True)
+    pe = [x] + [f(x * 2.0 ** k) for k in range(6) for f in (np.sin, np.cos)]
+    pe = np.concatenate(pe, 1)
+    h = pe
+    for l in range(9):
+        v = p[f"implicit_network.lin{l}.weight_v"].astype(np.float64)
+        w = p[f"implicit_network.lin{l}.weight_g"].astype(np.float64) * v / np.linalg.norm(v, axis=1, keepdims=True)
+        if l == 4:
+            h = np.concatenate([h, pe], 1) / np.sqrt(2.0)
+        a = h @ w.T + p[f"implicit_network.lin{l}.bias"].astype(np.float64)
+        h = np.maximum(a, 0) + np.log1p(np.exp(-np.abs(100 * a))) / 100 if l < 8 else a
+    b8 = p["implicit_network.lin8.bias"].astype(np.float64)
+    b8[0] -= h[:, 0].mean()
+    p["implicit_network.lin8.bias"] = b8.astype(F32)
+    return p
+
+
+WEIGHT_SETS = {"w0": lambda: make_params(0), "w1": lambda: make_trained_params(1)}
+
+
 BG_SDF_DIMS = [84, 256, 256, 256, 256, 256, 256, 256, 256, 257]     # lin3 emits 256 - 84 = 172 rows (skip at 4)
 
 

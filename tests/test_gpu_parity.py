@@ -25,9 +25,7 @@ def ops():
     return _ops
 
 
-@pytest.fixture(scope="module")
-def packed(dev, ops):
-    params = synth.make_params(0)
+def _pack(dev, ops, params):
     pk = ops.PackedMlp(dev)
     t = lambda k: torch.from_numpy(params[k]).to(dev)
     pk.pack_sdf([t(f"implicit_network.lin{l}.weight_v") for l in range(9)],
@@ -37,6 +35,17 @@ def packed(dev, ops):
                 [t(f"rendering_network.lin{l}.weight_g") for l in range(5)],
                 [t(f"rendering_network.lin{l}.bias") for l in range(5)])
     return pk, params
+
+
+@pytest.fixture(scope="module")
+def packed(dev, ops):
+    return _pack(dev, ops, synth.make_params(0))
+
+
+@pytest.fixture(scope="module")
+def packed_w1(dev, ops):
+    """the trained-scale weight set (synth.make_trained_params): gains up to ~3x, activations ~15, d sdf/dx ~20"""
+    return _pack(dev, ops, synth.make_trained_params(1))
 
 
 def G(a, dev):
@@ -85,15 +94,18 @@ def test_rays(dev, ops, golden_dir):
         np.testing.assert_allclose(ds.cpu().numpy(), g[t + "_depth_scale"], atol=3e-7)
 
 
-def test_sdf_mlp_golden(dev, ops, packed, golden_dir):
-    pk, params = packed
-    g = dict(np.load(os.path.join(golden_dir, "sdf_mlp.npz")))
+@pytest.mark.parametrize("name", ["sdf_mlp", "sdf_mlp_w1"])
+def test_sdf_mlp_golden(dev, ops, packed, packed_w1, golden_dir, name):
+    pk, params = packed_w1 if name.endswith("w1") else packed
+    g = dict(np.load(os.path.join(golden_dir, name + ".npz")))
     src = ops.PointSource(points=G(g["x"], dev))
     sdf = ops.sdf_vals(pk, src, 3.0, 20.0)
     np.testing.assert_allclose(sdf.cpu().numpy(), g["sdf_vals"], atol=1e-4)
     sdf2, grad, feat, hbuf, rows = ops.sdf_outputs(pk, src, 3.0, 20.0, want_feature_rows=True)
     np.testing.assert_allclose(sdf2.cpu().numpy(), g["sdf"], atol=1e-4)
-    np.testing.assert_allclose(rows.cpu().numpy(), g["feat"], atol=1e-4)
+    np.testing.assert_allclose(rows.cpu().numpy(), g["feat"], atol=1e-4, rtol=2e-5)
+    print(name, "max |sdf err|", float(np.abs(sdf2.cpu().numpy() - g["sdf"]).max()), "max |feat err|",
+          float(np.abs(rows.cpu().numpy() - g["feat"]).max()), "max |grad err|", float(np.abs(grad.cpu().numpy() - g["grad"]).max()))
     np.testing.assert_allclose(grad.cpu().numpy(), g["grad"], atol=2e-4, rtol=1e-4)
     _, graw, _, _, _ = ops.sdf_outputs(pk, src, 0.0, 20.0)
     np.testing.assert_allclose(graw.cpu().numpy(), g["grad_raw"], atol=2e-4, rtol=1e-4)
@@ -205,7 +217,10 @@ def test_sampler_golden_chain(dev, ops, packed, golden_dir, name):
                            sdf_override=[G(g[f"sdf_{i}"].reshape(g["dirs"].shape[0], -1), dev) for i in range(nr)])
     z = z.cpu().numpy()
     same = np.abs(z - g["z"]).max(-1) < 3e-4
-    assert same.mean() >= 0.75
+    # deterministic (the reference's own sdf values go in; the kernels are bit-identical to the oracle): the count of rays
+    # without a near-tie flip is pinned.  b = 0.01 with the full five rounds compounds the flips of every round.
+    expect = {"sampler_eval_b0.1_f-1": 12, "sampler_eval_b0.01_f-1": 9, "sampler_eval_b0.01_f2": 12}[name]
+    assert int(same.sum()) >= expect, f"{name}: {int(same.sum())}/{same.size} rays reproduce the reference's final samples, expected {expect}"
 
 
 def test_sampler_end_to_end(dev, ops, packed):
@@ -225,10 +240,10 @@ def test_sampler_end_to_end(dev, ops, packed):
 # ------------------------------------------------------------------------------------------------------
 # whole model through the reference's call surface
 # ------------------------------------------------------------------------------------------------------
-def _model(dev, beta):
+def _model(dev, beta, wset="w0"):
     from volsdf.utils.conf import dtu_model_conf
     from volsdf.model.network import VolSDFNetwork
-    params = synth.make_params(0)
+    params = synth.WEIGHT_SETS[wset]()
     m = VolSDFNetwork(dtu_model_conf())
     sd = {k: torch.from_numpy(v) for k, v in params.items()}
     sd["density.beta"] = torch.tensor(beta, dtype=torch.float32)
@@ -236,13 +251,20 @@ def _model(dev, beta):
     return m.to(dev), params
 
 
-@pytest.mark.parametrize("tag", ["eval_b0.1", "eval_b0.01", "eval_b0.01_f1", "train"])
+# rays of each fixture whose sample positions coincide with the reference's (the others carry a near-tie flip of one
+# inverse-CDF index: the reference normalises its pdf with a vectorised float32 sum).  The HIP sampler equals the numpy
+# oracle bit for bit, and the oracle's counts are deterministic (tests/test_oracle_golden.py::test_forward pins them).
+SAME_RAYS = {"eval_b0.1": 11, "eval_b0.01": 9, "eval_b0.01_f1": 12, "train": 12, "w1_eval": 9, "w1_train": 12}
+
+
+@pytest.mark.parametrize("tag", ["eval_b0.1", "eval_b0.01", "eval_b0.01_f1", "train", "w1_eval", "w1_train"])
 def test_model_forward_golden(dev, golden_dir, tag):
-    """VolSDFNetwork.forward (HIP) against the reference's outputs (fixtures).  rgb/depth <= 1e-4 on the rays
-    whose sample positions coincide (a near-tie flip in the sampler moves a sample by up to one bin)."""
+    """VolSDFNetwork.forward (HIP) against the reference's outputs (fixtures; w1_*: the trained-scale weight set).
+    rgb/depth <= 1e-4 on the rays whose sample positions coincide (a near-tie flip in the sampler moves a sample by up
+    to one bin)."""
     g = dict(np.load(os.path.join(golden_dir, "forward_" + tag + ".npz")))
-    m, _ = _model(dev, float(g["beta_param"]))
-    training = tag == "train"
+    m, _ = _model(dev, float(g["beta_param"]), "w1" if tag.startswith("w1") else "w0")
+    training = tag.endswith("train")
     m.train(training)
     R = g["uv"].shape[0]
     inp = {"intrinsics": G(g["K"], dev)[None], "uv": G(g["uv"], dev)[None], "pose": G(g["pose"], dev)[None]}
@@ -256,7 +278,10 @@ def test_model_forward_golden(dev, golden_dir, tag):
         out = m(inp, fast=int(g["fast"]))
     out = {k: v.detach().cpu().numpy() for k, v in out.items()}
     same = np.abs(out["depth_vals"] - g["depth_vals"]).max(-1) < 3e-4
-    assert same.mean() >= 0.75, same
+    # (the fused MLP's sdf differs from numpy's by ~2e-6, which can flip one more near-tie than the oracle's own count)
+    print(f"forward_{tag}: {int(same.sum())}/{same.size} rays with the reference's sample positions (oracle: {SAME_RAYS[tag]})")
+    assert int(same.sum()) >= SAME_RAYS[tag] - 1, (f"forward_{tag}: {int(same.sum())}/{same.size} rays with the reference's "
+                                                   f"sample positions, the oracle has {SAME_RAYS[tag]}")
     np.testing.assert_allclose(out["xyz"][same], g["xyz"][same], atol=3e-4)
     np.testing.assert_allclose(out["rgb_values"][same], g["rgb_values"][same], atol=1e-4)
     np.testing.assert_allclose(out["depth_values"][same], g["depth_values"][same], atol=2e-4)
@@ -278,7 +303,9 @@ def test_model_forward_vs_oracle_1024(dev):
     out = m(inp, fast=1)
     ref = orc.render_forward(params, uv, pose, K, beta_param=F32(0.1), fast=1)
     same = np.abs(out["depth_vals"].cpu().numpy() - ref["depth_vals"]).max(-1) < 3e-4
-    assert same.mean() > 0.95
+    # the sampler is bit-identical to the oracle given the same sdf values; the MLP's are equal to ~2e-6, which flips an
+    # index only at a near-tie: observed 1007 ... 1024 of 1024 rays
+    assert same.mean() >= 0.975, f"{int(same.sum())}/1024 rays with the oracle's sample positions"
     np.testing.assert_allclose(out["rgb_values"].cpu().numpy()[same], ref["rgb_values"][same], atol=1e-4)
     np.testing.assert_allclose(out["depth_values"].cpu().numpy()[same], ref["depth_values"][same], atol=2e-4)
 

@@ -26,11 +26,11 @@ def G(a, dev):
 from rng_inject import inject_rng   # noqa: E402
 
 
-def _setup(dev):
+def _setup(dev, wset="w0"):
     from volsdf.utils.conf import dtu_model_conf
     from volsdf.model.loss import VolSDFLoss
     from volsdf.model.network import VolSDFNetwork
-    params = synth.make_params(0)
+    params = synth.WEIGHT_SETS[wset]()
     m = VolSDFNetwork(dtu_model_conf())
     m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
     m.to(dev)
@@ -70,14 +70,16 @@ def _mvs(dev, g):
     return dict(views=dv, same_view=0, img_res=(576, 768), inverse_depth=False), views
 
 
-@pytest.mark.parametrize("fixture,groups", [("train_step", None), ("train_step_r32", None), ("train_step_r32", [(0, 16), (16, 32)])])
+@pytest.mark.parametrize("fixture,groups", [("train_step", None), ("train_step_r32", None), ("train_step_r32", [(0, 16), (16, 32)]),
+                                            ("train_step_w1", None)])
 def test_train_steps_fused(dev, golden_dir, fixture, groups):
     """TrainStep (forward, lookup, fused loss, hand-written backward, fused clip+guard+Adam) against the reference's own
     optimisation steps: 3 steps with 16 rays; 2 steps with 32 rays as one batch and as two ray groups on concurrent
-    streams (the default of bench.py / VolOpt at 1024 rays)."""
+    streams (the default of bench.py / VolOpt at 1024 rays); 2 steps with the trained-scale weight set (train_step_w1:
+    gains up to ~3x, beta = 0.005)."""
     from svs_hip.trainer import TrainStep
     g = dict(np.load(os.path.join(golden_dir, fixture + ".npz")))
-    m, loss = _setup(dev)
+    m, loss = _setup(dev, "w1" if fixture.endswith("w1") else "w0")
     ts = TrainStep(m, loss, lr=5e-4, groups=groups)
     mvs, views = _mvs(dev, g)
     R = g["uv"].shape[0]
@@ -103,7 +105,9 @@ def test_train_steps_fused(dev, golden_dir, fixture, groups):
         rel = _tensor_rel(g, step, "grad", named_g)
         print(f"step {step}: worst per-tensor gradient error", max(rel.values()), max(rel, key=rel.get))
         if step == 0:
-            _check_digest(g, step, "grad", named_g, rtol=2e-3, atol=2e-6 * max(1.0, norm), frac_ok=0.995)
+            # per ENTRY (2e-3 of the entry itself, small entries included): 99 % of the fingerprint; the per-tensor bound
+            # below is the parity criterion
+            _check_digest(g, step, "grad", named_g, rtol=2e-3, atol=2e-6 * max(1.0, norm), frac_ok=0.99)
         # after an Adam step, entries whose gradient is numerically zero have moved by +-lr with a noise-determined
         # sign (see the parameter check below), so later gradients agree per tensor, not per entry
         assert max(rel.values()) < (2e-3 if step == 0 else 3e-2), rel
@@ -117,6 +121,63 @@ def test_train_steps_fused(dev, golden_dir, fixture, groups):
         print(f"step {step}: params off by > 3e-5: {bad}/{tot}; worst per-tensor param error {max(prel.values()):.2e}")
         _check_digest(g, step, "param", list(m.named_parameters()), rtol=0.0, atol=3e-5, frac_ok=0.97 - 0.02 * step)
         _check_digest(g, step, "param", list(m.named_parameters()), rtol=0.0, atol=1.1e-3 * (step + 1), frac_ok=1.0)
+
+
+@pytest.mark.parametrize("R,wset", [(256, "w0"), (1024, "w0"), (256, "w1")])
+def test_step_gradient_at_bench_geometry(dev, R, wset):
+    """The flat gradient of ONE TrainStep at the benchmarked geometry -- 1024 rays (two ray groups on concurrent
+    streams, 800 workgroups per fused-MLP launch, shared float-atomic accumulators) and its 8-GPU shard of 256 rays --
+    against float64 torch autograd (oracle/torch_ref.py) on the very sample positions, prior look-ups and targets the
+    step used.  Per tensor: max |err| <= 2e-3 of the tensor's largest entry, the bound of the 16-ray reference steps."""
+    import torch_ref as tref
+    from svs_hip.trainer import TrainStep
+    m, loss = _setup(dev, wset)
+    params = synth.WEIGHT_SETS[wset]()
+    K, pose = synth.make_camera()
+    inp = {"intrinsics": G(K, dev)[None], "uv": G(synth.make_uv(R, seed=17), dev)[None], "pose": G(pose, dev)[None]}
+    rs = np.random.default_rng(5)
+    gt = {"rgb": G(rs.uniform(0, 1, (1, R, 3)).astype(F32), dev), "rgb_smooth": G(rs.uniform(0, 1, (1, R, 3)).astype(F32), dev)}
+    views = synth.make_mvs_views(2)
+    mvs = dict(views=[dict(K=v["K"], c2w=v["c2w"], cost=G(v["cost"], dev), z_mvs=G(v["z_mvs"], dev)) for v in views], same_view=0,
+               img_res=(576, 768), inverse_depth=False)
+    loss.iter_step = 50                                   # annealed phase: every term of the loss is live
+    ts = TrainStep(m, loss, lr=5e-4, groups="auto", graph=False)
+    S = ts.samples_per_ray()
+    n_groups = len(ts.split_rays(R, S))
+    assert n_groups == (2 if R == 1024 else 1)
+    p0 = {k: v.detach().clone() for k, v in m.state_dict().items()}       # the parameters the gradient belongs to
+    torch.manual_seed(3)
+    ts(inp, gt, mvs=mvs)
+    torch.cuda.synchronize()
+    norm = float(ts.opt.info[0])
+    coef = min(1.0, 1.0 / (norm + 1e-6))
+    got = {n: (p.grad / coef).double().cpu() for n, p in m.named_parameters()}
+    # what the step evaluated: per ray group the sample positions, the eikonal points, the prior look-ups
+    keeps = [h[0] for h in ts._hold]
+    outs = [r[1] for r in ts._results]
+    cat = lambda xs: torch.cat(xs, 0).double()
+    z = cat([k["z_vals"] for k in keeps]); dirs = cat([k["ray_dirs"] for k in keeps]); ds = cat([k["depth_scale"] for k in keeps])
+    cam = keeps[0]["cam_loc"].double()
+    # eikonal points of a group: [uniform draws of its rays, near-surface points of its rays]; torch_ref wants all uniform
+    # ones first -- the loss is a mean over them, the order inside does not matter
+    eik = cat([k["src"].points for k in keeps])
+    pj = cat([o["pj"] for o in outs]); pi = cat([o["pi"] for o in outs])
+    p = {k: torch.tensor(v.cpu().numpy(), dtype=torch.float64, device=dev, requires_grad=True) for k, v in p0.items()}
+    out = tref.forward_differentiable(p, cam, dirs, z, eik, ds, device=dev)
+    out["pj"], out["pi"] = pj, pi
+    total = tref.loss_fn(out, gt["rgb"].reshape(-1, 3).double(), gt["rgb_smooth"].reshape(-1, 3).double(), 50)
+    total.backward()
+    ref_norm = float(torch.sqrt(sum((v.grad ** 2).sum() for v in p.values())))
+    assert norm == pytest.approx(ref_norm, rel=1e-3), (norm, ref_norm)
+    worst, worst_name = 0.0, ""
+    for n in got:
+        ref = p[n].grad.cpu()
+        e = float((got[n] - ref).abs().max() / (ref.abs().max() + 1e-30))
+        if e > worst:
+            worst, worst_name = e, n
+    print(f"{R} rays, {wset}, {n_groups} group(s): worst per-tensor gradient error vs float64 autograd {worst:.2e} ({worst_name}); "
+          f"gradient norm {norm:.6f} vs {ref_norm:.6f}")
+    assert worst < 2e-3, (worst, worst_name)
 
 
 def test_train_step_autograd_bridge(dev, golden_dir):
