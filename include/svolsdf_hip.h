@@ -167,11 +167,14 @@ int svs_composite_bg(int n_rays, int n_samples, int n_bg, const float* z, const 
                      float beta_min, const float* z_bg, const float* bg_out0, const float* bg_rgb, const float* bg_depth,
                      float* weights, float* bg_trans, float* bg_weights, float* rgb_values, float* depth_values,
                      float* depth_values_all, float* depth_vals, float* normal_map, void* hip_stream);
-/* backward of svs_composite_bg: d_weights / d_depth_values may be NULL; d_beta_ray (n_rays) is workspace */
+/* backward of svs_composite_bg: d_weights / d_depth_values (gradient of the fg depth, network_bg.py:109-110) /
+ * d_depth_all (gradient of depth_values_all, :105-107 -- what VolSDFLoss's sparsity term reads, loss.py:72-73; needs
+ * bg_depth) may be NULL; d_beta_ray (n_rays) is workspace */
 int svs_composite_bg_bwd(int n_rays, int n_samples, int n_bg, const float* z, const float* z_max, const float* sdf,
                          const float* rgb, const float* depth_scale, const float* beta_param, float beta_min,
                          const float* z_bg, const float* bg_out0, const float* bg_rgb, const float* d_rgb_values,
-                         const float* d_weights, const float* d_depth_values, float* d_sdf, float* d_rgb,
+                         const float* d_weights, const float* d_depth_values, const float* d_depth_all,
+                         const float* bg_depth, float* d_sdf, float* d_rgb,
                          float* d_bg_out0, float* d_bg_rgb, float* d_beta_ray, float* d_beta_param, void* hip_stream);
 
 /* ---- a12  weight-gradient contraction of the training backward ---------------------------------------------------

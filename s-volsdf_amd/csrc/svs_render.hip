@@ -590,6 +590,9 @@ struct CompositeBgBwdArgs {
   const float* d_rgb_values;   // (R,3)
   const float* d_weights;      // (R,S) or nullptr
   const float* d_depth_values; // (R) or nullptr (the fg depth of network_bg.py:111-112)
+  const float* d_depth_all;    // (R) or nullptr: gradient of depth_values_all (network_bg.py:105-107) -- what the sparsity
+                               // term of the loss reads (loss.py:72-73); needs bg_depth
+  const float* bg_depth;       // (R,Nb) conventional depths of the inverse-sphere samples (with d_depth_all)
   float* d_sdf;                // (R*S)
   float* d_rgb;                // (R*S,3)
   float* d_bg_out0;            // (R*Nb)
@@ -625,8 +628,11 @@ __global__ __launch_bounds__(64) void composite_bg_bwd_kernel(CompositeBgBwdArgs
   const float tbg = det_exp(-tr[S]);
   const float ds = a.depth_scale[r];
   const float g0 = a.d_rgb_values[3 * r], g1 = a.d_rgb_values[3 * r + 1], g2 = a.d_rgb_values[3 * r + 2];
-  // background: weights, colour sums
+  // background: weights, colour sums, and the sums of depth_values_all = swd / (swa + 1e-8) over [w_fg, tbg * bw] with
+  // depths ds * [z, bg_depth]
+  const float ga = a.d_depth_all ? a.d_depth_all[r] : 0.0f;
   float bdot = 0.0f;       // sum_c g_c * sum_k bw_k cb_kc
+  float swa = 0.0f, swd = 0.0f;
   for (int i = lane; i < Nb; i += 64) {
     const size_t p = (size_t)r * Nb + i;
     const float T = det_exp(-btr[i]);
@@ -636,8 +642,9 @@ __global__ __launch_bounds__(64) void composite_bg_bwd_kernel(CompositeBgBwdArgs
     a.d_bg_rgb[3 * p] = (tbg * bw) * g0; a.d_bg_rgb[3 * p + 1] = (tbg * bw) * g1; a.d_bg_rgb[3 * p + 2] = (tbg * bw) * g2;
     const float cg = (c0 * g0 + c1 * g1) + c2 * g2;
     bdot += bw * cg;
-    bdw[i] = tbg * cg;                 // d loss / d bw_i
-    bpre[i] = bdw[i] * bw;
+    bdw[i] = tbg * cg;                 // d loss / d bw_i (colour term; the depth term follows once the sums are known)
+    bpre[i] = bw;
+    if (a.d_depth_all) { swa += tbg * bw; swd += (tbg * bw) * (ds * a.bg_depth[p]); }
   }
   bdot = wave_sum(bdot);
   // foreground: weights and their sums
@@ -650,6 +657,24 @@ __global__ __launch_bounds__(64) void composite_bg_bwd_kernel(CompositeBgBwdArgs
     sw += w; swz += w * (zs[i] * ds);
   }
   sw = wave_sum(sw); swz = wave_sum(swz);
+  float dall = 1.0f, qnum = 0.0f;       // depth_values_all's denominator and numerator
+  if (a.d_depth_all) {
+    swa = wave_sum(swa); swd = wave_sum(swd);
+    dall = (swa + sw) + 1e-8f; qnum = swd + swz;
+  }
+  __syncthreads();
+  // d depth_all / d (a weight with depth dv) = (dv * dall - qnum) / dall^2; through tbg it also reaches every fg free energy
+  float bdep = 0.0f;        // sum_k bw_k q_k: d depth_all / d tbg
+  for (int i = lane; i < Nb; i += 64) {
+    const float bw = bpre[i];
+    if (a.d_depth_all) {
+      const float q = ((ds * a.bg_depth[(size_t)r * Nb + i]) * dall - qnum) / (dall * dall);
+      bdw[i] += ga * tbg * q;
+      bdep += bw * q;
+    }
+    bpre[i] = bdw[i] * bw;
+  }
+  if (a.d_depth_all) bdot += ga * wave_sum(bdep);
   __syncthreads();
   const float gd = a.d_depth_values ? a.d_depth_values[r] : 0.0f;
   const float den = sw + 1e-8f;
@@ -661,6 +686,7 @@ __global__ __launch_bounds__(64) void composite_bg_bwd_kernel(CompositeBgBwdArgs
     float d = (c0 * g0 + c1 * g1) + c2 * g2;
     if (a.d_weights) d += a.d_weights[p];
     d += gd * ((zs[i] * ds) * den - swz) / (den * den);
+    if (a.d_depth_all) d += ga * ((zs[i] * ds) * dall - qnum) / (dall * dall);
     dw[i] = d;
     pre[i] = d * w;
   }
@@ -773,15 +799,17 @@ int svs_composite_bg(int n_rays, int n_samples, int n_bg, const float* z, const 
 int svs_composite_bg_bwd(int n_rays, int n_samples, int n_bg, const float* z, const float* z_max, const float* sdf,
                          const float* rgb, const float* depth_scale, const float* beta_param, float beta_min,
                          const float* z_bg, const float* bg_out0, const float* bg_rgb, const float* d_rgb_values,
-                         const float* d_weights, const float* d_depth_values, float* d_sdf, float* d_rgb,
+                         const float* d_weights, const float* d_depth_values, const float* d_depth_all,
+                         const float* bg_depth, float* d_sdf, float* d_rgb,
                          float* d_bg_out0, float* d_bg_rgb, float* d_beta_ray, float* d_beta_param, void* hip_stream) {
   if (!z || !z_max || !sdf || !rgb || !depth_scale || !beta_param || !z_bg || !bg_out0 || !bg_rgb || !d_rgb_values || !d_sdf ||
-      !d_rgb || !d_bg_out0 || !d_bg_rgb || !d_beta_ray || !d_beta_param || n_rays <= 0) {
+      !d_rgb || !d_bg_out0 || !d_bg_rgb || !d_beta_ray || !d_beta_param || n_rays <= 0 || (d_depth_all && !bg_depth)) {
     set_error("svs_composite_bg_bwd: null/invalid argument"); return SVS_EINVAL;
   }
   if (n_samples < 2 || n_samples + 1 > kMaxS || n_bg < 2 || n_bg > 64) { set_error("svs_composite_bg_bwd: sample counts out of range"); return SVS_ESHAPE; }
   CompositeBgBwdArgs a{n_rays, n_samples, n_bg, z, z_max, sdf, rgb, depth_scale, beta_param, beta_min, z_bg, bg_out0, bg_rgb,
-                       d_rgb_values, d_weights, d_depth_values, d_sdf, d_rgb, d_bg_out0, d_bg_rgb, d_beta_ray};
+                       d_rgb_values, d_weights, d_depth_values, d_depth_all, bg_depth, d_sdf, d_rgb, d_bg_out0, d_bg_rgb,
+                       d_beta_ray};
   hipStream_t s = (hipStream_t)hip_stream;
   composite_bg_bwd_kernel<<<n_rays, 64, 0, s>>>(a);
   beta_reduce_kernel<<<1, 256, 0, s>>>(d_beta_ray, n_rays, beta_param, d_beta_param, 0);

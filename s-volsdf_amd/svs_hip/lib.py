@@ -83,7 +83,7 @@ SIGNATURES = {
     "svs_bg_sdf_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "svs_bg_rbuf_bytes": (c_size_t, [c_int]),
     "svs_bg_rgb_eval": (c_int, [c_int, _P, c_int, _P, _P, _P, _P, _P]),
-    "svs_composite_bg_bwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P,
+    "svs_composite_bg_bwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P, _P,
                                      _P, _P, _P, _P, _P, _P, _P]),
     "svs_composite_bg": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P,
                                  _P, _P, _P, _P, _P, _P, _P, _P, _P]),

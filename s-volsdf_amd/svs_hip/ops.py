@@ -293,8 +293,10 @@ def composite_bg(z, z_max, sdf, rgb, depth_scale, beta_param, beta_min, z_bg, bg
 
 
 def composite_bg_bwd(z, z_max, sdf, rgb, depth_scale, beta_param, beta_min, z_bg, bg_out0, bg_rgb, d_rgb_values,
-                     d_weights=None, d_depth_values=None):
-    """backward of composite_bg -> d_sdf (R*S,1), d_rgb (R*S,3), d_bg_out0 (R*Nb,1), d_bg_rgb (R*Nb,3), d_beta (1,)"""
+                     d_weights=None, d_depth_values=None, d_depth_values_all=None, bg_depth=None):
+    """backward of composite_bg -> d_sdf (R*S,1), d_rgb (R*S,3), d_bg_out0 (R*Nb,1), d_bg_rgb (R*Nb,3), d_beta (1,).
+    d_depth_values: gradient of the foreground depth; d_depth_values_all (with bg_depth (R,Nb)): gradient of
+    depth_values_all, the fg + bg depth the loss's sparsity term reads (network_bg.py:105-110, loss.py:72-73)."""
     L = _lib.load()
     z = _f32(z)
     R, S = z.shape
@@ -307,7 +309,8 @@ def composite_bg_bwd(z, z_max, sdf, rgb, depth_scale, beta_param, beta_min, z_bg
     _lib.check(L.svs_composite_bg_bwd(R, S, Nb, _ptr(z), _ptr(_f32(z_max)), _ptr(_f32(sdf)), _ptr(_f32(rgb)),
                                       _ptr(_f32(depth_scale)), _ptr(_f32(beta_param).reshape(1)), float(beta_min),
                                       _ptr(_f32(z_bg)), _ptr(_f32(bg_out0)), _ptr(_f32(bg_rgb)), _ptr(_f32(d_rgb_values)),
-                                      opt(d_weights), opt(d_depth_values), _ptr(d_sdf), _ptr(d_rgb), _ptr(d_bo), _ptr(d_brgb),
+                                      opt(d_weights), opt(d_depth_values), opt(d_depth_values_all), opt(bg_depth),
+                                      _ptr(d_sdf), _ptr(d_rgb), _ptr(d_bo), _ptr(d_brgb),
                                       _ptr(d_beta_ray), _ptr(d_beta), _stream()), "svs_composite_bg_bwd")
     return d_sdf, d_rgb, d_bo, d_brgb, d_beta
 

@@ -377,10 +377,11 @@ class TrainStep:
                 g = self.loss.last_grads
                 stream.wait_event(packed)
                 if self.is_bg:
+                    # the loss read depth_values_all (fg + bg, loss.py:72-73): its gradient enters as such
                     d_sdf, d_rgb, d_bo, d_brgb, d_beta = ops.composite_bg_bwd(
                         keep["z_vals"], keep["z_max"], keep["sdf"], keep["rgb_flat"], keep["depth_scale"], m.density.beta,
                         m.density.beta_min_value, keep["z_bg"], keep["bg_out0"], keep["bg_rgb"], g["rgb_values"],
-                        g["weights"], g["depth_values"])
+                        g["weights"], None, d_depth_values_all=g["depth_values"], bg_depth=keep["bg_depth"])
                     sc.bg_bwd.accumulate(keep, d_brgb, d_bo, slot=gi)
                 else:
                     gw = m.white_bkgd_weight_grad(g["rgb_values"], g["weights"], keep["z_vals"].shape[1])

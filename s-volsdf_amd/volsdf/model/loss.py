@@ -62,11 +62,14 @@ class VolSDFLoss(nn.Module):
         if advance:
             self.iter_step += 1
         total = losses[4]
-        diff = [k for k in ('rgb_values', 'grad_theta', 'weights', 'depth_values')
-                if k in model_outputs and torch.is_tensor(model_outputs[k]) and model_outputs[k].requires_grad]
+        # (the depth the loss read -- and whose gradient grads['depth_values'] is -- is depth_values_all for the fg + bg model)
+        depth_key = 'depth_values_all' if 'depth_values_all' in model_outputs else 'depth_values'
+        diff = [(k, depth_key if k == 'depth_values' else k) for k in ('rgb_values', 'grad_theta', 'weights', 'depth_values')]
+        diff = [(gk, ok) for gk, ok in diff
+                if ok in model_outputs and torch.is_tensor(model_outputs[ok]) and model_outputs[ok].requires_grad]
         if diff:
             # connect the fused loss to autograd so that the reference's `loss.backward()` (vsdf.py:215) works
-            total = _FusedLossFunction.apply(losses, grads, diff, *[model_outputs[k] for k in diff])
+            total = _FusedLossFunction.apply(losses, grads, [gk for gk, _ in diff], *[model_outputs[ok] for _, ok in diff])
         return {'rgb_loss': losses[0], 'eikonal_loss': losses[1], 'mvs_loss': losses[2], 'sparse_loss': losses[3],
                 'loss': total}
 

@@ -112,9 +112,51 @@ class VolSDFNetworkBG(nn.Module):
 
     def forward(self, input, fast=-1):
         if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("training of VolSDFNetworkBG goes through svs_hip.trainer (fused backward); "
-                                      "wrap evaluation in torch.no_grad()")
+            # autograd bridge: the reference's own train_step (loss.backward(), clip_grad_norm_, torch Adam,
+            # volsdf/vsdf.py:214-219) drives the hand-written backward kernels, as with the DTU model
+            res = _RenderFunctionBG.apply(self, input, fast, *self._flat_param_list())
+            rgb_values, depth_values_all, depth_values, weights, grad_theta, depth_vals, xyz = res
+            return {'rgb_values': rgb_values, 'depth_values_all': depth_values_all, 'depth_values': depth_values,
+                    'depth_vals': depth_vals, 'weights': weights, 'xyz': xyz, 'grad_theta': grad_theta}
         return self._forward_impl(input, fast, None)
+
+    def backward_from_output_grads(self, keep, g_rgb_values, g_weights=None, g_depth_values=None, g_depth_values_all=None,
+                                   g_grad_theta=None):
+        """d loss / d parameters (in _flat_param_list() order) from d loss / d (rgb_values, weights, depth_values,
+        depth_values_all, grad_theta): fg / bg compositing backward, then the fused MLP backwards of all four networks."""
+        from svs_hip.train import BgBackward, MlpBackward, finalize
+        dev = keep["z_vals"].device
+        if getattr(self, "_mlp_bwd", None) is None or self._mlp_bwd.dev != dev:
+            self._mlp_bwd, self._bg_bwd = MlpBackward(dev), BgBackward(dev)
+        R = keep["z_vals"].shape[0]
+        if g_rgb_values is None:
+            g_rgb_values = torch.zeros(R, 3, device=dev)
+        d_sdf, d_rgb, d_bo, d_brgb, d_beta = ops.composite_bg_bwd(
+            keep["z_vals"], keep["z_max"], keep["sdf"], keep["rgb_flat"], keep["depth_scale"], self.density.beta,
+            self.density.beta_min_value, keep["z_bg"], keep["bg_out0"], keep["bg_rgb"], g_rgb_values, g_weights,
+            g_depth_values, d_depth_values_all=g_depth_values_all, bg_depth=keep["bg_depth"])
+        n_extra = keep["src"].n - keep["rgb"].shape[0]
+        if g_grad_theta is None and n_extra:
+            g_grad_theta = torch.zeros(n_extra, 3, device=dev)
+        sdf_p, rgb_p = self.mlp_params()
+        bg_sdf_wb, bg_rgb_wb = self.bg_params()
+        bw, bgb = self._mlp_bwd, self._bg_bwd
+        bw.streams.pack(sdf_p, rgb_p)
+        bgb.pack(bg_sdf_wb, bg_rgb_wb)
+        bw.accum.zero(); bgb.zero()
+        bgb.accumulate(keep, d_brgb, d_bo)
+        bw.accumulate(keep, d_rgb, d_sdf, g_grad_theta)
+        sdf_g, rgb_g = finalize(bw.accum, sdf_p, rgb_p)
+        bg_sdf_g, bg_rgb_g = bgb.finalize(bg_sdf_wb, bg_rgb_wb)
+        grads = []
+        for group in (sdf_g, rgb_g):
+            for gv, gg, gb in group:
+                grads += [gv, gg, gb]
+        grads.append(d_beta.reshape(self.density.beta.shape))
+        for group in (bg_sdf_g, bg_rgb_g):
+            for gw, gb in group:
+                grads += [gw, gb]
+        return grads
 
     def _forward_impl(self, input, fast, keep, rng=None):
         """network_bg.py:37-145 on the HIP kernels."""
@@ -165,3 +207,23 @@ class VolSDFNetworkBG(nn.Module):
         else:
             output['normal_map'] = comp["normal_map"]
         return output
+
+
+class _RenderFunctionBG(torch.autograd.Function):
+    """Autograd bridge of the fg + background model (see volsdf.model.network._RenderFunction).  Inputs after `fast` are
+    the parameters in VolSDFNetworkBG._flat_param_list() order."""
+
+    @staticmethod
+    def forward(ctx, model, input, fast, *params):
+        keep = {}
+        out = model._forward_impl(input, fast, keep)
+        ctx.model, ctx.keep = model, keep
+        ctx.mark_non_differentiable(out['depth_vals'], out['xyz'])
+        return (out['rgb_values'], out['depth_values_all'], out['depth_values'], out['weights'], out['grad_theta'],
+                out['depth_vals'], out['xyz'])
+
+    @staticmethod
+    def backward(ctx, g_rgb_values, g_depth_values_all, g_depth_values, g_weights, g_grad_theta, _g1, _g2):
+        grads = ctx.model.backward_from_output_grads(ctx.keep, g_rgb_values, g_weights, g_depth_values, g_depth_values_all,
+                                                     g_grad_theta)
+        return (None, None, None, *grads)

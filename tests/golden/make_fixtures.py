@@ -524,7 +524,7 @@ def fx_train_step(R=16, n_steps=3, name="train_step", wset="w0"):
     save(name, **arr)
 
 
-def fx_train_step_bg():
+def fx_train_step_bg(name="train_step_bg", iter_step=250, confi=1e-3, n_steps=2):
     """Two optimisation steps of the reference with the fg + background model (VolSDFNetworkBG, config 4): forward,
     cost_mapping, VolSDFLoss, clip, Adam (volsdf/vsdf.py:196-219); 32 rays (32 x 97 fg + 32 x 32 bg samples)."""
     from volsdf.vsdf import VolOpt
@@ -545,12 +545,15 @@ def fx_train_step_bg():
                          z_mvs={j: T(views[j]["z_mvs"])[None] for j in range(3)}, train_dataset=ds,
                          hparams=SimpleNamespace(inverse_depth=False), stg=0)
     loss = VolSDFLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, rgb_weight=1.0, mvs_weight=1.0, sparse_weight=1.0,
-                      anneal_rgb=200, gce=0.5, confi=1e-3)
-    loss.iter_step = 250        # past the rgb annealing: the plain L1 colour term is active and reaches the background
+                      anneal_rgb=200, gce=0.5, confi=confi)
+    # 250: past the rgb annealing: the plain L1 colour term is active and reaches the background.  train_step_bg_sparse:
+    # iteration 50 with confi = 1e3 -- every ray counts as unsupported by the MVS prior, so the sparsity term
+    # 1 / (depth_values_all + 1e-3) is live on all rays and its gradient reaches the background through the fg + bg depth
+    loss.iter_step = iter_step
     opt = torch.optim.Adam(m.parameters(), lr=5e-4)
     inp = {"intrinsics": T(K)[None], "uv": T(uv)[None], "pose": T(pose)[None]}
-    arr = dict(uv=uv, rgb=gt["rgb"], rgb_smooth=gt["rgb_smooth"], mvs_seed=5, loss_iter_step=250)
-    for step in range(2):
+    arr = dict(uv=uv, rgb=gt["rgb"], rgb_smooth=gt["rgb_smooth"], mvs_seed=5, loss_iter_step=iter_step, confi=np.asarray(confi, F32))
+    for step in range(n_steps):
         draws = synth.make_train_rng(R, seed=100 + step, bg=True)
         with inject_rng(draws):
             out = m(inp, fast=1)
@@ -569,7 +572,7 @@ def fx_train_step_bg():
             arr[f"s{step}_grad_idx/{n}"] = idx.astype(np.int32); arr[f"s{step}_grad/{n}"] = val
         for n, (idx, val) in param_digest([(n, p.detach().numpy()) for n, p in m.named_parameters()], seed=10 + step).items():
             arr[f"s{step}_param_idx/{n}"] = idx.astype(np.int32); arr[f"s{step}_param/{n}"] = val
-    save("train_step_bg", **arr)
+    save(name, **arr)
 
 
 def fx_fusion():
@@ -688,7 +691,8 @@ ALL = dict(fusion=fx_fusion, pfm=fx_pfm, chamfer=fx_chamfer, featurenet=fx_featu
            composite=fx_composite, forward=fx_forward, forward_bg=fx_forward_bg, cost_mapping=fx_cost_mapping, loss=fx_loss, casmvs=fx_casmvs, train_step=fx_train_step, train_step_r32=lambda: fx_train_step(32, 2, "train_step_r32"),
            sdf_mlp_w1=lambda: fx_sdf_mlp("w1"), forward_w1=fx_forward_w1,
            train_step_w1=lambda: fx_train_step(16, 2, "train_step_w1", "w1"),
-           train_step_bg=fx_train_step_bg)
+           train_step_bg=fx_train_step_bg,
+           train_step_bg_sparse=lambda: fx_train_step_bg("train_step_bg_sparse", 50, 1e3, 1))
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(ALL)

@@ -161,16 +161,19 @@ def test_composite_bg_backward(dev):
     assert abs(float(d_beta) - float(tb.grad)) / abs(float(tb.grad)) < 5e-5
 
 
-def test_bg_train_steps_fused(dev, golden_dir):
-    """TrainStep with VolSDFNetworkBG (forward incl. background, lookup, loss, fg + bg backward, clip + Adam) x 2
-    against the reference's optimisation steps (tests/golden/train_step_bg.npz)."""
+@pytest.mark.parametrize("fixture", ["train_step_bg", "train_step_bg_sparse"])
+def test_bg_train_steps_fused(dev, golden_dir, fixture):
+    """TrainStep with VolSDFNetworkBG (forward incl. background, lookup, loss, fg + bg backward, clip + Adam) against the
+    reference's optimisation steps.  train_step_bg: 2 steps past the annealing (the L1 colour term reaches the
+    background); train_step_bg_sparse: 1 step inside it with every ray unsupported by the prior -- the loss is eikonal
+    + sparsity only, and the sparsity term reads depth_values_all, whose gradient reaches the background networks."""
     from rng_inject import inject_rng
     from svs_hip.trainer import TrainStep
     from volsdf.model.loss import VolSDFLoss
-    g = dict(np.load(os.path.join(golden_dir, "train_step_bg.npz")))
+    g = dict(np.load(os.path.join(golden_dir, fixture + ".npz")))
     m = _model(dev, 0.1)
     loss = VolSDFLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, rgb_weight=1.0, mvs_weight=1.0, sparse_weight=1.0,
-                      anneal_rgb=200, gce=0.5, confi=1e-3)
+                      anneal_rgb=200, gce=0.5, confi=float(g["confi"]))
     loss.iter_step = int(g["loss_iter_step"])
     ts = TrainStep(m, loss, lr=5e-4)
     views = synth.make_mvs_views(int(g["mvs_seed"]))
@@ -179,6 +182,7 @@ def test_bg_train_steps_fused(dev, golden_dir):
     R = g["uv"].shape[0]
     inp = {"intrinsics": G(views[0]["K"], dev)[None], "uv": G(g["uv"], dev)[None], "pose": G(views[0]["c2w"], dev)[None]}
     gt = {"rgb": G(g["rgb"], dev), "rgb_smooth": G(g["rgb_smooth"], dev)}
+    n_steps = 1 + max(int(k[1]) for k in g if k.startswith("s") and k[1].isdigit() and k[2] == "_")
 
     def tensor_rel(step, kind, named):
         out = {}
@@ -188,7 +192,7 @@ def test_bg_train_steps_fused(dev, golden_dir):
             out[name] = float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30))
         return out
 
-    for step in range(2):
+    for step in range(n_steps):
         with inject_rng(synth.make_train_rng(R, seed=100 + step, bg=True)):
             lo, out = ts(inp, gt, mvs=mvs)
         torch.cuda.synchronize()
@@ -205,10 +209,58 @@ def test_bg_train_steps_fused(dev, golden_dir):
         print(f"step {step}: worst per-tensor gradient error {rel[worst]:.3e} {worst}")
         bg_rel = {k: v for k, v in rel.items() if k.startswith("bg_")}
         print(f"step {step}: worst background-tensor gradient error {max(bg_rel.values()):.3e}")
-        assert all(np.abs(g[f"s{step}_grad/{k}"]).max() > 0 for k in bg_rel), "the fixture must exercise the background nets"
+        # (sparse fixture: no colour term, so only the background DENSITY network receives gradients -- through
+        # depth_values_all; the sampled entries of its last layer's weight are all feature rows, which feed the colour net)
+        dead = ("bg_rendering", "bg_implicit_network.lin8.weight") if fixture.endswith("sparse") else ()
+        live = [k for k in bg_rel if not k.startswith(dead)] if dead else list(bg_rel)
+        assert all(np.abs(g[f"s{step}_grad/{k}"]).max() > 0 for k in live), "the fixture must exercise the background nets"
         assert max(rel.values()) < (3e-3 if step == 0 else 3e-2), rel
         prel = tensor_rel(step, "param", list(m.named_parameters()))
         assert max(prel.values()) < 2e-2, prel
+    if fixture.endswith("sparse"):
+        assert float(g["s0_sparse_loss"]) > 0 and float(g["s0_rgb_loss"]) == 0.0
+
+
+@pytest.mark.parametrize("fixture", ["train_step_bg", "train_step_bg_sparse"])
+def test_bg_train_step_autograd_bridge(dev, golden_dir, fixture):
+    """The reference's own sequence (volsdf/vsdf.py:196-219 with config/vol/bmvs.yaml's model class) -- model(...),
+    cost_mapping, loss(...), loss.backward(), clip_grad_norm_, torch Adam -- driving the HIP kernels of the fg + bg model
+    through its autograd bridge, against the reference's step."""
+    from rng_inject import inject_rng
+    from svs_hip import ops
+    from volsdf.model.loss import VolSDFLoss
+    g = dict(np.load(os.path.join(golden_dir, fixture + ".npz")))
+    m = _model(dev, 0.1)
+    m.train()
+    loss = VolSDFLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, rgb_weight=1.0, mvs_weight=1.0, sparse_weight=1.0,
+                      anneal_rgb=200, gce=0.5, confi=float(g["confi"]))
+    loss.iter_step = int(g["loss_iter_step"])
+    opt = torch.optim.Adam(m.parameters(), lr=5e-4)
+    views = synth.make_mvs_views(int(g["mvs_seed"]))
+    dv = [dict(K=v["K"], c2w=v["c2w"], cost=G(v["cost"], dev), z_mvs=G(v["z_mvs"], dev)) for v in views]
+    R = g["uv"].shape[0]
+    inp = {"intrinsics": G(views[0]["K"], dev)[None], "uv": G(g["uv"], dev)[None], "pose": G(views[0]["c2w"], dev)[None]}
+    gt = {"rgb": G(g["rgb"], dev), "rgb_smooth": G(g["rgb_smooth"], dev)}
+    with inject_rng(synth.make_train_rng(R, seed=100, bg=True)):
+        out = m(inp, fast=1)
+    assert out["rgb_values"].requires_grad and out["depth_values_all"].requires_grad
+    with torch.no_grad():
+        out['pj'], out['pi'], _ = ops.cost_lookup(dv, 0, (576, 768), xyz=out['xyz'])
+    lo = loss(out, gt)
+    opt.zero_grad()
+    lo['loss'].backward()
+    np.testing.assert_allclose(float(lo['loss'].detach()), float(g["s0_loss"]), rtol=3e-4)
+    worst, name = 0.0, ""
+    for n, p in m.named_parameters():
+        idx, ref = g[f"s0_grad_idx/{n}"], g[f"s0_grad/{n}"]
+        e = float(np.abs(p.grad.cpu().numpy().reshape(-1)[idx] - ref).max() / (np.abs(ref).max() + 1e-30))
+        if e > worst:
+            worst, name = e, n
+    print(f"{fixture}: bridge, worst per-tensor gradient error {worst:.3e} {name}")
+    assert worst < 3e-3, (worst, name)
+    norm = torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+    np.testing.assert_allclose(float(norm), float(g["s0_grad_norm"]), rtol=3e-4)
+    opt.step()
 
 
 def test_bg_ray_groups_do_not_change_the_step(dev):

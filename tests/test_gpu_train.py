@@ -93,8 +93,8 @@ def test_train_steps_fused(dev, golden_dir, fixture, groups):
         for k in ("rgb_loss", "eikonal_loss", "mvs_loss", "sparse_loss", "loss"):
             print(f"step {step} {k}: {float(lo[k]):.7f} ref {float(g[f's{step}_{k}']):.7f}")
             # step 0 sees identical parameters; later steps inherit the sign noise of numerically-zero gradients
-            np.testing.assert_allclose(float(lo[k]), float(g[f"s{step}_{k}"]), rtol=2e-4 if step == 0 else 5e-3, atol=2e-6,
-                                       err_msg=f"step {step} {k}")
+            np.testing.assert_allclose(float(lo[k]), float(g[f"s{step}_{k}"]), rtol=2e-4 if step == 0 else 5e-3,
+                                       atol=2e-6 if step == 0 else 2e-5, err_msg=f"step {step} {k}")
         # gradient norm before clipping (info[0]) and the raw gradients: the flat grad buffer holds the CLIPPED grads
         norm = float(ts.opt.info[0])
         # (step 0: identical parameters; later steps: parameters differ by Adam's sign noise on ~zero gradients)
@@ -356,3 +356,46 @@ def test_white_background_training(dev):
     for (n, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
         d = (pa - pb).abs()
         assert float(d.max()) <= 1.1e-3 and float((d > 2e-5).float().mean()) < 0.02, n     # Adam sign noise on ~zero gradients
+
+
+def test_rccl_path_on_one_gpu(dev):
+    """world = 1 under torch.distributed (backend nccl = RCCL): the step's single collective -- all-reduce (sum) of the flat
+    gradient -- is a no-op on one rank and must leave the step untouched: per-ray outputs bit-identical to a step without
+    a process group, gradient equal up to the float atomics' order.  (The N > 1 arithmetic is covered on CPU with gloo:
+    tests/test_dist_gloo.py::test_train_step_arithmetic_world2; 8-GPU runs are the driver's.)"""
+    import socket
+    import torch.distributed as dist
+    from svs_hip.trainer import TrainStep
+    R = 128
+    K, pose = synth.make_camera()
+    inp = {"intrinsics": G(K, dev)[None], "uv": G(synth.make_uv(R, seed=3), dev)[None], "pose": G(pose, dev)[None]}
+    rs = np.random.default_rng(5)
+    gt = {"rgb": G(rs.uniform(0, 1, (1, R, 3)).astype(F32), dev), "rgb_smooth": G(rs.uniform(0, 1, (1, R, 3)).astype(F32), dev)}
+
+    def one_step():
+        m, loss = _setup(dev)
+        ts = TrainStep(m, loss, world=1, rank=0)
+        torch.manual_seed(11)
+        lo, out = ts(inp, gt)
+        torch.cuda.synchronize()
+        return out["rgb_values"].clone(), out["weights"].clone(), ts.fp.grad.clone(), ts.fp.flat.clone()
+
+    plain = one_step()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    assert not dist.is_initialized()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        calls = []
+        orig = dist.all_reduce
+        dist.all_reduce = lambda t, *a, **k: (calls.append(t.numel()), orig(t, *a, **k))[1]
+        try:
+            with_pg = one_step()
+        finally:
+            dist.all_reduce = orig
+    finally:
+        dist.destroy_process_group()
+    assert calls == [plain[2].numel()], calls                      # ONE collective, over the whole flat gradient
+    assert torch.equal(plain[0], with_pg[0]) and torch.equal(plain[1], with_pg[1])
+    assert float((plain[2] - with_pg[2]).abs().max()) <= 1e-5 * float(plain[2].abs().max())
+    d = (plain[3] - with_pg[3]).abs()
+    assert float(d.max()) <= 1.1e-3 and float((d > 1e-5).float().mean()) < 1e-3
