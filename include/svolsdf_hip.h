@@ -296,12 +296,22 @@ int svs_loss(int n_rays, int n_samples, int n_eik, const float* rgb_values, cons
 size_t svs_loss_workspace_bytes(int n_rays, int n_eik);
 
 /* ---- f1  FeatureNet convolutions (models/CasMVSNet.py:24-55,338-439) ---------------------------------------------
- * out (Cout,Ho,Wo) = [add +] relu?(conv2d(in (Cin,H,W), weight [Cout][Cin][k][k]) + bias), k in {1,3,5}, padding k/2,
- * stride in {1,2}; BatchNorm(eval) folded into weight / bias by the caller.  add: optional (Cout,Ho,Wo) tensor added
+ * out (Cout,Ho,Wo) = [add +] relu?(conv2d(in (Cin,H,W), weight) + bias), k in {1,3,5}, padding k/2, stride in {1,2};
+ * BatchNorm(eval) folded into weight / bias by the caller.  weight is PACKED for scalar loads: [ceil(Cout/8)][Cin][k][k][8]
+ * floats, entry [g][ci][ky][kx][c] = W[8 g + c][ci][ky][kx], zero for 8 g + c >= Cout, 32-byte aligned (the caller packs
+ * once per weight tensor; svs_hip/costvol.py: conv2d_pack).  add: optional (Cout,Ho,Wo) tensor added
  * AFTER the activation; add_upsample2 != 0: add is (Cout,Ho/2,Wo/2) and enters nearest-up-sampled by 2 (the FPN's
  * top-down path, :413-431). */
 int svs_conv2d(const float* in, const float* weight, const float* bias, const float* add, int add_upsample2, float* out,
                int Cin, int Cout, int H, int W, int k, int stride, int relu, void* hip_stream);
+/* The whole 'fpn' FeatureNet (models/CasMVSNet.py:338-439, num_stage 3) for one image (3,H,W), H and W multiples of 4,
+ * enqueued by one call: weights[i] / biases[i] (biases[i] may be null), i = conv0.0, conv0.1, conv1.0, conv1.1, conv1.2,
+ * conv2.0, conv2.1, conv2.2 (BatchNorm folded), out1, inner1, out2, inner2, out3; weights packed as for svs_conv2d.
+ * stage1 (4b,H/4,W/4), stage2 (2b,H/2,W/2), stage3 (b,H,W), b = base_channels. */
+size_t svs_featurenet_fpn_workspace_bytes(int base_channels, int H, int W);
+int svs_featurenet_fpn(const float* image, int H, int W, int base_channels, const float* const* weights,
+                       const float* const* biases, float* workspace, float* stage1, float* stage2, float* stage3,
+                       void* hip_stream);
 
 /* ---- a13/a14  homography warp + variance --------------------------------------------------------------------
  * homo_warping (models/CasMVSNet.py:280-315) for every source view fused with the variance aggregation of

@@ -2,72 +2,238 @@
 //
 // Reference: models/CasMVSNet.py:24-55 (Conv2d block: conv + BatchNorm2d + ReLU) and :338-439 (FeatureNet, 'fpn':
 // 3x3 / 5x5 / 1x1 kernels, strides 1 / 2, nearest x2 up-sampling added to a 1x1 lateral convolution).  BatchNorm in
-// eval mode is folded into the weights by the caller.  The whole pyramid is ~5 GFLOP per 512x640 image and runs three
-// times per scan (the stage loop caches the features): direct float32 convolution on the vector units, one thread
-// = one output pixel x 8 output channels, the 8-channel weight slice in LDS, input rows shared through L1.
+// eval mode is folded into the weights by the caller.  The whole pyramid is ~5.6 GFLOP per 512x640 image in 13 launches
+// and runs three times per scan (the stage loop caches the features), so it is a vector-unit job: direct float32
+// convolution, one thread = PX adjacent output pixels x 8 output channels (PX * 8 accumulators), kernel size and stride
+// compile-time.  Per input channel and kernel row a thread loads the (PX - 1) * stride + K input values its pixels
+// share once into registers; a tap's 8 weights are the same for the whole wave, so they come through the SCALAR cache
+// into SGPRs (s_load_dwordx8 from the packed layout [Cout / 8][Cin][k][k][8], which the caller prepares once per weight
+// tensor) and feed the FMAs as scalar operands: no LDS, no vector memory traffic for weights.  (Reading them as
+// broadcast ds_read_b128 made the kernel LDS-issue bound: 2 reads per 8 FMAs at PX = 1.)
+// That direct kernel now serves the 1x1 lateral convolutions only (memory-bound); 3x3 / 5x5 run on the LDS-tiled kernel
+// below.  svs_featurenet_fpn enqueues the whole pyramid (13 launches) from one call.
 #include "svs_common.h"
 
 namespace svs {
 namespace conv2d {
 
 constexpr int kCT = 8;
-constexpr int kMaxW = 64 * 25 * kCT;          // Cin * k * k * 8 floats of LDS (51 KiB) at Cin = 64, k = 5
+constexpr int kThreads = 128;
 
 struct Args {
   const float* in;      // (Cin, H, W)
-  const float* w;       // [Cout][Cin][k][k]
+  const float* w;       // packed [ceil(Cout / 8)][Cin][k][k][8] (zero beyond Cout)
   const float* bias;    // [Cout] or nullptr
   const float* add;     // (Cout, Ho, Wo), or (Cout, Ho/2, Wo/2) with add_up2: added after the activation
   float* out;           // (Cout, Ho, Wo)
-  int Cin, Cout, H, W, Ho, Wo, k, stride, pad, relu, add_up2;
+  int Cin, Cout, H, W, Ho, Wo, relu, add_up2;
+  int groups_per_row;   // direct kernel: ceil(Wo / PX)
+  int chunk;            // tiled kernel: input channels per LDS tile
 };
 
-__global__ __launch_bounds__(256) void conv2d_kernel(Args a) {
-  extern __shared__ float wl[];                 // [ci][ky][kx][c]
+template <int K, int S, int PX>
+__global__ __launch_bounds__(kThreads) void conv2d_kernel(Args a) {
+  constexpr int KK = K * K, PAD = K / 2, SPAN = (PX - 1) * S + K, kRowUnroll = K == 5 ? 1 : K;
   const int co0 = blockIdx.y * kCT;
-  const int kk = a.k * a.k;
-  for (int i = threadIdx.x; i < a.Cin * kk * kCT; i += 256) {
-    const int c = i % kCT, r = i / kCT;         // r = ci * kk + tap
-    wl[i] = (co0 + c < a.Cout) ? a.w[(size_t)(co0 + c) * a.Cin * kk + r] : 0.0f;
-  }
-  __syncthreads();
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= a.Ho * a.Wo) return;
-  const int yo = p / a.Wo, xo = p - yo * a.Wo;
-  const int y0 = yo * a.stride - a.pad, x0 = xo * a.stride - a.pad;
-  float acc[kCT];
+  const float* __restrict__ wg = a.w + (size_t)blockIdx.y * a.Cin * KK * kCT;      // wave-uniform: scalar loads
+  const int g = blockIdx.x * kThreads + threadIdx.x;
+  if (g >= a.Ho * a.groups_per_row) return;
+  const int yo = g / a.groups_per_row, xo = (g - yo * a.groups_per_row) * PX;
+  const int y0 = yo * S - PAD, x0 = xo * S - PAD;
+  // column offsets and validity of the input span (the same for every channel and row)
+  int xoff[SPAN];
+  bool xok[SPAN];
 #pragma unroll
-  for (int c = 0; c < kCT; ++c) acc[c] = 0.0f;
+  for (int j = 0; j < SPAN; ++j) {
+    const int ix = x0 + j;
+    xok[j] = (unsigned)ix < (unsigned)a.W;
+    xoff[j] = xok[j] ? ix : 0;
+  }
+  float acc[PX][kCT];
+#pragma unroll
+  for (int p = 0; p < PX; ++p)
+#pragma unroll
+    for (int c = 0; c < kCT; ++c) acc[p][c] = 0.0f;
   const size_t plane = (size_t)a.H * a.W;
   for (int ci = 0; ci < a.Cin; ++ci) {
     const float* ip = a.in + ci * plane;
-    const float* wp = wl + ci * kk * kCT;
-    for (int ky = 0; ky < a.k; ++ky) {
+    const float4* wp = reinterpret_cast<const float4*>(wg + ci * KK * kCT);
+    // (K = 5: one kernel row at a time -- 25 taps x 8 weights would not fit the SGPR file)
+#pragma unroll kRowUnroll
+    for (int ky = 0; ky < K; ++ky) {
       const int iy = y0 + ky;
-      if ((unsigned)iy >= (unsigned)a.H) continue;
-      for (int kx = 0; kx < a.k; ++kx) {
-        const int ix = x0 + kx;
-        if ((unsigned)ix >= (unsigned)a.W) continue;
-        const float v = ip[(size_t)iy * a.W + ix];
-        const float* wv = wp + (ky * a.k + kx) * kCT;
+      const bool yok = (unsigned)iy < (unsigned)a.H;
+      const float* row = ip + (size_t)(yok ? iy : 0) * a.W;
+      float v[SPAN];
 #pragma unroll
-        for (int c = 0; c < kCT; ++c) acc[c] = __builtin_fmaf(wv[c], v, acc[c]);
+      for (int j = 0; j < SPAN; ++j) { const float t = row[xoff[j]]; v[j] = (yok && xok[j]) ? t : 0.0f; }
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        const float4 w0 = wp[(ky * K + kx) * 2], w1 = wp[(ky * K + kx) * 2 + 1];
+        const float wv[kCT] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+        for (int p = 0; p < PX; ++p)
+#pragma unroll
+          for (int c = 0; c < kCT; ++c) acc[p][c] = __builtin_fmaf(wv[c], v[p * S + kx], acc[p][c]);
       }
     }
   }
   const size_t oplane = (size_t)a.Ho * a.Wo;
+  const bool whole = (xo + PX <= a.Wo);
 #pragma unroll
   for (int c = 0; c < kCT; ++c) {
     const int co = co0 + c;
     if (co >= a.Cout) break;
-    float r = acc[c] + (a.bias ? a.bias[co] : 0.0f);
-    if (a.relu) r = __builtin_fmaxf(r, 0.0f);
-    if (a.add) {
-      if (a.add_up2) r += a.add[(size_t)co * (a.Ho / 2) * (a.Wo / 2) + (size_t)(yo >> 1) * (a.Wo / 2) + (xo >> 1)];   // nearest x2
-      else r += a.add[co * oplane + p];
+    const float b = a.bias ? a.bias[co] : 0.0f;
+    float r[PX];
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+      r[p] = acc[p][c] + b;
+      if (a.relu) r[p] = __builtin_fmaxf(r[p], 0.0f);
     }
-    a.out[co * oplane + p] = r;
+    if (a.add) {
+#pragma unroll
+      for (int p = 0; p < PX; ++p) {
+        if (xo + p >= a.Wo) break;
+        if (a.add_up2) r[p] += a.add[(size_t)co * (a.Ho / 2) * (a.Wo / 2) + (size_t)(yo >> 1) * (a.Wo / 2) + ((xo + p) >> 1)];   // nearest x2
+        else r[p] += a.add[co * oplane + (size_t)yo * a.Wo + xo + p];
+      }
+    }
+    float* op = a.out + co * oplane + (size_t)yo * a.Wo + xo;
+    if constexpr (PX == 4) {
+      if (whole && (a.Wo & 3) == 0) { *reinterpret_cast<float4*>(op) = make_float4(r[0], r[1], r[2], r[3]); continue; }
+    }
+    if constexpr (PX == 2) {
+      if (whole && (a.Wo & 1) == 0) { *reinterpret_cast<float2*>(op) = make_float2(r[0], r[1]); continue; }
+    }
+#pragma unroll
+    for (int p = 0; p < PX; ++p) if (xo + p < a.Wo) op[p] = r[p];
   }
+}
+
+template <int K, int S, int PX>
+int launch(Args a, hipStream_t s) {
+  a.groups_per_row = (a.Wo + PX - 1) / PX;
+  dim3 grid((a.Ho * a.groups_per_row + kThreads - 1) / kThreads, (a.Cout + kCT - 1) / kCT);
+  conv2d_kernel<K, S, PX><<<grid, kThreads, 0, s>>>(a);
+  return check_launch("svs_conv2d");
+}
+
+// ---- k = 3 / 5: output tile 64 x (4 PY) per block, input tile (+ halo) of a few channels at a time in LDS ----------
+// Thread (column tx = lane, wave wv) owns PY vertically adjacent output pixels x 8 channels.  Per input channel and
+// kernel column it reads the (PY - 1) S + K input values of its column from LDS (lanes side by side: conflict-free at
+// stride 1, two-way at stride 2) for K * PY * 8 FMAs; global memory is read once per tile (coalesced, zero-filled halo).
+constexpr int kTileW = 64;
+constexpr int kTileThreads = 256;
+constexpr int kTileLdsBudget = 40 * 1024;
+
+template <int K, int S, int PY> struct TileDims {
+  static constexpr int TH = 4 * PY, ROWS = (TH - 1) * S + K, COLS = (kTileW - 1) * S + K, PER_CH = ROWS * COLS;
+};
+
+template <int K, int S, int PY>
+__global__ __launch_bounds__(kTileThreads) void conv2d_tile_kernel(Args a) {
+  extern __shared__ float tile[];               // [channel of the chunk][ROWS][COLS]
+  using D = TileDims<K, S, PY>;
+  constexpr int KK = K * K, PAD = K / 2, SPAN = (PY - 1) * S + K;
+  const int tx = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int tiles_x = (a.Wo + kTileW - 1) / kTileW;
+  const int by = blockIdx.x / tiles_x, bx = blockIdx.x - by * tiles_x;
+  const int xo0 = bx * kTileW, yo0 = by * D::TH;
+  const int ix0 = xo0 * S - PAD, iy0 = yo0 * S - PAD;
+  const int co0 = blockIdx.y * kCT;
+  const float* __restrict__ wg = a.w + (size_t)blockIdx.y * a.Cin * KK * kCT;      // wave-uniform: scalar loads
+  const size_t plane = (size_t)a.H * a.W;
+  float acc[PY][kCT];
+#pragma unroll
+  for (int p = 0; p < PY; ++p)
+#pragma unroll
+    for (int c = 0; c < kCT; ++c) acc[p][c] = 0.0f;
+  for (int c0 = 0; c0 < a.Cin; c0 += a.chunk) {
+    const int nc = a.Cin - c0 < a.chunk ? a.Cin - c0 : a.chunk;
+    __syncthreads();                            // the previous chunk has been consumed
+    for (int i = threadIdx.x; i < nc * D::PER_CH; i += kTileThreads) {
+      const int c = i / D::PER_CH, r = i - c * D::PER_CH, ry = r / D::COLS, rx = r - ry * D::COLS;
+      const int iy = iy0 + ry, ix = ix0 + rx;
+      float v = 0.0f;
+      if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) v = a.in[(c0 + c) * plane + (size_t)iy * a.W + ix];
+      tile[i] = v;
+    }
+    __syncthreads();
+    for (int c = 0; c < nc; ++c) {
+      const float* tp = tile + c * D::PER_CH + (wv * PY * S) * D::COLS + tx * S;
+      const float4* wp = reinterpret_cast<const float4*>(wg + (size_t)(c0 + c) * KK * kCT);
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        float v[SPAN];
+#pragma unroll
+        for (int j = 0; j < SPAN; ++j) v[j] = tp[j * D::COLS + kx];
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+          const float4 w0 = wp[(ky * K + kx) * 2], w1 = wp[(ky * K + kx) * 2 + 1];
+          const float wv8[kCT] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+          for (int p = 0; p < PY; ++p)
+#pragma unroll
+            for (int cc = 0; cc < kCT; ++cc) acc[p][cc] = __builtin_fmaf(wv8[cc], v[p * S + ky], acc[p][cc]);
+        }
+      }
+    }
+  }
+  const int xo = xo0 + tx;
+  if (xo >= a.Wo) return;
+  const size_t oplane = (size_t)a.Ho * a.Wo;
+#pragma unroll
+  for (int p = 0; p < PY; ++p) {
+    const int yo = yo0 + wv * PY + p;
+    if (yo >= a.Ho) break;
+#pragma unroll
+    for (int c = 0; c < kCT; ++c) {
+      const int co = co0 + c;
+      if (co >= a.Cout) break;
+      float r = acc[p][c] + (a.bias ? a.bias[co] : 0.0f);
+      if (a.relu) r = __builtin_fmaxf(r, 0.0f);
+      if (a.add) {
+        if (a.add_up2) r += a.add[(size_t)co * (a.Ho / 2) * (a.Wo / 2) + (size_t)(yo >> 1) * (a.Wo / 2) + (xo >> 1)];   // nearest x2
+        else r += a.add[co * oplane + (size_t)yo * a.Wo + xo];
+      }
+      a.out[co * oplane + (size_t)yo * a.Wo + xo] = r;
+    }
+  }
+}
+
+template <int K, int S, int PY>
+int launch_tile(Args a, hipStream_t s) {
+  using D = TileDims<K, S, PY>;
+  int chunk = kTileLdsBudget / (D::PER_CH * (int)sizeof(float));
+  chunk = chunk < 1 ? 1 : (chunk > 8 ? 8 : chunk);
+  a.chunk = chunk < a.Cin ? chunk : a.Cin;
+  const size_t lds = (size_t)a.chunk * D::PER_CH * sizeof(float);
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_tile_kernel<K, S, PY>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("svs_conv2d: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+  }
+  dim3 grid(((a.Wo + kTileW - 1) / kTileW) * ((a.Ho + D::TH - 1) / D::TH), (a.Cout + kCT - 1) / kCT);
+  conv2d_tile_kernel<K, S, PY><<<grid, kTileThreads, lds, s>>>(a);
+  return check_launch("svs_conv2d");
+}
+
+// PY = 1 (64 x 4 tiles, ~13 KiB of LDS per block) everywhere: taller tiles lose more to the un-overlapped load phase of a
+// block than they gain in halo re-reads -- several small blocks per CU overlap each other's loads and FMAs (measured on
+// the 512 x 640 pyramid: 0.35 ms of kernel time at PY = 1, 0.37 at PY = 2 where it still gives 512 blocks, 0.58 at PY = 4).
+template <int K, int S>
+int launch_tiled(const Args& a, hipStream_t s) { return launch_tile<K, S, 1>(a, s); }
+
+// the largest PX that still gives the launch kMinWaves waves (256 CUs x 4 SIMDs; the accumulators give each wave plenty of
+// independent work, so a few waves per SIMD hide the load latency)
+constexpr int kMinWaves = 2048;
+template <int K, int S>
+int launch_px(const Args& a, hipStream_t s) {
+  const long cgroups = (a.Cout + kCT - 1) / kCT;
+  auto waves = [&](int px) { return (long)a.Ho * ((a.Wo + px - 1) / px) / 64 * cgroups; };
+  if (waves(4) >= kMinWaves) return launch<K, S, 4>(a, s);
+  if (waves(2) >= kMinWaves) return launch<K, S, 2>(a, s);
+  return launch<K, S, 1>(a, s);
 }
 
 }  // namespace conv2d
@@ -76,6 +242,38 @@ __global__ __launch_bounds__(256) void conv2d_kernel(Args a) {
 using namespace svs;
 using namespace svs::conv2d;
 
+namespace {
+
+int run_conv(const float* in, const float* weight, const float* bias, const float* add, int add_upsample2, float* out,
+             int Cin, int Cout, int H, int W, int k, int stride, int relu, hipStream_t s) {
+  Args a;
+  a.in = in; a.w = weight; a.bias = bias; a.add = add; a.out = out; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+  a.relu = relu; a.add_up2 = add_upsample2; a.groups_per_row = 0; a.chunk = 0;
+  const int pad = k / 2;
+  a.Ho = (H + 2 * pad - k) / stride + 1; a.Wo = (W + 2 * pad - k) / stride + 1;
+  if (add && add_upsample2 && ((a.Ho & 1) || (a.Wo & 1))) { set_error("svs_conv2d: x2 up-sampled addend needs even output sizes"); return SVS_ESHAPE; }
+  if (k == 1) return stride == 1 ? launch_px<1, 1>(a, s) : launch_px<1, 2>(a, s);
+  if (stride == 1) return k == 3 ? launch_tiled<3, 1>(a, s) : launch_tiled<5, 1>(a, s);
+  return k == 3 ? launch_tiled<3, 2>(a, s) : launch_tiled<5, 2>(a, s);
+}
+
+// workspace layout of svs_featurenet_fpn (floats), P = H * W, b = base channels
+struct FpnBuffers {
+  size_t c0a, c0, c1a, c1b, c1, c2a, c2b, c2, f1, f2, total;
+  FpnBuffers(int b, int H, int W) {
+    const size_t P = (size_t)H * W;
+    size_t o = 0;
+    auto take = [&](size_t n) { const size_t at = o; o += (n + 63) & ~(size_t)63; return at; };
+    c0a = take(b * P); c0 = take(b * P);
+    c1a = take(2 * b * P / 4); c1b = take(2 * b * P / 4); c1 = take(2 * b * P / 4);
+    c2a = take(4 * b * P / 16); c2b = take(4 * b * P / 16); c2 = take(4 * b * P / 16);
+    f1 = take(4 * b * P / 4); f2 = take(4 * b * P);
+    total = o;
+  }
+};
+
+}  // namespace
+
 extern "C" {
 
 int svs_conv2d(const float* in, const float* weight, const float* bias, const float* add, int add_upsample2, float* out,
@@ -83,21 +281,44 @@ int svs_conv2d(const float* in, const float* weight, const float* bias, const fl
   if (!in || !weight || !out || Cin < 1 || Cout < 1 || H < 1 || W < 1 || (k != 1 && k != 3 && k != 5) || (stride != 1 && stride != 2)) {
     set_error("svs_conv2d: bad argument (k in {1,3,5}, stride in {1,2})"); return SVS_EINVAL;
   }
-  if (Cin * k * k * kCT > kMaxW) { set_error("svs_conv2d: Cin * k * k too large for the LDS weight slice"); return SVS_ESHAPE; }
-  Args a;
-  a.in = in; a.w = weight; a.bias = bias; a.add = add; a.out = out; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
-  a.k = k; a.stride = stride; a.pad = k / 2; a.relu = relu; a.add_up2 = add_upsample2;
-  a.Ho = (H + 2 * a.pad - k) / stride + 1; a.Wo = (W + 2 * a.pad - k) / stride + 1;
-  if (add && add_upsample2 && ((a.Ho & 1) || (a.Wo & 1))) { set_error("svs_conv2d: x2 up-sampled addend needs even output sizes"); return SVS_ESHAPE; }
-  const size_t lds = (size_t)Cin * k * k * kCT * sizeof(float);
-  hipStream_t s = (hipStream_t)hip_stream;
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { set_error("svs_conv2d: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+  return run_conv(in, weight, bias, add, add_upsample2, out, Cin, Cout, H, W, k, stride, relu, (hipStream_t)hip_stream);
+}
+
+size_t svs_featurenet_fpn_workspace_bytes(int base_channels, int H, int W) {
+  if (base_channels < 1 || H < 4 || W < 4) return 0;
+  return FpnBuffers(base_channels, H, W).total * sizeof(float);
+}
+
+int svs_featurenet_fpn(const float* image, int H, int W, int base_channels, const float* const* weights, const float* const* biases,
+                       float* workspace, float* stage1, float* stage2, float* stage3, void* hip_stream) {
+  if (!image || !weights || !biases || !workspace || !stage1 || !stage2 || !stage3 || base_channels < 1) {
+    set_error("svs_featurenet_fpn: null argument"); return SVS_EINVAL;
   }
-  dim3 grid((a.Ho * a.Wo + 255) / 256, (Cout + kCT - 1) / kCT);
-  conv2d_kernel<<<grid, 256, lds, s>>>(a);
-  return check_launch("svs_conv2d");
+  if (H < 4 || W < 4 || (H & 3) || (W & 3)) { set_error("svs_featurenet_fpn: image height and width must be multiples of 4"); return SVS_ESHAPE; }
+  for (int i = 0; i < 13; ++i) if (!weights[i]) { set_error("svs_featurenet_fpn: weights[%d] is null", i); return SVS_EINVAL; }
+  const int b = base_channels, H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
+  const FpnBuffers B(b, H, W);
+  float* ws = workspace;
+  hipStream_t s = (hipStream_t)hip_stream;
+  int rc;
+#define SVS_FPN(...) if ((rc = run_conv(__VA_ARGS__)) != SVS_OK) return rc
+  // bottom-up path (models/CasMVSNet.py:343-361): conv + folded BatchNorm + ReLU
+  SVS_FPN(image, weights[0], biases[0], nullptr, 0, ws + B.c0a, 3, b, H, W, 3, 1, 1, s);
+  SVS_FPN(ws + B.c0a, weights[1], biases[1], nullptr, 0, ws + B.c0, b, b, H, W, 3, 1, 1, s);
+  SVS_FPN(ws + B.c0, weights[2], biases[2], nullptr, 0, ws + B.c1a, b, 2 * b, H, W, 5, 2, 1, s);
+  SVS_FPN(ws + B.c1a, weights[3], biases[3], nullptr, 0, ws + B.c1b, 2 * b, 2 * b, H2, W2, 3, 1, 1, s);
+  SVS_FPN(ws + B.c1b, weights[4], biases[4], nullptr, 0, ws + B.c1, 2 * b, 2 * b, H2, W2, 3, 1, 1, s);
+  SVS_FPN(ws + B.c1, weights[5], biases[5], nullptr, 0, ws + B.c2a, 2 * b, 4 * b, H2, W2, 5, 2, 1, s);
+  SVS_FPN(ws + B.c2a, weights[6], biases[6], nullptr, 0, ws + B.c2b, 4 * b, 4 * b, H4, W4, 3, 1, 1, s);
+  SVS_FPN(ws + B.c2b, weights[7], biases[7], nullptr, 0, ws + B.c2, 4 * b, 4 * b, H4, W4, 3, 1, 1, s);
+  // top-down path (:413-431): the nearest x2 up-sampling is an index shift in the lateral convolution's epilogue
+  SVS_FPN(ws + B.c2, weights[8], biases[8], nullptr, 0, stage1, 4 * b, 4 * b, H4, W4, 1, 1, 0, s);               // out1
+  SVS_FPN(ws + B.c1, weights[9], biases[9], ws + B.c2, 1, ws + B.f1, 2 * b, 4 * b, H2, W2, 1, 1, 0, s);          // inner1 + up(c2)
+  SVS_FPN(ws + B.f1, weights[10], biases[10], nullptr, 0, stage2, 4 * b, 2 * b, H2, W2, 3, 1, 0, s);             // out2
+  SVS_FPN(ws + B.c0, weights[11], biases[11], ws + B.f1, 1, ws + B.f2, b, 4 * b, H, W, 1, 1, 0, s);              // inner2 + up(f1)
+  SVS_FPN(ws + B.f2, weights[12], biases[12], nullptr, 0, stage3, 4 * b, b, H, W, 3, 1, 0, s);                   // out3
+#undef SVS_FPN
+  return SVS_OK;
 }
 
 }  // extern "C"

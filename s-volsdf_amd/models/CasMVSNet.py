@@ -4,8 +4,8 @@ fused homography warp + variance, 3-D U-Net with folded BatchNorm, softmax / dep
 depth hypotheses.  Checkpoints load with strict=True (`feature.*`, `cost_regularization.{0,1,2}.*`).
 
 The 2-D feature pyramid (`FeatureNet`) keeps torch modules as parameter containers so that
-the reference's checkpoint loads; on the device in eval mode its convolutions run on csrc/svs_conv2d.hip (BatchNorm
-folded, the FPN's nearest up-sampling fused into the lateral convolutions).  Inference only, like the reference
+the reference's checkpoint loads; on the device in eval mode the whole pyramid is one call into csrc/svs_conv2d.hip
+(svs_featurenet_fpn: BatchNorm folded, the FPN's nearest up-sampling fused into the lateral convolutions).  Inference only, like the reference
 (`@torch.no_grad()` forward).
 """
 import torch
@@ -50,20 +50,22 @@ class Conv2d(nn.Module):
     def forward(self, x):
         if x.is_cuda and not self.training:
             w, b = self.folded()
-            return torch.stack([costvol.conv2d(xi, w, b, stride=self.stride, relu=self.relu) for xi in x])
+            return _conv_batch(x, w, b, stride=self.stride, relu=self.relu)
         x = self.conv(x)
         if self.bn is not None:
             x = self.bn(x)
         return F.relu(x) if self.relu else x
 
 
-def _plain_conv(conv, x, add=None, add_upsample2=False):
-    """nn.Conv2d (no norm, no activation) on the HIP kernel: (B,Cin,H,W) -> (B,Cout,H,W) [+ add]."""
-    outs = []
-    for i, xi in enumerate(x):
-        outs.append(costvol.conv2d(xi, conv.weight.detach(), conv.bias.detach() if conv.bias is not None else None,
-                                   add=None if add is None else add[i], add_upsample2=add_upsample2, stride=1, relu=False))
-    return torch.stack(outs)
+def _conv_batch(x, w, b, add=None, add_upsample2=False, stride=1, relu=False):
+    """(B,Cin,H,W) -> (B,Cout,Ho,Wo): one launch per image, written straight into the batch tensor."""
+    k = w.shape[-1]
+    Ho, Wo = (x.shape[2] + 2 * (k // 2) - k) // stride + 1, (x.shape[3] + 2 * (k // 2) - k) // stride + 1
+    out = torch.empty(x.shape[0], w.shape[0], Ho, Wo, device=x.device)
+    for i in range(x.shape[0]):
+        costvol.conv2d(x[i], w, b, add=None if add is None else add[i], add_upsample2=add_upsample2, stride=stride, relu=relu,
+                       out=out[i])
+    return out
 
 
 class FeatureNet(nn.Module):
@@ -84,20 +86,27 @@ class FeatureNet(nn.Module):
         self.out2 = nn.Conv2d(4 * b, 2 * b, 3, padding=1, bias=False)
         self.out3 = nn.Conv2d(4 * b, b, 3, padding=1, bias=False)
         self.out_channels = [4 * b, 2 * b, b]
+        self._fpn = None
+
+    def _layers(self):
+        """(weight, bias) of the 13 convolutions in svs_featurenet_fpn's order, BatchNorm folded."""
+        blocks = list(self.conv0) + list(self.conv1) + list(self.conv2)
+        plain = [self.out1, self.inner1, self.out2, self.inner2, self.out3]
+        return [blk.folded() for blk in blocks] + [(c.weight.detach(), None if c.bias is None else c.bias.detach()) for c in plain]
 
     def forward(self, x):
+        if x.is_cuda and not self.training:
+            # the whole pyramid from one library call per image (csrc/svs_conv2d.hip: svs_featurenet_fpn); like the
+            # reference's top-down additions (models/CasMVSNet.py:413-431) it needs H and W to be multiples of 4
+            if self._fpn is None:
+                self._fpn = costvol.FeatureNetFpn(self.base_channels)
+            layers = self._layers()
+            per_image = [self._fpn(xi, layers) for xi in x]
+            return {f"stage{j + 1}": torch.stack([o[j] for o in per_image]) if len(per_image) > 1 else per_image[0][j][None]
+                    for j in range(3)}
         c0 = self.conv0(x)
         c1 = self.conv1(c0)
         c2 = self.conv2(c1)
-        if x.is_cuda and not self.training:
-            # top-down path (models/CasMVSNet.py:413-431): the nearest x2 up-sampling is an index shift inside the
-            # lateral 1x1 convolution's epilogue, no up-sampled tensor is materialised
-            out = {"stage1": _plain_conv(self.out1, c2)}
-            f = _plain_conv(self.inner1, c1, add=c2, add_upsample2=True)
-            out["stage2"] = _plain_conv(self.out2, f)
-            f = _plain_conv(self.inner2, c0, add=f, add_upsample2=True)
-            out["stage3"] = _plain_conv(self.out3, f)
-            return out
         out = {"stage1": self.out1(c2)}
         f = F.interpolate(c2, scale_factor=2, mode="nearest") + self.inner1(c1)
         out["stage2"] = self.out2(f)

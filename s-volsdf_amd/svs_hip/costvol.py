@@ -116,25 +116,92 @@ def mfma_weight_fragments(weight):
     return frag
 
 
-def conv2d(x, weight, bias=None, add=None, add_upsample2=False, stride=1, relu=False):
+_W2D_CACHE = {}
+
+
+def conv2d_pack(weight):
+    """(Cout,Cin,k,k) -> [ceil(Cout/8)][Cin][k][k][8] float32, the layout svs_conv2d reads through the scalar cache
+    (include/svolsdf_hip.h).  Cached per weight tensor (address + version)."""
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), weight.device)
+    hit = _W2D_CACHE.get(key)
+    if hit is not None:
+        return hit[0]
+    if len(_W2D_CACHE) > 64:
+        _W2D_CACHE.clear()
+    Cout, Cin, k, _ = weight.shape
+    G = (Cout + 7) // 8
+    w = torch.zeros(G * 8, Cin, k, k, device=weight.device, dtype=torch.float32)
+    w[:Cout] = weight.detach().float()
+    packed = w.view(G, 8, Cin, k, k).permute(0, 2, 3, 4, 1).contiguous()
+    _W2D_CACHE[key] = (packed, weight)                     # keep `weight` alive: the key holds its address
+    return packed
+
+
+def conv2d(x, weight, bias=None, add=None, add_upsample2=False, stride=1, relu=False, out=None):
     """FeatureNet convolution (csrc/svs_conv2d.hip): x (Cin,H,W), weight (Cout,Cin,k,k) with BatchNorm folded, padding
     k // 2 -> (Cout,Ho,Wo) = [add +] relu?(conv + bias); add_upsample2: `add` is at half resolution (nearest x2)."""
     L = _lib.load()
-    x, weight = _f32(x), _f32(weight)
+    x = _f32(x)
     Cin, H, W = x.shape
     Cout, cin_w, k, k2 = weight.shape
     if cin_w != Cin or k != k2:
         raise ValueError("weight shape does not match the input")
     pad = k // 2
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-    out = torch.empty(Cout, Ho, Wo, device=x.device)
+    if out is None:
+        out = torch.empty(Cout, Ho, Wo, device=x.device)
+    elif tuple(out.shape) != (Cout, Ho, Wo) or not out.is_contiguous() or out.dtype != torch.float32:
+        raise ValueError("out must be a contiguous float32 (Cout,Ho,Wo) tensor")
     bias = _f32(bias) if bias is not None else None
     add = _f32(add) if add is not None else None
     if add is not None and tuple(add.shape) != ((Cout, Ho // 2, Wo // 2) if add_upsample2 else (Cout, Ho, Wo)):
         raise ValueError("addend shape does not match the output")
-    _lib.check(L.svs_conv2d(_ptr(x), _ptr(weight), _ptr(bias), _ptr(add), int(bool(add_upsample2)), _ptr(out), Cin, Cout, H, W, k,
-                            stride, int(bool(relu)), _stream()), "svs_conv2d")
+    _lib.check(L.svs_conv2d(_ptr(x), _ptr(conv2d_pack(weight)), _ptr(bias), _ptr(add), int(bool(add_upsample2)), _ptr(out), Cin,
+                            Cout, H, W, k, stride, int(bool(relu)), _stream()), "svs_conv2d")
     return out
+
+
+class FeatureNetFpn:
+    """The 13 convolutions of the 'fpn' FeatureNet enqueued by ONE library call (svs_featurenet_fpn): the per-launch host
+    cost of going through Python 13 times was as large as the kernels' run time."""
+    LAYERS = 13
+
+    def __init__(self, base_channels):
+        self.b = int(base_channels)
+        self._ws, self._ws_key = None, None
+        self._tables, self._tables_key = None, None
+
+    def tables(self, layers):
+        """layers: 13 (weight (Cout,Cin,k,k), bias or None) pairs in the library's order -> pointer tables (cached until
+        a tensor changes)."""
+        key = tuple((w.data_ptr(), w._version, None if b is None else (b.data_ptr(), b._version)) for w, b in layers)
+        if key != self._tables_key:
+            packed = [conv2d_pack(w) for w, _ in layers]
+            biases = [None if b is None else _f32(b) for _, b in layers]
+            self._tables = (_ptr_array(packed), _ptr_array(biases), packed, biases, layers)
+            self._tables_key = key
+        return self._tables
+
+    def __call__(self, image, layers):
+        """image (3,H,W) -> stage1 (4b,H/4,W/4), stage2 (2b,H/2,W/2), stage3 (b,H,W)."""
+        L = _lib.load()
+        if len(layers) != self.LAYERS:
+            raise ValueError("13 layers expected")
+        image = _f32(image)
+        _, H, W = image.shape
+        if image.shape[0] != 3 or H % 4 or W % 4:
+            raise ValueError("image must be (3,H,W) with H, W multiples of 4")
+        dev, b = image.device, self.b
+        if self._ws_key != (H, W, dev):
+            self._ws = torch.empty(L.svs_featurenet_fpn_workspace_bytes(b, H, W) // 4, device=dev)
+            self._ws_key = (H, W, dev)
+        wt, bt = self.tables(layers)[:2]
+        s1 = torch.empty(4 * b, H // 4, W // 4, device=dev)
+        s2 = torch.empty(2 * b, H // 2, W // 2, device=dev)
+        s3 = torch.empty(b, H, W, device=dev)
+        _lib.check(L.svs_featurenet_fpn(_ptr(image), H, W, b, wt, bt, _ptr(self._ws), _ptr(s1), _ptr(s2), _ptr(s3), _stream()),
+                   "svs_featurenet_fpn")
+        return s1, s2, s3
 
 
 _GEMM_ON = [True]

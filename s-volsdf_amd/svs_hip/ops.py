@@ -205,6 +205,11 @@ class PackedBg:
     """Packed weight streams of bg_implicit_network / bg_rendering_network (no weight-norm)."""
 
     def __init__(self, device):
+        if default_precision() != F16X2:
+            # the background networks have fp16x2 kernels only (csrc/svs_bg_h2.hip); running them under a setting that
+            # promises float32 MFMA arithmetic would silently break that promise
+            raise NotImplementedError("SVS_MLP_PRECISION=f32 is not available for the inverted-sphere background model "
+                                      "(VolSDFNetworkBG): its networks run on the fp16x2 kernels only; unset SVS_MLP_PRECISION")
         L = _lib.load()
         self.device = device
         self.sdf_stream = torch.empty(L.svs_stream_bytes(5) // 4, device=device)

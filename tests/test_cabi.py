@@ -61,3 +61,16 @@ def test_missing_library_fails_loudly(lib, monkeypatch):
     monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libsvolsdf_hip.so")
     with pytest.raises(lib.SvsError):
         lib.load()
+
+
+def test_background_model_refuses_f32_setting(monkeypatch):
+    """SVS_MLP_PRECISION=f32 promises float32 MFMA arithmetic; the background networks only have fp16x2 kernels, so the
+    combination is an explicit error (before any device work), not a silent mix."""
+    import pytest
+    from svs_hip import ops
+    monkeypatch.setenv("SVS_MLP_PRECISION", "f32")
+    with pytest.raises(NotImplementedError, match="background"):
+        ops.PackedBg("cpu")
+    monkeypatch.setenv("SVS_MLP_PRECISION", "bf16")
+    with pytest.raises(ValueError):
+        ops.default_precision()

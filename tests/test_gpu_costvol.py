@@ -225,3 +225,31 @@ def test_feature_net_hip(dev, golden_dir, hw):
     assert np.abs(want["stage3"]).max() > 0.1
     net.train()                                                             # train mode: the torch modules (autograd), not the HIP path
     assert net(x)["stage1"].requires_grad
+
+
+@pytest.mark.parametrize("k,stride", [(1, 1), (1, 2), (3, 1), (3, 2), (5, 1), (5, 2)])
+def test_conv2d_single_layer(dev, k, stride):
+    """svs_conv2d alone (the entry the fused pyramid call is built from) against torch.nn.functional.conv2d on the CPU:
+    ragged sizes (tiles cut by both image edges), channel counts that are not multiples of 8, bias / ReLU / both kinds
+    of addend.  float32 FMA chains in a different order than torch's: 2e-5 absolute on O(1) outputs."""
+    from svs_hip import costvol
+    rs = np.random.default_rng(10 * k + stride)
+    for (Cin, Cout, H, W) in ((3, 8, 37, 70), (11, 13, 24, 132), (32, 8, 16, 64)):
+        x = rs.standard_normal((Cin, H, W)).astype(F32)
+        w = (rs.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(F32)
+        b = rs.standard_normal(Cout).astype(F32)
+        ref = torch.nn.functional.conv2d(torch.from_numpy(x)[None], torch.from_numpy(w), torch.from_numpy(b), stride=stride,
+                                         padding=k // 2)[0]
+        got = costvol.conv2d(G(x, dev), G(w, dev), G(b, dev), stride=stride, relu=False)
+        assert got.shape == ref.shape
+        np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), atol=2e-5)
+        Ho, Wo = ref.shape[1:]
+        add = rs.standard_normal((Cout, Ho, Wo)).astype(F32)
+        got = costvol.conv2d(G(x, dev), G(w, dev), None, add=G(add, dev), stride=stride, relu=True)
+        ref2 = torch.relu(ref - torch.from_numpy(b)[:, None, None]) + torch.from_numpy(add)
+        np.testing.assert_allclose(got.cpu().numpy(), ref2.numpy(), atol=2e-5)
+        if Ho % 2 == 0 and Wo % 2 == 0:
+            half = rs.standard_normal((Cout, Ho // 2, Wo // 2)).astype(F32)
+            got = costvol.conv2d(G(x, dev), G(w, dev), G(b, dev), add=G(half, dev), add_upsample2=True, stride=stride)
+            up = torch.nn.functional.interpolate(torch.from_numpy(half)[None], scale_factor=2, mode="nearest")[0]
+            np.testing.assert_allclose(got.cpu().numpy(), (ref + up).numpy(), atol=2e-5)
