@@ -18,9 +18,9 @@ steps until `--settle` seconds of steady state have passed (clocks, allocator), 
 steps, synchronize + barrier; the maximum over ranks is reported.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the kernel with the largest time per step; the per-launch durations
-come from HIP events on the launch streams (svs_hip/profiling.py) over eager steps run right AFTER the timed region in
-the same process -- events cannot be read back from inside a replayed graph -- and are listed for every fused-MLP
-kernel under `roofline.kernels`.  `cpu_baseline` times the CPU port on a bounded sample of the same workload.
+come from HIP events on each kernel's own launch stream (svs_hip/profiling.py) over steps run right AFTER the timed
+region in the same process -- an event pair per launch would perturb the timed region, and a replayed graph's kernels
+cannot be bracketed at all -- and are listed for every fused-MLP kernel under `roofline.kernels`.  `cpu_baseline` times the CPU port on a bounded sample of the same workload.
 SVS_MLP_PRECISION=f32 selects the float32-MFMA kernels instead of the default fp16x2 split-operand ones.
 """
 import argparse
@@ -319,8 +319,9 @@ def kernel_roofline(ts, step, R, S, h2, train, n_steps=12):
     top = dict(rows[0])
     top["traffic"] = traffic.get(top["kernel"], {}).get("hbm_bytes")
     top["traffic_source"] = src_prof
-    top["timing"] = (f"HIP events on the launch streams over {n_steps} eager steps after the timed region (same process; the "
-                     "timed region replays a hipGraph, whose kernels cannot be bracketed by events)")
+    top["timing"] = (f"HIP events on each kernel's own launch stream over {n_steps} steps after the timed region (same "
+                     "process, same launch sequence; kept out of the timed region because an event pair per launch "
+                     "serialises the host side)")
     top["peak_note"] = ("mfma rows: algorithmic float32 FLOP; fp16x2 evaluates each product as three fp16 MFMA products: "
                         "peak = 2500 / 3 TFLOP/s.  hbm rows: algorithmic bytes = every activation block the launch "
                         "reads or writes, once" if h2 else "dense float32 MFMA peak / HBM3E peak")
