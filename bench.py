@@ -88,6 +88,7 @@ def main():
                          "chain); off (default): eager launches -- measured faster on this ROCm stack, see DESIGN.md")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel event timing (roofline = null)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exact-f32", action="store_true", help="skip the extra float32-MFMA run (exact_f32_ms_per_step)")
     args = ap.parse_args()
 
     import numpy as np
@@ -239,7 +240,7 @@ def main():
                        "model_flops_per_s": world * R * args.steps / dt * flop_per_ray},
             "roofline": roofline,
         }
-        if train and h2 and world == 1 and args.model == "dtu" and not args.no_kernel_timing:
+        if train and h2 and world == 1 and args.model == "dtu" and not args.no_kernel_timing and not args.no_exact_f32:
             line["exact_f32_ms_per_step"] = exact_f32_step_ms(make_model, make_step)
         if not args.no_cpu_baseline and args.model == "dtu":
             line["cpu_baseline"] = cpu_baseline(params, K, pose, train=train)

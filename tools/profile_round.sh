@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --no-cpu-baseline"
+B="python3 $R/bench.py --no-cpu-baseline --no-exact-f32"
 rocprofv3 --kernel-trace --stats -d $O/train --output-format csv -- $B --steps 20 --warmup 10 > $O/train.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/render --output-format csv -- $B --mode render --steps 20 --warmup 10 > $O/render.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/train_onegroup --output-format csv -- $B --steps 20 --warmup 10 --groups none > $O/onegroup.log 2>&1
@@ -19,6 +19,10 @@ rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch --output-format csv -- $C > $O/f.log 
 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write --output-format csv -- $C > $O/w.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE \
   -d $O/pmc_mfma --output-format csv -- $C --groups none > $O/m.log 2>&1
+# secondary paths: the cost-volume build at config 3 and a whole-image eval render (fast = -1, 500-ray chunks)
+rocprofv3 --kernel-trace --stats -d $O/costvol --output-format csv -- python3 $R/tools/bench_costvol.py > $O/costvol.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/evalrender --output-format csv -- python3 $R/tools/bench_render_eval.py > $O/evalrender.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/featurenet --output-format csv -- python3 $R/tools/bench_featurenet.py > $O/featurenet.log 2>&1
 cd $R
 # keep what travels back small: the stats files and the counter tables only
 find $O -name '*kernel_trace.csv' -delete

@@ -1,6 +1,8 @@
 """Turns the rocprofv3 outputs under gpurun_out/<run>/ into the small summaries committed under profiles/:
   <tag>_train_kernel_stats.csv / <tag>_render_kernel_stats.csv   (rocprofv3 --kernel-trace --stats, as written)
   <tag>_train_onegroup_kernel_stats.csv                           (the same step as ONE ray group: a launch = a batch)
+  <tag>_{costvol,evalrender,featurenet}_kernel_stats.csv + _result.txt   (tools/bench_costvol.py = config 3, tools/
+                           bench_render_eval.py = a 768x576 eval render with fast = -1, tools/bench_featurenet.py)
   <tag>_pmc_mfma.json      matrix-core utilisation + wave-time split from the SQ counters (one-group step)
   <tag>_pmc_traffic.json   per-kernel HBM bytes per launch from separate --pmc FETCH_SIZE / WRITE_SIZE passes,
                            corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE counts 64 B per 128-B
@@ -31,10 +33,17 @@ def main(src, tag):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = os.path.join(root, "profiles")
     os.makedirs(out, exist_ok=True)
-    for mode in ("train", "render", "train_onegroup"):
+    for mode in ("train", "render", "train_onegroup", "costvol", "evalrender", "featurenet"):
         f = glob.glob(os.path.join(src, mode, "*", "*kernel_stats.csv"))
         if f:
             shutil.copy(f[0], os.path.join(out, f"{tag}_{mode}_kernel_stats.csv"))
+    # the JSON lines the secondary benches printed under the profiler
+    for name in ("costvol", "evalrender", "featurenet"):
+        log = os.path.join(src, name + ".log")
+        if os.path.exists(log):
+            lines = [ln.strip() for ln in open(log) if ln.startswith("{") or ln.startswith("FeatureNet")]
+            if lines:
+                open(os.path.join(out, f"{tag}_{name}_result.txt"), "w").write("\n".join(lines) + "\n")
     fetch = agg(os.path.join(src, "pmc_fetch", "*", "*counter_collection.csv"), "FETCH_SIZE")
     write = agg(os.path.join(src, "pmc_write", "*", "*counter_collection.csv"), "WRITE_SIZE")
     res = {"_note": "bytes per launch; fetch = 2 * FETCH_SIZE KiB (gfx950 wide-stream correction), write = WRITE_SIZE KiB",
