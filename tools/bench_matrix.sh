@@ -1,0 +1,22 @@
+#!/bin/bash
+# The secondary bench lines quoted in DESIGN.md section 5 (one GPU):  gpurun -- 'bash tools/bench_matrix.sh'
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/matrix; mkdir -p $O
+B="python3 $R/bench.py --no-cpu-baseline --no-exact-f32 --no-kernel-timing --steps 100"
+run() { name=$1; shift; $B "$@" 2>/dev/null | tail -1 > $O/$name.json; python3 - "$name" "$O/$name.json" <<'PY'
+import json, sys
+d = json.load(open(sys.argv[2]))
+print(f"{sys.argv[1]:14s} {d['ms_per_step']:.3f} ms/step  {d['value']:.0f} {d['unit']}")
+PY
+}
+run default
+run onegroup --groups none
+run render --mode render
+run bmvs --model bmvs
+run bmvs2048 --model bmvs --rays 2048
+run rays2048 --rays 2048
+run rays256 --rays 256
+run rays512 --rays 512
+run graph --graph on
+run graph256 --graph on --rays 256
+SVS_MLP_PRECISION=f32 run f32

@@ -1,3 +1,8 @@
+"""Reproducer of a HIP runtime defect met while capturing the train step ("hipGraph capture"): during
+stream capture, a stream forked from an already forked stream that joins back into its PARENT FORK (not into the origin
+stream) makes hipStreamEndCapture crash.  Each variant runs in a child process (the crash is a segfault) on one GPU:
+    python tools/repro_hip_capture_nested_fork.py
+svs_hip/trainer.py avoids the pattern: join events of nested forks are waited on by the origin stream."""
 import os, sys, subprocess
 CHILD = r'''
 import os, torch
