@@ -208,7 +208,8 @@ def main():
             flop_per_ray += (S + 2) * (2 * F_SDF + 2 * F_SDF) + S * (2 * F_RGB)
         roofline = None
         if not args.no_kernel_timing and world == 1:
-            roofline = kernel_roofline(ts, step, R, S, h2, train)
+            sizes = [g[1] - g[0] for g in ts.split_rays(R, S)] if (train and args.groups == "auto") else None
+            roofline = kernel_roofline(ts, step, R, S, h2, train, ray_groups=sizes)
         line = {
             "metric": "rendered rays/sec (1024-ray batch, 128 samples)",
             "value": world * R * args.steps / dt,
@@ -250,7 +251,7 @@ def main():
         dist.destroy_process_group()
 
 
-def kernel_roofline(ts, step, R, S, h2, train, n_steps=12):
+def kernel_roofline(ts, step, R, S, h2, train, n_steps=12, ray_groups=None):
     """Per-launch durations of every fused-MLP kernel over eager steps (HIP events on the launch streams), and the
     roofline of the one with the largest time per step."""
     import numpy as np
@@ -283,21 +284,29 @@ def kernel_roofline(ts, step, R, S, h2, train, n_steps=12):
                 kinds.setdefault(int(a[1]), []).append(t)
             for n_jobs, tt in kinds.items():
                 which = "radiance" if n_jobs == 5 else "sdf"
-                pts = (R * S if which == "radiance" else R * (S + 2)) * n_steps / len(tt)
-                rows.append(dict(entry=name, kernel=(k_h2 if h2 else k_f32), what=f"{what} ({which}, {n_jobs} layers)",
-                                 bound=bound, launches_per_step=len(tt) / n_steps, kernel_ms=float(np.mean(tt)),
-                                 points_per_launch=pts, work_per_point=bpp.get("wgrad_" + which)))
+                per_step = len(tt) // n_steps                  # one launch per ray group, enqueued in group order
+                sizes = ray_groups if (ray_groups and len(ray_groups) == per_step) else [R] * per_step
+                for gi, rays in enumerate(sizes):
+                    tg = tt[gi::per_step]
+                    pts = rays * S if which == "radiance" else rays * (S + 2)
+                    rows.append(dict(entry=name, kernel=(k_h2 if h2 else k_f32), what=f"{what} ({which}, {n_jobs} layers)",
+                                     bound=bound, launches_per_step=len(tg) / n_steps, kernel_ms=float(np.mean(tg)),
+                                     points_per_launch=float(pts), work_per_point=bpp.get("wgrad_" + which)))
             continue
         if name in ("svs_rgb_bwd", "svs_sdf_bwd_b"):
             pts = [int(a[0]) for a in metas]
         else:
             pts = [int(a[1]) + int(a[6]) * int(a[7]) for a in metas]
-        if name == "svs_sdf_vals":
-            pass
         w = work if work is not None else bpp.get(name)
-        rows.append(dict(entry=name, kernel=(k_h2 if h2 else k_f32), what=what, bound=bound,
-                         launches_per_step=len(ms) / n_steps, kernel_ms=float(np.mean(ms)),
-                         points_per_launch=float(np.mean(pts)), work_per_point=w))
+        # one row per launch SHAPE: the default step runs two ray groups of very different size (976 + 48 rays), and a
+        # rate averaged over both would describe neither launch
+        shapes = {}
+        for t, n_pts in zip(ms, pts):
+            shapes.setdefault(n_pts, []).append(t)
+        for n_pts, tt in shapes.items():
+            rows.append(dict(entry=name, kernel=(k_h2 if h2 else k_f32), what=what, bound=bound,
+                             launches_per_step=len(tt) / n_steps, kernel_ms=float(np.mean(tt)),
+                             points_per_launch=float(n_pts), work_per_point=w))
     for r in rows:
         r["ms_per_step"] = r["kernel_ms"] * r["launches_per_step"]
         per_launch = (r["work_per_point"] or 0) * r["points_per_launch"]
@@ -369,7 +378,7 @@ def cpu_baseline(params, K, pose, train=True, reps=5, warm=2):
     """CPU port of the reference's PyTorch path on a bounded sample of the same workload: numpy oracle for the sampler and
     the MVS prior lookup, plain torch float32 autograd (oracle/torch_ref.py) for the differentiable part, clip + Adam.
     Timed at 1 thread (what the reference's trainer forces, volsdf/vsdf.py:21), 8 threads and all host threads; the
-    sample size per thread count keeps one repetition at a few seconds."""
+    256 rays per repetition (about 3 s single-threaded)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import torch
@@ -410,7 +419,7 @@ def cpu_baseline(params, K, pose, train=True, reps=5, warm=2):
 
     by_threads = {}
     saved = torch.get_num_threads()
-    for threads, rays in ((1, 64), (8, 256), (min(all_threads, 32), 256)):
+    for threads, rays in ((1, 256), (8, 256), (min(all_threads, 32), 256)):
         if threads in by_threads or threads > all_threads:
             continue
         torch.set_num_threads(threads)
