@@ -82,7 +82,11 @@ struct RevEpi {
 
   // three slices, one per MFMA gap of a k-step: exp2 | 1 - e and the product | masks, split
   __device__ __forceinline__ void a(int r) {
+#if SVS_ABL & 512      // diagnostic: no softplus' arithmetic in the reverse epilogue
+    d = 0.5f;
+#else
     d = __builtin_amdgcn_exp2f(pair_at(h, r) * (-100.0f * 1.44269504088896341f));
+#endif
     pin(d);
   }
   __device__ __forceinline__ void a2(int r) {
@@ -115,7 +119,7 @@ struct RevEpi {
   }
   // the gbuf stores issued during tile t (see TrunkEpi::late_store): the hi pieces of k-steps 2(t-1) and 2(t-2)+1
   __device__ __forceinline__ void st(int t, int s) {
-    if (!gblk) return;
+    if (!gblk || (SVS_ABL & 256)) return;         // (256: diagnostic, no gbuf stores)
     if (s == 9) store_piece(gblk, 2 * (t - 1), lane, out->h[2 * (t - 1)]);
     if (t >= 2 && s == 11) store_piece(gblk, 2 * (t - 2) + 1, lane, out->h[2 * (t - 2) + 1]);
   }
@@ -143,7 +147,7 @@ __device__ __forceinline__ void reverse_layer_h2(Stream& st, const Pieces2& in, 
   for (int t = 0; t < 8; ++t) {
     const TilePieces hcur = hnext;
     auto hload = [&](int s) {
-      if (t == 7) return;
+      if (t == 7 || (SVS_ABL & 128)) return;      // (128: diagnostic, no h loads)
       if (s == 10) hnext.h[0] = load_piece(hblk, 2 * (t + 1), lane, 0);
       if (s == 12) hnext.h[1] = load_piece(hblk, 2 * (t + 1) + 1, lane, 0);
       if (s == 14) hnext.m[0] = load_piece(hblk, 2 * (t + 1), lane, 1);

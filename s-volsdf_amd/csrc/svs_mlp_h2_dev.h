@@ -83,7 +83,8 @@ __device__ __forceinline__ f32x16 tile_bias(const f32x4* __restrict__ chunk, int
 // Diagnostic builds (tools/ablate_fwd.sh): -DSVS_ABL=<mask> compiles parts of the forward kernels out to time the rest
 // (results are then wrong by construction).  1: identity instead of softplus, 2: no operand split, 4: no MFMAs,
 // 8: no chunk wait / barrier, 16: cycle stamps instead of results (sdf_only), 32: let the slimmer variants run two
-// workgroups per CU (otherwise their LDS request is padded to keep one).  Never defined in the product build.
+// workgroups per CU (otherwise their LDS request is padded to keep one), 64: no weight fetch; reverse pass of sdf_full:
+// 128: no h loads, 256: no gbuf stores, 512: no softplus' arithmetic.  Never defined in the product build.
 #ifndef SVS_ABL
 #define SVS_ABL 0
 #endif
