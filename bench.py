@@ -327,7 +327,10 @@ def kernel_roofline(ts, step, R, S, h2, train, n_steps=12, ray_groups=None):
     except Exception:
         pass
     top = dict(rows[0])
-    top["traffic"] = traffic.get(top["kernel"], {}).get("hbm_bytes")
+    # (the profile lists template instances: "svs::mlp::sdf_full_h2_kernel<true>"; its per-launch figure is the average
+    # over the launches of the profiled step, i.e. over both ray groups)
+    hit = [v for k, v in traffic.items() if k == top["kernel"] or k.startswith(top["kernel"] + "<")]
+    top["traffic"] = max((v.get("hbm_bytes") or 0.0) for v in hit) if hit else None
     top["traffic_source"] = src_prof
     top["timing"] = (f"HIP events on each kernel's own launch stream over {n_steps} steps after the timed region (same "
                      "process, same launch sequence; kept out of the timed region because an event pair per launch "

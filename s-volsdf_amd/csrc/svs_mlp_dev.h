@@ -4,6 +4,10 @@
 #include "svs_common.h"
 #include "svs_mlp_layout.h"
 
+#ifndef SVS_DMA_ASM
+#define SVS_DMA_ASM 1
+#endif
+
 namespace svs {
 namespace mlp {
 
@@ -21,9 +25,25 @@ __device__ __forceinline__ void chunk_issue_piece(const f32x4* __restrict__ g, f
   const int idx = i * kThreads + wave_base;  // wave-uniform (wave_base_f4(), read once per kernel: Stream::wb)
   const unsigned lane_bytes = (threadIdx.x & 63u) * 16u;
   if ((i + 1) * kThreads <= N16 || idx < N16) {   // i is a constant after unrolling: whole rounds carry no branch
+#if SVS_DMA_ASM
+    // Inline assembly, so that hipcc does not know the ring is written by vector-memory instructions.  The ring is
+    // ordered by hand (Stream::advance / advance_keep<N>: counted vmcnt + barrier, inline assembly as well, hence
+    // invisible to the waitcnt pass), and a DMA the pass can see makes it put `s_waitcnt vmcnt(0)` in front of the first
+    // LDS read of (every other) tile -- which drained exactly the loads and stores advance_keep<N> had left in flight:
+    // the reverse pass of sdf_full sat out the HBM latency of the h tile it had just requested, 32 k of its 180 k cycles.
+    // The pass now under-counts the operations in flight when it waits for an ordinary load, i.e. it waits for too much
+    // rather than too little: consumers therefore touch a side tile once at the TOP of the tile that uses it, before
+    // the tile's first piece is issued, where the count is exact (reverse_layer_h2).
+    // Address = SGPR pair + 32-bit lane offset: no per-piece vector address arithmetic.  M0 (LDS base of the piece) is a
+    // reserved register that hipcc re-materialises before each use of its own; one wait state before the DMA reads it.
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)(lds + idx);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(lane_bytes), "s"(g + idx), "s"(lds_base) : "memory");
+#else
     __builtin_amdgcn_global_load_lds(
         (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(g + idx) + lane_bytes),
         (__attribute__((address_space(3))) void*)(lds + idx), 16, 0, 0);
+#endif
   }
 }
 template <int N16>

@@ -70,13 +70,14 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_only_h2_kernel(SdfOnlyArgs a)
 // --------------------------------------------------------------------------------------------------------------
 // Epilogue of one tile of the gradient pass: ghat_{l-1} = g(a_{l-1}) = g(h_l) * softplus'(a_{l-1}) (softplus' from the
 // stored h_l tile `h`) -> gbuf (training), split into the next operand.
-struct RevEpi {
+template <bool GBUF>     // GBUF: training launch, ghat blocks are stored (compile-time: a run-time test put exec-mask
+struct RevEpi {           // branches into every tile and made hipcc's vmcnt bookkeeping take the minimum over both paths)
   f32x16 prev;
   TilePieces h;       // the stored h_l tile (pair block)
   float d;            // softplus' of the current slice
   float v8[8];
   Pieces2* out;
-  float* gblk;        // ghat_{l-1} block of gbuf (a HALF block, stored unscaled: record scale 1) or nullptr
+  float* gblk;        // ghat_{l-1} block of gbuf (a HALF block, stored unscaled: record scale 1); GBUF only
   int lane, half;
   bool l4;            // l == 4: rows >= 217 of h_4 are the PE splice, they do not flow into lin3
 
@@ -107,7 +108,7 @@ struct RevEpi {
       const int k = 2 * tp + (r >> 3);
       split8(v8, out->h[k], out->m[k]);
       pin(out->h[k], out->m[k]);
-      if (gblk && !DEFER) store_piece(gblk, k, lane, out->h[k]);
+      if (GBUF && !DEFER) store_piece(gblk, k, lane, out->h[k]);
     }
   }
   template <bool STORE = false>
@@ -115,11 +116,11 @@ struct RevEpi {
     const int k = 2 * tp + 1;
     split8(v8, out->h[k], out->m[k]);
     pin(out->h[k], out->m[k]);
-    if (gblk && STORE) store_piece(gblk, k, lane, out->h[k]);
+    if (GBUF && STORE) store_piece(gblk, k, lane, out->h[k]);
   }
   // the gbuf stores issued during tile t (see TrunkEpi::late_store): the hi pieces of k-steps 2(t-1) and 2(t-2)+1
   __device__ __forceinline__ void st(int t, int s) {
-    if (!gblk || (SVS_ABL & 256)) return;         // (256: diagnostic, no gbuf stores)
+    if (!GBUF || (SVS_ABL & 256)) return;         // (256: diagnostic, no gbuf stores)
     if (s == 9) store_piece(gblk, 2 * (t - 1), lane, out->h[2 * (t - 1)]);
     if (t >= 2 && s == 11) store_piece(gblk, 2 * (t - 2) + 1, lane, out->h[2 * (t - 2) + 1]);
   }
@@ -130,12 +131,13 @@ struct RevEpi {
 };
 
 // reverse of trunk layer l (7..1): in = g(a_l) pieces, out = g(a_{l-1}) pieces
+template <bool GBUF>
 __device__ __forceinline__ void reverse_layer_h2(Stream& st, const Pieces2& in, Pieces2& out, int l, const float* hb,
                                                  float* gb, f32x16& skip6, f32x16& skip7, int lane, int half) {
-  RevEpi ep;
+  RevEpi<GBUF> ep;
   ep.out = &out; ep.lane = lane; ep.half = half; ep.l4 = l == 4;
   const size_t LS = block_stride();
-  ep.gblk = gb ? gb + (size_t)(l - 1) * LS : nullptr;
+  ep.gblk = GBUF ? gb + (size_t)(l - 1) * LS : nullptr;
   const float* hblk = hb + (size_t)(l - 1) * LS;
   // h tile t + 1 (a pair: 4 fragments) is requested during tile t behind k-steps 10, 12, 14, 15 -- after the last LDS-DMA
   // piece (k-step 8), like the gbuf stores: in flight across the tile's barrier, complete one tile later, consumed by the
@@ -145,6 +147,10 @@ __device__ __forceinline__ void reverse_layer_h2(Stream& st, const Pieces2& in, 
   load_tile_pair(hblk, 0, lane, hnext);
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
+    // the h tile this tile's epilogue slices consume (ep.h, requested two tiles ago) is waited for HERE, before the tile's
+    // LDS-DMA pieces are issued: hipcc does not count those (svs_mlp_dev.h), so a wait placed among them would also
+    // wait for the pieces just issued
+    if (t >= 1) pin(ep.h.h[0], ep.h.h[1]), pin(ep.h.m[0], ep.h.m[1]);
     const TilePieces hcur = hnext;
     auto hload = [&](int s) {
       if (t == 7 || (SVS_ABL & 128)) return;      // (128: diagnostic, no h loads)
@@ -164,7 +170,7 @@ __device__ __forceinline__ void reverse_layer_h2(Stream& st, const Pieces2& in, 
     ep.prev = acc;
     ep.h = hcur;
     // in flight across the barrier: the 4 h loads (t < 7) and the gbuf stores (training: 1 in tile 1, then 2) of this tile
-    const int stores = !gb || t == 0 ? 0 : (t == 1 ? 1 : 2);
+    const int stores = !GBUF || t == 0 ? 0 : (t == 1 ? 1 : 2);
     if (t < 7) {
       if (stores == 0) st.advance_keep<4>(); else if (stores == 1) st.advance_keep<5>(); else st.advance_keep<6>();
     } else {
@@ -175,6 +181,7 @@ __device__ __forceinline__ void reverse_layer_h2(Stream& st, const Pieces2& in, 
   ep.all(7);
 }
 
+template <bool GBUF>
 __global__ __launch_bounds__(kThreads, 1) void sdf_full_h2_kernel(SdfFullArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Stream st;
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_h2_kernel(SdfFullArgs a)
   SVS_STAMP(1, pe.v[38])
 
   float* hb = a.hbuf + (size_t)wtile * kBlockF;                        // block l of this tile: + l * block_stride()
-  float* gb = a.gbuf ? a.gbuf + (size_t)wtile * kBlockF : nullptr;
+  float* gb = GBUF ? a.gbuf + (size_t)wtile * kBlockF : nullptr;
   Pieces2 x, xn;
   float sdf;
   {
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_h2_kernel(SdfFullArgs a)
       // ghat_7 = W8[0,:] * softplus'(a_7): a half block (unscaled).  (x already holds the pieces of h_8: the trunk's
       // last layer split and stored them.)
       split_tile(g, t, xn);
-      if (gb) {
+      if (GBUF) {
         store_piece(gb + 7 * block_stride(), 2 * t, lane, xn.h[2 * t]);
         store_piece(gb + 7 * block_stride(), 2 * t + 1, lane, xn.h[2 * t + 1]);
       }
@@ -266,8 +273,8 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_h2_kernel(SdfFullArgs a)
   f32x16 skip7 = (f32x16)(0.0f);   // g(PE[0..31]) from the skip connection (tile 7 of g(h_4 spliced))
   f32x16 skip6 = (f32x16)(0.0f);   // tile 6; only local rows 25..31 are PE[32..38]
   for (int l = 7; l >= 1; l -= 2) {
-    reverse_layer_h2(st, xn, x, l, hb, gb, skip6, skip7, lane, half);
-    if (l > 1) reverse_layer_h2(st, x, xn, l - 1, hb, gb, skip6, skip7, lane, half);
+    reverse_layer_h2<GBUF>(st, xn, x, l, hb, gb, skip6, skip7, lane, half);
+    if (l > 1) reverse_layer_h2<GBUF>(st, x, xn, l - 1, hb, gb, skip6, skip7, lane, half);
   }
   SVS_STAMP(5, skip7[0])
   // ---- reverse layer 0: g(PE) = W0^T g(a_0) (+ skip), 2 tiles; g(a_0) is in x
@@ -454,9 +461,13 @@ int launch_sdf_only_h2(const SdfOnlyArgs& a, hipStream_t s) {
   return check_launch("svs_sdf_vals");
 }
 int launch_sdf_full_h2(const SdfFullArgs& a, hipStream_t s) {
-  static int once = set_lds(sdf_full_h2_kernel, kLdsBytes + kLdsAbl, "svs_sdf_outputs");
+  static int once = set_lds(sdf_full_h2_kernel<true>, kLdsBytes + kLdsAbl, "svs_sdf_outputs");
   if (once) return once;
-  sdf_full_h2_kernel<<<(a.src.P + kWgPts - 1) / kWgPts, kThreads, kLdsBytes + kLdsAbl, s>>>(a);
+  static int once2 = set_lds(sdf_full_h2_kernel<false>, kLdsBytes + kLdsAbl, "svs_sdf_outputs");
+  if (once2) return once2;
+  const int grid = (a.src.P + kWgPts - 1) / kWgPts;
+  if (a.gbuf) sdf_full_h2_kernel<true><<<grid, kThreads, kLdsBytes + kLdsAbl, s>>>(a);     // training: ghat blocks stored
+  else sdf_full_h2_kernel<false><<<grid, kThreads, kLdsBytes + kLdsAbl, s>>>(a);
   return check_launch("svs_sdf_outputs");
 }
 int launch_rgb_h2(const RgbArgs& a, hipStream_t s) {
