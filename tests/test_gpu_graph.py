@@ -85,8 +85,10 @@ def test_captured_step_equals_eager(dev, kind, mode):
             # runs); a replay that missed an input update would be off by O(0.1)
             assert float((ra - rb).abs().max()) <= 1e-3 and float((wa - wb).abs().max()) <= 5e-3, step
         ratio = float((ga - gb).abs().max()) / float(ga.abs().max())
-        # (later steps, background model: 2.8e-3 seen at step 5 -- the two runs' parameters differ by then, see below)
-        assert ratio <= (1e-5 if step == 0 else 5e-3), (step, ratio)
+        # later steps: the two runs' parameters differ by then (float atomics + Adam's sign noise on ~zero gradients, see
+        # below): 1e-3 is typical, 5.1e-3 was seen once at step 4 of the background model in ~10 suite runs.  A replay that
+        # missed an input update (other batch, other view, stale annealing weight) is off by O(0.1 ... 1).
+        assert ratio <= (1e-5 if step == 0 else 3e-2), (step, ratio)
     # the sparse term is live in the annealed phase only, and its weight decays: 1, 2/3, 1/3, then off
     sp = [x[0]["sparse_loss"] for x in b]
     assert sp[0] > 0 and sp[2] > 0 and sp[3] == 0.0 and sp[5] == 0.0, sp
