@@ -199,17 +199,20 @@ def main():
         dt = float(t.item())
     del out
 
+    S = model.ray_sampler.N_samples + model.ray_sampler.N_samples_extra + 2 - (1 if args.model == "bmvs" else 0)
+    roofline = None
+    if not args.no_kernel_timing:
+        # every rank runs the extra steps (a train step contains the all-reduce); rank 0 reports its own kernel times
+        sizes = [g[1] - g[0] for g in ts.split_rays(R, S)] if (train and args.groups == "auto") else None
+        roofline = kernel_roofline(ts, step, R, S, h2, train, ray_groups=sizes)
+        if dist:
+            dist.barrier()
     if rank == 0:
-        S = model.ray_sampler.N_samples + model.ray_sampler.N_samples_extra + 2 - (1 if args.model == "bmvs" else 0)
         flop_per_ray = 128 * F_SDF + S * (2 * F_SDF + F_RGB) + 2 * (2 * F_SDF)
         if train:
             # backward: second-order sweep + backprop of the SDF MLP (2 x 8 layers), its two weight-gradient
             # contractions per layer, radiance backprop + weight gradients (approximate, SURVEY.md 8d: 0.92 GFLOP/ray)
             flop_per_ray += (S + 2) * (2 * F_SDF + 2 * F_SDF) + S * (2 * F_RGB)
-        roofline = None
-        if not args.no_kernel_timing and world == 1:
-            sizes = [g[1] - g[0] for g in ts.split_rays(R, S)] if (train and args.groups == "auto") else None
-            roofline = kernel_roofline(ts, step, R, S, h2, train, ray_groups=sizes)
         line = {
             "metric": "rendered rays/sec (1024-ray batch, 128 samples)",
             "value": world * R * args.steps / dt,
@@ -243,7 +246,7 @@ def main():
         }
         if train and h2 and world == 1 and args.model == "dtu" and not args.no_kernel_timing and not args.no_exact_f32:
             line["exact_f32_ms_per_step"] = exact_f32_step_ms(make_model, make_step)
-        if not args.no_cpu_baseline and args.model == "dtu":
+        if not args.no_cpu_baseline and args.model == "dtu" and world == 1:      # rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(params, K, pose, train=train)
         print(json.dumps(line), flush=True)
     if dist:

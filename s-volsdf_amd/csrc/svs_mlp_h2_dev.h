@@ -149,28 +149,6 @@ __device__ __forceinline__ f32x16 tile_mma_h2_pf(S& st, const Pieces2& x, int la
   return acc;
 }
 
-// The float32 activation stores of a sliced epilogue, deferred behind the LDS-DMA pieces of the tile (k-steps 0..8): the
-// tile's four float4 go out behind k-steps 9, 11, 13 and 15.  Vector-memory operations retire from vmcnt in issue order,
-// so whatever is issued BEFORE the last piece has to be complete when the tile's barrier waits for the pieces -- a store
-// then waits for its acknowledgement, a load for HBM (hundreds of cycles per tile) -- while what is issued after it can be
-// left in flight by Stream::advance_keep<N> and has a whole tile to finish.
-struct LateStore {
-  float q[16];
-  __device__ __forceinline__ void put(int r, float v) { q[r] = v; }
-  __device__ __forceinline__ void quarter(float* blk, int tp, int lane, int qd) {
-    SVS_STREAM_STORE(((f32x4){q[4 * qd], q[4 * qd + 1], q[4 * qd + 2], q[4 * qd + 3]}),
-                     reinterpret_cast<f32x4*>(blk) + (4 * tp + qd) * 64 + lane);
-  }
-  __device__ __forceinline__ void step(int s, float* blk, int tp, int lane) {   // after element s was put()
-    const int qd = s == 9 ? 0 : s == 11 ? 1 : s == 13 ? 2 : s == 15 ? 3 : -1;
-    if (qd >= 0) quarter(blk, tp, lane, qd);
-  }
-  __device__ __forceinline__ void all(float* blk, int tp, int lane) {
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd) quarter(blk, tp, lane, qd);
-  }
-};
-
 // softplus100 in slices (see tile_mma_h2 and TrunkEpi): exp2 | max, log2 | the final fma
 struct SoftplusA { float mx, lg; };
 __device__ __forceinline__ float softplus100_b(const SoftplusA& r) {

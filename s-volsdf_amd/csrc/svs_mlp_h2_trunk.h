@@ -54,7 +54,6 @@ struct TrunkEpi {
   f32x16 prev;
   SoftplusA sa;
   float v8[8];
-  f32x4 q4;
   Pieces2* xn;
   f32x16* y8;
   const typename Net::Pe* pe;
@@ -127,7 +126,7 @@ struct TrunkEpi {
   }
   // k-step s of tile t (whose MFMAs cover the epilogue of tile t-1): the pair stores of the pieces that are complete by
   // now -- k-step 2(t-1) (split in this tile's k-step 7) and k-step 2(t-2)+1 (split by finish(t-2) in front of this
-  // tile) -- behind the last LDS-DMA piece (k-step 8), so that Stream::advance_keep leaves them in flight (LateStore)
+  // tile) -- behind the last LDS-DMA piece (k-step 8), so that Stream::advance_keep leaves them in flight
   __device__ __forceinline__ void late_store(int t, int s) {
     if (!HBUF) return;
     const int k1 = 2 * (t - 1), k2 = 2 * (t - 2) + 1;

@@ -18,14 +18,24 @@ import shutil
 import sys
 
 
-def agg(pattern, counter):
-    d = collections.defaultdict(list)
-    files = glob.glob(pattern)
-    if not files:
+def newest(pattern):
+    """gpurun merges every call's files into gpurun_out/: take the most recent match."""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1] if files else None
+
+
+def agg(pattern, counter, by_grid=False):
+    """kernel -> [values] (by_grid: kernel -> {grid size -> [values]})"""
+    d = collections.defaultdict(lambda: collections.defaultdict(list)) if by_grid else collections.defaultdict(list)
+    f = newest(pattern)
+    if not f:
         return d
-    for row in csv.DictReader(open(files[0])):
+    for row in csv.DictReader(open(f)):
         if row.get("Counter_Name") == counter:
-            d[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+            if by_grid:
+                d[row["Kernel_Name"]][int(row["Grid_Size"])].append(float(row["Counter_Value"]))
+            else:
+                d[row["Kernel_Name"]].append(float(row["Counter_Value"]))
     return d
 
 
@@ -34,9 +44,9 @@ def main(src, tag):
     out = os.path.join(root, "profiles")
     os.makedirs(out, exist_ok=True)
     for mode in ("train", "render", "train_onegroup", "costvol", "evalrender", "featurenet"):
-        f = glob.glob(os.path.join(src, mode, "*", "*kernel_stats.csv"))
+        f = newest(os.path.join(src, mode, "*", "*kernel_stats.csv"))
         if f:
-            shutil.copy(f[0], os.path.join(out, f"{tag}_{mode}_kernel_stats.csv"))
+            shutil.copy(f, os.path.join(out, f"{tag}_{mode}_kernel_stats.csv"))
     # the JSON lines the secondary benches printed under the profiler
     for name in ("costvol", "evalrender", "featurenet"):
         log = os.path.join(src, name + ".log")
@@ -44,17 +54,24 @@ def main(src, tag):
             lines = [ln.strip() for ln in open(log) if ln.startswith("{") or ln.startswith("FeatureNet")]
             if lines:
                 open(os.path.join(out, f"{tag}_{name}_result.txt"), "w").write("\n".join(lines) + "\n")
-    fetch = agg(os.path.join(src, "pmc_fetch", "*", "*counter_collection.csv"), "FETCH_SIZE")
-    write = agg(os.path.join(src, "pmc_write", "*", "*counter_collection.csv"), "WRITE_SIZE")
-    res = {"_note": "bytes per launch; fetch = 2 * FETCH_SIZE KiB (gfx950 wide-stream correction), write = WRITE_SIZE KiB",
+    fetch = agg(os.path.join(src, "pmc_fetch", "*", "*counter_collection.csv"), "FETCH_SIZE", by_grid=True)
+    write = agg(os.path.join(src, "pmc_write", "*", "*counter_collection.csv"), "WRITE_SIZE", by_grid=True)
+    res = {"_note": "bytes per launch; fetch = 2 * FETCH_SIZE KiB (gfx950 wide-stream correction), write = WRITE_SIZE KiB.  "
+                    "The default step runs two ray groups, so most kernels are launched in two sizes: hbm_bytes is the "
+                    "figure of the LARGEST launch shape (grid size), by_grid_size lists every shape",
            "kernels": {}}
+    mean = lambda v: sum(v) / max(1, len(v))
     for k in fetch:
         if not k.startswith(("svs::", "void svs::")):
             continue
-        fb = 2.0 * 1024.0 * sum(fetch[k]) / len(fetch[k])
-        wb = 1024.0 * sum(write.get(k, [0.0])) / max(1, len(write.get(k, [])))
-        res["kernels"][k.split("(")[0].replace("void ", "")] = {"launches": len(fetch[k]), "fetch_bytes": fb,
-                                                              "write_bytes": wb, "hbm_bytes": fb + wb}
+        shapes = {}
+        for grid, vals in fetch[k].items():
+            fb = 2.0 * 1024.0 * mean(vals)
+            wb = 1024.0 * mean(write.get(k, {}).get(grid, [0.0]))
+            shapes[grid] = {"launches": len(vals), "fetch_bytes": fb, "write_bytes": wb, "hbm_bytes": fb + wb}
+        top = shapes[max(shapes)]
+        res["kernels"][k.split("(")[0].replace("void ", "")] = dict(top, grid_size=max(shapes),
+                                                                  by_grid_size={str(g): shapes[g] for g in sorted(shapes)})
     json.dump(res, open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps({k: round(v["hbm_bytes"] / 1e6, 1) for k, v in res["kernels"].items()}, indent=1))
     mfma_summary(src, out, tag)
