@@ -46,9 +46,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
                                                    float* __restrict__ v, long long n, const double* __restrict__ part,
                                                    const int* __restrict__ bad, int n_part, AdamScalars sc, int step,
                                                    const int* __restrict__ step_dev, float* __restrict__ info) {
+  // every wave reduces the partials itself, in one fixed order (lane l takes l, l + 64, ...; then a butterfly): the same
+  // bits in every wave of every block, without the 256-term serial sum each thread used to walk through
   double tot = 0.0;
   int nb = 0;
-  for (int i = 0; i < n_part; ++i) { tot += part[i]; nb |= bad[i]; }
+  for (int i = threadIdx.x & 63; i < n_part; i += 64) { tot += part[i]; nb |= bad[i]; }
+  for (int d = 32; d >= 1; d >>= 1) { tot += __shfl_xor(tot, d); nb |= __shfl_xor(nb, d); }
   if (step_dev) step = *step_dev;                      // graph replays: the counter lives on the device (grad_stats bumped it)
   const double bc1 = 1.0 - pow(sc.beta1_d, (double)step);
   const double bc2 = 1.0 - pow(sc.beta2_d, (double)step);

@@ -205,8 +205,15 @@ class MlpBackward:
                                    _ptr(gbuf), _ptr(self.a2buf), _ptr(S.sdf), prec, _ptr(self.abuf), _ptr(self.sbar),
                                    _ptr(acc.absmax) if h2 else None, _ptr(self.a2max) if h2 else None, st),
                    "svs_sdf_bwd_b")
-        _lib.check(L.svs_lin8_row0_grad(_ptr(hbuf), _ptr(self.ubuf), _ptr(self.sbar), n_total, prec, _ptr(acc.row0), st),
-                   "svs_lin8_row0_grad")
+        # the first row of lin8's weight gradient (a 257-vector reduction over two blocks) only needs pass B's sbar: it
+        # goes to the side stream, beside the weight-gradient launch, instead of in front of it
+        with torch.cuda.stream(side_stream):
+            if side:
+                after_b = torch.cuda.Event(); after_b.record(main)
+                side_stream.wait_event(after_b)
+            _lib.check(L.svs_lin8_row0_grad(_ptr(hbuf), _ptr(self.ubuf), _ptr(self.sbar), n_total, prec, _ptr(acc.row0),
+                                            _stream()), "svs_lin8_row0_grad")
+            join = torch.cuda.Event(); join.record(side_stream)
         ev = self.timer_events = ([torch.cuda.Event(enable_timing=True) for _ in range(2)] if self.time_wgrad else None)
         if ev:
             ev[0].record()
