@@ -320,8 +320,11 @@ def composite_bg_bwd(z, z_max, sdf, rgb, depth_scale, beta_param, beta_min, z_bg
     return d_sdf, d_rgb, d_bo, d_brgb, d_beta
 
 
-def composite_bwd(z, sdf, rgb, depth_scale, beta_param, beta_min, d_rgb_values, d_weights=None, d_depth_values=None):
-    """Reverse pass of `composite`: -> d_sdf (R*S,1), d_rgb (R*S,3), d_beta_param (1,)."""
+def composite_bwd(z, sdf, rgb, depth_scale, beta_param, beta_min, d_rgb_values, d_weights=None, d_depth_values=None,
+                  d_sdf_out=None, d_beta_out=None):
+    """Reverse pass of `composite`: -> d_sdf (R*S,1), d_rgb (R*S,3), d_beta_param (1,).  d_sdf_out / d_beta_out: optional
+    preallocated contiguous float32 tensors of those shapes to write into (the fused train step hands in views of its
+    persistent buffers, which saves a fill and two copies per ray group)."""
     L = _lib.load()
     z = _f32(z)
     R, S = z.shape
@@ -331,10 +334,13 @@ def composite_bwd(z, sdf, rgb, depth_scale, beta_param, beta_min, d_rgb_values, 
     g_rgb = _f32(d_rgb_values)
     g_w = _f32(d_weights) if d_weights is not None else None
     g_d = _f32(d_depth_values).reshape(-1) if d_depth_values is not None else None
-    d_sdf = torch.empty(R * S, 1, device=dev)
+    for t, shape in ((d_sdf_out, (R * S, 1)), (d_beta_out, (1,))):
+        if t is not None and (tuple(t.shape) != shape or t.dtype != torch.float32 or not t.is_contiguous()):
+            raise ValueError("composite_bwd: output tensor must be contiguous float32 of shape %s" % (shape,))
+    d_sdf = d_sdf_out if d_sdf_out is not None else torch.empty(R * S, 1, device=dev)
     d_rgb = torch.empty(R * S, 3, device=dev)
     ws = torch.empty(R, device=dev)
-    d_beta = torch.empty(1, device=dev)
+    d_beta = d_beta_out if d_beta_out is not None else torch.empty(1, device=dev)
     _lib.check(L.svs_composite_bwd(R, S, _ptr(z), _ptr(sdf), _ptr(rgb), _ptr(depth_scale), _ptr(beta_param),
                                    float(beta_min), _ptr(g_rgb), _ptr(g_w), _ptr(g_d), _ptr(d_sdf), _ptr(d_rgb),
                                    _ptr(ws), _ptr(d_beta), _stream()), "svs_composite_bwd")

@@ -132,7 +132,15 @@ class MlpBackward:
         self.pebuf = z(L.svs_block_bytes(n_total, 1))
         self.sbar = z(L.svs_block_bytes(n_total, 1) // (128 * 2))  # 32 floats per tile
         self.a2max = z(L.svs_block_bytes(n_total, 1) // (128 * 2))
+        # d loss / d sdf of all points of the launch: the ray samples' part is rewritten every step (sdf_grad_out()), the
+        # tail -- the eikonal points, which have no such term -- stays zero
+        self.d_sdf_full = torch.zeros(n_total, device=self.dev)
         self._n = (n_total, n_main)
+
+    def sdf_grad_out(self, n_total, n_main):
+        """(n_main,1) view of the persistent d_sdf buffer: compositing's backward writes into it directly."""
+        self._alloc(n_total, n_main)
+        return self.d_sdf_full[:n_main].view(n_main, 1)
 
     def accumulate(self, keep, d_rgb, d_sdf, d_grad_extra, wait=True, side=True):
         """Launches the backward of one ray group on the current stream (+ a side stream for the radiance weight
@@ -177,9 +185,12 @@ class MlpBackward:
         d_grad = d_normals if d_grad_extra is None else torch.cat([d_normals, _f32(d_grad_extra)], 0)
         if d_grad.shape[0] != n_total:
             raise ValueError("d_grad_extra must cover the points that follow the ray samples")
-        d_sdf_full = torch.zeros(n_total, device=dev)
-        if d_sdf is not None:
-            d_sdf_full[:n_main] = _f32(d_sdf).reshape(-1)
+        if d_sdf is not None and d_sdf.data_ptr() == self.d_sdf_full.data_ptr() and d_sdf.numel() == n_main:
+            d_sdf_full = self.d_sdf_full              # written in place by the caller (sdf_grad_out())
+        else:
+            d_sdf_full = torch.zeros(n_total, device=dev)
+            if d_sdf is not None:
+                d_sdf_full[:n_main] = _f32(d_sdf).reshape(-1)
         # ---- the radiance weight-gradient GEMMs only need rgb_bwd's outputs: they run on a side stream and fill the
         # CUs the SDF sweeps leave idle in their tail round
         main = torch.cuda.current_stream()

@@ -349,11 +349,11 @@ class TrainStep:
             if self.is_bg:
                 bg_sdf_wb, bg_rgb_wb = m.bg_params()
                 sc.bg_bwd.pack(bg_sdf_wb, bg_rgb_wb)
+            # the accumulators are zeroed here too: nothing adds into them before a stream has waited for `packed`
+            if self.is_bg:
+                sc.bg_bwd.zero()
+            sc.accum.zero()
             packed = torch.cuda.Event(); packed.record(prep)
-        if self.is_bg:
-            sc.bg_bwd.zero()
-        sc.accum.zero()
-        sc.d_beta.zero_()
         main.wait_event(rgb_packed)
         fork = torch.cuda.Event(); fork.record(main)
         results, joins, holds = [], [], []
@@ -385,10 +385,13 @@ class TrainStep:
                     sc.bg_bwd.accumulate(keep, d_brgb, d_bo, slot=gi)
                 else:
                     gw = m.white_bkgd_weight_grad(g["rgb_values"], g["weights"], keep["z_vals"].shape[1])
-                    d_sdf, d_rgb, d_beta = ops.composite_bwd(keep["z_vals"], keep["sdf"], keep["rgb_flat"], keep["depth_scale"],
-                                                             m.density.beta, m.density.beta_min_value, g["rgb_values"],
-                                                             gw, g["depth_values"])
-                sc.d_beta[gi:gi + 1].copy_(d_beta)
+                    d_sdf, d_rgb, d_beta = ops.composite_bwd(
+                        keep["z_vals"], keep["sdf"], keep["rgb_flat"], keep["depth_scale"], m.density.beta,
+                        m.density.beta_min_value, g["rgb_values"], gw, g["depth_values"],
+                        d_sdf_out=sc.bwd[gi].sdf_grad_out(keep["src"].n, keep["rgb_flat"].shape[0]),
+                        d_beta_out=sc.d_beta[gi:gi + 1])
+                if d_beta.data_ptr() != sc.d_beta[gi:gi + 1].data_ptr():
+                    sc.d_beta[gi:gi + 1].copy_(d_beta)
                 joins.append(sc.bwd[gi].accumulate(keep, d_rgb, d_sdf, g["grad_theta"], wait=False, side=not serial))
                 results.append((lo_out, out))
                 holds.append((keep, g, d_sdf, d_rgb, inp, g_gt))
@@ -399,7 +402,7 @@ class TrainStep:
         finalize(sc.accum, sdf_p, rgb_p, out=self.grad_out)
         if self.is_bg:
             sc.bg_bwd.finalize(bg_sdf_wb, bg_rgb_wb, out=self.bg_grad_out)
-        self.beta_grad.copy_(sc.d_beta.sum())
+        torch.sum(sc.d_beta[:len(groups)], dim=0, keepdim=True, out=self.beta_grad.view(1))
         return results, holds
 
     # ---- captured steps -----------------------------------------------------------------------------------------------------
