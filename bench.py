@@ -78,8 +78,9 @@ def main():
                     help="dtu: VolSDFNetwork (configs[1], the headline metric); bmvs: VolSDFNetworkBG, fg + inverted-sphere "
                          "background (config 4), train mode only")
     ap.add_argument("--groups", choices=["auto", "none"], default="auto",
-                    help="auto: the batch runs as two ray groups on concurrent streams, the first sized to whole rounds of "
-                         "256 workgroups, so that the last partial round of every launch overlaps (results do not depend on it)")
+                    help="auto: the batch may run as two ray groups on concurrent streams, the first sized to whole rounds of "
+                         "256 workgroups, so that the last partial round of every launch overlaps; TrainStep measures both "
+                         "schedules during the first steps and keeps the faster (results do not depend on it)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --rays rays per GPU; strong: --rays rays in total, rays/N per GPU")
     ap.add_argument("--settle", type=float, default=1.0, help="seconds of untimed steady-state steps before the timed region")
@@ -203,7 +204,7 @@ def main():
     roofline = None
     if not args.no_kernel_timing:
         # every rank runs the extra steps (a train step contains the all-reduce); rank 0 reports its own kernel times
-        sizes = [g[1] - g[0] for g in ts.split_rays(R, S)] if (train and args.groups == "auto") else None
+        sizes = [g[1] - g[0] for g in ts._groups_for(R)] if train else None
         roofline = kernel_roofline(ts, step, R, S, h2, train, ray_groups=sizes)
         if dist:
             dist.barrier()
@@ -235,8 +236,8 @@ def main():
                        "mode": args.mode,
                        "mlp_precision": ("fp16x2: two-piece fp16 operands on v_mfma_f32_32x32x16_f16, float32 accumulation "
                                          "(float32-class accuracy, same parity bounds)" if h2 else "float32 MFMA"),
-                       "ray_groups": ([list(g) for g in ts.split_rays(R, S)] if (train and args.groups == "auto")
-                                      else [[0, R]]),
+                       "ray_groups": ([list(g) for g in ts._groups_for(R)] if train else [[0, R]]),
+                       "ray_group_schedule": (ts.schedule.get(R) if (train and args.groups == "auto") else None),
                        "launch": ("hipGraph replay of the captured step + eager all-reduce / fused Adam"
                                   if (train and ts.graph) else "eager launches"),
                        "rays_per_gpu": R, "rays_total": R * world, "settle_steps": settle_steps,

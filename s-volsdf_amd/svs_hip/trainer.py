@@ -202,9 +202,17 @@ class TrainStep:
     (tools/ab_groups.py, interleaved A/B in one process): 5.05 ms/step ungrouped, 4.81 ms "auto", 4.78 ms two halves,
     4.94 ms three streams, 5.19 ms four (more launches than the host thread can enqueue ahead).
 
-    Captured steps (graph=True, the default; SVS_TRAIN_GRAPH=0 turns it off).  The ~100 launches of a step cost the host
-    thread ~3 ms to enqueue -- more than the GPU needs for a 256-ray shard.  The launch sequence contains no host
-    decision, so after one eager step per configuration (ray count, ray groups, model, MVS prior on / off) it is captured
+    Whether the split pays depends on how the runtime maps the step's streams onto hardware queues (measured with
+    GPU_MAX_HW_QUEUES = 2 ... 8: 3.0 ms/step at the default 4, 3.7 - 4.3 ms at any other value, against 3.1 ms unsplit at
+    every value: with a queue of its own the small group's launches run truly concurrently and cost the large group a
+    fourth round).  groups="auto" therefore MEASURES, once the process has warmed up (the first steps of a process are
+    slow and noisy: allocator growth, clocks): steps TUNE_START .. run split, the following ones unsplit (TUNE_STEPS each,
+    the first TUNE_SKIP of a phase untimed, whole steps timed with events on the step's stream), and the faster schedule
+    is kept (`schedule`); until then the step runs split.
+
+    Captured steps (graph=True or SVS_TRAIN_GRAPH=1; off by default: eager launches are faster on this ROCm stack,
+    DESIGN.md section 5).  The launch sequence contains no host
+    decision, so after one eager step per configuration (ray count, ray groups, model, MVS prior on / off) it can be captured
     once into a hipGraph and replayed: per step the host uploads the inputs (pixels, targets, camera, random draws and
     three scalars: rendered-view index, annealing state) into the graph's static tensors and launches the graph; the
     all-reduce and the fused optimiser launch stay outside it.  What a replay returns are views into the graph's memory:
@@ -233,6 +241,9 @@ class TrainStep:
         if self.is_bg:
             self.bg_grad_out = [[(next(it), next(it)) for _ in range(n)] for n in (9, 2)]
         self.groups = groups
+        self.schedule = {}                              # groups == "auto": ray count -> dict(choice, ms_split, ms_whole)
+        self._tune = {}
+        self._force_groups = None
         self.scratch = _Scratch(dev, self.is_bg)
         if graph is None:
             graph = os.environ.get("SVS_TRAIN_GRAPH", "0")
@@ -284,8 +295,55 @@ class TrainStep:
         """mvs: optional dict(views=[...], same_view=int, img_res=(H,W), inverse_depth=bool) for cost_mapping."""
         return self._step(model_input, ground_truth, mvs, fast)
 
+    TUNE_START, TUNE_STEPS, TUNE_SKIP = 24, 12, 2
+
     def _groups_for(self, R):
-        return self.split_rays(R, self.samples_per_ray()) if self.groups == "auto" else (self.groups or [(0, R)])
+        if self._force_groups is not None:
+            return self._force_groups
+        if self.groups != "auto":
+            return self.groups or [(0, R)]
+        sched = self.schedule.get(R)
+        if sched is not None and sched["choice"] == "whole":
+            return [(0, R)]
+        return self.split_rays(R, self.samples_per_ray())
+
+    def _tune_begin(self, R):
+        """groups == "auto", eager steps: which schedule does this step run, and is it timed?  -> (state, mode, timed)"""
+        if self.groups != "auto" or R in self.schedule:
+            return None
+        split = self.split_rays(R, self.samples_per_ray())
+        if len(split) == 1:
+            self.schedule[R] = dict(choice="whole", ms_split=None, ms_whole=None)
+            return None
+        st = self._tune.setdefault(R, dict(i=0, ev=[]))
+        i = st["i"] - self.TUNE_START
+        if i < 0:
+            return st, None, None                             # not yet: split, untimed
+        n = self.TUNE_STEPS
+        mode = "split" if i < n else "whole"
+        timed = (i % n) >= self.TUNE_SKIP
+        self._force_groups = split if mode == "split" else [(0, R)]
+        ev0 = None
+        if timed:
+            ev0 = torch.cuda.Event(enable_timing=True); ev0.record()
+        return st, mode, ev0
+
+    def _tune_end(self, R, tune):
+        st, mode, ev0 = tune
+        self._force_groups = None
+        if ev0 is not None:
+            ev1 = torch.cuda.Event(enable_timing=True); ev1.record()
+            st["ev"].append((mode, ev0, ev1))
+        st["i"] += 1
+        if st["i"] == self.TUNE_START + 2 * self.TUNE_STEPS:
+            torch.cuda.synchronize()
+            ms = {"split": [], "whole": []}
+            for mode, a, b in st["ev"]:
+                ms[mode].append(a.elapsed_time(b))
+            med = {k: sorted(v)[len(v) // 2] for k, v in ms.items()}
+            self.schedule[R] = dict(choice="split" if med["split"] <= med["whole"] else "whole", ms_split=med["split"],
+                                    ms_whole=med["whole"])
+            del self._tune[R]
 
     def _step(self, model_input, ground_truth, mvs=None, fast=1):
         m = self.model
@@ -297,11 +355,15 @@ class TrainStep:
             out = self._step_captured(model_input, ground_truth, mvs, fast)
             if out is not None:
                 return self._finish(out)
+        tune = None if self.graph else self._tune_begin(R)
         rng = m.draw_train_rng(R, uv.device)
         gt = {"rgb": ground_truth["rgb"].reshape(-1, 3), "rgb_smooth": ground_truth["rgb_smooth"].reshape(-1, 3)}
         results, holds = self._device_step(self.scratch, model_input, gt, mvs, fast, rng, dyn=None)
         self._hold = holds
-        return self._finish(results)
+        out = self._finish(results)
+        if tune is not None:
+            self._tune_end(R, tune)
+        return out
 
     def _finish(self, results):
         """What follows the gradient: the one collective of a data-parallel step, the fused optimiser, host counters."""
