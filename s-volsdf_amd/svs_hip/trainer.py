@@ -356,7 +356,7 @@ class TrainStep:
             if out is not None:
                 return self._finish(out)
         tune = None if self.graph else self._tune_begin(R)
-        rng = m.draw_train_rng(R, uv.device)
+        rng = m.draw_train_rng(R, uv.device, stream=self.scratch.prep)      # uploads on the (idle) pack stream
         gt = {"rgb": ground_truth["rgb"].reshape(-1, 3), "rgb_smooth": ground_truth["rgb_smooth"].reshape(-1, 3)}
         results, holds = self._device_step(self.scratch, model_input, gt, mvs, fast, rng, dyn=None)
         self._hold = holds

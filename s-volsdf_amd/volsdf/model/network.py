@@ -199,7 +199,7 @@ class VolSDFNetwork(nn.Module):
                     'xyz': xyz, 'grad_theta': grad_theta}
         return self._forward_impl(input, fast, None)
 
-    def draw_train_rng(self, R, dev, out=None):
+    def draw_train_rng(self, R, dev, out=None, stream=None):
         """All train-mode random draws of one forward for R rays, in the reference's order (sampler draws, then the
         uniform eikonal points of network.py:261).  Slices of it can be handed to _forward_impl per ray group."""
         rb = self.scene_bounding_sphere
@@ -213,7 +213,7 @@ class VolSDFNetwork(nn.Module):
             slot["eik_points"].uniform_(-rb, rb)
             return ["eik_points"]
 
-        return self.ray_sampler.draw_train_rng(R, dev, extra=eik, out=out)
+        return self.ray_sampler.draw_train_rng(R, dev, extra=eik, out=out, stream=stream)
 
     @staticmethod
     def slice_rng(rng, lo, hi):

@@ -92,7 +92,7 @@ class VolSDFNetworkBG(nn.Module):
         self._bg_key = None
 
     # ---- forward --------------------------------------------------------------------------------------------
-    def draw_train_rng(self, R, dev, out=None):
+    def draw_train_rng(self, R, dev, out=None, stream=None):
         rb = self.scene_bounding_sphere
 
         def eik(slot, n):
@@ -104,7 +104,7 @@ class VolSDFNetworkBG(nn.Module):
             slot["eik_points"].uniform_(-rb, rb)
             return ["eik_points"]
 
-        return self.ray_sampler.draw_train_rng(R, dev, extra=eik, out=out)
+        return self.ray_sampler.draw_train_rng(R, dev, extra=eik, out=out, stream=stream)
 
     @staticmethod
     def slice_rng(rng, lo, hi):
