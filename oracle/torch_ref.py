@@ -136,8 +136,9 @@ def bg_rgb_mlp(p, d, feat):
     return torch.sigmoid(h @ p["bg_rendering_network.lin1.weight"].T + p["bg_rendering_network.lin1.bias"])
 
 
-def composite_bg(z, z_max, sdf, rgb, beta_param, ds, z_bg, bg_out0, bg_rgb, beta_min=1e-4):
-    """network_bg.py:76-125,147-180 -> weights, bg_transmittance, rgb_values, depth_values"""
+def composite_bg(z, z_max, sdf, rgb, beta_param, ds, z_bg, bg_out0, bg_rgb, beta_min=1e-4, bg_depth=None):
+    """network_bg.py:76-125,147-180 -> weights, bg_transmittance, rgb_values, depth_values[, depth_values_all when the
+    background samples' conventional depths bg_depth (R,Nb) are given: network_bg.py:105-107]"""
     beta = beta_param.abs() + beta_min
     sigma = (1 / beta) * (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() / beta))
     dists = torch.cat([z[:, 1:] - z[:, :-1], z_max.unsqueeze(-1) - z[:, -1:]], -1)
@@ -153,23 +154,34 @@ def composite_bg(z, z_max, sdf, rgb, beta_param, ds, z_bg, bg_out0, bg_rgb, beta
     rgb_values = (w.unsqueeze(-1) * rgb).sum(1) + t_bg.unsqueeze(-1) * (bw.unsqueeze(-1) * bg_rgb).sum(1)
     dv = z * ds
     depth_values = (w * dv).sum(1, keepdim=True) / (w.sum(1, keepdim=True) + 1e-8)
-    return w, t_bg, rgb_values, depth_values
+    if bg_depth is None:
+        return w, t_bg, rgb_values, depth_values
+    w_all = torch.cat([w, t_bg.unsqueeze(-1) * bw], 1)
+    d_all = ds * torch.cat([z, bg_depth], 1)
+    depth_values_all = (w_all * d_all).sum(1, keepdim=True) / (w_all.sum(1, keepdim=True) + 1e-8)
+    return w, t_bg, rgb_values, depth_values, depth_values_all
 
 
-def forward_differentiable_bg(p, cam, dirs, z, z_max, eik_points, depth_scale, z_bg, bg_pts):
-    """VolSDFNetworkBG.forward after the sampler and depth2pts_outside, train mode (network_bg.py:60-134)."""
+def forward_differentiable_bg(p, cam, dirs, z, z_max, eik_points, depth_scale, z_bg, bg_pts, bg_depth=None, device=None):
+    """VolSDFNetworkBG.forward after the sampler and depth2pts_outside, train mode (network_bg.py:60-134).  bg_depth: the
+    background samples' conventional depths (adds depth_values_all); device: where the parameters live (None: CPU)."""
     R, S = z.shape
     Nb = z_bg.shape[1]
     dt = p["density.beta"].dtype
-    T = lambda a: torch.tensor(np.asarray(a), dtype=dt)
+    T = lambda a: (a.detach().to(device=device, dtype=dt) if torch.is_tensor(a)
+                   else torch.tensor(np.asarray(a), dtype=dt, device=device))
     cam_t, dirs_t, z_t = T(cam), T(dirs), T(z)
     pts = (cam_t.view(1, 1, 3) + z_t.unsqueeze(2) * dirs_t.unsqueeze(1)).reshape(-1, 3)
     sdf, feat, grad = sdf_outputs(p, pts, 0.0, 1.0)
     rgb = rgb_mlp(p, pts, grad, dirs_t.unsqueeze(1).repeat(1, S, 1).reshape(-1, 3), feat).reshape(R, S, 3)
     bg_out = bg_sdf_mlp(p, T(bg_pts).reshape(-1, 4))
     bg_rgb = bg_rgb_mlp(p, dirs_t.unsqueeze(1).repeat(1, Nb, 1).reshape(-1, 3), bg_out[:, 1:]).reshape(R, Nb, 3)
-    w, t_bg, rgb_values, depth_values = composite_bg(z_t, T(z_max), sdf.reshape(R, S), rgb, p["density.beta"], T(depth_scale),
-                                                     T(z_bg), bg_out[:, 0].reshape(R, Nb), bg_rgb)
+    comp = composite_bg(z_t, T(z_max), sdf.reshape(R, S), rgb, p["density.beta"], T(depth_scale), T(z_bg),
+                        bg_out[:, 0].reshape(R, Nb), bg_rgb, bg_depth=None if bg_depth is None else T(bg_depth))
+    w, t_bg, rgb_values, depth_values = comp[:4]
     _, _, gt = sdf_outputs(p, T(eik_points), clamp=False)
-    return dict(rgb_values=rgb_values, depth_values=depth_values, weights=w, grad_theta=gt, sdf=sdf, rgb=rgb,
-                bg_out0=bg_out[:, :1], bg_rgb=bg_rgb, bg_transmittance=t_bg)
+    out = dict(rgb_values=rgb_values, depth_values=depth_values, weights=w, grad_theta=gt, sdf=sdf, rgb=rgb,
+               bg_out0=bg_out[:, :1], bg_rgb=bg_rgb, bg_transmittance=t_bg)
+    if bg_depth is not None:
+        out["depth_values_all"] = comp[4]
+    return out

@@ -292,3 +292,68 @@ def test_bg_ray_groups_do_not_change_the_step(dev):
     assert torch.equal(ra, rb) and torch.equal(wa, wb)
     assert float((ga - gb).abs().max()) <= 1e-4 * float(ga.abs().max())
     assert float(ga.abs().max()) > 0
+
+
+@pytest.mark.parametrize("R,it", [(256, 250), (1024, 250), (1024, 50)])
+def test_bg_step_gradient_at_bench_geometry(dev, R, it):
+    """The flat gradient of ONE fused step of the fg + background model at the benchmarked geometry -- 1024 rays, and
+    256 rays = the per-GPU share of config 4's 2048-ray batch over 8 GPUs -- against float64 torch autograd
+    (oracle/torch_ref.py: forward_differentiable_bg) on the very sample positions, background points, prior look-ups and
+    targets the step used.  it = 250: past the colour annealing, every ray carries a colour term and the background
+    networks receive gradients; it = 50: the annealed phase, where the sparse term (which reads depth_values_all) is live.
+    Per tensor: max |err| <= 2e-3 of the tensor's largest entry, the bound of the reference-fixture steps."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import torch_ref as tref
+    from svs_hip.trainer import TrainStep
+    from volsdf.model.loss import VolSDFLoss
+    m = _model(dev, 0.1)
+    loss = VolSDFLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, rgb_weight=1.0, mvs_weight=1.0, sparse_weight=1.0,
+                      anneal_rgb=200, gce=0.5, confi=1e-3)
+    loss.iter_step = it
+    K, pose = synth.make_camera()
+    inp = {"intrinsics": G(K, dev)[None], "uv": G(synth.make_uv(R, seed=17), dev)[None], "pose": G(pose, dev)[None]}
+    rs = np.random.default_rng(5)
+    gt = {"rgb": G(rs.uniform(0, 1, (1, R, 3)).astype(np.float32), dev),
+          "rgb_smooth": G(rs.uniform(0, 1, (1, R, 3)).astype(np.float32), dev)}
+    views = synth.make_mvs_views(2)
+    mvs = dict(views=[dict(K=v["K"], c2w=v["c2w"], cost=G(v["cost"], dev), z_mvs=G(v["z_mvs"], dev)) for v in views], same_view=0,
+               img_res=(576, 768), inverse_depth=False)
+    ts = TrainStep(m, loss, lr=5e-4, groups="auto", graph=False)
+    p0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    torch.manual_seed(3)
+    ts(inp, gt, mvs=mvs)
+    torch.cuda.synchronize()
+    norm = float(ts.opt.info[0])
+    coef = min(1.0, 1.0 / (norm + 1e-6))
+    got = {n: (p.grad / coef).double().cpu() for n, p in m.named_parameters()}
+    keeps = [h[0] for h in ts._hold]
+    outs = [r[1] for r in ts._results]
+    cat = lambda xs: torch.cat(xs, 0).double()
+    z, dirs, ds = (cat([k[n] for k in keeps]) for n in ("z_vals", "ray_dirs", "depth_scale"))
+    z_max, z_bg, bg_depth = (cat([k[n] for k in keeps]) for n in ("z_max", "z_bg", "bg_depth"))
+    Nb = z_bg.shape[1]
+    bg_pts = cat([k["bg_pts"].reshape(-1, Nb, 4) for k in keeps])
+    eik = cat([k["src"].points for k in keeps])
+    pj, pi = cat([o["pj"] for o in outs]), cat([o["pi"] for o in outs])
+    p = {k: torch.tensor(v.cpu().numpy(), dtype=torch.float64, device=dev, requires_grad=True) for k, v in p0.items()}
+    out = tref.forward_differentiable_bg(p, keeps[0]["cam_loc"].double(), dirs, z, z_max, eik, ds, z_bg, bg_pts,
+                                         bg_depth=bg_depth, device=dev)
+    out["pj"], out["pi"] = pj, pi
+    out["depth_values"] = out["depth_values_all"]            # loss.py:72-73: the sparse term reads depth_values_all
+    total = tref.loss_fn(out, gt["rgb"].reshape(-1, 3).double(), gt["rgb_smooth"].reshape(-1, 3).double(), it)
+    total.backward()
+    ref_norm = float(torch.sqrt(sum((v.grad ** 2).sum() for v in p.values() if v.grad is not None)))
+    assert norm == pytest.approx(ref_norm, rel=1e-3), (norm, ref_norm)
+    worst, worst_name, live_bg = 0.0, "", 0
+    for n in got:
+        ref = p[n].grad.cpu() if p[n].grad is not None else torch.zeros_like(got[n])
+        live_bg += int(n.startswith("bg_") and float(ref.abs().max()) > 0)
+        e = float((got[n] - ref).abs().max() / (ref.abs().max() + 1e-30)) if float(ref.abs().max()) > 0 else float(got[n].abs().max())
+        if e > worst:
+            worst, worst_name = e, n
+    print(f"bmvs, {R} rays, step {it}, {len(keeps)} group(s): worst per-tensor gradient error vs float64 autograd {worst:.2e} ({worst_name}); "
+          f"gradient norm {norm:.6f} vs {ref_norm:.6f}; {live_bg} background tensors with gradients")
+    if it >= 200:
+        assert live_bg >= 18, live_bg
+    assert worst < 2e-3, (worst, worst_name)

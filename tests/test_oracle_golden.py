@@ -272,6 +272,37 @@ def test_forward_bg(golden_dir, tag):
         np.testing.assert_allclose(out["normal_map"][same], g["normal_map"][same], atol=2e-4)
 
 
+def test_torch_ref_forward_bg(golden_dir):
+    """oracle/torch_ref.py's differentiable fg + background forward (the float64 reference of the GPU gradient tests at
+    the benchmarked geometry) on the reference's own sample positions and background points == the reference's outputs
+    (forward_bg_train fixture), including depth_values_all."""
+    import torch
+    import torch_ref as tref
+    g = load(golden_dir, "forward_bg_train")
+    params = dict(synth.make_params(0)); params.update(synth.make_bg_params(0))
+    params["density.beta"] = np.asarray(g["beta_param"], F32)
+    dirs, cam, ds = orc.rays_from_uv(g["uv"], g["pose"], g["K"])
+    R = g["uv"].shape[0]
+    p = tref.to_torch(params, torch.float64)
+    with torch.enable_grad():
+        out = tref.forward_differentiable_bg(p, cam, dirs, g["z_vals"], g["z_max"], np.zeros((2, 3), F32), ds, g["z_bg"],
+                                             g["bg_points"], bg_depth=g["bg_depth"])
+    n = lambda t: t.detach().numpy()
+    np.testing.assert_allclose(n(out["weights"]), g["weights"], atol=2e-5)
+    np.testing.assert_allclose(n(out["bg_transmittance"]), g["bg_transmittance"], atol=2e-5)
+    np.testing.assert_allclose(n(out["rgb_values"]), g["rgb_values"], atol=2e-5)
+    # depth_values = sum(w z) / (sum(w) + 1e-8): rays that see only the background have sum(w) ~ 1e-7 in float32 (or an
+    # exact 0) and the quotient means nothing there
+    fg = g["weights"].sum(1) > 1e-3
+    assert fg.sum() >= 3
+    np.testing.assert_allclose(n(out["depth_values"])[fg], g["depth_values"][fg], rtol=2e-4)
+    np.testing.assert_allclose(n(out["depth_values_all"]), g["depth_values_all"], rtol=2e-4)
+    np.testing.assert_allclose(n(out["bg_out0"]), g["bg_sdf"], atol=2e-5)
+    # and it is differentiable down to the background parameters
+    out["depth_values_all"].sum().backward()
+    assert float(p["bg_implicit_network.lin0.weight"].grad.abs().max()) > 0
+
+
 @pytest.mark.parametrize("name", ["cost_mapping_inv0_v0", "cost_mapping_inv0_v2", "cost_mapping_inv1_v0",
                                   "cost_mapping_inv1_v2"])
 def test_cost_mapping(golden_dir, name):
