@@ -325,7 +325,9 @@ def kernel_roofline(ts, step, R, S, h2, train, n_steps=12, ray_groups=None):
     # tools/summarize_profiles.py); the bench itself cannot run the counters
     traffic, src_prof = {}, None
     try:
-        prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
+        # the latest round's summary: names are r<NN>_pmc_traffic.json (intermediate snapshots carry a suffix after r<NN>)
+        prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles"))
+                      if f.endswith("_pmc_traffic.json") and f[:1] == "r" and f[1:3].isdigit() and f[3] == "_")
         traffic = json.load(open(os.path.join(ROOT, "profiles", prof[-1])))["kernels"]
         src_prof = prof[-1]
     except Exception:
