@@ -123,14 +123,18 @@ def test_train_steps_fused(dev, golden_dir, fixture, groups):
         _check_digest(g, step, "param", list(m.named_parameters()), rtol=0.0, atol=1.1e-3 * (step + 1), frac_ok=1.0)
 
 
-@pytest.mark.parametrize("R,wset", [(256, "w0"), (1024, "w0"), (256, "w1")])
-def test_step_gradient_at_bench_geometry(dev, R, wset):
+@pytest.mark.parametrize("R,wset,precision", [(256, "w0", None), (1024, "w0", None), (256, "w1", None), (1024, "w0", "f32")])
+def test_step_gradient_at_bench_geometry(dev, R, wset, precision, monkeypatch):
     """The flat gradient of ONE TrainStep at the benchmarked geometry -- 1024 rays (two ray groups on concurrent
     streams, 800 workgroups per fused-MLP launch, shared float-atomic accumulators) and its 8-GPU shard of 256 rays --
     against float64 torch autograd (oracle/torch_ref.py) on the very sample positions, prior look-ups and targets the
-    step used.  Per tensor: max |err| <= 2e-3 of the tensor's largest entry, the bound of the 16-ray reference steps."""
+    step used.  Per tensor: max |err| <= 2e-3 of the tensor's largest entry, the bound of the 16-ray reference steps; with
+    SVS_MLP_PRECISION=f32 (the exact float32-MFMA kernels, float32 activation blocks) <= 3e-5."""
     import torch_ref as tref
     from svs_hip.trainer import TrainStep
+    if precision:
+        monkeypatch.setenv("SVS_MLP_PRECISION", precision)
+    bound = 3e-5 if precision == "f32" else 2e-3
     m, loss = _setup(dev, wset)
     params = synth.WEIGHT_SETS[wset]()
     K, pose = synth.make_camera()
@@ -168,16 +172,16 @@ def test_step_gradient_at_bench_geometry(dev, R, wset):
     total = tref.loss_fn(out, gt["rgb"].reshape(-1, 3).double(), gt["rgb_smooth"].reshape(-1, 3).double(), 50)
     total.backward()
     ref_norm = float(torch.sqrt(sum((v.grad ** 2).sum() for v in p.values())))
-    assert norm == pytest.approx(ref_norm, rel=1e-3), (norm, ref_norm)
+    assert norm == pytest.approx(ref_norm, rel=1e-3 if precision is None else 1e-5), (norm, ref_norm)
     worst, worst_name = 0.0, ""
     for n in got:
         ref = p[n].grad.cpu()
         e = float((got[n] - ref).abs().max() / (ref.abs().max() + 1e-30))
         if e > worst:
             worst, worst_name = e, n
-    print(f"{R} rays, {wset}, {n_groups} group(s): worst per-tensor gradient error vs float64 autograd {worst:.2e} ({worst_name}); "
+    print(f"{R} rays, {wset}, {precision or 'fp16x2'}, {n_groups} group(s): worst per-tensor gradient error vs float64 autograd {worst:.2e} ({worst_name}); "
           f"gradient norm {norm:.6f} vs {ref_norm:.6f}")
-    assert worst < 2e-3, (worst, worst_name)
+    assert worst < bound, (worst, worst_name)
 
 
 def test_train_step_autograd_bridge(dev, golden_dir):
