@@ -74,3 +74,21 @@ def test_background_model_refuses_f32_setting(monkeypatch):
     monkeypatch.setenv("SVS_MLP_PRECISION", "bf16")
     with pytest.raises(ValueError):
         ops.default_precision()
+
+
+def test_argument_errors_come_back_as_codes():
+    """Entry points validate their arguments before touching the device: null pointers and bad shapes return the
+    documented negative codes (and set the error string) -- no GPU needed, nothing is launched."""
+    import ctypes
+    from svs_hip import lib
+    L = lib.load()
+    dummy = ctypes.c_void_p(64)                      # never dereferenced: the shape checks come first
+    rc = L.svs_featurenet_fpn(None, 512, 640, 8, None, None, None, None, None, None, None)
+    assert rc < 0 and b"null" in L.svs_last_error_string()
+    rc = L.svs_featurenet_fpn(dummy, 510, 640, 8, dummy, dummy, dummy, dummy, dummy, dummy, None)
+    assert rc < 0 and b"multiples of 4" in L.svs_last_error_string()
+    assert L.svs_featurenet_fpn_workspace_bytes(8, 512, 640) > 0 and L.svs_featurenet_fpn_workspace_bytes(8, 2, 2) == 0
+    rc = L.svs_conv2d(dummy, dummy, None, None, 0, dummy, 8, 8, 16, 16, 4, 1, 0, None)        # k = 4
+    assert rc < 0 and b"k in {1,3,5}" in L.svs_last_error_string()
+    rc = L.svs_wgrad_multi(None, 0, 1, None)
+    assert rc < 0

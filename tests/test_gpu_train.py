@@ -403,3 +403,37 @@ def test_rccl_path_on_one_gpu(dev):
     assert float((plain[2] - with_pg[2]).abs().max()) <= 1e-5 * float(plain[2].abs().max())
     d = (plain[3] - with_pg[3]).abs()
     assert float(d.max()) <= 1.1e-3 and float((d > 1e-5).float().mean()) < 1e-3
+
+
+def test_ray_group_schedule_is_measured(dev):
+    """TrainStep(groups="auto") times the split and the unsplit schedule on the job's own steps and keeps one of them;
+    before the decision the step runs split, afterwards `_groups_for` returns the chosen one, and the steps go on
+    producing the same kind of result (loss terms finite, parameters moving)."""
+    from svs_hip.trainer import TrainStep
+    R = 512
+    m, loss = _setup(dev, "w0")
+    K, pose = synth.make_camera()
+    inp = {"intrinsics": G(K, dev)[None], "uv": G(synth.make_uv(R, seed=2), dev)[None], "pose": G(pose, dev)[None]}
+    rs = np.random.default_rng(1)
+    gt = {"rgb": G(rs.uniform(0, 1, (1, R, 3)).astype(F32), dev), "rgb_smooth": G(rs.uniform(0, 1, (1, R, 3)).astype(F32), dev)}
+    ts = TrainStep(m, loss, lr=5e-4, groups="auto", graph=False)
+    ts.TUNE_START, ts.TUNE_STEPS, ts.TUNE_SKIP = 2, 3, 1          # decision after step 2 + 2 * 3 = 8
+    split = ts.split_rays(R, ts.samples_per_ray())
+    assert len(split) == 2
+    p0 = ts.fp.flat.clone()
+    seen = []
+    for step in range(10):
+        assert (R in ts.schedule) == (step >= 8)
+        seen.append(len(ts._groups_for(R)) if ts._force_groups is None else None)
+        lo, out = ts(inp, gt)
+        assert np.isfinite(float(lo["loss"])) and out["rgb_values"].shape == (R, 3)
+    sched = ts.schedule[R]
+    assert sched["choice"] in ("split", "whole") and sched["ms_split"] > 0 and sched["ms_whole"] > 0
+    assert len(ts._groups_for(R)) == (2 if sched["choice"] == "split" else 1)
+    assert seen[0] == 2                                            # before the measurement: split
+    assert float((ts.fp.flat - p0).abs().max()) > 0 and bool(torch.isfinite(ts.fp.flat).all())
+    # a batch that cannot be split has nothing to measure
+    ts2 = TrainStep(m, loss, lr=5e-4, groups="auto", graph=False)
+    inp2 = dict(inp, uv=inp["uv"][:, :64].contiguous())
+    ts2(inp2, {k: v[:, :64].contiguous() for k, v in gt.items()})
+    assert ts2.schedule[64]["choice"] == "whole"
