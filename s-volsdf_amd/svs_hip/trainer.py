@@ -397,7 +397,7 @@ class TrainStep:
         # waits for the first event (recorded long before it gets there), the backward launches for the second.
         # Stream topology (also what a capture records): every side stream forks from `main` or from a group stream and
         # joins `main` DIRECTLY.  A stream forked from a forked stream that joins its parent again makes
-        # hipStreamEndCapture crash (ROCm 7.0 runtime of this torch build; tools/dbg_graph2.py), so the radiance
+        # hipStreamEndCapture crash (ROCm 7.0 runtime of this torch build; tools/repro_hip_capture_nested_fork.py), so the radiance
         # weight-gradient stream of a group hands its completion event up to here instead of joining the group stream.
         if not serial:
             prep.wait_stream(main)                       # parameters of this step are final, last step's readers are done
