@@ -118,7 +118,7 @@ def main():
         raise SystemExit(f"--scaling strong: {args.rays} rays do not shard over {world} ranks")
     R = args.rays if args.scaling == "weak" else args.rays // world
     train = args.mode == "train"
-    h2 = ops.default_precision() == ops.F16X2
+    h2 = ops.is_h2(ops.default_precision())
 
     def make_model(seed_params=0):
         params = synth.make_params(seed_params)

@@ -46,8 +46,15 @@ int svs_rays_from_uv(const float* uv, const float* pose, const float* intrinsics
  *   SVS_MMA_F32   v_mfma_f32_32x32x2_f32 on float32 operands (exact float32 products);
  *   SVS_MMA_F16X2 v_mfma_f32_32x32x16_f16 on operands split into two fp16 pieces, a = hi + mid, three products
  *                 per term (22-bit significands, float32 accumulation: float32-class accuracy at 2.8x the speed;
- *                 operands must stay below 65504).  Stream sizes do not depend on the precision. */
-enum { SVS_MMA_F32 = 0, SVS_MMA_F16X2 = 1 };
+ *                 operands must stay below 65504) -- forward AND backward: the activation blocks the training backward
+ *                 keeps in memory hold both pieces, parameter gradients agree with float64 autograd to < 1e-5 of a
+ *                 tensor's largest entry (the float32-MFMA kernels: 3e-6);
+ *   SVS_MMA_F16X2_HALF  the same kernels with the gradient-only blocks of the backward (ghat, u, a2, abar, zbar, fbar)
+ *                 stored as ONE fp16 piece under a per-point scale and one-product weight-gradient GEMMs: half the
+ *                 backward's block bytes, parameter gradients 2e-4 ... 8e-4 off (a mixed-precision training mode; the
+ *                 forward is identical).  Packs the same streams as SVS_MMA_F16X2.
+ * Stream sizes do not depend on the precision. */
+enum { SVS_MMA_F32 = 0, SVS_MMA_F16X2 = 1, SVS_MMA_F16X2_HALF = 2 };
 size_t svs_stream_bytes(int which);
 int svs_pack_stream(int which, int precision, const float* const* weight_v, const float* const* weight_g,
                     const float* const* bias, float* workspace, float* stream_out, void* hip_stream);
@@ -132,7 +139,8 @@ int svs_composite_bwd(int n_rays, int n_samples, const float* z, const float* sd
                       float* d_beta_ray, float* d_beta_param, void* hip_stream);
 
 /* ---- a9 (config 4)  inverted-sphere background model, VolSDFNetworkBG (volsdf/model/network_bg.py) -----------
- * fp16x2 only.  Streams: svs_pack_stream which = 5 (bg implicit forward), 6 (bg implicit backward), 7 (bg radiance
+ * fp16x2 only (precision = SVS_MMA_F16X2 or SVS_MMA_F16X2_HALF; it selects the format of the blocks kept for / written
+ * by the backward).  Streams: svs_pack_stream which = 5 (bg implicit forward), 6 (bg implicit backward), 7 (bg radiance
  * forward), 8 (bg radiance backward); weight arrays of 9 / 2 device pointers, weight_g = NULL (no weight-norm).
  *   svs_bg_points     UniformSampler(1,0,n_bg,far=1) * (1/radius), flipped (ray_sampler.py:22-43,215-216;
  *                     network_bg.py:79-82) + depth2pts_outside (:182-214): jitter (n_rays,n_bg) train draws or NULL
@@ -145,23 +153,23 @@ int svs_composite_bwd(int n_rays, int n_samples, const float* z, const float* sd
  *   svs_composite_bg  volume_rendering / bg_volume_rendering and the composition (:76-125,147-180) */
 int svs_bg_points(const float* cam, int cam_stride, const float* dirs, int n_rays, int n_bg, const float* jitter,
                   float radius, float* z_bg, float* pts, float* depth_real, void* hip_stream);
-int svs_bg_sdf_eval(const float* pts, int n_points, const float* stream, float* out0, float* feat_tiles, float* hbuf,
-                    float* ghat7, float* pebuf, void* hip_stream);
+int svs_bg_sdf_eval(const float* pts, int n_points, const float* stream, int precision, float* out0, float* feat_tiles,
+                    float* hbuf, float* ghat7, float* pebuf, void* hip_stream);
 size_t svs_bg_rbuf_bytes(int n_points);
 int svs_bg_rgb_eval(int n_points, const float* view_dirs, int view_S, const float* feat_tiles, const float* stream,
-                    float* rgb, float* rbuf, void* hip_stream);
+                    int precision, float* rgb, float* rbuf, void* hip_stream);
 /* training backward of the background networks (per-point scaling as in the fg sweeps; absmax: 3 floats, caller
  * zeroes once per step: [0] max |abar|, [1] max |zbar|, [2] max |feat_bar|):
- *   svs_bg_rgb_bwd  d_rgb (P,3), rgb (P,3), rbuf, stream (which = 8) -> zbuf (2 blocks/tile: zbar_0, zbar_1;
- *                   ZERO-INITIALISED by the caller once), feat_bar (1 block/tile)
+ *   svs_bg_rgb_bwd  d_rgb (P,3), rgb (P,3), rbuf, stream (which = 8) -> zbuf (svs_block_bytes(P,2): zbar_0, zbar_1 per
+ *                   tile; ZERO-INITIALISED by the caller once), feat_bar (svs_block_bytes(P,1))
  *   svs_bg_sdf_bwd  d_out0 (P), feat_bar, hbuf, ghat7, stream (which = 6) -> abuf (8 blocks/tile), sbar_out (padded P);
  *                   n_points must be a multiple of 32 (n_rays * 32 is)
  * Weight gradients: svs_wgrad_multi with A = abuf / feat_bar / zbuf blocks and B = pebuf / hbuf / rbuf blocks;
  * svs_lin8_row0_grad with ubuf = NULL; svs_unpack_wgrad maps 3 (bg lin4) and 4 (bg radiance lin0). */
-int svs_bg_rgb_bwd(int n_points, const float* d_rgb, const float* rgb, const float* rbuf, const float* stream, float* zbuf,
-                   float* feat_bar, float* absmax, void* hip_stream);
+int svs_bg_rgb_bwd(int n_points, const float* d_rgb, const float* rgb, const float* rbuf, const float* stream, int precision,
+                   float* zbuf, float* feat_bar, float* absmax, void* hip_stream);
 int svs_bg_sdf_bwd(int n_points, const float* d_out0, const float* feat_bar, const float* hbuf, const float* ghat7,
-                   const float* stream, float* abuf, float* sbar_out, float* absmax, void* hip_stream);
+                   const float* stream, int precision, float* abuf, float* sbar_out, float* absmax, void* hip_stream);
 int svs_composite_bg(int n_rays, int n_samples, int n_bg, const float* z, const float* z_max, const float* sdf,
                      const float* rgb, const float* normals, const float* depth_scale, const float* beta_param,
                      float beta_min, const float* z_bg, const float* bg_out0, const float* bg_rgb, const float* bg_depth,
@@ -183,8 +191,12 @@ int svs_composite_bg_bwd(int n_rays, int n_samples, int n_bg, const float* z, co
  * per block (dW columns
  * 256..271, ldw >= 272: the radiance MLP's first layer).  db[256] += row sums of pair 0's A (bias gradient).
  * dW / db are accumulated with float atomics: the caller zeroes them.
- * precision SVS_MMA_F16X2: the gradient-like operands (A of pair 0, B of pair 1) are scaled by a power of two derived
- * from *absmax (device float: their maximum magnitude, published by the fp16x2 sweeps below; NULL = no scaling). */
+ * precision SVS_MMA_F16X2 / _HALF: the gradient-like operands (A of pair 0, B of pair 1) are scaled blocks: every point
+ * carries a power-of-two scale, kept in the block's 64-float RECORD (rec0: records of a0's blocks, rec1: of b1's; [tile][64]
+ * floats, see the buffer layout below); the contraction re-scales them to one power of two per launch derived from
+ * *absmax (device float: their maximum magnitude, published by the fp16x2 sweeps below; NULL = operands are unscaled and
+ * no records are read).  SVS_MMA_F16X2 multiplies both fp16 pieces of both operands (three products), _HALF the hi
+ * pieces. */
 typedef struct svs_wgrad_job {
   const float *a0, *b0; long long sa0, sb0;   /* pair 0 */
   const float *a1, *b1; long long sa1, sb1;   /* pair 1, a1 == NULL: one pair */
@@ -192,6 +204,7 @@ typedef struct svs_wgrad_job {
   int n_points, ldw;
   float *dW, *db;                             /* db may be NULL */
   const float* absmax;                        /* fp16x2 scaling, may be NULL */
+  const float *rec0, *rec1;                   /* fp16x2 with absmax: scale records of a0's / b1's blocks, 64 floats per tile */
 } svs_wgrad_job;
 /* The weight gradients of several layers (<= 20 jobs, one with b_extra counts twice) in one call.  SVS_MMA_F16X2: ONE
  * launch, ~one workgroup per CU in total, split between the jobs in proportion to their work (so each layer flushes
@@ -200,17 +213,21 @@ int svs_wgrad_multi(const svs_wgrad_job* jobs, int n_jobs, int precision, void* 
 /* single job */
 int svs_wgrad(const float* a0, const float* b0, long long sa0, long long sb0, const float* a1, const float* b1,
               long long sa1, long long sb1, const float* b_extra, long long s_extra, int n_points, int precision,
-              const float* absmax, float* dW, int ldw, float* db, void* hip_stream);
+              const float* absmax, const float* rec0, const float* rec1, float* dW, int ldw, float* db, void* hip_stream);
 
 /* ---- a12  training backward of the fused MLPs (hand-written reverse mode; the reference uses torch.autograd,
  * loss.backward() at volsdf/vsdf.py:215, incl. the double backward through network.py:115-121) -------------------
- * Buffers are wave-tile activation blocks; svs_block_bytes(n_points, k) = bytes of k blocks per 32-point tile.
+ * Buffers are wave-tile activation blocks; svs_block_bytes(n_points, k) = bytes of k blocks per 32-point tile INCLUDING
+ * their records (below).
  * Layout of the multi-block buffers (hbuf, gbuf, ubuf, a2buf, abuf, rbuf, zbuf): [block][wave tile][128*64 floats], the tile
  * count T padded to whole workgroups (T = 4 * ceil(n_points / 128)): block b of tile t starts at float (b * T + t) *
  * 8192 -- what a launch touches at one time and what one weight-gradient job reads is contiguous (for svs_wgrad:
  * pointer = buffer + b * T * 8192, stride 8192).  The radiance buffers use the same layout: rbuf = [4 blocks][tile]
  * followed by the 1024-float extras of every tile, zbuf = [5 blocks][tile]; the background networks' two small
  * buffers (bg rbuf, bg zbuf) are [tile][block].
+ * Records (fp16x2): a buffer of k scaled blocks per tile (ubuf, a2buf, abuf, zbuf, feat_bar) is followed by k * T records
+ * of 64 floats ([scale of point 0..31][max |value| of point 0..31]), in the order of the slots: the record of block b of
+ * tile t is at float k * T * 8192 + (b * T + t) * 64 (also for bg zbuf, whose slots are [tile][block]).
  *   svs_rgb_bwd : d_rgb (P,3), rgb (P,3), rbuf, radiance backward stream (svs_pack_stream which=4)
  *                 -> zbuf (5 blocks/tile, ZERO-INITIALISED by the caller once), feat_bar (1 block/tile), d_normals (P,3)
  *   svs_sdf_bwd_a: second-order sweep.  points/rays as in svs_sdf_outputs; d_grad (P,3) = dL/d(d sdf/dx);

@@ -21,7 +21,7 @@ struct BgSdfArgs {
   float* pebuf;          // training: [wave tiles][kBlockF] the 84 PE inputs in PE order (first 3 tiles), B operand of dW_0
 };
 
-template <bool TRAIN>
+template <bool TRAIN, bool GP>      // GP: the blocks kept for the backward in the both-pieces format (svs_blocks_h2.h)
 __global__ __launch_bounds__(kThreads, 1) void bg_sdf_h2_kernel(BgSdfArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Stream st;
@@ -42,13 +42,13 @@ __global__ __launch_bounds__(kThreads, 1) void bg_sdf_h2_kernel(BgSdfArgs a) {
   float* hb = TRAIN ? a.hbuf + (size_t)wtile * kBlockF : nullptr;
   Pieces2 x, xn;
   if (TRAIN) {
-    // h_0 = PE (84 rows, 6 k-steps) in PE order as block fragments (hi plane), the rest zero: the B operand of dW_0
+    // h_0 = PE (84 rows, 6 k-steps) in PE order as block fragments, the rest zero: the B operand of dW_0
     float* pb = a.pebuf + (size_t)wtile * kBlockF;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       f16x8 fh = (f16x8)(_Float16)0.0f, fm = (f16x8)(_Float16)0.0f;
       if (k < NetBg::kSteps0) block_fragment<kBgPeDim>(pe.v, k, half, 1.0f, fh, fm);
-      store_piece(pb, k, lane, fh, 0);
+      store_grad<GP>(pb, k, lane, fh, fm);
     }
   }
   f32x16 y8[8];
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kThreads, 1) void bg_sdf_h2_kernel(BgSdfArgs a) {
       for (int sh = 0; sh < 2; ++sh) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v8[j] = g[8 * sh + j];
-        store_piece(g7, 2 * t + sh, lane, hi8(v8, 1.0f));       // ghat_7: a half block, unscaled
+        store_grad8<GP>(g7, 2 * t + sh, lane, v8);       // ghat_7, unscaled
       }
     }
   }
@@ -126,6 +126,7 @@ constexpr int kBgRgbBufF4 = kBgRgbChunk0F4;
 
 typedef StreamT<kBgRgbBufF4> BgRgbStream;
 
+template <bool GP>      // GP: r_1 kept with both pieces
 __global__ __launch_bounds__(kThreads, 1) void bg_rgb_h2_kernel(BgRgbArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   BgRgbStream st;
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(kThreads, 1) void bg_rgb_h2_kernel(BgRgbArgs a) {
         const int k = 2 * tp + (r >> 3);
         split8(v8, xn.h[k], xn.m[k]);
         pin(xn.h[k], xn.m[k]);
-        if (rb) store_piece(rb, k, lane, xn.h[k], 0);    // r_1: the hi plane (ReLU mask, weight gradient's B operand)
+        if (rb) store_grad<GP>(rb, k, lane, xn.h[k], xn.m[k]);    // r_1 (ReLU mask, weight gradient's B operand)
       }
     };
 #pragma unroll
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(kThreads, 1) void bg_rgb_h2_kernel(BgRgbArgs a) {
     if (rb) {
       // k-steps 8..15 (rows 128..255) of the r_1 block stay zero (the weight-gradient GEMM reads whole 256-row blocks)
 #pragma unroll
-      for (int k = 8; k < 16; ++k) store_piece(rb, k, lane, (f16x8)(_Float16)0.0f, 0);
+      for (int k = 8; k < 16; ++k) store_grad<GP>(rb, k, lane, (f16x8)(_Float16)0.0f, (f16x8)(_Float16)0.0f);
     }
   }
   // ---- layer 1: 128 -> 3 as one tile (rows 0..2 live in registers 0..2 of lanes 0..31), sigmoid
@@ -237,6 +238,7 @@ struct BgRgbBwdArgs {
   float* absmax;           // [3]: [1] = max |zbar|, [2] = max |feat_bar|
 };
 
+template <bool GP>
 __global__ __launch_bounds__(kThreads, 1) void bg_rgb_bwd_h2_kernel(BgRgbBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Stream st;
@@ -248,6 +250,10 @@ __global__ __launch_bounds__(kThreads, 1) void bg_rgb_bwd_h2_kernel(BgRgbBwdArgs
   const int pc = livep ? p : a.P - 1;
   const float* rb = a.rbuf + (size_t)wtile * kBgRbufF;
   float* zb = a.zbuf + (size_t)wtile * 2 * kBlockF;
+  // records behind the slots, [block][tile][64] as in every buffer (the SLOTS of this small buffer are [tile][block])
+  const size_t T = (size_t)gridDim.x * kWaves;
+  float* zrec0 = record_ptr(a.zbuf, 2, T, 0, wtile);
+  float* zrec1 = record_ptr(a.zbuf, 2, T, 1, wtile);
 
   st.prefetch<kW1TF4>();
   float dz[3];
@@ -262,9 +268,9 @@ __global__ __launch_bounds__(kThreads, 1) void bg_rgb_bwd_h2_kernel(BgRgbBwdArgs
   PointScale ps;
   ps.start(m0, 0.0f);
   {  // zbar_1: rows 0..2 = elements 0..2 of k-step 0 of half 0 (a half block; the rest stays zero)
-    float z8[8] = {dz[0], dz[1], dz[2], 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    store_piece(zb + (size_t)kBlockF, 0, lane, hi8(z8, ps.s_in));
-    store_record(zb + (size_t)kBlockF, lane, ps.s_in, m0);
+    float z8[8] = {dz[0] * ps.s_in, dz[1] * ps.s_in, dz[2] * ps.s_in, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    store_grad8<GP>(zb + (size_t)kBlockF, 0, lane, z8);
+    store_record(zrec1, lane, ps.s_in, m0);
   }
   st.advance();
   Pieces2 pz;
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(kThreads, 1) void bg_rgb_bwd_h2_kernel(BgRgbBwdArgs
   {
     // rbar_1 = W_1^T zbar_1 (K = 3: float32 MFMA from the short W1T chunk), masked by r_1 > 0 -> zbar_0 (4 tiles)
     const f32x4* c = st.cur_buf();
-    store_record(zb, lane, ps.s_out, 0.0f);
+    store_record(zrec0, lane, ps.s_out, 0.0f);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       TilePieces r;
@@ -285,8 +291,8 @@ __global__ __launch_bounds__(kThreads, 1) void bg_rgb_bwd_h2_kernel(BgRgbBwdArgs
 #pragma unroll
       for (int i = 0; i < 16; ++i) { acc[i] = hi_at(r, i) > 0.0f ? acc[i] : 0.0f; ps.track(acc[i]); }
       split_tile_scaled(acc, t, pz, ps.s_out);
-      store_piece(zb, 2 * t, lane, pz.h[2 * t]);              // zbar_0: a half block under s_out
-      store_piece(zb, 2 * t + 1, lane, pz.h[2 * t + 1]);
+      store_grad<GP>(zb, 2 * t, lane, pz.h[2 * t], pz.m[2 * t]);              // zbar_0: a scaled block under s_out
+      store_grad<GP>(zb, 2 * t + 1, lane, pz.h[2 * t + 1], pz.m[2 * t + 1]);
     }
   }
   ps.next();
@@ -300,8 +306,8 @@ __global__ __launch_bounds__(kThreads, 1) void bg_rgb_bwd_h2_kernel(BgRgbBwdArgs
   auto slice = [&](int tp, int r) {
     const float v = prev[r] * ps.inv_in;
     fmax = __builtin_fmaxf(fmax, __builtin_fabsf(v));
-    v8[r & 7] = v;
-    if ((r & 7) == 7) store_piece(fb, 2 * tp + (r >> 3), lane, hi8(v8, s_f));
+    v8[r & 7] = v * s_f;
+    if ((r & 7) == 7) store_grad8<GP>(fb, 2 * tp + (r >> 3), lane, v8);
   };
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(kThreads, 1) void bg_rgb_bwd_h2_kernel(BgRgbBwdArgs
 #pragma unroll
   for (int r = 0; r < 16; ++r) slice(7, r);
   fmax = __builtin_fmaxf(fmax, __shfl_xor(fmax, 32));
-  store_record(fb, lane, s_f, fmax);
+  store_record(record_ptr(a.feat_bar, 1, T, 0, wtile), lane, s_f, fmax);
   publish_max(a.absmax + 1, ps.gmax);
   publish_max(a.absmax + 2, fmax);
 }
@@ -334,57 +340,68 @@ size_t svs_bg_rbuf_bytes(int n_points) { return (size_t)wave_tiles(n_points) * k
 
 // bg_implicit_network (network_bg.py:85-88): pts (P,4) -> out0 (P) = output[:,0], feat_tiles (svs_feat_tiles_bytes);
 // training: hbuf (svs_sdf_hbuf_bytes) and ghat7 (svs_block_bytes(P,1)) for the backward, both or neither.
-int svs_bg_sdf_eval(const float* pts, int n_points, const float* stream, float* out0, float* feat_tiles, float* hbuf,
-                    float* ghat7, float* pebuf, void* hip_stream) {
+int svs_bg_sdf_eval(const float* pts, int n_points, const float* stream, int precision, float* out0, float* feat_tiles,
+                    float* hbuf, float* ghat7, float* pebuf, void* hip_stream) {
+  if (!is_h2(precision)) { set_error("svs_bg_sdf_eval: the background networks have fp16x2 kernels only (precision %d)", precision); return SVS_EINVAL; }
   if (!pts || n_points <= 0 || !stream || !out0 || !feat_tiles || (!hbuf != !ghat7) || (!hbuf != !pebuf)) {
     set_error("svs_bg_sdf_eval: null/invalid argument"); return SVS_EINVAL;
   }
   BgSdfArgs a{pts, n_points, reinterpret_cast<const f32x4*>(stream), out0, feat_tiles, hbuf, ghat7, pebuf};
-  static int once = set_lds(bg_sdf_h2_kernel<false>, kLdsBytes, "svs_bg_sdf_eval") | set_lds(bg_sdf_h2_kernel<true>, kLdsBytes, "svs_bg_sdf_eval");
+  static int once = set_lds(bg_sdf_h2_kernel<false, false>, kLdsBytes, "svs_bg_sdf_eval") |
+                    set_lds(bg_sdf_h2_kernel<true, false>, kLdsBytes, "svs_bg_sdf_eval") |
+                    set_lds(bg_sdf_h2_kernel<true, true>, kLdsBytes, "svs_bg_sdf_eval");
   if (once) return once;
   const dim3 grid((n_points + kWgPts - 1) / kWgPts);
-  if (hbuf) bg_sdf_h2_kernel<true><<<grid, kThreads, kLdsBytes, (hipStream_t)hip_stream>>>(a);
-  else bg_sdf_h2_kernel<false><<<grid, kThreads, kLdsBytes, (hipStream_t)hip_stream>>>(a);
+  if (!hbuf) bg_sdf_h2_kernel<false, false><<<grid, kThreads, kLdsBytes, (hipStream_t)hip_stream>>>(a);
+  else if (precision == kFmtF16x2) bg_sdf_h2_kernel<true, true><<<grid, kThreads, kLdsBytes, (hipStream_t)hip_stream>>>(a);
+  else bg_sdf_h2_kernel<true, false><<<grid, kThreads, kLdsBytes, (hipStream_t)hip_stream>>>(a);
   return check_launch("svs_bg_sdf_eval");
 }
 
 // bg_rendering_network (network_bg.py:91-93): view_dirs (n_rays,3) when view_S > 0 (points per ray) else (P,3)
 int svs_bg_rgb_eval(int n_points, const float* view_dirs, int view_S, const float* feat_tiles, const float* stream,
-                    float* rgb, float* rbuf, void* hip_stream) {
+                    int precision, float* rgb, float* rbuf, void* hip_stream) {
+  if (!is_h2(precision)) { set_error("svs_bg_rgb_eval: the background networks have fp16x2 kernels only (precision %d)", precision); return SVS_EINVAL; }
   if (n_points <= 0 || !view_dirs || !feat_tiles || !stream || !rgb || view_S < 0 || (view_S > 0 && n_points % view_S)) {
     set_error("svs_bg_rgb_eval: null/invalid argument"); return SVS_EINVAL;
   }
   BgRgbArgs a{n_points, view_dirs, view_S, feat_tiles, reinterpret_cast<const f32x4*>(stream), rgb, rbuf};
   constexpr int lds = 2 * kBgRgbBufF4 * 16;
-  static int once = set_lds(bg_rgb_h2_kernel, lds, "svs_bg_rgb_eval");
+  static int once = set_lds(bg_rgb_h2_kernel<true>, lds, "svs_bg_rgb_eval") | set_lds(bg_rgb_h2_kernel<false>, lds, "svs_bg_rgb_eval");
   if (once) return once;
-  bg_rgb_h2_kernel<<<(n_points + kWgPts - 1) / kWgPts, kThreads, lds, (hipStream_t)hip_stream>>>(a);
+  const int grid = (n_points + kWgPts - 1) / kWgPts;
+  if (rbuf && precision == kFmtF16x2) bg_rgb_h2_kernel<true><<<grid, kThreads, lds, (hipStream_t)hip_stream>>>(a);
+  else bg_rgb_h2_kernel<false><<<grid, kThreads, lds, (hipStream_t)hip_stream>>>(a);
   return check_launch("svs_bg_rgb_eval");
 }
 
 // bg_rendering_network backward (stream: which = 8): zbuf = 2 blocks per tile, ZERO-INITIALISED by the caller once
-int svs_bg_rgb_bwd(int n_points, const float* d_rgb, const float* rgb, const float* rbuf, const float* stream, float* zbuf,
-                   float* feat_bar, float* absmax, void* hip_stream) {
+int svs_bg_rgb_bwd(int n_points, const float* d_rgb, const float* rgb, const float* rbuf, const float* stream, int precision,
+                   float* zbuf, float* feat_bar, float* absmax, void* hip_stream) {
+  if (!is_h2(precision)) { set_error("svs_bg_rgb_bwd: the background networks have fp16x2 kernels only (precision %d)", precision); return SVS_EINVAL; }
   if (n_points <= 0 || !d_rgb || !rgb || !rbuf || !stream || !zbuf || !feat_bar || !absmax) {
     set_error("svs_bg_rgb_bwd: null/invalid argument"); return SVS_EINVAL;
   }
   BgRgbBwdArgs a{n_points, d_rgb, rgb, rbuf, reinterpret_cast<const f32x4*>(stream), zbuf, feat_bar, absmax};
-  static int once = set_lds(bg_rgb_bwd_h2_kernel, kLdsBytes, "svs_bg_rgb_bwd");
+  static int once = set_lds(bg_rgb_bwd_h2_kernel<true>, kLdsBytes, "svs_bg_rgb_bwd") | set_lds(bg_rgb_bwd_h2_kernel<false>, kLdsBytes, "svs_bg_rgb_bwd");
   if (once) return once;
-  bg_rgb_bwd_h2_kernel<<<(n_points + kWgPts - 1) / kWgPts, kThreads, kLdsBytes, (hipStream_t)hip_stream>>>(a);
+  const int grid = (n_points + kWgPts - 1) / kWgPts;
+  if (precision == kFmtF16x2) bg_rgb_bwd_h2_kernel<true><<<grid, kThreads, kLdsBytes, (hipStream_t)hip_stream>>>(a);
+  else bg_rgb_bwd_h2_kernel<false><<<grid, kThreads, kLdsBytes, (hipStream_t)hip_stream>>>(a);
   return check_launch("svs_bg_rgb_bwd");
 }
 
 // bg_implicit_network backward (stream: which = 6): d_out0 (P) = d loss / d output[:,0], feat_bar (1 block per tile),
 // hbuf / ghat7 from svs_bg_sdf_eval -> abuf (8 blocks per tile: abar_0..abar_7), sbar_out (padded P)
 int svs_bg_sdf_bwd(int n_points, const float* d_out0, const float* feat_bar, const float* hbuf, const float* ghat7,
-                   const float* stream, float* abuf, float* sbar_out, float* absmax, void* hip_stream) {
+                   const float* stream, int precision, float* abuf, float* sbar_out, float* absmax, void* hip_stream) {
+  if (!is_h2(precision)) { set_error("svs_bg_sdf_bwd: the background networks have fp16x2 kernels only (precision %d)", precision); return SVS_EINVAL; }
   if (n_points <= 0 || n_points % 32 || !d_out0 || !feat_bar || !hbuf || !ghat7 || !stream || !abuf || !sbar_out || !absmax) {
     set_error("svs_bg_sdf_bwd: null/invalid argument (n_points must be a multiple of 32)"); return SVS_EINVAL;
   }
   SdfBwdBArgs a{n_points, d_out0, nullptr, feat_bar, n_points / 32, hbuf, nullptr, nullptr,
                 reinterpret_cast<const f32x4*>(stream), abuf, sbar_out, absmax, nullptr, ghat7, (size_t)kBlockF};
-  return launch_bg_bwd_b_h2(a, (hipStream_t)hip_stream);
+  return launch_bg_bwd_b_h2(a, precision == kFmtF16x2, (hipStream_t)hip_stream);
 }
 
 }  // extern "C"

@@ -9,16 +9,19 @@
 //                The 16 bytes of lane L in k-step s are the MFMA B fragment of that k-step: rows 16 s + 8 (j >> 2) +
 //                4 (L >> 5) + (j & 3), j = 0..7, of point L & 31 -- registers 8 (s & 1) .. 8 (s & 1) + 7 of accumulator
 //                tile s >> 1.  Forward activations (h_l, the feature vector, the radiance network's r_l, PE(x)).
-//   half block   the hi plane only, of value * 2^k with one power of two per point and block, + a record of 64 floats at
-//                float index 4096 of the slot: [scale of point 0..31][max |value| of point 0..31].  Everything that
-//                exists only to form parameter gradients: ghat_l (stored unscaled: scale 1), u_l, a2_l, abar_l, zbar_l,
-//                fbar.  11 significand bits: tools/study/fp16_blocks_error.py measures what that costs (parameter
-//                gradients 3e-4 ... 8e-4 of a tensor's largest entry vs float64, inside the 2e-3 the parity tests
-//                allow); it halves the bytes these blocks move, and a sweep that only needs softplus' of h reads the
-//                hi plane of the pair block alone.
+//   scaled block  value * 2^k with one power of two per point and block, + a RECORD of 64 floats [scale of point 0..31]
+//                [max |value| of point 0..31].  Everything that exists only to form parameter gradients: ghat_l (stored
+//                unscaled, no record), u_l, a2_l, abar_l, zbar_l, fbar.  Two formats, chosen per launch (template
+//                parameter GP of the sweeps, `precision` of the C-ABI):
+//                  GP = true  (SVS_MMA_F16X2, the default): both pieces, hi plane then mid plane, like a pair block --
+//                             22 significand bits; parameter gradients within 1e-5 of float64 autograd, the float32 class
+//                  GP = false (SVS_MMA_F16X2_HALF): the hi plane only, 11 bits, half the bytes; parameter gradients
+//                             3e-4 ... 8e-4 of a tensor's largest entry off (tools/study/fp16_blocks_error.py); sweeps
+//                             that only need softplus' of h then read the hi plane of the pair block alone.
 //
-// Slot offsets and strides are those of the float32 blocks, so host code is format-agnostic; a half block simply leaves
-// the second half of its slot (beyond the record) untouched.
+// Slot offsets and strides are those of the float32 blocks, so host code is format-agnostic; a half block leaves the second
+// half of its slot untouched.  The records of a buffer of nb blocks x T wave tiles live BEHIND its slots:
+// [nb][T][kBlockF] floats, then [nb][T][64] floats (record_ptr(); the size functions of the C-ABI include them).
 #pragma once
 #include "svs_mlp_h2_dev.h"
 
@@ -26,7 +29,7 @@ namespace svs {
 namespace mlp {
 
 constexpr int kPlaneF4 = 1024;          // float4 per fp16 plane of a wave tile (16 KiB)
-constexpr int kRecordF = 4096;          // float index of a half block's scale / max record
+constexpr int kRecF = 64;               // floats per record of a scaled block
 
 __device__ __forceinline__ f32x4 as_f4(const f16x8& v) { return __builtin_bit_cast(f32x4, v); }
 __device__ __forceinline__ f16x8 as_h8(const f32x4& v) { return __builtin_bit_cast(f16x8, v); }
@@ -64,13 +67,47 @@ __device__ __forceinline__ void load_tile_pair(const float* __restrict__ blk, in
 __device__ __forceinline__ float hi_at(const TilePieces& p, int r) { return (float)p.h[r >> 3][r & 7]; }
 __device__ __forceinline__ float pair_at(const TilePieces& p, int r) { return (float)p.h[r >> 3][r & 7] + (float)p.m[r >> 3][r & 7]; }
 
-// the record of a half block: lane L < 32 writes the scale of its point, lane L >= 32 the maximum (both lane halves
-// hold both values)
-__device__ __forceinline__ void store_record(float* __restrict__ blk, int lane, float scale, float mx) {
-  blk[kRecordF + lane] = lane < 32 ? scale : mx;
+// The record of block l, wave tile `tile` of a buffer of nb blocks x T wave tiles laid out [block][tile] (T = the padded
+// tile count of the launch that wrote it: gridDim.x * kWaves).
+template <typename F>
+__device__ __forceinline__ F* record_ptr(F* buf, int nb, size_t T, int l, size_t tile) {
+  return buf + (size_t)nb * T * kBlockF + ((size_t)l * T + tile) * kRecF;
 }
-__device__ __forceinline__ float load_scale(const float* __restrict__ blk, int lane) { return blk[kRecordF + (lane & 31)]; }
-__device__ __forceinline__ float load_max(const float* __restrict__ blk, int lane) { return blk[kRecordF + 32 + (lane & 31)]; }
+// lane L < 32 writes the scale of its point, lane L >= 32 the maximum (both lane halves hold both values)
+__device__ __forceinline__ void store_record(float* __restrict__ rec, int lane, float scale, float mx) {
+  rec[lane] = lane < 32 ? scale : mx;
+}
+__device__ __forceinline__ float load_scale(const float* __restrict__ rec, int lane) { return rec[lane & 31]; }
+__device__ __forceinline__ float load_max(const float* __restrict__ rec, int lane) { return rec[32 + (lane & 31)]; }
+
+// ---- scaled (gradient-only) blocks in the launch's format GP
+// the fragment of k-step s: hi always, mid when GP
+template <bool GP>
+__device__ __forceinline__ void store_grad(float* __restrict__ blk, int s, int lane, const f16x8& h, const f16x8& m) {
+  store_piece(blk, s, lane, h, 0);
+  if (GP) store_piece(blk, s, lane, m, 1);
+}
+// 8 float32 values (already scaled) -> the stored fragment(s) of k-step s
+template <bool GP>
+__device__ __forceinline__ void store_grad8(float* __restrict__ blk, int s, int lane, const float* v) {
+  if (GP) {
+    f16x8 h, m;
+    split8(v, h, m);
+    store_piece(blk, s, lane, h, 0);
+    store_piece(blk, s, lane, m, 1);
+  } else {
+    f16x8 h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = (_Float16)v[j];
+    store_piece(blk, s, lane, h, 0);
+  }
+}
+template <bool GP>
+__device__ __forceinline__ void load_tile_grad(const float* __restrict__ blk, int t, int lane, TilePieces& p) {
+  if (GP) load_tile_pair(blk, t, lane, p); else load_tile_hi(blk, t, lane, p);
+}
+template <bool GP>
+__device__ __forceinline__ float grad_at(const TilePieces& p, int r) { return GP ? pair_at(p, r) : hi_at(p, r); }
 
 // Fragment of k-step s of a vector given in natural row order (vec[q], q < n, zero beyond), in the BLOCK convention
 // (row 16 s + 8 (j >> 2) + 4 half + (j & 3)) -- NOT the order split_pe() uses for the layer-0 operand (16 s + 8 half + j,

@@ -319,7 +319,7 @@ int svs_sdf_vals(const float* points, int n_points, const float* cam, int cam_st
   a.gate_points = gate_points > 0 ? gate_points : 0x7fffff80; a.gate_stride = gate_stride;
   if (gate && a.gate_points % kWgPts) { set_error("svs_sdf_vals: gate_points must be a multiple of %d", kWgPts); return SVS_EINVAL; }
   a.clamp_n = clamp_n < 0 ? a.src.P : clamp_n;
-  if (precision == kFmtF16x2) return launch_sdf_only_h2(a, (hipStream_t)hip_stream);
+  if (is_h2(precision)) return launch_sdf_only_h2(a, (hipStream_t)hip_stream);
   if (precision != kFmtF32) { set_error("svs_sdf_vals: unknown precision %d", precision); return SVS_EINVAL; }
   static int once = set_lds(sdf_only_kernel, kLdsBytes, "svs_sdf_vals");
   if (once) return once;
@@ -342,7 +342,7 @@ int svs_sdf_outputs(const float* points, int n_points, const float* cam, int cam
   a.gbuf = gbuf; a.clamp_mask = clamp_mask;
   a.sphere_radius = sphere_radius; a.sphere_scale = sphere_scale;
   a.clamp_n = clamp_n < 0 ? a.src.P : clamp_n;
-  if (precision == kFmtF16x2) return launch_sdf_full_h2(a, (hipStream_t)hip_stream);
+  if (is_h2(precision)) return launch_sdf_full_h2(a, precision == kFmtF16x2, (hipStream_t)hip_stream);
   if (precision != kFmtF32) { set_error("svs_sdf_outputs: unknown precision %d", precision); return SVS_EINVAL; }
   static int once = set_lds(sdf_full_kernel, kLdsBytes, "svs_sdf_outputs");
   if (once) return once;
@@ -352,7 +352,7 @@ int svs_sdf_outputs(const float* points, int n_points, const float* cam, int cam
 
 int svs_tiles_to_rows(const float* tiles, int n_points, int precision, float* rows, void* hip_stream) {
   if (!tiles || !rows || n_points <= 0) { set_error("svs_tiles_to_rows: bad argument"); return SVS_EINVAL; }
-  if (precision == kFmtF16x2) {
+  if (is_h2(precision)) {
     const size_t n2 = (size_t)n_points * 256;
     pair_tiles_to_rows_kernel<<<(unsigned)((n2 + 255) / 256), 256, 0, (hipStream_t)hip_stream>>>(tiles, n_points, rows);
     return check_launch("svs_tiles_to_rows");
@@ -372,7 +372,7 @@ int svs_rgb_eval(const float* points, int n_points, const float* cam, int cam_st
   }
   a.normals = normals; a.view = view_dirs; a.view_S = view_S; a.feat_tiles = feat_tiles;
   a.stream = reinterpret_cast<const f32x4*>(stream); a.rgb = rgb; a.rbuf = rbuf;
-  if (precision == kFmtF16x2) return launch_rgb_h2(a, (hipStream_t)hip_stream);
+  if (is_h2(precision)) return launch_rgb_h2(a, precision == kFmtF16x2, (hipStream_t)hip_stream);
   if (precision != kFmtF32) { set_error("svs_rgb_eval: unknown precision %d", precision); return SVS_EINVAL; }
   constexpr int lds = 2 * kRgbBufF4 * 16;
   static int once = set_lds(rgb_kernel, lds, "svs_rgb_eval");

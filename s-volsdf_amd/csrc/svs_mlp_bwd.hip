@@ -443,11 +443,13 @@ struct svs_unpack_job {          // include/svolsdf_hip.h
 
 extern "C" {
 
-size_t svs_rgb_zbuf_bytes(int n_points) { return (size_t)tiles_of(n_points) * 5 * kBlockF * sizeof(float); }
-size_t svs_sdf_ubuf_bytes(int n_points) { return (size_t)tiles_of(n_points) * 9 * kBlockF * sizeof(float); }
+// blocks_per_tile slots of kBlockF floats per wave tile, followed by one 64-float record per slot (the per-point scales and
+// maxima of scaled blocks, csrc/svs_blocks_h2.h)
 size_t svs_block_bytes(int n_points, int blocks_per_tile) {
-  return (size_t)tiles_of(n_points) * blocks_per_tile * kBlockF * sizeof(float);
+  return (size_t)tiles_of(n_points) * blocks_per_tile * (kBlockF + 64) * sizeof(float);
 }
+size_t svs_rgb_zbuf_bytes(int n_points) { return svs_block_bytes(n_points, 5); }
+size_t svs_sdf_ubuf_bytes(int n_points) { return svs_block_bytes(n_points, 9); }
 
 int svs_rgb_bwd(int n_points, const float* d_rgb, const float* rgb, const float* rbuf, const float* stream, int precision,
                 float* zbuf, float* feat_bar, float* d_normals, float* absmax, void* hip_stream) {
@@ -455,9 +457,9 @@ int svs_rgb_bwd(int n_points, const float* d_rgb, const float* rgb, const float*
     set_error("svs_rgb_bwd: null/invalid argument"); return SVS_EINVAL;
   }
   RgbBwdArgs a{n_points, d_rgb, rgb, rbuf, reinterpret_cast<const f32x4*>(stream), zbuf, feat_bar, d_normals, absmax};
-  if (precision == kFmtF16x2) {
+  if (is_h2(precision)) {
     if (!absmax) { set_error("svs_rgb_bwd: fp16x2 needs absmax"); return SVS_EINVAL; }
-    return launch_rgb_bwd_h2(a, (hipStream_t)hip_stream);
+    return launch_rgb_bwd_h2(a, precision == kFmtF16x2, (hipStream_t)hip_stream);
   }
   if (precision != kFmtF32) { set_error("svs_rgb_bwd: unknown precision %d", precision); return SVS_EINVAL; }
   static int once = set_lds_b(rgb_bwd_kernel, kLdsBytes, "svs_rgb_bwd");
@@ -480,9 +482,9 @@ int svs_sdf_bwd_a(const float* points, int n_points, const float* cam, int cam_s
   a.d_grad = d_grad; a.clamp_mask = clamp_mask; a.hbuf = hbuf; a.gbuf = gbuf;
   a.stream = reinterpret_cast<const f32x4*>(stream); a.ubuf = ubuf; a.a2buf = a2buf; a.pebuf = pebuf;
   a.absmax = absmax; a.a2max = a2max;
-  if (precision == kFmtF16x2) {
+  if (is_h2(precision)) {
     if (!absmax || !a2max) { set_error("svs_sdf_bwd_a: fp16x2 needs absmax and a2max"); return SVS_EINVAL; }
-    return launch_sdf_bwd_a_h2(a, (hipStream_t)hip_stream);
+    return launch_sdf_bwd_a_h2(a, precision == kFmtF16x2, (hipStream_t)hip_stream);
   }
   if (precision != kFmtF32) { set_error("svs_sdf_bwd_a: unknown precision %d", precision); return SVS_EINVAL; }
   static int once = set_lds_b(sdf_bwd_a_kernel, kLdsBytes, "svs_sdf_bwd_a");
@@ -500,9 +502,9 @@ int svs_sdf_bwd_b(int n_points, const float* d_sdf, const unsigned char* clamp_m
   SdfBwdBArgs a{n_points, d_sdf, clamp_mask, feat_bar, n_feat_points / 32, hbuf, gbuf, a2buf,
                 reinterpret_cast<const f32x4*>(stream) + kSdfTrainPassBF4, abuf, sbar_out, absmax, a2max,
                 gbuf + 7 * (size_t)tiles_of(n_points) * kBlockF, (size_t)kBlockF};     // w0 = ghat_7: block 7 of gbuf ([block][tile])
-  if (precision == kFmtF16x2) {
+  if (is_h2(precision)) {
     if (!absmax || !a2max) { set_error("svs_sdf_bwd_b: fp16x2 needs absmax and a2max"); return SVS_EINVAL; }
-    return launch_sdf_bwd_b_h2(a, (hipStream_t)hip_stream);
+    return launch_sdf_bwd_b_h2(a, precision == kFmtF16x2, (hipStream_t)hip_stream);
   }
   if (precision != kFmtF32) { set_error("svs_sdf_bwd_b: unknown precision %d", precision); return SVS_EINVAL; }
   static int once = set_lds_b(sdf_bwd_b_kernel, kLdsBytes, "svs_sdf_bwd_b");
@@ -514,7 +516,7 @@ int svs_sdf_bwd_b(int n_points, const float* d_sdf, const unsigned char* clamp_m
 int svs_lin8_row0_grad(const float* hbuf, const float* ubuf, const float* sbar, int n_points, int precision, float* out257,
                        void* hip_stream) {
   if (!hbuf || !sbar || !out257 || n_points <= 0) { set_error("svs_lin8_row0_grad: bad argument"); return SVS_EINVAL; }
-  if (precision == kFmtF16x2) return launch_lin8_row0_h2(hbuf, ubuf, sbar, n_points, tiles_of(n_points), out257, (hipStream_t)hip_stream);
+  if (is_h2(precision)) return launch_lin8_row0_h2(hbuf, ubuf, sbar, n_points, tiles_of(n_points), out257, precision == kFmtF16x2, (hipStream_t)hip_stream);
   if (precision != kFmtF32) { set_error("svs_lin8_row0_grad: unknown precision %d", precision); return SVS_EINVAL; }
   const int n_tiles = (n_points + 31) / 32;
   const int grid = n_tiles < 1024 ? n_tiles : 1024;

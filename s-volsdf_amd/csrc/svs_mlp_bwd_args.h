@@ -49,13 +49,14 @@ struct SdfBwdBArgs {
   // the block holding ghat_7 = W8[0,:] s'(a_7) of a tile is w0 + tile * w0_stride (fg: gbuf block 7, stride 8 blocks)
   const float* w0; size_t w0_stride;
 };
-int launch_bg_bwd_b_h2(const SdfBwdBArgs& a, hipStream_t s);   // background implicit network: no a2, bg splice rows
+// gp: the launch's scaled-block format (svs_blocks_h2.h): both fp16 pieces (true) or the hi piece only
+int launch_bg_bwd_b_h2(const SdfBwdBArgs& a, bool gp, hipStream_t s);   // background implicit network: no a2, bg splice rows
 
-int launch_rgb_bwd_h2(const RgbBwdArgs& a, hipStream_t s);
+int launch_rgb_bwd_h2(const RgbBwdArgs& a, bool gp, hipStream_t s);
 int launch_lin8_row0_h2(const float* hbuf, const float* ubuf, const float* sbar, int n_points, int n_tiles_pad, float* out257,
-                        hipStream_t s);
-int launch_sdf_bwd_a_h2(const SdfBwdAArgs& a, hipStream_t s);
-int launch_sdf_bwd_b_h2(const SdfBwdBArgs& a, hipStream_t s);
+                        bool gp, hipStream_t s);
+int launch_sdf_bwd_a_h2(const SdfBwdAArgs& a, bool gp, hipStream_t s);
+int launch_sdf_bwd_b_h2(const SdfBwdBArgs& a, bool gp, hipStream_t s);
 
 }  // namespace mlp
 }  // namespace svs

@@ -8,8 +8,10 @@
 // to split the operand a layer produces is derived from the maximum of the operand the layer consumed (the new
 // maximum is only known once all eight tiles are done), which leaves 2^11 of headroom for growth across one layer;
 // additive external inputs (a2 in pass B) enter through a per-point floor of the maximum.  What the sweeps write to
-// memory are the hi pieces of these scaled operands (half blocks with their per-point scale, svs_blocks_h2.h); forward
-// activations are read back from pair blocks, by their hi plane where only softplus' is needed.  The kernels also publish the global maxima of the gradient-like
+// memory are these scaled operands with their per-point scale (scaled blocks, svs_blocks_h2.h), in the launch's format GP:
+// both pieces (the default: gradients in the float32 accuracy class) or the hi piece only (half the bytes); forward
+// activations are read back from pair blocks -- with GP = false by their hi plane where only softplus' is needed.  The
+// kernels also publish the global maxima of the gradient-like
 // operands of the weight-gradient GEMMs (svs_wgrad.hip, fp16x2 path) with one atomic max per wave.
 #include "svs_mlp_h2_dev.h"
 #include "svs_mlp_host.h"
@@ -23,8 +25,9 @@ namespace mlp {
 // ==============================================================================================================
 // radiance MLP backward
 // ==============================================================================================================
-// zbar_{l-1} = rbar_l * [r_l > 0] for one tile: track, split; the hi pieces of the split (value * s_out) are what
-// zbuf stores (a HALF block, svs_blocks_h2.h)
+// zbar_{l-1} = rbar_l * [r_l > 0] for one tile: track, split; the pieces of the split (value * s_out) are what
+// zbuf stores (a scaled block, svs_blocks_h2.h)
+template <bool GP>
 struct RgbBwdEpi {
   f32x16 prev;
   TilePieces r;        // hi pieces of the stored r_l tile: only its sign is needed
@@ -44,8 +47,9 @@ struct RgbBwdEpi {
       pin(out->h[2 * tp + (rr >> 3)], out->m[2 * tp + (rr >> 3)]);
     }
     // stores behind the LDS-DMA pieces: k-step 9 (the piece split at element 7) and 15
-    if (rr == 9) store_piece(zblk, 2 * tp, lane, out->h[2 * tp]);
-    if (rr == 15) store_piece(zblk, 2 * tp + 1, lane, out->h[2 * tp + 1]);
+    if (rr == 9) store_piece(zblk, 2 * tp, lane, out->h[2 * tp], 0);
+    if (GP && rr == 11) store_piece(zblk, 2 * tp, lane, out->m[2 * tp], 1);
+    if (rr == 15) store_grad<GP>(zblk, 2 * tp + 1, lane, out->h[2 * tp + 1], out->m[2 * tp + 1]);
   }
   __device__ __forceinline__ void all(int tp) {
 #pragma unroll
@@ -54,11 +58,12 @@ struct RgbBwdEpi {
 };
 
 // rbar_l = W_l^T zbar_l fused with zbar_{l-1} (l = 3..1)
+template <bool GP>
 __device__ __forceinline__ void rgb_bwd_layer_h2(Stream& st, const Pieces2& in, Pieces2& out, const float* rblk, float* zblk,
-                                                 PointScale& ps, int lane) {
-  RgbBwdEpi ep;
+                                                 float* zrec, PointScale& ps, int lane) {
+  RgbBwdEpi<GP> ep;
   ep.out = &out; ep.zblk = zblk; ep.ps = &ps; ep.lane = lane;
-  store_record(zblk, lane, ps.s_out, 0.0f);
+  store_record(zrec, lane, ps.s_out, 0.0f);
   // Per tile: the next chunk's 9 LDS-DMA pieces behind k-steps 0..8 (Stream::prefetch_step), then -- younger than every
   // piece, so that the barrier leaves them in flight -- the 2 zbuf stores of tile t-1's epilogue (k-steps 9, 15) and the
   // 2 loads of r tile t+1 (k-steps 10, 12), which the epilogue of tile t+1 consumes during tile t+2.
@@ -76,14 +81,17 @@ __device__ __forceinline__ void rgb_bwd_layer_h2(Stream& st, const Pieces2& in, 
     if (t == 0) acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, NoEpi(), NoEpi(), rload);
     else acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, NoEpi(), [&](int s) { ep.b(t - 1, s); }, rload);
     ep.prev = acc; ep.r = rcur;
+    // in flight across the barrier: the 2 r loads (t < 7) and the zbuf stores of tile t-1's epilogue (2, with GP 4)
+    constexpr int kSt = GP ? 4 : 2;
     if (t == 0) st.advance_keep<2>();
-    else if (t < 7) st.advance_keep<4>();
-    else st.advance_keep<2>();
+    else if (t < 7) st.advance_keep<2 + kSt>();
+    else st.advance_keep<kSt>();
   }
   ep.all(7);
   ps.next();
 }
 
+template <bool GP>
 __global__ __launch_bounds__(kThreads, 1) void rgb_bwd_h2_kernel(RgbBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Stream st;
@@ -96,6 +104,8 @@ __global__ __launch_bounds__(kThreads, 1) void rgb_bwd_h2_kernel(RgbBwdArgs a) {
   const size_t LS = block_stride();                    // rbuf, zbuf: [block][wave tile]
   const float* rb = a.rbuf + (size_t)wtile * kBlockF;
   float* zb = a.zbuf + (size_t)wtile * kBlockF;
+  const size_t T = (size_t)gridDim.x * kWaves;
+  auto zrec = [&](int l) { return record_ptr(a.zbuf, 5, T, l, wtile); };
 
   st.prefetch<kW4TF4>();
   float dz[3];
@@ -110,9 +120,9 @@ __global__ __launch_bounds__(kThreads, 1) void rgb_bwd_h2_kernel(RgbBwdArgs a) {
   PointScale ps;
   ps.start(m0, 0.0f);
   {  // zbar_4: rows 0..2 = elements 0..2 of k-step 0 of half 0; the rest of the block stays zero (caller zeroes once)
-    float v8[8] = {dz[0], dz[1], dz[2], 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    store_piece(zb + 4 * LS, 0, lane, hi8(v8, ps.s_in));
-    store_record(zb + 4 * LS, lane, ps.s_in, m0);
+    float v8[8] = {dz[0] * ps.s_in, dz[1] * ps.s_in, dz[2] * ps.s_in, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    store_grad8<GP>(zb + 4 * LS, 0, lane, v8);
+    store_record(zrec(4), lane, ps.s_in, m0);
   }
   st.advance();
   Pieces2 pa, pb;
@@ -122,7 +132,7 @@ __global__ __launch_bounds__(kThreads, 1) void rgb_bwd_h2_kernel(RgbBwdArgs a) {
     const f32x4* c = st.cur_buf();
     const float* r4 = rb + 3 * LS;
     float* z3 = zb + 3 * LS;
-    store_record(z3, lane, ps.s_out, 0.0f);
+    store_record(zrec(3), lane, ps.s_out, 0.0f);
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       TilePieces r;
@@ -135,17 +145,17 @@ __global__ __launch_bounds__(kThreads, 1) void rgb_bwd_h2_kernel(RgbBwdArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) { acc[i] = hi_at(r, i) > 0.0f ? acc[i] : 0.0f; ps.track(acc[i]); }
       split_tile_scaled(acc, t, pa, ps.s_out);
-      store_piece(z3, 2 * t, lane, pa.h[2 * t]);
-      store_piece(z3, 2 * t + 1, lane, pa.h[2 * t + 1]);
+      store_grad<GP>(z3, 2 * t, lane, pa.h[2 * t], pa.m[2 * t]);
+      store_grad<GP>(z3, 2 * t + 1, lane, pa.h[2 * t + 1], pa.m[2 * t + 1]);
     }
   }
   ps.next();
   st.advance();
   // layers 3..1
-  rgb_bwd_layer_h2(st, pa, pb, rb + 2 * LS, zb + 2 * LS, ps, lane);
-  rgb_bwd_layer_h2(st, pb, pa, rb + 1 * LS, zb + 1 * LS, ps, lane);
-  rgb_bwd_layer_h2(st, pa, pb, rb, zb, ps, lane);
-  // layer 0: the input gradients from zbar_0 (feature rows: tiles 0..7, extras: tile 8).  fbar is stored as a HALF block
+  rgb_bwd_layer_h2<GP>(st, pa, pb, rb + 2 * LS, zb + 2 * LS, zrec(2), ps, lane);
+  rgb_bwd_layer_h2<GP>(st, pb, pa, rb + 1 * LS, zb + 1 * LS, zrec(1), ps, lane);
+  rgb_bwd_layer_h2<GP>(st, pa, pb, rb, zb, zrec(0), ps, lane);
+  // layer 0: the input gradients from zbar_0 (feature rows: tiles 0..7, extras: tile 8).  fbar is stored as a scaled block
   // under the scale predicted from zbar_0's maximum (ps.s_out, as between any two layers); its record -- pass B takes
   // the scale and the maximum from it -- is written once the maximum is known
   float* fb = a.feat_bar + (size_t)wtile * kBlockF;
@@ -157,8 +167,8 @@ __global__ __launch_bounds__(kThreads, 1) void rgb_bwd_h2_kernel(RgbBwdArgs a) {
     auto slice = [&](int tp, int r) {
       const float v = prev[r] * ps.inv_in;
       fmax = __builtin_fmaxf(fmax, __builtin_fabsf(v));
-      v8[r & 7] = v;
-      if ((r & 7) == 7) store_piece(fb, 2 * tp + (r >> 3), lane, hi8(v8, s_f));
+      v8[r & 7] = v * s_f;
+      if ((r & 7) == 7) store_grad8<GP>(fb, 2 * tp + (r >> 3), lane, v8);
     };
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -175,7 +185,7 @@ __global__ __launch_bounds__(kThreads, 1) void rgb_bwd_h2_kernel(RgbBwdArgs a) {
     }
   }
   fmax = __builtin_fmaxf(fmax, __shfl_xor(fmax, 32));
-  store_record(fb, lane, s_f, fmax);
+  store_record(record_ptr(a.feat_bar, 1, T, 0, wtile), lane, s_f, fmax);
   publish_max(a.absmax + 1, ps.gmax);
   publish_max(a.absmax + 2, fmax);
 }
@@ -189,16 +199,51 @@ constexpr int kSpliceF = 20;     // floats per lane kept in LDS for the skip spl
 // g(h) = d sdf / d h is O(0.1 ... 10) -- the 2^11 of headroom above the point's u maximum then cover |g| up to ~2600
 constexpr float kA2Down = 1.0f / 128.0f;
 
-template <bool SPLIT>
+// GP: the side tiles of pass A (h_{l+1} and ghat_l, both pieces: 8 KiB per wave and tile) are staged through LDS instead of
+// registers -- with 32 + 32 registers of them in flight and in use the kernel spilled (436 bytes per lane of scratch).  A wave
+// owns two 8-KiB buffers behind the weight ring and the splice area; a tile's eight 1-KiB fragments arrive by LDS-DMA exactly
+// as they lie in memory (piece_slot order: lane L's 16 bytes of a fragment sit at slot piece_slot(s, L), so its ds_read_b128
+// is conflict-free), [h hi k0, h hi k1, h mid k0, h mid k1, g hi k0, g hi k1, g mid k0, g mid k1].  The DMA of tile t+1 is
+// issued at the END of tile t, behind the last read of the buffer it overwrites (tile t-1's epilogue has just finished with
+// it) and behind the tile's weight pieces, so the tile barrier's counted wait leaves it in flight; it has landed when tile
+// t+1's barrier has been passed, and tile t+2's MFMAs cover the epilogue that reads it.
+constexpr int kSideWave = 2 * 8192;                 // bytes of side staging per wave
+constexpr int kSideBytes = kWaves * kSideWave;      // 64 KiB per workgroup
+__device__ __forceinline__ void side_dma_frag(const float* g, unsigned lds_byte) {
+  // g, lds_byte: wave-uniform (made provably so: an "s" operand the compiler believes divergent lands in VGPRs).  Streaming
+  // read (nt): these blocks are read once.  (M0: see chunk_issue_piece, svs_mlp_dev.h)
+  const unsigned long long ga = (unsigned long long)g;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ga), hi = __builtin_amdgcn_readfirstlane((unsigned)(ga >> 32));
+  const unsigned long long gs = ((unsigned long long)hi << 32) | lo;
+  const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_byte);
+  const unsigned lane_bytes = (threadIdx.x & 63u) * 16u;
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt"
+               :: "v"(lane_bytes), "s"(gs), "s"(m0v) : "memory");
+}
+// the eight fragments of tile t of (hblk, gblk) -> the 8-KiB buffer at LDS byte address `buf`
+__device__ __forceinline__ void side_issue(const float* hblk, const float* gblk, int t, unsigned buf) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const float* blk = q < 4 ? hblk : gblk;
+    const int plane = (q >> 1) & 1, s = 2 * t + (q & 1);
+    side_dma_frag(blk + (size_t)(plane * kPlaneF4 + s * 64) * 4, buf + q * 1024);
+  }
+}
+
+template <bool SPLIT, bool GP>
 struct PassAEpi {
   f32x16 prev;
-  TilePieces h, g;    // hi pieces of the stored h_{l+1} tile (softplus' only) and of ghat_l
+  TilePieces h, g;    // the stored h_{l+1} tile (softplus' only) and ghat_l, hi pieces (GP = false: register path)
+  const unsigned char* side;   // GP: this wave's LDS buffer holding the tile's eight fragments
+  f16x8 sh, sm, sg, sq;        // GP: the fragments of the current half tile (h hi, h mid, ghat hi, ghat mid)
   float v, s1;
   float v8[8], w8[8];
   f16x8 a2p[2], up[2];
+  f16x8 a2q[2], uq[2];   // the mid pieces (GP)
   Pieces2* out;       // u_{l+1} as the next operand (SPLIT)
-  float* ublk;        // u_{l+1} block (HALF block: value * s_out)
-  float* a2blk;       // a2_l block (HALF block: value * s_out * kA2Down)
+  float* ublk;        // u_{l+1} block (scaled block: value * s_out)
+  float* a2blk;       // a2_l block (scaled block: value * s_out * kA2Down)
+  float* urec; float* a2rec;   // their records
   PointScale* ps;
   const float* splice;  // LDS: this lane's u_0 splice values, [kSpliceF][kThreads]
   float a2m;          // running max |a2|
@@ -206,18 +251,28 @@ struct PassAEpi {
   bool l3;            // layer 3: the skip connection carries u_0 into rows >= 217 of u_4, a2 is zero there
 
   __device__ __forceinline__ void begin() {      // the records of the two blocks this layer writes
-    store_record(ublk, lane, ps->s_out, 0.0f);
-    store_record(a2blk, lane, ps->s_out * kA2Down, 0.0f);
+    store_record(urec, lane, ps->s_out, 0.0f);
+    store_record(a2rec, lane, ps->s_out * kA2Down, 0.0f);
   }
   __device__ __forceinline__ void a(int r) {
     v = prev[r] * ps->inv_in;
-    s1 = dsoftplus_from_h(hi_at(h, r));
+    if (GP) {
+      if ((r & 7) == 0) {       // the half tile's fragments, from the staging buffer
+        const f32x4* f = reinterpret_cast<const f32x4*>(side) + piece_slot(r >> 3, lane);   // (k-step parity = r >> 3)
+        sh = as_h8(f[(0 + (r >> 3)) * 64]); sm = as_h8(f[(2 + (r >> 3)) * 64]);
+        sg = as_h8(f[(4 + (r >> 3)) * 64]); sq = as_h8(f[(6 + (r >> 3)) * 64]);
+      }
+      s1 = dsoftplus_from_h((float)sh[r & 7] + (float)sm[r & 7]);
+    } else {
+      s1 = dsoftplus_from_h(hi_at(h, r));
+    }
     pin(v); pin(s1);
   }
   template <bool LATE = false>     // LATE: the stores wait for store_slot() (behind the tile's LDS-DMA pieces)
   __device__ __forceinline__ void b(int tp, int r) {
     float u = v * s1;
-    float a2 = v * hi_at(g, r) * (100.0f * (1.0f - s1));     // g = ghat_l = g(h_{l+1}) s'(a_l); s'' = 100 s' (1 - s')
+    const float gv = GP ? (float)sg[r & 7] + (float)sq[r & 7] : hi_at(g, r);
+    float a2 = v * gv * (100.0f * (1.0f - s1));     // g = ghat_l = g(h_{l+1}) s'(a_l); s'' = 100 s' (1 - s')
     if (tp == 6 && r >= 12 && l3) {
       // local rows 25..31 of tile 6 (registers 13..15 of half 0, 12..15 of half 1) carry u_0[32..38]
       const bool sp = half == 1 || r >= 13;
@@ -233,25 +288,30 @@ struct PassAEpi {
     a2m = __builtin_fmaxf(a2m, __builtin_fabsf(a2));
     ps->track(u);
     v8[r & 7] = u * ps->s_out;
-    w8[r & 7] = a2;
+    w8[r & 7] = a2 * (ps->s_out * kA2Down);
     if ((r & 7) == 7) {
-      const int k = 2 * tp + (r >> 3);
+      const int k = 2 * tp + (r >> 3), q = r >> 3;
       if (SPLIT) {
         split8(v8, out->h[k], out->m[k]);
         pin(out->h[k], out->m[k]);
-        up[r >> 3] = out->h[k];
+        up[q] = out->h[k];
+        if (GP) uq[q] = out->m[k];
+      } else if (GP) {
+        split8(v8, up[q], uq[q]);
       } else {
-        up[r >> 3] = hi8(v8, 1.0f);
+        up[q] = hi8(v8, 1.0f);
       }
-      a2p[r >> 3] = hi8(w8, ps->s_out * kA2Down);
-      if (!LATE) { store_piece(ublk, k, lane, up[r >> 3]); store_piece(a2blk, k, lane, a2p[r >> 3]); }
+      if (GP) split8(w8, a2p[q], a2q[q]); else a2p[q] = hi8(w8, 1.0f);
+      if (!LATE) { store_grad<GP>(ublk, k, lane, up[q], uq[q]); store_grad<GP>(a2blk, k, lane, a2p[q], a2q[q]); }
     }
   }
-  // k-step s of the tile whose MFMAs cover this epilogue: the four stores of tile tp behind the last LDS-DMA piece
+  // k-step s of the tile whose MFMAs cover this epilogue: the four (GP: eight) stores of tile tp behind the last LDS-DMA piece
   __device__ __forceinline__ void store_slot(int tp, int s) {
-    if (s == 9) store_piece(ublk, 2 * tp, lane, up[0]);
-    if (s == 11) store_piece(a2blk, 2 * tp, lane, a2p[0]);
-    if (s == 15) { store_piece(ublk, 2 * tp + 1, lane, up[1]); store_piece(a2blk, 2 * tp + 1, lane, a2p[1]); }
+    if (s == 9) store_piece(ublk, 2 * tp, lane, up[0], 0);
+    if (GP && s == 10) store_piece(ublk, 2 * tp, lane, uq[0], 1);
+    if (s == 11) store_piece(a2blk, 2 * tp, lane, a2p[0], 0);
+    if (GP && s == 12) store_piece(a2blk, 2 * tp, lane, a2q[0], 1);
+    if (s == 15) { store_grad<GP>(ublk, 2 * tp + 1, lane, up[1], uq[1]); store_grad<GP>(a2blk, 2 * tp + 1, lane, a2p[1], a2q[1]); }
   }
   __device__ __forceinline__ void all(int tp) {
 #pragma unroll
@@ -264,20 +324,20 @@ struct PassAEpi {
 };
 
 // layer l >= 1 of pass A; hblk/gblk: blocks l of hbuf / gbuf.  LAST: no chunk follows the layer's last one.
-template <bool SPLIT, bool LAST>
-__device__ __forceinline__ void pass_a_layer_h2(Stream& st, const Pieces2& in, PassAEpi<SPLIT>& ep, const float* hblk,
+template <bool SPLIT, bool LAST, bool GP>
+__device__ __forceinline__ void pass_a_layer_h2(Stream& st, const Pieces2& in, PassAEpi<SPLIT, GP>& ep, const float* hblk,
                                                 const float* gblk, int lane) {
-  // Per tile: the side tiles h, ghat of tile t (two fragments each: their hi planes) are requested in front of it (their
-  // epilogue runs during tile t+1); the next chunk's LDS-DMA pieces go behind k-steps 0..8 (Stream::prefetch_step); the
-  // a2 / u stores of tile t-1's epilogue are issued in k-steps 9, 11, 15: younger than every piece, they stay in flight
-  // across the tile's barrier.
+  // Per tile: the side tiles h, ghat of tile t (two fragments each: their hi planes; four with GP) are requested in front
+  // of it (their epilogue runs during tile t+1); the next chunk's LDS-DMA pieces go behind k-steps 0..8
+  // (Stream::prefetch_step); the a2 / u stores of tile t-1's epilogue are issued in k-steps 9 .. 15: younger than every
+  // piece, they stay in flight across the tile's barrier.
   ep.begin();
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     if (t == 7 && ep.l3) break;
     TilePieces hload, gload;
-    load_tile_hi(hblk, t, lane, hload);
-    load_tile_hi(gblk, t, lane, gload);
+    load_tile_grad<GP>(hblk, t, lane, hload);
+    load_tile_grad<GP>(gblk, t, lane, gload);
     const bool fetch = !(LAST && t == 7);
     f32x16 acc;
     if (!fetch) acc = tile_mma_h2<16>(st.cur_buf(), in, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.b(t - 1, s); });
@@ -287,7 +347,7 @@ __device__ __forceinline__ void pass_a_layer_h2(Stream& st, const Pieces2& in, P
     ep.prev = acc; ep.h = hload; ep.g = gload;
     if (fetch) {
       if (t == 0) st.advance();
-      else st.advance_keep<4>();
+      else st.advance_keep<GP ? 8 : 4>();
     }
   }
   if (ep.l3) { ep.all(6); ep.splice_tile7(); }
@@ -295,6 +355,48 @@ __device__ __forceinline__ void pass_a_layer_h2(Stream& st, const Pieces2& in, P
   ep.ps->next();
 }
 
+// The same layer with the side tiles staged through LDS (GP = true, see side_issue()).  side_lds: LDS byte address of this
+// wave's two buffers; par: the buffer tile 0's fragments were sent to by the PREVIOUS layer's last tile (tile t of this layer
+// uses buffer (par + t) & 1); next_h / next_g: the next layer's blocks, whose tile 0 this layer's last tile requests (nullptr:
+// none).  Returns the next layer's par.
+template <bool SPLIT, bool LAST>
+__device__ __forceinline__ int pass_a_layer_gp(Stream& st, const Pieces2& in, PassAEpi<SPLIT, true>& ep, const float* hblk,
+                                               const float* gblk, const float* next_h, const float* next_g, unsigned side_lds,
+                                               const unsigned char* side_ptr, int par, int lane) {
+  // Per tile: the next chunk's LDS-DMA pieces behind k-steps 0..8; the eight a2 / u stores of tile t-1's epilogue in k-steps
+  // 9 .. 15; the eight side fragments of tile t+1 (or of the next layer's tile 0) at the end: 16 operations younger than
+  // every piece stay in flight across the tile's barrier.
+  ep.begin();
+  const int n_tiles = ep.l3 ? 7 : 8;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    if (t == 7 && ep.l3) break;
+    const bool fetch = !(LAST && t == 7);
+    ep.side = side_ptr + (((par + t - 1) & 1) << 13);           // tile t-1's fragments, read by this tile's epilogue slices
+    f32x16 acc;
+    if (!fetch) acc = tile_mma_h2<16>(st.cur_buf(), in, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.b(t - 1, s); });
+    else if (t == 0) acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, NoEpi(), NoEpi());
+    else acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, [&](int s) { ep.a(s); },
+                                            [&](int s) { ep.template b<true>(t - 1, s); ep.store_slot(t - 1, s); });
+    ep.prev = acc;
+    if (fetch) {
+      // (buffer (par + t + 1) & 1 = the one tile t-1's epilogue has just finished reading)
+      const unsigned nb = side_lds + (((par + t + 1) & 1) << 13);
+      if (t + 1 < n_tiles) side_issue(hblk, gblk, t + 1, nb);
+      else if (next_h) side_issue(next_h, next_g, 0, nb);
+      if (t == 0) st.advance_keep<8>();
+      else if (t + 1 < n_tiles || next_h) st.advance_keep<16>();
+      else st.advance_keep<8>();
+    }
+  }
+  ep.side = side_ptr + (((par + n_tiles - 1) & 1) << 13);
+  if (ep.l3) { ep.all(6); ep.splice_tile7(); }
+  else ep.all(7);
+  ep.ps->next();
+  return (par + n_tiles) & 1;
+}
+
+template <bool GP>
 __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_h2_kernel(SdfBwdAArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Stream st;
@@ -304,6 +406,10 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_h2_kernel(SdfBwdAArgs a
   const int wtile = blockIdx.x * kWaves + wave;
   const int p = wtile * kTilePts + (lane & 31);
   const int pc = p < a.src.P ? p : a.src.P - 1;
+  // GP: this wave's side-tile staging buffers (behind the weight ring and the splice area)
+  const unsigned char* side_ptr = smem + kLdsBytes + kSpliceF * kThreads * sizeof(float) +
+                                  __builtin_amdgcn_readfirstlane(wave) * kSideWave;
+  const unsigned side_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)side_ptr;
 
   st.prefetch<kChunk0F4>();
   PointScale ps;
@@ -313,6 +419,9 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_h2_kernel(SdfBwdAArgs a
   const float* gb = a.gbuf + (size_t)wtile * kBlockF;
   float* ub = a.ubuf + (size_t)wtile * kBlockF;
   float* a2 = a.a2buf + (size_t)wtile * kBlockF;
+  const size_t T = (size_t)gridDim.x * kWaves;
+  auto urec = [&](int l) { return record_ptr(a.ubuf, 9, T, l, wtile); };
+  auto a2rec = [&](int l) { return record_ptr(a.a2buf, 8, T, l, wtile); };
   {
     float x0, x1, x2;
     load_point(a.src, p, x0, x1, x2);
@@ -350,59 +459,77 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_h2_kernel(SdfBwdAArgs a
 #pragma unroll
     for (int q = 0; q < 40; ++q) us.v[q] = u0.v[q] * ps.s_in;
     split_pe(us, half, pa);
-    // u_0 (HALF block, scale s_in) and h_0 = PE (PAIR block) in PE order, as block fragments: k-steps 0..2 hold the 39
+    // u_0 (scaled block, scale s_in) and h_0 = PE (PAIR block) in PE order, as block fragments: k-steps 0..2 hold the 39
     // rows, the rest of both blocks stays zero (the caller zeroes them once): the B operands of the two products of dW_0
     float* pbk = a.pebuf + (size_t)wtile * kBlockF;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       f16x8 fh, fm;
       block_fragment<kPeDim>(u0.v, k, half, ps.s_in, fh, fm);
-      store_piece(ub, k, lane, fh);
+      store_grad<GP>(ub, k, lane, fh, fm);
       block_fragment<kPeDim>(pe.v, k, half, 1.0f, fh, fm);
-      store_piece(pbk, k, lane, fh, 0);          // (the weight gradient reads hi planes only)
+      store_grad<GP>(pbk, k, lane, fh, fm);      // (GP = false: the weight gradient reads hi planes only)
     }
-    store_record(ub, lane, ps.s_in, m0);
+    store_record(urec(0), lane, ps.s_in, m0);
   }
   st.advance();
 
   float a2m = 0.0f;
   {
     // ---- layer 0 (three k-steps per tile: the epilogue of tile t-1 follows tile t's MFMAs)
-    PassAEpi<true> ep;
-    ep.out = &pb; ep.ublk = ub + LS; ep.a2blk = a2; ep.ps = &ps; ep.splice = splice; ep.a2m = 0.0f;
-    ep.lane = lane; ep.half = half; ep.l3 = false;
+    PassAEpi<true, GP> ep;
+    ep.out = &pb; ep.ublk = ub + LS; ep.a2blk = a2; ep.urec = urec(1); ep.a2rec = a2rec(0); ep.ps = &ps; ep.splice = splice;
+    ep.a2m = 0.0f; ep.lane = lane; ep.half = half; ep.l3 = false;
     ep.begin();
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
+      // (layer 0's tiles are three k-steps long and their epilogues are not sliced: its side tiles come through
+      // registers in both formats; GP: copied into the staging buffer the epilogue reads)
       TilePieces hload, gload;
-      load_tile_hi(hb, t, lane, hload);
-      load_tile_hi(gb, t, lane, gload);
+      load_tile_grad<GP>(hb, t, lane, hload);
+      load_tile_grad<GP>(gb, t, lane, gload);
       if (t < 7) st.prefetch<kChunk0F4>(); else st.prefetch<kChunkF4>();
       const f32x16 acc = tile_mma_h2<3>(st.cur_buf(), pa, lane);
       if (t > 0) ep.all(t - 1);
       ep.prev = acc; ep.h = hload; ep.g = gload;
-      st.advance();
+      if (GP) {
+        f32x4* f = reinterpret_cast<f32x4*>(const_cast<unsigned char*>(side_ptr) + 8192);   // buffer 1 (buffer 0: layer 1's tile 0)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int sl = piece_slot(c, lane);
+          f[(0 + c) * 64 + sl] = as_f4(hload.h[c]); f[(2 + c) * 64 + sl] = as_f4(hload.m[c]);
+          f[(4 + c) * 64 + sl] = as_f4(gload.h[c]); f[(6 + c) * 64 + sl] = as_f4(gload.m[c]);
+        }
+        ep.side = side_ptr + 8192;
+        if (t == 7) side_issue(hb + LS, gb + LS, 0, side_lds);     // layer 1's tile 0 -> buffer 0, behind the layer's last pieces
+      }
+      if (GP && t == 7) st.advance_keep<8>(); else st.advance();
     }
     ep.all(7);
     ps.next();
     a2m = ep.a2m;
   }
   // ---- layers 1..6: pb -> pa, copied back (one code body for all layers)
+  int par = 0;
   for (int l = 1; l < 7; ++l) {
-    PassAEpi<true> ep;
-    ep.out = &pa; ep.ublk = ub + (size_t)(l + 1) * LS; ep.a2blk = a2 + (size_t)l * LS; ep.ps = &ps;
-    ep.splice = splice; ep.a2m = a2m; ep.lane = lane; ep.half = half; ep.l3 = l == 3;
-    pass_a_layer_h2<true, false>(st, pb, ep, hb + (size_t)l * LS, gb + (size_t)l * LS, lane);
+    PassAEpi<true, GP> ep;
+    ep.out = &pa; ep.ublk = ub + (size_t)(l + 1) * LS; ep.a2blk = a2 + (size_t)l * LS; ep.urec = urec(l + 1); ep.a2rec = a2rec(l);
+    ep.ps = &ps; ep.splice = splice; ep.a2m = a2m; ep.lane = lane; ep.half = half; ep.l3 = l == 3;
+    if constexpr (GP) par = pass_a_layer_gp<true, false>(st, pb, ep, hb + (size_t)l * LS, gb + (size_t)l * LS, hb + (size_t)(l + 1) * LS,
+                                                         gb + (size_t)(l + 1) * LS, side_lds, side_ptr, par, lane);
+    else pass_a_layer_h2<true, false, GP>(st, pb, ep, hb + (size_t)l * LS, gb + (size_t)l * LS, lane);
     a2m = ep.a2m;
 #pragma unroll
     for (int s = 0; s < 16; ++s) { pb.h[s] = pa.h[s]; pb.m[s] = pa.m[s]; }
   }
   // ---- layer 7: u_8 (only needed for the row-0 gradient of lin8) is stored, not split
   {
-    PassAEpi<false> ep;
-    ep.out = nullptr; ep.ublk = ub + (size_t)8 * LS; ep.a2blk = a2 + (size_t)7 * LS; ep.ps = &ps;
-    ep.splice = splice; ep.a2m = a2m; ep.lane = lane; ep.half = half; ep.l3 = false;
-    pass_a_layer_h2<false, true>(st, pb, ep, hb + (size_t)7 * LS, gb + (size_t)7 * LS, lane);
+    PassAEpi<false, GP> ep;
+    ep.out = nullptr; ep.ublk = ub + (size_t)8 * LS; ep.a2blk = a2 + (size_t)7 * LS; ep.urec = urec(8); ep.a2rec = a2rec(7);
+    ep.ps = &ps; ep.splice = splice; ep.a2m = a2m; ep.lane = lane; ep.half = half; ep.l3 = false;
+    if constexpr (GP) pass_a_layer_gp<false, true>(st, pb, ep, hb + (size_t)7 * LS, gb + (size_t)7 * LS, nullptr, nullptr, side_lds, side_ptr,
+                                                   par, lane);
+    else pass_a_layer_h2<false, true, GP>(st, pb, ep, hb + (size_t)7 * LS, gb + (size_t)7 * LS, lane);
     a2m = ep.a2m;
   }
   a2m = __builtin_fmaxf(a2m, __shfl_xor(a2m, 32));
@@ -414,29 +541,30 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_h2_kernel(SdfBwdAArgs a
 // SDF MLP backward, pass B: hbar_8 = sbar W_8[0,:] + W_8[1:,:]^T fbar;  abar_l = hbar_{l+1} s'(a_l) + a2_l;
 //                           hbar_l = W_l^T abar_l
 // ==============================================================================================================
-template <bool FIRST, bool SPLIT, typename Net = NetFg, bool A2 = true>
+template <bool FIRST, bool SPLIT, typename Net, bool A2, bool GP>
 struct PassBEpi {
   f32x16 prev;
-  TilePieces h, a2, w0;    // hi pieces: h_{l+1} (softplus' only), a2_l (value * a2_scale), ghat_7
+  TilePieces h, a2, w0;    // h_{l+1} (softplus' only), a2_l (value * a2_scale), ghat_7: both pieces with GP, else the hi pieces
   float v, s1;
   float v8[8];
-  f16x8 ap[2];
+  f16x8 ap[2], aq[2];      // the pieces of abar being stored (aq: mid, GP)
   Pieces2* out;
-  float* ablk;             // abar_l block (HALF block: value * s_out)
+  float* ablk;             // abar_l block (scaled block: value * s_out)
+  float* arec;             // its record
   PointScale* ps;
   float sbar, a2_inv;      // a2_inv: 1 / (scale the a2 block was stored under)
   int lane, half;
   bool l4;            // producing abar_3: rows >= 217 of h_4 are the PE splice
   __device__ __forceinline__ void a(int r) {
     v = prev[r] * ps->inv_in;
-    s1 = dsoftplus_from_h(hi_at(h, r));
+    s1 = dsoftplus_from_h(grad_at<GP>(h, r));
     pin(v); pin(s1);
   }
   template <bool LATE = false>
   __device__ __forceinline__ void b(int tp, int r) {
     float o = v * s1;
-    if (A2) o += hi_at(a2, r) * a2_inv;
-    if (FIRST) o += sbar * hi_at(w0, r);      // w0 = ghat_7 = W8[0,:] s'(a_7)
+    if (A2) o += grad_at<GP>(a2, r) * a2_inv;
+    if (FIRST) o += sbar * grad_at<GP>(w0, r);      // w0 = ghat_7 = W8[0,:] s'(a_7)
     if (l4 && tp > Net::kSpliceTile) o = 0.0f;
     if (l4 && tp == Net::kSpliceTile) {
       const bool z0 = rho(r) >= Net::kSpliceLocal, z1 = rho(r) + 4 >= Net::kSpliceLocal;
@@ -446,20 +574,23 @@ struct PassBEpi {
     ps->track(o);
     v8[r & 7] = o * ps->s_out;
     if ((r & 7) == 7) {
-      const int k = 2 * tp + (r >> 3);
+      const int k = 2 * tp + (r >> 3), q = r >> 3;
       if (SPLIT) {
         split8(v8, out->h[k], out->m[k]);
         pin(out->h[k], out->m[k]);
-        ap[r >> 3] = out->h[k];
+        ap[q] = out->h[k];
+        if (GP) aq[q] = out->m[k];
+      } else if (GP) {
+        split8(v8, ap[q], aq[q]);
       } else {
-        ap[r >> 3] = hi8(v8, 1.0f);
+        ap[q] = hi8(v8, 1.0f);
       }
-      if (!LATE) store_piece(ablk, k, lane, ap[r >> 3]);
+      if (!LATE) store_grad<GP>(ablk, k, lane, ap[q], aq[q]);
     }
   }
   __device__ __forceinline__ void store_slot(int tp, int s) {     // behind the tile's LDS-DMA pieces
-    if (s == 9) store_piece(ablk, 2 * tp, lane, ap[0]);
-    if (s == 15) store_piece(ablk, 2 * tp + 1, lane, ap[1]);
+    if (s == 9) store_grad<GP>(ablk, 2 * tp, lane, ap[0], aq[0]);
+    if (s == 15) store_grad<GP>(ablk, 2 * tp + 1, lane, ap[1], aq[1]);
   }
   __device__ __forceinline__ void all(int tp) {
 #pragma unroll
@@ -468,20 +599,22 @@ struct PassBEpi {
 };
 
 // one stage of pass B: in -> (W^T in) fused with abar of block `blk` (h, a2 from blocks blk; FIRST: + sbar W8[0,:])
-template <bool FIRST, bool SPLIT, bool LAST_STAGE, typename Net = NetFg, bool A2 = true>
-__device__ __forceinline__ void pass_b_stage_h2(Stream& st, const Pieces2& in, PassBEpi<FIRST, SPLIT, Net, A2>& ep, const float* hblk,
-                                                const float* a2blk, const float* w0blk, int lane) {
+template <bool FIRST, bool SPLIT, bool LAST_STAGE, typename Net, bool A2, bool GP>
+__device__ __forceinline__ void pass_b_stage_h2(Stream& st, const Pieces2& in, PassBEpi<FIRST, SPLIT, Net, A2, GP>& ep, const float* hblk,
+                                                const float* a2blk, const float* a2rec, const float* w0blk, int lane) {
   // Per tile: the next chunk's LDS-DMA pieces behind k-steps 0..8 (Stream::prefetch_step), then -- younger than every
-  // piece, left in flight across the tile's barrier -- the 2 abuf stores of tile t-1's epilogue (k-steps 9, 15) and the
-  // loads of the side tiles (hi planes: two fragments each) h, a2 (FIRST: and ghat_7) of tile t+1, which the epilogue of
-  // tile t+1 consumes during tile t+2.
-  store_record(ep.ablk, lane, ep.ps->s_out, 0.0f);
-  ep.a2_inv = A2 ? PointScale::inv_pow2(load_scale(a2blk, lane)) : 0.0f;
+  // piece, left in flight across the tile's barrier -- the 2 abuf stores of tile t-1's epilogue (k-steps 9, 15; 4 with GP)
+  // and the loads of the side tiles (hi planes: two fragments each; with GP both planes: four) h, a2 (FIRST: and ghat_7)
+  // of tile t+1, which the epilogue of tile t+1 consumes during tile t+2.
+  store_record(ep.arec, lane, ep.ps->s_out, 0.0f);
+  ep.a2_inv = A2 ? PointScale::inv_pow2(load_scale(a2rec, lane)) : 0.0f;
   TilePieces hnext, anext, wnext;
-  load_tile_hi(hblk, 0, lane, hnext);
-  if (A2) load_tile_hi(a2blk, 0, lane, anext);
-  if (FIRST) load_tile_hi(w0blk, 0, lane, wnext);
-  constexpr int kLoads = 2 + (A2 ? 2 : 0) + (FIRST ? 2 : 0);
+  load_tile_grad<GP>(hblk, 0, lane, hnext);
+  if (A2) load_tile_grad<GP>(a2blk, 0, lane, anext);
+  if (FIRST) load_tile_grad<GP>(w0blk, 0, lane, wnext);
+  constexpr int kPer = GP ? 4 : 2;
+  constexpr int kLoads = kPer * (1 + (A2 ? 1 : 0) + (FIRST ? 1 : 0));
+  constexpr int kStores = GP ? 4 : 2;
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     const TilePieces hcur = hnext, acur = anext, wcur = wnext;
@@ -493,6 +626,14 @@ __device__ __forceinline__ void pass_b_stage_h2(Stream& st, const Pieces2& in, P
       if (A2 && s == 13) anext.h[1] = load_piece(a2blk, 2 * (t + 1) + 1, lane);
       if (FIRST && s == 14) wnext.h[0] = load_piece(w0blk, 2 * (t + 1), lane);
       if (FIRST && s == 15) wnext.h[1] = load_piece(w0blk, 2 * (t + 1) + 1, lane);
+      if (GP) {      // the mid planes, in the same gaps
+        if (s == 10) hnext.m[0] = load_piece(hblk, 2 * (t + 1), lane, 1);
+        if (s == 11) hnext.m[1] = load_piece(hblk, 2 * (t + 1) + 1, lane, 1);
+        if (A2 && s == 12) anext.m[0] = load_piece(a2blk, 2 * (t + 1), lane, 1);
+        if (A2 && s == 13) anext.m[1] = load_piece(a2blk, 2 * (t + 1) + 1, lane, 1);
+        if (FIRST && s == 14) wnext.m[0] = load_piece(w0blk, 2 * (t + 1), lane, 1);
+        if (FIRST && s == 15) wnext.m[1] = load_piece(w0blk, 2 * (t + 1) + 1, lane, 1);
+      }
     };
     const bool fetch = !(LAST_STAGE && t == 7);
     f32x16 acc;
@@ -505,15 +646,15 @@ __device__ __forceinline__ void pass_b_stage_h2(Stream& st, const Pieces2& in, P
     if (FIRST) ep.w0 = wcur;
     if (fetch) {
       if (t == 0) st.advance_keep<kLoads>();
-      else if (t < 7) st.advance_keep<kLoads + 2>();
-      else st.advance_keep<2>();
+      else if (t < 7) st.advance_keep<kLoads + kStores>();
+      else st.advance_keep<kStores>();
     }
   }
   ep.all(7);
   ep.ps->next();
 }
 
-template <typename Net, bool A2>
+template <typename Net, bool A2, bool GP>
 __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_h2_kernel(SdfBwdBArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Stream st;
@@ -531,18 +672,26 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_h2_kernel(SdfBwdBArgs a
   const float* w0 = a.w0 + (size_t)wtile * a.w0_stride;
   const float* a2 = A2 ? a.a2buf + (size_t)wtile * kBlockF : nullptr;
   float* ab = a.abuf + (size_t)wtile * kBlockF;
+  const size_t T = (size_t)gridDim.x * kWaves;
+  auto arec = [&](int l) { return record_ptr(a.abuf, 8, T, l, wtile); };
+  auto a2rec = [&](int l) { return A2 ? record_ptr(a.a2buf, 8, T, l, wtile) : nullptr; };
   const bool has_f = a.feat_bar && wtile < a.n_feat_tiles;
   PointScale ps;
   Pieces2 pa, pb;
   {
-    // fbar (a HALF block under its recorded scale) is the first operand as it stands; the scale floor covers the additive
+    // fbar (a scaled block under its recorded scale) is the first operand as it stands; the scale floor covers the additive
     // inputs a2 and sbar * W8[0,:]
     const float fl = __builtin_fmaxf(A2 ? a.a2max[p] : 0.0f, __builtin_fabsf(sbar));
     if (has_f) {
       const float* fb = a.feat_bar + (size_t)wtile * kBlockF;
+      // (feat_bar belongs to the launch over the ray samples only: its tile count is n_feat_tiles padded to workgroups)
+      const float* frec = record_ptr(a.feat_bar, 1, (size_t)((a.n_feat_tiles + kWaves - 1) / kWaves * kWaves), 0, wtile);
 #pragma unroll
-      for (int k = 0; k < 16; ++k) { pa.h[k] = load_piece(fb, k, lane); pa.m[k] = (f16x8)(_Float16)0.0f; }
-      ps.start_stored(load_scale(fb, lane), load_max(fb, lane), fl);
+      for (int k = 0; k < 16; ++k) {
+        pa.h[k] = load_piece(fb, k, lane);
+        pa.m[k] = GP ? load_piece(fb, k, lane, 1) : (f16x8)(_Float16)0.0f;
+      }
+      ps.start_stored(load_scale(frec, lane), load_max(frec, lane), fl);
     } else {
 #pragma unroll
       for (int k = 0; k < 16; ++k) { pa.h[k] = (f16x8)(_Float16)0.0f; pa.m[k] = (f16x8)(_Float16)0.0f; }
@@ -552,32 +701,35 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_h2_kernel(SdfBwdBArgs a
   }
   st.advance();
   {
-    // hbar_8 fused with abar_7 (gbuf block 7 = ghat_7 = W8[0,:] s'(a_7), a half block)
-    PassBEpi<true, true, Net, A2> ep;
-    ep.out = &pb; ep.ablk = ab + 7 * LS; ep.ps = &ps; ep.sbar = sbar; ep.lane = lane; ep.half = half; ep.l4 = false;
-    pass_b_stage_h2<true, true, false, Net, A2>(st, pa, ep, hb + 7 * LS, A2 ? a2 + 7 * LS : nullptr, w0, lane);
+    // hbar_8 fused with abar_7 (gbuf block 7 = ghat_7 = W8[0,:] s'(a_7), stored unscaled)
+    PassBEpi<true, true, Net, A2, GP> ep;
+    ep.out = &pb; ep.ablk = ab + 7 * LS; ep.arec = arec(7); ep.ps = &ps; ep.sbar = sbar; ep.lane = lane; ep.half = half; ep.l4 = false;
+    pass_b_stage_h2<true, true, false, Net, A2, GP>(st, pa, ep, hb + 7 * LS, A2 ? a2 + 7 * LS : nullptr, a2rec(7), w0, lane);
   }
   // layers 7..2: in = abar_l (pb), out = abar_{l-1} (pa, copied back: one code body for all layers)
   for (int l = 7; l >= 2; --l) {
-    PassBEpi<false, true, Net, A2> ep;
-    ep.out = &pa; ep.ablk = ab + (size_t)(l - 1) * LS; ep.ps = &ps; ep.sbar = 0.0f; ep.lane = lane; ep.half = half; ep.l4 = l == 4;
-    pass_b_stage_h2<false, true, false, Net, A2>(st, pb, ep, hb + (size_t)(l - 1) * LS, A2 ? a2 + (size_t)(l - 1) * LS : nullptr, nullptr, lane);
+    PassBEpi<false, true, Net, A2, GP> ep;
+    ep.out = &pa; ep.ablk = ab + (size_t)(l - 1) * LS; ep.arec = arec(l - 1); ep.ps = &ps; ep.sbar = 0.0f; ep.lane = lane; ep.half = half;
+    ep.l4 = l == 4;
+    pass_b_stage_h2<false, true, false, Net, A2, GP>(st, pb, ep, hb + (size_t)(l - 1) * LS, A2 ? a2 + (size_t)(l - 1) * LS : nullptr,
+                                                     a2rec(l - 1), nullptr, lane);
 #pragma unroll
     for (int s = 0; s < 16; ++s) { pb.h[s] = pa.h[s]; pb.m[s] = pa.m[s]; }
   }
   {
     // layer 1: abar_1 (in pb) -> abar_0, stored only
-    PassBEpi<false, false, Net, A2> ep;
-    ep.out = nullptr; ep.ablk = ab; ep.ps = &ps; ep.sbar = 0.0f; ep.lane = lane; ep.half = half; ep.l4 = false;
-    pass_b_stage_h2<false, false, true, Net, A2>(st, pb, ep, hb, a2, nullptr, lane);
+    PassBEpi<false, false, Net, A2, GP> ep;
+    ep.out = nullptr; ep.ablk = ab; ep.arec = arec(0); ep.ps = &ps; ep.sbar = 0.0f; ep.lane = lane; ep.half = half; ep.l4 = false;
+    pass_b_stage_h2<false, false, true, Net, A2, GP>(st, pb, ep, hb, a2, a2rec(0), nullptr, lane);
   }
   publish_max(a.absmax, ps.gmax);
 }
 
 // d loss / d W_8[0,:] = sum_p (sbar_p h_8[:,p] + u_8[:,p]);  d loss / d b_8[0] = sum_p sbar_p  (svs_mlp_bwd.hip) on the fp16x2
-// block forms: h_8 = pair block 7 of hbuf, u_8 = half block 8 of ubuf with its per-point scale.  Wave w of a workgroup
+// block forms: h_8 = pair block 7 of hbuf, u_8 = scaled block 8 of ubuf with its per-point scale (GP: both pieces).  Wave w of a workgroup
 // owns k-steps 4w..4w+3 (64 of the 256 rows), grid-strides over the tiles with the 12 loads of a tile in flight; the sum
 // over the 32 points of a lane half goes through LDS once per workgroup, then float atomics into out[257].
+template <bool GP>
 __global__ __launch_bounds__(256) void lin8_row0_h2_kernel(const float* __restrict__ hbuf, const float* __restrict__ ubuf,
                                                            const float* __restrict__ sbar, int n_tiles, int n_tiles_pad, int P,
                                                            float* __restrict__ out) {
@@ -591,23 +743,27 @@ __global__ __launch_bounds__(256) void lin8_row0_h2_kernel(const float* __restri
     const int p = t * 32 + (lane & 31);
     const float sb = p < P ? sbar[p] : 0.0f;
     const float* h = hbuf + ((size_t)7 * n_tiles_pad + t) * kBlockF;
-    f16x8 hh[4], hm[4], uh[4];
+    f16x8 hh[4], hm[4], uh[4], um[4];
     float us = 0.0f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { hh[k] = load_piece(h, 4 * quarter + k, lane, 0); hm[k] = load_piece(h, 4 * quarter + k, lane, 1); }
     if (ubuf) {
       const float* u = ubuf + ((size_t)8 * n_tiles_pad + t) * kBlockF;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) uh[k] = load_piece(u, 4 * quarter + k, lane);
-      us = p < P ? PointScale::inv_pow2(load_scale(u, lane)) : 0.0f;
+      for (int k = 0; k < 4; ++k) {
+        uh[k] = load_piece(u, 4 * quarter + k, lane);
+        um[k] = GP ? load_piece(u, 4 * quarter + k, lane, 1) : (f16x8)(_Float16)0.0f;
+      }
+      us = p < P ? PointScale::inv_pow2(load_scale(record_ptr(ubuf, 9, (size_t)n_tiles_pad, 8, t), lane)) : 0.0f;
     } else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) uh[k] = (f16x8)(_Float16)0.0f;
+      for (int k = 0; k < 4; ++k) { uh[k] = (f16x8)(_Float16)0.0f; um[k] = (f16x8)(_Float16)0.0f; }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[8 * k + j] += sb * ((float)hh[k][j] + (float)hm[k][j]) + us * (float)uh[k][j];
+      for (int j = 0; j < 8; ++j)
+        acc[8 * k + j] += sb * ((float)hh[k][j] + (float)hm[k][j]) + us * ((float)uh[k][j] + (float)um[k][j]);
     if (quarter == 0 && lane < 32) bsum += sb;
   }
 #pragma unroll
@@ -629,36 +785,49 @@ __global__ __launch_bounds__(256) void lin8_row0_h2_kernel(const float* __restri
 }
 
 int launch_lin8_row0_h2(const float* hbuf, const float* ubuf, const float* sbar, int n_points, int n_tiles_pad, float* out257,
-                        hipStream_t s) {
+                        bool gp, hipStream_t s) {
   const int n_tiles = (n_points + 31) / 32;
   const int grid = n_tiles < 1024 ? n_tiles : 1024;
-  lin8_row0_h2_kernel<<<grid, 256, 0, s>>>(hbuf, ubuf, sbar, n_tiles, n_tiles_pad, n_points, out257);
+  if (gp) lin8_row0_h2_kernel<true><<<grid, 256, 0, s>>>(hbuf, ubuf, sbar, n_tiles, n_tiles_pad, n_points, out257);
+  else lin8_row0_h2_kernel<false><<<grid, 256, 0, s>>>(hbuf, ubuf, sbar, n_tiles, n_tiles_pad, n_points, out257);
   return check_launch("svs_lin8_row0_grad");
 }
 
-int launch_rgb_bwd_h2(const RgbBwdArgs& a, hipStream_t s) {
-  static int once = set_lds(rgb_bwd_h2_kernel, kLdsBytes, "svs_rgb_bwd");
+int launch_rgb_bwd_h2(const RgbBwdArgs& a, bool gp, hipStream_t s) {
+  static int once = set_lds(rgb_bwd_h2_kernel<true>, kLdsBytes, "svs_rgb_bwd") | set_lds(rgb_bwd_h2_kernel<false>, kLdsBytes, "svs_rgb_bwd");
   if (once) return once;
-  rgb_bwd_h2_kernel<<<(a.P + kWgPts - 1) / kWgPts, kThreads, kLdsBytes, s>>>(a);
+  const int grid = (a.P + kWgPts - 1) / kWgPts;
+  if (gp) rgb_bwd_h2_kernel<true><<<grid, kThreads, kLdsBytes, s>>>(a);
+  else rgb_bwd_h2_kernel<false><<<grid, kThreads, kLdsBytes, s>>>(a);
   return check_launch("svs_rgb_bwd");
 }
-int launch_sdf_bwd_a_h2(const SdfBwdAArgs& a, hipStream_t s) {
+int launch_sdf_bwd_a_h2(const SdfBwdAArgs& a, bool gp, hipStream_t s) {
   constexpr int lds = kLdsBytes + kSpliceF * kThreads * (int)sizeof(float);
-  static int once = set_lds(sdf_bwd_a_h2_kernel, lds, "svs_sdf_bwd_a");
+  constexpr int lds_gp = lds + kSideBytes;       // + the side-tile staging buffers
+  static_assert(lds_gp <= 160 * 1024, "pass A: LDS budget");
+  static int once = set_lds(sdf_bwd_a_h2_kernel<true>, lds_gp, "svs_sdf_bwd_a") | set_lds(sdf_bwd_a_h2_kernel<false>, lds, "svs_sdf_bwd_a");
   if (once) return once;
-  sdf_bwd_a_h2_kernel<<<(a.src.P + kWgPts - 1) / kWgPts, kThreads, lds, s>>>(a);
+  const int grid = (a.src.P + kWgPts - 1) / kWgPts;
+  if (gp) sdf_bwd_a_h2_kernel<true><<<grid, kThreads, lds_gp, s>>>(a);
+  else sdf_bwd_a_h2_kernel<false><<<grid, kThreads, lds, s>>>(a);
   return check_launch("svs_sdf_bwd_a");
 }
-int launch_sdf_bwd_b_h2(const SdfBwdBArgs& a, hipStream_t s) {
-  static int once = set_lds(sdf_bwd_b_h2_kernel<NetFg, true>, kLdsBytes, "svs_sdf_bwd_b");
+int launch_sdf_bwd_b_h2(const SdfBwdBArgs& a, bool gp, hipStream_t s) {
+  static int once = set_lds(sdf_bwd_b_h2_kernel<NetFg, true, true>, kLdsBytes, "svs_sdf_bwd_b") |
+                    set_lds(sdf_bwd_b_h2_kernel<NetFg, true, false>, kLdsBytes, "svs_sdf_bwd_b");
   if (once) return once;
-  sdf_bwd_b_h2_kernel<NetFg, true><<<(a.P + kWgPts - 1) / kWgPts, kThreads, kLdsBytes, s>>>(a);
+  const int grid = (a.P + kWgPts - 1) / kWgPts;
+  if (gp) sdf_bwd_b_h2_kernel<NetFg, true, true><<<grid, kThreads, kLdsBytes, s>>>(a);
+  else sdf_bwd_b_h2_kernel<NetFg, true, false><<<grid, kThreads, kLdsBytes, s>>>(a);
   return check_launch("svs_sdf_bwd_b");
 }
-int launch_bg_bwd_b_h2(const SdfBwdBArgs& a, hipStream_t s) {
-  static int once = set_lds(sdf_bwd_b_h2_kernel<NetBg, false>, kLdsBytes, "svs_bg_sdf_bwd");
+int launch_bg_bwd_b_h2(const SdfBwdBArgs& a, bool gp, hipStream_t s) {
+  static int once = set_lds(sdf_bwd_b_h2_kernel<NetBg, false, true>, kLdsBytes, "svs_bg_sdf_bwd") |
+                    set_lds(sdf_bwd_b_h2_kernel<NetBg, false, false>, kLdsBytes, "svs_bg_sdf_bwd");
   if (once) return once;
-  sdf_bwd_b_h2_kernel<NetBg, false><<<(a.P + kWgPts - 1) / kWgPts, kThreads, kLdsBytes, s>>>(a);
+  const int grid = (a.P + kWgPts - 1) / kWgPts;
+  if (gp) sdf_bwd_b_h2_kernel<NetBg, false, true><<<grid, kThreads, kLdsBytes, s>>>(a);
+  else sdf_bwd_b_h2_kernel<NetBg, false, false><<<grid, kThreads, kLdsBytes, s>>>(a);
   return check_launch("svs_bg_sdf_bwd");
 }
 

@@ -70,14 +70,16 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_only_h2_kernel(SdfOnlyArgs a)
 // --------------------------------------------------------------------------------------------------------------
 // Epilogue of one tile of the gradient pass: ghat_{l-1} = g(a_{l-1}) = g(h_l) * softplus'(a_{l-1}) (softplus' from the
 // stored h_l tile `h`) -> gbuf (training), split into the next operand.
-template <bool GBUF>     // GBUF: training launch, ghat blocks are stored (compile-time: a run-time test put exec-mask
-struct RevEpi {           // branches into every tile and made hipcc's vmcnt bookkeeping take the minimum over both paths)
+// GBUF: training launch, ghat blocks are stored (compile-time: a run-time test put exec-mask branches into every tile and
+// made hipcc's vmcnt bookkeeping take the minimum over both paths); GP: as both pieces (svs_blocks_h2.h), else the hi piece
+template <bool GBUF, bool GP>
+struct RevEpi {
   f32x16 prev;
   TilePieces h;       // the stored h_l tile (pair block)
   float d;            // softplus' of the current slice
   float v8[8];
   Pieces2* out;
-  float* gblk;        // ghat_{l-1} block of gbuf (a HALF block, stored unscaled: record scale 1); GBUF only
+  float* gblk;        // ghat_{l-1} block of gbuf (stored unscaled, format GP); GBUF only
   int lane, half;
   bool l4;            // l == 4: rows >= 217 of h_4 are the PE splice, they do not flow into lin3
 
@@ -108,7 +110,7 @@ struct RevEpi {           // branches into every tile and made hipcc's vmcnt boo
       const int k = 2 * tp + (r >> 3);
       split8(v8, out->h[k], out->m[k]);
       pin(out->h[k], out->m[k]);
-      if (GBUF && !DEFER) store_piece(gblk, k, lane, out->h[k]);
+      if (GBUF && !DEFER) store_grad<GP>(gblk, k, lane, out->h[k], out->m[k]);
     }
   }
   template <bool STORE = false>
@@ -116,13 +118,15 @@ struct RevEpi {           // branches into every tile and made hipcc's vmcnt boo
     const int k = 2 * tp + 1;
     split8(v8, out->h[k], out->m[k]);
     pin(out->h[k], out->m[k]);
-    if (GBUF && STORE) store_piece(gblk, k, lane, out->h[k]);
+    if (GBUF && STORE) store_grad<GP>(gblk, k, lane, out->h[k], out->m[k]);
   }
-  // the gbuf stores issued during tile t (see TrunkEpi::late_store): the hi pieces of k-steps 2(t-1) and 2(t-2)+1
+  // the gbuf stores issued during tile t (see TrunkEpi::late_store): the pieces of k-steps 2(t-1) and 2(t-2)+1
   __device__ __forceinline__ void st(int t, int s) {
     if (!GBUF || (SVS_ABL & 256)) return;         // (256: diagnostic, no gbuf stores)
-    if (s == 9) store_piece(gblk, 2 * (t - 1), lane, out->h[2 * (t - 1)]);
-    if (t >= 2 && s == 11) store_piece(gblk, 2 * (t - 2) + 1, lane, out->h[2 * (t - 2) + 1]);
+    if (s == 9) store_piece(gblk, 2 * (t - 1), lane, out->h[2 * (t - 1)], 0);
+    if (t >= 2 && s == 11) store_piece(gblk, 2 * (t - 2) + 1, lane, out->h[2 * (t - 2) + 1], 0);
+    if (GP && s == 13) store_piece(gblk, 2 * (t - 1), lane, out->m[2 * (t - 1)], 1);
+    if (GP && t >= 2 && s == 14) store_piece(gblk, 2 * (t - 2) + 1, lane, out->m[2 * (t - 2) + 1], 1);
   }
   __device__ __forceinline__ void all(int tp) {
 #pragma unroll
@@ -131,10 +135,10 @@ struct RevEpi {           // branches into every tile and made hipcc's vmcnt boo
 };
 
 // reverse of trunk layer l (7..1): in = g(a_l) pieces, out = g(a_{l-1}) pieces
-template <bool GBUF>
+template <bool GBUF, bool GP>
 __device__ __forceinline__ void reverse_layer_h2(Stream& st, const Pieces2& in, Pieces2& out, int l, const float* hb,
                                                  float* gb, f32x16& skip6, f32x16& skip7, int lane, int half) {
-  RevEpi<GBUF> ep;
+  RevEpi<GBUF, GP> ep;
   ep.out = &out; ep.lane = lane; ep.half = half; ep.l4 = l == 4;
   const size_t LS = block_stride();
   ep.gblk = GBUF ? gb + (size_t)(l - 1) * LS : nullptr;
@@ -169,19 +173,22 @@ __device__ __forceinline__ void reverse_layer_h2(Stream& st, const Pieces2& in, 
     if (l == 4 && t == 6) skip6 = acc;
     ep.prev = acc;
     ep.h = hcur;
-    // in flight across the barrier: the 4 h loads (t < 7) and the gbuf stores (training: 1 in tile 1, then 2) of this tile
-    const int stores = !GBUF || t == 0 ? 0 : (t == 1 ? 1 : 2);
+    // in flight across the barrier: the 4 h loads (t < 7) and the gbuf stores (training: 1 in tile 1, then 2; twice that
+    // with GP) of this tile
+    constexpr int per = GP ? 2 : 1;
+    const int stores = !GBUF || t == 0 ? 0 : (t == 1 ? per : 2 * per);
     if (t < 7) {
-      if (stores == 0) st.advance_keep<4>(); else if (stores == 1) st.advance_keep<5>(); else st.advance_keep<6>();
+      if (stores == 0) st.advance_keep<4>(); else if (stores == 1) st.advance_keep<5>(); else if (stores == 2) st.advance_keep<6>();
+      else st.advance_keep<8>();
     } else {
-      if (stores == 0) st.advance(); else st.advance_keep<2>();
+      if (stores == 0) st.advance(); else if (stores == 2) st.advance_keep<2>(); else st.advance_keep<4>();
     }
   }
   ep.template finish<true>(6);
   ep.all(7);
 }
 
-template <bool GBUF>
+template <bool GBUF, bool GP>
 __global__ __launch_bounds__(kThreads, 1) void sdf_full_h2_kernel(SdfFullArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Stream st;
@@ -230,12 +237,12 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_h2_kernel(SdfFullArgs a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) g[4 * q + j] = w[j] * dsoftplus_from_h(y8[t][4 * q + j]);
       }
-      // ghat_7 = W8[0,:] * softplus'(a_7): a half block (unscaled).  (x already holds the pieces of h_8: the trunk's
-      // last layer split and stored them.)
+      // ghat_7 = W8[0,:] * softplus'(a_7), stored unscaled.  (x already holds the pieces of h_8: the trunk's last layer
+      // split and stored them.)
       split_tile(g, t, xn);
       if (GBUF) {
-        store_piece(gb + 7 * block_stride(), 2 * t, lane, xn.h[2 * t]);
-        store_piece(gb + 7 * block_stride(), 2 * t + 1, lane, xn.h[2 * t + 1]);
+        store_grad<GP>(gb + 7 * block_stride(), 2 * t, lane, xn.h[2 * t], xn.m[2 * t]);
+        store_grad<GP>(gb + 7 * block_stride(), 2 * t + 1, lane, xn.h[2 * t + 1], xn.m[2 * t + 1]);
       }
     }
     st.advance();
@@ -273,8 +280,8 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_h2_kernel(SdfFullArgs a)
   f32x16 skip7 = (f32x16)(0.0f);   // g(PE[0..31]) from the skip connection (tile 7 of g(h_4 spliced))
   f32x16 skip6 = (f32x16)(0.0f);   // tile 6; only local rows 25..31 are PE[32..38]
   for (int l = 7; l >= 1; l -= 2) {
-    reverse_layer_h2<GBUF>(st, xn, x, l, hb, gb, skip6, skip7, lane, half);
-    if (l > 1) reverse_layer_h2<GBUF>(st, x, xn, l - 1, hb, gb, skip6, skip7, lane, half);
+    reverse_layer_h2<GBUF, GP>(st, xn, x, l, hb, gb, skip6, skip7, lane, half);
+    if (l > 1) reverse_layer_h2<GBUF, GP>(st, x, xn, l - 1, hb, gb, skip6, skip7, lane, half);
   }
   SVS_STAMP(5, skip7[0])
   // ---- reverse layer 0: g(PE) = W0^T g(a_0) (+ skip), 2 tiles; g(a_0) is in x
@@ -341,11 +348,12 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_h2_kernel(SdfFullArgs a)
 // --------------------------------------------------------------------------------------------------------------
 // RenderingNetwork.forward, mode 'idr' (network.py:170-190)
 // --------------------------------------------------------------------------------------------------------------
+template <bool GP>      // GP: r_l is stored with both pieces (the weight gradient's three-product B operand), else its hi plane
 struct RgbEpi {
   f32x16 prev;
   float v8[8];
   Pieces2* out;
-  float* rblk;       // this layer's block of rbuf (the hi plane of a pair block) or nullptr
+  float* rblk;       // this layer's block of rbuf (a pair block; GP = false: its hi plane only) or nullptr
   int lane;
   __device__ __forceinline__ void b(int tp, int r) {
     float v;
@@ -356,11 +364,12 @@ struct RgbEpi {
       split8(v8, out->h[2 * tp + (r >> 3)], out->m[2 * tp + (r >> 3)]);
       pin(out->h[2 * tp + (r >> 3)], out->m[2 * tp + (r >> 3)]);
     }
-    // r_l is read back by the backward's ReLU mask and as the weight gradient's B operand, both from the hi plane: only
-    // that is stored, behind the LDS-DMA pieces (k-steps 0..9): k-steps 11 and 15
+    // r_l is read back by the backward's ReLU mask (hi plane) and as the weight gradient's B operand (GP: both planes);
+    // stored behind the LDS-DMA pieces (k-steps 0..9): k-steps 11 .. 15
     if (rblk) {
       if (r == 11) store_piece(rblk, 2 * tp, lane, out->h[2 * tp], 0);
-      if (r == 15) store_piece(rblk, 2 * tp + 1, lane, out->h[2 * tp + 1], 0);
+      if (GP && r == 13) store_piece(rblk, 2 * tp, lane, out->m[2 * tp], 1);
+      if (r == 15) store_grad<GP>(rblk, 2 * tp + 1, lane, out->h[2 * tp + 1], out->m[2 * tp + 1]);
     }
   }
   __device__ __forceinline__ void all(int tp) {
@@ -372,9 +381,9 @@ struct RgbEpi {
 // One radiance layer.  The next chunk (N16NEXT_LAST float4 behind the layer's last tile) is fetched in pieces behind the
 // first k-steps of each tile (Stream::prefetch_step: 9 or 10 pieces, k-steps 0..9); the rbuf stores of tile t-1's
 // epilogue are issued in k-steps 11, 15: younger than every piece, they may stay in flight.
-template <int KS, int N16NEXT_LAST>
+template <int KS, int N16NEXT_LAST, bool GP>
 __device__ __forceinline__ void rgb_layer_h2(RgbStream& st, const Pieces2& in, Pieces2& out, float* rblk, int lane) {
-  RgbEpi ep;
+  RgbEpi<GP> ep;
   ep.out = &out; ep.rblk = rblk; ep.lane = lane;
   constexpr int kNext = KS == 17 ? kRgbChunk0F4 : kChunkF4;
 #pragma unroll
@@ -385,12 +394,13 @@ __device__ __forceinline__ void rgb_layer_h2(RgbStream& st, const Pieces2& in, P
     else if (t < 7) acc = tile_mma_h2_pf<KS, kNext>(st, in, lane, NoEpi(), relu);
     else acc = tile_mma_h2_pf<KS, N16NEXT_LAST>(st, in, lane, NoEpi(), relu);
     ep.prev = acc;
-    if (rblk && t > 0) st.template advance_keep<2>();
+    if (rblk && t > 0) st.template advance_keep<GP ? 4 : 2>();
     else st.advance();
   }
   ep.all(7);
 }
 
+template <bool GP>
 __global__ __launch_bounds__(kThreads, 1) void rgb_h2_kernel(RgbArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   RgbStream st;
@@ -432,10 +442,10 @@ __global__ __launch_bounds__(kThreads, 1) void rgb_h2_kernel(RgbArgs a) {
   st.advance();
 
   // ---- layer 0: 271 -> 256; layers 1..3; every output r_l (post-ReLU) optionally kept in rbuf
-  rgb_layer_h2<17, kChunkF4>(st, x, xn, rb, lane);
-  rgb_layer_h2<16, kChunkF4>(st, xn, x, rb ? rb + 1 * LS : nullptr, lane);
-  rgb_layer_h2<16, kChunkF4>(st, x, xn, rb ? rb + 2 * LS : nullptr, lane);
-  rgb_layer_h2<16, kChunkF4>(st, xn, x, rb ? rb + 3 * LS : nullptr, lane);   // prefetches lin4's chunk
+  rgb_layer_h2<17, kChunkF4, GP>(st, x, xn, rb, lane);
+  rgb_layer_h2<16, kChunkF4, GP>(st, xn, x, rb ? rb + 1 * LS : nullptr, lane);
+  rgb_layer_h2<16, kChunkF4, GP>(st, x, xn, rb ? rb + 2 * LS : nullptr, lane);
+  rgb_layer_h2<16, kChunkF4, GP>(st, xn, x, rb ? rb + 3 * LS : nullptr, lane);   // prefetches lin4's chunk
   // ---- layer 4: 256 -> 3 as one tile (rows 0..2 live in registers 0..2 of lanes 0..31), sigmoid
   const f32x16 acc = tile_mma_h2<16>(st.cur_buf(), x, lane);
   if (half == 0 && p < a.src.P) {
@@ -460,21 +470,24 @@ int launch_sdf_only_h2(const SdfOnlyArgs& a, hipStream_t s) {
   sdf_only_h2_kernel<<<(a.src.P + kWgPts - 1) / kWgPts, kThreads, kLdsBytes + kLdsAbl, s>>>(a);
   return check_launch("svs_sdf_vals");
 }
-int launch_sdf_full_h2(const SdfFullArgs& a, hipStream_t s) {
-  static int once = set_lds(sdf_full_h2_kernel<true>, kLdsBytes + kLdsAbl, "svs_sdf_outputs");
+int launch_sdf_full_h2(const SdfFullArgs& a, bool grad_pair, hipStream_t s) {
+  static int once = set_lds(sdf_full_h2_kernel<true, true>, kLdsBytes + kLdsAbl, "svs_sdf_outputs") |
+                    set_lds(sdf_full_h2_kernel<true, false>, kLdsBytes + kLdsAbl, "svs_sdf_outputs") |
+                    set_lds(sdf_full_h2_kernel<false, false>, kLdsBytes + kLdsAbl, "svs_sdf_outputs");
   if (once) return once;
-  static int once2 = set_lds(sdf_full_h2_kernel<false>, kLdsBytes + kLdsAbl, "svs_sdf_outputs");
-  if (once2) return once2;
   const int grid = (a.src.P + kWgPts - 1) / kWgPts;
-  if (a.gbuf) sdf_full_h2_kernel<true><<<grid, kThreads, kLdsBytes + kLdsAbl, s>>>(a);     // training: ghat blocks stored
-  else sdf_full_h2_kernel<false><<<grid, kThreads, kLdsBytes + kLdsAbl, s>>>(a);
+  if (!a.gbuf) sdf_full_h2_kernel<false, false><<<grid, kThreads, kLdsBytes + kLdsAbl, s>>>(a);
+  else if (grad_pair) sdf_full_h2_kernel<true, true><<<grid, kThreads, kLdsBytes + kLdsAbl, s>>>(a);     // training: ghat blocks stored
+  else sdf_full_h2_kernel<true, false><<<grid, kThreads, kLdsBytes + kLdsAbl, s>>>(a);
   return check_launch("svs_sdf_outputs");
 }
-int launch_rgb_h2(const RgbArgs& a, hipStream_t s) {
+int launch_rgb_h2(const RgbArgs& a, bool grad_pair, hipStream_t s) {
   constexpr int lds = 2 * kRgbBufF4 * 16;
-  static int once = set_lds(rgb_h2_kernel, lds, "svs_rgb_eval");
+  static int once = set_lds(rgb_h2_kernel<true>, lds, "svs_rgb_eval") | set_lds(rgb_h2_kernel<false>, lds, "svs_rgb_eval");
   if (once) return once;
-  rgb_h2_kernel<<<(a.src.P + kWgPts - 1) / kWgPts, kThreads, lds, s>>>(a);
+  const int grid = (a.src.P + kWgPts - 1) / kWgPts;
+  if (grad_pair && a.rbuf) rgb_h2_kernel<true><<<grid, kThreads, lds, s>>>(a);
+  else rgb_h2_kernel<false><<<grid, kThreads, lds, s>>>(a);
   return check_launch("svs_rgb_eval");
 }
 }  // namespace mlp

@@ -54,6 +54,11 @@ constexpr int kNoBias = 0x100;            // flag: zero header
 //   kFmtF16x2 k-step = 16 input rows, per k-step 64 lanes x 8 fp16 of the hi piece, then of the mid piece
 //             (v_mfma_f32_32x32x16_f16, svs_mlp_h2_dev.h).  Same bytes per chunk as kFmtF32.
 enum BodyFormat { kFmtF32 = 0, kFmtF16x2 = 1 };
+// `precision` of the C-ABI: the two above, and kFmtF16x2Half = fp16x2 kernels whose gradient-only activation blocks are
+// stored as ONE fp16 piece (svs_blocks_h2.h, GP = false): half the backward's block bytes, parameter gradients 3e-4 ... 8e-4
+// of a tensor's largest entry off instead of < 1e-5.  Weight streams are packed identically for both fp16x2 values.
+constexpr int kFmtF16x2Half = 2;
+__host__ __device__ constexpr bool is_h2(int precision) { return precision == kFmtF16x2 || precision == kFmtF16x2Half; }
 
 __host__ __device__ constexpr int chunk_f4(int kind) {
   return kind == kSdfFwd0 ? kChunk0F4

@@ -312,13 +312,14 @@ size_t svs_pack_workspace_bytes(void) { return 9 * kScaleStride * sizeof(float);
 int svs_pack_stream(int which, int precision, const float* const* weight_v, const float* const* weight_g,
                     const float* const* bias, float* workspace, float* stream_out, void* hip_stream) {
   if (which < 0 || which >= kNumStreams || !weight_v || !bias || !workspace || !stream_out ||
-      (precision != kFmtF32 && precision != kFmtF16x2)) {
+      (precision != kFmtF32 && !is_h2(precision))) {
     set_error("svs_pack_stream: bad argument"); return SVS_EINVAL;
   }
   const bool is_rgb = which == kStreamRgbFwd || which == kStreamRgbBwd || which == kStreamBgRgbFwd || which == kStreamBgRgbBwd;
   const int net = stream_is_bg(which) ? 1 : 0;
   const int nl = is_rgb ? (net ? 2 : 5) : 9;
-  if (net && precision != kFmtF16x2) { set_error("svs_pack_stream: the background networks are fp16x2 only"); return SVS_EINVAL; }
+  if (net && !is_h2(precision)) { set_error("svs_pack_stream: the background networks are fp16x2 only"); return SVS_EINVAL; }
+  if (is_h2(precision)) precision = kFmtF16x2;     // one body encoding for both fp16x2 block formats
   LayerPtrs w = {};
   for (int l = 0; l < nl; ++l) {
     w.v[l] = weight_v[l]; w.g[l] = weight_g ? weight_g[l] : nullptr; w.b[l] = bias[l];

@@ -66,6 +66,47 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// ---- float64 helpers of the compositing BACKWARD kernels.  The forward kernels follow the bit-exact float32 contract of
+// the sampler; their reverse passes have no such contract (the reference gets these gradients from float32 autograd) and
+// d loss / d beta is a sum with 1 / beta^3 factors and heavy cancellation: in float32 it was 4e-4 off float64 autograd at
+// beta = 0.005.  Everything between the float32 inputs and the float32 outputs of the reverse passes is therefore double.
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+__device__ __forceinline__ double dexp(double x) { return x < -745.0 ? 0.0 : exp(x); }
+// out[j] = sum_{i <= j} in[i] (in place allowed); returns the total
+__device__ __forceinline__ double wave_cumsum_incl(const double* in, double* out, int m, int lane) {
+  const int c = (m + 63) >> 6;
+  const int lo = lane * c;
+  const int hi = (lo + c < m) ? lo + c : m;
+  double tot = 0.0;
+  for (int j = lo; j < hi; ++j) tot += in[j];
+  double scan = tot;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const double o = __shfl_up(scan, d);
+    if (lane >= d) scan += o;
+  }
+  double acc = scan - tot;
+  for (int j = lo; j < hi; ++j) { acc += in[j]; out[j] = acc; }
+  return __shfl(scan, 63);
+}
+// Laplace density and its derivatives in double (density.py:21-30)
+struct DensityD {
+  double sigma, dsig_dsdf, dsig_dbeta;
+  __device__ __forceinline__ DensityD(double s, double beta) {
+    const double as = s < 0.0 ? -s : s;
+    const double e = dexp(-as / beta);
+    const double sgn = s > 0.0 ? 1.0 : (s < 0.0 ? -1.0 : 0.0);
+    sigma = (1.0 / beta) * (0.5 + 0.5 * sgn * (e - 1.0));
+    // sign(0) = 0 in the reference's density: its gradient w.r.t. sdf vanishes there as well
+    dsig_dsdf = s != 0.0 ? -0.5 * e / (beta * beta) : 0.0;
+    dsig_dbeta = -sigma / beta + 0.5 * sgn * e * as / (beta * beta * beta);
+  }
+};
+
 struct CompositeArgs {
   int R, S;
   const float* z;            // (R,S)
@@ -139,68 +180,60 @@ struct CompositeBwdArgs {
 };
 
 __global__ __launch_bounds__(64) void composite_bwd_kernel(CompositeBwdArgs a) {
-  __shared__ float zs[kMaxS], fe[kMaxS], tr[kMaxS], dw[kMaxS], pre[kMaxS];
+  __shared__ double zs[kMaxS], fe[kMaxS], tr[kMaxS], dw[kMaxS], pre[kMaxS];
   const int r = blockIdx.x, lane = threadIdx.x, S = a.S;
-  const float beta = __builtin_fabsf(*a.beta_param) + a.beta_min;
-  for (int i = lane; i < S; i += 64) zs[i] = a.z[(size_t)r * S + i];
+  const double beta = (double)(__builtin_fabsf(*a.beta_param) + a.beta_min);
+  for (int i = lane; i < S; i += 64) zs[i] = (double)a.z[(size_t)r * S + i];
   __syncthreads();
   for (int i = lane; i < S; i += 64) {
-    const float dist = i < S - 1 ? zs[i + 1] - zs[i] : 1e10f;
-    fe[i] = dist * laplace_density(a.sdf[(size_t)r * S + i], beta);
+    const double dist = i < S - 1 ? (double)(float)(zs[i + 1] - zs[i]) : 1e10;      // (the forward's float32 distance)
+    fe[i] = dist * DensityD((double)a.sdf[(size_t)r * S + i], beta).sigma;
   }
   __syncthreads();
-  for (int i = lane; i < S; i += 64) tr[i] = i == 0 ? 0.0f : fe[i - 1];
+  wave_cumsum_incl(fe, tr, S, lane);           // tr[i] = sum_{j <= i} fe_j
   __syncthreads();
-  wave_cumsum_excl_out(tr, tr, S, lane);
-  __syncthreads();
-  float sw = 0.0f, swz = 0.0f;
+  double sw = 0.0, swz = 0.0;
   for (int i = lane; i < S; i += 64) {
-    const float T = det_exp(-tr[i]);
+    const double T = dexp(-(tr[i] - fe[i]));   // exp(-sum_{j < i} fe_j)
     tr[i] = T;
-    const float w = (1.0f - det_exp(-fe[i])) * T;
+    const double w = (1.0 - dexp(-fe[i])) * T;
     pre[i] = w;                         // weights, reused below
     sw += w; swz += w * zs[i];
   }
   sw = wave_sum(sw); swz = wave_sum(swz);
   __syncthreads();
-  const float ds = a.depth_scale[r];
-  const float g0 = a.d_rgb_values[3 * r], g1 = a.d_rgb_values[3 * r + 1], g2 = a.d_rgb_values[3 * r + 2];
-  const float gd = a.d_depth_values ? a.d_depth_values[r] * ds : 0.0f;
-  const float den = sw + 1e-8f;
+  const double ds = (double)a.depth_scale[r];
+  const double g0 = a.d_rgb_values[3 * r], g1 = a.d_rgb_values[3 * r + 1], g2 = a.d_rgb_values[3 * r + 2];
+  const double gd = a.d_depth_values ? (double)a.d_depth_values[r] * ds : 0.0;
+  const double den = sw + 1e-8;
   for (int i = lane; i < S; i += 64) {
     const size_t p = (size_t)r * S + i;
-    const float w = pre[i];
-    const float c0 = a.rgb[3 * p], c1 = a.rgb[3 * p + 1], c2 = a.rgb[3 * p + 2];
-    a.d_rgb[3 * p] = w * g0; a.d_rgb[3 * p + 1] = w * g1; a.d_rgb[3 * p + 2] = w * g2;
-    float d = (c0 * g0 + c1 * g1) + c2 * g2;
-    if (a.d_weights) d += a.d_weights[p];
+    const double w = pre[i];
+    const double c0 = a.rgb[3 * p], c1 = a.rgb[3 * p + 1], c2 = a.rgb[3 * p + 2];
+    a.d_rgb[3 * p] = (float)(w * g0); a.d_rgb[3 * p + 1] = (float)(w * g1); a.d_rgb[3 * p + 2] = (float)(w * g2);
+    double d = (c0 * g0 + c1 * g1) + c2 * g2;
+    if (a.d_weights) d += (double)a.d_weights[p];
     d += gd * (zs[i] * den - swz) / (den * den);
     dw[i] = d;
     pre[i] = d * w;                     // summand of the suffix sums
   }
   __syncthreads();
-  const float tot = wave_cumsum_excl_out(pre, pre, S, lane);   // inclusive prefix of dw_i * w_i
+  const double tot = wave_cumsum_incl(pre, pre, S, lane);   // inclusive prefix of dw_i * w_i
   __syncthreads();
-  float dbeta = 0.0f;
+  double dbeta = 0.0;
   for (int i = lane; i < S; i += 64) {
     const size_t p = (size_t)r * S + i;
-    const float suffix = tot - pre[i];                          // sum_{j>i} dw_j w_j
-    const float dfe = dw[i] * tr[i] * det_exp(-fe[i]) - suffix;
-    const float dist = i < S - 1 ? zs[i + 1] - zs[i] : 1e10f;
-    const float dsig = dfe * dist;
-    const float s = a.sdf[p];
-    const float as = __builtin_fabsf(s);
-    const float e = det_exp(-as / beta);
-    const float sgn = s > 0.0f ? 1.0f : (s < 0.0f ? -1.0f : 0.0f);
-    const float sigma = (1.0f / beta) * (0.5f + 0.5f * sgn * (e - 1.0f));
-    // sign(0) = 0 in the reference's density: its gradient w.r.t. sdf vanishes there as well
-    a.d_sdf[p] = (s != 0.0f) ? dsig * (-0.5f * e / (beta * beta)) : 0.0f;
-    const float dsig_dbeta = -sigma / beta + 0.5f * sgn * e * as / (beta * beta * beta);
+    const double suffix = tot - pre[i];                          // sum_{j>i} dw_j w_j
+    const double dfe = dw[i] * tr[i] * dexp(-fe[i]) - suffix;
+    const double dist = i < S - 1 ? (double)(float)(zs[i + 1] - zs[i]) : 1e10;
+    const double dsig = dfe * dist;
+    const DensityD dn((double)a.sdf[p], beta);
+    a.d_sdf[p] = (float)(dsig * dn.dsig_dsdf);
     // exp(-fe) underflows long before dist = 1e10 matters; guard the 0 * inf of the last sample
-    if (dfe != 0.0f) dbeta += dsig * dsig_dbeta;
+    if (dfe != 0.0) dbeta += dsig * dn.dsig_dbeta;
   }
   dbeta = wave_sum(dbeta);
-  if (lane == 0) a.d_beta_ray[r] = dbeta;
+  if (lane == 0) a.d_beta_ray[r] = (float)dbeta;
 }
 
 // d loss / d density.beta = sign(beta_param) * sum over rays (float64, fixed order -> reproducible)
@@ -602,73 +635,71 @@ struct CompositeBgBwdArgs {
 
 // backward of composite_bg_kernel with respect to sdf, rgb, beta, the bg density logits and the bg colours
 __global__ __launch_bounds__(64) void composite_bg_bwd_kernel(CompositeBgBwdArgs a) {
-  __shared__ float zs[kMaxS], fe[kMaxS], tr[kMaxS], dw[kMaxS], pre[kMaxS], bz[64], bfe[64], btr[64], bdw[64], bpre[64];
+  // (float64 throughout, see DensityD)
+  __shared__ double zs[kMaxS], fe[kMaxS], tr[kMaxS], dw[kMaxS], pre[kMaxS], bz[64], bfe[64], btr[64], bdw[64], bpre[64];
   const int r = blockIdx.x, lane = threadIdx.x, S = a.S, Nb = a.Nb;
-  const float beta = __builtin_fabsf(*a.beta_param) + a.beta_min;
-  for (int i = lane; i < S; i += 64) zs[i] = a.z[(size_t)r * S + i];
-  for (int i = lane; i < Nb; i += 64) bz[i] = a.z_bg[(size_t)r * Nb + i];
+  const double beta = (double)(__builtin_fabsf(*a.beta_param) + a.beta_min);
+  for (int i = lane; i < S; i += 64) zs[i] = (double)a.z[(size_t)r * S + i];
+  for (int i = lane; i < Nb; i += 64) bz[i] = (double)a.z_bg[(size_t)r * Nb + i];
   __syncthreads();
-  const float zmax = a.z_max[r];
-  for (int i = lane; i < S; i += 64) {
-    const float dist = i < S - 1 ? zs[i + 1] - zs[i] : zmax - zs[i];
-    fe[i] = dist * laplace_density(a.sdf[(size_t)r * S + i], beta);
-  }
+  const double zmax = (double)a.z_max[r];
+  auto fg_dist = [&](int i) { return (double)(float)((i < S - 1 ? zs[i + 1] : zmax) - zs[i]); };   // the forward's float32 distances
+  auto bg_dist = [&](int i) { return i < Nb - 1 ? (double)(float)(bz[i] - bz[i + 1]) : 1e10; };
+  for (int i = lane; i < S; i += 64) fe[i] = fg_dist(i) * DensityD((double)a.sdf[(size_t)r * S + i], beta).sigma;
   for (int i = lane; i < Nb; i += 64) {
-    const float dist = i < Nb - 1 ? bz[i] - bz[i + 1] : 1e10f;
-    bfe[i] = dist * __builtin_fabsf(a.bg_out0[(size_t)r * Nb + i]);
+    const double o = (double)a.bg_out0[(size_t)r * Nb + i];
+    bfe[i] = bg_dist(i) * (o < 0.0 ? -o : o);
   }
   __syncthreads();
-  for (int i = lane; i <= S; i += 64) tr[i] = i == 0 ? 0.0f : fe[i - 1];
-  for (int i = lane; i < Nb; i += 64) btr[i] = i == 0 ? 0.0f : bfe[i - 1];
+  const double fe_tot = wave_cumsum_incl(fe, tr, S, lane);     // tr[i] = sum_{j <= i} fe_j
   __syncthreads();
-  wave_cumsum_excl_out(tr, tr, S + 1, lane);
+  wave_cumsum_incl(bfe, btr, Nb, lane);
   __syncthreads();
-  wave_cumsum_excl_out(btr, btr, Nb, lane);
-  __syncthreads();
-  const float tbg = det_exp(-tr[S]);
-  const float ds = a.depth_scale[r];
-  const float g0 = a.d_rgb_values[3 * r], g1 = a.d_rgb_values[3 * r + 1], g2 = a.d_rgb_values[3 * r + 2];
+  const double tbg = dexp(-fe_tot);
+  const double ds = (double)a.depth_scale[r];
+  const double g0 = a.d_rgb_values[3 * r], g1 = a.d_rgb_values[3 * r + 1], g2 = a.d_rgb_values[3 * r + 2];
   // background: weights, colour sums, and the sums of depth_values_all = swd / (swa + 1e-8) over [w_fg, tbg * bw] with
   // depths ds * [z, bg_depth]
-  const float ga = a.d_depth_all ? a.d_depth_all[r] : 0.0f;
-  float bdot = 0.0f;       // sum_c g_c * sum_k bw_k cb_kc
-  float swa = 0.0f, swd = 0.0f;
+  const double ga = a.d_depth_all ? (double)a.d_depth_all[r] : 0.0;
+  double bdot = 0.0;       // sum_c g_c * sum_k bw_k cb_kc
+  double swa = 0.0, swd = 0.0;
   for (int i = lane; i < Nb; i += 64) {
     const size_t p = (size_t)r * Nb + i;
-    const float T = det_exp(-btr[i]);
+    const double T = dexp(-(btr[i] - bfe[i]));
     btr[i] = T;
-    const float bw = (1.0f - det_exp(-bfe[i])) * T;
-    const float c0 = a.bg_rgb[3 * p], c1 = a.bg_rgb[3 * p + 1], c2 = a.bg_rgb[3 * p + 2];
-    a.d_bg_rgb[3 * p] = (tbg * bw) * g0; a.d_bg_rgb[3 * p + 1] = (tbg * bw) * g1; a.d_bg_rgb[3 * p + 2] = (tbg * bw) * g2;
-    const float cg = (c0 * g0 + c1 * g1) + c2 * g2;
+    const double bw = (1.0 - dexp(-bfe[i])) * T;
+    const double c0 = a.bg_rgb[3 * p], c1 = a.bg_rgb[3 * p + 1], c2 = a.bg_rgb[3 * p + 2];
+    a.d_bg_rgb[3 * p] = (float)((tbg * bw) * g0); a.d_bg_rgb[3 * p + 1] = (float)((tbg * bw) * g1);
+    a.d_bg_rgb[3 * p + 2] = (float)((tbg * bw) * g2);
+    const double cg = (c0 * g0 + c1 * g1) + c2 * g2;
     bdot += bw * cg;
     bdw[i] = tbg * cg;                 // d loss / d bw_i (colour term; the depth term follows once the sums are known)
     bpre[i] = bw;
-    if (a.d_depth_all) { swa += tbg * bw; swd += (tbg * bw) * (ds * a.bg_depth[p]); }
+    if (a.d_depth_all) { swa += tbg * bw; swd += (tbg * bw) * (ds * (double)a.bg_depth[p]); }
   }
   bdot = wave_sum(bdot);
   // foreground: weights and their sums
-  float sw = 0.0f, swz = 0.0f;
+  double sw = 0.0, swz = 0.0;
   for (int i = lane; i < S; i += 64) {
-    const float T = det_exp(-tr[i]);
+    const double T = dexp(-(tr[i] - fe[i]));
     tr[i] = T;
-    const float w = (1.0f - det_exp(-fe[i])) * T;
+    const double w = (1.0 - dexp(-fe[i])) * T;
     pre[i] = w;
     sw += w; swz += w * (zs[i] * ds);
   }
   sw = wave_sum(sw); swz = wave_sum(swz);
-  float dall = 1.0f, qnum = 0.0f;       // depth_values_all's denominator and numerator
+  double dall = 1.0, qnum = 0.0;       // depth_values_all's denominator and numerator
   if (a.d_depth_all) {
     swa = wave_sum(swa); swd = wave_sum(swd);
-    dall = (swa + sw) + 1e-8f; qnum = swd + swz;
+    dall = (swa + sw) + 1e-8; qnum = swd + swz;
   }
   __syncthreads();
   // d depth_all / d (a weight with depth dv) = (dv * dall - qnum) / dall^2; through tbg it also reaches every fg free energy
-  float bdep = 0.0f;        // sum_k bw_k q_k: d depth_all / d tbg
+  double bdep = 0.0;        // sum_k bw_k q_k: d depth_all / d tbg
   for (int i = lane; i < Nb; i += 64) {
-    const float bw = bpre[i];
+    const double bw = bpre[i];
     if (a.d_depth_all) {
-      const float q = ((ds * a.bg_depth[(size_t)r * Nb + i]) * dall - qnum) / (dall * dall);
+      const double q = ((ds * (double)a.bg_depth[(size_t)r * Nb + i]) * dall - qnum) / (dall * dall);
       bdw[i] += ga * tbg * q;
       bdep += bw * q;
     }
@@ -676,54 +707,47 @@ __global__ __launch_bounds__(64) void composite_bg_bwd_kernel(CompositeBgBwdArgs
   }
   if (a.d_depth_all) bdot += ga * wave_sum(bdep);
   __syncthreads();
-  const float gd = a.d_depth_values ? a.d_depth_values[r] : 0.0f;
-  const float den = sw + 1e-8f;
+  const double gd = a.d_depth_values ? (double)a.d_depth_values[r] : 0.0;
+  const double den = sw + 1e-8;
   for (int i = lane; i < S; i += 64) {
     const size_t p = (size_t)r * S + i;
-    const float w = pre[i];
-    const float c0 = a.rgb[3 * p], c1 = a.rgb[3 * p + 1], c2 = a.rgb[3 * p + 2];
-    a.d_rgb[3 * p] = w * g0; a.d_rgb[3 * p + 1] = w * g1; a.d_rgb[3 * p + 2] = w * g2;
-    float d = (c0 * g0 + c1 * g1) + c2 * g2;
-    if (a.d_weights) d += a.d_weights[p];
+    const double w = pre[i];
+    const double c0 = a.rgb[3 * p], c1 = a.rgb[3 * p + 1], c2 = a.rgb[3 * p + 2];
+    a.d_rgb[3 * p] = (float)(w * g0); a.d_rgb[3 * p + 1] = (float)(w * g1); a.d_rgb[3 * p + 2] = (float)(w * g2);
+    double d = (c0 * g0 + c1 * g1) + c2 * g2;
+    if (a.d_weights) d += (double)a.d_weights[p];
     d += gd * ((zs[i] * ds) * den - swz) / (den * den);
     if (a.d_depth_all) d += ga * ((zs[i] * ds) * dall - qnum) / (dall * dall);
     dw[i] = d;
     pre[i] = d * w;
   }
   __syncthreads();
-  const float tot = wave_cumsum_excl_out(pre, pre, S, lane);
+  const double tot = wave_cumsum_incl(pre, pre, S, lane);
   __syncthreads();
-  const float btot = wave_cumsum_excl_out(bpre, bpre, Nb, lane);
+  const double btot = wave_cumsum_incl(bpre, bpre, Nb, lane);
   __syncthreads();
-  float dbeta = 0.0f;
+  double dbeta = 0.0;
   for (int i = lane; i < S; i += 64) {
     const size_t p = (size_t)r * S + i;
-    const float suffix = tot - pre[i];
+    const double suffix = tot - pre[i];
     // every free energy also attenuates the background term: d (tbg * B) / d fe_i = -tbg * B
-    const float dfe = (dw[i] * tr[i] * det_exp(-fe[i]) - suffix) - tbg * bdot;
-    const float dist = i < S - 1 ? zs[i + 1] - zs[i] : zmax - zs[i];
-    const float dsig = dfe * dist;
-    const float s = a.sdf[p];
-    const float as = __builtin_fabsf(s);
-    const float e = det_exp(-as / beta);
-    const float sgn = s > 0.0f ? 1.0f : (s < 0.0f ? -1.0f : 0.0f);
-    const float sigma = (1.0f / beta) * (0.5f + 0.5f * sgn * (e - 1.0f));
-    a.d_sdf[p] = (s != 0.0f) ? dsig * (-0.5f * e / (beta * beta)) : 0.0f;
-    const float dsig_dbeta = -sigma / beta + 0.5f * sgn * e * as / (beta * beta * beta);
-    dbeta += dsig * dsig_dbeta;
+    const double dfe = (dw[i] * tr[i] * dexp(-fe[i]) - suffix) - tbg * bdot;
+    const double dsig = dfe * fg_dist(i);
+    const DensityD dn((double)a.sdf[p], beta);
+    a.d_sdf[p] = (float)(dsig * dn.dsig_dsdf);
+    dbeta += dsig * dn.dsig_dbeta;
   }
   for (int i = lane; i < Nb; i += 64) {
     const size_t p = (size_t)r * Nb + i;
-    const float suffix = btot - bpre[i];
-    const float dfe = bdw[i] * btr[i] * det_exp(-bfe[i]) - suffix;
-    const float dist = i < Nb - 1 ? bz[i] - bz[i + 1] : 1e10f;
+    const double suffix = btot - bpre[i];
+    const double dfe = bdw[i] * btr[i] * dexp(-bfe[i]) - suffix;
     const float o = a.bg_out0[p];
-    const float sg = o > 0.0f ? 1.0f : (o < 0.0f ? -1.0f : 0.0f);
+    const double sg = o > 0.0f ? 1.0 : (o < 0.0f ? -1.0 : 0.0);
     // exp(-fe) underflows long before dist = 1e10 matters; guard the 0 * inf of the last sample
-    a.d_bg_out0[p] = dfe != 0.0f ? (dfe * dist) * sg : 0.0f;
+    a.d_bg_out0[p] = dfe != 0.0 ? (float)((dfe * bg_dist(i)) * sg) : 0.0f;
   }
   dbeta = wave_sum(dbeta);
-  if (lane == 0) a.d_beta_ray[r] = dbeta;
+  if (lane == 0) a.d_beta_ray[r] = (float)dbeta;
 }
 
 }  // namespace render

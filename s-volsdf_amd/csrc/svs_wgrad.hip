@@ -140,13 +140,15 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(Args a) {
 // --------------------------------------------------------------------------------------------------------------
 // fp16x2 variant: the same contraction on v_mfma_f32_32x32x16_f16, reading the operand blocks in the forms the sweeps
 // store them in (svs_blocks_h2.h): no conversion, no split, no staging registers.
-//   pair 0:  A = abar_l / zbar_l / fbar  HALF block, per-point scale  (gradient-like: one piece)
-//            B = h_l / r_l / feature     the HI PLANE of a pair block (the gradient's other factor has 11 bits anyway:
-//                                        tools/study/fp16_blocks_error.py, "h_wgrad_hi")
-//   pair 1:  A = ghat_l                  HALF block, unscaled
-//            B = u_l                     HALF block, per-point scale
+//   pair 0:  A = abar_l / zbar_l / fbar  scaled block, per-point scale
+//            B = h_l / r_l / feature     pair block
+//   pair 1:  A = ghat_l                  stored unscaled
+//            B = u_l                     scaled block, per-point scale
 //   narrow:  B = the 16 / 32 extra input rows of a radiance network's first layer, ONE float32 tile (split here)
-// One MFMA per k-step and B tile; 32 KiB per item.
+// GP = true (precision SVS_MMA_F16X2): every operand with both fp16 pieces, three MFMAs per k-step and B tile (hi hi + mid
+// hi + hi mid: the float32 accuracy class), 64 KiB per item, a ring of 2 item slots.
+// GP = false (SVS_MMA_F16X2_HALF): hi planes only (the scaled blocks hold nothing else), one MFMA, 32 KiB per item, a ring
+// of 4 slots with 3 items in flight.
 //
 // The contraction index is the POINT, which lives on the lanes of the fragments.  A 16-KiB plane is copied into LDS as it
 // stands by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction) into a ring of four item slots (A plane, B
@@ -173,17 +175,21 @@ typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
 #define SVS_LDS(T, ptr) ((__attribute__((address_space(3))) T*)(ptr))
 
 constexpr int kPlane = 16384;          // bytes of one fp16 plane of a block (svs_blocks_h2.h)
-constexpr int kRecordF = 4096;         // float index of a half block's per-point scale record
-constexpr int kSlot = 2 * kPlane;      // ring slot: A plane, B plane
-constexpr int kRing = 4;
-constexpr int kAhead = kRing - 1;      // items in flight beyond the one being multiplied
 constexpr int kExtraPiece = 32 * 64;   // narrow B tile: [32 points][32 features] fp16, 64-byte rows (hi, then mid)
 constexpr int kNarrowImg = 8192;       // a narrow job has no B plane: its float32 B tile lands (LDS-DMA) at the B plane's
                                        // place, its fp16 image (hi, mid) kNarrowImg bytes further
 constexpr int kRecBytes = 8 * 256;     // per ring slot: every wave's copy of the scaled operand's record (64 floats)
 constexpr int kFactorBytes = 8 * 64;   // per ring slot: 8 waves x 32 fp16 factors
-constexpr int kSlotAll = kSlot + kRecBytes + kFactorBytes;
-constexpr int kLdsBytes = kRing * kSlotAll;
+template <bool GP>
+struct Ring {
+  static constexpr int kPlanes = GP ? 2 : 1;            // planes per operand
+  static constexpr int kSlot = 2 * kPlanes * kPlane;    // ring slot: A plane(s), B plane(s)
+  static constexpr int kB = kPlanes * kPlane;           // offset of the B planes inside a slot
+  static constexpr int kRing = GP ? 2 : 4;
+  static constexpr int kAhead = kRing - 1;              // items in flight beyond the one being multiplied
+  static constexpr int kSlotAll = kSlot + kRecBytes + kFactorBytes;
+  static constexpr int kLdsBytes = kRing * kSlotAll;
+};
 
 // LDS reads of the main loop go through inline asm: hipcc's waitcnt pass makes every LDS access it can see wait for ALL
 // LDS-DMA in flight (vmcnt(0): it cannot tell the ring slots apart), which would un-pipeline the ring.  The reads are
@@ -204,14 +210,16 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(unsigned long long)SVS_LDS(const void, p);
 }
 
-// power-of-two scale from the maximum magnitude: s * absmax in [2^10, 2^11)
+// power-of-two scale from the maximum magnitude: s * absmax in [2^14, 2^15) -- as high as fp16 allows (the re-scaled A
+// fragments of points whose gradients are far below the launch's maximum go subnormal in fp16: every bit of range above
+// them is a bit of precision for those points)
 __device__ __forceinline__ void scale_from_absmax(const float* absmax, float& s, float& inv_s) {
   s = 1.0f; inv_s = 1.0f;
   if (!absmax) return;
   int e = (int)((__float_as_uint(*absmax) >> 23) & 0xff);
-  e = e < 12 ? 12 : (e > 250 ? 250 : e);
-  s = __uint_as_float((unsigned)(264 - e) << 23);
-  inv_s = __uint_as_float((unsigned)(e - 10) << 23);
+  e = e < 16 ? 16 : (e > 250 ? 250 : e);
+  s = __uint_as_float((unsigned)(268 - e) << 23);
+  inv_s = __uint_as_float((unsigned)(e - 14) << 23);
 }
 
 // One launch covers a list of jobs (the weight gradients of several layers): each job gets a contiguous range of
@@ -219,6 +227,7 @@ __device__ __forceinline__ void scale_from_absmax(const float* absmax, float& s,
 // in total, so the number of partial sums flushed with atomics per layer is ~256 / n_jobs instead of 256.
 struct Job {
   Pair p[2];
+  const float* rec[2];   // per pair: the records [tile][64] of its scaled operand (pair 0: A, pair 1: B), or nullptr
   int n_pairs;
   int n_tiles;           // point tiles (32 points each)
   int n_valid_points;    // points beyond this index contribute nothing (ragged last tile)
@@ -237,7 +246,10 @@ constexpr int kThreadsW = 512;          // 8 waves: wave w owns output tile w (3
 
 typedef const __attribute__((address_space(1))) void* gvoid;
 
+template <bool GP>
 __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs ma) {
+  typedef Ring<GP> R;
+  constexpr int kSlot = R::kSlot, kSlotAll = R::kSlotAll, kRing = R::kRing, kAhead = R::kAhead, kB = R::kB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_h2[];
   int jj = 0;
   for (int q = 1; q < ma.n_jobs; ++q) if ((int)blockIdx.x >= ma.job[q].wg_begin) jj = q;
@@ -280,25 +292,26 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
     const float* pa = p.a + (size_t)t * p.stride_a;
     const float* pb = p.b + (size_t)t * p.stride_b;
     unsigned char* slot = ring + (item % kRing) * kSlotAll;
+    // (the planes of a block are contiguous in memory and in the slot: piece index 16 = the mid plane's first piece)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < 2 * R::kPlanes; ++j) {
       const int piece = wave + 8 * j;
       __builtin_amdgcn_global_load_lds((gvoid)(reinterpret_cast<const f32x4*>(pa) + piece * 64 + lane),
                                        SVS_LDS(void, slot + piece * 1024), 16, 0, 0);
       if (!narrow)
         __builtin_amdgcn_global_load_lds((gvoid)(reinterpret_cast<const f32x4*>(pb) + piece * 64 + lane),
-                                         SVS_LDS(void, slot + kPlane + piece * 1024), 16, 0, 0);
+                                         SVS_LDS(void, slot + kB + piece * 1024), 16, 0, 0);
     }
     if (narrow)
       __builtin_amdgcn_global_load_lds((gvoid)(reinterpret_cast<const f32x4*>(pb) + (wave & 3) * 64 + lane),
-                                       SVS_LDS(void, slot + kPlane + (wave & 3) * 1024), 16, 0, 0);
+                                       SVS_LDS(void, slot + kB + (wave & 3) * 1024), 16, 0, 0);
     // scale record of the scaled operand: pair 0 scales A (abar-like), pair 1 B (u); applied to A either way
     if (a.absmax)
-      __builtin_amdgcn_global_load_lds((gvoid)((pi == 0 ? pa : pb) + kRecordF + lane),
+      __builtin_amdgcn_global_load_lds((gvoid)(a.rec[pi] + (size_t)t * 64 + lane),
                                        SVS_LDS(void, slot + kSlot + wave * 256), 4, 0, 0);
   };
   // number of vector-memory operations issue() makes per wave and item
-  const int ops = (narrow ? 3 : 4) + (a.absmax ? 1 : 0);
+  const int ops = (narrow ? 2 * R::kPlanes + 1 : 4 * R::kPlanes) + (a.absmax ? 1 : 0);
 
   // ---- per-item set-up once the wave's own copies have landed: its factor table; (narrow job) the fp16 B image -- whose
   // float32 source quarters were copied by waves 0..3, hence after the barrier
@@ -323,7 +336,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
     unsigned char* slot = ring + (item % kRing) * kSlotAll;
     if (tid < 256) {
       f32x4 v;
-      lds_read128(v, lds_addr(slot + kPlane + tid * 16));
+      lds_read128(v, lds_addr(slot + kB + tid * 16));
       lds_wait();
       f16x4 hi, mid;
 #pragma unroll
@@ -332,8 +345,8 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
         hi[j] = h;
         mid[j] = (_Float16)(v[j] - (float)h);
       }
-      *SVS_LDS(f16x4, slot + kPlane + kNarrowImg + wxoff) = hi;
-      *SVS_LDS(f16x4, slot + kPlane + kNarrowImg + kExtraPiece + wxoff) = mid;
+      *SVS_LDS(f16x4, slot + kB + kNarrowImg + wxoff) = hi;
+      *SVS_LDS(f16x4, slot + kB + kNarrowImg + kExtraPiece + wxoff) = mid;
     }
   };
 
@@ -349,7 +362,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
     // is done with the slot of item - 1, the one item + kAhead is about to be copied into
     {
       const int left = n_items - 1 - item;
-      const int later = (left < kAhead - 1 ? left : kAhead - 1) * ops;        // 0, ops or 2 ops: 0, 3, 4, 5, 6, 8, 10
+      const int later = (left < kAhead - 1 ? left : kAhead - 1) * ops;        // 0, ops or 2 ops: 0, 3, 4, 5, 6, 8, 10 (GP: 0)
       if (later == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
       else if (later == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else if (later == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -368,7 +381,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
     }
     if (item + kAhead < n_items) issue(item + kAhead);
     const unsigned la = lds_addr(ring + (item % kRing) * kSlotAll);
-    const unsigned lb = la + kPlane;
+    const unsigned lb = la + kB;
     const unsigned ftab = la + kSlot + kRecBytes + wave * 64;
     const unsigned nimg = lb + kNarrowImg;
     const bool want_bias = a.db && p0;
@@ -381,12 +394,23 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
       lds_read128(fraw, ftab + 32 * ks + 16 * rh);        // the factors of the fragment's 8 points (16 ks + 8 half + 0..7)
       lds_wait();
       const f16x8 ah = frag_of(fa) * __builtin_bit_cast(f16x8, fraw);
+      f16x8 am = ah;
+      if (GP) {
+        Frag fam;
+        tr_issue(fam, la + kPlane + 512 * ks + a_rd, la + kPlane + 512 * ks + (a_rd ^ 128));
+        lds_wait();
+        am = frag_of(fam) * __builtin_bit_cast(f16x8, fraw);
+      }
       if (want_bias) {
         // row sums of A: the fragment holds 8 points of row lane & 31 (the other lane half holds the other 8)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const f16x2 h2v = {ah[2 * j], ah[2 * j + 1]};
           bsum = __builtin_amdgcn_fdot2(h2v, one2, bsum, false);
+          if (GP) {
+            const f16x2 m2v = {am[2 * j], am[2 * j + 1]};
+            bsum = __builtin_amdgcn_fdot2(m2v, one2, bsum, false);
+          }
         }
       }
       // the two waves of a SIMD cover each other's LDS latency: no software pipelining of the B fragments
@@ -397,12 +421,14 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
         if (!narrow) {
           const unsigned rd = lb + 2048 * i + 512 * ks + rd0;
           tr_issue(fh, rd, rd ^ 128);
+          if (GP) tr_issue(fm, rd + kPlane, (rd ^ 128) + kPlane);
         } else {
           tr_issue(fh, nimg + ks * 1024 + rx0, nimg + ks * 1024 + rx1);
           tr_issue(fm, nimg + kExtraPiece + ks * 1024 + rx0, nimg + kExtraPiece + ks * 1024 + rx1);
         }
         lds_wait();
-        if (two) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, frag_of(fm), acc[i], 0, 0, 0);
+        if (two || GP) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, frag_of(fm), acc[i], 0, 0, 0);
+        if (GP) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, frag_of(fh), acc[i], 0, 0, 0);
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, frag_of(fh), acc[i], 0, 0, 0);
       }
     }
@@ -444,6 +470,7 @@ struct svs_wgrad_job {
   int n_points, ldw;
   float *dW, *db;
   const float* absmax;
+  const float *rec0, *rec1;     // fp16x2: records [tile][64] of the scaled operands (a0's; b1's), required with absmax
 };
 
 // Weight gradients of several layers in one call.  Per job: dW[256][ldw] += sum_p A(p) B(p)^T over one or two
@@ -458,9 +485,13 @@ int svs_wgrad_multi(const svs_wgrad_job* jobs, int n_jobs, int precision, void* 
     if (!q.a0 || !q.b0 || !q.dW || q.n_points <= 0 || q.ldw < 256 || q.ldw > 288 || (q.b_extra && q.ldw < 288) || (q.a1 && !q.b1)) {
       set_error("svs_wgrad_multi: bad argument in job %d", j); return SVS_EINVAL;
     }
+    if (mlp::is_h2(precision) && q.absmax && (!q.rec0 || (q.a1 && !q.rec1))) {
+      set_error("svs_wgrad_multi: job %d has absmax but no scale records", j); return SVS_EINVAL;
+    }
   }
   hipStream_t s = (hipStream_t)hip_stream;
-  if (precision == mlp::kFmtF16x2) {
+  if (mlp::is_h2(precision)) {
+    const bool gp = precision == mlp::kFmtF16x2;
     h2::MultiArgs ma;
     int n = 0;
     long long work[h2::kMaxJobs], total = 0;
@@ -468,9 +499,10 @@ int svs_wgrad_multi(const svs_wgrad_job* jobs, int n_jobs, int precision, void* 
       const svs_wgrad_job& q = jobs[j];
       h2::Job& J = ma.job[n];
       J.p[0] = Pair{q.a0, q.b0, (size_t)q.sa0, (size_t)q.sb0};
+      J.rec[0] = q.rec0; J.rec[1] = q.rec1;
       J.n_pairs = 1;
       if (q.a1) { J.p[1] = Pair{q.a1, q.b1, (size_t)q.sa1, (size_t)q.sb1}; J.n_pairs = 2; }
-      else J.p[1] = J.p[0];
+      else { J.p[1] = J.p[0]; J.rec[1] = J.rec[0]; }
       J.n_tiles = (q.n_points + 31) / 32; J.n_valid_points = q.n_points;
       J.b_tiles = 8; J.col0 = 0; J.dW = q.dW; J.ldw = q.ldw; J.db = q.db; J.absmax = q.absmax;
       work[n] = (long long)J.n_tiles * J.n_pairs * 10;
@@ -496,11 +528,15 @@ int svs_wgrad_multi(const svs_wgrad_job* jobs, int n_jobs, int precision, void* 
       ma.job[j].wg_begin = begin; ma.job[j].wg_count = (int)c;
       begin += (int)c;
     }
-    constexpr int lds = h2::kLdsBytes;
-    static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(h2::wgrad_h2_multi_kernel),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) { set_error("svs_wgrad_multi: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    h2::wgrad_h2_multi_kernel<<<begin, h2::kThreadsW, lds, s>>>(ma);
+    static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(h2::wgrad_h2_multi_kernel<false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, h2::Ring<false>::kLdsBytes);
+    static hipError_t ep = hipFuncSetAttribute(reinterpret_cast<const void*>(h2::wgrad_h2_multi_kernel<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, h2::Ring<true>::kLdsBytes);
+    if (e != hipSuccess || ep != hipSuccess) {
+      set_error("svs_wgrad_multi: hipFuncSetAttribute: %s", hipGetErrorString(e != hipSuccess ? e : ep)); return (int)(e != hipSuccess ? e : ep);
+    }
+    if (gp) h2::wgrad_h2_multi_kernel<true><<<begin, h2::kThreadsW, h2::Ring<true>::kLdsBytes, s>>>(ma);
+    else h2::wgrad_h2_multi_kernel<false><<<begin, h2::kThreadsW, h2::Ring<false>::kLdsBytes, s>>>(ma);
     return check_launch("svs_wgrad_multi");
   }
   if (precision != mlp::kFmtF32) { set_error("svs_wgrad_multi: unknown precision %d", precision); return SVS_EINVAL; }
@@ -536,8 +572,8 @@ int svs_wgrad_multi(const svs_wgrad_job* jobs, int n_jobs, int precision, void* 
 // single job (see svs_wgrad_multi)
 int svs_wgrad(const float* a0, const float* b0, long long sa0, long long sb0, const float* a1, const float* b1,
               long long sa1, long long sb1, const float* b_extra, long long s_extra, int n_points, int precision,
-              const float* absmax, float* dW, int ldw, float* db, void* hip_stream) {
-  svs_wgrad_job q{a0, b0, sa0, sb0, a1, b1, sa1, sb1, b_extra, s_extra, n_points, ldw, dW, db, absmax};
+              const float* absmax, const float* rec0, const float* rec1, float* dW, int ldw, float* db, void* hip_stream) {
+  svs_wgrad_job q{a0, b0, sa0, sb0, a1, b1, sa1, sb1, b_extra, s_extra, n_points, ldw, dW, db, absmax, rec0, rec1};
   return svs_wgrad_multi(&q, 1, precision, hip_stream);
 }
 

@@ -27,7 +27,8 @@ class WGradJob(ctypes.Structure):
                 ("a1", ctypes.c_void_p), ("b1", ctypes.c_void_p), ("sa1", ctypes.c_longlong), ("sb1", ctypes.c_longlong),
                 ("b_extra", ctypes.c_void_p), ("s_extra", ctypes.c_longlong),
                 ("n_points", ctypes.c_int), ("ldw", ctypes.c_int),
-                ("dW", ctypes.c_void_p), ("db", ctypes.c_void_p), ("absmax", ctypes.c_void_p)]
+                ("dW", ctypes.c_void_p), ("db", ctypes.c_void_p), ("absmax", ctypes.c_void_p),
+                ("rec0", ctypes.c_void_p), ("rec1", ctypes.c_void_p)]
 
 
 class UnpackJob(ctypes.Structure):
@@ -75,14 +76,14 @@ SIGNATURES = {
     "svs_composite": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P]),
     "svs_composite_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
     "svs_wgrad": (c_int, [_P, _P, ctypes.c_longlong, ctypes.c_longlong, _P, _P, ctypes.c_longlong, ctypes.c_longlong,
-                          _P, ctypes.c_longlong, c_int, c_int, _P, _P, c_int, _P, _P]),
+                          _P, ctypes.c_longlong, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P]),
     "svs_wgrad_multi": (c_int, [_P, c_int, c_int, _P]),
     "svs_bg_points": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_float, _P, _P, _P, _P]),
-    "svs_bg_sdf_eval": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P]),
-    "svs_bg_rgb_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "svs_bg_sdf_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "svs_bg_sdf_eval": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, _P, _P]),
+    "svs_bg_rgb_bwd": (c_int, [c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P]),
+    "svs_bg_sdf_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P]),
     "svs_bg_rbuf_bytes": (c_size_t, [c_int]),
-    "svs_bg_rgb_eval": (c_int, [c_int, _P, c_int, _P, _P, _P, _P, _P]),
+    "svs_bg_rgb_eval": (c_int, [c_int, _P, c_int, _P, _P, c_int, _P, _P, _P]),
     "svs_composite_bg_bwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P, _P,
                                      _P, _P, _P, _P, _P, _P, _P]),
     "svs_composite_bg": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P,

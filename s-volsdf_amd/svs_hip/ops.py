@@ -50,16 +50,25 @@ def rays_from_uv(uv, pose, intrinsics):
     return dirs, cam, ds
 
 
-F32, F16X2 = 0, 1          # MFMA precision of the MLP kernels (include/svolsdf_hip.h: SVS_MMA_F32 / SVS_MMA_F16X2)
+# MFMA precision of the MLP kernels (include/svolsdf_hip.h: SVS_MMA_F32 / SVS_MMA_F16X2 / SVS_MMA_F16X2_HALF)
+F32, F16X2, F16X2_HALF = 0, 1, 2
+_PRECISIONS = {"f32": F32, "f16x2": F16X2, "f16x2_half": F16X2_HALF}
+
+
+def is_h2(precision):
+    """the fp16x2 kernels (either format of the backward's gradient-only blocks)"""
+    return precision in (F16X2, F16X2_HALF)
 
 
 def default_precision():
-    """fp16x2 (two-piece fp16 operands, float32-class accuracy, 2.8x faster) unless SVS_MLP_PRECISION=f32."""
+    """SVS_MLP_PRECISION: f16x2 (default: two-piece fp16 operands on the 16-bit matrix cores, forward AND backward in the
+    float32 accuracy class), f16x2_half (the same kernels with the backward's gradient-only blocks stored as one fp16 piece:
+    a faster, mixed-precision training step whose parameter gradients are 2e-4 ... 8e-4 off), f32 (float32 MFMA)."""
     import os
     v = os.environ.get("SVS_MLP_PRECISION", "f16x2").lower()
-    if v not in ("f32", "f16x2"):
-        raise ValueError(f"SVS_MLP_PRECISION must be f32 or f16x2, not {v!r}")
-    return F32 if v == "f32" else F16X2
+    if v not in _PRECISIONS:
+        raise ValueError(f"SVS_MLP_PRECISION must be one of {sorted(_PRECISIONS)}, not {v!r}")
+    return _PRECISIONS[v]
 
 
 class PackedMlp:
@@ -204,8 +213,9 @@ def composite(z, sdf, rgb, depth_scale, beta_param, beta_min, normals=None):
 class PackedBg:
     """Packed weight streams of bg_implicit_network / bg_rendering_network (no weight-norm)."""
 
-    def __init__(self, device):
-        if default_precision() != F16X2:
+    def __init__(self, device, precision=None):
+        self.precision = default_precision() if precision is None else int(precision)
+        if not is_h2(self.precision):
             # the background networks have fp16x2 kernels only (csrc/svs_bg_h2.hip); running them under a setting that
             # promises float32 MFMA arithmetic would silently break that promise
             raise NotImplementedError("SVS_MLP_PRECISION=f32 is not available for the inverted-sphere background model "
@@ -223,7 +233,7 @@ class PackedBg:
         for which, (w, b), stream in ((5, sdf_wb, self.sdf_stream), (7, rgb_wb, self.rgb_stream)):
             w, b = [_f32(t) for t in w], [_f32(t) for t in b]
             self._keep += [w, b]
-            _lib.check(L.svs_pack_stream(which, F16X2, _ptr_array(w), None, _ptr_array(b), _ptr(self._ws), _ptr(stream),
+            _lib.check(L.svs_pack_stream(which, self.precision, _ptr_array(w), None, _ptr_array(b), _ptr(self._ws), _ptr(stream),
                                          _stream()), "svs_pack_stream(bg)")
 
 
@@ -255,8 +265,8 @@ def bg_sdf_eval(packed, pts, keep=None):
         ghat7 = torch.empty(L.svs_block_bytes(P, 1) // 4, device=dev)
         pebuf = torch.empty(L.svs_block_bytes(P, 1) // 4, device=dev)
         keep.update(bg_hbuf=hbuf, bg_ghat7=ghat7, bg_pebuf=pebuf, bg_pts=pts)
-    _lib.check(L.svs_bg_sdf_eval(_ptr(pts), P, _ptr(packed.sdf_stream), _ptr(out0), _ptr(feat), _ptr(hbuf), _ptr(ghat7),
-                                 _ptr(pebuf), _stream()), "svs_bg_sdf_eval")
+    _lib.check(L.svs_bg_sdf_eval(_ptr(pts), P, _ptr(packed.sdf_stream), packed.precision, _ptr(out0), _ptr(feat), _ptr(hbuf),
+                                 _ptr(ghat7), _ptr(pebuf), _stream()), "svs_bg_sdf_eval")
     return out0, feat
 
 
@@ -270,8 +280,8 @@ def bg_rgb_eval(packed, view_dirs, n_bg, feat_tiles, n_points, keep=None):
     if keep is not None:
         rbuf = torch.empty(L.svs_bg_rbuf_bytes(n_points) // 4, device=dev)
         keep.update(bg_rbuf=rbuf, bg_feat=feat_tiles, bg_rgb=rgb)
-    _lib.check(L.svs_bg_rgb_eval(n_points, _ptr(view_dirs), n_bg, _ptr(feat_tiles), _ptr(packed.rgb_stream), _ptr(rgb),
-                                 _ptr(rbuf), _stream()), "svs_bg_rgb_eval")
+    _lib.check(L.svs_bg_rgb_eval(n_points, _ptr(view_dirs), n_bg, _ptr(feat_tiles), _ptr(packed.rgb_stream), packed.precision,
+                                 _ptr(rgb), _ptr(rbuf), _stream()), "svs_bg_rgb_eval")
     return rgb
 
 

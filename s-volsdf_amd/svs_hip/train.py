@@ -15,9 +15,10 @@ import ctypes
 import torch
 
 from . import lib as _lib
-from .ops import _f32, _ptr, _ptr_array, _stream, default_precision, F16X2
+from .ops import _f32, _ptr, _ptr_array, _stream, default_precision, is_h2, F16X2, F16X2_HALF
 
 KBLOCK = 128 * 64           # floats per wave-tile activation block
+KREC = 64                   # floats per record of a scaled block (csrc/svs_blocks_h2.h)
 
 
 def block_stride(n_points):
@@ -25,6 +26,18 @@ def block_stride(n_points):
     abuf), which are laid out [block][wave tile] with the tile count padded to whole workgroups (svs_mlp_dev.h)."""
     return ((n_points + 127) // 128) * 4 * KBLOCK
 LDW = 288
+
+
+def n_tiles_padded(n_points):
+    """wave tiles of a launch over n_points, padded to whole workgroups"""
+    return ((n_points + 127) // 128) * 4
+
+
+def record_off(n_points, n_blocks, block):
+    """Float offset of the records of block `block` in a [block][tile] buffer of n_blocks scaled blocks per tile: the
+    records follow the slots, in slot order (include/svolsdf_hip.h, "Records")."""
+    T = n_tiles_padded(n_points)
+    return n_blocks * T * KBLOCK + block * T * KREC
 
 
 def _off(t, n_floats):
@@ -162,15 +175,16 @@ class MlpBackward:
         rbuf, feat = keep["rbuf"], keep["feat_tiles"]
 
         prec = S.precision
-        h2 = prec == F16X2
+        h2 = is_h2(prec)
 
         def addr(x):
             return x.value if isinstance(x, ctypes.c_void_p) else x
 
-        def job(slot, n_pts, amax, a0, sa0, b0, sb0, a1=None, sa1=0, b1=None, sb1=0, extra=None, sx=0):
+        def job(slot, n_pts, amax, a0, sa0, b0, sb0, a1=None, sa1=0, b1=None, sb1=0, extra=None, sx=0, rec0=None, rec1=None):
             return _lib.WGradJob(addr(a0), addr(b0), sa0, sb0, addr(a1), addr(b1), sa1, sb1,
                                  addr(extra), sx, n_pts, LDW, addr(_off(acc.dWk, slot * 256 * LDW)),
-                                 addr(_off(acc.dbk, slot * 256)), addr(_off(acc.absmax, amax)) if h2 else None)
+                                 addr(_off(acc.dbk, slot * 256)), addr(_off(acc.absmax, amax)) if h2 else None,
+                                 addr(rec0) if h2 else None, addr(rec1) if h2 else None)
 
         def wgrad_multi(jobs):
             arr = (_lib.WGradJob * len(jobs))(*jobs)
@@ -202,9 +216,12 @@ class MlpBackward:
             if side:
                 side_stream.wait_event(fork)
             LSm = block_stride(n_main)              # rbuf = [4 blocks][tile] + extras [tile][1024], zbuf = [5 blocks][tile]
-            jobs = [job(9, n_main, 1, _off(self.zbuf, 0), KBLOCK, _ptr(feat), KBLOCK, extra=_off(rbuf, 4 * LSm), sx=1024)]
+            zrec = lambda l: _off(self.zbuf, record_off(n_main, 5, l))
+            jobs = [job(9, n_main, 1, _off(self.zbuf, 0), KBLOCK, _ptr(feat), KBLOCK, extra=_off(rbuf, 4 * LSm), sx=1024,
+                        rec0=zrec(0))]
             for l in range(1, 5):
-                jobs.append(job(9 + l, n_main, 1, _off(self.zbuf, l * LSm), KBLOCK, _off(rbuf, (l - 1) * LSm), KBLOCK))
+                jobs.append(job(9 + l, n_main, 1, _off(self.zbuf, l * LSm), KBLOCK, _off(rbuf, (l - 1) * LSm), KBLOCK,
+                                rec0=zrec(l)))
             wgrad_multi(jobs)
             join = torch.cuda.Event(); join.record(side_stream)
         # ---- SDF MLP: pass A (needs nbar), pass B (needs sbar, fbar), then its weight gradients
@@ -228,12 +245,15 @@ class MlpBackward:
         ev = self.timer_events = ([torch.cuda.Event(enable_timing=True) for _ in range(2)] if self.time_wgrad else None)
         if ev:
             ev[0].record()
+        arec = lambda l: _off(self.abuf, record_off(n_total, 8, l))
+        urec = lambda l: _off(self.ubuf, record_off(n_total, 9, l))
         jobs = [job(0, n_total, 0, _off(self.abuf, 0), KBLOCK, _ptr(self.pebuf), KBLOCK,
-                    _off(gbuf, 0), KBLOCK, _off(self.ubuf, 0), KBLOCK)]
+                    _off(gbuf, 0), KBLOCK, _off(self.ubuf, 0), KBLOCK, rec0=arec(0), rec1=urec(0))]
         for l in range(1, 8):
             jobs.append(job(l, n_total, 0, _off(self.abuf, l * LS), KBLOCK, _off(hbuf, (l - 1) * LS), KBLOCK,
-                            _off(gbuf, l * LS), KBLOCK, _off(self.ubuf, l * LS), KBLOCK))
-        jobs.append(job(8, n_main, 2, _ptr(self.feat_bar), KBLOCK, _off(hbuf, 7 * LS), KBLOCK))
+                            _off(gbuf, l * LS), KBLOCK, _off(self.ubuf, l * LS), KBLOCK, rec0=arec(l), rec1=urec(l)))
+        jobs.append(job(8, n_main, 2, _ptr(self.feat_bar), KBLOCK, _off(hbuf, 7 * LS), KBLOCK,
+                        rec0=_off(self.feat_bar, record_off(n_main, 1, 0))))
         wgrad_multi(jobs)
         if ev:
             ev[1].record()
@@ -256,9 +276,12 @@ class BgBackward:
     csrc/svs_bg_h2.hip + the shared pass-B sweep and weight-gradient GEMM."""
     BGRBUF = KBLOCK + 1024
 
-    def __init__(self, device):
+    def __init__(self, device, precision=None):
         L = _lib.load()
         self.dev = device
+        self.precision = default_precision() if precision is None else int(precision)
+        if not is_h2(self.precision):
+            raise NotImplementedError("the inverted-sphere background networks run on the fp16x2 kernels only")
         self.sdf_stream = torch.empty(L.svs_stream_bytes(6) // 4, device=device)
         self.rgb_stream = torch.empty(L.svs_stream_bytes(8) // 4, device=device)
         self.ws = torch.empty(L.svs_pack_workspace_bytes() // 4, device=device)
@@ -274,7 +297,7 @@ class BgBackward:
         for which, (w, b), stream in ((6, sdf_wb, self.sdf_stream), (8, rgb_wb, self.rgb_stream)):
             w, b = [_f32(t) for t in w], [_f32(t) for t in b]
             self._keep += [w, b]
-            _lib.check(L.svs_pack_stream(which, F16X2, _ptr_array(w), None, _ptr_array(b), _ptr(self.ws), _ptr(stream),
+            _lib.check(L.svs_pack_stream(which, self.precision, _ptr_array(w), None, _ptr_array(b), _ptr(self.ws), _ptr(stream),
                                          _stream()), "svs_pack_stream(bg backward)")
 
     def zero(self):
@@ -300,29 +323,34 @@ class BgBackward:
         st = _stream()
         hbuf, ghat7, pebuf, rbuf, feat = keep["bg_hbuf"], keep["bg_ghat7"], keep["bg_pebuf"], keep["bg_rbuf"], keep["bg_feat"]
         d_bg_rgb, d_bg_out0 = _f32(d_bg_rgb), _f32(d_bg_out0)
-        _lib.check(L.svs_bg_rgb_bwd(P, _ptr(d_bg_rgb), _ptr(keep["bg_rgb"]), _ptr(rbuf), _ptr(self.rgb_stream), _ptr(zbuf),
+        prec = self.precision
+        _lib.check(L.svs_bg_rgb_bwd(P, _ptr(d_bg_rgb), _ptr(keep["bg_rgb"]), _ptr(rbuf), _ptr(self.rgb_stream), prec, _ptr(zbuf),
                                     _ptr(feat_bar), _ptr(self.absmax), st), "svs_bg_rgb_bwd")
-        _lib.check(L.svs_bg_sdf_bwd(P, _ptr(d_bg_out0), _ptr(feat_bar), _ptr(hbuf), _ptr(ghat7), _ptr(self.sdf_stream),
+        _lib.check(L.svs_bg_sdf_bwd(P, _ptr(d_bg_out0), _ptr(feat_bar), _ptr(hbuf), _ptr(ghat7), _ptr(self.sdf_stream), prec,
                                     _ptr(abuf), _ptr(sbar), _ptr(self.absmax), st), "svs_bg_sdf_bwd")
-        _lib.check(L.svs_lin8_row0_grad(_ptr(hbuf), None, _ptr(sbar), P, F16X2, _ptr(self.row0), st), "svs_lin8_row0_grad")
+        _lib.check(L.svs_lin8_row0_grad(_ptr(hbuf), None, _ptr(sbar), P, prec, _ptr(self.row0), st), "svs_lin8_row0_grad")
         LS, Z2 = block_stride(P), 2 * KBLOCK
+        T = n_tiles_padded(P)
 
         def addr(x):
             return x.value if isinstance(x, ctypes.c_void_p) else x
 
-        def job(slot, amax, a0, sa0, b0, sb0, extra=None, sx=0):
+        def job(slot, amax, a0, sa0, b0, sb0, rec0, extra=None, sx=0):
             return _lib.WGradJob(addr(a0), addr(b0), sa0, sb0, None, None, 0, 0, addr(extra), sx, P, LDW,
                                  addr(_off(self.dWk, slot * 256 * LDW)), addr(_off(self.dbk, slot * 256)),
-                                 addr(_off(self.absmax, amax)))
+                                 addr(_off(self.absmax, amax)), addr(rec0), None)
 
-        jobs = [job(0, 0, _off(abuf, 0), KBLOCK, _ptr(pebuf), KBLOCK)]
+        arec = lambda l: _off(abuf, record_off(P, 8, l))
+        jobs = [job(0, 0, _off(abuf, 0), KBLOCK, _ptr(pebuf), KBLOCK, arec(0))]
         for l in range(1, 8):
-            jobs.append(job(l, 0, _off(abuf, l * LS), KBLOCK, _off(hbuf, (l - 1) * LS), KBLOCK))
-        jobs.append(job(8, 2, _ptr(feat_bar), KBLOCK, _off(hbuf, 7 * LS), KBLOCK))
-        jobs.append(job(9, 1, _off(zbuf, 0), Z2, _ptr(feat), KBLOCK, extra=_off(rbuf, KBLOCK), sx=self.BGRBUF))
-        jobs.append(job(10, 1, _off(zbuf, KBLOCK), Z2, _ptr(rbuf), self.BGRBUF))
+            jobs.append(job(l, 0, _off(abuf, l * LS), KBLOCK, _off(hbuf, (l - 1) * LS), KBLOCK, arec(l)))
+        jobs.append(job(8, 2, _ptr(feat_bar), KBLOCK, _off(hbuf, 7 * LS), KBLOCK, _off(feat_bar, record_off(P, 1, 0))))
+        # bg zbuf slots are [tile][2 blocks]; its records, behind the slots, are [block][tile][64] like everywhere else
+        zrec = lambda b: _off(zbuf, 2 * T * KBLOCK + b * T * KREC)
+        jobs.append(job(9, 1, _off(zbuf, 0), Z2, _ptr(feat), KBLOCK, zrec(0), extra=_off(rbuf, KBLOCK), sx=self.BGRBUF))
+        jobs.append(job(10, 1, _off(zbuf, KBLOCK), Z2, _ptr(rbuf), self.BGRBUF, zrec(1)))
         arr = (_lib.WGradJob * len(jobs))(*jobs)
-        _lib.check(L.svs_wgrad_multi(ctypes.cast(arr, ctypes.c_void_p), len(jobs), F16X2, st), "svs_wgrad_multi(bg)")
+        _lib.check(L.svs_wgrad_multi(ctypes.cast(arr, ctypes.c_void_p), len(jobs), prec, st), "svs_wgrad_multi(bg)")
         self._hold = getattr(self, "_hold", {})
         self._hold[slot] = (d_bg_rgb, d_bg_out0)
 
@@ -358,9 +386,12 @@ def algorithmic_bytes_per_point(precision=None):
       wgrad_sdf       per layer abar_l, h_l (hi plane), ghat_l, u_l (l = 0..7) + fbar, h_8 (hi plane) for lin8
       wgrad_radiance  zbar_0..zbar_4, r_0..r_3 (hi planes), the feature block (hi plane), the 16 extra input rows"""
     precision = default_precision() if precision is None else precision
-    if precision == F16X2:
-        half, pair = 512, 1024
-        return {"svs_sdf_bwd_a": 8 * half + 8 * half + 9 * half + 8 * half + pair,
+    if is_h2(precision):
+        # F16X2: every block with both pieces (1024 B per point and block); F16X2_HALF: scaled blocks and the planes the
+        # sweeps / the weight gradient read of a pair block are 512 B
+        half = 512 if precision == F16X2_HALF else 1024
+        pair = 1024
+        return {"svs_sdf_bwd_a": 8 * half + 8 * half + 9 * half + 8 * half + (pair if half == 512 else pair),
                 "svs_sdf_bwd_b": 8 * half + 8 * half + half + half + 8 * half,
                 "wgrad_sdf": 8 * (half + half + half + half) + half + half,
                 "wgrad_radiance": 5 * half + 4 * half + half + 128}

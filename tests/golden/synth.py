@@ -318,10 +318,11 @@ def rows_to_pair_block(x):
     return out.reshape(nt, -1).view(F32)
 
 
-def rows_to_half_block(x, scaled=True):
-    """(P, F<=256) float32 rows -> HALF blocks (csrc/svs_blocks_h2.h): the hi plane of x * s_p, s_p the power of two that
-    puts the point's largest magnitude in [2^4, 2^5) (1 when not `scaled`), + the record [scale(32), max(32)] at float
-    index 4096.  Returns (blocks (ceil(P/32), 128*64) float32 words, the values the block actually holds (P, F))."""
+def rows_to_scaled_block(x, scaled=True, pair=False):
+    """(P, F<=256) float32 rows -> SCALED blocks (csrc/svs_blocks_h2.h): x * s_p with s_p the power of two that puts the
+    point's largest magnitude in [2^4, 2^5) (1 when not `scaled`), as the hi plane alone (pair=False, the
+    SVS_MMA_F16X2_HALF format) or as hi plane + mid plane (pair=True, SVS_MMA_F16X2).  Returns (blocks (ceil(P/32), 128*64)
+    float32 words, records (ceil(P/32), 64) = [scale(32), max(32)], the values the block actually holds (P, F))."""
     P, Fdim = x.shape
     nt = (P + 31) // 32
     mx = np.abs(x).max(1)
@@ -330,20 +331,24 @@ def rows_to_half_block(x, scaled=True):
         sp = (2.0 ** (4 - e)).astype(F32)
     else:
         sp = np.ones(P, F32)
-    hi = (x * sp[:, None]).astype(np.float16)
-    out = np.zeros((nt, 128 * 64 * 2), np.float16)
-    planes = out[:, :16 * 64 * 8].reshape(nt, 16, 64, 8)
+    xs = (x * sp[:, None]).astype(F32)
+    hi = xs.astype(np.float16)
+    mid = (xs - hi.astype(F32)).astype(np.float16)
+    out = np.zeros((nt, 2, 16, 64, 8), np.float16)
     s, j, half = _fragment_index(Fdim)
     p = np.arange(P)
     wt, lane = (p // 32)[:, None], (p % 32)[:, None] + 32 * half[None, :]
-    planes[wt, s[None, :], _piece_slot(s[None, :], lane), j[None, :]] = hi
-    words = out.view(F32).reshape(nt, 128 * 64)
+    slot = _piece_slot(s[None, :], lane)
+    out[wt, 0, s[None, :], slot, j[None, :]] = hi
+    if pair:
+        out[wt, 1, s[None, :], slot, j[None, :]] = mid
+    words = out.reshape(nt, -1).view(F32)
     rec = np.ones((nt, 64), F32)
     rec[:, 32:] = 0.0
     rec.reshape(-1)[(p // 32) * 64 + p % 32] = sp
     rec.reshape(-1)[(p // 32) * 64 + 32 + p % 32] = mx
-    words[:, 4096:4160] = rec
-    return words, hi.astype(F32) / sp[:, None]
+    held = hi.astype(F32) + (mid.astype(F32) if pair else 0.0)
+    return words, rec, held / sp[:, None]
 
 
 def make_fusion_views(seed, hw=(48, 64), n_views=3, noise=2e-3):

@@ -78,7 +78,7 @@ def main():
     st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     dn = torch.empty(n_main, 3, device=dev)
     prec = bw.streams.precision
-    h2 = prec == 1
+    h2 = prec in (1, 2)
     am = bw.accum.absmax
     N = lambda x: P(x) if h2 else None
     t = timeit(lambda: lib.check(L.svs_rgb_bwd(n_main, P(d_rgb), P(keep["rgb"]), P(keep["rbuf"]), P(bw.streams.rgb), prec,
@@ -94,16 +94,19 @@ def main():
     t = timeit(lambda: lib.check(L.svs_sdf_bwd_b(n_total, P(dsf), P(mask), P(bw.feat_bar), n_main, P(hbuf), P(gbuf), P(bw.a2buf),
                                                  P(bw.streams.sdf), prec, P(bw.abuf), P(bw.sbar), N(am), N(bw.a2max), st())))
     res["sdf_bwd_b"] = dict(ms=t, tflops=n_total * F_SDF / t / 1e9)
-    from svs_hip.train import block_stride
+    from svs_hip.train import block_stride, record_off
     LS = block_stride(n_total)
+    R = lambda buf, n, nb, l: _off(buf, record_off(n, nb, l)) if h2 else None
     dW = torch.zeros(256, 288, device=dev); db = torch.zeros(256, device=dev)
     l = 2
     t = timeit(lambda: lib.check(L.svs_wgrad(_off(bw.abuf, l * LS), _off(hbuf, (l - 1) * LS), KBLOCK, KBLOCK,
                                              _off(gbuf, l * LS), _off(bw.ubuf, l * LS), KBLOCK, KBLOCK,
-                                             None, 0, n_total, prec, N(am), P(dW), 288, P(db), st())))
+                                             None, 0, n_total, prec, N(am), R(bw.abuf, n_total, 8, l), R(bw.ubuf, n_total, 9, l),
+                                             P(dW), 288, P(db), st())))
     res["wgrad_2pair"] = dict(ms=t, tflops=2 * 2 * 256 * 256 * n_total / t / 1e9)
     t = timeit(lambda: lib.check(L.svs_wgrad(P(bw.feat_bar), _off(hbuf, 7 * LS), KBLOCK, KBLOCK, None, None, 0, 0,
-                                             None, 0, n_main, prec, _off(am, 2) if h2 else None, P(dW), 288, P(db), st())))
+                                             None, 0, n_main, prec, _off(am, 2) if h2 else None, R(bw.feat_bar, n_main, 1, 0), None,
+                                             P(dW), 288, P(db), st())))
     res["wgrad_1pair"] = dict(ms=t, tflops=2 * 256 * 256 * n_main / t / 1e9)
     if True:
         res["lin8_row0"] = dict(ms=timeit(lambda: lib.check(L.svs_lin8_row0_grad(P(hbuf), P(bw.ubuf), P(bw.sbar), n_total, prec, P(row0), st()))))
