@@ -21,7 +21,14 @@ Rank 0 prints ONE JSON line.  `roofline` prices the kernel with the largest time
 come from HIP events on each kernel's own launch stream (svs_hip/profiling.py) over steps run right AFTER the timed
 region in the same process -- an event pair per launch would perturb the timed region, and a replayed graph's kernels
 cannot be bracketed at all -- and are listed for every fused-MLP kernel under `roofline.kernels`.  `cpu_baseline` times the CPU port on a bounded sample of the same workload.
-SVS_MLP_PRECISION=f32 selects the float32-MFMA kernels instead of the default fp16x2 split-operand ones.
+`gpu_torch_baseline` times the reference's differentiable part -- plain PyTorch float32 autograd + clip + Adam -- on the same GPU.
+
+Precision.  The default (SVS_MLP_PRECISION=f16x2) evaluates every layer product, forward AND backward, as three fp16 MFMA
+products of two-piece operands with float32 accumulation, and every activation block kept for the backward holds both pieces:
+parameter gradients agree with float64 autograd like float32 autograd does (tests/test_gpu_train.py::
+test_step_gradient_at_bench_geometry, 3e-5 of a tensor's largest entry).  `value` is measured on that mode.  The line also
+carries, as extras measured in the same process: `fast_grad_*` = SVS_MLP_PRECISION=f16x2_half (gradient-only blocks as ONE fp16
+piece: a mixed-precision training step, 2e-4 ... 8e-4 gradient error) and `exact_f32_ms_per_step` = the float32-MFMA kernels.
 """
 import argparse
 import json
@@ -58,6 +65,8 @@ MLP_KERNELS = {
                       "SDF MLP backward, backprop sweep"),
     "svs_wgrad_multi": ("svs::wgrad::h2::wgrad_h2_multi_kernel", "svs::wgrad::wgrad_kernel<8>", "hbm", None,
                         "weight gradients of all layers of a network in one launch"),
+    "svs_lin8_row0_grad": ("svs::mlp::lin8_row0_h2_kernel", "svs::mlp::lin8_row0_kernel", "hbm", None,
+                           "row 0 of lin8's weight gradient (h_8 and u_8 blocks)"),
 }
 
 
@@ -89,7 +98,9 @@ def main():
                          "chain); off (default): eager launches -- measured faster on this ROCm stack, see DESIGN.md")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel event timing (roofline = null)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-exact-f32", action="store_true", help="skip the extra float32-MFMA run (exact_f32_ms_per_step)")
+    ap.add_argument("--no-exact-f32", action="store_true",
+                    help="skip the extra runs in the other precisions (fast_grad_*, exact_f32_ms_per_step)")
+    ap.add_argument("--no-gpu-torch", action="store_true", help="skip the PyTorch-eager comparator on the same GPU")
     args = ap.parse_args()
 
     import numpy as np
@@ -225,7 +236,7 @@ def main():
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": ("f32 (fp16x2 split operands on the fp16 matrix cores, f32 accumulate)" if h2 else "f32"),
+            "dtype": dtype_string(ops.default_precision()),
             "data": "synthetic",
             "config": {"workload": ("configs[1]: VolOpt.train_step (forward + MVS prior lookup + loss + backward + clip/guard/Adam), "
                                     if train else "configs[1]: VolSDFNetwork.forward as called by VolOpt.train_step, forward only, ")
@@ -234,8 +245,7 @@ def main():
                                    + (" + 32 inverted-sphere background samples per ray (8x256 bg implicit MLP + 128-wide bg "
                                       "radiance MLP): config 4, VolSDFNetworkBG" if args.model == "bmvs" else ""),
                        "mode": args.mode,
-                       "mlp_precision": ("fp16x2: two-piece fp16 operands on v_mfma_f32_32x32x16_f16, float32 accumulation "
-                                         "(float32-class accuracy, same parity bounds)" if h2 else "float32 MFMA"),
+                       "mlp_precision": precision_note(ops.default_precision()),
                        "ray_groups": ([list(g) for g in ts._groups_for(R)] if train else [[0, R]]),
                        "ray_group_schedule": (ts.schedule.get(R) if (train and args.groups == "auto") else None),
                        "launch": ("hipGraph replay of the captured step + eager all-reduce / fused Adam"
@@ -245,8 +255,18 @@ def main():
                        "model_flops_per_s": world * R * args.steps / dt * flop_per_ray},
             "roofline": roofline,
         }
+        if train and world == 1 and not args.no_gpu_torch and args.model == "dtu":
+            line["gpu_torch_baseline"] = gpu_torch_baseline(ts, params, gt, R, dev, 1e3 * dt / args.steps)
         if train and h2 and world == 1 and args.model == "dtu" and not args.no_kernel_timing and not args.no_exact_f32:
-            line["exact_f32_ms_per_step"] = exact_f32_step_ms(make_model, make_step)
+            if ops.default_precision() == ops.F16X2:
+                fg = other_precision_step_ms("f16x2_half", make_model, make_step, n=40, warm=60)
+                line["fast_grad_ms_per_step"] = fg
+                line["fast_grad_rays_per_s"] = R / (fg * 1e-3)
+                line["fast_grad_note"] = ("SVS_MLP_PRECISION=f16x2_half: the same step with the backward's gradient-only activation "
+                                          "blocks stored as one fp16 piece and one-product weight-gradient GEMMs -- a mixed-precision "
+                                          "training step (parameter gradients 2e-4 ... 8e-4 of a tensor's largest entry off float64 "
+                                          "autograd); NOT the figure `value` reports")
+            line["exact_f32_ms_per_step"] = other_precision_step_ms("f32", make_model, make_step, n=10, warm=4)
         if not args.no_cpu_baseline and args.model == "dtu" and world == 1:      # rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(params, K, pose, train=train)
         print(json.dumps(line), flush=True)
@@ -299,6 +319,8 @@ def kernel_roofline(ts, step, R, S, h2, train, n_steps=12, ray_groups=None):
             continue
         if name in ("svs_rgb_bwd", "svs_sdf_bwd_b"):
             pts = [int(a[0]) for a in metas]
+        elif name == "svs_lin8_row0_grad":
+            pts = [int(a[3]) for a in metas]
         else:
             pts = [int(a[1]) + int(a[6]) * int(a[7]) for a in metas]
         w = work if work is not None else bpp.get(name)
@@ -349,16 +371,85 @@ def kernel_roofline(ts, step, R, S, h2, train, n_steps=12, ray_groups=None):
     return top
 
 
-def exact_f32_step_ms(make_model, make_step, n=10):
-    """ms per step of the same workload on the exact float32-MFMA kernels (SVS_MLP_PRECISION=f32), eager launches."""
+def dtype_string(precision):
+    from svs_hip import ops
+    if precision == ops.F16X2:
+        return ("f32 (every product, forward and backward, as three fp16 MFMA products of two-piece fp16 operands with f32 "
+                "accumulate; activation blocks hold both pieces: float32 accuracy class)")
+    if precision == ops.F16X2_HALF:
+        return ("f32 forward (three fp16 MFMA products of two-piece operands), mixed-precision backward (gradient-only blocks as "
+                "one fp16 piece, one-product weight gradients)")
+    return "f32"
+
+
+def precision_note(precision):
+    from svs_hip import ops
+    return {ops.F16X2: "fp16x2: two-piece fp16 operands on v_mfma_f32_32x32x16_f16, float32 accumulation, forward and backward "
+                       "(float32-class accuracy: forward 2e-6, parameter gradients within 3e-5 of float64 autograd)",
+            ops.F16X2_HALF: "fp16x2 forward; backward with one-piece gradient blocks (SVS_MLP_PRECISION=f16x2_half)",
+            ops.F32: "float32 MFMA"}[precision]
+
+
+def gpu_torch_baseline(ts, params, gt, R, dev, our_ms, reps=5, warm=2):
+    """The reference's differentiable part in plain PyTorch float32 on the SAME GPU (oracle/torch_ref.py: the SDF and radiance
+    MLPs with the double backward through the normals, compositing, loss, loss.backward(), clip_grad_norm_, Adam.step --
+    volsdf/vsdf.py:196-219 with network.py:206-279), eager mode, at the sample positions, eikonal points and prior look-ups of
+    this process's last step.  NOT included: the error-bounded sampler (the reference runs it in torch under no_grad: one more
+    SDF evaluation of 128 points per ray + the beta search) and cost_mapping -- the baseline does less work than the reference
+    would, so the ratio is a lower bound.  Checker-side code, outside the timed region."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import torch
+    import torch_ref as tref
+    keeps = [h[0] for h in ts._hold]
+    outs = [r[1] for r in ts._results]
+    cat = lambda xs: torch.cat([x.detach() for x in xs], 0).float()
+    z, dirs, ds = (cat([k[n] for k in keeps]) for n in ("z_vals", "ray_dirs", "depth_scale"))
+    cam = keeps[0]["cam_loc"].detach().float()
+    eik = cat([k["src"].points for k in keeps])
+    pj, pi = cat([o["pj"] for o in outs]), cat([o["pi"] for o in outs])
+    p = {k: torch.tensor(np.asarray(v), dtype=torch.float32, device=dev, requires_grad=True) for k, v in params.items()}
+    opt = torch.optim.Adam(list(p.values()), lr=5e-4)
+    rgb, rgbs = gt["rgb"].reshape(-1, 3), gt["rgb_smooth"].reshape(-1, 3)
+
+    def one():
+        opt.zero_grad(set_to_none=True)
+        out = tref.forward_differentiable(p, cam, dirs, z, eik, ds, device=dev)
+        out["pj"], out["pi"] = pj, pi
+        tref.loss_fn(out, rgb, rgbs, 50).backward()
+        torch.nn.utils.clip_grad_norm_(list(p.values()), 1.0)
+        opt.step()
+
+    for _ in range(warm):
+        one()
+    torch.cuda.synchronize()
+    ts_ = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        one()
+        torch.cuda.synchronize()
+        ts_.append(time.perf_counter() - t0)
+    med = float(np.median(ts_))
+    return {"value": R / med, "unit": "rays/s", "ms_per_step": 1e3 * med, "rays": R, "kind": "port",
+            "what": "oracle/torch_ref.py on cuda:0, torch float32 eager: forward (SDF MLP + d sdf/dx via autograd, radiance MLP, "
+                    "compositing) + loss + backward (incl. the double backward) + clip_grad_norm_ + Adam at this step's sample "
+                    "positions; error-bounded sampler and MVS prior lookup NOT included (a lower bound of the reference's step)",
+            "median_of": reps, "warmups": warm, "ratio_value_over_baseline": (1e3 * med) / our_ms,
+            "torch": torch.__version__}
+
+
+def other_precision_step_ms(precision, make_model, make_step, n=10, warm=4):
+    """ms per step of the same workload with SVS_MLP_PRECISION=<precision> (f32: the exact float32-MFMA kernels; f16x2_half:
+    one-piece gradient blocks), eager launches, `warm` untimed steps first (the ray-group schedule is measured during steps
+    24-47: warm >= 48 times the schedule the step then keeps)."""
     import torch
     old = os.environ.get("SVS_MLP_PRECISION")
-    os.environ["SVS_MLP_PRECISION"] = "f32"
+    os.environ["SVS_MLP_PRECISION"] = precision
     try:
         _, model = make_model()
         ts, step = make_step(model)
         ts.graph = False
-        for _ in range(4):
+        for _ in range(warm):
             step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -199,43 +199,10 @@ constexpr int kSpliceF = 20;     // floats per lane kept in LDS for the skip spl
 // g(h) = d sdf / d h is O(0.1 ... 10) -- the 2^11 of headroom above the point's u maximum then cover |g| up to ~2600
 constexpr float kA2Down = 1.0f / 128.0f;
 
-// GP: the side tiles of pass A (h_{l+1} and ghat_l, both pieces: 8 KiB per wave and tile) are staged through LDS instead of
-// registers -- with 32 + 32 registers of them in flight and in use the kernel spilled (436 bytes per lane of scratch).  A wave
-// owns two 8-KiB buffers behind the weight ring and the splice area; a tile's eight 1-KiB fragments arrive by LDS-DMA exactly
-// as they lie in memory (piece_slot order: lane L's 16 bytes of a fragment sit at slot piece_slot(s, L), so its ds_read_b128
-// is conflict-free), [h hi k0, h hi k1, h mid k0, h mid k1, g hi k0, g hi k1, g mid k0, g mid k1].  The DMA of tile t+1 is
-// issued at the END of tile t, behind the last read of the buffer it overwrites (tile t-1's epilogue has just finished with
-// it) and behind the tile's weight pieces, so the tile barrier's counted wait leaves it in flight; it has landed when tile
-// t+1's barrier has been passed, and tile t+2's MFMAs cover the epilogue that reads it.
-constexpr int kSideWave = 2 * 8192;                 // bytes of side staging per wave
-constexpr int kSideBytes = kWaves * kSideWave;      // 64 KiB per workgroup
-__device__ __forceinline__ void side_dma_frag(const float* g, unsigned lds_byte) {
-  // g, lds_byte: wave-uniform (made provably so: an "s" operand the compiler believes divergent lands in VGPRs).  Streaming
-  // read (nt): these blocks are read once.  (M0: see chunk_issue_piece, svs_mlp_dev.h)
-  const unsigned long long ga = (unsigned long long)g;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ga), hi = __builtin_amdgcn_readfirstlane((unsigned)(ga >> 32));
-  const unsigned long long gs = ((unsigned long long)hi << 32) | lo;
-  const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_byte);
-  const unsigned lane_bytes = (threadIdx.x & 63u) * 16u;
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt"
-               :: "v"(lane_bytes), "s"(gs), "s"(m0v) : "memory");
-}
-// the eight fragments of tile t of (hblk, gblk) -> the 8-KiB buffer at LDS byte address `buf`
-__device__ __forceinline__ void side_issue(const float* hblk, const float* gblk, int t, unsigned buf) {
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const float* blk = q < 4 ? hblk : gblk;
-    const int plane = (q >> 1) & 1, s = 2 * t + (q & 1);
-    side_dma_frag(blk + (size_t)(plane * kPlaneF4 + s * 64) * 4, buf + q * 1024);
-  }
-}
-
 template <bool SPLIT, bool GP>
 struct PassAEpi {
   f32x16 prev;
-  TilePieces h, g;    // the stored h_{l+1} tile (softplus' only) and ghat_l, hi pieces (GP = false: register path)
-  const unsigned char* side;   // GP: this wave's LDS buffer holding the tile's eight fragments
-  f16x8 sh, sm, sg, sq;        // GP: the fragments of the current half tile (h hi, h mid, ghat hi, ghat mid)
+  TilePieces h, g;    // the stored h_{l+1} tile (softplus' only) and ghat_l: both pieces with GP, else the hi pieces
   float v, s1;
   float v8[8], w8[8];
   f16x8 a2p[2], up[2];
@@ -256,23 +223,13 @@ struct PassAEpi {
   }
   __device__ __forceinline__ void a(int r) {
     v = prev[r] * ps->inv_in;
-    if (GP) {
-      if ((r & 7) == 0) {       // the half tile's fragments, from the staging buffer
-        const f32x4* f = reinterpret_cast<const f32x4*>(side) + piece_slot(r >> 3, lane);   // (k-step parity = r >> 3)
-        sh = as_h8(f[(0 + (r >> 3)) * 64]); sm = as_h8(f[(2 + (r >> 3)) * 64]);
-        sg = as_h8(f[(4 + (r >> 3)) * 64]); sq = as_h8(f[(6 + (r >> 3)) * 64]);
-      }
-      s1 = dsoftplus_from_h((float)sh[r & 7] + (float)sm[r & 7]);
-    } else {
-      s1 = dsoftplus_from_h(hi_at(h, r));
-    }
+    s1 = dsoftplus_from_h(grad_at<GP>(h, r));
     pin(v); pin(s1);
   }
   template <bool LATE = false>     // LATE: the stores wait for store_slot() (behind the tile's LDS-DMA pieces)
   __device__ __forceinline__ void b(int tp, int r) {
     float u = v * s1;
-    const float gv = GP ? (float)sg[r & 7] + (float)sq[r & 7] : hi_at(g, r);
-    float a2 = v * gv * (100.0f * (1.0f - s1));     // g = ghat_l = g(h_{l+1}) s'(a_l); s'' = 100 s' (1 - s')
+    float a2 = v * grad_at<GP>(g, r) * (100.0f * (1.0f - s1));     // g = ghat_l = g(h_{l+1}) s'(a_l); s'' = 100 s' (1 - s')
     if (tp == 6 && r >= 12 && l3) {
       // local rows 25..31 of tile 6 (registers 13..15 of half 0, 12..15 of half 1) carry u_0[32..38]
       const bool sp = half == 1 || r >= 13;
@@ -355,47 +312,6 @@ __device__ __forceinline__ void pass_a_layer_h2(Stream& st, const Pieces2& in, P
   ep.ps->next();
 }
 
-// The same layer with the side tiles staged through LDS (GP = true, see side_issue()).  side_lds: LDS byte address of this
-// wave's two buffers; par: the buffer tile 0's fragments were sent to by the PREVIOUS layer's last tile (tile t of this layer
-// uses buffer (par + t) & 1); next_h / next_g: the next layer's blocks, whose tile 0 this layer's last tile requests (nullptr:
-// none).  Returns the next layer's par.
-template <bool SPLIT, bool LAST>
-__device__ __forceinline__ int pass_a_layer_gp(Stream& st, const Pieces2& in, PassAEpi<SPLIT, true>& ep, const float* hblk,
-                                               const float* gblk, const float* next_h, const float* next_g, unsigned side_lds,
-                                               const unsigned char* side_ptr, int par, int lane) {
-  // Per tile: the next chunk's LDS-DMA pieces behind k-steps 0..8; the eight a2 / u stores of tile t-1's epilogue in k-steps
-  // 9 .. 15; the eight side fragments of tile t+1 (or of the next layer's tile 0) at the end: 16 operations younger than
-  // every piece stay in flight across the tile's barrier.
-  ep.begin();
-  const int n_tiles = ep.l3 ? 7 : 8;
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    if (t == 7 && ep.l3) break;
-    const bool fetch = !(LAST && t == 7);
-    ep.side = side_ptr + (((par + t - 1) & 1) << 13);           // tile t-1's fragments, read by this tile's epilogue slices
-    f32x16 acc;
-    if (!fetch) acc = tile_mma_h2<16>(st.cur_buf(), in, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.b(t - 1, s); });
-    else if (t == 0) acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, NoEpi(), NoEpi());
-    else acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, [&](int s) { ep.a(s); },
-                                            [&](int s) { ep.template b<true>(t - 1, s); ep.store_slot(t - 1, s); });
-    ep.prev = acc;
-    if (fetch) {
-      // (buffer (par + t + 1) & 1 = the one tile t-1's epilogue has just finished reading)
-      const unsigned nb = side_lds + (((par + t + 1) & 1) << 13);
-      if (t + 1 < n_tiles) side_issue(hblk, gblk, t + 1, nb);
-      else if (next_h) side_issue(next_h, next_g, 0, nb);
-      if (t == 0) st.advance_keep<8>();
-      else if (t + 1 < n_tiles || next_h) st.advance_keep<16>();
-      else st.advance_keep<8>();
-    }
-  }
-  ep.side = side_ptr + (((par + n_tiles - 1) & 1) << 13);
-  if (ep.l3) { ep.all(6); ep.splice_tile7(); }
-  else ep.all(7);
-  ep.ps->next();
-  return (par + n_tiles) & 1;
-}
-
 template <bool GP>
 __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_h2_kernel(SdfBwdAArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -406,10 +322,6 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_h2_kernel(SdfBwdAArgs a
   const int wtile = blockIdx.x * kWaves + wave;
   const int p = wtile * kTilePts + (lane & 31);
   const int pc = p < a.src.P ? p : a.src.P - 1;
-  // GP: this wave's side-tile staging buffers (behind the weight ring and the splice area)
-  const unsigned char* side_ptr = smem + kLdsBytes + kSpliceF * kThreads * sizeof(float) +
-                                  __builtin_amdgcn_readfirstlane(wave) * kSideWave;
-  const unsigned side_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)side_ptr;
 
   st.prefetch<kChunk0F4>();
   PointScale ps;
@@ -483,8 +395,6 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_h2_kernel(SdfBwdAArgs a
     ep.begin();
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      // (layer 0's tiles are three k-steps long and their epilogues are not sliced: its side tiles come through
-      // registers in both formats; GP: copied into the staging buffer the epilogue reads)
       TilePieces hload, gload;
       load_tile_grad<GP>(hb, t, lane, hload);
       load_tile_grad<GP>(gb, t, lane, gload);
@@ -492,32 +402,18 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_h2_kernel(SdfBwdAArgs a
       const f32x16 acc = tile_mma_h2<3>(st.cur_buf(), pa, lane);
       if (t > 0) ep.all(t - 1);
       ep.prev = acc; ep.h = hload; ep.g = gload;
-      if (GP) {
-        f32x4* f = reinterpret_cast<f32x4*>(const_cast<unsigned char*>(side_ptr) + 8192);   // buffer 1 (buffer 0: layer 1's tile 0)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const int sl = piece_slot(c, lane);
-          f[(0 + c) * 64 + sl] = as_f4(hload.h[c]); f[(2 + c) * 64 + sl] = as_f4(hload.m[c]);
-          f[(4 + c) * 64 + sl] = as_f4(gload.h[c]); f[(6 + c) * 64 + sl] = as_f4(gload.m[c]);
-        }
-        ep.side = side_ptr + 8192;
-        if (t == 7) side_issue(hb + LS, gb + LS, 0, side_lds);     // layer 1's tile 0 -> buffer 0, behind the layer's last pieces
-      }
-      if (GP && t == 7) st.advance_keep<8>(); else st.advance();
+      st.advance();
     }
     ep.all(7);
     ps.next();
     a2m = ep.a2m;
   }
   // ---- layers 1..6: pb -> pa, copied back (one code body for all layers)
-  int par = 0;
   for (int l = 1; l < 7; ++l) {
     PassAEpi<true, GP> ep;
     ep.out = &pa; ep.ublk = ub + (size_t)(l + 1) * LS; ep.a2blk = a2 + (size_t)l * LS; ep.urec = urec(l + 1); ep.a2rec = a2rec(l);
     ep.ps = &ps; ep.splice = splice; ep.a2m = a2m; ep.lane = lane; ep.half = half; ep.l3 = l == 3;
-    if constexpr (GP) par = pass_a_layer_gp<true, false>(st, pb, ep, hb + (size_t)l * LS, gb + (size_t)l * LS, hb + (size_t)(l + 1) * LS,
-                                                         gb + (size_t)(l + 1) * LS, side_lds, side_ptr, par, lane);
-    else pass_a_layer_h2<true, false, GP>(st, pb, ep, hb + (size_t)l * LS, gb + (size_t)l * LS, lane);
+    pass_a_layer_h2<true, false, GP>(st, pb, ep, hb + (size_t)l * LS, gb + (size_t)l * LS, lane);
     a2m = ep.a2m;
 #pragma unroll
     for (int s = 0; s < 16; ++s) { pb.h[s] = pa.h[s]; pb.m[s] = pa.m[s]; }
@@ -527,9 +423,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_h2_kernel(SdfBwdAArgs a
     PassAEpi<false, GP> ep;
     ep.out = nullptr; ep.ublk = ub + (size_t)8 * LS; ep.a2blk = a2 + (size_t)7 * LS; ep.urec = urec(8); ep.a2rec = a2rec(7);
     ep.ps = &ps; ep.splice = splice; ep.a2m = a2m; ep.lane = lane; ep.half = half; ep.l3 = false;
-    if constexpr (GP) pass_a_layer_gp<false, true>(st, pb, ep, hb + (size_t)7 * LS, gb + (size_t)7 * LS, nullptr, nullptr, side_lds, side_ptr,
-                                                   par, lane);
-    else pass_a_layer_h2<false, true, GP>(st, pb, ep, hb + (size_t)7 * LS, gb + (size_t)7 * LS, lane);
+    pass_a_layer_h2<false, true, GP>(st, pb, ep, hb + (size_t)7 * LS, gb + (size_t)7 * LS, lane);
     a2m = ep.a2m;
   }
   a2m = __builtin_fmaxf(a2m, __shfl_xor(a2m, 32));
@@ -803,12 +697,10 @@ int launch_rgb_bwd_h2(const RgbBwdArgs& a, bool gp, hipStream_t s) {
 }
 int launch_sdf_bwd_a_h2(const SdfBwdAArgs& a, bool gp, hipStream_t s) {
   constexpr int lds = kLdsBytes + kSpliceF * kThreads * (int)sizeof(float);
-  constexpr int lds_gp = lds + kSideBytes;       // + the side-tile staging buffers
-  static_assert(lds_gp <= 160 * 1024, "pass A: LDS budget");
-  static int once = set_lds(sdf_bwd_a_h2_kernel<true>, lds_gp, "svs_sdf_bwd_a") | set_lds(sdf_bwd_a_h2_kernel<false>, lds, "svs_sdf_bwd_a");
+  static int once = set_lds(sdf_bwd_a_h2_kernel<true>, lds, "svs_sdf_bwd_a") | set_lds(sdf_bwd_a_h2_kernel<false>, lds, "svs_sdf_bwd_a");
   if (once) return once;
   const int grid = (a.src.P + kWgPts - 1) / kWgPts;
-  if (gp) sdf_bwd_a_h2_kernel<true><<<grid, kThreads, lds_gp, s>>>(a);
+  if (gp) sdf_bwd_a_h2_kernel<true><<<grid, kThreads, lds, s>>>(a);
   else sdf_bwd_a_h2_kernel<false><<<grid, kThreads, lds, s>>>(a);
   return check_launch("svs_sdf_bwd_a");
 }

@@ -91,7 +91,9 @@ __device__ __forceinline__ double wave_cumsum_incl(const double* in, double* out
   }
   double acc = scan - tot;
   for (int j = lo; j < hi; ++j) { acc += in[j]; out[j] = acc; }
-  return __shfl(scan, 63);
+  // the total is returned as the very value stored in out[m - 1]: callers form suffix sums as total - out[i], which must be
+  // exactly zero for the last element (its free energy carries dist = 1e10)
+  return __shfl(acc, (m - 1) / c);
 }
 // Laplace density and its derivatives in double (density.py:21-30)
 struct DensityD {
@@ -190,11 +192,15 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(CompositeBwdArgs a) {
     fe[i] = dist * DensityD((double)a.sdf[(size_t)r * S + i], beta).sigma;
   }
   __syncthreads();
-  wave_cumsum_incl(fe, tr, S, lane);           // tr[i] = sum_{j <= i} fe_j
+  // tr[i] = sum_{j < i} fe_j as the inclusive scan of the shifted sequence: the last free energy (dist = 1e10) must not
+  // enter any partial sum, it would cost the prefixes of its lane's chunk 1e-5 of absolute accuracy
+  for (int i = lane; i < S; i += 64) tr[i] = i == 0 ? 0.0 : fe[i - 1];
+  __syncthreads();
+  wave_cumsum_incl(tr, tr, S, lane);
   __syncthreads();
   double sw = 0.0, swz = 0.0;
   for (int i = lane; i < S; i += 64) {
-    const double T = dexp(-(tr[i] - fe[i]));   // exp(-sum_{j < i} fe_j)
+    const double T = dexp(-tr[i]);
     tr[i] = T;
     const double w = (1.0 - dexp(-fe[i])) * T;
     pre[i] = w;                         // weights, reused below
@@ -651,11 +657,16 @@ __global__ __launch_bounds__(64) void composite_bg_bwd_kernel(CompositeBgBwdArgs
     bfe[i] = bg_dist(i) * (o < 0.0 ? -o : o);
   }
   __syncthreads();
-  const double fe_tot = wave_cumsum_incl(fe, tr, S, lane);     // tr[i] = sum_{j <= i} fe_j
+  // exclusive prefixes as inclusive scans of the shifted sequences (the last background free energy, dist = 1e10, must not
+  // enter any partial sum); tr[S] = the total foreground free energy
+  for (int i = lane; i <= S; i += 64) tr[i] = i == 0 ? 0.0 : fe[i - 1];
+  for (int i = lane; i < Nb; i += 64) btr[i] = i == 0 ? 0.0 : bfe[i - 1];
   __syncthreads();
-  wave_cumsum_incl(bfe, btr, Nb, lane);
+  wave_cumsum_incl(tr, tr, S + 1, lane);
   __syncthreads();
-  const double tbg = dexp(-fe_tot);
+  wave_cumsum_incl(btr, btr, Nb, lane);
+  __syncthreads();
+  const double tbg = dexp(-tr[S]);
   const double ds = (double)a.depth_scale[r];
   const double g0 = a.d_rgb_values[3 * r], g1 = a.d_rgb_values[3 * r + 1], g2 = a.d_rgb_values[3 * r + 2];
   // background: weights, colour sums, and the sums of depth_values_all = swd / (swa + 1e-8) over [w_fg, tbg * bw] with
@@ -665,7 +676,7 @@ __global__ __launch_bounds__(64) void composite_bg_bwd_kernel(CompositeBgBwdArgs
   double swa = 0.0, swd = 0.0;
   for (int i = lane; i < Nb; i += 64) {
     const size_t p = (size_t)r * Nb + i;
-    const double T = dexp(-(btr[i] - bfe[i]));
+    const double T = dexp(-btr[i]);
     btr[i] = T;
     const double bw = (1.0 - dexp(-bfe[i])) * T;
     const double c0 = a.bg_rgb[3 * p], c1 = a.bg_rgb[3 * p + 1], c2 = a.bg_rgb[3 * p + 2];
@@ -681,7 +692,7 @@ __global__ __launch_bounds__(64) void composite_bg_bwd_kernel(CompositeBgBwdArgs
   // foreground: weights and their sums
   double sw = 0.0, swz = 0.0;
   for (int i = lane; i < S; i += 64) {
-    const double T = dexp(-(tr[i] - fe[i]));
+    const double T = dexp(-tr[i]);
     tr[i] = T;
     const double w = (1.0 - dexp(-fe[i])) * T;
     pre[i] = w;

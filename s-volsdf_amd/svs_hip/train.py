@@ -233,15 +233,11 @@ class MlpBackward:
                                    _ptr(gbuf), _ptr(self.a2buf), _ptr(S.sdf), prec, _ptr(self.abuf), _ptr(self.sbar),
                                    _ptr(acc.absmax) if h2 else None, _ptr(self.a2max) if h2 else None, st),
                    "svs_sdf_bwd_b")
-        # the first row of lin8's weight gradient (a 257-vector reduction over two blocks) only needs pass B's sbar: it
-        # goes to the side stream, beside the weight-gradient launch, instead of in front of it
-        with torch.cuda.stream(side_stream):
-            if side:
-                after_b = torch.cuda.Event(); after_b.record(main)
-                side_stream.wait_event(after_b)
-            _lib.check(L.svs_lin8_row0_grad(_ptr(hbuf), _ptr(self.ubuf), _ptr(self.sbar), n_total, prec, _ptr(acc.row0),
-                                            _stream()), "svs_lin8_row0_grad")
-            join = torch.cuda.Event(); join.record(side_stream)
+        # the first row of lin8's weight gradient: a 257-vector reduction over two blocks (0.04 ms alone).  On the side stream,
+        # beside the weight-gradient launch, it was starved to the length of that launch (one workgroup of the GEMM per CU
+        # leaves it a quarter of the register file): it runs in front of it on this stream
+        _lib.check(L.svs_lin8_row0_grad(_ptr(hbuf), _ptr(self.ubuf), _ptr(self.sbar), n_total, prec, _ptr(acc.row0),
+                                        _stream()), "svs_lin8_row0_grad")
         ev = self.timer_events = ([torch.cuda.Event(enable_timing=True) for _ in range(2)] if self.time_wgrad else None)
         if ev:
             ev[0].record()
@@ -391,10 +387,11 @@ def algorithmic_bytes_per_point(precision=None):
         # sweeps / the weight gradient read of a pair block are 512 B
         half = 512 if precision == F16X2_HALF else 1024
         pair = 1024
-        return {"svs_sdf_bwd_a": 8 * half + 8 * half + 9 * half + 8 * half + (pair if half == 512 else pair),
+        return {"svs_sdf_bwd_a": 8 * half + 8 * half + 9 * half + 8 * half + pair,
                 "svs_sdf_bwd_b": 8 * half + 8 * half + half + half + 8 * half,
                 "wgrad_sdf": 8 * (half + half + half + half) + half + half,
-                "wgrad_radiance": 5 * half + 4 * half + half + 128}
+                "wgrad_radiance": 5 * half + 4 * half + half + 128,
+                "svs_lin8_row0_grad": pair + half}
     blk = 1024
     return {"svs_sdf_bwd_a": (8 + 8 + 9 + 8 + 1) * blk, "svs_sdf_bwd_b": (8 + 8 + 1 + 1 + 8) * blk,
-            "wgrad_sdf": (8 * 4 + 2) * blk, "wgrad_radiance": (5 + 4 + 1) * blk + 128}
+            "wgrad_sdf": (8 * 4 + 2) * blk, "wgrad_radiance": (5 + 4 + 1) * blk + 128, "svs_lin8_row0_grad": 2 * blk}

@@ -90,6 +90,30 @@ def test_volopt_run_render_resume(tmp_path, monkeypatch):
     depth, confi = v.render_mvs(0, epoch)
     assert confi is None and depth.shape == (1, 24, 32) and depth.is_cuda and bool(torch.isfinite(depth).all())
     assert v.train_dataset.mode == "train" and float(depth.max()) > 0
+    # ... and its VALUES against the oracle run the way the reference renders: split_n_pixels rays per forward call
+    # (vsdf.py:237-287), depth_values * scale_factor with the max depth where the accumulated weight is below 0.2 (:259-263)
+    import itertools
+    import svs_oracle as orc
+    ds = v.train_dataset
+    ds.mode = "test"; ds.change_sampling_idx(-1)
+    _, inp0, _ = next(itertools.islice(v.eval_dataloader, 0, None))
+    ds.mode = "train"
+    params = {k: t.detach().cpu().numpy() for k, t in v.model.state_dict().items()}
+    uv0, pose0, K0 = inp0["uv"][0].numpy(), inp0["pose"][0].numpy(), inp0["intrinsics"][0].numpy()
+    dv, acc, same = [], [], []
+    v.model.eval()
+    with torch.no_grad():
+        for lo in range(0, len(uv0), v.split_n_pixels):
+            o = orc.render_forward(params, uv0[lo:lo + v.split_n_pixels], pose0, K0, beta_param=params["density.beta"], fast=-1)
+            g = v.model({k: t.cuda() for k, t in dict(inp0, uv=inp0["uv"][:, lo:lo + v.split_n_pixels]).items()}, fast=-1)
+            dv.append(np.asarray(o["depth_values"]).reshape(-1)); acc.append(np.asarray(o["weights"]).sum(1))
+            same.append(np.abs(g["depth_vals"].cpu().numpy() - np.asarray(o["depth_vals"])).max(-1) < 3e-4)
+    dv, acc, same = np.concatenate(dv) * v.scale_factor, np.concatenate(acc), np.concatenate(same)
+    ref_depth = np.where(acc < 0.2, dv.max(), dv).reshape(24, 32)
+    got_depth = depth[0].cpu().numpy()
+    ok = same.reshape(24, 32) & (np.abs(acc - 0.2).reshape(24, 32) > 1e-3)      # same samples, away from the mask threshold
+    assert ok.mean() > 0.85, ok.mean()
+    assert float(np.abs(got_depth - ref_depth)[ok].max()) < 3e-4 * max(1.0, float(v.scale_factor))
 
     # resume: a second VolOpt picks the latest run folder and continues from its checkpoints
     v.save_checkpoints(epoch)
