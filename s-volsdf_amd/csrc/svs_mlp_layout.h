@@ -24,6 +24,7 @@ constexpr int kBgPeDim = 84;              // 4 * (1 + 2 * 10): PE-10 of the 4-D 
 constexpr int kBgChunk0F4 = kHdrF4 + 6 * 128;   // bg implicit layer 0: 6 fp16x2 k-steps
 constexpr int kW1TF4 = 4 * 64;            // bg radiance lin1 transposed: 4 tiles x 64 lanes x 4 k-steps
 constexpr int kBgRgbChunk0F4 = kHdrF4 + 18 * 128;   // bg radiance layer 0: 16 feature k-steps + 2 k-steps of view-PE rows
+constexpr int kChunk0WF4 = kHdrF4 + 2 * 2 * 128;    // kSdfFwd0W: header + [2 sub-tiles][2 k-steps][hi, mid][64 lanes]
 
 // chunk kinds (svs_pack.hip packs them, the kernels consume them in stream order)
 enum ChunkKind {
@@ -46,6 +47,7 @@ enum ChunkKind {
   kBgRgbFwd1,     // bg radiance layer 1: 3 rows, K = 128
   kBgRgbW1T,      // bg radiance lin1^T (3 output rows), short chunk (4 tiles)
   kBgRgbRev0,     // bg radiance lin0^T onto the 256 feature rows, K = 128
+  kSdfFwd0W,      // SDF layer 0 for the 16-point-wave kernels (kFmtF16x2W): K = 39 PE rows -> 64 = 2 k-steps of 32
 };
 constexpr int kNoBias = 0x100;            // flag: zero header
 
@@ -53,7 +55,14 @@ constexpr int kNoBias = 0x100;            // flag: zero header
 //   kFmtF32   k-step = 2 input rows, one float per lane, [k-step/4][lane][4]     (v_mfma_f32_32x32x2_f32)
 //   kFmtF16x2 k-step = 16 input rows, per k-step 64 lanes x 8 fp16 of the hi piece, then of the mid piece
 //             (v_mfma_f32_32x32x16_f16, svs_mlp_h2_dev.h).  Same bytes per chunk as kFmtF32.
+//   kFmtF16x2W (internal: the streams of the 16-point-wave kernels, svs_mlp_w16.hip): v_mfma_f32_16x16x32_f16.  A chunk is
+//             still 32 output rows = two 16-row sub-tiles u; k-step = 32 input rows; fragment index
+//             ((u * KS + s) * 2 + piece) * 64 + lane, lane = 16 g + row: the lane's 8 fp16 are input rows
+//             16 (2 s + (j >> 2)) + 4 g + (j & 3) -- registers 0..3 of lane group g of the producing layer's 16-row
+//             output tiles 2 s and 2 s + 1, so a layer's accumulators are the next layer's B fragments as they stand.
+//             Header: float4 index u * 64 + lane = the bias of rows 4 g .. 4 g + 3 of sub-tile u.
 enum BodyFormat { kFmtF32 = 0, kFmtF16x2 = 1 };
+constexpr int kFmtF16x2W = 3;
 // `precision` of the C-ABI: the two above, and kFmtF16x2Half = fp16x2 kernels whose gradient-only activation blocks are
 // stored as ONE fp16 piece (svs_blocks_h2.h, GP = false): half the backward's block bytes, parameter gradients 3e-4 ... 8e-4
 // of a tensor's largest entry off instead of < 1e-5.  Weight streams are packed identically for both fp16x2 values.
@@ -67,6 +76,7 @@ __host__ __device__ constexpr int chunk_f4(int kind) {
        : kind == kBgFwd0 ? kBgChunk0F4
        : kind == kBgRgbFwd0 ? kBgRgbChunk0F4
        : kind == kBgRgbW1T ? kW1TF4
+       : kind == kSdfFwd0W ? kChunk0WF4
        : kChunkF4;
 }
 
@@ -76,9 +86,10 @@ enum StreamKind {
   kStreamBgFwd,      // bg implicit network: trunk + head vector + feature head
   kStreamBgTrain,    // bg implicit network backward: transposed feature head + transposed trunk
   kStreamBgRgbFwd, kStreamBgRgbBwd,
+  kStreamSdfFwdW,    // SDF forward (trunk + head vector) in the kFmtF16x2W encoding: svs_mlp_w16.hip
   kNumStreams
 };
-constexpr bool stream_is_bg(int which) { return which >= kStreamBgFwd; }
+constexpr bool stream_is_bg(int which) { return which >= kStreamBgFwd && which <= kStreamBgRgbBwd; }
 // offsets inside the SDF training stream (float4): pass A starts at 0, pass B after the 63 forward chunks
 constexpr size_t kSdfTrainPassBF4 = 8 * (size_t)kChunk0F4 + 55 * (size_t)kChunkF4;
 

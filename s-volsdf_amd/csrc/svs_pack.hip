@@ -74,6 +74,7 @@ __device__ __forceinline__ float body_value(const LayerPtrs& w, const float* sca
   const float inv_sqrt2 = 0.70710678118654752f;
   switch (kind) {
     case kSdfFwd0:
+    case kSdfFwd0W:
       return q0 < 39 ? weff(w, scale, 0, 32 * t + col32, q0, 39) : 0.0f;
     case kBgFwd0:
       return q0 < kBgPeDim ? weff(w, scale, 0, 32 * t + col32, q0, kBgPeDim) : 0.0f;
@@ -135,7 +136,7 @@ __device__ __forceinline__ float body_value(const LayerPtrs& w, const float* sca
 // bias of output row o_local = rho(r) + 4*half of tile t (header register r)
 __device__ __forceinline__ float header_value(const LayerPtrs& w, int kind, int l, int t, int o_local, int net) {
   switch (kind) {
-    case kSdfFwd0: case kBgFwd0: return w.b[0][32 * t + o_local];
+    case kSdfFwd0: case kSdfFwd0W: case kBgFwd0: return w.b[0][32 * t + o_local];
     case kBgRgbFwd0: { const int o = 32 * t + o_local; return o < 128 ? w.b[0][o] : 0.0f; }
     case kBgRgbFwd1: { const int o = 32 * t + o_local; return o < 3 ? w.b[1][o] : 0.0f; }
     case kSdfFwd: { const int o = 32 * t + o_local; return o < sdf_rows(l, net) ? w.b[l][o] : 0.0f; }
@@ -175,6 +176,33 @@ __global__ __launch_bounds__(256) void pack_stream_kernel(LayerPtrs w, const flo
       const int tt = wi / 256, lane = (wi & 255) >> 2, s = wi & 3;
       const int k = rho(s) + 4 * (lane >> 5);
       dst[wi] = k < 3 ? weff(w, scale, 1, k, 32 * tt + (lane & 31), 128) : 0.0f;
+    }
+    return;
+  }
+  if (fmt == kFmtF16x2W) {
+    // ---- the 16-point-wave encoding (svs_mlp_layout.h): header float4 u * 64 + lane = bias of rows 16 u + 4 g .. + 3
+    for (int wi = tid; wi < kHdrF4 * 4; wi += kPackStride) {
+      const int f4 = wi >> 2, c = wi & 3, u = f4 >> 6, lane = f4 & 63, g = lane >> 4;
+      dst[wi] = (nobias || u > 1) ? 0.0f : header_value(w, kind, l, t, 16 * u + 4 * g + c, net);
+    }
+    float* bodyw = dst + kHdrF4 * 4;
+    const int ks = kind == kSdfFwd0W ? 2 : 8;
+    uint4* fragw = reinterpret_cast<uint4*>(bodyw);
+    for (int f = tid; f < 2 * ks * 2 * 64; f += kPackStride) {
+      const int lane = f & 63, piece = (f >> 6) & 1, s = (f >> 7) % ks, u = (f >> 7) / ks, g = lane >> 4, row = lane & 15;
+      unsigned short ebits[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int crow = 16 * (2 * s + (j >> 2)) + 4 * g + (j & 3);        // input feature (kSdfFwd0W: PE index q0)
+        const float wv = body_value(w, scale, kind, l, t, 16 * u + row, crow, 32 * s + 8 * g + j, -1, net);
+        const _Float16 hi = (_Float16)wv;
+        const _Float16 mid = (_Float16)(wv - (float)hi);
+        ebits[j] = __builtin_bit_cast(unsigned short, piece == 0 ? hi : mid);
+      }
+      uint4 v;
+      v.x = ebits[0] | ((unsigned)ebits[1] << 16); v.y = ebits[2] | ((unsigned)ebits[3] << 16);
+      v.z = ebits[4] | ((unsigned)ebits[5] << 16); v.w = ebits[6] | ((unsigned)ebits[7] << 16);
+      fragw[f] = v;
     }
     return;
   }
@@ -286,6 +314,12 @@ static StreamTable& table_for(int which) {
       t.add(kBgRgbW1T, 1, 0);
       for (int i = 0; i < 8; ++i) t.add(kBgRgbRev0, 0, i);
       break;
+    case kStreamSdfFwdW:
+      for (int i = 0; i < 8; ++i) t.add(kSdfFwd0W, 0, i);
+      for (int l = 1; l < 8; ++l)
+        for (int i = 0; i < (l == 3 ? 7 : 8); ++i) t.add(kSdfFwd, l, i);
+      t.add(kSdfFwd, 8, 0);     // the head: rows 0..31 of lin8 as one more tile (row 0 = sdf; the kernel runs its first sub-tile)
+      break;
   }
   return t;
 }
@@ -300,7 +334,8 @@ extern "C" {
 
 // which: 0 SDF forward, 1 SDF full (forward + feature head + gradient pass), 2 SDF training backward,
 //        3 radiance forward, 4 radiance backward; background networks (fp16x2 only): 5 bg implicit forward,
-//        6 bg implicit backward, 7 bg radiance forward, 8 bg radiance backward.  precision: body encoding of the MFMA chunks, 0 float32, 1 fp16x2.
+//        6 bg implicit backward, 7 bg radiance forward, 8 bg radiance backward; 9 SDF forward for the 16-point-wave kernel
+//        (svs_sdf_vals16, fp16x2 only).  precision: body encoding of the MFMA chunks, 0 float32, 1 fp16x2.
 // Stream sizes do not depend on the precision.
 size_t svs_stream_bytes(int which) {
   if (which < 0 || which >= kNumStreams) return 0;
@@ -320,6 +355,10 @@ int svs_pack_stream(int which, int precision, const float* const* weight_v, cons
   const int nl = is_rgb ? (net ? 2 : 5) : 9;
   if (net && !is_h2(precision)) { set_error("svs_pack_stream: the background networks are fp16x2 only"); return SVS_EINVAL; }
   if (is_h2(precision)) precision = kFmtF16x2;     // one body encoding for both fp16x2 block formats
+  if (which == kStreamSdfFwdW) {
+    if (precision != kFmtF16x2) { set_error("svs_pack_stream: stream 9 (16-point-wave SDF forward) is fp16x2 only"); return SVS_EINVAL; }
+    precision = kFmtF16x2W;
+  }
   LayerPtrs w = {};
   for (int l = 0; l < nl; ++l) {
     w.v[l] = weight_v[l]; w.g[l] = weight_g ? weight_g[l] : nullptr; w.b[l] = bias[l];

@@ -80,6 +80,12 @@ class PackedMlp:
         self.precision = default_precision() if precision is None else int(precision)
         self.sdf_stream = torch.empty(L.svs_stream_bytes(1) // 4, device=device)
         self.rgb_stream = torch.empty(L.svs_stream_bytes(3) // 4, device=device)
+        # the sampler's sdf-only evaluations run on the 16-point-wave kernel (two waves per SIMD, csrc/svs_mlp_w16.hip), which
+        # reads its own encoding of the forward stream; SVS_SDF_TILE=32 keeps them on the 32-point kernel
+        import os
+        self.w16 = is_h2(self.precision) and os.environ.get("SVS_SDF_TILE", "16") == "16"
+        self.sdf_stream16 = torch.empty(L.svs_stream_bytes(9) // 4, device=device) if self.w16 else None
+        self._ws16 = torch.empty(L.svs_pack_workspace_bytes() // 4, device=device) if self.w16 else None
         # one row-norm workspace per stream: the fused train step packs the two on different HIP streams at the same time
         self._ws = torch.empty(L.svs_pack_workspace_bytes() // 4, device=device)
         self._ws_rgb = torch.empty(L.svs_pack_workspace_bytes() // 4, device=device)
@@ -93,6 +99,9 @@ class PackedMlp:
         self._keep = (v, b, g)
         _lib.check(L.svs_pack_stream(1, self.precision, _ptr_array(v), _ptr_array(g) if g else None, _ptr_array(b),
                                      _ptr(self._ws), _ptr(self.sdf_stream), _stream()), "svs_pack_stream(sdf)")
+        if self.w16:
+            _lib.check(L.svs_pack_stream(9, self.precision, _ptr_array(v), _ptr_array(g) if g else None, _ptr_array(b),
+                                         _ptr(self._ws16), _ptr(self.sdf_stream16), _stream()), "svs_pack_stream(sdf w16)")
 
     def pack_rgb(self, weight_v, weight_g, bias):
         L = _lib.load()
@@ -135,6 +144,11 @@ def sdf_vals(packed, src, sphere_radius, sphere_scale, out=None, gate=None, clam
     per group of gate_points points (0: one group), gate_stride ints apart: groups whose flag is 0 are skipped."""
     L = _lib.load()
     sdf = out if out is not None else torch.empty(src.n, 1, device=src.device)
+    if getattr(packed, "w16", False):
+        _lib.check(L.svs_sdf_vals16(*src.args(), _ptr(packed.sdf_stream16), float(sphere_radius), float(sphere_scale),
+                                    int(clamp_n), _ptr(sdf), ctypes.c_void_p(gate) if gate else None, int(gate_points),
+                                    int(gate_stride), _stream()), "svs_sdf_vals16")
+        return sdf
     _lib.check(L.svs_sdf_vals(*src.args(), _ptr(packed.sdf_stream), packed.precision, float(sphere_radius), float(sphere_scale),
                               int(clamp_n), _ptr(sdf), ctypes.c_void_p(gate) if gate else None, int(gate_points),
                               int(gate_stride), _stream()), "svs_sdf_vals")
