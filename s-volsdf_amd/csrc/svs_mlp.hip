@@ -15,6 +15,7 @@
 //     with conflict-free ds_read_b128;
 //   * exact float32 MFMA (v_mfma_f32_32x32x2_f32): the 1e-4 parity bound of the path rules out bf16.
 #include "svs_mlp_host.h"
+#include <cstdlib>
 #include "svs_mlp_args.h"
 
 namespace svs {
@@ -319,7 +320,10 @@ int svs_sdf_vals(const float* points, int n_points, const float* cam, int cam_st
   a.gate_points = gate_points > 0 ? gate_points : 0x7fffff80; a.gate_stride = gate_stride;
   if (gate && a.gate_points % kWgPts) { set_error("svs_sdf_vals: gate_points must be a multiple of %d", kWgPts); return SVS_EINVAL; }
   a.clamp_n = clamp_n < 0 ? a.src.P : clamp_n;
-  if (is_h2(precision)) return launch_sdf_only_h2(a, (hipStream_t)hip_stream);
+  if (is_h2(precision)) {
+    static const bool pair = !(getenv("SVS_MLP_PAIR") && atoi(getenv("SVS_MLP_PAIR")) == 0);
+    return pair ? launch_sdf_only_kp(a, (hipStream_t)hip_stream) : launch_sdf_only_h2(a, (hipStream_t)hip_stream);
+  }
   if (precision != kFmtF32) { set_error("svs_sdf_vals: unknown precision %d", precision); return SVS_EINVAL; }
   static int once = set_lds(sdf_only_kernel, kLdsBytes, "svs_sdf_vals");
   if (once) return once;

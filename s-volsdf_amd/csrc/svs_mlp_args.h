@@ -51,6 +51,7 @@ typedef StreamT<kRgbBufF4> RgbStream;
 
 // fp16x2 launches (svs_mlp_h2.hip)
 int launch_sdf_only_h2(const SdfOnlyArgs& a, hipStream_t s);
+int launch_sdf_only_kp(const SdfOnlyArgs& a, hipStream_t s);       // K-split pairs, two waves per SIMD (svs_mlp_h2p.hip)
 int launch_sdf_full_h2(const SdfFullArgs& a, bool grad_pair, hipStream_t s);   // grad_pair: ghat blocks as both pieces
 int launch_rgb_h2(const RgbArgs& a, bool grad_pair, hipStream_t s);           // grad_pair: r_l stored with both pieces
 

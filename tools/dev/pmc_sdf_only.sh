@@ -5,9 +5,9 @@ O=$R/gpurun_out/pmc_sdf_only
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 P="SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"
-SVS_SDF_TILE=32 rocprofv3 --pmc $P -d $O/t32 --output-format csv -- python3 $R/tools/dev/time_sdf_only.py > $O/t32.log 2>&1
+SVS_SDF_TILE=32 SVS_MLP_PAIR=0 rocprofv3 --pmc $P -d $O/t32 --output-format csv -- python3 $R/tools/dev/time_sdf_only.py > $O/t32.log 2>&1
 SVS_SDF_TILE=16 rocprofv3 --pmc $P -d $O/t16 --output-format csv -- python3 $R/tools/dev/time_sdf_only.py > $O/t16.log 2>&1
-SVS_SDF_TILE=16 SVS_W16_WAVES=4 rocprofv3 --pmc $P -d $O/t16w4 --output-format csv -- python3 $R/tools/dev/time_sdf_only.py > $O/t16w4.log 2>&1
+SVS_SDF_TILE=32 SVS_MLP_PAIR=1 rocprofv3 --pmc $P -d $O/t16w4 --output-format csv -- python3 $R/tools/dev/time_sdf_only.py > $O/t16w4.log 2>&1
 cd $R
 find $O -name '*agent_info.csv' -delete
 python3 - <<'PY'
