@@ -79,6 +79,11 @@ int svs_sdf_vals(const float* points, int n_points, const float* cam, int cam_st
 int svs_sdf_vals16(const float* points, int n_points, const float* cam, int cam_stride, const float* dirs, const float* z,
                    int S, int n_rays, const float* stream, float sphere_radius, float sphere_scale, int clamp_n, float* sdf,
                    const int* gate, int gate_points, int gate_stride, void* hip_stream);
+/* ... and by the K-split-pair kernel (two waves per SIMD on the same 32 points, csrc/svs_mlp_h2p.hip): the stream of
+ * svs_sdf_vals (which = 0 or 1, fp16x2).  Both variants are experiments kept for A/B runs. */
+int svs_sdf_vals_pair(const float* points, int n_points, const float* cam, int cam_stride, const float* dirs, const float* z,
+                      int S, int n_rays, const float* stream, float sphere_radius, float sphere_scale, int clamp_n, float* sdf,
+                      const int* gate, int gate_points, int gate_stride, void* hip_stream);
 /* svs_sdf_outputs: ImplicitNetwork.get_outputs (network.py:105-123) and .gradient (:90-103):
  *   sdf (P), grad = d sdf/dx (P,3), feat_tiles (svs_feat_tiles_bytes; wave-tile layout, may be NULL),
  *   hbuf (svs_sdf_hbuf_bytes): the activations h_1..h_8 kept for the gradient pass / training backward;

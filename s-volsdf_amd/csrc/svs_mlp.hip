@@ -320,15 +320,28 @@ int svs_sdf_vals(const float* points, int n_points, const float* cam, int cam_st
   a.gate_points = gate_points > 0 ? gate_points : 0x7fffff80; a.gate_stride = gate_stride;
   if (gate && a.gate_points % kWgPts) { set_error("svs_sdf_vals: gate_points must be a multiple of %d", kWgPts); return SVS_EINVAL; }
   a.clamp_n = clamp_n < 0 ? a.src.P : clamp_n;
-  if (is_h2(precision)) {
-    static const bool pair = !(getenv("SVS_MLP_PAIR") && atoi(getenv("SVS_MLP_PAIR")) == 0);
-    return pair ? launch_sdf_only_kp(a, (hipStream_t)hip_stream) : launch_sdf_only_h2(a, (hipStream_t)hip_stream);
-  }
+  if (is_h2(precision)) return launch_sdf_only_h2(a, (hipStream_t)hip_stream);
   if (precision != kFmtF32) { set_error("svs_sdf_vals: unknown precision %d", precision); return SVS_EINVAL; }
   static int once = set_lds(sdf_only_kernel, kLdsBytes, "svs_sdf_vals");
   if (once) return once;
   sdf_only_kernel<<<(a.src.P + kWgPts - 1) / kWgPts, kThreads, kLdsBytes, (hipStream_t)hip_stream>>>(a);
   return check_launch("svs_sdf_vals");
+}
+
+// svs_sdf_vals by the K-split-pair kernel (two waves per SIMD on the same 32 points, csrc/svs_mlp_h2p.hip): same stream
+// (fp16x2), same arguments.  An experiment kept for A/B runs; measured slower than svs_sdf_vals.
+int svs_sdf_vals_pair(const float* points, int n_points, const float* cam, int cam_stride, const float* dirs, const float* z,
+                      int S, int n_rays, const float* stream, float sphere_radius, float sphere_scale, int clamp_n, float* sdf,
+                      const int* gate, int gate_points, int gate_stride, void* hip_stream) {
+  SdfOnlyArgs a;
+  if (int rc = fill_src(a.src, points, n_points, cam, cam_stride, dirs, z, S, n_rays, "svs_sdf_vals_pair")) return rc;
+  if (!stream || !sdf) { set_error("svs_sdf_vals_pair: null stream/sdf"); return SVS_EINVAL; }
+  a.stream = reinterpret_cast<const f32x4*>(stream); a.sdf = sdf;
+  a.sphere_radius = sphere_radius; a.sphere_scale = sphere_scale; a.gate = gate;
+  a.gate_points = gate_points > 0 ? gate_points : 0x7fffff80; a.gate_stride = gate_stride;
+  if (gate && a.gate_points % kWgPts) { set_error("svs_sdf_vals_pair: gate_points must be a multiple of %d", kWgPts); return SVS_EINVAL; }
+  a.clamp_n = clamp_n < 0 ? a.src.P : clamp_n;
+  return launch_sdf_only_kp(a, (hipStream_t)hip_stream);
 }
 
 size_t svs_sdf_hbuf_bytes(int n_points) { return (size_t)wave_tiles(n_points) * 8 * 128 * 64 * sizeof(float); }

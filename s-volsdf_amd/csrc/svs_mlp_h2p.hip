@@ -83,7 +83,7 @@ struct TrunkEpiP {
 // one 256 -> 256 trunk layer (l >= 1).  On entry the layer's first chunk is current; on return the next layer's is.
 template <bool LAST>
 __device__ __forceinline__ void trunk_layer_p(StreamP& st, const PiecesP& x, TrunkEpiP<LAST>& ep, const Xchg& xc, int lane,
-                                              unsigned& c_loop, unsigned& c_sync) {
+                                              unsigned& c_loop, unsigned& c_sync, Trace& tr) {
   float mine[8];
   const int n_tiles = ep.splice ? 7 : 8;
 #pragma unroll
@@ -94,14 +94,14 @@ __device__ __forceinline__ void trunk_layer_p(StreamP& st, const PiecesP& x, Tru
     f32x16 acc;
     {
     KP_T0();
-    if (t == 0) acc = tile_mma_p<kChunkF4>(st, x, lane, ep.role, NoE(), NoE(), NoE(), NoP());
+    if (t == 0) acc = tile_mma_p<kChunkF4>(st, x, lane, ep.role, NoE(), NoE(), NoE(), NoP(), tr);
     else acc = tile_mma_p<kChunkF4>(st, x, lane, ep.role, [&](int s) { ep.a(s); }, [&](int s) { ep.a2(s); },
                                     [&](int s) { ep.b(t - 1, s); },
                                     [&]() {
                                       if (t >= 2) ep.finish(t - 2);
 #pragma unroll
                                       for (int j = 0; j < 4; ++j) { ep.prev[j] = mine[j] + r0[j]; ep.prev[4 + j] = mine[4 + j] + r1[j]; }
-                                    });
+                                    }, tr);
     asm volatile("" : "+v"(acc));
     KP_T1(c_loop);
     }
@@ -109,7 +109,9 @@ __device__ __forceinline__ void trunk_layer_p(StreamP& st, const PiecesP& x, Tru
     KP_T0();
     own_half(acc, ep.role, mine);
     xc.send(acc, t & 1, lane);
+    KP_MARK(tr);
     st.advance();
+    KP_MARK(tr);
     KP_T1(c_sync);
     }
   }
@@ -153,6 +155,12 @@ __global__ __launch_bounds__(kThreadsP, 1) void sdf_only_kp_kernel(SdfOnlyArgs a
   pe.compute(x0, x1, x2);
 
   PiecesP xa, xb;
+  Trace tr;
+  tr.on = false;
+  const bool trace_wg = blockIdx.x == gridDim.x - 1;
+#ifdef KP_TRACE
+  tr.n = 0;
+#endif
   unsigned c_loop = 0, c_sync = 0;
   {
     // ---- layer 0 : 39(48) -> 256.  K is three k-steps: both waves of a pair compute whole tiles and keep their half
@@ -176,15 +184,15 @@ __global__ __launch_bounds__(kThreadsP, 1) void sdf_only_kp_kernel(SdfOnlyArgs a
     // (one epilogue object per destination: a pointer that changes at run time would force the pieces into scratch)
     TrunkEpiP<false> ep;
     ep.pe = &pe; ep.lane = lane; ep.half = half; ep.role = role; ep.xn = &xb; ep.splice = l == 3;
-    trunk_layer_p<false>(st, xa, ep, xc, lane, c_loop, c_sync);
+    tr.on = trace_wg && l == 5; trunk_layer_p<false>(st, xa, ep, xc, lane, c_loop, c_sync, tr); tr.on = false;
     TrunkEpiP<false> ep2;
     ep2.pe = &pe; ep2.lane = lane; ep2.half = half; ep2.role = role; ep2.xn = &xa; ep2.splice = false;
-    trunk_layer_p<false>(st, xb, ep2, xc, lane, c_loop, c_sync);
+    trunk_layer_p<false>(st, xb, ep2, xc, lane, c_loop, c_sync, tr);
   }
   // ---- layer 7: output kept in float32
   TrunkEpiP<true> ep7;
   ep7.xn = nullptr; ep7.pe = &pe; ep7.lane = lane; ep7.half = half; ep7.role = role; ep7.splice = false;
-  trunk_layer_p<true>(st, xa, ep7, xc, lane, c_loop, c_sync);
+  trunk_layer_p<true>(st, xa, ep7, xc, lane, c_loop, c_sync, tr);
   const float* y8 = ep7.y8;
   // ---- head: current chunk = VEC (W8 row 0 in accumulator order as float32, b8[0]); this wave's 64 of the 256 terms
   float acc = 0.0f;
@@ -209,6 +217,12 @@ __global__ __launch_bounds__(kThreadsP, 1) void sdf_only_kp_kernel(SdfOnlyArgs a
     sdf = __builtin_fminf(sdf, a.sphere_scale * (a.sphere_radius - nrm));
   }
   if (role == 0 && half == 0 && p < a.src.P) a.sdf[p] = sdf;
+#ifdef KP_TRACE
+  if (trace_wg && lane == 0) {
+    for (int i = 0; i < 80; ++i) a.sdf[wave * 80 + i] = (float)(tr.t[i] - tr.t[0]);
+    a.sdf[640 + wave] = (float)(tr.t[0] & 0xffffff);
+  }
+#endif
 #ifdef KP_STAMP
   __syncthreads();
   if (lane == 0) { a.sdf[(size_t)blockIdx.x * kWgPts + 2 * wave] = (float)c_loop; a.sdf[(size_t)blockIdx.x * kWgPts + 2 * wave + 1] = (float)c_sync; }

@@ -25,6 +25,17 @@ namespace svs {
 namespace mlp {
 namespace kp {
 
+// diagnostic build (-DKP_TRACE, never in the product): the waves of the LAST workgroup stamp s_memtime in front of every
+// MFMA block and behind its vector block during one layer; the kernel writes the stamps over the first outputs
+#ifdef KP_TRACE
+struct Trace { unsigned t[80]; int n; bool on; };
+__device__ __forceinline__ void trace_mark(Trace& tr) { if (tr.on && tr.n < 80) tr.t[tr.n++] = (unsigned)__builtin_amdgcn_s_memtime(); }
+#define KP_MARK(tr) trace_mark(tr)
+#else
+struct Trace { bool on; };
+#define KP_MARK(tr)
+#endif
+
 constexpr int kWavesP = 8;
 constexpr int kThreadsP = kWavesP * 64;
 constexpr int kXchgTile = 2048;                        // bytes one wave sends per tile: 8 registers x 64 lanes
@@ -98,32 +109,64 @@ struct NoP { __device__ __forceinline__ void operator()() const {} };
 // from zero.  ea / eb / ec(s): slices of the previous tile's epilogue behind the three MFMAs of k-step s; pre(): vector work
 // issued while the tile waits for its first LDS reads; piece i of the next chunk's LDS-DMA goes behind k-step i.
 template <int N16NEXT, typename EA, typename EB, typename EC, typename Pre>
-__device__ __forceinline__ f32x16 tile_mma_p(StreamP& st, const PiecesP& x, int lane, int role, EA ea, EB eb, EC ec, Pre pre) {
+__device__ __forceinline__ f32x16 tile_mma_p(StreamP& st, const PiecesP& x, int lane, int role, EA ea, EB eb, EC ec, Pre pre,
+                                              Trace& tr) {
   const f32x4* chunk = st.cur_buf();
   f32x16 acc = tile_bias(chunk, lane);
   if (role) acc = (f32x16)(0.0f);
   const f16x8* a_ptr = reinterpret_cast<const f16x8*>(chunk + kHdrF4) + lane + role * 128;
-  f16x8 ah = a_ptr[0], am = a_ptr[64];
+  // MFMAs in blocks of KP_GROUP k-steps issued back to back, each followed by the vector work of those k-steps (epilogue
+  // slices, the next fragments' LDS reads, an LDS-DMA piece).  With two waves per SIMD the matrix core is shared at MFMA
+  // granularity: a partner can only use a gap of >= 32 contiguous cycles, so vector work sliced between single MFMAs (the
+  // one-wave kernels' schedule) leaves the partner nothing; blocks make the two waves alternate -- one's vector block under
+  // the other's MFMA block.
+#ifndef KP_GROUP
+#define KP_GROUP 1
+#endif
+  constexpr int G = KP_GROUP;
+  f16x8 fh[G + 1 > 8 ? 8 : 2 * G], fm[G + 1 > 8 ? 8 : 2 * G];      // fragments of the current and the next block
+#pragma unroll
+  for (int i = 0; i < G; ++i) { fh[i] = a_ptr[(4 * i) * 64]; fm[i] = a_ptr[(4 * i + 1) * 64]; }
   __builtin_amdgcn_sched_barrier(0);
   pre();
+  // The two waves of a SIMD start every tile together (barrier) and, running the same order, stay roughly in lockstep (KP_TRACE
+  // stamps).  -DKP_FLIP makes role 1 run each block pair in the opposite order, vector block first, so that one wave's vector
+  // block would lie under the other's MFMA block: measured SLOWER (0.364 vs 0.337 ms for the sdf-only evaluation of 131 072
+  // points; the one-wave-per-SIMD kernel: 0.302).
 #pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    f16x8 nh, nm;
-    __builtin_amdgcn_sched_barrier(0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, x.h[s], acc, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (s + 1 < 8) { nh = a_ptr[(4 * s + 4) * 64]; nm = a_ptr[(4 * s + 5) * 64]; }
-    ea(s);
-    __builtin_amdgcn_sched_barrier(0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, x.m[s], acc, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    eb(s);
-    __builtin_amdgcn_sched_barrier(0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, x.h[s], acc, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    ec(s);
-    if (N16NEXT > 0) st.template piece<N16NEXT>(s);
-    if (s + 1 < 8) { ah = nh; am = nm; }
+  for (int b = 0; b < 8 / G; ++b) {
+    const int cur = (b & 1) * G, nxt = ((b + 1) & 1) * G;
+    auto mblock = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      KP_MARK(tr);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        const int s = b * G + i;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fm[cur + i], x.h[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[cur + i], x.m[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[cur + i], x.h[s], acc, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto vblock = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      KP_MARK(tr);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        const int s = b * G + i;
+        if (s + G < 8) { fh[nxt + i] = a_ptr[(4 * (s + G)) * 64]; fm[nxt + i] = a_ptr[(4 * (s + G) + 1) * 64]; }
+        ea(s); eb(s); ec(s);
+        if (N16NEXT > 0) st.template piece<N16NEXT>(s);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+#ifdef KP_FLIP
+    if (role == 0) { mblock(); vblock(); } else { vblock(); mblock(); }
+#else
+    mblock(); vblock();
+#endif
   }
   if (N16NEXT > 0) st.template done<N16NEXT>();
   return acc;

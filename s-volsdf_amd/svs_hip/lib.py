@@ -50,6 +50,8 @@ SIGNATURES = {
                              c_int, c_int, _P]),
     "svs_sdf_vals16": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, _P, c_float, c_float, c_int, _P, _P,
                                c_int, c_int, _P]),
+    "svs_sdf_vals_pair": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, _P, c_float, c_float, c_int, _P, _P,
+                                  c_int, c_int, _P]),
     "svs_sdf_hbuf_bytes": (c_size_t, [c_int]),
     "svs_feat_tiles_bytes": (c_size_t, [c_int]),
     "svs_sdf_outputs": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, _P, c_int, c_float, c_float, c_int, _P, _P,

@@ -74,16 +74,21 @@ def default_precision():
 class PackedMlp:
     """Packed weight streams of one ImplicitNetwork / RenderingNetwork pair (rebuilt after every optimiser step)."""
 
-    def __init__(self, device, precision=None):
+    def __init__(self, device, precision=None, sdf_kernel=None):
         L = _lib.load()
         self.device = device
         self.precision = default_precision() if precision is None else int(precision)
         self.sdf_stream = torch.empty(L.svs_stream_bytes(1) // 4, device=device)
         self.rgb_stream = torch.empty(L.svs_stream_bytes(3) // 4, device=device)
-        # the sampler's sdf-only evaluations run on the 16-point-wave kernel (two waves per SIMD, csrc/svs_mlp_w16.hip), which
-        # reads its own encoding of the forward stream; SVS_SDF_TILE=32 keeps them on the 32-point kernel
+        # sdf_kernel / SVS_SDF_KERNEL: which kernel runs the sampler's sdf-only evaluations -- "32" (default: one wave per SIMD,
+        # 32 points per wave), "16" (two waves per SIMD, 16-point waves, csrc/svs_mlp_w16.hip: its own encoding of the forward
+        # stream) or "pair" (two waves per SIMD on the same 32 points, csrc/svs_mlp_h2p.hip).  The two-wave variants are
+        # experiments kept for A/B runs: same speed / slower (DESIGN.md section 4)
         import os
-        self.w16 = is_h2(self.precision) and os.environ.get("SVS_SDF_TILE", "16") == "16"
+        self.sdf_kernel = (sdf_kernel or os.environ.get("SVS_SDF_KERNEL", "32")) if is_h2(self.precision) else "32"
+        if self.sdf_kernel not in ("32", "16", "pair"):
+            raise ValueError(f"SVS_SDF_KERNEL must be 32, 16 or pair, not {self.sdf_kernel!r}")
+        self.w16 = self.sdf_kernel == "16"
         self.sdf_stream16 = torch.empty(L.svs_stream_bytes(9) // 4, device=device) if self.w16 else None
         self._ws16 = torch.empty(L.svs_pack_workspace_bytes() // 4, device=device) if self.w16 else None
         # one row-norm workspace per stream: the fused train step packs the two on different HIP streams at the same time
@@ -144,6 +149,11 @@ def sdf_vals(packed, src, sphere_radius, sphere_scale, out=None, gate=None, clam
     per group of gate_points points (0: one group), gate_stride ints apart: groups whose flag is 0 are skipped."""
     L = _lib.load()
     sdf = out if out is not None else torch.empty(src.n, 1, device=src.device)
+    if getattr(packed, "sdf_kernel", "32") == "pair":
+        _lib.check(L.svs_sdf_vals_pair(*src.args(), _ptr(packed.sdf_stream), float(sphere_radius), float(sphere_scale),
+                                       int(clamp_n), _ptr(sdf), ctypes.c_void_p(gate) if gate else None, int(gate_points),
+                                       int(gate_stride), _stream()), "svs_sdf_vals_pair")
+        return sdf
     if getattr(packed, "w16", False):
         _lib.check(L.svs_sdf_vals16(*src.args(), _ptr(packed.sdf_stream16), float(sphere_radius), float(sphere_scale),
                                     int(clamp_n), _ptr(sdf), ctypes.c_void_p(gate) if gate else None, int(gate_points),

@@ -231,6 +231,44 @@ def fx_sampler():
          inv_4log=(1.0 / (4.0 * torch.log(torch.tensor(0.1 + 1.0)))).numpy())
 
 
+def fx_sampler_r256():
+    """The eval sampler of the reference at R = 256 rays (fast = -1) for beta in {0.1, 0.01, 0.001}, stored compactly: per
+    round the sdf values the reference evaluated, its carried beta, its searchsorted indices (uint16), the two cdf entries that
+    bracket every u (what a near-tie check needs), and -- so that every round can be replayed from the REFERENCE's state --
+    its merged bins and gather indices (uint16); plus the final z.  And the whole forward on the same rays."""
+    params = synth.make_params(seed=0)
+    K, pose = synth.make_camera(center=(0.1, 0.05, -2.5), tilt=0.1)
+    R = 256
+    uv = synth.make_uv(R, seed=21, margin=0.05)
+    import oracle_path  # noqa
+    from svs_oracle import rays_from_uv
+    dirs, cam, _ = rays_from_uv(uv, pose, K)
+    cam_r = np.repeat(cam[None], R, 0).astype(F32)
+    inp = {"intrinsics": T(K)[None], "uv": T(uv)[None], "pose": T(pose)[None]}
+    for beta in (0.1, 0.01, 0.001):
+        m = build_model(params, beta=beta)
+        z, z_eik, rec, sdfs = run_sampler(m, dirs, cam_r, -1, False)
+        arr = dict(dirs=dirs, cam=cam_r, beta_param=F32(beta), fast=-1, z=z.numpy(), n_rounds=len(sdfs),
+                   inv_4log=(1.0 / (4.0 * torch.log(torch.tensor(0.1 + 1.0)))).numpy())
+        for i, sd in enumerate(sdfs):
+            arr[f"sdf_{i}"] = sd.reshape(R, -1)
+            arr[f"beta_{i}"] = rec.betas[i]
+        for i, a in enumerate(rec.inds):
+            cdf = rec.cdf[i]
+            n = cdf.shape[1]
+            assert a.max() <= n and n < 65536
+            arr[f"inds_{i}"] = a.astype(np.uint16)
+            arr[f"cdf_lo_{i}"] = np.take_along_axis(cdf, np.maximum(a - 1, 0), 1)
+            arr[f"cdf_hi_{i}"] = np.take_along_axis(cdf, np.minimum(a, n - 1), 1)
+        for i in range(len(rec.sort_idx) - 1):
+            arr[f"samples_idx_{i}"] = rec.sort_idx[i].astype(np.uint16); arr[f"zmerged_{i}"] = rec.sort_vals[i]
+        save(f"sampler256_b{beta}", **arr)
+        m.eval()
+        out = m(inp, fast=-1)
+        save(f"forward256_b{beta}", K=K, pose=pose, uv=uv, beta_param=F32(beta), fast=-1,
+             **{k: out[k].detach().numpy() for k in ("rgb_values", "depth_values", "normal_map", "depth_vals", "weights")})
+
+
 def fx_composite():
     params = synth.make_params(seed=0)
     m = build_model(params, beta=0.03)
@@ -692,7 +730,8 @@ ALL = dict(fusion=fx_fusion, pfm=fx_pfm, chamfer=fx_chamfer, featurenet=fx_featu
            sdf_mlp_w1=lambda: fx_sdf_mlp("w1"), forward_w1=fx_forward_w1,
            train_step_w1=lambda: fx_train_step(16, 2, "train_step_w1", "w1"),
            train_step_bg=fx_train_step_bg,
-           train_step_bg_sparse=lambda: fx_train_step_bg("train_step_bg_sparse", 50, 1e3, 1))
+           train_step_bg_sparse=lambda: fx_train_step_bg("train_step_bg_sparse", 50, 1e3, 1),
+           sampler_r256=fx_sampler_r256)
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(ALL)

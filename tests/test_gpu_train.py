@@ -78,9 +78,16 @@ def test_train_steps_fused(dev, golden_dir, fixture, groups):
     optimisation steps: 3 steps with 16 rays; 2 steps with 32 rays as one batch and as two ray groups on concurrent
     streams (the default of bench.py / VolOpt at 1024 rays); 2 steps with the trained-scale weight set (train_step_w1:
     gains up to ~3x, beta = 0.005)."""
+    from svs_hip import ops
     from svs_hip.trainer import TrainStep
     g = dict(np.load(os.path.join(golden_dir, fixture + ".npz")))
     m, loss = _setup(dev, "w1" if fixture.endswith("w1") else "w0")
+    # later-step bounds: the float32-class paths (default fp16x2 with both pieces, float32 MFMA) are held to the bounds the
+    # float32-block kernels of round 1 met; the one-piece mode (SVS_MLP_PRECISION=f16x2_half) to the looser ones it needs
+    half = ops.default_precision() == ops.F16X2_HALF
+    # (measured on the default path: 1.6e-3 on the eikonal term of step 2 -- after an Adam step the entries whose gradient is
+    # numerically zero have moved by +-lr with a noise-determined sign)
+    later_rtol, later_atol, digest_ok = (5e-3, 2e-5, 0.99) if half else (2.5e-3, 2e-6, 0.995)
     ts = TrainStep(m, loss, lr=5e-4, groups=groups)
     mvs, views = _mvs(dev, g)
     R = g["uv"].shape[0]
@@ -94,12 +101,12 @@ def test_train_steps_fused(dev, golden_dir, fixture, groups):
         for k in ("rgb_loss", "eikonal_loss", "mvs_loss", "sparse_loss", "loss"):
             print(f"step {step} {k}: {float(lo[k]):.7f} ref {float(g[f's{step}_{k}']):.7f}")
             # step 0 sees identical parameters; later steps inherit the sign noise of numerically-zero gradients
-            np.testing.assert_allclose(float(lo[k]), float(g[f"s{step}_{k}"]), rtol=2e-4 if step == 0 else 5e-3,
-                                       atol=2e-6 if step == 0 else 2e-5, err_msg=f"step {step} {k}")
+            np.testing.assert_allclose(float(lo[k]), float(g[f"s{step}_{k}"]), rtol=2e-4 if step == 0 else later_rtol,
+                                       atol=2e-6 if step == 0 else later_atol, err_msg=f"step {step} {k}")
         # gradient norm before clipping (info[0]) and the raw gradients: the flat grad buffer holds the CLIPPED grads
         norm = float(ts.opt.info[0])
         # (step 0: identical parameters; later steps: parameters differ by Adam's sign noise on ~zero gradients)
-        np.testing.assert_allclose(norm, float(g[f"s{step}_grad_norm"]), rtol=2e-4 if step == 0 else 5e-3,
+        np.testing.assert_allclose(norm, float(g[f"s{step}_grad_norm"]), rtol=2e-4 if step == 0 else later_rtol,
                                    err_msg=f"gradient norm, step {step}")
         coef = min(1.0, 1.0 / (float(g[f"s{step}_grad_norm"]) + 1e-6))
         named_g = [(n, p.grad / coef) for n, p in m.named_parameters()]
@@ -108,7 +115,7 @@ def test_train_steps_fused(dev, golden_dir, fixture, groups):
         if step == 0:
             # per ENTRY (2e-3 of the entry itself, small entries included): 99 % of the fingerprint; the per-tensor bound
             # below is the parity criterion
-            _check_digest(g, step, "grad", named_g, rtol=2e-3, atol=2e-6 * max(1.0, norm), frac_ok=0.99)
+            _check_digest(g, step, "grad", named_g, rtol=2e-3, atol=2e-6 * max(1.0, norm), frac_ok=digest_ok)
         # after an Adam step, entries whose gradient is numerically zero have moved by +-lr with a noise-determined
         # sign (see the parameter check below), so later gradients agree per tensor, not per entry
         assert max(rel.values()) < (2e-3 if step == 0 else 3e-2), rel

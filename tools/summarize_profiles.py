@@ -39,11 +39,21 @@ def agg(pattern, counter, by_grid=False):
     return d
 
 
+def flat(pattern, counter, kernel):
+    """[(grid size, value)] of one kernel's launches in dispatch order"""
+    f = newest(pattern)
+    if not f:
+        return []
+    rows = [r for r in csv.DictReader(open(f)) if r.get("Counter_Name") == counter and r["Kernel_Name"] == kernel]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    return [(int(r["Grid_Size"]), float(r["Counter_Value"])) for r in rows]
+
+
 def main(src, tag):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = os.path.join(root, "profiles")
     os.makedirs(out, exist_ok=True)
-    for mode in ("train", "render", "train_onegroup", "costvol", "evalrender", "featurenet"):
+    for mode in ("train", "render", "train_onegroup", "train_half", "train_256", "costvol", "evalrender", "featurenet"):
         f = newest(os.path.join(src, mode, "*", "*kernel_stats.csv"))
         if f:
             shutil.copy(f, os.path.join(out, f"{tag}_{mode}_kernel_stats.csv"))
@@ -54,27 +64,44 @@ def main(src, tag):
             lines = [ln.strip() for ln in open(log) if ln.startswith("{") or ln.startswith("FeatureNet")]
             if lines:
                 open(os.path.join(out, f"{tag}_{name}_result.txt"), "w").write("\n".join(lines) + "\n")
-    fetch = agg(os.path.join(src, "pmc_fetch", "*", "*counter_collection.csv"), "FETCH_SIZE", by_grid=True)
-    write = agg(os.path.join(src, "pmc_write", "*", "*counter_collection.csv"), "WRITE_SIZE", by_grid=True)
+    traffic(src, out, tag, "", "pmc_traffic")
+    traffic(src, out, tag, "_half", "half_pmc_traffic")       # SVS_MLP_PRECISION=f16x2_half: one-piece gradient blocks
+    mfma_summary(src, out, tag)
+
+
+def traffic(src, out, tag, suffix, name):
+    fetch = agg(os.path.join(src, "pmc_fetch" + suffix, "*", "*counter_collection.csv"), "FETCH_SIZE", by_grid=True)
+    write = agg(os.path.join(src, "pmc_write" + suffix, "*", "*counter_collection.csv"), "WRITE_SIZE", by_grid=True)
+    if not fetch:
+        return
     res = {"_note": "bytes per launch; fetch = 2 * FETCH_SIZE KiB (gfx950 wide-stream correction), write = WRITE_SIZE KiB.  "
-                    "The default step runs two ray groups, so most kernels are launched in two sizes: hbm_bytes is the "
-                    "figure of the LARGEST launch shape (grid size), by_grid_size lists every shape",
+                    "The default step runs two ray groups, so most kernels are launched in two sizes, and the weight-gradient "
+                    "GEMM four times with (nearly) one grid size (~one workgroup per CU whatever the batch: SDF / radiance x "
+                    "two groups).  Launches are therefore grouped by their POSITION in the step (the k-th launch of the kernel in "
+                    "every step), not by grid size -- round 2's summary averaged the two ray groups' weight-gradient launches "
+                    "together, which is where its 0.965 GB against 1.70 GB algorithmic came from.  hbm_bytes = the launch position "
+                    "with the most bytes; by_launch lists every position",
            "kernels": {}}
     mean = lambda v: sum(v) / max(1, len(v))
+    steps = 5            # bench.py --steps 3 --warmup 2
     for k in fetch:
         if not k.startswith(("svs::", "void svs::")):
             continue
+        # per-launch values in dispatch order (the by_grid dict keeps insertion order within a grid: rebuild the flat order)
+        fl = flat(os.path.join(src, "pmc_fetch" + suffix, "*", "*counter_collection.csv"), "FETCH_SIZE", k)
+        wl = flat(os.path.join(src, "pmc_write" + suffix, "*", "*counter_collection.csv"), "WRITE_SIZE", k)
+        per_step = max(1, len(fl) // steps)
         shapes = {}
-        for grid, vals in fetch[k].items():
-            fb = 2.0 * 1024.0 * mean(vals)
-            wb = 1024.0 * mean(write.get(k, {}).get(grid, [0.0]))
-            shapes[grid] = {"launches": len(vals), "fetch_bytes": fb, "write_bytes": wb, "hbm_bytes": fb + wb}
-        top = shapes[max(shapes)]
-        res["kernels"][k.split("(")[0].replace("void ", "")] = dict(top, grid_size=max(shapes),
-                                                                  by_grid_size={str(g): shapes[g] for g in sorted(shapes)})
-    json.dump(res, open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
-    print(json.dumps({k: round(v["hbm_bytes"] / 1e6, 1) for k, v in res["kernels"].items()}, indent=1))
-    mfma_summary(src, out, tag)
+        for pos in range(per_step):
+            fv = [v for (g, v) in fl[pos::per_step]]
+            wv = [v for (g, v) in wl[pos::per_step]] or [0.0]
+            fb, wb = 2.0 * 1024.0 * mean(fv), 1024.0 * mean(wv)
+            shapes[pos] = {"launches": len(fv), "grid_size": fl[pos][0], "fetch_bytes": fb, "write_bytes": wb, "hbm_bytes": fb + wb}
+        top_pos = max(shapes, key=lambda q: shapes[q]["hbm_bytes"])
+        res["kernels"][k.split("(")[0].replace("void ", "")] = dict(shapes[top_pos], launch_position=top_pos,
+                                                                  by_launch={str(q): shapes[q] for q in sorted(shapes)})
+    json.dump(res, open(os.path.join(out, f"{tag}_{name}.json"), "w"), indent=1, sort_keys=True)
+    print(name, json.dumps({k: round(v["hbm_bytes"] / 1e6, 1) for k, v in res["kernels"].items()}, indent=1))
 
 
 MFMA_COUNTERS = ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
