@@ -369,6 +369,29 @@ size_t svs_conv3d_mfma_wfrag_bytes(int Cin);
 int svs_conv3d_mfma(const float* in, const void* wfrag, const float* bias, const float* skip, float* out, int Cin,
                     int Cout, int D, int H, int W, int relu, void* hip_stream);
 
+/* conv0 of CostRegNet (C -> 8 at full resolution, models/CasMVSNet.py:444,460; 68 / 52 / 35 % of the U-Net's MACs at
+ * stage 1 / 2 / 3) fused with the producer of its input.  The variance volume travels between the two kernels as a
+ * "split volume": fp16 hi and mid parts (v = hi + mid to float32 accuracy) in channel-last 16-byte units with a zero
+ * border, [D+2][Hp][2 pieces][C/8][Wp] units, voxel (z,y,x) at (z+1,y+1,x+1), Hp = 4 ceil(H/4) + 2,
+ * Wp = 32 ceil(W/32) + 4.  svs_split_volume_dims returns its size in bytes (dims[0..1] = Hp, Wp); the caller zero-fills
+ * the buffer once, the producers write the interior only.
+ *   svs_warp_variance_split  = svs_warp_variance writing that form (DepthNet.forward steps 1-2, CasMVSNet.py:611-642);
+ *   svs_split_volume_pack    = the same form from a float32 (C,D,H,W) volume (tests, other callers);
+ *   svs_conv3d_pair          = relu?(conv3d(volume, 3x3x3, stride 1, padding 1) + bias), Cin in {8,16,32}, Cout <= 8:
+ *     the 16 rows of v_mfma_f32_16x16x32_f16 are 8 output channels x 2 neighbouring x positions, a column is that pair
+ *     of positions, K = 3 kd x 3 kh x 4 input columns x Cin (27 of 36 products useful; 27 of 54 with channels only).
+ *     wfrag (svs_conv3d_pair_wfrag_bytes(Cin)): [k-step s][piece][lane][8] fp16, row m = lane & 15 = (channel m & 7,
+ *     position m >> 3), k = 32 s + 8 (lane >> 4) + j = (((kd*3 + kh)*4 + t)*(Cin/8) + g)*8 + c8: the folded weight of
+ *     tap (kd, kh, kw = t - (m >> 3)) and input channel 8 g + c8, zero if kw is outside 0..2 or m & 7 >= Cout. */
+size_t svs_split_volume_dims(int C, int D, int H, int W, int* dims);
+int svs_split_volume_pack(const float* in, void* split, int C, int D, int H, int W, void* hip_stream);
+int svs_warp_variance_split(const float* ref_feature, const float* const* src_features_hwc, const float* rot_trans,
+                            int n_src, int C, int D, int H, int W, const float* depth_values, void* split,
+                            void* hip_stream);
+size_t svs_conv3d_pair_wfrag_bytes(int Cin);
+int svs_conv3d_pair(const void* split, const void* wfrag, const float* bias, float* out, int Cin, int Cout, int D, int H,
+                    int W, int relu, void* hip_stream);
+
 /* Every other 3x3x3 layer of the U-Net (stride 2, transposed, the 32/64-channel levels) as an implicit GEMM on the
  * same matrix-core instruction with both operands split: Cin in {8,16,32,64}, Cout <= 64
  * (svs_conv3d_gemm_supported).  One wave = 16 output voxels along x times all output channels; the transposed form

@@ -30,6 +30,7 @@ UNITS = {
     "svs_render.hip": ["-ffp-contract=off"],
     "svs_costvol.hip": ["-ffp-contract=off"],
     "svs_conv_mfma.hip": [],
+    "svs_conv_pair.hip": [],
     "svs_conv_gemm.hip": [],
     "svs_conv2d.hip": [],
     "svs_wgrad.hip": [],

@@ -130,6 +130,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_mfma_kernel(Args a) {
       __builtin_amdgcn_sched_barrier(0);
       acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm[s], bh[0], acc[0], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+#ifdef CONVX_NOLDS
+      nh[0] = bh[0]; nh[1] = bh[1]; nm[0] = bm[0]; nm[1] = bm[1];
+#else
       if (s + 1 < KS) {
         const unsigned char* p = smem + base[bkd[s + 1]] + boff[s + 1];
 #pragma unroll
@@ -138,11 +141,14 @@ __global__ __launch_bounds__(256, 1) void conv3d_mfma_kernel(Args a) {
           nm[xt] = *reinterpret_cast<const f16x8*>(p + PIECE + xt * 16 * PITCH);
         }
       }
+#endif
       __builtin_amdgcn_sched_barrier(0);
       acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm[s], bh[1], acc[1], 0, 0, 0);
       acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s], bm[0], acc[0], 0, 0, 0);
+#ifndef CONVX_NOFETCH
       if (s < CIN / 8) commit_group(slot_new, s);         // staged slice z+2, hidden behind the MFMAs
       if (s == CIN / 8) fetch(z + 3);                     // its registers are free again
+#endif
       acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s], bm[1], acc[1], 0, 0, 0);
       acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s], bh[0], acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s], bh[1], acc[1], 0, 0, 0);

@@ -8,9 +8,12 @@
 // three volumes live; here every output voxel is produced once -- sum and sum of squares stay in registers and
 // only the variance is written (algorithmic bytes: write C*D*H*W*4 + read D*H*W*4 + V*C*H*W*4).
 #include "svs_common.h"
+#include "svs_split_volume.h"
 
 namespace svs {
 namespace costvol {
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 // ---- (C,H,W) -> (H,W,C): a source view's feature map in channel-last order, so that one bilinear corner is one
 // contiguous C-vector -------------------------------------------------------------------------------------------
@@ -32,6 +35,7 @@ struct WarpArgs {
   float* variance;               // (C,D,H,W)
   int n_src, D, H, W;
   int raw_warp;                  // 1: write the warped volume of source 0 instead of the variance (homo_warping alone)
+  uint4* split;                  // not null: the variance goes here as a split volume (svs_split_volume.h), not to `variance`
 };
 
 // One workgroup: kWarpPasses * (256 / (C/4)) consecutive x of one image row, `dz` depth planes.
@@ -140,6 +144,27 @@ __global__ __launch_bounds__(256, 4) void warp_variance_kernel(WarpArgs a, int d
       }
       if (a.raw_warp) r[p] = sum;
       else { const f32x4 m = sum * inv_nv; r[p] = sq * inv_nv - m * m; }
+    }
+    if (a.split) {
+      // ---- phase C': fp16 hi / mid pieces straight from the registers: the two lanes that hold the 8 channels of a
+      // unit write its halves, a wave's store covers 64 / LPV consecutive voxels of every channel group
+      const int Hp = splitvol::padded_h(H), Wp = splitvol::padded_w(W);
+#pragma unroll
+      for (int p = 0; p < kWarpPasses; ++p) {
+        const int x = xt + p * VPP + vl;
+        if (x >= W) continue;
+        f16x4 h, m;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const _Float16 hh = (_Float16)r[p][j];
+          h[j] = hh;
+          m[j] = (_Float16)(r[p][j] - (float)hh);
+        }
+        uint2* u = reinterpret_cast<uint2*>(a.split + splitvol::unit(d, y, 0, cg >> 1, x, C / 8, Hp, Wp)) + (cg & 1);
+        u[0] = __builtin_bit_cast(uint2, h);
+        u[(size_t)(C / 8) * Wp * 2] = __builtin_bit_cast(uint2, m);
+      }
+      continue;
     }
     // ---- phase C: variance -> LDS tile -> contiguous runs of every channel plane ----------------------------------------
     __syncthreads();
@@ -467,16 +492,16 @@ int svs_chw_to_hwc(const float* in, float* out, int C, int H, int W, void* hip_s
   return check_launch("svs_chw_to_hwc");
 }
 
-int svs_warp_variance(const float* ref_feature, const float* const* src_features_hwc, const float* rot_trans, int n_src,
-                      int C, int D, int H, int W, const float* depth_values, float* variance, int raw_warp,
-                      void* hip_stream) {
-  if (!ref_feature || !src_features_hwc || !rot_trans || !depth_values || !variance) {
+static int warp_variance_any(const float* ref_feature, const float* const* src_features_hwc, const float* rot_trans,
+                             int n_src, int C, int D, int H, int W, const float* depth_values, float* variance,
+                             void* split, int raw_warp, void* hip_stream) {
+  if (!ref_feature || !src_features_hwc || !rot_trans || !depth_values || (!variance && !split)) {
     set_error("svs_warp_variance: null argument"); return SVS_EINVAL;
   }
   if (n_src < 1 || n_src > kMaxSrc || D < 1 || H < 2 || W < 2) { set_error("svs_warp_variance: bad sizes"); return SVS_ESHAPE; }
   WarpArgs a;
   a.ref = ref_feature; a.depth_values = depth_values; a.variance = variance; a.n_src = n_src; a.D = D; a.H = H; a.W = W;
-  a.raw_warp = raw_warp;
+  a.raw_warp = raw_warp; a.split = reinterpret_cast<uint4*>(split);
   for (int v = 0; v < n_src; ++v) {
     if (!src_features_hwc[v]) { set_error("svs_warp_variance: null source %d", v); return SVS_EINVAL; }
     a.src_hwc[v] = src_features_hwc[v];
@@ -489,6 +514,22 @@ int svs_warp_variance(const float* ref_feature, const float* const* src_features
   else if (C == 16) launch_warp<16>(a, s);
   else launch_warp<32>(a, s);
   return check_launch("svs_warp_variance");
+}
+
+int svs_warp_variance(const float* ref_feature, const float* const* src_features_hwc, const float* rot_trans, int n_src,
+                      int C, int D, int H, int W, const float* depth_values, float* variance, int raw_warp,
+                      void* hip_stream) {
+  return warp_variance_any(ref_feature, src_features_hwc, rot_trans, n_src, C, D, H, W, depth_values, variance, nullptr,
+                           raw_warp, hip_stream);
+}
+
+// the variance as a split volume (svs_split_volume_dims bytes, zero-filled by the caller before its first use): the
+// form svs_conv3d_pair reads.  Same values as svs_warp_variance, each split into its fp16 hi and mid parts.
+int svs_warp_variance_split(const float* ref_feature, const float* const* src_features_hwc, const float* rot_trans,
+                            int n_src, int C, int D, int H, int W, const float* depth_values, void* split,
+                            void* hip_stream) {
+  return warp_variance_any(ref_feature, src_features_hwc, rot_trans, n_src, C, D, H, W, depth_values, nullptr, split, 0,
+                           hip_stream);
 }
 
 // transposed != 0: ConvTranspose3d(k3,s2,p1,op1) (Do = 2*Di); else Conv3d(k3,p1,stride)

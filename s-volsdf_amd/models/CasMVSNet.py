@@ -182,13 +182,14 @@ class CostRegNet(nn.Module):
         self._prob_w, self._prob_key = None, None
 
     def forward(self, x):
-        """x (1,C,D,H,W) -> (1,1,D,H,W)"""
+        """x (1,C,D,H,W), or the same volume as a costvol.SplitVolume (conv0 fused with its producer) -> (1,1,D,H,W)"""
         if x.shape[0] != 1:
             raise NotImplementedError("batch size 1 (runner.py:122)")
         for n in x.shape[2:]:
             if n % 8:
                 raise ValueError("CostRegNet needs D, H, W divisible by 8 (three stride-2 levels)")
-        x = x[0]
+        if not isinstance(x, costvol.SplitVolume):
+            x = x[0]
         c0 = self.conv0(x)
         c2 = self.conv2(self.conv1(c0))
         c4 = self.conv4(self.conv3(c2))
@@ -219,7 +220,11 @@ class DepthNet(nn.Module):
                 prevent_oom=False):
         assert len(features) == proj_matrices.shape[1], "Different number of images and projection matrices"
         assert depth_values.shape[1] == num_depth
-        variance = costvol.warp_variance(features, proj_matrices, depth_values)      # steps 1-2, fused
+        # steps 1-2, fused; where conv0 has the fused form the volume goes to it as fp16 hi / mid pieces (SplitVolume)
+        conv0 = getattr(cost_regularization, "conv0", None)
+        split = (isinstance(conv0, Conv3d) and not conv0.training and features[0].is_cuda
+                 and costvol.pair_supported(features[0].shape[1], conv0.conv.out_channels))
+        variance = costvol.warp_variance(features, proj_matrices, depth_values, split=split)
         reg = cost_regularization(variance)[0, 0]                                    # step 3
         if prob_volume_init is not None:
             reg = reg + prob_volume_init[0]

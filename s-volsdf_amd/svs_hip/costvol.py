@@ -49,9 +49,55 @@ def _rot_trans(proj_matrices):
     return rt
 
 
-def warp_variance(features, proj_matrices, depth_values):
+class SplitVolume:
+    """A (C,D,H,W) volume in the form conv0 of the regularisation U-Net reads (include/svolsdf_hip.h,
+    svs_split_volume_dims): fp16 hi / mid parts, channel-last 16-byte units, zero border.  The buffers are cached per
+    shape: the border is zeroed once, producers rewrite the interior."""
+    _cache = {}
+
+    def __init__(self, C, D, H, W, device):
+        L = _lib.load()
+        self.C, self.D, self.H, self.W = C, D, H, W
+        self.shape = (1, C, D, H, W)
+        key = (C, D, H, W, str(device))
+        buf = SplitVolume._cache.get(key)
+        if buf is None:
+            if len(SplitVolume._cache) >= 8:
+                SplitVolume._cache.clear()
+            nbytes = L.svs_split_volume_dims(C, D, H, W, None)
+            buf = SplitVolume._cache[key] = torch.zeros(nbytes // 2, dtype=torch.float16, device=device)
+        self.buf = buf
+        self.device = buf.device
+
+    @staticmethod
+    def pack(x):
+        """float32 (C,D,H,W) -> SplitVolume"""
+        L = _lib.load()
+        x = _f32(x)
+        C, D, H, W = x.shape
+        sv = SplitVolume(C, D, H, W, x.device)
+        _lib.check(L.svs_split_volume_pack(_ptr(x), _ptr(sv.buf), C, D, H, W, _stream()), "svs_split_volume_pack")
+        return sv
+
+    def float(self):
+        """back to float32 (C,D,H,W): hi + mid (tests)"""
+        L = _lib.load()
+        dims = (ctypes.c_int * 2)()
+        L.svs_split_volume_dims(self.C, self.D, self.H, self.W, dims)
+        Hp, Wp = dims[0], dims[1]
+        G = self.C // 8
+        v = self.buf.view(self.D + 2, Hp, 2, G, Wp, 8)[1:self.D + 1, 1:self.H + 1, :, :, 1:self.W + 1].float()
+        return (v[:, :, 0] + v[:, :, 1]).permute(2, 4, 0, 1, 3).reshape(self.C, self.D, self.H, self.W)
+
+
+def pair_supported(C, Cout):
+    return C in (8, 16, 32) and Cout <= 8 and not os.environ.get("SVS_CONV_PAIR_OFF")
+
+
+def warp_variance(features, proj_matrices, depth_values, split=False):
     """DepthNet.forward step 2 (models/CasMVSNet.py:611-642).  features: list of (1,C,H,W) (reference first),
-    proj_matrices: (1,V,2,4,4), depth_values (1,D,H,W) -> variance (1,C,D,H,W)."""
+    proj_matrices: (1,V,2,4,4), depth_values (1,D,H,W) -> variance (1,C,D,H,W), or with split=True the same values
+    as a SplitVolume (the producer side of the fused conv0, svs_conv3d_pair)."""
     L = _lib.load()
     ref = _f32(features[0][0])
     C, H, W = ref.shape
@@ -64,8 +110,13 @@ def warp_variance(features, proj_matrices, depth_values):
         _lib.check(L.svs_chw_to_hwc(_ptr(_f32(f[0])), _ptr(o), C, H, W, _stream()), "svs_chw_to_hwc")
         hwc.append(o)
     rt = _rot_trans(proj_matrices)
-    var = torch.empty(1, C, D, H, W, device=dev)
     dv = _f32(depth_values[0])
+    if split:
+        sv = SplitVolume(C, D, H, W, dev)
+        _lib.check(L.svs_warp_variance_split(_ptr(ref), _ptr_array(hwc), rt, n_src, C, D, H, W, _ptr(dv), _ptr(sv.buf),
+                                             _stream()), "svs_warp_variance_split")
+        return sv
+    var = torch.empty(1, C, D, H, W, device=dev)
     _lib.check(L.svs_warp_variance(_ptr(ref), _ptr_array(hwc), rt, n_src, C, D, H, W, _ptr(dv), _ptr(var), 0, _stream()),
                "svs_warp_variance")
     return var
@@ -113,6 +164,35 @@ def mfma_weight_fragments(weight):
     mid = (w - hi.float()).half()
     frag = torch.stack([hi, mid], 1).contiguous()          # (KS, 2, 64, 8) fp16
     _WFRAG_CACHE[key] = (frag, weight)                     # keep `weight` alive: the key holds its address
+    return frag
+
+
+def pair_weight_fragments(weight):
+    """[Cin][27][Cout <= 8] folded float32 weights -> the fp16 hi / mid A fragments of svs_conv3d_pair
+    ([k-step][piece][lane][8] fp16, include/svolsdf_hip.h): row m = (channel m & 7, x parity m >> 3),
+    k = (((kd*3+kh)*4 + t)*G + g)*8 + c8 carries the weight of tap (kd, kh, kw = t - parity)."""
+    key = ("pair", weight.data_ptr(), weight._version, tuple(weight.shape))
+    hit = _WFRAG_CACHE.get(key)
+    if hit is not None:
+        return hit[0]
+    Cin, _, Cout = weight.shape
+    dev = weight.device
+    G = Cin // 8
+    KS = 9 * G
+    s = torch.arange(KS, device=dev).view(KS, 1, 1)
+    lane = torch.arange(64, device=dev).view(1, 64, 1)
+    j = torch.arange(8, device=dev).view(1, 1, 8)
+    kk = 32 * s + 8 * (lane >> 4) + j
+    c8, g, t, row9 = kk % 8, (kk // 8) % G, (kk // (8 * G)) % 4, kk // (32 * G)
+    m = (lane & 15).expand(KS, 64, 8)
+    co, kw = m & 7, t - (m >> 3)
+    ok = (kw >= 0) & (kw <= 2) & (co < Cout)
+    w = weight[8 * g + c8, (row9 * 3 + kw.clamp(0, 2)), co.clamp(max=Cout - 1)]
+    w = torch.where(ok, w, torch.zeros_like(w)).float()
+    hi = w.half()
+    mid = (w - hi.float()).half()
+    frag = torch.stack([hi, mid], 1).contiguous()          # (KS, 2, 64, 8) fp16
+    _WFRAG_CACHE[key] = (frag, weight)
     return frag
 
 
@@ -233,6 +313,15 @@ def gemm_weight_fragments(weight, transposed):
 def conv3d(x, weight, bias=None, skip=None, stride=1, transposed=False, relu=True):
     """x (Cin,D,H,W); weight [Cin][27][Cout] folded; -> (Cout,Do,Ho,Wo)."""
     L = _lib.load()
+    if isinstance(x, SplitVolume):
+        Cout = weight.shape[2]
+        if transposed or stride != 1 or skip is not None or not pair_supported(x.C, Cout):
+            raise ValueError("a SplitVolume feeds the stride-1 convolution with Cout <= 8 only (svs_conv3d_pair)")
+        frag = pair_weight_fragments(weight)
+        out = torch.empty((Cout, x.D, x.H, x.W), device=x.device)
+        _lib.check(L.svs_conv3d_pair(_ptr(x.buf), _ptr(frag), _ptr(bias), _ptr(out), x.C, Cout, x.D, x.H, x.W, int(relu),
+                                     _stream()), "svs_conv3d_pair")
+        return out
     x = _f32(x)
     Cin, D, H, W = x.shape
     Cout = weight.shape[2]

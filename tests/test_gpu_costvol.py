@@ -78,7 +78,8 @@ def test_three_stage_forward_golden(dev, golden_dir):
         o = outputs[f"stage{st + 1}"]
         np.testing.assert_allclose(o["depth_values"][0].cpu().numpy(), g[f"s{st}_depth_values"], rtol=5e-6,
                                    err_msg=f"hypotheses stage {st + 1}")
-        var = cap["var"][0].cpu().numpy().reshape(-1)
+        var = cap["var"]            # conv0's input travels as a SplitVolume (fp16 hi + mid pieces)
+        var = (var.float() if hasattr(var, "buf") else var[0]).cpu().numpy().reshape(-1)
         np.testing.assert_allclose(var[g[f"s{st}_variance_idx"]], g[f"s{st}_variance_val"], atol=2e-4)
         reg = cap["reg"][0, 0].cpu().numpy()
         np.testing.assert_allclose(reg, g[f"s{st}_reg"], atol=2e-3, err_msg=f"reg stage {st + 1}")
@@ -126,6 +127,70 @@ def test_warp_variance_ragged(dev, C, n_views, D, hw):
     assert np.abs(ref).max() > 0.1
 
 
+def _mvs_inputs(rng, C, n_views, D, H, W):
+    feats = [rng.normal(0, 1, (C, H, W)).astype(F32) for _ in range(n_views)]
+    projs = np.zeros((n_views, 2, 4, 4), F32)
+    for v in range(n_views):
+        ext = np.eye(4, dtype=F32)
+        ang = 0.03 * v
+        ext[:3, :3] = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], F32)
+        ext[0, 3], ext[1, 3] = 12.0 * v * (-1) ** v, 2.0 * v
+        K = np.eye(4, dtype=F32)
+        K[0, 0] = K[1, 1] = 1.5 * W
+        K[0, 2], K[1, 2] = W / 2.0, H / 2.0
+        projs[v, 0], projs[v, 1] = ext, K
+    dv = np.broadcast_to((400.0 + 7.0 * np.arange(D, dtype=F32))[:, None, None], (D, H, W)).copy()
+    dv += rng.uniform(0, 3, dv.shape).astype(F32)
+    return feats, projs, dv
+
+
+@pytest.mark.parametrize("C,n_views,D,hw", [(32, 3, 5, (21, 37)), (16, 2, 70, (13, 36)), (8, 5, 6, (10, 131)),
+                                             (32, 4, 9, (6, 200))])
+def test_warp_variance_split_volume(dev, C, n_views, D, hw):
+    """The split-volume output of the fused warp + variance (the input form of the fused conv0) holds the values of
+    the float32 output as fp16 hi + mid: equal to 2^-21 relative (two 11-bit pieces), zero outside the interior."""
+    from svs_hip import costvol
+    H, W = hw
+    feats, projs, dv = _mvs_inputs(np.random.default_rng(C + D), C, n_views, D, H, W)
+    args = ([G(f, dev)[None] for f in feats], G(projs, dev)[None], G(dv, dev)[None])
+    ref = costvol.warp_variance(*args)[0]
+    sv = costvol.warp_variance(*args, split=True)
+    got = sv.float()
+    err = (got - ref).abs()
+    assert float((err - ref.abs() * 2.0 ** -21).max()) <= 1e-7         # 1e-7: fp16 underflow of the mid piece
+    v6 = sv.buf.view(D + 2, -1, 2, C // 8, 32 * ((W + 31) // 32) + 4, 8)
+    assert v6.shape[1] == 4 * ((H + 3) // 4) + 2
+    border = v6.clone()
+    border[1:D + 1, 1:H + 1, :, :, 1:W + 1] = 0
+    assert not bool(border.any())                                      # nothing outside the interior is written
+    # packing the float32 volume gives the same pieces bit for bit
+    a = sv.buf.clone()
+    sv2 = costvol.SplitVolume.pack(ref)
+    assert sv2.buf.data_ptr() == sv.buf.data_ptr() and torch.equal(a, sv2.buf)
+
+
+@pytest.mark.parametrize("cin,cout,shape", [(32, 8, (5, 7, 37)), (16, 8, (3, 9, 70)), (8, 8, (9, 6, 33)), (32, 5, (2, 4, 32)),
+                                            (32, 8, (20, 8, 64))])
+def test_conv3d_pair_vs_float64(dev, cin, cout, shape):
+    """The fused conv0 (x-pair rows, split-volume input) against a float64 torch convolution on ragged shapes (H not a
+    multiple of 4, W not a multiple of 32, D shorter than the ring) and against the channel-row kernel it replaces.
+    Tolerance 3e-6 of the output scale: float32-class (fp16x2 operands carry 22 bits, float32 accumulation)."""
+    from svs_hip import costvol
+    rng = np.random.default_rng(cin + shape[2])
+    x = rng.normal(0, 1, (cin,) + shape).astype(F32)
+    w = (rng.normal(0, 1, (cin, 27, cout)) / np.sqrt(27 * cin)).astype(F32)
+    b = rng.normal(0, 1, cout).astype(F32)
+    for relu in (True, False):
+        got = costvol.conv3d(costvol.SplitVolume.pack(G(x, dev)), G(w, dev), G(b, dev), relu=relu).cpu().numpy()
+        wt = torch.from_numpy(w).double().permute(2, 0, 1).reshape(cout, cin, 3, 3, 3)
+        ref = torch.nn.functional.conv3d(torch.from_numpy(x).double()[None], wt, torch.from_numpy(b).double(), padding=1)[0]
+        ref = (ref.clamp(min=0) if relu else ref).numpy()
+        assert got.shape == ref.shape
+        np.testing.assert_allclose(got, ref, atol=3e-6 * np.abs(ref).max())
+        old = costvol.conv3d(G(x, dev), G(w, dev), G(b, dev), relu=relu).cpu().numpy()
+        np.testing.assert_allclose(got, old, atol=3e-6 * np.abs(ref).max())
+
+
 @pytest.mark.parametrize("cin,shape", [(32, (16, 16, 24)), (16, (8, 24, 16)), (8, (8, 8, 8))])
 def test_costreg_vs_torch_reference(dev, cin, shape):
     """3-D U-Net on random volumes (incl. non-cubic shapes) against the plain torch float32 reference."""
@@ -139,6 +204,11 @@ def test_costreg_vs_torch_reference(dev, cin, shape):
     ref = corc.cost_reg_net_torch(params, x)
     np.testing.assert_allclose(y, ref, atol=2e-3)
     assert np.abs(y - ref).mean() < 5e-5
+    # the same network fed with the split volume (conv0 fused with its producer, the path DepthNet takes)
+    from svs_hip import costvol
+    y2 = net(costvol.SplitVolume.pack(G(x, dev)))[0, 0].cpu().numpy()
+    np.testing.assert_allclose(y2, ref, atol=2e-3)
+    assert np.abs(y2 - ref).mean() < 5e-5
 
 
 def test_config3_sizes_run(dev):
