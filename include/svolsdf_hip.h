@@ -384,6 +384,10 @@ int svs_conv3d_mfma(const float* in, const void* wfrag, const float* bias, const
  *     position m >> 3), k = 32 s + 8 (lane >> 4) + j = (((kd*3 + kh)*4 + t)*(Cin/8) + g)*8 + c8: the folded weight of
  *     tap (kd, kh, kw = t - (m >> 3)) and input channel 8 g + c8, zero if kw is outside 0..2 or m & 7 >= Cout. */
 size_t svs_split_volume_dims(int C, int D, int H, int W, int* dims);
+/* The final `prob` layer (Cin -> 1, CasMVSNet.py:458,471): float32 fused multiply-adds on the vector ALUs (a one-row
+ * matrix-core tile would be 1/16 full).  weight [Cin][27][1]. */
+int svs_conv3d_c1(const float* in, const float* weight, const float* bias, const float* skip, float* out, int Cin, int D,
+                  int H, int W, int relu, void* hip_stream);
 int svs_split_volume_pack(const float* in, void* split, int C, int D, int H, int W, void* hip_stream);
 int svs_warp_variance_split(const float* ref_feature, const float* const* src_features_hwc, const float* rot_trans,
                             int n_src, int C, int D, int H, int W, const float* depth_values, void* split,

@@ -358,6 +358,251 @@ __global__ __launch_bounds__(kConvThreads) void deconv3d_kernel(ConvArgs a) {
   }
 }
 
+// ---- 3x3x3 convolution to ONE output channel (the U-Net's final `prob` layer, CasMVSNet.py:458,471), float32 on
+// the vector ALUs.  With one output channel a matrix-core tile is 1/16 full (0.097 ms at stage 1 on
+// conv3d_mfma_kernel, staging and conversion included); 216 float32 FMAs per voxel are 25 us of VALU time for the
+// whole volume.  A thread owns 4 x-positions of one row over a run of z: every loaded input value feeds up to 9 FMAs
+// (3 kw x 3 kd), rows of neighbouring threads overlap in the L1.  Weights are wave-uniform (scalar operands of
+// v_pk_fma_f32).  No LDS, no barrier.
+struct C1Args {
+  const float* in;     // (Cin, D, H, W)
+  const float* w;      // [Cin][27] (Cout = 1)
+  const float* bias;   // [1] or nullptr
+  const float* skip;   // (D, H, W) or nullptr
+  float* out;          // (D, H, W)
+  int Cin, D, H, W, relu;
+};
+#ifndef SVS_C1_VZ
+#define SVS_C1_VZ 4
+#endif
+constexpr int kC1VX = 4, kC1VZ = SVS_C1_VZ, kC1TX = 8, kC1TY = 32;
+
+// A thread marches along z over kC1VZ output slices of its 4 x-positions with three accumulator sets in flight: input
+// slice zi adds its kd = 2 / 1 / 0 taps to the outputs zi-1 / zi / zi+1, the oldest set is then complete.  Loads are
+// unconditional (clamped addresses, the value replaced by 0 outside the volume): no divergent branches around them.
+//
+// conv3d_c1_flat_kernel (W a multiple of 4): the lanes of a wave are 64 CONSECUTIVE 4-wide strips of the flattened
+// (y, x/4) plane, so a row of the window is one float4 load per lane (1 KiB contiguous per wave) and the two edge
+// columns x0-1, x0+4 come from the neighbouring lanes (only lanes 0 and 63 load theirs).  The first version loaded
+// the edge columns per lane: 27 load instructions per (channel, slice), 18 of them touching 8 lines for 256 useful
+// bytes -- the vector L1 bound the kernel at 0.12 ms.
+__global__ __launch_bounds__(256, 4) void conv3d_c1_flat_kernel(const float* __restrict__ in, const float* __restrict__ wgt,
+                                                                 const float* __restrict__ bias, const float* __restrict__ skip,
+                                                                 float* __restrict__ out, int Cin, int D, int H, int W, int relu) {
+  // (separate __restrict__ parameters: with the stores of finished slices inside the loop, hipcc reads weights it cannot
+  // prove unaliased through the vector memory path and waits for ALL outstanding loads -- the prefetched rows -- each time)
+  struct { const float* in; const float* w; const float* bias; const float* skip; float* out; int Cin, relu; } a{in, wgt, bias, skip, out, Cin, relu};
+  constexpr int VX = kC1VX, VZ = kC1VZ;
+  const int S = W / VX;                                     // strips per row
+  const int sidx = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool live = sidx < H * S;
+  const int sc = live ? sidx : H * S - 1;
+  const int y = sc / S, col = sc - y * S, x0 = col * VX, z0 = blockIdx.y * VZ;
+  const size_t HW = (size_t)H * W, DHW = (size_t)D * HW;
+  const float b = a.bias ? a.bias[0] : 0.0f;
+  int yoff[3];
+  bool yok[3];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int yi = y + kh - 1;
+    yok[kh] = yi >= 0 && yi < H;
+    yoff[kh] = (yi < 0 ? 0 : (yi >= H ? H - 1 : yi)) * W + x0;
+  }
+  const bool lok = col > 0, rok = col < S - 1;
+  // lanes 0 and 63 have their neighbour in another wave: one more load per row fetches lane 0's left and lane 63's
+  // right column (two addresses per wave-instruction: the lower half of the wave reads the one, the upper half the
+  // other).  Unconditional, so that hipcc can count the loads in flight and wait with vmcnt(N) on the prefetch ring.
+  int offL[3], offR[3];
+  {
+    const int first = blockIdx.x * 256 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+    const int last = first + 63 < H * S ? first + 63 : H * S - 1;
+    const int yL = first / S, cL = first - yL * S, yR = last / S, cR = last - yR * S;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int yl = yL + kh - 1, yr = yR + kh - 1;
+      offL[kh] = (yl < 0 ? 0 : (yl >= H ? H - 1 : yl)) * W + (cL > 0 ? cL * VX - 1 : 0);
+      offR[kh] = (yr < 0 ? 0 : (yr >= H ? H - 1 : yr)) * W + (cR < S - 1 ? cR * VX + VX : 0);
+    }
+  }
+  int offE[3];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) offE[kh] = lane < 32 ? offL[kh] : offR[kh];
+  float a0[VX], a1[VX], a2[VX];
+#pragma unroll
+  for (int v = 0; v < VX; ++v) a0[v] = a1[v] = a2[v] = 0.0f;
+  const int nz = D - z0 < VZ ? D - z0 : VZ;
+  // the window rows of one (slice, channel): fetched one iteration ahead of their FMAs (a thread's iterations are a
+  // serial chain and there are only ~2-4 waves per SIMD to hide a load behind)
+  struct Rows { f32x4 m[3]; float e[3]; };
+  auto fetch = [&](int zz, int c, Rows& R) {
+    const int zi = z0 + zz - 1;
+    const float* __restrict__ inc = a.in + (size_t)(zi < 0 ? 0 : (zi >= D ? D - 1 : zi)) * HW + (size_t)c * DHW;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const float* row = inc + yoff[kh];
+      R.m[kh] = *reinterpret_cast<const f32x4*>(row);
+      R.e[kh] = inc[offE[kh]];
+    }
+  };
+  // ring of kPF row sets, the loop unrolled by kPF so that every set has a fixed register home (a `cur = nxt` copy
+  // would wait for the prefetched loads at the end of every iteration); Cin is a multiple of kPF (launcher)
+  constexpr int kPF = 4;
+  Rows ring[kPF];
+#pragma unroll
+  for (int j = 0; j < kPF - 1; ++j) fetch(j / a.Cin, j % a.Cin, ring[j]);     // Cin >= kPF: slice 0
+  for (int zz = 0; zz < nz + 2; ++zz) {
+    const int zi = z0 + zz - 1;
+    const bool zok = zi >= 0 && zi < D;
+    const bool use2 = zz >= 2, use1 = zz >= 1 && zz <= nz, use0 = zz < nz;
+    for (int c0 = 0; c0 < a.Cin; c0 += kPF) {
+#pragma unroll
+      for (int j = 0; j < kPF; ++j) {
+        const int c = c0 + j;
+        {
+          const int cn = c + kPF - 1;
+          const bool wrap = cn >= a.Cin;
+          fetch(wrap ? zz + 1 : zz, wrap ? cn - a.Cin : cn, ring[(j + kPF - 1) % kPF]);   // (past the end: clamped, unused)
+        }
+        const Rows& cur = ring[j];
+        const float* __restrict__ wc = a.w + c * 27;
+        float r[3][VX + 2];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const bool ok = zok && yok[kh];
+          const f32x4 m = cur.m[kh];
+          // neighbour lanes' columns by DPP wave shifts (lane 0 / 63 keep their loaded edge column).  Inline assembly:
+          // with __builtin_amdgcn_update_dpp hipcc 7.2 fed m[0] to BOTH shifts.  s_nop: a DPP source written by the
+          // preceding vector instruction needs two wait states, which the compiler does not insert for inline assembly.
+          float l = cur.e[kh], rr = cur.e[kh];
+          asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                       "v_mov_b32_dpp %1, %3 wave_shl:1 row_mask:0xf bank_mask:0xf"
+                       : "+v"(l), "+v"(rr) : "v"(m[3]), "v"(m[0]));
+          r[kh][0] = (ok && lok) ? l : 0.0f;
+          r[kh][VX + 1] = (ok && rok) ? rr : 0.0f;
+#pragma unroll
+          for (int v = 0; v < VX; ++v) r[kh][1 + v] = ok ? m[v] : 0.0f;
+        }
+        auto taps = [&](int kd, float (&acc)[VX]) {
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+              const float wv = wc[(kd * 3 + kh) * 3 + kw];
+#pragma unroll
+              for (int v = 0; v < VX; ++v) acc[v] = __builtin_fmaf(wv, r[kh][v + kw], acc[v]);
+            }
+        };
+        if (use2) taps(2, a0);
+        if (use1) taps(1, a1);
+        if (use0) taps(0, a2);
+      }
+    }
+    if (use2 && live) {
+      const size_t o = (size_t)(zi - 1) * HW + (size_t)y * W + x0;
+      f32x4 res;
+#pragma unroll
+      for (int v = 0; v < VX; ++v) {
+        float t = a0[v] + b;
+        if (a.relu) t = __builtin_fmaxf(t, 0.0f);
+        if (a.skip) t += a.skip[o + v];
+        res[v] = t;
+      }
+      *reinterpret_cast<f32x4*>(a.out + o) = res;
+    }
+#pragma unroll
+    for (int v = 0; v < VX; ++v) { a0[v] = a1[v]; a1[v] = a2[v]; a2[v] = 0.0f; }
+  }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256, 4) void conv3d_c1_kernel(C1Args a) {
+  constexpr int VX = kC1VX, VZ = kC1VZ;
+  const int tx = threadIdx.x % kC1TX, ty = threadIdx.x / kC1TX;
+  const int x0 = (blockIdx.x * kC1TX + tx) * VX, y = blockIdx.y * kC1TY + ty, z0 = blockIdx.z * VZ;
+  const int D = a.D, H = a.H, W = a.W;
+  if (x0 >= W || y >= H) return;
+  const size_t HW = (size_t)H * W, DHW = (size_t)D * HW;
+  const float b = a.bias ? a.bias[0] : 0.0f;
+  // per-row constants: clamped row offsets and validity of the three kh rows, clamped edge columns
+  int yoff[3];
+  bool yok[3];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int yi = y + kh - 1;
+    yok[kh] = yi >= 0 && yi < H;
+    yoff[kh] = (yi < 0 ? 0 : (yi >= H ? H - 1 : yi)) * W;
+  }
+  const bool lok = x0 > 0, rok = x0 + VX < W;
+  const int xl = lok ? x0 - 1 : 0, xr = rok ? x0 + VX : W - 1;
+  float a0[VX], a1[VX], a2[VX];
+#pragma unroll
+  for (int v = 0; v < VX; ++v) a0[v] = a1[v] = a2[v] = 0.0f;
+  const int nz = D - z0 < VZ ? D - z0 : VZ;          // output slices of this thread
+  for (int zz = 0; zz < nz + 2; ++zz) {
+    const int zi = z0 + zz - 1;
+    const bool zok = zi >= 0 && zi < D;
+    const float* __restrict__ slice = a.in + (size_t)(zi < 0 ? 0 : (zi >= D ? D - 1 : zi)) * HW;
+    const bool use2 = zz >= 2, use1 = zz >= 1 && zz <= nz, use0 = zz < nz;
+#pragma unroll 2
+    for (int c = 0; c < a.Cin; ++c) {
+      const float* __restrict__ wc = a.w + c * 27;
+      const float* __restrict__ inc = slice + (size_t)c * DHW;
+      float r[3][VX + 2];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const float* row = inc + yoff[kh];
+        const bool ok = zok && yok[kh];
+        const float l = row[xl], rr = row[xr];
+        r[kh][0] = (ok && lok) ? l : 0.0f;
+        r[kh][VX + 1] = (ok && rok) ? rr : 0.0f;
+        if (VEC) {
+          const f32x4 m = *reinterpret_cast<const f32x4*>(row + x0);
+#pragma unroll
+          for (int v = 0; v < VX; ++v) r[kh][1 + v] = ok ? m[v] : 0.0f;
+        } else {
+#pragma unroll
+          for (int v = 0; v < VX; ++v) {
+            const float t = row[x0 + v < W ? x0 + v : W - 1];
+            r[kh][1 + v] = (ok && x0 + v < W) ? t : 0.0f;
+          }
+        }
+      }
+      auto taps = [&](int kd, float (&acc)[VX]) {
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const float wv = wc[(kd * 3 + kh) * 3 + kw];
+#pragma unroll
+            for (int v = 0; v < VX; ++v) acc[v] = __builtin_fmaf(wv, r[kh][v + kw], acc[v]);
+          }
+      };
+      if (use2) taps(2, a0);
+      if (use1) taps(1, a1);
+      if (use0) taps(0, a2);
+    }
+    if (use2) {
+      const size_t o = (size_t)(zi - 1) * HW + (size_t)y * W + x0;
+      float res[VX];
+#pragma unroll
+      for (int v = 0; v < VX; ++v) {
+        float t = a0[v] + b;
+        if (a.relu) t = __builtin_fmaxf(t, 0.0f);
+        if (a.skip && x0 + v < W) t += a.skip[o + v];
+        res[v] = t;
+      }
+      if (VEC) *reinterpret_cast<f32x4*>(a.out + o) = f32x4{res[0], res[1], res[2], res[3]};
+      else {
+#pragma unroll
+        for (int v = 0; v < VX; ++v) if (x0 + v < W) a.out[o + v] = res[v];
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < VX; ++v) { a0[v] = a1[v]; a1[v] = a2[v]; a2[v] = 0.0f; }
+  }
+}
+
 // ---- softmax over D, depth regression, photometric confidence (CasMVSNet.py:648-663) ----------------------------
 // 256 threads = 256/DS consecutive pixels x DS interleaved depth slices (slice sl owns d = sl, sl + DS, ...): at stage 1
 // there are only 128 x 160 pixels, one thread per pixel would leave most of the chip idle behind 3 x 192 serial loads.
@@ -567,6 +812,23 @@ int svs_conv3d(const float* in, const float* weight, const float* bias, const fl
     }
   }
   return check_launch("svs_conv3d");
+}
+
+// 3x3x3, stride 1, padding 1 convolution to one output channel in float32 (fused multiply-adds): the U-Net's `prob`
+// layer.  weight [Cin][27][1].
+int svs_conv3d_c1(const float* in, const float* weight, const float* bias, const float* skip, float* out, int Cin, int D,
+                  int H, int W, int relu, void* hip_stream) {
+  if (!in || !weight || !out || Cin < 1 || D < 1 || H < 1 || W < 1) { set_error("svs_conv3d_c1: bad argument"); return SVS_EINVAL; }
+  C1Args a{in, weight, bias, skip, out, Cin, D, H, W, relu};
+  hipStream_t s = (hipStream_t)hip_stream;
+  if (W % 4 == 0 && Cin % 4 == 0) {
+    dim3 grid((H * (W / kC1VX) + 255) / 256, (D + kC1VZ - 1) / kC1VZ);
+    conv3d_c1_flat_kernel<<<grid, 256, 0, s>>>(in, weight, bias, skip, out, Cin, D, H, W, relu);
+  } else {
+    dim3 grid((W + kC1VX * kC1TX - 1) / (kC1VX * kC1TX), (H + kC1TY - 1) / kC1TY, (D + kC1VZ - 1) / kC1VZ);
+    conv3d_c1_kernel<false><<<grid, 256, 0, s>>>(a);
+  }
+  return check_launch("svs_conv3d_c1");
 }
 
 int svs_prob_depth_conf(const float* reg, const float* depth_values, int D, int H, int W, float* prob, float* depth,

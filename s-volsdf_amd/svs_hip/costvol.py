@@ -325,6 +325,11 @@ def conv3d(x, weight, bias=None, skip=None, stride=1, transposed=False, relu=Tru
     x = _f32(x)
     Cin, D, H, W = x.shape
     Cout = weight.shape[2]
+    if not transposed and stride == 1 and Cout == 1 and not os.environ.get("SVS_CONV_C1_OFF"):
+        out = torch.empty((1, D, H, W), device=x.device)
+        _lib.check(L.svs_conv3d_c1(_ptr(x), _ptr(_f32(weight)), _ptr(bias), _ptr(skip), _ptr(out), Cin, D, H, W, int(relu),
+                                   _stream()), "svs_conv3d_c1")
+        return out
     if not transposed and stride == 1 and Cin in (8, 16, 32) and Cout <= 16 and not os.environ.get("SVS_CONV_RING_OFF"):
         frag = mfma_weight_fragments(weight)
         out = torch.empty((Cout, D, H, W), device=x.device)

@@ -125,6 +125,7 @@ SIGNATURES = {
     "svs_conv3d_gemm_pack": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "svs_conv3d_gemm": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "svs_conv3d_mfma": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "svs_conv3d_c1": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "svs_split_volume_dims": (c_size_t, [c_int, c_int, c_int, c_int, POINTER(c_int)]),
     "svs_split_volume_pack": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "svs_warp_variance_split": (c_int, [_P, _PP, POINTER(c_float), c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),

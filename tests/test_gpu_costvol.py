@@ -191,6 +191,24 @@ def test_conv3d_pair_vs_float64(dev, cin, cout, shape):
         np.testing.assert_allclose(got, old, atol=3e-6 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("cin,shape", [(8, (5, 7, 37)), (8, (11, 33, 40)), (16, (3, 5, 6)), (8, (24, 40, 64))])
+def test_conv3d_one_output_channel(dev, cin, shape):
+    """The `prob` layer's kernel (Cout = 1, float32 FMAs on the vector ALUs) against a float64 torch convolution:
+    widths that are / are not multiples of 4, depths that do not fill a thread's z run, with and without skip and ReLU.
+    Tolerance 2e-6 of the output scale (216-term float32 sums)."""
+    from svs_hip import costvol
+    rng = np.random.default_rng(cin + shape[2])
+    x = rng.normal(0, 1, (cin,) + shape).astype(F32)
+    w = (rng.normal(0, 1, (cin, 27, 1)) / np.sqrt(27 * cin)).astype(F32)
+    skip = rng.normal(0, 1, (1,) + shape).astype(F32)
+    wt = torch.from_numpy(w).double().permute(2, 0, 1).reshape(1, cin, 3, 3, 3)
+    ref = torch.nn.functional.conv3d(torch.from_numpy(x).double()[None], wt, padding=1)[0].numpy()
+    got = costvol.conv3d(G(x, dev), G(w, dev), None, relu=False).cpu().numpy()
+    np.testing.assert_allclose(got, ref, atol=2e-6 * np.abs(ref).max())
+    got = costvol.conv3d(G(x, dev), G(w, dev), G(np.array([0.25], F32), dev), skip=G(skip, dev), relu=True).cpu().numpy()
+    np.testing.assert_allclose(got, np.maximum(ref + 0.25, 0) + skip, atol=2e-6 * np.abs(ref).max())
+
+
 @pytest.mark.parametrize("cin,shape", [(32, (16, 16, 24)), (16, (8, 24, 16)), (8, (8, 8, 8))])
 def test_costreg_vs_torch_reference(dev, cin, shape):
     """3-D U-Net on random volumes (incl. non-cubic shapes) against the plain torch float32 reference."""

@@ -11,7 +11,7 @@ def t(fn, n=10):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-for cin, cout, shp in ((32, 8, (192, 128, 160)), (16, 8, (32, 256, 320)), (8, 8, (8, 512, 640)), (8, 1, (192, 128, 160)), (16, 16, (96, 64, 80))):
+for cin, cout, shp in ((32, 8, (192, 128, 160)), (16, 8, (32, 256, 320)), (8, 8, (8, 512, 640)), (8, 1, (192, 128, 160)), (8, 1, (32, 256, 320)), (8, 1, (8, 512, 640)), (16, 16, (96, 64, 80))):
     x = torch.randn(cin, *shp, device=dev)
     wt = torch.randn(cin, 27, cout, device=dev) * 0.1
     b = torch.randn(cout, device=dev)
