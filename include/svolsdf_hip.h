@@ -407,6 +407,14 @@ size_t svs_conv3d_gemm_wfrag_bytes(int Cin, int Cout, int transposed);
 int svs_conv3d_gemm_pack(const float* weight, int Cin, int Cout, int transposed, void* wfrag, void* hip_stream);
 int svs_conv3d_gemm(const float* in, const void* wfrag, const float* bias, const float* skip, float* out, int Cin, int Cout,
                     int Di, int Hi, int Wi, int stride, int transposed, int relu, void* hip_stream);
+/* conv1 of CostRegNet (8 -> 2b channels, stride 2, from the full-resolution volume: CasMVSNet.py:445,461): a lane group
+ * owns whole (kz,ky) input rows, one 8-byte load per (row, channel) serves the taps kx = 1, 2 and the neighbour lane's
+ * value the tap kx = 0.  Cout <= 16, Wi even.  wfrag (svs_conv3d_s2c8_wfrag_bytes()): [9 k-steps][piece][lane][8] fp16,
+ * row lane & 15 = output channel, k = 32 s + 8 g + j with s = kx*3 + q, g = lane >> 4: tap ((g+4q)/3, (g+4q)%3, kx),
+ * input channel j; zero for g + 4q > 8. */
+size_t svs_conv3d_s2c8_wfrag_bytes(void);
+int svs_conv3d_s2c8(const float* in, const void* wfrag, const float* bias, const float* skip, float* out, int Cout, int Di,
+                    int Hi, int Wi, int relu, void* hip_stream);
 
 /* ---- a14 tail  softmax over D, depth regression, photometric confidence (models/CasMVSNet.py:648-663) ---------
  * reg, depth_values (D,H,W) -> prob (D,H,W), depth (H,W), conf (H,W), index (H,W int, may be NULL). */

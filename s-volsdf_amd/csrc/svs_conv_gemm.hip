@@ -50,7 +50,7 @@ __host__ __device__ constexpr int ksteps_max(int cin, bool transposed) { return 
 // transposed: 0 convolution, 1 transposed (8 classes), 2 transposed with the x-parities paired (4 classes, M = 2 Cout)
 __global__ void pack_kernel(const float* __restrict__ w, int Cin, int Cout, int transposed, int MT, f16x8* __restrict__ frag) {
   const int KS = ksteps_max(Cin, transposed != 0);
-  const int n_class = transposed == 1 ? 8 : (transposed == 2 ? 4 : 1);
+  const int n_class = transposed == 1 ? 8 : (transposed >= 2 ? 4 : 1);
   const long long total = (long long)n_class * KS * MT * 64;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -61,6 +61,18 @@ __global__ void pack_kernel(const float* __restrict__ w, int Cin, int Cout, int 
   int tap = -1;
   if (!transposed) {
     if (t < 27) tap = t;
+  } else if (transposed == 3) {
+    // all classes share the B operand: slot t = (dz*2 + dy)*2 + dxs of the 8 input voxels a 2x2x2 output cell touches;
+    // class c = (pz,py) takes offset d along an axis with kernel index {parity 0: d=0 -> 1; parity 1: d=1 -> 0, d=0 -> 2}
+    const int pz = (c >> 1) & 1, py = c & 1;
+    const int px = co >= Cout ? 1 : 0;
+    co -= px * Cout;
+    if (px == 1 && co >= Cout) co = 1 << 20;
+    const int dz = t >> 2, dy = (t >> 1) & 1, dxs = t & 1;
+    const int kz = pz == 0 ? (dz == 0 ? 1 : -1) : (dz == 1 ? 0 : 2);
+    const int ky = py == 0 ? (dy == 0 ? 1 : -1) : (dy == 1 ? 0 : 2);
+    const int kx = px == 0 ? (dxs == 0 ? 1 : -1) : (dxs == 0 ? 2 : 0);
+    if (t < 8 && kz >= 0 && ky >= 0 && kx >= 0) tap = (kz * 3 + ky) * 3 + kx;
   } else if (transposed == 2) {
     // slot t = (a * ny + b) * 2 + dxs: input offset (dz(a), dy(b), dxs); row block px = co / Cout
     const int pz = (c >> 1) & 1, py = c & 1;
@@ -198,6 +210,152 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Args a) {
     }
 }
 
+// MODE 3 (Cin = 16, Cout = 8: conv11, the transposed convolution back to full resolution): one wave computes the whole
+// 2x2x2 output cell of each of its 16 input voxels -- the four (pz,py) classes as four M tiles (rows = 8 channels x
+// 2 x-parities) over ONE set of B fragments, the 8 input voxels (zi + dz, yi + dy, xi + dxs) x 16 channels = 4 k-steps;
+// a class skips the k-steps whose (dz,dy) it does not touch (9 of 16 blocks remain: the MFMA count of MODE 2).
+// The layer is HBM traffic (283 MB at stage 1: skip in, output out) behind a handful of MFMAs; as four MODE-2 waves per
+// cell each wave had ~3 KB in flight and the latency of its skip read at the very end (0.123 ms = 2.3 TB/s).  Here
+// every load of the wave -- 4 k-steps of B and the 16 skip values per lane -- is issued before the first MFMA.
+template <int CIN>
+__global__ __launch_bounds__(256) void deconv_cell_kernel(Args a) {
+  static_assert(CIN == 16, "one k-step = one (dz,dy) pair of input rows");
+  constexpr int KS = 8 * CIN / 32;
+  const int lane = threadIdx.x & 63;
+  const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= (long long)a.rows * a.xtiles) return;
+  const int xt = (int)(tile % a.xtiles), row = (int)(tile / a.xtiles);
+  const int n = lane & 15, g = lane >> 4;
+  const int zi = row / a.Hi, yi = row - zi * a.Hi, xi = 16 * xt + n;
+  const bool col_ok = xi < a.Wi;
+  const size_t chan_in = (size_t)a.Di * a.Hi * a.Wi, chan_out = (size_t)a.Do * a.Ho * a.Wo;
+  const int odd = g >> 1, cob = 4 * (g & 1);          // accumulator rows 4 g + j: channel cob + j at x = 2 xi + odd
+  // ---- skip values of the cell (16 per lane), requested first
+  float sk[4][4];
+  size_t obase[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    obase[m] = (size_t)cob * chan_out + ((size_t)(2 * zi + (m >> 1)) * a.Ho + (2 * yi + (m & 1))) * a.Wo + 2 * xi + odd;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sk[m][j] = (a.skip && col_ok) ? a.skip[obase[m] + (size_t)j * chan_out] : 0.0f;
+  }
+  // ---- B operand: k-step s = input rows (zi + (s >> 1), yi + (s & 1)), lane group g = (voxel xi + (g >> 1), channels 8 (g & 1)..)
+  float x[KS][8];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int iz = zi + (s >> 1), iy = yi + (s & 1), ix = xi + (g >> 1);
+    const bool ok = col_ok && iz < a.Di && iy < a.Hi && ix < a.Wi;
+    const float* p = a.in + (size_t)(8 * (g & 1)) * chan_in + ((size_t)(ok ? iz : 0) * a.Hi + (ok ? iy : 0)) * a.Wi + (ok ? ix : 0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float v = p[(size_t)j * chan_in]; x[s][j] = ok ? v : 0.0f; }
+  }
+  const f16x8* __restrict__ wf = a.wfrag + lane;      // [class][k-step][piece][lane]
+  f32x4 acc[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    f16x8 bh, bm;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const _Float16 h = (_Float16)x[s][j];
+      bh[j] = h; bm[j] = (_Float16)(x[s][j] - (float)h);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      if ((s >> 1) > (m >> 1) || (s & 1) > (m & 1)) continue;     // the class does not reach these input rows
+      const f16x8 ah = wf[(m * KS + s) * 128], am = wf[(m * KS + s) * 128 + 64];
+      acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am, bh, acc[m], 0, 0, 0);
+      acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bm, acc[m], 0, 0, 0);
+      acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[m], 0, 0, 0);
+    }
+  }
+  if (!col_ok) return;
+  float bias[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bias[j] = a.bias ? a.bias[cob + j] : 0.0f;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float r = acc[m][j] + bias[j];
+      if (a.relu) r = __builtin_fmaxf(r, 0.0f);
+      a.out[obase[m] + (size_t)j * chan_out] = r + sk[m][j];
+    }
+}
+
+// conv1 of the U-Net (8 -> 16 channels, stride 2, full resolution in: models/CasMVSNet.py:445,461): the general kernel
+// gathers every tap with 4-byte loads at stride 2 (56 load instructions per lane, three per input row touching the
+// same lines) and was bound by the vector L1 (0.082 ms at stage 1 for 126 MB of input).  Here a lane group owns whole
+// (kz,ky) input rows: one float2 load per (row, channel) brings the columns 2xo, 2xo+1 = taps kx 1 and 2, and tap
+// kx 0 (column 2xo-1) is the neighbour lane's second value (DPP row shift).  A wave's 16 columns are 15 outputs plus,
+// in lane 0, the column to their left, which only feeds lane 1 (loading the edge column separately cost as much L1
+// time as a full gather: the cost is per line touched).  K order: k-step s = kx*3 + q carries rows g + 4q (g = lane
+// group; rows 9..11: zero weights), 8 channels each: 9 k-steps instead of 7, 24 loads per lane instead of 56, all
+// issued up front.
+__global__ __launch_bounds__(256) void conv_s2c8_kernel(Args a) {
+  const int lane = threadIdx.x & 63;
+  const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= (long long)a.rows * a.xtiles) return;
+  const int xt = (int)(tile % a.xtiles), row = (int)(tile / a.xtiles);
+  const int n = lane & 15, g = lane >> 4;
+  const int zo = row / a.Ho, yo = row - zo * a.Ho, xo = 15 * xt + n - 1;
+  const bool col_in = xo >= 0 && xo < a.Wo;           // lane 0 of the first tile: the zero padding left of the volume
+  const bool col_ok = col_in && n > 0;                // lane 0 computes nothing of its own
+  const size_t chan_in = (size_t)a.Di * a.Hi * a.Wi;
+  const int xc = col_in ? 2 * xo : 0;                 // even column of this lane's pair (Wi is even: 2xo+1 < Wi)
+  float x0[3][8], x1[3][8], x2[3][8];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int r = g + 4 * q;
+    const int iz = 2 * zo - 1 + r / 3, iy = 2 * yo - 1 + r % 3;
+    const bool ok = col_in && r < 9 && (unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi;
+    const float* p = a.in + ((size_t)(ok ? iz : 0) * a.Hi + (ok ? iy : 0)) * a.Wi;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float2 v = *reinterpret_cast<const float2*>(p + (size_t)j * chan_in + xc);
+      const float odd = ok ? v.y : 0.0f;
+      // lane n takes lane n-1's odd column (s_nop: DPP source hazard; inline assembly: see the note in svs_costvol.hip,
+      // conv3d_c1_flat_kernel)
+      float e = 0.0f;
+      asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(e) : "v"(odd));   // (not volatile: a
+      // volatile asm is a barrier to the loads around it and the 24 loads would be waited for one by one)
+      x0[q][j] = e;
+      x1[q][j] = ok ? v.x : 0.0f;
+      x2[q][j] = odd;
+    }
+  }
+  const f16x8* __restrict__ wf = a.wfrag + lane;      // [k-step][piece][lane]
+  f32x4 acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  auto kstep = [&](int s, const float* x) {
+    f16x8 bh, bm;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const _Float16 h = (_Float16)x[j];
+      bh[j] = h; bm[j] = (_Float16)(x[j] - (float)h);
+    }
+    const f16x8 ah = wf[s * 128], am = wf[s * 128 + 64];
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(am, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+  };
+#pragma unroll
+  for (int q = 0; q < 3; ++q) { kstep(q, x0[q]); kstep(3 + q, x1[q]); kstep(6 + q, x2[q]); }
+  if (!col_ok) return;
+  const size_t chan_out = (size_t)a.Do * a.Ho * a.Wo;
+  const size_t vox = ((size_t)zo * a.Ho + yo) * a.Wo + xo;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int co = 4 * g + j;
+    if (co >= a.Cout) continue;
+    float r = acc[j] + (a.bias ? a.bias[co] : 0.0f);
+    if (a.relu) r = __builtin_fmaxf(r, 0.0f);
+    const size_t o = (size_t)co * chan_out + vox;
+    if (a.skip) r += a.skip[o];
+    a.out[o] = r;
+  }
+}
+
 template <int CIN, int MODE>
 static void launch_mt(const Args& a, int MT, long long tiles, hipStream_t s) {
   const unsigned grid = (unsigned)((tiles + 3) / 4);
@@ -219,7 +377,10 @@ static bool launch_cin(const Args& a, int Cin, int MT, long long tiles, hipStrea
 
 static int m_tiles(int rows) { return rows <= 16 ? 1 : (rows <= 32 ? 2 : 4); }
 // the transposed form pairs the x-parities when both fit the 64 output rows of a wave and rows split on lanes' groups of 4
-static int deconv_mode(int Cout) { return (Cout <= 32 && Cout % 4 == 0) ? 2 : 1; }
+static int deconv_mode(int Cin, int Cout) {
+  if (Cin == 16 && Cout == 8) return 3;            // whole 2x2x2 cells per wave (deconv_cell_kernel)
+  return (Cout <= 32 && Cout % 4 == 0) ? 2 : 1;
+}
 
 }  // namespace convgemm
 }  // namespace svs
@@ -233,15 +394,15 @@ int svs_conv3d_gemm_supported(int Cin, int Cout) { return (Cin == 8 || Cin == 16
 
 size_t svs_conv3d_gemm_wfrag_bytes(int Cin, int Cout, int transposed) {
   if (!svs_conv3d_gemm_supported(Cin, Cout)) return 0;
-  const int mode = transposed ? deconv_mode(Cout) : 0;
-  return (size_t)(mode == 1 ? 8 : (mode == 2 ? 4 : 1)) * ksteps_max(Cin, mode != 0) * m_tiles(mode == 2 ? 2 * Cout : Cout) * 128 * sizeof(f16x8);
+  const int mode = transposed ? deconv_mode(Cin, Cout) : 0;
+  return (size_t)(mode == 1 ? 8 : (mode >= 2 ? 4 : 1)) * ksteps_max(Cin, mode != 0) * m_tiles(mode >= 2 ? 2 * Cout : Cout) * 128 * sizeof(f16x8);
 }
 
 int svs_conv3d_gemm_pack(const float* weight, int Cin, int Cout, int transposed, void* wfrag, void* hip_stream) {
   if (!weight || !wfrag || !svs_conv3d_gemm_supported(Cin, Cout)) { set_error("svs_conv3d_gemm_pack: bad argument"); return SVS_EINVAL; }
-  const int mode = transposed ? deconv_mode(Cout) : 0;
-  const int MT = m_tiles(mode == 2 ? 2 * Cout : Cout);
-  const long long total = (long long)(mode == 1 ? 8 : (mode == 2 ? 4 : 1)) * ksteps_max(Cin, mode != 0) * MT * 64;
+  const int mode = transposed ? deconv_mode(Cin, Cout) : 0;
+  const int MT = m_tiles(mode >= 2 ? 2 * Cout : Cout);
+  const long long total = (long long)(mode == 1 ? 8 : (mode >= 2 ? 4 : 1)) * ksteps_max(Cin, mode != 0) * MT * 64;
   pack_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)hip_stream>>>(weight, Cin, Cout, mode, MT, (f16x8*)wfrag);
   return check_launch("svs_conv3d_gemm_pack");
 }
@@ -258,7 +419,11 @@ int svs_conv3d_gemm(const float* in, const void* wfrag, const float* bias, const
   if (transposed) {
     a.Do = 2 * Di; a.Ho = 2 * Hi; a.Wo = 2 * Wi;
     a.xtiles = (Wi + 15) / 16; a.rows = Di * Hi;
-    if (deconv_mode(Cout) == 2) { MT = m_tiles(2 * Cout); launch_cin<2>(a, Cin, MT, 4LL * a.rows * a.xtiles, s); }
+    const int mode = deconv_mode(Cin, Cout);
+    if (mode == 3) {
+      const long long tiles = (long long)a.rows * a.xtiles;
+      deconv_cell_kernel<16><<<(unsigned)((tiles + 3) / 4), 256, 0, s>>>(a);
+    } else if (mode == 2) { MT = m_tiles(2 * Cout); launch_cin<2>(a, Cin, MT, 4LL * a.rows * a.xtiles, s); }
     else launch_cin<1>(a, Cin, MT, 8LL * a.rows * a.xtiles, s);
   } else {
     a.Do = (Di - 1) / stride + 1; a.Ho = (Hi - 1) / stride + 1; a.Wo = (Wi - 1) / stride + 1;
@@ -266,6 +431,26 @@ int svs_conv3d_gemm(const float* in, const void* wfrag, const float* bias, const
     launch_cin<0>(a, Cin, MT, (long long)a.rows * a.xtiles, s);
   }
   return check_launch("svs_conv3d_gemm");
+}
+
+// The stride-2 convolution from 8 channels (conv1) with whole input rows per lane group (conv_s2c8_kernel): Cout <= 16,
+// Wi even.  wfrag: 9 k-steps x 2 pieces x 64 lanes x 16 B: row = lane & 15 (output channel), k = 32 s + 8 g + j with
+// s = kx*3 + q, g = lane >> 4: the folded weight of tap ((g + 4q) / 3, (g + 4q) % 3, kx) and input channel j (zero for
+// g + 4q > 8).
+size_t svs_conv3d_s2c8_wfrag_bytes(void) { return (size_t)9 * 2 * 64 * 16; }
+int svs_conv3d_s2c8(const float* in, const void* wfrag, const float* bias, const float* skip, float* out, int Cout, int Di,
+                    int Hi, int Wi, int relu, void* hip_stream) {
+  if (!in || !wfrag || !out || Cout < 1 || Cout > 16 || Di < 1 || Hi < 1 || Wi < 2 || (Wi & 1)) {
+    set_error("svs_conv3d_s2c8: bad argument (Cout <= 16, Wi even)"); return SVS_EINVAL;
+  }
+  Args a;
+  a.in = in; a.wfrag = (const f16x8*)wfrag; a.bias = bias; a.skip = skip; a.out = out; a.Cout = Cout;
+  a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.stride = 2; a.relu = relu;
+  a.Do = (Di - 1) / 2 + 1; a.Ho = (Hi - 1) / 2 + 1; a.Wo = (Wi - 1) / 2 + 1;
+  a.xtiles = (a.Wo + 14) / 15; a.rows = a.Do * a.Ho;
+  const long long tiles = (long long)a.rows * a.xtiles;
+  conv_s2c8_kernel<<<(unsigned)((tiles + 3) / 4), 256, 0, (hipStream_t)hip_stream>>>(a);
+  return check_launch("svs_conv3d_s2c8");
 }
 
 }  // extern "C"

@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256, 4) void conv3d_c1_flat_kernel(const float* __r
           // with __builtin_amdgcn_update_dpp hipcc 7.2 fed m[0] to BOTH shifts.  s_nop: a DPP source written by the
           // preceding vector instruction needs two wait states, which the compiler does not insert for inline assembly.
           float l = cur.e[kh], rr = cur.e[kh];
-          asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+          asm("s_nop 1\n\tv_mov_b32_dpp %0, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
                        "v_mov_b32_dpp %1, %3 wave_shl:1 row_mask:0xf bank_mask:0xf"
                        : "+v"(l), "+v"(rr) : "v"(m[3]), "v"(m[0]));
           r[kh][0] = (ok && lok) ? l : 0.0f;

@@ -38,15 +38,48 @@ def host_copy(t):
     return hit[1]
 
 
+_RT_CACHE = {}
+_HWC_CACHE = {}
+
+
+def _tensor_key(t):
+    return (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), str(t.device), t.dtype)
+
+
 def _rot_trans(proj_matrices):
-    """(1,V,2,4,4) projection matrices -> ctypes float[12*(V-1)] for svs_warp_variance (host launch arguments)."""
+    """(1,V,2,4,4) projection matrices -> ctypes float[12*(V-1)] for svs_warp_variance (host launch arguments).
+    Cached per tensor like host_copy: a stage's matrices are the same tensor in every iteration of the stage loop."""
+    key = _tensor_key(proj_matrices)
+    hit = _RT_CACHE.get(key)
+    if hit is not None:
+        return hit[1]
     P = host_copy(proj_matrices)[0]
     n_src = P.shape[0] - 1
     rt = (ctypes.c_float * (12 * n_src))()
     for v in range(n_src):
         for k, x in enumerate(relative_projection(P[v + 1], P[0])):
             rt[12 * v + k] = float(x)
+    if len(_RT_CACHE) >= 64:
+        _RT_CACHE.clear()
+    _RT_CACHE[key] = (proj_matrices, rt)
     return rt
+
+
+def _hwc(f):
+    """(C,H,W) source feature map -> its channel-last copy (H,W,C), cached per tensor (storage + version): a view's
+    features are built once per scan and warped in every cost-volume build of the stage loop."""
+    key = _tensor_key(f)
+    hit = _HWC_CACHE.get(key)
+    if hit is not None:
+        return hit[1]
+    L = _lib.load()
+    C, H, W = f.shape
+    o = torch.empty(H, W, C, device=f.device)
+    _lib.check(L.svs_chw_to_hwc(_ptr(_f32(f)), _ptr(o), C, H, W, _stream()), "svs_chw_to_hwc")
+    if len(_HWC_CACHE) >= 32:
+        _HWC_CACHE.clear()
+    _HWC_CACHE[key] = (f, o)          # keeps `f` alive: the key holds its address
+    return o
 
 
 class SplitVolume:
@@ -104,11 +137,7 @@ def warp_variance(features, proj_matrices, depth_values, split=False):
     D = depth_values.shape[1]
     dev = ref.device
     n_src = len(features) - 1
-    hwc = []
-    for f in features[1:]:
-        o = torch.empty(H, W, C, device=dev)
-        _lib.check(L.svs_chw_to_hwc(_ptr(_f32(f[0])), _ptr(o), C, H, W, _stream()), "svs_chw_to_hwc")
-        hwc.append(o)
+    hwc = [_hwc(f[0]) for f in features[1:]]
     rt = _rot_trans(proj_matrices)
     dv = _f32(depth_values[0])
     if split:
@@ -295,6 +324,32 @@ def gemm_enabled(on=None):
     return _GEMM_ON[0]
 
 
+def s2c8_weight_fragments(weight):
+    """[8][27][Cout <= 16] folded float32 weights -> the fp16 hi / mid A fragments of svs_conv3d_s2c8
+    ([9 k-steps][piece][lane][8], include/svolsdf_hip.h)."""
+    key = ("s2c8", weight.data_ptr(), weight._version, tuple(weight.shape))
+    hit = _WFRAG_CACHE.get(key)
+    if hit is not None:
+        return hit[0]
+    Cin, _, Cout = weight.shape
+    dev = weight.device
+    s = torch.arange(9, device=dev).view(9, 1, 1)
+    lane = torch.arange(64, device=dev).view(1, 64, 1)
+    j = torch.arange(8, device=dev).view(1, 1, 8).expand(9, 64, 8)
+    kx, q = s // 3, s % 3
+    row = (lane >> 4) + 4 * q
+    co = (lane & 15).expand(9, 64, 8)
+    ok = ((row < 9) & (co < Cout)).expand(9, 64, 8)
+    tap = (row.clamp(max=8) * 3 + kx).expand(9, 64, 8)
+    w = weight[j, tap, co.clamp(max=Cout - 1)]
+    w = torch.where(ok, w, torch.zeros_like(w)).float()
+    hi = w.half()
+    mid = (w - hi.float()).half()
+    frag = torch.stack([hi, mid], 1).contiguous()          # (9, 2, 64, 8) fp16
+    _WFRAG_CACHE[key] = (frag, weight)
+    return frag
+
+
 def gemm_weight_fragments(weight, transposed):
     """[Cin][27][Cout] folded float32 weights -> the A fragments of svs_conv3d_gemm (packed on the device, cached)."""
     key = (weight.data_ptr(), weight._version, tuple(weight.shape), bool(transposed))
@@ -341,6 +396,11 @@ def conv3d(x, weight, bias=None, skip=None, stride=1, transposed=False, relu=Tru
     else:
         shp = (Cout, (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1)
     out = torch.empty(shp, device=x.device)
+    if not transposed and stride == 2 and Cin == 8 and Cout <= 16 and W % 2 == 0 and not os.environ.get("SVS_CONV_S2C8_OFF"):
+        frag = s2c8_weight_fragments(weight)
+        _lib.check(L.svs_conv3d_s2c8(_ptr(x), _ptr(frag), _ptr(bias), _ptr(skip), _ptr(out), Cout, D, H, W, int(relu),
+                                     _stream()), "svs_conv3d_s2c8")
+        return out
     if gemm_enabled() and L.svs_conv3d_gemm_supported(Cin, Cout):
         frag = gemm_weight_fragments(weight, transposed)
         _lib.check(L.svs_conv3d_gemm(_ptr(x), _ptr(frag), _ptr(bias), _ptr(skip), _ptr(out), Cin, Cout, D, H, W, stride,

@@ -191,6 +191,24 @@ def test_conv3d_pair_vs_float64(dev, cin, cout, shape):
         np.testing.assert_allclose(got, old, atol=3e-6 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("cout,shape", [(16, (5, 7, 38)), (16, (6, 9, 70)), (12, (8, 8, 32)), (16, (16, 24, 96))])
+def test_conv3d_stride2_from_8_channels(dev, cout, shape):
+    """conv1's kernel (8 -> Cout <= 16, stride 2; whole input rows per lane group, tap kx = 0 from the neighbour lane)
+    against a float64 torch convolution: odd D / H, output widths that do not fill a 16-column tile, several tiles per
+    row (the tile's left edge column).  Tolerance 3e-6 of the output scale (fp16x2 operands)."""
+    from svs_hip import costvol
+    rng = np.random.default_rng(cout + shape[2])
+    x = rng.normal(0, 1, (8,) + shape).astype(F32)
+    w = (rng.normal(0, 1, (8, 27, cout)) / np.sqrt(27 * 8)).astype(F32)
+    b = rng.normal(0, 1, cout).astype(F32)
+    got = costvol.conv3d(G(x, dev), G(w, dev), G(b, dev), stride=2, relu=True).cpu().numpy()
+    wt = torch.from_numpy(w).double().permute(2, 0, 1).reshape(cout, 8, 3, 3, 3)
+    ref = torch.nn.functional.conv3d(torch.from_numpy(x).double()[None], wt, torch.from_numpy(b).double(), stride=2,
+                                     padding=1)[0].clamp(min=0).numpy()
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, atol=3e-6 * np.abs(ref).max())
+
+
 @pytest.mark.parametrize("cin,shape", [(8, (5, 7, 37)), (8, (11, 33, 40)), (16, (3, 5, 6)), (8, (24, 40, 64))])
 def test_conv3d_one_output_channel(dev, cin, shape):
     """The `prob` layer's kernel (Cout = 1, float32 FMAs on the vector ALUs) against a float64 torch convolution:
