@@ -24,8 +24,11 @@ for name, cin, cout, (d, h, w), stride, tr in (("conv0", C0, 8, (D, H, W), 1, Fa
     x = torch.randn(cin, d, h, w, device=dev)
     wt = torch.randn(cin, 27, cout, device=dev) * 0.1
     b = torch.randn(cout, device=dev)
-    ms = t(lambda: costvol.conv3d(x, wt, b, stride=stride, transposed=tr))
     od = (d * 2, h * 2, w * 2) if tr else ((d - 1) // stride + 1, (h - 1) // stride + 1, (w - 1) // stride + 1)
+    xin = costvol.SplitVolume.pack(x) if name == "conv0" else x              # conv0 reads the producer's split volume
+    skip = torch.randn(cout, *od, device=dev) if tr else None                # the transposed layers add a skip
+    b = None if name == "prob" else b
+    ms = t(lambda: costvol.conv3d(xin, wt, b, skip=skip, stride=stride, transposed=tr, relu=name != "prob"))
     macs = od[0] * od[1] * od[2] * cout * cin * (27 / 8 if tr else 27)
     tot += ms
     print(f"{name:7s} {cin:3d}->{cout:3d} {ms:7.3f} ms  {2 * macs / ms / 1e9:7.1f} TFLOP/s")
