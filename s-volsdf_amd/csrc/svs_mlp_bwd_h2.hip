@@ -259,11 +259,16 @@ struct PassAEpi {
         up[q] = hi8(v8, 1.0f);
       }
       if (GP) split8(w8, a2p[q], a2q[q]); else a2p[q] = hi8(w8, 1.0f);
+#if !(SVS_ABL & 2048)  // diagnostic: no u / a2 stores
       if (!LATE) { store_grad<GP>(ublk, k, lane, up[q], uq[q]); store_grad<GP>(a2blk, k, lane, a2p[q], a2q[q]); }
+#endif
     }
   }
   // k-step s of the tile whose MFMAs cover this epilogue: the four (GP: eight) stores of tile tp behind the last LDS-DMA piece
   __device__ __forceinline__ void store_slot(int tp, int s) {
+#if SVS_ABL & 2048
+    return;
+#endif
     if (s == 9) store_piece(ublk, 2 * tp, lane, up[0], 0);
     if (GP && s == 10) store_piece(ublk, 2 * tp, lane, uq[0], 1);
     if (s == 11) store_piece(a2blk, 2 * tp, lane, a2p[0], 0);
@@ -293,8 +298,12 @@ __device__ __forceinline__ void pass_a_layer_h2(Stream& st, const Pieces2& in, P
   for (int t = 0; t < 8; ++t) {
     if (t == 7 && ep.l3) break;
     TilePieces hload, gload;
+#if SVS_ABL & 1024     // diagnostic: no side-tile loads
+    hload = ep.h; gload = ep.g;
+#else
     load_tile_grad<GP>(hblk, t, lane, hload);
     load_tile_grad<GP>(gblk, t, lane, gload);
+#endif
     const bool fetch = !(LAST && t == 7);
     f32x16 acc;
     if (!fetch) acc = tile_mma_h2<16>(st.cur_buf(), in, lane, [&](int s) { ep.a(s); }, [&](int s) { ep.b(t - 1, s); });

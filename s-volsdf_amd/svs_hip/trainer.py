@@ -206,9 +206,10 @@ class TrainStep:
     GPU_MAX_HW_QUEUES = 2 ... 8: 3.0 ms/step at the default 4, 3.7 - 4.3 ms at any other value, against 3.1 ms unsplit at
     every value: with a queue of its own the small group's launches run truly concurrently and cost the large group a
     fourth round).  groups="auto" therefore MEASURES, once the process has warmed up (the first steps of a process are
-    slow and noisy: allocator growth, clocks): steps TUNE_START .. run split, the following ones unsplit (TUNE_STEPS each,
-    the first TUNE_SKIP of a phase untimed, whole steps timed with events on the step's stream), and the faster schedule
-    is kept (`schedule`); until then the step runs split.
+    slow and noisy: allocator growth, clocks): from step TUNE_START on, 2 * TUNE_STEPS steps alternate between the split
+    and the unsplit schedule (the first TUNE_SKIP of each untimed, whole steps timed with events on the step's stream), and
+    the unsplit schedule is kept only if its median beats the split one by more than half the spread of the samples
+    (`schedule`); until then the step runs split.
 
     Captured steps (graph=True or SVS_TRAIN_GRAPH=1; off by default: eager launches are faster on this ROCm stack,
     DESIGN.md section 5).  The launch sequence contains no host
@@ -319,9 +320,9 @@ class TrainStep:
         i = st["i"] - self.TUNE_START
         if i < 0:
             return st, None, None                             # not yet: split, untimed
-        n = self.TUNE_STEPS
-        mode = "split" if i < n else "whole"
-        timed = (i % n) >= self.TUNE_SKIP
+        # the two schedules alternate step by step (clock drift, a preview render or a logging stall then hit both alike)
+        mode = "split" if i % 2 == 0 else "whole"
+        timed = i >= 2 * self.TUNE_SKIP
         self._force_groups = split if mode == "split" else [(0, R)]
         ev0 = None
         if timed:
@@ -341,8 +342,10 @@ class TrainStep:
             for mode, a, b in st["ev"]:
                 ms[mode].append(a.elapsed_time(b))
             med = {k: sorted(v)[len(v) // 2] for k, v in ms.items()}
-            self.schedule[R] = dict(choice="split" if med["split"] <= med["whole"] else "whole", ms_split=med["split"],
-                                    ms_whole=med["whole"])
+            spread = max(max(v) - min(v) for v in (sorted(x)[1:-1] or x for x in ms.values()))
+            # within the noise of the samples the split schedule stays (it is the better one wherever a difference shows)
+            choice = "whole" if med["whole"] < med["split"] - 0.5 * spread else "split"
+            self.schedule[R] = dict(choice=choice, ms_split=med["split"], ms_whole=med["whole"], spread=spread)
             del self._tune[R]
 
     def _step(self, model_input, ground_truth, mvs=None, fast=1):
@@ -356,11 +359,15 @@ class TrainStep:
             if out is not None:
                 return self._finish(out)
         tune = None if self.graph else self._tune_begin(R)
-        rng = m.draw_train_rng(R, uv.device, stream=self.scratch.prep)      # uploads on the (idle) pack stream
-        gt = {"rgb": ground_truth["rgb"].reshape(-1, 3), "rgb_smooth": ground_truth["rgb_smooth"].reshape(-1, 3)}
-        results, holds = self._device_step(self.scratch, model_input, gt, mvs, fast, rng, dyn=None)
-        self._hold = holds
-        out = self._finish(results)
+        try:
+            rng = m.draw_train_rng(R, uv.device, stream=self.scratch.prep)      # uploads on the (idle) pack stream
+            gt = {"rgb": ground_truth["rgb"].reshape(-1, 3), "rgb_smooth": ground_truth["rgb_smooth"].reshape(-1, 3)}
+            results, holds = self._device_step(self.scratch, model_input, gt, mvs, fast, rng, dyn=None)
+            self._hold = holds
+            out = self._finish(results)
+        except BaseException:
+            self._force_groups = None            # a failed step (e.g. an OOM the caller catches) must not pin the schedule
+            raise
         if tune is not None:
             self._tune_end(R, tune)
         return out
@@ -472,8 +479,23 @@ class TrainStep:
         R = model_input["uv"].shape[1]
         mk = None
         if mvs is not None:
+            # everything ops.cost_lookup hands to the kernel BY VALUE is baked into the capture: the cost / z range
+            # addresses and shapes, and the camera parameters of every view (an MVS re-run can return a re-used address
+            # with different cameras)
+            def view_key(v):
+                ptrs = tuple((int(v[k].data_ptr()), tuple(v[k].shape)) for k in ("cost", "z_mvs") if torch.is_tensor(v.get(k)))
+                cams = []
+                for k in sorted(v):
+                    if k in ("cost", "z_mvs"):
+                        continue
+                    x = v[k]
+                    if torch.is_tensor(x):
+                        cams.append((k, int(x.data_ptr()), x._version, tuple(x.shape)))
+                    else:
+                        cams.append((k, repr(x)))
+                return ptrs, tuple(cams)
             mk = (len(mvs["views"]), tuple(mvs["img_res"]), bool(mvs.get("inverse_depth", False)),
-                  tuple(int(v["cost"].data_ptr()) for v in mvs["views"]))
+                  tuple(view_key(v) for v in mvs["views"]))
         return (R, tuple(self._groups_for(R)), fast, mk, str(model_input["uv"].device), self.graph)
 
     def _upload(self, cs, model_input, ground_truth, mvs):
@@ -510,7 +532,8 @@ class TrainStep:
         cs = self._captured.get(key)
         if cs is None:
             if len(self._captured) >= 4:                 # a few configurations at most (stages, render previews)
-                self._captured.pop(next(iter(self._captured)))
+                # the evicted graph's result tensors may still be the caller's: it is destroyed one step later
+                self._evicted = self._captured.pop(next(iter(self._captured)))
             cs = self._captured[key] = _CapturedStep()
         cs.calls += 1
         if cs.calls == 1:

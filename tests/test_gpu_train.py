@@ -452,3 +452,16 @@ def test_ray_group_schedule_is_measured(dev):
     inp2 = dict(inp, uv=inp["uv"][:, :64].contiguous())
     ts2(inp2, {k: v[:, :64].contiguous() for k, v in gt.items()})
     assert ts2.schedule[64]["choice"] == "whole"
+    # a step that fails inside the measurement window leaves no forced schedule behind
+    ts3 = TrainStep(m, loss, lr=5e-4, groups="auto", graph=False)
+    ts3.TUNE_START = 0
+
+    def boom(*a, **k):
+        raise RuntimeError("simulated failure inside the step")
+    orig, ts3._device_step = ts3._device_step, boom
+    with pytest.raises(RuntimeError):
+        ts3(inp, gt)
+    assert ts3._force_groups is None
+    ts3._device_step = orig
+    lo, _ = ts3(inp, gt)
+    assert np.isfinite(float(lo["loss"]))

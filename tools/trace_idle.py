@@ -1,7 +1,9 @@
 """GPU idle time per step from a rocprofv3 kernel trace of bench.py: the union of all kernel intervals (all streams) over the
 last steps of the run, against the wall time they span.
-    rocprofv3 --kernel-trace -d <dir> --output-format csv -- python3 bench.py --steps 30 --warmup 10 --settle 0 \
-              --no-cpu-baseline --no-exact-f32 --no-kernel-timing
+    rocprofv3 --kernel-trace -d <dir> --output-format csv -- python3 bench.py --steps 30 --warmup 50 --settle 0 \
+              --no-cpu-baseline --no-exact-f32 --no-gpu-torch --no-kernel-timing
+(--warmup 50: the auto-schedule measurement of trainer.TrainStep alternates split and whole steps during steps 24-47 of a
+process; the traced steps must all run the schedule it settled on -- or pass --groups none / a fixed split)
     python tools/trace_idle.py <dir> [n_steps]
 """
 import csv
