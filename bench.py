@@ -21,7 +21,7 @@ Rank 0 prints ONE JSON line.  `roofline` prices the kernel with the largest time
 come from HIP events on each kernel's own launch stream (svs_hip/profiling.py) over steps run right AFTER the timed
 region in the same process -- an event pair per launch would perturb the timed region, and a replayed graph's kernels
 cannot be bracketed at all -- and are listed for every fused-MLP kernel under `roofline.kernels`.  `cpu_baseline` times the CPU port on a bounded sample of the same workload.
-`gpu_torch_baseline` times the reference's differentiable part -- plain PyTorch float32 autograd + clip + Adam -- on the same GPU.
+`gpu_torch_baseline` times the reference's step -- the sampler under no_grad, then plain PyTorch float32 autograd + clip + Adam -- on the same GPU.
 
 Precision.  The default (SVS_MLP_PRECISION=f16x2) evaluates every layer product, forward AND backward, as three fp16 MFMA
 products of two-piece operands with float32 accumulation, and every activation block kept for the backward holds both pieces:
@@ -391,12 +391,13 @@ def precision_note(precision):
 
 
 def gpu_torch_baseline(ts, params, gt, R, dev, our_ms, reps=5, warm=2):
-    """The reference's differentiable part in plain PyTorch float32 on the SAME GPU (oracle/torch_ref.py: the SDF and radiance
-    MLPs with the double backward through the normals, compositing, loss, loss.backward(), clip_grad_norm_, Adam.step --
-    volsdf/vsdf.py:196-219 with network.py:206-279), eager mode, at the sample positions, eikonal points and prior look-ups of
-    this process's last step.  NOT included: the error-bounded sampler (the reference runs it in torch under no_grad: one more
-    SDF evaluation of 128 points per ray + the beta search) and cost_mapping -- the baseline does less work than the reference
-    would, so the ratio is a lower bound.  Checker-side code, outside the timed region."""
+    """The reference's train step in plain PyTorch float32 on the SAME GPU (oracle/torch_ref.py), eager mode:
+    the error-bounded sampler under no_grad (ray_sampler.py:67-219 at fast = 1: the SDF network on 128 points per ray, the
+    beta search, inverse-CDF sampling, extras, sort; fresh draws every step), then the SDF and radiance MLPs with the double
+    backward through the normals, compositing, loss, loss.backward(), clip_grad_norm_, Adam.step (volsdf/vsdf.py:196-219 with
+    network.py:206-279) at the rays, eikonal points and prior look-up results of this process's last step.  NOT included:
+    cost_mapping (the MVS prior look-up, vsdf.py:382-452; its results are taken from our step) -- the baseline does a
+    little less work than the reference would, so the ratio is a lower bound.  Checker-side code, outside the timed region."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import torch
@@ -404,36 +405,56 @@ def gpu_torch_baseline(ts, params, gt, R, dev, our_ms, reps=5, warm=2):
     keeps = [h[0] for h in ts._hold]
     outs = [r[1] for r in ts._results]
     cat = lambda xs: torch.cat([x.detach() for x in xs], 0).float()
-    z, dirs, ds = (cat([k[n] for k in keeps]) for n in ("z_vals", "ray_dirs", "depth_scale"))
-    cam = keeps[0]["cam_loc"].detach().float()
+    dirs, ds = (cat([k[n] for k in keeps]) for n in ("ray_dirs", "depth_scale"))
+    cam = keeps[0]["cam_loc"].detach().float().reshape(3)
     eik = cat([k["src"].points for k in keeps])
     pj, pi = cat([o["pj"] for o in outs]), cat([o["pi"] for o in outs])
     p = {k: torch.tensor(np.asarray(v), dtype=torch.float32, device=dev, requires_grad=True) for k, v in params.items()}
     opt = torch.optim.Adam(list(p.values()), lr=5e-4)
     rgb, rgbs = gt["rgb"].reshape(-1, 3), gt["rgb_smooth"].reshape(-1, 3)
+    n_rays = dirs.shape[0]
 
-    def one():
+    def sdf_fn(x):
+        sdf = tref.sdf_mlp(p, x)[:, 0]
+        return torch.minimum(sdf, 20.0 * (3.0 - x.norm(2, 1)))          # get_sdf_vals, network.py:125-131
+
+    def one(sampler=True):
         opt.zero_grad(set_to_none=True)
+        if sampler:
+            with torch.no_grad():
+                rng = dict(jitter=torch.rand(n_rays, 128, device=dev), u=torch.rand(n_rays, 64, device=dev),
+                           perm=torch.randperm(128, device=dev), eik_idx=torch.randint(0, 98, (n_rays,), device=dev))
+                beta0 = float(p["density.beta"].abs() + 1e-4)
+                z, _ = tref.error_bound_sampler_train(sdf_fn, cam, dirs, beta0, rng, fast=1)
+        else:
+            z = z_ours
         out = tref.forward_differentiable(p, cam, dirs, z, eik, ds, device=dev)
         out["pj"], out["pi"] = pj, pi
         tref.loss_fn(out, rgb, rgbs, 50).backward()
         torch.nn.utils.clip_grad_norm_(list(p.values()), 1.0)
         opt.step()
 
-    for _ in range(warm):
-        one()
-    torch.cuda.synchronize()
-    ts_ = []
-    for _ in range(reps):
-        t0 = time.perf_counter()
-        one()
+    z_ours = cat([k["z_vals"] for k in keeps])
+
+    def timed(**kw):
+        for _ in range(warm):
+            one(**kw)
         torch.cuda.synchronize()
-        ts_.append(time.perf_counter() - t0)
-    med = float(np.median(ts_))
+        ts_ = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            one(**kw)
+            torch.cuda.synchronize()
+            ts_.append(time.perf_counter() - t0)
+        return float(np.median(ts_))
+    med = timed(sampler=True)
+    med_nosampler = timed(sampler=False)
     return {"value": R / med, "unit": "rays/s", "ms_per_step": 1e3 * med, "rays": R, "kind": "port",
-            "what": "oracle/torch_ref.py on cuda:0, torch float32 eager: forward (SDF MLP + d sdf/dx via autograd, radiance MLP, "
-                    "compositing) + loss + backward (incl. the double backward) + clip_grad_norm_ + Adam at this step's sample "
-                    "positions; error-bounded sampler and MVS prior lookup NOT included (a lower bound of the reference's step)",
+            "what": "oracle/torch_ref.py on cuda:0, torch float32 eager: error-bounded sampler (fast = 1, under no_grad) + "
+                    "forward (SDF MLP + d sdf/dx via autograd, radiance MLP, compositing) + loss + backward (incl. the double "
+                    "backward) + clip_grad_norm_ + Adam; the MVS prior look-up (cost_mapping) is NOT included (a lower bound "
+                    "of the reference's step)",
+            "ms_per_step_without_sampler": 1e3 * med_nosampler,
             "median_of": reps, "warmups": warm, "ratio_value_over_baseline": (1e3 * med) / our_ms,
             "torch": torch.__version__}
 

@@ -6,6 +6,8 @@ reference; this file is that reference for everything that needs gradients: the 
 optimisation step (volsdf/vsdf.py:214-219).  The sampler (no gradients flow through it) comes from svs_oracle.
 Pinned by tests/test_oracle_golden.py::test_torch_ref_* against the reference-generated fixtures.
 """
+import math
+
 import numpy as np
 import torch
 
@@ -185,3 +187,109 @@ def forward_differentiable_bg(p, cam, dirs, z, z_max, eik_points, depth_scale, z
     if bg_depth is not None:
         out["depth_values_all"] = comp[4]
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The error-bounded sampler in plain torch (train mode), for the same-GPU comparator of bench.py: the reference runs
+# ErrorBoundSampler.get_z_vals (volsdf/model/ray_sampler.py:67-219) in torch under no_grad in every train step.  This
+# is the same sequence of tensor operations in float32 -- NOT the bit-exact restatement (that is oracle/svs_oracle.py,
+# numpy, with the reference's reduction orders); tests/test_oracle_golden.py holds it to the restatement to 1e-4.
+# ---------------------------------------------------------------------------------------------------------------------
+def _density(sdf, beta):
+    alpha = 1.0 / beta
+    return alpha * (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() / beta))
+
+
+def _error_bound(beta, sdf, dists, d_star):
+    density = _density(sdf, beta)
+    sfe = torch.cat([torch.zeros_like(dists[:, :1]), dists * density[:, :-1]], -1)
+    integral = torch.cumsum(sfe, -1)
+    err = torch.exp(-d_star / beta) * (dists ** 2.0) / (4 * beta ** 2)
+    err_int = torch.cumsum(err, -1)
+    bound = (torch.clamp(torch.exp(err_int), max=1.0e6) - 1.0) * torch.exp(-integral[:, :-1])
+    return bound.max(-1)[0]
+
+
+def error_bound_sampler_train(sdf_fn, cam, dirs, beta0, rng, *, near=1e-4, radius=3.0, N_samples=64, N_samples_eval=128,
+                              N_samples_extra=32, eps=0.1, beta_iters=10, max_total_iters=5, fast=1):
+    """sdf_fn (P,3) -> (P,) ; cam (3,), dirs (R,3); rng: 'jitter' (R,128), 'u' (R,64), 'perm' (n,), 'eik_idx' (R,) tensors.
+    -> z_vals (R, N_samples + N_samples_extra + 2), z_eik (R,1)."""
+    R, dev = dirs.shape[0], dirs.device
+    far = 2.0 * radius
+    max_iters = fast if fast >= 0 else max_total_iters
+    t = torch.linspace(0.0, 1.0, N_samples_eval, device=dev)
+    z = (near * (1.0 - t) + far * t).expand(R, -1)
+    mids = 0.5 * (z[:, 1:] + z[:, :-1])
+    upper, lower = torch.cat([mids, z[:, -1:]], -1), torch.cat([z[:, :1], mids], -1)
+    z = lower + (upper - lower) * rng["jitter"]
+    samples, samples_idx = z, None
+    dists = z[:, 1:] - z[:, :-1]
+    bound = (1.0 / (4.0 * math.log(eps + 1.0))) * (dists ** 2.0).sum(-1)
+    beta = torch.sqrt(bound)
+    beta0 = torch.as_tensor(beta0, dtype=torch.float32, device=dev)
+    total, not_converge, sdf = 0, True, None
+    while not_converge and total < max_iters:
+        pts = cam.view(1, 1, 3) + samples.unsqueeze(2) * dirs.unsqueeze(1)
+        with torch.no_grad():
+            samples_sdf = sdf_fn(pts.reshape(-1, 3)).reshape(R, -1)
+        if samples_idx is not None:
+            sdf = torch.gather(torch.cat([sdf, samples_sdf], -1), 1, samples_idx)
+        else:
+            sdf = samples_sdf
+        dists = z[:, 1:] - z[:, :-1]
+        a, b, c = dists, sdf[:, :-1].abs(), sdf[:, 1:].abs()
+        first, second = a.pow(2) + b.pow(2) <= c.pow(2), a.pow(2) + c.pow(2) <= b.pow(2)
+        d_star = torch.zeros_like(dists)
+        d_star[first] = b[first]
+        d_star[second] = c[second]
+        s = (a + b + c) / 2.0
+        area = s * (s - a) * (s - b) * (s - c)
+        mask = ~first & ~second & (b + c - a > 0)
+        d_star[mask] = (2.0 * torch.sqrt(area[mask])) / a[mask]
+        d_star = (sdf[:, 1:].sign() * sdf[:, :-1].sign() == 1) * d_star
+        curr = _error_bound(beta0, sdf, dists, d_star)
+        beta = torch.where(curr <= eps, beta0.expand_as(beta), beta)
+        beta_min, beta_max = beta0.expand_as(beta).clone(), beta
+        for _ in range(beta_iters):
+            mid = (beta_min + beta_max) / 2.0
+            curr = _error_bound(mid.unsqueeze(-1), sdf, dists, d_star)
+            beta_max = torch.where(curr <= eps, mid, beta_max)
+            beta_min = torch.where(curr > eps, mid, beta_min)
+        beta = beta_max
+        density = _density(sdf, beta.unsqueeze(-1))
+        d1 = torch.cat([dists, torch.full_like(dists[:, :1], 1e10)], -1)
+        fe = d1 * density
+        sfe = torch.cat([torch.zeros_like(fe[:, :1]), fe[:, :-1]], -1)
+        alpha = 1 - torch.exp(-fe)
+        trans = torch.exp(-torch.cumsum(sfe, -1))
+        weights = alpha * trans
+        total += 1
+        not_converge = bool((beta.max() > beta0).item())            # the reference's host synchronisation (:136)
+        if not_converge and total < max_iters:
+            N = N_samples_eval
+            bins = z
+            err = torch.exp(-d_star / beta.unsqueeze(-1)) * (dists ** 2.0) / (4 * beta.unsqueeze(-1) ** 2)
+            err_int = torch.cumsum(err, -1)
+            pdf = (torch.clamp(torch.exp(err_int), max=1.0e6) - 1.0) * trans[:, :-1]
+            N, u = N_samples_eval, torch.linspace(0.0, 1.0, N_samples_eval, device=dev).expand(R, -1)
+        else:
+            bins = z
+            pdf = weights[..., :-1] + 1e-5
+            N, u = N_samples, rng["u"]
+        pdf = pdf / pdf.sum(-1, keepdim=True)
+        cdf = torch.cat([torch.zeros_like(pdf[:, :1]), torch.cumsum(pdf, -1)], -1)
+        inds = torch.searchsorted(cdf, u.contiguous(), right=True)
+        below, above = (inds - 1).clamp(min=0), inds.clamp(max=cdf.shape[-1] - 1)
+        cb, ca = torch.gather(cdf, 1, below), torch.gather(cdf, 1, above)
+        bb, ba = torch.gather(bins, 1, below), torch.gather(bins, 1, above)
+        denom = ca - cb
+        denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+        samples = bb + (u - cb) / denom * (ba - bb)
+        if not_converge and total < max_iters:
+            z, samples_idx = torch.sort(torch.cat([z, samples], -1), -1)
+    z_samples = samples
+    nearc, farc = torch.full((R, 1), near, device=dev), torch.full((R, 1), far, device=dev)
+    idx = rng["perm"][:N_samples_extra]
+    z_final = torch.sort(torch.cat([z_samples, nearc, farc, z[:, idx]], -1), -1)[0]
+    z_eik = torch.gather(z_final, 1, rng["eik_idx"].view(-1, 1))
+    return z_final, z_eik

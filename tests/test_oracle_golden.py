@@ -272,6 +272,24 @@ def test_sampler_train_round(golden_dir):
         np.testing.assert_allclose(z_eik, g["z_eik"], atol=2e-4)
 
 
+def test_torch_sampler_port_vs_reference(golden_dir):
+    """oracle/torch_ref.error_bound_sampler_train (the plain-torch sampler bench.py's same-GPU comparator runs) against
+    the reference's own train-mode output on the `sampler_train` fixture: same draws, the reference's sdf values fed
+    back in.  Same tolerance as the restatement's finalize (conditioning of (u - cdf_b) / denom)."""
+    import torch
+    import torch_ref as tref
+    g = load(golden_dir, "sampler_train")
+    R = g["dirs"].shape[0]
+    rng = synth.make_train_rng(R, seed=4)
+    trng = {k: torch.from_numpy(np.asarray(v)) for k, v in rng.items() if k in ("jitter", "u", "perm", "eik_idx")}
+    sdf0 = torch.from_numpy(g["sdf_0"].astype(F32)).reshape(-1)
+    z, z_eik = tref.error_bound_sampler_train(lambda pts: sdf0, torch.zeros(3), torch.from_numpy(g["dirs"].astype(F32)),
+                                              float(orc.get_beta(g["beta_param"])), trng, fast=1)
+    np.testing.assert_allclose(z.numpy(), g["z"], atol=2e-4)
+    assert (np.abs(z.numpy() - g["z"]) > 2e-6).mean() < 0.01
+    np.testing.assert_allclose(z_eik.numpy(), g["z_eik"], atol=2e-4)
+
+
 @pytest.mark.parametrize("tag", ["eval_b0.1", "eval_b0.01", "eval_b0.01_f1", "train", "w1_eval", "w1_train"])
 def test_forward(golden_dir, tag):
     """Whole forward (oracle MLPs + oracle sampler) against VolSDFNetwork.forward of the reference.
