@@ -19,6 +19,7 @@
 // [Cout,2Cout) the odd-x ones, over the same B fragments (input voxels xi and xi+1) -- one third fewer input loads,
 // full M tiles for Cout = 8, and the even/odd outputs of a channel leave in the same store instruction.
 #include "svs_common.h"
+#include <cstdlib>
 
 namespace svs {
 namespace convgemm {
@@ -109,10 +110,14 @@ __global__ void pack_kernel(const float* __restrict__ w, int Cin, int Cout, int 
 }
 
 // MODE 0: convolution (stride 1 or 2); MODE 1: transposed convolution, 8 classes; MODE 2: transposed, x-parities paired
-template <int CIN, int MT, int MODE>
+// KSPLIT: the four waves of a workgroup share ONE tile, wave w takes the k-steps s = w (mod 4) and the partial sums meet in
+// LDS -- for the coarse levels (fewer tiles than SIMDs x 2), where a wave's k-steps are a serial chain of latencies and three
+// quarters of the chip would otherwise idle; every wave then finishes the M tiles m = w (mod 4).
+template <int CIN, int MT, int MODE, bool KSPLIT>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(Args a) {
   const int lane = threadIdx.x & 63;
-  long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int wave = threadIdx.x >> 6;
+  long long tile = KSPLIT ? (long long)blockIdx.x : (long long)blockIdx.x * 4 + wave;
   const long long per_class = (long long)a.rows * a.xtiles;
   int cls = 0;
   if (MODE >= 1) { cls = (int)(tile / per_class); tile -= (long long)cls * per_class; if (cls >= (MODE == 1 ? 8 : 4)) return; }
@@ -167,26 +172,51 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Args a) {
   f32x4 acc[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  // Both operands of k-step s+1 are requested before the MFMAs of k-step s: the B fragment (input voxels) and the A
+  // fragments (weights, from L2).  The coarse levels of the U-Net run well under one wave per SIMD (768 waves at
+  // 24 x 16 x 20), so a wave's k-steps are a serial chain; with the weights read at their point of use every k-step
+  // waited out an L2 round trip (conv6: 54 of them).
   float xc[8], xn[8];
-  load_b(0, xc);
-  for (int s = 0; s < KS; ++s) {
-    if (s + 1 < KS) load_b(s + 1, xn);
+  f16x8 ahc[MT], amc[MT], ahn[MT], amn[MT];
+  constexpr int SS = KSPLIT ? 4 : 1;                 // stride between this wave's k-steps
+  const int s0 = KSPLIT ? wave : 0;
+  if (s0 < KS) {
+    load_b(s0, xc);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { ahc[m] = wf[((size_t)s0 * MT + m) * 128]; amc[m] = wf[((size_t)s0 * MT + m) * 128 + 64]; }
+  }
+  for (int s = s0; s < KS; s += SS) {
+    if (s + SS < KS) {
+      load_b(s + SS, xn);
+      const f16x8* wn = wf + (size_t)(s + SS) * MT * 128;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) { ahn[m] = wn[m * 128]; amn[m] = wn[m * 128 + 64]; }
+    }
     f16x8 bh, bm;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const _Float16 h = (_Float16)xc[j];
       bh[j] = h; bm[j] = (_Float16)(xc[j] - (float)h);
     }
-    const f16x8* ws = wf + (size_t)s * MT * 128;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      const f16x8 ah = ws[m * 128], am = ws[m * 128 + 64];
-      acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am, bh, acc[m], 0, 0, 0);
-      acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bm, acc[m], 0, 0, 0);
-      acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[m], 0, 0, 0);
+      acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(amc[m], bh, acc[m], 0, 0, 0);
+      acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahc[m], bm, acc[m], 0, 0, 0);
+      acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahc[m], bh, acc[m], 0, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) xc[j] = xn[j];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { ahc[m] = ahn[m]; amc[m] = amn[m]; }
+  }
+  if (KSPLIT) {
+    __shared__ f32x4 part[4][MT][64];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) part[wave][m][lane] = acc[m];
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+      if ((m & 3) == wave) acc[m] = (part[0][m][lane] + part[1][m][lane]) + (part[2][m][lane] + part[3][m][lane]);
   }
   if (!col_ok) return;
   const size_t chan_out = (size_t)a.Do * a.Ho * a.Wo;
@@ -195,6 +225,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Args a) {
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+      if (KSPLIT && (m & 3) != wave) continue;
       int co = 16 * m + 4 * g + j;                 // accumulator row of v_mfma_f32_16x16x32: 4 * (lane >> 4) + j
       if (MODE == 2) {                             // rows [Cout, 2 Cout): the odd-x outputs (Cout is a multiple of 4)
         const int odd = co >= a.Cout ? 1 : 0;
@@ -356,12 +387,24 @@ __global__ __launch_bounds__(256) void conv_s2c8_kernel(Args a) {
   }
 }
 
+constexpr long long kKsplitTiles = 2048;   // measured: pays below ~2 tiles per SIMD-pair (conv5-conv7 of every stage), costs above
+
 template <int CIN, int MODE>
 static void launch_mt(const Args& a, int MT, long long tiles, hipStream_t s) {
+  // few tiles (the coarse levels): four waves per tile; SVS_GEMM_KSPLIT=0/1 forces the choice (measurements)
+  static const char* env = getenv("SVS_GEMM_KSPLIT");
+  const bool ksplit = (env && env[0]) ? env[0] == '1' : tiles <= kKsplitTiles;
+  if (ksplit) {
+    const unsigned grid = (unsigned)tiles;
+    if (MT == 1) conv_gemm_kernel<CIN, 1, MODE, true><<<grid, 256, 0, s>>>(a);
+    else if (MT == 2) conv_gemm_kernel<CIN, 2, MODE, true><<<grid, 256, 0, s>>>(a);
+    else conv_gemm_kernel<CIN, 4, MODE, true><<<grid, 256, 0, s>>>(a);
+    return;
+  }
   const unsigned grid = (unsigned)((tiles + 3) / 4);
-  if (MT == 1) conv_gemm_kernel<CIN, 1, MODE><<<grid, 256, 0, s>>>(a);
-  else if (MT == 2) conv_gemm_kernel<CIN, 2, MODE><<<grid, 256, 0, s>>>(a);
-  else conv_gemm_kernel<CIN, 4, MODE><<<grid, 256, 0, s>>>(a);
+  if (MT == 1) conv_gemm_kernel<CIN, 1, MODE, false><<<grid, 256, 0, s>>>(a);
+  else if (MT == 2) conv_gemm_kernel<CIN, 2, MODE, false><<<grid, 256, 0, s>>>(a);
+  else conv_gemm_kernel<CIN, 4, MODE, false><<<grid, 256, 0, s>>>(a);
 }
 
 template <int MODE>
