@@ -143,6 +143,8 @@ class VolOpt():
         dataset_conf['data_dir_root'] = self.hparams.data_dir_root
         assert [self.hparams.max_h, self.hparams.max_w] == list(dataset_conf['img_res'])
         self._dataset_class = kwargs.get('dataset_class') or utils.get_class(self.conf.get_string('train.dataset_class'))
+        # opt-in: train batches drawn on the device instead of the reference's DataLoader loop (svs_hip/batches.py)
+        self._device_batches = bool(kwargs.get('device_batches', os.environ.get('SVS_DEVICE_BATCHES', '0') == '1'))
 
         # generate dataset
         self.data_confs = [copy.deepcopy(dataset_conf) for _ in range(3)]
@@ -230,6 +232,7 @@ class VolOpt():
         self.img_res = self.train_dataset.img_res
         self.scale_factor = self.train_dataset.scale_factor
         self.n_batches = len(self.train_dataloader)
+        self.device_batches = None          # (re)built by run() for the current dataset when the option is on
 
     # ---- one optimisation step (vsdf.py:196-235) ----------------------------------------------------------------------------
     def _mvs_views(self, ts):
@@ -259,7 +262,8 @@ class VolOpt():
             self.writer.add_scalar('t/beta', beta, self.total_step)
             self.writer.add_scalar('t/alpha', 1. / beta, self.total_step)
             self.writer.add_scalar('t/psnr', (-10. * torch.log10(mse)).item(), self.total_step)
-        self.train_dataset.change_sampling_idx(self.num_pixels)
+        if self.device_batches is None:
+            self.train_dataset.change_sampling_idx(self.num_pixels)
         self.iter_step += 1
         self.total_step += 1
         return loss_output
@@ -344,6 +348,14 @@ class VolOpt():
                 self.save_checkpoints(epoch)
             if epoch % self.render_freq == 0 or (done <= 120 * 50 and epoch % early_every == 0):
                 self._preview(epoch)
+            if self._device_batches and self.device_batches is None and torch.cuda.is_available():
+                from svs_hip.batches import DeviceBatches
+                self.device_batches = DeviceBatches(self.train_dataset, self.num_pixels,
+                                                    torch.device("cuda", torch.cuda.current_device()))
+            if self.device_batches is not None:          # opt-in: batches drawn on the device (svs_hip/batches.py)
+                for batch in self.device_batches:
+                    self.train_step(batch, self.hparams.use_mvs)
+                continue
             self.train_dataset.change_sampling_idx(self.num_pixels)
             for batch in self.train_dataloader:
                 self.train_step(batch, self.hparams.use_mvs)

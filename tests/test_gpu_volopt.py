@@ -176,3 +176,34 @@ def test_volopt_config_errors(tmp_path, monkeypatch):
     bad = make_args(); del bad["vol"]["train"]["num_pixels"]
     with pytest.raises(KeyError):
         build(bad)
+
+
+def test_device_batches(tmp_path, monkeypatch):
+    """`VolOpt(device_batches=True)`: the opt-in batch source that draws train batches on the device (svs_hip/batches.py)
+    produces batches of the layout SceneDataset.collate_fn gives (distinct pixels of one train view, uv = (col, row) of the
+    drawn pixels, rgb / rgb_smooth of those pixels) and `run` trains on them: same number of steps per epoch, finite losses,
+    every parameter moving."""
+    monkeypatch.chdir(tmp_path)
+    torch.manual_seed(0)
+    v = build(make_args(), device_batches=True)
+    p0 = {k: t.clone() for k, t in v.model.state_dict().items()}
+    epoch = v.run(opt_stepN=7)
+    assert epoch == 1 and v.iter_step == 10                      # two passes over the 5-image dataset, as with the DataLoader
+    assert v.device_batches is not None
+    assert all(not torch.equal(t, p0[k]) for k, t in v.model.state_dict().items())
+    ds, db = v.train_dataset, v.device_batches
+    for _ in range(4):
+        ind, sample, gt = db.batch()
+        view = int(ind[0])
+        assert view in ds.trains_ids() and sample["uv"].shape == (1, 512, 2) and gt["rgb"].shape == (1, 512, 3)
+        uv = sample["uv"][0].long()
+        flat = uv[:, 1] * ds.img_res[1] + uv[:, 0]
+        assert flat.unique().numel() == 512 and int(flat.max()) < ds.total_pixels
+        assert torch.equal(gt["rgb"][0].cpu(), ds.rgb_images[view][flat.cpu()])
+        assert torch.equal(gt["rgb_smooth"][0].cpu(), ds.rgb_smooth[view][flat.cpu()])
+        assert torch.equal(sample["pose"][0].cpu(), ds.pose_all[view]) and torch.equal(sample["intrinsics"][0].cpu(), ds.intrinsics_all[view])
+        # the reference's grid: uv = (x = col, y = row) of the pixel (scene_dataset.py:227-229)
+        _, ref_sample, _ = ds[0]
+    ds.change_sampling_idx(-1)
+    _, full, _ = ds[0]
+    assert torch.equal(full["uv"][flat.cpu()], sample["uv"][0].cpu())
