@@ -36,6 +36,9 @@ __device__ __forceinline__ void chunk_issue_piece(const f32x4* __restrict__ g, f
     // the tile's first piece is issued, where the count is exact (reverse_layer_h2).
     // Address = SGPR pair + 32-bit lane offset: no per-piece vector address arithmetic.  M0 (LDS base of the piece) is a
     // reserved register that hipcc re-materialises before each use of its own; one wait state before the DMA reads it.
+    // (Listing "m0" as a clobber is not possible: hipcc rejects reserved registers on the clobber list, -Winline-asm
+    // "may lead to undefined behaviour".  No other M0 user exists in the translation units that contain this asm: no
+    // s_movrel / sendmsg / builtin LDS-DMA.)
     const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)(lds + idx);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                  :: "v"(lane_bytes), "s"(g + idx), "s"(lds_base) : "memory");
