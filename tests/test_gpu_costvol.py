@@ -272,6 +272,23 @@ def test_config3_sizes_run(dev):
     np.testing.assert_allclose(v2.cpu().numpy(), 4.0 * v1.cpu().numpy(), rtol=1e-5, atol=1e-6)
 
 
+def test_conv0_full_size_pair_vs_channel_rows(dev):
+    """BASELINE config 3, stage 1 (C = 32, 192 x 128 x 160): the fused conv0 (x-pair rows, K split over wave pairs, split-volume
+    input) and the channel-row kernel it replaces are two independent float32-class evaluations of the same layer; at
+    full size they agree to 3e-6 of the output scale, and the fused kernel is linear in its input."""
+    from svs_hip import costvol
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn(32, 192, 128, 160, device=dev, generator=g)
+    w = torch.randn(32, 27, 8, device=dev, generator=g) / (27 * 32) ** 0.5
+    b = torch.randn(8, device=dev, generator=g)
+    a = costvol.conv3d(costvol.SplitVolume.pack(x), w, b, relu=False)
+    ref = costvol.conv3d(x, w, b, relu=False)
+    scale = float(ref.abs().max())
+    assert float((a - ref).abs().max()) <= 3e-6 * scale
+    a2 = costvol.conv3d(costvol.SplitVolume.pack(2.0 * x), w, None, relu=False)
+    assert float((a2 - 2.0 * (a - b.view(8, 1, 1, 1))).abs().max()) <= 3e-6 * scale
+
+
 def test_stage_loop_feature_cache(dev):
     """runner.py:178-243 through svs_hip.stage_loop.StageLoop: three reference views x three stages with the images'
     features extracted once each (3 calls instead of 27), identical outputs to the uncached loop, and the depth
