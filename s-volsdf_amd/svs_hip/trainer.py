@@ -113,6 +113,33 @@ class _GroupedOutputs(dict):
         return self._parts[0].keys()
 
 
+class _ValidRays(dict):
+    """Model outputs of a step whose batch was padded to a multiple of the kernels' ray granularity: per-ray tensors are cut
+    back to the caller's rays on access (grad_theta: its two per-ray halves)."""
+
+    def __init__(self, outputs, n_valid, n_padded):
+        super().__init__()
+        self._o, self._v, self._p = outputs, n_valid, n_padded
+
+    def __missing__(self, key):
+        t = self._o[key]
+        if torch.is_tensor(t) and t.dim() > 0:
+            if key == "grad_theta" and t.shape[0] == 2 * self._p:
+                t = torch.cat([t[:self._v], t[self._p:self._p + self._v]], 0)
+            elif t.shape[0] == self._p:
+                t = t[:self._v]
+            elif t.shape[0] % self._p == 0 and t.shape[0] > self._p:       # flattened (rays x samples, ...) tensors
+                t = t.reshape(self._p, -1, *t.shape[1:])[:self._v].reshape(-1, *t.shape[1:])
+        self[key] = t
+        return t
+
+    def __contains__(self, key):
+        return key in self._o
+
+    def keys(self):
+        return self._o.keys()
+
+
 class _GroupedLosses(dict):
     """Loss terms of a step that ran as ray groups: each group's terms are already normalised by the whole batch, so a
     term is the sum over the groups -- formed on first access (logging reads them every 50 steps; summed eagerly they
@@ -266,16 +293,33 @@ class TrainStep:
         rs = self.model.ray_sampler
         return rs.N_samples + rs.N_samples_extra + 2 - (1 if self.is_bg else 0)
 
-    def check_batch(self, R):
-        """The fused MLP kernels work on 32-point wave tiles and the ray samples of a batch (R x S points) must end on a
+    def ray_multiple(self):
+        """The fused MLP kernels work on 32-point wave tiles and the ray samples of a launch (R x S points) must end on a
         tile boundary, where the eikonal points start: R x S % 32 == 0, i.e. R % 16 == 0 for the DTU model (S = 98) and
-        R % 32 == 0 for the fg + background model (S = 97).  The reference has no such constraint; its configurations
-        use 512 / 1024 / 2048 rays."""
-        S = self.samples_per_ray()
-        if R <= 0 or (R * S) % 32:
-            import math
-            raise ValueError(f"train.num_pixels = {R}: rays x samples ({R} x {S}) must be a multiple of 32 on the fused "
-                             f"path -- use a multiple of {32 // math.gcd(S, 32)} rays")
+        R % 32 == 0 for the fg + background model (S = 97)."""
+        import math
+        return 32 // math.gcd(self.samples_per_ray(), 32)
+
+    def check_batch(self, R):
+        """Any ray count > 0 is accepted (as by the reference).  A count that is not a multiple of ray_multiple() is padded
+        up to one by repeating the last ray (`_pad_batch`); the padding rays run through the kernels, are left out of the
+        loss and contribute no gradient."""
+        if R <= 0:
+            raise ValueError(f"train.num_pixels = {R}")
+
+    def _pad_batch(self, model_input, ground_truth):
+        """-> (model_input, ground_truth, n_valid): inputs padded to a multiple of ray_multiple() rays, n_valid = the true
+        ray count (== the padded count when nothing was added)."""
+        R = model_input["uv"].shape[1]
+        m = self.ray_multiple()
+        pad = (-R) % m
+        if pad == 0:
+            return model_input, ground_truth, R
+        rep = lambda t: torch.cat([t, t[:, -1:].expand(t.shape[0], pad, *t.shape[2:])], 1)
+        mi = dict(model_input)
+        mi["uv"] = rep(model_input["uv"])
+        gt = {k: (rep(v) if torch.is_tensor(v) and v.dim() == 3 and v.shape[1] == R else v) for k, v in ground_truth.items()}
+        return mi, gt, R
 
     @staticmethod
     def split_rays(R, S, n_cu=256, wg_points=128):
@@ -294,7 +338,13 @@ class TrainStep:
 
     def __call__(self, model_input, ground_truth, mvs=None, fast=1):
         """mvs: optional dict(views=[...], same_view=int, img_res=(H,W), inverse_depth=bool) for cost_mapping."""
-        return self._step(model_input, ground_truth, mvs, fast)
+        model_input, ground_truth, n_valid = self._pad_batch(model_input, ground_truth)
+        self._n_valid = n_valid
+        out = self._step(model_input, ground_truth, mvs, fast)
+        if n_valid == model_input["uv"].shape[1]:
+            return out
+        losses, outputs = out
+        return losses, _ValidRays(outputs, n_valid, model_input["uv"].shape[1])
 
     TUNE_START, TUNE_STEPS, TUNE_SKIP = 24, 12, 2
 
@@ -372,6 +422,31 @@ class TrainStep:
             self._tune_end(R, tune)
         return out
 
+    def _loss_on_valid(self, out, g_gt, v, Rg, norm, anneal_dev):
+        """The loss of a ray group whose last Rg - v rays are padding: evaluated on the first v rays (and their 2 eikonal
+        points each: rows [0,v) and [Rg, Rg+v) of grad_theta, network.py:258-266), gradients zero-padded to the group."""
+        per_ray = ("rgb_values", "weights", "depth_values", "depth_values_all", "pi", "pj")
+        ov = {k: (t[:v] if k in per_ray and torch.is_tensor(t) else t) for k, t in out.items()}
+        gt_full = out.get("grad_theta")
+        if gt_full is not None:
+            ov["grad_theta"] = torch.cat([gt_full[:v], gt_full[Rg:Rg + v]], 0)
+        gv = {k: t[:v] for k, t in g_gt.items()}
+        lo_out = self.loss(ov, gv, norm=norm, advance=False, anneal_dev=anneal_dev)
+        g = {}
+        for k, t in self.loss.last_grads.items():
+            if t is None:
+                g[k] = None
+            elif k == "grad_theta":
+                full = torch.zeros(gt_full.shape, dtype=t.dtype, device=t.device)
+                full[:v] = t[:v]
+                full[Rg:Rg + v] = t[v:]
+                g[k] = full
+            else:
+                full = torch.zeros((Rg,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+                full[:v] = t
+                g[k] = full
+        return lo_out, g
+
     def _finish(self, results):
         """What follows the gradient: the one collective of a data-parallel step, the fused optimiser, host counters."""
         allreduce_flat_grad(self.fp.grad, self.world)
@@ -441,9 +516,15 @@ class TrainStep:
                                                               inverse_depth=mvs.get("inverse_depth", False),
                                                               same_view_dev=dyn["same_view"] if dyn else None)
                 g_gt = {"rgb": gt["rgb"][lo:hi], "rgb_smooth": gt["rgb_smooth"][lo:hi]}
-                lo_out = self.loss(out, g_gt, norm=loss_norm(R, self.world), advance=False,
-                                   anneal_dev=dyn["anneal"] if dyn else None)
-                g = self.loss.last_grads
+                n_valid = getattr(self, "_n_valid", R)
+                valid_g = max(0, min(hi, n_valid) - lo)          # rays of this group that are not padding
+                if valid_g == hi - lo:
+                    lo_out = self.loss(out, g_gt, norm=loss_norm(n_valid, self.world), advance=False,
+                                       anneal_dev=dyn["anneal"] if dyn else None)
+                    g = self.loss.last_grads
+                else:
+                    lo_out, g = self._loss_on_valid(out, g_gt, valid_g, hi - lo, loss_norm(n_valid, self.world),
+                                                    dyn["anneal"] if dyn else None)
                 stream.wait_event(packed)
                 if self.is_bg:
                     # the loss read depth_values_all (fg + bg, loss.py:72-73): its gradient enters as such
@@ -496,7 +577,7 @@ class TrainStep:
                 return ptrs, tuple(cams)
             mk = (len(mvs["views"]), tuple(mvs["img_res"]), bool(mvs.get("inverse_depth", False)),
                   tuple(view_key(v) for v in mvs["views"]))
-        return (R, tuple(self._groups_for(R)), fast, mk, str(model_input["uv"].device), self.graph)
+        return (R, getattr(self, "_n_valid", R), tuple(self._groups_for(R)), fast, mk, str(model_input["uv"].device), self.graph)
 
     def _upload(self, cs, model_input, ground_truth, mvs):
         """Host -> static tensors of a captured step, on the current stream (ordered before the graph launch)."""

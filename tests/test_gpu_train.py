@@ -199,6 +199,68 @@ def test_step_gradient_at_bench_geometry(dev, R, wset, precision, it, monkeypatc
         assert_f32_class(per_tensor_errors(got, ref, yard), what, floor=bound, floors={"density.beta": 1e-4})
 
 
+@pytest.mark.parametrize("R", [1000, 250, 7])
+def test_step_with_any_ray_count(dev, R):
+    """`train.num_pixels` need not be a multiple of the kernels' ray granularity (16 rays for this model): TrainStep pads the
+    batch by repeating its last ray, leaves the padding out of the loss and hands back outputs for the caller's rays only.
+    The flat gradient equals float64 autograd (oracle/torch_ref.py) over exactly the R rays -- same float32-class criterion
+    as test_step_gradient_at_bench_geometry -- and the loss terms are means over R rays."""
+    import torch_ref as tref
+    from svs_hip.trainer import TrainStep
+    m, loss = _setup(dev, "w0")
+    K, pose = synth.make_camera()
+    inp = {"intrinsics": G(K, dev)[None], "uv": G(synth.make_uv(R, seed=23), dev)[None], "pose": G(pose, dev)[None]}
+    rs = np.random.default_rng(6)
+    gt = {"rgb": G(rs.uniform(0, 1, (1, R, 3)).astype(F32), dev), "rgb_smooth": G(rs.uniform(0, 1, (1, R, 3)).astype(F32), dev)}
+    views = synth.make_mvs_views(2)
+    mvs = dict(views=[dict(K=v["K"], c2w=v["c2w"], cost=G(v["cost"], dev), z_mvs=G(v["z_mvs"], dev)) for v in views], same_view=0,
+               img_res=(576, 768), inverse_depth=False)
+    it = 50
+    loss.iter_step = it
+    ts = TrainStep(m, loss, lr=5e-4, groups="auto", graph=False)
+    assert R % ts.ray_multiple() != 0
+    p0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    torch.manual_seed(3)
+    lo, out = ts(inp, gt, mvs=mvs)
+    torch.cuda.synchronize()
+    assert out["rgb_values"].shape == (R, 3) and out["weights"].shape[0] == R and out["grad_theta"].shape == (2 * R, 3)
+    norm = float(ts.opt.info[0])
+    coef = min(1.0, 1.0 / (norm + 1e-6))
+    got = {n: (p.grad / coef).double().cpu() for n, p in m.named_parameters()}
+    keeps = [h[0] for h in ts._hold]
+    outs = [r[1] for r in ts._results]
+    Rp = sum(k["z_vals"].shape[0] for k in keeps)
+    assert Rp % ts.ray_multiple() == 0 and 0 < Rp - R < ts.ray_multiple()
+    cat = lambda xs: torch.cat(xs, 0).double()
+    z = cat([k["z_vals"] for k in keeps])[:R]; dirs = cat([k["ray_dirs"] for k in keeps])[:R]
+    ds = cat([k["depth_scale"] for k in keeps])[:R]
+    cam = keeps[0]["cam_loc"].double()
+    eik, lo_ray = [], 0
+    for k in keeps:                                  # a group's eikonal points: [uniform of its rays, near-surface of its rays]
+        rg = k["z_vals"].shape[0]
+        v = max(0, min(lo_ray + rg, R) - lo_ray)
+        pts = k["src"].points.double()
+        eik += [pts[:v], pts[rg:rg + v]]
+        lo_ray += rg
+    eik = torch.cat(eik, 0)
+    pj = cat([o["pj"] for o in outs])[:R]; pi = cat([o["pi"] for o in outs])[:R]
+
+    def autograd(dt, pp=None):
+        p = {k: (pp or p0)[k].detach().to(dt).clone().requires_grad_(True) for k in p0}
+        o = tref.forward_differentiable(p, cam.to(dt), dirs.to(dt), z.to(dt), eik.to(dt), ds.to(dt), device=dev)
+        o["pj"], o["pi"] = pj.to(dt), pi.to(dt)
+        total = tref.loss_fn(o, gt["rgb"].reshape(-1, 3).to(dt), gt["rgb_smooth"].reshape(-1, 3).to(dt), it)
+        total.backward()
+        autograd.total = float(total)
+        return {k: v.grad.cpu() for k, v in p.items()}
+    ref = autograd(torch.float64)
+    assert float(lo["loss"]) == pytest.approx(autograd.total, rel=2e-5)
+    ref_norm = float(torch.sqrt(sum((v ** 2).sum() for v in ref.values())))
+    assert norm == pytest.approx(ref_norm, rel=1e-5), (norm, ref_norm)
+    yard = f32_yardstick(autograd, p0)
+    assert_f32_class(per_tensor_errors(got, ref, yard), f"{R} rays padded to {Rp}", floor=3e-5, floors={"density.beta": 1e-4})
+
+
 def test_train_step_autograd_bridge(dev, golden_dir):
     """The reference's own sequence -- model(...), loss(...), loss.backward(), clip_grad_norm_, torch Adam -- driving
     the HIP kernels through the autograd bridge (what runner.py does with the drop-in classes)."""
