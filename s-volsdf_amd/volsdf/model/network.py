@@ -193,10 +193,12 @@ class VolSDFNetwork(nn.Module):
     def forward(self, input, fast=-1):
         if self.training and torch.is_grad_enabled():
             params = self._flat_param_list()
+            input, n_valid, n_pad = pad_rays(input, self.ray_sampler.N_samples + self.ray_sampler.N_samples_extra + 2)
             res = _RenderFunction.apply(self, input, fast, *params)
             rgb_values, depth_values, weights, grad_theta, depth_vals, xyz = res
-            return {'rgb_values': rgb_values, 'depth_values': depth_values, 'depth_vals': depth_vals, 'weights': weights,
-                    'xyz': xyz, 'grad_theta': grad_theta}
+            out = {'rgb_values': rgb_values, 'depth_values': depth_values, 'depth_vals': depth_vals, 'weights': weights,
+                   'xyz': xyz, 'grad_theta': grad_theta}
+            return cut_rays(out, n_valid, n_pad)
         return self._forward_impl(input, fast, None)
 
     def draw_train_rng(self, R, dev, out=None, stream=None):
@@ -308,6 +310,39 @@ class VolSDFNetwork(nn.Module):
                              self.density.beta, self.density.beta_min_value)
         dists = torch.cat([z_vals[:, 1:] - z_vals[:, :-1], torch.full((R, 1), 1e10, device=dev)], -1)
         return comp["weights"], dists
+
+
+def pad_rays(input, samples_per_ray):
+    """The backward kernels want rays x samples to be a multiple of 32 (svs_hip/train.py): a batch that is not gets its last
+    ray repeated.  -> (input, rays of the caller, rays after padding)."""
+    import math
+    R = input["uv"].shape[1]
+    pad = (-R) % (32 // math.gcd(samples_per_ray, 32))
+    if pad == 0:
+        return input, R, R
+    uv = input["uv"]
+    inp = dict(input)
+    inp["uv"] = torch.cat([uv, uv[:, -1:].expand(uv.shape[0], pad, uv.shape[2])], 1)
+    return inp, R, R + pad
+
+
+def cut_rays(out, n_valid, n_pad):
+    """Model outputs of a padded batch without the padding rays.  Plain slicing: autograd hands the padding zero gradients."""
+    if n_valid == n_pad:
+        return out
+    res = {}
+    for k, t in out.items():
+        if not torch.is_tensor(t) or t.dim() == 0:
+            res[k] = t
+        elif k == "grad_theta" and t.shape[0] == 2 * n_pad:
+            res[k] = torch.cat([t[:n_valid], t[n_pad:n_pad + n_valid]], 0)
+        elif t.shape[0] == n_pad:
+            res[k] = t[:n_valid]
+        elif t.shape[0] % n_pad == 0:                      # flattened (rays x samples, ...) tensors
+            res[k] = t.reshape(n_pad, -1, *t.shape[1:])[:n_valid].reshape(-1, *t.shape[1:])
+        else:
+            res[k] = t
+    return res
 
 
 class _RenderFunction(torch.autograd.Function):

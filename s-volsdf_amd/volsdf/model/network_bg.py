@@ -114,10 +114,13 @@ class VolSDFNetworkBG(nn.Module):
         if self.training and torch.is_grad_enabled():
             # autograd bridge: the reference's own train_step (loss.backward(), clip_grad_norm_, torch Adam,
             # volsdf/vsdf.py:214-219) drives the hand-written backward kernels, as with the DTU model
+            from .network import cut_rays, pad_rays
+            rs = self.ray_sampler
+            input, n_valid, n_pad = pad_rays(input, rs.N_samples + rs.N_samples_extra + 1)
             res = _RenderFunctionBG.apply(self, input, fast, *self._flat_param_list())
             rgb_values, depth_values_all, depth_values, weights, grad_theta, depth_vals, xyz = res
-            return {'rgb_values': rgb_values, 'depth_values_all': depth_values_all, 'depth_values': depth_values,
-                    'depth_vals': depth_vals, 'weights': weights, 'xyz': xyz, 'grad_theta': grad_theta}
+            return cut_rays({'rgb_values': rgb_values, 'depth_values_all': depth_values_all, 'depth_values': depth_values,
+                             'depth_vals': depth_vals, 'weights': weights, 'xyz': xyz, 'grad_theta': grad_theta}, n_valid, n_pad)
         return self._forward_impl(input, fast, None)
 
     def backward_from_output_grads(self, keep, g_rgb_values, g_weights=None, g_depth_values=None, g_depth_values_all=None,

@@ -261,6 +261,46 @@ def test_step_with_any_ray_count(dev, R):
     assert_f32_class(per_tensor_errors(got, ref, yard), f"{R} rays padded to {Rp}", floor=3e-5, floors={"density.beta": 1e-4})
 
 
+def test_autograd_bridge_with_any_ray_count(dev):
+    """The reference's own sequence (model(...), a loss on its outputs, loss.backward()) with a ray count that is not a
+    multiple of the kernels' granularity: forward() pads the batch and cuts the padding off its outputs, autograd hands the
+    padding zero gradients.  Parameter gradients against float64 autograd (oracle/torch_ref.py) at the sample positions the
+    forward used, float32-class criterion."""
+    import torch_ref as tref
+    R = 100
+    m, _ = _setup(dev, "w0")
+    K, pose = synth.make_camera()
+    inp = {"intrinsics": G(K, dev)[None], "uv": G(synth.make_uv(R, seed=31), dev)[None], "pose": G(pose, dev)[None]}
+    rs = np.random.default_rng(7)
+    tgt = G(rs.uniform(0, 1, (R, 3)).astype(F32), dev)
+    p0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    torch.manual_seed(5)
+    m.train()
+    out = m(inp, fast=1)
+    assert out["rgb_values"].shape == (R, 3) and out["weights"].shape[0] == R and out["grad_theta"].shape == (2 * R, 3)
+
+    def objective(o, t):
+        return (o["rgb_values"] - t).abs().mean() + 0.1 * ((o["grad_theta"].norm(2, dim=1) - 1) ** 2).mean() + 0.05 * o["depth_values"].mean()
+    objective(out, tgt).backward()
+    got = {n: p.grad.double().cpu() for n, p in m.named_parameters()}
+    node = out["rgb_values"].grad_fn.next_functions[0][0]          # the bridge's autograd node holds what the forward kept
+    keep = node.keep
+    Rp = keep["z_vals"].shape[0]
+    assert Rp == 112
+    z, dirs, ds = (keep[k].double()[:R] for k in ("z_vals", "ray_dirs", "depth_scale"))
+    pts = keep["src"].points.double()
+    eik = torch.cat([pts[:R], pts[Rp:Rp + R]], 0)
+
+    def autograd(dt, pp=None):
+        p = {k: (pp or p0)[k].detach().to(dt).clone().requires_grad_(True) for k in p0}
+        o = tref.forward_differentiable(p, keep["cam_loc"].to(dt), dirs.to(dt), z.to(dt), eik.to(dt), ds.to(dt), device=dev)
+        objective(o, tgt.to(dt)).backward()
+        return {k: v.grad.cpu() for k, v in p.items()}
+    ref = autograd(torch.float64)
+    yard = f32_yardstick(autograd, p0)
+    assert_f32_class(per_tensor_errors(got, ref, yard), f"bridge, {R} rays padded to {Rp}", floor=3e-5, floors={"density.beta": 1e-4})
+
+
 def test_train_step_autograd_bridge(dev, golden_dir):
     """The reference's own sequence -- model(...), loss(...), loss.backward(), clip_grad_norm_, torch Adam -- driving
     the HIP kernels through the autograd bridge (what runner.py does with the drop-in classes)."""
