@@ -410,7 +410,11 @@ class TrainStep:
                 return self._finish(out)
         tune = None if self.graph else self._tune_begin(R)
         try:
-            rng = m.draw_train_rng(R, uv.device, stream=self.scratch.prep)      # uploads on the (idle) pack stream
+            n_valid = getattr(self, "_n_valid", R)
+            rng = m.draw_train_rng(n_valid, uv.device, stream=self.scratch.prep)      # uploads on the (idle) pack stream
+            if n_valid < R:                      # padded batch: the random stream is consumed as for the caller's rays
+                from volsdf.model.network import pad_rng
+                rng = pad_rng(rng, R)
             gt = {"rgb": ground_truth["rgb"].reshape(-1, 3), "rgb_smooth": ground_truth["rgb_smooth"].reshape(-1, 3)}
             results, holds = self._device_step(self.scratch, model_input, gt, mvs, fast, rng, dyn=None)
             self._hold = holds
@@ -604,7 +608,16 @@ class TrainStep:
         st["anneal"].copy_(st["scalars"][:2], non_blocking=True)
         st["same_view_host"][0] = int(mvs["same_view"]) if mvs is not None else -1
         st["same_view"].copy_(st["same_view_host"], non_blocking=True)
-        self.model.draw_train_rng(model_input["uv"].shape[1], dev, out=st["rng"])
+        n_valid, n_pad = getattr(self, "_n_valid", model_input["uv"].shape[1]), model_input["uv"].shape[1]
+        if n_valid < n_pad:
+            from volsdf.model.network import pad_rng
+            drawn = self.model.draw_train_rng(n_valid, dev)
+            for k, v in pad_rng(drawn, n_pad).items():
+                if k not in st["rng"]:
+                    st["rng"][k] = torch.empty_like(v)
+                st["rng"][k].copy_(v, non_blocking=True)
+        else:
+            self.model.draw_train_rng(n_pad, dev, out=st["rng"])
 
     def _step_captured(self, model_input, ground_truth, mvs, fast):
         """-> results of the step (replayed from its graph), or None when this call has to run eagerly: the first step of

@@ -233,7 +233,10 @@ class VolSDFNetwork(nn.Module):
         num_pixels = ray_dirs.shape[0]
 
         if self.training and rng is None:
-            rng = self.draw_train_rng(num_pixels, ray_dirs.device)
+            n_valid = input.get("_valid_rays", num_pixels)
+            rng = self.draw_train_rng(n_valid, ray_dirs.device)
+            if n_valid < num_pixels:
+                rng = pad_rng(rng, num_pixels)
         z_vals, z_samples_eik = self.ray_sampler.get_z_vals(ray_dirs, cam_loc, self, fast=fast,
                                                             iter_step=input.get("iter_step", 1), rng=rng)
         N_samples = z_vals.shape[1]
@@ -312,6 +315,18 @@ class VolSDFNetwork(nn.Module):
         return comp["weights"], dists
 
 
+def pad_rng(rng, n_pad):
+    """Train-mode draws made for the caller's rays, extended to a padded batch by repeating the last ray's rows: the random
+    stream is consumed exactly as for the unpadded batch and the caller's rays see the same draws."""
+    out = {}
+    for k, v in rng.items():
+        if k == "perm" or not torch.is_tensor(v) or v.shape[0] >= n_pad:
+            out[k] = v
+        else:
+            out[k] = torch.cat([v, v[-1:].expand(n_pad - v.shape[0], *v.shape[1:])], 0).contiguous()
+    return out
+
+
 def pad_rays(input, samples_per_ray):
     """The backward kernels want rays x samples to be a multiple of 32 (svs_hip/train.py): a batch that is not gets its last
     ray repeated.  -> (input, rays of the caller, rays after padding)."""
@@ -323,6 +338,7 @@ def pad_rays(input, samples_per_ray):
     uv = input["uv"]
     inp = dict(input)
     inp["uv"] = torch.cat([uv, uv[:, -1:].expand(uv.shape[0], pad, uv.shape[2])], 1)
+    inp["_valid_rays"] = R                  # _forward_impl draws for R rays and repeats the last ray's draws (pad_rng)
     return inp, R, R + pad
 
 

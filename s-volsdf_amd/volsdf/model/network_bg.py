@@ -171,7 +171,11 @@ class VolSDFNetworkBG(nn.Module):
         ray_dirs, cam_loc, depth_scale = ops.rays_from_uv(uv[0], pose[0], intrinsics[0])
         R = ray_dirs.shape[0]
         if self.training and rng is None:
-            rng = self.draw_train_rng(R, ray_dirs.device)
+            n_valid = input.get("_valid_rays", R)
+            rng = self.draw_train_rng(n_valid, ray_dirs.device)
+            if n_valid < R:
+                from .network import pad_rng
+                rng = pad_rng(rng, R)
         (z_all, _), z_samples_eik = self.ray_sampler.get_z_vals(ray_dirs, cam_loc, self, fast=fast,
                                                                 iter_step=input.get("iter_step", 1), rng=rng)
         z_bg, bg_pts, bg_depth = self.ray_sampler._bg_last
