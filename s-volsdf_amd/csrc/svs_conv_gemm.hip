@@ -66,9 +66,10 @@ __global__ void pack_kernel(const float* __restrict__ w, int Cin, int Cout, int 
     // all classes share the B operand: slot t = (dz*2 + dy)*2 + dxs of the 8 input voxels a 2x2x2 output cell touches;
     // class c = (pz,py) takes offset d along an axis with kernel index {parity 0: d=0 -> 1; parity 1: d=1 -> 0, d=0 -> 2}
     const int pz = (c >> 1) & 1, py = c & 1;
-    const int px = co >= Cout ? 1 : 0;
-    co -= px * Cout;
-    if (px == 1 && co >= Cout) co = 1 << 20;
+    // row r of the 16: channel 2 (r >> 2) + ((r >> 1) & 1), x parity r & 1 -- a lane's four accumulator rows are then the
+    // even / odd outputs of two channels: both parities of a channel leave (and their skip values arrive) as one float2
+    const int px = co & 1;
+    co = 2 * (co >> 2) + ((co >> 1) & 1);
     const int dz = t >> 2, dy = (t >> 1) & 1, dxs = t & 1;
     const int kz = pz == 0 ? (dz == 0 ? 1 : -1) : (dz == 1 ? 0 : 2);
     const int ky = py == 0 ? (dy == 0 ? 1 : -1) : (dy == 1 ? 0 : 2);
@@ -260,15 +261,16 @@ __global__ __launch_bounds__(256) void deconv_cell_kernel(Args a) {
   const int zi = row / a.Hi, yi = row - zi * a.Hi, xi = 16 * xt + n;
   const bool col_ok = xi < a.Wi;
   const size_t chan_in = (size_t)a.Di * a.Hi * a.Wi, chan_out = (size_t)a.Do * a.Ho * a.Wo;
-  const int odd = g >> 1, cob = 4 * (g & 1);          // accumulator rows 4 g + j: channel cob + j at x = 2 xi + odd
-  // ---- skip values of the cell (16 per lane), requested first
-  float sk[4][4];
+  // accumulator rows 4 g + j of a lane: (channel 2 g + (j >> 1), x = 2 xi + (j & 1)) -- see pack_kernel, mode 3
+  // ---- skip values of the cell (8 float2 per lane), requested first
+  float2 sk[4][2];
   size_t obase[4];
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
-    obase[m] = (size_t)cob * chan_out + ((size_t)(2 * zi + (m >> 1)) * a.Ho + (2 * yi + (m & 1))) * a.Wo + 2 * xi + odd;
+    obase[m] = (size_t)(2 * g) * chan_out + ((size_t)(2 * zi + (m >> 1)) * a.Ho + (2 * yi + (m & 1))) * a.Wo + 2 * xi;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sk[m][j] = (a.skip && col_ok) ? a.skip[obase[m] + (size_t)j * chan_out] : 0.0f;
+    for (int q = 0; q < 2; ++q)
+      sk[m][q] = (a.skip && col_ok) ? *reinterpret_cast<const float2*>(a.skip + obase[m] + (size_t)q * chan_out) : float2{0.0f, 0.0f};
   }
   // ---- B operand: k-step s = input rows (zi + (s >> 1), yi + (s & 1)), lane group g = (voxel xi + (g >> 1), channels 8 (g & 1)..)
   float x[KS][8];
@@ -302,16 +304,16 @@ __global__ __launch_bounds__(256) void deconv_cell_kernel(Args a) {
     }
   }
   if (!col_ok) return;
-  float bias[4];
+  float bias[2];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) bias[j] = a.bias ? a.bias[cob + j] : 0.0f;
+  for (int q = 0; q < 2; ++q) bias[q] = a.bias ? a.bias[2 * g + q] : 0.0f;
 #pragma unroll
   for (int m = 0; m < 4; ++m)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float r = acc[m][j] + bias[j];
-      if (a.relu) r = __builtin_fmaxf(r, 0.0f);
-      a.out[obase[m] + (size_t)j * chan_out] = r + sk[m][j];
+    for (int q = 0; q < 2; ++q) {
+      float r0 = acc[m][2 * q] + bias[q], r1 = acc[m][2 * q + 1] + bias[q];
+      if (a.relu) { r0 = __builtin_fmaxf(r0, 0.0f); r1 = __builtin_fmaxf(r1, 0.0f); }
+      *reinterpret_cast<float2*>(a.out + obase[m] + (size_t)q * chan_out) = float2{r0 + sk[m][q].x, r1 + sk[m][q].y};
     }
 }
 
