@@ -40,6 +40,19 @@ inline int check_launch(const char* what) {
 
 // Row of a 32x32 MFMA accumulator tile held in register r by a lane of half h (h = lane >> 5):
 // row = (r & 3) + 8 * (r >> 2) + 4 * h, column = lane & 31  (C/D layout of v_mfma_f32_32x32x2_f32).
+// Workgroups are dealt to the 8 XCDs (each with its own L2) round-robin in launch order.  xcd_chunked(i, n): the work item
+// workgroup i of n takes so that XCD k processes the contiguous range [k n/8, (k+1) n/8) -- neighbouring tiles, which share
+// halo rows, then meet in one L2.  (n not a multiple of 8: identity.)  Used by conv0 (svs_conv_pair.hip: 5-7 % at the
+// three stage sizes of config 3); measured neutral for conv2 / prob and harmful for the transposed-convolution GEMMs, whose
+// parity classes interleave in the output (conv7 0.025 -> 0.034 ms, conv9 0.049 -> 0.062): not applied there.
+__device__ __forceinline__ unsigned xcd_chunked(unsigned i, unsigned n) {
+#ifdef SVS_NO_XCD_REMAP
+  return i;
+#else
+  return (n & 7u) ? i : (i & 7u) * (n >> 3) + (i >> 3);
+#endif
+}
+
 __host__ __device__ constexpr int rho(int r) { return (r & 3) + 8 * (r >> 2); }
 
 // ------------------------------------------------------------------------------------------

@@ -75,8 +75,12 @@ __global__ __launch_bounds__(256 * KSPLIT, 1) void conv3d_pair_kernel(Args a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int row = wave & 3, half = wave >> 2;
   const int n = lane & 15, kg = lane >> 4;
-  const int x0 = blockIdx.x * kTX, y0 = blockIdx.y * kTY;
-  const int z_begin = blockIdx.z * a.z_per_wg;
+  // Workgroups are dealt to the 8 XCDs round-robin in launch order; neighbouring windows share halo rows and columns, so
+  // XCD k takes a contiguous range of the (z chunk, y, x) window list and finds its neighbours' halos in its own L2.
+  const unsigned wg = xcd_chunked(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
+  const int bx = wg % gridDim.x, by = (wg / gridDim.x) % gridDim.y, bz = wg / (gridDim.x * gridDim.y);
+  const int x0 = bx * kTX, y0 = by * kTY;
+  const int z_begin = bz * a.z_per_wg;
   const int z_end = z_begin + a.z_per_wg < a.D ? z_begin + a.z_per_wg : a.D;
   const int Hp = padded_h(a.H), Wp = padded_w(a.W);
   const size_t HW = (size_t)a.H * a.W, DHW = (size_t)a.D * HW;
