@@ -259,6 +259,12 @@ struct PassAEpi {
         up[q] = hi8(v8, 1.0f);
       }
       if (GP) split8(w8, a2p[q], a2q[q]); else a2p[q] = hi8(w8, 1.0f);
+#ifdef SVS_EXP_A2_HI      // experiment: what a one-piece a2 block would do to the gradients (mid piece dropped, traffic unchanged)
+      if (GP) a2q[q] = (f16x8)(_Float16)0;
+#endif
+#ifdef SVS_EXP_U_HI       // experiment: the same for the STORED u block (the in-register operand of the next layer keeps both)
+      if (GP) uq[q] = (f16x8)(_Float16)0;
+#endif
 #if !(SVS_ABL & 2048)  // diagnostic: no u / a2 stores
       if (!LATE) { store_grad<GP>(ublk, k, lane, up[q], uq[q]); store_grad<GP>(a2blk, k, lane, a2p[q], a2q[q]); }
 #endif
