@@ -413,8 +413,17 @@ int svs_conv3d_gemm(const float* in, const void* wfrag, const float* bias, const
  * row lane & 15 = output channel, k = 32 s + 8 g + j with s = kx*3 + q, g = lane >> 4: tap ((g+4q)/3, (g+4q)%3, kx),
  * input channel j; zero for g + 4q > 8. */
 size_t svs_conv3d_s2c8_wfrag_bytes(void);
-int svs_conv3d_s2c8(const float* in, const void* wfrag, const float* bias, const float* skip, float* out, int Cout, int Di,
-                    int Hi, int Wi, int relu, void* hip_stream);
+/* split_out != NULL (Cout = 16, no skip): the output leaves as a split volume (svs_split_volume_dims(16, Do, Ho, Wo)) instead
+ * of float32 to `out` -- the input form of svs_conv3d_rows (conv2). */
+int svs_conv3d_s2c8(const float* in, const void* wfrag, const float* bias, const float* skip, float* out, void* split_out,
+                    int Cout, int Di, int Hi, int Wi, int relu, void* hip_stream);
+/* conv2 of CostRegNet (2b -> 2b at half resolution, CasMVSNet.py:446,462) from a split volume: slice ring + LDS-DMA as
+ * svs_conv3d_pair, the 16 MFMA rows = output channels.  Cin = 16, Cout <= 16.  wfrag (svs_conv3d_rows_wfrag_bytes(Cin)):
+ * [k-step s][piece][lane][8] fp16, row lane & 15 = output channel, k-step s / lane group lane >> 4 = combination
+ * 4 s + (lane >> 4) = tap * (Cin/8) + g of the (kd,kh,kw)-major tap list: weight of that tap, input channel 8 g + c8. */
+size_t svs_conv3d_rows_wfrag_bytes(int Cin);
+int svs_conv3d_rows(const void* split, const void* wfrag, const float* bias, float* out, int Cin, int Cout, int D, int H,
+                    int W, int relu, void* hip_stream);
 
 /* ---- a14 tail  softmax over D, depth regression, photometric confidence (models/CasMVSNet.py:648-663) ---------
  * reg, depth_values (D,H,W) -> prob (D,H,W), depth (H,W), conf (H,W), index (H,W int, may be NULL). */

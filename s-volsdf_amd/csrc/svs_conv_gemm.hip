@@ -19,6 +19,7 @@
 // [Cout,2Cout) the odd-x ones, over the same B fragments (input voxels xi and xi+1) -- one third fewer input loads,
 // full M tiles for Cout = 8, and the even/odd outputs of a channel leave in the same store instruction.
 #include "svs_common.h"
+#include "svs_split_volume.h"
 #include <cstdlib>
 
 namespace svs {
@@ -34,6 +35,7 @@ struct Args {
   float* out;           // (Cout, Do, Ho, Wo)
   int Cout, Di, Hi, Wi, Do, Ho, Wo, stride, relu;
   int xtiles, rows;     // tiles per output row (per class row for the transposed form), rows = Dz * Hy
+  uint4* split;         // conv_s2c8_kernel only: not null = the output leaves as a split volume (svs_split_volume.h), not to `out`
 };
 
 // taps of class (pz,py,px) of the transposed convolution, per dimension: parity 0 -> kernel index 1, input offset 0;
@@ -377,6 +379,24 @@ __global__ __launch_bounds__(256) void conv_s2c8_kernel(Args a) {
   if (!col_ok) return;
   const size_t chan_out = (size_t)a.Do * a.Ho * a.Wo;
   const size_t vox = ((size_t)zo * a.Ho + yo) * a.Wo + xo;
+  if (a.split) {
+    // the next layer (conv2, svs_conv3d_rows) reads fp16 hi / mid pieces, 8 channels per 16-byte unit: this lane's four
+    // channels 4g .. 4g+3 are one half of unit g >> 1 (Cout = 16: rows beyond Cout hold zeros, their weights being zero)
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    f16x4 h, m;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float r = acc[j] + ((a.bias && 4 * g + j < a.Cout) ? a.bias[4 * g + j] : 0.0f);
+      if (a.relu) r = __builtin_fmaxf(r, 0.0f);
+      const _Float16 hh = (_Float16)r;
+      h[j] = hh; m[j] = (_Float16)(r - (float)hh);
+    }
+    const int Gs = 2, Hp = splitvol::padded_h(a.Ho), Wp = splitvol::padded_w(a.Wo);
+    uint2* u = reinterpret_cast<uint2*>(a.split + splitvol::unit(zo, yo, 0, g >> 1, xo, Gs, Hp, Wp)) + (g & 1);
+    u[0] = __builtin_bit_cast(uint2, h);
+    u[(size_t)Gs * Wp * 2] = __builtin_bit_cast(uint2, m);
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int co = 4 * g + j;
@@ -458,7 +478,7 @@ int svs_conv3d_gemm(const float* in, const void* wfrag, const float* bias, const
   if (!svs_conv3d_gemm_supported(Cin, Cout)) { set_error("svs_conv3d_gemm: Cin must be 8/16/32/64 and Cout <= 64"); return SVS_ESHAPE; }
   Args a;
   a.in = in; a.wfrag = (const f16x8*)wfrag; a.bias = bias; a.skip = skip; a.out = out; a.Cout = Cout;
-  a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.stride = stride; a.relu = relu;
+  a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.stride = stride; a.relu = relu; a.split = nullptr;
   hipStream_t s = (hipStream_t)hip_stream;
   int MT = m_tiles(Cout);
   if (transposed) {
@@ -483,14 +503,17 @@ int svs_conv3d_gemm(const float* in, const void* wfrag, const float* bias, const
 // s = kx*3 + q, g = lane >> 4: the folded weight of tap ((g + 4q) / 3, (g + 4q) % 3, kx) and input channel j (zero for
 // g + 4q > 8).
 size_t svs_conv3d_s2c8_wfrag_bytes(void) { return (size_t)9 * 2 * 64 * 16; }
-int svs_conv3d_s2c8(const float* in, const void* wfrag, const float* bias, const float* skip, float* out, int Cout, int Di,
-                    int Hi, int Wi, int relu, void* hip_stream) {
-  if (!in || !wfrag || !out || Cout < 1 || Cout > 16 || Di < 1 || Hi < 1 || Wi < 2 || (Wi & 1)) {
-    set_error("svs_conv3d_s2c8: bad argument (Cout <= 16, Wi even)"); return SVS_EINVAL;
+// split_out: not null = the output (Cout = 16 channels) leaves as a split volume (svs_split_volume_dims(16, Do, Ho, Wo)
+// bytes, zero-filled by the caller before its first use) instead of float32 to `out` -- the form svs_conv3d_rows reads.
+int svs_conv3d_s2c8(const float* in, const void* wfrag, const float* bias, const float* skip, float* out, void* split_out,
+                    int Cout, int Di, int Hi, int Wi, int relu, void* hip_stream) {
+  if (!in || !wfrag || (!out && !split_out) || Cout < 1 || Cout > 16 || Di < 1 || Hi < 1 || Wi < 2 || (Wi & 1) ||
+      (split_out && (Cout != 16 || skip))) {
+    set_error("svs_conv3d_s2c8: bad argument (Cout <= 16, Wi even; split_out: Cout = 16, no skip)"); return SVS_EINVAL;
   }
   Args a;
   a.in = in; a.wfrag = (const f16x8*)wfrag; a.bias = bias; a.skip = skip; a.out = out; a.Cout = Cout;
-  a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.stride = 2; a.relu = relu;
+  a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.stride = 2; a.relu = relu; a.split = reinterpret_cast<uint4*>(split_out);
   a.Do = (Di - 1) / 2 + 1; a.Ho = (Hi - 1) / 2 + 1; a.Wo = (Wi - 1) / 2 + 1;
   a.xtiles = (a.Wo + 14) / 15; a.rows = a.Do * a.Ho;
   const long long tiles = (long long)a.rows * a.xtiles;

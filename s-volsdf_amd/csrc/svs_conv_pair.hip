@@ -213,6 +213,147 @@ int launch(const Args& a, hipStream_t s) {
   return check_launch("svs_conv3d_pair");
 }
 
+// ---- conv2 of the U-Net (2b -> 2b channels at half resolution, CasMVSNet.py:446,462) from a split volume: the same slice
+// ring and LDS-DMA copy as above, but the 16 MFMA rows are 16 output channels (no pairing needed) and a column is one x
+// position; a wave computes one output row as two 16-column tiles over shared weight fragments.  K = (kd, kh, kw, g) in
+// that order, 4 combinations per k-step; 27 G / 4 k-steps (13.5 at C = 16: the second half of the last one is zero).
+// Its input comes from conv1, whose epilogue writes the split form directly (svs_conv3d_s2c8 with split_out).
+struct RowsArgs {
+  const uint4* in;      // split volume of (Cin, D, H, W)
+  const uint4* wfrag;   // [KS][2 pieces][64 lanes] A fragments
+  const float* bias;
+  float* out;           // (Cout, D, H, W) float32
+  int Cout, D, H, W, relu;
+  int z_per_wg;
+};
+
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void conv3d_rows_kernel(RowsArgs a) {
+  constexpr int G = CIN / 8;
+  constexpr int KS = (27 * G + 3) / 4;
+  constexpr int UNITS = kHY * 2 * G * kRS;
+  constexpr int SLICE = UNITS * 16;
+  constexpr int NDMA = (UNITS + 255) / 256;
+  constexpr int PD = 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, kg = lane >> 4;
+  const int x0 = blockIdx.x * kTX, y0 = blockIdx.y * kTY;
+  const int z_begin = blockIdx.z * a.z_per_wg;
+  const int z_end = z_begin + a.z_per_wg < a.D ? z_begin + a.z_per_wg : a.D;
+  const int Hp = padded_h(a.H), Wp = padded_w(a.W);
+  const size_t HW = (size_t)a.H * a.W, DHW = (size_t)a.D * HW;
+  const size_t slice_units = (size_t)Hp * 2 * G * Wp;
+
+  f16x8 wh[KS], wm[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    wh[s] = __builtin_bit_cast(f16x8, a.wfrag[(2 * s) * 64 + lane]);
+    wm[s] = __builtin_bit_cast(f16x8, a.wfrag[(2 * s + 1) * 64 + lane]);
+  }
+  unsigned goff[NDMA];
+#pragma unroll
+  for (int j = 0; j < NDMA; ++j) {
+    const int u = (wave + 4 * j) * 64 + lane;
+    const int rs = u / kRS, x = u - rs * kRS;
+    const int ly = rs / (2 * G), pg = rs - ly * (2 * G);
+    goff[j] = (unsigned)((((y0 + ly) * 2 * G + pg) * Wp + x0 + x) * 16);
+  }
+  auto copy_slice = [&](int z, int slot) {
+    const uint4* gz = a.in + (size_t)(z + 1) * slice_units;
+#pragma unroll
+    for (int j = 0; j < NDMA; ++j) {
+      const int piece = wave + 4 * j;
+      if ((j + 1) * 256 <= UNITS || piece * 64 + lane < UNITS) {
+        const unsigned lds_base =
+            (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)(smem + slot * SLICE + piece * 1024);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     :: "v"(goff[j]), "s"(gz), "s"(lds_base) : "memory");
+      }
+    }
+  };
+  // B fragment of k-step s, lane group kg: combination c = 4 s + kg = (tap c / G, channel group c % G); tap > 26: zero
+  // weights (any valid address will do).  Per k-step: the slice (kd) and the byte offset of (row + kh, piece 0, g, n + kw).
+  int bkd[KS], boff[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int c = 4 * s + kg;
+    int tap = c / G;
+    const int g = c % G;
+    if (tap > 26) tap = 26;
+    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+    bkd[s] = kd;
+    boff[s] = ((((wave + kh) * 2) * G + g) * kRS + n + kw) * 16;
+  }
+  const int yo = y0 + wave;
+  float bias[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bias[r] = (a.bias && 4 * kg + r < a.Cout) ? a.bias[4 * kg + r] : 0.0f;
+  f32x4v res[2];
+  res[0] = (f32x4v)(0.0f); res[1] = (f32x4v)(0.0f);
+  auto finish = [&](int z) {
+    if (yo >= a.H) return;
+#pragma unroll
+    for (int xt = 0; xt < 2; ++xt) {
+      const int xo = x0 + 16 * xt + n;
+      if (xo >= a.W) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = 4 * kg + r;
+        if (co >= a.Cout) continue;
+        float o = res[xt][r] + bias[r];
+        if (a.relu) o = __builtin_fmaxf(o, 0.0f);
+        a.out[(size_t)co * DHW + (size_t)z * HW + (size_t)yo * a.W + xo] = o;
+      }
+    }
+  };
+  copy_slice(z_begin - 1, 0);
+  copy_slice(z_begin, 1);
+  copy_slice(z_begin + 1, 2);
+  for (int z = z_begin; z < z_end; ++z) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int r0 = (z - z_begin) & 3;
+    if (z + 2 <= z_end) copy_slice(z + 2, (r0 + 3) & 3);
+    if (z > z_begin) finish(z - 1);
+    int sb[3];
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) sb[kd] = ((r0 + kd) & 3) * SLICE;
+    constexpr int PIECE = G * kRS * 16;            // piece 1 (mid) of a row segment set follows piece 0 (hi)
+    f32x4v acc[2][3];
+#pragma unroll
+    for (int xt = 0; xt < 2; ++xt) { acc[xt][0] = (f32x4v)(0.0f); acc[xt][1] = (f32x4v)(0.0f); acc[xt][2] = (f32x4v)(0.0f); }
+    f16x8 bh[KS][2], bm[KS][2];
+    auto frag = [&](int s) {
+      const unsigned char* p = smem + sb[bkd[s]] + boff[s];
+#pragma unroll
+      for (int xt = 0; xt < 2; ++xt) {
+        bh[s][xt] = *reinterpret_cast<const f16x8*>(p + xt * 256);
+        bm[s][xt] = *reinterpret_cast<const f16x8*>(p + PIECE + xt * 256);
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < PD && s < KS; ++s) frag(s);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + PD < KS) frag(s + PD);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int xt = 0; xt < 2; ++xt) {
+        acc[xt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm[s], bh[s][xt], acc[xt][0], 0, 0, 0);
+        acc[xt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s], bm[s][xt], acc[xt][1], 0, 0, 0);
+        acc[xt][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s], bh[s][xt], acc[xt][2], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int xt = 0; xt < 2; ++xt) res[xt] = (acc[xt][0] + acc[xt][1]) + acc[xt][2];
+  }
+  if (z_end > z_begin) finish(z_end - 1);
+}
+
 // float32 channel-first volume -> split volume (interior only; the border is the caller's zero fill).  One thread per unit.
 __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ in, uint4* __restrict__ out, int C,
                                                          int D, int H, int W) {
@@ -298,6 +439,40 @@ int svs_conv3d_pair(const void* split, const void* wfrag, const float* bias, flo
   if (Cin == 8) return convpair::launch<8, 1>(a, s);
   if (Cin == 16) return convpair::launch<16, 1>(a, s);
   return convpair::launch<32, CONVP_SPLIT32>(a, s);
+}
+
+// bytes of the packed A fragments of svs_conv3d_rows: [ceil(27 Cin / 32)][2][64][16 B]
+size_t svs_conv3d_rows_wfrag_bytes(int Cin) { return (size_t)((27 * (Cin / 8) + 3) / 4) * 2 * 64 * 16; }
+
+// out (Cout,D,H,W) = [relu](conv3d(split volume of (Cin,D,H,W), 3x3x3, stride 1, padding 1) + bias); Cin = 16, Cout <= 16
+// (conv2 of CostRegNet).  wfrag: fragment [k-step s][piece][lane]: row lane & 15 = output channel, k = 32 s + 8 (lane >> 4)
+// + c8 with combination 4 s + (lane >> 4) = tap * (Cin/8) + g (tap = (kd*3+kh)*3+kw): the folded weight of that tap and
+// input channel 8 g + c8; zero for tap > 26 and channels >= Cout.
+int svs_conv3d_rows(const void* split, const void* wfrag, const float* bias, float* out, int Cin, int Cout, int D, int H,
+                    int W, int relu, void* hip_stream) {
+  if (!split || !wfrag || !out || Cout < 1 || Cout > 16 || D < 1 || H < 1 || W < 1 || Cin != 16) {
+    set_error("svs_conv3d_rows: bad argument (Cin = 16, Cout <= 16)"); return SVS_EINVAL;
+  }
+  convpair::RowsArgs a{reinterpret_cast<const uint4*>(split), reinterpret_cast<const uint4*>(wfrag), bias, out, Cout, D, H, W,
+                       relu, 0};
+  const int xy = ((W + convpair::kTX - 1) / convpair::kTX) * ((H + convpair::kTY - 1) / convpair::kTY);
+  int best = 1;
+  double best_cost = 1e30;
+  for (int zs = 1; zs <= D && zs <= 64; ++zs) {
+    const int zp = (D + zs - 1) / zs;
+    const long long wgs = (long long)xy * ((D + zp - 1) / zp);
+    const double rounds = (double)((wgs + 511) / 512);          // two workgroups per CU
+    const double cost = rounds * (zp + 2);
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = zs; }
+  }
+  a.z_per_wg = (D + best - 1) / best;
+  constexpr int lds = 4 * convpair::kHY * 2 * 2 * convpair::kRS * 16;
+  static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(convpair::conv3d_rows_kernel<16>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) { set_error("svs_conv3d_rows: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+  dim3 grid((W + convpair::kTX - 1) / convpair::kTX, (H + convpair::kTY - 1) / convpair::kTY, (D + a.z_per_wg - 1) / a.z_per_wg);
+  convpair::conv3d_rows_kernel<16><<<grid, 256, lds, (hipStream_t)hip_stream>>>(a);
+  return check_launch("svs_conv3d_rows");
 }
 
 }  // extern "C"

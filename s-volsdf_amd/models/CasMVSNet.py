@@ -147,11 +147,12 @@ class _Block3d(nn.Module):
             self._key = key
         return self._folded
 
-    def forward(self, x, skip=None):
+    def forward(self, x, skip=None, split_out=False):
         if self.training:
             raise NotImplementedError("CasMVSNet is inference-only in S-VolSDF (runner.py:153); call .eval()")
         w, b = self.folded()
-        return costvol.conv3d(x, w, b, skip=skip, stride=self.stride, transposed=self.transposed, relu=True)
+        return costvol.conv3d(x, w, b, skip=skip, stride=self.stride, transposed=self.transposed, relu=True,
+                              split_out=split_out)
 
 
 class Conv3d(_Block3d):
@@ -165,6 +166,10 @@ class Deconv3d(_Block3d):
                  output_padding=1, **kw):
         assert kernel_size == 3 and stride == 2 and relu and bn and padding == 1 and output_padding == 1
         super().__init__(in_channels, out_channels, stride=2, transposed=True)
+
+
+def x_is_device(t):
+    return torch.is_tensor(t) and t.is_cuda
 
 
 class CostRegNet(nn.Module):
@@ -191,7 +196,10 @@ class CostRegNet(nn.Module):
         if not isinstance(x, costvol.SplitVolume):
             x = x[0]
         c0 = self.conv0(x)
-        c2 = self.conv2(self.conv1(c0))
+        # conv1 hands its output to conv2 as fp16 hi / mid pieces where both have the fused form (svs_conv3d_s2c8 -> _rows)
+        fused12 = (x_is_device(c0) and costvol.rows_supported(self.conv1.conv.out_channels, self.conv2.conv.out_channels)
+                   and self.conv1.conv.in_channels == 8 and c0.shape[-1] % 2 == 0)
+        c2 = self.conv2(self.conv1(c0, split_out=fused12))
         c4 = self.conv4(self.conv3(c2))
         y = self.conv6(self.conv5(c4))
         y = self.conv7(y, skip=c4)

@@ -324,6 +324,33 @@ def gemm_enabled(on=None):
     return _GEMM_ON[0]
 
 
+def rows_weight_fragments(weight):
+    """[16][27][Cout <= 16] folded float32 weights -> the fp16 hi / mid A fragments of svs_conv3d_rows
+    ([k-step][piece][lane][8], include/svolsdf_hip.h): k-step s, lane group kg = combination 4 s + kg = tap * G + g."""
+    key = ("rows", weight.data_ptr(), weight._version, tuple(weight.shape))
+    hit = _WFRAG_CACHE.get(key)
+    if hit is not None:
+        return hit[0]
+    Cin, _, Cout = weight.shape
+    dev = weight.device
+    G = Cin // 8
+    KS = (27 * G + 3) // 4
+    s = torch.arange(KS, device=dev).view(KS, 1, 1)
+    lane = torch.arange(64, device=dev).view(1, 64, 1)
+    j = torch.arange(8, device=dev).view(1, 1, 8)
+    c = 4 * s + (lane >> 4)
+    tap, g = (c // G).expand(KS, 64, 8), (c % G).expand(KS, 64, 8)
+    co = (lane & 15).expand(KS, 64, 8)
+    ok = (tap < 27) & (co < Cout)
+    w = weight[8 * g + j, tap.clamp(max=26), co.clamp(max=Cout - 1)]
+    w = torch.where(ok, w, torch.zeros_like(w)).float()
+    hi = w.half()
+    mid = (w - hi.float()).half()
+    frag = torch.stack([hi, mid], 1).contiguous()
+    _WFRAG_CACHE[key] = (frag, weight)
+    return frag
+
+
 def s2c8_weight_fragments(weight):
     """[8][27][Cout <= 16] folded float32 weights -> the fp16 hi / mid A fragments of svs_conv3d_s2c8
     ([9 k-steps][piece][lane][8], include/svolsdf_hip.h)."""
@@ -365,9 +392,23 @@ def gemm_weight_fragments(weight, transposed):
     return frag
 
 
-def conv3d(x, weight, bias=None, skip=None, stride=1, transposed=False, relu=True):
-    """x (Cin,D,H,W); weight [Cin][27][Cout] folded; -> (Cout,Do,Ho,Wo)."""
+def rows_supported(Cin, Cout):
+    return Cin == 16 and Cout <= 16 and not os.environ.get("SVS_CONV_ROWS_OFF")
+
+
+def conv3d(x, weight, bias=None, skip=None, stride=1, transposed=False, relu=True, split_out=False):
+    """x (Cin,D,H,W); weight [Cin][27][Cout] folded; -> (Cout,Do,Ho,Wo).  split_out: return the result as a SplitVolume (the
+    stride-2 convolution from 8 to 16 channels only: conv1 feeding conv2)."""
     L = _lib.load()
+    if isinstance(x, SplitVolume) and x.C == 16:
+        Cout = weight.shape[2]
+        if transposed or stride != 1 or skip is not None or not rows_supported(x.C, Cout):
+            raise ValueError("a 16-channel SplitVolume feeds the stride-1 convolution with Cout <= 16 only (svs_conv3d_rows)")
+        frag = rows_weight_fragments(weight)
+        out = torch.empty((Cout, x.D, x.H, x.W), device=x.device)
+        _lib.check(L.svs_conv3d_rows(_ptr(x.buf), _ptr(frag), _ptr(bias), _ptr(out), x.C, Cout, x.D, x.H, x.W, int(relu),
+                                     _stream()), "svs_conv3d_rows")
+        return out
     if isinstance(x, SplitVolume):
         Cout = weight.shape[2]
         if transposed or stride != 1 or skip is not None or not pair_supported(x.C, Cout):
@@ -398,7 +439,12 @@ def conv3d(x, weight, bias=None, skip=None, stride=1, transposed=False, relu=Tru
     out = torch.empty(shp, device=x.device)
     if not transposed and stride == 2 and Cin == 8 and Cout <= 16 and W % 2 == 0 and not os.environ.get("SVS_CONV_S2C8_OFF"):
         frag = s2c8_weight_fragments(weight)
-        _lib.check(L.svs_conv3d_s2c8(_ptr(x), _ptr(frag), _ptr(bias), _ptr(skip), _ptr(out), Cout, D, H, W, int(relu),
+        if split_out and Cout == 16 and skip is None:
+            sv = SplitVolume(Cout, *shp[1:], x.device)
+            _lib.check(L.svs_conv3d_s2c8(_ptr(x), _ptr(frag), _ptr(bias), None, None, _ptr(sv.buf), Cout, D, H, W, int(relu),
+                                         _stream()), "svs_conv3d_s2c8")
+            return sv
+        _lib.check(L.svs_conv3d_s2c8(_ptr(x), _ptr(frag), _ptr(bias), _ptr(skip), _ptr(out), None, Cout, D, H, W, int(relu),
                                      _stream()), "svs_conv3d_s2c8")
         return out
     if gemm_enabled() and L.svs_conv3d_gemm_supported(Cin, Cout):

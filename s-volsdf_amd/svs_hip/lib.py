@@ -126,7 +126,9 @@ SIGNATURES = {
     "svs_conv3d_gemm": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "svs_conv3d_mfma": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "svs_conv3d_s2c8_wfrag_bytes": (c_size_t, []),
-    "svs_conv3d_s2c8": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "svs_conv3d_s2c8": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "svs_conv3d_rows_wfrag_bytes": (c_size_t, [c_int]),
+    "svs_conv3d_rows": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "svs_conv3d_c1": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "svs_split_volume_dims": (c_size_t, [c_int, c_int, c_int, c_int, POINTER(c_int)]),
     "svs_split_volume_pack": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -209,6 +209,36 @@ def test_conv3d_stride2_from_8_channels(dev, cout, shape):
     np.testing.assert_allclose(got, ref, atol=3e-6 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("cout,shape", [(16, (5, 7, 37)), (16, (3, 9, 70)), (11, (9, 6, 33)), (16, (20, 8, 64))])
+def test_conv3d_rows_from_split_volume(dev, cout, shape):
+    """conv2's kernel (16 -> Cout <= 16, stride 1, split-volume input, output channels as MFMA rows) against a float64 torch
+    convolution on ragged shapes and against the kernel it replaces; and conv1's split-volume output (the producer side) holds
+    the pieces of its float32 output bit for bit.  Tolerance 3e-6 of the output scale (fp16x2 operands)."""
+    from svs_hip import costvol
+    rng = np.random.default_rng(cout + shape[2])
+    x = rng.normal(0, 1, (16,) + shape).astype(F32)
+    w = (rng.normal(0, 1, (16, 27, cout)) / np.sqrt(27 * 16)).astype(F32)
+    b = rng.normal(0, 1, cout).astype(F32)
+    got = costvol.conv3d(costvol.SplitVolume.pack(G(x, dev)), G(w, dev), G(b, dev), relu=True).cpu().numpy()
+    wt = torch.from_numpy(w).double().permute(2, 0, 1).reshape(cout, 16, 3, 3, 3)
+    ref = torch.nn.functional.conv3d(torch.from_numpy(x).double()[None], wt, torch.from_numpy(b).double(), padding=1)[0]
+    ref = ref.clamp(min=0).numpy()
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, atol=3e-6 * np.abs(ref).max())
+    old = costvol.conv3d(G(x, dev), G(w, dev), G(b, dev), relu=True).cpu().numpy()
+    np.testing.assert_allclose(got, old, atol=3e-6 * np.abs(ref).max())
+    # the producer: conv1 (8 -> 16, stride 2) writing the split form
+    D, H, W = 2 * shape[0], 2 * shape[1], 2 * shape[2]
+    x1 = rng.normal(0, 1, (8, D, H, W)).astype(F32)
+    w1 = (rng.normal(0, 1, (8, 27, 16)) / np.sqrt(27 * 8)).astype(F32)
+    b1 = rng.normal(0, 1, 16).astype(F32)
+    f = costvol.conv3d(G(x1, dev), G(w1, dev), G(b1, dev), stride=2, relu=True)
+    sv = costvol.conv3d(G(x1, dev), G(w1, dev), G(b1, dev), stride=2, relu=True, split_out=True)
+    assert isinstance(sv, costvol.SplitVolume) and sv.shape == (1, 16) + tuple(f.shape[1:])
+    a = sv.buf.clone()
+    assert torch.equal(a, costvol.SplitVolume.pack(f).buf)
+
+
 @pytest.mark.parametrize("cin,shape", [(8, (5, 7, 37)), (8, (11, 33, 40)), (16, (3, 5, 6)), (8, (24, 40, 64))])
 def test_conv3d_one_output_channel(dev, cin, shape):
     """The `prob` layer's kernel (Cout = 1, float32 FMAs on the vector ALUs) against a float64 torch convolution:
