@@ -251,10 +251,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Args a) {
 // The layer is HBM traffic (283 MB at stage 1: skip in, output out) behind a handful of MFMAs; as four MODE-2 waves per
 // cell each wave had ~3 KB in flight and the latency of its skip read at the very end (0.123 ms = 2.3 TB/s).  Here
 // every load of the wave -- 4 k-steps of B and the 16 skip values per lane -- is issued before the first MFMA.
-template <int CIN>
+// MTC = M tiles per class: 1 (conv11, Cin 16 -> Cout 8) or 2 (conv9, 32 -> 16); M tile mt of a class holds channels 8 mt ..
+// 8 mt + 7 in the (channel, parity) row order.  One k-step = 32 / CIN of the 8 input voxels of the cell.
+template <int CIN, int MTC>
 __global__ __launch_bounds__(256) void deconv_cell_kernel(Args a) {
-  static_assert(CIN == 16, "one k-step = one (dz,dy) pair of input rows");
+  static_assert(CIN == 16 || CIN == 32, "k-steps cover whole input voxels");
   constexpr int KS = 8 * CIN / 32;
+  constexpr int VPS = 32 / CIN;                       // input voxels (offsets) per k-step: 2 or 1
   const int lane = threadIdx.x & 63;
   const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tile >= (long long)a.rows * a.xtiles) return;
@@ -263,31 +266,39 @@ __global__ __launch_bounds__(256) void deconv_cell_kernel(Args a) {
   const int zi = row / a.Hi, yi = row - zi * a.Hi, xi = 16 * xt + n;
   const bool col_ok = xi < a.Wi;
   const size_t chan_in = (size_t)a.Di * a.Hi * a.Wi, chan_out = (size_t)a.Do * a.Ho * a.Wo;
-  // accumulator rows 4 g + j of a lane: (channel 2 g + (j >> 1), x = 2 xi + (j & 1)) -- see pack_kernel, mode 3
-  // ---- skip values of the cell (8 float2 per lane), requested first
-  float2 sk[4][2];
+  // accumulator rows 4 g + j of a lane in M tile mt: (channel 8 mt + 2 g + (j >> 1), x = 2 xi + (j & 1)) -- pack_kernel, mode 3
+  // ---- skip values of the cell (8 MTC float2 per lane), requested first
+  float2 sk[4][MTC][2];
   size_t obase[4];
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     obase[m] = (size_t)(2 * g) * chan_out + ((size_t)(2 * zi + (m >> 1)) * a.Ho + (2 * yi + (m & 1))) * a.Wo + 2 * xi;
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
-      sk[m][q] = (a.skip && col_ok) ? *reinterpret_cast<const float2*>(a.skip + obase[m] + (size_t)q * chan_out) : float2{0.0f, 0.0f};
+    for (int mt = 0; mt < MTC; ++mt)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        sk[m][mt][q] = (a.skip && col_ok) ? *reinterpret_cast<const float2*>(a.skip + obase[m] + (size_t)(8 * mt + q) * chan_out)
+                                          : float2{0.0f, 0.0f};
   }
-  // ---- B operand: k-step s = input rows (zi + (s >> 1), yi + (s & 1)), lane group g = (voxel xi + (g >> 1), channels 8 (g & 1)..)
+  // ---- B operand: offset t = (dz*2 + dy)*2 + dxs of the cell's 8 input voxels.  CIN = 16: k-step s = offsets 2s (lane groups
+  // 0,1) and 2s+1 (groups 2,3), 8 channels per group; CIN = 32: k-step s = offset s, lane group g = channels 8g..8g+7
   float x[KS][8];
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
-    const int iz = zi + (s >> 1), iy = yi + (s & 1), ix = xi + (g >> 1);
+    const int t = VPS * s + (VPS == 2 ? (g >> 1) : 0);
+    const int c0 = VPS == 2 ? 8 * (g & 1) : 8 * g;
+    const int iz = zi + (t >> 2), iy = yi + ((t >> 1) & 1), ix = xi + (t & 1);
     const bool ok = col_ok && iz < a.Di && iy < a.Hi && ix < a.Wi;
-    const float* p = a.in + (size_t)(8 * (g & 1)) * chan_in + ((size_t)(ok ? iz : 0) * a.Hi + (ok ? iy : 0)) * a.Wi + (ok ? ix : 0);
+    const float* p = a.in + (size_t)c0 * chan_in + ((size_t)(ok ? iz : 0) * a.Hi + (ok ? iy : 0)) * a.Wi + (ok ? ix : 0);
 #pragma unroll
     for (int j = 0; j < 8; ++j) { const float v = p[(size_t)j * chan_in]; x[s][j] = ok ? v : 0.0f; }
   }
-  const f16x8* __restrict__ wf = a.wfrag + lane;      // [class][k-step][piece][lane]
-  f32x4 acc[4];
+  const f16x8* __restrict__ wf = a.wfrag + lane;      // [class][k-step][M tile][piece][lane]
+  f32x4 acc[4][MTC];
 #pragma unroll
-  for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int mt = 0; mt < MTC; ++mt) acc[m][mt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     f16x8 bh, bm;
@@ -296,27 +307,35 @@ __global__ __launch_bounds__(256) void deconv_cell_kernel(Args a) {
       const _Float16 h = (_Float16)x[s][j];
       bh[j] = h; bm[j] = (_Float16)(x[s][j] - (float)h);
     }
+    const int dz = (VPS * s) >> 2, dy = ((VPS * s) >> 1) & 1;     // (the offsets of a k-step share dz, dy)
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      if ((s >> 1) > (m >> 1) || (s & 1) > (m & 1)) continue;     // the class does not reach these input rows
-      const f16x8 ah = wf[(m * KS + s) * 128], am = wf[(m * KS + s) * 128 + 64];
-      acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am, bh, acc[m], 0, 0, 0);
-      acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bm, acc[m], 0, 0, 0);
-      acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[m], 0, 0, 0);
+      if (dz > (m >> 1) || dy > (m & 1)) continue;                // the class does not reach these input rows
+#pragma unroll
+      for (int mt = 0; mt < MTC; ++mt) {
+        const f16x8 ah = wf[((m * KS + s) * MTC + mt) * 128], am = wf[((m * KS + s) * MTC + mt) * 128 + 64];
+        acc[m][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am, bh, acc[m][mt], 0, 0, 0);
+        acc[m][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bm, acc[m][mt], 0, 0, 0);
+        acc[m][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[m][mt], 0, 0, 0);
+      }
     }
   }
   if (!col_ok) return;
-  float bias[2];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) bias[q] = a.bias ? a.bias[2 * g + q] : 0.0f;
+  for (int mt = 0; mt < MTC; ++mt) {
+    float bias[2];
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+    for (int q = 0; q < 2; ++q) bias[q] = a.bias ? a.bias[8 * mt + 2 * g + q] : 0.0f;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      float r0 = acc[m][2 * q] + bias[q], r1 = acc[m][2 * q + 1] + bias[q];
-      if (a.relu) { r0 = __builtin_fmaxf(r0, 0.0f); r1 = __builtin_fmaxf(r1, 0.0f); }
-      *reinterpret_cast<float2*>(a.out + obase[m] + (size_t)q * chan_out) = float2{r0 + sk[m][q].x, r1 + sk[m][q].y};
-    }
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        float r0 = acc[m][mt][2 * q] + bias[q], r1 = acc[m][mt][2 * q + 1] + bias[q];
+        if (a.relu) { r0 = __builtin_fmaxf(r0, 0.0f); r1 = __builtin_fmaxf(r1, 0.0f); }
+        *reinterpret_cast<float2*>(a.out + obase[m] + (size_t)(8 * mt + q) * chan_out) =
+            float2{r0 + sk[m][mt][q].x, r1 + sk[m][mt][q].y};
+      }
+  }
 }
 
 // conv1 of the U-Net (8 -> 16 channels, stride 2, full resolution in: models/CasMVSNet.py:445,461): the general kernel
@@ -443,7 +462,7 @@ static bool launch_cin(const Args& a, int Cin, int MT, long long tiles, hipStrea
 static int m_tiles(int rows) { return rows <= 16 ? 1 : (rows <= 32 ? 2 : 4); }
 // the transposed form pairs the x-parities when both fit the 64 output rows of a wave and rows split on lanes' groups of 4
 static int deconv_mode(int Cin, int Cout) {
-  if (Cin == 16 && Cout == 8) return 3;            // whole 2x2x2 cells per wave (deconv_cell_kernel)
+  if ((Cin == 16 && Cout == 8) || (Cin == 32 && Cout == 16)) return 3;     // whole 2x2x2 cells per wave (deconv_cell_kernel)
   return (Cout <= 32 && Cout % 4 == 0) ? 2 : 1;
 }
 
@@ -487,7 +506,8 @@ int svs_conv3d_gemm(const float* in, const void* wfrag, const float* bias, const
     const int mode = deconv_mode(Cin, Cout);
     if (mode == 3) {
       const long long tiles = (long long)a.rows * a.xtiles;
-      deconv_cell_kernel<16><<<(unsigned)((tiles + 3) / 4), 256, 0, s>>>(a);
+      if (Cin == 16) deconv_cell_kernel<16, 1><<<(unsigned)((tiles + 3) / 4), 256, 0, s>>>(a);
+      else deconv_cell_kernel<32, 2><<<(unsigned)((tiles + 3) / 4), 256, 0, s>>>(a);
     } else if (mode == 2) { MT = m_tiles(2 * Cout); launch_cin<2>(a, Cin, MT, 4LL * a.rows * a.xtiles, s); }
     else launch_cin<1>(a, Cin, MT, 8LL * a.rows * a.xtiles, s);
   } else {
