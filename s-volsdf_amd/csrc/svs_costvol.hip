@@ -616,8 +616,24 @@ __global__ __launch_bounds__(256) void prob_depth_conf_kernel(const float* __res
   const int lp = threadIdx.x % PX, sl = threadIdx.x / PX;
   const int p = blockIdx.x * PX + lp;
   const bool live = p < HW;
+  // A thread's share of the depth axis (<= kSoftN values: D = 192 at DS = 8) stays in registers across the three passes
+  // (maximum, sum of exponentials, probabilities): `reg` is read once.  Deeper volumes fall back to re-reading it.
+  constexpr int kSoftN = 24;
+  const bool cached = D <= kSoftN * DS;
+  float v[kSoftN];
   float m = -__builtin_inff();
-  if (live) for (int d = sl; d < D; d += DS) m = __builtin_fmaxf(m, reg[(size_t)d * HW + p]);
+  if (live) {
+    if (cached) {
+#pragma unroll
+      for (int i = 0; i < kSoftN; ++i) {
+        const int d = sl + i * DS;
+        v[i] = d < D ? reg[(size_t)d * HW + p] : -__builtin_inff();
+        m = __builtin_fmaxf(m, v[i]);
+      }
+    } else {
+      for (int d = sl; d < D; d += DS) m = __builtin_fmaxf(m, reg[(size_t)d * HW + p]);
+    }
+  }
   if (DS > 1) {
     red[0][sl][lp] = m;
     __syncthreads();
@@ -625,7 +641,15 @@ __global__ __launch_bounds__(256) void prob_depth_conf_kernel(const float* __res
     for (int k = 0; k < DS; ++k) m = __builtin_fmaxf(m, red[0][k][lp]);
   }
   float s = 0.0f;
-  if (live) for (int d = sl; d < D; d += DS) s += __expf(reg[(size_t)d * HW + p] - m);
+  if (live) {
+    if (cached) {
+#pragma unroll
+      for (int i = 0; i < kSoftN; ++i)
+        if (sl + i * DS < D) { v[i] = __expf(v[i] - m); s += v[i]; }
+    } else {
+      for (int d = sl; d < D; d += DS) s += __expf(reg[(size_t)d * HW + p] - m);
+    }
+  }
   if (DS > 1) {
     red[1][sl][lp] = s;
     __syncthreads();
@@ -635,11 +659,26 @@ __global__ __launch_bounds__(256) void prob_depth_conf_kernel(const float* __res
   }
   const float inv = 1.0f / s;
   float dep = 0.0f, idxf = 0.0f;
-  if (live) for (int d = sl; d < D; d += DS) {
-    const float pr = __expf(reg[(size_t)d * HW + p] - m) * inv;
-    prob[(size_t)d * HW + p] = pr;
-    dep += pr * depth_values[(size_t)d * HW + p];
-    idxf += pr * (float)d;
+  if (live) {
+    if (cached) {
+#pragma unroll
+      for (int i = 0; i < kSoftN; ++i) {
+        const int d = sl + i * DS;
+        if (d < D) {
+          const float pr = v[i] * inv;
+          prob[(size_t)d * HW + p] = pr;
+          dep += pr * depth_values[(size_t)d * HW + p];
+          idxf += pr * (float)d;
+        }
+      }
+    } else {
+      for (int d = sl; d < D; d += DS) {
+        const float pr = __expf(reg[(size_t)d * HW + p] - m) * inv;
+        prob[(size_t)d * HW + p] = pr;
+        dep += pr * depth_values[(size_t)d * HW + p];
+        idxf += pr * (float)d;
+      }
+    }
   }
   if (DS > 1) {
     __syncthreads();                          // red[0] is read by every slice above
