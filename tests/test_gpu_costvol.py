@@ -319,6 +319,28 @@ def test_conv0_full_size_pair_vs_channel_rows(dev):
     assert float((a2 - 2.0 * (a - b.view(8, 1, 1, 1))).abs().max()) <= 3e-6 * scale
 
 
+def test_reference_resolution_sizes_run(dev):
+    """The resolution the reference's MVS dataset actually feeds (1152 x 1536 after its x2 up-scaling, general_eval.py:225-229;
+    D = 192 / 32 / 8): every fused path of the cost volume at its largest shapes -- 2.8 GB split volume at stage 1 -- runs,
+    probabilities sum to one, depths stay inside the hypothesis range."""
+    feats, proj, depth_values = synth.make_mvs_sample(5, img_hw=(1152, 1536))
+    m = _model(dev, [192, 32, 8])
+    sample = dict(imgs=torch.zeros(1, 3, 3, 1152, 1536, device=dev), depth_values=G(depth_values, dev)[None],
+                  proj_matrices={k: G(v, dev)[None] for k, v in proj.items()})
+    features = [{k: G(v, dev)[None] for k, v in f.items()} for f in feats]
+    outputs = None
+    for st in range(3):
+        outputs, _ = m(st, sample, features=features, extra=None, outputs=outputs, int_r=m.depth_interals_ratio[st])
+        o = outputs[f"stage{st + 1}"]
+        sc = (4, 2, 1)[st]
+        assert o["depth"].shape == (1, 1152 // sc, 1536 // sc)
+        assert torch.isfinite(o["depth"]).all() and torch.isfinite(o["photometric_confidence"]).all()
+        assert float((o["prob_volume"].sum(1) - 1.0).abs().max()) < 1e-5
+        dv = o["depth_values"]
+        assert bool((o["depth"] >= dv.min(1)[0] - 1e-3).all()) and bool((o["depth"] <= dv.max(1)[0] + 1e-3).all())
+    torch.cuda.empty_cache()
+
+
 def test_stage_loop_feature_cache(dev):
     """runner.py:178-243 through svs_hip.stage_loop.StageLoop: three reference views x three stages with the images'
     features extracted once each (3 calls instead of 27), identical outputs to the uncached loop, and the depth
