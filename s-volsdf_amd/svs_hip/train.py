@@ -281,10 +281,14 @@ class BgBackward:
         self.sdf_stream = torch.empty(L.svs_stream_bytes(6) // 4, device=device)
         self.rgb_stream = torch.empty(L.svs_stream_bytes(8) // 4, device=device)
         self.ws = torch.empty(L.svs_pack_workspace_bytes() // 4, device=device)
-        self.dWk = torch.zeros(11, 256, LDW, device=device)      # 0..8 implicit layers, 9..10 radiance layers
-        self.dbk = torch.zeros(11, 256, device=device)
-        self.row0 = torch.zeros(257, device=device)
-        self.absmax = torch.zeros(4, device=device)
+        # one allocation, one memset per step (as WGradAccum)
+        n = [11 * 256 * LDW, 11 * 256, 260, 4]
+        self.flat = torch.zeros(sum(n), device=device)
+        parts = torch.split(self.flat, n)
+        self.dWk = parts[0].view(11, 256, LDW)                   # 0..8 implicit layers, 9..10 radiance layers
+        self.dbk = parts[1].view(11, 256)
+        self.row0 = parts[2][:257]
+        self.absmax = parts[3]
         self._scratch = {}          # per concurrent ray group: (n, zbuf, feat_bar, abuf, sbar); the accumulators are shared
 
     def pack(self, sdf_wb, rgb_wb):
@@ -297,7 +301,7 @@ class BgBackward:
                                          _stream()), "svs_pack_stream(bg backward)")
 
     def zero(self):
-        self.dWk.zero_(); self.dbk.zero_(); self.row0.zero_(); self.absmax.zero_()
+        self.flat.zero_()
 
     def _alloc(self, n, slot):
         cur = self._scratch.get(slot)
