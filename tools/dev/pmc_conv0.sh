@@ -9,8 +9,8 @@ P2="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_LDS_UNALIGNED_STALL G
 for v in "" $VARIANTS; do
   n=${v:-default}
   if [ -n "$v" ]; then export SVS_LIB_PATH=$R/s-volsdf_amd/lib_ab/libsvolsdf_hip_$v.so; fi
-  rocprofv3 --pmc $P1 -d $O/${n}_1 --output-format csv -- python3 $R/tools/dev/time_conv0.py > $O/$n.log 2>&1
-  rocprofv3 --pmc $P2 -d $O/${n}_2 --output-format csv -- python3 $R/tools/dev/time_conv0.py > $O/$n.log 2>&1
+  timeout 180 rocprofv3 --pmc $P1 -d $O/${n}_1 --output-format csv -- python3 $R/tools/dev/time_conv0.py > $O/$n.log 2>&1
+  timeout 180 rocprofv3 --pmc $P2 -d $O/${n}_2 --output-format csv -- python3 $R/tools/dev/time_conv0.py > $O/$n.log 2>&1
 done
 cd $R
 find $O -name '*agent_info.csv' -delete

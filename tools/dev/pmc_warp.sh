@@ -1,5 +1,6 @@
 #!/bin/bash
-# counters of the fused warp + variance kernel (dev aid; run on the GPU box)
+# counters of the fused warp + variance kernel (dev aid; run on the GPU box).  Every pass under `timeout`: a counter set
+# the profiler rejects (FETCH_SIZE with TCC_HIT_sum did) aborts it and leaves it hanging until gpurun's limit.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/pmc_warp
 rm -rf $O; mkdir -p $O
@@ -8,9 +9,9 @@ i=0
 for P in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE" \
          "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_TA_BUSY_sum TA_BUSY_avr GRBM_GUI_ACTIVE" \
          "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE" \
-         "FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"; do
+         "FETCH_SIZE GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --pmc $P -d $O/p$i --output-format csv -- python3 $R/tools/dev/time_warp.py > $O/p$i.log 2>&1
+  timeout 180 rocprofv3 --pmc $P -d $O/p$i --output-format csv -- python3 $R/tools/dev/time_warp.py > $O/p$i.log 2>&1
 done
 cd $R
 find $O -name '*agent_info.csv' -delete
