@@ -60,5 +60,31 @@ class DeviceBatches:
         return self.idx_t[view], sample, gt
 
     def __iter__(self):
-        for _ in range(len(self)):
-            yield self.batch()
+        """One epoch of batches.  Batch i+1 is drawn on a side stream while step i runs (the device `randperm` and the gathers
+        are 0.2 ms of small kernels that would otherwise sit in front of every step); the consumer's stream waits for it."""
+        if self.device.type != "cuda":
+            for _ in range(len(self)):
+                yield self.batch()
+            return
+        side = getattr(self, "_side", None)
+        if side is None:
+            side = self._side = torch.cuda.Stream(device=self.device)
+
+        def draw():
+            main = torch.cuda.current_stream(self.device)
+            side.wait_stream(main)                       # (the images were uploaded on the consumer's stream)
+            with torch.cuda.stream(side):
+                b = self.batch()
+                ev = torch.cuda.Event(); ev.record(side)
+            for d in b[1:]:
+                for t in d.values():
+                    if torch.is_tensor(t) and t.is_cuda:
+                        t.record_stream(main)            # allocated on the side stream, consumed on the main one
+            return b, ev
+        nxt = draw()
+        for i in range(len(self)):
+            cur, ev = nxt
+            if i + 1 < len(self):
+                nxt = draw()
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            yield cur
