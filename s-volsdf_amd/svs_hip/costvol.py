@@ -400,6 +400,12 @@ def conv3d(x, weight, bias=None, skip=None, stride=1, transposed=False, relu=Tru
     """x (Cin,D,H,W); weight [Cin][27][Cout] folded; -> (Cout,Do,Ho,Wo).  split_out: return the result as a SplitVolume (the
     stride-2 convolution from 8 to 16 channels only: conv1 feeding conv2)."""
     L = _lib.load()
+    if isinstance(x, SplitVolume):
+        Cout = weight.shape[2]
+        fused = (not transposed and stride == 1 and skip is None
+                 and (rows_supported(x.C, Cout) if (x.C == 16 and Cout > 8) else pair_supported(x.C, Cout)))
+        if not fused:
+            x = x.float()            # no fused form for this layer (or switched off): back to the float32 volume
     if isinstance(x, SplitVolume) and x.C == 16 and weight.shape[2] > 8:      # (Cout <= 8: conv0 of stage 2, the x-pair kernel below)
         Cout = weight.shape[2]
         if transposed or stride != 1 or skip is not None or not rows_supported(x.C, Cout):
