@@ -415,6 +415,7 @@ class TrainStep:
             if n_valid < R:                      # padded batch: the random stream is consumed as for the caller's rays
                 from volsdf.model.network import pad_rng
                 rng = pad_rng(rng, R)
+            self._draws_done()
             gt = {"rgb": ground_truth["rgb"].reshape(-1, 3), "rgb_smooth": ground_truth["rgb_smooth"].reshape(-1, 3)}
             results, holds = self._device_step(self.scratch, model_input, gt, mvs, fast, rng, dyn=None)
             self._hold = holds
@@ -425,6 +426,16 @@ class TrainStep:
         if tune is not None:
             self._tune_end(R, tune)
         return out
+
+    after_draws = None      # optional callable, invoked once per step right after the step's random draws have been made
+
+    def _draws_done(self):
+        """The step has consumed the CPU generator (sampler jitter, eikonal points, ...): from here on it only enqueues
+        launches.  A caller that feeds the step from the reference's DataLoader loop starts drawing the NEXT batch now
+        (volsdf/vsdf.py::VolOpt.run) -- the generator is used by one thread at a time, in the reference's order."""
+        cb, self.after_draws = self.after_draws, None
+        if cb is not None:
+            cb()
 
     def _loss_on_valid(self, out, g_gt, v, Rg, norm, anneal_dev):
         """The loss of a ray group whose last Rg - v rays are padding: evaluated on the first v rays (and their 2 eikonal
@@ -638,6 +649,7 @@ class TrainStep:
         if ev is not None:
             ev.synchronize()
         self._upload(cs, model_input, ground_truth, mvs)
+        self._draws_done()
         cs.uploaded = torch.cuda.Event(); cs.uploaded.record()
         if cs.graph is None:
             st = cs.static

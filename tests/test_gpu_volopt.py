@@ -207,3 +207,35 @@ def test_device_batches(tmp_path, monkeypatch):
     ds.change_sampling_idx(-1)
     _, full, _ = ds[0]
     assert torch.equal(full["uv"][flat.cpu()], sample["uv"][0].cpu())
+
+
+def test_overlapped_loader_draws_the_same_batches(tmp_path, monkeypatch):
+    """`VolOpt.run` prepares the next batch of the reference's DataLoader loop in a helper thread while the current step is
+    being enqueued (`_epoch_overlapped`, the default).  It must be the SAME loop: with equal seeds the view and pixel
+    sequence over several epochs, the first step's sample positions, and the final states of torch's CPU generator and of
+    Python's `random` are identical to the plain loop's (`overlap_loader=False`)."""
+    import random
+    monkeypatch.chdir(tmp_path)
+
+    def run(overlap):
+        torch.manual_seed(11); random.seed(11); np.random.seed(11)
+        v = build(make_args(), overlap_loader=overlap)
+        seen = []
+        orig = v.train_step
+
+        def spy(batch, use_mvs=False, **kw):
+            seen.append((int(batch[0][0]), batch[1]["uv"].clone(), batch[2]["rgb"].clone()))
+            out = orig(batch, use_mvs, **kw)
+            if len(seen) == 1:
+                seen.append(v.step_fn._hold[0][0]["z_vals"].detach().cpu().clone())
+            return out
+        v.train_step = spy
+        v.run(opt_stepN=11)                                   # three passes over the 5-image dataset
+        return seen, torch.get_rng_state(), random.getstate(), v.iter_step
+    a, ta, ra, na = run(True)
+    b, tb, rb, nb = run(False)
+    assert na == nb == 15 and len(a) == len(b) == 16
+    assert torch.equal(a[1], b[1])                            # step 0: same jitter / u / extras -> same sample positions
+    for x, y in zip(a[:1] + a[2:], b[:1] + b[2:]):
+        assert x[0] == y[0] and torch.equal(x[1], y[1]) and torch.equal(x[2], y[2])
+    assert torch.equal(ta, tb) and ra == rb
