@@ -210,7 +210,7 @@ class VolSDFNetwork(nn.Module):
             if n is None:       # CPU tensors (no device)
                 slot["eik_points"] = torch.empty(R, 3).uniform_(-rb, rb)
                 return ["eik_points"]
-            if "eik_points" not in slot:
+            if "eik_points" not in slot:                 # (the sampler's ring reserves it inside its packed pinned buffer)
                 slot["eik_points"] = torch.empty(R, 3).pin_memory()
             slot["eik_points"].uniform_(-rb, rb)
             return ["eik_points"]
@@ -219,7 +219,7 @@ class VolSDFNetwork(nn.Module):
 
     @staticmethod
     def slice_rng(rng, lo, hi):
-        return {k: (v if k == "perm" else v[lo:hi].contiguous()) for k, v in rng.items()}
+        return {k: (v if k == "perm" else v[lo:hi].contiguous()) for k, v in rng.items() if not k.startswith("_")}
 
     def _forward_impl(self, input, fast, keep, rng=None):
         """network.py:206-279 on the HIP kernels.  keep: dict that receives what the backward kernels need.
@@ -320,6 +320,8 @@ def pad_rng(rng, n_pad):
     stream is consumed exactly as for the unpadded batch and the caller's rays see the same draws."""
     out = {}
     for k, v in rng.items():
+        if k.startswith("_"):                  # (the packed upload buffer of ray_sampler.draw_train_rng)
+            continue
         if k == "perm" or not torch.is_tensor(v) or v.shape[0] >= n_pad:
             out[k] = v
         else:

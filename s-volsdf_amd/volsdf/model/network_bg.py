@@ -108,7 +108,7 @@ class VolSDFNetworkBG(nn.Module):
 
     @staticmethod
     def slice_rng(rng, lo, hi):
-        return {k: (v if k == "perm" else v[lo:hi].contiguous()) for k, v in rng.items()}
+        return {k: (v if k == "perm" else v[lo:hi].contiguous()) for k, v in rng.items() if not k.startswith("_")}
 
     def forward(self, input, fast=-1):
         if self.training and torch.is_grad_enabled():

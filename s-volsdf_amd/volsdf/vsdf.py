@@ -145,9 +145,10 @@ class VolOpt():
         self._dataset_class = kwargs.get('dataset_class') or utils.get_class(self.conf.get_string('train.dataset_class'))
         # opt-in: train batches drawn on the device instead of the reference's DataLoader loop (svs_hip/batches.py)
         self._device_batches = bool(kwargs.get('device_batches', os.environ.get('SVS_DEVICE_BATCHES', '0') == '1'))
-        # the reference's DataLoader loop with the next batch prepared by a helper thread while the current step is being
-        # enqueued: same batches, same random streams (_epoch_overlapped); SVS_OVERLAP_LOADER=0 restores the plain loop
-        self._overlap_loader = bool(kwargs.get('overlap_loader', os.environ.get('SVS_OVERLAP_LOADER', '1') == '1'))
+        # opt-in: the reference's DataLoader loop with the next batch prepared by a helper thread while the current step is
+        # being enqueued: same batches, same random streams (_epoch_overlapped).  What it gains depends on how much of the
+        # dataset's work releases the GIL on the host at hand (measured: 5.4 -> 4.8 ms per step on one box, nothing on another)
+        self._overlap_loader = bool(kwargs.get('overlap_loader', os.environ.get('SVS_OVERLAP_LOADER', '0') == '1'))
 
         # generate dataset
         self.data_confs = [copy.deepcopy(dataset_conf) for _ in range(3)]
@@ -277,7 +278,7 @@ class VolOpt():
         step i.  The order in which the generators are consumed is the reference's: step i's own draws (sampler jitter,
         eikonal points; made first thing in the step) -> randperm for batch i+1 -> random.randint of __getitem__ -> step
         i+1's draws ...; the helper is started by the step right after its draws and joined before the next step, so the
-        generators are never used by two threads at once.  5.4 -> 4.x ms per step end to end (tools/bench_volopt.py)."""
+        generators are never used by two threads at once.  Opt-in (`overlap_loader=True` / SVS_OVERLAP_LOADER=1)."""
         import threading
         it = iter(self.train_dataloader)
         batch = next(it, None)

@@ -211,7 +211,7 @@ def test_device_batches(tmp_path, monkeypatch):
 
 def test_overlapped_loader_draws_the_same_batches(tmp_path, monkeypatch):
     """`VolOpt.run` prepares the next batch of the reference's DataLoader loop in a helper thread while the current step is
-    being enqueued (`_epoch_overlapped`, the default).  It must be the SAME loop: with equal seeds the view and pixel
+    being enqueued (`_epoch_overlapped`, opt-in).  It must be the SAME loop: with equal seeds the view and pixel
     sequence over several epochs, the first step's sample positions, and the final states of torch's CPU generator and of
     Python's `random` are identical to the plain loop's (`overlap_loader=False`)."""
     import random
