@@ -402,28 +402,19 @@ def conv3d(x, weight, bias=None, skip=None, stride=1, transposed=False, relu=Tru
     L = _lib.load()
     if isinstance(x, SplitVolume):
         Cout = weight.shape[2]
+        rows = x.C == 16 and Cout > 8                # conv2 (channel rows); otherwise conv0 (x-pair rows, Cout <= 8)
         fused = (not transposed and stride == 1 and skip is None
-                 and (rows_supported(x.C, Cout) if (x.C == 16 and Cout > 8) else pair_supported(x.C, Cout)))
-        if not fused:
-            x = x.float()            # no fused form for this layer (or switched off): back to the float32 volume
-    if isinstance(x, SplitVolume) and x.C == 16 and weight.shape[2] > 8:      # (Cout <= 8: conv0 of stage 2, the x-pair kernel below)
-        Cout = weight.shape[2]
-        if transposed or stride != 1 or skip is not None or not rows_supported(x.C, Cout):
-            raise ValueError("a 16-channel SplitVolume feeds the stride-1 convolution with Cout <= 16 only (svs_conv3d_rows)")
-        frag = rows_weight_fragments(weight)
-        out = torch.empty((Cout, x.D, x.H, x.W), device=x.device)
-        _lib.check(L.svs_conv3d_rows(_ptr(x.buf), _ptr(frag), _ptr(bias), _ptr(out), x.C, Cout, x.D, x.H, x.W, int(relu),
-                                     _stream()), "svs_conv3d_rows")
-        return out
-    if isinstance(x, SplitVolume):
-        Cout = weight.shape[2]
-        if transposed or stride != 1 or skip is not None or not pair_supported(x.C, Cout):
-            raise ValueError("a SplitVolume feeds the stride-1 convolution with Cout <= 8 only (svs_conv3d_pair)")
-        frag = pair_weight_fragments(weight)
-        out = torch.empty((Cout, x.D, x.H, x.W), device=x.device)
-        _lib.check(L.svs_conv3d_pair(_ptr(x.buf), _ptr(frag), _ptr(bias), _ptr(out), x.C, Cout, x.D, x.H, x.W, int(relu),
-                                     _stream()), "svs_conv3d_pair")
-        return out
+                 and (rows_supported(x.C, Cout) if rows else pair_supported(x.C, Cout)))
+        if fused:
+            out = torch.empty((Cout, x.D, x.H, x.W), device=x.device)
+            if rows:
+                _lib.check(L.svs_conv3d_rows(_ptr(x.buf), _ptr(rows_weight_fragments(weight)), _ptr(bias), _ptr(out), x.C, Cout,
+                                             x.D, x.H, x.W, int(relu), _stream()), "svs_conv3d_rows")
+            else:
+                _lib.check(L.svs_conv3d_pair(_ptr(x.buf), _ptr(pair_weight_fragments(weight)), _ptr(bias), _ptr(out), x.C, Cout,
+                                             x.D, x.H, x.W, int(relu), _stream()), "svs_conv3d_pair")
+            return out
+        x = x.float()                # no fused form for this layer (or switched off): back to the float32 volume
     x = _f32(x)
     Cin, D, H, W = x.shape
     Cout = weight.shape[2]
