@@ -265,6 +265,19 @@ struct PassAEpi {
 #ifdef SVS_EXP_U_HI       // experiment: the same for the STORED u block (the in-register operand of the next layer keeps both)
       if (GP) uq[q] = (f16x8)(_Float16)0;
 #endif
+#if defined(SVS_EXP_U_FP8) || defined(SVS_EXP_A2_FP8)   // experiment: the mid piece rounded to 3 mantissa bits (what an e4m3 mid
+      {                                                  // piece would keep), traffic unchanged
+        typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+        auto q8 = [](f16x8 v) { u16x8 b = __builtin_bit_cast(u16x8, v); b = (b + (unsigned short)0x40) & (unsigned short)0xFF80;
+                                return __builtin_bit_cast(f16x8, b); };
+#ifdef SVS_EXP_U_FP8
+        if (GP) uq[q] = q8(uq[q]);
+#endif
+#ifdef SVS_EXP_A2_FP8
+        if (GP) a2q[q] = q8(a2q[q]);
+#endif
+      }
+#endif
 #if !(SVS_ABL & 2048)  // diagnostic: no u / a2 stores
       if (!LATE) { store_grad<GP>(ublk, k, lane, up[q], uq[q]); store_grad<GP>(a2blk, k, lane, a2p[q], a2q[q]); }
 #endif
