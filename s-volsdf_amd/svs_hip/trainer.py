@@ -523,6 +523,7 @@ class TrainStep:
                     stream.wait_event(fork)
                 inp = dict(model_input)
                 inp["uv"] = uv[:, lo:hi].contiguous()
+                inp["_skip_xyz"] = True              # the prior lookup below works from (cam, dirs, z): no (R,S,3) point list
                 keep = {}
                 out = m._forward_impl(inp, fast, keep, rng=m.slice_rng(rng, lo, hi))
                 if mvs is not None:

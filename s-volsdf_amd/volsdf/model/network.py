@@ -266,9 +266,12 @@ class VolSDFNetwork(nn.Module):
         if self.white_bkgd:
             acc_map = torch.sum(comp["weights"], -1)
             rgb_values = rgb_values + (1. - acc_map[..., None]) * self.bg_color.unsqueeze(0)
-        points = cam_loc.view(1, 1, 3) + z_vals.unsqueeze(2) * ray_dirs.unsqueeze(1)
         output = {'rgb_values': rgb_values, 'depth_values': comp["depth_values"], 'depth_vals': comp["depth_vals"],
-                  'weights': comp["weights"], 'xyz': points}
+                  'weights': comp["weights"]}
+        if not input.get("_skip_xyz"):
+            # (the reference hands the sample positions to cost_mapping; the fused train step looks the prior up from
+            # (cam, dirs, z) directly and skips these two launches: svs_hip/trainer.py)
+            output['xyz'] = cam_loc.view(1, 1, 3) + z_vals.unsqueeze(2) * ray_dirs.unsqueeze(1)
         if self.training:
             output['grad_theta'] = grad_theta
         else:

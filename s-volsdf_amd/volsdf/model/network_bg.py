@@ -205,7 +205,7 @@ class VolSDFNetworkBG(nn.Module):
         if keep is not None:
             keep.update(z_vals=z_vals, z_max=z_max, sdf=sdf, rgb_flat=rgb_flat, depth_scale=depth_scale, cam_loc=cam_loc,
                         ray_dirs=ray_dirs, z_bg=z_bg, bg_out0=bg_out0, bg_depth=bg_depth, comp=comp)
-        points = cam_loc.view(1, 1, 3) + z_vals.unsqueeze(2) * ray_dirs.unsqueeze(1)
+        points = None if input.get("_skip_xyz") else cam_loc.view(1, 1, 3) + z_vals.unsqueeze(2) * ray_dirs.unsqueeze(1)
         output = {'rgb_values': comp["rgb_values"], 'depth_values_all': comp["depth_values_all"],
                   'depth_values': comp["depth_values"], 'depth_vals': comp["depth_vals"], 'weights': comp["weights"],
                   'xyz': points}
