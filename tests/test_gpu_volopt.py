@@ -239,3 +239,21 @@ def test_overlapped_loader_draws_the_same_batches(tmp_path, monkeypatch):
     for x, y in zip(a[:1] + a[2:], b[:1] + b[2:]):
         assert x[0] == y[0] and torch.equal(x[1], y[1]) and torch.equal(x[2], y[2])
     assert torch.equal(ta, tb) and ra == rb
+
+
+def test_device_batches_blendedmvs_near_pose(monkeypatch):
+    """BlendedMVS batches carry the pose of a neighbouring view (`near_pose`, scene_dataset.py:239-240, through the dataset
+    module's `get_near_id`): the device batch source reproduces it."""
+    import synthetic_scene
+    from svs_hip.batches import DeviceBatches
+    monkeypatch.setattr(synthetic_scene, "get_near_id", lambda data_dir, scan_id, idx: (idx + 1) % 5, raising=False)
+    ds = synthetic_scene.SyntheticSceneDataset(data_dir="BlendedMVS", img_res=(24, 32))
+    db = DeviceBatches(ds, 96, torch.device("cuda:0"))
+    for _ in range(6):
+        ind, sample, gt = db.batch()
+        view = int(ind[0])
+        assert torch.equal(sample["near_pose"][0].cpu(), ds.pose_all[(view + 1) % 5])
+        assert sample["uv"].shape == (1, 96, 2) and gt["rgb"].shape == (1, 96, 3)
+    monkeypatch.delattr(synthetic_scene, "get_near_id")
+    with pytest.raises(NotImplementedError):
+        DeviceBatches(ds, 96, torch.device("cuda:0"))
