@@ -92,10 +92,11 @@ class SplitVolume:
         L = _lib.load()
         self.C, self.D, self.H, self.W = C, D, H, W
         self.shape = (1, C, D, H, W)
-        key = (C, D, H, W, str(device))
+        # (one buffer per shape AND stream: views processed on concurrent streams must not share it)
+        key = (C, D, H, W, str(device), torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0)
         buf = SplitVolume._cache.get(key)
         if buf is None:
-            if len(SplitVolume._cache) >= 8:
+            if len(SplitVolume._cache) >= 16:
                 SplitVolume._cache.clear()
             nbytes = L.svs_split_volume_dims(C, D, H, W, None)
             buf = SplitVolume._cache[key] = torch.zeros(nbytes // 2, dtype=torch.float16, device=device)
