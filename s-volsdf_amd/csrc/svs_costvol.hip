@@ -8,6 +8,7 @@
 // three volumes live; here every output voxel is produced once -- sum and sum of squares stay in registers and
 // only the variance is written (algorithmic bytes: write C*D*H*W*4 + read D*H*W*4 + V*C*H*W*4).
 #include "svs_common.h"
+#include <cstdlib>
 #include "svs_split_volume.h"
 
 namespace svs {
@@ -191,6 +192,140 @@ __global__ __launch_bounds__(256, 4) void warp_variance_kernel(WarpArgs a, int d
         if (xt + vx < W) a.variance[c * cs + row + vx] = tile[c * S + (vx ^ (((c >> 2) & 2) << 2))];
       }
     }
+  }
+}
+
+// ---- the split-volume producer with corner reuse along the depth axis ---------------------------------------------------
+// Neighbouring depth planes move a voxel's sampling position in the source view by a fraction of a pixel (at config 3: the four
+// bilinear corners of 3 voxels out of 4 are those of the plane before, at every stage; on DTU geometry the step is ~0.4 px at
+// stage 1 and less afterwards).  The texture path is what bounds the kernel above (TA 73 % busy), so this variant keeps a
+// voxel's corners in registers while it walks kWarpDz planes and gathers again only where the integer position has changed:
+// the depth loop is the INNER loop (passes over x outside), the corner tables of all planes of the workgroup are computed up
+// front.  Output: split volume only (direct stores; the float32 form needs a plane's whole tile at once and stays on the
+// kernel above).
+#ifndef SVS_WARP_DZ
+#define SVS_WARP_DZ 4
+#endif
+constexpr int kWarpDz = SVS_WARP_DZ;
+
+template <int C>
+__device__ __forceinline__ void warp_taps(const WarpArgs& a, int v, int x, int y, int d, f32x4& w4, i32x4& o4) {
+  const int H = a.H, W = a.W;
+  w4 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  o4 = i32x4{0, 0, 0, 0};
+  if (x >= W || d >= a.D) return;
+  const float depth = a.depth_values[((size_t)d * H + y) * W + x];
+  const float fx = (float)x, fy = (float)y;
+  const float* R = a.rot[v];
+  // rot @ [x,y,1] * depth + trans   (CasMVSNet.py:300-303); same operations, same order as warp_variance_kernel
+  const float qx = ((R[0] * fx + R[1] * fy) + R[2]) * depth + a.trans[v][0];
+  const float qy = ((R[3] * fx + R[4] * fy) + R[5]) * depth + a.trans[v][1];
+  const float qz = ((R[6] * fx + R[7] * fy) + R[8]) * depth + a.trans[v][2];
+  const float px = qx / qz, py = qy / qz;
+  const float gx = px / ((float)(W - 1) / 2.0f) - 1.0f, gy = py / ((float)(H - 1) / 2.0f) - 1.0f;
+  const float ix = ((gx + 1.0f) * (float)W - 1.0f) / 2.0f, iy = ((gy + 1.0f) * (float)H - 1.0f) / 2.0f;
+  const float x0 = __builtin_floorf(ix), y0 = __builtin_floorf(iy);
+  const float tx = ix - x0, ty = iy - y0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float xx = x0 + (float)(k & 1), yy = y0 + (float)(k >> 1);
+    if (xx >= 0.0f && xx <= (float)(W - 1) && yy >= 0.0f && yy <= (float)(H - 1)) {
+      w4[k] = ((k & 1) ? tx : 1.0f - tx) * ((k >> 1) ? ty : 1.0f - ty);
+      o4[k] = ((int)yy * W + (int)xx) * (C * 4);      // byte offset
+    }
+  }
+}
+
+// passes over x per workgroup: the corner tables (kWarpDz x NS x TW x 32 B) stay at 40 KiB for two sources (four workgroups
+// per CU): TW = 160 voxels at C = 32, 128 at C = 16 and 8
+template <int C> constexpr int reuse_passes() { return C == 32 ? 5 : (C == 16 ? 2 : 1); }
+
+template <int C, int NS>
+__global__ __launch_bounds__(256, 4) void warp_variance_reuse_kernel(WarpArgs a) {
+  constexpr int kPasses = reuse_passes<C>();
+  constexpr int LPV = C / 4, VPP = 256 / LPV, TW = kPasses * VPP;
+  __shared__ __attribute__((aligned(16))) f32x4 tapw[kWarpDz][NS][TW];
+  __shared__ __attribute__((aligned(16))) i32x4 tapo[kWarpDz][NS][TW];
+  const int tid = threadIdx.x;
+  const int cg = tid % LPV, vl = tid / LPV;
+  const int H = a.H, W = a.W, y = blockIdx.y;
+  const int xt = blockIdx.x * TW, d0 = blockIdx.z * kWarpDz;
+  const size_t HW = (size_t)H * W;
+  const float inv_nv = 1.0f / (float)(NS + 1);
+  const int Hp = splitvol::padded_h(H), Wp = splitvol::padded_w(W);
+  // ---- corner weights and offsets of all planes, one (plane, source, voxel) per thread and round
+  for (int i = tid; i < kWarpDz * NS * TW; i += 256) {
+    const int dz = i / (NS * TW), r = i - dz * (NS * TW);
+    const int v = r / TW, vx = r - v * TW;
+    f32x4 w4; i32x4 o4;
+    warp_taps<C>(a, v, xt + vx, y, d0 + dz, w4, o4);
+    tapw[dz][v][vx] = w4;
+    tapo[dz][v][vx] = o4;
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int p = 0; p < kPasses; ++p) {
+    const int vx = p * VPP + vl, x = xt + vx;
+    f32x4 ref;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ref[j] = x < W ? a.ref[(size_t)(4 * cg + j) * HW + (size_t)y * W + x] : 0.0f;
+    f32x4 f[NS][4];
+    i32x4 held[NS];
+#pragma unroll
+    for (int v = 0; v < NS; ++v) held[v] = i32x4{-1, -1, -1, -1};
+#pragma unroll
+    for (int dz = 0; dz < kWarpDz; ++dz) {
+      const int d = d0 + dz;
+      f32x4 sum = ref, sq = ref * ref;
+      f32x4 w4s[NS];
+      // all sources' (conditional) gathers are requested before the first blend
+#pragma unroll
+      for (int v = 0; v < NS; ++v) {
+        w4s[v] = tapw[dz][v][vx];
+        const i32x4 o4 = tapo[dz][v][vx];
+        const char* __restrict__ src = reinterpret_cast<const char*>(a.src_hwc[v]);
+        // (a voxel's LPV lanes take the same branch; a corner outside the image has offset 0 and weight 0)
+        if (o4[0] != held[v][0] || o4[1] != held[v][1] || o4[2] != held[v][2] || o4[3] != held[v][3]) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) f[v][k] = *reinterpret_cast<const f32x4*>(src + ((unsigned)o4[k] + 16u * cg));
+          held[v] = o4;
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < NS; ++v) {
+        f32x4 warped = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          warped = __builtin_elementwise_fma(f32x4{w4s[v][k], w4s[v][k], w4s[v][k], w4s[v][k]}, f[v][k], warped);
+        sum += warped; sq = __builtin_elementwise_fma(warped, warped, sq);
+      }
+      const f32x4 m = sum * inv_nv;
+      const f32x4 res = sq * inv_nv - m * m;
+      if (x < W && d < a.D) {
+        f16x4 h, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const _Float16 hh = (_Float16)res[j];
+          h[j] = hh;
+          lo[j] = (_Float16)(res[j] - (float)hh);
+        }
+        uint2* u = reinterpret_cast<uint2*>(a.split + splitvol::unit(d, y, 0, cg >> 1, x, C / 8, Hp, Wp)) + (cg & 1);
+        u[0] = __builtin_bit_cast(uint2, h);
+        u[(size_t)(C / 8) * Wp * 2] = __builtin_bit_cast(uint2, lo);
+      }
+    }
+  }
+}
+
+template <int C>
+static void launch_warp_reuse(const WarpArgs& a, hipStream_t s) {
+  const int tw = reuse_passes<C>() * (256 / (C / 4));
+  dim3 grid((a.W + tw - 1) / tw, a.H, (a.D + kWarpDz - 1) / kWarpDz), block(256);
+  switch (a.n_src) {
+    case 1: warp_variance_reuse_kernel<C, 1><<<grid, block, 0, s>>>(a); break;
+    case 2: warp_variance_reuse_kernel<C, 2><<<grid, block, 0, s>>>(a); break;
+    case 3: warp_variance_reuse_kernel<C, 3><<<grid, block, 0, s>>>(a); break;
+    default: warp_variance_reuse_kernel<C, 4><<<grid, block, 0, s>>>(a); break;
   }
 }
 
@@ -794,6 +929,13 @@ static int warp_variance_any(const float* ref_feature, const float* const* src_f
   }
   if (C != 8 && C != 16 && C != 32) { set_error("svs_warp_variance: C must be 8, 16 or 32 (FeatureNet outputs)"); return SVS_ESHAPE; }
   hipStream_t s = (hipStream_t)hip_stream;
+  static const char* no_reuse = getenv("SVS_WARP_REUSE_OFF");
+  if (a.split && !raw_warp && !(no_reuse && no_reuse[0] == '1')) {
+    if (C == 8) launch_warp_reuse<8>(a, s);
+    else if (C == 16) launch_warp_reuse<16>(a, s);
+    else launch_warp_reuse<32>(a, s);
+    return check_launch("svs_warp_variance_split");
+  }
   if (C == 8) launch_warp<8>(a, s);
   else if (C == 16) launch_warp<16>(a, s);
   else launch_warp<32>(a, s);
