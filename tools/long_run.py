@@ -1,8 +1,9 @@
 """Sanity run: N optimisation steps (default 2000) of the DTU model on a smooth synthetic target with the default step
-(fp16x2 kernels, single-fp16 gradient blocks, measured ray-group schedule) AND with the exact float32-MFMA kernels
-(SVS_MLP_PRECISION=f32), same seeds, same pixel batches.  The colour and eikonal losses must fall, beta must shrink, and
-the two precisions must follow the same trajectory: this is the end-to-end check that the 2e-4 ... 8e-4 gradient error of
-the fp16x2 path does not change what the optimiser does.  Prints a row every 250 steps and a
+(the process's SVS_MLP_PRECISION, default fp16x2 with float32-class gradients; measured ray-group schedule) AND with the exact
+float32-MFMA kernels (SVS_MLP_PRECISION=f32), same seeds, same pixel batches.  The colour and eikonal losses must fall,
+beta must shrink, and the two precisions must follow the same trajectory: the end-to-end check that the gradient error of the
+fp16x2 path (run with SVS_MLP_PRECISION=f16x2_half for the one-piece mode's 2e-4 ... 8e-4) does not
+change what the optimiser does.  Prints a row every 250 steps and a
 comparison at the end.      python tools/long_run.py [steps]
 """
 import os
