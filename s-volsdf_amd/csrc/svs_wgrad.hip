@@ -442,7 +442,13 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
     for (int r = 0; r < 16; ++r) {
       const int row = 32 * wave + rho(r) + 4 * half;
       const int c = a.col0 + 32 * i + col;
+#if defined(SVS_WGRAD_DIAG) && (SVS_WGRAD_DIAG & 1)   // diagnostic build: no flush (the guard keeps the accumulators alive)
+      if (c < a.ldw && acc[i][r] == 1.2345e-31f) a.dW[(size_t)row * a.ldw + c] = acc[i][r];
+#elif defined(SVS_WGRAD_DIAG) && (SVS_WGRAD_DIAG & 2) // diagnostic build: plain stores instead of atomics (wrong sums)
+      if (c < a.ldw) a.dW[(size_t)row * a.ldw + c] = acc[i][r] * inv_s;
+#else
       if (c < a.ldw) atomicAdd(&a.dW[(size_t)row * a.ldw + c], acc[i][r] * inv_s);
+#endif
     }
   }
   if (a.db) {
