@@ -152,12 +152,35 @@ __global__ __launch_bounds__(kTileThreads) void conv2d_tile_kernel(Args a) {
   for (int c0 = 0; c0 < a.Cin; c0 += a.chunk) {
     const int nc = a.Cin - c0 < a.chunk ? a.Cin - c0 : a.chunk;
     __syncthreads();                            // the previous chunk has been consumed
-    for (int i = threadIdx.x; i < nc * D::PER_CH; i += kTileThreads) {
-      const int c = i / D::PER_CH, r = i - c * D::PER_CH, ry = r / D::COLS, rx = r - ry * D::COLS;
-      const int iy = iy0 + ry, ix = ix0 + rx;
-      float v = 0.0f;
-      if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) v = a.in[(c0 + c) * plane + (size_t)iy * a.W + ix];
-      tile[i] = v;
+    // one tile row (channel, input row) per wave and pass: the row index math is wave-uniform (scalar unit), a lane only adds
+    // its column -- the element-indexed form spent as many instructions on divisions as the block spends on FMAs
+    constexpr int kXP = (D::COLS + 63) / 64, kRB = 8;      // kRB rows of a wave in flight at a time
+    const int n_rows = nc * D::ROWS;
+    for (int rb = wv; rb < n_rows; rb += 4 * kRB) {
+      float v[kRB][kXP];
+#pragma unroll
+      for (int q = 0; q < kRB; ++q) {
+        const int r = rb + 4 * q;
+        const int c = r / D::ROWS, ry = r - c * D::ROWS, iy = iy0 + ry;
+        const bool yok = r < n_rows && (unsigned)iy < (unsigned)a.H;
+        const float* __restrict__ src = a.in + (c0 + c) * plane + (size_t)(yok ? iy : 0) * a.W;
+#pragma unroll
+        for (int j = 0; j < kXP; ++j) {
+          const int rx = 64 * j + tx, ix = ix0 + rx;
+          v[q][j] = (yok && rx < D::COLS && (unsigned)ix < (unsigned)a.W) ? src[ix] : 0.0f;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < kRB; ++q) {
+        const int r = rb + 4 * q;
+        if (r < n_rows) {
+#pragma unroll
+          for (int j = 0; j < kXP; ++j) {
+            const int rx = 64 * j + tx;
+            if (64 * (j + 1) <= D::COLS || rx < D::COLS) tile[r * D::COLS + rx] = v[q][j];
+          }
+        }
+      }
     }
     __syncthreads();
     for (int c = 0; c < nc; ++c) {
@@ -221,6 +244,9 @@ int launch_tile(Args a, hipStream_t s) {
 // PY = 1 (64 x 4 tiles, ~13 KiB of LDS per block) everywhere: taller tiles lose more to the un-overlapped load phase of a
 // block than they gain in halo re-reads -- several small blocks per CU overlap each other's loads and FMAs (measured on
 // the 512 x 640 pyramid: 0.35 ms of kernel time at PY = 1, 0.37 at PY = 2 where it still gives 512 blocks, 0.58 at PY = 4).
+// Also measured and dropped: the four waves of a block sharing one output row and splitting the input channels (four
+// times the blocks for the quarter-resolution layers, partial sums added through LDS): 35 us instead of 28 for the
+// 32 -> 32 layers, slower on every layer.
 template <int K, int S>
 int launch_tiled(const Args& a, hipStream_t s) { return launch_tile<K, S, 1>(a, s); }
 
