@@ -488,6 +488,17 @@ int svs_cloud_compact(const double* pts, const uint8_t* mask, int n, int* offset
 size_t svs_cloud_mean_workspace_bytes(void);
 int svs_cloud_mean_below(const double* dist, int n, double max_dist, double* workspace, double* mean_count, void* hip_stream);
 
+/* Evaluator --mode mesh (evals/eval_dtu.py:14-23 sample_single_tri, :62-90): the points the script samples on every
+ * triangle of the predicted mesh before it proceeds as in point-cloud mode.  tri: DEVICE double[n_tri][11] =
+ * [n1, n2, v1(3), v2(3), p0(3)] per triangle of non-zero area (:70-83; integer-valued n1 = floor(l1 / thr), n2).
+ * svs_mesh_sample_count: counts[t] = number of grid entries ((i + 0.5) / max(n1, 1e-7), (j + 0.5) / max(n2, 1e-7)),
+ *   i = 0..n1, j = 0..n2, whose coordinates sum to less than 1 (:22).
+ * svs_mesh_sample_points: out[offsets[t] + m] = v1 c0 + v2 c1 + p0 (:23) for the m-th such entry in row-major order;
+ *   offsets = exclusive prefix sum of counts, out: DEVICE double[sum(counts)][3].  Each product and sum is rounded
+ *   separately, as numpy's. */
+int svs_mesh_sample_count(const double* tri, int n_tri, long long* counts, void* hip_stream);
+int svs_mesh_sample_points(const double* tri, int n_tri, const long long* offsets, double* out, void* hip_stream);
+
 /* ---- numeric-contract self tests (used by tests/test_gpu_parity.py) --------------------------------------- */
 int svs_selftest_exp(const float* x, float* y_exp, float* y_expm1, int n, void* hip_stream);
 int svs_selftest_arith(const float* a, const float* b, float* quotient, float* sqrt_abs_a, int n, void* hip_stream);

@@ -5,10 +5,41 @@ The neighbour searches of the reference live in a third-party dependency that IS
 oracle calls it exactly as evals/eval_dtu.py:104-176 does and restates the numpy steps around it.
 PINNED by tests/golden/chamfer_ref.npz: the reference script itself run end to end on a synthetic scan
 (tests/golden/make_fixtures.py::fx_chamfer; open3d's PLY reader is replaced by a numpy reader, the unseeded shuffle
-by a seeded one).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+by a seeded one); the mesh-mode sampler below by tests/golden/chamfer_mesh_ref.npz (the script run with --mode mesh,
+fx_chamfer_mesh).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 """
 import numpy as np
 import sklearn.neighbors as skln
+
+
+def sample_single_tri(n1, n2, v1, v2, tri_vert):
+    """eval_dtu.py:14-23: the grid points of one triangle."""
+    c = np.mgrid[:n1 + 1, :n2 + 1]
+    c += 0.5
+    c[0] /= max(n1, 1e-7)
+    c[1] /= max(n2, 1e-7)
+    c = np.transpose(c, (1, 2, 0))
+    k = c[c.sum(axis=-1) < 1]
+    return v1 * k[:, :1] + v2 * k[:, 1:] + tri_vert
+
+
+def sample_mesh(vertices, triangles, thresh):
+    """eval_dtu.py:65-90 -> (data_pcd = [vertices ; sampled points], points per triangle of non-zero area)."""
+    tri_vert = vertices[triangles]
+    v1 = tri_vert[:, 1] - tri_vert[:, 0]
+    v2 = tri_vert[:, 2] - tri_vert[:, 0]
+    l1 = np.linalg.norm(v1, axis=-1, keepdims=True)
+    l2 = np.linalg.norm(v2, axis=-1, keepdims=True)
+    area2 = np.linalg.norm(np.cross(v1, v2), axis=-1, keepdims=True)
+    non_zero_area = (area2 > 0)[:, 0]
+    l1, l2, area2, v1, v2, tri_vert = [arr[non_zero_area] for arr in [l1, l2, area2, v1, v2, tri_vert]]
+    thr = thresh * np.sqrt(l1 * l2 / area2)
+    n1 = np.floor(l1 / thr)
+    n2 = np.floor(l2 / thr)
+    new_pts = [sample_single_tri(n1[i, 0], n2[i, 0], v1[i:i + 1], v2[i:i + 1], tri_vert[i:i + 1, 0]) for i in range(len(n1))]
+    per_tri = np.asarray([len(q) for q in new_pts], np.int64)
+    new_pts = np.concatenate(new_pts, axis=0) if new_pts else np.zeros((0, 3))
+    return np.concatenate([vertices, new_pts], axis=0), per_tri
 
 
 def radius_downsample(data_pcd, thresh, n_jobs=-1):

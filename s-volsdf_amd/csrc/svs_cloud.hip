@@ -323,6 +323,40 @@ int build_grid(const double* pts, int n, const double* origin, double h, void* w
   return check_launch("cell grid");
 }
 
+// ---- mesh mode: points sampled on the triangles (evals/eval_dtu.py:14-23 sample_single_tri, :70-90) -----------------
+// One triangle per thread, record [n1, n2, v1(3), v2(3), p0(3)] (the per-triangle quantities of :70-83, which the caller
+// computes with numpy exactly as the script does).  The script's grid c[i][j] = ((i + 0.5) / max(n1, 1e-7),
+// (j + 0.5) / max(n2, 1e-7)), i = 0..n1, j = 0..n2, keeps the entries with c0 + c1 < 1 in row-major order and emits
+// v1 c0 + v2 c1 + p0; c1 grows with j, so the kept entries of a row are a prefix.  Every product and sum is rounded
+// separately (numpy does not contract), hence the _rn intrinsics.
+constexpr int kTriRecord = 11;
+
+template <bool WRITE>
+__global__ __launch_bounds__(256) void mesh_sample_kernel(const double* __restrict__ tri, int n_tri, long long* __restrict__ counts,
+                                                          const long long* __restrict__ offsets, double* __restrict__ out) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_tri) return;
+  const double* r = tri + (size_t)t * kTriRecord;
+  const double n1 = r[0], n2 = r[1];
+  const double d1 = fmax(n1, 1e-7), d2 = fmax(n2, 1e-7);
+  long long m = 0;
+  double* o = WRITE ? out + 3 * offsets[t] : nullptr;
+  for (double i = 0.0; i <= n1; i += 1.0) {
+    const double c0 = __ddiv_rn(__dadd_rn(i, 0.5), d1);
+    for (double j = 0.0; j <= n2; j += 1.0) {
+      const double c1 = __ddiv_rn(__dadd_rn(j, 0.5), d2);
+      if (!(__dadd_rn(c0, c1) < 1.0)) break;
+      if (WRITE) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+          o[3 * m + a] = __dadd_rn(__dadd_rn(__dmul_rn(r[2 + a], c0), __dmul_rn(r[5 + a], c1)), r[8 + a]);
+      }
+      ++m;
+    }
+  }
+  if (!WRITE) counts[t] = m;
+}
+
 }  // namespace
 
 extern "C" {
@@ -416,4 +450,19 @@ int svs_cloud_mean_below(const double* dist, int n, double max_dist, double* wor
   return check_launch("svs_cloud_mean_below");
 }
 
+int svs_mesh_sample_count(const double* tri, int n_tri, long long* counts, void* hip_stream) {
+  if (n_tri < 0 || (n_tri > 0 && (!tri || !counts))) { set_error("svs_mesh_sample_count: bad argument"); return SVS_EINVAL; }
+  if (n_tri == 0) return SVS_OK;
+  mesh_sample_kernel<false><<<(n_tri + 255) / 256, 256, 0, (hipStream_t)hip_stream>>>(tri, n_tri, counts, nullptr, nullptr);
+  return check_launch("svs_mesh_sample_count");
+}
+
+int svs_mesh_sample_points(const double* tri, int n_tri, const long long* offsets, double* out, void* hip_stream) {
+  if (n_tri < 0 || (n_tri > 0 && (!tri || !offsets || !out))) { set_error("svs_mesh_sample_points: bad argument"); return SVS_EINVAL; }
+  if (n_tri == 0) return SVS_OK;
+  mesh_sample_kernel<true><<<(n_tri + 255) / 256, 256, 0, (hipStream_t)hip_stream>>>(tri, n_tri, nullptr, offsets, out);
+  return check_launch("svs_mesh_sample_points");
+}
+
 }  // extern "C"
+

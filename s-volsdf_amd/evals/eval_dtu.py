@@ -1,4 +1,5 @@
-"""DTU Chamfer evaluation on the HIP path (reference: evals/eval_dtu.py:52-196, mode 'pcd').
+"""DTU Chamfer evaluation on the HIP path (reference: evals/eval_dtu.py:52-196, modes 'pcd' and 'mesh'; SURVEY.md
+section 8 row f4).
 
 The reference is a command-line script around sklearn's kd-tree; the protocol is exposed here as functions on arrays
 (`evaluate_scan`) and on the DTU file layout (`evaluate_scan_files`, `main`).  Every per-point step runs on the GPU
@@ -58,6 +59,44 @@ def nearest_neighbor(ref, query, max_radius, cell=None, return_index=False):
     _lib.check(L.svs_cloud_nn(_ptr(ref), nr, _ptr(query), nq, org, float(cell), float(max_radius), _ptr(ws), _ptr(dist), _ptr(idx),
                               _stream()), "svs_cloud_nn")
     return (dist, idx) if return_index else dist
+
+
+def sample_mesh(vertices, triangles, thresh):
+    """The cloud the reference's mesh mode evaluates (evals/eval_dtu.py:65-90): the vertices followed by the points of a
+    regular grid on every triangle of non-zero area, spaced so that the samples are about `thresh` apart.  The
+    per-triangle quantities are the script's numpy expressions; the points come from the library.  Returns (n,3) float64
+    on the device."""
+    L = _lib.load()
+    vertices = np.asarray(vertices, np.float64)
+    tri_vert = vertices[np.asarray(triangles)]
+    v1 = tri_vert[:, 1] - tri_vert[:, 0]
+    v2 = tri_vert[:, 2] - tri_vert[:, 0]
+    l1 = np.linalg.norm(v1, axis=-1, keepdims=True)
+    l2 = np.linalg.norm(v2, axis=-1, keepdims=True)
+    area2 = np.linalg.norm(np.cross(v1, v2), axis=-1, keepdims=True)
+    non_zero_area = (area2 > 0)[:, 0]
+    l1, l2, area2, v1, v2, tri_vert = [arr[non_zero_area] for arr in [l1, l2, area2, v1, v2, tri_vert]]
+    thr = thresh * np.sqrt(l1 * l2 / area2)
+    n1 = np.floor(l1 / thr)
+    n2 = np.floor(l2 / thr)
+    verts_d = _cloud(vertices)
+    n_tri = len(n1)
+    if n_tri == 0:
+        return verts_d
+    if not (np.isfinite(n1).all() and np.isfinite(n2).all()):
+        raise ValueError("sample_mesh: a triangle's sample counts are not finite")
+    rec = torch.from_numpy(np.ascontiguousarray(np.concatenate([n1, n2, v1, v2, tri_vert[:, 0]], 1))).to(_dev())
+    counts = torch.empty(n_tri, dtype=torch.int64, device=rec.device)
+    _lib.check(L.svs_mesh_sample_count(_ptr(rec), n_tri, _ptr(counts), _stream()), "svs_mesh_sample_count")
+    ends = torch.cumsum(counts, 0)
+    offsets = (ends - counts).contiguous()
+    total = int(ends[-1].item())
+    out = torch.empty(verts_d.shape[0] + total, 3, dtype=torch.float64, device=rec.device)
+    out[:verts_d.shape[0]] = verts_d
+    new_pts = out[verts_d.shape[0]:]
+    if total:
+        _lib.check(L.svs_mesh_sample_points(_ptr(rec), n_tri, _ptr(offsets), _ptr(new_pts), _stream()), "svs_mesh_sample_points")
+    return out
 
 
 def radius_downsample(pts, radius):
@@ -148,12 +187,18 @@ def evaluate_scan(data_pcd, stl, ObsMask, BB, Res, ground_plane, downsample_dens
     return mean_d2s, mean_s2d, over_all
 
 
-def evaluate_scan_files(scan, datadir, dataset_dir, **kw):
+def evaluate_scan_files(scan, datadir, dataset_dir, mode="pcd", **kw):
     """The reference's file layout (eval_dtu.py:59,121,139,158-161): {datadir}/mvsnet{scan:03}_l3.ply against
-    {dataset_dir}/ObsMask/ObsMask{scan}_10.mat, Plane{scan}.mat (scan 82 uses Plane83) and Points/stl/stl{scan:03}_total.ply."""
+    {dataset_dir}/ObsMask/ObsMask{scan}_10.mat, Plane{scan}.mat (scan 82 uses Plane83) and Points/stl/stl{scan:03}_total.ply.
+    mode 'mesh': the prediction is a triangle mesh, sampled at the down-sampling density first (:62-90)."""
     from scipy.io import loadmat
-    from svs_hip.fusion import read_ply_points
-    data_pcd, _ = read_ply_points(os.path.join(datadir, "mvsnet{:0>3}_l3.ply".format(scan)))
+    from svs_hip.fusion import read_ply_mesh, read_ply_points
+    pred = os.path.join(datadir, "mvsnet{:0>3}_l3.ply".format(scan))
+    if mode == "mesh":
+        vertices, triangles = read_ply_mesh(pred)
+        data_pcd = sample_mesh(vertices, triangles, kw.get("downsample_density", 0.2)).cpu().numpy()
+    else:
+        data_pcd, _ = read_ply_points(pred)
     obs = loadmat(f"{dataset_dir}/ObsMask/ObsMask{scan}_10.mat")
     stl, _ = read_ply_points(f"{dataset_dir}/Points/stl/stl{scan:03}_total.ply")
     plane = loadmat(f"{dataset_dir}/ObsMask/Plane{83 if scan == 82 else scan}.mat")["P"]
@@ -170,8 +215,6 @@ def main(argv=None):
     parser.add_argument('--patch_size', type=float, default=60)
     parser.add_argument('--max_dist', type=float, default=20)
     args = parser.parse_args(argv)
-    if args.mode == 'mesh':
-        raise NotImplementedError("mesh mode (triangle sampling, eval_dtu.py:65-93) is not part of the hot path")
     dataset_dir = os.path.join(args.data_dir_root, 'DTU', 'DTU_MVS_Data')
     scans = [21, 34, 38, 82, 24, 37, 40, 106, 110, 114, 118]
     if args.scan in scans:
@@ -180,7 +223,7 @@ def main(argv=None):
     print("ply_name, accuracy(mm), completeness(mm), overall(mm)")
     for scan in scans:
         try:
-            r = evaluate_scan_files(scan, args.datadir, dataset_dir, downsample_density=args.downsample_density,
+            r = evaluate_scan_files(scan, args.datadir, dataset_dir, mode=args.mode, downsample_density=args.downsample_density,
                                     patch_size=args.patch_size, max_dist=args.max_dist)
         except (OSError, ValueError):
             r = (10000., 10000., 10000.)                      # the reference's fallback row (:163-167)

@@ -149,6 +149,67 @@ def read_ply_points(filename):
     return pts, rgb
 
 
+def read_ply_mesh(filename):
+    """(vertices (n,3) float64, triangles (m,3) int64) of an ascii / binary PLY with a face element -- what the Chamfer
+    evaluator's mesh mode takes from open3d.io.read_triangle_mesh (evals/eval_dtu.py:65-68).  Faces with more than three
+    corners are fanned around their first corner, as open3d's reader does."""
+    with open(filename, "rb") as f:
+        if f.readline().strip() != b"ply":
+            raise ValueError("not a PLY file")
+        fmt, elements = None, []                       # [name, count, [(property name, type) or (name, count type, item type)]]
+        while True:
+            line = f.readline()
+            if not line:
+                raise ValueError("PLY header without end_header")
+            tok = line.decode("ascii").split()
+            if not tok or tok[0] == "comment":
+                continue
+            if tok[0] == "format":
+                fmt = tok[1]
+            elif tok[0] == "element":
+                elements.append([tok[1], int(tok[2]), []])
+            elif tok[0] == "property":
+                elements[-1][2].append((tok[4], _PLY_TYPES[tok[2]], _PLY_TYPES[tok[3]]) if tok[1] == "list"
+                                       else (tok[2], _PLY_TYPES[tok[1]]))
+            elif tok[0] == "end_header":
+                break
+        order = "<" if fmt == "binary_little_endian" else ">"
+        vertices, faces = None, []
+        for name, n, props in elements:
+            has_list = any(len(q) == 3 for q in props)
+            if not has_list:
+                if fmt == "ascii":
+                    rows = np.loadtxt(f, max_rows=n, ndmin=2) if n else np.zeros((0, len(props)))
+                    cols = {q[0]: rows[:, i] for i, q in enumerate(props)}
+                else:
+                    rec = np.fromfile(f, dtype=[(q[0], order + q[1]) for q in props], count=n)
+                    cols = {q[0]: rec[q[0]] for q in props}
+                if name == "vertex":
+                    vertices = np.stack([np.asarray(cols[k], np.float64) for k in "xyz"], 1)
+                continue
+            for _ in range(n):                           # elements with list properties: record by record
+                if fmt == "ascii":
+                    tok = f.readline().split()
+                    at = 0
+                for q in props:
+                    if len(q) == 2:
+                        if fmt == "ascii":
+                            at += 1
+                        else:
+                            f.read(np.dtype(q[1]).itemsize)
+                        continue
+                    if fmt == "ascii":
+                        k = int(tok[at]); items = [int(float(v)) for v in tok[at + 1:at + 1 + k]]; at += 1 + k
+                    else:
+                        k = int(np.frombuffer(f.read(np.dtype(q[1]).itemsize), order + q[1])[0])
+                        items = np.frombuffer(f.read(k * np.dtype(q[2]).itemsize), order + q[2]).astype(np.int64).tolist()
+                    if name == "face" and q[0] in ("vertex_indices", "vertex_index"):
+                        faces.extend((items[0], items[i], items[i + 1]) for i in range(1, k - 1))
+    if vertices is None:
+        raise ValueError("PLY file without a vertex element")
+    return vertices, np.asarray(faces, np.int64).reshape(-1, 3)
+
+
 def filter_depth(views, pairs, conf=0.0, filter_dist=1, filter_diff=0.01, thres_view=1, plyfilename=None, eval_masks=None,
                  mask_dir=None):
     """filter_depth (runner.py:301-401) on in-memory views.  views: {view_id: dict(K, E, img, depth, confidence)},

@@ -711,6 +711,79 @@ def fx_chamfer():
                                                             len(g["data_in_obs"])))
 
 
+def fx_chamfer_mesh():
+    """The reference's evaluation script in --mode mesh (evals/eval_dtu.py:62-90 and on), run as __main__ through runpy
+    on the synthetic scan of fx_chamfer with a predicted triangle mesh.  Substitutions, none in the algorithm: the open3d
+    stub's read_triangle_mesh / read_point_cloud parse the PLYs written below with numpy; multiprocessing.Pool is a
+    serial map (the script's worker function lives in the runpy module, which a forked worker cannot import); the
+    unseeded np.random.default_rng() is seeded."""
+    import multiprocessing
+    import runpy
+    import tempfile
+    import types
+    from scipy.io import savemat
+    scan = 24
+    sc = synth.make_dtu_scan(31)
+    vertices, triangles = synth.make_dtu_mesh(53)
+
+    def write_ply(fn, pts):
+        with open(fn, "wb") as f:
+            f.write(("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty double x\nproperty double y\n"
+                     "property double z\nend_header\n" % len(pts)).encode())
+            np.ascontiguousarray(pts, "<f8").tofile(f)
+
+    def read_point_cloud(fn):
+        with open(fn, "rb") as f:
+            while f.readline().strip() != b"end_header":
+                pass
+            pts = np.fromfile(f, "<f8").reshape(-1, 3)
+        return types.SimpleNamespace(points=pts)
+
+    class SerialPool:
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def map(self, fn, it, chunksize=None):
+            return [fn(x) for x in it]
+
+    o3d = types.ModuleType("open3d")
+    o3d.io = types.SimpleNamespace(read_point_cloud=read_point_cloud,
+                                   read_triangle_mesh=lambda fn: types.SimpleNamespace(vertices=vertices.copy(), triangles=triangles.copy()))
+    sys.modules["open3d"] = o3d
+    real_rng, real_pool = np.random.default_rng, multiprocessing.Pool
+    with tempfile.TemporaryDirectory() as td:
+        ds = os.path.join(td, "root", "DTU", "DTU_MVS_Data")
+        os.makedirs(os.path.join(ds, "ObsMask")); os.makedirs(os.path.join(ds, "Points", "stl")); os.makedirs(os.path.join(td, "pred"))
+        savemat(os.path.join(ds, "ObsMask", f"ObsMask{scan}_10.mat"), dict(ObsMask=sc["ObsMask"], BB=sc["BB"], Res=sc["Res"]))
+        savemat(os.path.join(ds, "ObsMask", f"Plane{scan}.mat"), dict(P=sc["P"]))
+        write_ply(os.path.join(ds, "Points", "stl", f"stl{scan:03}_total.ply"), sc["stl"])
+        argv = sys.argv
+        sys.argv = ["eval_dtu.py", "--data_dir_root", os.path.join(td, "root"), "--datadir", os.path.join(td, "pred"), "--scan", str(scan),
+                    "--mode", "mesh"]
+        np.random.default_rng = lambda *a: real_rng(*a) if a else real_rng(78)
+        multiprocessing.Pool = SerialPool
+        try:
+            g = runpy.run_path(os.path.join(ref_shim.REFERENCE_ROOT, "evals", "eval_dtu.py"), run_name="__main__")
+        finally:
+            np.random.default_rng = real_rng
+            multiprocessing.Pool = real_pool
+            sys.argv = argv
+    new_pts = g["new_pts"]
+    save("chamfer_mesh_ref", scan_seed=np.asarray(31), mesh_seed=np.asarray(53), shuffle_seed=np.asarray(78),
+         n_new_pts=np.asarray(len(new_pts)), per_tri=np.asarray([len(q) for q in g["mp_pool"].map(g["sample_single_tri"], (
+             (g["n1"][i, 0], g["n2"][i, 0], g["v1"][i:i + 1], g["v2"][i:i + 1], g["tri_vert"][i:i + 1, 0]) for i in range(len(g["n1"]))))], np.int32),
+         new_pts_every_61=new_pts[::61], new_pts_sum=new_pts.sum(0), data_pcd_shuffled_head=g["data_pcd"][:64],
+         keep=np.packbits(g["mask"]), n_down=np.asarray(len(g["data_down"])), n_in=np.asarray(len(g["data_in"])),
+         n_in_obs=np.asarray(len(g["data_in_obs"])), n_stl_above=np.asarray(len(g["stl_above"])),
+         dist_d2s=g["dist_d2s"][:, 0], dist_s2d=g["dist_s2d"][:, 0], mean_d2s=np.asarray(g["mean_d2s"]),
+         mean_s2d=np.asarray(g["mean_s2d"]), over_all=np.asarray(g["over_all"]))
+    print("   mesh: %d triangles (%d with area), %d sampled points; acc %.4f comp %.4f, kept %d of %d" % (
+        len(triangles), len(g["n1"]), len(new_pts), g["mean_d2s"], g["mean_s2d"], len(g["data_down"]), len(g["data_pcd"])))
+
+
 def fx_featurenet():
     """FeatureNet (arch_mode 'fpn', base 8) of the reference on a 3 x 36 x 52 image (sizes that are multiples of 4 but
     not of 8, so that the strided 5x5 layers see odd intermediate sizes): the three pyramid outputs."""
@@ -725,7 +798,7 @@ def fx_featurenet():
     save("featurenet", seed=np.asarray(41), img=img, **{k: v[0].numpy() for k, v in out.items()})
 
 
-ALL = dict(fusion=fx_fusion, pfm=fx_pfm, chamfer=fx_chamfer, featurenet=fx_featurenet, rays=fx_rays, sdf_mlp=fx_sdf_mlp, rgb_mlp=fx_rgb_mlp, density=fx_density, sampler=fx_sampler,
+ALL = dict(fusion=fx_fusion, pfm=fx_pfm, chamfer=fx_chamfer, chamfer_mesh=fx_chamfer_mesh, featurenet=fx_featurenet, rays=fx_rays, sdf_mlp=fx_sdf_mlp, rgb_mlp=fx_rgb_mlp, density=fx_density, sampler=fx_sampler,
            composite=fx_composite, forward=fx_forward, forward_bg=fx_forward_bg, cost_mapping=fx_cost_mapping, loss=fx_loss, casmvs=fx_casmvs, train_step=fx_train_step, train_step_r32=lambda: fx_train_step(32, 2, "train_step_r32"),
            sdf_mlp_w1=lambda: fx_sdf_mlp("w1"), forward_w1=fx_forward_w1,
            train_step_w1=lambda: fx_train_step(16, 2, "train_step_w1", "w1"),

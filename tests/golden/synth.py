@@ -419,6 +419,30 @@ def make_dtu_scan(seed, n_pred=12000, n_stl=10000):
     return dict(data_pcd=data_pcd, stl=stl, ObsMask=ObsMask, BB=BB, Res=Res, P=P)
 
 
+def make_dtu_mesh(seed, rows=9, cols=13):
+    """Synthetic predicted MESH for the evaluator's mesh mode (evals/eval_dtu.py:62-90), in the frame of make_dtu_scan: a
+    (rows x cols)-cell patch of the bumpy sphere's upper side with jittered vertices, two triangles per cell with
+    alternating diagonals, plus three degenerate triangles (a repeated corner twice, three equal corners once) that the
+    script's area test has to drop.  Returns (vertices (n,3) float64, triangles (m,3) int64)."""
+    rng = np.random.default_rng(seed)
+    c = np.array([5.0, -3.0, 2.0])
+    th = np.linspace(0.35, 1.15, rows + 1)[:, None] + rng.normal(0, 0.004, (rows + 1, cols + 1))      # polar angle
+    ph = np.linspace(-0.6, 0.7, cols + 1)[None, :] + rng.normal(0, 0.004, (rows + 1, cols + 1))
+    d = np.stack([np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), np.cos(th)], -1).reshape(-1, 3)
+    r = 40.0 + 1.5 * np.sin(5 * d[:, :1]) * np.cos(4 * d[:, 1:2]) + rng.normal(0, 0.15, (len(d), 1))
+    vertices = c + r * d
+    idx = np.arange((rows + 1) * (cols + 1)).reshape(rows + 1, cols + 1)
+    tris = []
+    for i in range(rows):
+        for j in range(cols):
+            a, b, e, f = idx[i, j], idx[i, j + 1], idx[i + 1, j], idx[i + 1, j + 1]
+            tris += [(a, b, f), (a, f, e)] if (i + j) % 2 == 0 else [(a, b, e), (b, f, e)]
+    tris.insert(7, (idx[0, 0], idx[0, 0], idx[1, 1]))
+    tris.insert(40, (idx[2, 3], idx[3, 3], idx[2, 3]))
+    tris.append((idx[4, 4], idx[4, 4], idx[4, 4]))
+    return vertices, np.asarray(tris, np.int64)
+
+
 def make_featurenet_params(seed, base=8):
     """State-dict-named float32 arrays of FeatureNet, arch_mode 'fpn' (models/CasMVSNet.py:338-399), BN in eval form."""
     rng = np.random.default_rng(seed)

@@ -38,6 +38,72 @@ def test_evaluate_scan_matches_reference_script(dev, golden_dir):
     np.testing.assert_allclose([acc, comp, overall], [float(g["mean_d2s"]), float(g["mean_s2d"]), float(g["over_all"])], rtol=1e-12)
 
 
+def test_mesh_mode_matches_reference_script(dev, golden_dir, tmp_path):
+    """--mode mesh end to end: the sampled cloud is the script's point for point (fixture chamfer_mesh_ref.npz), and so are
+    the protocol's results on it; once on arrays, once through the file layout and the command line."""
+    from evals import eval_dtu
+    from scipy.io import savemat
+    g = dict(np.load(os.path.join(golden_dir, "chamfer_mesh_ref.npz")))
+    sc = synth.make_dtu_scan(int(g["scan_seed"]))
+    vertices, triangles = synth.make_dtu_mesh(int(g["mesh_seed"]))
+    cloud = eval_dtu.sample_mesh(vertices, triangles, 0.2).cpu().numpy()
+    want, per_tri = corc.sample_mesh(vertices, triangles, 0.2)
+    np.testing.assert_array_equal(cloud, want)                                   # HIP == oracle, bit for bit
+    new_pts = cloud[len(vertices):]
+    assert len(new_pts) == int(g["n_new_pts"]) == int(per_tri.sum())
+    np.testing.assert_array_equal(new_pts[::61], g["new_pts_every_61"])          # == the reference script's points
+    np.testing.assert_array_equal(new_pts.sum(0), g["new_pts_sum"])
+    (acc, comp, overall), d = eval_dtu.evaluate_scan(cloud, sc["stl"], sc["ObsMask"], sc["BB"], sc["Res"], sc["P"],
+                                                     shuffle_rng=np.random.default_rng(int(g["shuffle_seed"])), details=True)
+    np.testing.assert_array_equal(d["data_pcd"][:64], g["data_pcd_shuffled_head"])
+    assert np.array_equal(d["keep"].cpu().numpy(), np.unpackbits(g["keep"])[:len(cloud)].astype(bool))
+    assert (len(d["data_down"]), len(d["data_in"]), len(d["data_in_obs"]), len(d["stl_above"])) == \
+        (int(g["n_down"]), int(g["n_in"]), int(g["n_in_obs"]), int(g["n_stl_above"]))
+    for k in ("dist_d2s", "dist_s2d"):
+        got, ref = d[k].cpu().numpy(), g[k]
+        near = ref < 20
+        np.testing.assert_array_equal(got[near], ref[near])
+        assert (got[~near] >= 20).all()
+    np.testing.assert_allclose([acc, comp, overall], [float(g["mean_d2s"]), float(g["mean_s2d"]), float(g["over_all"])], rtol=1e-12)
+
+    # the file layout of the script (mesh PLY with float64 vertices, so that nothing is lost on the way)
+    scan = 24
+    ds = tmp_path / "root" / "DTU" / "DTU_MVS_Data"
+    (ds / "ObsMask").mkdir(parents=True); (ds / "Points" / "stl").mkdir(parents=True); (tmp_path / "pred").mkdir()
+    savemat(str(ds / "ObsMask" / f"ObsMask{scan}_10.mat"), dict(ObsMask=sc["ObsMask"], BB=sc["BB"], Res=sc["Res"]))
+    savemat(str(ds / "ObsMask" / f"Plane{scan}.mat"), dict(P=sc["P"]))
+    with open(ds / "Points" / "stl" / f"stl{scan:03}_total.ply", "wb") as f:
+        f.write(("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty double x\nproperty double y\n"
+                 "property double z\nend_header\n" % len(sc["stl"])).encode())
+        np.ascontiguousarray(sc["stl"], "<f8").tofile(f)
+    with open(tmp_path / "pred" / f"mvsnet{scan:03}_l3.ply", "wb") as f:
+        f.write(("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty double x\nproperty double y\nproperty double z\n"
+                 "element face %d\nproperty list uchar int vertex_indices\nend_header\n" % (len(vertices), len(triangles))).encode())
+        np.ascontiguousarray(vertices, "<f8").tofile(f)
+        for t in triangles:
+            f.write(b"\x03" + np.asarray(t, "<i4").tobytes())
+    res = eval_dtu.main(["--data_dir_root", str(tmp_path / "root"), "--datadir", str(tmp_path / "pred"), "--scan", str(scan), "--mode", "mesh"])
+    # the command line shuffles with an unseeded generator like the script: the means move in the last digits only
+    np.testing.assert_allclose(res, [float(g["mean_d2s"]), float(g["mean_s2d"]), float(g["over_all"])], rtol=0.02)
+
+
+@pytest.mark.parametrize("seed,n_tri,thresh", [(0, 300, 0.2), (1, 5000, 0.05), (2, 40, 1.0)])
+def test_mesh_sampler_vs_oracle(dev, seed, n_tri, thresh):
+    """Random triangle soups (slivers, tiny and large triangles, some with no sample at all) against the oracle's
+    restatement of sample_single_tri: same points, same order, bit for bit."""
+    from evals import eval_dtu
+    rng = np.random.default_rng(seed)
+    vertices = rng.normal(0, 1, (n_tri + 2, 3)) * rng.choice([0.05, 0.5, 3.0], (n_tri + 2, 1))
+    triangles = np.stack([rng.integers(0, len(vertices), n_tri) for _ in range(3)], 1)
+    triangles[::17, 1] = triangles[::17, 0]                                     # degenerate ones in between
+    want, per_tri = corc.sample_mesh(vertices, triangles, thresh)
+    got = eval_dtu.sample_mesh(vertices, triangles, thresh).cpu().numpy()
+    assert (per_tri == 0).any() and per_tri.max() > 5
+    np.testing.assert_array_equal(got, want)
+    # no triangle at all: the vertices alone
+    np.testing.assert_array_equal(eval_dtu.sample_mesh(vertices, np.zeros((0, 3), np.int64), thresh).cpu().numpy(), vertices)
+
+
 @pytest.mark.parametrize("n_ref,n_q,seed", [(5000, 3000, 0), (1, 17, 1), (257, 1, 2), (20000, 20000, 3)])
 def test_nearest_neighbor_vs_sklearn(dev, n_ref, n_q, seed):
     from evals import eval_dtu
