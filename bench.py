@@ -394,7 +394,8 @@ def gpu_torch_baseline(ts, params, gt, R, dev, our_ms, reps=5, warm=2):
     """The reference's train step in plain PyTorch float32 on the SAME GPU (oracle/torch_ref.py), eager mode:
     the error-bounded sampler under no_grad (ray_sampler.py:67-219 at fast = 1: the SDF network on 128 points per ray, the
     beta search, inverse-CDF sampling, extras, sort; fresh draws every step), then the SDF and radiance MLPs with the double
-    backward through the normals, compositing, loss, loss.backward(), clip_grad_norm_, Adam.step (volsdf/vsdf.py:196-219 with
+    backward through the normals, compositing, loss, loss.backward(), clip_grad_norm_, the per-parameter NaN / Inf test
+    (on_after_backward, vsdf.py:454-464), Adam.step, get_psnr (volsdf/vsdf.py:196-222 with
     network.py:206-279) at the rays, eikonal points and prior look-up results of this process's last step.  NOT included:
     cost_mapping (the MVS prior look-up, vsdf.py:382-452; its results are taken from our step) -- the baseline does a
     little less work than the reference would, so the ratio is a lower bound.  Checker-side code, outside the timed region."""
@@ -418,7 +419,7 @@ def gpu_torch_baseline(ts, params, gt, R, dev, our_ms, reps=5, warm=2):
         sdf = tref.sdf_mlp(p, x)[:, 0]
         return torch.minimum(sdf, 20.0 * (3.0 - x.norm(2, 1)))          # get_sdf_vals, network.py:125-131
 
-    def one(sampler=True):
+    def one(sampler=True, guard=True):
         opt.zero_grad(set_to_none=True)
         if sampler:
             with torch.no_grad():
@@ -432,7 +433,20 @@ def gpu_torch_baseline(ts, params, gt, R, dev, our_ms, reps=5, warm=2):
         out["pj"], out["pi"] = pj, pi
         tref.loss_fn(out, rgb, rgbs, 50).backward()
         torch.nn.utils.clip_grad_norm_(list(p.values()), 1.0)
+        if guard:
+            # on_after_backward (vsdf.py:454-464): a NaN / Inf test per parameter tensor, each a host synchronisation
+            valid = True
+            for q in p.values():
+                if q.grad is not None:
+                    valid = not (torch.isnan(q.grad).any() or torch.isinf(q.grad).any())
+                    if not valid:
+                        break
+            if not valid:
+                opt.zero_grad()
         opt.step()
+        if guard:
+            mse = torch.mean((out["rgb_values"] - rgb) ** 2)                   # get_psnr, vsdf.py:221 / rend_util.py:14-22
+            return -10. * torch.log(mse) / torch.log(torch.tensor([10.], device=dev))
 
     z_ours = cat([k["z_vals"] for k in keeps])
 
@@ -448,12 +462,14 @@ def gpu_torch_baseline(ts, params, gt, R, dev, our_ms, reps=5, warm=2):
             ts_.append(time.perf_counter() - t0)
         return float(np.median(ts_))
     med = timed(sampler=True)
-    med_nosampler = timed(sampler=False)
+    med_noguard = timed(sampler=True, guard=False)
+    med_nosampler = timed(sampler=False, guard=False)
     return {"value": R / med, "unit": "rays/s", "ms_per_step": 1e3 * med, "rays": R, "kind": "port",
             "what": "oracle/torch_ref.py on cuda:0, torch float32 eager: error-bounded sampler (fast = 1, under no_grad) + "
                     "forward (SDF MLP + d sdf/dx via autograd, radiance MLP, compositing) + loss + backward (incl. the double "
-                    "backward) + clip_grad_norm_ + Adam; the MVS prior look-up (cost_mapping) is NOT included (a lower bound "
-                    "of the reference's step)",
+                    "backward) + clip_grad_norm_ + the per-parameter NaN / Inf test of on_after_backward + Adam + get_psnr; "
+                    "the MVS prior look-up (cost_mapping) is NOT included (a lower bound of the reference's step)",
+            "ms_per_step_without_nan_test_and_psnr": 1e3 * med_noguard,
             "ms_per_step_without_sampler": 1e3 * med_nosampler,
             "median_of": reps, "warmups": warm, "ratio_value_over_baseline": (1e3 * med) / our_ms,
             "torch": torch.__version__}
