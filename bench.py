@@ -256,7 +256,7 @@ def main():
             "roofline": roofline,
         }
         if train and world == 1 and not args.no_gpu_torch and args.model == "dtu":
-            line["gpu_torch_baseline"] = gpu_torch_baseline(ts, params, gt, R, dev, 1e3 * dt / args.steps)
+            line["gpu_torch_baseline"] = gpu_torch_baseline(ts, params, gt, R, dev, 1e3 * dt / args.steps, mvs)
         if train and h2 and world == 1 and args.model == "dtu" and not args.no_kernel_timing and not args.no_exact_f32:
             if ops.default_precision() == ops.F16X2:
                 fg = other_precision_step_ms("f16x2_half", make_model, make_step, n=40, warm=60)
@@ -390,15 +390,15 @@ def precision_note(precision):
             ops.F32: "float32 MFMA"}[precision]
 
 
-def gpu_torch_baseline(ts, params, gt, R, dev, our_ms, reps=5, warm=2):
+def gpu_torch_baseline(ts, params, gt, R, dev, our_ms, mvs, reps=5, warm=2):
     """The reference's train step in plain PyTorch float32 on the SAME GPU (oracle/torch_ref.py), eager mode:
     the error-bounded sampler under no_grad (ray_sampler.py:67-219 at fast = 1: the SDF network on 128 points per ray, the
     beta search, inverse-CDF sampling, extras, sort; fresh draws every step), then the SDF and radiance MLPs with the double
     backward through the normals, compositing, loss, loss.backward(), clip_grad_norm_, the per-parameter NaN / Inf test
     (on_after_backward, vsdf.py:454-464), Adam.step, get_psnr (volsdf/vsdf.py:196-222 with
-    network.py:206-279) at the rays, eikonal points and prior look-up results of this process's last step.  NOT included:
-    cost_mapping (the MVS prior look-up, vsdf.py:382-452; its results are taken from our step) -- the baseline does a
-    little less work than the reference would, so the ratio is a lower bound.  Checker-side code, outside the timed region."""
+    network.py:206-279) and cost_mapping (the MVS prior look-up, vsdf.py:382-452, torch_ref.cost_mapping) at the rays and
+    eikonal points of this process's last step.  Not included: the reference's host-side work per step (five draws from the
+    CPU generator and their upload, the dataset's randperm).  Checker-side code, outside the timed region."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import torch
@@ -419,7 +419,7 @@ def gpu_torch_baseline(ts, params, gt, R, dev, our_ms, reps=5, warm=2):
         sdf = tref.sdf_mlp(p, x)[:, 0]
         return torch.minimum(sdf, 20.0 * (3.0 - x.norm(2, 1)))          # get_sdf_vals, network.py:125-131
 
-    def one(sampler=True, guard=True):
+    def one(sampler=True, guard=True, lookup=True):
         opt.zero_grad(set_to_none=True)
         if sampler:
             with torch.no_grad():
@@ -430,7 +430,11 @@ def gpu_torch_baseline(ts, params, gt, R, dev, our_ms, reps=5, warm=2):
         else:
             z = z_ours
         out = tref.forward_differentiable(p, cam, dirs, z, eik, ds, device=dev)
-        out["pj"], out["pi"] = pj, pi
+        if lookup:
+            xyz = cam.view(1, 1, 3) + z.unsqueeze(-1) * dirs.unsqueeze(1)
+            out["pj"], out["pi"], _ = tref.cost_mapping(xyz, mvs["same_view"], mvs["views"], mvs["img_res"], mvs["inverse_depth"])
+        else:
+            out["pj"], out["pi"] = pj, pi
         tref.loss_fn(out, rgb, rgbs, 50).backward()
         torch.nn.utils.clip_grad_norm_(list(p.values()), 1.0)
         if guard:
@@ -449,6 +453,13 @@ def gpu_torch_baseline(ts, params, gt, R, dev, our_ms, reps=5, warm=2):
             return -10. * torch.log(mse) / torch.log(torch.tensor([10.], device=dev))
 
     z_ours = cat([k["z_vals"] for k in keeps])
+    # the torch look-up at our samples gives our kernel's values (the comparator does the same work on the same data)
+    with torch.no_grad():
+        tj, ti, _ = tref.cost_mapping(cam.view(1, 1, 3) + z_ours.unsqueeze(-1) * dirs.unsqueeze(1), mvs["same_view"], mvs["views"],
+                                      mvs["img_res"], mvs["inverse_depth"])
+    lookup_err = max(float((tj - pj).abs().max()), float((ti - pi).abs().max()))
+    if not lookup_err < 1e-4:
+        raise AssertionError("comparator's prior look-up differs from the step's: %g" % lookup_err)
 
     def timed(**kw):
         for _ in range(warm):
@@ -463,13 +474,16 @@ def gpu_torch_baseline(ts, params, gt, R, dev, our_ms, reps=5, warm=2):
         return float(np.median(ts_))
     med = timed(sampler=True)
     med_noguard = timed(sampler=True, guard=False)
-    med_nosampler = timed(sampler=False, guard=False)
+    med_nolookup = timed(sampler=True, guard=False, lookup=False)
+    med_nosampler = timed(sampler=False, guard=False, lookup=False)
     return {"value": R / med, "unit": "rays/s", "ms_per_step": 1e3 * med, "rays": R, "kind": "port",
             "what": "oracle/torch_ref.py on cuda:0, torch float32 eager: error-bounded sampler (fast = 1, under no_grad) + "
                     "forward (SDF MLP + d sdf/dx via autograd, radiance MLP, compositing) + loss + backward (incl. the double "
-                    "backward) + clip_grad_norm_ + the per-parameter NaN / Inf test of on_after_backward + Adam + get_psnr; "
-                    "the MVS prior look-up (cost_mapping) is NOT included (a lower bound of the reference's step)",
+                    "backward) + the MVS prior look-up (cost_mapping) + clip_grad_norm_ + the per-parameter NaN / Inf test of "
+                    "on_after_backward + Adam + get_psnr",
             "ms_per_step_without_nan_test_and_psnr": 1e3 * med_noguard,
+            "ms_per_step_without_those_and_prior_lookup": 1e3 * med_nolookup,
+            "prior_lookup_max_abs_diff_vs_step": lookup_err,
             "ms_per_step_without_sampler": 1e3 * med_nosampler,
             "median_of": reps, "warmups": warm, "ratio_value_over_baseline": (1e3 * med) / our_ms,
             "torch": torch.__version__}

@@ -407,6 +407,22 @@ def test_cost_mapping(golden_dir, name):
     np.testing.assert_allclose(pi, g["pi"], atol=2e-6)
 
 
+@pytest.mark.parametrize("name", ["cost_mapping_inv0_v0", "cost_mapping_inv0_v2", "cost_mapping_inv1_v0",
+                                  "cost_mapping_inv1_v2"])
+def test_torch_cost_mapping_vs_reference(golden_dir, name):
+    """oracle/torch_ref.cost_mapping (the prior look-up of bench.py's same-GPU comparator) against the reference's own
+    outputs, same fixtures and bars as the numpy restatement."""
+    import torch
+    import torch_ref as tref
+    g = load(golden_dir, name)
+    views = synth.make_mvs_views(int(g["seed"]))
+    pj, pi, valid = tref.cost_mapping(torch.from_numpy(g["xyz"].astype(F32)), int(g["view_index"]), views, (576, 768),
+                                      bool(g["inverse_depth"]))
+    assert np.array_equal(valid.numpy(), g["valid"])
+    np.testing.assert_allclose(pj.numpy(), g["pj"], atol=2e-6)
+    np.testing.assert_allclose(pi.numpy(), g["pi"], atol=2e-6)
+
+
 def test_loss(golden_dir):
     g = load(golden_dir, "loss")
     out = {k: g[k] for k in ("rgb_values", "grad_theta", "weights", "pi", "pj", "depth_values")}
