@@ -397,8 +397,9 @@ def gpu_torch_baseline(ts, params, gt, R, dev, our_ms, mvs, reps=5, warm=2):
     backward through the normals, compositing, loss, loss.backward(), clip_grad_norm_, the per-parameter NaN / Inf test
     (on_after_backward, vsdf.py:454-464), Adam.step, get_psnr (volsdf/vsdf.py:196-222 with
     network.py:206-279) and cost_mapping (the MVS prior look-up, vsdf.py:382-452, torch_ref.cost_mapping) at the rays and
-    eikonal points of this process's last step.  Not included: the reference's host-side work per step (five draws from the
-    CPU generator and their upload, the dataset's randperm).  Checker-side code, outside the timed region."""
+    eikonal points of this process's last step.  The draws are made on the device here (the reference, and the timed step of
+    this bench, draw from the CPU generator and upload); the dataset's randperm is outside both.  Checker-side code, outside
+    the timed region."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import torch
