@@ -450,7 +450,7 @@ def cost_lookup(views, same_view, img_res, *, xyz=None, cam=None, dirs=None, z=N
                                  int(bool(inverse_depth)), float(img_res[1]), float(img_res[0]), vp,
                                  _ptr_array(cost_p), _ptr_array(near_p), _ptr_array(far_p), dims, _ptr(pj), _ptr(pi),
                                  _ptr(valid), _ptr(same_view_dev), _stream()), "svs_cost_lookup")
-    return pj, pi, valid.bool()
+    return pj, pi, valid.view(torch.bool)              # the kernel writes 0 / 1: reinterpreted, not converted
 
 
 def loss_fwd_bwd(rgb_values, rgb_target, weights, depth_values, grad_theta=None, pi=None, pj=None, *, rgb_weight=1.0,
