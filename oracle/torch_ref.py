@@ -296,11 +296,11 @@ def error_bound_sampler_train(sdf_fn, cam, dirs, beta0, rng, *, near=1e-4, radiu
 
 
 def cost_mapping(xyz, view_index, views, img_res, inverse_depth=False):
-    """VolOpt.cost_mapping (vsdf.py:382-452) with the reference's torch operations: per training view a rigid transform,
-    the skew-aware projection, two bilinear look-ups of the near / far hypotheses, the depth normalisation and one trilinear
-    look-up of the probability volume (grid_sample, zeros padding, align_corners=True).  Torch counterpart of
-    svs_oracle.cost_mapping (same arguments; tensors on xyz's device) for bench.py's same-GPU comparator; held to that
-    restatement by tests/test_oracle_golden.py::test_torch_cost_mapping_vs_oracle."""
+    """VolOpt.cost_mapping (vsdf.py:382-452) in torch: per training view a rigid transform, the skew-aware projection, two
+    bilinear look-ups of the near / far hypotheses, the depth normalisation and one trilinear look-up of the probability
+    volume (grid_sample, zeros padding, align_corners=True, as the reference calls it).  Torch counterpart of
+    svs_oracle.cost_mapping (same arguments; tensors on xyz's device) for bench.py's same-GPU comparator; held to the
+    reference's outputs by tests/test_oracle_golden.py::test_torch_cost_mapping_vs_reference."""
     from torch.nn.functional import grid_sample
     dev = xyz.device
     R, S, _ = xyz.shape
@@ -319,33 +319,33 @@ def cost_mapping(xyz, view_index, views, img_res, inverse_depth=False):
                 z_mvs = torch.stack([as_t(v["z_near"]), as_t(v["z_far"])])
             cost, z_mvs = cost.reshape(cost.shape[-3:]).to(dev), z_mvs.reshape(z_mvs.shape[-3:]).to(dev)
             fx, fy, cx, cy, sk = K[0, 0], K[1, 1], K[0, 2], K[1, 2], K[0, 1]
-            p = xyz.detach().clone()
-            p -= c2w[:, 3].view(1, 1, 3)
-            p = p @ c2w[:, :3]
-            p[..., :2] /= p[..., 2:]
-            p[..., 1] = p[..., 1] * fy + cy
-            p[..., 0] = p[..., 0] * fx + cx + (p[..., 1] - cy) * sk / fy
-            p[..., 0] = p[..., 0] / ((_w - 1) / 2) - 1
-            p[..., 1] = p[..., 1] / ((_h - 1) / 2) - 1
-            p = p.view(1, R, S, 3)
-            inval = (p[..., 2] < 1e-5) | (p[..., 0] > 1.001) | (p[..., 0] < -1.001) | (p[..., 1] > 1.001) | (p[..., 1] < -1.001)
-            p[inval, :] = -99.
-            near = grid_sample(z_mvs[None, :1], p[..., :2], mode='bilinear', padding_mode='zeros', align_corners=True)[:, 0]
-            far = grid_sample(z_mvs[None, -1:], p[..., :2], mode='bilinear', padding_mode='zeros', align_corners=True)[:, 0]
+            # same sequence as svs_oracle.cost_mapping, one torch operation per numpy operation
+            p = (xyz - c2w[:, 3].view(1, 1, 3)) @ c2w[:, :3]
+            z = p[..., 2]
+            y = (p[..., 1] / z) * fy + cy
+            x = (p[..., 0] / z) * fx + cx + (y - cy) * sk / fy
+            x = x / ((_w - 1) / 2) - 1
+            y = y / ((_h - 1) / 2) - 1
+            inval = (z < 1e-5) | (x > 1.001) | (x < -1.001) | (y > 1.001) | (y < -1.001)
+            off = torch.full_like(x, -99.)
+            x, y, z = torch.where(inval, off, x), torch.where(inval, off, y), torch.where(inval, off, z)
+            xy = torch.stack([x, y], -1).view(1, R, S, 2)
+            near = grid_sample(z_mvs[None, :1], xy, mode='bilinear', padding_mode='zeros', align_corners=True)[0, 0]
+            far = grid_sample(z_mvs[None, -1:], xy, mode='bilinear', padding_mode='zeros', align_corners=True)[0, 0]
             if inverse_depth:
-                far[inval] = 1e-8
-                p[..., 2] = 2 * (1. - near / p[..., 2]) / (1. - near / far) - 1
+                far = torch.where(inval, torch.full_like(far, 1e-8), far)
+                zn = 2 * (1. - near / z) / (1. - near / far) - 1
             else:
-                p[..., 2] = 2 * (p[..., 2] - near) / (far - near) - 1
-            inval = (near < 1e-5) | (far < 1e-5) | (p[..., 2] > 1.01) | (p[..., 2] < -1.01) | inval
-            p[inval, :] = -99.
-            g = p.view(1, R, S, 1, 3).permute(0, 2, 1, 3, 4)
+                zn = 2 * (z - near) / (far - near) - 1
+            inval = (near < 1e-5) | (far < 1e-5) | (zn > 1.01) | (zn < -1.01) | inval
+            x, y, zn = torch.where(inval, off, x), torch.where(inval, off, y), torch.where(inval, off, zn)
+            g = torch.stack([x, y, zn], -1).permute(1, 0, 2).reshape(1, S, R, 1, 3)
             c = grid_sample(cost[None, None], g, mode='bilinear', padding_mode='zeros', align_corners=True)
             c = c.reshape(S, R).permute(1, 0)
             if i == view_index:
                 pi = c
             else:
                 pj = pj + c
-                valid = valid | ~inval[0]
+                valid = valid | ~inval
         pi = torch.where(valid, pi, torch.zeros_like(pi))
     return pj, pi, valid
