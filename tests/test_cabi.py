@@ -92,3 +92,8 @@ def test_argument_errors_come_back_as_codes():
     assert rc < 0 and b"k in {1,3,5}" in L.svs_last_error_string()
     rc = L.svs_wgrad_multi(None, 0, 1, None)
     assert rc < 0
+    rc = L.svs_mesh_sample_count(None, 5, None, None)
+    assert rc < 0 and b"svs_mesh_sample_count" in L.svs_last_error_string()
+    rc = L.svs_mesh_sample_points(dummy, 5, None, dummy, None)
+    assert rc < 0 and b"svs_mesh_sample_points" in L.svs_last_error_string()
+    assert L.svs_mesh_sample_count(None, 0, None, None) == 0          # an empty mesh is not an error
