@@ -867,9 +867,9 @@ __device__ __forceinline__ float upsampled_prev(const HypoArgs& a, int yi, int x
 
 __global__ void depth_hypotheses_kernel(HypoArgs a) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= a.D * a.Hs * a.Ws) return;
-  const int x = idx % a.Ws, y = (idx / a.Ws) % a.Hs, d = idx / (a.Ws * a.Hs);
   if (!a.prev_depth) {
+    if (idx >= a.D * a.Hs * a.Ws) return;
+    const int d = idx / (a.Ws * a.Hs);
     float v;
     if (a.inverse) {
       const float step = 1.0f / (float)(a.D - 1);
@@ -881,19 +881,33 @@ __global__ void depth_hypotheses_kernel(HypoArgs a) {
     a.out[idx] = v;
     return;
   }
-  // trilinear resize (D,H_img,W_img) -> (D,Hs,Ws): depth axis is an identity, the spatial axes interpolate
+  // trilinear resize (D,H_img,W_img) -> (D,Hs,Ws): depth axis is an identity, the spatial axes interpolate.  One thread per
+  // pixel: the four corner hypotheses' start and step do not depend on the plane, so they are formed once and the thread
+  // walks the D planes (per plane the expressions of the per-voxel form, value for value).
+  if (idx >= a.Hs * a.Ws) return;
+  const int x = idx % a.Ws, y = idx / a.Ws;
   int y0, y1, x0, x1; float ty, tx;
   lin_src(y, a.H_img, a.Hs, y0, y1, ty);
   lin_src(x, a.W_img, a.Ws, x0, x1, tx);
-  auto hyp = [&](int yi, int xi) {
-    const float cur = upsampled_prev(a, yi, xi);
+  float cmin[4], step[4];
+  const int yi[4] = {y0, y0, y1, y1}, xi[4] = {x0, x1, x0, x1};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float cur = upsampled_prev(a, yi[c], xi[c]);
     const float half = (float)a.D / 2.0f * a.pix_interval;
-    const float cmin = cur - half, cmax = cur + half;
-    return cmin + (float)d * ((cmax - cmin) / (float)(a.D - 1));
-  };
-  const float top = (1.0f - tx) * hyp(y0, x0) + tx * hyp(y0, x1);
-  const float bot = (1.0f - tx) * hyp(y1, x0) + tx * hyp(y1, x1);
-  a.out[idx] = (1.0f - ty) * top + ty * bot;
+    const float lo = cur - half, hi = cur + half;
+    cmin[c] = lo;
+    step[c] = (hi - lo) / (float)(a.D - 1);
+  }
+  const size_t plane = (size_t)a.Hs * a.Ws;
+  for (int d = 0; d < a.D; ++d) {
+    float h[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) h[c] = cmin[c] + (float)d * step[c];
+    const float top = (1.0f - tx) * h[0] + tx * h[1];
+    const float bot = (1.0f - tx) * h[2] + tx * h[3];
+    a.out[d * plane + idx] = (1.0f - ty) * top + ty * bot;
+  }
 }
 
 }  // namespace costvol
@@ -1031,7 +1045,7 @@ int svs_depth_hypotheses(const float* prev_depth, int Hp, int Wp, int H_img, int
     set_error("svs_depth_hypotheses: bad argument"); return SVS_EINVAL;
   }
   HypoArgs a{prev_depth, Hp, Wp, H_img, W_img, D, H_img / scale, W_img / scale, dmin, dmax, pix_interval, inverse, out};
-  const int n = D * a.Hs * a.Ws;
+  const int n = (prev_depth ? 1 : D) * a.Hs * a.Ws;
   depth_hypotheses_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)hip_stream>>>(a);
   return check_launch("svs_depth_hypotheses");
 }
