@@ -486,6 +486,11 @@ int svs_cloud_obs_filter(const double* pts, int n, const float* bb, double res, 
 int svs_cloud_plane_side(const double* pts, int n, const double* plane, uint8_t* above, void* hip_stream);
 int svs_cloud_compact(const double* pts, const uint8_t* mask, int n, int* offset_ws, double* out, int* count, void* hip_stream);
 size_t svs_cloud_mean_workspace_bytes(void);
+/* svs_cloud_bounds: lo_hi[0..2] = per-axis minimum, lo_hi[3..5] = per-axis maximum of pts (n >= 1; DEVICE double[6]) -- the
+ * origin and extent of the search grids (the evaluator took them from two column reductions of torch: 2.6 ms per 4 M-point
+ * cloud, as long as the neighbour search itself).  workspace: svs_cloud_bounds_workspace_bytes(). */
+size_t svs_cloud_bounds_workspace_bytes(void);
+int svs_cloud_bounds(const double* pts, int n, double* workspace, double* lo_hi, void* hip_stream);
 int svs_cloud_mean_below(const double* dist, int n, double max_dist, double* workspace, double* mean_count, void* hip_stream);
 
 /* Evaluator --mode mesh (evals/eval_dtu.py:14-23 sample_single_tri, :62-90): the points the script samples on every

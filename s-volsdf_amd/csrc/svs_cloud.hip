@@ -12,6 +12,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include "svs_common.h"
+#include "svs_scan.h"
 
 namespace svs {
 namespace cloud {
@@ -205,29 +206,7 @@ __global__ void plane_side_kernel(const double* __restrict__ pts, int n, double 
   above[i] = (((p0 * pts[3 * (size_t)i] + p1 * pts[3 * (size_t)i + 1]) + p2 * pts[3 * (size_t)i + 2]) + p3 * 1.0) > 0.0 ? 1 : 0;
 }
 
-// ---- ordered compaction of (n,3) float64 rows ------------------------------------------------------------------------------------
-constexpr int kScanThreads = 1024;
-__global__ __launch_bounds__(kScanThreads) void rows_scan_kernel(const uint8_t* __restrict__ mask, int n, int* __restrict__ offset,
-                                                                 int* __restrict__ count) {
-  __shared__ int part[kScanThreads];
-  const int t = threadIdx.x;
-  const int per = (n + kScanThreads - 1) / kScanThreads;
-  const long long lo_ = (long long)t * per;
-  const int lo = lo_ < n ? (int)lo_ : n, hi = lo_ + per < n ? (int)(lo_ + per) : n;
-  int s = 0;
-  for (int i = lo; i < hi; ++i) s += mask[i] != 0;
-  part[t] = s;
-  __syncthreads();
-  for (int d = 1; d < kScanThreads; d <<= 1) {
-    const int v = t >= d ? part[t - d] : 0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
-  }
-  int run = part[t] - s;
-  for (int i = lo; i < hi; ++i) { offset[i] = run; run += mask[i] != 0; }
-  if (t == kScanThreads - 1) *count = part[t];
-}
+// ---- ordered compaction of (n,3) float64 rows: offsets from svs_scan.h --------------------------------------------------------
 __global__ void rows_scatter_kernel(const double* __restrict__ pts, const uint8_t* __restrict__ mask, const int* __restrict__ offset,
                                     int n, double* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -321,6 +300,45 @@ int build_grid(const double* pts, int n, const double* origin, double h, void* w
   g->ox = origin[0]; g->oy = origin[1]; g->oz = origin[2]; g->inv_h = 1.0 / h; g->h = h;
   g->pts = spts; g->perm = sidx; g->hkey = hkey; g->hrun = hrun; g->mask = L.cap - 1; g->n = n;
   return check_launch("cell grid");
+}
+
+// ---- bounding box of a cloud (the grids' origin): per-block minima / maxima, then one block ---------------------------------
+constexpr int kBoundsBlocks = 512;
+__global__ __launch_bounds__(256) void bounds_partial_kernel(const double* __restrict__ pts, int n, double* __restrict__ part) {
+  __shared__ double red[4][6];
+  double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += kBoundsBlocks * 256) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double v = pts[3 * (size_t)i + a];
+      lo[a] = fmin(lo[a], v); hi[a] = fmax(hi[a], v);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+    for (int d = 32; d >= 1; d >>= 1) { lo[a] = fmin(lo[a], __shfl_xor(lo[a], d)); hi[a] = fmax(hi[a], __shfl_xor(hi[a], d)); }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { red[wave][a] = lo[a]; red[wave][3 + a] = hi[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const bool is_lo = threadIdx.x < 3;
+    double v = red[0][threadIdx.x];
+    for (int w = 1; w < 4; ++w) v = is_lo ? fmin(v, red[w][threadIdx.x]) : fmax(v, red[w][threadIdx.x]);
+    part[6 * blockIdx.x + threadIdx.x] = v;
+  }
+}
+__global__ __launch_bounds__(64) void bounds_final_kernel(const double* __restrict__ part, double* __restrict__ out) {
+  const int lane = threadIdx.x;
+  for (int c = 0; c < 6; ++c) {
+    const bool is_lo = c < 3;
+    double v = is_lo ? INFINITY : -INFINITY;
+    for (int b = lane; b < kBoundsBlocks; b += 64) v = is_lo ? fmin(v, part[6 * b + c]) : fmax(v, part[6 * b + c]);
+    for (int d = 32; d >= 1; d >>= 1) v = is_lo ? fmin(v, __shfl_xor(v, d)) : fmax(v, __shfl_xor(v, d));
+    if (lane == 0) out[c] = v;
+  }
 }
 
 // ---- mesh mode: points sampled on the triangles (evals/eval_dtu.py:14-23 sample_single_tri, :70-90) -----------------
@@ -435,7 +453,7 @@ int svs_cloud_plane_side(const double* pts, int n, const double* plane, uint8_t*
 int svs_cloud_compact(const double* pts, const uint8_t* mask, int n, int* offset_ws, double* out, int* count, void* hip_stream) {
   if (!pts || !mask || !offset_ws || !out || !count || n < 0) { set_error("svs_cloud_compact: bad argument"); return SVS_EINVAL; }
   hipStream_t s = (hipStream_t)hip_stream;
-  rows_scan_kernel<<<1, kScanThreads, 0, s>>>(mask, n, offset_ws, count);
+  scan::mask_offsets(mask, n, offset_ws, count, s);
   if (n > 0) rows_scatter_kernel<<<(n + 255) / 256, 256, 0, s>>>(pts, mask, offset_ws, n, out);
   return check_launch("svs_cloud_compact");
 }
@@ -448,6 +466,16 @@ int svs_cloud_mean_below(const double* dist, int n, double max_dist, double* wor
   mean_partial_kernel<<<kMeanBlocks, 256, 0, s>>>(dist, n, max_dist, workspace);
   mean_final_kernel<<<1, 1, 0, s>>>(workspace, mean_count);
   return check_launch("svs_cloud_mean_below");
+}
+
+size_t svs_cloud_bounds_workspace_bytes(void) { return sizeof(double) * 6 * kBoundsBlocks; }
+
+int svs_cloud_bounds(const double* pts, int n, double* workspace, double* lo_hi, void* hip_stream) {
+  if (!pts || !workspace || !lo_hi || n < 1) { set_error("svs_cloud_bounds: bad argument (at least one point)"); return SVS_EINVAL; }
+  hipStream_t s = (hipStream_t)hip_stream;
+  bounds_partial_kernel<<<kBoundsBlocks, 256, 0, s>>>(pts, n, workspace);
+  bounds_final_kernel<<<1, 64, 0, s>>>(workspace, lo_hi);
+  return check_launch("svs_cloud_bounds");
 }
 
 int svs_mesh_sample_count(const double* tri, int n_tri, long long* counts, void* hip_stream) {

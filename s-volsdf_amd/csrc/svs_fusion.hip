@@ -9,6 +9,7 @@
 // One thread per reference pixel, all source views in registers: 4 B read per (pixel, view) for the reference
 // side plus one bilinear fetch of the source depth -- HBM/latency-bound integer-and-double work, no matrix cores.
 #include "svs_common.h"
+#include "svs_scan.h"
 
 namespace svs {
 namespace fusion {
@@ -117,30 +118,7 @@ __global__ __launch_bounds__(256) void fuse_view_kernel(FuseArgs a) {
   a.photo_mask[pix] = photo ? 1 : 0; a.geo_mask[pix] = geo ? 1 : 0; a.final_mask[pix] = fin ? 1 : 0;
 }
 
-// ---- ordered compaction: vertices in row-major order of the surviving pixels (runner.py:377-386) -----------------------
-// One workgroup scans the whole mask (<= a few million pixels): thread t owns a contiguous slice.
-constexpr int kScanThreads = 1024;
-
-__global__ __launch_bounds__(kScanThreads) void mask_scan_kernel(const uint8_t* __restrict__ mask, int n, int* __restrict__ offset,
-                                                                 int* __restrict__ count) {
-  __shared__ int part[kScanThreads];
-  const int t = threadIdx.x;
-  const int per = (n + kScanThreads - 1) / kScanThreads;
-  const int lo = t * per < n ? t * per : n, hi = lo + per < n ? lo + per : n;
-  int s = 0;
-  for (int i = lo; i < hi; ++i) s += mask[i] != 0;
-  part[t] = s;
-  __syncthreads();
-  for (int d = 1; d < kScanThreads; d <<= 1) {           // Hillis-Steele inclusive scan
-    const int v = t >= d ? part[t - d] : 0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
-  }
-  int run = part[t] - s;
-  for (int i = lo; i < hi; ++i) { offset[i] = run; run += mask[i] != 0; }
-  if (t == kScanThreads - 1) *count = part[t];
-}
+// ---- ordered compaction: vertices in row-major order of the surviving pixels (runner.py:377-386): svs_scan.h -----------
 
 struct PointArgs {
   const double* depth_avg;
@@ -209,7 +187,7 @@ int svs_fuse_points(const double* depth_avg, const uint8_t* final_mask, const fl
   }
   if (H < 1 || W < 1) { set_error("svs_fuse_points: bad sizes"); return SVS_ESHAPE; }
   hipStream_t s = (hipStream_t)hip_stream;
-  mask_scan_kernel<<<1, kScanThreads, 0, s>>>(final_mask, H * W, offset_ws, count);
+  scan::mask_offsets(final_mask, (long long)H * W, offset_ws, count, s);
   int rc = check_launch("svs_fuse_points(scan)");
   if (rc) return rc;
   PointArgs a{depth_avg, final_mask, offset_ws, ref_img, mats, H, W, xyz, rgb};

@@ -32,9 +32,16 @@ def _cloud(a):
 
 
 def _origin(clouds, pad):
-    lo = torch.stack([c.min(0).values for c in clouds if c.shape[0]]).min(0).values.cpu().numpy() - pad
-    hi = torch.stack([c.max(0).values for c in clouds if c.shape[0]]).max(0).values.cpu().numpy() + pad
-    return lo, hi
+    """Padded bounding box of the clouds (one library call per cloud, one read-back for all)."""
+    L = _lib.load()
+    clouds = [c for c in clouds if c.shape[0]]
+    dev = clouds[0].device
+    ws = torch.empty(L.svs_cloud_bounds_workspace_bytes() // 8, dtype=torch.float64, device=dev)
+    box = torch.empty(len(clouds), 6, dtype=torch.float64, device=dev)
+    for k, c in enumerate(clouds):
+        _lib.check(L.svs_cloud_bounds(_ptr(c), c.shape[0], _ptr(ws), _ptr(box[k]), _stream()), "svs_cloud_bounds")
+    box = box.cpu().numpy()
+    return box[:, :3].min(0) - pad, box[:, 3:].max(0) + pad
 
 
 def nearest_neighbor(ref, query, max_radius, cell=None, return_index=False):

@@ -114,6 +114,8 @@ SIGNATURES = {
     "svs_cloud_compact": (c_int, [_P, _P, c_int, _P, _P, _P, _P]),
     "svs_cloud_mean_workspace_bytes": (c_size_t, []),
     "svs_cloud_mean_below": (c_int, [_P, c_int, c_double, _P, _P, _P]),
+    "svs_cloud_bounds_workspace_bytes": (c_size_t, []),
+    "svs_cloud_bounds": (c_int, [_P, c_int, _P, _P, _P]),
     "svs_mesh_sample_count": (c_int, [_P, c_int, _P, _P]),
     "svs_mesh_sample_points": (c_int, [_P, c_int, _P, _P, _P]),
     "svs_fuse_view": (c_int, [_P, _P, _PP, _P, c_int, c_int, c_int, c_float, c_double, c_float, c_int, _P, _P, _P, _P, _P,

@@ -208,3 +208,33 @@ def test_large_cloud_properties(dev):
     dropped = eval_dtu.compact(pts, ~keep)
     dk = eval_dtu.nearest_neighbor(kept, dropped, 1.0)
     assert float(dk.max()) <= 0.2
+
+
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 4095, 4096, 4097, 100001, 5_000_011])
+def test_compact_keeps_order_at_any_size(dev, n):
+    """The ordered compaction (block-wise mask scan, csrc/svs_scan.h) at sizes around its 16-byte / 4096-byte units, with an
+    aligned and an unaligned mask: rows with a non-zero mask byte, in order."""
+    from evals import eval_dtu
+    g = torch.Generator(device="cpu").manual_seed(n)
+    pts = torch.randn(n, 3, generator=g, dtype=torch.float64).to(dev)
+    raw = (torch.rand(n + 1, generator=g) < 0.37).to(torch.uint8).to(dev)
+    raw[raw != 0] = 7                                           # any non-zero byte counts
+    for mask in (raw[:n], raw[1:]):                             # raw[1:] starts one byte off a 16-byte boundary
+        got = eval_dtu.compact(pts, mask)
+        want = pts[mask != 0]
+        assert got.shape == want.shape and torch.equal(got, want)
+    assert eval_dtu.compact(pts, torch.zeros(n, dtype=torch.uint8, device=dev)).shape == (0, 3)
+    assert torch.equal(eval_dtu.compact(pts, torch.ones(n, dtype=torch.uint8, device=dev)), pts)
+
+
+@pytest.mark.parametrize("n", [1, 63, 1000, 3_000_001])
+def test_cloud_bounds(dev, n):
+    from svs_hip import lib
+    from svs_hip.ops import _ptr, _stream
+    L = lib.load()
+    pts = (torch.randn(n, 3, dtype=torch.float64) * torch.tensor([1.0, 50.0, 0.01], dtype=torch.float64)).to(dev)
+    ws = torch.empty(L.svs_cloud_bounds_workspace_bytes() // 8, dtype=torch.float64, device=dev)
+    box = torch.empty(6, dtype=torch.float64, device=dev)
+    lib.check(L.svs_cloud_bounds(_ptr(pts), n, _ptr(ws), _ptr(box), _stream()), "svs_cloud_bounds")
+    want = torch.cat([pts.min(0).values, pts.max(0).values])
+    assert torch.equal(box, want)
