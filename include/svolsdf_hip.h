@@ -508,6 +508,11 @@ int svs_mesh_sample_points(const double* tri, int n_tri, const long long* offset
 int svs_selftest_exp(const float* x, float* y_exp, float* y_expm1, int n, void* hip_stream);
 int svs_selftest_arith(const float* a, const float* b, float* quotient, float* sqrt_abs_a, int n, void* hip_stream);
 int svs_selftest_cumsum(const float* x, float* y, float* total, int rows, int m, void* hip_stream);
+/* total[r] = torch.sum(x[r, :m], -1) of a float32 row in ATen's cascade_sum order (the order of the reference's
+ * `pdf / torch.sum(pdf, -1, keepdim=True)`, volsdf/model/ray_sampler.py:149,161, and of `(dists ** 2.).sum(-1)`, :77);
+ * svs_selftest_exp evaluates the restated Sleef_expf8_u10 / Sleef_expm1f8_u10 (torch.exp pinned / torch.expm1,
+ * ray_sampler.py:130-146,225-227, volsdf/model/density.py:26).  1 <= m <= 16000. */
+int svs_selftest_rowsum(const float* x, float* total, int rows, int m, void* hip_stream);
 
 #ifdef __cplusplus
 }

@@ -11,18 +11,38 @@ against golden arrays produced by importing the reference itself on CPU
 (tests/golden/make_fixtures.py, run in the build container; the reference has no
 tests or golden vectors of its own -- SURVEY.md section 4).
 
-Numeric contract (what "bit-exact" means for the sampler), also in DESIGN.md:
+Numeric contract (what "bit-exact" means for the sampler), also in DESIGN.md section 2:
   * every elementary op (+ - * / sqrt, compare) is an IEEE float32 op in the
-    reference's order, with no fused multiply-add;
-  * exp / expm1 are `det_exp` / `det_expm1` below: evaluated in float64 by a fixed
-    Cody-Waite + degree-13 Horner recipe that uses only IEEE add/mul (no fma, no
-    libm), then rounded once to float32.  They agree with torch's float32
-    exp/expm1 to <= 1 ulp and are reproducible bit for bit on any IEEE machine,
-    which is what lets the HIP sampler be compared bit-exactly with this file;
-  * cumsum / row sums accumulate in float64 and round each prefix to float32
-    (what torch-CPU cumsum does) in the CANONICAL BLOCKED ORDER of
-    `canon_cumsum` (64 contiguous chunks, sequential inside a chunk, Kogge-Stone
-    across chunks) -- the order a 64-lane wavefront scan produces.
+    reference's order, with no fused multiply-add except where the restated
+    library routine itself uses one (written `_fma32`);
+  * `torch.expm1(float32)` on CPU is Sleef's `Sleef_expm1f8_u10` (sleef 3.x as bundled
+    with torch 2.10, `xexpm1f` / `expk2f` of sleefsimdsp.c, FMA build): restated here
+    operation by operation as `sleef_expm1f`; bit-equal to the library routine
+    exported by libtorch_cpu.so on 12.6 M inputs (tests/golden/check_primitives.py);
+  * `torch.sum(float32 row, dim=-1)` on CPU is ATen's `cascade_sum`
+    (aten/src/ATen/native/cpu/SumKernel.cpp: `vectorized_inner_sum` -> `row_sum` ->
+    `multi_row_sum`, 8-lane vectors, 4 independent accumulators, cascade levels of
+    16): restated as `aten_sum`; the AVX2 kernel also serves AVX-512 hosts (the stub
+    is registered without an AVX-512 variant), so the order is the same on every
+    x86-64 host; bit-equal to torch.sum for every row length 1..700 and longer rows;
+  * `torch.exp(float32)` on CPU is NOT an open algorithm in an MKL build of torch: it
+    dispatches to Intel MKL VML `vmsExp` (closed source), whose AVX-512 / AVX2 / SSE
+    kernels return different float32 results on 1-4 % of all inputs (measured,
+    check_primitives.py), so the reference's own exp depends on the host.  The
+    contract pins the one OPEN implementation torch has: Sleef's `Sleef_expf8_u10`
+    (what ATen's Vectorized<float>::exp() calls in a build without MKL), restated as
+    `sleef_expf`.  The golden fixtures are generated with the reference's
+    `torch.exp` bound to that very library routine (tests/golden/ref_shim.py::
+    pin_open_exp), which makes them host-independent; `sampler64_hostexp_*.npz`
+    holds the unpinned reference for the cross-check with the host's own exp;
+  * `torch.sqrt(float32)` is likewise MKL VML in an MKL build (AVX-512 kernel: off by one
+    ulp on 0.7 % of all inputs, AVX2 kernel: IEEE); pinned to the IEEE square root
+    (ATen's Vectorized<float>::sqrt()), `ref_sqrt`;
+  * cumsum accumulates in float64 and rounds each prefix to float32 (what torch-CPU
+    cumsum does) in the CANONICAL BLOCKED ORDER of `canon_cumsum`
+    (64 contiguous chunks, sequential inside a chunk, Kogge-Stone across chunks) --
+    the order a 64-lane wavefront scan produces (float64 sums of <= 640 float32
+    terms round to the same float32 in any order except at measure-zero ties).
 """
 from __future__ import annotations
 
@@ -33,59 +53,214 @@ import numpy as np
 F32 = np.float32
 F64 = np.float64
 
-# ----------------------------------------------------------------------------------------
-# deterministic transcendental functions
-# ----------------------------------------------------------------------------------------
-_LOG2E = 1.4426950408889634
-_LN2_HI = 6.93147180369123816490e-01   # 0x3fe62e42fee00000
-_LN2_LO = 1.90821492927058770002e-10   # 0x3dea39ef35793c76
-# 1/n! for n = 0..13, nearest doubles
-_EXP_C = (
-    1.0, 1.0, 0.5, 1.6666666666666666e-01, 4.1666666666666664e-02, 8.3333333333333332e-03,
-    1.3888888888888889e-03, 1.9841269841269841e-04, 2.4801587301587302e-05,
-    2.7557319223985893e-06, 2.7557319223985888e-07, 2.5052108385441720e-08,
-    2.0876756987868100e-09, 1.6059043836821613e-10,
-)
-_EXP_HI = 88.72283935546875     # above this float32 exp overflows to +inf
-_EXP_LO = -104.0                # below this the float32 result is 0
 
-
-def _exp64(x: np.ndarray) -> np.ndarray:
-    """float64 exp by the fixed recipe (input already float64, finite, in [_EXP_LO,_EXP_HI])."""
-    k = np.rint(x * _LOG2E)
-    r = (x - k * _LN2_HI) - k * _LN2_LO
-    p = np.full_like(r, _EXP_C[13])
-    for c in _EXP_C[12::-1]:
-        p = p * r + c
-    return p * np.ldexp(1.0, k.astype(np.int64))
-
-
-def det_exp(x) -> np.ndarray:
-    """float32 -> float32 exp, reproducible bit for bit (see module docstring)."""
-    x = np.asarray(x, dtype=F32)
-    xd = x.astype(F64)
+def _fma32(a, b, c):
+    """float32 fused multiply-add with ONE rounding, emulated exactly: the product of two float32 is exact in
+    float64; the float64 sum is rounded to odd (TwoSum error term), so the final rounding to float32 cannot
+    double-round."""
+    a = np.asarray(a, F32).astype(F64)
+    b = np.asarray(b, F32).astype(F64)
+    c = np.asarray(c, F32).astype(F64)
     with np.errstate(all="ignore"):
-        inner = _exp64(np.clip(np.nan_to_num(xd, nan=0.0), _EXP_LO, _EXP_HI))
-        y = inner.astype(F32)
-    y = np.where(xd > _EXP_HI, F32(np.inf), y)
-    y = np.where(xd < _EXP_LO, F32(0.0), y)
-    y = np.where(np.isnan(xd), F32(np.nan), y)
-    return y.astype(F32)
+        p = a * b
+        s = p + c
+        bb = s - p
+        e = (p - (s - bb)) + (c - bb)
+        even = (np.atleast_1d(s).view(np.int64) & 1).reshape(np.shape(s)) == 0
+        fix = (e != 0) & even & np.isfinite(s)
+        s = np.where(fix, np.nextafter(s, np.where(e > 0, np.inf, -np.inf)), s)
+        return s.astype(F32)
 
 
-def det_expm1(x) -> np.ndarray:
-    """float32 -> float32 expm1: |x| < 2^-20 -> x + x*x/2, else exp64(x) - 1 (float64), rounded once."""
-    x = np.asarray(x, dtype=F32)
-    xd = x.astype(F64)
+# ----------------------------------------------------------------------------------------
+# exp / expm1: Sleef 3.x (bundled with torch), u10 single-precision routines, FMA build
+# ----------------------------------------------------------------------------------------
+_R_LN2F = F32(1.4426950216293335)          # 0x3fb8aa3b
+_L2UF = F32(0.693145751953125)             # 0x3f317200
+_L2LF = F32(1.428606765330187e-06)         # 0x35bfbe8e
+_EXPF_C = tuple(F32(c) for c in (0.00019852761761285365, 0.0013930435525253415, 0.008333360776305199,
+                                 0.041666485369205475, 0.1666666716337204, 0.5))
+_EXPK2F_C = tuple(F32(c) for c in (0.00019809602235909551, 0.0013942564837634563, 0.008333456702530384,
+                                   0.04166637361049652))
+
+
+def _f(x):
+    return np.asarray(x).astype(F32)
+
+
+def _ldexp2f(u, q):
+    """vldexp2_vf_vf_vi2: u * 2^(q>>1) * 2^(q - (q>>1)), two float32 multiplications"""
+    h = q >> 1
+    return _f(_f(u * np.ldexp(F32(1.0), h).astype(F32)) * np.ldexp(F32(1.0), q - h).astype(F32))
+
+
+def sleef_expf(d) -> np.ndarray:
+    """Sleef_expf8_u10 (xexpf, sleefsimdsp.c), float32 -> float32.  q = rint(d / ln2) by cvtps2dq (nearest even);
+    s = fma(q, -L2U, d); s = fma(q, -L2L, s); degree-5 Horner in fma; u = fma(s*s, u, s) + 1; ldexp2;
+    0 below -104, +inf above 100."""
+    d = np.asarray(d, F32)
     with np.errstate(all="ignore"):
-        xc = np.clip(np.nan_to_num(xd, nan=0.0), _EXP_LO, _EXP_HI)
-        big = _exp64(xc) - 1.0
-        small = xd + (xd * xd) * 0.5
-        y = np.where(np.abs(xd) < 9.5367431640625e-07, small, big).astype(F32)
-    y = np.where(xd > _EXP_HI, F32(np.inf), y)
-    y = np.where(xd < _EXP_LO, F32(-1.0), y)
-    y = np.where(np.isnan(xd), F32(np.nan), y)
-    return y.astype(F32)
+        dc = np.clip(np.nan_to_num(d, nan=0.0), -200.0, 200.0).astype(F32)
+        q = np.rint(_f(dc * _R_LN2F)).astype(np.int32)
+        qf = q.astype(F32)
+        s = _fma32(qf, -_L2UF, dc)
+        s = _fma32(qf, -_L2LF, s)
+        u = np.full_like(s, _EXPF_C[0])
+        for c in _EXPF_C[1:]:
+            u = _fma32(u, s, c)
+        u = _f(_fma32(_f(s * s), u, s) + F32(1.0))
+        u = _ldexp2f(u, q)
+    u = np.where(d < F32(-104.0), F32(0.0), u)
+    u = np.where(d > F32(100.0), F32(np.inf), u)
+    u = np.where(np.isnan(d), F32(np.nan), u)
+    return u.astype(F32)
+
+
+# double-float helpers of sleef (df.h, FMA variants); a double-float is a pair (x, y) of float32 arrays
+def _dfadd2_f_f(x, y):
+    s = _f(x + y)
+    v = _f(s - x)
+    return s, _f(_f(x - _f(s - v)) + _f(y - v))
+
+
+def _dfadd2_f2_f(xx, xy, y):
+    s, t = _dfadd2_f_f(xx, y)
+    return s, _f(t + xy)
+
+
+def _dfadd2_f2_f2(xx, xy, yx, yy):
+    s, t = _dfadd2_f_f(xx, yx)
+    return s, _f(t + _f(xy + yy))
+
+
+def _dfmul_f2_f(xx, xy, y):
+    s = _f(xx * y)
+    return s, _fma32(xy, y, _fma32(xx, y, -s))
+
+
+def _dfmul_f2_f2(xx, xy, yx, yy):
+    s = _f(xx * yx)
+    return s, _fma32(xx, yy, _fma32(xy, yx, _fma32(xx, yx, -s)))
+
+
+def _dfsqu_f2(xx, xy):
+    s = _f(xx * xx)
+    return s, _fma32(_f(xx + xx), xy, _fma32(xx, xx, -s))
+
+
+def sleef_expm1f(a) -> np.ndarray:
+    """Sleef_expm1f8_u10 (xexpm1f = expk2f(a) + (-1) in double-float arithmetic, sleefsimdsp.c)."""
+    a = np.asarray(a, F32)
+    with np.errstate(all="ignore"):
+        ac = np.clip(np.nan_to_num(a, nan=0.0), -200.0, 200.0).astype(F32)
+        q = np.rint(_f(_f(ac + F32(0.0)) * _R_LN2F)).astype(np.int32)
+        qf = q.astype(F32)
+        sx, sy = _dfadd2_f2_f(ac, np.zeros_like(ac), _f(qf * -_L2UF))
+        sx, sy = _dfadd2_f2_f(sx, sy, _f(qf * -_L2LF))
+        u = np.full_like(sx, _EXPK2F_C[0])
+        for c in _EXPK2F_C[1:]:
+            u = _fma32(u, sx, c)
+        tx, ty = _dfmul_f2_f(sx, sy, u)
+        tx, ty = _dfadd2_f2_f(tx, ty, F32(0.1666666567325592))
+        tx, ty = _dfmul_f2_f2(sx, sy, tx, ty)
+        tx, ty = _dfadd2_f2_f(tx, ty, F32(0.5))
+        qx, qy = _dfsqu_f2(sx, sy)
+        mx, my = _dfmul_f2_f2(qx, qy, tx, ty)
+        tx, ty = _dfadd2_f2_f2(sx, sy, mx, my)
+        s = _f(F32(1.0) + tx)                                   # dfadd_vf2_vf_vf2(1, t)
+        ty = _f(_f(_f(F32(1.0) - s) + tx) + ty)
+        tx = s
+        tx, ty = _ldexp2f(tx, q), _ldexp2f(ty, q)
+        low = ac < F32(-104.0)
+        tx, ty = np.where(low, F32(0.0), tx), np.where(low, F32(0.0), ty)
+        dx, dy = _dfadd2_f2_f(tx, ty, F32(-1.0))
+        x = _f(dx + dy)
+    x = np.where(a > F32(88.72283172607422), F32(np.inf), x)
+    x = np.where(a < F32(-16.63553237915039), F32(-1.0), x)
+    x = np.where((a == 0) & np.signbit(a), F32(-0.0), x)
+    x = np.where(np.isnan(a), F32(np.nan), x)
+    return x.astype(F32)
+
+
+# ----------------------------------------------------------------------------------------
+# torch.sum(float32, dim=-1) on CPU: ATen cascade_sum (SumKernel.cpp), AVX2 kernel
+# ----------------------------------------------------------------------------------------
+_SUM_LANES = 8        # Vectorized<float>::size() of the kernel that is dispatched (AVX2, also on AVX-512 hosts)
+_SUM_ILP = 4          # row_sum's ilp_factor
+_SUM_LEVELS = 4       # multi_row_sum's num_levels
+
+
+def _multi_row_sum(v):
+    """multi_row_sum<acc_t, 4>: v (R, size, 4, L) -> (R, 4, L); level 0 takes `level_step` rows, then folds upwards."""
+    R, size = v.shape[:2]
+    clog = 0
+    while (1 << clog) < size:
+        clog += 1
+    power = max(4, clog // _SUM_LEVELS)
+    step, mask = 1 << power, (1 << power) - 1
+    acc = np.zeros((_SUM_LEVELS,) + (R,) + v.shape[2:], F32)
+    i = 0
+    while i + step <= size:
+        for _ in range(step):
+            acc[0] = acc[0] + v[:, i]
+            i += 1
+        for j in range(1, _SUM_LEVELS):
+            acc[j] = acc[j] + acc[j - 1]
+            acc[j - 1] = 0
+            if (i & (mask << (j * power))) != 0:
+                break
+    while i < size:
+        acc[0] = acc[0] + v[:, i]
+        i += 1
+    for j in range(1, _SUM_LEVELS):
+        acc[0] = acc[0] + acc[j]
+    return acc[0]
+
+
+def _row_sum(v):
+    """row_sum<acc_t>: v (R, size, L) (L = 8 for vector loads, 1 for scalar loads) -> (R, L)"""
+    R, size, L = v.shape
+    n4 = size // _SUM_ILP
+    part = _multi_row_sum(v[:, :n4 * _SUM_ILP].reshape(R, n4, _SUM_ILP, L))
+    p0 = part[:, 0]
+    for i in range(n4 * _SUM_ILP, size):
+        p0 = p0 + v[:, i]
+    for k in range(1, _SUM_ILP):
+        p0 = p0 + part[:, k]
+    return p0
+
+
+def aten_sum(x) -> np.ndarray:
+    """torch.sum(x, -1, keepdim=True) for a contiguous float32 x, in ATen's order (module docstring)."""
+    x = np.asarray(x, F32)
+    m = x.shape[-1]
+    x2 = x.reshape(-1, m)
+    R = x2.shape[0]
+    with np.errstate(over="ignore", invalid="ignore"):
+        if m < _SUM_LANES:                                   # scalar_inner_sum
+            out = _row_sum(x2.reshape(R, m, 1))[:, 0]
+        else:                                                # vectorized_inner_sum
+            nv = m // _SUM_LANES
+            vec = _row_sum(x2[:, :nv * _SUM_LANES].reshape(R, nv, _SUM_LANES))
+            out = np.zeros(R, F32)
+            for k in range(nv * _SUM_LANES, m):
+                out = out + x2[:, k]
+            for k in range(_SUM_LANES):
+                out = out + vec[:, k]
+    return out.reshape(x.shape[:-1] + (1,)).astype(F32)
+
+
+# the three primitives as the restatement below calls them (module attributes, so that a test can bind the
+# host's own exp for the cross-check against the unpinned reference)
+ref_exp = sleef_expf
+ref_expm1 = sleef_expm1f
+ref_sum = aten_sum
+
+
+def ref_sqrt(x):
+    """torch.sqrt pinned to the IEEE square root (module docstring: in an MKL build the reference's `torch.sqrt` is
+    MKL VML, whose AVX-512 kernel is off by one ulp on 0.7 % of all inputs)."""
+    return np.sqrt(np.asarray(x, F32)).astype(F32)
 
 
 # ----------------------------------------------------------------------------------------
@@ -125,11 +300,6 @@ def canon_cumsum64(x) -> np.ndarray:
 def canon_cumsum(x) -> np.ndarray:
     """torch.cumsum(float32) restatement: float64 accumulate, each prefix rounded to float32."""
     return canon_cumsum64(x).astype(F32)
-
-
-def canon_sum(x) -> np.ndarray:
-    """Row sum = last prefix of canon_cumsum (float32), keepdims."""
-    return canon_cumsum64(x)[..., -1:].astype(F32)
 
 
 # ----------------------------------------------------------------------------------------
@@ -342,18 +512,13 @@ def laplace_density(sdf, beta):
     sdf = np.asarray(sdf, F32)
     beta = np.asarray(beta, F32)
     alpha = (F32(1.0) / beta).astype(F32)
-    e = det_expm1((-np.abs(sdf) / beta).astype(F32))
+    e = ref_expm1((-np.abs(sdf) / beta).astype(F32))
     return (alpha * (F32(0.5) + F32(0.5) * np.sign(sdf).astype(F32) * e)).astype(F32)
 
 
 # ----------------------------------------------------------------------------------------
 # a2  uniform sampler     volsdf/model/ray_sampler.py:22-43
 # ----------------------------------------------------------------------------------------
-def _fma32(a, b, c):
-    """float32 fused multiply-add (one rounding), emulated exactly in float64."""
-    return (np.asarray(a, F32).astype(F64) * np.asarray(b, F32).astype(F64) + np.asarray(c, F32).astype(F64)).astype(F32)
-
-
 def linspace32(start, end, n):
     """torch.linspace(start,end,n) in float32: step=(end-start)/(n-1) (float32);
     fma(step, i, start) for i < n/2, fma(-step, n-1-i, end) otherwise (ATen RangeFactories)."""
@@ -401,7 +566,7 @@ def d_star_bound(z, sdf):
     area = (((s * (s - a)).astype(F32) * (s - b)).astype(F32) * (s - c)).astype(F32)
     mask = ~first & ~second & ((b + c).astype(F32) - a > 0)
     with np.errstate(invalid="ignore", divide="ignore"):
-        tri = ((F32(2.0) * np.sqrt(area).astype(F32)).astype(F32) / a).astype(F32)
+        tri = ((F32(2.0) * ref_sqrt(area)).astype(F32) / a).astype(F32)
     d_star[mask] = tri[mask]
     same_sign = (np.sign(sdf[:, 1:]) * np.sign(sdf[:, :-1])) == 1
     return dists, (same_sign.astype(F32) * d_star).astype(F32)
@@ -414,11 +579,11 @@ def error_bound(beta, sdf, dists, d_star):
     sfe = np.concatenate([np.zeros((dists.shape[0], 1), F32), (dists * density[:, :-1]).astype(F32)], -1)
     integral = canon_cumsum(sfe)
     with np.errstate(over="ignore", invalid="ignore"):
-        eps_sec = ((det_exp((-d_star / beta).astype(F32)) * (dists * dists).astype(F32)).astype(F32)
+        eps_sec = ((ref_exp((-d_star / beta).astype(F32)) * (dists * dists).astype(F32)).astype(F32)
                    / (F32(4.0) * (beta * beta).astype(F32)).astype(F32)).astype(F32)
         err_int = canon_cumsum(eps_sec)
-        bound = ((np.minimum(det_exp(err_int), F32(1.0e6)) - F32(1.0)).astype(F32)
-                 * det_exp(-integral[:, :-1])).astype(F32)
+        bound = ((np.minimum(ref_exp(err_int), F32(1.0e6)) - F32(1.0)).astype(F32)
+                 * ref_exp(-integral[:, :-1])).astype(F32)
     return bound.max(-1)
 
 
@@ -429,8 +594,8 @@ def ray_weights(z, sdf, beta, last_dist=1e10):
                             np.full((z.shape[0], 1), last_dist, F32)], -1)
     fe = (dists * density).astype(F32)
     sfe = np.concatenate([np.zeros((z.shape[0], 1), F32), fe[:, :-1]], -1)
-    alpha = (F32(1.0) - det_exp(-fe)).astype(F32)
-    trans = det_exp(-canon_cumsum(sfe))
+    alpha = (F32(1.0) - ref_exp(-fe)).astype(F32)
+    trans = ref_exp(-canon_cumsum(sfe))
     return (alpha * trans).astype(F32), trans, dists
 
 
@@ -500,16 +665,16 @@ def sampler_round(z, sdf, beta_in, beta0, *, upsample_allowed, training=False, u
         N = N_samples_eval
         with np.errstate(over="ignore", invalid="ignore"):
             b = beta[:, None]
-            eps_sec = ((det_exp((-d_star / b).astype(F32)) * (dists * dists).astype(F32)).astype(F32)
+            eps_sec = ((ref_exp((-d_star / b).astype(F32)) * (dists * dists).astype(F32)).astype(F32)
                        / (F32(4.0) * (b * b).astype(F32)).astype(F32)).astype(F32)
             err_int = canon_cumsum(eps_sec)
-            bound_op = ((np.minimum(det_exp(err_int), F32(1.0e6)) - F32(1.0)).astype(F32)
+            bound_op = ((np.minimum(ref_exp(err_int), F32(1.0e6)) - F32(1.0)).astype(F32)
                         * trans[:, :-1]).astype(F32)
         pdf = (bound_op + F32(add_tiny)).astype(F32)
     else:
         N = N_samples
         pdf = (weights[:, :-1] + F32(1e-5)).astype(F32)
-    pdf = (pdf / canon_sum(pdf)).astype(F32)
+    pdf = (pdf / ref_sum(pdf)).astype(F32)
     cdf = np.concatenate([np.zeros((R, 1), F32), canon_cumsum(pdf)], -1)
 
     if upsample or not training:
@@ -563,8 +728,8 @@ def error_bound_sampler(sdf_fn, ray_dirs, cam_loc, beta0, *, near=1e-4, scene_bo
     dists = (z[:, 1:] - z[:, :-1]).astype(F32)
     if inv_4log is None:
         inv_4log = F32(1.0) / (F32(4.0) * F32(math.log(F32(eps) + F32(1.0))))
-    bound = (F32(inv_4log) * canon_sum((dists * dists).astype(F32))[:, 0]).astype(F32)
-    beta = np.sqrt(bound).astype(F32)
+    bound = (F32(inv_4log) * ref_sum((dists * dists).astype(F32))[:, 0]).astype(F32)
+    beta = ref_sqrt(bound)
 
     total_iters, not_converge = 0, True
     sdf = None
@@ -719,8 +884,8 @@ def fg_weights_bg_model(z, z_max, sdf, beta):
     dists = np.concatenate([z[:, 1:] - z[:, :-1], z_max[:, None] - z[:, -1:]], -1).astype(F32)
     free = (dists * sigma).astype(F32)
     shifted = np.concatenate([np.zeros((z.shape[0], 1), F32), free], -1)
-    alpha = (F32(1.0) - det_exp(-free)).astype(F32)
-    trans = det_exp(-canon_cumsum(shifted))
+    alpha = (F32(1.0) - ref_exp(-free)).astype(F32)
+    trans = ref_exp(-canon_cumsum(shifted))
     return (alpha * trans[:, :-1]).astype(F32), trans[:, -1].astype(F32), dists
 
 
@@ -729,8 +894,8 @@ def bg_weights(z_bg, bg_sigma):
     dists = np.concatenate([z_bg[:, :-1] - z_bg[:, 1:], np.full((z_bg.shape[0], 1), 1e10, F32)], -1).astype(F32)
     free = (dists * bg_sigma).astype(F32)
     shifted = np.concatenate([np.zeros((z_bg.shape[0], 1), F32), free[:, :-1]], -1)
-    alpha = (F32(1.0) - det_exp(-free)).astype(F32)
-    trans = det_exp(-canon_cumsum(shifted))
+    alpha = (F32(1.0) - ref_exp(-free)).astype(F32)
+    trans = ref_exp(-canon_cumsum(shifted))
     return (alpha * trans).astype(F32)
 
 

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(64) void composite_kernel(CompositeArgs a) {
   const float ds = a.depth_scale[r];
   for (int i = lane; i < S; i += 64) {
     const size_t p = (size_t)r * S + i;
-    const float w = (1.0f - det_exp(-fe[i])) * det_exp(-sfe[i]);
+    const float w = (1.0f - sleef_expf(-fe[i])) * sleef_expf(-sfe[i]);
     a.weights[p] = w;
     a.depth_vals[p] = zs[i] * ds;
     sw += w; swz += w * zs[i];
@@ -583,12 +583,12 @@ __global__ __launch_bounds__(64) void composite_bg_kernel(CompositeBgArgs a) {
   __syncthreads();
   wave_cumsum_excl_out(bsf, bsf, Nb, lane);
   __syncthreads();
-  const float tbg = det_exp(-sfe[S]);
+  const float tbg = sleef_expf(-sfe[S]);
   const float ds = a.depth_scale[r];
   float sw = 0.0f, swz = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, n0 = 0.0f, n1 = 0.0f, n2 = 0.0f, swa = 0.0f, swd = 0.0f;
   for (int i = lane; i < S; i += 64) {
     const size_t p = (size_t)r * S + i;
-    const float w = (1.0f - det_exp(-fe[i])) * det_exp(-sfe[i]);
+    const float w = (1.0f - sleef_expf(-fe[i])) * sleef_expf(-sfe[i]);
     a.weights[p] = w;
     const float dv = zs[i] * ds;
     a.depth_vals[p] = dv;
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(64) void composite_bg_kernel(CompositeBgArgs a) {
   float b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
   for (int i = lane; i < Nb; i += 64) {
     const size_t p = (size_t)r * Nb + i;
-    const float bw = (1.0f - det_exp(-bfe[i])) * det_exp(-bsf[i]);
+    const float bw = (1.0f - sleef_expf(-bfe[i])) * sleef_expf(-bsf[i]);
     a.bg_weights[p] = bw;
     b0 += bw * a.bg_rgb[3 * p]; b1 += bw * a.bg_rgb[3 * p + 1]; b2 += bw * a.bg_rgb[3 * p + 2];
     const float wa = tbg * bw;

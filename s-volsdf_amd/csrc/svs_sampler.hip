@@ -3,10 +3,11 @@
 // Reference: volsdf/model/ray_sampler.py:22-43 (UniformSampler), :67-219 (ErrorBoundSampler.get_z_vals),
 // :221-229 (get_error_bound); volsdf/model/density.py:21-30; volsdf/utils/rend_util.py:200-216.
 //
-// Numeric contract (DESIGN.md): float32 IEEE ops in the reference's order with no fma contraction (this
-// file is compiled with -ffp-contract=off), exp/expm1 = svs::det_exp/det_expm1, cumsum/sum accumulate in
-// float64 in the canonical blocked order (64 contiguous chunks, Kogge-Stone across lanes).  With that the
-// kernels reproduce oracle/svs_oracle.py bit for bit, indices included.
+// Numeric contract (DESIGN.md section 2): float32 IEEE ops in the reference's order with no fma contraction (this
+// file is compiled with -ffp-contract=off); exp / expm1 = svs::sleef_expf / sleef_expm1f (the Sleef u10 routines torch-CPU
+// evaluates, restated); the pdf's row sum = svs::aten_row_sum (ATen's cascade_sum order); cumsum accumulates in
+// float64 and rounds every prefix, as torch-CPU cumsum does (blocked over the 64 lanes).  With that the kernels
+// reproduce oracle/svs_oracle.py -- and through it the reference's CPU path -- bit for bit, indices included.
 //
 // Control flow: the reference's data-dependent `while` (batch-global `beta.max() > beta0`, :136) becomes
 // device-side flags: round-A kernels OR the per-ray convergence test into conv_flag[i], round-B kernels read
@@ -106,7 +107,7 @@ __device__ __forceinline__ float error_bound(RayLds& L, int n, float beta, int l
   const float four_b2 = 4.0f * (beta * beta);
   for (int i = lane; i < n; i += 64) {
     L.t0[i] = i == 0 ? 0.0f : L.dists[i - 1] * laplace_density(L.sdf[i - 1], beta);
-    if (i < n - 1) L.t1[i] = (det_exp(-L.dstar[i] / beta) * (L.dists[i] * L.dists[i])) / four_b2;
+    if (i < n - 1) L.t1[i] = (sleef_expf(-L.dstar[i] / beta) * (L.dists[i] * L.dists[i])) / four_b2;
   }
   __syncthreads();
   wave_cumsum(L.t0, L.t0, n, lane);
@@ -115,8 +116,8 @@ __device__ __forceinline__ float error_bound(RayLds& L, int n, float beta, int l
   float m = -__builtin_inff();
   bool has_nan = false;
   for (int i = lane; i < n - 1; i += 64) {
-    const float e = det_exp(L.t1[i]);
-    const float bo = ((e > 1.0e6f ? 1.0e6f : e) - 1.0f) * det_exp(-L.t0[i]);
+    const float e = sleef_expf(L.t1[i]);
+    const float bo = ((e > 1.0e6f ? 1.0e6f : e) - 1.0f) * sleef_expf(-L.t0[i]);
     has_nan |= (bo != bo);
     m = __builtin_fmaxf(m, bo);
   }
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(64) void init_kernel(InitArgs a) {
     if (i < n - 1) { const float d = zs[i + 1] - zs[i]; ds[i] = d * d; }
   }
   __syncthreads();
-  const float tot = wave_cumsum(ds, ds, n - 1, lane);
+  const float tot = aten_row_sum(ds, n - 1, lane);       // (dists ** 2).sum(-1), ray_sampler.py:77
   if (lane == 0) a.beta[r] = __builtin_sqrtf(a.inv_4log * tot);
 }
 
@@ -337,35 +338,35 @@ __global__ __launch_bounds__(64) void round_b_kernel(RoundArgs a) {
   __syncthreads();
   wave_cumsum(L.t0, L.t0, n, lane);
   __syncthreads();
-  for (int i = lane; i < n; i += 64) L.t0[i] = det_exp(-L.t0[i]);      // transmittance
+  for (int i = lane; i < n; i += 64) L.t0[i] = sleef_expf(-L.t0[i]);      // transmittance
   __syncthreads();
   const int N = upsample ? a.n_eval : a.n_final;
   if (upsample) {
     const float four_b2 = 4.0f * (beta * beta);
     for (int i = lane; i < n - 1; i += 64)
-      L.t1[i] = (det_exp(-L.dstar[i] / beta) * (L.dists[i] * L.dists[i])) / four_b2;
+      L.t1[i] = (sleef_expf(-L.dstar[i] / beta) * (L.dists[i] * L.dists[i])) / four_b2;
     __syncthreads();
     wave_cumsum(L.t1, L.t1, n - 1, lane);
     __syncthreads();
     for (int i = lane; i < n - 1; i += 64) {
-      const float e = det_exp(L.t1[i]);
+      const float e = sleef_expf(L.t1[i]);
       L.t1[i] = ((e > 1.0e6f ? 1.0e6f : e) - 1.0f) * L.t0[i] + a.add_tiny;
     }
   } else {
     for (int i = lane; i < n - 1; i += 64) {
       const float fe = L.dists[i] * laplace_density(L.sdf[i], beta);
-      const float w = (1.0f - det_exp(-fe)) * L.t0[i];
+      const float w = (1.0f - sleef_expf(-fe)) * L.t0[i];
       L.t1[i] = w + 1e-5f;
       if (a.dbg_weights) a.dbg_weights[(size_t)r * kCap + i] = w;
     }
   }
   __syncthreads();
   // pdf / sum, cdf = [0, cumsum(pdf)]  -> L.t1[0..n)
-  const float tot = wave_cumsum(L.t1, L.dstar, n - 1, lane);   // dstar no longer needed: holds cumsum(pdf) scratch
+  const float tot = aten_row_sum(L.t1, n - 1, lane);          // torch.sum(pdf, -1), ray_sampler.py:149,161
   __syncthreads();
   for (int i = lane; i < n - 1; i += 64) L.t1[i] = L.t1[i] / tot;
   __syncthreads();
-  wave_cumsum(L.t1, L.dstar, n - 1, lane);
+  wave_cumsum(L.t1, L.dstar, n - 1, lane);                    // dstar no longer needed: holds cumsum(pdf)
   __syncthreads();
   for (int i = lane; i < n; i += 64) {
     const float c = i == 0 ? 0.0f : L.dstar[i - 1];
@@ -479,7 +480,7 @@ int svs_sampler_round(int phase, int n_rays, int round, int max_iters, int n_eva
 // bit-exactness self-test hooks for the numeric contract (tests/test_gpu_numeric_contract.py)
 __global__ void selftest_exp_kernel(const float* x, float* y_exp, float* y_expm1, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { y_exp[i] = det_exp(x[i]); y_expm1[i] = det_expm1(x[i]); }
+  if (i < n) { y_exp[i] = sleef_expf(x[i]); y_expm1[i] = sleef_expm1f(x[i]); }
 }
 __global__ void selftest_arith_kernel(const float* a, const float* b, float* q, float* s, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -496,6 +497,20 @@ __global__ __launch_bounds__(64) void selftest_cumsum_kernel(const float* x, flo
   if (lane == 0) tot[blockIdx.x] = t;
 }
 
+__global__ __launch_bounds__(64) void selftest_rowsum_kernel(const float* x, float* tot, int m) {
+  extern __shared__ float rowbuf[];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < m; i += 64) rowbuf[i] = x[(size_t)blockIdx.x * m + i];
+  __syncthreads();
+  const float t = aten_row_sum(rowbuf, m, lane);
+  if (lane == 0) tot[blockIdx.x] = t;
+}
+
+int svs_selftest_rowsum(const float* x, float* tot, int rows, int m, void* hip_stream) {
+  if (m < 1 || m > 16000) { set_error("svs_selftest_rowsum: m out of range (1..16000)"); return SVS_ESHAPE; }
+  selftest_rowsum_kernel<<<rows, 64, (size_t)m * sizeof(float), (hipStream_t)hip_stream>>>(x, tot, m);
+  return check_launch("svs_selftest_rowsum");
+}
 int svs_selftest_exp(const float* x, float* y_exp, float* y_expm1, int n, void* hip_stream) {
   selftest_exp_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)hip_stream>>>(x, y_exp, y_expm1, n);
   return check_launch("svs_selftest_exp");

@@ -145,6 +145,7 @@ SIGNATURES = {
     "svs_selftest_exp": (c_int, [_P, _P, _P, c_int, _P]),
     "svs_selftest_arith": (c_int, [_P, _P, _P, _P, c_int, _P]),
     "svs_selftest_cumsum": (c_int, [_P, _P, _P, c_int, c_int, _P]),
+    "svs_selftest_rowsum": (c_int, [_P, _P, c_int, c_int, _P]),
 }
 
 

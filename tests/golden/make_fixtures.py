@@ -19,6 +19,10 @@ import synth     # noqa: E402
 ref_shim.install()
 import torch  # noqa: E402
 
+# torch.exp of the reference bound to torch's open-source exp (Sleef_expf8_u10) instead of the host-dependent,
+# closed-source MKL VML routine -- see ref_shim.pin_open_exp; fx_sampler_hostexp lifts the pin for its cross-check
+UNPIN_EXP = ref_shim.pin_open_exp()
+
 torch.set_num_threads(4)
 F32 = np.float32
 
@@ -267,6 +271,71 @@ def fx_sampler_r256():
         out = m(inp, fast=-1)
         save(f"forward256_b{beta}", K=K, pose=pose, uv=uv, beta_param=F32(beta), fast=-1,
              **{k: out[k].detach().numpy() for k in ("rgb_values", "depth_values", "normal_map", "depth_vals", "weights")})
+
+
+def fx_primitives():
+    """What torch's own OPEN routines return for the three primitives the sampler's bit-exactness hangs on, so that the
+    restatements in oracle/svs_oracle.py (and the device functions behind `svs_test_primitives`) are pinned on any host:
+    Sleef_expf8_u10 and Sleef_expm1f8_u10 as exported by libtorch_cpu.so, and torch.sum(dim=-1) on float32 rows of every
+    length 1..160 plus the sampler's lengths up to 640 and two long rows that exercise the cascade levels."""
+    rng = np.random.default_rng(17)
+    n = 1 << 13
+    x = np.concatenate([-rng.random(n) * 20, rng.random(n // 2) * 14, -np.exp(rng.random(n) * 30 - 25),
+                        rng.standard_normal(n // 2) * 1e-3, -rng.random(n // 4) * 110, rng.random(n // 4) * 95,
+                        [0, -0.0, 1e-45, -1e-45, 88.7, 88.73, 100, 100.5, -104, -104.5, -103.9, -87.5, -16.635,
+                         -16.636, 1e-30, -1e-30, np.inf, -np.inf, 16.0, -1.0]]).astype(F32)
+    arr = dict(x=x, expf=ref_shim.torch_vec8("Sleef_expf8_u10")(x), expm1f=ref_shim.torch_vec8("Sleef_expm1f8_u10")(x))
+    assert np.array_equal(arr["expm1f"].view(np.uint32), torch.expm1(T(x)).numpy().view(np.uint32))   # torch.expm1 IS that routine
+    lens = list(range(1, 161)) + [254, 255, 256, 382, 383, 384, 510, 511, 512, 513, 638, 639, 640, 641, 1023, 1024, 1025,
+                                  2047, 4100, 20001]
+    rows, sums = [], []
+    for m in lens:
+        nr = 8 if m <= 160 else (2 if m <= 641 else 1)
+        r = (rng.random((nr, m)) * np.exp(rng.random((nr, 1)) * 12 - 8)).astype(F32)
+        rows.append(r.ravel()); sums.append(torch.sum(T(r), -1).numpy())
+    arr.update(sum_lens=np.asarray(lens), sum_rows=np.concatenate(rows), sum_out=np.concatenate(sums))
+    save("primitives", **arr)
+
+
+def fx_sampler_hostexp():
+    """The UNPINNED reference (torch.exp = this host's MKL VML kernel) on 64 rays, beta = 0.01, fast = -1, in the compact
+    layout of fx_sampler_r256, plus a probe of the host's exp (inputs and outputs): a test that finds the same exp on its
+    host binds it into the oracle and must then reproduce these indices and cdf entries exactly -- the proof that the
+    restated sum and expm1 are the reference's and that exp is the only host-dependent primitive."""
+    global UNPIN_EXP
+    UNPIN_EXP()
+    try:
+        params = synth.make_params(seed=0)
+        K, pose = synth.make_camera(center=(0.1, 0.05, -2.5), tilt=0.1)
+        R = 64
+        uv = synth.make_uv(R, seed=22, margin=0.05)
+        import oracle_path  # noqa
+        from svs_oracle import rays_from_uv
+        dirs, cam, _ = rays_from_uv(uv, pose, K)
+        cam_r = np.repeat(cam[None], R, 0).astype(F32)
+        rng = np.random.default_rng(5)
+        probe = np.concatenate([-rng.random(4096) * 20, rng.random(2048) * 14, -np.exp(rng.random(2048) * 20 - 15)]).astype(F32)
+        for beta in (0.01,):
+            m = build_model(params, beta=beta)
+            z, z_eik, rec, sdfs = run_sampler(m, dirs, cam_r, -1, False)
+            arr = dict(dirs=dirs, cam=cam_r, beta_param=F32(beta), fast=-1, z=z.numpy(), n_rounds=len(sdfs),
+                       inv_4log=(1.0 / (4.0 * torch.log(torch.tensor(0.1 + 1.0)))).numpy(),
+                       exp_probe_in=probe, exp_probe_out=torch.exp(T(probe)).numpy(),
+                       sqrt_probe_in=np.abs(probe), sqrt_probe_out=torch.sqrt(T(np.abs(probe))).numpy())
+            for i, sd in enumerate(sdfs):
+                arr[f"sdf_{i}"] = sd.reshape(R, -1)
+                arr[f"beta_{i}"] = rec.betas[i]
+            for i, a in enumerate(rec.inds):
+                cdf = rec.cdf[i]
+                n = cdf.shape[1]
+                arr[f"inds_{i}"] = a.astype(np.uint16)
+                arr[f"cdf_lo_{i}"] = np.take_along_axis(cdf, np.maximum(a - 1, 0), 1)
+                arr[f"cdf_hi_{i}"] = np.take_along_axis(cdf, np.minimum(a, n - 1), 1)
+            for i in range(len(rec.sort_idx) - 1):
+                arr[f"samples_idx_{i}"] = rec.sort_idx[i].astype(np.uint16); arr[f"zmerged_{i}"] = rec.sort_vals[i]
+            save(f"sampler64_hostexp_b{beta}", **arr)
+    finally:
+        UNPIN_EXP = ref_shim.pin_open_exp()
 
 
 def fx_composite():
@@ -804,7 +873,7 @@ ALL = dict(fusion=fx_fusion, pfm=fx_pfm, chamfer=fx_chamfer, chamfer_mesh=fx_cha
            train_step_w1=lambda: fx_train_step(16, 2, "train_step_w1", "w1"),
            train_step_bg=fx_train_step_bg,
            train_step_bg_sparse=lambda: fx_train_step_bg("train_step_bg_sparse", 50, 1e3, 1),
-           sampler_r256=fx_sampler_r256)
+           sampler_r256=fx_sampler_r256, sampler_hostexp=fx_sampler_hostexp, primitives=fx_primitives)
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(ALL)

@@ -109,19 +109,19 @@ def test_bg_model_forward_golden(dev, golden_dir, tag):
         else:
             out = m(inp, fast=int(g["fast"]))
     out = {k: v.detach().cpu().numpy() for k, v in out.items()}
-    same = np.abs(out["depth_vals"] - g["depth_vals"]).max(-1) < 3e-4
-    assert same.mean() >= 0.75, same
-    np.testing.assert_allclose(out["xyz"][same], g["xyz"][same], atol=3e-4)
-    np.testing.assert_allclose(out["rgb_values"][same], g["rgb_values"][same], atol=1e-4)
-    np.testing.assert_allclose(out["rgb_values"], g["rgb_values"], atol=5e-4)
-    assert np.abs(out["weights"][same] - g["weights"][same]).mean() < 2e-5
+    # every ray; per-sample arrays where the sample did not move (tests/test_gpu_parity.py::_moved)
+    moved = np.abs(out["depth_vals"] - g["depth_vals"]) > 3e-4
+    assert moved.mean() < 0.06 and max(out["weights"][moved].max(initial=0.0), g["weights"][moved].max(initial=0.0)) < 1e-4
+    np.testing.assert_allclose(out["xyz"][~moved], g["xyz"][~moved], atol=3e-4)
+    np.testing.assert_allclose(out["rgb_values"], g["rgb_values"], atol=1e-4)
+    assert np.abs(out["weights"][~moved] - g["weights"][~moved]).mean() < 2e-5
     wsum = g["weights"].sum(1, keepdims=True)
-    assert (np.abs(out["depth_values"] - g["depth_values"])[same] <= 3e-4 / np.maximum(wsum[same], 1e-3)).all()
-    np.testing.assert_allclose(out["depth_values_all"][same], g["depth_values_all"][same], rtol=3e-3)
+    assert (np.abs(out["depth_values"] - g["depth_values"]) <= 3e-4 / np.maximum(wsum, 1e-3)).all()
+    np.testing.assert_allclose(out["depth_values_all"], g["depth_values_all"], rtol=3e-3)
     if training:
         np.testing.assert_allclose(out["grad_theta"][:R], g["grad_theta"][:R], atol=2e-4)
     else:
-        np.testing.assert_allclose(out["normal_map"][same], g["normal_map"][same], atol=2e-4)
+        np.testing.assert_allclose(out["normal_map"], g["normal_map"], atol=2e-4)
 
 
 def _rel(a, b):

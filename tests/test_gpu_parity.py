@@ -53,10 +53,31 @@ def G(a, dev):
 
 
 # ------------------------------------------------------------------------------------------------------
-def test_numeric_contract_exp(dev):
+def test_numeric_contract_exp(dev, golden_dir):
     import ctypes
     from svs_hip import lib
     L = lib.load()
+    # the device's exp / expm1 / row sum against what torch's own routines returned (fixture `primitives`)
+    g = dict(np.load(os.path.join(golden_dir, "primitives.npz")))
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    xd = G(g["x"], dev)
+    y1, y2 = torch.empty_like(xd), torch.empty_like(xd)
+    lib.check(L.svs_selftest_exp(P(xd), P(y1), P(y2), xd.numel(), s))
+    for mine, ref in ((y1.cpu().numpy(), g["expf"]), (y2.cpu().numpy(), g["expm1f"])):
+        ok = (mine.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(mine) & np.isnan(ref))
+        assert ok.all(), (g["x"][~ok][:8], mine[~ok][:8], ref[~ok][:8])
+    off = o = 0
+    for m in g["sum_lens"]:
+        m = int(m)
+        nr = 8 if m <= 160 else (2 if m <= 641 else 1)
+        if m <= 16000:
+            rows = G(g["sum_rows"][off:off + nr * m].reshape(nr, m), dev)
+            tg = torch.empty(nr, device=dev)
+            lib.check(L.svs_selftest_rowsum(P(rows), P(tg), nr, m, s))
+            assert np.array_equal(tg.cpu().numpy(), g["sum_out"][o:o + nr]), m
+        off += nr * m
+        o += nr
     rng = np.random.default_rng(0)
     x = np.concatenate([rng.uniform(-104, 89, 200000), -np.logspace(-12, 2, 20000), rng.normal(0, 1e-6, 1000),
                         [0.0, -0.0, 88.7228, 88.73, -103.9, -104.1, np.inf, -np.inf]]).astype(F32)
@@ -65,8 +86,8 @@ def test_numeric_contract_exp(dev):
     s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     P = lambda t: ctypes.c_void_p(t.data_ptr())
     lib.check(L.svs_selftest_exp(P(xd), P(y1), P(y2), x.size, s))
-    assert np.array_equal(y1.cpu().numpy().view(np.uint32), orc.det_exp(x).view(np.uint32))
-    assert np.array_equal(y2.cpu().numpy().view(np.uint32), orc.det_expm1(x).view(np.uint32))
+    assert np.array_equal(y1.cpu().numpy().view(np.uint32), orc.ref_exp(x).view(np.uint32))
+    assert np.array_equal(y2.cpu().numpy().view(np.uint32), orc.ref_expm1(x).view(np.uint32))
     # IEEE float32 division and sqrt are correctly rounded on the device
     a = (rng.normal(0, 1, 300000) * 10.0 ** rng.integers(-20, 20, 300000)).astype(F32)
     b = (rng.normal(0, 1, 300000) * 10.0 ** rng.integers(-20, 20, 300000)).astype(F32)
@@ -82,7 +103,8 @@ def test_numeric_contract_exp(dev):
         yg, tg = torch.empty_like(xg), torch.empty(37, device=dev)
         lib.check(L.svs_selftest_cumsum(P(xg), P(yg), P(tg), 37, m, s))
         assert np.array_equal(yg.cpu().numpy().view(np.uint32), orc.canon_cumsum(xx).view(np.uint32)), m
-        assert np.array_equal(tg.cpu().numpy().view(np.uint32), orc.canon_sum(xx)[:, 0].view(np.uint32)), m
+        lib.check(L.svs_selftest_rowsum(P(xg), P(tg), 37, m, s))
+        assert np.array_equal(tg.cpu().numpy().view(np.uint32), orc.ref_sum(xx)[:, 0].view(np.uint32)), m
 
 
 def test_rays(dev, ops, golden_dir):
@@ -234,9 +256,11 @@ def test_sampler_bit_exact(dev, ops, packed, beta_param, fast, training):
         assert np.array_equal(z_eik.cpu().numpy().view(np.uint32), zeik_ref.view(np.uint32))
 
 
-@pytest.mark.parametrize("name", ["sampler_eval_b0.1_f-1", "sampler_eval_b0.01_f-1", "sampler_eval_b0.01_f2"])
+@pytest.mark.parametrize("name", ["sampler_eval_b0.1_f-1", "sampler_eval_b0.01_f-1", "sampler_eval_b0.01_f2", "sampler_eval_b0.001_f-1",
+                                  "sampler_eval_b0.01_f0", "sampler_eval_b0.01_f1"])
 def test_sampler_golden_chain(dev, ops, packed, golden_dir, name):
-    """HIP sampler on the reference's own per-round sdf (fixture): well-conditioned cases reproduce its z."""
+    """HIP sampler, all rounds chained, on the reference's own per-round sdf (fixture): the final sample set is the
+    REFERENCE's bit for bit on every ray."""
     pk, _ = packed
     g = dict(np.load(os.path.join(golden_dir, name + ".npz")))
     nr = int(g["n_rounds"])
@@ -244,21 +268,15 @@ def test_sampler_golden_chain(dev, ops, packed, golden_dir, name):
                            scene_bounding_sphere=3.0, sphere_scale=20.0, sdf_clamp_radius=3.0, fast=int(g["fast"]),
                            inv_4log=float(g["inv_4log"]),
                            sdf_override=[G(g[f"sdf_{i}"].reshape(g["dirs"].shape[0], -1), dev) for i in range(nr)])
-    z = z.cpu().numpy()
-    same = np.abs(z - g["z"]).max(-1) < 3e-4
-    # deterministic (the reference's own sdf values go in; the kernels are bit-identical to the oracle): the count of rays
-    # without a near-tie flip is pinned.  b = 0.01 with the full five rounds compounds the flips of every round.
-    expect = {"sampler_eval_b0.1_f-1": 12, "sampler_eval_b0.01_f-1": 9, "sampler_eval_b0.01_f2": 12}[name]
-    assert int(same.sum()) >= expect, f"{name}: {int(same.sum())}/{same.size} rays reproduce the reference's final samples, expected {expect}"
+    assert np.array_equal(z.cpu().numpy().view(np.uint32), g["z"].view(np.uint32))
 
 
 @pytest.mark.parametrize("beta", ["0.1", "0.01", "0.001"])
 def test_sampler_r256_on_reference_sdf(dev, ops, packed, golden_dir, beta):
-    """256 rays, all rounds, on the REFERENCE's per-round sdf values (fixture sampler256_*): the HIP sampler equals the oracle's
-    chain bit for bit (bins, beta, cdf, every index, final z).  The oracle's indices are held against the reference's one by one
-    in tests/test_oracle_golden.py::test_sampler_r256_indices (every difference a near-tie, <= 0.2 % of the indices); with the
-    bit-equality here that statement carries over to the kernels.  The rays that reproduce the reference's final samples are
-    counted as well."""
+    """256 rays, all rounds (5 at beta <= 0.01), on the REFERENCE's per-round sdf values (fixture sampler256_*), checked
+    against the REFERENCE itself: every searchsorted index (49 152 / 147 456 / 147 456), the cdf entries that bracket every
+    u, beta per round, the merged bins and the final sample set of all 256 rays are the reference's, bit for bit -- and the
+    oracle's chain likewise."""
     pk, params = packed
     g = dict(np.load(os.path.join(golden_dir, f"sampler256_b{beta}.npz")))
     R, nr = g["dirs"].shape[0], int(g["n_rounds"])
@@ -271,36 +289,53 @@ def test_sampler_r256_on_reference_sdf(dev, ops, packed, golden_dir, beta):
                            scene_bounding_sphere=3.0, sphere_scale=20.0, sdf_clamp_radius=3.0, fast=-1,
                            inv_4log=float(g["inv_4log"]), debug=dbg, sdf_override=[G(t, dev) for t in sdfs])
     torch.cuda.synchronize()
-    assert len(dbg["rounds"]) >= len(trace)
+    assert len(dbg["rounds"]) >= len(trace) == nr
+    n_idx = 0
     for i, t in enumerate(trace):
         d, n, N = dbg["rounds"][i], t["n"], t["inds"].shape[1]
-        assert np.array_equal(d["beta"].cpu().numpy().view(np.uint32), t["beta"].view(np.uint32)), f"round {i} beta"
-        assert np.array_equal(d["cdf"].cpu().numpy()[:, :n].view(np.uint32), t["cdf"].view(np.uint32)), f"round {i} cdf"
-        assert np.array_equal(d["inds"].cpu().numpy()[:, :N].astype(np.int64), t["inds"]), f"round {i} inds"
+        ref = g[f"inds_{i}"].astype(np.int64)
+        inds = d["inds"].cpu().numpy()[:, :N].astype(np.int64)
+        cdf = d["cdf"].cpu().numpy()[:, :n]
+        assert np.array_equal(d["beta"].cpu().numpy().view(np.uint32), g[f"beta_{i}"].view(np.uint32)), f"round {i} beta"
+        assert np.array_equal(inds, ref), f"round {i}: {(inds != ref).sum()} indices differ from the reference's"
+        assert np.array_equal(np.take_along_axis(cdf, np.maximum(ref - 1, 0), 1), g[f"cdf_lo_{i}"]), f"round {i} cdf"
+        assert np.array_equal(np.take_along_axis(cdf, np.minimum(ref, n - 1), 1), g[f"cdf_hi_{i}"]), f"round {i} cdf"
+        assert np.array_equal(cdf.view(np.uint32), t["cdf"].view(np.uint32)), f"round {i} cdf vs oracle"
+        if f"zmerged_{i}" in g and i + 1 < nr:
+            assert np.array_equal(dbg["rounds"][i + 1]["z"].cpu().numpy()[:, :n + N], g[f"zmerged_{i}"]), f"round {i} merged bins"
+        n_idx += ref.size
     assert np.array_equal(z.cpu().numpy().view(np.uint32), z_ref.view(np.uint32))
-    same = np.abs(z.cpu().numpy() - g["z"]).max(-1) < 3e-4
-    print(f"sampler256_b{beta}: {int(same.sum())}/{R} rays reproduce the reference's final samples")
-    assert same.sum() >= {"0.1": 250, "0.01": 190, "0.001": 160}[beta]
+    assert np.array_equal(z.cpu().numpy().view(np.uint32), g["z"].view(np.uint32))
+    print(f"sampler256_b{beta}: 0 of {n_idx} indices differ from the reference's; 256/256 rays reproduce its final samples bit for bit")
+
+
+def _moved(out, g, tol=3e-4):
+    """Samples whose position differs from the reference's: the fused MLP's sdf values differ from torch's in their last
+    bits (as any two evaluation orders do), and where the cdf is flat -- transmittance ~ 0 behind the surface, denom clamped
+    to 1e-5 -- the inverse-CDF map turns one ulp of cdf into up to 1e-2 of a bin.  Such samples carry no weight."""
+    moved = np.abs(out["depth_vals"] - g["depth_vals"]) > tol
+    assert g["weights"][moved].max(initial=0.0) < 1e-4 and out["weights"][moved].max(initial=0.0) < 1e-4, \
+        (g["weights"][moved].max(initial=0.0), out["weights"][moved].max(initial=0.0))
+    return moved
 
 
 @pytest.mark.parametrize("beta", ["0.1", "0.01", "0.001"])
 def test_model_forward_r256(dev, golden_dir, beta):
-    """VolSDFNetwork.forward (HIP, eval, fast = -1) on 256 rays against the reference (fixture forward256_*): colours to 1e-4 and
-    depths to 2e-4 on the rays whose samples coincide with the reference's, and the stated bounds on ALL rays."""
+    """VolSDFNetwork.forward (HIP, eval, fast = -1, up to five sampler rounds) on 256 rays against the reference (fixture
+    forward256_*): colours to 1e-4, depths and normals to 2e-4 on EVERY ray."""
     g = dict(np.load(os.path.join(golden_dir, f"forward256_b{beta}.npz")))
     m, _ = _model(dev, float(g["beta_param"]))
     m.eval()
     inp = {"intrinsics": G(g["K"], dev)[None], "uv": G(g["uv"], dev)[None], "pose": G(g["pose"], dev)[None]}
     with torch.no_grad():
         out = {k: v.cpu().numpy() for k, v in m(inp, fast=-1).items() if torch.is_tensor(v)}
-    same = np.abs(out["depth_vals"] - g["depth_vals"]).max(-1) < 3e-4
-    err_same = float(np.abs(out["rgb_values"] - g["rgb_values"])[same].max())
-    err_all = float(np.abs(out["rgb_values"] - g["rgb_values"]).max())
-    print(f"forward256_b{beta}: {int(same.sum())}/256 rays with the reference's samples; rgb max err {err_same:.2e} on those, {err_all:.2e} on all")
-    assert same.sum() >= {"0.1": 245, "0.01": 185, "0.001": 150}[beta]
-    assert err_same < 1e-4 and err_all < 5e-4
-    np.testing.assert_allclose(out["depth_values"].reshape(-1)[same], g["depth_values"].reshape(-1)[same], atol=2e-4)
-    np.testing.assert_allclose(out["normal_map"][same], g["normal_map"][same], atol=2e-4)
+    moved = _moved(out, g, 5e-3)
+    print(f"forward256_b{beta}: max err on ALL 256 rays: rgb {np.abs(out['rgb_values'] - g['rgb_values']).max():.2e}, "
+          f"depth {np.abs(out['depth_values'].reshape(-1) - g['depth_values'].reshape(-1)).max():.2e}, "
+          f"normal {np.abs(out['normal_map'] - g['normal_map']).max():.2e}; {int(moved.sum())} weightless samples moved")
+    np.testing.assert_allclose(out["rgb_values"], g["rgb_values"], atol=1e-4)
+    np.testing.assert_allclose(out["depth_values"].reshape(-1), g["depth_values"].reshape(-1), atol=2e-4)
+    np.testing.assert_allclose(out["normal_map"], g["normal_map"], atol=2e-4)
 
 
 def test_sampler_end_to_end(dev, ops, packed):
@@ -331,17 +366,10 @@ def _model(dev, beta, wset="w0"):
     return m.to(dev), params
 
 
-# rays of each fixture whose sample positions coincide with the reference's (the others carry a near-tie flip of one
-# inverse-CDF index: the reference normalises its pdf with a vectorised float32 sum).  The HIP sampler equals the numpy
-# oracle bit for bit, and the oracle's counts are deterministic (tests/test_oracle_golden.py::test_forward pins them).
-SAME_RAYS = {"eval_b0.1": 11, "eval_b0.01": 9, "eval_b0.01_f1": 12, "train": 12, "w1_eval": 9, "w1_train": 12}
-
-
 @pytest.mark.parametrize("tag", ["eval_b0.1", "eval_b0.01", "eval_b0.01_f1", "train", "w1_eval", "w1_train"])
 def test_model_forward_golden(dev, golden_dir, tag):
-    """VolSDFNetwork.forward (HIP) against the reference's outputs (fixtures; w1_*: the trained-scale weight set).
-    rgb/depth <= 1e-4 on the rays whose sample positions coincide (a near-tie flip in the sampler moves a sample by up
-    to one bin)."""
+    """VolSDFNetwork.forward (HIP) against the reference's outputs (fixtures; w1_*: the trained-scale weight set):
+    colours to 1e-4, depths / normals to 2e-4 on every ray; per-sample arrays where the sample did not move (`_moved`)."""
     g = dict(np.load(os.path.join(golden_dir, "forward_" + tag + ".npz")))
     m, _ = _model(dev, float(g["beta_param"]), "w1" if tag.startswith("w1") else "w0")
     training = tag.endswith("train")
@@ -357,37 +385,32 @@ def test_model_forward_golden(dev, golden_dir, tag):
     else:
         out = m(inp, fast=int(g["fast"]))
     out = {k: v.detach().cpu().numpy() for k, v in out.items()}
-    same = np.abs(out["depth_vals"] - g["depth_vals"]).max(-1) < 3e-4
-    # (the fused MLP's sdf differs from numpy's by ~2e-6, which can flip one more near-tie than the oracle's own count)
-    print(f"forward_{tag}: {int(same.sum())}/{same.size} rays with the reference's sample positions (oracle: {SAME_RAYS[tag]})")
-    assert int(same.sum()) >= SAME_RAYS[tag] - 1, (f"forward_{tag}: {int(same.sum())}/{same.size} rays with the reference's "
-                                                   f"sample positions, the oracle has {SAME_RAYS[tag]}")
-    np.testing.assert_allclose(out["xyz"][same], g["xyz"][same], atol=3e-4)
-    np.testing.assert_allclose(out["rgb_values"][same], g["rgb_values"][same], atol=1e-4)
-    np.testing.assert_allclose(out["depth_values"][same], g["depth_values"][same], atol=2e-4)
-    np.testing.assert_allclose(out["rgb_values"], g["rgb_values"], atol=5e-4)
-    assert np.abs(out["weights"][same] - g["weights"][same]).mean() < 2e-5
+    moved = _moved(out, g)
+    print(f"forward_{tag}: {int(moved.sum())} of {moved.size} samples moved (weightless); rgb max err on all rays "
+          f"{np.abs(out['rgb_values'] - g['rgb_values']).max():.2e}")
+    assert moved.mean() < 0.06
+    np.testing.assert_allclose(out["xyz"][~moved], g["xyz"][~moved], atol=3e-4)
+    np.testing.assert_allclose(out["rgb_values"], g["rgb_values"], atol=1e-4)
+    np.testing.assert_allclose(out["depth_values"], g["depth_values"], atol=2e-4)
+    assert np.abs(out["weights"][~moved] - g["weights"][~moved]).mean() < 2e-5
     if training:
         np.testing.assert_allclose(out["grad_theta"][:R], g["grad_theta"][:R], atol=2e-4)
     else:
-        np.testing.assert_allclose(out["normal_map"][same], g["normal_map"][same], atol=2e-4)
+        np.testing.assert_allclose(out["normal_map"], g["normal_map"], atol=2e-4)
 
 
 def test_model_forward_vs_oracle_1024(dev):
-    """Full-size batch (1024 rays): integrated outputs against the oracle within 1e-4 on matching rays."""
+    """Full-size batch (1024 rays): integrated outputs against the oracle within 1e-4 / 2e-4 on every ray."""
     m, params = _model(dev, 0.1)
     m.eval()
     K, pose = synth.make_camera()
     uv = synth.make_uv(1024, seed=31)
     inp = {"intrinsics": G(K, dev)[None], "uv": G(uv, dev)[None], "pose": G(pose, dev)[None]}
-    out = m(inp, fast=1)
+    out = {k: v.cpu().numpy() for k, v in m(inp, fast=1).items() if torch.is_tensor(v)}
     ref = orc.render_forward(params, uv, pose, K, beta_param=F32(0.1), fast=1)
-    same = np.abs(out["depth_vals"].cpu().numpy() - ref["depth_vals"]).max(-1) < 3e-4
-    # the sampler is bit-identical to the oracle given the same sdf values; the MLP's are equal to ~2e-6, which flips an
-    # index only at a near-tie: observed 1007 ... 1024 of 1024 rays
-    assert same.mean() >= 0.975, f"{int(same.sum())}/1024 rays with the oracle's sample positions"
-    np.testing.assert_allclose(out["rgb_values"].cpu().numpy()[same], ref["rgb_values"][same], atol=1e-4)
-    np.testing.assert_allclose(out["depth_values"].cpu().numpy()[same], ref["depth_values"][same], atol=2e-4)
+    _moved(out, ref)
+    np.testing.assert_allclose(out["rgb_values"], ref["rgb_values"], atol=1e-4)
+    np.testing.assert_allclose(out["depth_values"], ref["depth_values"], atol=2e-4)
 
 
 # ------------------------------------------------------------------------------------------------------

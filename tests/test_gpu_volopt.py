@@ -111,8 +111,8 @@ def test_volopt_run_render_resume(tmp_path, monkeypatch):
     dv, acc, same = np.concatenate(dv) * v.scale_factor, np.concatenate(acc), np.concatenate(same)
     ref_depth = np.where(acc < 0.2, dv.max(), dv).reshape(24, 32)
     got_depth = depth[0].cpu().numpy()
-    ok = same.reshape(24, 32) & (np.abs(acc - 0.2).reshape(24, 32) > 1e-3)      # same samples, away from the mask threshold
-    assert ok.mean() > 0.85, ok.mean()
+    ok = np.abs(acc - 0.2).reshape(24, 32) > 1e-3                               # every pixel away from the mask threshold
+    assert ok.mean() > 0.95, ok.mean()
     assert float(np.abs(got_depth - ref_depth)[ok].max()) < 3e-4 * max(1.0, float(v.scale_factor))
 
     # resume: a second VolOpt picks the latest run folder and continues from its checkpoints

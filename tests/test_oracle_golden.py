@@ -16,20 +16,53 @@ def load(golden_dir, name):
     return dict(np.load(os.path.join(golden_dir, name + ".npz")))
 
 
-def test_det_exp_matches_libm():
-    x = np.concatenate([np.linspace(-104, 89, 20001), [-1e-8, 0.0, 1e-8, -200.0, 100.0, np.inf, -np.inf]]).astype(F32)
-    y = orc.det_exp(x)
+def test_exp_restatements_within_one_ulp_of_libm():
+    x = np.concatenate([np.linspace(-104, 89, 20001), [-1e-8, 0.0, 1e-8, -200.0, 100.5, np.inf, -np.inf]]).astype(F32)
+    y = orc.ref_exp(x)
     ref = np.exp(x.astype(np.float64))
     with np.errstate(over="ignore"):
         ref32 = ref.astype(F32)
     fin = np.isfinite(ref32) & (ref32 > 1e-37)
     ulp = np.abs(y[fin].astype(np.float64) - ref[fin]) / np.spacing(ref32[fin]).astype(np.float64)
-    assert ulp.max() <= 0.5000001
+    assert ulp.max() <= 1.0                     # Sleef's u10 bound
     assert y[-1] == 0.0 and np.isinf(y[-2]) and y[-4] == 0.0 and np.isinf(y[-3])
     xm = np.concatenate([-np.logspace(-12, 2, 4000), np.logspace(-12, 1, 500)]).astype(F32)
-    ym = orc.det_expm1(xm)
+    ym = orc.ref_expm1(xm)
     refm = np.expm1(xm.astype(np.float64))
     assert np.max(np.abs(ym - refm) / np.abs(refm)) < 1.2e-7
+
+
+def test_primitives_bit_equal_torch_routines(golden_dir):
+    """The three primitives the sampler's bit-exactness hangs on, against what torch's own routines returned in the
+    build container (fixture `primitives`, make_fixtures.py::fx_primitives): Sleef_expf8_u10 / Sleef_expm1f8_u10 as
+    exported by libtorch_cpu.so (torch.expm1 IS the latter; torch.exp is pinned to the former, see svs_oracle's
+    docstring) and torch.sum(dim=-1) for rows of every length 1..160, the sampler's lengths and rows long enough to
+    fold two cascade levels."""
+    g = load(golden_dir, "primitives")
+    x = g["x"]
+    for mine, ref in ((orc.sleef_expf(x), g["expf"]), (orc.sleef_expm1f(x), g["expm1f"])):
+        both_nan = np.isnan(mine) & np.isnan(ref)
+        assert np.array_equal(mine.view(np.uint32)[~both_nan], ref.view(np.uint32)[~both_nan])
+    off = o = 0
+    for m in g["sum_lens"]:
+        nr = 8 if m <= 160 else (2 if m <= 641 else 1)
+        rows = g["sum_rows"][off:off + nr * m].reshape(nr, m)
+        assert np.array_equal(orc.aten_sum(rows)[:, 0], g["sum_out"][o:o + nr]), m
+        off += nr * m
+        o += nr
+
+
+def test_primitives_against_this_hosts_torch():
+    """Same, live, where torch is importable: torch.expm1 and torch.sum are the restated routines on every x86-64 host
+    (expm1: Sleef; sum: the AVX2 kernel also serves AVX-512 hosts).  torch.exp / torch.sqrt are NOT compared -- in an
+    MKL build they are host-dependent closed-source routines (test_sampler_hostexp covers them)."""
+    import torch
+    rng = np.random.default_rng(3)
+    x = np.concatenate([-rng.random(20000) * 30, rng.random(5000) * 20, rng.standard_normal(5000) * 1e-4]).astype(F32)
+    assert np.array_equal(orc.sleef_expm1f(x).view(np.uint32), torch.expm1(torch.from_numpy(x)).numpy().view(np.uint32))
+    for m in list(range(1, 130)) + [255, 383, 511, 639, 640, 5000]:
+        r = (rng.random((16, m)) * np.exp(rng.random((16, 1)) * 12 - 8)).astype(F32)
+        assert np.array_equal(orc.aten_sum(r)[:, 0], torch.sum(torch.from_numpy(r), -1).numpy()), m
 
 
 def test_canon_cumsum_is_f64_cumsum():
@@ -119,7 +152,7 @@ def _replay_rounds(g, training=False, rng=None):
     if z.shape[0] == 1:
         z = np.repeat(z, R, 0)
     d = z[:, 1:] - z[:, :-1]
-    beta_in = np.sqrt(F32(g["inv_4log"]) * orc.canon_sum(d * d)[:, 0]).astype(F32)
+    beta_in = orc.ref_sqrt((F32(g["inv_4log"]) * orc.ref_sum(d * d)[:, 0]).astype(F32))
     sdf = None
     for i in range(nr):
         new_sdf = g[f"sdf_{i}"].reshape(R, -1)
@@ -133,42 +166,29 @@ def _replay_rounds(g, training=False, rng=None):
 
 
 def _check_inds(rec, g, i):
-    """searchsorted indices equal the reference's, except where u sits within 1.5e-6 of a cdf entry: the
-    reference normalises the pdf with a vectorised float32 sum (error ~ sqrt(n) ulp) and Sleef
-    exp; the oracle with a float64 sum and a correctly rounded exp -- DESIGN.md 'numeric contract'."""
-    ref_inds, ref_cdf = g[f"inds_{i}"], g[f"cdf_{i}"]
-    np.testing.assert_allclose(rec["cdf"], ref_cdf, atol=1.5e-6)
-    r, j = np.nonzero(rec["inds"] != ref_inds)
-    for rr, jj in zip(r, j):
-        lo, hi = sorted((int(rec["inds"][rr, jj]), int(ref_inds[rr, jj])))
-        assert np.all(np.abs(ref_cdf[rr, lo:hi] - rec["u"][rr, jj]) <= 1.5e-6), (i, rr, jj, lo, hi)
-    return len(r)
+    """searchsorted indices and the whole cdf equal the reference's bit for bit (the reference's primitives are restated
+    exactly: svs_oracle's docstring)."""
+    assert np.array_equal(rec["cdf"], g[f"cdf_{i}"]), i
+    assert np.array_equal(rec["inds"], g[f"inds_{i}"]), i
+    return 0
 
 
 @pytest.mark.parametrize("name", SAMPLER_FX)
 def test_sampler_eval_rounds(golden_dir, name):
+    """Every round of the reference's eval sampler replayed from the reference's state: beta, cdf, indices and the merged
+    bins are the reference's bit for bit."""
     g = load(golden_dir, name)
-    flips, total = 0, 0
     for i, rec in _replay_rounds(g):
-        np.testing.assert_allclose(rec["beta"], g[f"beta_{i}"], rtol=2e-3)   # one bisection step = 2^-10
-        assert (np.abs(rec["beta"] - g[f"beta_{i}"]) > 1e-6 * g[f"beta_{i}"]).mean() <= 0.1
-        flips += _check_inds(rec, g, i)
-        total += rec["inds"].size
+        assert np.array_equal(rec["beta"], g[f"beta_{i}"]), i
+        _check_inds(rec, g, i)
         if rec["upsample"]:
             assert f"samples_idx_{i}" in g
             ref_idx = g[f"samples_idx_{i}"]
-            assert np.array_equal(np.sort(ref_idx, -1), np.sort(rec["samples_idx"], -1))
-            # torch.sort is not stable: the two orders may differ only inside runs of equal keys
+            assert np.array_equal(rec["z_next"], g[f"zmerged_{i}"]), i
+            # torch.sort is not stable: the two gather orders may differ only inside runs of equal keys
             cat = np.concatenate([rec["z"], rec["samples"]], -1)
-            # (u - cdf_b)/denom with denom >= 1e-5 amplifies a 1-ulp cdf difference by up to 1e-2 * bin width
-            # rows with a near-tie flip are excluded: across a flat cdf stretch (denom < 1e-5 -> 1) a flip moves
-            # the sample by a whole bin in the reference as well
-            ok = (rec["inds"] == g[f"inds_{i}"]).all(-1)
-            mine = np.take_along_axis(cat, rec["samples_idx"], -1)
-            np.testing.assert_allclose(mine[ok], g[f"zmerged_{i}"][ok], atol=2e-4)
-            np.testing.assert_allclose(np.take_along_axis(cat, ref_idx, -1)[ok], g[f"zmerged_{i}"][ok], atol=2e-4)
-            assert (np.abs(mine[ok] - g[f"zmerged_{i}"][ok]) > 2e-6).mean() < 2e-3
-    assert flips <= max(1, total // 200), f"{flips}/{total} near-tie flips"   # observed: 0 .. 0.2 % (beta=1e-3)
+            assert np.array_equal(np.sort(ref_idx, -1), np.sort(rec["samples_idx"], -1))
+            assert np.array_equal(np.take_along_axis(cat, ref_idx, -1), g[f"zmerged_{i}"])
 
 
 R256 = ["sampler256_b0.1", "sampler256_b0.01", "sampler256_b0.001"]
@@ -183,80 +203,97 @@ def load256(golden_dir, name):
     return g
 
 
-def near_tie_flips(inds, u, g, i, cdf=None):
-    """Entries where `inds` (R, N) differs from the reference's searchsorted result of round i; asserts that each of them is a
-    near-tie: u within 1.5e-6 of the cdf entry whose comparison decides between the two counts (the reference's bracketing
-    entries are in the fixture; a difference of more than one index needs the whole run of `cdf` in between)."""
-    ref = g[f"inds_{i}"]
-    r, j = np.nonzero(inds != ref)
-    for rr, jj in zip(r, j):
-        d = int(inds[rr, jj]) - int(ref[rr, jj])
-        uu = u[rr, jj] if np.ndim(u) == 2 else u[jj]
-        if d == 1:
-            assert abs(g[f"cdf_hi_{i}"][rr, jj] - uu) <= 1.5e-6, (i, rr, jj, d)
-        elif d == -1:
-            assert abs(g[f"cdf_lo_{i}"][rr, jj] - uu) <= 1.5e-6, (i, rr, jj, d)
-        else:
-            lo, hi = sorted((int(inds[rr, jj]), int(ref[rr, jj])))
-            assert cdf is not None and np.all(np.abs(cdf[rr, lo:hi] - uu) <= 1.5e-6), (i, rr, jj, d)
-    return len(r)
+def _assert_rounds_exact(g):
+    n_idx = 0
+    for i, rec in _replay_rounds(g):
+        ref = g[f"inds_{i}"]
+        n = rec["cdf"].shape[1]
+        assert np.array_equal(rec["beta"], g[f"beta_{i}"]), i
+        assert np.array_equal(np.take_along_axis(rec["cdf"], np.maximum(ref - 1, 0), 1), g[f"cdf_lo_{i}"]), i
+        assert np.array_equal(np.take_along_axis(rec["cdf"], np.minimum(ref, n - 1), 1), g[f"cdf_hi_{i}"]), i
+        assert np.array_equal(rec["inds"], ref), (i, int((rec["inds"] != ref).sum()))
+        if rec["upsample"]:
+            assert np.array_equal(rec["z_next"], g[f"zmerged_{i}"]), i
+        n_idx += ref.size
+    return n_idx
 
 
 @pytest.mark.parametrize("name", R256)
 def test_sampler_r256_indices(golden_dir, name):
-    """Index-level agreement with the reference sampler on 256 rays, all rounds, every round replayed from the reference's own
-    state: every searchsorted index equals the reference's except at near-ties (u within 1.5e-6 of the deciding cdf entry;
-    measured <= 2.4e-7 -- the reference normalises its pdf with torch.sum, a vectorised float32 reduction whose order depends
-    on the host's SIMD width; the oracle and the kernels with a float64 sum), at most 0.2 % of the indices
-    (measured 0.14 / 0.12 / 0.14 %); the cdf entries that bracket every u agree to 4e-6; beta agrees to one bisection step."""
+    """Index-level identity with the reference sampler on 256 rays, all rounds (5 at beta <= 0.01), every round replayed
+    from the reference's own state: ZERO differing searchsorted indices (49 152 / 147 456 / 147 456), the bracketing cdf
+    entries, beta and the merged bins bit-equal.  (Round 3 accepted 0.14 % near-tie flips; they were the float64 row sum
+    and the correctly-rounded exp / expm1 of that round's contract, not properties of the reference.)"""
     g = load256(golden_dir, name)
+    n_idx = _assert_rounds_exact(g)
+    print(f"{name}: 0 differing indices of {n_idx} ({int(g['n_rounds'])} rounds)")
+
+
+def _host_matches(g):
+    import torch
+    e = torch.exp(torch.from_numpy(g["exp_probe_in"])).numpy()
+    q = torch.sqrt(torch.from_numpy(g["sqrt_probe_in"])).numpy()
+    return np.array_equal(e, g["exp_probe_out"]) and np.array_equal(q, g["sqrt_probe_out"])
+
+
+def test_sampler_hostexp(golden_dir):
+    """The UNPINNED reference (torch.exp / torch.sqrt = the generating host's MKL VML kernels; 64 rays, beta = 0.01, 5
+    rounds).  On a host whose torch returns the same exp and sqrt (probe vectors in the fixture) the oracle with those
+    two host routines bound in reproduces every index, cdf entry, beta and merged bin of the unmodified reference -- so
+    the restated sum / expm1 / cumsum and every elementary operation are the reference's, and exp / sqrt are the only
+    host-dependent primitives.  With the pinned (open) exp / sqrt the same fixture shows what that host dependence
+    amounts to: a fraction of a percent of near-tie indices."""
+    import torch
+    g = load256(golden_dir, "sampler64_hostexp_b0.01")
     flips = total = 0
     for i, rec in _replay_rounds(g):
-        np.testing.assert_allclose(rec["beta"], g[f"beta_{i}"], rtol=2e-3)   # one bisection step = 2^-10
-        assert (np.abs(rec["beta"] - g[f"beta_{i}"]) > 1e-6 * g[f"beta_{i}"]).mean() <= 0.1
-        ref = g[f"inds_{i}"]
-        n = rec["cdf"].shape[1]
-        # (measured: 7.5e-7 / 3.0e-6 / 1.7e-6 for beta = 0.1 / 0.01 / 0.001 -- sqrt(640) ulp of the float32 row sum)
-        np.testing.assert_allclose(np.take_along_axis(rec["cdf"], np.maximum(ref - 1, 0), 1), g[f"cdf_lo_{i}"], atol=4e-6)
-        np.testing.assert_allclose(np.take_along_axis(rec["cdf"], np.minimum(ref, n - 1), 1), g[f"cdf_hi_{i}"], atol=4e-6)
-        flips += near_tie_flips(rec["inds"], rec["u"], g, i, rec["cdf"])
-        total += ref.size
-    print(f"{name}: {flips} near-tie flips in {total} indices ({int(g['n_rounds'])} rounds)")
-    assert flips <= 0.002 * total, f"{flips}/{total}"
+        flips += int((rec["inds"] != g[f"inds_{i}"]).sum())
+        total += rec["inds"].size
+    print(f"pinned exp/sqrt vs the generating host's MKL kernels: {flips} of {total} indices differ")
+    assert flips <= 0.003 * total
+    if not _host_matches(g):
+        pytest.skip("this host's torch.exp / torch.sqrt (MKL VML dispatch) differ from the generating host's")
+    saved = orc.ref_exp, orc.ref_sqrt
+    orc.ref_exp = lambda x: torch.exp(torch.from_numpy(np.ascontiguousarray(x, F32))).numpy()
+    orc.ref_sqrt = lambda x: torch.sqrt(torch.from_numpy(np.ascontiguousarray(x, F32))).numpy()
+    try:
+        _assert_rounds_exact(g)
+    finally:
+        orc.ref_exp, orc.ref_sqrt = saved
 
 
 @pytest.mark.parametrize("beta", ["0.1", "0.01", "0.001"])
 def test_forward_r256(golden_dir, beta):
-    """The whole eval forward (fast = -1) on 256 rays against the reference: on the rays whose final samples coincide with the
-    reference's (no near-tie flip on the way) colours to 1e-4 and depths to 2e-4; on every ray a flip moves at most a sample or
-    two by a bin, which the bounds on ALL rays state."""
+    """The whole eval forward (fast = -1, up to 5 sampler rounds) on 256 rays against the reference, EVERY ray: colours,
+    depths and normals far inside the north star's 1e-4 (observed 3e-7 / 5e-5 / 1e-6).  Sample POSITIONS are compared
+    where they carry weight: the oracle's SDF values differ from the reference's in the last bits (MKL sgemm vs a numpy
+    matmul -- any two evaluation orders do), and where the cdf is flat (transmittance ~ 0 behind the surface, denom
+    clamped to 1e-5) the inverse-CDF map turns one ulp of cdf into up to 1e-2 of a bin; those samples have weight
+    < 1e-5 and do not reach any output."""
     g = load(golden_dir, "forward256_b" + beta)
     params = synth.make_params(0)
     out = orc.render_forward(params, g["uv"], g["pose"], g["K"], beta_param=g["beta_param"], fast=-1)
-    same = np.abs(out["depth_vals"] - g["depth_vals"]).max(-1) < 3e-4
-    print(f"forward256_b{beta}: {int(same.sum())}/256 rays with the reference's samples; max rgb err on those "
-          f"{np.abs(out['rgb_values'] - g['rgb_values'])[same].max():.2e}, on all {np.abs(out['rgb_values'] - g['rgb_values']).max():.2e}")
-    # (deterministic: the oracle's counts are pinned exactly; a near-tie in any of up to five rounds moves a sample)
-    assert same.sum() >= {"0.1": 250, "0.01": 198, "0.001": 170}[beta]
-    np.testing.assert_allclose(out["rgb_values"][same], g["rgb_values"][same], atol=1e-4)
-    np.testing.assert_allclose(out["depth_values"][same], g["depth_values"][same], atol=2e-4)
-    np.testing.assert_allclose(out["normal_map"][same], g["normal_map"][same], atol=2e-4)
-    np.testing.assert_allclose(out["rgb_values"], g["rgb_values"], atol=5e-4)
-    np.testing.assert_allclose(out["depth_values"], g["depth_values"], atol=5e-3)
+    print(f"forward256_b{beta}: max err on ALL 256 rays: rgb {np.abs(out['rgb_values'] - g['rgb_values']).max():.2e}, "
+          f"depth {np.abs(out['depth_values'] - g['depth_values']).max():.2e}, "
+          f"normal {np.abs(out['normal_map'] - g['normal_map']).max():.2e}")
+    np.testing.assert_allclose(out["rgb_values"], g["rgb_values"], atol=5e-6)
+    np.testing.assert_allclose(out["depth_values"], g["depth_values"], atol=2e-4)
+    np.testing.assert_allclose(out["normal_map"], g["normal_map"], atol=1e-5)
+    moved = np.abs(out["depth_vals"] - g["depth_vals"]) > 5e-3
+    assert g["weights"][moved].max(initial=0.0) < 1e-5 and out["weights"][moved].max(initial=0.0) < 1e-5
 
 
-def test_sampler_eval_chain(golden_dir):
-    """Whole sampler (all rounds chained) on the reference's per-round sdf, well-conditioned case."""
-    g = load(golden_dir, "sampler_eval_b0.1_f-1")
-    nr = int(g["n_rounds"])
-    z, _ = orc.error_bound_sampler(None, g["dirs"], g["cam"], orc.get_beta(g["beta_param"]), fast=-1,
-                                   inv_4log=g["inv_4log"], sdf_override=[g[f"sdf_{i}"] for i in range(nr)])
-    np.testing.assert_allclose(z, g["z"], atol=2e-5)
-    g = load(golden_dir, "sampler_eval_b0.01_f0")
-    z, _ = orc.error_bound_sampler(None, g["dirs"], g["cam"], orc.get_beta(g["beta_param"]), fast=0,
-                                   inv_4log=g["inv_4log"])
-    np.testing.assert_allclose(z, g["z"], atol=1e-6)
-    assert z.shape[1] == 128 + 34
+@pytest.mark.parametrize("name", SAMPLER_FX + R256)
+def test_sampler_eval_chain(golden_dir, name):
+    """Whole sampler, all rounds CHAINED (no restart from the reference's state), on the reference's per-round sdf values:
+    the final sample set is the reference's bit for bit, on every ray (12 / 256 rays, 1 - 5 rounds, beta 0.1 ... 0.001)."""
+    g = load(golden_dir, name)
+    R, nr = g["dirs"].shape[0], int(g["n_rounds"])
+    z, _ = orc.error_bound_sampler(None, g["dirs"], g["cam"], orc.get_beta(g["beta_param"]), fast=int(g["fast"]),
+                                   inv_4log=g["inv_4log"], sdf_override=[g[f"sdf_{i}"].reshape(R, -1) for i in range(nr)])
+    assert np.array_equal(z, g["z"])
+    if int(g["fast"]) == 0:
+        assert z.shape[1] == 128 + 34
 
 
 def test_sampler_train_round(golden_dir):
@@ -267,9 +304,7 @@ def test_sampler_train_round(golden_dir):
         assert _check_inds(rec, g, i) == 0
         assert not rec["upsample"]
         z, z_eik = orc.sampler_finalize(rec["z"], rec["samples"], near=F32(1e-4), far=F32(6.0), training=True, rng=rng)
-        np.testing.assert_allclose(z, g["z"], atol=2e-4)       # conditioning of (u-cdf_b)/denom, see above
-        assert (np.abs(z - g["z"]) > 2e-6).mean() < 0.01
-        np.testing.assert_allclose(z_eik, g["z_eik"], atol=2e-4)
+        assert np.array_equal(z, g["z"]) and np.array_equal(z_eik, g["z_eik"])
 
 
 def test_torch_sampler_port_vs_reference(golden_dir):
@@ -292,9 +327,10 @@ def test_torch_sampler_port_vs_reference(golden_dir):
 
 @pytest.mark.parametrize("tag", ["eval_b0.1", "eval_b0.01", "eval_b0.01_f1", "train", "w1_eval", "w1_train"])
 def test_forward(golden_dir, tag):
-    """Whole forward (oracle MLPs + oracle sampler) against VolSDFNetwork.forward of the reference.
-    A near-tie flip in the sampler moves one sample by up to a bin (see _check_inds), so per-sample
-    arrays are compared on the rays whose sample positions agree and the integrated outputs on all rays.
+    """Whole forward (oracle MLPs + oracle sampler) against VolSDFNetwork.forward of the reference, every ray: integrated
+    outputs to 5e-6 (colours) / 1e-5 (depths, normals).  Per-sample arrays are compared where the sample did not move:
+    the oracle's SDF values differ from the reference's in their last bits, which the inverse-CDF map amplifies where
+    the cdf is flat (test_forward_r256); such samples must carry no weight (< 1e-5).
     w1_*: the trained-scale weight set at its own beta = 0.005."""
     g = load(golden_dir, "forward_" + tag)
     params = synth.WEIGHT_SETS["w1" if tag.startswith("w1") else "w0"]()
@@ -303,23 +339,19 @@ def test_forward(golden_dir, tag):
     rng = synth.make_train_rng(R, seed=6) if training else None
     out = orc.render_forward(params, g["uv"], g["pose"], g["K"], beta_param=g["beta_param"], fast=int(g["fast"]),
                              training=training, rng=rng)
-    same = np.abs(out["depth_vals"] - g["depth_vals"]).max(-1) < 3e-4
-    # the oracle is deterministic: the number of rays whose samples coincide with the reference's is pinned exactly (the
-    # others carry a near-tie flip of one inverse-CDF index, see _check_inds; multi-round eval sampling compounds them)
-    expect = {"eval_b0.1": 11, "eval_b0.01": 9, "eval_b0.01_f1": 12, "train": 12, "w1_eval": 9, "w1_train": 12}[tag]
-    assert int(same.sum()) >= expect, f"forward_{tag}: {int(same.sum())}/{same.size} rays with identical samples, expected {expect}"
-    np.testing.assert_allclose(out["xyz"][same], g["xyz"][same], atol=3e-4)
-    np.testing.assert_allclose(out["weights"][same], g["weights"][same], atol=2e-3)
-    assert np.abs(out["weights"][same] - g["weights"][same]).mean() < 2e-5
-    np.testing.assert_allclose(out["rgb_values"], g["rgb_values"], atol=2e-4)
-    np.testing.assert_allclose(out["depth_values"], g["depth_values"], atol=2e-3)
-    np.testing.assert_allclose(out["depth_values"][same], g["depth_values"][same], atol=2e-4)
+    moved = np.abs(out["depth_vals"] - g["depth_vals"]) > 3e-4
+    assert moved.mean() < 0.05
+    assert g["weights"][moved].max(initial=0.0) < 1e-5 and out["weights"][moved].max(initial=0.0) < 1e-5
+    np.testing.assert_allclose(out["xyz"][~moved], g["xyz"][~moved], atol=3e-4)
+    np.testing.assert_allclose(out["weights"][~moved], g["weights"][~moved], atol=2e-3)
+    assert np.abs(out["weights"][~moved] - g["weights"][~moved]).mean() < 2e-5
+    np.testing.assert_allclose(out["rgb_values"], g["rgb_values"], atol=5e-6)
+    np.testing.assert_allclose(out["depth_values"], g["depth_values"], atol=1e-5)
     if training:
         np.testing.assert_allclose(out["grad_theta"][:R], g["grad_theta"][:R], atol=1e-4)
-        np.testing.assert_allclose(out["grad_theta"][R:][same], g["grad_theta"][R:][same], atol=2e-3)
+        np.testing.assert_allclose(out["grad_theta"][R:], g["grad_theta"][R:], atol=2e-3)
     else:
-        np.testing.assert_allclose(out["normal_map"], g["normal_map"], atol=2e-3)
-        np.testing.assert_allclose(out["normal_map"][same], g["normal_map"][same], atol=2e-4)
+        np.testing.assert_allclose(out["normal_map"], g["normal_map"], atol=1e-5)
 
 
 @pytest.mark.parametrize("tag", ["eval_b0.1", "eval_b0.01", "train"])
@@ -348,20 +380,21 @@ def test_forward_bg(golden_dir, tag):
                                 training=training, rng=rng, near_pose=g["near_pose"])
     np.testing.assert_allclose(out["z_bg"], g["z_bg"], atol=1e-7)
     np.testing.assert_allclose(out["z_max"], g["z_max"], atol=2e-6)
-    same = np.abs(out["depth_vals"] - g["depth_vals"]).max(-1) < 3e-4
-    assert same.mean() >= 0.75, same
-    np.testing.assert_allclose(out["weights"][same], g["weights"][same], atol=2e-3)
-    np.testing.assert_allclose(out["bg_transmittance"][same], g["bg_transmittance"][same], atol=2e-4)
-    np.testing.assert_allclose(out["rgb_values"], g["rgb_values"], atol=3e-4)
+    # every ray; per-sample weights where the sample did not move (see test_forward)
+    moved = np.abs(out["depth_vals"] - g["depth_vals"]) > 3e-4
+    assert moved.mean() < 0.05 and max(out["weights"][moved].max(initial=0.0), g["weights"][moved].max(initial=0.0)) < 1e-5
+    np.testing.assert_allclose(out["weights"][~moved], g["weights"][~moved], atol=2e-3)
+    np.testing.assert_allclose(out["bg_transmittance"], g["bg_transmittance"], atol=2e-5)
+    np.testing.assert_allclose(out["rgb_values"], g["rgb_values"], atol=5e-6)
     # depth_values is normalised by the fg weight sum, which is small for rays that mostly see the background
     wsum = g["weights"].sum(1, keepdims=True)
-    assert (np.abs(out["depth_values"] - g["depth_values"])[same] <= 3e-4 / np.maximum(wsum[same], 1e-3)).all()
+    assert (np.abs(out["depth_values"] - g["depth_values"]) <= 3e-5 / np.maximum(wsum, 1e-3)).all()
     # the background depths reach 1e6 (1 / (depth + 1e-6)): small weight differences move this mean visibly
-    np.testing.assert_allclose(out["depth_values_all"][same], g["depth_values_all"][same], rtol=3e-3)
+    np.testing.assert_allclose(out["depth_values_all"], g["depth_values_all"], rtol=3e-3)
     if training:
         np.testing.assert_allclose(out["grad_theta"][:R], g["grad_theta"][:R], atol=1e-4)
     else:
-        np.testing.assert_allclose(out["normal_map"][same], g["normal_map"][same], atol=2e-4)
+        np.testing.assert_allclose(out["normal_map"], g["normal_map"], atol=2e-5)
 
 
 def test_torch_ref_forward_bg(golden_dir):
