@@ -101,7 +101,16 @@ def main():
     ap.add_argument("--no-exact-f32", action="store_true",
                     help="skip the extra runs in the other precisions (fast_grad_*, exact_f32_ms_per_step)")
     ap.add_argument("--no-gpu-torch", action="store_true", help="skip the PyTorch-eager comparator on the same GPU")
+    ap.add_argument("--no-volopt-loop", action="store_true",
+                    help="skip the end-to-end `VolOpt.run` measurement (`volopt_run` on the line)")
+    ap.add_argument("--no-other-scaling", action="store_true",
+                    help="N > 1: skip the second timed region in the other scaling mode (`other_scaling` on the line)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as a plain `python bench.py --gpus N`: this process has not touched a GPU; it starts the N ranks as
+        # children (one process per GPU over RCCL, the launch line of the module docstring) and relays their output
+        raise SystemExit(self_launch(args.gpus))
 
     import numpy as np
     import torch
@@ -147,10 +156,18 @@ def main():
         raise SystemExit("--model bmvs is benchmarked in train mode")
     params, model = make_model()
     K, pose = synth.make_camera()
-    # each rank renders its own pixel shard of the view
-    uv = synth.make_uv(R * world, seed=100)[rank * R:(rank + 1) * R] if args.scaling == "strong" else synth.make_uv(R, seed=100 + rank)
-    inp = {"intrinsics": torch.from_numpy(K)[None].to(dev), "uv": torch.from_numpy(np.ascontiguousarray(uv))[None].to(dev),
-           "pose": torch.from_numpy(pose)[None].to(dev)}
+
+    def make_inputs(R, scaling):
+        """each rank renders its own pixel shard of the view: R rays of a world x R ray batch (strong) / R rays of its own (weak)"""
+        uv = synth.make_uv(R * world, seed=100)[rank * R:(rank + 1) * R] if scaling == "strong" else synth.make_uv(R, seed=100 + rank)
+        inp = {"intrinsics": torch.from_numpy(K)[None].to(dev), "uv": torch.from_numpy(np.ascontiguousarray(uv))[None].to(dev),
+               "pose": torch.from_numpy(pose)[None].to(dev)}
+        rs = np.random.default_rng(11 + rank)
+        gt = {"rgb": torch.from_numpy(rs.uniform(0, 1, (1, R, 3)).astype(np.float32)).to(dev),
+              "rgb_smooth": torch.from_numpy(rs.uniform(0, 1, (1, R, 3)).astype(np.float32)).to(dev)}
+        return inp, gt
+
+    inp, gt_all = make_inputs(R, args.scaling)
     torch.manual_seed(1234 + rank)
 
     mvs = gt = None
@@ -165,11 +182,9 @@ def main():
             zm = torch.linspace(1.5, 3.5, 192, device=dev).view(-1, 1, 1) * (1 + 0.05 * (torch.rand(1, 288, 384, device=dev, generator=gen) * 2 - 1))
             views.append(dict(K=Kj, c2w=Pj, cost=prob, z_near=zm[0].contiguous(), z_far=zm[-1].contiguous()))
         mvs = dict(views=views, same_view=0, img_res=(576, 768), inverse_depth=False)
-        rs = np.random.default_rng(11 + rank)
-        gt = {"rgb": torch.from_numpy(rs.uniform(0, 1, (1, R, 3)).astype(np.float32)).to(dev),
-              "rgb_smooth": torch.from_numpy(rs.uniform(0, 1, (1, R, 3)).astype(np.float32)).to(dev)}
+        gt = gt_all
 
-    def make_step(mdl):
+    def make_step(mdl, inp=inp, gt=gt):
         if not train:
             def fwd():
                 with torch.no_grad():
@@ -210,6 +225,34 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     del out
+
+    other = None
+    if world > 1 and train and not args.no_other_scaling and args.rays % world == 0:
+        # the same job in the OTHER scaling mode, so that one driver run reports both: weak = every GPU its own --rays
+        # batch; strong = ONE --rays batch sharded over the GPUs (config 4's partitioning: 2048 rays over 8 GPUs)
+        o_scaling = "strong" if args.scaling == "weak" else "weak"
+        R2 = args.rays // world if o_scaling == "strong" else args.rays
+        inp2, gt2 = make_inputs(R2, o_scaling)
+        _, model2 = make_model()
+        ts2, step2 = make_step(model2, inp2, gt2)
+        for _ in range(60):                      # past TrainStep's schedule tuning (steps 24..47)
+            step2()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        n2 = max(50, args.steps // 2)
+        for _ in range(n2):
+            step2()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        d2 = torch.tensor([time.perf_counter() - t2], device=dev, dtype=torch.float64)
+        dist.all_reduce(d2, op=dist.ReduceOp.MAX)
+        d2 = float(d2.item())
+        other = {"scaling": o_scaling, "rays_per_gpu": R2, "rays_total": R2 * world, "steps": n2,
+                 "ms_per_step": 1e3 * d2 / n2, "value": world * R2 * n2 / d2, "unit": "rays/s"}
+        del ts2, step2, model2
 
     S = model.ray_sampler.N_samples + model.ray_sampler.N_samples_extra + 2 - (1 if args.model == "bmvs" else 0)
     roofline = None
@@ -255,6 +298,8 @@ def main():
                        "model_flops_per_s": world * R * args.steps / dt * flop_per_ray},
             "roofline": roofline,
         }
+        if other is not None:
+            line["other_scaling"] = other
         if train and world == 1 and not args.no_gpu_torch and args.model == "dtu":
             line["gpu_torch_baseline"] = gpu_torch_baseline(ts, params, gt, R, dev, 1e3 * dt / args.steps, mvs)
         if train and h2 and world == 1 and args.model == "dtu" and not args.no_kernel_timing and not args.no_exact_f32:
@@ -267,12 +312,75 @@ def main():
                                           "training step (parameter gradients 2e-4 ... 8e-4 of a tensor's largest entry off float64 "
                                           "autograd); NOT the figure `value` reports")
             line["exact_f32_ms_per_step"] = other_precision_step_ms("f32", make_model, make_step, n=10, warm=4)
+        if train and world == 1 and args.model == "dtu" and not args.no_volopt_loop:
+            line["volopt_run"] = volopt_loop(args.rays)
         if not args.no_cpu_baseline and args.model == "dtu" and world == 1:      # rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(params, K, pose, train=train)
         print(json.dumps(line), flush=True)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def volopt_loop(rays, warm=60, steps=200):
+    """What a runner.py user gets: `VolOpt.run` (the reference's optimisation loop, volsdf/vsdf.py:322-367) end to end on a
+    synthetic in-memory scene with the SceneDataset interface at 576 x 768 (tests/synthetic_scene.py: full pixel grid per
+    item, torch.randperm over all pixels on the CPU, one torch thread, as the reference's dataset does), `rays` pixels per
+    step, no MVS prior, previews and checkpoints off -- ms per step including the DataLoader, for (a) the default loop
+    (next batch prepared by a helper thread while the step is enqueued: same batches, same random streams), (b) the
+    strictly sequential loop (`overlap_loader=False`), (c) the opt-in device-side batch source.  Outside the timed
+    region; the step itself is the one `value` times."""
+    import tempfile
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_volopt as tv
+    cwd = os.getcwd()
+    os.chdir(tempfile.mkdtemp(prefix="svs_volopt_"))
+    res = {}
+    try:
+        for name, kw in (("default", {}), ("sequential", dict(overlap_loader=False)), ("device_batches", dict(device_batches=True))):
+            a = tv.make_args()
+            a["vol"]["dataset"]["img_res"] = [576, 768]
+            a["vol"]["train"].update(num_pixels=rays, render_freq=10 ** 9, checkpoint_freq=10 ** 9)
+            a["max_h"], a["max_w"] = 576, 768
+            v = tv.build(a, **kw)
+            v._preview = lambda *x, **k: None
+            v.save_checkpoints = lambda *x, **k: None
+            v.run(opt_stepN=warm)                   # kernel attribute set-up, TrainStep's schedule measurement (steps 24..47)
+            torch.cuda.synchronize()
+            n0, t0 = v.total_step, time.perf_counter()
+            v.run(opt_stepN=steps)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            n = v.total_step - n0
+            res[name] = {"ms_per_step": 1e3 * dt / n, "rays_per_s": rays * n / dt, "steps": n}
+            del v
+    finally:
+        os.chdir(cwd)
+    res["note"] = ("VolOpt.run end to end incl. the DataLoader over a SceneDataset-style dataset (host work per step: randperm "
+                   "over 442 368 pixels + the full pixel grid); `default` is what runner.py gets")
+    return res
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a child and return its exit code (rank 0's
+    JSON line goes to this process's stdout).  Counting devices does not initialise the GPU; nothing else here does."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"bench.py --gpus {n}: this box shows {have} GPU(s) (torch.cuda.device_count()); one rank per GPU is needed -- "
+              f"run with --gpus <= {have}" + (" (there is no CPU fallback of the product path)" if have == 0 else ""),
+              file=sys.stderr, flush=True)
+        return 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def kernel_roofline(ts, step, R, S, h2, train, n_steps=12, ray_groups=None):

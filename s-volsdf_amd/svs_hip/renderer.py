@@ -29,8 +29,9 @@ def gather_image(part, lo, hi, total_pixels, world):
     """Assembles the full-image tensors from every rank's part (dict of (hi - lo, ...) tensors) with one all-gather per
     key (RCCL on the GPU box, gloo in the CPU test); ranks pad to the largest part."""
     import torch.distributed as dist
-    sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
-    dist.all_gather(sizes, torch.tensor([hi - lo], dtype=torch.int64))
+    dev = next(iter(part.values())).device        # (RCCL gathers device tensors; gloo in the CPU test takes host tensors)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([hi - lo], dtype=torch.int64, device=dev))
     sizes = [int(s) for s in sizes]
     m = max(sizes)
     out = {}

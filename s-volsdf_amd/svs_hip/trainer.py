@@ -246,9 +246,14 @@ class TrainStep:
     all-reduce and the fused optimiser launch stay outside it.  What a replay returns are views into the graph's memory:
     valid until the next step."""
 
-    def __init__(self, model, loss, lr=5e-4, grad_clip=True, world=1, rank=0, groups=None, graph=None):
+    def __init__(self, model, loss, lr=5e-4, grad_clip=True, world=1, rank=0, groups=None, graph=None, shard_draws=False):
         import os
         self.model, self.loss = model, loss
+        # world > 1 and shard_draws: every rank makes the train-mode draws of the WHOLE batch (world x local rays; the
+        # ranks' host generators are in the same state) and keeps the rows of its own rays -- the sharded step then sees
+        # exactly the draws the single-GPU step of the same batch sees (SURVEY.md section 8e).  Off: each rank draws for
+        # its own rays (independent shards, bench.py's weak scaling).
+        self.shard_draws = bool(shard_draws)
         self.fp = FlatParams(model._flat_param_list())
         self.opt = FusedAdam(self.fp, lr=lr, max_norm=1.0 if grad_clip else 0.0)
         self.world, self.rank = world, rank
@@ -349,6 +354,14 @@ class TrainStep:
     TUNE_START, TUNE_STEPS, TUNE_SKIP = 24, 12, 2
 
     def _groups_for(self, R):
+        groups = self._groups_raw(R)
+        # a padded batch (up to ray_multiple() - 1 repeated rays at the end): no ray group may consist of padding only
+        # (its loss would be a mean over zero rays); such a batch runs as one group
+        if len(groups) > 1 and groups[-1][0] >= getattr(self, "_n_valid", R):
+            return [(0, R)]
+        return groups
+
+    def _groups_raw(self, R):
         if self._force_groups is not None:
             return self._force_groups
         if self.groups != "auto":
@@ -411,7 +424,11 @@ class TrainStep:
         tune = None if self.graph else self._tune_begin(R)
         try:
             n_valid = getattr(self, "_n_valid", R)
-            rng = m.draw_train_rng(n_valid, uv.device, stream=self.scratch.prep)      # uploads on the (idle) pack stream
+            if self.world > 1 and self.shard_draws:
+                rng = m.slice_rng(m.draw_train_rng(n_valid * self.world, uv.device, stream=self.scratch.prep),
+                                  self.rank * n_valid, (self.rank + 1) * n_valid)
+            else:
+                rng = m.draw_train_rng(n_valid, uv.device, stream=self.scratch.prep)  # uploads on the (idle) pack stream
             if n_valid < R:                      # padded batch: the random stream is consumed as for the caller's rays
                 from volsdf.model.network import pad_rng
                 rng = pad_rng(rng, R)

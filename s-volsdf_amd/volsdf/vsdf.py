@@ -21,7 +21,7 @@ import torch
 
 import volsdf.utils.general as utils
 from svs_hip import ops, renderer
-from svs_hip.trainer import TrainStep
+from svs_hip.trainer import TrainStep, shard_rays
 from volsdf.utils.conf import Conf, attr_view, to_plain
 
 
@@ -97,10 +97,53 @@ class AdamStateView:
             f.lr = float(sd["param_groups"][0].get("lr", f.lr))
 
 
+def init_data_parallel():
+    """-> (world, rank, local_rank).  Data-parallel optimisation of ONE scan (BASELINE config 4: a 2048-ray batch sharded
+    over the 8 GPUs of a node): launched as one process per GPU (`python -m torch.distributed.run --nproc-per-node N
+    runner.py ...`), every process builds the same VolOpt; WORLD_SIZE / RANK / LOCAL_RANK come from the launcher.  Binds
+    the process to its GPU BEFORE anything touches a device and joins the RCCL process group (backend "nccl"; gloo when
+    there is no GPU, which is what the CPU tests use).  SVS_FORCE_DIST=1 joins a one-rank group (the RCCL path on a single
+    GPU).  Without a launcher: (1, 0, 0) and no process group."""
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world <= 1 and os.environ.get("SVS_FORCE_DIST", "0") != "1":
+        return 1, 0, 0
+    has_gpu = torch.cuda.device_count() > 0
+    if has_gpu:
+        if local >= torch.cuda.device_count():
+            raise RuntimeError(f"LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) are visible: launch at most "
+                               f"one rank per GPU")
+        torch.cuda.set_device(local)
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl" if has_gpu else "gloo", rank=rank, world_size=world)
+    return world, rank, local
+
+
+def sync_host_rng(world):
+    """Every rank continues from rank 0's host generators (torch CPU, Python `random`, numpy): the ranks then draw the same
+    view, the same pixels and the same sampler / eikonal numbers at every step, of which each keeps its rays' share."""
+    if world <= 1:
+        return
+    import random
+    import numpy as np
+    import torch.distributed as dist
+    box = [(torch.get_rng_state(), random.getstate(), np.random.get_state()) if dist.get_rank() == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    t, r, n = box[0]
+    torch.set_rng_state(t)
+    random.setstate(r)
+    np.random.set_state(n)
+
+
 class VolOpt():
     def __init__(self, **kwargs):
         torch.set_default_dtype(torch.float32)
         torch.set_num_threads(1)
+        # one process per GPU; a single process when no launcher set WORLD_SIZE (init_data_parallel)
+        self.world, self.rank, self.local_rank = init_data_parallel()
 
         # get configs
         self.hparams = attr_view(copy.deepcopy(kwargs['args']))
@@ -127,6 +170,11 @@ class VolOpt():
         # experiment / checkpoint folders (the reference's layout)
         self.expdir = os.path.join(root, self.exps_folder_name, self.expname)
         self.timestamp = '{:%Y_%m_%d_%H_%M_%S}'.format(datetime.now())
+        if self.world > 1:                               # one run folder: rank 0's time stamp
+            import torch.distributed as dist
+            box = [self.timestamp]
+            dist.broadcast_object_list(box, src=0)
+            self.timestamp = box[0]
         self.plots_dir = os.path.join(self.expdir, self.timestamp, 'plots')
         self.checkpoints_path = os.path.join(self.expdir, self.timestamp, 'checkpoints')
         self.model_params_subdir = "ModelParameters"
@@ -134,7 +182,8 @@ class VolOpt():
         for d in (self.plots_dir, os.path.join(self.checkpoints_path, self.model_params_subdir),
                   os.path.join(self.checkpoints_path, self.optimizer_params_subdir)):
             os.makedirs(d, exist_ok=True)
-        self._save_run_config(os.path.join(self.expdir, self.timestamp, 'run.yaml'), kwargs['args'])
+        if self.rank == 0:
+            self._save_run_config(os.path.join(self.expdir, self.timestamp, 'run.yaml'), kwargs['args'])
 
         # dataset config
         dataset_conf = dict(self.conf.get_config('dataset'))
@@ -145,10 +194,13 @@ class VolOpt():
         self._dataset_class = kwargs.get('dataset_class') or utils.get_class(self.conf.get_string('train.dataset_class'))
         # opt-in: train batches drawn on the device instead of the reference's DataLoader loop (svs_hip/batches.py)
         self._device_batches = bool(kwargs.get('device_batches', os.environ.get('SVS_DEVICE_BATCHES', '0') == '1'))
-        # opt-in: the reference's DataLoader loop with the next batch prepared by a helper thread while the current step is
-        # being enqueued: same batches, same random streams (_epoch_overlapped).  What it gains depends on how much of the
-        # dataset's work releases the GIL on the host at hand (measured: 5.4 -> 4.8 ms per step on one box, nothing on another)
-        self._overlap_loader = bool(kwargs.get('overlap_loader', os.environ.get('SVS_OVERLAP_LOADER', '0') == '1'))
+        # the reference's DataLoader loop with the next batch prepared by a helper thread while the current step is being
+        # enqueued: same batches, same random streams (_epoch_overlapped; pinned by test_overlapped_loader_draws_the_same_
+        # batches).  Default since round 4 (5.3 -> 4.3-4.5 ms per step end to end: the dataset's ~2.6 ms of host work per
+        # step -- torch.randperm over all pixels, the full pixel grid per item -- no longer sits in front of the step's
+        # 2.2 ms of enqueueing); `overlap_loader=False` / SVS_OVERLAP_LOADER=0 gives the strictly sequential loop.
+        self._overlap_loader = bool(kwargs.get('overlap_loader', os.environ.get('SVS_OVERLAP_LOADER', '1') == '1'))
+        self._loader_pool = None
 
         # generate dataset
         self.data_confs = [copy.deepcopy(dataset_conf) for _ in range(3)]
@@ -162,7 +214,9 @@ class VolOpt():
         self.model.cuda()
         self.loss = utils.get_class(self.conf.get_string('train.loss_class'))(**self.conf.get_config('loss'))
         self.lr = self.conf.get_float('train.learning_rate')
-        self.step_fn = TrainStep(self.model, self.loss, lr=self.lr, grad_clip=bool(self.hparams.grad_clip), groups="auto")
+        # data parallel: this rank's share of every batch, one all-reduce of the flat gradient per step (trainer.py)
+        self.step_fn = TrainStep(self.model, self.loss, lr=self.lr, grad_clip=bool(self.hparams.grad_clip), groups="auto",
+                                 world=self.world, rank=self.rank, shard_draws=True)
         self.optimizer = AdamStateView(self.step_fn.opt, self.model)
 
         # load ckpt
@@ -183,9 +237,11 @@ class VolOpt():
         self.split_n_pixels = self.conf.get_int('train.split_n_pixels', default=10000)
         self.plot_conf = self.conf.get_config('plot')
 
-        self.writer = _summary_writer(os.path.join(self.plots_dir, 'logs'))
+        # logs, plots and checkpoints are rank 0's (all ranks hold identical replicas)
+        self.writer = _summary_writer(os.path.join(self.plots_dir, 'logs')) if self.rank == 0 else _NoWriter()
         self.model.hparams = self.hparams
         self.loss.hparams = self.hparams
+        sync_host_rng(self.world)
 
     @staticmethod
     def _save_run_config(path, args):
@@ -210,6 +266,8 @@ class VolOpt():
         self.optimizer.load_state_dict(data["optimizer_state_dict"])
 
     def save_checkpoints(self, epoch, latest_only=False):
+        if self.rank != 0:
+            return 0
         for name in ("latest",) + (() if latest_only else (str(epoch),)):
             torch.save({"epoch": epoch, "model_state_dict": self.model.state_dict(), "iter_step": self.iter_step},
                        os.path.join(self.checkpoints_path, self.model_params_subdir, name + ".pth"))
@@ -277,40 +335,44 @@ class VolOpt():
         `__getitem__`: the full pixel grid, the gathers; the collate) done by a helper thread while the main thread enqueues
         step i.  The order in which the generators are consumed is the reference's: step i's own draws (sampler jitter,
         eikonal points; made first thing in the step) -> randperm for batch i+1 -> random.randint of __getitem__ -> step
-        i+1's draws ...; the helper is started by the step right after its draws and joined before the next step, so the
-        generators are never used by two threads at once.  Opt-in (`overlap_loader=True` / SVS_OVERLAP_LOADER=1)."""
-        import threading
+        i+1's draws ...; the helper's job is submitted by the step right after its draws and awaited before the next step, so
+        the generators are never used by two threads at once.  (`overlap_loader=False` / SVS_OVERLAP_LOADER=0: sequential.)"""
+        from concurrent.futures import ThreadPoolExecutor
+        if self._loader_pool is None:
+            self._loader_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="svs-next-batch")
         it = iter(self.train_dataloader)
         batch = next(it, None)
+
+        def fetch():
+            self.train_dataset.change_sampling_idx(self.num_pixels)
+            return next(it, None)
+
         while batch is not None:
-            box = {}
-
-            def fetch():
-                try:
-                    self.train_dataset.change_sampling_idx(self.num_pixels)
-                    box["batch"] = next(it, None)
-                except BaseException as e:           # re-raised in the main thread
-                    box["error"] = e
-            th = threading.Thread(target=fetch, name="svs-next-batch")
-            started = []
-
-            def start():
-                started.append(True)
-                th.start()
-            self.step_fn.after_draws = start
+            fut = []
+            self.step_fn.after_draws = lambda: fut.append(self._loader_pool.submit(fetch))
             try:
                 self.train_step(batch, self.hparams.use_mvs, _resample=False)
             finally:
                 self.step_fn.after_draws = None
-                if not started:
-                    start()                          # (a step that made no draws: nothing to wait for)
-                th.join()
-            if "error" in box:
-                raise box["error"]
-            batch = box["batch"]
+                if not fut:                              # (a step that made no draws: nothing to wait for)
+                    fut.append(self._loader_pool.submit(fetch))
+                nxt = fut[0].result()                    # re-raises what the helper raised
+            batch = nxt
+
+    def _shard_batch(self, model_input, ground_truth):
+        """This rank's contiguous share of the batch's rays (every rank holds the same batch: sync_host_rng)."""
+        if self.world == 1:
+            return model_input, ground_truth
+        mi = dict(model_input)
+        mi["uv"] = shard_rays(model_input["uv"], self.rank, self.world)
+        R = model_input["uv"].shape[1]
+        gt = {k: (shard_rays(v, self.rank, self.world) if torch.is_tensor(v) and v.dim() >= 2 and v.shape[1] == R else v)
+              for k, v in ground_truth.items()}
+        return mi, gt
 
     def train_step(self, batch, use_mvs=False, _resample=True):
         indices, model_input, ground_truth = batch
+        model_input, ground_truth = self._shard_batch(model_input, ground_truth)
         model_input = {k: self._to_device("in." + k, v) for k, v in model_input.items()}
         model_input['iter_step'] = self.iter_step
         if use_mvs and bool(self.hparams.inverse_depth) and self.stg >= 1:
@@ -318,10 +380,21 @@ class VolOpt():
         gt = {k: self._to_device("gt." + k, ground_truth[k]) for k in ("rgb", "rgb_smooth")}
         loss_output, model_outputs = self.step_fn(model_input, gt, mvs=self._mvs_views(indices) if use_mvs else None, fast=1)
         if self.total_step % 50 == 0:
+            mse = torch.mean((model_outputs['rgb_values'] - gt['rgb'].reshape(-1, 3)) ** 2)
+            if self.world > 1:
+                # a rank's loss terms are its rays' share of the batch means (trainer.loss_norm): their sum over the ranks
+                # is the batch's loss; the mse is a mean per rank
+                import torch.distributed as dist
+                keys = sorted(loss_output.keys())
+                vec = torch.stack([torch.as_tensor(loss_output[k], dtype=torch.float32, device=mse.device).reshape(())
+                                   for k in keys] + [mse / self.world])
+                dist.all_reduce(vec)
+                loss_output = dict(loss_output)
+                loss_output.update({k: vec[i] for i, k in enumerate(keys)})
+                mse = vec[-1]
             for k, v in loss_output.items():
                 self.writer.add_scalar('t/' + k, v, self.total_step)
             beta = self.model.density.get_beta().item()
-            mse = torch.mean((model_outputs['rgb_values'] - gt['rgb'].reshape(-1, 3)) ** 2)
             self.writer.add_scalar('t/beta', beta, self.total_step)
             self.writer.add_scalar('t/alpha', 1. / beta, self.total_step)
             self.writer.add_scalar('t/psnr', (-10. * torch.log10(mse)).item(), self.total_step)
@@ -337,15 +410,17 @@ class VolOpt():
         indices, model_input, ground_truth = batch
         model_input = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in model_input.items()}
         model_input['iter_step'] = self.iter_step
+        # data parallel: whole split_n_pixels chunks per rank, the image assembled with one all-gather per output
         model_outputs = renderer.render_image(self.model, model_input, dataset.total_pixels, split_n_pixels=self.split_n_pixels,
-                                              fast=fast)
+                                              fast=fast, rank=self.rank, world=self.world)
         # (1,H,W): the reference's lin2img(...)[0] keeps the channel axis, which the next MVS stage reads as the batch axis
         depth_cuda = renderer.depth_image(model_outputs, dataset.img_res, self.scale_factor)[None]
         mask_bin = ground_truth['mask'].reshape(-1, 3).cuda() == 1.
         mse = torch.mean((model_outputs['rgb_values'] - ground_truth['rgb'].reshape(-1, 3).cuda())[mask_bin] ** 2)
         self.last_val_psnr = -10. * torch.log10(mse)
         self.writer.add_scalar('val/psnr', self.last_val_psnr.item(), self.total_step)
-        self._plot(indices, model_input, model_outputs, ground_truth, epoch, dataset, mask_bin)
+        if self.rank == 0:
+            self._plot(indices, model_input, model_outputs, ground_truth, epoch, dataset, mask_bin)
         self.total_step += 1
         return depth_cuda, None
 
@@ -411,6 +486,9 @@ class VolOpt():
                 self.save_checkpoints(epoch)
             if epoch % self.render_freq == 0 or (done <= 120 * 50 and epoch % early_every == 0):
                 self._preview(epoch)
+            if self._device_batches and self.world > 1:
+                raise NotImplementedError("device_batches draws on the device per process; the data-parallel ranks need the "
+                                          "same batch: use the DataLoader loop (default) or overlap_loader")
             if self._device_batches and self.device_batches is None and torch.cuda.is_available():
                 from svs_hip.batches import DeviceBatches
                 self.device_batches = DeviceBatches(self.train_dataset, self.num_pixels,

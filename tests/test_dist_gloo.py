@@ -248,3 +248,81 @@ def test_sharded_image_render():
         assert np.array_equal(out["rgb_values"], np.stack([uv[:, 0], uv[:, 1], uv.sum(1)], 1))
         assert np.array_equal(out["depth_values"], uv[:, :1] * 2.0)
         assert out["weights"].shape == (N, 5)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# VolOpt-level data parallelism (volsdf/vsdf.py): joining the process group from the launcher's environment, host random
+# generators continued from rank 0, the batch and the train-mode draws sharded the way TrainStep(shard_draws=True) does
+# --------------------------------------------------------------------------------------------------------------
+def _volopt_worker(rank, world, port, q):
+    sys.path[:0] = [os.path.join(ROOT, "s-volsdf_amd")]
+    import random
+    from types import SimpleNamespace
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import volsdf.vsdf as vs
+    from volsdf.model.network import VolSDFNetwork
+    from volsdf.model.ray_sampler import ErrorBoundSampler
+    assert vs.init_data_parallel() == (world, rank, rank) and dist.get_backend() == "gloo"
+    # ranks arrive with DIFFERENT generator states ...
+    torch.manual_seed(100 + rank); random.seed(200 + rank); np.random.seed(300 + rank)
+    vs.sync_host_rng(world)
+    # ... and continue from rank 0's: same view, same pixels
+    view, perm, npr = random.randint(0, 48), torch.randperm(24 * 32)[:16], float(np.random.rand())
+    # the batch every rank drew, and this rank's share of it (VolOpt._shard_batch)
+    uv = torch.stack([perm % 32, perm // 32], 1).float()[None]
+    gt = {"rgb": torch.rand(1, 16, 3), "rgb_smooth": torch.rand(1, 16, 3), "mask": torch.ones(1, 16, 3)}
+    me = SimpleNamespace(world=world, rank=rank)
+    mi, g = vs.VolOpt._shard_batch(me, {"uv": uv, "pose": torch.eye(4)[None]}, gt)
+    # the step's draws: for the WHOLE batch (world x local rays), then this rank's rows (TrainStep._step, shard_draws)
+    k = 16 // world
+    sampler = SimpleNamespace(N_samples=64, N_samples_eval=128, N_samples_extra=32, inverse_sphere_bg=False)
+    full = ErrorBoundSampler.draw_train_rng(sampler, k * world, torch.device("cpu"))
+    mine = VolSDFNetwork.slice_rng(full, rank * k, (rank + 1) * k)
+    # the logged loss terms: each rank's are its rays' share of the batch means; all-reduced like VolOpt.train_step does
+    vec = torch.tensor([0.25 * (rank + 1), 1.5 * (rank + 1)])
+    dist.all_reduce(vec)
+    q.put((rank, view, perm.numpy(), npr, mi["uv"].numpy(), {n: v.numpy() for n, v in g.items()}, uv.numpy(),
+           {n: v.numpy() for n, v in gt.items()}, {n: v.numpy() for n, v in mine.items()},
+           {n: v.numpy() for n, v in full.items()}, vec.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_volopt_data_parallel_pieces_world2():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_volopt_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    a, b = res
+    assert a[1] == b[1] and np.array_equal(a[2], b[2]) and a[3] == b[3]          # same view / pixels / numpy draw on both ranks
+    assert np.array_equal(a[6], b[6]) and all(np.array_equal(a[7][n], b[7][n]) for n in a[7])
+    # the shards tile the batch: rays, colours ...
+    assert np.array_equal(np.concatenate([a[4], b[4]], 1), a[6])
+    for n in ("rgb", "rgb_smooth", "mask"):
+        assert np.array_equal(np.concatenate([a[5][n], b[5][n]], 1), a[7][n])
+    # ... and the draws (the extras' permutation is per batch, not per ray: identical on both ranks)
+    for n, full in a[9].items():
+        assert np.array_equal(full, b[9][n])
+        if n == "perm":
+            assert np.array_equal(a[8][n], full) and np.array_equal(b[8][n], full)
+        else:
+            assert np.array_equal(np.concatenate([a[8][n], b[8][n]], 0), full), n
+    assert np.allclose(a[10], [0.75, 4.5]) and np.array_equal(a[10], b[10])
+
+
+def test_init_data_parallel_without_launcher(monkeypatch):
+    sys.path.insert(0, os.path.join(ROOT, "s-volsdf_amd"))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SVS_FORCE_DIST"):
+        monkeypatch.delenv(k, raising=False)
+    import torch.distributed as dist
+    import volsdf.vsdf as vs
+    assert vs.init_data_parallel() == (1, 0, 0) and not dist.is_initialized()

@@ -257,3 +257,65 @@ def test_device_batches_blendedmvs_near_pose(monkeypatch):
     monkeypatch.delattr(synthetic_scene, "get_near_id")
     with pytest.raises(NotImplementedError):
         DeviceBatches(ds, 96, torch.device("cuda:0"))
+
+
+def test_volopt_data_parallel_one_gpu(tmp_path, monkeypatch):
+    """The data-parallel path of VolOpt on ONE GPU (SVS_FORCE_DIST=1: a one-rank RCCL group; volsdf/vsdf.py::
+    init_data_parallel): the steps are bit-identical in their per-ray outputs and loss terms to the VolOpt without a process
+    group, ONE all-reduce over the whole flat gradient per step, checkpoints written by rank 0.  And: more ranks than
+    visible GPUs is refused with a clear message before any collective is attempted."""
+    import socket
+    import torch.distributed as dist
+    monkeypatch.chdir(tmp_path)
+
+    def steps(v, n=3):
+        v.train_dataset.change_sampling_idx(v.num_pixels)
+        outs = []
+        for _, batch in zip(range(n), v.train_dataloader):
+            lo = v.train_step(batch)
+            res = v.step_fn._results
+            outs.append(({k: float(x) for k, x in lo.items()}, torch.cat([o["rgb_values"] for _, o in res]).clone()))
+        torch.cuda.synchronize()
+        return outs
+
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    torch.manual_seed(0)
+    import random
+    random.seed(0)
+    plain = steps(build(make_args()))
+    assert not dist.is_initialized()
+
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    monkeypatch.setenv("SVS_FORCE_DIST", "1")
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", str(port))
+    torch.manual_seed(0)
+    random.seed(0)
+    try:
+        v = build(make_args())
+        assert dist.is_initialized() and dist.get_backend() == "nccl" and (v.world, v.rank) == (1, 0)
+        calls, orig = [], dist.all_reduce
+        dist.all_reduce = lambda t, *a, **k: (calls.append(t.numel()), orig(t, *a, **k))[1]
+        try:
+            forced = steps(v)
+        finally:
+            dist.all_reduce = orig
+        v.save_checkpoints(0)
+        assert os.path.exists(os.path.join(v.checkpoints_path, "ModelParameters", "latest.pth"))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    assert calls == [v.step_fn.fp.grad.numel()] * 3, calls
+    # step 0 bit for bit; later steps start from parameters that went through an Adam step on a gradient whose float atomics
+    # add up in a different order from run to run (with or without a process group)
+    assert plain[0][0] == forced[0][0] and torch.equal(plain[0][1], forced[0][1])
+    for (la, ra), (lb, rb) in zip(plain[1:], forced[1:]):
+        assert all(abs(la[k] - lb[k]) <= 2e-3 * max(1.0, abs(la[k])) for k in la), (la, lb)
+        assert float((ra - rb).abs().max()) < 5e-3
+
+    monkeypatch.delenv("SVS_FORCE_DIST")
+    monkeypatch.setenv("WORLD_SIZE", "2"); monkeypatch.setenv("RANK", "1"); monkeypatch.setenv("LOCAL_RANK", str(torch.cuda.device_count()))
+    with pytest.raises(RuntimeError, match="one rank per GPU"):
+        build(make_args())
+    assert not dist.is_initialized()
