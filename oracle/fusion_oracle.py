@@ -12,8 +12,12 @@ Pinning status:
   * remap_linear (cv2.remap, INTER_LINEAR, BORDER_CONSTANT 0, float32 image): PARITY UNPINNED.  Restated from
     OpenCV's documented algorithm (imgproc remap: float maps are converted to fixed point with INTER_BITS = 5
     fractional bits via cvRound, the four weights come from the float bilinear table, border taps read 0).
-  * filter_depth aggregation and the PLY layout (plyfile, not installed): PARITY UNPINNED, restated from
-    runner.py:323-401; the PFM codec is pinned (tests/golden/pfm_codec.npz, reference datasets/data_io.py).
+  * filter_depth (runner.py:301-404: the loop, mask aggregation, depth averaging, back-projection, vertex / colour
+    arrays) and the PLY vertex layout: PINNED by tests/golden/filter_depth.npz -- the reference's own function, its source
+    taken from runner.py with `ast` (the module cannot be imported: hydra's get_config() runs at import) and executed
+    unmodified on a synthetic scan folder, with cv2.remap bound as above and plyfile's PlyData / PlyElement replaced by a
+    stub that captures the structured vertex array (make_fixtures.py::fx_filter_depth); the oracle reproduces every
+    mask, vertex and colour exactly.  The PFM codec is pinned (tests/golden/pfm_codec.npz, reference datasets/data_io.py).
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 """
 import numpy as np

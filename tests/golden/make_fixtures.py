@@ -706,6 +706,96 @@ def fx_fusion():
     save("fusion_geo", **arr)
 
 
+def fx_filter_depth():
+    """`filter_depth` of the reference (runner.py:301-404) run END TO END on a synthetic scan folder.  runner.py cannot be
+    imported (hydra's get_config() runs at import), so the function's own source is taken from the file with `ast`, compiled
+    and executed -- unmodified -- in a namespace that binds the names it uses: the reference's own helpers
+    (read_camera_parameters, read_img, save_mask, check_geometric_consistency, read_pfm, get_trains_ids), numpy / os / Path,
+    `args` as a namespace, a silent logger, and two stand-ins for packages the image lacks: cv2.remap -> the oracle's
+    restatement of OpenCV's fixed-point INTER_LINEAR remap (as in fx_fusion) and plyfile's PlyData / PlyElement -> a stub that
+    CAPTURES what the function hands to PlyElement.describe (the structured vertex array: field order, dtypes, values).
+    Inputs (cams/*.txt written by the reference's write_cam, images/*.jpg, depth_est / confidence PFMs written by the
+    reference's save_pfm) and outputs (vertex array, the three masks per view) are stored; the test replays the files."""
+    import ast
+    import io
+    import shutil
+    import tempfile
+    from pathlib import Path
+    from PIL import Image
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle"))
+    import fusion_oracle
+    import cv2
+    cv2.INTER_LINEAR = 1
+    cv2.remap = lambda src, mx, my, interpolation: fusion_oracle.remap_linear(src, mx, my)
+    if not hasattr(np, "bool"):
+        np.bool = np.bool_
+    import helpers.utils as hu
+    from datasets.data_io import read_pfm, save_pfm
+    from volsdf.datasets.scene_dataset import get_trains_ids
+
+    src = open(os.path.join(ref_shim.REFERENCE_ROOT, "runner.py")).read()
+    fn = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "filter_depth")
+    captured = {}
+
+    class PlyElement:
+        @staticmethod
+        def describe(arr, name):
+            captured["vertex"], captured["element"] = arr.copy(), name
+            return ("element", name)
+
+    class PlyData:
+        def __init__(self, els):
+            captured["n_elements"] = len(els)
+
+        def write(self, filename):
+            captured["plyfile"] = filename
+
+    conf = dict(conf=0.3, filter_dist=1, filter_diff=0.01, thres_view=1)
+    args = SimpleNamespace(vol=SimpleNamespace(dataset=SimpleNamespace(data_dir="DTU")), num_view=3, eval_mask=False,
+                           data_dir_root="unused", **conf)
+    ns = dict(np=np, os=os, Path=Path, args=args, logger=ref_shim._NoLog(), get_trains_ids=get_trains_ids,
+              read_camera_parameters=hu.read_camera_parameters, read_img=hu.read_img, read_pfm=read_pfm,
+              check_geometric_consistency=hu.check_geometric_consistency, save_mask=hu.save_mask, cv2=cv2,
+              PlyData=PlyData, PlyElement=PlyElement)
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "runner.py:filter_depth", "exec"), ns)
+
+    ids = get_trains_ids("DTU", "scan24", 3)                               # [25, 22, 28]
+    views = synth.make_fusion_views(33, hw=(40, 56), n_views=3)
+    root = tempfile.mkdtemp(prefix="svs_fd_")
+    try:
+        scan, out = os.path.join(root, "scan24"), os.path.join(root, "out", "scan24")
+        for d in ("cams", "images"):
+            os.makedirs(os.path.join(scan, d))
+        for d in ("depth_est", "confidence"):
+            os.makedirs(os.path.join(out, d))
+        arr = {"view_ids": np.asarray(ids), "hw": np.asarray((40, 56)), **{k: np.asarray(v) for k, v in conf.items()}}
+        for vid, v in zip(ids, views.values()):
+            K4 = np.eye(4, dtype=F32); K4[:3, :3] = v["K"]
+            hu.write_cam(os.path.join(scan, "cams/{:0>8}_cam.txt".format(vid)), [v["E"], K4], cam_near_far=(1.0, 0.01, 192, 3.0))
+            Image.fromarray((v["img"] * 255).astype(np.uint8)).save(os.path.join(scan, "images/{:0>8}.jpg".format(vid)), quality=95)
+            save_pfm(os.path.join(out, "depth_est/{:0>8}.pfm".format(vid)), v["depth"])
+            save_pfm(os.path.join(out, "confidence/{:0>8}.pfm".format(vid)), v["confidence"])
+            arr[f"cam_{vid}"] = np.frombuffer(open(os.path.join(scan, "cams/{:0>8}_cam.txt".format(vid)), "rb").read(), np.uint8)
+            arr[f"jpg_{vid}"] = np.frombuffer(open(os.path.join(scan, "images/{:0>8}.jpg".format(vid)), "rb").read(), np.uint8)
+            arr[f"depth_{vid}"], arr[f"confidence_{vid}"] = v["depth"], v["confidence"]
+            arr[f"img_{vid}"] = hu.read_img(os.path.join(scan, "images/{:0>8}.jpg".format(vid)))      # what the function sees
+            K, E = hu.read_camera_parameters(os.path.join(scan, "cams/{:0>8}_cam.txt".format(vid)))
+            arr[f"K_{vid}"], arr[f"E_{vid}"] = K, E
+        ns["filter_depth"](scan, out, os.path.join(root, "scan24.ply"))
+        vtx = captured["vertex"]
+        assert captured["element"] == "vertex" and captured["n_elements"] == 1
+        arr["vertex_descr"] = np.asarray(repr(vtx.dtype.descr))
+        arr["vertex_xyz"] = np.stack([vtx[k] for k in "xyz"], 1)
+        arr["vertex_rgb"] = np.stack([vtx[k] for k in ("red", "green", "blue")], 1)
+        for vid in ids:
+            for tag in ("photo", "geo", "final"):
+                arr[f"mask_{vid}_{tag}"] = np.array(Image.open(os.path.join(out, "mask/{:0>8}_{}.png".format(vid, tag)))) > 0
+        print(f"   filter_depth: {len(vtx)} vertices, dtype {vtx.dtype.descr}")
+        save("filter_depth", **arr)
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 def fx_pfm():
     """datasets/data_io.py save_pfm / read_pfm of the reference: the bytes it writes for a grey and a colour image and
     what it reads back."""
@@ -867,7 +957,7 @@ def fx_featurenet():
     save("featurenet", seed=np.asarray(41), img=img, **{k: v[0].numpy() for k, v in out.items()})
 
 
-ALL = dict(fusion=fx_fusion, pfm=fx_pfm, chamfer=fx_chamfer, chamfer_mesh=fx_chamfer_mesh, featurenet=fx_featurenet, rays=fx_rays, sdf_mlp=fx_sdf_mlp, rgb_mlp=fx_rgb_mlp, density=fx_density, sampler=fx_sampler,
+ALL = dict(fusion=fx_fusion, filter_depth=fx_filter_depth, pfm=fx_pfm, chamfer=fx_chamfer, chamfer_mesh=fx_chamfer_mesh, featurenet=fx_featurenet, rays=fx_rays, sdf_mlp=fx_sdf_mlp, rgb_mlp=fx_rgb_mlp, density=fx_density, sampler=fx_sampler,
            composite=fx_composite, forward=fx_forward, forward_bg=fx_forward_bg, cost_mapping=fx_cost_mapping, loss=fx_loss, casmvs=fx_casmvs, train_step=fx_train_step, train_step_r32=lambda: fx_train_step(32, 2, "train_step_r32"),
            sdf_mlp_w1=lambda: fx_sdf_mlp("w1"), forward_w1=fx_forward_w1,
            train_step_w1=lambda: fx_train_step(16, 2, "train_step_w1", "w1"),

@@ -113,3 +113,47 @@ def test_ply_writer_and_reader(tmp_path):
     assert col is None
     write_ply(fn, np.zeros((0, 3), F32), np.zeros((0, 3), np.uint8))               # empty cloud
     assert read_ply_points(fn)[0].shape == (0, 3)
+
+
+def load_filter_depth(golden_dir):
+    g = dict(np.load(os.path.join(golden_dir, "filter_depth.npz")))
+    ids = [int(v) for v in g["view_ids"]]
+    views = {v: dict(K=g[f"K_{v}"], E=g[f"E_{v}"], depth=g[f"depth_{v}"], confidence=g[f"confidence_{v}"], img=g[f"img_{v}"])
+             for v in ids}
+    conf = dict(conf=float(g["conf"]), filter_dist=float(g["filter_dist"]), filter_diff=float(g["filter_diff"]),
+                thres_view=int(g["thres_view"]))
+    return g, ids, views, conf
+
+
+def test_oracle_filter_depth_matches_reference_end_to_end(golden_dir):
+    """`filter_depth` of the reference itself (runner.py:301-404, its source executed by make_fixtures.fx_filter_depth on a
+    synthetic scan folder: fixture filter_depth.npz) against the oracle's restatement of its loop: the three masks of every
+    view, every vertex, every colour, and the layout of the structured array the function hands to plyfile."""
+    g, ids, views, conf = load_filter_depth(golden_dir)
+    xyz, rgb = [], []
+    for v in ids:
+        out = forc.fuse_view(views[v], [views[s] for s in ids if s != v], **conf)
+        for tag in ("photo", "geo", "final"):
+            assert np.array_equal(out[tag + "_mask"], g[f"mask_{v}_{tag}"]), (v, tag)
+        xyz.append(out["xyz"]); rgb.append(out["rgb"])
+    xyz, rgb = np.concatenate(xyz), np.concatenate(rgb)
+    assert len(xyz) == len(g["vertex_xyz"]) > 1000
+    np.testing.assert_array_equal(xyz, g["vertex_xyz"])
+    np.testing.assert_array_equal(rgb, g["vertex_rgb"])
+    # runner.py:389-400: vertex record = x, y, z (little-endian float32) then red, green, blue (uint8), element 'vertex'
+    assert str(g["vertex_descr"]) == "[('x', '<f4'), ('y', '<f4'), ('z', '<f4'), ('red', '|u1'), ('green', '|u1'), ('blue', '|u1')]"
+    body = forc.ply_bytes(xyz, rgb).split(b"end_header\n", 1)[1]
+    rec = np.frombuffer(body, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("red", "u1"), ("green", "u1"), ("blue", "u1")])
+    assert len(rec) == len(xyz) and np.array_equal(rec["z"], g["vertex_xyz"][:, 2]) and np.array_equal(rec["blue"], g["vertex_rgb"][:, 2])
+
+
+def test_camera_and_image_files_of_the_fixture_read_back(golden_dir, tmp_path):
+    """The drop-in readers on the very files the reference read (camera text written by its write_cam, a JPEG)."""
+    from helpers.utils import read_camera_parameters, read_img
+    g, ids, views, _ = load_filter_depth(golden_dir)
+    for v in ids:
+        (tmp_path / "cam.txt").write_bytes(g[f"cam_{v}"].tobytes())
+        (tmp_path / "im.jpg").write_bytes(g[f"jpg_{v}"].tobytes())
+        K, E = read_camera_parameters(str(tmp_path / "cam.txt"))
+        np.testing.assert_array_equal(K, views[v]["K"]); np.testing.assert_array_equal(E, views[v]["E"])
+        np.testing.assert_array_equal(read_img(str(tmp_path / "im.jpg")), views[v]["img"])

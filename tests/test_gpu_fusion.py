@@ -124,3 +124,42 @@ def test_fuse_argument_errors(dev):
     with pytest.raises(AssertionError):
         fusion.fuse_view(views[0], [bad])
     assert lib.load().svs_fuse_mats_per_src() == 68
+
+
+def test_filter_depth_folder_vs_reference_end_to_end(dev, golden_dir, tmp_path):
+    """`svs_hip.fusion.filter_depth_folder` (files in, PLY out) against the reference's own `filter_depth` run on the same
+    scan folder (runner.py:301-404 executed by make_fixtures.fx_filter_depth; fixture filter_depth.npz): the three masks per
+    view (float64 geometry on both sides: a pixel may differ where a quantity sits within rounding of its threshold), and
+    -- where the final masks agree -- every vertex, every colour and the PLY file byte for byte in the layout the reference
+    hands to plyfile."""
+    from datasets.data_io import save_pfm
+    from PIL import Image
+    from svs_hip import fusion
+    from test_fusion_cpu import load_filter_depth
+    g, ids, views, conf = load_filter_depth(golden_dir)
+    scan, out = tmp_path / "scan24", tmp_path / "out" / "scan24"
+    for d in (scan / "cams", scan / "images", out / "depth_est", out / "confidence"):
+        d.mkdir(parents=True)
+    for v in ids:
+        (scan / "cams" / "{:0>8}_cam.txt".format(v)).write_bytes(g[f"cam_{v}"].tobytes())
+        (scan / "images" / "{:0>8}.jpg".format(v)).write_bytes(g[f"jpg_{v}"].tobytes())
+        save_pfm(str(out / "depth_est" / "{:0>8}.pfm".format(v)), views[v]["depth"])
+        save_pfm(str(out / "confidence" / "{:0>8}.pfm".format(v)), views[v]["confidence"])
+    ply = str(tmp_path / "scan24.ply")
+    xyz, rgb, stats = fusion.filter_depth_folder(str(scan), str(out), ply, ids, **conf)
+    same = True
+    for v in ids:
+        for tag in ("photo", "geo", "final"):
+            got = np.array(Image.open(str(out / "mask" / "{:0>8}_{}.png".format(v, tag)))) > 0
+            if tag == "photo":
+                assert np.array_equal(got, g[f"mask_{v}_{tag}"])
+            else:
+                same &= bool(_masks_agree(got, g[f"mask_{v}_{tag}"]).all())
+    assert abs(len(xyz) - len(g["vertex_xyz"])) <= 3
+    if same:
+        np.testing.assert_allclose(xyz, g["vertex_xyz"], rtol=2e-6, atol=2e-6)
+        assert np.array_equal(rgb, g["vertex_rgb"])
+        assert open(ply, "rb").read() == forc.ply_bytes(xyz, rgb)
+    pts, col = fusion.read_ply_points(ply)
+    assert pts.shape == (len(xyz), 3) and np.array_equal(col, rgb)
+    print(f"filter_depth: {len(xyz)} vertices (reference {len(g['vertex_xyz'])}), masks identical: {same}")
