@@ -41,8 +41,8 @@ int svs_rays_from_uv(const float* uv, const float* pose, const float* intrinsics
  * weight_g == NULL for networks without weight-norm.  workspace: svs_pack_workspace_bytes().
  * which: 0 SDF forward, 1 SDF full (forward + feature head + input-gradient pass), 2 SDF training backward,
  *        3 radiance forward, 4 radiance backward (5..8: the background networks, see below), 9 SDF forward for
- *        svs_sdf_vals16 (fp16x2 only).  The first svs_pack_stream call per `which` uploads a 2 KiB chunk
- * table (one hipMalloc + hipMemcpy; make that call outside graph capture).
+ *        svs_sdf_vals16 (fp16x2 only; experimental build).  Like every entry point, svs_pack_stream allocates and copies
+ * nothing on its own: the stream's chunk table (<= 2.2 KB) travels in the kernel arguments.
  * precision: how the kernels that consume the stream evaluate the layer products (the same value is passed to them):
  *   SVS_MMA_F32   v_mfma_f32_32x32x2_f32 on float32 operands (exact float32 products);
  *   SVS_MMA_F16X2 v_mfma_f32_32x32x16_f16 on operands split into two fp16 pieces, a = hi + mid, three products
@@ -73,6 +73,7 @@ size_t svs_pack_workspace_bytes(void);
 int svs_sdf_vals(const float* points, int n_points, const float* cam, int cam_stride, const float* dirs, const float* z,
                  int S, int n_rays, const float* stream, int precision, float sphere_radius, float sphere_scale,
                  int clamp_n, float* sdf, const int* gate, int gate_points, int gate_stride, void* hip_stream);
+#ifdef SVS_EXPERIMENTAL_KERNELS   /* built only with SVS_BUILD_EXPERIMENTS=1 (s-volsdf_amd/build.py); not part of the default library */
 /* The same evaluation by the 16-point-wave kernel (two waves per SIMD, v_mfma_f32_16x16x32_f16, csrc/svs_mlp_w16.hip):
  * `stream` packed with which = 9; fp16x2 arithmetic; results agree with svs_sdf_vals to float32 rounding of the
  * accumulation order. */
@@ -84,6 +85,7 @@ int svs_sdf_vals16(const float* points, int n_points, const float* cam, int cam_
 int svs_sdf_vals_pair(const float* points, int n_points, const float* cam, int cam_stride, const float* dirs, const float* z,
                       int S, int n_rays, const float* stream, float sphere_radius, float sphere_scale, int clamp_n, float* sdf,
                       const int* gate, int gate_points, int gate_stride, void* hip_stream);
+#endif
 /* svs_sdf_outputs: ImplicitNetwork.get_outputs (network.py:105-123) and .gradient (:90-103):
  *   sdf (P), grad = d sdf/dx (P,3), feat_tiles (svs_feat_tiles_bytes; wave-tile layout, may be NULL),
  *   hbuf (svs_sdf_hbuf_bytes): the activations h_1..h_8 kept for the gradient pass / training backward;

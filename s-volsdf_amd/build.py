@@ -23,8 +23,6 @@ UNITS = {
     "svs_pack.hip": [],
     "svs_mlp.hip": [],
     "svs_mlp_h2.hip": [],
-    "svs_mlp_w16.hip": [],
-    "svs_mlp_h2p.hip": [],
     "svs_bg_h2.hip": [],
     "svs_sampler.hip": ["-ffp-contract=off"],
     "svs_render.hip": ["-ffp-contract=off"],
@@ -40,7 +38,12 @@ UNITS = {
     "svs_fusion.hip": ["-ffp-contract=off"],
     "svs_cloud.hip": ["-ffp-contract=off"],
 }
-BASE_FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+# The two-waves-per-SIMD experiments of round 3 (svs_sdf_vals16 / svs_sdf_vals_pair, measured no faster
+# than the default kernel) are built only on request: SVS_BUILD_EXPERIMENTS=1.
+EXPERIMENTS = os.environ.get("SVS_BUILD_EXPERIMENTS", "0") == "1"
+if EXPERIMENTS:
+    UNITS.update({"svs_mlp_w16.hip": [], "svs_mlp_h2p.hip": []})
+BASE_FLAGS = (["-DSVS_EXPERIMENTAL_KERNELS"] if EXPERIMENTS else []) + ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
               "-x", "hip"]
 
 
@@ -57,6 +60,7 @@ def _stamp():
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(name.encode()); h.update(f.read())
     h.update(repr(sorted(UNITS.items())).encode())
+    h.update(repr(BASE_FLAGS).encode())
     return h.hexdigest()
 
 

@@ -328,6 +328,7 @@ int svs_sdf_vals(const float* points, int n_points, const float* cam, int cam_st
   return check_launch("svs_sdf_vals");
 }
 
+#ifdef SVS_EXPERIMENTAL_KERNELS
 // svs_sdf_vals by the K-split-pair kernel (two waves per SIMD on the same 32 points, csrc/svs_mlp_h2p.hip): same stream
 // (fp16x2), same arguments.  An experiment kept for A/B runs; measured slower than svs_sdf_vals.
 int svs_sdf_vals_pair(const float* points, int n_points, const float* cam, int cam_stride, const float* dirs, const float* z,
@@ -343,6 +344,7 @@ int svs_sdf_vals_pair(const float* points, int n_points, const float* cam, int c
   a.clamp_n = clamp_n < 0 ? a.src.P : clamp_n;
   return launch_sdf_only_kp(a, (hipStream_t)hip_stream);
 }
+#endif
 
 size_t svs_sdf_hbuf_bytes(int n_points) { return (size_t)wave_tiles(n_points) * 8 * 128 * 64 * sizeof(float); }
 size_t svs_feat_tiles_bytes(int n_points) { return (size_t)wave_tiles(n_points) * 128 * 64 * sizeof(float); }

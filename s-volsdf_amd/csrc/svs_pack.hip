@@ -66,6 +66,11 @@ __device__ __forceinline__ int rev0_pe(int tile, int local) {
 }
 
 struct ChunkDesc { int kind, layer, tile, off_f4; };   // off_f4: offset of the chunk in the stream, in float4
+// The chunk table of a stream travels BY VALUE in the kernel arguments (<= 136 descriptors = 2176 bytes of the 4 KiB a
+// launch may carry): the library allocates nothing and copies nothing on its own -- the boundary's "no allocation" rule
+// holds for svs_pack_stream too (until round 3 its first call per stream kind did a hipMalloc + hipMemcpy of the table).
+constexpr int kMaxChunks = 136;
+struct ChunkTable { ChunkDesc d[kMaxChunks]; };
 
 // Weight that multiplies input row `crow` (C-layout row of the layer input) in output row 32*t + col32 of a chunk.
 // q0: PE index of the element (SDF layer 0); e: index into the 16 extra input rows (radiance layer 0) or -1.
@@ -153,9 +158,9 @@ __device__ __forceinline__ float header_value(const LayerPtrs& w, int kind, int 
 constexpr int kPackParts = 4;
 constexpr int kPackStride = 256 * kPackParts;
 __global__ __launch_bounds__(256) void pack_stream_kernel(LayerPtrs w, const float* __restrict__ scale,
-                                                          const ChunkDesc* __restrict__ table, int fmt, int net,
+                                                          const ChunkTable table, int fmt, int net,
                                                           float* __restrict__ out) {
-  const ChunkDesc d = table[blockIdx.x / kPackParts];
+  const ChunkDesc d = table.d[blockIdx.x / kPackParts];
   const int tid = (blockIdx.x % kPackParts) * 256 + threadIdx.x;
   const int kind = d.kind & 0xff;
   const bool nobias = (d.kind & kNoBias) != 0;
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(256) void pack_stream_kernel(LayerPtrs w, const flo
 // ------------------------------------------------------------------------------------------------------------
 struct StreamTable {
   std::vector<ChunkDesc> host;
-  ChunkDesc* dev = nullptr;
+  ChunkTable arg;                     // the same descriptors in the form the kernel takes them
   size_t total_f4 = 0;
   void add(int kind, int layer, int tile) {
     host.push_back(ChunkDesc{kind, layer, tile, (int)total_f4});
@@ -321,6 +326,9 @@ static StreamTable& table_for(int which) {
       t.add(kSdfFwd, 8, 0);     // the head: rows 0..31 of lin8 as one more tile (row 0 = sdf; the kernel runs its first sub-tile)
       break;
   }
+  if (t.host.size() > (size_t)kMaxChunks) { t.host.clear(); t.total_f4 = 0; return t; }   // (cannot happen: static layouts)
+  t.arg = ChunkTable{};
+  for (size_t i = 0; i < t.host.size(); ++i) t.arg.d[i] = t.host[i];
   return t;
 }
 
@@ -365,14 +373,10 @@ int svs_pack_stream(int which, int precision, const float* const* weight_v, cons
     if (!w.v[l] || !w.b[l]) { set_error("svs_pack_stream: null layer %d", l); return SVS_EINVAL; }
   }
   StreamTable& t = table_for(which);
-  if (!t.dev) {
-    hipError_t e = hipMalloc(&t.dev, t.host.size() * sizeof(ChunkDesc));
-    if (e == hipSuccess) e = hipMemcpy(t.dev, t.host.data(), t.host.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { set_error("svs_pack_stream: table upload: %s", hipGetErrorString(e)); t.dev = nullptr; return (int)e; }
-  }
+  if (t.host.empty()) { set_error("svs_pack_stream: stream %d has no chunk table", which); return SVS_EINVAL; }
   hipStream_t s = (hipStream_t)hip_stream;
   rownorm_kernel<<<(nl * kScaleStride + 3) / 4, 256, 0, s>>>(w, nl, is_rgb ? 1 : 0, net, workspace);
-  pack_stream_kernel<<<(unsigned)t.host.size() * kPackParts, 256, 0, s>>>(w, workspace, t.dev, precision, net, stream_out);
+  pack_stream_kernel<<<(unsigned)t.host.size() * kPackParts, 256, 0, s>>>(w, workspace, t.arg, precision, net, stream_out);
   return check_launch("svs_pack_stream");
 }
 

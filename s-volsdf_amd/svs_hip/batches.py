@@ -27,7 +27,16 @@ class DeviceBatches:
         self.ds, self.num_pixels, self.device = dataset, int(num_pixels), torch.device(device)
         self.W = int(dataset.img_res[1])
         self.total_pixels = int(dataset.total_pixels)
-        self.train_ids = list(dataset.trains_ids())
+        # scene_dataset.py:215-219: with num_views >= 1 a train item is a random one of the first num_views training views;
+        # otherwise (num_views < 1: every image is a training image) the DataLoader's shuffled index over all images
+        self.num_views = int(getattr(dataset, "num_views", 1))
+        if self.num_views >= 1:
+            self.train_ids = list(dataset.trains_ids())[:self.num_views]
+            if len(self.train_ids) != self.num_views:
+                raise ValueError(f"dataset.trains_ids() has {len(self.train_ids)} entries, num_views = {self.num_views}")
+        else:
+            self.train_ids = list(range(int(dataset.n_images)))
+        self._order = []
         self.centers = bool(getattr(dataset, "use_pixel_centers", False))
         up = lambda t: t.to(self.device, dtype=torch.float32).contiguous()
         self.rgb = {i: up(dataset.rgb_images[i]) for i in self.train_ids}
@@ -48,7 +57,12 @@ class DeviceBatches:
         return len(self.ds)            # an epoch is len(dataset) steps, as with the reference's DataLoader
 
     def batch(self):
-        view = self.train_ids[random.randint(0, len(self.train_ids) - 1)]
+        if self.num_views >= 1:
+            view = self.train_ids[random.randint(0, self.num_views - 1)]
+        else:
+            if not self._order:                      # a shuffled pass over all images, like DataLoader(shuffle=True)
+                self._order = torch.randperm(len(self.train_ids)).tolist()
+            view = self.train_ids[self._order.pop()]
         idx = torch.randperm(self.total_pixels, device=self.device)[:self.num_pixels]
         uv = torch.stack([idx % self.W, idx // self.W], -1).to(torch.float32)
         if self.centers:

@@ -76,10 +76,30 @@ def _hwc(f):
     C, H, W = f.shape
     o = torch.empty(H, W, C, device=f.device)
     _lib.check(L.svs_chw_to_hwc(_ptr(_f32(f)), _ptr(o), C, H, W, _stream()), "svs_chw_to_hwc")
-    if len(_HWC_CACHE) >= 32:
+    # bounded by bytes (a 32 x 1200 x 1600 float32 map and its copy are 490 MB), not by entries; `clear_caches()` drops
+    # everything at the end of a scan / stage loop.  The key is (storage address, torch version counter, shape): a producer
+    # that rewrites a cached feature map through this library's raw-pointer kernels does not bump the counter -- such
+    # buffers must not be recycled while cached (the FeatureNet wrapper hands out fresh tensors).
+    global _HWC_BYTES
+    nbytes = 2 * f.numel() * 4
+    if _HWC_BYTES + nbytes > _HWC_BUDGET:
         _HWC_CACHE.clear()
+        _HWC_BYTES = 0
     _HWC_CACHE[key] = (f, o)          # keeps `f` alive: the key holds its address
+    _HWC_BYTES += nbytes
     return o
+
+
+_HWC_BYTES = 0
+_HWC_BUDGET = int(os.environ.get("SVS_HWC_CACHE_BYTES", str(1 << 30)))
+
+
+def clear_caches():
+    """Drop the cached channel-last feature maps and projection constants (end of a scan / stage loop)."""
+    global _HWC_BYTES
+    _HWC_CACHE.clear()
+    _RT_CACHE.clear()
+    _HWC_BYTES = 0
 
 
 class SplitVolume:
@@ -102,6 +122,17 @@ class SplitVolume:
             buf = SplitVolume._cache[key] = torch.zeros(nbytes // 2, dtype=torch.float16, device=device)
         self.buf = buf
         self.device = buf.device
+        # the buffer is shared by every SplitVolume of this shape and stream: a new one takes it over, and a holder of an
+        # older object must not read it any more (`check_current`, called by the consumers)
+        self._key = key
+        self.generation = SplitVolume._generation[key] = SplitVolume._generation.get(key, 0) + 1
+
+    _generation = {}
+
+    def check_current(self):
+        if SplitVolume._generation.get(self._key) != self.generation:
+            raise RuntimeError("this SplitVolume's buffer has been reused by a later volume of the same shape on the same "
+                               "stream (the buffers are cached per shape); consume a split volume before building the next")
 
     @staticmethod
     def pack(x):
@@ -115,6 +146,7 @@ class SplitVolume:
 
     def float(self):
         """back to float32 (C,D,H,W): hi + mid (tests)"""
+        self.check_current()
         L = _lib.load()
         dims = (ctypes.c_int * 2)()
         L.svs_split_volume_dims(self.C, self.D, self.H, self.W, dims)
@@ -407,6 +439,7 @@ def conv3d(x, weight, bias=None, skip=None, stride=1, transposed=False, relu=Tru
         fused = (not transposed and stride == 1 and skip is None
                  and (rows_supported(x.C, Cout) if rows else pair_supported(x.C, Cout)))
         if fused:
+            x.check_current()
             out = torch.empty((Cout, x.D, x.H, x.W), device=x.device)
             if rows:
                 _lib.check(L.svs_conv3d_rows(_ptr(x.buf), _ptr(rows_weight_fragments(weight)), _ptr(bias), _ptr(out), x.C, Cout,

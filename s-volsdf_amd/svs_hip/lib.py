@@ -48,10 +48,6 @@ SIGNATURES = {
     "svs_pack_workspace_bytes": (c_size_t, []),
     "svs_sdf_vals": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, _P, c_int, c_float, c_float, c_int, _P, _P,
                              c_int, c_int, _P]),
-    "svs_sdf_vals16": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, _P, c_float, c_float, c_int, _P, _P,
-                               c_int, c_int, _P]),
-    "svs_sdf_vals_pair": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, _P, c_float, c_float, c_int, _P, _P,
-                                  c_int, c_int, _P]),
     "svs_sdf_hbuf_bytes": (c_size_t, [c_int]),
     "svs_feat_tiles_bytes": (c_size_t, [c_int]),
     "svs_sdf_outputs": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, _P, c_int, c_float, c_float, c_int, _P, _P,
@@ -149,6 +145,15 @@ SIGNATURES = {
 }
 
 
+# entry points of the experimental kernels: present only in a library built with SVS_BUILD_EXPERIMENTS=1
+EXPERIMENTAL_SIGNATURES = {
+    "svs_sdf_vals16": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, _P, c_float, c_float, c_int, _P, _P,
+                               c_int, c_int, _P]),
+    "svs_sdf_vals_pair": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, _P, c_float, c_float, c_int, _P, _P,
+                                  c_int, c_int, _P]),
+}
+
+
 def load():
     """Load the shared library once; raises SvsError when it has not been built."""
     global _lib
@@ -162,6 +167,11 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in EXPERIMENTAL_SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     _lib = lib
     return lib
 

@@ -97,6 +97,9 @@ class PackedMlp:
         self.sdf_kernel = (sdf_kernel or os.environ.get("SVS_SDF_KERNEL", "32")) if is_h2(self.precision) else "32"
         if self.sdf_kernel not in ("32", "16", "pair"):
             raise ValueError(f"SVS_SDF_KERNEL must be 32, 16 or pair, not {self.sdf_kernel!r}")
+        if self.sdf_kernel != "32" and not hasattr(L, "svs_sdf_vals_pair"):
+            raise _lib.SvsError(f"SVS_SDF_KERNEL={self.sdf_kernel}: the experimental two-waves-per-SIMD kernels are not in this "
+                                "library; rebuild with SVS_BUILD_EXPERIMENTS=1 python s-volsdf_amd/build.py --force")
         self.w16 = self.sdf_kernel == "16"
         self.sdf_stream16 = torch.empty(L.svs_stream_bytes(9) // 4, device=device) if self.w16 else None
         self._ws16 = torch.empty(L.svs_pack_workspace_bytes() // 4, device=device) if self.w16 else None

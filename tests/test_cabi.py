@@ -22,6 +22,8 @@ def lib():
 def _header_decls():
     src = open(os.path.join(ROOT, "include", "svolsdf_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    # (the experimental kernels' prototypes: only in a library built with SVS_BUILD_EXPERIMENTS=1)
+    src = re.sub(r"#ifdef SVS_EXPERIMENTAL_KERNELS.*?#endif", "", src, flags=re.S)
     decls = {}
     for m in re.finditer(r"\b(?:int|size_t|const char\*)\s+(svs_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         args = m.group(2).strip()

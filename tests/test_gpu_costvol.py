@@ -165,8 +165,13 @@ def test_warp_variance_split_volume(dev, C, n_views, D, hw):
     assert not bool(border.any())                                      # nothing outside the interior is written
     # packing the float32 volume gives the same pieces bit for bit
     a = sv.buf.clone()
+    inner = sv.buf.view(D + 2, -1, 2, C // 8, 32 * ((W + 31) // 32) + 4, 8)[1:D + 1, 1:H + 1, :, :, 1:W + 1]
+    inner.add_(1.0)                                                    # a pack that wrote nothing would leave this behind
     sv2 = costvol.SplitVolume.pack(ref)
     assert sv2.buf.data_ptr() == sv.buf.data_ptr() and torch.equal(a, sv2.buf)
+    # the buffer is shared per shape: the older object is stale now and says so
+    with pytest.raises(RuntimeError, match="reused"):
+        sv.float()
 
 
 @pytest.mark.parametrize("cin,cout,shape", [(32, 8, (5, 7, 37)), (16, 8, (3, 9, 70)), (8, 8, (9, 6, 33)), (32, 5, (2, 4, 32)),

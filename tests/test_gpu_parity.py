@@ -158,7 +158,10 @@ def test_sdf_mlp_ragged(dev, ops, packed, P):
 @pytest.mark.parametrize("kernel", ["16", "pair"])
 def test_sdf_vals_two_wave_variants(dev, ops, kernel):
     """The two experimental two-waves-per-SIMD sdf-only kernels (SVS_SDF_KERNEL=16 / pair) against the oracle and against the
-    default kernel: ragged sizes, ray mode with the sphere clamp, and a gated launch."""
+    default kernel: ragged sizes, ray mode with the sphere clamp, and a gated launch.  (Opt-in build: SVS_BUILD_EXPERIMENTS=1.)"""
+    from svs_hip import lib
+    if not hasattr(lib.load(), "svs_sdf_vals_pair"):
+        pytest.skip("library built without the experimental kernels (SVS_BUILD_EXPERIMENTS=1 python s-volsdf_amd/build.py --force)")
     params = synth.make_params(0)
     layers = orc.effective_weights(params, "implicit_network", 9)
     v, g, b = ([params[f"implicit_network.lin{l}.{n}"] for l in range(9)] for n in ("weight_v", "weight_g", "bias"))

@@ -16,8 +16,11 @@ from models.CasMVSNet import CascadeMVSNet  # noqa: E402
 from svs_hip import costvol  # noqa: E402
 
 
-def main():
-    dev = torch.device("cuda:0")
+def measure(dev=None):
+    """-> dict: per-stage ms of the three CasMVSNet stages of one reference view (config 3), and roofline-style rows for
+    the fused warp + variance kernel (HBM: algorithmic bytes of SURVEY.md 8d) and the regularisation U-Net (MFMA: 2 x MACs
+    per voxel x voxels, priced against 2500 / 3 TFLOP/s like the fp16x2 MLP kernels), conv0 on its own, FeatureNet."""
+    dev = dev or torch.device("cuda:0")
     H, W = 512, 640
     feats, proj, depth_values = synth.make_mvs_sample(3, img_hw=(H, W))
     m = CascadeMVSNet(refine=False, ndepths=[192, 32, 8], depth_interals_ratio=[1.0, 0.5, 0.5], share_cr=False,
@@ -67,7 +70,53 @@ def main():
         res[key + "_warp_ms"] = t * 1e3
         res[key + "_warp_GBps"] = bytes_ / t / 1e9
         res[key + "_unet_TFLOPs"] = 2 * macs[st] * D * h * w / ((res[key + "_ms"] * 1e-3 - t)) / 1e12
-    print(json.dumps(res))
+        rows = res.setdefault("roofline", [])
+        rows.append(dict(kernel="svs::costvol::warp_variance_reuse_kernel", stage=st + 1, bound="hbm", kernel_ms=t * 1e3,
+                         algorithmic_bytes=bytes_, achieved=bytes_ / t / 1e9, peak=8000.0, unit="GB/s", frac=bytes_ / t / 8.0e12))
+        flop = 2 * macs[st] * D * h * w
+        tu = res[key + "_ms"] * 1e-3 - t
+        rows.append(dict(kernel="CostRegNet (11 launches)", stage=st + 1, bound="mfma", kernel_ms=tu * 1e3, algorithmic_flop=flop,
+                         achieved=flop / tu / 1e12, peak=2500.0 / 3, unit="TFLOP/s", frac=flop / tu / (2.5e15 / 3)))
+        if st == 0:
+            # conv0 alone (32 -> 8 channels on the split volume the warp kernel wrote): 68 % of the stage-1 U-Net's MACs
+            cr = m.cost_regularization[0]
+            sv = costvol.warp_variance(fs, sample["proj_matrices"][key], dv, split=True)
+            w0, b0 = cr.conv0.folded()
+            if True:
+                tc = []
+                for _ in range(5):
+                    sv = costvol.warp_variance(fs, sample["proj_matrices"][key], dv, split=True)
+                    e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                    e[0].record()
+                    costvol.conv3d(sv, w0, b0, relu=True)
+                    e[1].record()
+                    torch.cuda.synchronize()
+                    tc.append(e[0].elapsed_time(e[1]))
+                f0 = 2 * 27 * 32 * 8 * D * h * w
+                res["stage1_conv0_ms"] = min(tc)
+                rows.append(dict(kernel="svs::conv::conv3d_pair_kernel<32,2>", stage=1, bound="mfma", kernel_ms=min(tc),
+                                 algorithmic_flop=f0, achieved=f0 / (min(tc) * 1e-3) / 1e12, peak=2500.0 / 3, unit="TFLOP/s",
+                                 frac=f0 / (min(tc) * 1e-3) / (2.5e15 / 3)))
+    # FeatureNet (row f1) on one 512 x 640 image
+    from models.CasMVSNet import FeatureNet
+    net = FeatureNet(8, 3, 4, "fpn")
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_featurenet_params(1).items()})
+    net.to(dev).eval()
+    x = torch.rand(1, 3, H, W, device=dev)
+    with torch.no_grad():
+        net(x); torch.cuda.synchronize()
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        e[0].record()
+        for _ in range(10):
+            net(x)
+        e[1].record(); torch.cuda.synchronize()
+    res["featurenet_ms_per_image"] = e[0].elapsed_time(e[1]) / 10
+    res["workload"] = "configs[2]: CasMVSNet 3-stage cost volume, 640x512 image, D = 192/32/8, 3 views, one reference view"
+    return res
+
+
+def main():
+    print(json.dumps(measure()))
 
 
 if __name__ == "__main__":

@@ -16,7 +16,7 @@ import torch  # noqa: E402
 import synth  # noqa: E402
 
 
-def main():
+def measure(chunk_loop_too=True):
     from volsdf.utils.conf import dtu_model_conf
     from volsdf.model.network import VolSDFNetwork
     from svs_hip.renderer import depth_image, render_image
@@ -53,10 +53,15 @@ def main():
             for lo in range(0, N, 500):
                 o = m(dict(inp, uv=inp["uv"][:, lo:lo + 500]), fast=-1)
         return o
-    t, _ = timed(chunk_loop, 1)
-    res["chunk_loop_500_s"] = t
-    res["chunk_loop_500_rays_per_s"] = N / t
-    print(json.dumps(res))
+    if chunk_loop_too:
+        t, _ = timed(chunk_loop, 1)
+        res["chunk_loop_500_s"] = t
+        res["chunk_loop_500_rays_per_s"] = N / t
+    return res
+
+
+def main():
+    print(json.dumps(measure()))
 
 
 if __name__ == "__main__":

@@ -29,4 +29,4 @@ for rep in range(5):
         ops.sdf_vals(pk, src, 3.0, 20.0)
     e1.record(); torch.cuda.synchronize()
     best.append(e0.elapsed_time(e1) / 50)
-print(os.environ.get("SVS_LIB_PATH", "default").split("_")[-1], os.environ.get("SVS_SDF_TILE", "16"), R, "rays: ms", " ".join(f"{t:.4f}" for t in best))
+print(os.environ.get("SVS_LIB_PATH", "default").split("_")[-1], "SVS_SDF_KERNEL=" + os.environ.get("SVS_SDF_KERNEL", "32"), R, "rays: ms", " ".join(f"{t:.4f}" for t in best))
