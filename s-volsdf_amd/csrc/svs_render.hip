@@ -421,7 +421,10 @@ __global__ __launch_bounds__(256) void loss_rays_kernel(LossArgs a, double* __re
       for (int c = 0; c < 3; ++c) {
         const float d = a.rgb_values[3 * r + c] - a.rgb_gt[3 * r + c];
         l1 += (double)__builtin_fabsf(d);
-        const float sg = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+        // torch.sign: sign(NaN) = NaN -- a non-finite colour poisons the step's gradient, which the NaN guard then drops
+        // as a whole (volsdf/vsdf.py:454-463), exactly what happens in the reference (e.g. the ray through the centre of
+        // the bounding sphere in the inverted-sphere background, network_bg.py:196-197: rot_axis = 0 / 0)
+        const float sg = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : d);
         a.d_rgb_values[3 * r + c] = rgb_on ? a.rgb_weight * sg / (3.0f * (float)a.R_norm) : 0.0f;
       }
       float dd = 0.0f;
@@ -442,7 +445,7 @@ __global__ __launch_bounds__(256) void loss_rays_kernel(LossArgs a, double* __re
       const float g0 = a.grad_theta[3 * i], g1 = a.grad_theta[3 * i + 1], g2 = a.grad_theta[3 * i + 2];
       const float n = __builtin_sqrtf((g0 * g0 + g1 * g1) + g2 * g2);
       e = (double)(n - 1.0f) * (double)(n - 1.0f);
-      const float k = n > 0.0f ? a.eikonal_weight * 2.0f * (n - 1.0f) / (n * (float)a.n_eik_norm) : 0.0f;
+      const float k = n > 0.0f ? a.eikonal_weight * 2.0f * (n - 1.0f) / (n * (float)a.n_eik_norm) : (n != n ? n : 0.0f);
       a.d_grad_theta[3 * i] = k * g0; a.d_grad_theta[3 * i + 1] = k * g1; a.d_grad_theta[3 * i + 2] = k * g2;
     }
     for (int d = 32; d >= 1; d >>= 1) e += __shfl_xor(e, d);

@@ -377,3 +377,38 @@ def test_bg_step_gradient_at_bench_geometry(dev, R, it, precision, monkeypatch):
         assert norm == pytest.approx(ref_norm, rel=1e-5), (norm, ref_norm)
         yard = f32_yardstick(autograd, p0)
         assert_f32_class(per_tensor_errors(got, ref, yard), what, floor=bound, floors={"density.beta": 1e-4})
+
+
+def test_degenerate_ray_poisons_the_step_like_the_reference(dev):
+    """A ray through the centre of the bounding sphere has no rotation axis in the inverted-sphere parametrisation
+    (network_bg.py:196-197: rot_axis = cross(ray_o, p_sphere) / 0): the reference's background points, colour and loss are NaN,
+    `loss.backward()` makes EVERY gradient NaN (L1's sign(NaN) is NaN, the weight-gradient sums run over all points) and
+    on_after_backward (vsdf.py:454-463) drops the step.  Same here: NaN loss, the guard zeroes the whole gradient (info[1] =
+    1) and a fresh optimiser leaves the parameters where they were."""
+    from svs_hip.trainer import TrainStep
+    from volsdf.model.loss import VolSDFLoss
+    R = 64
+    K, pose = synth.make_camera()                       # looks at the origin: the principal point's ray hits the sphere centre
+    uv = synth.make_uv(R, seed=8).astype(F32)
+    uv[5] = (K[0, 2], K[1, 2])
+    inp = {"intrinsics": G(K, dev)[None], "uv": G(uv, dev)[None], "pose": G(pose, dev)[None]}
+    rs = np.random.default_rng(6)
+    gt = {"rgb": G(rs.uniform(0, 1, (1, R, 3)).astype(F32), dev), "rgb_smooth": G(rs.uniform(0, 1, (1, R, 3)).astype(F32), dev)}
+    m = _model(dev, 0.1)
+    loss = VolSDFLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, rgb_weight=1.0, mvs_weight=0.0, sparse_weight=0.0,
+                      anneal_rgb=0, gce=0.5, confi=1e-3)
+    ts = TrainStep(m, loss)
+    before = ts.fp.flat.clone()
+    torch.manual_seed(3)
+    lo, out = ts(inp, gt)
+    torch.cuda.synchronize()
+    bad = ~torch.isfinite(out["rgb_values"]).all(-1)
+    assert bad.nonzero().flatten().tolist() == [5] and not np.isfinite(float(lo["rgb_loss"]))
+    assert float(ts.opt.info[1]) == 1.0                         # the guard dropped the gradient
+    assert torch.equal(ts.fp.flat, before)                      # zero gradient + fresh Adam moments: no parameter moved
+    # the same batch without that ray is an ordinary step
+    uv[5] = uv[6] + 1
+    ts2 = TrainStep(_model(dev, 0.1), loss)
+    torch.manual_seed(3)
+    lo2, _ = ts2(dict(inp, uv=G(uv, dev)[None]), gt)
+    assert np.isfinite(float(lo2["rgb_loss"])) and float(ts2.opt.info[1]) == 0.0

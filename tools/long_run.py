@@ -4,7 +4,13 @@ float32-MFMA kernels (SVS_MLP_PRECISION=f32), same seeds, same pixel batches.  T
 beta must shrink, and the two precisions must follow the same trajectory: the end-to-end check that the gradient error of the
 fp16x2 path (run with SVS_MLP_PRECISION=f16x2_half for the one-piece mode's 2e-4 ... 8e-4) does not
 change what the optimiser does.  Prints a row every 250 steps and a
-comparison at the end.      python tools/long_run.py [steps]
+comparison at the end.      python tools/long_run.py [steps] [dtu|bmvs] [plain|full]
+  plain (default): colour + eikonal terms only, no annealing (round 3's run).
+  full: the reference's whole loss (config/ours.yaml:16-21: anneal_rgb = 200, MVS prior term, sparse term) with synthetic prior
+        volumes, so that the run crosses the colour annealing -- iterations 0 ... 199 train on the masked smooth target, 200+ on
+        the image: the regime of the "iteration 250" gradient tests, where the radiance networks' tensors sit behind ReLU kinks.
+  bmvs: the fg + inverted-sphere background model (config 4).  Its float32-MFMA variant does not exist,
+        so the comparison there is default precision vs the one-piece mode, each against its own run-to-run spread.
 """
 import os
 import sys
@@ -21,6 +27,9 @@ from volsdf.model.loss import VolSDFLoss  # noqa: E402
 from svs_hip.trainer import TrainStep  # noqa: E402
 
 
+MODEL, MODE = "dtu", "plain"
+
+
 def run(precision, steps):
     if precision:
         os.environ["SVS_MLP_PRECISION"] = precision
@@ -28,12 +37,25 @@ def run(precision, steps):
         os.environ.pop("SVS_MLP_PRECISION", None)
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    m = VolSDFNetwork(dtu_model_conf())
-    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_params(0).items()})
+    params = dict(synth.make_params(0))
+    if MODEL == "bmvs":
+        from volsdf.utils.conf import bmvs_model_conf
+        from volsdf.model.network_bg import VolSDFNetworkBG
+        params.update(synth.make_bg_params(0))
+        m = VolSDFNetworkBG(bmvs_model_conf())
+    else:
+        m = VolSDFNetwork(dtu_model_conf())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
     m.to(dev).train()
-    loss = VolSDFLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, rgb_weight=1.0, mvs_weight=0.0, sparse_weight=0.0,
-                      anneal_rgb=0, gce=0.5, confi=1e-3)
+    full = MODE == "full"
+    loss = VolSDFLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, rgb_weight=1.0, mvs_weight=1.0 if full else 0.0,
+                      sparse_weight=1.0 if full else 0.0, anneal_rgb=200 if full else 0, gce=0.5, confi=1e-3)
     ts = TrainStep(m, loss, groups="auto")
+    mvs = None
+    if full:
+        views = synth.make_mvs_views(3)
+        mvs = dict(views=[dict(K=v["K"], c2w=v["c2w"], cost=torch.from_numpy(v["cost"]).to(dev), z_mvs=torch.from_numpy(v["z_mvs"]).to(dev))
+                          for v in views], same_view=0, img_res=(576, 768), inverse_depth=False)
     K, pose = synth.make_camera()
     R, H, W = 1024, 576, 768
     yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
@@ -42,8 +64,15 @@ def run(precision, steps):
     hist, window = [], []
     for step in range(steps):
         uv = synth.make_uv(R, seed=step)
+        # (the synthetic camera looks exactly at the origin: the principal point's ray goes through the sphere centre, where
+        # the inverted-sphere background of the reference is 0 / 0 -- such a step is dropped by the NaN guard, as in the
+        # reference; keep the runs comparable by keeping that one pixel out of the batches)
+        uv = uv[~((uv[:, 0] == K[0, 2]) & (uv[:, 1] == K[1, 2]))]
+        if len(uv) < R:
+            uv = np.concatenate([uv, uv[:R - len(uv)] + 1], 0)
         gt_rgb = torch.from_numpy(img[uv[:, 1].astype(int), uv[:, 0].astype(int)])[None].to(dev)
-        lo, _ = ts({"intrinsics": Kd, "uv": torch.from_numpy(uv)[None].to(dev), "pose": Pd}, {"rgb": gt_rgb, "rgb_smooth": gt_rgb})
+        lo, _ = ts({"intrinsics": Kd, "uv": torch.from_numpy(uv)[None].to(dev), "pose": Pd}, {"rgb": gt_rgb, "rgb_smooth": gt_rgb},
+                   mvs=mvs)
         if step >= steps - 100:
             window.append((float(lo["rgb_loss"]), float(lo["eikonal_loss"])))
         if step % 250 == 0 or step == steps - 1:
@@ -61,22 +90,27 @@ def run(precision, steps):
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+    MODEL = sys.argv[2] if len(sys.argv) > 2 else "dtu"
+    MODE = sys.argv[3] if len(sys.argv) > 3 else "plain"
+    OTHER = "f32" if MODEL == "dtu" else "f16x2_half"
+    print(f"model {MODEL}, loss {MODE}, {n} steps: default precision vs {OTHER}")
     # two runs per precision: float atomics make any two runs differ in the last bits, and 2000 Adam steps amplify that --
     # the spread between two runs of the SAME precision is the yardstick for the difference between the precisions
-    runs = {prec: [run(prec, n) for _ in range(2)] for prec in (None, "f32")}
+    runs = {prec: [run(prec, n) for _ in range(2)] for prec in (None, OTHER)}
     (ha, ra), (ha2, ra2) = runs[None]
-    (hb, rb), (hb2, rb2) = runs["f32"]
-    print("\nstep   rgb_loss fp16x2 #1 #2 / f32 #1 #2              eikonal fp16x2 #1 #2 / f32 #1 #2")
+    (hb, rb), (hb2, rb2) = runs[OTHER]
+    print(f"\nstep   rgb_loss fp16x2 #1 #2 / {OTHER} #1 #2              eikonal fp16x2 #1 #2 / {OTHER} #1 #2")
     for a, a2, b, b2 in zip(ha, ha2, hb, hb2):
         print(f"{a[0]:5d}   {a[1]:.5f} {a2[1]:.5f} / {b[1]:.5f} {b2[1]:.5f}        {a[2]:.5f} {a2[2]:.5f} / {b[2]:.5f} {b2[2]:.5f}")
     for key in ("rgb_last100", "eik_last100", "beta"):
-        print(f"{key:12s} fp16x2 {ra[key]:.5f} {ra2[key]:.5f}   f32 {rb[key]:.5f} {rb2[key]:.5f}")
-    for _, r in runs[None] + runs["f32"]:
+        print(f"{key:12s} fp16x2 {ra[key]:.5f} {ra2[key]:.5f}   {OTHER} {rb[key]:.5f} {rb2[key]:.5f}")
+    for _, r in runs[None] + runs[OTHER]:
         assert r["finite"] and r["dropped"] == 0.0
-    assert ha[-1][1] < 0.2 * ha[0][1], "the colour loss did not fall"
+    first = 1 if MODE == "full" else 0        # (full: while the colour term is annealed -- steps < 200 -- its masked form is ~0)
+    assert ha[-1][1] < (0.5 if MODE == "full" else 0.2) * ha[first][1], "the colour loss did not fall"
     mean = lambda k, rs: 0.5 * (rs[0][1][k] + rs[1][1][k])
     for key in ("rgb_last100", "eik_last100", "beta"):
         within = max(abs(ra[key] - ra2[key]), abs(rb[key] - rb2[key]))
-        across = abs(mean(key, runs[None]) - mean(key, runs["f32"]))
+        across = abs(mean(key, runs[None]) - mean(key, runs[OTHER]))
         print(f"{key}: between precisions {across:.5f}, between two runs of one precision {within:.5f}")
-        assert across <= max(3.0 * within, 0.15 * mean(key, runs["f32"])), f"fp16x2 and float32 runs differ in {key}"
+        assert across <= max(3.0 * within, 0.15 * mean(key, runs[OTHER])), f"default-precision and {OTHER} runs differ in {key}"
