@@ -52,7 +52,7 @@ struct WarpArgs {
 constexpr int kWarpPasses = 5;      // 5 * 32 = 160 = stage-1 width at C = 32 (and 320 / C = 16, 640 / C = 8)
 
 template <int C, int NS>
-__global__ __launch_bounds__(256, 4) void warp_variance_kernel(WarpArgs a, int dz_planes) {
+__global__ __launch_bounds__(256, NS <= 2 ? 4 : 2) void warp_variance_kernel(WarpArgs a, int dz_planes) {
   constexpr int LPV = C / 4;                       // lanes per voxel
   constexpr int VPP = 256 / LPV;                   // voxels per pass
   constexpr int TW = kWarpPasses * VPP;            // tile width in x
@@ -241,7 +241,7 @@ __device__ __forceinline__ void warp_taps(const WarpArgs& a, int v, int x, int y
 template <int C> constexpr int reuse_passes() { return C == 32 ? 5 : (C == 16 ? 2 : 1); }
 
 template <int C, int NS>
-__global__ __launch_bounds__(256, 4) void warp_variance_reuse_kernel(WarpArgs a) {
+__global__ __launch_bounds__(256, NS <= 2 ? 4 : 2) void warp_variance_reuse_kernel(WarpArgs a) {
   constexpr int kPasses = reuse_passes<C>();
   constexpr int LPV = C / 4, VPP = 256 / LPV, TW = kPasses * VPP;
   __shared__ __attribute__((aligned(16))) f32x4 tapw[kWarpDz][NS][TW];

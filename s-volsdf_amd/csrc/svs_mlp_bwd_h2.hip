@@ -350,6 +350,9 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_h2_kernel(SdfBwdAArgs a
   const int wtile = blockIdx.x * kWaves + wave;
   const int p = wtile * kTilePts + (lane & 31);
   const int pc = p < a.src.P ? p : a.src.P - 1;
+#ifdef SVS_EXP_STAGGER    // experiment: odd workgroups start SVS_EXP_STAGGER x 2 us late (are the sweeps phase-locked chip-wide?)
+  if (blockIdx.x & 1) for (int i = 0; i < SVS_EXP_STAGGER; ++i) __builtin_amdgcn_s_sleep(64);
+#endif
 
   st.prefetch<kChunk0F4>();
   PointScale ps;

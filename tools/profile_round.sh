@@ -4,12 +4,12 @@
 # then, back in the container:  python tools/summarize_profiles.py gpurun_out/r02 r02
 # Kernel trace and counter passes are separate runs (a --pmc pass never carries a trace domain besides the kernel
 # dispatch records rocprofv3 adds by itself); the program follows "--" directly.
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --no-cpu-baseline --no-exact-f32 --no-gpu-torch"
+B="python3 $R/bench.py --no-cpu-baseline --no-exact-f32 --no-gpu-torch --no-volopt-loop --no-extras"
 rocprofv3 --kernel-trace --stats -d $O/train --output-format csv -- $B --steps 20 --warmup 10 > $O/train.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/render --output-format csv -- $B --mode render --steps 20 --warmup 10 > $O/render.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/train_onegroup --output-format csv -- $B --steps 20 --warmup 10 --groups none > $O/onegroup.log 2>&1
