@@ -11,6 +11,7 @@ Structure (so that a batch can be processed in several ray groups on concurrent 
   finalize()     kernel order -> parameter gradients (weight-norm backward), once per step
 """
 import ctypes
+import os
 
 import torch
 
@@ -210,6 +211,8 @@ class MlpBackward:
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream(device=dev)
+        if os.environ.get("SVS_RGB_WGRAD_SIDE", "1") == "0":   # A/B switch: the radiance weight gradients in line, in front of pass A
+            side = False
         side_stream = self._side if side else main          # side=False: everything on the current stream
         fork = torch.cuda.Event(); fork.record(main)
         with torch.cuda.stream(side_stream):
