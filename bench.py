@@ -261,6 +261,27 @@ def main():
         # every rank runs the extra steps (a train step contains the all-reduce); rank 0 reports its own kernel times
         sizes = [g[1] - g[0] for g in ts._groups_for(R)] if train else None
         roofline = kernel_roofline(ts, step, R, S, h2, train, ray_groups=sizes)
+        if train and roofline is not None:
+            # The dominant kernel (pass A of the SDF backward, HBM-bound) shares HBM with the radiance weight-gradient
+            # launch that runs beside it on a side stream (the faster schedule: -1.2 % per step).  The same steps with that
+            # launch IN LINE (SVS_RGB_WGRAD_SIDE=0) show what each kernel does with the memory system to itself.
+            os.environ["SVS_RGB_WGRAD_SIDE"] = "0"
+            try:
+                alone = kernel_roofline(ts, step, R, S, h2, train, ray_groups=sizes)
+            finally:
+                os.environ.pop("SVS_RGB_WGRAD_SIDE", None)
+            key = lambda r: (r["kernel"], r["what"], r["points_per_launch"])
+            by = {key(r): r for r in alone["kernels"]}
+            for r in roofline["kernels"]:
+                o = by.get(key(r))
+                if o is not None:
+                    r["kernel_ms_in_line"], r["frac_in_line"] = o["kernel_ms"], o["frac"]
+            top = by.get((roofline["kernel"], roofline["what"], roofline["points_per_launch"]))
+            if top is not None:
+                roofline["in_line"] = {"kernel_ms": top["kernel_ms"], "achieved": top["achieved"], "frac": top["frac"],
+                                       "note": "the same kernel with the radiance weight-gradient launch in line instead of beside it "
+                                               "(SVS_RGB_WGRAD_SIDE=0: +1.2 % per step, not the default); `achieved` / `frac` above "
+                                               "are of the default schedule, where the two launches share HBM"}
         if dist:
             dist.barrier()
     if rank == 0:
