@@ -675,8 +675,9 @@ def cpu_baseline(params, K, pose, train=True):
     """CPU port of the reference's PyTorch path on a bounded sample of the same workload: numpy oracle for the sampler and
     the MVS prior lookup, plain torch float32 autograd (oracle/torch_ref.py) for the differentiable part, clip + Adam.
     Timed at 1 torch thread (what the reference's trainer forces, volsdf/vsdf.py:21) on 256 rays, at 32 threads on the
-    benchmark's own 1024-ray batch (and on 256 rays, to show that the step's cost is linear in the rays), and at ALL host
-    threads (1 and all cores) on a 64-ray sample, once: that configuration oversubscribes (see below).  For this leg the oracle's exp / expm1 / row sum are
+    benchmark's own 1024-ray batch (and on 256 rays, to show that the step's cost is linear in the rays).  ALL host
+    threads (1 and all cores) were measured in round 4 and are an opt-in since: 256 torch threads
+    oversubscribe (see the plan below).  For this leg the oracle's exp / expm1 / row sum are
     bound to numpy's (the bit-exact restatements of torch's routines emulate float32 fma in float64 and would make the
     baseline slower than a CPU path is)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -724,10 +725,11 @@ def cpu_baseline(params, K, pose, train=True):
         orc.ref_expm1 = lambda x: np.expm1(np.asarray(x, np.float32))
         orc.ref_sum = lambda x: np.asarray(x, np.float32).sum(-1, keepdims=True, dtype=np.float32)
         try:
-            # ALL host threads get a 64-ray sample, once: with torch's intra-op pool at 256 threads the small per-layer ops
-            # oversubscribe (measured in round 4 on the 1024-ray batch: 197 s per step = 5.2 rays/s, 34x slower than at 32)
+            # ALL host threads are not run by default: with torch's intra-op pool at 256 threads every small per-layer op
+            # oversubscribes -- measured in round 4 on the GPU box: 197 s per 1024-ray step (5.2 rays/s) and 126 s per
+            # 64-ray step (0.5 rays/s), against 5.8 s (177 rays/s) at 32 threads; SVS_CPU_BASELINE_ALL_THREADS=1 repeats it
             plan = [(1, 256, 1, 2), (min(32, all_threads), 256, 1, 2), (min(32, all_threads), 1024, 1, 2)]
-            if all_threads > 32:
+            if all_threads > 32 and os.environ.get("SVS_CPU_BASELINE_ALL_THREADS") == "1":
                 plan.append((all_threads, 64, 0, 1))
             seen = set()
             for threads, rays, warm, reps in plan:
@@ -756,8 +758,9 @@ def cpu_baseline(params, K, pose, train=True):
     return {"value": best["rays_per_s"], "unit": "rays/s", "cores": best["threads"], "kind": "port",
             "sample": f"{best['rays']} rays (the benchmark's batch) of the same {what}; median of {best['reps']} after "
                       f"{best['warmups']} warm-up; 32 torch intra-op threads (the numpy parts are single-threaded); 1 thread is "
-                      f"timed on 256 rays (the step is linear in the rays: compare the two 32-thread rows) and all {all_threads} host "
-                      "threads on 64 rays, once (`runs`: oversubscribed, slower than 32)",
+                      f"timed on 256 rays (the step is linear in the rays: compare the two 32-thread rows); all {all_threads} host threads "
+                      "oversubscribe torch's intra-op pool (measured once in round 4: 5.2 rays/s on this batch, 0.5 rays/s on 64 "
+                      "rays) and are not part of the default run",
             "single_thread_rays_per_s": next(r["rays_per_s"] for r in rows if r["threads"] == 1),
             "all_threads_rays_per_s": next((r["rays_per_s"] for r in rows if r["threads"] == all_threads), None),
             "runs": rows, "host_cpu": cpu_model_name(), "host_threads": all_threads}
