@@ -128,12 +128,15 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU fallback of the product path)"
+    if os.environ.get("SVS_DIST_SHARE_GPU") == "1":      # validation aid: N ranks on one GPU, collectives over gloo
+        local_rank %= torch.cuda.device_count()          # (SVS_DIST_BACKEND=gloo; exercises the N > 1 code path, measures nothing)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1 or os.environ.get("SVS_FORCE_DIST") == "1":      # the env switch exercises the RCCL path on one GPU
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("SVS_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
     if args.scaling == "strong" and args.rays % world:
         raise SystemExit(f"--scaling strong: {args.rays} rays do not shard over {world} ranks")

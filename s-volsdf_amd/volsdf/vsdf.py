@@ -110,6 +110,10 @@ def init_data_parallel():
     if world <= 1 and os.environ.get("SVS_FORCE_DIST", "0") != "1":
         return 1, 0, 0
     has_gpu = torch.cuda.device_count() > 0
+    if has_gpu and os.environ.get("SVS_DIST_SHARE_GPU", "0") == "1":
+        # validation aid (tools/dev/dp_two_ranks.py): several ranks on ONE GPU, collectives over gloo -- exercises the whole
+        # data-parallel path on a single-GPU box; RCCL itself refuses two ranks on one device
+        local %= torch.cuda.device_count()
     if has_gpu:
         if local >= torch.cuda.device_count():
             raise RuntimeError(f"LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) are visible: launch at most "
@@ -118,7 +122,7 @@ def init_data_parallel():
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl" if has_gpu else "gloo", rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get("SVS_DIST_BACKEND", "nccl" if has_gpu else "gloo"), rank=rank, world_size=world)
     return world, rank, local
 
 
