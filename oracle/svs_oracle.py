@@ -305,9 +305,19 @@ def canon_cumsum(x) -> np.ndarray:
 # ----------------------------------------------------------------------------------------
 # a1  rays      volsdf/utils/rend_util.py:60-95 (get_camera_params), :143-156 (lift)
 # ----------------------------------------------------------------------------------------
+def norm3(v):
+    """torch `x.norm(2, dim=-1, keepdim=True)` of float32 3-vectors on CPU: the vectorised reduce kernel contracts
+    acc + x*x into a fused multiply-add, i.e. sqrt(fma(x2, x2, fma(x1, x1, x0*x0))) (checked on 200 000 rows)."""
+    v = np.asarray(v, F32)
+    acc = _f(v[..., 0] * v[..., 0])
+    for k in range(1, v.shape[-1]):
+        acc = _fma32(v[..., k], v[..., k], acc)
+    return np.sqrt(acc).astype(F32)[..., None]
+
+
 def _normalize(v, eps=1e-12):
-    n = np.sqrt((v * v).sum(-1, keepdims=True, dtype=F32)).astype(F32)
-    return (v / np.maximum(n, F32(eps))).astype(F32)
+    """F.normalize: v / max(||v||_2, eps)"""
+    return (v / np.maximum(norm3(v), F32(eps))).astype(F32)
 
 
 def lift(x, y, z, K):
@@ -336,8 +346,11 @@ def rays_from_uv(uv, pose, K):
 
 def sphere_intersections(cam_loc, dirs, r):
     """rend_util.py:200-216.  cam_loc (R,3), dirs (R,3) -> (R,2) near/far, clamped >= 0."""
-    dot = (dirs * cam_loc).sum(-1, keepdims=True, dtype=F32)
-    under = dot ** 2 - ((cam_loc * cam_loc).sum(-1, keepdims=True, dtype=F32) - F32(r * r))
+    # ray_cam_dot: torch.bmm of (1,3) x (3,1) -- ATen's small-matrix loop, plain multiply-add in index order;
+    # cam_loc.norm(2, 1) ** 2: the SQUARE of the rounded norm (norm3), not the sum of squares
+    dot = _f(_f(_f(dirs[:, 0] * cam_loc[:, 0]) + _f(dirs[:, 1] * cam_loc[:, 1])) + _f(dirs[:, 2] * cam_loc[:, 2]))[:, None]
+    nrm = norm3(cam_loc)
+    under = _f(_f(dot * dot) - _f(_f(nrm * nrm) - F32(r * r)))
     if (under <= 0).any():
         raise ValueError("BOUNDING SPHERE PROBLEM")       # the reference calls exit() here
     s = np.sqrt(under).astype(F32)
@@ -860,19 +873,19 @@ def depth2pts_outside(ray_o, ray_d, depth, r):
     d_sphere = (np.sqrt(under_sqrt) - o_dot_d).astype(F32)
     p_sphere = (ray_o + d_sphere[..., None] * ray_d).astype(F32)
     p_mid = (ray_o - o_dot_d[..., None] * ray_d).astype(F32)
-    p_mid_norm = np.sqrt((p_mid * p_mid).sum(-1, dtype=F32)).astype(F32)
+    p_mid_norm = norm3(p_mid)[..., 0]
     rot_axis = np.cross(ray_o, p_sphere).astype(F32)
-    rot_axis = (rot_axis / np.sqrt((rot_axis * rot_axis).sum(-1, keepdims=True, dtype=F32))).astype(F32)
+    rot_axis = (rot_axis / norm3(rot_axis)).astype(F32)
     phi = np.arcsin(p_mid_norm / F32(r)).astype(F32)
     theta = np.arcsin(p_mid_norm * depth).astype(F32)
     rot_angle = (phi - theta)[..., None].astype(F32)
     c, sn = np.cos(rot_angle).astype(F32), np.sin(rot_angle).astype(F32)
     p_new = (p_sphere * c + np.cross(rot_axis, p_sphere).astype(F32) * sn
              + rot_axis * (rot_axis * p_sphere).sum(-1, keepdims=True, dtype=F32) * (F32(1.0) - c)).astype(F32)
-    p_new = (p_new / np.sqrt((p_new * p_new).sum(-1, keepdims=True, dtype=F32))).astype(F32)
+    p_new = (p_new / norm3(p_new)).astype(F32)
     pts = np.concatenate([p_new, depth[..., None]], -1).astype(F32)
     d1 = (-o_dot_d / (ray_d * ray_d).sum(-1, dtype=F32)).astype(F32)
-    ray_d_cos = (F32(1.0) / np.sqrt((ray_d * ray_d).sum(-1, dtype=F32))).astype(F32)
+    ray_d_cos = (F32(1.0) / norm3(ray_d)[..., 0]).astype(F32)
     depth_real = (F32(1.0) / (depth + F32(1e-6)) * np.cos(theta).astype(F32) * ray_d_cos + d1).astype(F32)
     return pts, depth_real
 

@@ -26,9 +26,9 @@ __global__ void rays_kernel(const float* __restrict__ uv, const float* __restric
     const float rot = (pose[4 * i] * xl + pose[4 * i + 1] * yl) + pose[4 * i + 2] * zl;
     w[i] = (rot + pose[4 * i + 3]) - pose[4 * i + 3];     // world point minus camera centre (rend_util.py:92)
   }
-  const float n = __builtin_fmaxf(__builtin_sqrtf((w[0] * w[0] + w[1] * w[1]) + w[2] * w[2]), 1e-12f);
+  const float n = __builtin_fmaxf(norm3(w[0], w[1], w[2]), 1e-12f);          // F.normalize: x / max(x.norm(2), eps)
   dirs[3 * r] = w[0] / n; dirs[3 * r + 1] = w[1] / n; dirs[3 * r + 2] = w[2] / n;
-  const float nc = __builtin_fmaxf(__builtin_sqrtf((xl * xl + yl * yl) + zl * zl), 1e-12f);
+  const float nc = __builtin_fmaxf(norm3(xl, yl, zl), 1e-12f);
   depth_scale[r] = zl / nc;                                // network.py:216-217
 }
 
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(64) void composite_kernel(CompositeArgs a) {
     c0 += w * a.rgb[3 * p]; c1 += w * a.rgb[3 * p + 1]; c2 += w * a.rgb[3 * p + 2];
     if (a.normal_map) {
       const float g0 = a.normals[3 * p], g1 = a.normals[3 * p + 1], g2 = a.normals[3 * p + 2];
-      const float nn = __builtin_sqrtf((g0 * g0 + g1 * g1) + g2 * g2);
+      const float nn = norm3(g0, g1, g2);            // gradients.norm(2, -1)
       n0 += w * (g0 / nn); n1 += w * (g1 / nn); n2 += w * (g2 / nn);
     }
   }
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256) void loss_rays_kernel(LossArgs a, double* __re
     double e = 0.0;
     if (i < a.n_eik) {
       const float g0 = a.grad_theta[3 * i], g1 = a.grad_theta[3 * i + 1], g2 = a.grad_theta[3 * i + 2];
-      const float n = __builtin_sqrtf((g0 * g0 + g1 * g1) + g2 * g2);
+      const float n = norm3(g0, g1, g2);             // grad_theta.norm(2, dim=1), loss.py:50
       e = (double)(n - 1.0f) * (double)(n - 1.0f);
       const float k = n > 0.0f ? a.eikonal_weight * 2.0f * (n - 1.0f) / (n * (float)a.n_eik_norm) : (n != n ? n : 0.0f);
       a.d_grad_theta[3 * i] = k * g0; a.d_grad_theta[3 * i + 1] = k * g1; a.d_grad_theta[3 * i + 2] = k * g2;
@@ -516,9 +516,9 @@ __global__ void bg_points_kernel(BgPointsArgs a) {
   float ps[3], pm[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) { ps[c] = o[c] + d_sphere * d[c]; pm[c] = o[c] - o_dot_d * d[c]; }
-  const float pm_norm = __builtin_sqrtf((pm[0] * pm[0] + pm[1] * pm[1]) + pm[2] * pm[2]);
+  const float pm_norm = norm3(pm[0], pm[1], pm[2]);
   float ax[3] = {o[1] * ps[2] - o[2] * ps[1], o[2] * ps[0] - o[0] * ps[2], o[0] * ps[1] - o[1] * ps[0]};
-  const float axn = __builtin_sqrtf((ax[0] * ax[0] + ax[1] * ax[1]) + ax[2] * ax[2]);
+  const float axn = norm3(ax[0], ax[1], ax[2]);
 #pragma unroll
   for (int c = 0; c < 3; ++c) ax[c] = ax[c] / axn;
   const float phi = asinf(pm_norm / a.radius);
@@ -530,12 +530,12 @@ __global__ void bg_points_kernel(BgPointsArgs a) {
   float pn[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) pn[c] = (ps[c] * ca + cr[c] * sa) + (ax[c] * adp) * (1.0f - ca);
-  const float pnn = __builtin_sqrtf((pn[0] * pn[0] + pn[1] * pn[1]) + pn[2] * pn[2]);
+  const float pnn = norm3(pn[0], pn[1], pn[2]);
   a.pts[4 * (size_t)idx] = pn[0] / pnn; a.pts[4 * (size_t)idx + 1] = pn[1] / pnn; a.pts[4 * (size_t)idx + 2] = pn[2] / pnn;
   a.pts[4 * (size_t)idx + 3] = depth;
   const float dd = (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2];
   const float d1 = -o_dot_d / dd;
-  const float ray_d_cos = 1.0f / __builtin_sqrtf(dd);
+  const float ray_d_cos = 1.0f / norm3(d[0], d[1], d[2]);
   a.depth_real[idx] = ((1.0f / (depth + 1e-6f)) * cosf(theta)) * ray_d_cos + d1;
 }
 
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(64) void composite_bg_kernel(CompositeBgArgs a) {
     c0 += w * a.rgb[3 * p]; c1 += w * a.rgb[3 * p + 1]; c2 += w * a.rgb[3 * p + 2];
     if (a.normal_map) {
       const float g0 = a.normals[3 * p], g1 = a.normals[3 * p + 1], g2 = a.normals[3 * p + 2];
-      const float nn = __builtin_sqrtf((g0 * g0 + g1 * g1) + g2 * g2);
+      const float nn = norm3(g0, g1, g2);            // gradients.norm(2, -1)
       n0 += w * (g0 / nn); n1 += w * (g1 / nn); n2 += w * (g2 / nn);
     }
   }

@@ -160,8 +160,8 @@ __global__ __launch_bounds__(64) void init_kernel(InitArgs a) {
     const float* o = a.cam + (size_t)r * a.cam_stride;
     const float* d = a.dirs + 3 * (size_t)r;
     const float dot = (d[0] * o[0] + d[1] * o[1]) + d[2] * o[2];
-    const float oo = (o[0] * o[0] + o[1] * o[1]) + o[2] * o[2];
-    const float under = dot * dot - (oo - a.sphere_radius * a.sphere_radius);
+    const float nrm = norm3(o[0], o[1], o[2]);            // cam_loc.norm(2, 1) ** 2: the square of the ROUNDED norm
+    const float under = dot * dot - (nrm * nrm - a.sphere_radius * a.sphere_radius);
     if (under <= 0.0f) { if (lane == 0) *a.err = 1; }
     far = __builtin_fmaxf(__builtin_sqrtf(under) - dot, 0.0f);
   }

@@ -338,6 +338,48 @@ def fx_sampler_hostexp():
         UNPIN_EXP = ref_shim.pin_open_exp()
 
 
+def fx_sampler_r256_more():
+    """Two more 256-ray sampler runs of the reference in the compact layout of fx_sampler_r256:
+    `sampler256_train_b0.05`: TRAIN mode (fast = 1: one round; stratified jitter, random u, randperm extras, eikonal pick --
+    the draws of synth.make_train_rng fed through torch's CPU RNG call sites in the reference's order);
+    `sampler256_bg_b0.01`: the fg + inverted-sphere background model in eval mode (fast = -1): far = sphere exit per ray,
+    add_tiny = 1e-6 in the up-sampling pdf, the inverse-sphere depths returned beside the fg samples."""
+    params = dict(synth.make_params(seed=0))
+    K, pose = synth.make_camera(center=(0.1, 0.05, -2.5), tilt=0.1)
+    R = 256
+    uv = synth.make_uv(R, seed=23, margin=0.05)
+    import oracle_path  # noqa
+    from svs_oracle import rays_from_uv
+    dirs, cam, _ = rays_from_uv(uv, pose, K)
+    cam_r = np.repeat(cam[None], R, 0).astype(F32)
+    inv4 = (1.0 / (4.0 * torch.log(torch.tensor(0.1 + 1.0)))).numpy()
+
+    def pack(arr, rec, sdfs):
+        for i, sd in enumerate(sdfs):
+            arr[f"sdf_{i}"] = sd.reshape(R, -1)
+            arr[f"beta_{i}"] = rec.betas[i]
+        for i, a in enumerate(rec.inds):
+            cdf = rec.cdf[i]
+            n = cdf.shape[1]
+            arr[f"inds_{i}"] = a.astype(np.uint16)
+            arr[f"cdf_lo_{i}"] = np.take_along_axis(cdf, np.maximum(a - 1, 0), 1)
+            arr[f"cdf_hi_{i}"] = np.take_along_axis(cdf, np.minimum(a, n - 1), 1)
+        for i in range(len(rec.sort_idx) - 1):
+            arr[f"samples_idx_{i}"] = rec.sort_idx[i].astype(np.uint16); arr[f"zmerged_{i}"] = rec.sort_vals[i]
+        return arr
+
+    m = build_model(params, beta=0.05)
+    draws = synth.make_train_rng(R, seed=31)
+    z, z_eik, rec, sdfs = run_sampler(m, dirs, cam_r, 1, True, draws)
+    save("sampler256_train_b0.05", **pack(dict(dirs=dirs, cam=cam_r, beta_param=F32(0.05), fast=1, rng_seed=31, z=z.numpy(),
+                                               z_eik=z_eik.numpy(), n_rounds=len(sdfs), inv_4log=inv4), rec, sdfs))
+    bgp = dict(params); bgp.update(synth.make_bg_params(seed=0))
+    m = build_bg_model(bgp, 0.01)
+    (z, z_bg), z_eik, rec, sdfs = run_sampler(m, dirs, cam_r, -1, False)
+    save("sampler256_bg_b0.01", **pack(dict(dirs=dirs, cam=cam_r, beta_param=F32(0.01), fast=-1, z=z.numpy(), z_bg=z_bg.numpy(),
+                                            n_rounds=len(sdfs), inv_4log=inv4), rec, sdfs))
+
+
 def fx_composite():
     params = synth.make_params(seed=0)
     m = build_model(params, beta=0.03)
@@ -963,7 +1005,7 @@ ALL = dict(fusion=fx_fusion, filter_depth=fx_filter_depth, pfm=fx_pfm, chamfer=f
            train_step_w1=lambda: fx_train_step(16, 2, "train_step_w1", "w1"),
            train_step_bg=fx_train_step_bg,
            train_step_bg_sparse=lambda: fx_train_step_bg("train_step_bg_sparse", 50, 1e3, 1),
-           sampler_r256=fx_sampler_r256, sampler_hostexp=fx_sampler_hostexp, primitives=fx_primitives)
+           sampler_r256=fx_sampler_r256, sampler_r256_more=fx_sampler_r256_more, sampler_hostexp=fx_sampler_hostexp, primitives=fx_primitives)
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(ALL)

@@ -87,9 +87,9 @@ def test_rays(golden_dir):
     g = load(golden_dir, "rays")
     for t in "ab":
         dirs, cam, ds = orc.rays_from_uv(g[t + "_uv"], g[t + "_pose"], g[t + "_K"])
-        np.testing.assert_allclose(dirs, g[t + "_dirs"], atol=2e-7)
-        np.testing.assert_allclose(cam, g[t + "_cam"], atol=0)
-        np.testing.assert_allclose(ds, g[t + "_depth_scale"], atol=2e-7)
+        # bit for bit since round 4 (F.normalize's norm is sqrt(fma(z, z, fma(y, y, x*x))) in torch's reduce kernel: norm3)
+        assert np.array_equal(dirs, g[t + "_dirs"]) and np.array_equal(cam, g[t + "_cam"])
+        assert np.array_equal(ds, g[t + "_depth_scale"])
 
 
 def test_density(golden_dir):
@@ -227,6 +227,32 @@ def test_sampler_r256_indices(golden_dir, name):
     g = load256(golden_dir, name)
     n_idx = _assert_rounds_exact(g)
     print(f"{name}: 0 differing indices of {n_idx} ({int(g['n_rounds'])} rounds)")
+
+
+def test_sampler_r256_train_mode(golden_dir):
+    """The reference's TRAIN-mode sampler on 256 rays (fast = 1; stratified jitter, random u, randperm extras, eikonal pick):
+    index, cdf, beta and final z / z_eik identity, bit for bit."""
+    g = load256(golden_dir, "sampler256_train_b0.05")
+    rng = synth.make_train_rng(256, seed=int(g["rng_seed"]))
+    for i, rec in _replay_rounds(g, training=True, rng=rng):
+        ref = g[f"inds_{i}"]
+        assert np.array_equal(rec["beta"], g[f"beta_{i}"]) and np.array_equal(rec["inds"], ref)
+        assert np.array_equal(np.take_along_axis(rec["cdf"], np.maximum(ref - 1, 0), 1), g[f"cdf_lo_{i}"])
+    z, z_eik = orc.error_bound_sampler(None, g["dirs"], g["cam"], orc.get_beta(g["beta_param"]), fast=1, training=True, rng=rng,
+                                       inv_4log=g["inv_4log"], sdf_override=[g["sdf_0"]])
+    assert np.array_equal(z, g["z"]) and np.array_equal(z_eik, g["z_eik"])
+
+
+def test_sampler_r256_background_model(golden_dir):
+    """The sampler of the fg + inverted-sphere background model on 256 rays (far = sphere exit per ray -- through
+    `cam_loc.norm(2, 1) ** 2`, the square of the rounded norm --, near = 0, add_tiny = 1e-6): the fg samples and the
+    inverse-sphere depths are the reference's bit for bit."""
+    g = load256(golden_dir, "sampler256_bg_b0.01")
+    nr = int(g["n_rounds"])
+    (z, z_bg), _ = orc.error_bound_sampler(None, g["dirs"], g["cam"], orc.get_beta(g["beta_param"]), near=0.0, fast=-1,
+                                           inv_4log=g["inv_4log"], inverse_sphere_bg=True, N_samples_inverse_sphere=32,
+                                           add_tiny=1e-6, sdf_override=[g[f"sdf_{i}"] for i in range(nr)])
+    assert np.array_equal(z, g["z"]) and np.array_equal(z_bg, g["z_bg"])
 
 
 def _host_matches(g):
