@@ -208,7 +208,7 @@ def test_composite_golden(dev, ops, golden_dir):
                         torch.tensor(float(g["beta_param"]), device=dev), 1e-4, normals=G(nrm, dev))
     ref = orc.composite(g["z"], g["sdf"], g["rgb"], orc.get_beta(g["beta_param"]), ds, normals=nrm)
     assert np.array_equal(out["weights"].cpu().numpy().view(np.uint32), ref["weights"].view(np.uint32))
-    np.testing.assert_allclose(out["weights"].cpu().numpy(), g["weights"], rtol=2e-5, atol=1.2e-7)
+    assert np.array_equal(out["weights"].cpu().numpy(), g["weights"])            # ... and the REFERENCE, bit for bit
     for k in ("rgb_values", "depth_values", "depth_vals", "normal_map"):
         np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], atol=2e-6, err_msg=k)
 

@@ -97,11 +97,9 @@ def test_density(golden_dir):
     for i, b in enumerate((0.1, 0.01, 0.001)):
         beta = orc.get_beta(b)
         assert beta == g[f"beta_{i}"]
-        # expm1 near -1 differs by <= 1 ulp(1) between Sleef and the correctly rounded value; the
-        # cancellation 0.5 + 0.5*expm1 turns that into an absolute 6e-8/beta.
-        np.testing.assert_allclose(orc.laplace_density(g["sdf"], beta), g[f"sigma_{i}"], rtol=3e-7, atol=6.1e-8 / beta)
-    np.testing.assert_allclose(orc.laplace_density(g["sdf_ray"], g["beta_ray"]), g["sigma_ray"], rtol=3e-7,
-                               atol=6.1e-8 / g["beta_ray"].min())
+        # bit for bit since round 4: expm1 is the restated Sleef routine (svs_oracle.sleef_expm1f)
+        assert np.array_equal(orc.laplace_density(g["sdf"], beta), g[f"sigma_{i}"])
+    assert np.array_equal(orc.laplace_density(g["sdf_ray"], g["beta_ray"]), g["sigma_ray"])
 
 
 @pytest.mark.parametrize("name,wset", [("sdf_mlp", "w0"), ("sdf_mlp_w1", "w1")])
@@ -132,8 +130,8 @@ def test_rgb_mlp(golden_dir):
 def test_composite(golden_dir):
     g = load(golden_dir, "composite")
     w, _, dists = orc.ray_weights(g["z"], g["sdf"], orc.get_beta(g["beta_param"]))
-    np.testing.assert_allclose(dists, g["dists"], atol=0)
-    np.testing.assert_allclose(w, g["weights"], rtol=2e-5, atol=1.2e-7)  # alpha = 1-exp(-fe): 1 ulp(1) absolute
+    assert np.array_equal(dists, g["dists"])
+    assert np.array_equal(w, g["weights"])          # bit for bit (exp = the pinned Sleef routine, cumsum in float64)
 
 
 SAMPLER_FX = sorted(os.path.basename(p)[:-4] for p in
