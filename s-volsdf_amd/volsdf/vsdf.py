@@ -336,32 +336,36 @@ class VolOpt():
     def _epoch_overlapped(self):
         """One pass `for batch in self.train_dataloader: self.train_step(batch)` with the SAME batches and the same use of the
         random generators, but with the dataset's work for step i+1 (`change_sampling_idx`: torch.randperm over all pixels;
-        `__getitem__`: the full pixel grid, the gathers; the collate) done by a helper thread while the main thread enqueues
-        step i.  The order in which the generators are consumed is the reference's: step i's own draws (sampler jitter,
-        eikonal points; made first thing in the step) -> randperm for batch i+1 -> random.randint of __getitem__ -> step
-        i+1's draws ...; the helper's job is submitted by the step right after its draws and awaited before the next step, so
-        the generators are never used by two threads at once.  (`overlap_loader=False` / SVS_OVERLAP_LOADER=0: sequential.)"""
+        `__getitem__`: the full pixel grid, the gathers; the collate) done by a persistent helper thread while the main thread
+        enqueues step i.  The order in which the generators are consumed is the reference's: step i's own draws (sampler
+        jitter, eikonal points; made first thing in the step) -> randperm for batch i+1 -> random.randint of __getitem__ ->
+        step i+1's draws ...; the helper's job is submitted by the step right after its draws and awaited before the next
+        step, so the generators are never used by two threads at once.  (`overlap_loader=False` / SVS_OVERLAP_LOADER=0:
+        strictly sequential.  SVS_OVERLAP_NEXT=main keeps only the randperm in the helper and runs the DataLoader's `next()`
+        in the main thread after the step is enqueued -- A/B'd on one box (tools/dev/loop_ab.py): 4.38 / 4.11 ms against
+        3.91 / 4.10 for the default and 4.72 / 4.88 sequential: no better.)"""
         from concurrent.futures import ThreadPoolExecutor
         if self._loader_pool is None:
             self._loader_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="svs-next-batch")
         it = iter(self.train_dataloader)
         batch = next(it, None)
+        fetch_in_helper = os.environ.get("SVS_OVERLAP_NEXT", "helper") == "helper"    # A/B switch
 
-        def fetch():
+        def resample():
             self.train_dataset.change_sampling_idx(self.num_pixels)
-            return next(it, None)
+            return next(it, None) if fetch_in_helper else None
 
         while batch is not None:
             fut = []
-            self.step_fn.after_draws = lambda: fut.append(self._loader_pool.submit(fetch))
+            self.step_fn.after_draws = lambda: fut.append(self._loader_pool.submit(resample))
             try:
                 self.train_step(batch, self.hparams.use_mvs, _resample=False)
             finally:
                 self.step_fn.after_draws = None
-                if not fut:                              # (a step that made no draws: nothing to wait for)
-                    fut.append(self._loader_pool.submit(fetch))
-                nxt = fut[0].result()                    # re-raises what the helper raised
-            batch = nxt
+                if not fut:                              # (a step that made no draws: nothing ran beside it)
+                    fut.append(self._loader_pool.submit(resample))
+                got = fut[0].result()                    # re-raises what the helper raised
+            batch = got if fetch_in_helper else next(it, None)
 
     def _shard_batch(self, model_input, ground_truth):
         """This rank's contiguous share of the batch's rays (every rank holds the same batch: sync_host_rng)."""
