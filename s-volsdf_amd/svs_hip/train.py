@@ -43,7 +43,7 @@ def record_off(n_points, n_blocks, block):
 
 def _off(t, n_floats):
     """device pointer `n_floats` floats into tensor t"""
-    return ctypes.c_void_p(t.data_ptr() + 4 * n_floats)
+    return t.data_ptr() + 4 * n_floats
 
 
 class TrainStreams:
@@ -130,6 +130,7 @@ class MlpBackward:
         self.accum = accum or WGradAccum(device)
         self._n = None
         self._side = None
+        self._job_cache = {}
         self.time_wgrad = False
         self.timer_events = None
 
@@ -150,6 +151,13 @@ class MlpBackward:
         # tail -- the eikonal points, which have no such term -- stays zero
         self.d_sdf_full = torch.zeros(n_total, device=self.dev)
         self._n = (n_total, n_main)
+
+    def _cache_jobs(self, key, jobs):
+        if len(self._job_cache) >= 64:
+            self._job_cache.clear()
+        arr = (_lib.WGradJob * len(jobs))(*jobs)
+        hit = self._job_cache[key] = (ctypes.cast(arr, ctypes.c_void_p), len(jobs), arr)    # (arr kept alive beside its address)
+        return hit[:2]
 
     def sdf_grad_out(self, n_total, n_main):
         """(n_main,1) view of the persistent d_sdf buffer: compositing's backward writes into it directly."""
@@ -187,9 +195,9 @@ class MlpBackward:
                                  addr(_off(acc.dbk, slot * 256)), addr(_off(acc.absmax, amax)) if h2 else None,
                                  addr(rec0) if h2 else None, addr(rec1) if h2 else None)
 
-        def wgrad_multi(jobs):
-            arr = (_lib.WGradJob * len(jobs))(*jobs)
-            _lib.check(L.svs_wgrad_multi(ctypes.cast(arr, ctypes.c_void_p), len(jobs), prec, _stream()), "svs_wgrad_multi")
+        def wgrad_multi(cached):
+            arr, n = cached
+            _lib.check(L.svs_wgrad_multi(arr, n, prec, _stream()), "svs_wgrad_multi")
 
         # ---- radiance MLP: input gradients
         d_rgb = _f32(d_rgb)
@@ -218,14 +226,21 @@ class MlpBackward:
         with torch.cuda.stream(side_stream):
             if side:
                 side_stream.wait_event(fork)
-            LSm = block_stride(n_main)              # rbuf = [4 blocks][tile] + extras [tile][1024], zbuf = [5 blocks][tile]
-            zrec = lambda l: _off(self.zbuf, record_off(n_main, 5, l))
-            jobs = [job(9, n_main, 1, _off(self.zbuf, 0), KBLOCK, _ptr(feat), KBLOCK, extra=_off(rbuf, 4 * LSm), sx=1024,
-                        rec0=zrec(0))]
-            for l in range(1, 5):
-                jobs.append(job(9 + l, n_main, 1, _off(self.zbuf, l * LSm), KBLOCK, _off(rbuf, (l - 1) * LSm), KBLOCK,
-                                rec0=zrec(l)))
-            wgrad_multi(jobs)
+            # the job lists are a function of the buffers' addresses and the point counts: built once per configuration (a
+            # step's scratch comes back at the same addresses from torch's caching allocator), ~40 ctypes structures a step
+            rkey = ("rgb", n_main, prec, self.zbuf.data_ptr(), feat.data_ptr(), rbuf.data_ptr(), acc.dWk.data_ptr())
+            arr_r = self._job_cache.get(rkey)
+            arr_r = arr_r[:2] if arr_r is not None else None
+            if arr_r is None:
+                LSm = block_stride(n_main)          # rbuf = [4 blocks][tile] + extras [tile][1024], zbuf = [5 blocks][tile]
+                zrec = lambda l: _off(self.zbuf, record_off(n_main, 5, l))
+                jobs = [job(9, n_main, 1, _off(self.zbuf, 0), KBLOCK, _ptr(feat), KBLOCK, extra=_off(rbuf, 4 * LSm), sx=1024,
+                            rec0=zrec(0))]
+                for l in range(1, 5):
+                    jobs.append(job(9 + l, n_main, 1, _off(self.zbuf, l * LSm), KBLOCK, _off(rbuf, (l - 1) * LSm), KBLOCK,
+                                    rec0=zrec(l)))
+                arr_r = self._cache_jobs(rkey, jobs)
+            wgrad_multi(arr_r)
             join = torch.cuda.Event(); join.record(side_stream)
         # ---- SDF MLP: pass A (needs nbar), pass B (needs sbar, fbar), then its weight gradients
         st = _stream()
@@ -244,16 +259,22 @@ class MlpBackward:
         ev = self.timer_events = ([torch.cuda.Event(enable_timing=True) for _ in range(2)] if self.time_wgrad else None)
         if ev:
             ev[0].record()
-        arec = lambda l: _off(self.abuf, record_off(n_total, 8, l))
-        urec = lambda l: _off(self.ubuf, record_off(n_total, 9, l))
-        jobs = [job(0, n_total, 0, _off(self.abuf, 0), KBLOCK, _ptr(self.pebuf), KBLOCK,
-                    _off(gbuf, 0), KBLOCK, _off(self.ubuf, 0), KBLOCK, rec0=arec(0), rec1=urec(0))]
-        for l in range(1, 8):
-            jobs.append(job(l, n_total, 0, _off(self.abuf, l * LS), KBLOCK, _off(hbuf, (l - 1) * LS), KBLOCK,
-                            _off(gbuf, l * LS), KBLOCK, _off(self.ubuf, l * LS), KBLOCK, rec0=arec(l), rec1=urec(l)))
-        jobs.append(job(8, n_main, 2, _ptr(self.feat_bar), KBLOCK, _off(hbuf, 7 * LS), KBLOCK,
-                        rec0=_off(self.feat_bar, record_off(n_main, 1, 0))))
-        wgrad_multi(jobs)
+        skey = ("sdf", n_total, n_main, prec, self.abuf.data_ptr(), self.ubuf.data_ptr(), self.pebuf.data_ptr(), hbuf.data_ptr(),
+                gbuf.data_ptr(), self.feat_bar.data_ptr(), acc.dWk.data_ptr())
+        arr_s = self._job_cache.get(skey)
+        arr_s = arr_s[:2] if arr_s is not None else None
+        if arr_s is None:
+            arec = lambda l: _off(self.abuf, record_off(n_total, 8, l))
+            urec = lambda l: _off(self.ubuf, record_off(n_total, 9, l))
+            jobs = [job(0, n_total, 0, _off(self.abuf, 0), KBLOCK, _ptr(self.pebuf), KBLOCK,
+                        _off(gbuf, 0), KBLOCK, _off(self.ubuf, 0), KBLOCK, rec0=arec(0), rec1=urec(0))]
+            for l in range(1, 8):
+                jobs.append(job(l, n_total, 0, _off(self.abuf, l * LS), KBLOCK, _off(hbuf, (l - 1) * LS), KBLOCK,
+                                _off(gbuf, l * LS), KBLOCK, _off(self.ubuf, l * LS), KBLOCK, rec0=arec(l), rec1=urec(l)))
+            jobs.append(job(8, n_main, 2, _ptr(self.feat_bar), KBLOCK, _off(hbuf, 7 * LS), KBLOCK,
+                            rec0=_off(self.feat_bar, record_off(n_main, 1, 0))))
+            arr_s = self._cache_jobs(skey, jobs)
+        wgrad_multi(arr_s)
         if ev:
             ev[1].record()
         if wait and side:
