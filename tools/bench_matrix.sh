@@ -2,7 +2,7 @@
 # The secondary bench lines quoted in DESIGN.md section 5 (one GPU):  gpurun -- 'bash tools/bench_matrix.sh'
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/matrix; mkdir -p $O
-B="python3 $R/bench.py --no-cpu-baseline --no-exact-f32 --no-gpu-torch --no-kernel-timing --steps 100"
+B="python3 $R/bench.py --no-cpu-baseline --no-exact-f32 --no-gpu-torch --no-kernel-timing --no-volopt-loop --no-extras --steps 100"
 run() { name=$1; shift; $B "$@" 2>/dev/null | tail -1 > $O/$name.json; python3 - "$name" "$O/$name.json" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[2]))
