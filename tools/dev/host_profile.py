@@ -12,7 +12,7 @@ from volsdf.model.network import VolSDFNetwork
 import cProfile, pstats
 
 dev = torch.device("cuda:0")
-R = 1024
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 m = VolSDFNetwork(dtu_model_conf()); m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_params(0).items()}); m.to(dev).train()
 K, pose = synth.make_camera()
 inp = {"intrinsics": torch.from_numpy(K)[None].to(dev), "uv": torch.from_numpy(synth.make_uv(R, seed=1))[None].to(dev), "pose": torch.from_numpy(pose)[None].to(dev)}
