@@ -284,7 +284,7 @@ def fx_primitives():
                         rng.standard_normal(n // 2) * 1e-3, -rng.random(n // 4) * 110, rng.random(n // 4) * 95,
                         [0, -0.0, 1e-45, -1e-45, 88.7, 88.73, 100, 100.5, -104, -104.5, -103.9, -87.5, -16.635,
                          -16.636, 1e-30, -1e-30, np.inf, -np.inf, 16.0, -1.0]]).astype(F32)
-    arr = dict(x=x, expf=ref_shim.torch_vec8("Sleef_expf8_u10")(x), expm1f=ref_shim.torch_vec8("Sleef_expm1f8_u10")(x))
+    arr = dict(x=x, expf=ref_shim.torch_vec8("Sleef_expf8_u10avx2")(x), expm1f=ref_shim.torch_vec8("Sleef_expm1f8_u10avx2")(x))
     assert np.array_equal(arr["expm1f"].view(np.uint32), torch.expm1(T(x)).numpy().view(np.uint32))   # torch.expm1 IS that routine
     lens = list(range(1, 161)) + [254, 255, 256, 382, 383, 384, 510, 511, 512, 513, 638, 639, 640, 641, 1023, 1024, 1025,
                                   2047, 4100, 20001]

@@ -84,7 +84,7 @@ def pin_open_exp():
     0.7 % (the AVX-512 kernel is not correctly rounded; check_primitives.py) -- i.e. the reference's own results depend
     on the host.  The pin makes the fixtures host-independent and restatable; `expm1` (already Sleef) and `sum`
     (ATen) are not touched.  Returns a function that restores the original bindings."""
-    sleef_exp = torch_vec8("Sleef_expf8_u10")
+    sleef_exp = torch_vec8("Sleef_expf8_u10avx2")        # the AVX2 + FMA build of the routine, named explicitly
     saved = (torch.exp, torch.sqrt)
     o_exp, o_sqrt = torch.exp, torch.sqrt
 
