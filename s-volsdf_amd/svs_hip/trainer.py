@@ -7,6 +7,8 @@ train_step (vsdf.py:196-235) without the dataset / logging plumbing, used by ben
 """
 import ctypes
 
+import os
+
 import torch
 
 from . import lib as _lib
@@ -193,6 +195,13 @@ class _Scratch:
         self.sides = []
         self.d_beta = torch.zeros(8, device=dev)
         self.bg_bwd = BgBackward(dev) if is_bg else None
+        self._bg_streams = {}
+
+    def bg_stream(self, gi):
+        """stream of ray group gi's background-network backward (runs beside the fg backward)"""
+        if gi not in self._bg_streams:
+            self._bg_streams[gi] = torch.cuda.Stream(device=self.dev)
+        return self._bg_streams[gi]
 
     def for_groups(self, n):
         if n > self.d_beta.numel():
@@ -565,7 +574,21 @@ class TrainStep:
                         keep["z_vals"], keep["z_max"], keep["sdf"], keep["rgb_flat"], keep["depth_scale"], m.density.beta,
                         m.density.beta_min_value, keep["z_bg"], keep["bg_out0"], keep["bg_rgb"], g["rgb_values"],
                         g["weights"], None, d_depth_values_all=g["depth_values"], bg_depth=keep["bg_depth"])
-                    sc.bg_bwd.accumulate(keep, d_brgb, d_bo, slot=gi)
+                    # The background networks' backward (radiance backward, pass B, weight gradients: three launches that
+                    # depend on compositing's backward only) runs BESIDE the fg backward on a stream of its own -- at 256
+                    # rays per GPU (config 4 over 8 GPUs) its 64 workgroups and the fg sweeps' 200 fit the chip together.
+                    # Like the radiance weight-gradient stream it joins the ORIGIN stream, not its parent group stream.
+                    if serial or os.environ.get("SVS_BG_SIDE", "1") == "0":
+                        sc.bg_bwd.accumulate(keep, d_brgb, d_bo, slot=gi)
+                    else:
+                        # (a stream of its own: re-using the stream of the group's background FORWARD was measured slower at
+                        # 1024 rays, 4.87 against 4.58 ms)
+                        bs = sc.bg_stream(gi)
+                        ev = torch.cuda.Event(); ev.record(stream)
+                        with torch.cuda.stream(bs):
+                            bs.wait_event(ev)
+                            sc.bg_bwd.accumulate(keep, d_brgb, d_bo, slot=gi)
+                            evj = torch.cuda.Event(); evj.record(bs); joins.append(evj)
                 else:
                     gw = m.white_bkgd_weight_grad(g["rgb_values"], g["weights"], keep["z_vals"].shape[1])
                     d_sdf, d_rgb, d_beta = ops.composite_bwd(

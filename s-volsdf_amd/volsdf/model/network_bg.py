@@ -7,6 +7,8 @@ svs_render.hip for the inverse-sphere points and the fg/bg compositing).
 `implicit_network.*`, `rendering_network.*`, `density.beta`, `bg_implicit_network.lin{0..8}.{weight,bias}`,
 `bg_rendering_network.lin{0,1}.{weight,bias}`.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -40,6 +42,7 @@ class VolSDFNetworkBG(nn.Module):
                                       "skip-4 implicit network, 283->128->3 'nerf' radiance network, no weight-norm)")
         self._pk = self._pk_bg = None
         self._bg_key = None
+        self._bg_streams = {}              # per calling stream: the stream the background networks' forward runs on
 
     # ---- packed weights -------------------------------------------------------------------------------------
     def packed_mlp(self, rgb=True):
@@ -187,19 +190,43 @@ class VolSDFNetworkBG(nn.Module):
         if self.training:
             eik_near = cam_loc.view(1, 3) + z_samples_eik * ray_dirs
             eikonal_points = torch.cat([rng["eik_points"], eik_near], 0)
-        src = ops.PointSource(points=eikonal_points, cam=cam_loc, dirs=ray_dirs, z=z_vals)
-        sdf, gradients, feat_tiles, _, _ = ops.sdf_outputs(pk, src, 0.0, net.sphere_scale, clamp_n=n_main, keep=keep)
-        grad_theta = gradients[n_main:]
-        sdf, gradients = sdf[:n_main], gradients[:n_main]
         view_dirs = ray_dirs
         if not self.training:
             # nearest training view's directions (network_bg.py:69-74)
             view_dirs, _, _ = ops.rays_from_uv(uv[0], input["near_pose"][0].to(uv.device), intrinsics[0])
+
+        def background():
+            # network_bg.py:78-100: the background networks on the inverse-sphere samples
+            out0, feat = ops.bg_sdf_eval(pkb, bg_pts, keep=keep)
+            return out0, ops.bg_rgb_eval(pkb, view_dirs, Nb, feat, R * Nb, keep=keep)
+
+        # The background networks need the sampler's inverse-sphere points and the view directions only: in a train step
+        # they run on a stream of their own BESIDE the fg networks (R x 32 points against R x 100: at 256 rays per GPU the
+        # two launches together still fit the chip once) and compositing waits for them.  Not while a launch sequence is
+        # being captured (a fork of a forked stream that joins its parent: the runtime defect of trainer._device_step's note).
+        bg_join = None
+        cur = torch.cuda.current_stream()
+        if (self.training and keep is not None and os.environ.get("SVS_BG_SIDE", "1") != "0"
+                and not torch.cuda.is_current_stream_capturing()):
+            key = cur.cuda_stream
+            bs = self._bg_streams.get(key)
+            if bs is None:
+                bs = self._bg_streams[key] = torch.cuda.Stream(device=ray_dirs.device)
+            fork = torch.cuda.Event(); fork.record(cur)
+            with torch.cuda.stream(bs):
+                bs.wait_event(fork)
+                bg_out0, bg_rgb = background()
+                bg_join = torch.cuda.Event(); bg_join.record(bs)
+        src = ops.PointSource(points=eikonal_points, cam=cam_loc, dirs=ray_dirs, z=z_vals)
+        sdf, gradients, feat_tiles, _, _ = ops.sdf_outputs(pk, src, 0.0, net.sphere_scale, clamp_n=n_main, keep=keep)
+        grad_theta = gradients[n_main:]
+        sdf, gradients = sdf[:n_main], gradients[:n_main]
         src_main = ops.PointSource(cam=cam_loc, dirs=ray_dirs, z=z_vals)
         rgb_flat = ops.rgb_eval(pk, src_main, gradients, view_dirs, feat_tiles, keep=keep)
-        # background (network_bg.py:78-100)
-        bg_out0, bg_feat = ops.bg_sdf_eval(pkb, bg_pts, keep=keep)
-        bg_rgb = ops.bg_rgb_eval(pkb, view_dirs, Nb, bg_feat, R * Nb, keep=keep)
+        if bg_join is not None:
+            torch.cuda.current_stream().wait_event(bg_join)
+        else:
+            bg_out0, bg_rgb = background()
         comp = ops.composite_bg(z_vals, z_max, sdf, rgb_flat, depth_scale, self.density.beta, self.density.beta_min_value,
                                 z_bg, bg_out0, bg_rgb, bg_depth, normals=None if self.training else gradients)
         if keep is not None:
