@@ -41,6 +41,9 @@ def record_off(n_points, n_blocks, block):
     return n_blocks * T * KBLOCK + block * T * KREC
 
 
+_WGRAD_SPLIT = os.environ.get("SVS_WGRAD_SPLIT", "0")         # 0 (default) | 1 | auto (MlpBackward.accumulate: an experiment)
+
+
 def _off(t, n_floats):
     """device pointer `n_floats` floats into tensor t"""
     return t.data_ptr() + 4 * n_floats
@@ -189,10 +192,11 @@ class MlpBackward:
         def addr(x):
             return x.value if isinstance(x, ctypes.c_void_p) else x
 
-        def job(slot, n_pts, amax, a0, sa0, b0, sb0, a1=None, sa1=0, b1=None, sb1=0, extra=None, sx=0, rec0=None, rec1=None):
+        def job(slot, n_pts, amax, a0, sa0, b0, sb0, a1=None, sa1=0, b1=None, sb1=0, extra=None, sx=0, rec0=None, rec1=None,
+                bias=True):
             return _lib.WGradJob(addr(a0), addr(b0), sa0, sb0, addr(a1), addr(b1), sa1, sb1,
                                  addr(extra), sx, n_pts, LDW, addr(_off(acc.dWk, slot * 256 * LDW)),
-                                 addr(_off(acc.dbk, slot * 256)), addr(_off(acc.absmax, amax)) if h2 else None,
+                                 addr(_off(acc.dbk, slot * 256)) if bias else None, addr(_off(acc.absmax, amax)) if h2 else None,
                                  addr(rec0) if h2 else None, addr(rec1) if h2 else None)
 
         def wgrad_multi(cached):
@@ -247,6 +251,27 @@ class MlpBackward:
         _lib.check(L.svs_sdf_bwd_a(*src.args(), _ptr(d_grad), _ptr(mask), _ptr(hbuf), _ptr(gbuf), _ptr(S.sdf), prec,
                                    _ptr(self.ubuf), _ptr(self.a2buf), _ptr(self.pebuf),
                                    _ptr(acc.absmax) if h2 else None, _ptr(self.a2max) if h2 else None, st), "svs_sdf_bwd_a")
+        # Experiment (SVS_WGRAD_SPLIT=1 | auto; OFF by default): at small batches (config 4's 256 rays per GPU: the step is the
+        # SUM of its kernels' latencies) the second-order half of the SDF weight gradients -- ghat_l x u_l^T, whose operands
+        # are complete once pass A is -- as a launch of its own BESIDE pass B, on the radiance weight gradients' stream; the
+        # first-order half (abar_l x h_l^T, bias gradients) after pass B.  Same sums, same accumulators (gradient tests pass)
+        # -- and measured SLOWER at every size: 1.46 against 1.42 ms at 256 rays, 1.17 / 1.145 at 128, 2.37 / 2.28 at 512
+        # (A/B three times on one box): the second launch's ~70 us of ring fill outweigh what runs under pass B.
+        split = h2 and side and (_WGRAD_SPLIT == "1" or (_WGRAD_SPLIT == "auto" and n_total <= 40960))
+        join2 = None
+        if split:
+            k2 = ("sdf2", n_total, prec, self.ubuf.data_ptr(), gbuf.data_ptr(), acc.dWk.data_ptr())
+            arr_2 = self._job_cache.get(k2)
+            arr_2 = arr_2[:2] if arr_2 is not None else None
+            if arr_2 is None:
+                urec = lambda l: _off(self.ubuf, record_off(n_total, 9, l))
+                arr_2 = self._cache_jobs(k2, [job(l, n_total, 0, _off(gbuf, l * LS), KBLOCK, _off(self.ubuf, l * LS), KBLOCK,
+                                                  rec0=urec(l), bias=False) for l in range(8)])
+            after_a = torch.cuda.Event(); after_a.record(main)
+            with torch.cuda.stream(side_stream):
+                side_stream.wait_event(after_a)
+                wgrad_multi(arr_2)
+                join2 = torch.cuda.Event(); join2.record(side_stream)
         _lib.check(L.svs_sdf_bwd_b(n_total, _ptr(d_sdf_full), _ptr(mask), _ptr(self.feat_bar), n_main, _ptr(hbuf),
                                    _ptr(gbuf), _ptr(self.a2buf), _ptr(S.sdf), prec, _ptr(self.abuf), _ptr(self.sbar),
                                    _ptr(acc.absmax) if h2 else None, _ptr(self.a2max) if h2 else None, st),
@@ -259,24 +284,27 @@ class MlpBackward:
         ev = self.timer_events = ([torch.cuda.Event(enable_timing=True) for _ in range(2)] if self.time_wgrad else None)
         if ev:
             ev[0].record()
-        skey = ("sdf", n_total, n_main, prec, self.abuf.data_ptr(), self.ubuf.data_ptr(), self.pebuf.data_ptr(), hbuf.data_ptr(),
-                gbuf.data_ptr(), self.feat_bar.data_ptr(), acc.dWk.data_ptr())
+        skey = ("sdf1" if split else "sdf", n_total, n_main, prec, self.abuf.data_ptr(), self.ubuf.data_ptr(), self.pebuf.data_ptr(),
+                hbuf.data_ptr(), gbuf.data_ptr(), self.feat_bar.data_ptr(), acc.dWk.data_ptr())
         arr_s = self._job_cache.get(skey)
         arr_s = arr_s[:2] if arr_s is not None else None
         if arr_s is None:
             arec = lambda l: _off(self.abuf, record_off(n_total, 8, l))
             urec = lambda l: _off(self.ubuf, record_off(n_total, 9, l))
-            jobs = [job(0, n_total, 0, _off(self.abuf, 0), KBLOCK, _ptr(self.pebuf), KBLOCK,
-                        _off(gbuf, 0), KBLOCK, _off(self.ubuf, 0), KBLOCK, rec0=arec(0), rec1=urec(0))]
+            second = (lambda l: dict(a1=_off(gbuf, l * LS), sa1=KBLOCK, b1=_off(self.ubuf, l * LS), sb1=KBLOCK, rec1=urec(l))) \
+                if not split else (lambda l: {})
+            jobs = [job(0, n_total, 0, _off(self.abuf, 0), KBLOCK, _ptr(self.pebuf), KBLOCK, rec0=arec(0), **second(0))]
             for l in range(1, 8):
-                jobs.append(job(l, n_total, 0, _off(self.abuf, l * LS), KBLOCK, _off(hbuf, (l - 1) * LS), KBLOCK,
-                                _off(gbuf, l * LS), KBLOCK, _off(self.ubuf, l * LS), KBLOCK, rec0=arec(l), rec1=urec(l)))
+                jobs.append(job(l, n_total, 0, _off(self.abuf, l * LS), KBLOCK, _off(hbuf, (l - 1) * LS), KBLOCK, rec0=arec(l),
+                                **second(l)))
             jobs.append(job(8, n_main, 2, _ptr(self.feat_bar), KBLOCK, _off(hbuf, 7 * LS), KBLOCK,
                             rec0=_off(self.feat_bar, record_off(n_main, 1, 0))))
             arr_s = self._cache_jobs(skey, jobs)
         wgrad_multi(arr_s)
         if ev:
             ev[1].record()
+        if join2 is not None:
+            join = join2                      # (recorded on the same side stream, after the radiance launch's event)
         if wait and side:
             main.wait_event(join)
         self._hold = (d_grad, d_sdf_full, d_normals, d_rgb)      # keep inputs alive until the streams are joined
