@@ -326,3 +326,18 @@ def test_init_data_parallel_without_launcher(monkeypatch):
     import torch.distributed as dist
     import volsdf.vsdf as vs
     assert vs.init_data_parallel() == (1, 0, 0) and not dist.is_initialized()
+
+
+def test_no_ray_group_of_pure_padding():
+    """A padded batch (TrainStep._pad_batch repeats the last ray up to the kernels' granularity) must not be split so that a
+    ray group consists of padding only -- its loss would be a mean over zero rays; such a batch runs as one group."""
+    sys.path.insert(0, os.path.join(ROOT, "s-volsdf_amd"))
+    from types import SimpleNamespace
+    from svs_hip.trainer import TrainStep
+    me = SimpleNamespace(_force_groups=None, groups=[(0, 992), (992, 1008)], schedule={}, _n_valid=990)
+    me._groups_raw = lambda R: TrainStep._groups_raw(me, R)
+    assert TrainStep._groups_for(me, 1008) == [(0, 1008)]                  # rays 990..1007 are padding: the tail group is all padding
+    me._n_valid = 1000
+    assert TrainStep._groups_for(me, 1008) == [(0, 992), (992, 1008)]      # 8 real rays in the tail group: the split stays
+    me._n_valid = 1008
+    assert TrainStep._groups_for(me, 1008) == [(0, 992), (992, 1008)]
