@@ -48,6 +48,8 @@ class SyntheticSceneDataset(torch.utils.data.Dataset):
         uv = np.mgrid[0:self.img_res[0], 0:self.img_res[1]].astype(np.int32)
         uv = torch.from_numpy(np.flip(uv, axis=0).copy()).float().reshape(2, -1).transpose(1, 0)
         sample = {"uv": uv, "intrinsics": self.intrinsics_all[idx], "pose": self.pose_all[idx]}
+        if self.data_dir == "BlendedMVS":        # scene_dataset.py:239-240: the pose of a neighbouring view (eval-mode bg colours)
+            sample["near_pose"] = self.pose_all[(idx + 1) % self.n_images]
         gt = {"rgb": self.rgb_images[idx], "rgb_smooth": self.rgb_smooth[idx], "mask": self.masks[idx]}
         if self.sampling_idx is not None:
             gt["rgb"] = self.rgb_images[idx][self.sampling_idx, :]

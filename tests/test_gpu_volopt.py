@@ -319,3 +319,36 @@ def test_volopt_data_parallel_one_gpu(tmp_path, monkeypatch):
     with pytest.raises(RuntimeError, match="one rank per GPU"):
         build(make_args())
     assert not dist.is_initialized()
+
+
+def test_volopt_background_model(tmp_path, monkeypatch):
+    """BASELINE config 4's model through the reference's driver surface: `train.model_class:
+    volsdf.model.network_bg.VolSDFNetworkBG` with the bmvs.yaml model section on a BlendedMVS-style dataset (items carry
+    `near_pose`): optimisation steps with the MVS prior, a render for the MVS stage (eval mode: background colours from the
+    neighbouring view's directions), checkpoints that a second VolOpt resumes from."""
+    from volsdf.utils.conf import bmvs_model_conf
+    monkeypatch.chdir(tmp_path)
+    torch.manual_seed(0)
+    args = make_args(use_mvs=True)
+    args["vol"]["train"].update(model_class="volsdf.model.network_bg.VolSDFNetworkBG", num_pixels=256)
+    args["vol"]["model"] = bmvs_model_conf()
+    args["vol"]["dataset"]["data_dir"] = "BlendedMVS"
+    v = build(args)
+    assert type(v.model).__name__ == "VolSDFNetworkBG" and v.step_fn.is_bg
+    v.get_mvs_input(mvs_outputs(v))
+    n_params = sum(p.numel() for p in v.model.parameters())
+    assert n_params == 1361387                                   # SURVEY.md section 8: fg + bg model
+    p0 = v.step_fn.fp.flat.clone()
+    epoch = v.run(opt_stepN=6)
+    assert v.iter_step == 10 and bool(torch.isfinite(v.step_fn.fp.flat).all()) and not torch.equal(p0, v.step_fn.fp.flat)
+    depth, _ = v.render_mvs(1, epoch)
+    assert depth.shape == (1, 24, 32) and bool(torch.isfinite(depth).all()) and float(depth.max()) > 0
+    v.save_checkpoints(epoch)
+    v2 = build(args, is_continue=True)
+    assert v2.iter_step == v.iter_step
+    for k, t in v.model.state_dict().items():
+        assert torch.equal(t, v2.model.state_dict()[k]), k
+    v2.get_mvs_input(mvs_outputs(v2))
+    v2.train_dataset.change_sampling_idx(v2.num_pixels)
+    lo = v2.train_step(next(iter(v2.train_dataloader)), use_mvs=True)
+    assert np.isfinite(float(lo["loss"]))
