@@ -24,6 +24,11 @@ def job():
     torch.manual_seed(0); random.seed(0); np.random.seed(0)
     args = tv.make_args()
     args["vol"]["train"]["num_pixels"] = 256
+    if os.environ.get("DP_MODEL") == "bmvs":              # BASELINE config 4's model: fg + inverted-sphere background
+        from volsdf.utils.conf import bmvs_model_conf
+        args["vol"]["train"]["model_class"] = "volsdf.model.network_bg.VolSDFNetworkBG"
+        args["vol"]["model"] = bmvs_model_conf()
+        args["vol"]["dataset"]["data_dir"] = "BlendedMVS"
     v = tv.build(args, overlap_loader=False)
     depth0, _ = v.render_mvs(0, 0)                                  # before any step: identical parameters everywhere
     v.train_dataset.change_sampling_idx(v.num_pixels)
