@@ -95,6 +95,9 @@ def allreduce_flat_grad(flat_grad, world):
     return flat_grad
 
 
+_SMALL_GROUP_INLINE = os.environ.get("SVS_SMALL_GROUP_INLINE", "0") == "1"     # A/B: the small ray group's radiance weight gradients in line
+
+
 class _GroupedOutputs(dict):
     """Model outputs of a step that ran as ray groups: per-ray tensors are concatenated in ray order on first access
     (the step itself never needs the merged tensors; logging does, every 50 steps)."""
@@ -598,7 +601,8 @@ class TrainStep:
                         d_beta_out=sc.d_beta[gi:gi + 1])
                 if d_beta.data_ptr() != sc.d_beta[gi:gi + 1].data_ptr():
                     sc.d_beta[gi:gi + 1].copy_(d_beta)
-                joins.append(sc.bwd[gi].accumulate(keep, d_rgb, d_sdf, g["grad_theta"], wait=False, side=not serial))
+                joins.append(sc.bwd[gi].accumulate(keep, d_rgb, d_sdf, g["grad_theta"], wait=False,
+                                                   side=not serial and not (gi and _SMALL_GROUP_INLINE)))
                 results.append((lo_out, out))
                 holds.append((keep, g, d_sdf, d_rgb, inp, g_gt))
                 if gi:

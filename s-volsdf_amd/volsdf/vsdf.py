@@ -200,9 +200,9 @@ class VolOpt():
         self._device_batches = bool(kwargs.get('device_batches', os.environ.get('SVS_DEVICE_BATCHES', '0') == '1'))
         # the reference's DataLoader loop with the next batch prepared by a helper thread while the current step is being
         # enqueued: same batches, same random streams (_epoch_overlapped; pinned by test_overlapped_loader_draws_the_same_
-        # batches).  Default since round 4 (5.3 -> 4.3-4.5 ms per step end to end: the dataset's ~2.6 ms of host work per
+        # batches).  Default since round 4 (4.7-5.3 -> 4.0-4.15 ms per step end to end: the dataset's ~2.6 ms of host work per
         # step -- torch.randperm over all pixels, the full pixel grid per item -- no longer sits in front of the step's
-        # 2.2 ms of enqueueing); `overlap_loader=False` / SVS_OVERLAP_LOADER=0 gives the strictly sequential loop.
+        # 1.7 ms of enqueueing); `overlap_loader=False` / SVS_OVERLAP_LOADER=0 gives the strictly sequential loop.
         self._overlap_loader = bool(kwargs.get('overlap_loader', os.environ.get('SVS_OVERLAP_LOADER', '1') == '1'))
         self._loader_pool = None
 
