@@ -380,6 +380,38 @@ def fx_sampler_r256_more():
                                             n_rounds=len(sdfs), inv_4log=inv4), rec, sdfs))
 
 
+def fx_forward_r256_more():
+    """Whole forwards of the reference at 256 rays beyond the eval runs of fx_sampler_r256: the DTU model in TRAIN mode
+    (fast = 1, the draws of synth.make_train_rng) and the fg + inverted-sphere background model in eval (fast = -1, near_pose)
+    and train mode -- integrated outputs, per-sample weights / depths, eikonal gradients."""
+    params = dict(synth.make_params(seed=0))
+    K, pose = synth.make_camera(center=(0.1, 0.05, -2.5), tilt=0.1)
+    _, near_pose = synth.make_camera(center=(0.25, 0.0, -2.45), tilt=0.05)
+    R = 256
+    uv = synth.make_uv(R, seed=27, margin=0.05)
+    inp = {"intrinsics": T(K)[None], "uv": T(uv)[None], "pose": T(pose)[None]}
+    keep = ("rgb_values", "depth_values", "depth_values_all", "depth_vals", "weights", "grad_theta", "normal_map")
+    m = build_model(params, beta=0.05)
+    m.train()
+    with inject_rng(synth.make_train_rng(R, seed=33)):
+        out = m(inp, fast=1)
+    save("forward256_train_b0.05", K=K, pose=pose, uv=uv, beta_param=F32(0.05), fast=1, rng_seed=33,
+         **{k: out[k].detach().numpy() for k in keep if k in out})
+    bgp = dict(params); bgp.update(synth.make_bg_params(seed=0))
+    inp_bg = dict(inp, near_pose=T(near_pose)[None])
+    m = build_bg_model(bgp, 0.01)
+    m.eval()
+    out = m(inp_bg, fast=-1)
+    save("forward256_bg_eval_b0.01", K=K, pose=pose, near_pose=near_pose, uv=uv, beta_param=F32(0.01), fast=-1,
+         **{k: out[k].detach().numpy() for k in keep if k in out})
+    m = build_bg_model(bgp, 0.05)
+    m.train()
+    with inject_rng(synth.make_train_rng(R, seed=35, n_final=98, bg=True)):
+        out = m(inp_bg, fast=1)
+    save("forward256_bg_train_b0.05", K=K, pose=pose, near_pose=near_pose, uv=uv, beta_param=F32(0.05), fast=1, rng_seed=35,
+         **{k: out[k].detach().numpy() for k in keep if k in out})
+
+
 def fx_composite():
     params = synth.make_params(seed=0)
     m = build_model(params, beta=0.03)
@@ -1005,7 +1037,7 @@ ALL = dict(fusion=fx_fusion, filter_depth=fx_filter_depth, pfm=fx_pfm, chamfer=f
            train_step_w1=lambda: fx_train_step(16, 2, "train_step_w1", "w1"),
            train_step_bg=fx_train_step_bg,
            train_step_bg_sparse=lambda: fx_train_step_bg("train_step_bg_sparse", 50, 1e3, 1),
-           sampler_r256=fx_sampler_r256, sampler_r256_more=fx_sampler_r256_more, sampler_hostexp=fx_sampler_hostexp, primitives=fx_primitives)
+           sampler_r256=fx_sampler_r256, sampler_r256_more=fx_sampler_r256_more, forward_r256_more=fx_forward_r256_more, sampler_hostexp=fx_sampler_hostexp, primitives=fx_primitives)
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(ALL)

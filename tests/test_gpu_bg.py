@@ -124,6 +124,31 @@ def test_bg_model_forward_golden(dev, golden_dir, tag):
         np.testing.assert_allclose(out["normal_map"], g["normal_map"], atol=2e-4)
 
 
+@pytest.mark.parametrize("name", ["forward256_bg_eval_b0.01", "forward256_bg_train_b0.05"])
+def test_bg_model_forward_r256(dev, golden_dir, name):
+    """VolSDFNetworkBG.forward (HIP) on 256 rays against the reference, eval (fast = -1, near_pose) and train mode: colours to
+    1e-4 on every ray, fg depths to 2e-4 / fg weight sum, all-depths to 3e-3 relative."""
+    from rng_inject import inject_rng
+    g = dict(np.load(os.path.join(golden_dir, name + ".npz")))
+    training = "train" in name
+    m = _model(dev, float(g["beta_param"]))
+    m.train(training)
+    inp = {"intrinsics": G(g["K"], dev)[None], "uv": G(g["uv"], dev)[None], "pose": G(g["pose"], dev)[None],
+           "near_pose": G(g["near_pose"], dev)[None]}
+    with torch.no_grad():
+        if training:
+            with inject_rng(synth.make_train_rng(256, seed=int(g["rng_seed"]), bg=True)):
+                out = m(inp, fast=int(g["fast"]))
+        else:
+            out = m(inp, fast=int(g["fast"]))
+    out = {k: v.detach().cpu().numpy() for k, v in out.items() if torch.is_tensor(v)}
+    print(f"{name}: rgb max err on all 256 rays {np.abs(out['rgb_values'] - g['rgb_values']).max():.2e}")
+    np.testing.assert_allclose(out["rgb_values"], g["rgb_values"], atol=1e-4)
+    wsum = g["weights"].sum(1, keepdims=True)
+    assert (np.abs(out["depth_values"] - g["depth_values"]) <= 3e-4 / np.maximum(wsum, 1e-3)).all()
+    np.testing.assert_allclose(out["depth_values_all"], g["depth_values_all"], rtol=3e-3)
+
+
 def _rel(a, b):
     return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / (np.abs(np.asarray(b, np.float64)).max() + 1e-30))
 

@@ -425,6 +425,26 @@ def test_model_forward_golden(dev, golden_dir, tag):
         np.testing.assert_allclose(out["normal_map"], g["normal_map"], atol=2e-4)
 
 
+def test_model_forward_r256_train(dev, golden_dir):
+    """VolSDFNetwork.forward in TRAIN mode (fast = 1; jitter, random u, randperm extras, eikonal points fed through torch's
+    CPU RNG call sites) on 256 rays against the reference (forward256_train_b0.05): colours / depths / eikonal gradients on
+    every ray."""
+    from rng_inject import inject_rng
+    g = dict(np.load(os.path.join(golden_dir, "forward256_train_b0.05.npz")))
+    m, _ = _model(dev, float(g["beta_param"]))
+    m.train()
+    inp = {"intrinsics": G(g["K"], dev)[None], "uv": G(g["uv"], dev)[None], "pose": G(g["pose"], dev)[None]}
+    with inject_rng(synth.make_train_rng(256, seed=int(g["rng_seed"]))):
+        out = {k: v.detach().cpu().numpy() for k, v in m(inp, fast=1).items() if torch.is_tensor(v)}
+    moved = _moved(out, g)
+    print(f"forward256_train: rgb max err on all rays {np.abs(out['rgb_values'] - g['rgb_values']).max():.2e}, "
+          f"{int(moved.sum())} of {moved.size} samples moved")
+    np.testing.assert_allclose(out["rgb_values"], g["rgb_values"], atol=1e-4)
+    np.testing.assert_allclose(out["depth_values"], g["depth_values"], atol=2e-4)
+    np.testing.assert_allclose(out["grad_theta"][:256], g["grad_theta"][:256], atol=2e-4)       # the uniform eikonal points
+    np.testing.assert_allclose(out["grad_theta"][256:], g["grad_theta"][256:], atol=5e-3)       # at the sampler's extra depths
+
+
 def test_model_forward_vs_oracle_1024(dev):
     """Full-size batch (1024 rays): integrated outputs against the oracle within 1e-4 / 2e-4 on every ray."""
     m, params = _model(dev, 0.1)

@@ -227,6 +227,31 @@ def test_sampler_r256_indices(golden_dir, name):
     print(f"{name}: 0 differing indices of {n_idx} ({int(g['n_rounds'])} rounds)")
 
 
+@pytest.mark.parametrize("name", ["forward256_train_b0.05", "forward256_bg_eval_b0.01", "forward256_bg_train_b0.05"])
+def test_forward_r256_train_and_background(golden_dir, name):
+    """Whole forwards at 256 rays beyond the eval runs: the DTU model in TRAIN mode and the fg + background model in eval and
+    train mode -- colours to 5e-6 on every ray (north star: 1e-4), depths to their scale."""
+    g = load(golden_dir, name)
+    bg, training = "_bg_" in name, "train" in name
+    params = dict(synth.make_params(0))
+    rng = synth.make_train_rng(256, seed=int(g["rng_seed"]), bg=bg) if training else None
+    if bg:
+        params.update(synth.make_bg_params(0))
+        out = orc.render_forward_bg(params, g["uv"], g["pose"], g["K"], beta_param=g["beta_param"], fast=int(g["fast"]),
+                                    training=training, rng=rng, near_pose=g["near_pose"])
+        np.testing.assert_allclose(out["depth_values_all"], g["depth_values_all"], rtol=1e-5)
+    else:
+        out = orc.render_forward(params, g["uv"], g["pose"], g["K"], beta_param=g["beta_param"], fast=int(g["fast"]),
+                                 training=training, rng=rng)
+    np.testing.assert_allclose(out["rgb_values"], g["rgb_values"], atol=5e-6)
+    np.testing.assert_allclose(out["depth_values"], g["depth_values"], atol=1e-4)
+    if training:
+        np.testing.assert_allclose(out["grad_theta"], g["grad_theta"], atol=2e-3)
+        np.testing.assert_allclose(out["grad_theta"][:256], g["grad_theta"][:256], atol=1e-4)
+    else:
+        np.testing.assert_allclose(out["normal_map"], g["normal_map"], atol=1e-5)
+
+
 def test_sampler_r256_train_mode(golden_dir):
     """The reference's TRAIN-mode sampler on 256 rays (fast = 1; stratified jitter, random u, randperm extras, eikonal pick):
     index, cdf, beta and final z / z_eik identity, bit for bit."""
