@@ -93,9 +93,11 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --rays rays per GPU; strong: --rays rays in total, rays/N per GPU")
     ap.add_argument("--settle", type=float, default=1.0, help="seconds of untimed steady-state steps before the timed region")
-    ap.add_argument("--graph", choices=["off", "on", "linear"], default="off",
-                    help="replay the step's launch sequence from a hipGraph (on: with its stream topology; linear: as one "
-                         "chain); off (default): eager launches -- measured faster on this ROCm stack, see DESIGN.md")
+    ap.add_argument("--graph", choices=["off", "on", "linear", "plan", "auto"], default="auto",
+                    help="how the ~100 launches of a step are enqueued.  off: eager launches from Python; plan: the step's "
+                         "captured sequence enqueued as plain launches by one library call (svs_plan_run); auto (default, also "
+                         "VolOpt's): plan for batches that run as one ray group (< 328 rays per GPU: the host-bound sizes), "
+                         "eager otherwise; on / linear: hipGraphLaunch of the capture (with its stream topology / as one chain)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel event timing (roofline = null)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-f32", action="store_true",
@@ -197,7 +199,7 @@ def main():
         loss = VolSDFLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, rgb_weight=1.0, mvs_weight=1.0,
                           sparse_weight=1.0, anneal_rgb=200, gce=0.5, confi=1e-3)       # config/ours.yaml:16-21
         t = TrainStep(mdl, loss, lr=5e-4, world=world, rank=rank, groups=None if args.groups == "none" else "auto",
-                      graph={"off": False, "on": True, "linear": "linear"}[args.graph])
+                      graph={"off": False, "on": True, "linear": "linear", "plan": "plan", "auto": "auto"}[args.graph])
         return t, (lambda: t(inp, gt, mvs=mvs))
 
     ts, step = make_step(model)
@@ -229,6 +231,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     del out
+
+    # host side of a step: wall time the host thread needs to ENQUEUE a step (six steps into an empty queue, nothing
+    # blocks on the device); a step whose kernels take less than this is host-bound
+    host_ms = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        for _ in range(6):
+            step()
+        host_ms.append(1e3 * (time.perf_counter() - th) / 6)
+    torch.cuda.synchronize()
+    host_enqueue_ms = sorted(host_ms)[1]
 
     other = None
     if world > 1 and train and not args.no_other_scaling and args.rays % world == 0:
@@ -301,6 +315,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
+            "host_enqueue_ms_per_step": host_enqueue_ms,
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
@@ -316,8 +331,13 @@ def main():
                        "mlp_precision": precision_note(ops.default_precision()),
                        "ray_groups": ([list(g) for g in ts._groups_for(R)] if train else [[0, R]]),
                        "ray_group_schedule": (ts.schedule.get(R) if (train and args.groups == "auto") else None),
-                       "launch": ("hipGraph replay of the captured step + eager all-reduce / fused Adam"
-                                  if (train and ts.graph) else "eager launches"),
+                       "launch": ("eager launches" if not (train and ts.graph) else
+                                  "launch plan (the captured step enqueued as plain launches by one library call: svs_plan_run) "
+                                  "+ all-reduce / fused Adam" if (ts.graph in ("plan", "auto") and any(c.plan is not None for c in ts._captured.values())) else
+                                  "eager launches" if ts.graph == "auto" else
+                                  "hipGraph replay of the captured step + eager all-reduce / fused Adam"),
+                       "launch_plan": (next((c.plan.info for c in ts._captured.values() if c.plan is not None), None)
+                                       if train else None),
                        "rays_per_gpu": R, "rays_total": R * world, "settle_steps": settle_steps,
                        "flop_per_ray": flop_per_ray,
                        "model_flops_per_s": world * R * args.steps / dt * flop_per_ray},

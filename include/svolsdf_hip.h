@@ -34,6 +34,13 @@ const char* svs_last_error_string(void);
 int svs_rays_from_uv(const float* uv, const float* pose, const float* intrinsics, int n_rays, float* ray_dirs,
                      float* cam_loc, float* depth_scale, void* hip_stream);
 
+/* The eikonal points of a train-mode forward (volsdf/model/network.py:258-266; BG model: network_bg.py:128-138):
+ * points[0..n_rays) = uniform_points (the host's uniform draws in the bounding sphere, (n_rays,3)),
+ * points[n_rays + r] = cam_loc + z_eik[r] * ray_dirs[r] (the sampler's extra depth per ray, ray_sampler.py:200-208).
+ * points: DEVICE float[2 n_rays][3], the tail of the point list the fused SDF launch evaluates. */
+int svs_eikonal_points(const float* uniform_points, const float* cam_loc, const float* z_eik, const float* ray_dirs,
+                       int n_rays, float* points, void* hip_stream);
+
 /* ---- a5/a6  weight packing --------------------------------------------------------------------------
  * Weight-norm materialisation w = g*v/||v|| (nn.utils.weight_norm, volsdf/model/network.py:64-65) and the
  * permutation into the MFMA consumption order.  weight_v/weight_g/bias: HOST arrays of 9 (SDF) / 5 (radiance)
@@ -515,6 +522,27 @@ int svs_selftest_cumsum(const float* x, float* y, float* total, int rows, int m,
  * svs_selftest_exp evaluates the restated Sleef_expf8_u10 / Sleef_expm1f8_u10 (torch.exp pinned / torch.expm1,
  * ray_sampler.py:130-146,225-227, volsdf/model/density.py:26).  1 <= m <= 16000. */
 int svs_selftest_rowsum(const float* x, float* total, int rows, int m, void* hip_stream);
+
+/* ---- launch plans: the device part of a step enqueued by one call --------------------------------------------
+ * The launch sequence of VolOpt.train_step (volsdf/vsdf.py:196-235: forward, prior lookup, loss, backward) contains no host
+ * decision; the host records it once per configuration with a stream capture and hands the captured hipGraph_t to
+ * svs_plan_build, which reads its nodes and edges (kernel, memcpy, memset and empty nodes; anything else: SVS_EINVAL) into
+ * a plan: the nodes in a topological order, each on one of <= 12 HIP streams (chains of the dependency graph), one event
+ * per edge that crosses streams.  The critical chain (every node hands its stream to the successor with the longest way
+ * to the end) is the first chain; side_streams: optional hipStream_t handles of the caller for the 2nd, 3rd ... chain
+ * (which hardware queue a stream maps to is decided when it is created -- a caller whose eager schedule runs well hands in
+ * the streams of that schedule); chains beyond them get streams the plan creates.  svs_plan_run enqueues the plan with plain launches -- first chain on `hip_stream`, the
+ * others on streams the plan owns, ordered behind what `hip_stream` held when the call was made and joined back into it
+ * before the call returns -- and does not synchronise.  The graph is never instantiated or launched; it must outlive the
+ * plan (the kernel arguments stay in its nodes).  svs_plan_info: counts[8] = nodes, kernels, copies, memsets, empty
+ * nodes, streams, events, side streams that start at the entry. */
+int svs_plan_build(void* hip_graph, void* const* side_streams, int n_side_streams, void** plan_out);
+int svs_plan_run(void* plan, void* hip_stream);
+int svs_plan_info(void* plan, int* counts);
+/* one line per node in issue order: "<position> s<stream> kernel <name> grid .. | memcpy .. | memset .. | empty", followed by
+ * " w<event>" per event waited for in front of it and " r<event>" when an event is recorded behind it (HOST text buffer) */
+int svs_plan_describe(void* plan, char* text, size_t capacity);
+int svs_plan_destroy(void* plan);
 
 #ifdef __cplusplus
 }

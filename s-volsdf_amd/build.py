@@ -37,6 +37,7 @@ UNITS = {
     "svs_optim.hip": ["-ffp-contract=off"],
     "svs_fusion.hip": ["-ffp-contract=off"],
     "svs_cloud.hip": ["-ffp-contract=off"],
+    "svs_plan.hip": [],
 }
 # The two-waves-per-SIMD experiments of round 3 (svs_sdf_vals16 / svs_sdf_vals_pair, measured no faster
 # than the default kernel) are built only on request: SVS_BUILD_EXPERIMENTS=1.

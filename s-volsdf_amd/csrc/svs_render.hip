@@ -32,6 +32,19 @@ __global__ void rays_kernel(const float* __restrict__ uv, const float* __restric
   depth_scale[r] = zl / nc;                                // network.py:216-217
 }
 
+// ---- a9: the eikonal points of a train-mode forward (network.py:258-266) -----------------------------------------------
+// out[0..R) = the uniform draws; out[R + r] = cam + z_eik[r] * dirs[r] (one product, one sum per component, as the
+// reference's broadcast expression evaluates it)
+__global__ void eikonal_points_kernel(const float* __restrict__ uniform, const float* __restrict__ cam,
+                                      const float* __restrict__ z_eik, const float* __restrict__ dirs, int R,
+                                      float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * R) return;
+  out[i] = uniform[i];
+  const int r = i / 3, c = i - 3 * r;
+  out[3 * R + i] = cam[c] + z_eik[r] * dirs[i];
+}
+
 // ---- a8: compositing ------------------------------------------------------------------------------------
 constexpr int kMaxS = 256;
 
@@ -782,6 +795,16 @@ int svs_rays_from_uv(const float* uv, const float* pose, const float* intrinsics
   rays_kernel<<<(n_rays + 255) / 256, 256, 0, (hipStream_t)hip_stream>>>(uv, pose, intrinsics, n_rays, ray_dirs, cam_loc,
                                                                         depth_scale);
   return check_launch("svs_rays_from_uv");
+}
+
+int svs_eikonal_points(const float* uniform_points, const float* cam_loc, const float* z_eik, const float* ray_dirs,
+                       int n_rays, float* points, void* hip_stream) {
+  if (!uniform_points || !cam_loc || !z_eik || !ray_dirs || !points || n_rays <= 0) {
+    set_error("svs_eikonal_points: null/invalid argument"); return SVS_EINVAL;
+  }
+  eikonal_points_kernel<<<(3 * n_rays + 255) / 256, 256, 0, (hipStream_t)hip_stream>>>(uniform_points, cam_loc, z_eik,
+                                                                                      ray_dirs, n_rays, points);
+  return check_launch("svs_eikonal_points");
 }
 
 int svs_composite(int n_rays, int n_samples, const float* z, const float* sdf, const float* rgb, const float* normals,

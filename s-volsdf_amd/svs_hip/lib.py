@@ -144,6 +144,14 @@ SIGNATURES = {
     "svs_selftest_rowsum": (c_int, [_P, _P, c_int, c_int, _P]),
 }
 
+SIGNATURES.update({
+    "svs_eikonal_points": (c_int, [_P, _P, _P, _P, c_int, _P, _P]),
+    "svs_plan_build": (c_int, [_P, _PP, c_int, _PP]),
+    "svs_plan_run": (c_int, [_P, _P]),
+    "svs_plan_info": (c_int, [_P, _P]),
+    "svs_plan_describe": (c_int, [_P, c_char_p, c_size_t]),
+    "svs_plan_destroy": (c_int, [_P]),
+})
 
 # entry points of the experimental kernels: present only in a library built with SVS_BUILD_EXPERIMENTS=1
 EXPERIMENTAL_SIGNATURES = {

@@ -345,19 +345,35 @@ def composite_bg(z, z_max, sdf, rgb, depth_scale, beta_param, beta_min, z_bg, bg
                 depth_values=depth_values, depth_values_all=depth_all, depth_vals=depth_vals, normal_map=normal_map)
 
 
+def eikonal_points(uniform_points, cam_loc, z_eik, ray_dirs):
+    """network.py:258-266: (2R,3) = [the uniform draws ; cam + z_eik * dirs] in one launch."""
+    R = ray_dirs.shape[0]
+    out = torch.empty(2 * R, 3, device=ray_dirs.device)
+    _lib.check(_lib.load().svs_eikonal_points(_ptr(_f32(uniform_points)), _ptr(_f32(cam_loc)), _ptr(_f32(z_eik)),
+                                              _ptr(_f32(ray_dirs)), R, _ptr(out), _stream()), "svs_eikonal_points")
+    return out
+
+
 def composite_bg_bwd(z, z_max, sdf, rgb, depth_scale, beta_param, beta_min, z_bg, bg_out0, bg_rgb, d_rgb_values,
-                     d_weights=None, d_depth_values=None, d_depth_values_all=None, bg_depth=None):
+                     d_weights=None, d_depth_values=None, d_depth_values_all=None, bg_depth=None, d_sdf_out=None,
+                     d_beta_out=None):
     """backward of composite_bg -> d_sdf (R*S,1), d_rgb (R*S,3), d_bg_out0 (R*Nb,1), d_bg_rgb (R*Nb,3), d_beta (1,).
     d_depth_values: gradient of the foreground depth; d_depth_values_all (with bg_depth (R,Nb)): gradient of
-    depth_values_all, the fg + bg depth the loss's sparsity term reads (network_bg.py:105-110, loss.py:72-73)."""
+    depth_values_all, the fg + bg depth the loss's sparsity term reads (network_bg.py:105-110, loss.py:72-73).
+    d_sdf_out / d_beta_out: optional contiguous float32 device tensors the two results are written into (as composite_bwd)."""
     L = _lib.load()
     z = _f32(z)
     R, S = z.shape
     Nb = z_bg.shape[1]
     dev = z.device
     f = lambda *s: torch.empty(*s, device=dev)
-    d_sdf, d_rgb, d_bo, d_brgb = f(R * S, 1), f(R * S, 3), f(R * Nb, 1), f(R * Nb, 3)
-    d_beta_ray, d_beta = f(R), f(1)
+    for t, shape in ((d_sdf_out, (R * S, 1)), (d_beta_out, (1,))):
+        if t is not None and (tuple(t.shape) != shape or t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev):
+            raise ValueError(f"output tensor must be contiguous float32 {shape} on {dev}")
+    d_sdf = d_sdf_out if d_sdf_out is not None else f(R * S, 1)
+    d_rgb, d_bo, d_brgb = f(R * S, 3), f(R * Nb, 1), f(R * Nb, 3)
+    d_beta_ray = f(R)
+    d_beta = d_beta_out if d_beta_out is not None else f(1)
     opt = lambda t: _ptr(_f32(t)) if t is not None else None
     _lib.check(L.svs_composite_bg_bwd(R, S, Nb, _ptr(z), _ptr(_f32(z_max)), _ptr(_f32(sdf)), _ptr(_f32(rgb)),
                                       _ptr(_f32(depth_scale)), _ptr(_f32(beta_param).reshape(1)), float(beta_min),

@@ -214,11 +214,52 @@ class _Scratch:
             self.sides.append(torch.cuda.Stream(device=self.dev))
 
 
+class _LaunchPlan:
+    """The launch sequence of a captured step as a plan of the library (csrc/svs_plan.hip): the capture's nodes and edges
+    read once, then enqueued per step by one call -- plain launches on the step's stream topology, no hipGraphLaunch, no
+    interpreter between the launches (the call releases the GIL)."""
+
+    def __init__(self, graph, side_streams=()):
+        import ctypes
+        from .lib import check, load
+        self._lib, self._check = load(), check
+        self.graph = graph                               # the kernel arguments live in the graph's nodes
+        self.side_streams = list(side_streams)           # torch streams the side chains run on (kept alive here)
+        arr = (ctypes.c_void_p * max(1, len(self.side_streams)))(*[s.cuda_stream for s in self.side_streams])
+        handle = ctypes.c_void_p()
+        check(self._lib.svs_plan_build(ctypes.c_void_p(int(graph.raw_cuda_graph())), arr, len(self.side_streams),
+                                       ctypes.byref(handle)), "svs_plan_build")
+        self.handle = handle
+        counts = (ctypes.c_int * 8)()
+        check(self._lib.svs_plan_info(handle, counts), "svs_plan_info")
+        self.info = dict(zip(("nodes", "kernels", "copies", "memsets", "empty", "streams", "events", "entry_streams"),
+                             list(counts)))
+
+    def describe(self):
+        """one line per node, in issue order (stream, kernel name and launch shape, events waited for / recorded)"""
+        import ctypes
+        buf = ctypes.create_string_buffer(1 << 18)
+        self._check(self._lib.svs_plan_describe(self.handle, buf, len(buf)), "svs_plan_describe")
+        return buf.value.decode()
+
+    def run(self):
+        self._check(self._lib.svs_plan_run(self.handle, torch.cuda.current_stream().cuda_stream), "svs_plan_run")
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            try:
+                self._lib.svs_plan_destroy(h)
+            except Exception:
+                pass
+
+
 class _CapturedStep:
     """One captured launch sequence (hipGraph) of the device part of a step, with the static tensors it reads."""
 
     def __init__(self):
         self.graph = None
+        self.plan = None            # graph == "plan": the capture replayed as eager launches by the library
         self.static = {}            # name -> persistent device tensor (inputs, random draws, step-varying scalars)
         self.scratch = None
         self.result = None          # what the eager step would have returned: tensors inside the graph's pool
@@ -291,9 +332,14 @@ class TrainStep:
         self._force_groups = None
         self.scratch = _Scratch(dev, self.is_bg)
         if graph is None:
-            graph = os.environ.get("SVS_TRAIN_GRAPH", "0")
-            graph = {"0": False, "1": True}.get(graph, graph)
-        self.graph = graph                              # False | True (the step's stream topology) | "linear" (one chain)
+            graph = os.environ.get("SVS_TRAIN_GRAPH", "auto")
+            graph = {"0": False, "off": False, "1": True}.get(graph, graph)
+        if graph not in (False, True, "linear", "plan", "auto"):
+            raise ValueError(f"graph / SVS_TRAIN_GRAPH = {graph!r}: one of 0 | 1 | linear | plan | auto")
+        # False | True (hipGraph replay, the step's stream topology) | "linear" (hipGraph, one chain) | "plan" (the capture
+        # read into a launch plan and enqueued as plain launches by the library: csrc/svs_plan.hip) | "auto" (plans for
+        # single-group batches, eager launches otherwise)
+        self.graph = graph
         self._captured = {}
         self._graph_pool = None
 
@@ -305,6 +351,13 @@ class TrainStep:
     @property
     def accum(self):
         return self.scratch.accum
+
+    def takes_host_inputs(self, R):
+        """True when a batch of R rays runs from a captured sequence: the step then stages pixels, camera and targets itself
+        (one transfer from its ring of pinned buffers), so a caller holding HOST tensors hands them over as they are."""
+        if not self.graph:
+            return False
+        return self.graph != "auto" or len(self.split_rays(R, self.samples_per_ray())) == 1
 
     def samples_per_ray(self):
         rs = self.model.ray_sampler
@@ -429,11 +482,24 @@ class TrainStep:
         uv = model_input["uv"]
         R = uv.shape[1]
         self.check_batch(R)
-        if self.graph:
+        captured = bool(self.graph)
+        if self.graph == "auto":
+            # launch plans where the step is short enough for the host to matter: one ray group (< 328 rays of the DTU
+            # model; config 4 over 8 GPUs runs 256 per GPU) -- larger batches are bound by the device, and their two
+            # concurrent ray groups are scheduled better by the eager launch order
+            captured = len(self.split_rays(R, self.samples_per_ray())) == 1
+        if captured:
             out = self._step_captured(model_input, ground_truth, mvs, fast)
             if out is not None:
                 return self._finish(out)
-        tune = None if self.graph else self._tune_begin(R)
+        # (an eager step works on device tensors; a caller of the captured path may hand over the DataLoader's host tensors)
+        dev = self.fp.flat.device
+        if not uv.is_cuda:
+            model_input = {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in model_input.items()}
+            uv = model_input["uv"]
+        if not ground_truth["rgb"].is_cuda:
+            ground_truth = {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in ground_truth.items()}
+        tune = None if captured else self._tune_begin(R)
         try:
             n_valid = getattr(self, "_n_valid", R)
             if self.world > 1 and self.shard_draws:
@@ -554,7 +620,10 @@ class TrainStep:
                 inp["uv"] = uv[:, lo:hi].contiguous()
                 inp["_skip_xyz"] = True              # the prior lookup below works from (cam, dirs, z): no (R,S,3) point list
                 keep = {}
+                # (a capture tolerates the background forward's side stream only below the ORIGIN stream: the note above)
+                m._side_ok_in_capture = gi == 0 and not serial
                 out = m._forward_impl(inp, fast, keep, rng=m.slice_rng(rng, lo, hi))
+                m._side_ok_in_capture = False
                 if mvs is not None:
                     out['pj'], out['pi'], _ = ops.cost_lookup(mvs["views"], mvs["same_view"], mvs["img_res"],
                                                               cam=keep["cam_loc"], dirs=keep["ray_dirs"], z=keep["z_vals"],
@@ -576,7 +645,9 @@ class TrainStep:
                     d_sdf, d_rgb, d_bo, d_brgb, d_beta = ops.composite_bg_bwd(
                         keep["z_vals"], keep["z_max"], keep["sdf"], keep["rgb_flat"], keep["depth_scale"], m.density.beta,
                         m.density.beta_min_value, keep["z_bg"], keep["bg_out0"], keep["bg_rgb"], g["rgb_values"],
-                        g["weights"], None, d_depth_values_all=g["depth_values"], bg_depth=keep["bg_depth"])
+                        g["weights"], None, d_depth_values_all=g["depth_values"], bg_depth=keep["bg_depth"],
+                        d_sdf_out=sc.bwd[gi].sdf_grad_out(keep["src"].n, keep["rgb_flat"].shape[0]),
+                        d_beta_out=sc.d_beta[gi:gi + 1])
                     # The background networks' backward (radiance backward, pass B, weight gradients: three launches that
                     # depend on compositing's backward only) runs BESIDE the fg backward on a stream of its own -- at 256
                     # rays per GPU (config 4 over 8 GPUs) its 64 workgroups and the fg sweeps' 200 fit the chip together.
@@ -637,43 +708,101 @@ class TrainStep:
                 return ptrs, tuple(cams)
             mk = (len(mvs["views"]), tuple(mvs["img_res"]), bool(mvs.get("inverse_depth", False)),
                   tuple(view_key(v) for v in mvs["views"]))
-        return (R, getattr(self, "_n_valid", R), tuple(self._groups_for(R)), fast, mk, str(model_input["uv"].device), self.graph)
+        return (R, getattr(self, "_n_valid", R), tuple(self._groups_for(R)), fast, mk, str(self.fp.flat.device), self.graph)
 
     def _upload(self, cs, model_input, ground_truth, mvs):
-        """Host -> static tensors of a captured step, on the current stream (ordered before the graph launch)."""
+        """Host -> static tensors of a captured step, on the current stream (ordered before the replay).  Everything
+        except the random draws -- pixels, camera, target colours, the two annealing scalars, the rendered-view index --
+        has a fixed place in ONE static device buffer and travels in one transfer from a 4-deep ring of pinned staging
+        buffers (the host waits for the transfer made FOUR steps ago, i.e. never in practice: with one staging buffer it
+        waited for the previous step's, which sits behind that step's kernels -- host and GPU took turns).  An input that
+        already lives on the device is copied into its place by a device copy behind the transfer."""
         st = cs.static
-        dev = model_input["uv"].device
-        for k in ("uv", "intrinsics", "pose"):
-            src = model_input[k]
-            if k not in st:
-                st[k] = torch.empty(src.shape, dtype=torch.float32, device=dev)
-            st[k].copy_(src, non_blocking=True)
+        dev = self.fp.flat.device
         annealed, anneal_sparse = self.loss.anneal_state()
         target = ground_truth["rgb_smooth"] if annealed else ground_truth["rgb"]
-        if "target" not in st:
-            st["target"] = torch.empty(target.reshape(-1, 3).shape, dtype=torch.float32, device=dev)
-        st["target"].copy_(target.reshape(-1, 3), non_blocking=True)
-        if "scalars" not in st:
-            st["scalars"] = torch.zeros(4, dtype=torch.float32).pin_memory()
-            st["anneal"] = torch.zeros(2, dtype=torch.float32, device=dev)
-            st["same_view"] = torch.zeros(1, dtype=torch.int32, device=dev)
-            st["same_view_host"] = torch.zeros(1, dtype=torch.int32).pin_memory()
+        origin = {k: model_input[k] for k in ("uv", "intrinsics", "pose")}
+        origin["target"] = target
+        pieces = [(k, model_input[k]) for k in ("uv", "intrinsics", "pose")] + [("target", target.reshape(-1, 3))]
+        if "_all" not in st:
+            off = 4                                          # words 0..1: annealing state, word 2: rendered-view index (int32)
+            st["_layout"] = {}
+            for k, src in pieces:
+                st["_layout"][k] = (off, tuple(src.shape))
+                off += (src.numel() + 3) // 4 * 4            # 16-byte aligned pieces
+            st["_all"] = torch.zeros(off, dtype=torch.float32, device=dev)
+            st["_ring"] = [dict(pin=torch.zeros(off, dtype=torch.float32).pin_memory(), ev=None) for _ in range(4)]
+            st["_i"] = 0
+            for k, (o, shape) in st["_layout"].items():
+                n = 1
+                for d in shape:
+                    n *= d
+                st[k] = st["_all"][o:o + n].view(shape)
+            st["anneal"] = st["_all"][0:2]
+            st["same_view"] = st["_all"][2:3].view(torch.int32)
             st["rng"] = {}
-        st["scalars"][0] = 1.0 if annealed else 0.0
-        st["scalars"][1] = float(anneal_sparse)
-        st["anneal"].copy_(st["scalars"][:2], non_blocking=True)
-        st["same_view_host"][0] = int(mvs["same_view"]) if mvs is not None else -1
-        st["same_view"].copy_(st["same_view_host"], non_blocking=True)
+        slot = st["_ring"][st["_i"] % 4]
+        st["_i"] += 1
+        if slot["ev"] is not None:
+            slot["ev"].synchronize()
+        pin = slot["pin"]
+        pin[0] = 1.0 if annealed else 0.0
+        pin[1] = float(anneal_sparse)
+        pin[2:3].view(torch.int32)[0] = int(mvs["same_view"]) if mvs is not None else -1
+        on_device, host = [], False
+        seen = st.setdefault("_seen", {})
+        for k, src in pieces:
+            o, shape = st["_layout"][k]
+            if tuple(src.shape) != shape:
+                raise ValueError(f"captured step: input {k} changed shape {shape} -> {tuple(src.shape)}")
+            if src.is_cuda:
+                # a device tensor the caller hands over unchanged step after step is in place: the SAME tensor object (kept
+                # referenced here, so its storage cannot have been handed to another tensor) at the same version
+                tag = (origin[k], origin[k]._version)
+                old = seen.get(k)
+                if old is None or old[0] is not tag[0] or old[1] != tag[1]:
+                    on_device.append((k, src, tag))
+            else:
+                pin[o:o + src.numel()].copy_(src.reshape(-1))
+                host = True
+                seen.pop(k, None)
+        head = (float(pin[0]), float(pin[1]), int(pin[2:3].view(torch.int32)[0]))
+        if host:
+            # (pieces that live on the device keep their place in the static buffer: the transfer writes their region of the
+            # staging buffer -- stale -- over them, so they are copied again behind it)
+            if any(src.is_cuda for _, src in pieces):
+                on_device = [(k, src, (origin[k], origin[k]._version)) for k, src in pieces if src.is_cuda]
+            st["_all"].copy_(pin, non_blocking=True)
+        elif st.get("_head") != head:
+            st["_all"][:4].copy_(pin[:4], non_blocking=True)      # the three scalars only
+        if host or st.get("_head") != head:
+            slot["ev"] = torch.cuda.Event()
+            slot["ev"].record()
+            st["_head"] = head
+        for k, src, tag in on_device:
+            st[k].copy_(src, non_blocking=True)
+            seen[k] = tag
         n_valid, n_pad = getattr(self, "_n_valid", model_input["uv"].shape[1]), model_input["uv"].shape[1]
-        if n_valid < n_pad:
-            from volsdf.model.network import pad_rng
-            drawn = self.model.draw_train_rng(n_valid, dev)
-            for k, v in pad_rng(drawn, n_pad).items():
+        m = self.model
+        sharded = self.world > 1 and self.shard_draws
+        if sharded or n_valid < n_pad:
+            # (as the eager step: a data-parallel rank draws for the whole batch and keeps its rays' rows; a padded batch
+            # consumes the random stream of the caller's rays)
+            if sharded:
+                drawn = m.slice_rng(m.draw_train_rng(n_valid * self.world, dev), self.rank * n_valid, (self.rank + 1) * n_valid)
+            else:
+                drawn = m.draw_train_rng(n_valid, dev)
+            if n_valid < n_pad:
+                from volsdf.model.network import pad_rng
+                drawn = pad_rng(drawn, n_pad)
+            for k, v in drawn.items():
+                if k.startswith("_"):
+                    continue
                 if k not in st["rng"]:
                     st["rng"][k] = torch.empty_like(v)
                 st["rng"][k].copy_(v, non_blocking=True)
         else:
-            self.model.draw_train_rng(n_pad, dev, out=st["rng"])
+            m.draw_train_rng(n_pad, dev, out=st["rng"])
 
     def _step_captured(self, model_input, ground_truth, mvs, fast):
         """-> results of the step (replayed from its graph), or None when this call has to run eagerly: the first step of
@@ -689,29 +818,45 @@ class TrainStep:
         if cs.calls == 1:
             return None
         m = self.model
-        # the pinned staging scalars are re-written by the host every step: wait until last step's uploads have left them
-        ev = getattr(cs, "uploaded", None)
-        if ev is not None:
-            ev.synchronize()
         self._upload(cs, model_input, ground_truth, mvs)
         self._draws_done()
-        cs.uploaded = torch.cuda.Event(); cs.uploaded.record()
         if cs.graph is None:
             st = cs.static
-            cs.scratch = _Scratch(model_input["uv"].device, self.is_bg)
+            cs.scratch = _Scratch(self.fp.flat.device, self.is_bg)
             inp = dict(model_input)
             inp.update(uv=st["uv"], intrinsics=st["intrinsics"], pose=st["pose"])
             gt = {"rgb": st["target"], "rgb_smooth": st["target"]}
             dyn = dict(same_view=st["same_view"], anneal=st["anneal"])
+            # one eager pass over the capture's own scratch first: what a step allocates once and keeps (the backward's blocks,
+            # zero-initialised: ~1 GB per 256 rays) must exist BEFORE the recording -- allocated inside it, the zero fills would
+            # be recorded as launches and repeated by every replay (that, not the replay mechanism, was what made the captured
+            # step of round 3 slower than the eager one)
+            self._device_step(cs.scratch, inp, gt, mvs, fast, st["rng"], dyn, serial=self.graph == "linear")
             m.invalidate_packed()                        # the capture must contain the weight packing
-            graph = torch.cuda.CUDAGraph()
+            plan_mode = self.graph in ("plan", "auto")
+            # (keep_graph: the capture stays a hipGraph_t that svs_plan_build can read; it is never instantiated)
+            graph = torch.cuda.CUDAGraph(keep_graph=True) if plan_mode else torch.cuda.CUDAGraph()
             if self._graph_pool is None:
                 self._graph_pool = torch.cuda.graph_pool_handle()
-            with torch.cuda.graph(graph, pool=self._graph_pool):
+            # (thread_local: a helper thread that prepares the next batch meanwhile -- VolOpt.run -- does not disturb the capture)
+            with torch.cuda.graph(graph, pool=self._graph_pool, capture_error_mode="thread_local"):
                 cs.result, cs.hold = self._device_step(cs.scratch, inp, gt, mvs, fast, st["rng"], dyn,
                                                        serial=self.graph == "linear")
             cs.graph = graph
-        cs.graph.replay()
+            if plan_mode:
+                # the side chains run on streams of the capture's own scratch (torch pool streams, as in the eager schedule)
+                sc = cs.scratch
+                side = ([sc.prep] + list(sc.sides) + [b._side for b in sc.bwd] + list(getattr(m, "_bg_streams", {}).values())
+                        + list(sc._bg_streams.values()))
+                cs.plan = _LaunchPlan(graph, [x for x in side if x is not None])
+                if os.environ.get("SVS_PLAN_DEBUG") == "1":
+                    import sys
+                    print(cs.plan.info, file=sys.stderr)
+                    print(cs.plan.describe(), file=sys.stderr)
+        if cs.plan is not None:
+            cs.plan.run()
+        else:
+            cs.graph.replay()
         return cs.result
 
 

@@ -245,11 +245,9 @@ class VolSDFNetwork(nn.Module):
         if self.training:
             # eikonal samples (network.py:258-266) ride in the same launch as the ray samples; they
             # differentiate the raw network output (ImplicitNetwork.gradient), the ray samples the clamped sdf
-            # [uniform points in the bounding sphere ; one point per ray at the sampler's extra depth]: two launches
-            # (copy, addcmul) straight into the launch's point list
-            eikonal_points = torch.empty(2 * num_pixels, 3, device=ray_dirs.device)
-            eikonal_points[:num_pixels].copy_(rng["eik_points"])
-            torch.addcmul(cam_loc.view(1, 3).expand(num_pixels, 3), z_samples_eik, ray_dirs, out=eikonal_points[num_pixels:])
+            # [uniform points in the bounding sphere ; one point per ray at the sampler's extra depth]: one launch straight
+            # into the launch's point list
+            eikonal_points = ops.eikonal_points(rng["eik_points"], cam_loc, z_samples_eik, ray_dirs)
         src = ops.PointSource(points=eikonal_points, cam=cam_loc, dirs=ray_dirs, z=z_vals)
         sdf, gradients, feat_tiles, _, _ = ops.sdf_outputs(pk, src, net.sdf_bounding_sphere, net.sphere_scale,
                                                            clamp_n=n_main, keep=keep)

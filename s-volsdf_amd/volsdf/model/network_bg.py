@@ -188,8 +188,7 @@ class VolSDFNetworkBG(nn.Module):
         n_main = R * S
         eikonal_points = None
         if self.training:
-            eik_near = cam_loc.view(1, 3) + z_samples_eik * ray_dirs
-            eikonal_points = torch.cat([rng["eik_points"], eik_near], 0)
+            eikonal_points = ops.eikonal_points(rng["eik_points"], cam_loc, z_samples_eik, ray_dirs)
         view_dirs = ray_dirs
         if not self.training:
             # nearest training view's directions (network_bg.py:69-74)
@@ -207,7 +206,7 @@ class VolSDFNetworkBG(nn.Module):
         bg_join = None
         cur = torch.cuda.current_stream()
         if (self.training and keep is not None and os.environ.get("SVS_BG_SIDE", "1") != "0"
-                and not torch.cuda.is_current_stream_capturing()):
+                and (not torch.cuda.is_current_stream_capturing() or getattr(self, "_side_ok_in_capture", False))):
             key = cur.cuda_stream
             bs = self._bg_streams.get(key)
             if bs is None:

@@ -420,13 +420,17 @@ class VolOpt():
     def train_step(self, batch, use_mvs=False, _resample=True):
         indices, model_input, ground_truth = batch
         model_input, ground_truth = self._shard_batch(model_input, ground_truth)
-        model_input, gt = self._upload_batch(model_input, ground_truth)
+        if self.step_fn.takes_host_inputs(model_input["uv"].shape[1]):
+            # (a planned step stages its inputs itself: the loader's host tensors go in as they are)
+            model_input, gt = dict(model_input), {k: ground_truth[k] for k in ("rgb", "rgb_smooth")}
+        else:
+            model_input, gt = self._upload_batch(model_input, ground_truth)
         model_input['iter_step'] = self.iter_step
         if use_mvs and bool(self.hparams.inverse_depth) and self.stg >= 1:
             raise NotImplementedError                                      # vsdf.py:429-430
         loss_output, model_outputs = self.step_fn(model_input, gt, mvs=self._mvs_views(indices) if use_mvs else None, fast=1)
         if self.total_step % 50 == 0:
-            mse = torch.mean((model_outputs['rgb_values'] - gt['rgb'].reshape(-1, 3)) ** 2)
+            mse = torch.mean((model_outputs['rgb_values'] - gt['rgb'].reshape(-1, 3).to(model_outputs['rgb_values'].device)) ** 2)
             if self.world > 1:
                 # a rank's loss terms are its rays' share of the batch means (trainer.loss_norm): their sum over the ranks
                 # is the batch's loss; the mse is a mean per rank

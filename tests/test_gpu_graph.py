@@ -41,7 +41,7 @@ def _fresh(dev, kind):
     return m.to(dev), loss
 
 
-@pytest.mark.parametrize("kind,mode", [("dtu", True), ("dtu", "linear"), ("bmvs", True)])
+@pytest.mark.parametrize("kind,mode", [("dtu", True), ("dtu", "linear"), ("bmvs", True), ("dtu", "plan"), ("bmvs", "plan")])
 def test_captured_step_equals_eager(dev, kind, mode):
     from svs_hip.trainer import TrainStep
     R, n_steps = 128, 6
@@ -69,6 +69,16 @@ def test_captured_step_equals_eager(dev, kind, mode):
                         ts.fp.grad.clone()))
         if graph:
             assert len(ts._captured) == 1 and next(iter(ts._captured.values())).graph is not None
+            plan = next(iter(ts._captured.values())).plan
+            assert (plan is not None) == (graph == "plan")
+            if plan is not None:
+                # the launch plan (csrc/svs_plan.hip): every launch of the step is a kernel node, the two ray groups and the
+                # side branches are chains on a handful of streams
+                info = plan.info
+                assert info["kernels"] == info["nodes"] >= 50 and info["copies"] == info["memsets"] == 0, info
+                assert 3 <= info["streams"] <= 8 and info["events"] >= 4, info
+                text = plan.describe().splitlines()
+                assert len(text) == info["nodes"] and sum("sdf_full_h2_kernel" in t for t in text) == 2, text[:5]
         else:
             assert not ts._captured
         assert ts.opt.step_count == n_steps and loss.iter_step == n_steps
@@ -102,6 +112,75 @@ def test_captured_step_equals_eager(dev, kind, mode):
     d = (pa - pb).abs()
     # six Adam steps: entries whose gradient is numerically zero take +-lr per step with a noise-determined sign
     assert float(d.max()) <= 4e-3 and float((d > 1e-5).float().mean()) < 5e-2
+
+
+def test_launch_plan_takes_host_inputs(dev):
+    """A planned step fed with HOST tensors (what the DataLoader hands VolOpt.train_step) == the same step fed with device
+    tensors: the host pieces travel through the ring of pinned staging buffers in one transfer."""
+    from svs_hip.trainer import TrainStep
+    R = 64
+    rs = np.random.default_rng(9)
+    K, pose = synth.make_camera()
+    host = [({"intrinsics": torch.from_numpy(K)[None], "uv": torch.from_numpy(synth.make_uv(R, seed=20 + j))[None],
+              "pose": torch.from_numpy(pose)[None]},
+             {"rgb": torch.from_numpy(rs.uniform(0, 1, (1, R, 3)).astype(F32)),
+              "rgb_smooth": torch.from_numpy(rs.uniform(0, 1, (1, R, 3)).astype(F32))}) for j in range(3)]
+    outs = {}
+    for where in ("device", "host"):
+        m, loss = _fresh(dev, "dtu")
+        ts = TrainStep(m, loss, graph="plan")
+        torch.manual_seed(3)
+        rec = []
+        for step in range(6):
+            inp, gt = host[step % 3]
+            if where == "device":
+                inp, gt = {k: v.to(dev) for k, v in inp.items()}, {k: v.to(dev) for k, v in gt.items()}
+            lo, out = ts(inp, gt)
+            rec.append((float(lo["loss"]), out["rgb_values"].clone()))
+        assert next(iter(ts._captured.values())).plan is not None
+        outs[where] = rec
+    for step, ((la, ra), (lb, rb)) in enumerate(zip(outs["device"], outs["host"])):
+        if step == 0:
+            assert torch.equal(ra, rb) and la == lb
+        else:
+            assert float((ra - rb).abs().max()) <= 1e-3 and la == pytest.approx(lb, rel=5e-3), step
+
+
+def test_launch_plan_of_a_foreign_capture(dev):
+    """svs_plan_build / svs_plan_run on a capture that is not the train step: two kernels on the origin stream, a branch
+    on a forked stream that joins again; replays follow the inputs.  A capture with a device-to-device copy is refused
+    (the runtime does not return the parameters of a captured 1-D copy node)."""
+    from svs_hip.lib import SvsError
+    from svs_hip.trainer import _LaunchPlan
+    a = torch.arange(1 << 16, device=dev, dtype=torch.float32)
+    b, c, d = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph(keep_graph=True)
+    with torch.cuda.graph(g):
+        cur = torch.cuda.current_stream()
+        torch.mul(a, 2.0, out=b)
+        fork = torch.cuda.Event(); fork.record(cur)
+        with torch.cuda.stream(side):
+            side.wait_event(fork)
+            torch.add(b, 1.0, out=c)
+            join = torch.cuda.Event(); join.record(side)
+        torch.mul(b, b, out=d)
+        cur.wait_event(join)
+        torch.add(d, c, out=d)
+    plan = _LaunchPlan(g)
+    assert plan.info["kernels"] == 4 and plan.info["streams"] == 2 and plan.info["events"] == 2, plan.info
+    for scale in (1.0, 3.0):
+        a.copy_(torch.arange(1 << 16, device=dev, dtype=torch.float32) * scale)
+        plan.run()
+        torch.cuda.synchronize()
+        x = torch.arange(1 << 16, dtype=torch.float32) * scale       # the same float32 operations on the host
+        assert torch.equal(d.cpu(), (x * 2.0) * (x * 2.0) + (x * 2.0 + 1.0))
+    g2 = torch.cuda.CUDAGraph(keep_graph=True)
+    with torch.cuda.graph(g2):
+        b.copy_(a)
+    with pytest.raises(SvsError, match="copy node"):
+        _LaunchPlan(g2)
 
 
 def test_adam_device_step_counter(dev):
