@@ -523,6 +523,14 @@ int svs_selftest_cumsum(const float* x, float* y, float* total, int rows, int m,
  * ray_sampler.py:130-146,225-227, volsdf/model/density.py:26).  1 <= m <= 16000. */
 int svs_selftest_rowsum(const float* x, float* total, int rows, int m, void* hip_stream);
 
+/* ---- host: the training pixels of a step (volsdf/datasets/scene_dataset.py:275-279 `change_sampling_idx`, called by
+ * volsdf/vsdf.py:234 after every step) ------------------------------------------------------------------------------
+ * out[0..k) = torch.randperm(n)[:k] for the CPU generator whose serialised state (torch.get_rng_state(): 5056 HOST bytes)
+ * is rng_state, which is advanced exactly as torch.randperm(n) advances it (n - 1 draws of at::mt19937): the first k
+ * iterations of ATen's forward Fisher-Yates shuffle, the remaining draws skipped without being formed -- O(k + n / 624)
+ * instead of a shuffle of all n pixels.  HOST pointers; n < 2^32 / 20 (ATen's small-n algorithm). */
+int svs_randperm_prefix(unsigned char* rng_state, size_t state_bytes, long long n, long long k, long long* out);
+
 /* ---- launch plans: the device part of a step enqueued by one call --------------------------------------------
  * The launch sequence of VolOpt.train_step (volsdf/vsdf.py:196-235: forward, prior lookup, loss, backward) contains no host
  * decision; the host records it once per configuration with a stream capture and hands the captured hipGraph_t to

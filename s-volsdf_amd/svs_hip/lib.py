@@ -4,7 +4,7 @@ The product path has NO CPU fallback: if the library is missing or a call fails,
 """
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SVS_LIB_PATH: another build of the same library (A/B timing of kernel variants on one box, tools/ab_variant.sh)
@@ -145,6 +145,7 @@ SIGNATURES = {
 }
 
 SIGNATURES.update({
+    "svs_randperm_prefix": (c_int, [_P, c_size_t, c_longlong, c_longlong, _P]),
     "svs_eikonal_points": (c_int, [_P, _P, _P, _P, c_int, _P, _P]),
     "svs_plan_build": (c_int, [_P, _PP, c_int, _PP]),
     "svs_plan_run": (c_int, [_P, _P]),

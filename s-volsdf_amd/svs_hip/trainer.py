@@ -611,6 +611,8 @@ class TrainStep:
         main.wait_event(rgb_packed)
         fork = torch.cuda.Event(); fork.record(main)
         results, joins, holds = [], [], []
+        # d loss / d beta of a group: one group writes it straight into the flat gradient, several into slots that are summed
+        beta_out = (lambda gi: self.beta_grad.view(1)) if len(groups) == 1 else (lambda gi: sc.d_beta[gi:gi + 1])
         for gi, (lo, hi) in enumerate(groups):
             stream = main if gi == 0 else sc.sides[gi - 1]
             with torch.cuda.stream(stream):
@@ -647,7 +649,7 @@ class TrainStep:
                         m.density.beta_min_value, keep["z_bg"], keep["bg_out0"], keep["bg_rgb"], g["rgb_values"],
                         g["weights"], None, d_depth_values_all=g["depth_values"], bg_depth=keep["bg_depth"],
                         d_sdf_out=sc.bwd[gi].sdf_grad_out(keep["src"].n, keep["rgb_flat"].shape[0]),
-                        d_beta_out=sc.d_beta[gi:gi + 1])
+                        d_beta_out=beta_out(gi))
                     # The background networks' backward (radiance backward, pass B, weight gradients: three launches that
                     # depend on compositing's backward only) runs BESIDE the fg backward on a stream of its own -- at 256
                     # rays per GPU (config 4 over 8 GPUs) its 64 workgroups and the fg sweeps' 200 fit the chip together.
@@ -669,9 +671,9 @@ class TrainStep:
                         keep["z_vals"], keep["sdf"], keep["rgb_flat"], keep["depth_scale"], m.density.beta,
                         m.density.beta_min_value, g["rgb_values"], gw, g["depth_values"],
                         d_sdf_out=sc.bwd[gi].sdf_grad_out(keep["src"].n, keep["rgb_flat"].shape[0]),
-                        d_beta_out=sc.d_beta[gi:gi + 1])
-                if d_beta.data_ptr() != sc.d_beta[gi:gi + 1].data_ptr():
-                    sc.d_beta[gi:gi + 1].copy_(d_beta)
+                        d_beta_out=beta_out(gi))
+                if d_beta.data_ptr() != beta_out(gi).data_ptr():
+                    beta_out(gi).copy_(d_beta)
                 joins.append(sc.bwd[gi].accumulate(keep, d_rgb, d_sdf, g["grad_theta"], wait=False,
                                                    side=not serial and not (gi and _SMALL_GROUP_INLINE)))
                 results.append((lo_out, out))
@@ -683,7 +685,10 @@ class TrainStep:
         finalize(sc.accum, sdf_p, rgb_p, out=self.grad_out)
         if self.is_bg:
             sc.bg_bwd.finalize(bg_sdf_wb, bg_rgb_wb, out=self.bg_grad_out)
-        torch.sum(sc.d_beta[:len(groups)], dim=0, keepdim=True, out=self.beta_grad.view(1))
+        if len(groups) == 1:
+            pass                                         # (written in place: d_beta_out above)
+        else:
+            torch.sum(sc.d_beta[:len(groups)], dim=0, keepdim=True, out=self.beta_grad.view(1))
         return results, holds
 
     # ---- captured steps -----------------------------------------------------------------------------------------------------
@@ -831,7 +836,15 @@ class TrainStep:
             # zero-initialised: ~1 GB per 256 rays) must exist BEFORE the recording -- allocated inside it, the zero fills would
             # be recorded as launches and repeated by every replay (that, not the replay mechanism, was what made the captured
             # step of round 3 slower than the eager one)
-            self._device_step(cs.scratch, inp, gt, mvs, fast, st["rng"], dyn, serial=self.graph == "linear")
+            # -- on the stream the recording will run on: the model keeps per-stream workspaces (the sampler's, the side
+            # streams of the background networks), which would otherwise be created, and zero-filled, inside the recording
+            if getattr(self, "_capture_stream", None) is None:
+                self._capture_stream = torch.cuda.Stream(device=self.fp.flat.device)
+            cap = self._capture_stream
+            cap.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cap):
+                self._device_step(cs.scratch, inp, gt, mvs, fast, st["rng"], dyn, serial=self.graph == "linear")
+            torch.cuda.current_stream().wait_stream(cap)
             m.invalidate_packed()                        # the capture must contain the weight packing
             plan_mode = self.graph in ("plan", "auto")
             # (keep_graph: the capture stays a hipGraph_t that svs_plan_build can read; it is never instantiated)
@@ -839,7 +852,7 @@ class TrainStep:
             if self._graph_pool is None:
                 self._graph_pool = torch.cuda.graph_pool_handle()
             # (thread_local: a helper thread that prepares the next batch meanwhile -- VolOpt.run -- does not disturb the capture)
-            with torch.cuda.graph(graph, pool=self._graph_pool, capture_error_mode="thread_local"):
+            with torch.cuda.graph(graph, pool=self._graph_pool, stream=cap, capture_error_mode="thread_local"):
                 cs.result, cs.hold = self._device_step(cs.scratch, inp, gt, mvs, fast, st["rng"], dyn,
                                                        serial=self.graph == "linear")
             cs.graph = graph
