@@ -359,6 +359,10 @@ def main():
             line["exact_f32_ms_per_step"] = other_precision_step_ms("f32", make_model, make_step, n=10, warm=4)
         if train and world == 1 and args.model == "dtu" and not args.no_volopt_loop:
             line["volopt_run"] = volopt_loop(args.rays)
+            if args.rays != 256:
+                # config 4's per-GPU share when its 2048-ray batch is sharded over 8 GPUs: the loop at 256 rays (launch plans;
+                # the host side decides here)
+                line["volopt_run_256_rays"] = volopt_loop(256, variants=("default",))
         if world == 1 and train and args.model == "dtu" and not args.no_extras:
             # the other configurations of BASELINE.json, as extras measured after the timed region (same process, same box):
             # configs[2] = the CasMVSNet cost volume (tools/bench_costvol.py), and whole-image eval rendering, the
@@ -382,10 +386,10 @@ def main():
         dist.destroy_process_group()
 
 
-def volopt_loop(rays, warm=60, steps=200):
+def volopt_loop(rays, warm=60, steps=200, variants=("default", "sequential", "device_batches")):
     """What a runner.py user gets: `VolOpt.run` (the reference's optimisation loop, volsdf/vsdf.py:322-367) end to end on a
     synthetic in-memory scene with the SceneDataset interface at 576 x 768 (tests/synthetic_scene.py: full pixel grid per
-    item, torch.randperm over all pixels on the CPU, one torch thread, as the reference's dataset does), `rays` pixels per
+    item, the reference's `change_sampling_idx`, one torch thread, as the reference's dataset does), `rays` pixels per
     step, no MVS prior, previews and checkpoints off -- ms per step including the DataLoader, for (a) the default loop
     (next batch prepared by a helper thread while the step is enqueued: same batches, same random streams), (b) the
     strictly sequential loop (`overlap_loader=False`), (c) the opt-in device-side batch source.  Outside the timed
@@ -399,6 +403,8 @@ def volopt_loop(rays, warm=60, steps=200):
     res = {}
     try:
         for name, kw in (("default", {}), ("sequential", dict(overlap_loader=False)), ("device_batches", dict(device_batches=True))):
+            if name not in variants:
+                continue
             a = tv.make_args()
             a["vol"]["dataset"]["img_res"] = [576, 768]
             a["vol"]["train"].update(num_pixels=rays, render_freq=10 ** 9, checkpoint_freq=10 ** 9)
@@ -417,8 +423,9 @@ def volopt_loop(rays, warm=60, steps=200):
             del v
     finally:
         os.chdir(cwd)
-    res["note"] = ("VolOpt.run end to end incl. the DataLoader over a SceneDataset-style dataset (host work per step: randperm "
-                   "over 442 368 pixels + the full pixel grid); `default` is what runner.py gets")
+    res["note"] = ("VolOpt.run end to end incl. the DataLoader over a SceneDataset-style dataset (host work per step: the "
+                   "step's pixel indices -- torch.randperm(442 368)[:rays], drawn as its first `rays` shuffle iterations by "
+                   "svs_randperm_prefix -- and the dataset's full pixel grid); `default` is what runner.py gets")
     return res
 
 

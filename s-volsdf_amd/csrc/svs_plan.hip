@@ -111,7 +111,7 @@ static int build(hipGraph_t graph, const hipStream_t* given, int n_given, Plan**
   std::vector<int> depth(n, 0), height(n, 0), wanted(n, -1), heir(n, -1);
   // (second criterion where two ways have the same number of nodes: the threads launched along them -- the fg sweep
   // against the background network's, which join at compositing after two launches each)
-  std::vector<double> threads(n, 0.0), below(n, 0.0);
+  std::vector<double> threads(n, 0.0), below(n, 0.0), above(n, 0.0);
   for (size_t i = 0; i < n; ++i) {
     hipGraphNodeType t;
     hipKernelNodeParams k;
@@ -122,8 +122,13 @@ static int build(hipGraph_t graph, const hipStream_t* given, int n_given, Plan**
   for (size_t q = 0; q < n; ++q) {
     const int i = order[q];
     for (int pr : preds[i]) {
+      const int w = wanted[i];
+      const double via = above[pr] + threads[pr];
+      if (w < 0 || depth[pr] > depth[w] || (depth[pr] == depth[w] && (via > above[i] || (via == above[i] && pr < w)))) {
+        wanted[i] = pr;
+        above[i] = via;
+      }
       depth[i] = std::max(depth[i], depth[pr] + 1);
-      if (wanted[i] < 0 || depth[pr] > depth[wanted[i]] || (depth[pr] == depth[wanted[i]] && pr < wanted[i])) wanted[i] = pr;
     }
   }
   for (size_t q = n; q-- > 0;) {
@@ -198,8 +203,9 @@ static int build(hipGraph_t graph, const hipStream_t* given, int n_given, Plan**
       // a branch that forks off: a side stream whose last node this one depends on anyway is free for it (no ordering is
       // added) -- the radiance weight gradients run where the weight packing ran -- so the step gets by with few streams:
       // the runtime maps streams onto 4 hardware queues, and two busy chains that share a queue run one after the other
+      // (not one whose last node still waits for its heir)
       for (size_t t = 1; t < tail.size() && s < 0; ++t)
-        if (tail[t] >= 0 && depends_on(i, tail[t])) s = (int)t;
+        if (tail[t] >= 0 && depends_on(i, tail[t]) && !(heir[tail[t]] >= 0 && stream_of[heir[tail[t]]] < 0)) s = (int)t;
     }
     if (s < 0) {
       if (tail.empty() || (int)tail.size() < kMaxStreams) {

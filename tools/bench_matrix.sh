@@ -20,6 +20,13 @@ run rays512 --rays 512
 run graph --graph on
 run graph256 --graph on --rays 256
 run bmvs256 --model bmvs --rays 256
+run bmvs128 --model bmvs --rays 128
+# launch mode: the default is `auto` (launch plans below 328 rays, eager launches above)
+run eager256 --graph off --rays 256
+run eager_bmvs256 --graph off --model bmvs --rays 256
+run eager_bmvs128 --graph off --model bmvs --rays 128
+run plan1024 --graph plan
+run plan1024_1grp --graph plan --groups none
 SVS_MLP_PRECISION=f32 run f32
 SVS_MLP_PRECISION=f16x2_half run half
 SVS_MLP_PRECISION=f16x2_half run half256 --rays 256
