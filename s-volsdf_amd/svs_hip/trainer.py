@@ -357,7 +357,16 @@ class TrainStep:
         (one transfer from its ring of pinned buffers), so a caller holding HOST tensors hands them over as they are."""
         if not self.graph:
             return False
-        return self.graph != "auto" or len(self.split_rays(R, self.samples_per_ray())) == 1
+        return self.graph != "auto" or self._auto_plans(R)
+
+    def _auto_plans(self, R):
+        """graph == "auto": launch plans where the step is short enough for the host to matter -- batches of less than two
+        rounds of 256 workgroups x 128 points (< 656 rays of the DTU model; config 4 over 8 GPUs runs 256 per GPU).  Measured
+        (DESIGN.md section 5): the planned step is 4-15 % faster at 128 / 256 rays and keeps `VolOpt.run` at the bare step's
+        time at 512 (2.25 against 2.6-3.3 ms: the eager step's 1.5 ms of enqueueing and the DataLoader share one interpreter);
+        from 1024 rays on the device bounds the step either way and the eager launch order overlaps the two ray groups
+        1.5-2 % better."""
+        return R * (self.samples_per_ray() + 2) < 2 * 256 * 128
 
     def samples_per_ray(self):
         rs = self.model.ray_sampler
@@ -484,10 +493,7 @@ class TrainStep:
         self.check_batch(R)
         captured = bool(self.graph)
         if self.graph == "auto":
-            # launch plans where the step is short enough for the host to matter: one ray group (< 328 rays of the DTU
-            # model; config 4 over 8 GPUs runs 256 per GPU) -- larger batches are bound by the device, and their two
-            # concurrent ray groups are scheduled better by the eager launch order
-            captured = len(self.split_rays(R, self.samples_per_ray())) == 1
+            captured = self._auto_plans(R)
         if captured:
             out = self._step_captured(model_input, ground_truth, mvs, fast)
             if out is not None:
@@ -852,9 +858,19 @@ class TrainStep:
             if self._graph_pool is None:
                 self._graph_pool = torch.cuda.graph_pool_handle()
             # (thread_local: a helper thread that prepares the next batch meanwhile -- VolOpt.run -- does not disturb the capture)
-            with torch.cuda.graph(graph, pool=self._graph_pool, stream=cap, capture_error_mode="thread_local"):
-                cs.result, cs.hold = self._device_step(cs.scratch, inp, gt, mvs, fast, st["rng"], dyn,
-                                                       serial=self.graph == "linear")
+            # No cyclic garbage collection while the recording runs: a collection that finds an earlier TrainStep's
+            # capture (a graph + its memory pool) would free device memory in the middle of this one, which the runtime
+            # refuses -- from a destructor, i.e. the process aborts.  (torch.cuda.graph collects once on entry.)
+            import gc
+            gc_was_on = gc.isenabled()
+            gc.disable()
+            try:
+                with torch.cuda.graph(graph, pool=self._graph_pool, stream=cap, capture_error_mode="thread_local"):
+                    cs.result, cs.hold = self._device_step(cs.scratch, inp, gt, mvs, fast, st["rng"], dyn,
+                                                           serial=self.graph == "linear")
+            finally:
+                if gc_was_on:
+                    gc.enable()
             cs.graph = graph
             if plan_mode:
                 # the side chains run on streams of the capture's own scratch (torch pool streams, as in the eager schedule)
