@@ -4,7 +4,9 @@ float32-MFMA kernels (SVS_MLP_PRECISION=f32), same seeds, same pixel batches.  T
 beta must shrink, and the two precisions must follow the same trajectory: the end-to-end check that the gradient error of the
 fp16x2 path (run with SVS_MLP_PRECISION=f16x2_half for the one-piece mode's 2e-4 ... 8e-4) does not
 change what the optimiser does.  Prints a row every 250 steps and a
-comparison at the end.      python tools/long_run.py [steps] [dtu|bmvs] [plain|full]
+comparison at the end.      python tools/long_run.py [steps] [dtu|bmvs] [plain|full] [rays] [precision|launch]
+  launch (5th argument): instead of two precisions, compare the two ways a step is enqueued -- eager launches from Python
+        against launch plans (csrc/svs_plan.hip; what `auto` uses below 656 rays) -- at the given ray count.
   plain (default): colour + eikonal terms only, no annealing (round 3's run).
   full: the reference's whole loss (config/ours.yaml:16-21: anneal_rgb = 200, MVS prior term, sparse term) with synthetic prior
         volumes, so that the run crosses the colour annealing -- iterations 0 ... 199 train on the masked smooth target, 200+ on
@@ -27,10 +29,12 @@ from volsdf.model.loss import VolSDFLoss  # noqa: E402
 from svs_hip.trainer import TrainStep  # noqa: E402
 
 
-MODEL, MODE = "dtu", "plain"
+MODEL, MODE, RAYS = "dtu", "plain", 1024
 
 
-def run(precision, steps):
+def run(precision, steps, graph=None):
+    if precision in ("eager", "plan"):
+        graph, precision = (False if precision == "eager" else "plan"), None
     if precision:
         os.environ["SVS_MLP_PRECISION"] = precision
     else:
@@ -50,14 +54,15 @@ def run(precision, steps):
     full = MODE == "full"
     loss = VolSDFLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, rgb_weight=1.0, mvs_weight=1.0 if full else 0.0,
                       sparse_weight=1.0 if full else 0.0, anneal_rgb=200 if full else 0, gce=0.5, confi=1e-3)
-    ts = TrainStep(m, loss, groups="auto")
+    ts = TrainStep(m, loss, groups="auto", graph=graph)
+    label = {False: "eager", "plan": "plan"}.get(graph, precision or "fp16x2")
     mvs = None
     if full:
         views = synth.make_mvs_views(3)
         mvs = dict(views=[dict(K=v["K"], c2w=v["c2w"], cost=torch.from_numpy(v["cost"]).to(dev), z_mvs=torch.from_numpy(v["z_mvs"]).to(dev))
                           for v in views], same_view=0, img_res=(576, 768), inverse_depth=False)
     K, pose = synth.make_camera()
-    R, H, W = 1024, 576, 768
+    R, H, W = RAYS, 576, 768
     yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
     img = np.stack([0.5 + 0.4 * np.sin(xx / 90.0), 0.5 + 0.4 * np.cos(yy / 70.0), 0.5 + 0.3 * np.sin((xx + yy) / 120.0)], -1).astype(np.float32)
     Kd, Pd = torch.from_numpy(K)[None].to(dev), torch.from_numpy(pose)[None].to(dev)
@@ -78,13 +83,15 @@ def run(precision, steps):
         if step % 250 == 0 or step == steps - 1:
             info = ts.opt.info.cpu().numpy()
             hist.append((step, float(lo["rgb_loss"]), float(lo["eikonal_loss"]), float(info[0]), float(m.density.get_beta())))
-            print(precision or "fp16x2", hist[-1], flush=True)
+            print(label, hist[-1], flush=True)
     p = ts.fp.flat
     w = np.asarray(window)
     res = dict(finite=bool(torch.isfinite(p).all()), max_abs_param=float(p.abs().max()), rgb_last100=float(w[:, 0].mean()),
                eik_last100=float(w[:, 1].mean()), beta=float(m.density.get_beta()), dropped=float(ts.opt.info[1]),
                schedule=ts.schedule.get(R))
-    print(precision or "fp16x2", res, flush=True)
+    if graph:
+        res["planned"] = any(c.plan is not None for c in ts._captured.values())
+    print(label, res, flush=True)
     return hist, res
 
 
@@ -92,18 +99,27 @@ if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
     MODEL = sys.argv[2] if len(sys.argv) > 2 else "dtu"
     MODE = sys.argv[3] if len(sys.argv) > 3 else "plain"
+    RAYS = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
+    COMPARE = sys.argv[5] if len(sys.argv) > 5 else "precision"
     OTHER = "f32" if MODEL == "dtu" else "f16x2_half"
-    print(f"model {MODEL}, loss {MODE}, {n} steps: default precision vs {OTHER}")
+    BASE = None
+    if COMPARE == "launch":
+        BASE, OTHER = "eager", "plan"
+    print(f"model {MODEL}, loss {MODE}, {n} steps of {RAYS} rays: {BASE or 'default precision'} vs {OTHER}")
     # two runs per precision: float atomics make any two runs differ in the last bits, and 2000 Adam steps amplify that --
     # the spread between two runs of the SAME precision is the yardstick for the difference between the precisions
-    runs = {prec: [run(prec, n) for _ in range(2)] for prec in (None, OTHER)}
+    runs = {prec: [run(prec, n) for _ in range(2)] for prec in (BASE, OTHER)}
+    runs[None] = runs[BASE]
+    if COMPARE == "launch":
+        assert all(r["planned"] for _, r in runs["plan"])
     (ha, ra), (ha2, ra2) = runs[None]
     (hb, rb), (hb2, rb2) = runs[OTHER]
-    print(f"\nstep   rgb_loss fp16x2 #1 #2 / {OTHER} #1 #2              eikonal fp16x2 #1 #2 / {OTHER} #1 #2")
+    A = BASE or "fp16x2"
+    print(f"\nstep   rgb_loss {A} #1 #2 / {OTHER} #1 #2              eikonal {A} #1 #2 / {OTHER} #1 #2")
     for a, a2, b, b2 in zip(ha, ha2, hb, hb2):
         print(f"{a[0]:5d}   {a[1]:.5f} {a2[1]:.5f} / {b[1]:.5f} {b2[1]:.5f}        {a[2]:.5f} {a2[2]:.5f} / {b[2]:.5f} {b2[2]:.5f}")
     for key in ("rgb_last100", "eik_last100", "beta"):
-        print(f"{key:12s} fp16x2 {ra[key]:.5f} {ra2[key]:.5f}   {OTHER} {rb[key]:.5f} {rb2[key]:.5f}")
+        print(f"{key:12s} {A} {ra[key]:.5f} {ra2[key]:.5f}   {OTHER} {rb[key]:.5f} {rb2[key]:.5f}")
     for _, r in runs[None] + runs[OTHER]:
         assert r["finite"] and r["dropped"] == 0.0
     first = 1 if MODE == "full" else 0        # (full: while the colour term is annealed -- steps < 200 -- its masked form is ~0)
@@ -112,5 +128,5 @@ if __name__ == "__main__":
     for key in ("rgb_last100", "eik_last100", "beta"):
         within = max(abs(ra[key] - ra2[key]), abs(rb[key] - rb2[key]))
         across = abs(mean(key, runs[None]) - mean(key, runs[OTHER]))
-        print(f"{key}: between precisions {across:.5f}, between two runs of one precision {within:.5f}")
+        print(f"{key}: between the two {'launch modes' if COMPARE == 'launch' else 'precisions'} {across:.5f}, between two runs of one {within:.5f}")
         assert across <= max(3.0 * within, 0.15 * mean(key, runs[OTHER])), f"default-precision and {OTHER} runs differ in {key}"
