@@ -41,6 +41,11 @@ def record_off(n_points, n_blocks, block):
     return n_blocks * T * KBLOCK + block * T * KREC
 
 
+# Experiment, OFF by default: in captured sequences the prior look-up as a branch beside the fused SDF / radiance launches and
+# lin8's first-row gradient beside the SDF weight-gradient launch (51 us of small launches off a 256-ray step's critical
+# chain).  Measured with launch plans, A/B twice on one box: 1.315 / 1.311 against 1.319 / 1.311 ms (DTU model, 256 rays), 1.55
+# against 1.495 with the background model -- the branches' stream crossings and the fifth busy stream cost what they save.
+_PLAN_BRANCHES = os.environ.get("SVS_PLAN_BRANCHES", "0") == "1"
 _WGRAD_SPLIT = os.environ.get("SVS_WGRAD_SPLIT", "0")         # 0 (default) | 1 | auto (MlpBackward.accumulate: an experiment)
 
 
@@ -279,8 +284,18 @@ class MlpBackward:
         # the first row of lin8's weight gradient: a 257-vector reduction over two blocks (0.04 ms alone).  On the side stream,
         # beside the weight-gradient launch, it was starved to the length of that launch (one workgroup of the GEMM per CU
         # leaves it a quarter of the register file): it runs in front of it on this stream
-        _lib.check(L.svs_lin8_row0_grad(_ptr(hbuf), _ptr(self.ubuf), _ptr(self.sbar), n_total, prec, _ptr(acc.row0),
-                                        _stream()), "svs_lin8_row0_grad")
+        # (experiment, SVS_PLAN_BRANCHES=1: in a captured sequence on the radiance weight gradients' stream after all)
+        row0_aside = side and _PLAN_BRANCHES and torch.cuda.is_current_stream_capturing()
+        if row0_aside:
+            after_b = torch.cuda.Event(); after_b.record(main)
+            with torch.cuda.stream(side_stream):
+                side_stream.wait_event(after_b)
+                _lib.check(L.svs_lin8_row0_grad(_ptr(hbuf), _ptr(self.ubuf), _ptr(self.sbar), n_total, prec, _ptr(acc.row0),
+                                                _stream()), "svs_lin8_row0_grad")
+                join = torch.cuda.Event(); join.record(side_stream)
+        else:
+            _lib.check(L.svs_lin8_row0_grad(_ptr(hbuf), _ptr(self.ubuf), _ptr(self.sbar), n_total, prec, _ptr(acc.row0),
+                                            _stream()), "svs_lin8_row0_grad")
         ev = self.timer_events = ([torch.cuda.Event(enable_timing=True) for _ in range(2)] if self.time_wgrad else None)
         if ev:
             ev[0].record()
@@ -303,7 +318,7 @@ class MlpBackward:
         wgrad_multi(arr_s)
         if ev:
             ev[1].record()
-        if join2 is not None:
+        if join2 is not None and not row0_aside:
             join = join2                      # (recorded on the same side stream, after the radiance launch's event)
         if wait and side:
             main.wait_event(join)

@@ -95,6 +95,11 @@ def allreduce_flat_grad(flat_grad, world):
     return flat_grad
 
 
+# Experiment, OFF by default: in captured sequences the prior look-up as a branch beside the fused SDF / radiance launches and
+# lin8's first-row gradient beside the SDF weight-gradient launch (51 us of small launches off a 256-ray step's critical
+# chain).  Measured with launch plans, A/B twice on one box: 1.315 / 1.311 against 1.319 / 1.311 ms (DTU model, 256 rays), 1.55
+# against 1.495 with the background model -- the branches' stream crossings and the fifth busy stream cost what they save.
+_PLAN_BRANCHES = os.environ.get("SVS_PLAN_BRANCHES", "0") == "1"
 _SMALL_GROUP_INLINE = os.environ.get("SVS_SMALL_GROUP_INLINE", "0") == "1"     # A/B: the small ray group's radiance weight gradients in line
 
 
@@ -199,6 +204,12 @@ class _Scratch:
         self.d_beta = torch.zeros(8, device=dev)
         self.bg_bwd = BgBackward(dev) if is_bg else None
         self._bg_streams = {}
+
+    def lookup_stream(self):
+        """stream of the prior look-up when it runs as a branch of a captured sequence"""
+        if getattr(self, "_lookup", None) is None:
+            self._lookup = torch.cuda.Stream(device=self.dev)
+        return self._lookup
 
     def bg_stream(self, gi):
         """stream of ray group gi's background-network backward (runs beside the fg backward)"""
@@ -630,9 +641,27 @@ class TrainStep:
                 keep = {}
                 # (a capture tolerates the background forward's side stream only below the ORIGIN stream: the note above)
                 m._side_ok_in_capture = gi == 0 and not serial
+                # (experiment, SVS_PLAN_BRANCHES=1: the prior look-up -- it needs the sample depths only -- as a branch of a
+                # captured sequence; the model calls the hook right after its sampler)
+                looked_up = {}
+                if mvs is not None and dyn is not None and m._side_ok_in_capture and _PLAN_BRANCHES:
+                    def after_sampling(cam_loc, ray_dirs, z_vals, stream=stream):
+                        ev = torch.cuda.Event(); ev.record(stream)
+                        ls = sc.lookup_stream()
+                        with torch.cuda.stream(ls):
+                            ls.wait_event(ev)
+                            looked_up["res"] = ops.cost_lookup(mvs["views"], mvs["same_view"], mvs["img_res"], cam=cam_loc,
+                                                               dirs=ray_dirs, z=z_vals,
+                                                               inverse_depth=mvs.get("inverse_depth", False),
+                                                               same_view_dev=dyn["same_view"])
+                            looked_up["join"] = torch.cuda.Event(); looked_up["join"].record(ls)
+                    inp["_after_sampling"] = after_sampling
                 out = m._forward_impl(inp, fast, keep, rng=m.slice_rng(rng, lo, hi))
                 m._side_ok_in_capture = False
-                if mvs is not None:
+                if looked_up:
+                    stream.wait_event(looked_up["join"])
+                    out['pj'], out['pi'], _ = looked_up["res"]
+                elif mvs is not None:
                     out['pj'], out['pi'], _ = ops.cost_lookup(mvs["views"], mvs["same_view"], mvs["img_res"],
                                                               cam=keep["cam_loc"], dirs=keep["ray_dirs"], z=keep["z_vals"],
                                                               inverse_depth=mvs.get("inverse_depth", False),

@@ -241,6 +241,9 @@ class VolSDFNetwork(nn.Module):
                                                             iter_step=input.get("iter_step", 1), rng=rng)
         N_samples = z_vals.shape[1]
         n_main = num_pixels * N_samples
+        hook = input.get("_after_sampling")          # (trainer: work that depends on the sample depths only)
+        if hook is not None:
+            hook(cam_loc, ray_dirs, z_vals)
         eikonal_points = None
         if self.training:
             # eikonal samples (network.py:258-266) ride in the same launch as the ray samples; they

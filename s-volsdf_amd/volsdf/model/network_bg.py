@@ -185,6 +185,9 @@ class VolSDFNetworkBG(nn.Module):
         z_max = z_all[:, -1].contiguous()
         z_vals = z_all[:, :-1].contiguous()
         S, Nb = z_vals.shape[1], z_bg.shape[1]
+        hook = input.get("_after_sampling")          # (trainer: work that depends on the sample depths only)
+        if hook is not None:
+            hook(cam_loc, ray_dirs, z_vals)
         n_main = R * S
         eikonal_points = None
         if self.training:
