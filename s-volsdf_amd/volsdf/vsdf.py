@@ -341,14 +341,23 @@ class VolOpt():
 
     # ---- one optimisation step (vsdf.py:196-235) ----------------------------------------------------------------------------
     def _mvs_views(self, ts):
-        views, same = [], -1
+        """The prior of the current MVS stage as `ops.cost_lookup` takes it.  The per-view tensors are formed ONCE per stage
+        (get_mvs_input): a step must see the same device tensors as the step before -- a captured step is keyed on their
+        addresses (a new `.contiguous()` copy of the depth range per step would be a new configuration per step)."""
+        cache = self.__dict__.get("_mvs_view_cache")
+        key = (id(self.costs), id(self.z_mvs), tuple(int(x) for x in self.trains_i))
+        if cache is None or cache[0] != key:
+            views = []
+            for i, id_k in enumerate(self.trains_i):
+                z = self.z_mvs[i]
+                views.append(dict(K=self.train_dataset.intrinsics_all[id_k], c2w=self.train_dataset.pose_all[id_k],
+                                  cost=self.costs[i], z_near=z[0, 0].contiguous(), z_far=z[0, -1].contiguous()))
+            cache = self._mvs_view_cache = (key, views, (self.costs, self.z_mvs))      # (the dicts kept alive: id() stays theirs)
+        same = -1
         for i, id_k in enumerate(self.trains_i):
             if int(ts[0]) == int(id_k):
                 same = i
-            z = self.z_mvs[i]
-            views.append(dict(K=self.train_dataset.intrinsics_all[id_k], c2w=self.train_dataset.pose_all[id_k],
-                              cost=self.costs[i], z_near=z[0, 0].contiguous(), z_far=z[0, -1].contiguous()))
-        return dict(views=views, same_view=same, img_res=tuple(self.train_dataset.img_res),
+        return dict(views=cache[1], same_view=same, img_res=tuple(self.train_dataset.img_res),
                     inverse_depth=bool(self.hparams.inverse_depth) and self.stg == 0)
 
     def _to_device(self, key, t):
