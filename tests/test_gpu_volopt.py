@@ -78,6 +78,15 @@ def test_volopt_run_render_resume(tmp_path, monkeypatch):
     batch = next(iter(v.train_dataloader))
     lo = v.train_step(batch, use_mvs=True)
     assert float(lo["mvs_loss"]) > 0 and np.isfinite(float(lo["loss"])) and v.iter_step == 11
+    # the steps of one MVS stage are ONE configuration for the launch plans (the prior's tensors are formed once per stage):
+    # later steps -- other pixels, other views -- replay the plan made by the second one
+    n_cfg = len(v.step_fn._captured)
+    for _ in range(4):
+        v.train_dataset.change_sampling_idx(v.num_pixels)
+        lo = v.train_step(next(iter(v.train_dataloader)), use_mvs=True)
+    assert len(v.step_fn._captured) == n_cfg and np.isfinite(float(lo["loss"])) and v.iter_step == 15
+    with_prior = [c for k, c in v.step_fn._captured.items() if k[4] is not None]
+    assert len(with_prior) == 1 and with_prior[0].calls == 5 and with_prior[0].plan is not None
     # cost_mapping keeps the reference's signature and returns (pj, pi, valid)
     v.model.eval()
     inp = {k: t.cuda() for k, t in batch[1].items()}
