@@ -559,19 +559,17 @@ class TrainStep:
             ov["grad_theta"] = torch.cat([gt_full[:v], gt_full[Rg:Rg + v]], 0)
         gv = {k: t[:v] for k, t in g_gt.items()}
         lo_out = self.loss(ov, gv, norm=norm, advance=False, anneal_dev=anneal_dev)
+        # (zero-padded with torch.cat: a slice assignment of contiguous rows is a device-to-device copy, which a captured
+        # sequence cannot carry into a launch plan -- csrc/svs_plan.hip)
         g = {}
         for k, t in self.loss.last_grads.items():
             if t is None:
                 g[k] = None
             elif k == "grad_theta":
-                full = torch.zeros(gt_full.shape, dtype=t.dtype, device=t.device)
-                full[:v] = t[:v]
-                full[Rg:Rg + v] = t[v:]
-                g[k] = full
+                z = t.new_zeros((Rg - v,) + tuple(t.shape[1:]))
+                g[k] = torch.cat([t[:v], z, t[v:], z], 0)
             else:
-                full = torch.zeros((Rg,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-                full[:v] = t
-                g[k] = full
+                g[k] = torch.cat([t, t.new_zeros((Rg - v,) + tuple(t.shape[1:]))], 0)
         return lo_out, g
 
     def _finish(self, results):
@@ -906,7 +904,16 @@ class TrainStep:
                 sc = cs.scratch
                 side = ([sc.prep] + list(sc.sides) + [b._side for b in sc.bwd] + list(getattr(m, "_bg_streams", {}).values())
                         + list(sc._bg_streams.values()))
-                cs.plan = _LaunchPlan(graph, [x for x in side if x is not None])
+                try:
+                    cs.plan = _LaunchPlan(graph, [x for x in side if x is not None])
+                except _lib.SvsError as e:
+                    # "auto" never costs a run: a sequence the plan builder refuses (a node type it cannot replay) is
+                    # launched as the graph it is (hipGraphLaunch: same results, slower above ~500 rays)
+                    if self.graph != "auto":
+                        raise
+                    import warnings
+                    warnings.warn(f"launch plan refused, this configuration replays its hipGraph instead: {e}")
+                    graph.instantiate()
                 if os.environ.get("SVS_PLAN_DEBUG") == "1":
                     import sys
                     print(cs.plan.info, file=sys.stderr)

@@ -146,6 +146,74 @@ def test_launch_plan_takes_host_inputs(dev):
             assert float((ra - rb).abs().max()) <= 1e-3 and la == pytest.approx(lb, rel=5e-3), step
 
 
+@pytest.mark.parametrize("kind,R", [("dtu", 100), ("bmvs", 250)])
+def test_planned_step_with_padded_batch(dev, kind, R):
+    """A ray count that is not a multiple of the kernels' tile (padded by repeating the last ray, the padding left out of the
+    loss): the planned step == the eager step, and its outputs have the caller's ray count."""
+    from svs_hip.trainer import TrainStep
+    K, pose = synth.make_camera()
+    rs = np.random.default_rng(1)
+    inp = {"intrinsics": G(K, dev)[None], "uv": G(synth.make_uv(R, seed=3), dev)[None], "pose": G(pose, dev)[None]}
+    gt = {"rgb": G(rs.uniform(0, 1, (1, R, 3)).astype(F32), dev), "rgb_smooth": G(rs.uniform(0, 1, (1, R, 3)).astype(F32), dev)}
+    runs = {}
+    for graph in (False, "auto"):
+        m, loss = _fresh(dev, kind)
+        ts = TrainStep(m, loss, graph=graph)
+        assert ts.ray_multiple() in (16, 32) and R % ts.ray_multiple()
+        torch.manual_seed(1)
+        rec = []
+        for step in range(4):
+            lo, out = ts(inp, gt)
+            rec.append((float(lo["loss"]), out["rgb_values"].clone()))
+        assert (len(ts._captured) == 1 and next(iter(ts._captured.values())).plan is not None) if graph else not ts._captured
+        runs[graph] = rec
+    for step, ((la, ra), (lb, rb)) in enumerate(zip(runs[False], runs["auto"])):
+        assert ra.shape == rb.shape == (R, 3)
+        if step == 0:
+            assert torch.equal(ra, rb) and la == lb
+        else:
+            assert float((ra - rb).abs().max()) <= 1e-3 and la == pytest.approx(lb, rel=5e-3), step
+
+
+def test_auto_falls_back_to_the_graph(dev, monkeypatch):
+    """graph="auto" never costs a run: when the plan builder refuses a captured sequence, that configuration replays its
+    hipGraph (with a warning); graph="plan" raises."""
+    from svs_hip import trainer
+    from svs_hip.lib import SvsError
+
+    def refuse(*a, **k):
+        raise SvsError("svs_plan_build failed (test)")
+    monkeypatch.setattr(trainer, "_LaunchPlan", refuse)
+    R = 64
+    K, pose = synth.make_camera()
+    rs = np.random.default_rng(2)
+    inp = {"intrinsics": G(K, dev)[None], "uv": G(synth.make_uv(R, seed=4), dev)[None], "pose": G(pose, dev)[None]}
+    gt = {"rgb": G(rs.uniform(0, 1, (1, R, 3)).astype(F32), dev), "rgb_smooth": G(rs.uniform(0, 1, (1, R, 3)).astype(F32), dev)}
+    outs = {}
+    for graph in (False, "auto"):
+        m, loss = _fresh(dev, "dtu")
+        ts = trainer.TrainStep(m, loss, graph=graph)
+        torch.manual_seed(2)
+        if graph:
+            ts(inp, gt)
+            with pytest.warns(UserWarning, match="launch plan refused"):
+                lo, out = ts(inp, gt)
+            lo, out = ts(inp, gt)
+            cs = next(iter(ts._captured.values()))
+            assert cs.plan is None and cs.graph is not None and cs.calls == 3
+        else:
+            for _ in range(3):
+                lo, out = ts(inp, gt)
+        outs[graph] = (float(lo["loss"]), out["rgb_values"].clone())
+    assert outs[False][0] == pytest.approx(outs["auto"][0], rel=5e-3)
+    assert float((outs[False][1] - outs["auto"][1]).abs().max()) <= 1e-3
+    m, loss = _fresh(dev, "dtu")
+    ts = trainer.TrainStep(m, loss, graph="plan")
+    ts(inp, gt)
+    with pytest.raises(SvsError):
+        ts(inp, gt)
+
+
 def test_launch_plan_of_a_foreign_capture(dev):
     """svs_plan_build / svs_plan_run on a capture that is not the train step: two kernels on the origin stream, a branch
     on a forked stream that joins again; replays follow the inputs.  A capture with a device-to-device copy is refused
