@@ -99,3 +99,13 @@ def test_argument_errors_come_back_as_codes():
     rc = L.svs_mesh_sample_points(dummy, 5, None, dummy, None)
     assert rc < 0 and b"svs_mesh_sample_points" in L.svs_last_error_string()
     assert L.svs_mesh_sample_count(None, 0, None, None) == 0          # an empty mesh is not an error
+    # launch plans and the eikonal points: argument checks come before any HIP call
+    plan = ctypes.c_void_p()
+    assert L.svs_plan_build(None, None, 0, ctypes.byref(plan)) < 0 and not plan.value
+    assert L.svs_plan_build(dummy, None, 2, ctypes.byref(plan)) < 0          # two side streams announced, none given
+    assert L.svs_plan_run(None, None) < 0 and L.svs_plan_destroy(None) < 0
+    counts = (ctypes.c_int * 8)()
+    assert L.svs_plan_info(None, counts) < 0 and L.svs_plan_describe(None, None, 0) < 0
+    rc = L.svs_eikonal_points(None, dummy, dummy, dummy, 4, dummy, None)
+    assert rc < 0 and b"svs_eikonal_points" in L.svs_last_error_string()
+    assert L.svs_eikonal_points(dummy, dummy, dummy, dummy, 0, dummy, None) < 0

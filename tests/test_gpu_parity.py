@@ -107,6 +107,21 @@ def test_numeric_contract_exp(dev, golden_dir):
         assert np.array_equal(tg.cpu().numpy().view(np.uint32), orc.ref_sum(xx)[:, 0].view(np.uint32)), m
 
 
+def test_eikonal_points(dev, ops):
+    """svs_eikonal_points (network.py:258-266): [the uniform draws ; cam + z_eik * dirs], one product and one sum per
+    component like the reference's broadcast expression -- bit-equal to numpy's float32 evaluation, ragged ray counts."""
+    rs = np.random.default_rng(4)
+    for R in (1, 37, 256, 1000):
+        uni = rs.uniform(-3, 3, (R, 3)).astype(F32)
+        cam = rs.standard_normal(3).astype(F32)
+        z = rs.uniform(0.1, 5.5, (R, 1)).astype(F32)
+        dirs = rs.standard_normal((R, 3)).astype(F32)
+        dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        got = ops.eikonal_points(G(uni, dev), G(cam, dev), G(z, dev), G(dirs, dev)).cpu().numpy()
+        want = np.concatenate([uni, cam[None, :] + z * dirs], 0)
+        assert got.shape == (2 * R, 3) and np.array_equal(got, want)
+
+
 def test_rays(dev, ops, golden_dir):
     g = dict(np.load(os.path.join(golden_dir, "rays.npz")))
     for t in "ab":
