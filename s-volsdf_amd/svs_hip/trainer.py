@@ -375,8 +375,7 @@ class TrainStep:
         rounds of 256 workgroups x 128 points (< 656 rays of the DTU model; config 4 over 8 GPUs runs 256 per GPU).  Measured
         (DESIGN.md section 5): the planned step is 4-15 % faster at 128 / 256 rays and keeps `VolOpt.run` at the bare step's
         time at 512 (2.25 against 2.6-3.3 ms: the eager step's 1.5 ms of enqueueing and the DataLoader share one interpreter);
-        from 1024 rays on the device bounds the step either way and the eager launch order overlaps the two ray groups
-        1.5-2 % better."""
+        from 1024 rays on the device bounds the step either way and the eager launches are 1.5-2 % ahead."""
         return R * (self.samples_per_ray() + 2) < 2 * 256 * 128
 
     def samples_per_ray(self):
