@@ -712,7 +712,9 @@ __global__ __launch_bounds__(256) void lin8_row0_h2_kernel(const float* __restri
 int launch_lin8_row0_h2(const float* hbuf, const float* ubuf, const float* sbar, int n_points, int n_tiles_pad, float* out257,
                         bool gp, hipStream_t s) {
   const int n_tiles = (n_points + 31) / 32;
-  const int grid = n_tiles < 1024 ? n_tiles : 1024;
+  // one workgroup per CU: every workgroup ends with 257 float atomics onto the same addresses, and with a workgroup per tile
+  // (800 at 256 rays) their contention was most of the launch (26 -> 17 us at 256 rays, 44 -> 37 at 1024; 128: 17 / 45)
+  const int grid = n_tiles < 256 ? n_tiles : 256;
   if (gp) lin8_row0_h2_kernel<true><<<grid, 256, 0, s>>>(hbuf, ubuf, sbar, n_tiles, n_tiles_pad, n_points, out257);
   else lin8_row0_h2_kernel<false><<<grid, 256, 0, s>>>(hbuf, ubuf, sbar, n_tiles, n_tiles_pad, n_points, out257);
   return check_launch("svs_lin8_row0_grad");

@@ -327,20 +327,24 @@ __device__ __forceinline__ float sample3d(const float* __restrict__ vol, int D, 
   return acc;
 }
 
-__global__ void cost_lookup_kernel(LookupArgs a) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= a.P) return;
-  const int same_view = a.same_view_dev ? *a.same_view_dev : a.same_view;
-  float X, Y, Z;
-  if (a.xyz) { X = a.xyz[3 * p]; Y = a.xyz[3 * p + 1]; Z = a.xyz[3 * p + 2]; }
-  else {
-    const int r = p / a.S;
-    const float zz = a.z[p];
-    X = a.cam[0] + zz * a.dirs[3 * r]; Y = a.cam[1] + zz * a.dirs[3 * r + 1]; Z = a.cam[2] + zz * a.dirs[3 * r + 2];
-  }
-  float pj = 0.0f, pi = 0.0f;
-  bool valid = false;
-  for (int j = 0; j < a.n_views; ++j) {
+// One wave per (64 samples, view): the views of a sample are independent chains of dependent gathers (depth range: 2 x 4
+// texels, then the 8 texels of the probability volume), so they run as the waves of one workgroup instead of one after the
+// other in a thread (25 -> 12 us for 256 rays x 98 samples x 3 views); wave 0 adds them up in view order, as the reference's
+// loop does (vsdf.py:399-449).
+__global__ __launch_bounds__(64 * kMaxViews) void cost_lookup_kernel(LookupArgs a) {
+  __shared__ float cs[kMaxViews][64];
+  __shared__ unsigned char ok[kMaxViews][64];
+  const int lane = threadIdx.x & 63;
+  const int j = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // this wave's view
+  const int p = blockIdx.x * 64 + lane;
+  if (p < a.P) {
+    float X, Y, Z;
+    if (a.xyz) { X = a.xyz[3 * p]; Y = a.xyz[3 * p + 1]; Z = a.xyz[3 * p + 2]; }
+    else {
+      const int r = p / a.S;
+      const float zz = a.z[p];
+      X = a.cam[0] + zz * a.dirs[3 * r]; Y = a.cam[1] + zz * a.dirs[3 * r + 1]; Z = a.cam[2] + zz * a.dirs[3 * r + 2];
+    }
     const LookupView& v = a.v[j];
     // xyz_j = (xyz - t) @ R   (row vector times the c2w rotation = world -> camera), vsdf.py:402-403
     const float dx = X - v.c2w[3], dy = Y - v.c2w[7], dz = Z - v.c2w[11];
@@ -364,9 +368,18 @@ __global__ void cost_lookup_kernel(LookupArgs a) {
     }
     inval = (nearv < 1e-5f) || (farv < 1e-5f) || (zn > 1.01f) || (zn < -1.01f) || inval;
     if (inval) { x = -99.0f; y = -99.0f; zn = -99.0f; }
-    const float c = sample3d(v.cost, v.D, v.H, v.W, x, y, zn);
-    if (j == same_view) pi = c;
-    else { pj += c; valid = valid || !inval; }
+    cs[j][lane] = sample3d(v.cost, v.D, v.H, v.W, x, y, zn);
+    ok[j][lane] = inval ? 0 : 1;
+  }
+  __syncthreads();
+  if (j != 0 || p >= a.P) return;
+  const int same_view = a.same_view_dev ? *a.same_view_dev : a.same_view;
+  float pj = 0.0f, pi = 0.0f;
+  bool valid = false;
+  for (int k = 0; k < a.n_views; ++k) {
+    const float c = cs[k][lane];
+    if (k == same_view) pi = c;
+    else { pj += c; valid = valid || ok[k][lane]; }
   }
   a.pj[p] = pj;
   a.pi[p] = valid ? pi : 0.0f;
@@ -914,7 +927,7 @@ int svs_cost_lookup(const float* xyz, const float* cam, const float* dirs, const
       set_error("svs_cost_lookup: bad view %d", j); return SVS_EINVAL;
     }
   }
-  cost_lookup_kernel<<<(n_points + 255) / 256, 256, 0, (hipStream_t)hip_stream>>>(a);
+  cost_lookup_kernel<<<(n_points + 63) / 64, 64 * n_views, 0, (hipStream_t)hip_stream>>>(a);
   return check_launch("svs_cost_lookup");
 }
 
