@@ -622,7 +622,9 @@ class TrainStep:
                 sc.bg_bwd.zero()
             sc.accum.zero()
             packed = torch.cuda.Event(); packed.record(prep)
-        main.wait_event(rgb_packed)
+        # (the radiance forward stream is needed by the radiance launch only: every group's stream waits for `rgb_packed`
+        # right in front of that launch -- the model calls the hook -- and the sampler and the fused SDF launch start ~20 us
+        # earlier than when the origin stream waited here, in front of the fork)
         fork = torch.cuda.Event(); fork.record(main)
         results, joins, holds = [], [], []
         # d loss / d beta of a group: one group writes it straight into the flat gradient, several into slots that are summed
@@ -635,6 +637,7 @@ class TrainStep:
                 inp = dict(model_input)
                 inp["uv"] = uv[:, lo:hi].contiguous()
                 inp["_skip_xyz"] = True              # the prior lookup below works from (cam, dirs, z): no (R,S,3) point list
+                inp["_before_rgb"] = lambda stream=stream: stream.wait_event(rgb_packed)
                 keep = {}
                 # (a capture tolerates the background forward's side stream only below the ORIGIN stream: the note above)
                 m._side_ok_in_capture = gi == 0 and not serial

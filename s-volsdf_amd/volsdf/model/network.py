@@ -257,6 +257,9 @@ class VolSDFNetwork(nn.Module):
         grad_theta = gradients[n_main:]
         sdf, gradients = sdf[:n_main], gradients[:n_main]
         src_main = ops.PointSource(cam=cam_loc, dirs=ray_dirs, z=z_vals)
+        hook = input.get("_before_rgb")              # (trainer: the radiance weight stream is packed on another stream)
+        if hook is not None:
+            hook()
         rgb_flat = ops.rgb_eval(pk, src_main, gradients, ray_dirs, feat_tiles, keep=keep)
         comp = ops.composite(z_vals, sdf, rgb_flat, depth_scale, self.density.beta, self.density.beta_min_value,
                              normals=None if self.training else gradients)

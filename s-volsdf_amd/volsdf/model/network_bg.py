@@ -224,6 +224,9 @@ class VolSDFNetworkBG(nn.Module):
         grad_theta = gradients[n_main:]
         sdf, gradients = sdf[:n_main], gradients[:n_main]
         src_main = ops.PointSource(cam=cam_loc, dirs=ray_dirs, z=z_vals)
+        hook = input.get("_before_rgb")              # (trainer: the radiance weight stream is packed on another stream)
+        if hook is not None:
+            hook()
         rgb_flat = ops.rgb_eval(pk, src_main, gradients, view_dirs, feat_tiles, keep=keep)
         if bg_join is not None:
             torch.cuda.current_stream().wait_event(bg_join)
