@@ -1,5 +1,8 @@
+"""Padded batches (ray counts that are not a multiple of the kernels' tile) through eager launches and launch plans (dev aid;
+run on the GPU box)."""
 import sys, os
-sys.path[:0] = ["/root/repo/s-volsdf_amd", "/root/repo/tests/golden", "/root/repo/tests"]
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [os.path.join(ROOT, "s-volsdf_amd"), os.path.join(ROOT, "tests", "golden"), os.path.join(ROOT, "tests")]
 import numpy as np, torch, synth
 from test_gpu_graph import _fresh, G
 from svs_hip.trainer import TrainStep
