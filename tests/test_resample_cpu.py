@@ -2,8 +2,23 @@
 `svs_randperm_prefix` -- a host routine of the C-ABI library -- against torch.randperm itself: the same indices AND the same
 generator state afterwards, so every later draw of the run (the sampler's jitter, the eikonal points, the next batches) is
 unchanged.  No GPU involved."""
+import importlib.util
+import os
+
 import numpy as np
+import pytest
 import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built_library():
+    """the routine is host code of the C-ABI library: build it if this checkout has not yet (hipcc cross-compiles here)"""
+    spec = importlib.util.spec_from_file_location("svs_build", os.path.join(ROOT, "s-volsdf_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.build(verbose=False)
 
 
 def _fast(n, k):
