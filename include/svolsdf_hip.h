@@ -40,6 +40,9 @@ int svs_rays_from_uv(const float* uv, const float* pose, const float* intrinsics
  * points: DEVICE float[2 n_rays][3], the tail of the point list the fused SDF launch evaluates. */
 int svs_eikonal_points(const float* uniform_points, const float* cam_loc, const float* z_eik, const float* ray_dirs,
                        int n_rays, float* points, void* hip_stream);
+/* BG model (volsdf/model/network_bg.py:60-62): z (n_rays, n) -> head (n_rays, n - 1) = z[:, :-1] dense, last (n_rays) =
+ * z[:, -1] (the sphere exit depth), one launch. */
+int svs_split_last(const float* z, int n_rays, int n, float* head, float* last, void* hip_stream);
 
 /* ---- a5/a6  weight packing --------------------------------------------------------------------------
  * Weight-norm materialisation w = g*v/||v|| (nn.utils.weight_norm, volsdf/model/network.py:64-65) and the

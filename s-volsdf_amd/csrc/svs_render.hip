@@ -45,6 +45,16 @@ __global__ void eikonal_points_kernel(const float* __restrict__ uniform, const f
   out[3 * R + i] = cam[c] + z_eik[r] * dirs[i];
 }
 
+// BG model: the sampler's depths (R, n) -> the n - 1 foreground depths, dense, and the last one (the sphere exit,
+// network_bg.py:60-62: z_max = z_vals[:, -1]; z_vals = z_vals[:, :-1])
+__global__ void split_last_kernel(const float* __restrict__ z, int R, int n, float* __restrict__ head, float* __restrict__ last) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R * n) return;
+  const int r = i / n, c = i - r * n;
+  if (c == n - 1) last[r] = z[i];
+  else head[r * (n - 1) + c] = z[i];
+}
+
 // ---- a8: compositing ------------------------------------------------------------------------------------
 constexpr int kMaxS = 256;
 
@@ -808,6 +818,12 @@ int svs_rays_from_uv(const float* uv, const float* pose, const float* intrinsics
   rays_kernel<<<(n_rays + 255) / 256, 256, 0, (hipStream_t)hip_stream>>>(uv, pose, intrinsics, n_rays, ray_dirs, cam_loc,
                                                                         depth_scale);
   return check_launch("svs_rays_from_uv");
+}
+
+int svs_split_last(const float* z, int n_rays, int n, float* head, float* last, void* hip_stream) {
+  if (!z || !head || !last || n_rays <= 0 || n < 2) { set_error("svs_split_last: null/invalid argument"); return SVS_EINVAL; }
+  split_last_kernel<<<(n_rays * n + 255) / 256, 256, 0, (hipStream_t)hip_stream>>>(z, n_rays, n, head, last);
+  return check_launch("svs_split_last");
 }
 
 int svs_eikonal_points(const float* uniform_points, const float* cam_loc, const float* z_eik, const float* ray_dirs,

@@ -345,6 +345,15 @@ def composite_bg(z, z_max, sdf, rgb, depth_scale, beta_param, beta_min, z_bg, bg
                 depth_values=depth_values, depth_values_all=depth_all, depth_vals=depth_vals, normal_map=normal_map)
 
 
+def split_last(z):
+    """(R, n) -> (z[:, :-1] dense, z[:, -1]) in one launch (network_bg.py:60-62)."""
+    z = _f32(z)
+    R, n = z.shape
+    head, last = torch.empty(R, n - 1, device=z.device), torch.empty(R, device=z.device)
+    _lib.check(_lib.load().svs_split_last(_ptr(z), R, n, _ptr(head), _ptr(last), _stream()), "svs_split_last")
+    return head, last
+
+
 def eikonal_points(uniform_points, cam_loc, z_eik, ray_dirs):
     """network.py:258-266: (2R,3) = [the uniform draws ; cam + z_eik * dirs] in one launch."""
     R = ray_dirs.shape[0]

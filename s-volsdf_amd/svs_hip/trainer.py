@@ -608,9 +608,13 @@ class TrainStep:
         if not serial:
             prep.wait_stream(main)                       # parameters of this step are final, last step's readers are done
         pk = m.packed_mlp(rgb=False)                     # pack once, before the streams fork
-        if self.is_bg:
-            m.packed_bg()                                # (the group streams are ordered behind `fork`, not behind each other)
         with torch.cuda.stream(prep):
+            bg_packed = None
+            if self.is_bg:
+                # the background networks' forward streams too (two rownorm + pack pairs: 30 us that sat on the origin
+                # stream in front of the sampler); awaited in front of their first launch (`_before_bg`)
+                m.packed_bg()
+                bg_packed = torch.cuda.Event(); bg_packed.record(prep)
             m.rendering_network.pack_into(pk)
             rgb_packed = torch.cuda.Event(); rgb_packed.record(prep)
             sc.tstreams.pack(sdf_p, rgb_p)
@@ -638,6 +642,8 @@ class TrainStep:
                 inp["uv"] = uv[:, lo:hi].contiguous()
                 inp["_skip_xyz"] = True              # the prior lookup below works from (cam, dirs, z): no (R,S,3) point list
                 inp["_before_rgb"] = lambda stream=stream: stream.wait_event(rgb_packed)
+                if bg_packed is not None:
+                    inp["_before_bg"] = lambda: torch.cuda.current_stream().wait_event(bg_packed)
                 keep = {}
                 # (a capture tolerates the background forward's side stream only below the ORIGIN stream: the note above)
                 m._side_ok_in_capture = gi == 0 and not serial

@@ -179,11 +179,14 @@ class VolSDFNetworkBG(nn.Module):
             if n_valid < R:
                 from .network import pad_rng
                 rng = pad_rng(rng, R)
-        (z_all, _), z_samples_eik = self.ray_sampler.get_z_vals(ray_dirs, cam_loc, self, fast=fast,
-                                                                iter_step=input.get("iter_step", 1), rng=rng)
+        self.ray_sampler.return_bg_ascending = False          # (this model takes the background samples from _bg_last)
+        try:
+            (z_all, _), z_samples_eik = self.ray_sampler.get_z_vals(ray_dirs, cam_loc, self, fast=fast,
+                                                                    iter_step=input.get("iter_step", 1), rng=rng)
+        finally:
+            self.ray_sampler.return_bg_ascending = True
         z_bg, bg_pts, bg_depth = self.ray_sampler._bg_last
-        z_max = z_all[:, -1].contiguous()
-        z_vals = z_all[:, :-1].contiguous()
+        z_vals, z_max = ops.split_last(z_all)
         S, Nb = z_vals.shape[1], z_bg.shape[1]
         hook = input.get("_after_sampling")          # (trainer: work that depends on the sample depths only)
         if hook is not None:
@@ -199,6 +202,9 @@ class VolSDFNetworkBG(nn.Module):
 
         def background():
             # network_bg.py:78-100: the background networks on the inverse-sphere samples
+            hook = input.get("_before_bg")           # (trainer: their weight streams are packed on another stream)
+            if hook is not None:
+                hook()
             out0, feat = ops.bg_sdf_eval(pkb, bg_pts, keep=keep)
             return out0, ops.bg_rgb_eval(pkb, view_dirs, Nb, feat, R * Nb, keep=keep)
 

@@ -215,7 +215,8 @@ class ErrorBoundSampler(RaySampler):
             jit = rng.get("jitter_bg") if (model.training and rng) else None
             self._bg_last = ops.bg_points(cam_loc, ray_dirs, self.inverse_sphere_sampler.N_samples,
                                           self.scene_bounding_sphere, jitter=jit)
-            z = (z, torch.flip(self._bg_last[0], dims=[-1]))
+            # (the reference returns z_bg ascending; the drop-in model reads _bg_last and asks for no flip)
+            z = (z, torch.flip(self._bg_last[0], dims=[-1]) if getattr(self, "return_bg_ascending", True) else None)
         return z, z_eik
 
     def get_error_bound(self, beta, model, sdf, z_vals, dists, d_star):
