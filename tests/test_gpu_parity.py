@@ -122,6 +122,15 @@ def test_eikonal_points(dev, ops):
         assert got.shape == (2 * R, 3) and np.array_equal(got, want)
 
 
+def test_split_last(dev, ops):
+    """svs_split_last (network_bg.py:60-62): z[:, :-1] dense and z[:, -1] in one launch."""
+    rs = np.random.default_rng(5)
+    for R, n in ((1, 2), (37, 98), (256, 98), (1000, 5)):
+        z = rs.standard_normal((R, n)).astype(F32)
+        head, last = ops.split_last(G(z, dev))
+        assert np.array_equal(head.cpu().numpy(), z[:, :-1]) and np.array_equal(last.cpu().numpy(), z[:, -1])
+
+
 def test_rays(dev, ops, golden_dir):
     g = dict(np.load(os.path.join(golden_dir, "rays.npz")))
     for t in "ab":
