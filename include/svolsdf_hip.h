@@ -40,6 +40,11 @@ int svs_rays_from_uv(const float* uv, const float* pose, const float* intrinsics
  * points: DEVICE float[2 n_rays][3], the tail of the point list the fused SDF launch evaluates. */
 int svs_eikonal_points(const float* uniform_points, const float* cam_loc, const float* z_eik, const float* ray_dirs,
                        int n_rays, float* points, void* hip_stream);
+/* The small per-step inputs of VolOpt.train_step (volsdf/vsdf.py:196-204: `model_input[...].cuda()`, and the train-mode
+ * draws of the sampler): `bytes` (a multiple of 4) from a PINNED HOST buffer (hipHostMalloc / torch pin_memory: mapped
+ * into the device's address space) to device memory by a kernel on hip_stream; both 16-byte aligned.  The host must not
+ * rewrite the buffer before the launch has run (the callers keep a ring of staging buffers and an event per slot). */
+int svs_stage_in(const void* pinned_host, void* device, size_t bytes, void* hip_stream);
 /* BG model (volsdf/model/network_bg.py:60-62): z (n_rays, n) -> head (n_rays, n - 1) = z[:, :-1] dense, last (n_rays) =
  * z[:, -1] (the sphere exit depth), one launch. */
 int svs_split_last(const float* z, int n_rays, int n, float* head, float* last, void* hip_stream);

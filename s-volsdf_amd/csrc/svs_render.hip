@@ -45,6 +45,17 @@ __global__ void eikonal_points_kernel(const float* __restrict__ uniform, const f
   out[3 * R + i] = cam[c] + z_eik[r] * dirs[i];
 }
 
+// A step's small host inputs (the train-mode draws, pixels, camera: 0.2-0.8 MB) read by a kernel straight from the
+// pinned staging buffer (hipHostMalloc memory is mapped into the device's address space).  A hipMemcpyAsync does the same
+// transfer, but the first kernel behind it starts ~30 us after it ends (cache maintenance and a barrier around the blit);
+// behind this kernel the next one starts at once.
+__global__ void stage_in_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, long long n4, const float* src_tail,
+                                float* dst_tail, int n_tail) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
+    dst[i] = __builtin_nontemporal_load(src + i);
+  if (blockIdx.x == 0 && (int)threadIdx.x < n_tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+
 // BG model: the sampler's depths (R, n) -> the n - 1 foreground depths, dense, and the last one (the sphere exit,
 // network_bg.py:60-62: z_max = z_vals[:, -1]; z_vals = z_vals[:, :-1])
 __global__ void split_last_kernel(const float* __restrict__ z, int R, int n, float* __restrict__ head, float* __restrict__ last) {
@@ -818,6 +829,19 @@ int svs_rays_from_uv(const float* uv, const float* pose, const float* intrinsics
   rays_kernel<<<(n_rays + 255) / 256, 256, 0, (hipStream_t)hip_stream>>>(uv, pose, intrinsics, n_rays, ray_dirs, cam_loc,
                                                                         depth_scale);
   return check_launch("svs_rays_from_uv");
+}
+
+int svs_stage_in(const void* pinned_host, void* device, size_t bytes, void* hip_stream) {
+  if (!pinned_host || !device || bytes == 0 || (bytes & 3) || (((uintptr_t)pinned_host | (uintptr_t)device) & 15)) {
+    set_error("svs_stage_in: 16-byte aligned buffers, a multiple of 4 bytes"); return SVS_EINVAL;
+  }
+  const long long n4 = (long long)(bytes >> 4);
+  const int n_tail = (int)((bytes & 15) >> 2);
+  long long blocks = (n4 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+  stage_in_kernel<<<(int)blocks, 256, 0, (hipStream_t)hip_stream>>>((const f32x4*)pinned_host, (f32x4*)device, n4,
+                                                                    (const float*)pinned_host + 4 * n4, (float*)device + 4 * n4, n_tail);
+  return check_launch("svs_stage_in");
 }
 
 int svs_split_last(const float* z, int n_rays, int n, float* head, float* last, void* hip_stream) {

@@ -148,6 +148,7 @@ SIGNATURES.update({
     "svs_randperm_prefix": (c_int, [_P, c_size_t, c_longlong, c_longlong, _P]),
     "svs_eikonal_points": (c_int, [_P, _P, _P, _P, c_int, _P, _P]),
     "svs_split_last": (c_int, [_P, c_int, c_int, _P, _P, _P]),
+    "svs_stage_in": (c_int, [_P, _P, c_size_t, _P]),
     "svs_plan_build": (c_int, [_P, _PP, c_int, _PP]),
     "svs_plan_run": (c_int, [_P, _P]),
     "svs_plan_info": (c_int, [_P, _P]),

@@ -5,6 +5,7 @@ Shapes/semantics follow the reference functions named in each docstring (paths r
 reference root).
 """
 import ctypes
+import os
 
 import torch
 
@@ -343,6 +344,23 @@ def composite_bg(z, z_max, sdf, rgb, depth_scale, beta_param, beta_min, z_bg, bg
                "svs_composite_bg")
     return dict(weights=weights, bg_transmittance=bg_trans, bg_weights=bg_w, rgb_values=rgb_values,
                 depth_values=depth_values, depth_values_all=depth_all, depth_vals=depth_vals, normal_map=normal_map)
+
+
+_STAGE_IN = os.environ.get("SVS_STAGE_IN", "1") != "0"      # A/B switch: 0 = hipMemcpyAsync (tensor.copy_)
+
+
+def stage_in(dev_tensor, pinned_tensor):
+    """pinned host tensor -> device tensor of the same byte size, by a kernel on the current stream (svs_stage_in); falls back to
+    a non-blocking copy_ for buffers the kernel does not take (alignment, sizes that are not a multiple of 4 bytes)."""
+    nbytes = pinned_tensor.numel() * pinned_tensor.element_size()
+    ok = (_STAGE_IN and pinned_tensor.is_pinned() and pinned_tensor.is_contiguous() and dev_tensor.is_contiguous()
+          and nbytes == dev_tensor.numel() * dev_tensor.element_size() and nbytes % 4 == 0
+          and pinned_tensor.data_ptr() % 16 == 0 and dev_tensor.data_ptr() % 16 == 0 and nbytes > 0)
+    if not ok:
+        dev_tensor.copy_(pinned_tensor, non_blocking=True)
+        return dev_tensor
+    _lib.check(_lib.load().svs_stage_in(pinned_tensor.data_ptr(), dev_tensor.data_ptr(), nbytes, _stream()), "svs_stage_in")
+    return dev_tensor
 
 
 def split_last(z):

@@ -818,7 +818,7 @@ class TrainStep:
             # staging buffer -- stale -- over them, so they are copied again behind it)
             if any(src.is_cuda for _, src in pieces):
                 on_device = [(k, src, (origin[k], origin[k]._version)) for k, src in pieces if src.is_cuda]
-            st["_all"].copy_(pin, non_blocking=True)
+            ops.stage_in(st["_all"], pin)
         elif st.get("_head") != head:
             st["_all"][:4].copy_(pin[:4], non_blocking=True)      # the three scalars only
         if host or st.get("_head") != head:

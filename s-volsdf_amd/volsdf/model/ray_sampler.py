@@ -144,7 +144,7 @@ class ErrorBoundSampler(RaySampler):
             packed = [k for k in names if k in slot["_off"] and slot[k].data_ptr() == slot["_pin"].data_ptr() + 4 * slot["_off"][k][0]]
             if "_all" not in dbuf:
                 dbuf["_all"] = torch.empty(slot["_pin"].shape, dtype=torch.float32, device=dev)
-            dbuf["_all"].copy_(slot["_pin"], non_blocking=True)
+            ops.stage_in(dbuf["_all"], slot["_pin"])          # (a kernel that reads the pinned buffer: svs_stage_in)
             for k in names:
                 if k in packed:
                     off, n = slot["_off"][k]

@@ -464,7 +464,7 @@ class VolOpt():
             slot["pin"][off:off + n].copy_(t.reshape(-1))
             views.append(slot["dev"][off:off + n].view(t.shape))
             off += n
-        slot["dev"].copy_(slot["pin"], non_blocking=True)
+        ops.stage_in(slot["dev"], slot["pin"])
         slot["ev"] = torch.cuda.Event()
         slot["ev"].record()
         mi = {k: v for k, v in model_input.items() if not torch.is_tensor(v)}

@@ -110,3 +110,5 @@ def test_argument_errors_come_back_as_codes():
     assert rc < 0 and b"svs_eikonal_points" in L.svs_last_error_string()
     assert L.svs_eikonal_points(dummy, dummy, dummy, dummy, 0, dummy, None) < 0
     assert L.svs_split_last(dummy, 4, 1, dummy, dummy, None) < 0 and L.svs_split_last(None, 4, 3, dummy, dummy, None) < 0
+    assert L.svs_stage_in(None, dummy, 64, None) < 0 and L.svs_stage_in(dummy, dummy, 6, None) < 0
+    assert L.svs_stage_in(ctypes.c_void_p(68), dummy, 64, None) < 0            # not 16-byte aligned

@@ -122,6 +122,29 @@ def test_eikonal_points(dev, ops):
         assert got.shape == (2 * R, 3) and np.array_equal(got, want)
 
 
+def test_stage_in(dev, ops):
+    """svs_stage_in: a pinned host buffer read by a kernel into device memory == a copy; sizes with a tail of 1..3 words,
+    a large buffer, and buffers the kernel does not take (unaligned views, byte tensors) through the fallback copy."""
+    rs = np.random.default_rng(6)
+    for n in (1, 3, 4, 7, 1021, 200000):
+        src = torch.from_numpy(rs.standard_normal(n).astype(F32)).pin_memory()
+        dst = torch.zeros(n, device=dev)
+        assert ops.stage_in(dst, src) is dst
+        assert torch.equal(dst.cpu(), src)
+    src = torch.arange(64, dtype=torch.int32).pin_memory()
+    dst = torch.zeros(64, dtype=torch.int32, device=dev)
+    ops.stage_in(dst, src)
+    assert torch.equal(dst.cpu(), src)
+    base = torch.from_numpy(rs.standard_normal(33).astype(F32)).pin_memory()
+    dst = torch.zeros(32, device=dev)
+    ops.stage_in(dst, base[1:])                       # 4-byte aligned only: fallback
+    assert torch.equal(dst.cpu(), base[1:])
+    b = torch.arange(7, dtype=torch.uint8).pin_memory()
+    d = torch.zeros(7, dtype=torch.uint8, device=dev)
+    ops.stage_in(d, b)                                # not a multiple of 4 bytes: fallback
+    assert torch.equal(d.cpu(), b)
+
+
 def test_split_last(dev, ops):
     """svs_split_last (network_bg.py:60-62): z[:, :-1] dense and z[:, -1] in one launch."""
     rs = np.random.default_rng(5)
