@@ -820,7 +820,7 @@ class TrainStep:
                 on_device = [(k, src, (origin[k], origin[k]._version)) for k, src in pieces if src.is_cuda]
             ops.stage_in(st["_all"], pin)
         elif st.get("_head") != head:
-            st["_all"][:4].copy_(pin[:4], non_blocking=True)      # the three scalars only
+            ops.stage_in(st["_all"][:4], pin[:4])                  # the three scalars only
         if host or st.get("_head") != head:
             slot["ev"] = torch.cuda.Event()
             slot["ev"].record()
