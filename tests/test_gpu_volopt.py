@@ -250,6 +250,53 @@ def test_overlapped_loader_draws_the_same_batches(tmp_path, monkeypatch):
     assert torch.equal(ta, tb) and ra == rb
 
 
+def test_launch_plans_and_pixel_draw_keep_the_run(tmp_path, monkeypatch):
+    """`VolOpt.run` with the round-4 defaults (launch plans for short steps, the step's pixels drawn by svs_randperm_prefix,
+    the loader's host tensors handed to the planned step) against the plain path (eager launches, the dataset's own
+    `torch.randperm`): the same batch sequence and the same final states of both random generators bit for bit, the same
+    first step, parameters within Adam's sign noise after 15 steps."""
+    import random
+    from volsdf import vsdf
+    monkeypatch.chdir(tmp_path)
+
+    def run(graph, fast):
+        monkeypatch.setenv("SVS_TRAIN_GRAPH", graph)
+        monkeypatch.setenv("SVS_FAST_RESAMPLE", fast)
+        vsdf._RESAMPLE_IS_REFERENCE.clear()
+        torch.manual_seed(13); random.seed(13); np.random.seed(13)
+        v = build(make_args())
+        seen, first = [], []
+        orig = v.train_step
+
+        def spy(batch, use_mvs=False, **kw):
+            seen.append((int(batch[0][0]), batch[1]["uv"].clone(), batch[2]["rgb"].clone()))
+            out = orig(batch, use_mvs, **kw)
+            if len(seen) == 1:
+                first.append({k: float(x) for k, x in out.items()})
+            return out
+        v.train_step = spy
+        v.run(opt_stepN=11)
+        planned = any(c.plan is not None for c in v.step_fn._captured.values())
+        return seen, first[0], torch.get_rng_state(), random.getstate(), v.step_fn.fp.flat.clone(), planned
+
+    a = run("auto", "1")
+    b = run("0", "0")
+    b2 = run("0", "0")                     # the plain path twice: the yardstick (float atomics + 15 Adam steps)
+    vsdf._RESAMPLE_IS_REFERENCE.clear()
+    assert a[5] and not b[5]
+    assert len(a[0]) == len(b[0]) == 15
+    for x, y in zip(a[0], b[0]):
+        assert x[0] == y[0] and torch.equal(x[1], y[1]) and torch.equal(x[2], y[2])
+    assert torch.equal(a[2], b[2]) and a[3] == b[3]
+    for k in a[1]:
+        assert a[1][k] == pytest.approx(b[1][k], rel=1e-6, abs=1e-9), k
+    d, d0 = (a[4] - b[4]).abs(), (b2[4] - b[4]).abs()
+    moved, moved0 = float((d > 1e-5).float().mean()), float((d0 > 1e-5).float().mean())
+    print(f"parameters after 15 steps: defaults vs plain max {float(d.max()):.2e}, {moved:.3f} of the entries off by > 1e-5; "
+          f"plain vs plain max {float(d0.max()):.2e}, {moved0:.3f}")
+    assert float(d.max()) <= 8e-3 and moved <= max(2.0 * moved0, 0.05) + 0.05
+
+
 def test_device_batches_blendedmvs_near_pose(monkeypatch):
     """BlendedMVS batches carry the pose of a neighbouring view (`near_pose`, scene_dataset.py:239-240, through the dataset
     module's `get_near_id`): the device batch source reproduces it."""
