@@ -273,7 +273,8 @@ def main():
         dist.all_reduce(d2, op=dist.ReduceOp.MAX)
         d2 = float(d2.item())
         other = {"scaling": o_scaling, "rays_per_gpu": R2, "rays_total": R2 * world, "steps": n2,
-                 "ms_per_step": 1e3 * d2 / n2, "value": world * R2 * n2 / d2, "unit": "rays/s"}
+                 "ms_per_step": 1e3 * d2 / n2, "value": world * R2 * n2 / d2, "unit": "rays/s",
+                 "launch": ("launch plan" if any(c.plan is not None for c in ts2._captured.values()) else "eager launches")}
         del ts2, step2, model2
 
     S = model.ray_sampler.N_samples + model.ray_sampler.N_samples_extra + 2 - (1 if args.model == "bmvs" else 0)
