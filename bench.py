@@ -103,6 +103,9 @@ def main():
                          "VolOpt's): plan for batches that run as one ray group (< 328 rays per GPU: the host-bound sizes), "
                          "eager otherwise; on / linear: hipGraphLaunch of the capture (with its stream topology / as one chain)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel event timing (roofline = null)")
+    ap.add_argument("--no-host-timing", action="store_true",
+                    help="skip the 18 extra steps that time the host's enqueueing (`host_enqueue_ms_per_step`): counter passes "
+                         "under rocprofv3 --pmc count on exactly --warmup + --steps steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-f32", action="store_true",
                     help="skip the extra runs in the other precisions (fast_grad_*, exact_f32_ms_per_step)")
@@ -239,14 +242,14 @@ def main():
     # host side of a step: wall time the host thread needs to ENQUEUE a step (six steps into an empty queue, nothing
     # blocks on the device); a step whose kernels take less than this is host-bound
     host_ms = []
-    for _ in range(3):
+    for _ in range(0 if args.no_host_timing else 3):
         torch.cuda.synchronize()
         th = time.perf_counter()
         for _ in range(6):
             step()
         host_ms.append(1e3 * (time.perf_counter() - th) / 6)
     torch.cuda.synchronize()
-    host_enqueue_ms = sorted(host_ms)[1]
+    host_enqueue_ms = sorted(host_ms)[1] if host_ms else None
 
     other = None
     if world > 1 and train and not args.no_other_scaling and args.rays % world == 0:

@@ -6,7 +6,7 @@ B="python3 $R/bench.py --no-cpu-baseline --no-exact-f32 --no-gpu-torch --no-kern
 run() { name=$1; shift; $B "$@" 2>/dev/null | tail -1 > $O/$name.json; python3 - "$name" "$O/$name.json" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[2]))
-print(f"{sys.argv[1]:14s} {d['ms_per_step']:.3f} ms/step  {d['value']:.0f} {d['unit']}  (host enqueue {d.get('host_enqueue_ms_per_step', 0):.2f} ms)")
+print(f"{sys.argv[1]:14s} {d['ms_per_step']:.3f} ms/step  {d['value']:.0f} {d['unit']}  (host enqueue {(d.get('host_enqueue_ms_per_step') or 0):.2f} ms)")
 PY
 }
 run default

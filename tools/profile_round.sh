@@ -14,7 +14,7 @@ rocprofv3 --kernel-trace --stats -d $O/train --output-format csv -- $B --steps 2
 rocprofv3 --kernel-trace --stats -d $O/render --output-format csv -- $B --mode render --steps 20 --warmup 10 > $O/render.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/train_onegroup --output-format csv -- $B --steps 20 --warmup 10 --groups none > $O/onegroup.log 2>&1
 # counter passes: few steps, no settle phase / extra passes (every dispatch is serialised under --pmc)
-C="$B --steps 3 --warmup 2 --settle 0 --no-kernel-timing"
+C="$B --steps 3 --warmup 2 --settle 0 --no-kernel-timing --no-host-timing"
 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch --output-format csv -- $C > $O/f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write --output-format csv -- $C > $O/w.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE \
