@@ -104,8 +104,10 @@ int svs_sdf_vals_pair(const float* points, int n_points, const float* cam, int c
 /* svs_sdf_outputs: ImplicitNetwork.get_outputs (network.py:105-123) and .gradient (:90-103):
  *   sdf (P), grad = d sdf/dx (P,3), feat_tiles (svs_feat_tiles_bytes; wave-tile layout, may be NULL),
  *   hbuf (svs_sdf_hbuf_bytes): the activations h_1..h_8 kept for the gradient pass / training backward;
- *   gbuf (same size, may be NULL): ghat_l = g(h_{l+1}) * softplus'(a_l), l = 0..7, of the gradient pass; clamp_mask (P bytes, may be NULL): 1 where
- *   the sphere clamp is active -- both are only needed by the training backward. */
+ *   gbuf (svs_sdf_gbuf_bytes, may be NULL): ghat_l = g(h_{l+1}) * softplus'(a_l), l = 0..7, of the gradient pass, and -- fp16x2
+ *   precisions -- behind the 8 blocks of every tile their records [1.0 x 32][max_r |ghat_l| of point 0..31] (the layout of
+ *   "Records" below), which svs_sdf_bwd_b reads; clamp_mask (P bytes, may be NULL): 1 where the sphere clamp is active -- both
+ *   are only needed by the training backward. */
 size_t svs_sdf_hbuf_bytes(int n_points_total);
 size_t svs_feat_tiles_bytes(int n_points_total);
 int svs_sdf_outputs(const float* points, int n_points, const float* cam, int cam_stride, const float* dirs,
@@ -259,32 +261,37 @@ int svs_wgrad(const float* a0, const float* b0, long long sa0, long long sb0, co
  * tile t is at float k * T * 8192 + (b * T + t) * 64 (also for bg zbuf, whose slots are [tile][block]).
  *   svs_rgb_bwd : d_rgb (P,3), rgb (P,3), rbuf, radiance backward stream (svs_pack_stream which=4)
  *                 -> zbuf (5 blocks/tile, ZERO-INITIALISED by the caller once), feat_bar (1 block/tile), d_normals (P,3)
- *   svs_sdf_bwd_a: second-order sweep.  points/rays as in svs_sdf_outputs; d_grad (P,3) = dL/d(d sdf/dx);
- *                 hbuf, gbuf from svs_sdf_outputs; stream = SDF training stream (which=2)
- *                 -> ubuf (9 blocks/tile), a2buf (8), pebuf (1)
+ *   svs_sdf_bwd_a: second-order sweep (forward mode: u_0 = J_PE nbar, u_{l+1} = (W_l u_l) s'(a_l)).  points/rays as in
+ *                 svs_sdf_outputs; d_grad (P,3) = dL/d(d sdf/dx); hbuf, gbuf from svs_sdf_outputs; stream = SDF training
+ *                 stream (which=2) -> ubuf (9 blocks/tile), pebuf (1), and with SVS_MMA_F32 the second-order source blocks
+ *                 a2_l = (W_l u_l) ghat_l 100 (1 - s'(a_l)) -> a2buf (8).  fp16x2 (since round 5): gbuf is not read and a2buf
+ *                 not written (both may be NULL); the second half of the record of u_{l+1} holds max_r |(W_l u_l)| 100 (1 - s')
  *   svs_sdf_bwd_b: backprop.  d_sdf (P) or NULL, feat_bar for the first n_feat_points points (multiple of 32)
- *                 -> abuf (8 blocks/tile), sbar_out (32 floats per tile)
+ *                 -> abuf (8 blocks/tile), sbar_out (32 floats per tile).  SVS_MMA_F32 reads a2buf (ubuf may be NULL); fp16x2
+ *                 re-forms a2_l = u_{l+1} ghat_l 100 (1 - s') / s' from ubuf (with pass A's records) and gbuf (with the records
+ *                 svs_sdf_outputs wrote behind it: max_r |ghat_l| per point; svs_sdf_gbuf_bytes) -- a2buf may be NULL: 8 KB
+ *                 per point less HBM traffic than storing a2 in pass A and reading it here
  *   svs_lin8_row0_grad: out257[0..255] += dL/dW8[0,:], out257[256] += dL/db8[0] (caller zeroes)
  *   precision SVS_MMA_F16X2 (streams packed with the same precision): every point carries its own power-of-two
  *                 scale through the sweeps (gradients are far below fp16's range); all buffers hold true float32
  *                 values.  Extra arguments, NULL for SVS_MMA_F32: absmax (3 floats, caller zeroes once per step:
- *                 [0] max |abar|,|u|, [1] max |zbar|, [2] max |feat_bar| -- the scales of svs_wgrad), a2max (padded
- *                 n_points floats, pass A -> pass B).
+ *                 [0] max |abar|,|u|, [1] max |zbar|, [2] max |feat_bar| -- the scales of svs_wgrad).
  *   svs_unpack_wgrad: kernel-order dW (from svs_wgrad) -> parameter gradients incl. weight-norm backward
  *                 (w = g v/|v|, network.py:64-65).  map: 0 identity, 1 SDF lin4 (skip splice, 1/sqrt2),
  *                 2 radiance lin0, 3 bg lin4, 4 bg radiance lin0.  row_off: first parameter row covered by dWk (SDF lin8: 1, with row0 = out257). */
 size_t svs_block_bytes(int n_points, int blocks_per_tile);
 size_t svs_rgb_zbuf_bytes(int n_points);
 size_t svs_sdf_ubuf_bytes(int n_points);
+size_t svs_sdf_gbuf_bytes(int n_points);      /* gbuf of svs_sdf_outputs: 8 blocks per tile + their records */
 int svs_rgb_bwd(int n_points, const float* d_rgb, const float* rgb, const float* rbuf, const float* stream, int precision,
                 float* zbuf, float* feat_bar, float* d_normals, float* absmax, void* hip_stream);
 int svs_sdf_bwd_a(const float* points, int n_points, const float* cam, int cam_stride, const float* dirs, const float* z,
                   int S, int n_rays, const float* d_grad, const unsigned char* clamp_mask, const float* hbuf,
                   const float* gbuf, const float* stream, int precision, float* ubuf, float* a2buf, float* pebuf,
-                  float* absmax, float* a2max, void* hip_stream);
+                  float* absmax, void* hip_stream);
 int svs_sdf_bwd_b(int n_points, const float* d_sdf, const unsigned char* clamp_mask, const float* feat_bar,
-                  int n_feat_points, const float* hbuf, const float* gbuf, const float* a2buf, const float* stream,
-                  int precision, float* abuf, float* sbar_out, float* absmax, const float* a2max, void* hip_stream);
+                  int n_feat_points, const float* hbuf, const float* gbuf, const float* a2buf, const float* ubuf,
+                  const float* stream, int precision, float* abuf, float* sbar_out, float* absmax, void* hip_stream);
 int svs_lin8_row0_grad(const float* hbuf, const float* ubuf, const float* sbar, int n_points, int precision, float* out257,
                        void* hip_stream);
 int svs_unpack_wgrad(const float* dWk, const float* dbk, int ldw, int map, int rows, int cols, int row_off,

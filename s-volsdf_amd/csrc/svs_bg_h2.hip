@@ -399,8 +399,8 @@ int svs_bg_sdf_bwd(int n_points, const float* d_out0, const float* feat_bar, con
   if (n_points <= 0 || n_points % 32 || !d_out0 || !feat_bar || !hbuf || !ghat7 || !stream || !abuf || !sbar_out || !absmax) {
     set_error("svs_bg_sdf_bwd: null/invalid argument (n_points must be a multiple of 32)"); return SVS_EINVAL;
   }
-  SdfBwdBArgs a{n_points, d_out0, nullptr, feat_bar, n_points / 32, hbuf, nullptr, nullptr,
-                reinterpret_cast<const f32x4*>(stream), abuf, sbar_out, absmax, nullptr, ghat7, (size_t)kBlockF};
+  SdfBwdBArgs a{n_points, d_out0, nullptr, feat_bar, n_points / 32, hbuf, nullptr, nullptr, nullptr,
+                reinterpret_cast<const f32x4*>(stream), abuf, sbar_out, absmax, ghat7, (size_t)kBlockF};
   return launch_bg_bwd_b_h2(a, precision == kFmtF16x2, (hipStream_t)hip_stream);
 }
 

@@ -450,6 +450,7 @@ size_t svs_block_bytes(int n_points, int blocks_per_tile) {
 }
 size_t svs_rgb_zbuf_bytes(int n_points) { return svs_block_bytes(n_points, 5); }
 size_t svs_sdf_ubuf_bytes(int n_points) { return svs_block_bytes(n_points, 9); }
+size_t svs_sdf_gbuf_bytes(int n_points) { return svs_block_bytes(n_points, 8); }
 
 int svs_rgb_bwd(int n_points, const float* d_rgb, const float* rgb, const float* rbuf, const float* stream, int precision,
                 float* zbuf, float* feat_bar, float* d_normals, float* absmax, void* hip_stream) {
@@ -471,19 +472,21 @@ int svs_rgb_bwd(int n_points, const float* d_rgb, const float* rgb, const float*
 int svs_sdf_bwd_a(const float* points, int n_points, const float* cam, int cam_stride, const float* dirs, const float* z,
                   int S, int n_rays, const float* d_grad, const unsigned char* clamp_mask, const float* hbuf,
                   const float* gbuf, const float* stream, int precision, float* ubuf, float* a2buf, float* pebuf,
-                  float* absmax, float* a2max, void* hip_stream) {
+                  float* absmax, void* hip_stream) {
   SdfBwdAArgs a;
+  const bool h2 = is_h2(precision);      // fp16x2: gbuf is not read and a2buf not written (pass B re-forms a2)
   if (n_points < 0 || n_rays < 0 || (n_points == 0 && n_rays == 0) || (n_points > 0 && !points) ||
-      (n_rays > 0 && !(cam && dirs && z && S > 0)) || !d_grad || !hbuf || !gbuf || !stream || !ubuf || !a2buf || !pebuf) {
+      (n_rays > 0 && !(cam && dirs && z && S > 0)) || !d_grad || !hbuf || (!h2 && !gbuf) || !stream || !ubuf || (!h2 && !a2buf) ||
+      !pebuf) {
     set_error("svs_sdf_bwd_a: null/invalid argument"); return SVS_EINVAL;
   }
   a.src.pts = points; a.src.cam = cam; a.src.dirs = dirs; a.src.z = z; a.src.cam_stride = cam_stride;
   a.src.S = S > 0 ? S : 1; a.src.n_ray = n_rays * (S > 0 ? S : 0); a.src.P = a.src.n_ray + n_points;
   a.d_grad = d_grad; a.clamp_mask = clamp_mask; a.hbuf = hbuf; a.gbuf = gbuf;
   a.stream = reinterpret_cast<const f32x4*>(stream); a.ubuf = ubuf; a.a2buf = a2buf; a.pebuf = pebuf;
-  a.absmax = absmax; a.a2max = a2max;
-  if (is_h2(precision)) {
-    if (!absmax || !a2max) { set_error("svs_sdf_bwd_a: fp16x2 needs absmax and a2max"); return SVS_EINVAL; }
+  a.absmax = absmax;
+  if (h2) {
+    if (!absmax) { set_error("svs_sdf_bwd_a: fp16x2 needs absmax"); return SVS_EINVAL; }
     return launch_sdf_bwd_a_h2(a, precision == kFmtF16x2, (hipStream_t)hip_stream);
   }
   if (precision != kFmtF32) { set_error("svs_sdf_bwd_a: unknown precision %d", precision); return SVS_EINVAL; }
@@ -494,16 +497,17 @@ int svs_sdf_bwd_a(const float* points, int n_points, const float* cam, int cam_s
 }
 
 int svs_sdf_bwd_b(int n_points, const float* d_sdf, const unsigned char* clamp_mask, const float* feat_bar,
-                  int n_feat_points, const float* hbuf, const float* gbuf, const float* a2buf, const float* stream,
-                  int precision, float* abuf, float* sbar_out, float* absmax, const float* a2max, void* hip_stream) {
-  if (!hbuf || !gbuf || !a2buf || !stream || !abuf || !sbar_out || n_points <= 0 || n_feat_points % 32) {
+                  int n_feat_points, const float* hbuf, const float* gbuf, const float* a2buf, const float* ubuf,
+                  const float* stream, int precision, float* abuf, float* sbar_out, float* absmax, void* hip_stream) {
+  const bool h2 = is_h2(precision);      // fp16x2: a2 is re-formed from ubuf and gbuf (+ their records); float32: read from a2buf
+  if (!hbuf || !gbuf || (h2 ? !ubuf : !a2buf) || !stream || !abuf || !sbar_out || n_points <= 0 || n_feat_points % 32) {
     set_error("svs_sdf_bwd_b: null/invalid argument (n_feat_points must be a multiple of 32)"); return SVS_EINVAL;
   }
-  SdfBwdBArgs a{n_points, d_sdf, clamp_mask, feat_bar, n_feat_points / 32, hbuf, gbuf, a2buf,
-                reinterpret_cast<const f32x4*>(stream) + kSdfTrainPassBF4, abuf, sbar_out, absmax, a2max,
+  SdfBwdBArgs a{n_points, d_sdf, clamp_mask, feat_bar, n_feat_points / 32, hbuf, gbuf, a2buf, ubuf,
+                reinterpret_cast<const f32x4*>(stream) + kSdfTrainPassBF4, abuf, sbar_out, absmax,
                 gbuf + 7 * (size_t)tiles_of(n_points) * kBlockF, (size_t)kBlockF};     // w0 = ghat_7: block 7 of gbuf ([block][tile])
-  if (is_h2(precision)) {
-    if (!absmax || !a2max) { set_error("svs_sdf_bwd_b: fp16x2 needs absmax and a2max"); return SVS_EINVAL; }
+  if (h2) {
+    if (!absmax) { set_error("svs_sdf_bwd_b: fp16x2 needs absmax"); return SVS_EINVAL; }
     return launch_sdf_bwd_b_h2(a, precision == kFmtF16x2, (hipStream_t)hip_stream);
   }
   if (precision != kFmtF32) { set_error("svs_sdf_bwd_b: unknown precision %d", precision); return SVS_EINVAL; }

@@ -23,14 +23,13 @@ struct SdfBwdAArgs {
   const float* d_grad;        // (P,3) nbar = d loss / d (d sdf/dx)
   const unsigned char* clamp_mask;  // (P) or nullptr: clamped points contribute no nbar
   const float* hbuf;          // [wave tiles][8][kBlockF] forward activations
-  const float* gbuf;          // [wave tiles][8][kBlockF] ghat_l = g(h_{l+1}) * s'(a_l) (svs_sdf_outputs)
+  const float* gbuf;          // [wave tiles][8][kBlockF] ghat_l = g(h_{l+1}) * s'(a_l) (svs_sdf_outputs); float32 kernels only
   const f32x4* stream;        // SDF training stream (pass A part at offset 0)
   float* ubuf;                // out [wave tiles][9][kBlockF]: block 0 = u_0 (PE order, first 2 tiles), blocks 1..8 = u_1..u_8
-  float* a2buf;               // out [wave tiles][8][kBlockF]
+  float* a2buf;               // out [wave tiles][8][kBlockF]; float32 kernels only (fp16x2: pass B re-forms a2 from ubuf and gbuf)
   float* pebuf;               // out [wave tiles][kBlockF]: h_0 = PE(x) in PE order (first 2 tiles), B operand of dW_0
   // fp16x2 only:
   float* absmax;              // [3]: [0] = max |u| (atomic max; caller zeroes)
-  float* a2max;               // out (padded P): max_l |a2_l| of each point (the scale floor of pass B)
 };
 
 struct SdfBwdBArgs {
@@ -39,13 +38,15 @@ struct SdfBwdBArgs {
   const unsigned char* clamp_mask;
   const float* feat_bar;      // [wave tiles][kBlockF] fbar (or nullptr: zero)
   int n_feat_tiles;           // wave tiles that have a feat_bar block (ray samples); later tiles (eikonal points) have none
-  const float* hbuf; const float* gbuf; const float* a2buf;
+  const float* hbuf; const float* gbuf;
+  const float* a2buf;         // float32 kernels: the second-order blocks pass A stored
+  const float* ubuf;          // fp16x2 foreground network: pass A's u blocks WITH their records (pass B re-forms a2 from them, gbuf
+                              // and gbuf's records)
   const f32x4* stream;        // SDF training stream, pass B part
   float* abuf;                // out [wave tiles][8][kBlockF] abar_0..abar_7
   float* sbar_out;            // out (padded P): the effective sbar (clamp applied), for the lin8 row-0 gradient; may be null
   // fp16x2 only:
   float* absmax;              // [3]: [0] = max |abar| (atomic max)
-  const float* a2max;         // (padded P) from pass A
   // the block holding ghat_7 = W8[0,:] s'(a_7) of a tile is w0 + tile * w0_stride (fg: gbuf block 7, stride 8 blocks)
   const float* w0; size_t w0_stride;
 };

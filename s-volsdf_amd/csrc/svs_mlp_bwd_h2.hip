@@ -195,31 +195,35 @@ __global__ __launch_bounds__(kThreads, 1) void rgb_bwd_h2_kernel(RgbBwdArgs a) {
 // ==============================================================================================================
 constexpr int kSpliceF = 20;     // floats per lane kept in LDS for the skip splice of pass A (tile 7 + 4 registers of tile 6)
 
-// a2 is stored under the scale of the u it is produced with, lowered by 2^7: a2 / u = 100 g(h) (1 - s') elementwise, and
-// g(h) = d sdf / d h is O(0.1 ... 10) -- the 2^11 of headroom above the point's u maximum then cover |g| up to ~2600
-constexpr float kA2Down = 1.0f / 128.0f;
-
+// Since round 5 pass A no longer forms the second-order blocks a2_l = v_l ghat_l 100 (1 - s'(a_l)): with u_{l+1} = v_l s'(a_l)
+// they are u_{l+1} ghat_l 100 (1 - s') / s', and pass B -- which reads h_{l+1} for s' anyway -- re-forms them from the stored
+// u_{l+1} and ghat_l blocks.  Pass A then neither reads gbuf (8 KB per point) nor writes a2buf (8 KB); pass B reads ubuf and
+// gbuf instead of a2buf (+8 KB): 8 KB per point less, and this kernel's GP instance no longer spills.  What pass B still
+// needs from here is a bound of max_r |a2_l| per point for its scale floor: the factor max_r |v_l| 100 (1 - s'(a_l)) goes into
+// the second half of u_{l+1}'s record, the other factor, max_r |ghat_l|, is in gbuf's records (sdf_full_h2_kernel).
 template <bool SPLIT, bool GP>
 struct PassAEpi {
   f32x16 prev;
-  TilePieces h, g;    // the stored h_{l+1} tile (softplus' only) and ghat_l: both pieces with GP, else the hi pieces
+  TilePieces h;       // the stored h_{l+1} tile (softplus' only): both pieces with GP, else the hi pieces
   float v, s1;
-  float v8[8], w8[8];
-  f16x8 a2p[2], up[2];
-  f16x8 a2q[2], uq[2];   // the mid pieces (GP)
+  float v8[8];
+  f16x8 up[2], uq[2]; // the pieces of u being stored (uq: mid, GP)
   Pieces2* out;       // u_{l+1} as the next operand (SPLIT)
   float* ublk;        // u_{l+1} block (scaled block: value * s_out)
-  float* a2blk;       // a2_l block (scaled block: value * s_out * kA2Down)
-  float* urec; float* a2rec;   // their records
+  float* urec;        // its record: [scale][max_r |v_l| 100 (1 - s'(a_l))]
   PointScale* ps;
   const float* splice;  // LDS: this lane's u_0 splice values, [kSpliceF][kThreads]
-  float a2m;          // running max |a2|
+  float vm;           // running max |v_l| 100 (1 - s')
   int lane, half;
-  bool l3;            // layer 3: the skip connection carries u_0 into rows >= 217 of u_4, a2 is zero there
+  bool l3;            // layer 3: the skip connection carries u_0 into rows >= 217 of u_4 (no second-order term there)
 
-  __device__ __forceinline__ void begin() {      // the records of the two blocks this layer writes
-    store_record(urec, lane, ps->s_out, 0.0f);
-    store_record(a2rec, lane, ps->s_out * kA2Down, 0.0f);
+  __device__ __forceinline__ void begin() {
+    if (lane < 32) urec[lane] = ps->s_out;
+    vm = 0.0f;
+  }
+  __device__ __forceinline__ void end() {        // the record's second half, once the layer's maximum is known
+    vm = __builtin_fmaxf(vm, __shfl_xor(vm, 32));
+    if (lane >= 32) urec[lane] = vm;
   }
   __device__ __forceinline__ void a(int r) {
     v = prev[r] * ps->inv_in;
@@ -229,23 +233,22 @@ struct PassAEpi {
   template <bool LATE = false>     // LATE: the stores wait for store_slot() (behind the tile's LDS-DMA pieces)
   __device__ __forceinline__ void b(int tp, int r) {
     float u = v * s1;
-    float a2 = v * grad_at<GP>(g, r) * (100.0f * (1.0f - s1));     // g = ghat_l = g(h_{l+1}) s'(a_l); s'' = 100 s' (1 - s')
+    float w = __builtin_fabsf(v) * (100.0f - 100.0f * s1);
     if (tp == 6 && r >= 12 && l3) {
       // local rows 25..31 of tile 6 (registers 13..15 of half 0, 12..15 of half 1) carry u_0[32..38]
       const bool sp = half == 1 || r >= 13;
       const float us = splice[(16 + (r - 12)) * kThreads];
       u = sp ? us : u;
-      a2 = sp ? 0.0f : a2;
+      w = sp ? 0.0f : w;
     }
-    pin(u); pin(a2);
-    emit<LATE>(tp, r, u, a2);
+    pin(u); pin(w);
+    emit<LATE>(tp, r, u, w);
   }
   template <bool LATE = false>
-  __device__ __forceinline__ void emit(int tp, int r, float u, float a2) {
-    a2m = __builtin_fmaxf(a2m, __builtin_fabsf(a2));
+  __device__ __forceinline__ void emit(int tp, int r, float u, float w) {
+    vm = __builtin_fmaxf(vm, w);
     ps->track(u);
     v8[r & 7] = u * ps->s_out;
-    w8[r & 7] = a2 * (ps->s_out * kA2Down);
     if ((r & 7) == 7) {
       const int k = 2 * tp + (r >> 3), q = r >> 3;
       if (SPLIT) {
@@ -258,70 +261,56 @@ struct PassAEpi {
       } else {
         up[q] = hi8(v8, 1.0f);
       }
-      if (GP) split8(w8, a2p[q], a2q[q]); else a2p[q] = hi8(w8, 1.0f);
-#ifdef SVS_EXP_A2_HI      // experiment: what a one-piece a2 block would do to the gradients (mid piece dropped, traffic unchanged)
-      if (GP) a2q[q] = (f16x8)(_Float16)0;
-#endif
-#ifdef SVS_EXP_U_HI       // experiment: the same for the STORED u block (the in-register operand of the next layer keeps both)
+#ifdef SVS_EXP_U_HI       // experiment: a one-piece STORED u block (the in-register operand of the next layer keeps both)
       if (GP) uq[q] = (f16x8)(_Float16)0;
 #endif
-#if defined(SVS_EXP_U_FP8) || defined(SVS_EXP_A2_FP8)   // experiment: the mid piece rounded to 3 mantissa bits (what an e4m3 mid
-      {                                                  // piece would keep), traffic unchanged
+#ifdef SVS_EXP_U_FP8      // experiment: the stored mid piece rounded to 3 mantissa bits (what an e4m3 mid piece would keep)
+      {
         typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
-        auto q8 = [](f16x8 v) { u16x8 b = __builtin_bit_cast(u16x8, v); b = (b + (unsigned short)0x40) & (unsigned short)0xFF80;
-                                return __builtin_bit_cast(f16x8, b); };
-#ifdef SVS_EXP_U_FP8
-        if (GP) uq[q] = q8(uq[q]);
-#endif
-#ifdef SVS_EXP_A2_FP8
-        if (GP) a2q[q] = q8(a2q[q]);
-#endif
+        u16x8 bb = __builtin_bit_cast(u16x8, uq[q]); bb = (bb + (unsigned short)0x40) & (unsigned short)0xFF80;
+        if (GP) uq[q] = __builtin_bit_cast(f16x8, bb);
       }
 #endif
-#if !(SVS_ABL & 2048)  // diagnostic: no u / a2 stores
-      if (!LATE) { store_grad<GP>(ublk, k, lane, up[q], uq[q]); store_grad<GP>(a2blk, k, lane, a2p[q], a2q[q]); }
+#if !(SVS_ABL & 2048)  // diagnostic: no u stores
+      if (!LATE) store_grad<GP>(ublk, k, lane, up[q], uq[q]);
 #endif
     }
   }
-  // k-step s of the tile whose MFMAs cover this epilogue: the four (GP: eight) stores of tile tp behind the last LDS-DMA piece
+  // k-step s of the tile whose MFMAs cover this epilogue: the two (GP: four) stores of tile tp behind the last LDS-DMA piece
   __device__ __forceinline__ void store_slot(int tp, int s) {
 #if SVS_ABL & 2048
     return;
 #endif
     if (s == 9) store_piece(ublk, 2 * tp, lane, up[0], 0);
-    if (GP && s == 10) store_piece(ublk, 2 * tp, lane, uq[0], 1);
-    if (s == 11) store_piece(a2blk, 2 * tp, lane, a2p[0], 0);
-    if (GP && s == 12) store_piece(a2blk, 2 * tp, lane, a2q[0], 1);
-    if (s == 15) { store_grad<GP>(ublk, 2 * tp + 1, lane, up[1], uq[1]); store_grad<GP>(a2blk, 2 * tp + 1, lane, a2p[1], a2q[1]); }
+    if (GP && s == 11) store_piece(ublk, 2 * tp, lane, uq[0], 1);
+    if (s == 15) store_grad<GP>(ublk, 2 * tp + 1, lane, up[1], uq[1]);
   }
   __device__ __forceinline__ void all(int tp) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { a(r); b(tp, r); }
   }
-  __device__ __forceinline__ void splice_tile7() {   // layer 3, tile 7: u = u_0[0..31], a2 = 0 (no MFMA)
+  __device__ __forceinline__ void splice_tile7() {   // layer 3, tile 7: u = u_0[0..31] (no MFMA)
 #pragma unroll
     for (int r = 0; r < 16; ++r) emit(7, r, splice[r * kThreads], 0.0f);
   }
 };
 
-// layer l >= 1 of pass A; hblk/gblk: blocks l of hbuf / gbuf.  LAST: no chunk follows the layer's last one.
+// layer l >= 1 of pass A; hblk: block l of hbuf.  LAST: no chunk follows the layer's last one.
 template <bool SPLIT, bool LAST, bool GP>
-__device__ __forceinline__ void pass_a_layer_h2(Stream& st, const Pieces2& in, PassAEpi<SPLIT, GP>& ep, const float* hblk,
-                                                const float* gblk, int lane) {
-  // Per tile: the side tiles h, ghat of tile t (two fragments each: their hi planes; four with GP) are requested in front
-  // of it (their epilogue runs during tile t+1); the next chunk's LDS-DMA pieces go behind k-steps 0..8
-  // (Stream::prefetch_step); the a2 / u stores of tile t-1's epilogue are issued in k-steps 9 .. 15: younger than every
-  // piece, they stay in flight across the tile's barrier.
+__device__ __forceinline__ void pass_a_layer_h2(Stream& st, const Pieces2& in, PassAEpi<SPLIT, GP>& ep, const float* hblk, int lane) {
+  // Per tile: the side tile h of tile t (two fragments: the hi plane; four with GP) is requested in front of it (its
+  // epilogue runs during tile t+1); the next chunk's LDS-DMA pieces go behind k-steps 0..8 (Stream::prefetch_step); the u
+  // stores of tile t-1's epilogue are issued in k-steps 9 .. 15: younger than every piece, they stay in flight across the
+  // tile's barrier.
   ep.begin();
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     if (t == 7 && ep.l3) break;
-    TilePieces hload, gload;
+    TilePieces hload;
 #if SVS_ABL & 1024     // diagnostic: no side-tile loads
-    hload = ep.h; gload = ep.g;
+    hload = ep.h;
 #else
     load_tile_grad<GP>(hblk, t, lane, hload);
-    load_tile_grad<GP>(gblk, t, lane, gload);
 #endif
     const bool fetch = !(LAST && t == 7);
     f32x16 acc;
@@ -329,14 +318,15 @@ __device__ __forceinline__ void pass_a_layer_h2(Stream& st, const Pieces2& in, P
     else if (t == 0) acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, NoEpi(), NoEpi());
     else acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, [&](int s) { ep.a(s); },
                                             [&](int s) { ep.template b<true>(t - 1, s); ep.store_slot(t - 1, s); });
-    ep.prev = acc; ep.h = hload; ep.g = gload;
+    ep.prev = acc; ep.h = hload;
     if (fetch) {
       if (t == 0) st.advance();
-      else st.advance_keep<GP ? 8 : 4>();
+      else st.advance_keep<GP ? 4 : 2>();
     }
   }
   if (ep.l3) { ep.all(6); ep.splice_tile7(); }
   else ep.all(7);
+  ep.end();
   ep.ps->next();
 }
 
@@ -359,12 +349,9 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_h2_kernel(SdfBwdAArgs a
   Pieces2 pa, pb;
   const size_t LS = block_stride();
   const float* hb = a.hbuf + (size_t)wtile * kBlockF;
-  const float* gb = a.gbuf + (size_t)wtile * kBlockF;
   float* ub = a.ubuf + (size_t)wtile * kBlockF;
-  float* a2 = a.a2buf + (size_t)wtile * kBlockF;
   const size_t T = (size_t)gridDim.x * kWaves;
   auto urec = [&](int l) { return record_ptr(a.ubuf, 9, T, l, wtile); };
-  auto a2rec = [&](int l) { return record_ptr(a.a2buf, 8, T, l, wtile); };
   {
     float x0, x1, x2;
     load_point(a.src, p, x0, x1, x2);
@@ -417,48 +404,42 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_h2_kernel(SdfBwdAArgs a
   }
   st.advance();
 
-  float a2m = 0.0f;
   {
     // ---- layer 0 (three k-steps per tile: the epilogue of tile t-1 follows tile t's MFMAs)
     PassAEpi<true, GP> ep;
-    ep.out = &pb; ep.ublk = ub + LS; ep.a2blk = a2; ep.urec = urec(1); ep.a2rec = a2rec(0); ep.ps = &ps; ep.splice = splice;
-    ep.a2m = 0.0f; ep.lane = lane; ep.half = half; ep.l3 = false;
+    ep.out = &pb; ep.ublk = ub + LS; ep.urec = urec(1); ep.ps = &ps; ep.splice = splice;
+    ep.lane = lane; ep.half = half; ep.l3 = false;
     ep.begin();
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      TilePieces hload, gload;
+      TilePieces hload;
       load_tile_grad<GP>(hb, t, lane, hload);
-      load_tile_grad<GP>(gb, t, lane, gload);
       if (t < 7) st.prefetch<kChunk0F4>(); else st.prefetch<kChunkF4>();
       const f32x16 acc = tile_mma_h2<3>(st.cur_buf(), pa, lane);
       if (t > 0) ep.all(t - 1);
-      ep.prev = acc; ep.h = hload; ep.g = gload;
+      ep.prev = acc; ep.h = hload;
       st.advance();
     }
     ep.all(7);
+    ep.end();
     ps.next();
-    a2m = ep.a2m;
   }
   // ---- layers 1..6: pb -> pa, copied back (one code body for all layers)
   for (int l = 1; l < 7; ++l) {
     PassAEpi<true, GP> ep;
-    ep.out = &pa; ep.ublk = ub + (size_t)(l + 1) * LS; ep.a2blk = a2 + (size_t)l * LS; ep.urec = urec(l + 1); ep.a2rec = a2rec(l);
-    ep.ps = &ps; ep.splice = splice; ep.a2m = a2m; ep.lane = lane; ep.half = half; ep.l3 = l == 3;
-    pass_a_layer_h2<true, false, GP>(st, pb, ep, hb + (size_t)l * LS, gb + (size_t)l * LS, lane);
-    a2m = ep.a2m;
+    ep.out = &pa; ep.ublk = ub + (size_t)(l + 1) * LS; ep.urec = urec(l + 1);
+    ep.ps = &ps; ep.splice = splice; ep.lane = lane; ep.half = half; ep.l3 = l == 3;
+    pass_a_layer_h2<true, false, GP>(st, pb, ep, hb + (size_t)l * LS, lane);
 #pragma unroll
     for (int s = 0; s < 16; ++s) { pb.h[s] = pa.h[s]; pb.m[s] = pa.m[s]; }
   }
-  // ---- layer 7: u_8 (only needed for the row-0 gradient of lin8) is stored, not split
+  // ---- layer 7: u_8 (needed for the row-0 gradient of lin8 and for pass B's a2_7) is stored, not split
   {
     PassAEpi<false, GP> ep;
-    ep.out = nullptr; ep.ublk = ub + (size_t)8 * LS; ep.a2blk = a2 + (size_t)7 * LS; ep.urec = urec(8); ep.a2rec = a2rec(7);
-    ep.ps = &ps; ep.splice = splice; ep.a2m = a2m; ep.lane = lane; ep.half = half; ep.l3 = false;
-    pass_a_layer_h2<false, true, GP>(st, pb, ep, hb + (size_t)7 * LS, gb + (size_t)7 * LS, lane);
-    a2m = ep.a2m;
+    ep.out = nullptr; ep.ublk = ub + (size_t)8 * LS; ep.urec = urec(8);
+    ep.ps = &ps; ep.splice = splice; ep.lane = lane; ep.half = half; ep.l3 = false;
+    pass_a_layer_h2<false, true, GP>(st, pb, ep, hb + (size_t)7 * LS, lane);
   }
-  a2m = __builtin_fmaxf(a2m, __shfl_xor(a2m, 32));
-  if (half == 0) a.a2max[p] = a2m;
   publish_max(a.absmax, ps.gmax);
 }
 
@@ -466,30 +447,45 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_a_h2_kernel(SdfBwdAArgs a
 // SDF MLP backward, pass B: hbar_8 = sbar W_8[0,:] + W_8[1:,:]^T fbar;  abar_l = hbar_{l+1} s'(a_l) + a2_l;
 //                           hbar_l = W_l^T abar_l
 // ==============================================================================================================
+// A2 (the foreground network): the second-order source a2_l = v_l ghat_l 100 (1 - s'(a_l)) of svs_mlp_bwd.hip is re-formed here
+// from what pass A stored, u_{l+1} = v_l s'(a_l):  a2_l = u_{l+1} ghat_l * 100 (1 - s') / s'  (s' from the h_{l+1} tile the
+// stage reads anyway; s' = 0 only where softplus underflowed to h = 0, and there u is 0 too: the quotient is guarded, the
+// product is 0).  Absolute errors stay those of the stored blocks: an error du of u becomes du ghat 100 (1 - s') / s' =
+// du * 100 g(h_{l+1}) (1 - s'), the size an error of v itself would have.
 template <bool FIRST, bool SPLIT, typename Net, bool A2, bool GP>
 struct PassBEpi {
+  static constexpr bool kG = A2 || FIRST;      // the stage reads a ghat tile (A2: ghat_l; FIRST: ghat_7 = W8[0,:] s'(a_7))
   f32x16 prev;
-  TilePieces h, a2, w0;    // h_{l+1} (softplus' only), a2_l (value * a2_scale), ghat_7: both pieces with GP, else the hi pieces
-  float v, s1;
+  TilePieces h, u, g;      // h_{l+1} (softplus' only), u_{l+1} (value * its block's scale), ghat_l: both pieces with GP, else hi
+  float v, s1, q;
   float v8[8];
   f16x8 ap[2], aq[2];      // the pieces of abar being stored (aq: mid, GP)
   Pieces2* out;
   float* ablk;             // abar_l block (scaled block: value * s_out)
   float* arec;             // its record
   PointScale* ps;
-  float sbar, a2_inv;      // a2_inv: 1 / (scale the a2 block was stored under)
+  float sbar, u_inv100;    // u_inv100: 100 / (scale the u block was stored under)
   int lane, half;
   bool l4;            // producing abar_3: rows >= 217 of h_4 are the PE splice
   __device__ __forceinline__ void a(int r) {
     v = prev[r] * ps->inv_in;
-    s1 = dsoftplus_from_h(grad_at<GP>(h, r));
+    const float e = __builtin_amdgcn_exp2f(grad_at<GP>(h, r) * (-100.0f * 1.44269504088896341f));   // 1 - s'
+    s1 = 1.0f - e;
+    if (A2) q = e * u_inv100;
     pin(v); pin(s1);
+    if (A2) pin(q);
   }
   template <bool LATE = false>
   __device__ __forceinline__ void b(int tp, int r) {
     float o = v * s1;
-    if (A2) o += grad_at<GP>(a2, r) * a2_inv;
-    if (FIRST) o += sbar * grad_at<GP>(w0, r);      // w0 = ghat_7 = W8[0,:] s'(a_7)
+    if (A2) {
+      const float gg = grad_at<GP>(g, r);
+      const float t = grad_at<GP>(u, r) * gg;
+      o += t * (q * __builtin_amdgcn_rcpf(__builtin_fmaxf(s1, 1e-30f)));
+      if (FIRST) o += sbar * gg;
+    } else if (FIRST) {
+      o += sbar * grad_at<GP>(g, r);      // ghat_7 = W8[0,:] s'(a_7)
+    }
     if (l4 && tp > Net::kSpliceTile) o = 0.0f;
     if (l4 && tp == Net::kSpliceTile) {
       const bool z0 = rho(r) >= Net::kSpliceLocal, z1 = rho(r) + 4 >= Net::kSpliceLocal;
@@ -499,18 +495,18 @@ struct PassBEpi {
     ps->track(o);
     v8[r & 7] = o * ps->s_out;
     if ((r & 7) == 7) {
-      const int k = 2 * tp + (r >> 3), q = r >> 3;
+      const int k = 2 * tp + (r >> 3), q2 = r >> 3;
       if (SPLIT) {
         split8(v8, out->h[k], out->m[k]);
         pin(out->h[k], out->m[k]);
-        ap[q] = out->h[k];
-        if (GP) aq[q] = out->m[k];
+        ap[q2] = out->h[k];
+        if (GP) aq[q2] = out->m[k];
       } else if (GP) {
-        split8(v8, ap[q], aq[q]);
+        split8(v8, ap[q2], aq[q2]);
       } else {
-        ap[q] = hi8(v8, 1.0f);
+        ap[q2] = hi8(v8, 1.0f);
       }
-      if (!LATE) store_grad<GP>(ablk, k, lane, ap[q], aq[q]);
+      if (!LATE) store_grad<GP>(ablk, k, lane, ap[q2], aq[q2]);
     }
   }
   __device__ __forceinline__ void store_slot(int tp, int s) {     // behind the tile's LDS-DMA pieces
@@ -523,41 +519,43 @@ struct PassBEpi {
   }
 };
 
-// one stage of pass B: in -> (W^T in) fused with abar of block `blk` (h, a2 from blocks blk; FIRST: + sbar W8[0,:])
+// one stage of pass B: in -> (W^T in) fused with abar_l (h_{l+1} from hblk; A2: u_{l+1} from ublk with its record urec and
+// ghat_l from gblk; FIRST without A2: ghat_7 from gblk).  next_floor: the scale floor of the NEXT stage's output.
 template <bool FIRST, bool SPLIT, bool LAST_STAGE, typename Net, bool A2, bool GP>
 __device__ __forceinline__ void pass_b_stage_h2(Stream& st, const Pieces2& in, PassBEpi<FIRST, SPLIT, Net, A2, GP>& ep, const float* hblk,
-                                                const float* a2blk, const float* a2rec, const float* w0blk, int lane) {
+                                                const float* ublk, const float* urec, const float* gblk, float next_floor, int lane) {
   // Per tile: the next chunk's LDS-DMA pieces behind k-steps 0..8 (Stream::prefetch_step), then -- younger than every
   // piece, left in flight across the tile's barrier -- the 2 abuf stores of tile t-1's epilogue (k-steps 9, 15; 4 with GP)
-  // and the loads of the side tiles (hi planes: two fragments each; with GP both planes: four) h, a2 (FIRST: and ghat_7)
-  // of tile t+1, which the epilogue of tile t+1 consumes during tile t+2.
+  // and the loads of the side tiles (hi planes: two fragments each; with GP both planes: four) h, u, ghat of tile t+1,
+  // which the epilogue of tile t+1 consumes during tile t+2.
+  constexpr bool kG = A2 || FIRST;
   store_record(ep.arec, lane, ep.ps->s_out, 0.0f);
-  ep.a2_inv = A2 ? PointScale::inv_pow2(load_scale(a2rec, lane)) : 0.0f;
-  TilePieces hnext, anext, wnext;
+  ep.u_inv100 = A2 ? 100.0f * PointScale::inv_pow2(load_scale(urec, lane)) : 0.0f;
+  TilePieces hnext, unext, gnext;
   load_tile_grad<GP>(hblk, 0, lane, hnext);
-  if (A2) load_tile_grad<GP>(a2blk, 0, lane, anext);
-  if (FIRST) load_tile_grad<GP>(w0blk, 0, lane, wnext);
+  if (A2) load_tile_grad<GP>(ublk, 0, lane, unext);
+  if (kG) load_tile_grad<GP>(gblk, 0, lane, gnext);
   constexpr int kPer = GP ? 4 : 2;
-  constexpr int kLoads = kPer * (1 + (A2 ? 1 : 0) + (FIRST ? 1 : 0));
+  constexpr int kLoads = kPer * (1 + (A2 ? 1 : 0) + (kG ? 1 : 0));
   constexpr int kStores = GP ? 4 : 2;
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
-    const TilePieces hcur = hnext, acur = anext, wcur = wnext;
+    const TilePieces hcur = hnext, ucur = unext, gcur = gnext;
     auto side = [&](int s) {
       if (t == 7) return;
       if (s == 10) hnext.h[0] = load_piece(hblk, 2 * (t + 1), lane);
       if (s == 11) hnext.h[1] = load_piece(hblk, 2 * (t + 1) + 1, lane);
-      if (A2 && s == 12) anext.h[0] = load_piece(a2blk, 2 * (t + 1), lane);
-      if (A2 && s == 13) anext.h[1] = load_piece(a2blk, 2 * (t + 1) + 1, lane);
-      if (FIRST && s == 14) wnext.h[0] = load_piece(w0blk, 2 * (t + 1), lane);
-      if (FIRST && s == 15) wnext.h[1] = load_piece(w0blk, 2 * (t + 1) + 1, lane);
+      if (A2 && s == 12) unext.h[0] = load_piece(ublk, 2 * (t + 1), lane);
+      if (A2 && s == 13) unext.h[1] = load_piece(ublk, 2 * (t + 1) + 1, lane);
+      if (kG && s == 14) gnext.h[0] = load_piece(gblk, 2 * (t + 1), lane);
+      if (kG && s == 15) gnext.h[1] = load_piece(gblk, 2 * (t + 1) + 1, lane);
       if (GP) {      // the mid planes, in the same gaps
         if (s == 10) hnext.m[0] = load_piece(hblk, 2 * (t + 1), lane, 1);
         if (s == 11) hnext.m[1] = load_piece(hblk, 2 * (t + 1) + 1, lane, 1);
-        if (A2 && s == 12) anext.m[0] = load_piece(a2blk, 2 * (t + 1), lane, 1);
-        if (A2 && s == 13) anext.m[1] = load_piece(a2blk, 2 * (t + 1) + 1, lane, 1);
-        if (FIRST && s == 14) wnext.m[0] = load_piece(w0blk, 2 * (t + 1), lane, 1);
-        if (FIRST && s == 15) wnext.m[1] = load_piece(w0blk, 2 * (t + 1) + 1, lane, 1);
+        if (A2 && s == 12) unext.m[0] = load_piece(ublk, 2 * (t + 1), lane, 1);
+        if (A2 && s == 13) unext.m[1] = load_piece(ublk, 2 * (t + 1) + 1, lane, 1);
+        if (kG && s == 14) gnext.m[0] = load_piece(gblk, 2 * (t + 1), lane, 1);
+        if (kG && s == 15) gnext.m[1] = load_piece(gblk, 2 * (t + 1) + 1, lane, 1);
       }
     };
     const bool fetch = !(LAST_STAGE && t == 7);
@@ -567,8 +565,8 @@ __device__ __forceinline__ void pass_b_stage_h2(Stream& st, const Pieces2& in, P
     else acc = tile_mma_h2_pf<16, kChunkF4>(st, in, lane, [&](int s) { ep.a(s); },
                                             [&](int s) { ep.template b<true>(t - 1, s); ep.store_slot(t - 1, s); }, side);
     ep.prev = acc; ep.h = hcur;
-    if (A2) ep.a2 = acur;
-    if (FIRST) ep.w0 = wcur;
+    if (A2) ep.u = ucur;
+    if (kG) ep.g = gcur;
     if (fetch) {
       if (t == 0) st.advance_keep<kLoads>();
       else if (t < 7) st.advance_keep<kLoads + kStores>();
@@ -576,6 +574,7 @@ __device__ __forceinline__ void pass_b_stage_h2(Stream& st, const Pieces2& in, P
     }
   }
   ep.all(7);
+  ep.ps->floor_m = next_floor;
   ep.ps->next();
 }
 
@@ -594,19 +593,25 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_h2_kernel(SdfBwdBArgs a
   if (half == 0 && a.sbar_out) a.sbar_out[p] = sbar;
   const size_t LS = block_stride();
   const float* hb = a.hbuf + (size_t)wtile * kBlockF;
-  const float* w0 = a.w0 + (size_t)wtile * a.w0_stride;
-  const float* a2 = A2 ? a.a2buf + (size_t)wtile * kBlockF : nullptr;
+  // A2: ghat_l = block l of gbuf; else only ghat_7, at w0 + tile * w0_stride (the background network keeps no other block)
+  const float* gb = A2 ? a.gbuf + (size_t)wtile * kBlockF : a.w0 + (size_t)wtile * a.w0_stride - 7 * LS;
+  const float* ub = A2 ? a.ubuf + (size_t)wtile * kBlockF : nullptr;
   float* ab = a.abuf + (size_t)wtile * kBlockF;
   const size_t T = (size_t)gridDim.x * kWaves;
   auto arec = [&](int l) { return record_ptr(a.abuf, 8, T, l, wtile); };
-  auto a2rec = [&](int l) { return A2 ? record_ptr(a.a2buf, 8, T, l, wtile) : nullptr; };
+  auto urec = [&](int l) { return A2 ? record_ptr(a.ubuf, 9, T, l, wtile) : nullptr; };
+  // >= max_r |a2_l| of this lane's point: (max_r |v_l| 100 (1 - s'), pass A) x (max_r |ghat_l|, sdf_full); with |sbar| (the
+  // other additive input, first stage) the floor of the scale abar_l is split under
+  const float asb = __builtin_fabsf(sbar);
+  auto floor_of = [&](int l) {
+    return A2 ? __builtin_fmaxf(asb, load_max(urec(l + 1), lane) * load_max(record_ptr(a.gbuf, 8, T, l, wtile), lane)) : asb;
+  };
   const bool has_f = a.feat_bar && wtile < a.n_feat_tiles;
   PointScale ps;
   Pieces2 pa, pb;
   {
-    // fbar (a scaled block under its recorded scale) is the first operand as it stands; the scale floor covers the additive
-    // inputs a2 and sbar * W8[0,:]
-    const float fl = __builtin_fmaxf(A2 ? a.a2max[p] : 0.0f, __builtin_fabsf(sbar));
+    // fbar (a scaled block under its recorded scale) is the first operand as it stands
+    const float fl = floor_of(7);
     if (has_f) {
       const float* fb = a.feat_bar + (size_t)wtile * kBlockF;
       // (feat_bar belongs to the launch over the ray samples only: its tile count is n_feat_tiles padded to workgroups)
@@ -626,18 +631,19 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_h2_kernel(SdfBwdBArgs a
   }
   st.advance();
   {
-    // hbar_8 fused with abar_7 (gbuf block 7 = ghat_7 = W8[0,:] s'(a_7), stored unscaled)
+    // hbar_8 fused with abar_7 (ghat_7 = W8[0,:] s'(a_7), stored unscaled)
     PassBEpi<true, true, Net, A2, GP> ep;
     ep.out = &pb; ep.ablk = ab + 7 * LS; ep.arec = arec(7); ep.ps = &ps; ep.sbar = sbar; ep.lane = lane; ep.half = half; ep.l4 = false;
-    pass_b_stage_h2<true, true, false, Net, A2, GP>(st, pa, ep, hb + 7 * LS, A2 ? a2 + 7 * LS : nullptr, a2rec(7), w0, lane);
+    pass_b_stage_h2<true, true, false, Net, A2, GP>(st, pa, ep, hb + 7 * LS, A2 ? ub + 8 * LS : nullptr, urec(8), gb + 7 * LS,
+                                                    floor_of(6), lane);
   }
   // layers 7..2: in = abar_l (pb), out = abar_{l-1} (pa, copied back: one code body for all layers)
   for (int l = 7; l >= 2; --l) {
     PassBEpi<false, true, Net, A2, GP> ep;
     ep.out = &pa; ep.ablk = ab + (size_t)(l - 1) * LS; ep.arec = arec(l - 1); ep.ps = &ps; ep.sbar = 0.0f; ep.lane = lane; ep.half = half;
     ep.l4 = l == 4;
-    pass_b_stage_h2<false, true, false, Net, A2, GP>(st, pb, ep, hb + (size_t)(l - 1) * LS, A2 ? a2 + (size_t)(l - 1) * LS : nullptr,
-                                                     a2rec(l - 1), nullptr, lane);
+    pass_b_stage_h2<false, true, false, Net, A2, GP>(st, pb, ep, hb + (size_t)(l - 1) * LS, A2 ? ub + (size_t)l * LS : nullptr, urec(l),
+                                                     A2 ? gb + (size_t)(l - 1) * LS : nullptr, floor_of(l >= 2 ? l - 2 : 0), lane);
 #pragma unroll
     for (int s = 0; s < 16; ++s) { pb.h[s] = pa.h[s]; pb.m[s] = pa.m[s]; }
   }
@@ -645,7 +651,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_h2_kernel(SdfBwdBArgs a
     // layer 1: abar_1 (in pb) -> abar_0, stored only
     PassBEpi<false, false, Net, A2, GP> ep;
     ep.out = nullptr; ep.ablk = ab; ep.arec = arec(0); ep.ps = &ps; ep.sbar = 0.0f; ep.lane = lane; ep.half = half; ep.l4 = false;
-    pass_b_stage_h2<false, false, true, Net, A2, GP>(st, pb, ep, hb, a2, a2rec(0), nullptr, lane);
+    pass_b_stage_h2<false, false, true, Net, A2, GP>(st, pb, ep, hb, A2 ? ub + LS : nullptr, urec(1), A2 ? gb : nullptr, asb, lane);
   }
   publish_max(a.absmax, ps.gmax);
 }

@@ -80,6 +80,7 @@ struct RevEpi {
   float v8[8];
   Pieces2* out;
   float* gblk;        // ghat_{l-1} block of gbuf (stored unscaled, format GP); GBUF only
+  float gm;           // GBUF: running max |ghat_{l-1}| of this lane's rows -> the block's record (pass B's scale floor)
   int lane, half;
   bool l4;            // l == 4: rows >= 217 of h_4 are the PE splice, they do not flow into lin3
 
@@ -105,6 +106,7 @@ struct RevEpi {
       if (z0 || z1) { if (half ? z1 : z0) v = 0.0f; }
     }
     pin(v);
+    if (GBUF) { gm = __builtin_fmaxf(gm, __builtin_fabsf(v)); pin(gm); }   // (pinned: LLVM re-associates the chain into a tree and keeps 16 values alive)
     v8[r & 7] = v;
     if ((r & 7) == 7 && !(DEFER && r == 15)) {
       const int k = 2 * tp + (r >> 3);
@@ -137,9 +139,10 @@ struct RevEpi {
 // reverse of trunk layer l (7..1): in = g(a_l) pieces, out = g(a_{l-1}) pieces
 template <bool GBUF, bool GP>
 __device__ __forceinline__ void reverse_layer_h2(Stream& st, const Pieces2& in, Pieces2& out, int l, const float* hb,
-                                                 float* gb, f32x16& skip6, f32x16& skip7, int lane, int half) {
+                                                 float* gb, float* grec0, size_t rec_stride, f32x16& skip6, f32x16& skip7, int lane,
+                                                 int half) {
   RevEpi<GBUF, GP> ep;
-  ep.out = &out; ep.lane = lane; ep.half = half; ep.l4 = l == 4;
+  ep.out = &out; ep.lane = lane; ep.half = half; ep.l4 = l == 4; ep.gm = 0.0f;
   const size_t LS = block_stride();
   ep.gblk = GBUF ? gb + (size_t)(l - 1) * LS : nullptr;
   const float* hblk = hb + (size_t)(l - 1) * LS;
@@ -186,6 +189,8 @@ __device__ __forceinline__ void reverse_layer_h2(Stream& st, const Pieces2& in, 
   }
   ep.template finish<true>(6);
   ep.all(7);
+  // the record of ghat_{l-1}: scale 1 (the block is stored unscaled), max |ghat_{l-1}| of the point
+  if (GBUF) store_record(grec0 + (size_t)(l - 1) * rec_stride, lane, 1.0f, __builtin_fmaxf(ep.gm, __shfl_xor(ep.gm, 32)));
 }
 
 template <bool GBUF, bool GP>
@@ -216,6 +221,10 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_h2_kernel(SdfFullArgs a)
 
   float* hb = a.hbuf + (size_t)wtile * kBlockF;                        // block l of this tile: + l * block_stride()
   float* gb = GBUF ? a.gbuf + (size_t)wtile * kBlockF : nullptr;
+  // gbuf's records (behind its slots, like a scaled buffer's: svs_sdf_gbuf_bytes): [1.0][max_r |ghat_l| of the point] per block
+  // and tile -- with the factor pass A leaves in u's records, pass B's bound of the a2 it re-forms (svs_mlp_bwd_h2.hip)
+  const size_t rec_stride = (size_t)gridDim.x * kWaves * kRecF;
+  float* grec0 = GBUF ? record_ptr(a.gbuf, 8, (size_t)gridDim.x * kWaves, 0, wtile) : nullptr;
   Pieces2 x, xn;
   float sdf;
   {
@@ -228,6 +237,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_h2_kernel(SdfFullArgs a)
     // x = h_8 (input of the feature head, split by the trunk), xn = g(a_7) = W8[0,:] * softplus'(a_7): the VEC chunk's
     // buffer is overwritten two prefetches from now, so its weights are consumed here
     const f32x4* w_ptr = st.cur_buf() + kHdrF4 + lane;
+    float gm7 = 0.0f;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       f32x16 g;
@@ -235,7 +245,10 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_h2_kernel(SdfFullArgs a)
       for (int q = 0; q < 4; ++q) {
         const f32x4 w = w_ptr[(4 * t + q) * 64];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) g[4 * q + j] = w[j] * dsoftplus_from_h(y8[t][4 * q + j]);
+        for (int j = 0; j < 4; ++j) {
+          g[4 * q + j] = w[j] * dsoftplus_from_h(y8[t][4 * q + j]);
+          if (GBUF) gm7 = __builtin_fmaxf(gm7, __builtin_fabsf(g[4 * q + j]));
+        }
       }
       // ghat_7 = W8[0,:] * softplus'(a_7), stored unscaled.  (x already holds the pieces of h_8: the trunk's last layer
       // split and stored them.)
@@ -245,6 +258,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_h2_kernel(SdfFullArgs a)
         store_grad<GP>(gb + 7 * block_stride(), 2 * t + 1, lane, xn.h[2 * t + 1], xn.m[2 * t + 1]);
       }
     }
+    if (GBUF) store_record(grec0 + 7 * rec_stride, lane, 1.0f, __builtin_fmaxf(gm7, __shfl_xor(gm7, 32)));
     st.advance();
   }
   SVS_STAMP(3, sdf)
@@ -280,8 +294,8 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_h2_kernel(SdfFullArgs a)
   f32x16 skip7 = (f32x16)(0.0f);   // g(PE[0..31]) from the skip connection (tile 7 of g(h_4 spliced))
   f32x16 skip6 = (f32x16)(0.0f);   // tile 6; only local rows 25..31 are PE[32..38]
   for (int l = 7; l >= 1; l -= 2) {
-    reverse_layer_h2<GBUF, GP>(st, xn, x, l, hb, gb, skip6, skip7, lane, half);
-    if (l > 1) reverse_layer_h2<GBUF, GP>(st, x, xn, l - 1, hb, gb, skip6, skip7, lane, half);
+    reverse_layer_h2<GBUF, GP>(st, xn, x, l, hb, gb, grec0, rec_stride, skip6, skip7, lane, half);
+    if (l > 1) reverse_layer_h2<GBUF, GP>(st, x, xn, l - 1, hb, gb, grec0, rec_stride, skip6, skip7, lane, half);
   }
   SVS_STAMP(5, skip7[0])
   // ---- reverse layer 0: g(PE) = W0^T g(a_0) (+ skip), 2 tiles; g(a_0) is in x

@@ -49,6 +49,7 @@ SIGNATURES = {
     "svs_sdf_vals": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, _P, c_int, c_float, c_float, c_int, _P, _P,
                              c_int, c_int, _P]),
     "svs_sdf_hbuf_bytes": (c_size_t, [c_int]),
+    "svs_sdf_gbuf_bytes": (c_size_t, [c_int]),
     "svs_feat_tiles_bytes": (c_size_t, [c_int]),
     "svs_sdf_outputs": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, _P, c_int, c_float, c_float, c_int, _P, _P,
                                 _P, _P, _P, _P, _P]),
@@ -60,8 +61,8 @@ SIGNATURES = {
     "svs_sdf_ubuf_bytes": (c_size_t, [c_int]),
     "svs_rgb_bwd": (c_int, [c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P]),
     "svs_sdf_bwd_a": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P, _P, _P,
-                              _P, _P, _P]),
-    "svs_sdf_bwd_b": (c_int, [c_int, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P]),
+                              _P, _P]),
+    "svs_sdf_bwd_b": (c_int, [c_int, _P, _P, _P, c_int, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P]),
     "svs_lin8_row0_grad": (c_int, [_P, _P, _P, c_int, c_int, _P, _P]),
     "svs_unpack_wgrad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "svs_unpack_wgrad_multi": (c_int, [_P, c_int, _P]),

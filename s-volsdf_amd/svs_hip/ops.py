@@ -194,7 +194,7 @@ def sdf_outputs(packed, src, sphere_radius, sphere_scale, want_feature_rows=Fals
     hbuf = torch.empty(L.svs_sdf_hbuf_bytes(src.n) // 4, device=dev)
     gbuf = mask = None
     if keep is not None:          # training: keep the gradient-pass state for the backward kernels
-        gbuf = torch.empty(L.svs_sdf_hbuf_bytes(src.n) // 4, device=dev)
+        gbuf = torch.empty(L.svs_sdf_gbuf_bytes(src.n) // 4, device=dev)      # 8 blocks + their records (max |ghat_l| per point)
         mask = torch.empty(src.n, dtype=torch.uint8, device=dev)
         keep.update(hbuf=hbuf, gbuf=gbuf, clamp_mask=mask, src=src)
     _lib.check(L.svs_sdf_outputs(*src.args(), _ptr(packed.sdf_stream), packed.precision, float(sphere_radius), float(sphere_scale),

@@ -150,11 +150,11 @@ class MlpBackward:
         self.zbuf = z(L.svs_rgb_zbuf_bytes(n_main))           # zero-initialised once: zbar_4 only writes its first tile
         self.feat_bar = z(L.svs_block_bytes(n_main, 1))
         self.ubuf = z(L.svs_sdf_ubuf_bytes(n_total))
-        self.a2buf = z(L.svs_block_bytes(n_total, 8))
+        # float32 kernels only: the fp16x2 pass B re-forms a2 from ubuf and gbuf (8 KB per point less traffic and memory)
+        self.a2buf = z(L.svs_block_bytes(n_total, 8)) if not is_h2(self.streams.precision) else None
         self.abuf = z(L.svs_block_bytes(n_total, 8))
         self.pebuf = z(L.svs_block_bytes(n_total, 1))
         self.sbar = z(L.svs_block_bytes(n_total, 1) // (128 * 2))  # 32 floats per tile
-        self.a2max = z(L.svs_block_bytes(n_total, 1) // (128 * 2))
         # d loss / d sdf of all points of the launch: the ray samples' part is rewritten every step (sdf_grad_out()), the
         # tail -- the eikonal points, which have no such term -- stays zero
         self.d_sdf_full = torch.zeros(n_total, device=self.dev)
@@ -255,7 +255,7 @@ class MlpBackward:
         st = _stream()
         _lib.check(L.svs_sdf_bwd_a(*src.args(), _ptr(d_grad), _ptr(mask), _ptr(hbuf), _ptr(gbuf), _ptr(S.sdf), prec,
                                    _ptr(self.ubuf), _ptr(self.a2buf), _ptr(self.pebuf),
-                                   _ptr(acc.absmax) if h2 else None, _ptr(self.a2max) if h2 else None, st), "svs_sdf_bwd_a")
+                                   _ptr(acc.absmax) if h2 else None, st), "svs_sdf_bwd_a")
         # Experiment (SVS_WGRAD_SPLIT=1 | auto; OFF by default): at small batches (config 4's 256 rays per GPU: the step is the
         # SUM of its kernels' latencies) the second-order half of the SDF weight gradients -- ghat_l x u_l^T, whose operands
         # are complete once pass A is -- as a launch of its own BESIDE pass B, on the radiance weight gradients' stream; the
@@ -278,8 +278,8 @@ class MlpBackward:
                 wgrad_multi(arr_2)
                 join2 = torch.cuda.Event(); join2.record(side_stream)
         _lib.check(L.svs_sdf_bwd_b(n_total, _ptr(d_sdf_full), _ptr(mask), _ptr(self.feat_bar), n_main, _ptr(hbuf),
-                                   _ptr(gbuf), _ptr(self.a2buf), _ptr(S.sdf), prec, _ptr(self.abuf), _ptr(self.sbar),
-                                   _ptr(acc.absmax) if h2 else None, _ptr(self.a2max) if h2 else None, st),
+                                   _ptr(gbuf), _ptr(self.a2buf), _ptr(self.ubuf), _ptr(S.sdf), prec, _ptr(self.abuf),
+                                   _ptr(self.sbar), _ptr(acc.absmax) if h2 else None, st),
                    "svs_sdf_bwd_b")
         # the first row of lin8's weight gradient: a 257-vector reduction over two blocks (0.04 ms alone).  On the side stream,
         # beside the weight-gradient launch, it was starved to the length of that launch (one workgroup of the GEMM per CU
@@ -448,8 +448,10 @@ def algorithmic_bytes_per_point(precision=None):
     bench.py's roofline prices).  One 256-feature block slot = 1024 bytes per point in float32
     (precision f32); on the fp16x2 path (csrc/svs_blocks_h2.h) a PAIR block is 1024 bytes per point, its hi plane alone
     512, a HALF block 512.
-      svs_sdf_bwd_a   reads h_1..h_8 (hi planes), ghat_0..ghat_7; writes u_0..u_8, a2_0..a2_7, the PE block
-      svs_sdf_bwd_b   reads h_1..h_8 (hi planes), a2_0..a2_7, ghat_7, fbar; writes abar_0..abar_7
+      svs_sdf_bwd_a   float32: reads h_1..h_8, ghat_0..ghat_7; writes u_0..u_8, a2_0..a2_7, the PE block
+                      fp16x2 (round 5): reads h_1..h_8; writes u_0..u_8, the PE block (a2 is re-formed by pass B)
+      svs_sdf_bwd_b   float32: reads h_1..h_8, a2_0..a2_7, ghat_7, fbar; writes abar_0..abar_7
+                      fp16x2: reads h_1..h_8 (hi planes in the one-piece mode), u_1..u_8, ghat_0..ghat_7, fbar; writes abar_0..abar_7
       wgrad_sdf       per layer abar_l, h_l (hi plane), ghat_l, u_l (l = 0..7) + fbar, h_8 (hi plane) for lin8
       wgrad_radiance  zbar_0..zbar_4, r_0..r_3 (hi planes), the feature block (hi plane), the 16 extra input rows"""
     precision = default_precision() if precision is None else precision
@@ -458,8 +460,8 @@ def algorithmic_bytes_per_point(precision=None):
         # sweeps / the weight gradient read of a pair block are 512 B
         half = 512 if precision == F16X2_HALF else 1024
         pair = 1024
-        return {"svs_sdf_bwd_a": 8 * half + 8 * half + 9 * half + 8 * half + pair,
-                "svs_sdf_bwd_b": 8 * half + 8 * half + half + half + 8 * half,
+        return {"svs_sdf_bwd_a": 8 * half + 9 * half + pair,
+                "svs_sdf_bwd_b": 8 * half + 8 * half + 8 * half + half + 8 * half,
                 "wgrad_sdf": 8 * (half + half + half + half) + half + half,
                 "wgrad_radiance": 5 * half + 4 * half + half + 128,
                 "svs_lin8_row0_grad": pair + half}

@@ -89,10 +89,10 @@ def main():
     dsf = torch.zeros(n_total, device=dev)
     row0 = torch.zeros(257, device=dev)
     t = timeit(lambda: lib.check(L.svs_sdf_bwd_a(*src.args(), P(d_grad), P(mask), P(hbuf), P(gbuf), P(bw.streams.sdf), prec,
-                                                 P(bw.ubuf), P(bw.a2buf), P(bw.pebuf), N(am), N(bw.a2max), st())))
+                                                 P(bw.ubuf), P(bw.a2buf), P(bw.pebuf), N(am), st())))
     res["sdf_bwd_a"] = dict(ms=t, tflops=n_total * 0.9 * F_SDF / t / 1e9)
-    t = timeit(lambda: lib.check(L.svs_sdf_bwd_b(n_total, P(dsf), P(mask), P(bw.feat_bar), n_main, P(hbuf), P(gbuf), P(bw.a2buf),
-                                                 P(bw.streams.sdf), prec, P(bw.abuf), P(bw.sbar), N(am), N(bw.a2max), st())))
+    t = timeit(lambda: lib.check(L.svs_sdf_bwd_b(n_total, P(dsf), P(mask), P(bw.feat_bar), n_main, P(hbuf), P(gbuf), P(bw.a2buf), P(bw.ubuf),
+                                                 P(bw.streams.sdf), prec, P(bw.abuf), P(bw.sbar), N(am), st())))
     res["sdf_bwd_b"] = dict(ms=t, tflops=n_total * F_SDF / t / 1e9)
     from svs_hip.train import block_stride, record_off
     LS = block_stride(n_total)

@@ -73,9 +73,9 @@ def main():
         "sdf_only": lambda: ops.sdf_vals(pk, src128, 3.0, 20.0),
         "sdf_full": lambda: ops.sdf_outputs(pk, src, 3.0, 20.0, clamp_n=n_main, keep={}),
         "bwd_a": lambda: lib.check(L.svs_sdf_bwd_a(*src.args(), P(d_grad), P(cmask), P(hbuf), P(gbuf), P(bw.streams.sdf), prec,
-                                                  P(bw.ubuf), P(bw.a2buf), P(bw.pebuf), P(am), P(bw.a2max), st())),
-        "bwd_b": lambda: lib.check(L.svs_sdf_bwd_b(n_total, P(dsf), P(cmask), P(bw.feat_bar), n_main, P(hbuf), P(gbuf), P(bw.a2buf),
-                                                  P(bw.streams.sdf), prec, P(bw.abuf), P(bw.sbar), P(am), P(bw.a2max), st())),
+                                                  P(bw.ubuf), P(bw.a2buf), P(bw.pebuf), P(am), st())),
+        "bwd_b": lambda: lib.check(L.svs_sdf_bwd_b(n_total, P(dsf), P(cmask), P(bw.feat_bar), n_main, P(hbuf), P(gbuf), P(bw.a2buf), P(bw.ubuf),
+                                                  P(bw.streams.sdf), prec, P(bw.abuf), P(bw.sbar), P(am), st())),
     }
 
     def timeit(fn, stream, n=6):
