@@ -100,8 +100,8 @@ def main():
     ap.add_argument("--graph", choices=["off", "on", "linear", "plan", "auto"], default="auto",
                     help="how the ~100 launches of a step are enqueued.  off: eager launches from Python; plan: the step's "
                          "captured sequence enqueued as plain launches by one library call (svs_plan_run); auto (default, also "
-                         "VolOpt's): plan for batches that run as one ray group (< 328 rays per GPU: the host-bound sizes), "
-                         "eager otherwise; on / linear: hipGraphLaunch of the capture (with its stream topology / as one chain)")
+                         "VolOpt's): plan for batches of less than two rounds of workgroups (< 656 rays per GPU of the DTU model, "
+                         "one or two ray groups: the host-bound sizes), eager otherwise; on / linear: hipGraphLaunch of the capture (with its stream topology / as one chain)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel event timing (roofline = null)")
     ap.add_argument("--no-host-timing", action="store_true",
                     help="skip the 18 extra steps that time the host's enqueueing (`host_enqueue_ms_per_step`): counter passes "
@@ -457,13 +457,13 @@ def _volopt_loop(rays, warm=60, steps=200, variants=("default", "sequential", "d
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
     --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a child and return its exit code (rank 0's
-    JSON line goes to this process's stdout).  Counting devices does not initialise the GPU; nothing else here does."""
+    JSON line goes to this process's stdout).  The parent never touches the HIP runtime: GPUs are counted from the KFD
+    topology in sysfs (gpu_count(); where that is not readable the children report what they find)."""
     import socket
     import subprocess
-    import torch
-    have = torch.cuda.device_count()
-    if have < n:
-        print(f"bench.py --gpus {n}: this box shows {have} GPU(s) (torch.cuda.device_count()); one rank per GPU is needed -- "
+    have = gpu_count()
+    if 0 < have < n or (have == 0 and not os.path.isdir("/sys/class/kfd/kfd/topology/nodes")):
+        print(f"bench.py --gpus {n}: this box shows {have} GPU(s) (KFD topology); one rank per GPU is needed -- "
               f"run with --gpus <= {have}" + (" (there is no CPU fallback of the product path)" if have == 0 else ""),
               file=sys.stderr, flush=True)
         return 2
@@ -726,13 +726,53 @@ def cpu_model_name():
     return "unknown"
 
 
+def physical_cores():
+    """physical cores of the host: distinct (physical id, core id) pairs of /proc/cpuinfo (None if it cannot be read)"""
+    try:
+        cores, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+        if core is not None:
+            cores.add((phys, core))
+        return len(cores) or None
+    except OSError:
+        return None
+
+
+def gpu_count():
+    """GPUs this process may use, WITHOUT touching the HIP runtime: the KFD topology lists every agent, GPUs are the nodes
+    with a non-zero simd_count (CPUs have 0); HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES narrow it."""
+    import glob
+    n = 0
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            props = dict(line.split()[:2] for line in open(f) if len(line.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def cpu_baseline(params, K, pose, train=True):
     """CPU port of the reference's PyTorch path on a bounded sample of the same workload: numpy oracle for the sampler and
     the MVS prior lookup, plain torch float32 autograd (oracle/torch_ref.py) for the differentiable part, clip + Adam.
-    Timed at 1 torch thread (what the reference's trainer forces, volsdf/vsdf.py:21) on 256 rays, at 32 threads on the
-    benchmark's own 1024-ray batch (and on 256 rays, to show that the step's cost is linear in the rays).  ALL host
-    threads (1 and all cores) were measured in round 4 and are an opt-in since: 256 torch threads
-    oversubscribe (see the plan below).  For this leg the oracle's exp / expm1 / row sum are
+    Sample: the first 256 rays of the benchmark's batch (the step is linear in the rays: the 1024-ray row shows it), median of
+    5 steps after 2 warm-ups at 1 torch thread (what the reference's trainer forces, volsdf/vsdf.py:21), at 32
+    threads and at ALL PHYSICAL cores ("1 and all cores"; counted from /proc/cpuinfo); all hardware threads
+    -- 256 on the round-4 box -- oversubscribe torch's intra-op pool (measured in round 4) and stay an opt-in; plus one
+    row on the full 1024-ray batch at 32 threads.  For this leg the oracle's exp / expm1 / row sum are
     bound to numpy's (the bit-exact restatements of torch's routines emulate float32 fma in float64 and would make the
     baseline slower than a CPU path is)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -783,8 +823,9 @@ def cpu_baseline(params, K, pose, train=True):
             # ALL host threads are not run by default: with torch's intra-op pool at 256 threads every small per-layer op
             # oversubscribes -- measured in round 4 on the GPU box: 197 s per 1024-ray step (5.2 rays/s) and 126 s per
             # 64-ray step (0.5 rays/s), against 5.8 s (177 rays/s) at 32 threads; SVS_CPU_BASELINE_ALL_THREADS=1 repeats it
-            plan = [(1, 256, 1, 2), (min(32, all_threads), 256, 1, 2), (min(32, all_threads), 1024, 1, 2)]
-            if all_threads > 32 and os.environ.get("SVS_CPU_BASELINE_ALL_THREADS") == "1":
+            phys = physical_cores() or all_threads
+            plan = [(1, 256, 2, 5), (min(32, all_threads), 256, 2, 5), (phys, 256, 2, 5), (min(32, all_threads), 1024, 1, 2)]
+            if all_threads > phys and os.environ.get("SVS_CPU_BASELINE_ALL_THREADS") == "1":
                 plan.append((all_threads, 64, 0, 1))
             seen = set()
             for threads, rays, warm, reps in plan:
@@ -806,18 +847,23 @@ def cpu_baseline(params, K, pose, train=True):
         finally:
             torch.set_num_threads(saved[0])
             orc.ref_exp, orc.ref_expm1, orc.ref_sum = saved[1:]
-    full = [r for r in rows if r["rays"] == 1024] or rows
-    best = max(full, key=lambda r: r["rays_per_s"])
+    sample = [r for r in rows if r["rays"] == 256 and r["reps"] >= 5] or rows
+    best = max(sample, key=lambda r: r["rays_per_s"])
     what = ("train step (numpy sampler + MVS prior lookup, torch float32 autograd, clip, Adam)" if train
             else "train-mode fast=1 forward, numpy oracle")
+    full = next((r for r in rows if r["rays"] == 1024), None)
     return {"value": best["rays_per_s"], "unit": "rays/s", "cores": best["threads"], "kind": "port",
-            "sample": f"{best['rays']} rays (the benchmark's batch) of the same {what}; median of {best['reps']} after "
-                      f"{best['warmups']} warm-up; 32 torch intra-op threads (the numpy parts are single-threaded); 1 thread is "
-                      f"timed on 256 rays (the step is linear in the rays: compare the two 32-thread rows); all {all_threads} host threads "
-                      "oversubscribe torch's intra-op pool (measured once in round 4: 5.2 rays/s on this batch, 0.5 rays/s on 64 "
-                      "rays) and are not part of the default run",
+            "sample": f"{best['rays']} rays of the benchmark's 1024-ray batch through the same {what}; median of {best['reps']} "
+                      f"steps after {best['warmups']} warm-ups at 1, 32 and {phys} (= all physical cores) torch intra-op threads, the "
+                      "best of the three reported (the numpy parts are single-threaded); the step is linear in the rays "
+                      "(`full_batch_rays_per_s`: the whole 1024-ray batch at 32 threads, median of 2 after 1); all "
+                      f"{all_threads} hardware threads oversubscribe torch's intra-op pool (round 4: 5.2 rays/s) and are an opt-in "
+                      "(SVS_CPU_BASELINE_ALL_THREADS=1)",
             "single_thread_rays_per_s": next(r["rays_per_s"] for r in rows if r["threads"] == 1),
-            "all_threads_rays_per_s": next((r["rays_per_s"] for r in rows if r["threads"] == all_threads), None),
+            "physical_cores": phys,
+            "all_physical_cores_rays_per_s": next((r["rays_per_s"] for r in rows if r["threads"] == phys and r["rays"] == 256), None),
+            "all_threads_rays_per_s": next((r["rays_per_s"] for r in rows if r["threads"] == all_threads and all_threads != phys), None),
+            "full_batch_rays_per_s": full["rays_per_s"] if full else None,
             "runs": rows, "host_cpu": cpu_model_name(), "host_threads": all_threads}
 
 

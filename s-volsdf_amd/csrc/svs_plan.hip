@@ -28,8 +28,7 @@ constexpr int kMaxStreams = 12;
 struct Node {
   hipGraphNodeType type;
   hipKernelNodeParams k;
-  hipMemcpy3DParms c;
-  hipMemsetParams m;
+  hipMemsetParams m;            // (copy nodes are refused at build time: no parameters of theirs are kept)
   int stream = 0;
   int record = -1;              // event recorded behind this node (it has a successor on another stream)
   std::vector<int> wait;        // events this node's stream waits for in front of it
@@ -44,7 +43,7 @@ struct Plan {
   std::vector<int> entry_waiters;     // streams != 0 that start with a root node: they wait for `entry`
   hipEvent_t entry = nullptr;
   std::vector<hipEvent_t> tails;      // per stream != 0: recorded behind its last node, stream 0 waits for it
-  int n_kernels = 0, n_copies = 0, n_memsets = 0, n_empty = 0;
+  int n_kernels = 0, n_memsets = 0, n_empty = 0;
   long long runs = 0;
 };
 
@@ -277,7 +276,10 @@ static int run(Plan* p, hipStream_t s0) {
         hipError_t e = hipErrorInvalidDeviceFunction;
         if (!nd.via_module) {
           e = hipLaunchKernel(k.func, k.gridDim, k.blockDim, k.kernelParams, k.sharedMemBytes, st);
-          if (e != hipSuccess && p->runs == 0) {
+          // a node captured from a module launch carries a hipFunction_t, which hipLaunchKernel does not know: only THAT
+          // error switches the node over (any other -- a bad launch configuration -- is the caller's to see)
+          if ((e == hipErrorInvalidDeviceFunction || e == hipErrorInvalidSymbol || e == hipErrorNotFound ||
+               e == hipErrorInvalidResourceHandle) && p->runs == 0) {
             (void)hipGetLastError();
             nd.via_module = true;
           }
@@ -286,14 +288,6 @@ static int run(Plan* p, hipStream_t s0) {
           e = hipModuleLaunchKernel((hipFunction_t)k.func, k.gridDim.x, k.gridDim.y, k.gridDim.z, k.blockDim.x, k.blockDim.y,
                                     k.blockDim.z, k.sharedMemBytes, st, k.kernelParams, k.kernelParams ? nullptr : k.extra);
         PLAN_CHECK(e);
-        break;
-      }
-      case hipGraphNodeTypeMemcpy: {
-        const hipMemcpy3DParms& c = nd.c;
-        if (c.extent.height <= 1 && c.extent.depth <= 1 && !c.srcArray && !c.dstArray)
-          PLAN_CHECK(hipMemcpyAsync(c.dstPtr.ptr, c.srcPtr.ptr, c.extent.width, c.kind, st));
-        else
-          PLAN_CHECK(hipMemcpy3DAsync(&c, st));
         break;
       }
       case hipGraphNodeTypeMemset: {
@@ -343,7 +337,7 @@ int svs_plan_info(void* plan, int* counts) {
   const svs::plan::Plan* p = (const svs::plan::Plan*)plan;
   counts[0] = (int)p->nodes.size();
   counts[1] = p->n_kernels;
-  counts[2] = p->n_copies;
+  counts[2] = 0;                 // copy nodes: always 0 (svs_plan_build refuses them)
   counts[3] = p->n_memsets;
   counts[4] = p->n_empty;
   counts[5] = (int)p->streams.size();
@@ -369,11 +363,6 @@ int svs_plan_describe(void* plan, char* text, size_t capacity) {
                             nd.k.sharedMemBytes);
         break;
       }
-      case hipGraphNodeTypeMemcpy:
-        len = std::snprintf(line, sizeof line, "%zu s%d memcpy dst %p src %p extent %zu,%zu,%zu kind %d", q, nd.stream,
-                            nd.c.dstPtr.ptr, nd.c.srcPtr.ptr, nd.c.extent.width, nd.c.extent.height, nd.c.extent.depth,
-                            (int)nd.c.kind);
-        break;
       case hipGraphNodeTypeMemset:
         len = std::snprintf(line, sizeof line, "%zu s%d memset dst %p value %u elem %u width %zu height %zu", q, nd.stream,
                             nd.m.dst, nd.m.value, nd.m.elementSize, nd.m.width, nd.m.height);

@@ -524,15 +524,30 @@ int svs_wgrad_multi(const svs_wgrad_job* jobs, int n_jobs, int precision, void* 
       }
     }
     ma.n_jobs = n;
-    // ~one workgroup per CU in total, split in proportion to the work, at least one each and no more than tiles
+    // One workgroup per CU in total, at least one per job and no more than a job has tiles; the rest are handed out one at a
+    // time to the job whose workgroups carry the most work (the launch lasts as long as its longest workgroup: with jobs of
+    // very different sizes -- a step's two ray groups in one launch -- rounding each share on its own left a small job's
+    // single workgroup with a third more tiles than anybody else)
+    (void)total;
     const int n_wg_total = 256;
+    int count[h2::kMaxJobs];
+    int used = 0;
+    for (int j = 0; j < n; ++j) { count[j] = 1; ++used; }
+    while (used < n_wg_total) {
+      int best = -1;
+      double load = 0.0;
+      for (int j = 0; j < n; ++j) {
+        if (count[j] >= ma.job[j].n_tiles) continue;
+        const double l = (double)work[j] / count[j];
+        if (l > load) { load = l; best = j; }
+      }
+      if (best < 0) break;
+      ++count[best]; ++used;
+    }
     int begin = 0;
     for (int j = 0; j < n; ++j) {
-      long long c = (work[j] * n_wg_total + total / 2) / total;
-      if (c < 1) c = 1;
-      if (c > ma.job[j].n_tiles) c = ma.job[j].n_tiles;
-      ma.job[j].wg_begin = begin; ma.job[j].wg_count = (int)c;
-      begin += (int)c;
+      ma.job[j].wg_begin = begin; ma.job[j].wg_count = count[j];
+      begin += count[j];
     }
     static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(h2::wgrad_h2_multi_kernel<false>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, h2::Ring<false>::kLdsBytes);

@@ -95,11 +95,14 @@ _HWC_BUDGET = int(os.environ.get("SVS_HWC_CACHE_BYTES", str(1 << 30)))
 
 
 def clear_caches():
-    """Drop the cached channel-last feature maps and projection constants (end of a scan / stage loop)."""
+    """Drop the cached channel-last feature maps and projection constants, and the prior look-up's per-view constants (end of
+    a scan / stage loop; StageLoop calls it per scan, VolOpt.get_mvs_input per stage)."""
     global _HWC_BYTES
     _HWC_CACHE.clear()
     _RT_CACHE.clear()
     _HWC_BYTES = 0
+    from . import ops
+    ops.clear_lookup_caches()
 
 
 class SplitVolume:

@@ -458,6 +458,14 @@ def _host_f32(t):
 _LOOKUP_CONSTS = {}
 
 
+def clear_lookup_caches():
+    """Drop the cached per-view constants of cost_lookup and the host copies of camera matrices -- with them the references
+    that keep a stage's probability volumes and depth ranges on the GPU (called when a new MVS stage hands over its volumes:
+    VolOpt.get_mvs_input, costvol.clear_caches)."""
+    _LOOKUP_CONSTS.clear()
+    _HOST_COPIES.clear()
+
+
 def cost_lookup(views, same_view, img_res, *, xyz=None, cam=None, dirs=None, z=None, inverse_depth=False,
                 same_view_dev=None):
     """VolOpt.cost_mapping (volsdf/vsdf.py:382-452).
@@ -488,6 +496,7 @@ def cost_lookup(views, same_view, img_res, *, xyz=None, cam=None, dirs=None, z=N
         vp = (ctypes.c_float * (17 * V))()
         dims = (ctypes.c_int * (3 * V))()
         keep, cost_p, near_p, far_p = [], [], [], []
+        copied = False
         for j, v in enumerate(views):
             K, c2w = _host_f32(v["K"]), _host_f32(v["c2w"])
             vals = [K[0, 0], K[1, 1], K[0, 2], K[1, 2], K[0, 1]] + [c2w[i, k] for i in range(3) for k in range(4)]
@@ -499,12 +508,19 @@ def cost_lookup(views, same_view, img_res, *, xyz=None, cam=None, dirs=None, z=N
                 zn, zf = _f32(zm[0]), _f32(zm[-1])
             else:
                 zn, zf = _f32(v["z_near"]), _f32(v["z_far"])
-            keep += [cost, zn, zf, v["K"], v["c2w"]]              # (kept alive: the key holds their addresses)
+            # kept alive: the key holds the addresses of the ORIGINAL tensors (v["cost"], z range) -- not only those of the
+            # float32 / contiguous copies _f32 may have made -- so neither can be recycled while the entry lives
+            keep += [cost, zn, zf, v["K"], v["c2w"], v["cost"], v.get("z_mvs"), v.get("z_near"), v.get("z_far")]
+            copied = copied or cost.data_ptr() != v["cost"].data_ptr()
             cost_p.append(cost); near_p.append(zn); far_p.append(zf)
             dims[3 * j], dims[3 * j + 1], dims[3 * j + 2] = cost.shape
-        if len(_LOOKUP_CONSTS) >= 16:
+        if len(_LOOKUP_CONSTS) >= 4:
             _LOOKUP_CONSTS.clear()
-        hit = _LOOKUP_CONSTS[key] = (vp, dims, _ptr_array(cost_p), _ptr_array(near_p), _ptr_array(far_p), keep)
+        hit = (vp, dims, _ptr_array(cost_p), _ptr_array(near_p), _ptr_array(far_p), keep)
+        if not copied:
+            # (a volume _f32 had to convert -- not float32 or not contiguous -- is looked up from a private copy: the original
+            # may change without its address changing, so such a call is not cached)
+            _LOOKUP_CONSTS[key] = hit
     vp, dims, cost_arr, near_arr, far_arr, _ = hit
     pj = torch.empty(R, S, device=dev)
     pi = torch.empty(R, S, device=dev)

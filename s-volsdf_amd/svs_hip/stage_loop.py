@@ -19,8 +19,10 @@ class StageLoop:
         self.feature_calls = 0
 
     def clear(self):
-        """forget the cached features (new scan)"""
+        """forget the cached features (new scan) and what the cost-volume / prior look-up wrappers cached for the old one"""
         self._features.clear()
+        from . import costvol
+        costvol.clear_caches()
 
     @staticmethod
     def _fingerprint(img):

@@ -172,14 +172,18 @@ class MlpBackward:
         self._alloc(n_total, n_main)
         return self.d_sdf_full[:n_main].view(n_main, 1)
 
-    def accumulate(self, keep, d_rgb, d_sdf, d_grad_extra, wait=True, side=True):
+    def accumulate(self, keep, d_rgb, d_sdf, d_grad_extra, wait=True, side=True, defer_wgrad=False, extra=None):
         """Launches the backward of one ray group on the current stream (+ a side stream for the radiance weight
         gradients) and adds its weight gradients into self.accum.  Returns the event that marks the end of the side
         stream's work; wait=True also makes the current stream wait for it.  (A caller that runs groups on forked streams
         passes wait=False and lets its ORIGIN stream wait for the event: see trainer.TrainStep._device_step.)
         keep: dict filled by ops.sdf_outputs / ops.rgb_eval (hbuf, gbuf, clamp_mask, src, rbuf, feat_tiles, rgb).
         d_rgb (n_main,3); d_sdf (n_main,1) or None; d_grad_extra (n_extra,3) or None: dL/d(d sdf/dx) of the extra
-        (eikonal) points that follow the ray samples in the launch."""
+        (eikonal) points that follow the ray samples in the launch.
+        defer_wgrad: only the sweeps run (radiance backward, pass A, pass B, lin8's first row); the group's weight-gradient
+        JOBS are returned instead of launched -- dict(rgb=[jobs], sdf=[jobs], ev_rgb, ev_all, key) -- for another group's
+        call to take along as `extra`: that call's two weight-gradient launches then cover both groups (a small ray group's
+        own launches cost a ring fill and one workgroup per CU each for a twentieth of the points)."""
         L = _lib.load()
         src = keep["src"]
         n_total, n_main = src.n, keep["rgb"].shape[0]
@@ -208,6 +212,23 @@ class MlpBackward:
             arr, n = cached
             _lib.check(L.svs_wgrad_multi(arr, n, prec, _stream()), "svs_wgrad_multi")
 
+        def job_list(key, build):
+            """the group's own jobs (ctypes structures), built once per configuration"""
+            hit = self._job_cache.get(key)
+            if hit is None:
+                if len(self._job_cache) >= 64:
+                    self._job_cache.clear()
+                hit = self._job_cache[key] = build()
+            return hit
+
+        def job_array(key, own, more):
+            """own jobs (+ those of a folded-in group) as the array one launch takes"""
+            key = ("arr",) + key + ((more["key"],) if more else ())
+            hit = self._job_cache.get(key)
+            if hit is None:
+                return self._cache_jobs(key, list(own) + (list(more["jobs"]) if more else []))
+            return hit[:2]
+
         # ---- radiance MLP: input gradients
         d_rgb = _f32(d_rgb)
         d_normals = torch.empty(n_main, 3, device=dev)
@@ -231,26 +252,34 @@ class MlpBackward:
         if os.environ.get("SVS_RGB_WGRAD_SIDE", "1") == "0":   # A/B switch: the radiance weight gradients in line, in front of pass A
             side = False
         side_stream = self._side if side else main          # side=False: everything on the current stream
-        fork = torch.cuda.Event(); fork.record(main)
-        with torch.cuda.stream(side_stream):
-            if side:
-                side_stream.wait_event(fork)
-            # the job lists are a function of the buffers' addresses and the point counts: built once per configuration (a
-            # step's scratch comes back at the same addresses from torch's caching allocator), ~40 ctypes structures a step
-            rkey = ("rgb", n_main, prec, self.zbuf.data_ptr(), feat.data_ptr(), rbuf.data_ptr(), acc.dWk.data_ptr())
-            arr_r = self._job_cache.get(rkey)
-            arr_r = arr_r[:2] if arr_r is not None else None
-            if arr_r is None:
-                LSm = block_stride(n_main)          # rbuf = [4 blocks][tile] + extras [tile][1024], zbuf = [5 blocks][tile]
-                zrec = lambda l: _off(self.zbuf, record_off(n_main, 5, l))
-                jobs = [job(9, n_main, 1, _off(self.zbuf, 0), KBLOCK, _ptr(feat), KBLOCK, extra=_off(rbuf, 4 * LSm), sx=1024,
-                            rec0=zrec(0))]
-                for l in range(1, 5):
-                    jobs.append(job(9 + l, n_main, 1, _off(self.zbuf, l * LSm), KBLOCK, _off(rbuf, (l - 1) * LSm), KBLOCK,
-                                    rec0=zrec(l)))
-                arr_r = self._cache_jobs(rkey, jobs)
-            wgrad_multi(arr_r)
-            join = torch.cuda.Event(); join.record(side_stream)
+        # the job lists are a function of the buffers' addresses and the point counts: built once per configuration (a
+        # step's scratch comes back at the same addresses from torch's caching allocator), ~40 ctypes structures a step
+        rkey = ("rgb", n_main, prec, self.zbuf.data_ptr(), feat.data_ptr(), rbuf.data_ptr(), acc.dWk.data_ptr())
+
+        def rgb_jobs():
+            LSm = block_stride(n_main)          # rbuf = [4 blocks][tile] + extras [tile][1024], zbuf = [5 blocks][tile]
+            zrec = lambda l: _off(self.zbuf, record_off(n_main, 5, l))
+            jobs = [job(9, n_main, 1, _off(self.zbuf, 0), KBLOCK, _ptr(feat), KBLOCK, extra=_off(rbuf, 4 * LSm), sx=1024,
+                        rec0=zrec(0))]
+            for l in range(1, 5):
+                jobs.append(job(9 + l, n_main, 1, _off(self.zbuf, l * LSm), KBLOCK, _off(rbuf, (l - 1) * LSm), KBLOCK,
+                                rec0=zrec(l)))
+            return jobs
+
+        deferred = None
+        if defer_wgrad:
+            ev_rgb = torch.cuda.Event(); ev_rgb.record(main)
+            deferred = dict(rgb=dict(jobs=job_list(rkey, rgb_jobs), key=rkey), ev_rgb=ev_rgb)
+            join = None
+        else:
+            fork = torch.cuda.Event(); fork.record(main)
+            with torch.cuda.stream(side_stream):
+                if side:
+                    side_stream.wait_event(fork)
+                if extra is not None:
+                    side_stream.wait_event(extra["ev_rgb"])
+                wgrad_multi(job_array(rkey, job_list(rkey, rgb_jobs), extra["rgb"] if extra else None))
+                join = torch.cuda.Event(); join.record(side_stream)
         # ---- SDF MLP: pass A (needs nbar), pass B (needs sbar, fbar), then its weight gradients
         st = _stream()
         _lib.check(L.svs_sdf_bwd_a(*src.args(), _ptr(d_grad), _ptr(mask), _ptr(hbuf), _ptr(gbuf), _ptr(S.sdf), prec,
@@ -262,7 +291,8 @@ class MlpBackward:
         # first-order half (abar_l x h_l^T, bias gradients) after pass B.  Same sums, same accumulators (gradient tests pass)
         # -- and measured SLOWER at every size: 1.46 against 1.42 ms at 256 rays, 1.17 / 1.145 at 128, 2.37 / 2.28 at 512
         # (A/B three times on one box): the second launch's ~70 us of ring fill outweigh what runs under pass B.
-        split = h2 and side and (_WGRAD_SPLIT == "1" or (_WGRAD_SPLIT == "auto" and n_total <= 40960))
+        split = h2 and side and not defer_wgrad and extra is None and \
+            (_WGRAD_SPLIT == "1" or (_WGRAD_SPLIT == "auto" and n_total <= 40960))
         join2 = None
         if split:
             k2 = ("sdf2", n_total, prec, self.ubuf.data_ptr(), gbuf.data_ptr(), acc.dWk.data_ptr())
@@ -285,7 +315,7 @@ class MlpBackward:
         # beside the weight-gradient launch, it was starved to the length of that launch (one workgroup of the GEMM per CU
         # leaves it a quarter of the register file): it runs in front of it on this stream
         # (experiment, SVS_PLAN_BRANCHES=1: in a captured sequence on the radiance weight gradients' stream after all)
-        row0_aside = side and _PLAN_BRANCHES and torch.cuda.is_current_stream_capturing()
+        row0_aside = side and not defer_wgrad and _PLAN_BRANCHES and torch.cuda.is_current_stream_capturing()
         if row0_aside:
             after_b = torch.cuda.Event(); after_b.record(main)
             with torch.cuda.stream(side_stream):
@@ -301,9 +331,8 @@ class MlpBackward:
             ev[0].record()
         skey = ("sdf1" if split else "sdf", n_total, n_main, prec, self.abuf.data_ptr(), self.ubuf.data_ptr(), self.pebuf.data_ptr(),
                 hbuf.data_ptr(), gbuf.data_ptr(), self.feat_bar.data_ptr(), acc.dWk.data_ptr())
-        arr_s = self._job_cache.get(skey)
-        arr_s = arr_s[:2] if arr_s is not None else None
-        if arr_s is None:
+
+        def sdf_jobs():
             arec = lambda l: _off(self.abuf, record_off(n_total, 8, l))
             urec = lambda l: _off(self.ubuf, record_off(n_total, 9, l))
             second = (lambda l: dict(a1=_off(gbuf, l * LS), sa1=KBLOCK, b1=_off(self.ubuf, l * LS), sb1=KBLOCK, rec1=urec(l))) \
@@ -314,8 +343,16 @@ class MlpBackward:
                                 **second(l)))
             jobs.append(job(8, n_main, 2, _ptr(self.feat_bar), KBLOCK, _off(hbuf, 7 * LS), KBLOCK,
                             rec0=_off(self.feat_bar, record_off(n_main, 1, 0))))
-            arr_s = self._cache_jobs(skey, jobs)
-        wgrad_multi(arr_s)
+            return jobs
+
+        if defer_wgrad:
+            deferred["sdf"] = dict(jobs=job_list(skey, sdf_jobs), key=skey)
+            deferred["ev_all"] = torch.cuda.Event(); deferred["ev_all"].record(main)
+            deferred["hold"] = self._hold = (d_grad, d_sdf_full, d_normals, d_rgb)
+            return deferred
+        if extra is not None:
+            main.wait_event(extra["ev_all"])
+        wgrad_multi(job_array(skey, job_list(skey, sdf_jobs), extra["sdf"] if extra else None))
         if ev:
             ev[1].record()
         if join2 is not None and not row0_aside:

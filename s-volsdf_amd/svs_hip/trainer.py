@@ -101,6 +101,10 @@ def allreduce_flat_grad(flat_grad, world):
 # against 1.495 with the background model -- the branches' stream crossings and the fifth busy stream cost what they save.
 _PLAN_BRANCHES = os.environ.get("SVS_PLAN_BRANCHES", "0") == "1"
 _SMALL_GROUP_INLINE = os.environ.get("SVS_SMALL_GROUP_INLINE", "0") == "1"     # A/B: the small ray group's radiance weight gradients in line
+# Two ray groups: the second (small) group only runs its sweeps; its weight-gradient jobs ride along in the first group's two
+# launches (train.MlpBackward.accumulate, defer_wgrad / extra).  The small group's own launches cost a ring fill and a
+# workgroup per CU each for 5 % of the points: 0.46 + 0.2 ms of kernel time per step beside the large group's (round 4).
+_FOLD_WGRAD = os.environ.get("SVS_FOLD_WGRAD", "1") == "1"
 
 
 class _GroupedOutputs(dict):
@@ -370,6 +374,15 @@ class TrainStep:
             return False
         return self.graph != "auto" or self._auto_plans(R)
 
+    def inputs_changed(self):
+        """Tell the captured steps that a DEVICE-resident input (uv, intrinsics, pose, target colours) was modified in place by
+        something torch does not see -- a kernel of this library or any other raw-pointer writer leaves `tensor._version`
+        untouched.  A captured step copies a device input into its static buffer only when it is a new tensor object or
+        its version moved (the bench's resident batch is copied once, not every step); host inputs are always staged anew,
+        new device tensors and in-place torch ops are noticed by themselves.  Eager steps read the inputs directly."""
+        for cs in self._captured.values():
+            cs.static.pop("_seen", None)
+
     def _auto_plans(self, R):
         """graph == "auto": launch plans where the step is short enough for the host to matter -- batches of less than two
         rounds of 256 workgroups x 128 points (< 656 rays of the DTU model; config 4 over 8 GPUs runs 256 per GPU).  Measured
@@ -630,10 +643,14 @@ class TrainStep:
         # right in front of that launch -- the model calls the hook -- and the sampler and the fused SDF launch start ~20 us
         # earlier than when the origin stream waited here, in front of the fork)
         fork = torch.cuda.Event(); fork.record(main)
-        results, joins, holds = [], [], []
+        results, joins, holds = [None] * len(groups), [], [None] * len(groups)     # (in group order whatever the enqueue order)
         # d loss / d beta of a group: one group writes it straight into the flat gradient, several into slots that are summed
         beta_out = (lambda gi: self.beta_grad.view(1)) if len(groups) == 1 else (lambda gi: sc.d_beta[gi:gi + 1])
-        for gi, (lo, hi) in enumerate(groups):
+        fold = _FOLD_WGRAD and len(groups) == 2 and not serial
+        folded = None
+        # (folded: the small group is enqueued FIRST, on its side stream, so that the events the large group's weight-gradient
+        # launches wait for exist when those launches are enqueued)
+        for gi, (lo, hi) in (list(enumerate(groups))[::-1] if fold else enumerate(groups)):
             stream = main if gi == 0 else sc.sides[gi - 1]
             with torch.cuda.stream(stream):
                 if gi:
@@ -715,10 +732,14 @@ class TrainStep:
                         d_beta_out=beta_out(gi))
                 if d_beta.data_ptr() != beta_out(gi).data_ptr():
                     beta_out(gi).copy_(d_beta)
-                joins.append(sc.bwd[gi].accumulate(keep, d_rgb, d_sdf, g["grad_theta"], wait=False,
-                                                   side=not serial and not (gi and _SMALL_GROUP_INLINE)))
-                results.append((lo_out, out))
-                holds.append((keep, g, d_sdf, d_rgb, inp, g_gt))
+                if fold and gi == 1:
+                    folded = sc.bwd[gi].accumulate(keep, d_rgb, d_sdf, g["grad_theta"], wait=False, side=False, defer_wgrad=True)
+                else:
+                    joins.append(sc.bwd[gi].accumulate(keep, d_rgb, d_sdf, g["grad_theta"], wait=False,
+                                                       side=not serial and not (gi and _SMALL_GROUP_INLINE),
+                                                       extra=folded if (fold and gi == 0) else None))
+                results[gi] = (lo_out, out)
+                holds[gi] = (keep, g, d_sdf, d_rgb, inp, g_gt, folded)
                 if gi:
                     ev = torch.cuda.Event(); ev.record(stream); joins.append(ev)
         for ev in joins:
@@ -921,8 +942,12 @@ class TrainStep:
                         raise
                     import warnings
                     warnings.warn(f"launch plan refused, this configuration replays its hipGraph instead: {e}")
+                    cs.plan = None
                     graph.instantiate()
-                if os.environ.get("SVS_PLAN_DEBUG") == "1":
+                    if os.environ.get("SVS_PLAN_DEBUG") == "1":
+                        import sys
+                        print(f"launch plan refused: {e}", file=sys.stderr)
+                if cs.plan is not None and os.environ.get("SVS_PLAN_DEBUG") == "1":
                     import sys
                     print(cs.plan.info, file=sys.stderr)
                     print(cs.plan.describe(), file=sys.stderr)

@@ -143,6 +143,39 @@ def sync_host_rng(world):
 
 
 _RESAMPLE_IS_REFERENCE = {}
+_PREFIX_CHECK = {}
+
+
+def randperm_prefix_matches_torch(n=442368, k=1024):
+    """One self-check per process and size: `svs_randperm_prefix` rests on internals of THIS torch -- the serialised layout of
+    the CPU generator (mt19937, 5056 bytes), ATen's forward Fisher-Yates `randperm` and its n < 2^32 / 20 branch (tested against
+    torch 2.10; the reference pins 1.9).  On a private generator it must return torch.randperm(n)[:k] AND leave the generator
+    where torch leaves it (state bytes and the next draw); otherwise the dataset's own method is used (warned once)."""
+    hit = _PREFIX_CHECK.get((n, k))
+    if hit is None:
+        hit = False
+        try:
+            from svs_hip import lib as _lib
+            g = torch.Generator()
+            g.manual_seed(0x5EED5)
+            torch.randint(0, 10, (3,), generator=g)                 # (not at a state boundary of the twister)
+            state = g.get_state().clone()
+            want = torch.randperm(n, generator=g)[:k]
+            out = torch.empty(k, dtype=torch.int64)
+            rc = _lib.load().svs_randperm_prefix(state.data_ptr(), state.numel(), n, k, out.data_ptr())
+            if rc == 0 and torch.equal(out, want) and torch.equal(state, g.get_state()):
+                g2 = torch.Generator()
+                g2.set_state(state)
+                hit = bool(torch.equal(torch.rand(5, generator=g2), torch.rand(5, generator=g)))
+        except Exception:
+            hit = False
+        if not hit:
+            import warnings
+            warnings.warn("svs_randperm_prefix does not reproduce this torch's randperm (generator layout or shuffle changed): "
+                          "pixel batches are drawn by the dataset's own change_sampling_idx")
+        _PREFIX_CHECK[(n, k)] = hit
+    return hit
+
 
 
 def change_sampling_idx(dataset, sampling_size):
@@ -170,7 +203,8 @@ def change_sampling_idx(dataset, sampling_size):
         n, sampling_size = int(n), int(sampling_size)
     except (TypeError, ValueError):
         ok = False
-    if not ok or sampling_size == -1 or not 0 <= sampling_size <= n or not 1 <= n < (1 << 32) // 20:
+    if not ok or sampling_size == -1 or not 0 <= sampling_size <= n or not 1 <= n < (1 << 32) // 20 or \
+            not randperm_prefix_matches_torch(n, sampling_size):
         return dataset.change_sampling_idx(sampling_size)
     from svs_hip import lib as _lib
     state = torch.get_rng_state()
@@ -615,6 +649,10 @@ class VolOpt():
 
     # ---- MVS prior (vsdf.py:369-452) ---------------------------------------------------------------------------------------------------
     def get_mvs_input(self, outs_samples):
+        # the previous stage's volumes go first: nothing may keep them on the GPU while this stage's are built (the per-view
+        # dicts of _mvs_views and the look-up's constant cache hold references to them)
+        self.__dict__.pop("_mvs_view_cache", None)
+        ops.clear_lookup_caches()
         self.costs, self.z_mvs, self.bd_mvs = dict(), dict(), dict()
         sphere = self.conf.get_float('model.scene_bounding_sphere')
         for i in range(len(outs_samples)):

@@ -412,6 +412,24 @@ def fx_forward_r256_more():
          **{k: out[k].detach().numpy() for k in keep if k in out})
 
 
+def fx_forward_r1024_train():
+    """The DTU model's TRAIN-mode forward (fast = 1) of the reference at the bench batch size, 1024 rays (configs[1]):
+    integrated outputs and eikonal gradients of every ray, the per-sample arrays of every 8th ray (size)."""
+    params = dict(synth.make_params(seed=0))
+    K, pose = synth.make_camera(center=(0.1, 0.05, -2.5), tilt=0.1)
+    R = 1024
+    uv = synth.make_uv(R, seed=29, margin=0.05)
+    inp = {"intrinsics": T(K)[None], "uv": T(uv)[None], "pose": T(pose)[None]}
+    m = build_model(params, beta=0.05)
+    m.train()
+    with inject_rng(synth.make_train_rng(R, seed=37)):
+        out = m(inp, fast=1)
+    o = {k: out[k].detach().numpy() for k in ("rgb_values", "depth_values", "depth_vals", "weights", "grad_theta")}
+    save("forward1024_train_b0.05", K=K, pose=pose, uv=uv, beta_param=F32(0.05), fast=1, rng_seed=37, every=8,
+         rgb_values=o["rgb_values"], depth_values=o["depth_values"], grad_theta=o["grad_theta"],
+         depth_vals=o["depth_vals"][::8], weights=o["weights"][::8])
+
+
 def fx_composite():
     params = synth.make_params(seed=0)
     m = build_model(params, beta=0.03)
@@ -625,8 +643,7 @@ def fx_casmvs():
         arr[f"s{st}_reg"] = cap["reg"][0, 0]
         arr[f"s{st}_depth"] = o["depth"][0].numpy() if st else None
         arr[f"s{st}_conf"] = o["photometric_confidence"][0].numpy()
-        if st == 0:
-            arr[f"s{st}_prob"] = o["prob_volume"][0].numpy()
+        arr[f"s{st}_prob"] = o["prob_volume"][0].numpy()       # what cost_mapping consumes, at every stage
         arr[f"s{st}_depth_values"] = o["depth_values"][0].numpy()
     # stage-1 depth before the override
     arr["s0_depth"] = (arr["stage1_depth_override"] - 4.0) / 0.98
@@ -1037,7 +1054,7 @@ ALL = dict(fusion=fx_fusion, filter_depth=fx_filter_depth, pfm=fx_pfm, chamfer=f
            train_step_w1=lambda: fx_train_step(16, 2, "train_step_w1", "w1"),
            train_step_bg=fx_train_step_bg,
            train_step_bg_sparse=lambda: fx_train_step_bg("train_step_bg_sparse", 50, 1e3, 1),
-           sampler_r256=fx_sampler_r256, sampler_r256_more=fx_sampler_r256_more, forward_r256_more=fx_forward_r256_more, sampler_hostexp=fx_sampler_hostexp, primitives=fx_primitives)
+           sampler_r256=fx_sampler_r256, sampler_r256_more=fx_sampler_r256_more, forward_r256_more=fx_forward_r256_more, forward_r1024_train=fx_forward_r1024_train, sampler_hostexp=fx_sampler_hostexp, primitives=fx_primitives)
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(ALL)

@@ -88,8 +88,9 @@ def test_three_stage_forward_golden(dev, golden_dir):
         np.testing.assert_allclose(o["depth"][0].cpu().numpy(), g[f"s{st}_depth"], rtol=2e-5)
         dconf = np.abs(o["photometric_confidence"][0].cpu().numpy() - g[f"s{st}_conf"])
         assert (dconf > 1e-4).mean() < 0.01
+        # the probability volume -- what VolOpt.cost_mapping looks up -- at every stage
+        np.testing.assert_allclose(o["prob_volume"][0].cpu().numpy(), g[f"s{st}_prob"], atol=2e-5, err_msg=f"prob stage {st + 1}")
         if st == 0:
-            np.testing.assert_allclose(o["prob_volume"][0].cpu().numpy(), g["s0_prob"], atol=2e-5)
             ov = G(g["stage1_depth_override"], dev)[None]
             outputs["stage1"]["depth"] = ov
             outputs["depth"] = ov

@@ -492,6 +492,31 @@ def test_model_forward_r256_train(dev, golden_dir):
     np.testing.assert_allclose(out["grad_theta"][256:], g["grad_theta"][256:], atol=5e-3)       # at the sampler's extra depths
 
 
+def test_model_forward_r1024_train(dev, golden_dir):
+    """The bench geometry (configs[1]): VolSDFNetwork.forward in TRAIN mode on 1024 rays against the REFERENCE's forward
+    (fixture forward1024_train_b0.05; round 4 pinned this size only in eval mode and against the oracle): colours to 1e-4,
+    depths to 2e-4, eikonal gradients on every ray; per-sample weights on every 8th ray where the sample did not move."""
+    from rng_inject import inject_rng
+    g = dict(np.load(os.path.join(golden_dir, "forward1024_train_b0.05.npz")))
+    m, _ = _model(dev, float(g["beta_param"]))
+    m.train()
+    inp = {"intrinsics": G(g["K"], dev)[None], "uv": G(g["uv"], dev)[None], "pose": G(g["pose"], dev)[None]}
+    with inject_rng(synth.make_train_rng(1024, seed=int(g["rng_seed"]))):
+        out = {k: v.detach().cpu().numpy() for k, v in m(inp, fast=1).items() if torch.is_tensor(v)}
+    ev = int(g["every"])
+    sub = dict(depth_vals=out["depth_vals"][::ev])
+    moved = _moved(sub, g)
+    print(f"forward1024_train: rgb max err on all rays {np.abs(out['rgb_values'] - g['rgb_values']).max():.2e}, "
+          f"{int(moved.sum())} of {moved.size} samples (every {ev}th ray) moved")
+    np.testing.assert_allclose(out["rgb_values"], g["rgb_values"], atol=1e-4)
+    np.testing.assert_allclose(out["depth_values"], g["depth_values"], atol=2e-4)
+    np.testing.assert_allclose(out["grad_theta"][:1024], g["grad_theta"][:1024], atol=2e-4)     # the uniform eikonal points
+    np.testing.assert_allclose(out["grad_theta"][1024:], g["grad_theta"][1024:], atol=5e-3)     # at the sampler's extra depths
+    rays = ~moved.any(1)         # (a moved sample changes its neighbours' interval lengths, hence their weights)
+    assert rays.mean() > 0.9
+    np.testing.assert_allclose(out["weights"][::ev][rays], g["weights"][rays], atol=1e-4)
+
+
 def test_model_forward_vs_oracle_1024(dev):
     """Full-size batch (1024 rays): integrated outputs against the oracle within 1e-4 / 2e-4 on every ray."""
     m, params = _model(dev, 0.1)

@@ -87,3 +87,43 @@ def test_volopt_resample_keeps_the_batches():
     o = Other()
     vsdf.change_sampling_idx(o, 7)
     assert o.calls == 1 and torch.equal(o.sampling_idx, torch.arange(7)) and vsdf._RESAMPLE_IS_REFERENCE[Other] is False
+
+
+def test_randperm_prefix_self_check_and_fallback(monkeypatch):
+    """The per-process self-check of the routine against THIS torch's randperm (volsdf.vsdf.randperm_prefix_matches_torch): it
+    passes here, leaves the default generator alone, and where it fails -- a torch whose generator layout or shuffle differs,
+    simulated by a library call that returns other indices -- the dataset's own method draws the batch."""
+    import warnings
+    import synthetic_scene
+    from svs_hip import lib
+    from volsdf import vsdf
+    vsdf._PREFIX_CHECK.clear()
+    before = torch.get_rng_state()
+    assert vsdf.randperm_prefix_matches_torch(576 * 768, 1024) and vsdf.randperm_prefix_matches_torch(48 * 64, 200)
+    assert torch.equal(before, torch.get_rng_state())
+    ds = synthetic_scene.SyntheticSceneDataset(img_res=(48, 64))
+    real = lib.load()
+
+    class Broken:
+        def __getattr__(self, name):
+            return getattr(real, name)
+
+        def svs_randperm_prefix(self, state, nbytes, n, k, out):
+            rc = real.svs_randperm_prefix(state, nbytes, n, k, out)
+            torch.frombuffer((ctypes.c_int64 * max(k, 1)).from_address(out), dtype=torch.int64)[:1] += 1
+            return rc
+
+    import ctypes
+    vsdf._PREFIX_CHECK.clear()
+    monkeypatch.setattr(lib, "load", lambda: Broken())
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        torch.manual_seed(9)
+        vsdf.change_sampling_idx(ds, 200)
+        got = ds.sampling_idx.clone()
+        after = torch.rand(3)
+    assert any("svs_randperm_prefix" in str(x.message) for x in w)
+    torch.manual_seed(9)
+    ds.change_sampling_idx(200)
+    assert torch.equal(got, ds.sampling_idx) and torch.equal(after, torch.rand(3))
+    vsdf._PREFIX_CHECK.clear()

@@ -21,7 +21,7 @@ run graph --graph on
 run graph256 --graph on --rays 256
 run bmvs256 --model bmvs --rays 256
 run bmvs128 --model bmvs --rays 128
-# launch mode: the default is `auto` (launch plans below 328 rays, eager launches above)
+# launch mode: the default is `auto` (launch plans below 656 rays, eager launches above)
 run eager256 --graph off --rays 256
 run eager_bmvs256 --graph off --model bmvs --rays 256
 run eager_bmvs128 --graph off --model bmvs --rays 128
