@@ -78,8 +78,12 @@ def block_bytes():
 
 def main():
     if len(sys.argv) == 3 and sys.argv[1] == "--volopt-child":
-        rays, warm, steps, variants = sys.argv[2].split(":")
-        print(json.dumps(_volopt_loop(int(rays), int(warm), int(steps), tuple(variants.split(",")))))
+        rays, warm, steps, variants = sys.argv[2].split(":")[:4]
+        model = (sys.argv[2].split(":") + ["dtu"])[4]
+        print(json.dumps(_volopt_loop(int(rays), int(warm), int(steps), tuple(variants.split(",")), model=model)))
+        return
+    if len(sys.argv) == 3 and sys.argv[1] == "--allreduce-child":
+        print(json.dumps(_allreduce_one_rank(int(sys.argv[2]))))
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -371,6 +375,9 @@ def main():
                 # config 4's per-GPU share when its 2048-ray batch is sharded over 8 GPUs: the loop at 256 rays (launch plans;
                 # the host side decides here)
                 line["volopt_run_256_rays"] = volopt_loop(256, variants=("default",))
+            if not args.no_extras:
+                l256 = line.get("volopt_run_256_rays", line["volopt_run"]).get("default", {}).get("ms_per_step")
+                line["config4"] = config4_extra(dtu_loop_256_ms=l256)
         if world == 1 and train and args.model == "dtu" and not args.no_extras:
             # the other configurations of BASELINE.json, as extras measured after the timed region (same process, same box):
             # configs[2] = the CasMVSNet cost volume (tools/bench_costvol.py), and whole-image eval rendering, the
@@ -411,7 +418,83 @@ def volopt_loop(rays, warm=60, steps=200, variants=("default", "sequential", "de
         return res
 
 
-def _volopt_loop(rays, warm=60, steps=200, variants=("default", "sequential", "device_batches")):
+def _allreduce_one_rank(n_floats, reps=200):
+    """torch.distributed.all_reduce (RCCL) of the flat float32 gradient in a ONE-rank process group on this GPU: what the
+    collective's call costs a step before any byte crosses xGMI (the step's only collective, trainer.TrainStep)."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in os.environ:
+        import socket
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(s.getsockname()[1]); s.close()
+    os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", device_id=dev)
+    g = torch.randn(n_floats, device=dev)
+    for _ in range(20):
+        dist.all_reduce(g)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dist.all_reduce(g)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    dist.destroy_process_group()
+    return {"ms": ms, "bytes": 4 * n_floats, "ranks": 1}
+
+
+def _child_json(argv, timeout=900):
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv, capture_output=True, text=True, timeout=timeout)
+    # (the last JSON line: RCCL's banner is flushed to stdout when the process exits, behind it)
+    return json.loads(next(l for l in reversed(r.stdout.strip().splitlines()) if l.startswith("{")))
+
+
+def config4_extra(dtu_loop_256_ms=None):
+    """BASELINE.json configs[3]: a 2048-ray batch sharded over the 8 GPUs of a node = 256 rays per GPU + one all-reduce of the
+    flat gradient.  No 8-GPU node is the builder's to run on, so this is a PROJECTION from one GPU, stated as such: the bare
+    step at 2048 and at 256 rays, `VolOpt.run` end to end at 256 rays (the loop a runner.py user gets: DataLoader, pixel draw,
+    launch plan), the all-reduce call in a one-rank RCCL group, for the fg + background model (config 4's) and the DTU model;
+    projected_strong_scaling_8 = t(2048 rays, 1 GPU) / (t(256-ray loop) + t(all-reduce)).  The all-reduce term is given twice:
+    as measured with one rank (no xGMI traffic) and as a model of the 8-rank ring over xGMI (2 x 7/8 of the buffer per GPU at
+    one link's ~50 GB/s effective, + 20 us per ring phase latency x 2 phases -- MI355X_MICROARCH.md's xGMI figures)."""
+    quick = ["--no-cpu-baseline", "--no-exact-f32", "--no-gpu-torch", "--no-extras", "--no-volopt-loop", "--no-other-scaling",
+             "--no-kernel-timing", "--steps", "100"]
+    out = {}
+    for model, n_grad in (("bmvs", 1361387), ("dtu", 797883)):
+        row = {}
+        try:
+            for rays in (2048, 256):
+                d = _child_json(["--model", model, "--rays", str(rays)] + quick)
+                row[f"step_ms_{rays}_rays"] = d["ms_per_step"]
+                row[f"launch_{rays}_rays"] = d["config"]["launch"][:40]
+            if model == "dtu" and dtu_loop_256_ms is not None:
+                row["volopt_run_ms_256_rays"] = dtu_loop_256_ms
+            else:
+                row["volopt_run_ms_256_rays"] = _child_json(["--volopt-child", f"256:60:200:default:{model}"])["default"]["ms_per_step"]
+            ar = _child_json(["--allreduce-child", str(n_grad)])
+            row["allreduce_one_rank_ms"] = ar["ms"]
+            row["gradient_bytes"] = ar["bytes"]
+            ring = 1e3 * (2 * 7 / 8 * ar["bytes"] / 50e9) + 0.04
+            row["allreduce_8_rank_ring_model_ms"] = ring
+            t1 = row["step_ms_2048_rays"]
+            row["projected_strong_scaling_8"] = t1 / (row["volopt_run_ms_256_rays"] + ar["ms"])
+            row["projected_strong_scaling_8_ring_model"] = t1 / (row["volopt_run_ms_256_rays"] + ring)
+            row["projected_strong_scaling_8_bare_step"] = t1 / (row["step_ms_256_rays"] + ar["ms"])
+        except Exception as e:                                   # noqa: BLE001 -- an extra must not cost the bench line
+            row["error"] = repr(e)[:200]
+        out[model] = row
+    out["note"] = ("PROJECTION from one GPU, no 8-GPU curve was measured here: configs[3] shards ONE 2048-ray batch over 8 GPUs "
+                   "(256 rays each, SURVEY.md 8e); projected_strong_scaling_8 = step_ms_2048_rays / (volopt_run_ms_256_rays + "
+                   "allreduce_one_rank_ms), `_ring_model` with the modelled 8-rank xGMI ring instead, `_bare_step` with the bare "
+                   "256-ray step instead of the VolOpt.run loop; north_star asks >= 6")
+    return out
+
+
+def _volopt_loop(rays, warm=60, steps=200, variants=("default", "sequential", "device_batches"), model="dtu"):
     """What a runner.py user gets: `VolOpt.run` (the reference's optimisation loop, volsdf/vsdf.py:322-367) end to end on a
     synthetic in-memory scene with the SceneDataset interface at 576 x 768 (tests/synthetic_scene.py: full pixel grid per
     item, the reference's `change_sampling_idx`, one torch thread, as the reference's dataset does), `rays` pixels per
@@ -431,6 +514,12 @@ def _volopt_loop(rays, warm=60, steps=200, variants=("default", "sequential", "d
             if name not in variants:
                 continue
             a = tv.make_args()
+            if model == "bmvs":                          # config 4: fg + inverted-sphere background model on a BlendedMVS-style scan
+                import copy
+                from volsdf.utils.conf import bmvs_model_conf
+                a["vol"]["model"] = copy.deepcopy(dict(bmvs_model_conf()))
+                a["vol"]["train"]["model_class"] = "volsdf.model.network_bg.VolSDFNetworkBG"
+                a["vol"]["dataset"]["data_dir"] = "BlendedMVS"
             a["vol"]["dataset"]["img_res"] = [576, 768]
             a["vol"]["train"].update(num_pixels=rays, render_freq=10 ** 9, checkpoint_freq=10 ** 9)
             a["max_h"], a["max_w"] = 576, 768

@@ -102,3 +102,132 @@ class DeviceBatches:
                 nxt = draw()
             torch.cuda.current_stream(self.device).wait_event(ev)
             yield cur
+
+
+class CachedItems(torch.utils.data.Dataset):
+    """The reference's train items without their per-item image-sized work -- the SAME batches and the same use of the
+    random generators, for the DataLoader loop that stays the default (`VolOpt.gen_dataset` wraps the train dataset in this;
+    SVS_CACHED_ITEMS=0 or `cached_items=False` turns it off).
+
+    `SceneDataset.__getitem__` (volsdf/datasets/scene_dataset.py:211-253) rebuilds the whole pixel grid with numpy for
+    every item (`np.mgrid`, flip, copy, transpose: 442 368 x 2 values at 576 x 768), gathers `num_pixels` rows of it and of the
+    two images, and the collate stacks -- copies -- the view's full mask image (5.3 MB): 1.2 ms of host work per step, as
+    much as a 256-ray step takes on the GPU (config 4 over 8 GPUs).  Here the grid is built ONCE, a view's static parts are
+    taken from the first item the dataset's OWN method returns for it, and later items of that view are assembled by
+    gathering the `num_pixels` rows from the cached grid and the dataset's image tensors; a batch of one item is collated by
+    `unsqueeze(0)` views.
+
+    Nothing is assumed about the dataset class; it is OBSERVED.  The first time a view comes up the dataset's own
+    `__getitem__` builds the item (the reference's path, unchanged) and the assembly is checked against it: same keys, every
+    tensor equal, the same view index, and Python's `random` generator in the same state as after the single
+    `random.randint(0, num_views - 1)` the fast path makes (scene_dataset.py:219).  Any difference -- another dataset class,
+    another mode, missing attributes -- and this object hands every item to the dataset's own method from then on (`reason`
+    says why).  The train-mode item of a BlendedMVS scan carries `near_pose` (scene_dataset.py:239-240): taken from the
+    observed item of the view."""
+
+    def __init__(self, dataset):
+        self.ds = dataset
+        self.reason = None              # why the fast path is off (None: it is on)
+        self._views = {}                # view index -> dict(static sample entries, mask)
+        self._uv = None
+        self.fast_items = self.own_items = 0
+        need = ("rgb_images", "rgb_smooth", "masks", "intrinsics_all", "pose_all", "img_res", "num_views", "trains_ids", "mode")
+        missing = [a for a in need if not hasattr(dataset, a)]
+        if missing:
+            self.reason = "dataset has no " + ", ".join(missing)
+        elif int(dataset.num_views) < 1:
+            self.reason = "num_views < 1: the item index is the DataLoader's"
+
+    def __len__(self):
+        return len(self.ds)
+
+    def __getattr__(self, name):        # (everything else -- trains_ids, total_pixels, change_sampling_idx ... -- is the dataset's)
+        return getattr(self.__dict__["ds"], name)
+
+    # ---- the cached parts
+    def _grid(self):
+        if self._uv is None:
+            import numpy as np
+            H, W = int(self.ds.img_res[0]), int(self.ds.img_res[1])
+            uv = np.mgrid[0:H, 0:W].astype(np.int32)                                  # scene_dataset.py:228-233, once
+            uv = torch.from_numpy(np.flip(uv, axis=0).copy()).float()
+            uv = uv.reshape(2, -1).transpose(1, 0)
+            if getattr(self.ds, "use_pixel_centers", False):
+                uv = uv + 0.5
+            self._uv = uv.contiguous()
+        return self._uv
+
+    def _assemble(self, idx, view):
+        ds, sel = self.ds, self.ds.sampling_idx
+        sample = dict(view["sample"])
+        gt = {"rgb": ds.rgb_images[idx], "rgb_smooth": ds.rgb_smooth[idx], "mask": ds.masks[idx]}
+        if sel is not None:
+            gt["rgb"] = ds.rgb_images[idx][sel, :]
+            gt["rgb_smooth"] = ds.rgb_smooth[idx][sel, :]
+            sample["uv"] = self._grid()[sel, :]
+        else:
+            sample["uv"] = self._grid()
+        # the order of the keys is the reference's: uv, intrinsics, pose[, near_pose]
+        return idx, {k: sample[k] for k in view["order"]}, gt
+
+    @staticmethod
+    def _same(a, b):
+        if torch.is_tensor(a) != torch.is_tensor(b):
+            return False
+        if torch.is_tensor(a):
+            return a.shape == b.shape and a.dtype == b.dtype and bool(torch.equal(a, b))
+        return a == b
+
+    def _learn(self, item_index, state):
+        """the dataset's own item for a view not seen yet; the assembly must reproduce it"""
+        random.setstate(state)
+        item = self.ds[item_index]
+        after = random.getstate()
+        self.own_items += 1
+        try:
+            idx, sample, gt = item
+            random.setstate(state)
+            mine_idx = self.ds.trains_ids()[random.randint(0, int(self.ds.num_views) - 1)]
+            ok = random.getstate() == after and int(mine_idx) == int(idx) and isinstance(sample, dict) and isinstance(gt, dict)
+            if ok:
+                static = {k: v for k, v in sample.items() if k != "uv"}
+                view = dict(sample=static, order=list(sample.keys()))
+                mine = self._assemble(int(idx), view)
+                ok = (list(mine[1]) == list(sample) and list(mine[2]) == list(gt)
+                      and all(self._same(mine[1][k], sample[k]) for k in sample) and all(self._same(mine[2][k], gt[k]) for k in gt)
+                      and self._same(static.get("intrinsics"), self.ds.intrinsics_all[int(idx)])
+                      and self._same(static.get("pose"), self.ds.pose_all[int(idx)]))
+                if ok:
+                    self._views[int(idx)] = view
+            if not ok:
+                self.reason = "the dataset's own item differs from the cached assembly"
+        except Exception as e:                       # (an item of another shape: not ours to interpret)
+            self.reason = f"could not check the dataset's item: {e!r}"
+        random.setstate(after)
+        return item
+
+    def __getitem__(self, item_index):
+        ds = self.ds
+        if self.reason is not None or ds.mode != 'train':
+            self.own_items += 1
+            return ds[item_index]
+        state = random.getstate()
+        idx = ds.trains_ids()[random.randint(0, int(ds.num_views) - 1)]          # scene_dataset.py:216-219
+        view = self._views.get(int(idx))
+        if view is None:
+            return self._learn(item_index, state)
+        self.fast_items += 1
+        return self._assemble(int(idx), view)
+
+    def collate_fn(self, batch_list):
+        """`SceneDataset.collate_fn` (scene_dataset.py:258-273) for a batch of ONE item without its copies: `torch.stack` of
+        one tensor is `unsqueeze(0)` of it (the mask image alone is 5.3 MB per step); larger batches go to the dataset's."""
+        if len(batch_list) != 1 or self.reason is not None:
+            return self.ds.collate_fn(batch_list)
+        out = []
+        for entry in batch_list[0]:
+            if isinstance(entry, dict):
+                out.append({k: v.unsqueeze(0) for k, v in entry.items()})
+            else:
+                out.append(torch.LongTensor([entry]))
+        return tuple(out)

@@ -277,6 +277,7 @@ class VolOpt():
         # step -- torch.randperm over all pixels, the full pixel grid per item -- no longer sits in front of the step's
         # 1.7 ms of enqueueing); `overlap_loader=False` / SVS_OVERLAP_LOADER=0 gives the strictly sequential loop.
         self._overlap_loader = bool(kwargs.get('overlap_loader', os.environ.get('SVS_OVERLAP_LOADER', '1') == '1'))
+        self._cached_items = bool(kwargs.get('cached_items', os.environ.get('SVS_CACHED_ITEMS', '1') == '1'))
         self._loader_pool = None
 
         # generate dataset
@@ -363,8 +364,15 @@ class VolOpt():
 
     def gen_dataset(self, stg):
         self.train_dataset = self._dataset_class(**self.data_confs[stg])
-        self.train_dataloader = torch.utils.data.DataLoader(self.train_dataset, batch_size=self.batch_size, shuffle=True,
-                                                            collate_fn=self.train_dataset.collate_fn)
+        # the train loader draws the dataset's items through svs_hip.batches.CachedItems: the same items and the same use of
+        # the random generators, assembled from a pixel grid built once instead of per item (checked against the dataset's own
+        # method view by view; SVS_CACHED_ITEMS=0: the dataset itself)
+        items = self.train_dataset
+        if self._cached_items:
+            from svs_hip.batches import CachedItems
+            items = self.train_items = CachedItems(self.train_dataset)
+        self.train_dataloader = torch.utils.data.DataLoader(items, batch_size=self.batch_size, shuffle=True,
+                                                            collate_fn=items.collate_fn)
         self.eval_dataloader = torch.utils.data.DataLoader(self.train_dataset, batch_size=1, shuffle=False,
                                                            collate_fn=self.train_dataset.collate_fn)
         self.total_pixels = self.train_dataset.total_pixels

@@ -222,13 +222,15 @@ def test_overlapped_loader_draws_the_same_batches(tmp_path, monkeypatch):
     """`VolOpt.run` prepares the next batch of the reference's DataLoader loop in a helper thread while the current step is
     being enqueued (`_epoch_overlapped`, opt-in).  It must be the SAME loop: with equal seeds the view and pixel
     sequence over several epochs, the first step's sample positions, and the final states of torch's CPU generator and of
-    Python's `random` are identical to the plain loop's (`overlap_loader=False`)."""
+    Python's `random` are identical to the plain loop's (`overlap_loader=False`).  Round 5: the same with the items
+    assembled from the cached pixel grid (svs_hip.batches.CachedItems, the default) against the dataset's own `__getitem__`
+    and collate (`cached_items=False`: the reference's loop as it stands)."""
     import random
     monkeypatch.chdir(tmp_path)
 
-    def run(overlap):
+    def run(overlap, cached=True):
         torch.manual_seed(11); random.seed(11); np.random.seed(11)
-        v = build(make_args(), overlap_loader=overlap)
+        v = build(make_args(), overlap_loader=overlap, cached_items=cached)
         seen = []
         orig = v.train_step
 
@@ -240,14 +242,20 @@ def test_overlapped_loader_draws_the_same_batches(tmp_path, monkeypatch):
             return out
         v.train_step = spy
         v.run(opt_stepN=11)                                   # three passes over the 5-image dataset
+        if cached:
+            ci = v.train_items
+            assert ci.reason is None and ci.own_items == 3 and ci.fast_items == 12, (ci.reason, ci.own_items, ci.fast_items)
+        else:
+            assert not hasattr(v, "train_items")
         return seen, torch.get_rng_state(), random.getstate(), v.iter_step
     a, ta, ra, na = run(True)
-    b, tb, rb, nb = run(False)
-    assert na == nb == 15 and len(a) == len(b) == 16
-    assert torch.equal(a[1], b[1])                            # step 0: same jitter / u / extras -> same sample positions
-    for x, y in zip(a[:1] + a[2:], b[:1] + b[2:]):
-        assert x[0] == y[0] and torch.equal(x[1], y[1]) and torch.equal(x[2], y[2])
-    assert torch.equal(ta, tb) and ra == rb
+    for overlap, cached in ((False, True), (False, False), (True, False)):
+        b, tb, rb, nb = run(overlap, cached)
+        assert na == nb == 15 and len(a) == len(b) == 16
+        assert torch.equal(a[1], b[1])                        # step 0: same jitter / u / extras -> same sample positions
+        for x, y in zip(a[:1] + a[2:], b[:1] + b[2:]):
+            assert x[0] == y[0] and torch.equal(x[1], y[1]) and torch.equal(x[2], y[2])
+        assert torch.equal(ta, tb) and ra == rb
 
 
 def test_launch_plans_and_pixel_draw_keep_the_run(tmp_path, monkeypatch):
