@@ -266,10 +266,24 @@ class MlpBackward:
                                 rec0=zrec(l)))
             return jobs
 
+        # Experiment (SVS_WGRAD_SPLIT = 1 | auto: up to 40 960 points; OFF by default).  Small batches (config 4's 256 rays per
+        # GPU): the step is the SUM of its kernels' latencies, the sweeps' workgroups do not fill the chip and HBM idles under
+        # them.  The second-order half of the SDF weight gradients -- ghat_l x u_l^T, complete once pass A is -- rides with
+        # the radiance weight gradients in ONE launch beside pass B, and the launch that ends the step is the first-order
+        # half (abar_l x h_l^T, bias gradients) only.  Same sums, same accumulators (gradient tests pass).  Round 4 had the
+        # second-order launch queued BEHIND the radiance launch (it started when pass B was half done): 1.46 against 1.42 ms.
+        # Round 5, merged, A/B three times on one box: 1.186 against 1.194 ms at 256 rays (DTU), 1.358 against 1.324 with the
+        # background model, 1.94 / 1.94 at 512 rays -- the launch that ends the step is not HBM-bound at this size (26 items
+        # per workgroup: ring fill, atomic flush and the spread of the workgroups' finishing times), halving its bytes takes
+        # 15 % off it, and pass B runs slower beside 0.7 GB of streaming.  Off.
+        split = h2 and side and not defer_wgrad and extra is None and \
+            (_WGRAD_SPLIT == "1" or (_WGRAD_SPLIT == "auto" and n_total <= 40960))
         deferred = None
         if defer_wgrad:
             ev_rgb = torch.cuda.Event(); ev_rgb.record(main)
             deferred = dict(rgb=dict(jobs=job_list(rkey, rgb_jobs), key=rkey), ev_rgb=ev_rgb)
+            join = None
+        elif split:
             join = None
         else:
             fork = torch.cuda.Event(); fork.record(main)
@@ -285,27 +299,17 @@ class MlpBackward:
         _lib.check(L.svs_sdf_bwd_a(*src.args(), _ptr(d_grad), _ptr(mask), _ptr(hbuf), _ptr(gbuf), _ptr(S.sdf), prec,
                                    _ptr(self.ubuf), _ptr(self.a2buf), _ptr(self.pebuf),
                                    _ptr(acc.absmax) if h2 else None, st), "svs_sdf_bwd_a")
-        # Experiment (SVS_WGRAD_SPLIT=1 | auto; OFF by default): at small batches (config 4's 256 rays per GPU: the step is the
-        # SUM of its kernels' latencies) the second-order half of the SDF weight gradients -- ghat_l x u_l^T, whose operands
-        # are complete once pass A is -- as a launch of its own BESIDE pass B, on the radiance weight gradients' stream; the
-        # first-order half (abar_l x h_l^T, bias gradients) after pass B.  Same sums, same accumulators (gradient tests pass)
-        # -- and measured SLOWER at every size: 1.46 against 1.42 ms at 256 rays, 1.17 / 1.145 at 128, 2.37 / 2.28 at 512
-        # (A/B three times on one box): the second launch's ~70 us of ring fill outweigh what runs under pass B.
-        split = h2 and side and not defer_wgrad and extra is None and \
-            (_WGRAD_SPLIT == "1" or (_WGRAD_SPLIT == "auto" and n_total <= 40960))
         join2 = None
         if split:
             k2 = ("sdf2", n_total, prec, self.ubuf.data_ptr(), gbuf.data_ptr(), acc.dWk.data_ptr())
-            arr_2 = self._job_cache.get(k2)
-            arr_2 = arr_2[:2] if arr_2 is not None else None
-            if arr_2 is None:
-                urec = lambda l: _off(self.ubuf, record_off(n_total, 9, l))
-                arr_2 = self._cache_jobs(k2, [job(l, n_total, 0, _off(gbuf, l * LS), KBLOCK, _off(self.ubuf, l * LS), KBLOCK,
-                                                  rec0=urec(l), bias=False) for l in range(8)])
+            urec = lambda l: _off(self.ubuf, record_off(n_total, 9, l))
+            second = lambda: [job(l, n_total, 0, _off(gbuf, l * LS), KBLOCK, _off(self.ubuf, l * LS), KBLOCK,
+                                  rec0=urec(l), bias=False) for l in range(8)]
             after_a = torch.cuda.Event(); after_a.record(main)
             with torch.cuda.stream(side_stream):
                 side_stream.wait_event(after_a)
-                wgrad_multi(arr_2)
+                # one launch: the radiance network's five layers + the eight second-order products of the SDF network
+                wgrad_multi(job_array(rkey + k2, job_list(rkey, rgb_jobs), dict(jobs=job_list(k2, second), key=k2)))
                 join2 = torch.cuda.Event(); join2.record(side_stream)
         _lib.check(L.svs_sdf_bwd_b(n_total, _ptr(d_sdf_full), _ptr(mask), _ptr(self.feat_bar), n_main, _ptr(hbuf),
                                    _ptr(gbuf), _ptr(self.a2buf), _ptr(self.ubuf), _ptr(S.sdf), prec, _ptr(self.abuf),
