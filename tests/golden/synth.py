@@ -467,3 +467,63 @@ def make_featurenet_params(seed, base=8):
         if bias:
             p[f"{name}.bias"] = rng.normal(0, 0.1, cout).astype(F32)
     return p
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# An analytic scene with known geometry (round 5: Chamfer parity, tools/chamfer_parity.py).  A sphere and a box, Lambertian
+# shading under one directional light with a smooth albedo pattern; a numpy sphere tracer renders any pin-hole view of it.
+# Normalised scene units (inside VolSDF's bounding sphere of radius 3; the geometric initialisation is a sphere of radius 0.6).
+# ---------------------------------------------------------------------------------------------------------------------------
+ANALYTIC = dict(sphere_c=(-0.22, 0.05, 0.0), sphere_r=0.42, box_c=(0.33, -0.08, 0.05), box_h=(0.26, 0.34, 0.3),
+                light=(-0.35, 0.45, 0.82))          # direction the light travels (the cameras look along +z)
+
+
+def analytic_sdf(x):
+    """signed distance of the union sphere + axis-aligned box; x (..., 3) float64 -> (...)"""
+    x = np.asarray(x, np.float64)
+    ds = np.linalg.norm(x - np.asarray(ANALYTIC["sphere_c"]), axis=-1) - ANALYTIC["sphere_r"]
+    q = np.abs(x - np.asarray(ANALYTIC["box_c"])) - np.asarray(ANALYTIC["box_h"])
+    db = np.linalg.norm(np.maximum(q, 0.0), axis=-1) + np.minimum(q.max(-1), 0.0)
+    return np.minimum(ds, db)
+
+
+def analytic_normal(x, h=1e-5):
+    g = np.stack([analytic_sdf(x + h * e) - analytic_sdf(x - h * e) for e in np.eye(3)], -1)
+    return g / np.maximum(np.linalg.norm(g, axis=-1, keepdims=True), 1e-12)
+
+
+def analytic_albedo(x):
+    x = np.asarray(x, np.float64)
+    base = np.stack([0.55 + 0.35 * np.sin(7.0 * x[..., 0] + 1.0), 0.55 + 0.35 * np.sin(6.0 * x[..., 1] - 0.5),
+                     0.55 + 0.35 * np.sin(8.0 * x[..., 2] + 2.0)], -1)
+    return np.clip(base, 0.05, 0.95)
+
+
+def render_analytic_view(K, pose, hw, t_max=6.0, n_iter=96):
+    """Sphere tracing from the camera (K: 4x4 or 3x3 intrinsics of an hw image, pose: camera-to-world).  -> dict(rgb (H,W,3)
+    float32 in [0,1], black background; mask (H,W) bool; depth (H,W) float64 z-depth in the camera frame, 0 off the object;
+    points (n,3) float64 world points of the hit pixels)."""
+    H, W = hw
+    K = np.asarray(K, np.float64)
+    v, u = np.mgrid[0:H, 0:W].astype(np.float64)
+    y = (v - K[1, 2]) / K[1, 1]
+    xcam = (u - K[0, 2] - K[0, 1] * y) / K[0, 0]
+    d_cam = np.stack([xcam, y, np.ones_like(xcam)], -1)
+    R, c = np.asarray(pose, np.float64)[:3, :3], np.asarray(pose, np.float64)[:3, 3]
+    d = d_cam @ R.T
+    scale = np.linalg.norm(d, axis=-1, keepdims=True)
+    d = d / scale
+    t = np.zeros((H, W))
+    alive = np.ones((H, W), bool)
+    for _ in range(n_iter):
+        s = analytic_sdf(c + t[..., None] * d)
+        t = np.where(alive, t + s, t)
+        alive &= t < t_max
+    hit = alive & (np.abs(analytic_sdf(c + t[..., None] * d)) < 1e-6)
+    p = c + t[..., None] * d
+    n = analytic_normal(p)
+    l = np.asarray(ANALYTIC["light"], np.float64); l = l / np.linalg.norm(l)
+    shade = 0.25 + 0.75 * np.maximum(0.0, -(n @ l))
+    rgb = np.where(hit[..., None], analytic_albedo(p) * shade[..., None], 0.0).astype(F32)
+    depth = np.where(hit, t / scale[..., 0], 0.0)
+    return dict(rgb=rgb, mask=hit, depth=depth, points=p[hit])

@@ -68,3 +68,24 @@ class SyntheticSceneDataset(torch.utils.data.Dataset):
 
     def change_sampling_idx(self, sampling_size):
         self.sampling_idx = None if sampling_size == -1 else torch.randperm(self.total_pixels)[:sampling_size]
+
+
+class AnalyticSceneDataset(SyntheticSceneDataset):
+    """The same interface over images of the analytic scene of synth.render_analytic_view (sphere + box, Lambertian):
+    a scan with KNOWN geometry, for the Chamfer parity runs (tools/chamfer_parity.py).  `rgb_smooth` is a 5 x 5 box blur of
+    the image (the reference smooths with a Gaussian, scene_dataset.py:150-170; only the annealing phase of a run with an MVS
+    prior reads it).  scale_factor: world units (mm) per normalised scene unit, as the DTU scans' scale matrices give."""
+
+    def __init__(self, data_dir_root=None, data_dir="DTU", img_res=(192, 256), scan_id=24, num_views=3, scale_factor=200.0, **kw):
+        super().__init__(data_dir_root, data_dir, img_res, scan_id, num_views, scale_factor, **kw)
+        H, W = img_res
+        self.renders = []
+        for v in range(self.n_images):
+            r = synth.render_analytic_view(self.intrinsics_all[v].numpy(), self.pose_all[v].numpy(), (H, W))
+            self.renders.append(r)
+            img = r["rgb"]
+            pad = np.pad(img, ((2, 2), (2, 2), (0, 0)), mode="edge")
+            smooth = sum(pad[i:i + H, j:j + W] for i in range(5) for j in range(5)) / 25.0
+            self.rgb_images[v] = torch.from_numpy(img.reshape(-1, 3).copy())
+            self.rgb_smooth[v] = torch.from_numpy(smooth.reshape(-1, 3).astype(np.float32))
+            self.masks[v] = torch.from_numpy(np.repeat(r["mask"].reshape(-1, 1), 3, 1).astype(np.float32))
