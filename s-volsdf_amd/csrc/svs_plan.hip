@@ -101,13 +101,20 @@ static int build(hipGraph_t graph, const hipStream_t* given, int n_given, Plan**
   }
   if (order.size() != n) return SVS_EINVAL;      // a cycle: not a capture
 
-  // longest way (in nodes) from the start to a node and from a node to the end.  A node wants the stream of its deepest
+  // longest way from the start to a node and from a node to the end.  A node wants the stream of its deepest
   // predecessor (the end of the longest chain that leads to it); of the successors that want a node's stream, the one
   // with the longest way to the end of the sequence gets it (ties: the one issued first), the others fork off.  The step's
   // critical chain therefore stays on one stream from its first to its last launch -- a dependency that crosses streams
   // costs 10-25 us on this runtime -- and the side branches (weight packing, the radiance weight gradients, a second ray
   // group, the background networks) each keep a stream of their own from fork to join.
-  std::vector<int> depth(n, 0), height(n, 0), wanted(n, -1), heir(n, -1);
+  // "Long" is an ESTIMATE OF TIME since round 5, not a number of nodes: the weight-packing chain of the fg + background model
+  // is 16 launches of 5-12 us, more nodes than the whole forward has -- counted in nodes it was the "deepest" predecessor
+  // of the compositing backward, the critical chain hopped onto its stream there and back at the end (13 + 12 us of
+  // crossings per 256-ray step).  A node costs max(one small launch, waves x weight): the fused sweeps and the weight-
+  // gradient GEMM (one wave per SIMD walking its points through all layers; recognised by their >= 48 KiB of dynamic LDS)
+  // ~0.25 us per wave, everything else ~5 ns per wave, a launch at least ~5 us.
+  std::vector<long long> depth(n, 0), height(n, 0), cost(n, 470);
+  std::vector<int> wanted(n, -1), heir(n, -1);
   // (second criterion where two ways have the same number of nodes: the threads launched along them -- the fg sweep
   // against the background network's, which join at compositing after two launches each)
   std::vector<double> threads(n, 0.0), below(n, 0.0), above(n, 0.0);
@@ -115,33 +122,37 @@ static int build(hipGraph_t graph, const hipStream_t* given, int n_given, Plan**
     hipGraphNodeType t;
     hipKernelNodeParams k;
     if (hipGraphNodeGetType(handles[i], &t) == hipSuccess && t == hipGraphNodeTypeKernel &&
-        hipGraphKernelNodeGetParams(handles[i], &k) == hipSuccess)
+        hipGraphKernelNodeGetParams(handles[i], &k) == hipSuccess) {
       threads[i] = (double)k.gridDim.x * k.gridDim.y * k.gridDim.z * k.blockDim.x * k.blockDim.y * k.blockDim.z;
+      const double waves = threads[i] / 64.0;
+      cost[i] = std::max(470LL, (long long)(waves * (k.sharedMemBytes >= 48 * 1024 ? 24.0 : 0.5)));
+    }
   }
   for (size_t q = 0; q < n; ++q) {
     const int i = order[q];
     for (int pr : preds[i]) {
       const int w = wanted[i];
       const double via = above[pr] + threads[pr];
-      if (w < 0 || depth[pr] > depth[w] || (depth[pr] == depth[w] && (via > above[i] || (via == above[i] && pr < w)))) {
+      if (w < 0 || depth[pr] + cost[pr] > depth[w] + cost[w] ||
+          (depth[pr] + cost[pr] == depth[w] + cost[w] && (via > above[i] || (via == above[i] && pr < w)))) {
         wanted[i] = pr;
         above[i] = via;
       }
-      depth[i] = std::max(depth[i], depth[pr] + 1);
+      depth[i] = std::max(depth[i], depth[pr] + cost[pr]);
     }
   }
   for (size_t q = n; q-- > 0;) {
     const int i = order[q];
     for (int su : succs[i])
-      if (height[su] + 1 > height[i] || (height[su] + 1 == height[i] && below[su] + threads[su] > below[i])) {
-        height[i] = height[su] + 1;
+      if (height[su] + cost[su] > height[i] || (height[su] + cost[su] == height[i] && below[su] + threads[su] > below[i])) {
+        height[i] = height[su] + cost[su];
         below[i] = below[su] + threads[su];
       }
     for (int su : succs[i]) {
       if (wanted[su] != i) continue;
       const int h = heir[i];
-      if (h < 0 || height[su] > height[h] ||
-          (height[su] == height[h] && (below[su] + threads[su] > below[h] + threads[h] ||
+      if (h < 0 || height[su] + cost[su] > height[h] + cost[h] ||
+          (height[su] + cost[su] == height[h] + cost[h] && (below[su] + threads[su] > below[h] + threads[h] ||
                                        (below[su] + threads[su] == below[h] + threads[h] && su < h))))
         heir[i] = su;
     }

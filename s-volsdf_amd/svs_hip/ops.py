@@ -534,7 +534,7 @@ def cost_lookup(views, same_view, img_res, *, xyz=None, cam=None, dirs=None, z=N
 
 def loss_fwd_bwd(rgb_values, rgb_target, weights, depth_values, grad_theta=None, pi=None, pj=None, *, rgb_weight=1.0,
                  eikonal_weight=0.1, mvs_weight=0.0, sparse_weight=0.0, gce=1.0, confi=0.0, annealed=False,
-                 anneal_sparse=0.0, norm=None, anneal_dev=None):
+                 anneal_sparse=0.0, norm=None, anneal_dev=None, grad_theta_out=None):
     """VolSDFLoss.forward (volsdf/model/loss.py:80-114) and d(total)/d(model outputs) in one launch.
     norm = (R_total, n_eik_total): denominators of the means when the batch is processed in ray groups.
     anneal_dev: optional device float32[2] = {annealed, anneal_sparse} read at run time (captured launch sequences).
@@ -549,7 +549,12 @@ def loss_fwd_bwd(rgb_values, rgb_target, weights, depth_values, grad_theta=None,
     pi_, pj_ = (_f32(pi), _f32(pj)) if pi is not None else (None, None)
     losses = torch.empty(5, device=dev)
     d_rgb = torch.empty(R, 3, device=dev)
-    d_gt = torch.empty(n_eik, 3, device=dev) if n_eik else None
+    # grad_theta_out: optional (n_eik,3) float32 destination of d loss / d grad_theta (the backward's own buffer: train.MlpBackward)
+    d_gt = None
+    if n_eik:
+        ok = (grad_theta_out is not None and grad_theta_out.is_cuda and grad_theta_out.dtype == torch.float32
+              and tuple(grad_theta_out.shape) == (n_eik, 3) and grad_theta_out.is_contiguous())
+        d_gt = grad_theta_out if ok else torch.empty(n_eik, 3, device=dev)
     d_w = torch.empty(R, S, device=dev)
     d_dep = torch.empty(R, 1, device=dev)
     ws = torch.empty(L.svs_loss_workspace_bytes(R, n_eik) // 8, dtype=torch.float64, device=dev)

@@ -158,6 +158,10 @@ class MlpBackward:
         # d loss / d sdf of all points of the launch: the ray samples' part is rewritten every step (sdf_grad_out()), the
         # tail -- the eikonal points, which have no such term -- stays zero
         self.d_sdf_full = torch.zeros(n_total, device=self.dev)
+        # d loss / d (d sdf / dx) of all points of the launch, pass A's input: rows [0, n_main) = d loss / d normals, written by
+        # the radiance backward; the tail = the eikonal points' gradients, written by the loss kernel (grad_extra_out()) --
+        # no concatenation launch between the radiance backward and pass A
+        self.d_grad_full = torch.zeros(n_total, 3, device=self.dev)
         self._n = (n_total, n_main)
 
     def _cache_jobs(self, key, jobs):
@@ -171,6 +175,12 @@ class MlpBackward:
         """(n_main,1) view of the persistent d_sdf buffer: compositing's backward writes into it directly."""
         self._alloc(n_total, n_main)
         return self.d_sdf_full[:n_main].view(n_main, 1)
+
+    def grad_extra_out(self, n_total, n_main):
+        """(n_total - n_main, 3) view of the persistent d loss / d (d sdf / dx) buffer: the loss kernel writes the eikonal
+        points' gradients into it directly."""
+        self._alloc(n_total, n_main)
+        return self.d_grad_full[n_main:]
 
     def accumulate(self, keep, d_rgb, d_sdf, d_grad_extra, wait=True, side=True, defer_wgrad=False, extra=None):
         """Launches the backward of one ray group on the current stream (+ a side stream for the radiance weight
@@ -231,13 +241,18 @@ class MlpBackward:
 
         # ---- radiance MLP: input gradients
         d_rgb = _f32(d_rgb)
-        d_normals = torch.empty(n_main, 3, device=dev)
+        d_grad = self.d_grad_full
+        d_normals = d_grad[:n_main]
+        n_extra = 0 if d_grad_extra is None else d_grad_extra.shape[0]
+        if n_main + n_extra != n_total:
+            raise ValueError("d_grad_extra must cover the points that follow the ray samples")
+        if n_extra and d_grad_extra.data_ptr() != d_grad[n_main:].data_ptr():
+            # (a caller that did not write into grad_extra_out(); by a kernel, not copy_: a captured device copy is a node a
+            # launch plan cannot replay, csrc/svs_plan.hip)
+            torch.mul(_f32(d_grad_extra), 1.0, out=d_grad[n_main:])
         _lib.check(L.svs_rgb_bwd(n_main, _ptr(d_rgb), _ptr(keep["rgb"]), _ptr(rbuf), _ptr(S.rgb), prec, _ptr(self.zbuf),
                                  _ptr(self.feat_bar), _ptr(d_normals), _ptr(acc.absmax) if h2 else None, _stream()),
                    "svs_rgb_bwd")
-        d_grad = d_normals if d_grad_extra is None else torch.cat([d_normals, _f32(d_grad_extra)], 0)
-        if d_grad.shape[0] != n_total:
-            raise ValueError("d_grad_extra must cover the points that follow the ray samples")
         if d_sdf is not None and d_sdf.data_ptr() == self.d_sdf_full.data_ptr() and d_sdf.numel() == n_main:
             d_sdf_full = self.d_sdf_full              # written in place by the caller (sdf_grad_out())
         else:

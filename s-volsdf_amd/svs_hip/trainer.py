@@ -694,7 +694,8 @@ class TrainStep:
                 valid_g = max(0, min(hi, n_valid) - lo)          # rays of this group that are not padding
                 if valid_g == hi - lo:
                     lo_out = self.loss(out, g_gt, norm=loss_norm(n_valid, self.world), advance=False,
-                                       anneal_dev=dyn["anneal"] if dyn else None)
+                                       anneal_dev=dyn["anneal"] if dyn else None,
+                                       grad_theta_out=sc.bwd[gi].grad_extra_out(keep["src"].n, keep["rgb_flat"].shape[0]))
                     g = self.loss.last_grads
                 else:
                     lo_out, g = self._loss_on_valid(out, g_gt, valid_g, hi - lo, loss_norm(n_valid, self.world),

@@ -43,7 +43,7 @@ class VolSDFLoss(nn.Module):
         annealed = self.sparse_weight > 0 and self.anneal_rgb > 0 and self.iter_step < self.anneal_rgb
         return annealed, (anneal_linearly(self.iter_step / self.anneal_rgb, 1.0, 0.) if annealed else 0.0)
 
-    def forward(self, model_outputs, ground_truth, norm=None, advance=True, anneal_dev=None):
+    def forward(self, model_outputs, ground_truth, norm=None, advance=True, anneal_dev=None, grad_theta_out=None):
         """anneal_dev: optional device float32[2] holding anneal_state() -- the kernels then read the annealing from it
         (a captured launch sequence stays valid while the iteration count advances; trainer.TrainStep)."""
         dev = model_outputs['rgb_values'].device
@@ -57,7 +57,7 @@ class VolSDFLoss(nn.Module):
             rgb_weight=self.rgb_weight, eikonal_weight=self.eikonal_weight,
             mvs_weight=self.mvs_weight if has_mvs else 0.0, sparse_weight=self.sparse_weight, gce=float(self.gce),
             confi=float(self.confi), annealed=annealed and has_mvs, anneal_sparse=float(anneal_sparse), norm=norm,
-            anneal_dev=anneal_dev)
+            anneal_dev=anneal_dev, grad_theta_out=grad_theta_out)
         self.last_grads = grads
         if advance:
             self.iter_step += 1

@@ -75,7 +75,7 @@ def test_captured_step_equals_eager(dev, kind, mode):
                 # the launch plan (csrc/svs_plan.hip): every launch of the step is a kernel node, the two ray groups and the
                 # side branches are chains on a handful of streams
                 info = plan.info
-                assert info["kernels"] == info["nodes"] >= 50 and info["copies"] == info["memsets"] == 0, info
+                assert info["kernels"] == info["nodes"] >= 44 and info["copies"] == info["memsets"] == 0, info      # (round 5: 48)
                 assert 3 <= info["streams"] <= 8 and info["events"] >= 4, info
                 text = plan.describe().splitlines()
                 assert len(text) == info["nodes"] and sum("sdf_full_h2_kernel" in t for t in text) == 2, text[:5]
