@@ -46,6 +46,7 @@ def record_off(n_points, n_blocks, block):
 # chain).  Measured with launch plans, A/B twice on one box: 1.315 / 1.311 against 1.319 / 1.311 ms (DTU model, 256 rays), 1.55
 # against 1.495 with the background model -- the branches' stream crossings and the fifth busy stream cost what they save.
 _PLAN_BRANCHES = os.environ.get("SVS_PLAN_BRANCHES", "0") == "1"
+_RGB_MERGE = os.environ.get("SVS_RGB_WGRAD_MERGE", "0")       # 0 (default) | 1 | auto (MlpBackward.accumulate: an experiment)
 _WGRAD_SPLIT = os.environ.get("SVS_WGRAD_SPLIT", "0")         # 0 (default) | 1 | auto (MlpBackward.accumulate: an experiment)
 
 
@@ -293,12 +294,24 @@ class MlpBackward:
         # 15 % off it, and pass B runs slower beside 0.7 GB of streaming.  Off.
         split = h2 and side and not defer_wgrad and extra is None and \
             (_WGRAD_SPLIT == "1" or (_WGRAD_SPLIT == "auto" and n_total <= 40960))
+        # Experiment (SVS_RGB_WGRAD_MERGE = 1 | auto: up to 40 960 points; OFF by default): the radiance network's weight
+        # gradients ride in the SDF network's launch at the end of the step instead of running beside pass A on a stream of
+        # their own.  One workgroup of the GEMM takes a whole CU (8 waves, 136 KB of LDS), and so does one of a sweep (one
+        # 512-register wave per SIMD): beside pass A the radiance launch's 256 workgroups take turns with the sweep's ~200 -- at
+        # 256 rays pass A lasts 122 us (195 with the background networks' launches beside it as well), pass B 226.  Merged, the
+        # sweeps run alone and the last launch grows -- A/B three times on one box: 1.215 against 1.208 ms (DTU model), 1.39
+        # against 1.363 with the background model, 2.02 / 2.01 at 512 rays: what the concurrent launch costs the sweeps is less
+        # than its own duration.  Off.
+        merge_rgb = h2 and side and not defer_wgrad and extra is None and not split and \
+            (_RGB_MERGE == "1" or (_RGB_MERGE == "auto" and n_total <= 40960))
         deferred = None
         if defer_wgrad:
             ev_rgb = torch.cuda.Event(); ev_rgb.record(main)
             deferred = dict(rgb=dict(jobs=job_list(rkey, rgb_jobs), key=rkey), ev_rgb=ev_rgb)
             join = None
         elif split:
+            join = None
+        elif merge_rgb:
             join = None
         else:
             fork = torch.cuda.Event(); fork.record(main)
@@ -371,7 +384,11 @@ class MlpBackward:
             return deferred
         if extra is not None:
             main.wait_event(extra["ev_all"])
-        wgrad_multi(job_array(skey, job_list(skey, sdf_jobs), extra["sdf"] if extra else None))
+        if merge_rgb:
+            wgrad_multi(job_array(skey + rkey, job_list(skey, sdf_jobs), dict(jobs=job_list(rkey, rgb_jobs), key=rkey)))
+            join = torch.cuda.Event(); join.record(main)
+        else:
+            wgrad_multi(job_array(skey, job_list(skey, sdf_jobs), extra["sdf"] if extra else None))
         if ev:
             ev[1].record()
         if join2 is not None and not row0_aside:
