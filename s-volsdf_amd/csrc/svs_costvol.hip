@@ -206,6 +206,11 @@ __global__ __launch_bounds__(256, NS <= 2 ? 4 : 2) void warp_variance_kernel(War
 #ifndef SVS_WARP_DZ
 #define SVS_WARP_DZ 4
 #endif
+// Diagnostic builds (tools/dev/ablate_warp.sh; results are then wrong by construction): -DSVS_WARP_ABL=<mask>, 1: no stores of
+// the volume, 2: no gathers (a voxel's corners are never re-fetched), 4: no projection arithmetic (constant corner tables).
+#ifndef SVS_WARP_ABL
+#define SVS_WARP_ABL 0
+#endif
 constexpr int kWarpDz = SVS_WARP_DZ;
 
 template <int C>
@@ -214,15 +219,25 @@ __device__ __forceinline__ void warp_taps(const WarpArgs& a, int v, int x, int y
   w4 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   o4 = i32x4{0, 0, 0, 0};
   if (x >= W || d >= a.D) return;
+#if SVS_WARP_ABL & 16
+  const float depth = 500.0f + (float)d;
+#else
   const float depth = a.depth_values[((size_t)d * H + y) * W + x];
+#endif
   const float fx = (float)x, fy = (float)y;
   const float* R = a.rot[v];
   // rot @ [x,y,1] * depth + trans   (CasMVSNet.py:300-303); same operations, same order as warp_variance_kernel
   const float qx = ((R[0] * fx + R[1] * fy) + R[2]) * depth + a.trans[v][0];
   const float qy = ((R[3] * fx + R[4] * fy) + R[5]) * depth + a.trans[v][1];
   const float qz = ((R[6] * fx + R[7] * fy) + R[8]) * depth + a.trans[v][2];
+#if SVS_WARP_ABL & 8
+  const float rz = __builtin_amdgcn_rcpf(qz);
+  const float px = qx * rz, py = qy * rz;
+  const float gx = px * __builtin_amdgcn_rcpf((float)(W - 1) / 2.0f) - 1.0f, gy = py * __builtin_amdgcn_rcpf((float)(H - 1) / 2.0f) - 1.0f;
+#else
   const float px = qx / qz, py = qy / qz;
   const float gx = px / ((float)(W - 1) / 2.0f) - 1.0f, gy = py / ((float)(H - 1) / 2.0f) - 1.0f;
+#endif
   const float ix = ((gx + 1.0f) * (float)W - 1.0f) / 2.0f, iy = ((gy + 1.0f) * (float)H - 1.0f) / 2.0f;
   const float x0 = __builtin_floorf(ix), y0 = __builtin_floorf(iy);
   const float tx = ix - x0, ty = iy - y0;
@@ -258,7 +273,11 @@ __global__ __launch_bounds__(256, NS <= 2 ? 4 : 2) void warp_variance_reuse_kern
     const int dz = i / (NS * TW), r = i - dz * (NS * TW);
     const int v = r / TW, vx = r - v * TW;
     f32x4 w4; i32x4 o4;
+#if SVS_WARP_ABL & 4
+    w4 = f32x4{0.25f, 0.25f, 0.25f, 0.25f}; o4 = i32x4{0, C * 4, C * 4 * W, C * 4 * (W + 1)};
+#else
     warp_taps<C>(a, v, xt + vx, y, d0 + dz, w4, o4);
+#endif
     tapw[dz][v][vx] = w4;
     tapo[dz][v][vx] = o4;
   }
@@ -285,7 +304,8 @@ __global__ __launch_bounds__(256, NS <= 2 ? 4 : 2) void warp_variance_reuse_kern
         const i32x4 o4 = tapo[dz][v][vx];
         const char* __restrict__ src = reinterpret_cast<const char*>(a.src_hwc[v]);
         // (a voxel's LPV lanes take the same branch; a corner outside the image has offset 0 and weight 0)
-        if (o4[0] != held[v][0] || o4[1] != held[v][1] || o4[2] != held[v][2] || o4[3] != held[v][3]) {
+        if (!((SVS_WARP_ABL & 2) && dz > 0) &&
+            (o4[0] != held[v][0] || o4[1] != held[v][1] || o4[2] != held[v][2] || o4[3] != held[v][3])) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) f[v][k] = *reinterpret_cast<const f32x4*>(src + ((unsigned)o4[k] + 16u * cg));
           held[v] = o4;
@@ -301,7 +321,7 @@ __global__ __launch_bounds__(256, NS <= 2 ? 4 : 2) void warp_variance_reuse_kern
       }
       const f32x4 m = sum * inv_nv;
       const f32x4 res = sq * inv_nv - m * m;
-      if (x < W && d < a.D) {
+      if (x < W && d < a.D && !((SVS_WARP_ABL & 1) && res[0] != 1.2345e-30f)) {
         f16x4 h, lo;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
