@@ -394,17 +394,20 @@ def main():
             except Exception as e:
                 line["render_eval"] = {"error": repr(e)}
             # BASELINE.json's "Chamfer parity" on a scene with known geometry (tools/chamfer_parity.py; the 3000-step runs are
-            # profiles/r05_chamfer_parity.json): a short optimisation per path, rendered, fused and evaluated like a DTU scan
+            # profiles/r05_chamfer_parity_prior.json): a short optimisation per path WITH a synthetic MVS prior (the reference's
+            # stage-0 loss), rendered, fused and evaluated like a DTU scan
             try:
                 import chamfer_parity
-                cp = chamfer_parity.measure(steps=600, seeds=(0, 1), paths=("hip", "hip_f32", "torch_f32"), rays=512, timeout=600)
+                cp = chamfer_parity.measure(steps=600, seeds=(0, 1), paths=("hip", "hip_f32", "torch_f32"), rays=512, timeout=600,
+                                            prior=True)
                 line["chamfer_parity"] = {"hip": cp.get("hip", {}).get("overall_mm"), "hip_f32": cp.get("hip_f32", {}).get("overall_mm"),
                                           "torch_f32": cp.get("torch_f32", {}).get("overall_mm"), "spread": cp.get("spread_mm"),
                                           "unit": "mm", "steps": 600, "seeds": [0, 1], "what": cp.get("what"),
                                           "runs": {k: [{q: r.get(q) for q in ("seed", "accuracy_mm", "completeness_mm", "overall_mm",
                                                                                   "train_s", "error")} for r in v["runs"]]
                                                    for k, v in cp.items() if isinstance(v, dict) and "runs" in v},
-                                          "long_runs": "profiles/r05_chamfer_parity.json (3000 steps, two seeds per path)"}
+                                          "long_runs": "profiles/r05_chamfer_parity_prior.json (3000 steps, three seeds per path, with the "
+                                                       "synthetic MVS prior); profiles/r05_chamfer_parity*.json without a prior"}
             except Exception as e:
                 line["chamfer_parity"] = {"error": repr(e)}
         if not args.no_cpu_baseline and args.model == "dtu" and world == 1:      # rank 0 at N = 1 only

@@ -213,16 +213,16 @@ __global__ __launch_bounds__(256, NS <= 2 ? 4 : 2) void warp_variance_kernel(War
 #endif
 constexpr int kWarpDz = SVS_WARP_DZ;
 
+// depth: the hypothesis of voxel (d, y, x), loaded by the caller (all of a thread's loads are requested before the first
+// projection: a load per loop iteration in front of its ~100 dependent instructions was a latency chain, round 5)
 template <int C>
-__device__ __forceinline__ void warp_taps(const WarpArgs& a, int v, int x, int y, int d, f32x4& w4, i32x4& o4) {
+__device__ __forceinline__ void warp_taps(const WarpArgs& a, int v, int x, int y, int d, float depth, f32x4& w4, i32x4& o4) {
   const int H = a.H, W = a.W;
   w4 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   o4 = i32x4{0, 0, 0, 0};
   if (x >= W || d >= a.D) return;
 #if SVS_WARP_ABL & 16
-  const float depth = 500.0f + (float)d;
-#else
-  const float depth = a.depth_values[((size_t)d * H + y) * W + x];
+  depth = 500.0f + (float)d;
 #endif
   const float fx = (float)x, fy = (float)y;
   const float* R = a.rot[v];
@@ -268,49 +268,65 @@ __global__ __launch_bounds__(256, NS <= 2 ? 4 : 2) void warp_variance_reuse_kern
   const size_t HW = (size_t)H * W;
   const float inv_nv = 1.0f / (float)(NS + 1);
   const int Hp = splitvol::padded_h(H), Wp = splitvol::padded_w(W);
-  // ---- corner weights and offsets of all planes, one (plane, source, voxel) per thread and round
-  for (int i = tid; i < kWarpDz * NS * TW; i += 256) {
+  // ---- corner weights and offsets of all planes, one (plane, source, voxel) per thread and round; the depth hypotheses of
+  // all rounds first
+  constexpr int kRounds = (kWarpDz * NS * TW + 255) / 256;
+  float dep[kRounds];
+#pragma unroll
+  for (int k = 0; k < kRounds; ++k) {
+    const int i = tid + 256 * k;
+    const int dz = i / (NS * TW), r = i - dz * (NS * TW);
+    const int vx = r - (r / TW) * TW;
+    const int x = xt + vx, d = d0 + dz;
+    dep[k] = (i < kWarpDz * NS * TW && x < W && d < a.D) ? a.depth_values[((size_t)d * H + y) * W + x] : 0.0f;
+  }
+#pragma unroll
+  for (int k = 0; k < kRounds; ++k) {
+    const int i = tid + 256 * k;
+    if (i >= kWarpDz * NS * TW) break;
     const int dz = i / (NS * TW), r = i - dz * (NS * TW);
     const int v = r / TW, vx = r - v * TW;
     f32x4 w4; i32x4 o4;
 #if SVS_WARP_ABL & 4
     w4 = f32x4{0.25f, 0.25f, 0.25f, 0.25f}; o4 = i32x4{0, C * 4, C * 4 * W, C * 4 * (W + 1)};
 #else
-    warp_taps<C>(a, v, xt + vx, y, d0 + dz, w4, o4);
+    warp_taps<C>(a, v, xt + vx, y, d0 + dz, dep[k], w4, o4);
 #endif
     tapw[dz][v][vx] = w4;
     tapo[dz][v][vx] = o4;
   }
   __syncthreads();
+  // Loads and stores retire from vmcnt in issue order: a wait for a plane's gathers also waited for the previous plane's
+  // stores to be acknowledged -- every plane paid a write latency (ablation, round 5: the stores cost 0.085 of the kernel's
+  // 0.205 ms although nothing reads them).  The plane loop is therefore skewed by one plane: a plane's two stores are issued
+  // BEHIND the table reads and (conditional) gathers of the next plane -- or of the next pass's first plane, which are
+  // unconditional: a new voxel -- so that the wait in front of the next blend leaves exactly those stores in flight.
+  f32x4 f[NS][4];
+  i32x4 held[NS];
+  f32x4 w4s[NS];
+  f32x4 ref;
+  auto first_gathers = [&](int pass) {
+    const int vxn = pass * VPP + vl;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ref[j] = xt + vxn < W ? a.ref[(size_t)(4 * cg + j) * HW + (size_t)y * W + xt + vxn] : 0.0f;
+#pragma unroll
+    for (int v = 0; v < NS; ++v) {
+      w4s[v] = tapw[0][v][vxn];
+      const i32x4 o4 = tapo[0][v][vxn];
+      const char* __restrict__ src = reinterpret_cast<const char*>(a.src_hwc[v]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) f[v][k] = *reinterpret_cast<const f32x4*>(src + ((unsigned)o4[k] + 16u * cg));
+      held[v] = o4;
+    }
+  };
+  first_gathers(0);
 #pragma unroll 1
   for (int p = 0; p < kPasses; ++p) {
     const int vx = p * VPP + vl, x = xt + vx;
-    f32x4 ref;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) ref[j] = x < W ? a.ref[(size_t)(4 * cg + j) * HW + (size_t)y * W + x] : 0.0f;
-    f32x4 f[NS][4];
-    i32x4 held[NS];
-#pragma unroll
-    for (int v = 0; v < NS; ++v) held[v] = i32x4{-1, -1, -1, -1};
 #pragma unroll
     for (int dz = 0; dz < kWarpDz; ++dz) {
       const int d = d0 + dz;
       f32x4 sum = ref, sq = ref * ref;
-      f32x4 w4s[NS];
-      // all sources' (conditional) gathers are requested before the first blend
-#pragma unroll
-      for (int v = 0; v < NS; ++v) {
-        w4s[v] = tapw[dz][v][vx];
-        const i32x4 o4 = tapo[dz][v][vx];
-        const char* __restrict__ src = reinterpret_cast<const char*>(a.src_hwc[v]);
-        // (a voxel's LPV lanes take the same branch; a corner outside the image has offset 0 and weight 0)
-        if (!((SVS_WARP_ABL & 2) && dz > 0) &&
-            (o4[0] != held[v][0] || o4[1] != held[v][1] || o4[2] != held[v][2] || o4[3] != held[v][3])) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) f[v][k] = *reinterpret_cast<const f32x4*>(src + ((unsigned)o4[k] + 16u * cg));
-          held[v] = o4;
-        }
-      }
 #pragma unroll
       for (int v = 0; v < NS; ++v) {
         f32x4 warped = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -321,14 +337,37 @@ __global__ __launch_bounds__(256, NS <= 2 ? 4 : 2) void warp_variance_reuse_kern
       }
       const f32x4 m = sum * inv_nv;
       const f32x4 res = sq * inv_nv - m * m;
-      if (x < W && d < a.D && !((SVS_WARP_ABL & 1) && res[0] != 1.2345e-30f)) {
-        f16x4 h, lo;
+      f16x4 h, lo;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const _Float16 hh = (_Float16)res[j];
-          h[j] = hh;
-          lo[j] = (_Float16)(res[j] - (float)hh);
+      for (int j = 0; j < 4; ++j) {
+        const _Float16 hh = (_Float16)res[j];
+        h[j] = hh;
+        lo[j] = (_Float16)(res[j] - (float)hh);
+      }
+      // the next plane's corner weights and (conditional) gathers: all sources requested before this plane's stores
+      if (dz + 1 < kWarpDz) {
+#pragma unroll
+        for (int v = 0; v < NS; ++v) {
+          w4s[v] = tapw[dz + 1][v][vx];
+          const i32x4 o4 = tapo[dz + 1][v][vx];
+          const char* __restrict__ src = reinterpret_cast<const char*>(a.src_hwc[v]);
+          // (a voxel's LPV lanes take the same branch; a corner outside the image has offset 0 and weight 0)
+#if SVS_WARP_ABL & 32          // diagnostic: every plane gathers again (no reuse along depth; static load / store counts)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) f[v][k] = *reinterpret_cast<const f32x4*>(src + ((unsigned)o4[k] + 16u * cg));
+#else
+          if (!(SVS_WARP_ABL & 2) &&
+              (o4[0] != held[v][0] || o4[1] != held[v][1] || o4[2] != held[v][2] || o4[3] != held[v][3])) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) f[v][k] = *reinterpret_cast<const f32x4*>(src + ((unsigned)o4[k] + 16u * cg));
+            held[v] = o4;
+          }
+#endif
         }
+      } else if (p + 1 < kPasses) {
+        first_gathers(p + 1);
+      }
+      if (x < W && d < a.D && !((SVS_WARP_ABL & 1) && res[0] != 1.2345e-30f)) {
         uint2* u = reinterpret_cast<uint2*>(a.split + splitvol::unit(d, y, 0, cg >> 1, x, C / 8, Hp, Wp)) + (cg & 1);
         u[0] = __builtin_bit_cast(uint2, h);
         u[(size_t)(C / 8) * Wp * 2] = __builtin_bit_cast(uint2, lo);

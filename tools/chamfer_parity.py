@@ -38,9 +38,40 @@ IMG_RES = (192, 256)
 MM = 200.0                      # world millimetres per normalised scene unit (the dataset's scale_factor)
 
 
-def make_args(rays):
+PRIOR_D, PRIOR_Z = 48, (1.8, 3.3)      # the synthetic MVS prior: 48 depth planes over the scene's depth range (normalised units)
+
+
+def build_prior(ds):
+    """An MVS prior for the training views from the ANALYTIC depth maps, in the form the MVS stage hands to
+    `VolOpt.get_mvs_input` (runner.py:209-236: per view a probability volume (1, D, h, w) and its depth hypotheses in MVS
+    units): D uniform planes over the scene's depth range at half the image resolution, probability = a Gaussian of one
+    plane spacing around the true depth, normalised over the planes; pixels that miss the object carry no probability (the
+    confidence test of the loss, loss.py:96-105, then applies the sparsity term to their rays).  What a converged CasMVSNet
+    stage would give on this scene, without the network (the image holds no trained weights)."""
+    import numpy as np
+    import torch
+    H, W = ds.img_res
+    h, w = H // 2, W // 2
+    planes = np.linspace(PRIOR_Z[0], PRIOR_Z[1], PRIOR_D).astype(np.float32)
+    step = planes[1] - planes[0]
+    outs = []
+    for i in ds.trains_ids():
+        r = ds.renders[i]
+        depth = r["depth"].reshape(h, 2, w, 2)
+        hit = r["mask"].reshape(h, 2, w, 2)
+        n = hit.sum((1, 3))
+        d = np.where(n > 0, (depth * hit).sum((1, 3)) / np.maximum(n, 1), 0.0).astype(np.float32)      # mean over the hit sub-pixels
+        prob = np.exp(-0.5 * ((planes[:, None, None] - d[None]) / step) ** 2)
+        prob = prob / np.maximum(prob.sum(0, keepdims=True), 1e-12) * (n[None] > 0)
+        z = np.broadcast_to(planes[:, None, None], (PRIOR_D, h, w)) * MM
+        outs.append(dict(prob_volume=torch.from_numpy(prob.astype(np.float32))[None],
+                         depth_values=torch.from_numpy(np.ascontiguousarray(z, np.float32))[None]))
+    return outs
+
+
+def make_args(rays, prior=False):
     import test_gpu_volopt as tv
-    a = tv.make_args()
+    a = tv.make_args(use_mvs=prior)
     a["vol"]["train"].update(dataset_class="synthetic_scene.AnalyticSceneDataset", num_pixels=rays, render_freq=10 ** 9,
                              checkpoint_freq=10 ** 9, plot_freq=10 ** 9)
     a["vol"]["dataset"].update(img_res=list(IMG_RES), scale_factor=MM)
@@ -48,22 +79,25 @@ def make_args(rays):
     return a
 
 
-def train_hip(seed, steps, rays):
-    """VolOpt.run as runner.py drives it (no MVS prior: the loss is the colour term + 0.1 eikonal, loss.py:80-114)."""
+def train_hip(seed, steps, rays, prior=False):
+    """VolOpt.run as runner.py drives it.  Without a prior the loss is the colour term + 0.1 eikonal (loss.py:80-114); with
+    the synthetic MVS prior (build_prior) it is the reference's stage-0 loss: MVS term, annealed sparsity and rgb_smooth."""
     import numpy as np
     import torch
     import test_gpu_volopt as tv
     torch.manual_seed(seed); random.seed(seed); np.random.seed(seed)
-    v = tv.build(make_args(rays))
+    v = tv.build(make_args(rays, prior))
     v._preview = lambda *x, **k: None
     v.save_checkpoints = lambda *x, **k: None
+    if prior:
+        v.get_mvs_input(build_prior(v.train_dataset))
     t0 = time.perf_counter()
     v.run(opt_stepN=steps)
     torch.cuda.synchronize()
     return v, dict(steps=int(v.iter_step), train_s=time.perf_counter() - t0)
 
 
-def train_torch(seed, steps, rays):
+def train_torch(seed, steps, rays, prior=False):
     """The same optimisation in plain PyTorch float32 (oracle/torch_ref.py) on the GPU; the trained weights are loaded into a
     VolOpt (never stepped) for the common render -> fuse -> evaluate tail."""
     import numpy as np
@@ -73,8 +107,16 @@ def train_torch(seed, steps, rays):
     import test_gpu_volopt as tv
     from svs_hip import ops
     torch.manual_seed(seed); random.seed(seed); np.random.seed(seed)
-    v = tv.build(make_args(rays))
+    v = tv.build(make_args(rays, prior))
     ds, dev = v.train_dataset, torch.device("cuda", 0)
+    views = None
+    if prior:
+        views = []
+        for i, o in zip(ds.trains_ids(), build_prior(ds)):
+            z = (o["depth_values"][0] / MM).to(dev)
+            views.append(dict(K=ds.intrinsics_all[i], c2w=ds.pose_all[i], cost=o["prob_volume"][0].to(dev),
+                              z_near=z[0].contiguous(), z_far=z[-1].contiguous()))
+        smooth = {i: ds.rgb_smooth[i].to(dev) for i in ds.trains_ids()}
     p = {k: t.detach().clone().float().to(dev).requires_grad_(True) for k, t in v.model.state_dict().items()}
     opt = torch.optim.Adam(list(p.values()), lr=5e-4)
     imgs = {i: ds.rgb_images[i].to(dev) for i in ds.trains_ids()}
@@ -99,8 +141,13 @@ def train_torch(seed, steps, rays):
             eik = torch.cat([torch.empty(rays, 3, device=dev).uniform_(-3.0, 3.0), cam.view(1, 3) + z_eik.view(-1, 1) * dirs], 0)
         out = tref.forward_differentiable(p, cam, dirs, z, eik, dscale, device=dev)
         rgb = imgs[idx][sel]
+        rgb_s = rgb
+        if prior:
+            xyz = cam.view(1, 1, 3) + z.unsqueeze(-1) * dirs.unsqueeze(1)
+            out["pj"], out["pi"], _ = tref.cost_mapping(xyz, list(ds.trains_ids()).index(idx), views, (H, W), False)
+            rgb_s = smooth[idx][sel]
         opt.zero_grad(set_to_none=True)
-        tref.loss_fn(out, rgb, rgb, it).backward()
+        tref.loss_fn(out, rgb, rgb_s, it).backward()
         torch.nn.utils.clip_grad_norm_(list(p.values()), 1.0)
         opt.step()
     torch.cuda.synchronize()
@@ -170,14 +217,14 @@ def fuse_and_evaluate(v, workdir):
                 n_ground_truth=int(len(stl)), render_s=render_s)
 
 
-def child(path, seed, steps, rays):
+def child(path, seed, steps, rays, prior=False):
     import torch
     assert torch.cuda.is_available(), "chamfer_parity needs the GPU"
     cwd = os.getcwd()
     work = tempfile.mkdtemp(prefix="svs_chamfer_")
     os.chdir(work)
     try:
-        v, info = (train_torch if path == "torch_f32" else train_hip)(seed, steps, rays)
+        v, info = (train_torch if path == "torch_f32" else train_hip)(seed, steps, rays, prior)
         info.update(fuse_and_evaluate(v, work))
         from svs_hip import ops
         info["precision"] = "torch float32 autograd" if path == "torch_f32" else str(ops.default_precision())
@@ -187,7 +234,7 @@ def child(path, seed, steps, rays):
     print(json.dumps(info), flush=True)
 
 
-def measure(steps=3000, seeds=(0, 1), paths=("hip", "hip_f32", "torch_f32"), rays=512, timeout=3000):
+def measure(steps=3000, seeds=(0, 1), paths=("hip", "hip_f32", "torch_f32"), rays=512, timeout=3000, prior=False):
     res = {}
     for path in paths:
         runs = []
@@ -196,7 +243,7 @@ def measure(steps=3000, seeds=(0, 1), paths=("hip", "hip_f32", "torch_f32"), ray
             env.pop("SVS_MLP_PRECISION", None)
             if path == "hip_f32":
                 env["SVS_MLP_PRECISION"] = "f32"
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", f"{path}:{s}:{steps}:{rays}"], env=env,
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", f"{path}:{s}:{steps}:{rays}:{int(prior)}"], env=env,
                                capture_output=True, text=True, timeout=timeout)
             try:
                 runs.append(dict(seed=s, **json.loads(next(l for l in reversed(r.stdout.strip().splitlines()) if l.startswith("{")))))
@@ -212,7 +259,9 @@ def measure(steps=3000, seeds=(0, 1), paths=("hip", "hip_f32", "torch_f32"), ray
     res["spread_mm"] = max([v.get("spread_mm", 0.0) for v in res.values() if isinstance(v, dict)] or [0.0])
     if "overall_mm" in res.get("hip", {}) and "overall_mm" in res.get("torch_f32", {}):
         res["hip_minus_torch_mm"] = res["hip"]["overall_mm"] - res["torch_f32"]["overall_mm"]
-    res["what"] = (f"analytic sphere + box scene ({IMG_RES[0]} x {IMG_RES[1]} images, 3 training views, {MM:.0f} mm per unit): {steps} "
+    res["prior"] = bool(prior)
+    res["what"] = (("WITH a synthetic MVS prior (48 planes, Gaussian around the analytic depth; MVS + annealed sparsity + rgb_smooth terms): "
+                    if prior else "no MVS prior (colour + eikonal terms): ") + f"analytic sphere + box scene ({IMG_RES[0]} x {IMG_RES[1]} images, 3 training views, {MM:.0f} mm per unit): {steps} "
                    f"optimisation steps of {rays} rays per path and seed -> render_mvs -> filter_depth -> evaluate_scan against the "
                    "analytic surface points the training views see; overall = (accuracy + completeness) / 2 in mm")
     return res
@@ -220,8 +269,8 @@ def measure(steps=3000, seeds=(0, 1), paths=("hip", "hip_f32", "torch_f32"), ray
 
 if __name__ == "__main__":
     if len(sys.argv) == 3 and sys.argv[1] == "--child":
-        path, seed, steps, rays = sys.argv[2].split(":")
-        child(path, int(seed), int(steps), int(rays))
+        path, seed, steps, rays, prior = (sys.argv[2].split(":") + ["0"])[:5]
+        child(path, int(seed), int(steps), int(rays), prior == "1")
     else:
         ap = argparse.ArgumentParser()
         ap.add_argument("--steps", type=int, default=3000)
@@ -229,8 +278,9 @@ if __name__ == "__main__":
         ap.add_argument("--paths", default="hip,hip_f32,torch_f32")
         ap.add_argument("--rays", type=int, default=512)
         ap.add_argument("--out", default=None)
+        ap.add_argument("--prior", action="store_true", help="optimise with the synthetic MVS prior (the reference's stage-0 loss)")
         a = ap.parse_args()
-        out = measure(a.steps, tuple(int(s) for s in a.seeds.split(",")), tuple(a.paths.split(",")), a.rays)
+        out = measure(a.steps, tuple(int(s) for s in a.seeds.split(",")), tuple(a.paths.split(",")), a.rays, prior=a.prior)
         text = json.dumps(out, indent=1)
         print(text)
         if a.out:
