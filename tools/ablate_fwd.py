@@ -76,6 +76,11 @@ def child(mask):
         start = o[:, 5]
         res["wg_start_spread_us"] = round(float((start.max() - start.min()) % (1 << 24)) / 100.0, 1)
     res["sdf_full_ms"] = round(timeit(lambda: ops.sdf_outputs(pk, s100, 3.0, 20.0, clamp_n=R * 98, keep={})), 4)
+    if not (mask & 16):
+        # the radiance forward (training launch: r blocks stored) on the same points
+        _, grads, feat, _, _ = ops.sdf_outputs(pk, s100, 3.0, 20.0, clamp_n=R * 98, keep={})
+        res["rgb_ms"] = round(timeit(lambda: ops.rgb_eval(pk, s100, grads, dirs, feat, keep={})), 4)
+        res["rgb_render_ms"] = round(timeit(lambda: ops.rgb_eval(pk, s100, grads, dirs, feat)), 4)
     if mask & 16:   # sdf_full_h2_kernel's stamps: pe, trunk, head, features, reverse 7..1, reverse 0 + Jacobian, total
         o = ops.sdf_outputs(pk, s100, 3.0, 20.0, clamp_n=R * 98, keep={})
         o = o[1].reshape(-1, 384)[:, :8].double().cpu()
