@@ -67,6 +67,43 @@ __device__ __forceinline__ void load_tile_pair(const float* __restrict__ blk, in
 __device__ __forceinline__ float hi_at(const TilePieces& p, int r) { return (float)p.h[r >> 3][r & 7]; }
 __device__ __forceinline__ float pair_at(const TilePieces& p, int r) { return (float)p.h[r >> 3][r & 7] + (float)p.m[r >> 3][r & 7]; }
 
+// The same sums and products in one instruction each (v_fma_mix_f32 converts its fp16 operands on the way in; hipcc 7.2 does
+// not form it from the C expressions above but emits cvt + cvt + add).  j: the element's index in its fragment (0..7), a
+// constant once the epilogue loops are unrolled: the branch on its parity folds away.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned word_of(const f16x8& v, int j) { return __builtin_bit_cast(u32x4, v)[j >> 1]; }
+__device__ __forceinline__ float mix_sum(unsigned h, unsigned m, int odd) {      // (float)h.half[odd] + (float)m.half[odd]
+  float r;
+  if (odd) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(h), "v"(m));
+  else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(h), "v"(m));
+  return r;
+}
+__device__ __forceinline__ float mix_fma(unsigned h, int odd, float c, float a) {   // (float)h.half[odd] * c + a
+  float r;
+  if (odd) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(c), "v"(a));
+  else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(c), "v"(a));
+  return r;
+}
+__device__ __forceinline__ float mix_mul(unsigned h, int odd, float c) {            // (float)h.half[odd] * c
+  float r;
+  if (odd) asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(c));
+  else asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(c));
+  return r;
+}
+// element r of a tile: value * c (both pieces with GP: hi * c + mid * c, two instructions)
+template <bool GP>
+__device__ __forceinline__ float grad_times(const TilePieces& p, int r, float c) {
+  const int q = r >> 3, j = r & 7;
+  if (GP) return mix_fma(word_of(p.h[q], j), j & 1, c, mix_mul(word_of(p.m[q], j), j & 1, c));
+  return mix_mul(word_of(p.h[q], j), j & 1, c);
+}
+template <bool GP>
+__device__ __forceinline__ float grad_mix(const TilePieces& p, int r) {
+  const int q = r >> 3, j = r & 7;
+  if (GP) return mix_sum(word_of(p.h[q], j), word_of(p.m[q], j), j & 1);
+  return mix_mul(word_of(p.h[q], j), j & 1, 1.0f);
+}
+
 // The record of block l, wave tile `tile` of a buffer of nb blocks x T wave tiles laid out [block][tile] (T = the padded
 // tile count of the launch that wrote it: gridDim.x * kWaves).
 template <typename F>

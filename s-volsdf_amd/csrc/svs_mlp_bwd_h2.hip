@@ -227,7 +227,7 @@ struct PassAEpi {
   }
   __device__ __forceinline__ void a(int r) {
     v = prev[r] * ps->inv_in;
-    s1 = dsoftplus_from_h(grad_at<GP>(h, r));
+    s1 = 1.0f - __builtin_amdgcn_exp2f(grad_times<GP>(h, r, -100.0f * 1.44269504088896341f));   // s'(a) from h (svs_mlp_dev.h)
     pin(v); pin(s1);
   }
   template <bool LATE = false>     // LATE: the stores wait for store_slot() (behind the tile's LDS-DMA pieces)
@@ -467,9 +467,18 @@ struct PassBEpi {
   float sbar, u_inv100;    // u_inv100: 100 / (scale the u block was stored under)
   int lane, half;
   bool l4;            // producing abar_3: rows >= 217 of h_4 are the PE splice
+#if SVS_ABL & 65536
+  unsigned* cyc;
+#endif
   __device__ __forceinline__ void a(int r) {
     v = prev[r] * ps->inv_in;
-    const float e = __builtin_amdgcn_exp2f(grad_at<GP>(h, r) * (-100.0f * 1.44269504088896341f));   // 1 - s'
+#if SVS_ABL & 32768    // diagnostic: no softplus' arithmetic
+    float e = 0.5f;
+#else
+    float e = __builtin_amdgcn_exp2f(grad_times<GP>(h, r, -100.0f * 1.44269504088896341f));   // 1 - s'
+#endif
+    // (A2: s' >= 2^-24 keeps the quotient of b() finite; where softplus' underflowed u is 0 and so is the product)
+    if (A2) e = __builtin_fminf(e, 0.99999994f);
     s1 = 1.0f - e;
     if (A2) q = e * u_inv100;
     pin(v); pin(s1);
@@ -478,13 +487,17 @@ struct PassBEpi {
   template <bool LATE = false>
   __device__ __forceinline__ void b(int tp, int r) {
     float o = v * s1;
+#if SVS_ABL & 16384    // diagnostic: no second-order / sbar terms in the epilogue
+    if (false) {
+#else
     if (A2) {
-      const float gg = grad_at<GP>(g, r);
-      const float t = grad_at<GP>(u, r) * gg;
-      o += t * (q * __builtin_amdgcn_rcpf(__builtin_fmaxf(s1, 1e-30f)));
-      if (FIRST) o += sbar * gg;
+#endif
+      const float gg = grad_mix<GP>(g, r);
+      const float t = grad_times<GP>(u, r, gg);
+      o = __builtin_fmaf(t, q * __builtin_amdgcn_rcpf(s1), o);
+      if (FIRST) o = __builtin_fmaf(sbar, gg, o);
     } else if (FIRST) {
-      o += sbar * grad_at<GP>(g, r);      // ghat_7 = W8[0,:] s'(a_7)
+      o = __builtin_fmaf(sbar, grad_mix<GP>(g, r), o);      // ghat_7 = W8[0,:] s'(a_7)
     }
     if (l4 && tp > Net::kSpliceTile) o = 0.0f;
     if (l4 && tp == Net::kSpliceTile) {
@@ -506,10 +519,15 @@ struct PassBEpi {
       } else {
         ap[q2] = hi8(v8, 1.0f);
       }
+#if !(SVS_ABL & 8192)  // diagnostic: no abar stores
       if (!LATE) store_grad<GP>(ablk, k, lane, ap[q2], aq[q2]);
+#endif
     }
   }
   __device__ __forceinline__ void store_slot(int tp, int s) {     // behind the tile's LDS-DMA pieces
+#if SVS_ABL & 8192
+    return;
+#endif
     if (s == 9) store_grad<GP>(ablk, 2 * tp, lane, ap[0], aq[0]);
     if (s == 15) store_grad<GP>(ablk, 2 * tp + 1, lane, ap[1], aq[1]);
   }
@@ -536,13 +554,16 @@ __device__ __forceinline__ void pass_b_stage_h2(Stream& st, const Pieces2& in, P
   if (A2) load_tile_grad<GP>(ublk, 0, lane, unext);
   if (kG) load_tile_grad<GP>(gblk, 0, lane, gnext);
   constexpr int kPer = GP ? 4 : 2;
-  constexpr int kLoads = kPer * (1 + (A2 ? 1 : 0) + (kG ? 1 : 0));
-  constexpr int kStores = GP ? 4 : 2;
+  constexpr int kLoads = (SVS_ABL & 4096) ? 0 : kPer * (1 + (A2 ? 1 : 0) + (kG ? 1 : 0));
+  constexpr int kStores = (SVS_ABL & 8192) ? 0 : (GP ? 4 : 2);
+#if SVS_ABL & 65536    // diagnostic: cycles per tile, MFMA part and wait + barrier part, summed over the stages
+  uint64_t t0 = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     const TilePieces hcur = hnext, ucur = unext, gcur = gnext;
     auto side = [&](int s) {
-      if (t == 7) return;
+      if (t == 7 || (SVS_ABL & 4096)) return;      // (4096: diagnostic, no side-tile loads)
       if (s == 10) hnext.h[0] = load_piece(hblk, 2 * (t + 1), lane);
       if (s == 11) hnext.h[1] = load_piece(hblk, 2 * (t + 1) + 1, lane);
       if (A2 && s == 12) unext.h[0] = load_piece(ublk, 2 * (t + 1), lane);
@@ -567,13 +588,26 @@ __device__ __forceinline__ void pass_b_stage_h2(Stream& st, const Pieces2& in, P
     ep.prev = acc; ep.h = hcur;
     if (A2) ep.u = ucur;
     if (kG) ep.g = gcur;
+#if SVS_ABL & 65536
+    asm volatile("" : "+v"(ep.prev[15]));
+    const uint64_t t1 = __builtin_amdgcn_s_memtime();
+#endif
     if (fetch) {
       if (t == 0) st.advance_keep<kLoads>();
       else if (t < 7) st.advance_keep<kLoads + kStores>();
       else st.advance_keep<kStores>();
     }
+#if SVS_ABL & 65536
+    const uint64_t t2 = __builtin_amdgcn_s_memtime();
+    ep.cyc[t] += (unsigned)(t1 - t0); ep.cyc[8 + t] += (unsigned)(t2 - t1);
+    t0 = t2;
+#endif
   }
   ep.all(7);
+#if SVS_ABL & 65536
+  asm volatile("" : "+v"(ep.v8[7]));
+  ep.cyc[16] += (unsigned)(__builtin_amdgcn_s_memtime() - t0);
+#endif
   ep.ps->floor_m = next_floor;
   ep.ps->next();
 }
@@ -607,6 +641,11 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_h2_kernel(SdfBwdBArgs a
     return A2 ? __builtin_fmaxf(asb, load_max(urec(l + 1), lane) * load_max(record_ptr(a.gbuf, 8, T, l, wtile), lane)) : asb;
   };
   const bool has_f = a.feat_bar && wtile < a.n_feat_tiles;
+#if SVS_ABL & 65536
+  unsigned cyc[17];
+  for (int i = 0; i < 17; ++i) cyc[i] = 0;
+  const uint64_t k0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   PointScale ps;
   Pieces2 pa, pb;
   {
@@ -634,6 +673,9 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_h2_kernel(SdfBwdBArgs a
     // hbar_8 fused with abar_7 (ghat_7 = W8[0,:] s'(a_7), stored unscaled)
     PassBEpi<true, true, Net, A2, GP> ep;
     ep.out = &pb; ep.ablk = ab + 7 * LS; ep.arec = arec(7); ep.ps = &ps; ep.sbar = sbar; ep.lane = lane; ep.half = half; ep.l4 = false;
+#if SVS_ABL & 65536
+    ep.cyc = cyc;
+#endif
     pass_b_stage_h2<true, true, false, Net, A2, GP>(st, pa, ep, hb + 7 * LS, A2 ? ub + 8 * LS : nullptr, urec(8), gb + 7 * LS,
                                                     floor_of(6), lane);
   }
@@ -642,6 +684,9 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_h2_kernel(SdfBwdBArgs a
     PassBEpi<false, true, Net, A2, GP> ep;
     ep.out = &pa; ep.ablk = ab + (size_t)(l - 1) * LS; ep.arec = arec(l - 1); ep.ps = &ps; ep.sbar = 0.0f; ep.lane = lane; ep.half = half;
     ep.l4 = l == 4;
+#if SVS_ABL & 65536
+    ep.cyc = cyc;
+#endif
     pass_b_stage_h2<false, true, false, Net, A2, GP>(st, pb, ep, hb + (size_t)(l - 1) * LS, A2 ? ub + (size_t)l * LS : nullptr, urec(l),
                                                      A2 ? gb + (size_t)(l - 1) * LS : nullptr, floor_of(l >= 2 ? l - 2 : 0), lane);
 #pragma unroll
@@ -651,9 +696,23 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_h2_kernel(SdfBwdBArgs a
     // layer 1: abar_1 (in pb) -> abar_0, stored only
     PassBEpi<false, false, Net, A2, GP> ep;
     ep.out = nullptr; ep.ablk = ab; ep.arec = arec(0); ep.ps = &ps; ep.sbar = 0.0f; ep.lane = lane; ep.half = half; ep.l4 = false;
+#if SVS_ABL & 65536
+    ep.cyc = cyc;
+#endif
     pass_b_stage_h2<false, false, true, Net, A2, GP>(st, pb, ep, hb, A2 ? ub + LS : nullptr, urec(1), A2 ? gb : nullptr, asb, lane);
   }
   publish_max(a.absmax, ps.gmax);
+#if SVS_ABL & 65536
+  {
+    const uint64_t k1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    __syncthreads();
+    if (threadIdx.x == 0 && a.sbar_out) {     // per tile index: MFMA part x8, wait part x8, last epilogue, total, real time
+      float* o = a.sbar_out + (size_t)blockIdx.x * kWaves * kTilePts;
+      for (int i = 0; i < 17; ++i) o[i] = (float)cyc[i];
+      o[17] = (float)(k1 - k0); o[18] = (float)(r1 - r0);
+    }
+  }
+#endif
 }
 
 // d loss / d W_8[0,:] = sum_p (sbar_p h_8[:,p] + u_8[:,p]);  d loss / d b_8[0] = sum_p sbar_p  (svs_mlp_bwd.hip) on the fp16x2

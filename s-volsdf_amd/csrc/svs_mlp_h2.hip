@@ -89,7 +89,7 @@ struct RevEpi {
 #if SVS_ABL & 512      // diagnostic: no softplus' arithmetic in the reverse epilogue
     d = 0.5f;
 #else
-    d = __builtin_amdgcn_exp2f(pair_at(h, r) * (-100.0f * 1.44269504088896341f));
+    d = __builtin_amdgcn_exp2f(grad_times<true>(h, r, -100.0f * 1.44269504088896341f));
 #endif
     pin(d);
   }

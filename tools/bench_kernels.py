@@ -32,7 +32,7 @@ def timeit(fn, n=10):
 def main():
     dev = torch.device("cuda:0")
     L = lib.load()
-    R = 1024
+    R = int(os.environ.get("BK_RAYS", "1024"))
     params = synth.make_params(0)
     m = VolSDFNetwork(dtu_model_conf())
     m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
@@ -74,7 +74,7 @@ def main():
         name = "wgrad_multi_%d_layers" % a[1]
         t = timeit(lambda: lib.check(orig(a[0], a[1], a[2], ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))))
         res[name] = dict(ms=t)
-    P = lambda x: ctypes.c_void_p(x.data_ptr())
+    P = lambda x: ctypes.c_void_p(x.data_ptr()) if x is not None else None
     st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     dn = torch.empty(n_main, 3, device=dev)
     prec = bw.streams.precision
@@ -94,6 +94,14 @@ def main():
     t = timeit(lambda: lib.check(L.svs_sdf_bwd_b(n_total, P(dsf), P(mask), P(bw.feat_bar), n_main, P(hbuf), P(gbuf), P(bw.a2buf), P(bw.ubuf),
                                                  P(bw.streams.sdf), prec, P(bw.abuf), P(bw.sbar), N(am), st())))
     res["sdf_bwd_b"] = dict(ms=t, tflops=n_total * F_SDF / t / 1e9)
+    if os.environ.get("BK_STAMPS"):      # a -DSVS_ABL=65536 build: cycle stamps of wave 0 of every workgroup in sbar_out
+        torch.cuda.synchronize()
+        o = bw.sbar[: (n_total // 128) * 128].reshape(-1, 128)[:, :19].double().cpu().numpy()
+        np.set_printoptions(linewidth=200, suppress=True)
+        print("workgroups", o.shape[0], "shader MHz during the kernel %.0f" % (o[:, 17] / o[:, 18] * 100).mean(), file=sys.stderr)
+        print("per tile index, cycles summed over 8 stages: MFMA part", o[:, :8].mean(0).round(0), file=sys.stderr)
+        print("                                    wait + barrier part", o[:, 8:16].mean(0).round(0), file=sys.stderr)
+        print("last epilogues %.0f  total %.0f  (sum of parts %.0f)" % (o[:, 16].mean(), o[:, 17].mean(), o[:, :17].sum(1).mean()), file=sys.stderr)
     from svs_hip.train import block_stride, record_off
     LS = block_stride(n_total)
     R = lambda buf, n, nb, l: _off(buf, record_off(n, nb, l)) if h2 else None
