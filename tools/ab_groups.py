@@ -22,9 +22,24 @@ for j, dx in enumerate((0.0, 0.3, -0.3)):
     views.append(dict(K=Kj, c2w=Pj, cost=prob, z_near=zm[0].contiguous(), z_far=zm[-1].contiguous()))
 mvs = dict(views=views, same_view=0, img_res=(576, 768), inverse_depth=False)
 cfgs = {}
+def spans(*sizes):
+    out, lo = [], 0
+    for n in sizes:
+        out.append((lo, lo + n)); lo += n
+    assert lo == R
+    return out
+
+
+SEL = os.environ.get("AB_GROUPS")
 for name, groups in (("none", None), ("auto", "auto"), ("halves", [(0, 512), (512, 1024)]), ("q3+1", [(0, 768), (768, 1024)]),
+                     ("656+368", spans(656, 368)), ("640+336+48", spans(640, 336, 48)),
+                     ("336+336+352", spans(336, 336, 352)), ("320+320+384", spans(320, 320, 384)), ("384+384+256", spans(384, 384, 256)),
+                     ("400+400+224", spans(400, 400, 224)), ("320+336+368", spans(320, 336, 368)), ("256x4", spans(256, 256, 256, 256)),
+                     ("320x3+64", spans(320, 320, 320, 64)), ("496+480+48", spans(496, 480, 48)),
                      ("thirds", [(0, 352), (352, 704), (704, 1024)]), ("quarters", [(0, 256), (256, 512), (512, 768), (768, 1024)]),
                      ("3/8-3/8-1/4", [(0, 384), (384, 768), (768, 1024)]), ("eighths", [(128 * i, 128 * (i + 1)) for i in range(8)])):
+    if SEL and name not in SEL.split(","):
+        continue
     m = VolSDFNetwork(dtu_model_conf()); m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_params(0).items()}); m.to(dev).train()
     loss = VolSDFLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, rgb_weight=1.0, mvs_weight=1.0, sparse_weight=1.0, anneal_rgb=200, gce=0.5, confi=1e-3)
     if groups == "auto-rev":
