@@ -40,8 +40,16 @@ __device__ __forceinline__ void chunk_issue_piece(const f32x4* __restrict__ g, f
     // "may lead to undefined behaviour".  No other M0 user exists in the translation units that contain this asm: no
     // s_movrel / sendmsg / builtin LDS-DMA.)
     const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)(lds + idx);
+#if defined(SVS_ABL) && (SVS_ABL & 131072)      // diagnostic: a quarter of the lanes only (same instruction count, a quarter of the data)
+    asm volatile("s_mov_b64 s[96:97], exec\n\ts_mov_b64 exec, 0xffff\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\t"
+                 "s_mov_b64 exec, s[96:97]" :: "v"(lane_bytes), "s"(g + idx), "s"(lds_base) : "memory", "s96", "s97");
+#elif defined(SVS_ABL) && (SVS_ABL & 262144)    // diagnostic: every lane fetches the SAME 16 bytes (same LDS write, one line of L2 traffic)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(0u), "s"(g + idx), "s"(lds_base) : "memory");
+#else
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                  :: "v"(lane_bytes), "s"(g + idx), "s"(lds_base) : "memory");
+#endif
 #else
     __builtin_amdgcn_global_load_lds(
         (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(g + idx) + lane_bytes),
