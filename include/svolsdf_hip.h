@@ -170,8 +170,8 @@ int svs_composite_bwd(int n_rays, int n_samples, const float* z, const float* sd
                       float* d_beta_ray, float* d_beta_param, void* hip_stream);
 
 /* ---- a9 (config 4)  inverted-sphere background model, VolSDFNetworkBG (volsdf/model/network_bg.py) -----------
- * fp16x2 only (precision = SVS_MMA_F16X2 or SVS_MMA_F16X2_HALF; it selects the format of the blocks kept for / written
- * by the backward).  Streams: svs_pack_stream which = 5 (bg implicit forward), 6 (bg implicit backward), 7 (bg radiance
+ * precision = SVS_MMA_F16X2 / SVS_MMA_F16X2_HALF (csrc/svs_bg_h2.hip; selects the format of the blocks kept for / written by
+ * the backward) or SVS_MMA_F32 (csrc/svs_bg_f32.hip: float32 MFMAs, every block a float32 block; same buffer sizes).  Streams: svs_pack_stream which = 5 (bg implicit forward), 6 (bg implicit backward), 7 (bg radiance
  * forward), 8 (bg radiance backward); weight arrays of 9 / 2 device pointers, weight_g = NULL (no weight-norm).
  *   svs_bg_points     UniformSampler(1,0,n_bg,far=1) * (1/radius), flipped (ray_sampler.py:22-43,215-216;
  *                     network_bg.py:79-82) + depth2pts_outside (:182-214): jitter (n_rays,n_bg) train draws or NULL

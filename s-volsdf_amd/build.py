@@ -24,6 +24,7 @@ UNITS = {
     "svs_mlp.hip": [],
     "svs_mlp_h2.hip": [],
     "svs_bg_h2.hip": [],
+    "svs_bg_f32.hip": [],
     "svs_sampler.hip": ["-ffp-contract=off"],
     "svs_render.hip": ["-ffp-contract=off"],
     "svs_costvol.hip": ["-ffp-contract=off"],

@@ -1,25 +1,13 @@
 // The inverted-sphere background networks of VolSDFNetworkBG (volsdf/model/network_bg.py:31-35, 85-103) on fp16x2
-// MFMAs: bg_implicit_network (4-D points, PE-10 = 84 inputs, 8 x 256 softplus, skip at 4, no weight-norm; output =
+// MFMAs (the float32-MFMA forms behind the same entry points: svs_bg_f32.hip): bg_implicit_network (4-D points, PE-10 = 84 inputs, 8 x 256 softplus, skip at 4, no weight-norm; output =
 // [density logit, 256 features]) and bg_rendering_network (mode 'nerf': cat[PE4(view)(27), feature(256)] -> 128 ReLU
 // -> 3 sigmoid).  Same machinery as svs_mlp_h2.hip (shared trunk: svs_mlp_h2_trunk.h with the NetBg geometry).
-#include "svs_mlp_h2_trunk.h"
+#include "svs_bg_args.h"
 #include "svs_mlp_host.h"
-#include "svs_mlp_bwd_args.h"
 #include "svs_mlp_bwd_h2_dev.h"
 
 namespace svs {
 namespace mlp {
-
-struct BgSdfArgs {
-  const float* pts;      // (P,4) inverted-sphere points (unit direction, 1/r)
-  int P;
-  const f32x4* stream;   // kStreamBgFwd
-  float* out0;           // (P) raw output[:, 0] (the density is its absolute value, AbsDensity)
-  float* feat_tiles;     // [wave tiles][kBlockF]
-  float* hbuf;           // training: [wave tiles][8][kBlockF] h_1..h_8, else nullptr
-  float* ghat7;          // training: [wave tiles][kBlockF] W8[0,:] * softplus'(a_7) (pass B's seed), else nullptr
-  float* pebuf;          // training: [wave tiles][kBlockF] the 84 PE inputs in PE order (first 3 tiles), B operand of dW_0
-};
 
 template <bool TRAIN, bool GP>      // GP: the blocks kept for the backward in the both-pieces format (svs_blocks_h2.h)
 __global__ __launch_bounds__(kThreads, 1) void bg_sdf_h2_kernel(BgSdfArgs a) {
@@ -112,20 +100,6 @@ __global__ __launch_bounds__(kThreads, 1) void bg_sdf_h2_kernel(BgSdfArgs a) {
 // ------------------------------------------------------------------------------------------------------------
 // bg_rendering_network, mode 'nerf' (network.py:170-190 with bmvs.yaml:70-77)
 // ------------------------------------------------------------------------------------------------------------
-struct BgRgbArgs {
-  int P;
-  const float* view;       // view directions: (R,3) if view_S > 0 (one per ray) else (P,3)
-  int view_S;
-  const float* feat_tiles; // [wave tiles][kBlockF]
-  const f32x4* stream;     // kStreamBgRgbFwd
-  float* rgb;              // (P,3)
-  float* rbuf;             // training: [wave tiles][kBgRbufF]: r_1 (post-ReLU, tiles 0..3) and the 32 view-PE rows, else nullptr
-};
-constexpr int kBgRbufF = kBlockF + 1024;
-constexpr int kBgRgbBufF4 = kBgRgbChunk0F4;
-
-typedef StreamT<kBgRgbBufF4> BgRgbStream;
-
 template <bool GP>      // GP: r_1 kept with both pieces
 __global__ __launch_bounds__(kThreads, 1) void bg_rgb_h2_kernel(BgRgbArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -226,18 +200,6 @@ __global__ __launch_bounds__(kThreads, 1) void bg_rgb_h2_kernel(BgRgbArgs a) {
 // bg_rendering_network backward: zbar_1 = d_rgb * sigmoid', zbar_0 = (W1^T zbar_1) * [r_1 > 0],
 // fbar = W0[:, 27:]^T zbar_0 (the view directions get no gradient).  Per-point scaling as in svs_mlp_bwd_h2.hip.
 // ------------------------------------------------------------------------------------------------------------
-struct BgRgbBwdArgs {
-  int P;
-  const float* d_rgb;      // (P,3)
-  const float* rgb;        // (P,3) forward output
-  const float* rbuf;       // forward activations [wave tiles][kBgRbufF]
-  const f32x4* stream;     // kStreamBgRgbBwd
-  float* zbuf;             // out [wave tiles][2][kBlockF]: zbar_0 (tiles 0..3), zbar_1 (rows 0..2 of tile 0); the other
-                           // tiles stay zero (ZERO-INITIALISED by the caller once)
-  float* feat_bar;         // out [wave tiles][kBlockF]
-  float* absmax;           // [3]: [1] = max |zbar|, [2] = max |feat_bar|
-};
-
 template <bool GP>
 __global__ __launch_bounds__(kThreads, 1) void bg_rgb_bwd_h2_kernel(BgRgbBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -342,11 +304,12 @@ size_t svs_bg_rbuf_bytes(int n_points) { return (size_t)wave_tiles(n_points) * k
 // training: hbuf (svs_sdf_hbuf_bytes) and ghat7 (svs_block_bytes(P,1)) for the backward, both or neither.
 int svs_bg_sdf_eval(const float* pts, int n_points, const float* stream, int precision, float* out0, float* feat_tiles,
                     float* hbuf, float* ghat7, float* pebuf, void* hip_stream) {
-  if (!is_h2(precision)) { set_error("svs_bg_sdf_eval: the background networks have fp16x2 kernels only (precision %d)", precision); return SVS_EINVAL; }
+  if (!is_h2(precision) && precision != kFmtF32) { set_error("svs_bg_sdf_eval: unknown precision %d", precision); return SVS_EINVAL; }
   if (!pts || n_points <= 0 || !stream || !out0 || !feat_tiles || (!hbuf != !ghat7) || (!hbuf != !pebuf)) {
     set_error("svs_bg_sdf_eval: null/invalid argument"); return SVS_EINVAL;
   }
   BgSdfArgs a{pts, n_points, reinterpret_cast<const f32x4*>(stream), out0, feat_tiles, hbuf, ghat7, pebuf};
+  if (precision == kFmtF32) return launch_bg_sdf_f32(a, (hipStream_t)hip_stream);
   static int once = set_lds(bg_sdf_h2_kernel<false, false>, kLdsBytes, "svs_bg_sdf_eval") |
                     set_lds(bg_sdf_h2_kernel<true, false>, kLdsBytes, "svs_bg_sdf_eval") |
                     set_lds(bg_sdf_h2_kernel<true, true>, kLdsBytes, "svs_bg_sdf_eval");
@@ -361,11 +324,12 @@ int svs_bg_sdf_eval(const float* pts, int n_points, const float* stream, int pre
 // bg_rendering_network (network_bg.py:91-93): view_dirs (n_rays,3) when view_S > 0 (points per ray) else (P,3)
 int svs_bg_rgb_eval(int n_points, const float* view_dirs, int view_S, const float* feat_tiles, const float* stream,
                     int precision, float* rgb, float* rbuf, void* hip_stream) {
-  if (!is_h2(precision)) { set_error("svs_bg_rgb_eval: the background networks have fp16x2 kernels only (precision %d)", precision); return SVS_EINVAL; }
+  if (!is_h2(precision) && precision != kFmtF32) { set_error("svs_bg_rgb_eval: unknown precision %d", precision); return SVS_EINVAL; }
   if (n_points <= 0 || !view_dirs || !feat_tiles || !stream || !rgb || view_S < 0 || (view_S > 0 && n_points % view_S)) {
     set_error("svs_bg_rgb_eval: null/invalid argument"); return SVS_EINVAL;
   }
   BgRgbArgs a{n_points, view_dirs, view_S, feat_tiles, reinterpret_cast<const f32x4*>(stream), rgb, rbuf};
+  if (precision == kFmtF32) return launch_bg_rgb_f32(a, (hipStream_t)hip_stream);
   constexpr int lds = 2 * kBgRgbBufF4 * 16;
   static int once = set_lds(bg_rgb_h2_kernel<true>, lds, "svs_bg_rgb_eval") | set_lds(bg_rgb_h2_kernel<false>, lds, "svs_bg_rgb_eval");
   if (once) return once;
@@ -378,11 +342,12 @@ int svs_bg_rgb_eval(int n_points, const float* view_dirs, int view_S, const floa
 // bg_rendering_network backward (stream: which = 8): zbuf = 2 blocks per tile, ZERO-INITIALISED by the caller once
 int svs_bg_rgb_bwd(int n_points, const float* d_rgb, const float* rgb, const float* rbuf, const float* stream, int precision,
                    float* zbuf, float* feat_bar, float* absmax, void* hip_stream) {
-  if (!is_h2(precision)) { set_error("svs_bg_rgb_bwd: the background networks have fp16x2 kernels only (precision %d)", precision); return SVS_EINVAL; }
-  if (n_points <= 0 || !d_rgb || !rgb || !rbuf || !stream || !zbuf || !feat_bar || !absmax) {
+  if (!is_h2(precision) && precision != kFmtF32) { set_error("svs_bg_rgb_bwd: unknown precision %d", precision); return SVS_EINVAL; }
+  if (n_points <= 0 || !d_rgb || !rgb || !rbuf || !stream || !zbuf || !feat_bar || (!absmax && is_h2(precision))) {
     set_error("svs_bg_rgb_bwd: null/invalid argument"); return SVS_EINVAL;
   }
   BgRgbBwdArgs a{n_points, d_rgb, rgb, rbuf, reinterpret_cast<const f32x4*>(stream), zbuf, feat_bar, absmax};
+  if (precision == kFmtF32) return launch_bg_rgb_bwd_f32(a, (hipStream_t)hip_stream);
   static int once = set_lds(bg_rgb_bwd_h2_kernel<true>, kLdsBytes, "svs_bg_rgb_bwd") | set_lds(bg_rgb_bwd_h2_kernel<false>, kLdsBytes, "svs_bg_rgb_bwd");
   if (once) return once;
   const int grid = (n_points + kWgPts - 1) / kWgPts;
@@ -395,12 +360,14 @@ int svs_bg_rgb_bwd(int n_points, const float* d_rgb, const float* rgb, const flo
 // hbuf / ghat7 from svs_bg_sdf_eval -> abuf (8 blocks per tile: abar_0..abar_7), sbar_out (padded P)
 int svs_bg_sdf_bwd(int n_points, const float* d_out0, const float* feat_bar, const float* hbuf, const float* ghat7,
                    const float* stream, int precision, float* abuf, float* sbar_out, float* absmax, void* hip_stream) {
-  if (!is_h2(precision)) { set_error("svs_bg_sdf_bwd: the background networks have fp16x2 kernels only (precision %d)", precision); return SVS_EINVAL; }
-  if (n_points <= 0 || n_points % 32 || !d_out0 || !feat_bar || !hbuf || !ghat7 || !stream || !abuf || !sbar_out || !absmax) {
+  if (!is_h2(precision) && precision != kFmtF32) { set_error("svs_bg_sdf_bwd: unknown precision %d", precision); return SVS_EINVAL; }
+  if (n_points <= 0 || n_points % 32 || !d_out0 || !feat_bar || !hbuf || !ghat7 || !stream || !abuf || !sbar_out ||
+      (!absmax && is_h2(precision))) {
     set_error("svs_bg_sdf_bwd: null/invalid argument (n_points must be a multiple of 32)"); return SVS_EINVAL;
   }
   SdfBwdBArgs a{n_points, d_out0, nullptr, feat_bar, n_points / 32, hbuf, nullptr, nullptr, nullptr,
                 reinterpret_cast<const f32x4*>(stream), abuf, sbar_out, absmax, ghat7, (size_t)kBlockF};
+  if (precision == kFmtF32) return launch_bg_bwd_b_f32(a, (hipStream_t)hip_stream);
   return launch_bg_bwd_b_h2(a, precision == kFmtF16x2, (hipStream_t)hip_stream);
 }
 

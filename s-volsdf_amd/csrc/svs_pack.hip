@@ -341,7 +341,7 @@ using namespace svs::mlp;
 extern "C" {
 
 // which: 0 SDF forward, 1 SDF full (forward + feature head + gradient pass), 2 SDF training backward,
-//        3 radiance forward, 4 radiance backward; background networks (fp16x2 only): 5 bg implicit forward,
+//        3 radiance forward, 4 radiance backward; background networks: 5 bg implicit forward,
 //        6 bg implicit backward, 7 bg radiance forward, 8 bg radiance backward; 9 SDF forward for the 16-point-wave kernel
 //        (svs_sdf_vals16, fp16x2 only).  precision: body encoding of the MFMA chunks, 0 float32, 1 fp16x2.
 // Stream sizes do not depend on the precision.
@@ -361,7 +361,6 @@ int svs_pack_stream(int which, int precision, const float* const* weight_v, cons
   const bool is_rgb = which == kStreamRgbFwd || which == kStreamRgbBwd || which == kStreamBgRgbFwd || which == kStreamBgRgbBwd;
   const int net = stream_is_bg(which) ? 1 : 0;
   const int nl = is_rgb ? (net ? 2 : 5) : 9;
-  if (net && !is_h2(precision)) { set_error("svs_pack_stream: the background networks are fp16x2 only"); return SVS_EINVAL; }
   if (is_h2(precision)) precision = kFmtF16x2;     // one body encoding for both fp16x2 block formats
   if (which == kStreamSdfFwdW) {
     if (precision != kFmtF16x2) { set_error("svs_pack_stream: stream 9 (16-point-wave SDF forward) is fp16x2 only"); return SVS_EINVAL; }

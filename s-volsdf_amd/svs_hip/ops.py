@@ -247,18 +247,13 @@ def composite(z, sdf, rgb, depth_scale, beta_param, beta_min, normals=None):
 
 
 # ---------------------------------------------------------------------------------------------------
-# inverted-sphere background model (volsdf/model/network_bg.py), fp16x2 kernels of svs_bg_h2.hip
+# inverted-sphere background model (volsdf/model/network_bg.py): kernels of svs_bg_h2.hip (fp16x2) / svs_bg_f32.hip (float32 MFMA)
 # ---------------------------------------------------------------------------------------------------
 class PackedBg:
     """Packed weight streams of bg_implicit_network / bg_rendering_network (no weight-norm)."""
 
     def __init__(self, device, precision=None):
         self.precision = default_precision() if precision is None else int(precision)
-        if not is_h2(self.precision):
-            # the background networks have fp16x2 kernels only (csrc/svs_bg_h2.hip); running them under a setting that
-            # promises float32 MFMA arithmetic would silently break that promise
-            raise NotImplementedError("SVS_MLP_PRECISION=f32 is not available for the inverted-sphere background model "
-                                      "(VolSDFNetworkBG): its networks run on the fp16x2 kernels only; unset SVS_MLP_PRECISION")
         L = _lib.load()
         self.device = device
         self.sdf_stream = torch.empty(L.svs_stream_bytes(5) // 4, device=device)

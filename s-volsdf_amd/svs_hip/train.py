@@ -408,16 +408,14 @@ class MlpBackward:
 
 class BgBackward:
     """Training backward of the background networks of VolSDFNetworkBG (bg_implicit_network: ordinary backprop, no
-    second-order sweep because its input gradient is never used; bg_rendering_network), fp16x2 kernels of
-    csrc/svs_bg_h2.hip + the shared pass-B sweep and weight-gradient GEMM."""
+    second-order sweep because its input gradient is never used; bg_rendering_network): the kernels of csrc/svs_bg_h2.hip
+    (fp16x2) or csrc/svs_bg_f32.hip (float32 MFMA) + the shared pass-B sweep and weight-gradient kernels."""
     BGRBUF = KBLOCK + 1024
 
     def __init__(self, device, precision=None):
         L = _lib.load()
         self.dev = device
         self.precision = default_precision() if precision is None else int(precision)
-        if not is_h2(self.precision):
-            raise NotImplementedError("the inverted-sphere background networks run on the fp16x2 kernels only")
         self.sdf_stream = torch.empty(L.svs_stream_bytes(6) // 4, device=device)
         self.rgb_stream = torch.empty(L.svs_stream_bytes(8) // 4, device=device)
         self.ws = torch.empty(L.svs_pack_workspace_bytes() // 4, device=device)

@@ -65,17 +65,23 @@ def test_missing_library_fails_loudly(lib, monkeypatch):
         lib.load()
 
 
-def test_background_model_refuses_f32_setting(monkeypatch):
-    """SVS_MLP_PRECISION=f32 promises float32 MFMA arithmetic; the background networks only have fp16x2 kernels, so the
-    combination is an explicit error (before any device work), not a silent mix."""
+def test_precision_setting_is_validated(monkeypatch):
+    """SVS_MLP_PRECISION names one of the three arithmetic settings (f32 covers the background networks too since round 5:
+    csrc/svs_bg_f32.hip); anything else is an error before any device work."""
     import pytest
     from svs_hip import ops
     monkeypatch.setenv("SVS_MLP_PRECISION", "f32")
-    with pytest.raises(NotImplementedError, match="background"):
-        ops.PackedBg("cpu")
+    assert ops.default_precision() == ops.F32
     monkeypatch.setenv("SVS_MLP_PRECISION", "bf16")
     with pytest.raises(ValueError):
         ops.default_precision()
+    # the background entry points refuse a precision they do not know (argument check, nothing is launched)
+    import ctypes
+    from svs_hip import lib
+    L = lib.load()
+    d = ctypes.c_void_p(64)
+    assert L.svs_bg_sdf_eval(d, 32, d, 7, d, d, None, None, None, None) < 0 and b"precision" in L.svs_last_error_string()
+    assert L.svs_bg_rgb_eval(32, d, 0, d, d, 7, d, None, None) < 0 and b"precision" in L.svs_last_error_string()
 
 
 def test_argument_errors_come_back_as_codes():

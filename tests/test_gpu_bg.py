@@ -44,9 +44,13 @@ def _model(dev, beta):
     return m.to(dev)
 
 
+@pytest.mark.parametrize("precision", [None, "f32"])
 @pytest.mark.parametrize("tag", ["eval_b0.1", "train"])
-def test_bg_pieces(dev, golden_dir, tag):
-    """inverse-sphere points, bg implicit / radiance networks and the fg/bg compositing, each on the reference's inputs"""
+def test_bg_pieces(dev, golden_dir, tag, precision, monkeypatch):
+    """inverse-sphere points, bg implicit / radiance networks and the fg/bg compositing, each on the reference's inputs
+    (precision f32: the float32-MFMA forms of the two networks, csrc/svs_bg_f32.hip)"""
+    if precision:
+        monkeypatch.setenv("SVS_MLP_PRECISION", precision)
     from svs_hip import ops
     g = dict(np.load(os.path.join(golden_dir, "forward_bg_" + tag + ".npz")))
     params = _params()
@@ -65,8 +69,8 @@ def test_bg_pieces(dev, golden_dir, tag):
     rows = torch.empty(R * Nb, 256, device=dev)
     from svs_hip import lib
     import ctypes
-    lib.check(lib.load().svs_tiles_to_rows(ctypes.c_void_p(feat.data_ptr()), R * Nb, 1, ctypes.c_void_p(rows.data_ptr()),
-                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))   # bg: fp16x2 pair block
+    lib.check(lib.load().svs_tiles_to_rows(ctypes.c_void_p(feat.data_ptr()), R * Nb, pkb.precision, ctypes.c_void_p(rows.data_ptr()),
+                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))   # pair block / float32 block
     np.testing.assert_allclose(rows.cpu().numpy(), ref_out[:, 1:], atol=1e-4)
     view = orc.rays_from_uv(g["uv"], g["near_pose"], g["K"])[0] if tag != "train" else dirs
     rgb = ops.bg_rgb_eval(pkb, G(view, dev), Nb, feat, R * Nb)
@@ -91,9 +95,12 @@ def test_bg_pieces(dev, golden_dir, tag):
     np.testing.assert_allclose(comp["rgb_values"].cpu().numpy(), rgb_ref, atol=2e-6)
 
 
-@pytest.mark.parametrize("tag", ["eval_b0.1", "eval_b0.01", "train"])
-def test_bg_model_forward_golden(dev, golden_dir, tag):
-    """VolSDFNetworkBG.forward (HIP) against the reference's outputs."""
+@pytest.mark.parametrize("tag,precision", [("eval_b0.1", None), ("eval_b0.01", None), ("train", None), ("eval_b0.1", "f32"),
+                                           ("train", "f32")])
+def test_bg_model_forward_golden(dev, golden_dir, tag, precision, monkeypatch):
+    """VolSDFNetworkBG.forward (HIP) against the reference's outputs (f32: all four networks on the float32-MFMA kernels)."""
+    if precision:
+        monkeypatch.setenv("SVS_MLP_PRECISION", precision)
     from rng_inject import inject_rng
     g = dict(np.load(os.path.join(golden_dir, "forward_bg_" + tag + ".npz")))
     m = _model(dev, float(g["beta_param"]))
@@ -320,7 +327,8 @@ def test_bg_ray_groups_do_not_change_the_step(dev):
 
 
 @pytest.mark.parametrize("R,it,precision", [(256, 50, None), (1024, 50, None), (2048, 50, None), (256, 250, None), (1024, 250, None),
-                                            (1024, 250, "f16x2_half"), (1000, 250, None), (90, 50, None)])
+                                            (1024, 250, "f16x2_half"), (1000, 250, None), (90, 50, None), (256, 250, "f32"),
+                                            (1024, 50, "f32")])
 def test_bg_step_gradient_at_bench_geometry(dev, R, it, precision, monkeypatch):
     """The flat gradient of ONE fused step of the fg + background model at the benchmarked geometry -- 1024 rays, and
     256 rays = the per-GPU share of config 4's 2048-ray batch over 8 GPUs -- against float64 torch autograd
@@ -329,7 +337,8 @@ def test_bg_step_gradient_at_bench_geometry(dev, R, it, precision, monkeypatch):
     networks receive gradients; it = 50: the annealed phase, where the sparse term (which reads depth_values_all) is live.
     2048 rays: config 4's whole batch on one GPU.  1000 / 90 rays: not multiples of the kernels' 32-ray granularity -- the step
     pads the batch and leaves the padding out of the loss; the reference gradient is taken over the caller's rays.  Per tensor: max |err| <= 3e-5 of the tensor's largest entry (the float32
-    class) on the default fp16x2 path; 2e-3 with SVS_MLP_PRECISION=f16x2_half (one-piece gradient blocks)."""
+    class) on the default fp16x2 path and with SVS_MLP_PRECISION=f32 (float32 MFMA kernels for all four networks); 2e-3 with
+    SVS_MLP_PRECISION=f16x2_half (one-piece gradient blocks)."""
     if precision:
         monkeypatch.setenv("SVS_MLP_PRECISION", precision)
     bound = 2e-3 if precision == "f16x2_half" else 3e-5
