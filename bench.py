@@ -403,6 +403,12 @@ def main():
                 line["chamfer_parity"] = {"hip": cp.get("hip", {}).get("overall_mm"), "hip_f32": cp.get("hip_f32", {}).get("overall_mm"),
                                           "torch_f32": cp.get("torch_f32", {}).get("overall_mm"), "spread": cp.get("spread_mm"),
                                           "unit": "mm", "steps": 600, "seeds": [0, 1], "what": cp.get("what"),
+                                          "note": "means of two seeds; at 600 steps single runs of EVERY path scatter between 0.8 and 1.5 mm, "
+                                                  "the odd one up to 2.4 (tools/dev/chamfer_600_distribution.py: six seeds per path), and the "
+                                                  "HIP paths are not repeatable run to run (float atomics) -- the statement with small error "
+                                                  "bars is the 3000-step one under long_runs",
+                                          "range": {k: [v.get("min_mm"), v.get("max_mm")] for k, v in cp.items()
+                                                    if isinstance(v, dict) and "runs" in v},
                                           "runs": {k: [{q: r.get(q) for q in ("seed", "accuracy_mm", "completeness_mm", "overall_mm",
                                                                                   "train_s", "error")} for r in v["runs"]]
                                                    for k, v in cp.items() if isinstance(v, dict) and "runs" in v},

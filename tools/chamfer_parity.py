@@ -255,7 +255,10 @@ def measure(steps=3000, seeds=(0, 1), paths=("hip", "hip_f32", "torch_f32"), ray
             res[path].update(overall_mm=sum(x["overall_mm"] for x in ok) / len(ok),
                              accuracy_mm=sum(x["accuracy_mm"] for x in ok) / len(ok),
                              completeness_mm=sum(x["completeness_mm"] for x in ok) / len(ok),
-                             spread_mm=max(x["overall_mm"] for x in ok) - min(x["overall_mm"] for x in ok))
+                             spread_mm=max(x["overall_mm"] for x in ok) - min(x["overall_mm"] for x in ok),
+                             median_mm=sorted(x["overall_mm"] for x in ok)[len(ok) // 2] if len(ok) % 2 else
+                             0.5 * (sorted(x["overall_mm"] for x in ok)[len(ok) // 2 - 1] + sorted(x["overall_mm"] for x in ok)[len(ok) // 2]),
+                             min_mm=min(x["overall_mm"] for x in ok), max_mm=max(x["overall_mm"] for x in ok))
     res["spread_mm"] = max([v.get("spread_mm", 0.0) for v in res.values() if isinstance(v, dict)] or [0.0])
     if "overall_mm" in res.get("hip", {}) and "overall_mm" in res.get("torch_f32", {}):
         res["hip_minus_torch_mm"] = res["hip"]["overall_mm"] - res["torch_f32"]["overall_mm"]
