@@ -469,9 +469,10 @@ def _allreduce_one_rank(n_floats, reps=200):
     return {"ms": ms, "bytes": 4 * n_floats, "ranks": 1}
 
 
-def _child_json(argv, timeout=900):
+def _child_json(argv, timeout=900, env=None):
     import subprocess
-    r = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv, capture_output=True, text=True, timeout=timeout)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv, capture_output=True, text=True, timeout=timeout,
+                       env=dict(os.environ, **env) if env else None)
     # (the last JSON line: RCCL's banner is flushed to stdout when the process exits, behind it)
     return json.loads(next(l for l in reversed(r.stdout.strip().splitlines()) if l.startswith("{")))
 
@@ -494,6 +495,10 @@ def config4_extra(dtu_loop_256_ms=None):
                 d = _child_json(["--model", model, "--rays", str(rays)] + quick)
                 row[f"step_ms_{rays}_rays"] = d["ms_per_step"]
                 row[f"launch_{rays}_rays"] = d["config"]["launch"][:40]
+            if model == "bmvs":
+                # the strict-float32 figure of config 4's model (float32 MFMA kernels for all four networks: csrc/svs_bg_f32.hip)
+                row["exact_f32_step_ms_2048_rays"] = _child_json(["--model", model, "--rays", "2048"] + quick[:-1] + ["30"],
+                                                                 env={"SVS_MLP_PRECISION": "f32"})["ms_per_step"]
             if model == "dtu" and dtu_loop_256_ms is not None:
                 row["volopt_run_ms_256_rays"] = dtu_loop_256_ms
             else:
