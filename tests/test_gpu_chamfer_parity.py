@@ -30,7 +30,7 @@ def test_chamfer_parity_short():
     scatter is 0.06-0.15 mm, are profiles/r05_chamfer_parity_prior.json / r05_chamfer_prior_seeds.json."""
     assert torch.cuda.is_available()
     import chamfer_parity
-    res = chamfer_parity.measure(steps=600, seeds=(0, 1, 2), paths=("hip", "torch_f32"), rays=512, timeout=900, prior=True)
+    res = chamfer_parity.measure(steps=600, seeds=(0, 1, 2), paths=("hip", "torch_f32"), rays=512, timeout=900, prior=True, parallel=True)
     for p in ("hip", "torch_f32"):
         assert all("overall_mm" in r for r in res[p]["runs"]), res[p]["runs"]
         assert res[p]["runs"][0]["n_fused"] > 5000
@@ -38,7 +38,7 @@ def test_chamfer_parity_short():
     ref = [r["overall_mm"] for r in res["torch_f32"]["runs"]]
     lo, hi = min(ref) - 0.35, max(ref) + 0.35
     if not lo <= _median(hip) <= hi:
-        more = chamfer_parity.measure(steps=600, seeds=(3, 4), paths=("hip",), rays=512, timeout=900, prior=True)
+        more = chamfer_parity.measure(steps=600, seeds=(3, 4), paths=("hip",), rays=512, timeout=900, prior=True, parallel=True)
         hip += [r["overall_mm"] for r in more["hip"]["runs"]]
     print(f"chamfer parity (600 steps, MVS prior): hip {[round(v, 3) for v in hip]} mm (median {_median(hip):.3f}), torch float32 "
           f"{[round(v, 3) for v in ref]} mm (median {_median(ref):.3f})")

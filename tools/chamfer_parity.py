@@ -234,21 +234,35 @@ def child(path, seed, steps, rays, prior=False):
     print(json.dumps(info), flush=True)
 
 
-def measure(steps=3000, seeds=(0, 1), paths=("hip", "hip_f32", "torch_f32"), rays=512, timeout=3000, prior=False):
+def measure(steps=3000, seeds=(0, 1), paths=("hip", "hip_f32", "torch_f32"), rays=512, timeout=3000, prior=False, parallel=False):
+    """parallel: all (path, seed) runs as concurrent child processes on the one GPU (the plain-torch comparator is bound by its
+    host-side launches: three of them side by side take as long as one); train_s of a run is then not a timing of anything."""
+    def start(path, s):
+        env = dict(os.environ)
+        env.pop("SVS_MLP_PRECISION", None)
+        if path == "hip_f32":
+            env["SVS_MLP_PRECISION"] = "f32"
+        return subprocess.Popen([sys.executable, os.path.abspath(__file__), "--child", f"{path}:{s}:{steps}:{rays}:{int(prior)}"], env=env,
+                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+    def finish(proc, s):
+        try:
+            out, err = proc.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+            out, err = proc.communicate()
+            return dict(seed=s, error="timeout: " + (err or out)[-400:])
+        try:
+            return dict(seed=s, **json.loads(next(l for l in reversed(out.strip().splitlines()) if l.startswith("{"))))
+        except Exception:                                # noqa: BLE001
+            return dict(seed=s, error=(err or out)[-600:])
+
+    procs = {(path, s): start(path, s) for path in paths for s in seeds} if parallel else {}
     res = {}
     for path in paths:
         runs = []
         for s in seeds:
-            env = dict(os.environ)
-            env.pop("SVS_MLP_PRECISION", None)
-            if path == "hip_f32":
-                env["SVS_MLP_PRECISION"] = "f32"
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", f"{path}:{s}:{steps}:{rays}:{int(prior)}"], env=env,
-                               capture_output=True, text=True, timeout=timeout)
-            try:
-                runs.append(dict(seed=s, **json.loads(next(l for l in reversed(r.stdout.strip().splitlines()) if l.startswith("{")))))
-            except Exception:                                # noqa: BLE001
-                runs.append(dict(seed=s, error=(r.stderr or r.stdout)[-600:]))
+            runs.append(finish(procs[(path, s)] if parallel else start(path, s), s))
         ok = [x for x in runs if "overall_mm" in x]
         res[path] = dict(runs=runs)
         if ok:
