@@ -399,14 +399,15 @@ def main():
             try:
                 import chamfer_parity
                 cp = chamfer_parity.measure(steps=600, seeds=(0, 1, 2), paths=("hip", "hip_f32", "torch_f32"), rays=512, timeout=600,
-                                            prior=True, parallel=True)
+                                            prior=True, parallel=True, seeds_by_path={"hip": (0, 1, 2, 3, 4, 5, 6)})
                 line["chamfer_parity"] = {"hip": cp.get("hip", {}).get("median_mm"), "hip_f32": cp.get("hip_f32", {}).get("median_mm"),
                                           "torch_f32": cp.get("torch_f32", {}).get("median_mm"), "spread": cp.get("spread_mm"),
-                                          "unit": "mm", "steps": 600, "seeds": [0, 1, 2], "statistic": "median of three seeds",
+                                          "unit": "mm", "steps": 600, "seeds": {"hip": 7, "hip_f32": 3, "torch_f32": 3},
+                                          "statistic": "median over the seeds of a path (seven for the default HIP path, three for the others)",
                                           "what": cp.get("what"),
                                           "note": "at 600 steps single runs of EVERY path scatter between 0.8 and 1.5 mm, the odd one up "
                                                   "to 2.4 (tools/dev/chamfer_600_distribution.py: six seeds per path), and the HIP paths are "
-                                                  "not repeatable run to run (float atomics): medians of three seeds, the runs (started side "
+                                                  "not repeatable run to run (float atomics): medians, the runs (started side "
                                                   "by side on the one GPU) listed below; the statement with small error bars is the "
                                                   "3000-step one under long_runs",
                                           "mean": {k: v.get("overall_mm") for k, v in cp.items() if isinstance(v, dict) and "runs" in v},

@@ -234,8 +234,9 @@ def child(path, seed, steps, rays, prior=False):
     print(json.dumps(info), flush=True)
 
 
-def measure(steps=3000, seeds=(0, 1), paths=("hip", "hip_f32", "torch_f32"), rays=512, timeout=3000, prior=False, parallel=False):
-    """parallel: all (path, seed) runs as concurrent child processes on the one GPU (the plain-torch comparator is bound by its
+def measure(steps=3000, seeds=(0, 1), paths=("hip", "hip_f32", "torch_f32"), rays=512, timeout=3000, prior=False, parallel=False,
+            seeds_by_path=None):
+    """seeds_by_path: {path: seeds} overriding `seeds` for a path (the HIP runs are cheap: more of them steady a median).  parallel: all (path, seed) runs as concurrent child processes on the one GPU (the plain-torch comparator is bound by its
     host-side launches: three of them side by side take as long as one); train_s of a run is then not a timing of anything."""
     def start(path, s):
         env = dict(os.environ)
@@ -257,11 +258,12 @@ def measure(steps=3000, seeds=(0, 1), paths=("hip", "hip_f32", "torch_f32"), ray
         except Exception:                                # noqa: BLE001
             return dict(seed=s, error=(err or out)[-600:])
 
-    procs = {(path, s): start(path, s) for path in paths for s in seeds} if parallel else {}
+    sb = lambda path: tuple((seeds_by_path or {}).get(path, seeds))
+    procs = {(path, s): start(path, s) for path in paths for s in sb(path)} if parallel else {}
     res = {}
     for path in paths:
         runs = []
-        for s in seeds:
+        for s in sb(path):
             runs.append(finish(procs[(path, s)] if parallel else start(path, s), s))
         ok = [x for x in runs if "overall_mm" in x]
         res[path] = dict(runs=runs)
