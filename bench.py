@@ -399,11 +399,13 @@ def main():
             try:
                 import chamfer_parity
                 cp = chamfer_parity.measure(steps=600, seeds=(0, 1, 2), paths=("hip", "hip_f32", "torch_f32"), rays=512, timeout=600,
-                                            prior=True, parallel=True, seeds_by_path={"hip": (0, 1, 2, 3, 4, 5, 6)})
+                                            prior=True, parallel=True,
+                                            seeds_by_path={"hip": (0, 1, 2, 3, 4, 5, 6), "torch_f32": (0, 1, 2, 3, 4)})
                 line["chamfer_parity"] = {"hip": cp.get("hip", {}).get("median_mm"), "hip_f32": cp.get("hip_f32", {}).get("median_mm"),
                                           "torch_f32": cp.get("torch_f32", {}).get("median_mm"), "spread": cp.get("spread_mm"),
-                                          "unit": "mm", "steps": 600, "seeds": {"hip": 7, "hip_f32": 3, "torch_f32": 3},
-                                          "statistic": "median over the seeds of a path (seven for the default HIP path, three for the others)",
+                                          "unit": "mm", "steps": 600, "seeds": {"hip": 7, "hip_f32": 3, "torch_f32": 5},
+                                          "statistic": "median over the seeds of a path (seven for the default HIP path, five for the torch "
+                                                       "comparator, three for the float32 kernels)",
                                           "what": cp.get("what"),
                                           "note": "at 600 steps single runs of EVERY path scatter between 0.8 and 1.5 mm, the odd one up "
                                                   "to 2.4 (tools/dev/chamfer_600_distribution.py: six seeds per path), and the HIP paths are "
