@@ -313,7 +313,11 @@ __global__ __launch_bounds__(256) void deconv_cell_kernel(Args a) {
       if (dz > (m >> 1) || dy > (m & 1)) continue;                // the class does not reach these input rows
 #pragma unroll
       for (int mt = 0; mt < MTC; ++mt) {
+#ifdef CONV_ABL_W0      // diagnostic: every fragment is fragment 0 (no weight traffic beyond one line per lane)
+        const f16x8 ah = wf[0], am = wf[64];
+#else
         const f16x8 ah = wf[((m * KS + s) * MTC + mt) * 128], am = wf[((m * KS + s) * MTC + mt) * 128 + 64];
+#endif
         acc[m][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am, bh, acc[m][mt], 0, 0, 0);
         acc[m][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bm, acc[m][mt], 0, 0, 0);
         acc[m][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[m][mt], 0, 0, 0);
