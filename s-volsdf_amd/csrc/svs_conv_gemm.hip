@@ -186,14 +186,22 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Args a) {
   if (s0 < KS) {
     load_b(s0, xc);
 #pragma unroll
+#ifdef CONV_ABL_W0
+    for (int m = 0; m < MT; ++m) { ahc[m] = wf[0]; amc[m] = wf[64]; }
+#else
     for (int m = 0; m < MT; ++m) { ahc[m] = wf[((size_t)s0 * MT + m) * 128]; amc[m] = wf[((size_t)s0 * MT + m) * 128 + 64]; }
+#endif
   }
   for (int s = s0; s < KS; s += SS) {
     if (s + SS < KS) {
       load_b(s + SS, xn);
       const f16x8* wn = wf + (size_t)(s + SS) * MT * 128;
 #pragma unroll
+#ifdef CONV_ABL_W0
+      for (int m = 0; m < MT; ++m) { ahn[m] = wf[0]; amn[m] = wf[64]; }
+#else
       for (int m = 0; m < MT; ++m) { ahn[m] = wn[m * 128]; amn[m] = wn[m * 128 + 64]; }
+#endif
     }
     f16x8 bh, bm;
 #pragma unroll
