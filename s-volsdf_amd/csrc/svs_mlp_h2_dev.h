@@ -84,7 +84,10 @@ __device__ __forceinline__ f32x16 tile_bias(const f32x4* __restrict__ chunk, int
 // (results are then wrong by construction).  1: identity instead of softplus, 2: no operand split, 4: no MFMAs,
 // 8: no chunk wait / barrier, 16: cycle stamps instead of results (sdf_only), 32: let the slimmer variants run two
 // workgroups per CU (otherwise their LDS request is padded to keep one), 64: no weight fetch; reverse pass of sdf_full:
-// 128: no h loads, 256: no gbuf stores, 512: no softplus' arithmetic.  Never defined in the product build.
+// 128: no h loads, 256: no gbuf stores, 512: no softplus' arithmetic; pass A (svs_mlp_bwd_h2.hip): 1024 no side-tile loads,
+// 2048 no u stores; pass B: 4096 no side-tile loads, 8192 no abar stores, 16384 no second-order / sbar terms, 32768 no softplus'
+// arithmetic, 65536 per-tile cycle stamps into sbar_out (tools/bench_kernels.py BK_STAMPS=1); the weight fetch (svs_mlp_dev.h):
+// 131072 a quarter of the lanes per LDS-DMA instruction, 262144 every lane the same address.  Never defined in the product build.
 #ifndef SVS_ABL
 #define SVS_ABL 0
 #endif

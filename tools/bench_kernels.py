@@ -1,5 +1,6 @@
 """Per-kernel timings at bench sizes (1024 rays): isolates each hot kernel with events on the launch stream.
-Development aid for the roofline work; prints one JSON object."""
+Development aid for the roofline work; prints one JSON object.  BK_RAYS=<n>: another batch size (default 1024); BK_STAMPS=1 with a
+-DSVS_ABL=65536 build of svs_mlp_bwd_h2.hip (tools/dev/ab_defs.sh + SVS_LIB_PATH): pass B's per-tile cycle stamps and clock."""
 import ctypes
 import json
 import os
