@@ -63,8 +63,7 @@ MLP_KERNELS = {
                       "SDF MLP backward, second-order sweep"),
     "svs_sdf_bwd_b": ("svs::mlp::sdf_bwd_b_h2_kernel", "svs::mlp::sdf_bwd_b_kernel", "hbm", None,
                       "SDF MLP backward, backprop sweep"),
-    "svs_wgrad_multi": ("svs::wgrad::h2::wgrad_h2_multi_kernel", "svs::wgrad::wgrad_kernel<8>", "hbm", None,
-                        "weight gradients of all layers of a network in one launch"),
+    "svs_wgrad_multi": ("svs::wgrad::h2::wgrad_h2_multi_kernel", "svs::wgrad::wgrad_kernel<8>", "hbm", None, "weight-gradient GEMMs"),
     "svs_lin8_row0_grad": ("svs::mlp::lin8_row0_h2_kernel", "svs::mlp::lin8_row0_kernel", "hbm", None,
                            "row 0 of lin8's weight gradient (h_8 and u_8 blocks)"),
 }
@@ -119,7 +118,23 @@ def main():
                     help="skip the end-to-end `VolOpt.run` measurement (`volopt_run` on the line)")
     ap.add_argument("--no-other-scaling", action="store_true",
                     help="N > 1: skip the second timed region in the other scaling mode (`other_scaling` on the line)")
+    # opt-in extras: none of them is part of the default command (round 5's line lost its driver record to them); their results
+    # go to bench_extras.json, never onto the final stdout line
+    ap.add_argument("--other-precisions", action="store_true", help="extra: the same step at SVS_MLP_PRECISION=f16x2_half and f32")
+    ap.add_argument("--inline-ab", action="store_true",
+                    help="extra: the kernel table a second time with the radiance weight-gradient launch in line (SVS_RGB_WGRAD_SIDE=0)")
+    ap.add_argument("--volopt-loop", action="store_true", help="extra: `VolOpt.run` end to end in a child process (1024 and 256 rays)")
+    ap.add_argument("--config4", action="store_true",
+                    help="extra: configs[3]'s projection from one GPU (child benches at 2048 / 256 rays, both models, all-reduce child)")
+    ap.add_argument("--chamfer", action="store_true",
+                    help="extra: short Chamfer optimisations per path on the analytic scene (tools/chamfer_parity.py; minutes)")
+    ap.add_argument("--all-extras", action="store_true", help="all of the opt-in extras above")
+    ap.add_argument("--extras-file", default=None,
+                    help="where the full record goes (default: gpurun_out/bench_extras.json when that directory exists, and "
+                         "bench_extras.json next to this script)")
     args = ap.parse_args()
+    if args.all_extras:
+        args.other_precisions = args.inline_ab = args.volopt_loop = args.config4 = args.chamfer = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started as a plain `python bench.py --gpus N`: this process has not touched a GPU; it starts the N ranks as
@@ -290,7 +305,7 @@ def main():
         # every rank runs the extra steps (a train step contains the all-reduce); rank 0 reports its own kernel times
         sizes = [g[1] - g[0] for g in ts._groups_for(R)] if train else None
         roofline = kernel_roofline(ts, step, R, S, h2, train, ray_groups=sizes)
-        if train and roofline is not None:
+        if train and roofline is not None and args.inline_ab:
             # The dominant kernel (pass A of the SDF backward, HBM-bound) shares HBM with the radiance weight-gradient
             # launch that runs beside it on a side stream (the faster schedule: -1.2 % per step).  The same steps with that
             # launch IN LINE (SVS_RGB_WGRAD_SIDE=0) show what each kernel does with the memory system to itself.
@@ -359,7 +374,7 @@ def main():
             line["other_scaling"] = other
         if train and world == 1 and not args.no_gpu_torch and args.model == "dtu":
             line["gpu_torch_baseline"] = gpu_torch_baseline(ts, params, gt, R, dev, 1e3 * dt / args.steps, mvs)
-        if train and h2 and world == 1 and args.model == "dtu" and not args.no_kernel_timing and not args.no_exact_f32:
+        if train and h2 and world == 1 and args.model == "dtu" and args.other_precisions and not args.no_exact_f32:
             if ops.default_precision() == ops.F16X2:
                 fg = other_precision_step_ms("f16x2_half", make_model, make_step, n=40, warm=60)
                 line["fast_grad_ms_per_step"] = fg
@@ -369,14 +384,15 @@ def main():
                                           "training step (parameter gradients 2e-4 ... 8e-4 of a tensor's largest entry off float64 "
                                           "autograd); NOT the figure `value` reports")
             line["exact_f32_ms_per_step"] = other_precision_step_ms("f32", make_model, make_step, n=10, warm=4)
-        if train and world == 1 and args.model == "dtu" and not args.no_volopt_loop:
-            line["volopt_run"] = volopt_loop(args.rays)
+        if train and world == 1 and args.model == "dtu" and (args.volopt_loop or args.config4) and not args.no_volopt_loop:
+            if args.volopt_loop:
+                line["volopt_run"] = volopt_loop(args.rays)
             if args.rays != 256:
                 # config 4's per-GPU share when its 2048-ray batch is sharded over 8 GPUs: the loop at 256 rays (launch plans;
                 # the host side decides here)
                 line["volopt_run_256_rays"] = volopt_loop(256, variants=("default",))
-            if not args.no_extras:
-                l256 = line.get("volopt_run_256_rays", line["volopt_run"]).get("default", {}).get("ms_per_step")
+            if args.config4:
+                l256 = line.get("volopt_run_256_rays", line.get("volopt_run", {})).get("default", {}).get("ms_per_step")
                 line["config4"] = config4_extra(dtu_loop_256_ms=l256)
         if world == 1 and train and args.model == "dtu" and not args.no_extras:
             # the other configurations of BASELINE.json, as extras measured after the timed region (same process, same box):
@@ -397,6 +413,8 @@ def main():
             # profiles/r05_chamfer_parity_prior.json): a short optimisation per path WITH a synthetic MVS prior (the reference's
             # stage-0 loss), rendered, fused and evaluated like a DTU scan
             try:
+                if not args.chamfer:
+                    raise _Skip()
                 import chamfer_parity
                 cp = chamfer_parity.measure(steps=600, seeds=(0, 1, 2), paths=("hip", "hip_f32", "torch_f32"), rays=512, timeout=600,
                                             prior=True, parallel=True,
@@ -420,14 +438,132 @@ def main():
                                                    for k, v in cp.items() if isinstance(v, dict) and "runs" in v},
                                           "long_runs": "profiles/r05_chamfer_parity_prior.json (3000 steps, three seeds per path, with the "
                                                        "synthetic MVS prior); profiles/r05_chamfer_parity*.json without a prior"}
+            except _Skip:
+                pass
             except Exception as e:
                 line["chamfer_parity"] = {"error": repr(e)}
         if not args.no_cpu_baseline and args.model == "dtu" and world == 1:      # rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(params, K, pose, train=train)
-        print(json.dumps(line), flush=True)
+        emit(line, args.extras_file)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+class _Skip(Exception):
+    pass
+
+
+MAX_LINE = 6144        # bytes of the final stdout line (the driver's record keeps a tail of ~8 KB)
+
+
+def _r(x, sig=5):
+    """floats to `sig` significant digits (the line is a record, not a checkpoint)"""
+    if isinstance(x, float):
+        return float(f"{x:.{sig}g}")
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+def compact_line(full):
+    """The ONE line the driver parses: the contract's keys, `roofline` = the dominant kernel's row + the five largest rows,
+    `cpu_baseline` = value / cores / kind / sample + one figure per thread count, and a few numbers of the secondary
+    measurements.  Everything else is in bench_extras.json (`extras_file`)."""
+    keys = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "host_enqueue_ms_per_step", "higher_is_better",
+            "scaling", "vs_baseline", "dtype", "data")
+    out = {k: full[k] for k in keys if k in full}
+    c = full["config"]
+    out["config"] = {"workload": c["workload"], "mode": c["mode"], "mlp_precision": c["mlp_precision"].split(":")[0],
+                     "ray_groups": c["ray_groups"], "launch": c["launch"][:40], "rays_per_gpu": c["rays_per_gpu"],
+                     "rays_total": c["rays_total"], "flop_per_ray": c["flop_per_ray"], "model_flops_per_s": c["model_flops_per_s"]}
+    rf = full.get("roofline")
+    if rf is not None:
+        short = lambda k: k.split("::")[-1]
+        top = {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "what",
+                                  "launches_per_step", "kernel_ms", "ms_per_step", "points_per_launch", "work_per_point") if k in rf}
+        top["timing"] = "HIP events on the kernel's launch stream, steps after the timed region"
+        top["peak_basis"] = "mfma: 2500/3 TFLOP/s (fp16x2 = 3 fp16 products); hbm: 8 TB/s" if "fp16" in full["dtype"] else "f32 MFMA 157.3 TFLOP/s; hbm 8 TB/s"
+        top["kernels"] = [{"kernel": short(r["kernel"]), "what": r["what"][:48], "bound": r["bound"], "launches_per_step": r["launches_per_step"],
+                           "kernel_ms": r["kernel_ms"], "ms_per_step": r["ms_per_step"], "achieved": r["achieved"], "unit": r["unit"],
+                           "frac": r["frac"]} for r in rf["kernels"][:6]]
+        out["roofline"] = top
+    else:
+        out["roofline"] = None
+    cb = full.get("cpu_baseline")
+    if cb is not None:
+        out["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"],
+                               "by_threads": {str(r["threads"]): r["rays_per_s"] for r in cb.get("runs", []) if r["rays"] == cb.get("sample_rays")},
+                               "host_cpu": cb.get("host_cpu"), "host_threads": cb.get("host_threads")}
+    gt = full.get("gpu_torch_baseline")
+    if gt is not None:
+        out["gpu_torch_baseline"] = {k: gt[k] for k in ("value", "unit", "ms_per_step", "ratio_value_over_baseline") if k in gt}
+        out["gpu_torch_baseline"]["what"] = "the reference's step in torch float32 eager on the same GPU (oracle/torch_ref.py)"
+    if "other_scaling" in full:
+        out["other_scaling"] = {k: full["other_scaling"][k] for k in ("scaling", "rays_per_gpu", "rays_total", "steps", "ms_per_step", "value")}
+    cv = full.get("costvol")
+    if isinstance(cv, dict):
+        out["costvol"] = ({"error": cv["error"][:120]} if "error" in cv else
+                          {k: cv[k] for k in cv if k != "roofline" and k != "workload"})
+        if "roofline" in cv:
+            name = lambda r: "warp" if r["bound"] == "hbm" else ("unet" if r["kernel"].startswith("CostRegNet") else "conv0")
+            out["costvol"]["frac"] = {f"s{r['stage']}_{name(r)}": r.get("frac") for r in cv["roofline"] if "stage" in r}
+    re_ = full.get("render_eval")
+    if isinstance(re_, dict):
+        out["render_eval"] = ({"error": re_["error"][:120]} if "error" in re_ else
+                              {"image": re_.get("image"), "rays_per_s": re_.get("render_image_rays_per_s")})
+    out["extras_file"] = full.get("extras_file")
+    return _r(out)
+
+
+def check_line(text):
+    """self-test of the line the driver will parse: strict JSON (no NaN / Infinity), bounded size, every roofline fraction in
+    (0, 1] -- a fraction above 1 is a mis-priced row, not a fast kernel"""
+    if len(text) >= MAX_LINE + 2048:
+        raise AssertionError(f"bench line is {len(text)} bytes")
+    d = json.loads(text, parse_constant=lambda c: (_ for _ in ()).throw(ValueError("non-finite number on the bench line: " + c)))
+    json.dumps(d, allow_nan=False)
+    rf = d.get("roofline")
+    if rf is not None:
+        for r in [rf] + rf.get("kernels", []):
+            if not (0.0 < r["frac"] <= 1.0):
+                raise AssertionError(f"roofline fraction outside (0, 1]: {r}")
+    return d
+
+
+def emit(full, extras_file=None):
+    """writes the full record to the extras file(s), prints the compact line LAST"""
+    paths = [extras_file] if extras_file else \
+        ([os.path.join(ROOT, "gpurun_out", "bench_extras.json")] if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else []) + \
+        [os.path.join(ROOT, "bench_extras.json")]
+    written = []
+    for p in paths:
+        try:
+            with open(p, "w") as f:
+                json.dump(full, f, indent=1, allow_nan=False)
+            written.append(os.path.relpath(p, ROOT))
+        except (OSError, ValueError) as e:
+            print(f"bench.py: could not write {p}: {e!r}", file=sys.stderr)
+    full["extras_file"] = written
+    line = compact_line(full)
+    text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    if len(text) > MAX_LINE:                       # drop the least important parts, never the contract's keys
+        for k in ("render_eval", "costvol", "other_scaling", "gpu_torch_baseline"):
+            line.pop(k, None)
+            text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+            if len(text) <= MAX_LINE:
+                break
+    try:
+        check_line(text)
+    except AssertionError as e:
+        # the line still goes out (a record with a flagged row beats no record); the failure is loud and on the line
+        line["self_test_failed"] = str(e)[:300]
+        text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+        print("bench.py: SELF-TEST FAILED: " + str(e), file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    print(text, flush=True)
 
 
 def volopt_loop(rays, warm=60, steps=200, variants=("default", "sequential", "device_batches")):
@@ -624,21 +760,34 @@ def kernel_roofline(ts, step, R, S, h2, train, n_steps=12, ray_groups=None):
             continue
         metas = lt.meta[name]
         if name == "svs_wgrad_multi":
-            # two launches per ray group: the SDF network's layers (9 jobs; 11 with the background network's) and the
-            # radiance network's (5 jobs, side stream)
+            # one launch = a list of jobs (svs_wgrad_job: one layer's products over n_points points); a launch may carry the
+            # jobs of SEVERAL ray groups and of more than one network, so it is priced from its own job list: every operand
+            # block a job reads, once, n_points x (bytes per point of that block) -- never from the number of jobs
+            import ctypes
+            from svs_hip import lib as _lib
+            from svs_hip.train import LDW
+            operand = 1024 if not h2 else bpp["wgrad_sdf"] // 34             # bytes per point of one operand block
+            base = ts.accum.dWk.data_ptr() if ts is not None else 0          # accumulator slots: 0..8 SDF layers, 9..13 radiance
             kinds = {}
             for t, a in zip(ms, metas):
-                kinds.setdefault(int(a[1]), []).append(t)
-            for n_jobs, tt in kinds.items():
-                which = "radiance" if n_jobs == 5 else "sdf"
-                per_step = len(tt) // n_steps                  # one launch per ray group, enqueued in group order
-                sizes = ray_groups if (ray_groups and len(ray_groups) == per_step) else [R] * per_step
-                for gi, rays in enumerate(sizes):
-                    tg = tt[gi::per_step]
-                    pts = rays * S if which == "radiance" else rays * (S + 2)
-                    rows.append(dict(entry=name, kernel=(k_h2 if h2 else k_f32), what=f"{what} ({which}, {n_jobs} layers)",
-                                     bound=bound, launches_per_step=len(tg) / n_steps, kernel_ms=float(np.mean(tg)),
-                                     points_per_launch=float(pts), work_per_point=bpp.get("wgrad_" + which)))
+                jobs = ctypes.cast(a[0], ctypes.POINTER(_lib.WGradJob))
+                n_jobs = int(a[1])
+                nbytes, pts = 0, {}
+                for j in range(n_jobs):
+                    jb = jobs[j]
+                    nbytes += jb.n_points * (operand * (2 + (2 if jb.a1 else 0)) + (128 if jb.b_extra else 0))
+                    slot, rem = divmod((jb.dW or 0) - base, 256 * LDW * 4)
+                    net = ("sdf" if slot < 9 else "radiance") if (rem == 0 and 0 <= slot < 14) else "background"
+                    pts.setdefault(net, {}).setdefault(slot, 0)
+                    pts[net][slot] += jb.n_points
+                # points of a network in this launch = those of its first layer's jobs (one job per ray group)
+                n_pts = {net: v[min(v)] for net, v in pts.items()}
+                kinds.setdefault((tuple(sorted(n_pts)), n_jobs, nbytes, sum(n_pts.values())), []).append(t)
+            for (nets, n_jobs, nbytes, n_pts), tg in kinds.items():
+                which = " + ".join(nets)
+                rows.append(dict(entry=name, kernel=(k_h2 if h2 else k_f32), what=f"{what} ({which}: {n_jobs} layer jobs)",
+                                 bound=bound, launches_per_step=len(tg) / n_steps, kernel_ms=float(np.mean(tg)),
+                                 points_per_launch=float(n_pts), work_per_point=nbytes / max(n_pts, 1)))
             continue
         if name in ("svs_rgb_bwd", "svs_sdf_bwd_b"):
             pts = [int(a[0]) for a in metas]
@@ -891,8 +1040,8 @@ def gpu_count():
 def cpu_baseline(params, K, pose, train=True):
     """CPU port of the reference's PyTorch path on a bounded sample of the same workload: numpy oracle for the sampler and
     the MVS prior lookup, plain torch float32 autograd (oracle/torch_ref.py) for the differentiable part, clip + Adam.
-    Sample: the first 256 rays of the benchmark's batch (the step is linear in the rays: the 1024-ray row shows it), median of
-    5 steps after 2 warm-ups at 1 torch thread (what the reference's trainer forces, volsdf/vsdf.py:21), at 32
+    Sample: the first 256 rays of the benchmark's batch (the step is linear in the rays: the opt-in 1024-ray row shows it), median of
+    3 / 5 / 3 steps after 1 warm-up at 1 torch thread (what the reference's trainer forces, volsdf/vsdf.py:21), at 32
     threads and at ALL PHYSICAL cores ("1 and all cores"; counted from /proc/cpuinfo); all hardware threads
     -- 256 on the round-4 box -- oversubscribe torch's intra-op pool (measured in round 4) and stay an opt-in; plus one
     row on the full 1024-ray batch at 32 threads.  For this leg the oracle's exp / expm1 / row sum are
@@ -947,7 +1096,10 @@ def cpu_baseline(params, K, pose, train=True):
             # oversubscribes -- measured in round 4 on the GPU box: 197 s per 1024-ray step (5.2 rays/s) and 126 s per
             # 64-ray step (0.5 rays/s), against 5.8 s (177 rays/s) at 32 threads; SVS_CPU_BASELINE_ALL_THREADS=1 repeats it
             phys = physical_cores() or all_threads
-            plan = [(1, 256, 2, 5), (min(32, all_threads), 256, 2, 5), (phys, 256, 2, 5), (min(32, all_threads), 1024, 1, 2)]
+            # ~35 s of CPU work in the default command; SVS_CPU_BASELINE_FULL=1 adds the whole 1024-ray batch at 32 threads
+            plan = [(1, 256, 1, 3), (min(32, all_threads), 256, 1, 5), (phys, 256, 1, 3)]
+            if os.environ.get("SVS_CPU_BASELINE_FULL") == "1":
+                plan.append((min(32, all_threads), 1024, 1, 2))
             if all_threads > phys and os.environ.get("SVS_CPU_BASELINE_ALL_THREADS") == "1":
                 plan.append((all_threads, 64, 0, 1))
             seen = set()
@@ -970,23 +1122,23 @@ def cpu_baseline(params, K, pose, train=True):
         finally:
             torch.set_num_threads(saved[0])
             orc.ref_exp, orc.ref_expm1, orc.ref_sum = saved[1:]
-    sample = [r for r in rows if r["rays"] == 256 and r["reps"] >= 5] or rows
+    sample = [r for r in rows if r["rays"] == 256] or rows
     best = max(sample, key=lambda r: r["rays_per_s"])
     what = ("train step (numpy sampler + MVS prior lookup, torch float32 autograd, clip, Adam)" if train
             else "train-mode fast=1 forward, numpy oracle")
     full = next((r for r in rows if r["rays"] == 1024), None)
     return {"value": best["rays_per_s"], "unit": "rays/s", "cores": best["threads"], "kind": "port",
             "sample": f"{best['rays']} rays of the benchmark's 1024-ray batch through the same {what}; median of {best['reps']} "
-                      f"steps after {best['warmups']} warm-ups at 1, 32 and {phys} (= all physical cores) torch intra-op threads, the "
-                      "best of the three reported (the numpy parts are single-threaded); the step is linear in the rays "
-                      "(`full_batch_rays_per_s`: the whole 1024-ray batch at 32 threads, median of 2 after 1); all "
-                      f"{all_threads} hardware threads oversubscribe torch's intra-op pool (round 4: 5.2 rays/s) and are an opt-in "
-                      "(SVS_CPU_BASELINE_ALL_THREADS=1)",
+                      f"steps after {best['warmups']} warm-up at the best of 1 / 32 / {phys} (all physical cores) torch threads",
+            "sample_rays": best["rays"],
             "single_thread_rays_per_s": next(r["rays_per_s"] for r in rows if r["threads"] == 1),
             "physical_cores": phys,
             "all_physical_cores_rays_per_s": next((r["rays_per_s"] for r in rows if r["threads"] == phys and r["rays"] == 256), None),
             "all_threads_rays_per_s": next((r["rays_per_s"] for r in rows if r["threads"] == all_threads and all_threads != phys), None),
             "full_batch_rays_per_s": full["rays_per_s"] if full else None,
+            "note": "the numpy parts are single-threaded; the step is linear in the rays (SVS_CPU_BASELINE_FULL=1: the whole batch "
+                    f"at 32 threads); all {all_threads} hardware threads oversubscribe torch's intra-op pool (round 4: 5.2 rays/s; "
+                    "SVS_CPU_BASELINE_ALL_THREADS=1 repeats it)",
             "runs": rows, "host_cpu": cpu_model_name(), "host_threads": all_threads}
 
 

@@ -23,8 +23,21 @@
 extern "C" {
 #endif
 
+/* ABI version.  101 (round 6): svs_set_deterministic / svs_get_deterministic added.  100 -> 101 also marks the argument
+ * lists that changed during round 5 without a version signal: svs_sdf_bwd_a lost `a2max`, svs_sdf_bwd_b gained `ubuf`, and in
+ * fp16x2 svs_sdf_outputs writes records BEHIND gbuf's 8 blocks -- size gbuf with svs_sdf_gbuf_bytes(), not svs_sdf_hbuf_bytes().
+ * A host binding should refuse a library whose version differs from the one it was written against (svs_hip/lib.py does). */
 int svs_version(void);
 const char* svs_last_error_string(void);
+
+/* Deterministic accumulation of the weight gradients (process-wide, off by default; returns the previous setting).
+ * The reference's CPU path (torch autograd on one thread, volsdf/vsdf.py:21) gives the same gradient for the same inputs
+ * every time; svs_wgrad / svs_wgrad_multi / svs_lin8_row0_grad add their workgroups' partial sums with float atomics, in
+ * arrival order.  With the switch on, the workgroups that add into one accumulator do so in launch order (csrc/svs_ticket.h):
+ * one fixed summation order, bit-identical results run to run, at the cost of serialised flushes.  Launches that add into the
+ * same accumulator must then be ordered by the caller (one stream). */
+int svs_set_deterministic(int on);
+int svs_get_deterministic(void);
 
 /* ---- a1  rays ---------------------------------------------------------------------------------------
  * rend_util.get_camera_params + lift (volsdf/utils/rend_util.py:60-95,143-156) and the depth_scale of

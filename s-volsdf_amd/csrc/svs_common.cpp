@@ -5,7 +5,10 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 namespace svs {
+static std::atomic<int> g_deterministic{0};
+bool deterministic() { return g_deterministic.load() != 0; }
 static thread_local char g_err[512] = "";
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -116,6 +119,9 @@ int svs_randperm_prefix(unsigned char* rng_state, size_t state_bytes, long long 
   return SVS_OK;
 }
 
-int svs_version(void) { return 100; }
+int svs_version(void) { return 101; }
+// deterministic accumulation of the weight gradients (csrc/svs_ticket.h): process-wide switch, off by default
+int svs_set_deterministic(int on) { const int was = svs::g_deterministic.load(); svs::g_deterministic.store(on ? 1 : 0); return was; }
+int svs_get_deterministic(void) { return svs::g_deterministic.load(); }
 const char* svs_last_error_string(void) { return svs::g_err; }
 }

@@ -17,6 +17,7 @@
 // activations in registers, LDS-DMA weight streaming, float32 MFMA) with bias-free / transposed weight streams.
 #include "svs_mlp_dev.h"
 #include "svs_mlp_bwd_args.h"
+#include "svs_ticket.h"
 
 namespace svs {
 namespace mlp {
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_kernel(SdfBwdBArgs a) {
 // points of a lane half goes through LDS once per workgroup, then float atomics into out[257] (index 256 = bias).
 __global__ __launch_bounds__(256) void lin8_row0_kernel(const float* __restrict__ hbuf, const float* __restrict__ ubuf,
                                                         const float* __restrict__ sbar, int n_tiles, int n_tiles_pad, int P,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, det::Ticket ticket) {
   __shared__ float red[4][32][65];
   const int lane = threadIdx.x & 63, quarter = threadIdx.x >> 6;
   float acc[32];
@@ -330,6 +331,7 @@ __global__ __launch_bounds__(256) void lin8_row0_kernel(const float* __restrict_
 #pragma unroll
   for (int i = 0; i < 32; ++i) red[quarter][i][lane] = acc[i];
   __syncthreads();
+  det::wait_turn(ticket, blockIdx.x);
   // thread -> (quarter, register i, half): sum its 32 points
   {
     const int q = threadIdx.x >> 6, i = (threadIdx.x >> 1) & 31, hf = threadIdx.x & 1;
@@ -344,6 +346,7 @@ __global__ __launch_bounds__(256) void lin8_row0_kernel(const float* __restrict_
     for (int d = 16; d >= 1; d >>= 1) bsum += __shfl_xor(bsum, d);
     if (lane == 0) atomicAdd(&out[256], bsum);
   }
+  det::pass_turn(ticket, blockIdx.x);
 }
 
 // ==============================================================================================================
@@ -524,7 +527,8 @@ int svs_lin8_row0_grad(const float* hbuf, const float* ubuf, const float* sbar, 
   if (precision != kFmtF32) { set_error("svs_lin8_row0_grad: unknown precision %d", precision); return SVS_EINVAL; }
   const int n_tiles = (n_points + 31) / 32;
   const int grid = n_tiles < 1024 ? n_tiles : 1024;
-  lin8_row0_kernel<<<grid, 256, 0, (hipStream_t)hip_stream>>>(hbuf, ubuf, sbar, n_tiles, tiles_of(n_points), n_points, out257);
+  const det::Ticket ticket{det::take_slots(1), 0u, (unsigned)grid};
+  lin8_row0_kernel<<<grid, 256, 0, (hipStream_t)hip_stream>>>(hbuf, ubuf, sbar, n_tiles, tiles_of(n_points), n_points, out257, ticket);
   return check_launch("svs_lin8_row0_grad");
 }
 

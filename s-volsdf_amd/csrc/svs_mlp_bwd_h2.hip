@@ -18,6 +18,7 @@
 #include "svs_mlp_bwd_args.h"
 #include "svs_mlp_h2_trunk.h"
 #include "svs_mlp_bwd_h2_dev.h"
+#include "svs_ticket.h"
 
 namespace svs {
 namespace mlp {
@@ -722,7 +723,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_h2_kernel(SdfBwdBArgs a
 template <bool GP>
 __global__ __launch_bounds__(256) void lin8_row0_h2_kernel(const float* __restrict__ hbuf, const float* __restrict__ ubuf,
                                                            const float* __restrict__ sbar, int n_tiles, int n_tiles_pad, int P,
-                                                           float* __restrict__ out) {
+                                                           float* __restrict__ out, det::Ticket ticket) {
   __shared__ float red[4][32][65];
   const int lane = threadIdx.x & 63, quarter = threadIdx.x >> 6;
   float acc[32];
@@ -759,6 +760,7 @@ __global__ __launch_bounds__(256) void lin8_row0_h2_kernel(const float* __restri
 #pragma unroll
   for (int i = 0; i < 32; ++i) red[quarter][i][lane] = acc[i];
   __syncthreads();
+  det::wait_turn(ticket, blockIdx.x);
   // thread -> (quarter, element i = 8 k + j, half): sum its 32 points; row = 16 (4 q + k) + 8 (j >> 2) + 4 half + (j & 3)
   {
     const int q = threadIdx.x >> 6, i = (threadIdx.x >> 1) & 31, hf = threadIdx.x & 1;
@@ -772,6 +774,7 @@ __global__ __launch_bounds__(256) void lin8_row0_h2_kernel(const float* __restri
     for (int d = 16; d >= 1; d >>= 1) bsum += __shfl_xor(bsum, d);
     if (lane == 0) atomicAdd(&out[256], bsum);
   }
+  det::pass_turn(ticket, blockIdx.x);
 }
 
 int launch_lin8_row0_h2(const float* hbuf, const float* ubuf, const float* sbar, int n_points, int n_tiles_pad, float* out257,
@@ -780,8 +783,9 @@ int launch_lin8_row0_h2(const float* hbuf, const float* ubuf, const float* sbar,
   // one workgroup per CU: every workgroup ends with 257 float atomics onto the same addresses, and with a workgroup per tile
   // (800 at 256 rays) their contention was most of the launch (26 -> 17 us at 256 rays, 44 -> 37 at 1024; 128: 17 / 45)
   const int grid = n_tiles < 256 ? n_tiles : 256;
-  if (gp) lin8_row0_h2_kernel<true><<<grid, 256, 0, s>>>(hbuf, ubuf, sbar, n_tiles, n_tiles_pad, n_points, out257);
-  else lin8_row0_h2_kernel<false><<<grid, 256, 0, s>>>(hbuf, ubuf, sbar, n_tiles, n_tiles_pad, n_points, out257);
+  const det::Ticket ticket{det::take_slots(1), 0u, (unsigned)grid};
+  if (gp) lin8_row0_h2_kernel<true><<<grid, 256, 0, s>>>(hbuf, ubuf, sbar, n_tiles, n_tiles_pad, n_points, out257, ticket);
+  else lin8_row0_h2_kernel<false><<<grid, 256, 0, s>>>(hbuf, ubuf, sbar, n_tiles, n_tiles_pad, n_points, out257, ticket);
   return check_launch("svs_lin8_row0_grad");
 }
 

@@ -13,6 +13,7 @@
 // "Global float atomics").
 #include "svs_common.h"
 #include "svs_mlp_layout.h"
+#include "svs_ticket.h"
 #include <cstdlib>
 
 namespace svs {
@@ -34,6 +35,7 @@ struct Args {
   float* dW;             // [256][ldw] accumulated with atomics (caller zeroes)
   int ldw;
   float* db;             // [256] row sums of A of pair 0 (bias gradient) or nullptr
+  det::Ticket ticket;    // deterministic mode: the workgroups flush in block order (svs_ticket.h)
 };
 
 struct Staging {
@@ -123,6 +125,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(Args a) {
     __syncthreads();
   }
   // flush: C[row = rho(r) + 4*half][col]; two 128-byte row segments per wave-instruction
+  det::wait_turn(a.ticket, blockIdx.x);
 #pragma unroll
   for (int o = 0; o < 2; ++o)
 #pragma unroll
@@ -134,6 +137,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(Args a) {
         if (c < a.ldw) atomicAdd(&a.dW[(size_t)row * a.ldw + c], acc[o][i][r]);
       }
   if (a.db) atomicAdd(&a.db[tid], bias_acc);
+  det::pass_turn(a.ticket, blockIdx.x);
 }
 
 
@@ -238,6 +242,7 @@ struct Job {
   float* db;             // [256] row sums of A of pair 0 (bias gradient) or nullptr
   const float* absmax;   // device float: max magnitude of the scaled operands, or nullptr (scales ignored)
   int wg_begin, wg_count;
+  det::Ticket ticket;    // deterministic mode: the workgroups that add into this job's dW columns flush in turn (svs_ticket.h)
 };
 constexpr int kMaxJobs = 20;
 struct MultiArgs { Job job[kMaxJobs]; int n_jobs; };
@@ -435,6 +440,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
   }
   // flush: C[row = rho(r) + 4*half][col]; two 128-byte row segments per wave-instruction
   const int half = lane >> 5, col = lane & 31;
+  det::wait_turn(a.ticket, wg);
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     if (i > 0 && narrow) break;
@@ -455,6 +461,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
     bsum += __shfl_xor(bsum, 32);
     if (half == 0) atomicAdd(&a.db[32 * wave + col], bsum * inv_s);
   }
+  det::pass_turn(a.ticket, wg);
 }
 
 }  // namespace h2
@@ -548,6 +555,23 @@ int svs_wgrad_multi(const svs_wgrad_job* jobs, int n_jobs, int precision, void* 
     for (int j = 0; j < n; ++j) {
       ma.job[j].wg_begin = begin; ma.job[j].wg_count = count[j];
       begin += count[j];
+      ma.job[j].ticket = det::Ticket{nullptr, 0u, 0u};
+    }
+    if (deterministic()) {
+      // jobs that add into the same columns of the same accumulator (the ray groups of a step) share a turn counter; their
+      // workgroups take tickets in job order, then block order
+      int owner[h2::kMaxJobs], n_owner = 0;
+      for (int j = 0; j < n; ++j) {
+        owner[j] = -1;
+        for (int k = 0; k < j; ++k)
+          if (ma.job[k].dW == ma.job[j].dW && ma.job[k].col0 == ma.job[j].col0) { owner[j] = owner[k]; break; }
+        if (owner[j] < 0) owner[j] = n_owner++;
+      }
+      unsigned* turn = det::take_slots((unsigned)n_owner);
+      if (!turn) { set_error("svs_wgrad_multi: no turn counters (deterministic mode)"); return SVS_EINVAL; }
+      unsigned total[h2::kMaxJobs] = {0};
+      for (int j = 0; j < n; ++j) { ma.job[j].ticket.turn = turn + owner[j]; ma.job[j].ticket.first = total[owner[j]]; total[owner[j]] += (unsigned)count[j]; }
+      for (int j = 0; j < n; ++j) ma.job[j].ticket.total = total[owner[j]];
     }
     static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(h2::wgrad_h2_multi_kernel<false>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, h2::Ring<false>::kLdsBytes);
@@ -572,6 +596,7 @@ int svs_wgrad_multi(const svs_wgrad_job* jobs, int n_jobs, int precision, void* 
     a.b_extra = q.b_extra; a.stride_extra = (size_t)q.s_extra;
     a.dW = q.dW; a.ldw = q.ldw; a.db = q.db;
     const int grid = a.n_tiles < 256 ? a.n_tiles : 256;
+    a.ticket = det::Ticket{det::take_slots(1), 0u, (unsigned)grid};
     if (q.b_extra) {
       constexpr int lds = 2 * 32 * (260 + 292) * 4;
       static hipError_t e9 = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<9>),

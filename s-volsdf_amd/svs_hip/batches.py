@@ -142,7 +142,10 @@ class CachedItems(torch.utils.data.Dataset):
         return len(self.ds)
 
     def __getattr__(self, name):        # (everything else -- trains_ids, total_pixels, change_sampling_idx ... -- is the dataset's)
-        return getattr(self.__dict__["ds"], name)
+        ds = self.__dict__.get("ds")
+        if ds is None:                  # being unpickled / deep-copied (DataLoader workers): no attribute yet, not a KeyError
+            raise AttributeError(name)
+        return getattr(ds, name)
 
     # ---- the cached parts
     def _grid(self):
@@ -225,9 +228,13 @@ class CachedItems(torch.utils.data.Dataset):
         if len(batch_list) != 1 or self.reason is not None:
             return self.ds.collate_fn(batch_list)
         out = []
+        # Small tensors (intrinsics, pose, near_pose: 64 bytes each) are copied like torch.stack copies them; the large ones
+        # (the mask image, the pixel grid when nothing is sampled, the images) stay VIEWS of the dataset's tensors -- READ-ONLY
+        # by contract: an in-place operation on a batch would change the dataset for every later item (the reference's loop
+        # only uploads them: volsdf/vsdf.py:331-335)
         for entry in batch_list[0]:
             if isinstance(entry, dict):
-                out.append({k: v.unsqueeze(0) for k, v in entry.items()})
+                out.append({k: (v.unsqueeze(0).clone() if v.numel() <= 64 else v.unsqueeze(0)) for k, v in entry.items()})
             else:
                 out.append(torch.LongTensor([entry]))
         return tuple(out)

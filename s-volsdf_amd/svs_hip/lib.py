@@ -41,6 +41,8 @@ class UnpackJob(ctypes.Structure):
 
 SIGNATURES = {
     "svs_version": (c_int, []),
+    "svs_set_deterministic": (c_int, [c_int]),
+    "svs_get_deterministic": (c_int, []),
     "svs_last_error_string": (c_char_p, []),
     "svs_rays_from_uv": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P]),
     "svs_stream_bytes": (c_size_t, [c_int]),
@@ -166,6 +168,9 @@ EXPERIMENTAL_SIGNATURES = {
 }
 
 
+ABI_VERSION = 101          # svs_version() of the library this binding was written against (include/svolsdf_hip.h)
+
+
 def load():
     """Load the shared library once; raises SvsError when it has not been built."""
     global _lib
@@ -184,8 +189,19 @@ def load():
         if fn is not None:
             fn.restype = res
             fn.argtypes = args
+    have = lib.svs_version()
+    if have != ABI_VERSION:
+        raise SvsError(f"{LIB_PATH} has ABI version {have}, this binding was written against {ABI_VERSION}: "
+                       "rebuild with `python s-volsdf_amd/build.py --force`")
+    if os.environ.get("SVS_DETERMINISTIC") == "1":
+        lib.svs_set_deterministic(1)
     _lib = lib
     return lib
+
+
+def deterministic():
+    """SVS_DETERMINISTIC=1 (or svs_set_deterministic(1)): weight gradients summed in one fixed order, steps on one stream."""
+    return bool(load().svs_get_deterministic())
 
 
 def check(rc, what=""):

@@ -501,8 +501,10 @@ def cost_lookup(views, same_view, img_res, *, xyz=None, cam=None, dirs=None, z=N
             if "z_mvs" in v:
                 zm = v["z_mvs"].reshape(v["z_mvs"].shape[-3:])
                 zn, zf = _f32(zm[0]), _f32(zm[-1])
+                copied = copied or zn.data_ptr() != zm[0].data_ptr() or zf.data_ptr() != zm[-1].data_ptr()
             else:
                 zn, zf = _f32(v["z_near"]), _f32(v["z_far"])
+                copied = copied or zn.data_ptr() != v["z_near"].data_ptr() or zf.data_ptr() != v["z_far"].data_ptr()
             # kept alive: the key holds the addresses of the ORIGINAL tensors (v["cost"], z range) -- not only those of the
             # float32 / contiguous copies _f32 may have made -- so neither can be recycled while the entry lives
             keep += [cost, zn, zf, v["K"], v["c2w"], v["cost"], v.get("z_mvs"), v.get("z_near"), v.get("z_far")]
@@ -513,8 +515,8 @@ def cost_lookup(views, same_view, img_res, *, xyz=None, cam=None, dirs=None, z=N
             _LOOKUP_CONSTS.clear()
         hit = (vp, dims, _ptr_array(cost_p), _ptr_array(near_p), _ptr_array(far_p), keep)
         if not copied:
-            # (a volume _f32 had to convert -- not float32 or not contiguous -- is looked up from a private copy: the original
-            # may change without its address changing, so such a call is not cached)
+            # (a volume or a depth-range plane _f32 had to convert -- not float32 or not contiguous -- is looked up from a
+            # private copy: the original may change without its address changing, so such a call is not cached)
             _LOOKUP_CONSTS[key] = hit
     vp, dims, cost_arr, near_arr, far_arr, _ = hit
     pj = torch.empty(R, S, device=dev)

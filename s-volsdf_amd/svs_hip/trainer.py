@@ -341,6 +341,12 @@ class TrainStep:
         self.is_bg = hasattr(model, "bg_implicit_network")      # VolSDFNetworkBG: fg + inverted-sphere background
         if self.is_bg:
             self.bg_grad_out = [[(next(it), next(it)) for _ in range(n)] for n in (9, 2)]
+        # SVS_DETERMINISTIC=1 (svs_hip.lib.deterministic): the library sums the weight gradients in one fixed order, and the
+        # step runs as ONE ray group on ONE stream from eager launches -- no measured choice between schedules, no launches
+        # on concurrent streams adding into one accumulator: the same inputs give the same bits, run after run
+        self.deterministic = _lib.deterministic()
+        if self.deterministic:
+            groups, graph = None, False
         self.groups = groups
         self.schedule = {}                              # groups == "auto": ray count -> dict(choice, ms_split, ms_whole)
         self._tune = {}
@@ -541,7 +547,7 @@ class TrainStep:
                 rng = pad_rng(rng, R)
             self._draws_done()
             gt = {"rgb": ground_truth["rgb"].reshape(-1, 3), "rgb_smooth": ground_truth["rgb_smooth"].reshape(-1, 3)}
-            results, holds = self._device_step(self.scratch, model_input, gt, mvs, fast, rng, dyn=None)
+            results, holds = self._device_step(self.scratch, model_input, gt, mvs, fast, rng, dyn=None, serial=self.deterministic)
             self._hold = holds
             out = self._finish(results)
         except BaseException:

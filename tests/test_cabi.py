@@ -38,7 +38,7 @@ def test_header_matches_library_and_ctypes_table(lib):
     for name, nargs in decls.items():
         assert hasattr(L, name), f"{name} declared in the header but not exported"
         assert len(lib.SIGNATURES[name][1]) == nargs, name
-    assert L.svs_version() >= 100
+    assert L.svs_version() == 101
 
 
 def test_size_queries(lib):

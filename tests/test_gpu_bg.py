@@ -446,3 +446,58 @@ def test_degenerate_ray_poisons_the_step_like_the_reference(dev):
     torch.manual_seed(3)
     lo2, _ = ts2(dict(inp, uv=G(uv, dev)[None]), gt)
     assert np.isfinite(float(lo2["rgb_loss"])) and float(ts2.opt.info[1]) == 0.0
+
+
+@pytest.mark.parametrize("model_kind,R", [("bg", 256), ("dtu", 1024)])
+def test_deterministic_mode_repeats_bit_for_bit(dev, model_kind, R):
+    """svs_set_deterministic(1) (SVS_DETERMINISTIC=1): three optimisation steps from the same state and the same draws give the
+    SAME parameters, bit for bit, in two runs -- the weight-gradient workgroups add their partial sums in launch order
+    (csrc/svs_ticket.h) and the step runs as one ray group on one stream.  The default mode (float atomics in arrival order,
+    concurrent streams) agrees with it to the float-atomic noise, and is what the other tests and the bench measure."""
+    from svs_hip import lib as _lib
+    from svs_hip.trainer import TrainStep
+    from volsdf.model.loss import VolSDFLoss
+    K, pose = synth.make_camera()
+    inp = {"intrinsics": G(K, dev)[None], "uv": G(synth.make_uv(R, seed=4), dev)[None], "pose": G(pose, dev)[None]}
+    rs = np.random.default_rng(6)
+    gt = {"rgb": G(rs.uniform(0, 1, (1, R, 3)).astype(np.float32), dev), "rgb_smooth": G(rs.uniform(0, 1, (1, R, 3)).astype(np.float32), dev)}
+    views = synth.make_mvs_views(2)
+    mvs = dict(views=[dict(K=v["K"], c2w=v["c2w"], cost=G(v["cost"], dev), z_mvs=G(v["z_mvs"], dev)) for v in views], same_view=0,
+               img_res=(576, 768), inverse_depth=False)
+
+    def make_model():
+        if model_kind == "bg":
+            return _model(dev, 0.1)
+        from volsdf.utils.conf import dtu_model_conf
+        from volsdf.model.network import VolSDFNetwork
+        m = VolSDFNetwork(dtu_model_conf())
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_params(0).items()}, strict=True)
+        return m.to(dev).train()
+
+    def run(det):
+        L = _lib.load()
+        was = L.svs_set_deterministic(1 if det else 0)
+        try:
+            m = make_model()
+            loss = VolSDFLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, rgb_weight=1.0, mvs_weight=1.0, sparse_weight=1.0,
+                              anneal_rgb=200, gce=0.5, confi=1e-3)
+            loss.iter_step = 250
+            ts = TrainStep(m, loss)
+            assert ts.deterministic == det
+            torch.manual_seed(13)
+            grads = []
+            for _ in range(3):
+                ts(inp, gt, mvs=mvs)
+                grads.append(ts.fp.grad.clone())
+            torch.cuda.synchronize()
+            return grads, ts.fp.flat.clone()
+        finally:
+            L.svs_set_deterministic(was)
+
+    (ga, pa), (gb, pb) = run(True), run(True)
+    for i, (x, y) in enumerate(zip(ga, gb)):
+        assert torch.equal(x, y), f"step {i}: gradients of two deterministic runs differ in {int((x != y).sum())} entries"
+    assert torch.equal(pa, pb)
+    assert float(ga[0].abs().max()) > 0 and torch.isfinite(pa).all()
+    gd, pd = run(False)                                    # default mode: same sums in another order
+    assert float((ga[0] - gd[0]).abs().max()) <= 1e-4 * float(ga[0].abs().max())

@@ -278,12 +278,34 @@ def measure(steps=3000, seeds=(0, 1), paths=("hip", "hip_f32", "torch_f32"), ray
     res["spread_mm"] = max([v.get("spread_mm", 0.0) for v in res.values() if isinstance(v, dict)] or [0.0])
     if "overall_mm" in res.get("hip", {}) and "overall_mm" in res.get("torch_f32", {}):
         res["hip_minus_torch_mm"] = res["hip"]["overall_mm"] - res["torch_f32"]["overall_mm"]
+    res["paired"] = paired_differences(res)
     res["prior"] = bool(prior)
     res["what"] = (("WITH a synthetic MVS prior (48 planes, Gaussian around the analytic depth; MVS + annealed sparsity + rgb_smooth terms): "
                     if prior else "no MVS prior (colour + eikonal terms): ") + f"analytic sphere + box scene ({IMG_RES[0]} x {IMG_RES[1]} images, 3 training views, {MM:.0f} mm per unit): {steps} "
                    f"optimisation steps of {rays} rays per path and seed -> render_mvs -> filter_depth -> evaluate_scan against the "
                    "analytic surface points the training views see; overall = (accuracy + completeness) / 2 in mm")
     return res
+
+
+def paired_differences(res, base="torch_f32"):
+    """Per path: the differences to the comparator over the seeds BOTH ran (a seed fixes the initial weights of every path:
+    the runs of a seed are paired by their starting point), their mean, the standard error of that mean and the ratio --
+    |mean| < 2 SE = no difference between the paths that this many seeds can show."""
+    out = {}
+    ref = {r["seed"]: r["overall_mm"] for r in res.get(base, {}).get("runs", []) if "overall_mm" in r}
+    for path, v in res.items():
+        if path == base or not isinstance(v, dict) or "runs" not in v:
+            continue
+        d = [r["overall_mm"] - ref[r["seed"]] for r in v["runs"] if "overall_mm" in r and r["seed"] in ref]
+        if len(d) < 2:
+            continue
+        n = len(d)
+        mean = sum(d) / n
+        sd = (sum((x - mean) ** 2 for x in d) / (n - 1)) ** 0.5
+        se = sd / n ** 0.5
+        out[f"{path}_minus_{base}"] = dict(n=n, mean_mm=mean, sd_mm=sd, se_mm=se, mean_over_se=(mean / se if se > 0 else None),
+                                           within_2_se=bool(abs(mean) < 2 * se), differences_mm=d)
+    return out
 
 
 if __name__ == "__main__":
@@ -298,8 +320,10 @@ if __name__ == "__main__":
         ap.add_argument("--rays", type=int, default=512)
         ap.add_argument("--out", default=None)
         ap.add_argument("--prior", action="store_true", help="optimise with the synthetic MVS prior (the reference's stage-0 loss)")
+        ap.add_argument("--parallel", action="store_true", help="all (path, seed) runs side by side on the one GPU")
         a = ap.parse_args()
-        out = measure(a.steps, tuple(int(s) for s in a.seeds.split(",")), tuple(a.paths.split(",")), a.rays, prior=a.prior)
+        out = measure(a.steps, tuple(int(s) for s in a.seeds.split(",")), tuple(a.paths.split(",")), a.rays, prior=a.prior,
+                      parallel=a.parallel)
         text = json.dumps(out, indent=1)
         print(text)
         if a.out:
