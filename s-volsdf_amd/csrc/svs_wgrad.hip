@@ -245,7 +245,8 @@ struct Job {
   det::Ticket ticket;    // deterministic mode: the workgroups that add into this job's dW columns flush in turn (svs_ticket.h)
 };
 constexpr int kMaxJobs = 20;
-struct MultiArgs { Job job[kMaxJobs]; int n_jobs; };
+struct MultiArgs { Job job[kMaxJobs]; int n_jobs; int touch; };
+static_assert(sizeof(MultiArgs) <= 4096, "kernel arguments");
 
 constexpr int kThreadsW = 512;          // 8 waves: wave w owns output tile w (32 rows) x all B tiles
 
@@ -315,6 +316,22 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
       __builtin_amdgcn_global_load_lds((gvoid)(a.rec[pi] + (size_t)t * 64 + lane),
                                        SVS_LDS(void, slot + kSlot + wave * 256), 4, 0, 0);
   };
+  // ---- L2 prefetch of the item AFTER the one being copied (GP ring: 2 slots of 64 KiB fill the LDS, so only ONE item can be
+  // in flight into LDS while one is multiplied -- 64 KiB per CU is less than HBM's latency-bandwidth product wants).  Every
+  // thread reads 4 bytes of one 128-byte line of the item after next into a register nobody reads: the line comes into
+  // the XCD's L2, and the LDS-DMA of that item, issued one iteration later, finds it there.  One extra vector-memory
+  // operation per wave and item, issued BEHIND the item's copies (loads return in order: the counted wait below lets it
+  // stay in flight).
+  unsigned sink = 0;
+  auto touch = [&](int item) {
+    const int t = wg + (item / a.n_pairs) * nwg, pi = item % a.n_pairs;
+    const Pair& p = a.p[pi];
+    constexpr int kLines = R::kPlanes * (kPlane / 128);          // 128-byte lines per operand block
+    const int nb = narrow ? 32 : kLines;
+    const float* q = tid < kLines ? p.a + (size_t)t * p.stride_a + tid * 32
+                                  : p.b + (size_t)t * p.stride_b + (tid - kLines) * 32;
+    if (tid < kLines + nb) asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(q) : "memory");
+  };
   // number of vector-memory operations issue() makes per wave and item
   const int ops = (narrow ? 2 * R::kPlanes + 1 : 4 * R::kPlanes) + (a.absmax ? 1 : 0);
 
@@ -359,6 +376,9 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
 
   // ---- prologue: kAhead items in flight
   for (int i0 = 0; i0 < kAhead && i0 < n_items; ++i0) issue(i0);
+  const bool touching = GP && ma.touch;
+  bool touched = false;                  // a touch is the youngest outstanding operation of this wave
+  if (touching && kAhead < n_items) { touch(kAhead); touched = true; }
   for (int item = 0; item < n_items; ++item) {
     const int pi = item % a.n_pairs;
     const bool p0 = pi == 0;
@@ -374,6 +394,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
       else if (later == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
       else if (later == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else if (later == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else if (touched) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");       // (GP: later == 0; the touch stays in flight)
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     // (raw s_barrier: __syncthreads() carries a fence that hipcc lowers to vmcnt(0), which would also wait for the
@@ -385,6 +406,8 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     if (item + kAhead < n_items) issue(item + kAhead);
+    touched = false;
+    if (touching && item + kAhead + 1 < n_items) { touch(item + kAhead + 1); touched = true; }
     const unsigned la = lds_addr(ring + (item % kRing) * kSlotAll);
     const unsigned lb = la + kB;
     const unsigned ftab = la + kSlot + kRecBytes + wave * 64;
@@ -438,6 +461,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
       }
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" :: "v"(sink) : "memory");          // the last touch has returned; `sink` lived until here
   // flush: C[row = rho(r) + 4*half][col]; two 128-byte row segments per wave-instruction
   const int half = lane >> 5, col = lane & 31;
   det::wait_turn(a.ticket, wg);
@@ -531,6 +555,8 @@ int svs_wgrad_multi(const svs_wgrad_job* jobs, int n_jobs, int precision, void* 
       }
     }
     ma.n_jobs = n;
+    static const int touch_env = [] { const char* e = getenv("SVS_WGRAD_TOUCH"); return e ? atoi(e) : 0; }();
+    ma.touch = touch_env;
     // One workgroup per CU in total, at least one per job and no more than a job has tiles; the rest are handed out one at a
     // time to the job whose workgroups carry the most work (the launch lasts as long as its longest workgroup: with jobs of
     // very different sizes -- a step's two ray groups in one launch -- rounding each share on its own left a small job's

@@ -100,14 +100,19 @@ def _unpack_all(jobs):
     _lib.check(L.svs_unpack_wgrad_multi(ctypes.cast(arr, ctypes.c_void_p), len(jobs), _stream()), "svs_unpack_wgrad_multi")
 
 
-def finalize(accum, sdf_params, rgb_params, out=None):
+def finalize(accum, sdf_params, rgb_params, out=None, nets=(0, 1)):
     """kernel-order accumulators -> (sdf_grads, rgb_grads): lists of (grad_v, grad_g, grad_b) per layer; `out`
-    optionally names the destination tensors (views of a flat gradient buffer).  One launch for all 14 layers."""
+    optionally names the destination tensors (views of a flat gradient buffer).  One launch for all 14 layers; `nets`
+    restricts it to the SDF network (0) or the radiance network (1): a data-parallel step unpacks the radiance gradients as
+    soon as their GEMM launch has retired, so that their bucket can be all-reduced beside the SDF backward (trainer.py)."""
     dev = accum.dWk.device
     res, jobs, keep = [], [], []
     for gi, (params, base, n) in enumerate(((sdf_params, 0, 9), (rgb_params, 9, 5))):
         v, g, _ = params
         group = []
+        if gi not in nets:
+            res.append(group)
+            continue
         for l in range(n):
             rows, cols = v[l].shape
             if out is not None:

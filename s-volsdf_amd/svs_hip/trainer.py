@@ -95,6 +95,30 @@ def allreduce_flat_grad(flat_grad, world):
     return flat_grad
 
 
+def data_parallel(world):
+    import torch.distributed as dist
+    return world > 1 or (dist.is_available() and dist.is_initialized())
+
+
+def grad_buckets(n_sdf, n):
+    """The flat gradient as two contiguous buckets in the order they COMPLETE inside a step: [n_sdf, n) -- the radiance
+    network, density.beta and (VolSDFNetworkBG) the background networks, whose weight gradients are final once the radiance
+    GEMM launch / the background backward has retired, ~0.3 ms (1024 rays) before the step ends -- then [0, n_sdf): the SDF
+    network, whose GEMM launch is the last of the step.  (The flat order is model._flat_param_list(): SDF layers, radiance
+    layers, beta, background networks -- the reference's parameter order, which the checkpoints' Adam state follows.)"""
+    return [(n_sdf, n), (0, n_sdf)]
+
+
+def allreduce_range(flat_grad, lo, hi, async_op=False):
+    """all-reduce (sum) of flat_grad[lo:hi] in place; -> the Work handle when async_op (its .wait() orders the CURRENT stream
+    behind the collective).  A sum all-reduce acts element by element, so reducing a buffer in contiguous pieces gives every
+    rank the same values as reducing it whole -- bit for bit with two ranks (a + b commutes), and with a ring of more ranks up
+    to the order in which the ranks' contributions meet, which depends on where an element falls in the collective's chunks:
+    the replicas stay identical among themselves either way (tests/test_dist_gloo.py::test_bucketed_allreduce_equals_single_world2)."""
+    import torch.distributed as dist
+    return dist.all_reduce(flat_grad[lo:hi], op=dist.ReduceOp.SUM, async_op=async_op)
+
+
 # Experiment, OFF by default: in captured sequences the prior look-up as a branch beside the fused SDF / radiance launches and
 # lin8's first-row gradient beside the SDF weight-gradient launch (51 us of small launches off a 256-ray step's critical
 # chain).  Measured with launch plans, A/B twice on one box: 1.315 / 1.311 against 1.319 / 1.311 ms (DTU model, 256 rays), 1.55
@@ -105,6 +129,7 @@ _SMALL_GROUP_INLINE = os.environ.get("SVS_SMALL_GROUP_INLINE", "0") == "1"     #
 # launches (train.MlpBackward.accumulate, defer_wgrad / extra).  The small group's own launches cost a ring fill and a
 # workgroup per CU each for 5 % of the points: 0.46 + 0.2 ms of kernel time per step beside the large group's (round 4).
 _FOLD_WGRAD = os.environ.get("SVS_FOLD_WGRAD", "1") == "1"
+_DP_BUCKETS = os.environ.get("SVS_DP_BUCKETS", "1") == "1"        # A/B: 0 = one all-reduce of the whole flat gradient at the end
 
 
 class _GroupedOutputs(dict):
@@ -337,6 +362,10 @@ class TrainStep:
                 group.append((gv, gg, next(it)))
             self.grad_out.append(group)
         self.beta_grad = next(it)
+        n_sdf = sum(t.numel() for grp in self.grad_out[0] for t in grp if t is not None)
+        self._buckets = grad_buckets(n_sdf, self.fp.n)
+        self._early_work = None
+        self._comm = None                                   # stream the early bucket is unpacked and reduced on
         dev = self.fp.flat.device
         self.is_bg = hasattr(model, "bg_implicit_network")      # VolSDFNetworkBG: fg + inverted-sphere background
         if self.is_bg:
@@ -592,7 +621,15 @@ class TrainStep:
 
     def _finish(self, results):
         """What follows the gradient: the one collective of a data-parallel step, the fused optimiser, host counters."""
-        allreduce_flat_grad(self.fp.grad, self.world)
+        early, self._early_work = getattr(self, "_early_work", None), None
+        if early is not None:
+            # the early bucket (radiance / beta / background networks) is being reduced on the comm stream since its GEMM
+            # launch retired; the SDF bucket is complete now; the optimiser waits for both
+            lo, hi = self._buckets[1]
+            allreduce_range(self.fp.grad, lo, hi)
+            early.wait()
+        else:
+            allreduce_flat_grad(self.fp.grad, self.world)
         self.opt.step()
         self.model.invalidate_packed()          # the fused kernel bypasses torch's version counters
         self.loss.iter_step += 1
@@ -749,13 +786,35 @@ class TrainStep:
                 holds[gi] = (keep, g, d_sdf, d_rgb, inp, g_gt, folded)
                 if gi:
                     ev = torch.cuda.Event(); ev.record(stream); joins.append(ev)
+        # Data-parallel eager steps (SVS_DP_BUCKETS=0: one collective at the end): everything but the SDF network's gradients
+        # is final once the radiance GEMM launch (and the background backward) has retired -- `joins` holds exactly those
+        # events plus the small group's -- while pass A / pass B / the SDF GEMM still run on `main`.  A comm stream waits for
+        # them, unpacks the radiance (and background) gradients into the flat gradient and starts the all-reduce of that
+        # bucket; `_finish` reduces the SDF bucket and waits for both.  Captured sequences keep the single collective (the
+        # capture ends at the flat gradient; a collective inside a launch plan is not something the plan builder replays).
+        early = (dyn is None and not serial and _DP_BUCKETS and data_parallel(self.world)
+                 and not torch.cuda.is_current_stream_capturing())
+        if early:
+            if self._comm is None:
+                self._comm = torch.cuda.Stream(device=dev)
+            comm = self._comm
+            with torch.cuda.stream(comm):
+                for ev in joins:
+                    comm.wait_event(ev)
+                finalize(sc.accum, sdf_p, rgb_p, out=self.grad_out, nets=(1,))
+                if self.is_bg:
+                    sc.bg_bwd.finalize(bg_sdf_wb, bg_rgb_wb, out=self.bg_grad_out)
+                if len(groups) > 1:
+                    torch.sum(sc.d_beta[:len(groups)], dim=0, keepdim=True, out=self.beta_grad.view(1))
+                lo, hi = self._buckets[0]
+                self._early_work = allreduce_range(self.fp.grad, lo, hi, async_op=True)
         for ev in joins:
             main.wait_event(ev)
-        finalize(sc.accum, sdf_p, rgb_p, out=self.grad_out)
-        if self.is_bg:
+        finalize(sc.accum, sdf_p, rgb_p, out=self.grad_out, nets=(0,) if early else (0, 1))
+        if self.is_bg and not early:
             sc.bg_bwd.finalize(bg_sdf_wb, bg_rgb_wb, out=self.bg_grad_out)
-        if len(groups) == 1:
-            pass                                         # (written in place: d_beta_out above)
+        if len(groups) == 1 or early:
+            pass                                         # (written in place: d_beta_out above / summed on the comm stream)
         else:
             torch.sum(sc.d_beta[:len(groups)], dim=0, keepdim=True, out=self.beta_grad.view(1))
         return results, holds

@@ -341,3 +341,50 @@ def test_no_ray_group_of_pure_padding():
     assert TrainStep._groups_for(me, 1008) == [(0, 992), (992, 1008)]      # 8 real rays in the tail group: the split stays
     me._n_valid = 1008
     assert TrainStep._groups_for(me, 1008) == [(0, 992), (992, 1008)]
+
+
+# --------------------------------------------------------------------------------------------------------------
+# the flat gradient reduced in BUCKETS (trainer.grad_buckets / allreduce_range: the radiance bucket is reduced on a side stream
+# beside the SDF backward, the SDF bucket at the end) against ONE all-reduce of the whole buffer
+def _bucket_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "s-volsdf_amd"))
+    import torch.distributed as dist
+    from svs_hip.trainer import allreduce_flat_grad, allreduce_range, grad_buckets
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, n_sdf = 797883, 556545                                     # the DTU model's flat gradient and its SDF share
+    g = torch.Generator().manual_seed(100 + rank)
+    # gradient-like values over many orders of magnitude, a few exact zeros
+    grad = torch.randn(n, generator=g) * torch.exp(torch.randn(n, generator=g) * 4.0)
+    grad[torch.randint(0, n, (1000,), generator=g)] = 0.0
+    whole = grad.clone()
+    allreduce_flat_grad(whole, world)
+    buckets = grad_buckets(n_sdf, n)
+    assert buckets == [(n_sdf, n), (0, n_sdf)] and sum(hi - lo for lo, hi in buckets) == n
+    pieces = grad.clone()
+    (lo0, hi0), (lo1, hi1) = buckets
+    work = allreduce_range(pieces, lo0, hi0, async_op=True)      # the early bucket, in flight ...
+    pieces[lo1:hi1] *= 1.0                                         # ... while the step still writes the late one
+    allreduce_range(pieces, lo1, hi1)
+    work.wait()
+    q.put((rank, torch.equal(whole, pieces), whole.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_equals_single_world2():
+    """two buckets that tile the flat gradient == one all-reduce of the whole buffer, bit for bit, on both ranks; and the ranks
+    hold identical sums (replicas stay identical)"""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(same for _, same, _ in res)
+    np.testing.assert_array_equal(res[0][2], res[1][2])

@@ -480,8 +480,8 @@ def test_white_background_training(dev):
 
 
 def test_rccl_path_on_one_gpu(dev):
-    """world = 1 under torch.distributed (backend nccl = RCCL): the step's single collective -- all-reduce (sum) of the flat
-    gradient -- is a no-op on one rank and must leave the step untouched: per-ray outputs bit-identical to a step without
+    """world = 1 under torch.distributed (backend nccl = RCCL): the step's collectives -- the all-reduce (sum) of the flat
+    gradient, in two buckets -- are no-ops on one rank and must leave the step untouched: per-ray outputs bit-identical to a step without
     a process group, gradient equal up to the float atomics' order.  (The N > 1 arithmetic is covered on CPU with gloo:
     tests/test_dist_gloo.py::test_train_step_arithmetic_world2; 8-GPU runs are the driver's.)"""
     import socket
@@ -515,7 +515,10 @@ def test_rccl_path_on_one_gpu(dev):
             dist.all_reduce = orig
     finally:
         dist.destroy_process_group()
-    assert calls == [plain[2].numel()], calls                      # ONE collective, over the whole flat gradient
+    # two collectives that tile the flat gradient: the radiance / beta bucket (reduced beside the SDF backward), then the SDF
+    # network's bucket (trainer.grad_buckets); SVS_DP_BUCKETS=0: one collective over the whole buffer
+    n_sdf = sum(p.numel() for n, p in _setup(dev)[0].named_parameters() if n.startswith("implicit_network."))
+    assert calls == [plain[2].numel() - n_sdf, n_sdf], calls
     assert torch.equal(plain[0], with_pg[0]) and torch.equal(plain[1], with_pg[1])
     assert float((plain[2] - with_pg[2]).abs().max()) <= 1e-5 * float(plain[2].abs().max())
     d = (plain[3] - with_pg[3]).abs()

@@ -370,7 +370,11 @@ def test_volopt_data_parallel_one_gpu(tmp_path, monkeypatch):
     finally:
         if dist.is_initialized():
             dist.destroy_process_group()
-    assert calls == [v.step_fn.fp.grad.numel()] * 3, calls
+    # per step the flat gradient is reduced exactly once: as two buckets that tile it (eager steps: trainer.grad_buckets) or
+    # as one collective (captured steps)
+    n = v.step_fn.fp.grad.numel()
+    lo, hi = v.step_fn._buckets[0]
+    assert sum(calls) == 3 * n and all(c in (n, hi - lo, n - (hi - lo)) for c in calls), calls
     # step 0 bit for bit; later steps start from parameters that went through an Adam step on a gradient whose float atomics
     # add up in a different order from run to run (with or without a process group)
     assert plain[0][0] == forced[0][0] and torch.equal(plain[0][1], forced[0][1])

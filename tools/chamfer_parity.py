@@ -12,6 +12,8 @@ of them training views: tests/synthetic_scene.py::AnalyticSceneDataset) goes thr
 once per PATH and seed; the ground truth are the analytic surface points the training views see.  Paths:
     hip         the product: VolOpt.run on the HIP kernels at the default precision (fp16x2, float32 class)
     hip_f32     the same with SVS_MLP_PRECISION=f32 (float32 MFMA kernels)
+    hip_det     the same as `hip` with SVS_DETERMINISTIC=1 (weight gradients summed in one fixed order, one stream: a seed gives
+                one answer, run after run)
     torch_f32   the comparator: the same optimisation in plain PyTorch float32 autograd on the same GPU (oracle/torch_ref.py:
                 the reference's sampler, networks, compositing, loss; Adam, clip) -- checker-side code; its trained weights
                 are then rendered, fused and evaluated by the same renderer / fusion / evaluator as the other paths
@@ -241,8 +243,11 @@ def measure(steps=3000, seeds=(0, 1), paths=("hip", "hip_f32", "torch_f32"), ray
     def start(path, s):
         env = dict(os.environ)
         env.pop("SVS_MLP_PRECISION", None)
+        env.pop("SVS_DETERMINISTIC", None)
         if path == "hip_f32":
             env["SVS_MLP_PRECISION"] = "f32"
+        if path == "hip_det":
+            env["SVS_DETERMINISTIC"] = "1"
         return subprocess.Popen([sys.executable, os.path.abspath(__file__), "--child", f"{path}:{s}:{steps}:{rays}:{int(prior)}"], env=env,
                                 stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
 
@@ -259,12 +264,13 @@ def measure(steps=3000, seeds=(0, 1), paths=("hip", "hip_f32", "torch_f32"), ray
             return dict(seed=s, error=(err or out)[-600:])
 
     sb = lambda path: tuple((seeds_by_path or {}).get(path, seeds))
-    procs = {(path, s): start(path, s) for path in paths for s in sb(path)} if parallel else {}
+    # (keyed by position: a seed may be listed twice -- the repeatability check of the deterministic path)
+    procs = {(path, i): start(path, s) for path in paths for i, s in enumerate(sb(path))} if parallel else {}
     res = {}
     for path in paths:
         runs = []
-        for s in sb(path):
-            runs.append(finish(procs[(path, s)] if parallel else start(path, s), s))
+        for i, s in enumerate(sb(path)):
+            runs.append(finish(procs[(path, i)] if parallel else start(path, s), s))
         ok = [x for x in runs if "overall_mm" in x]
         res[path] = dict(runs=runs)
         if ok:
