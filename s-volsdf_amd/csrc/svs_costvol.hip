@@ -376,6 +376,311 @@ __global__ __launch_bounds__(256, NS <= 2 ? 4 : 2) void warp_variance_reuse_kern
   }
 }
 
+// ---- round 6: the same producer with EIGHT channels per lane --------------------------------------------------------------
+// The kernel above is bound by the vector ALUs' issue rate, not by memory: per (voxel, plane) it executes ~1540 lane-instructions
+// -- 2 x 250 for the two corner-table entries and 8 lanes x 130 in the blend loop, of which only ~50 are the blend, the variance
+// and the fp16 split; the rest is per-LANE overhead that does not depend on how many channels a lane carries (table reads,
+// the moved-or-not test, register copies around the conditional gathers, address arithmetic, waits) -- and 3.93 M voxels x
+// 1540 / 64 lanes x 4 cycles / (1024 SIMDs x 1.9 GHz) = 0.195 ms is what it takes at stage 1 (measured 0.195-0.22).
+// Here a lane owns one 16-byte UNIT of the split volume (8 consecutive channels): C/8 lanes per voxel, twice the channels per
+// lane and half the lanes, so the per-lane overhead is paid half as often; both stores of a lane are whole units
+// (global_store_dwordx4).  The corner tables are computed with the source index uniform per round (camera block in SGPRs,
+// the depth hypothesis loaded once for all sources).  All vector-memory operations of the blend loop are inline assembly:
+//   * the conditional re-gather writes INTO the registers that hold the corners (tied operands): no copy of the old corners,
+//     and hipcc's waitcnt pass -- which put a vmcnt(0) in front of every copy -- does not see them;
+//   * loads and stores retire from vmcnt in issue order, so the loop is skewed by one plane: a plane's two stores are issued
+//     BEHIND the next plane's gathers and `s_waitcnt vmcnt(2)` in front of the next blend waits for the gathers only.  The
+//     count is static because an active wave always issues exactly two stores per plane (waves without a voxel inside the
+//     image leave the pass before they issue anything).
+// Same arithmetic per channel in the same order as warp_variance_kernel: the values are the float32 kernel's bit for bit
+// (tests/test_gpu_costvol.py::test_warp_variance_split_volume).
+// IEEE float32 quotients n0 / d and n1 / d as the compiler's own division sequence computes them (v_div_scale, v_rcp, the
+// two Newton steps on the reciprocal and the quotient, v_div_fmas, v_div_fixup: LLVM's AMDGPU f32 fdiv lowering), with the
+// scaling and fix-up instructions left out and the refined reciprocal shared by both quotients: when neither operand is
+// scaled (|d| and |n| well inside the normal range: v_div_scale returns them unchanged, v_div_fmas is a plain fma,
+// v_div_fixup passes the quotient through) these ARE that sequence's operations, operation by operation, so the quotients
+// are the correctly rounded ones bit for bit.  Outside that range the ordinary division runs.  (A projection divides two
+// coordinates by one depth and the two results by two constants: four divisions of ~12 instructions per table entry.)
+__device__ __forceinline__ void div2_ieee(float n0, float n1, float d, float& q0, float& q1) {
+  const float ad = __builtin_fabsf(d);
+  if (ad > 0x1p-40f && ad < 0x1p40f && __builtin_fabsf(n0) < 0x1p40f && __builtin_fabsf(n1) < 0x1p40f) {
+    float r = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    float m0 = n0 * r, m1 = n1 * r;
+    m0 = __builtin_fmaf(__builtin_fmaf(-d, m0, n0), r, m0);
+    m1 = __builtin_fmaf(__builtin_fmaf(-d, m1, n1), r, m1);
+    q0 = __builtin_fmaf(__builtin_fmaf(-d, m0, n0), r, m0);
+    q1 = __builtin_fmaf(__builtin_fmaf(-d, m1, n1), r, m1);
+  } else {
+    q0 = n0 / d; q1 = n1 / d;
+  }
+}
+// n / d for a constant d whose refined reciprocal r = refine(rcp(d)) the caller formed once (same sequence)
+__device__ __forceinline__ float refined_rcp(float d) {
+  float r = __builtin_amdgcn_rcpf(d);
+  return __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+}
+__device__ __forceinline__ float div_const_ieee(float n, float d, float r) {
+  if (__builtin_fabsf(n) < 0x1p40f) {
+    float m = n * r;
+    m = __builtin_fmaf(__builtin_fmaf(-d, m, n), r, m);
+    return __builtin_fmaf(__builtin_fmaf(-d, m, n), r, m);
+  }
+  return n / d;
+}
+
+// warp_taps (above) for the eight-channel producer: the same operations in the same order, with the four divisions as
+// above (hw = (W - 1) / 2, hh = (H - 1) / 2 and their refined reciprocals are formed once per thread) and the four corners
+// without branches (compare, select): an entry costs ~130 instructions instead of ~245.
+template <int C>
+__device__ __forceinline__ void warp_taps8(const WarpArgs& a, int v, int x, int y, int d, float depth, float hw, float rhw,
+                                           float hh, float rhh, f32x4& w4, i32x4& o4) {
+  const int H = a.H, W = a.W;
+  const float fx = (float)x, fy = (float)y;
+  const float* R = a.rot[v];
+  const float qx = ((R[0] * fx + R[1] * fy) + R[2]) * depth + a.trans[v][0];
+  const float qy = ((R[3] * fx + R[4] * fy) + R[5]) * depth + a.trans[v][1];
+  const float qz = ((R[6] * fx + R[7] * fy) + R[8]) * depth + a.trans[v][2];
+  float px, py;
+  div2_ieee(qx, qy, qz, px, py);
+  const float gx = div_const_ieee(px, hw, rhw) - 1.0f, gy = div_const_ieee(py, hh, rhh) - 1.0f;
+  const float ix = ((gx + 1.0f) * (float)W - 1.0f) / 2.0f, iy = ((gy + 1.0f) * (float)H - 1.0f) / 2.0f;
+  const float x0 = __builtin_floorf(ix), y0 = __builtin_floorf(iy);
+  const float tx = ix - x0, ty = iy - y0;
+  const float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+  const float wmax = (float)(W - 1), hmax = (float)(H - 1);
+  const bool live = x < W && d < a.D;
+  // zeros padding: a corner outside contributes nothing (NaN coordinates compare false)
+  const bool vx0 = live && x0 >= 0.0f && x0 <= wmax, vx1 = live && x1 >= 0.0f && x1 <= wmax;
+  const bool vy0 = y0 >= 0.0f && y0 <= hmax, vy1 = y1 >= 0.0f && y1 <= hmax;
+  const float ux = 1.0f - tx, uy = 1.0f - ty;
+  w4[0] = (vx0 && vy0) ? ux * uy : 0.0f;
+  w4[1] = (vx1 && vy0) ? tx * uy : 0.0f;
+  w4[2] = (vx0 && vy1) ? ux * ty : 0.0f;
+  w4[3] = (vx1 && vy1) ? tx * ty : 0.0f;
+  const int xi0 = (int)x0, xi1 = (int)x1, r0 = (int)y0 * W, r1 = (int)y1 * W;
+  o4[0] = (vx0 && vy0) ? (r0 + xi0) * (C * 4) : 0;
+  o4[1] = (vx1 && vy0) ? (r0 + xi1) * (C * 4) : 0;
+  o4[2] = (vx0 && vy1) ? (r1 + xi0) * (C * 4) : 0;
+  o4[3] = (vx1 && vy1) ? (r1 + xi1) * (C * 4) : 0;
+}
+
+template <int C> struct Warp8 {};
+template <> struct Warp8<32> { static constexpr int T = 320, P = 2; };   // 80 voxels per pass: TW = 160 = stage-1 width
+template <> struct Warp8<16> { static constexpr int T = 320, P = 1; };   // 160 voxels per pass
+template <> struct Warp8<8>  { static constexpr int T = 128, P = 1; };   // 128 voxels per pass (tables: 32 KiB for two sources)
+
+__device__ __forceinline__ void gload128(f32x4& v, unsigned off, const void* base) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory");
+}
+__device__ __forceinline__ void gload128_16(f32x4& v, unsigned off, const void* base) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(v) : "v"(off), "s"(base) : "memory");
+}
+__device__ __forceinline__ void gload32(float& v, unsigned off, const void* base) {
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory");
+}
+__device__ __forceinline__ void gstore128(unsigned off, const i32x4& v, void* base) {
+  asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(off), "v"(v), "s"(base) : "memory");
+}
+// The conditional re-gather of one source's four corners (2 x 16 bytes each) for the lanes of `mask`: exec is narrowed INSIDE
+// the statement and the corner registers are tied operands of straight-line code.  (As `if (moved) f = load(...)` in C++ the
+// merge of old and new corners becomes a copy of all eight registers in front of the branch -- 72 v_mov per plane -- and, with
+// loads the compiler can see, a vmcnt(0) in front of each copy.)  No lane moved: the loads are skipped, nothing is counted.
+__device__ __forceinline__ void regather(f32x4 (&f)[4][2], const i32x4& o4, unsigned lane_off, const void* base,
+                                         unsigned long long mask) {
+  unsigned long long saved;
+  const unsigned o0 = (unsigned)o4[0] + lane_off, o1 = (unsigned)o4[1] + lane_off, o2 = (unsigned)o4[2] + lane_off,
+                 o3 = (unsigned)o4[3] + lane_off;
+  asm volatile(
+      "s_and_saveexec_b64 %[sv], %[mask]\n\t"
+      "s_cbranch_execz 1f\n\t"
+      "global_load_dwordx4 %[a0], %[o0], %[base]\n\t"
+      "global_load_dwordx4 %[a1], %[o0], %[base] offset:16\n\t"
+      "global_load_dwordx4 %[b0], %[o1], %[base]\n\t"
+      "global_load_dwordx4 %[b1], %[o1], %[base] offset:16\n\t"
+      "global_load_dwordx4 %[c0], %[o2], %[base]\n\t"
+      "global_load_dwordx4 %[c1], %[o2], %[base] offset:16\n\t"
+      "global_load_dwordx4 %[d0], %[o3], %[base]\n\t"
+      "global_load_dwordx4 %[d1], %[o3], %[base] offset:16\n"
+      "1:\n\t"
+      "s_mov_b64 exec, %[sv]"
+      : [a0] "+v"(f[0][0]), [a1] "+v"(f[0][1]), [b0] "+v"(f[1][0]), [b1] "+v"(f[1][1]), [c0] "+v"(f[2][0]), [c1] "+v"(f[2][1]),
+        [d0] "+v"(f[3][0]), [d1] "+v"(f[3][1]), [sv] "=&s"(saved)
+      : [o0] "v"(o0), [o1] "v"(o1), [o2] "v"(o2), [o3] "v"(o3), [base] "s"(base), [mask] "s"(mask)
+      : "memory");
+}
+
+// `s_waitcnt vmcnt(N)` + a scheduling barrier: hipcc otherwise hoists register-only instructions above an asm wait
+// (the loads are invisible to its own waitcnt pass; naming the loaded registers as operands of the wait instead makes the
+// register allocator copy every one of them around it: 80 v_mov per plane)
+template <int N>
+__device__ __forceinline__ void wait_loads() {
+  if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+#ifndef SVS_WARP8_MINB
+#define SVS_WARP8_MINB 1
+#endif
+template <int C, int NS>
+__global__ __launch_bounds__(Warp8<C>::T, SVS_WARP8_MINB) void warp_variance_reuse8_kernel(WarpArgs a) {
+  constexpr int T = Warp8<C>::T, P = Warp8<C>::P;
+  constexpr int LPV = C / 8, VPP = T / LPV, TW = P * VPP, G = C / 8;
+  constexpr int S = T / TW;                         // table slices (one plane of one source) per round
+  static_assert(T % TW == 0 && kWarpDz % S == 0 && T == S * TW, "table rounds");
+  __shared__ __attribute__((aligned(16))) f32x4 tapw[kWarpDz][NS][TW];
+  __shared__ __attribute__((aligned(16))) i32x4 tapo[kWarpDz][NS][TW];
+  const int tid = threadIdx.x;
+  const int H = a.H, W = a.W, y = blockIdx.y;
+  const int xt = blockIdx.x * TW, d0 = blockIdx.z * kWarpDz;
+  const float inv_nv = 1.0f / (float)(NS + 1);
+  // ---- corner tables: thread -> voxel vx of slice `sub` of every round; round (j, v): plane j * S + sub of source v.  v is
+  // uniform (the rot / trans rows come from the kernel arguments as scalars), a plane's depth is loaded once for all sources
+  {
+    const int sub = tid / TW, vx = tid - sub * TW, x = xt + vx;
+    float dep[kWarpDz / S];
+#pragma unroll
+    for (int j = 0; j < kWarpDz / S; ++j) {
+      const int d = d0 + j * S + sub;
+      dep[j] = (x < W && d < a.D) ? a.depth_values[((size_t)d * H + y) * W + x] : 0.0f;
+    }
+    const float hw = (float)(W - 1) / 2.0f, hh = (float)(H - 1) / 2.0f;
+    const float rhw = refined_rcp(hw), rhh = refined_rcp(hh);
+#pragma unroll
+    for (int j = 0; j < kWarpDz / S; ++j) {
+#pragma unroll
+      for (int v = 0; v < NS; ++v) {
+        f32x4 w4; i32x4 o4;
+#ifdef SVS_WARP8_PLAIN_TAPS
+        warp_taps<C>(a, v, x, y, d0 + j * S + sub, dep[j], w4, o4);
+#else
+        warp_taps8<C>(a, v, x, y, d0 + j * S + sub, dep[j], hw, rhw, hh, rhh, w4, o4);
+#endif
+        tapw[j * S + sub][v][vx] = w4;
+        tapo[j * S + sub][v][vx] = o4;
+      }
+    }
+  }
+  __syncthreads();
+  const int g = tid % LPV, vl = tid / LPV;
+  const int Hp = splitvol::padded_h(H), Wp = splitvol::padded_w(W);
+  const unsigned plane_b = (unsigned)((size_t)Hp * 2 * G * Wp * 16);     // bytes between two planes of the split volume
+  const unsigned mid_b = (unsigned)(G * Wp * 16);                        // from a unit's hi piece to its mid piece
+  const unsigned HW4 = (unsigned)(H * W) * 4u;
+  f32x4 f[NS][4][2];
+  float ref[8];
+  i32x4 held[NS];
+  f32x4 w4s[NS];
+#pragma unroll
+  for (int v = 0; v < NS; ++v)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { f[v][k][0] = f32x4{0, 0, 0, 0}; f[v][k][1] = f32x4{0, 0, 0, 0}; }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ref[j] = 0.0f;
+  // first plane of a pass: a new voxel, everything is fetched
+  auto first_loads = [&](int vxn) {
+    const int xc = xt + vxn < W ? xt + vxn : W - 1;                      // (lanes outside the image fetch a valid address)
+    unsigned ro = ((unsigned)(8 * g) * (unsigned)(H * W) + (unsigned)(y * W + xc)) * 4u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { gload32(ref[j], ro, a.ref); ro += HW4; }
+#pragma unroll
+    for (int v = 0; v < NS; ++v) {
+      w4s[v] = tapw[0][v][vxn];
+      const i32x4 o4 = tapo[0][v][vxn];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        gload128(f[v][k][0], (unsigned)o4[k] + 32u * g, a.src_hwc[v]);
+        gload128_16(f[v][k][1], (unsigned)o4[k] + 32u * g, a.src_hwc[v]);
+      }
+      held[v] = o4;
+    }
+  };
+  // Straight-line code from here on (P and kWarpDz are unrolled; the only run-time branches are uniform and merge no
+  // registers): planes beyond D are computed like the others (their table entries have weight 0 and offset 0) and not stored.
+  int prev_stored = 0;                   // uniform: did the plane before this one issue its two stores?
+  first_loads(vl);
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int vx = p * VPP + vl, x = xt + vx;
+    // waves without a voxel inside the image leave here (x grows with p: they were not active before either)
+    if (__builtin_amdgcn_readfirstlane(xt + p * VPP + (tid & ~63) / LPV) >= W) break;
+    unsigned so = (unsigned)(splitvol::unit(d0, y, 0, g, x < W ? x : W - 1, G, Hp, Wp) * 16);
+#pragma unroll
+    for (int dz = 0; dz < kWarpDz; ++dz) {
+      const int d = d0 + dz;
+      if (prev_stored) wait_loads<2>(); else wait_loads<0>();
+      f32x4 res[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const f32x4 rf = {ref[4 * hh], ref[4 * hh + 1], ref[4 * hh + 2], ref[4 * hh + 3]};
+        f32x4 sum = rf, sq = rf * rf;
+#pragma unroll
+        for (int v = 0; v < NS; ++v) {
+          f32x4 warped = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            warped = __builtin_elementwise_fma(f32x4{w4s[v][k], w4s[v][k], w4s[v][k], w4s[v][k]}, f[v][k][hh], warped);
+          sum += warped; sq = __builtin_elementwise_fma(warped, warped, sq);
+        }
+        const f32x4 m = sum * inv_nv;
+        res[hh] = sq * inv_nv - m * m;
+      }
+      f16x4 h[2], lo[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const _Float16 q = (_Float16)res[hh][j];
+          h[hh][j] = q;
+          lo[hh][j] = (_Float16)(res[hh][j] - (float)q);
+        }
+      // the next plane's corner weights and (masked) gathers -- or the next pass's first plane -- in front of this plane's
+      // stores
+      if (dz + 1 < kWarpDz) {
+#pragma unroll
+        for (int v = 0; v < NS; ++v) {
+          w4s[v] = tapw[dz + 1][v][vx];
+          const i32x4 o4 = tapo[dz + 1][v][vx];
+          // (a voxel's LPV lanes decide alike; a corner outside the image has offset 0 and weight 0)
+          const bool moved = o4[0] != held[v][0] || o4[1] != held[v][1] || o4[2] != held[v][2] || o4[3] != held[v][3];
+          regather(f[v], o4, 32u * g, a.src_hwc[v], __builtin_amdgcn_ballot_w64(moved));
+          held[v] = o4;
+        }
+      } else if (p + 1 < P) {
+        first_loads((p + 1) * VPP + vl);
+      }
+      const int stored = d < a.D;                                        // uniform
+      if (stored && x < W) {
+        i32x4 uh, um;
+        uh = __builtin_bit_cast(i32x4, __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7));
+        um = __builtin_bit_cast(i32x4, __builtin_shufflevector(lo[0], lo[1], 0, 1, 2, 3, 4, 5, 6, 7));
+        gstore128(so, uh, a.split);
+        gstore128(so + mid_b, um, a.split);
+      }
+      prev_stored = stored;
+      so += plane_b;
+    }
+  }
+}
+
+template <int C>
+static bool launch_warp_reuse8(const WarpArgs& a, hipStream_t s) {
+  // 32-bit byte offsets into the split volume and the feature maps
+  const size_t vol = (size_t)(a.D + 2) * splitvol::padded_h(a.H) * 2 * (C / 8) * splitvol::padded_w(a.W) * 16;
+  if (vol >= (1ull << 32) || (size_t)a.H * a.W * C * 4 >= (1ull << 31)) return false;
+  constexpr int T = Warp8<C>::T, tw = Warp8<C>::P * (T / (C / 8));
+  dim3 grid((a.W + tw - 1) / tw, a.H, (a.D + kWarpDz - 1) / kWarpDz), block(T);
+  switch (a.n_src) {
+    case 1: warp_variance_reuse8_kernel<C, 1><<<grid, block, 0, s>>>(a); break;
+    case 2: warp_variance_reuse8_kernel<C, 2><<<grid, block, 0, s>>>(a); break;
+    case 3: warp_variance_reuse8_kernel<C, 3><<<grid, block, 0, s>>>(a); break;
+    default: warp_variance_reuse8_kernel<C, 4><<<grid, block, 0, s>>>(a); break;
+  }
+  return true;
+}
+
 template <int C>
 static void launch_warp_reuse(const WarpArgs& a, hipStream_t s) {
   const int tw = reuse_passes<C>() * (256 / (C / 4));
@@ -1003,7 +1308,12 @@ static int warp_variance_any(const float* ref_feature, const float* const* src_f
   if (C != 8 && C != 16 && C != 32) { set_error("svs_warp_variance: C must be 8, 16 or 32 (FeatureNet outputs)"); return SVS_ESHAPE; }
   hipStream_t s = (hipStream_t)hip_stream;
   static const char* no_reuse = getenv("SVS_WARP_REUSE_OFF");
+  static const char* which = getenv("SVS_WARP_KERNEL");            // A/B: "4" = the four-channels-per-lane producer of round 5
   if (a.split && !raw_warp && !(no_reuse && no_reuse[0] == '1')) {
+    if (!(which && which[0] == '4')) {
+      const bool ok = C == 8 ? launch_warp_reuse8<8>(a, s) : (C == 16 ? launch_warp_reuse8<16>(a, s) : launch_warp_reuse8<32>(a, s));
+      if (ok) return check_launch("svs_warp_variance_split");
+    }
     if (C == 8) launch_warp_reuse<8>(a, s);
     else if (C == 16) launch_warp_reuse<16>(a, s);
     else launch_warp_reuse<32>(a, s);

@@ -307,6 +307,16 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_full_h2_kernel(SdfFullArgs a)
   gpe1 += skip6;
 
   // ---- d/dx of the positional encoding
+  if (!GBUF) {
+    // Render instance: the 39 encoding values are formed AGAIN here instead of being held through the reverse sweep (the
+    // trunk consumed them at the skip splice; recomputing costs ~1.5 k instructions per wave, holding them made this instance
+    // spill 136 bytes per lane: rounds 3-5; now 0).  The point index passes through an empty asm so that the two evaluations
+    // are not merged back into one long-lived set of registers; same inputs, same routines: same bits.
+    int p2 = p;
+    asm volatile("" : "+v"(p2));
+    load_point(a.src, p2, x0, x1, x2);          // (the point itself too: three more registers through the sweep otherwise)
+    pe.compute(x0, x1, x2);
+  }
   float dx0 = 0.0f, dx1 = 0.0f, dx2 = 0.0f;
   // PE entry q: q<3 identity; else f=(q-3)/6, w=(q-3)%6: w<3 sin(2^f x_w) else cos(2^f x_{w-3})
   auto accum = [&](int q, float g, bool active) {
