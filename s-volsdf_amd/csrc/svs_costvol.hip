@@ -376,22 +376,23 @@ __global__ __launch_bounds__(256, NS <= 2 ? 4 : 2) void warp_variance_reuse_kern
   }
 }
 
-// ---- round 6: the same producer with EIGHT channels per lane --------------------------------------------------------------
-// The kernel above is bound by the vector ALUs' issue rate, not by memory: per (voxel, plane) it executes ~1540 lane-instructions
-// -- 2 x 250 for the two corner-table entries and 8 lanes x 130 in the blend loop, of which only ~50 are the blend, the variance
-// and the fp16 split; the rest is per-LANE overhead that does not depend on how many channels a lane carries (table reads,
-// the moved-or-not test, register copies around the conditional gathers, address arithmetic, waits) -- and 3.93 M voxels x
-// 1540 / 64 lanes x 4 cycles / (1024 SIMDs x 1.9 GHz) = 0.195 ms is what it takes at stage 1 (measured 0.195-0.22).
-// Here a lane owns one 16-byte UNIT of the split volume (8 consecutive channels): C/8 lanes per voxel, twice the channels per
-// lane and half the lanes, so the per-lane overhead is paid half as often; both stores of a lane are whole units
-// (global_store_dwordx4).  The corner tables are computed with the source index uniform per round (camera block in SGPRs,
-// the depth hypothesis loaded once for all sources).  All vector-memory operations of the blend loop are inline assembly:
-//   * the conditional re-gather writes INTO the registers that hold the corners (tied operands): no copy of the old corners,
-//     and hipcc's waitcnt pass -- which put a vmcnt(0) in front of every copy -- does not see them;
-//   * loads and stores retire from vmcnt in issue order, so the loop is skewed by one plane: a plane's two stores are issued
-//     BEHIND the next plane's gathers and `s_waitcnt vmcnt(2)` in front of the next blend waits for the gathers only.  The
-//     count is static because an active wave always issues exactly two stores per plane (waves without a voxel inside the
-//     image leave the pass before they issue anything).
+// ---- round 6: the producer re-written around its instruction count ---------------------------------------------------------
+// Per (voxel, plane) round 5's kernel executes ~1540 lane-instructions -- 2 x 250 for the two corner-table entries and 8 lanes x
+// 130 in the blend loop, of which ~50 are the blend, the variance and the fp16 split; the rest is per-lane overhead (table
+// reads, the moved-or-not test, 16 register copies around the conditional gathers, address arithmetic, waits).  This kernel:
+//   * the conditional re-gather is ONE inline-asm statement per source: exec is narrowed INSIDE it and the corner registers are
+//     tied operands of straight-line code (no copy of the old corners, no vmcnt(0) in front of one); all vector-memory operations
+//     of the blend loop are inline assembly, the loop is skewed by one plane (a plane's two stores are issued BEHIND the next
+//     plane's gathers; `s_waitcnt vmcnt(2)` in front of the next blend waits for the gathers only -- the count is static because
+//     an active wave issues exactly two stores per stored plane, and waves without a voxel inside the image leave the pass);
+//   * corner tables source-major (a wave's entries belong to one source: its camera block comes from SGPRs), the four corners
+//     without branches, the four IEEE divisions as the compiler's own sequence without its scaling / fix-up instructions where
+//     no operand needs them, the refined reciprocal shared (bit-identical quotients);
+//   * CPL channels per lane: 4 (default: round 5's shape, 16 waves per CU) or 8 (one 16-byte unit per lane, half the per-lane
+//     overhead, but 176-190 VGPRs: one 5-wave workgroup per CU -- measured slower, SVS_WARP_KERNEL=8).
+// ~1060 lane-instructions per (voxel, plane) at CPL = 4.  Measured (NOTES/r06.md): -4 % / -11 % / -6 % at the three stage
+// shapes against round 5's kernel -- a third fewer instructions buy a twentieth of the time, so the kernel is NOT bound by
+// instruction issue (this round's hypothesis), nor by where its gathers hit (XCD experiment below).
 // Same arithmetic per channel in the same order as warp_variance_kernel: the values are the float32 kernel's bit for bit
 // (tests/test_gpu_costvol.py::test_warp_variance_split_volume).
 // IEEE float32 quotients n0 / d and n1 / d as the compiler's own division sequence computes them (v_div_scale, v_rcp, the
@@ -466,10 +467,18 @@ __device__ __forceinline__ void warp_taps8(const WarpArgs& a, int v, int x, int 
   o4[3] = (vx1 && vy1) ? (r1 + xi1) * (C * 4) : 0;
 }
 
-template <int C> struct Warp8 {};
-template <> struct Warp8<32> { static constexpr int T = 320, P = 2; };   // 80 voxels per pass: TW = 160 = stage-1 width
-template <> struct Warp8<16> { static constexpr int T = 320, P = 1; };   // 160 voxels per pass
-template <> struct Warp8<8>  { static constexpr int T = 128, P = 1; };   // 128 voxels per pass (tables: 32 KiB for two sources)
+// Geometry of the producer for CPL channels per lane: T threads, P passes over x per workgroup (TW = P * T / (C / CPL) voxels).
+//   CPL = 4 (default): 256 threads, TW = 160 / 128 / 128 at C = 32 / 16 / 8 -- round 5's shape: 16 waves per CU;
+//   CPL = 8: 320 / 320 / 128 threads, TW = 160 / 160 / 128 -- half the per-lane overhead, but 176-190 VGPRs (64 of them
+//            corners): one 5-wave workgroup per CU instead of four 4-wave ones, and the kernel turns latency-bound (measured
+//            0.267 against 0.226 ms at stage 1, NOTES/r06.md): kept selectable (SVS_WARP_KERNEL=8), not the default.
+template <int C, int CPL> struct WarpCfg {};
+template <> struct WarpCfg<32, 4> { static constexpr int T = 256, P = 5; };
+template <> struct WarpCfg<16, 4> { static constexpr int T = 256, P = 2; };
+template <> struct WarpCfg<8, 4>  { static constexpr int T = 256, P = 1; };
+template <> struct WarpCfg<32, 8> { static constexpr int T = 320, P = 2; };
+template <> struct WarpCfg<16, 8> { static constexpr int T = 320, P = 1; };
+template <> struct WarpCfg<8, 8>  { static constexpr int T = 128, P = 1; };
 
 __device__ __forceinline__ void gload128(f32x4& v, unsigned off, const void* base) {
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory");
@@ -482,6 +491,10 @@ __device__ __forceinline__ void gload32(float& v, unsigned off, const void* base
 }
 __device__ __forceinline__ void gstore128(unsigned off, const i32x4& v, void* base) {
   asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(off), "v"(v), "s"(base) : "memory");
+}
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gstore64(unsigned off, const i32x2& v, void* base) {
+  asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"(off), "v"(v), "s"(base) : "memory");
 }
 // The conditional re-gather of one source's four corners (2 x 16 bytes each) for the lanes of `mask`: exec is narrowed INSIDE
 // the statement and the corner registers are tied operands of straight-line code.  (As `if (moved) f = load(...)` in C++ the
@@ -511,6 +524,25 @@ __device__ __forceinline__ void regather(f32x4 (&f)[4][2], const i32x4& o4, unsi
       : "memory");
 }
 
+__device__ __forceinline__ void regather(f32x4 (&f)[4][1], const i32x4& o4, unsigned lane_off, const void* base,
+                                         unsigned long long mask) {
+  unsigned long long saved;
+  const unsigned o0 = (unsigned)o4[0] + lane_off, o1 = (unsigned)o4[1] + lane_off, o2 = (unsigned)o4[2] + lane_off,
+                 o3 = (unsigned)o4[3] + lane_off;
+  asm volatile(
+      "s_and_saveexec_b64 %[sv], %[mask]\n\t"
+      "s_cbranch_execz 1f\n\t"
+      "global_load_dwordx4 %[a0], %[o0], %[base]\n\t"
+      "global_load_dwordx4 %[b0], %[o1], %[base]\n\t"
+      "global_load_dwordx4 %[c0], %[o2], %[base]\n\t"
+      "global_load_dwordx4 %[d0], %[o3], %[base]\n"
+      "1:\n\t"
+      "s_mov_b64 exec, %[sv]"
+      : [a0] "+v"(f[0][0]), [b0] "+v"(f[1][0]), [c0] "+v"(f[2][0]), [d0] "+v"(f[3][0]), [sv] "=&s"(saved)
+      : [o0] "v"(o0), [o1] "v"(o1), [o2] "v"(o2), [o3] "v"(o3), [base] "s"(base), [mask] "s"(mask)
+      : "memory");
+}
+
 // `s_waitcnt vmcnt(N)` + a scheduling barrier: hipcc otherwise hoists register-only instructions above an asm wait
 // (the loads are invisible to its own waitcnt pass; naming the loaded registers as operands of the wait instead makes the
 // register allocator copy every one of them around it: 80 v_mov per plane)
@@ -521,46 +553,58 @@ __device__ __forceinline__ void wait_loads() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-#ifndef SVS_WARP8_MINB
-#define SVS_WARP8_MINB 1
-#endif
-template <int C, int NS>
-__global__ __launch_bounds__(Warp8<C>::T, SVS_WARP8_MINB) void warp_variance_reuse8_kernel(WarpArgs a) {
-  constexpr int T = Warp8<C>::T, P = Warp8<C>::P;
-  constexpr int LPV = C / 8, VPP = T / LPV, TW = P * VPP, G = C / 8;
-  constexpr int S = T / TW;                         // table slices (one plane of one source) per round
-  static_assert(T % TW == 0 && kWarpDz % S == 0 && T == S * TW, "table rounds");
+template <int C, int NS, int CPL>
+__global__ __launch_bounds__((WarpCfg<C, CPL>::T), (CPL == 4 ? (NS <= 2 ? 4 : 2) : 1)) void warp_variance_reuse2_kernel(WarpArgs a) {
+  constexpr int T = WarpCfg<C, CPL>::T, P = WarpCfg<C, CPL>::P;
+  constexpr int LPV = C / CPL, VPP = T / LPV, TW = P * VPP, G = C / 8, Q = CPL / 4;
+  constexpr int kSlice = kWarpDz * TW;              // table entries of one source
+  static_assert(kSlice % 64 == 0, "a wave's table entries belong to one source");
   __shared__ __attribute__((aligned(16))) f32x4 tapw[kWarpDz][NS][TW];
   __shared__ __attribute__((aligned(16))) i32x4 tapo[kWarpDz][NS][TW];
   const int tid = threadIdx.x;
-  const int H = a.H, W = a.W, y = blockIdx.y;
-  const int xt = blockIdx.x * TW, d0 = blockIdx.z * kWarpDz;
+  const int H = a.H, W = a.W;
+  // (Experiment, -DSVS_WARP_XCD_ROWS: workgroups are dealt to the 8 XCDs round-robin in launch order, so every XCD sees every
+  // row and gathers from the WHOLE source feature maps; re-dealing the launch index (xcd_chunked) row-slowest gives XCD k
+  // the rows [k H/8, (k+1) H/8).  Measured on one box, three alternations: 0.216-0.222 against 0.213-0.220 ms at stage 1,
+  // 0.085 / 0.085 at stage 2, 0.057 against 0.061 at stage 3: the gathers are not what the kernel waits for.  Off.)
+#ifndef SVS_WARP_XCD_ROWS
+  const int y = blockIdx.y, xb = blockIdx.x, zb = blockIdx.z;
+#else
+  const unsigned gx = gridDim.x, gz = gridDim.z;
+  const unsigned lin = xcd_chunked(blockIdx.x + gx * (blockIdx.y + gridDim.y * blockIdx.z), gx * gridDim.y * gz);
+  const int y = (int)(lin / (gx * gz));
+  const unsigned rem = lin - (unsigned)y * (gx * gz);
+  const int zb = (int)(rem / gx), xb = (int)(rem - (unsigned)zb * gx);
+#endif
+  const int xt = xb * TW, d0 = zb * kWarpDz;
   const float inv_nv = 1.0f / (float)(NS + 1);
-  // ---- corner tables: thread -> voxel vx of slice `sub` of every round; round (j, v): plane j * S + sub of source v.  v is
-  // uniform (the rot / trans rows come from the kernel arguments as scalars), a plane's depth is loaded once for all sources
+  // ---- corner tables, one (source, plane, voxel) per thread and round, source-major: a wave's entries of a round belong to
+  // ONE source (its rot / trans rows are scalars); the depth hypotheses of all rounds are requested first
   {
-    const int sub = tid / TW, vx = tid - sub * TW, x = xt + vx;
-    float dep[kWarpDz / S];
+    constexpr int kRounds = (NS * kSlice + T - 1) / T;
+    float dep[kRounds];
 #pragma unroll
-    for (int j = 0; j < kWarpDz / S; ++j) {
-      const int d = d0 + j * S + sub;
-      dep[j] = (x < W && d < a.D) ? a.depth_values[((size_t)d * H + y) * W + x] : 0.0f;
+    for (int k = 0; k < kRounds; ++k) {
+      const int i = tid + T * k, v = i / kSlice, r = i - v * kSlice, dz = r / TW, vx = r - dz * TW;
+      const int x = xt + vx, d = d0 + dz;
+      dep[k] = (i < NS * kSlice && x < W && d < a.D) ? a.depth_values[((size_t)d * H + y) * W + x] : 0.0f;
     }
     const float hw = (float)(W - 1) / 2.0f, hh = (float)(H - 1) / 2.0f;
     const float rhw = refined_rcp(hw), rhh = refined_rcp(hh);
 #pragma unroll
-    for (int j = 0; j < kWarpDz / S; ++j) {
-#pragma unroll
-      for (int v = 0; v < NS; ++v) {
-        f32x4 w4; i32x4 o4;
+    for (int k = 0; k < kRounds; ++k) {
+      const int i = tid + T * k;
+      if (i >= NS * kSlice) break;
+      const int v = __builtin_amdgcn_readfirstlane(i / kSlice);
+      const int r = i - v * kSlice, dz = r / TW, vx = r - dz * TW;
+      f32x4 w4; i32x4 o4;
 #ifdef SVS_WARP8_PLAIN_TAPS
-        warp_taps<C>(a, v, x, y, d0 + j * S + sub, dep[j], w4, o4);
+      warp_taps<C>(a, v, xt + vx, y, d0 + dz, dep[k], w4, o4);
 #else
-        warp_taps8<C>(a, v, x, y, d0 + j * S + sub, dep[j], hw, rhw, hh, rhh, w4, o4);
+      warp_taps8<C>(a, v, xt + vx, y, d0 + dz, dep[k], hw, rhw, hh, rhh, w4, o4);
 #endif
-        tapw[j * S + sub][v][vx] = w4;
-        tapo[j * S + sub][v][vx] = o4;
-      }
+      tapw[dz][v][vx] = w4;
+      tapo[dz][v][vx] = o4;
     }
   }
   __syncthreads();
@@ -569,30 +613,33 @@ __global__ __launch_bounds__(Warp8<C>::T, SVS_WARP8_MINB) void warp_variance_reu
   const unsigned plane_b = (unsigned)((size_t)Hp * 2 * G * Wp * 16);     // bytes between two planes of the split volume
   const unsigned mid_b = (unsigned)(G * Wp * 16);                        // from a unit's hi piece to its mid piece
   const unsigned HW4 = (unsigned)(H * W) * 4u;
-  f32x4 f[NS][4][2];
-  float ref[8];
+  const unsigned lane_off = (unsigned)(4 * CPL * g);                     // this lane's channels inside a corner's C-vector
+  f32x4 f[NS][4][Q];
+  float ref[CPL];
   i32x4 held[NS];
   f32x4 w4s[NS];
 #pragma unroll
   for (int v = 0; v < NS; ++v)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { f[v][k][0] = f32x4{0, 0, 0, 0}; f[v][k][1] = f32x4{0, 0, 0, 0}; }
+    for (int k = 0; k < 4; ++k)
 #pragma unroll
-  for (int j = 0; j < 8; ++j) ref[j] = 0.0f;
+      for (int q = 0; q < Q; ++q) f[v][k][q] = f32x4{0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) ref[j] = 0.0f;
   // first plane of a pass: a new voxel, everything is fetched
   auto first_loads = [&](int vxn) {
     const int xc = xt + vxn < W ? xt + vxn : W - 1;                      // (lanes outside the image fetch a valid address)
-    unsigned ro = ((unsigned)(8 * g) * (unsigned)(H * W) + (unsigned)(y * W + xc)) * 4u;
+    unsigned ro = ((unsigned)(CPL * g) * (unsigned)(H * W) + (unsigned)(y * W + xc)) * 4u;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { gload32(ref[j], ro, a.ref); ro += HW4; }
+    for (int j = 0; j < CPL; ++j) { gload32(ref[j], ro, a.ref); ro += HW4; }
 #pragma unroll
     for (int v = 0; v < NS; ++v) {
       w4s[v] = tapw[0][v][vxn];
       const i32x4 o4 = tapo[0][v][vxn];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        gload128(f[v][k][0], (unsigned)o4[k] + 32u * g, a.src_hwc[v]);
-        gload128_16(f[v][k][1], (unsigned)o4[k] + 32u * g, a.src_hwc[v]);
+        gload128(f[v][k][0], (unsigned)o4[k] + lane_off, a.src_hwc[v]);
+        if (Q == 2) gload128_16(f[v][k][Q - 1], (unsigned)o4[k] + lane_off, a.src_hwc[v]);
       }
       held[v] = o4;
     }
@@ -606,14 +653,16 @@ __global__ __launch_bounds__(Warp8<C>::T, SVS_WARP8_MINB) void warp_variance_reu
     const int vx = p * VPP + vl, x = xt + vx;
     // waves without a voxel inside the image leave here (x grows with p: they were not active before either)
     if (__builtin_amdgcn_readfirstlane(xt + p * VPP + (tid & ~63) / LPV) >= W) break;
-    unsigned so = (unsigned)(splitvol::unit(d0, y, 0, g, x < W ? x : W - 1, G, Hp, Wp) * 16);
+    // CPL = 8: the lane owns unit g; CPL = 4: half (g & 1) of unit g >> 1
+    unsigned so = (unsigned)(splitvol::unit(d0, y, 0, CPL == 8 ? g : g >> 1, x < W ? x : W - 1, G, Hp, Wp) * 16) +
+                  (CPL == 8 ? 0u : 8u * (g & 1));
 #pragma unroll
     for (int dz = 0; dz < kWarpDz; ++dz) {
       const int d = d0 + dz;
       if (prev_stored) wait_loads<2>(); else wait_loads<0>();
-      f32x4 res[2];
+      f32x4 res[Q];
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
+      for (int hh = 0; hh < Q; ++hh) {
         const f32x4 rf = {ref[4 * hh], ref[4 * hh + 1], ref[4 * hh + 2], ref[4 * hh + 3]};
         f32x4 sum = rf, sq = rf * rf;
 #pragma unroll
@@ -627,9 +676,9 @@ __global__ __launch_bounds__(Warp8<C>::T, SVS_WARP8_MINB) void warp_variance_reu
         const f32x4 m = sum * inv_nv;
         res[hh] = sq * inv_nv - m * m;
       }
-      f16x4 h[2], lo[2];
+      f16x4 h[Q], lo[Q];
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh)
+      for (int hh = 0; hh < Q; ++hh)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const _Float16 q = (_Float16)res[hh][j];
@@ -645,7 +694,7 @@ __global__ __launch_bounds__(Warp8<C>::T, SVS_WARP8_MINB) void warp_variance_reu
           const i32x4 o4 = tapo[dz + 1][v][vx];
           // (a voxel's LPV lanes decide alike; a corner outside the image has offset 0 and weight 0)
           const bool moved = o4[0] != held[v][0] || o4[1] != held[v][1] || o4[2] != held[v][2] || o4[3] != held[v][3];
-          regather(f[v], o4, 32u * g, a.src_hwc[v], __builtin_amdgcn_ballot_w64(moved));
+          regather(f[v], o4, lane_off, a.src_hwc[v], __builtin_amdgcn_ballot_w64(moved));
           held[v] = o4;
         }
       } else if (p + 1 < P) {
@@ -653,11 +702,13 @@ __global__ __launch_bounds__(Warp8<C>::T, SVS_WARP8_MINB) void warp_variance_reu
       }
       const int stored = d < a.D;                                        // uniform
       if (stored && x < W) {
-        i32x4 uh, um;
-        uh = __builtin_bit_cast(i32x4, __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7));
-        um = __builtin_bit_cast(i32x4, __builtin_shufflevector(lo[0], lo[1], 0, 1, 2, 3, 4, 5, 6, 7));
-        gstore128(so, uh, a.split);
-        gstore128(so + mid_b, um, a.split);
+        if (CPL == 8) {
+          gstore128(so, __builtin_bit_cast(i32x4, __builtin_shufflevector(h[0], h[Q - 1], 0, 1, 2, 3, 4, 5, 6, 7)), a.split);
+          gstore128(so + mid_b, __builtin_bit_cast(i32x4, __builtin_shufflevector(lo[0], lo[Q - 1], 0, 1, 2, 3, 4, 5, 6, 7)), a.split);
+        } else {
+          gstore64(so, __builtin_bit_cast(i32x2, h[0]), a.split);
+          gstore64(so + mid_b, __builtin_bit_cast(i32x2, lo[0]), a.split);
+        }
       }
       prev_stored = stored;
       so += plane_b;
@@ -665,20 +716,30 @@ __global__ __launch_bounds__(Warp8<C>::T, SVS_WARP8_MINB) void warp_variance_reu
   }
 }
 
-template <int C>
-static bool launch_warp_reuse8(const WarpArgs& a, hipStream_t s) {
+template <int C, int CPL>
+static bool launch_warp_reuse2(const WarpArgs& a, hipStream_t s) {
   // 32-bit byte offsets into the split volume and the feature maps
   const size_t vol = (size_t)(a.D + 2) * splitvol::padded_h(a.H) * 2 * (C / 8) * splitvol::padded_w(a.W) * 16;
   if (vol >= (1ull << 32) || (size_t)a.H * a.W * C * 4 >= (1ull << 31)) return false;
-  constexpr int T = Warp8<C>::T, tw = Warp8<C>::P * (T / (C / 8));
+  constexpr int T = WarpCfg<C, CPL>::T, tw = WarpCfg<C, CPL>::P * (T / (C / CPL));
   dim3 grid((a.W + tw - 1) / tw, a.H, (a.D + kWarpDz - 1) / kWarpDz), block(T);
+  if (CPL == 8) {
+    if (a.n_src == 1) warp_variance_reuse2_kernel<C, 1, CPL><<<grid, block, 0, s>>>(a);
+    else if (a.n_src == 2) warp_variance_reuse2_kernel<C, 2, CPL><<<grid, block, 0, s>>>(a);
+    else return false;
+    return true;
+  }
   switch (a.n_src) {
-    case 1: warp_variance_reuse8_kernel<C, 1><<<grid, block, 0, s>>>(a); break;
-    case 2: warp_variance_reuse8_kernel<C, 2><<<grid, block, 0, s>>>(a); break;
-    case 3: warp_variance_reuse8_kernel<C, 3><<<grid, block, 0, s>>>(a); break;
-    default: warp_variance_reuse8_kernel<C, 4><<<grid, block, 0, s>>>(a); break;
+    case 1: warp_variance_reuse2_kernel<C, 1, 4><<<grid, block, 0, s>>>(a); break;
+    case 2: warp_variance_reuse2_kernel<C, 2, 4><<<grid, block, 0, s>>>(a); break;
+    case 3: warp_variance_reuse2_kernel<C, 3, 4><<<grid, block, 0, s>>>(a); break;
+    default: warp_variance_reuse2_kernel<C, 4, 4><<<grid, block, 0, s>>>(a); break;
   }
   return true;
+}
+template <int CPL>
+static bool launch_warp_reuse2_any(int C, const WarpArgs& a, hipStream_t s) {
+  return C == 8 ? launch_warp_reuse2<8, CPL>(a, s) : (C == 16 ? launch_warp_reuse2<16, CPL>(a, s) : launch_warp_reuse2<32, CPL>(a, s));
 }
 
 template <int C>
@@ -1308,10 +1369,12 @@ static int warp_variance_any(const float* ref_feature, const float* const* src_f
   if (C != 8 && C != 16 && C != 32) { set_error("svs_warp_variance: C must be 8, 16 or 32 (FeatureNet outputs)"); return SVS_ESHAPE; }
   hipStream_t s = (hipStream_t)hip_stream;
   static const char* no_reuse = getenv("SVS_WARP_REUSE_OFF");
-  static const char* which = getenv("SVS_WARP_KERNEL");            // A/B: "4" = the four-channels-per-lane producer of round 5
+  static const char* which = getenv("SVS_WARP_KERNEL");            // A/B: "8" | "5" (below)
   if (a.split && !raw_warp && !(no_reuse && no_reuse[0] == '1')) {
-    if (!(which && which[0] == '4')) {
-      const bool ok = C == 8 ? launch_warp_reuse8<8>(a, s) : (C == 16 ? launch_warp_reuse8<16>(a, s) : launch_warp_reuse8<32>(a, s));
+    // default: the round-6 producer at four channels per lane; "8": eight channels per lane; "5": round 5's kernel
+    if (!(which && which[0] == '5')) {
+      // (eight channels per lane only with up to two sources: 64 corner registers per source pair)
+      const bool ok = (which && which[0] == '8' && n_src <= 2) ? launch_warp_reuse2_any<8>(C, a, s) : launch_warp_reuse2_any<4>(C, a, s);
       if (ok) return check_launch("svs_warp_variance_split");
     }
     if (C == 8) launch_warp_reuse<8>(a, s);

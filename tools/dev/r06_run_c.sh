@@ -13,3 +13,12 @@ import json
 for n in ("new","old"):
     d=json.load(open("$O/costvol_%s.json"%n)); print(n, {k: round(v,4) for k,v in d.items() if isinstance(v,float)})
 PY
+# the eval render (the sdf_full render instance no longer spills) and the deterministic Chamfer path, one run at a time
+python tools/bench_render_eval.py 2>/dev/null | tail -1 | cut -c1-400 | tee $O/render_eval.json
+timeout 1200 python3 tools/chamfer_parity.py --steps 3000 --seeds 0,0,1,2,3 --paths hip_det --prior --out $O/chamfer_det.json > $O/chamfer_det.log 2>&1
+python - <<PY
+import json
+try:
+    d=json.load(open("$O/chamfer_det.json")); print("hip_det", [(r["seed"], r.get("overall_mm"), r.get("train_s")) for r in d["hip_det"]["runs"]])
+except Exception as e: print("chamfer_det failed", e)
+PY
