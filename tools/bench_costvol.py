@@ -71,7 +71,7 @@ def measure(dev=None):
         res[key + "_warp_GBps"] = bytes_ / t / 1e9
         res[key + "_unet_TFLOPs"] = 2 * macs[st] * D * h * w / ((res[key + "_ms"] * 1e-3 - t)) / 1e12
         rows = res.setdefault("roofline", [])
-        rows.append(dict(kernel="svs::costvol::warp_variance_reuse_kernel", stage=st + 1, bound="hbm", kernel_ms=t * 1e3,
+        rows.append(dict(kernel="svs::costvol::warp_variance_reuse2_kernel", stage=st + 1, bound="hbm", kernel_ms=t * 1e3,
                          algorithmic_bytes=bytes_, achieved=bytes_ / t / 1e9, peak=8000.0, unit="GB/s", frac=bytes_ / t / 8.0e12))
         flop = 2 * macs[st] * D * h * w
         tu = res[key + "_ms"] * 1e-3 - t
