@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-/* ABI version.  101 (round 6): svs_set_deterministic / svs_get_deterministic added.  100 -> 101 also marks the argument
+/* ABI version.  101 (round 6): svs_set_deterministic / svs_get_deterministic, svs_conv2d_mfma*, svs_featurenet_fpn2 added.  100 -> 101 also marks the argument
  * lists that changed during round 5 without a version signal: svs_sdf_bwd_a lost `a2max`, svs_sdf_bwd_b gained `ubuf`, and in
  * fp16x2 svs_sdf_outputs writes records BEHIND gbuf's 8 blocks -- size gbuf with svs_sdf_gbuf_bytes(), not svs_sdf_hbuf_bytes().
  * A host binding should refuse a library whose version differs from the one it was written against (svs_hip/lib.py does). */
@@ -378,6 +378,20 @@ size_t svs_featurenet_fpn_workspace_bytes(int base_channels, int H, int W);
 int svs_featurenet_fpn(const float* image, int H, int W, int base_channels, const float* const* weights,
                        const float* const* biases, float* workspace, float* stage1, float* stage2, float* stage3,
                        void* hip_stream);
+/* The 3x3 (stride 1; Cin in {8,16,32}) and 5x5 (stride 2; Cin in {8,16}) layers of the pyramid, Cout <= 32, on the fp16 matrix
+ * cores with two-piece fp16 operands and float32 accumulation (csrc/svs_conv2d_mfma.hip: the float32 accuracy class, 2e-7
+ * relative per layer): out (Cout,Ho,Wo) = relu?(conv2d(in (Cin,H,W), k x k, padding k / 2, stride) + bias).  The weights
+ * (Cout,Cin,k,k) float32, BatchNorm folded, are packed once per tensor by svs_conv2d_mfma_pack into svs_conv2d_mfma_wfrag_bytes
+ * bytes of MFMA A fragments.  svs_featurenet_fpn2 = svs_featurenet_fpn with an optional table of 13 fragment pointers: layer i
+ * runs on the matrix cores where wfrags[i] is not null (and the shape is supported), on the float32 kernels otherwise. */
+int svs_conv2d_mfma_supported(int Cin, int Cout, int k, int stride);
+size_t svs_conv2d_mfma_wfrag_bytes(int Cin, int Cout, int k);
+int svs_conv2d_mfma_pack(const float* weight, int Cin, int Cout, int k, void* wfrag, void* hip_stream);
+int svs_conv2d_mfma(const float* in, const void* wfrag, const float* bias, float* out, int Cin, int Cout, int H, int W, int k,
+                    int stride, int relu, void* hip_stream);
+int svs_featurenet_fpn2(const float* image, int H, int W, int base_channels, const float* const* weights,
+                        const float* const* biases, const void* const* wfrags, float* workspace, float* stage1, float* stage2,
+                        float* stage3, void* hip_stream);
 
 /* ---- a13/a14  homography warp + variance --------------------------------------------------------------------
  * homo_warping (models/CasMVSNet.py:280-315) for every source view fused with the variance aggregation of

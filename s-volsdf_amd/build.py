@@ -32,6 +32,7 @@ UNITS = {
     "svs_conv_pair.hip": [],
     "svs_conv_gemm.hip": [],
     "svs_conv2d.hip": [],
+    "svs_conv2d_mfma.hip": [],
     "svs_wgrad.hip": [],
     "svs_mlp_bwd.hip": [],
     "svs_mlp_bwd_h2.hip": [],

@@ -268,6 +268,14 @@ int launch_px(const Args& a, hipStream_t s) {
 using namespace svs;
 using namespace svs::conv2d;
 
+namespace svs {
+namespace conv2dmfma {      // csrc/svs_conv2d_mfma.hip
+bool supported(int Cin, int Cout, int k, int stride);
+int run(const float* in, const void* wfrag, const float* bias, float* out, int Cin, int Cout, int H, int W, int k, int stride,
+        int relu, hipStream_t s);
+}  // namespace conv2dmfma
+}  // namespace svs
+
 namespace {
 
 int run_conv(const float* in, const float* weight, const float* bias, const float* add, int add_upsample2, float* out,
@@ -315,8 +323,18 @@ size_t svs_featurenet_fpn_workspace_bytes(int base_channels, int H, int W) {
   return FpnBuffers(base_channels, H, W).total * sizeof(float);
 }
 
+int svs_featurenet_fpn2(const float* image, int H, int W, int base_channels, const float* const* weights, const float* const* biases,
+                        const void* const* wfrags, float* workspace, float* stage1, float* stage2, float* stage3, void* hip_stream);
+
 int svs_featurenet_fpn(const float* image, int H, int W, int base_channels, const float* const* weights, const float* const* biases,
                        float* workspace, float* stage1, float* stage2, float* stage3, void* hip_stream) {
+  return svs_featurenet_fpn2(image, H, W, base_channels, weights, biases, nullptr, workspace, stage1, stage2, stage3, hip_stream);
+}
+
+// wfrags: null, or 13 entries: wfrags[i] != null -> layer i runs on the matrix cores (svs_conv2d_mfma: the caller packed its
+// weights with svs_conv2d_mfma_pack and checked svs_conv2d_mfma_supported); null entries run on the float32 kernels
+int svs_featurenet_fpn2(const float* image, int H, int W, int base_channels, const float* const* weights, const float* const* biases,
+                        const void* const* wfrags, float* workspace, float* stage1, float* stage2, float* stage3, void* hip_stream) {
   if (!image || !weights || !biases || !workspace || !stage1 || !stage2 || !stage3 || base_channels < 1) {
     set_error("svs_featurenet_fpn: null argument"); return SVS_EINVAL;
   }
@@ -327,22 +345,29 @@ int svs_featurenet_fpn(const float* image, int H, int W, int base_channels, cons
   float* ws = workspace;
   hipStream_t s = (hipStream_t)hip_stream;
   int rc;
-#define SVS_FPN(...) if ((rc = run_conv(__VA_ARGS__)) != SVS_OK) return rc
+  // layer i on the matrix cores where the caller handed in its fragments (no addend there), else on the float32 kernels
+  auto conv = [&](int i, const float* in, const float* add, int add_up2, float* out, int Cin, int Cout, int h, int w, int k, int stride,
+                  int relu) -> int {
+    if (wfrags && wfrags[i] && !add && svs::conv2dmfma::supported(Cin, Cout, k, stride))
+      return svs::conv2dmfma::run(in, wfrags[i], biases[i], out, Cin, Cout, h, w, k, stride, relu, s);
+    return run_conv(in, weights[i], biases[i], add, add_up2, out, Cin, Cout, h, w, k, stride, relu, s);
+  };
+#define SVS_FPN(...) if ((rc = conv(__VA_ARGS__)) != SVS_OK) return rc
   // bottom-up path (models/CasMVSNet.py:343-361): conv + folded BatchNorm + ReLU
-  SVS_FPN(image, weights[0], biases[0], nullptr, 0, ws + B.c0a, 3, b, H, W, 3, 1, 1, s);
-  SVS_FPN(ws + B.c0a, weights[1], biases[1], nullptr, 0, ws + B.c0, b, b, H, W, 3, 1, 1, s);
-  SVS_FPN(ws + B.c0, weights[2], biases[2], nullptr, 0, ws + B.c1a, b, 2 * b, H, W, 5, 2, 1, s);
-  SVS_FPN(ws + B.c1a, weights[3], biases[3], nullptr, 0, ws + B.c1b, 2 * b, 2 * b, H2, W2, 3, 1, 1, s);
-  SVS_FPN(ws + B.c1b, weights[4], biases[4], nullptr, 0, ws + B.c1, 2 * b, 2 * b, H2, W2, 3, 1, 1, s);
-  SVS_FPN(ws + B.c1, weights[5], biases[5], nullptr, 0, ws + B.c2a, 2 * b, 4 * b, H2, W2, 5, 2, 1, s);
-  SVS_FPN(ws + B.c2a, weights[6], biases[6], nullptr, 0, ws + B.c2b, 4 * b, 4 * b, H4, W4, 3, 1, 1, s);
-  SVS_FPN(ws + B.c2b, weights[7], biases[7], nullptr, 0, ws + B.c2, 4 * b, 4 * b, H4, W4, 3, 1, 1, s);
+  SVS_FPN(0, image, nullptr, 0, ws + B.c0a, 3, b, H, W, 3, 1, 1);
+  SVS_FPN(1, ws + B.c0a, nullptr, 0, ws + B.c0, b, b, H, W, 3, 1, 1);
+  SVS_FPN(2, ws + B.c0, nullptr, 0, ws + B.c1a, b, 2 * b, H, W, 5, 2, 1);
+  SVS_FPN(3, ws + B.c1a, nullptr, 0, ws + B.c1b, 2 * b, 2 * b, H2, W2, 3, 1, 1);
+  SVS_FPN(4, ws + B.c1b, nullptr, 0, ws + B.c1, 2 * b, 2 * b, H2, W2, 3, 1, 1);
+  SVS_FPN(5, ws + B.c1, nullptr, 0, ws + B.c2a, 2 * b, 4 * b, H2, W2, 5, 2, 1);
+  SVS_FPN(6, ws + B.c2a, nullptr, 0, ws + B.c2b, 4 * b, 4 * b, H4, W4, 3, 1, 1);
+  SVS_FPN(7, ws + B.c2b, nullptr, 0, ws + B.c2, 4 * b, 4 * b, H4, W4, 3, 1, 1);
   // top-down path (:413-431): the nearest x2 up-sampling is an index shift in the lateral convolution's epilogue
-  SVS_FPN(ws + B.c2, weights[8], biases[8], nullptr, 0, stage1, 4 * b, 4 * b, H4, W4, 1, 1, 0, s);               // out1
-  SVS_FPN(ws + B.c1, weights[9], biases[9], ws + B.c2, 1, ws + B.f1, 2 * b, 4 * b, H2, W2, 1, 1, 0, s);          // inner1 + up(c2)
-  SVS_FPN(ws + B.f1, weights[10], biases[10], nullptr, 0, stage2, 4 * b, 2 * b, H2, W2, 3, 1, 0, s);             // out2
-  SVS_FPN(ws + B.c0, weights[11], biases[11], ws + B.f1, 1, ws + B.f2, b, 4 * b, H, W, 1, 1, 0, s);              // inner2 + up(f1)
-  SVS_FPN(ws + B.f2, weights[12], biases[12], nullptr, 0, stage3, 4 * b, b, H, W, 3, 1, 0, s);                   // out3
+  SVS_FPN(8, ws + B.c2, nullptr, 0, stage1, 4 * b, 4 * b, H4, W4, 1, 1, 0);               // out1
+  SVS_FPN(9, ws + B.c1, ws + B.c2, 1, ws + B.f1, 2 * b, 4 * b, H2, W2, 1, 1, 0);          // inner1 + up(c2)
+  SVS_FPN(10, ws + B.f1, nullptr, 0, stage2, 4 * b, 2 * b, H2, W2, 3, 1, 0);              // out2
+  SVS_FPN(11, ws + B.c0, ws + B.f1, 1, ws + B.f2, b, 4 * b, H, W, 1, 1, 0);               // inner2 + up(f1)
+  SVS_FPN(12, ws + B.f2, nullptr, 0, stage3, 4 * b, b, H, W, 3, 1, 0);                    // out3
 #undef SVS_FPN
   return SVS_OK;
 }

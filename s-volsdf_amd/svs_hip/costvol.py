@@ -306,6 +306,54 @@ def conv2d(x, weight, bias=None, add=None, add_upsample2=False, stride=1, relu=F
     return out
 
 
+_W2D_MFMA_CACHE = {}
+
+
+def conv2d_mfma_supported(Cin, Cout, k, stride):
+    return bool(_lib.load().svs_conv2d_mfma_supported(int(Cin), int(Cout), int(k), int(stride)))
+
+
+def conv2d_mfma_frag(weight):
+    """(Cout,Cin,k,k) float32 -> the fp16 hi / mid MFMA A fragments svs_conv2d_mfma reads (packed on the device by
+    svs_conv2d_mfma_pack; cached per weight tensor: address + version)."""
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), weight.device)
+    hit = _W2D_MFMA_CACHE.get(key)
+    if hit is not None:
+        return hit[0]
+    if len(_W2D_MFMA_CACHE) > 64:
+        _W2D_MFMA_CACHE.clear()
+    L = _lib.load()
+    Cout, Cin, k, _ = weight.shape
+    w = _f32(weight.detach())
+    frag = torch.empty(L.svs_conv2d_mfma_wfrag_bytes(Cin, Cout, k) // 2, dtype=torch.float16, device=weight.device)
+    _lib.check(L.svs_conv2d_mfma_pack(_ptr(w), Cin, Cout, k, _ptr(frag), _stream()), "svs_conv2d_mfma_pack")
+    _W2D_MFMA_CACHE[key] = (frag, weight, w)               # keep `weight` alive: the key holds its address
+    return frag
+
+
+def conv2d_mfma(x, weight, bias=None, stride=1, relu=False):
+    """A FeatureNet 3x3 (stride 1) / 5x5 (stride 2) convolution on the matrix cores (csrc/svs_conv2d_mfma.hip): x (Cin,H,W),
+    weight (Cout,Cin,k,k), padding k // 2 -> (Cout,Ho,Wo) = relu?(conv + bias), float32 class (fp16x2)."""
+    L = _lib.load()
+    x = _f32(x)
+    Cin, H, W = x.shape
+    Cout, cin_w, k, k2 = weight.shape
+    if cin_w != Cin or k != k2 or not conv2d_mfma_supported(Cin, Cout, k, stride):
+        raise ValueError("shape not supported by svs_conv2d_mfma")
+    pad = k // 2
+    out = torch.empty(Cout, (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1, device=x.device)
+    bias = _f32(bias) if bias is not None else None
+    _lib.check(L.svs_conv2d_mfma(_ptr(x), _ptr(conv2d_mfma_frag(weight)), _ptr(bias), _ptr(out), Cin, Cout, H, W, k, stride,
+                                 int(bool(relu)), _stream()), "svs_conv2d_mfma")
+    return out
+
+
+_FPN_MFMA = os.environ.get("SVS_FPN_MFMA", "1") != "0"     # A/B: 0 = every layer of the pyramid on the float32 vector kernels
+# (layer index -> stride) of svs_featurenet_fpn's 13 convolutions
+_FPN_STRIDES = (1, 1, 2, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1)
+_FPN_ADDEND = (9, 11)                                      # the lateral 1x1 convolutions take an addend: float32 kernels
+
+
 class FeatureNetFpn:
     """The 13 convolutions of the 'fpn' FeatureNet enqueued by ONE library call (svs_featurenet_fpn): the per-launch host
     cost of going through Python 13 times was as large as the kernels' run time."""
@@ -323,7 +371,12 @@ class FeatureNetFpn:
         if key != self._tables_key:
             packed = [conv2d_pack(w) for w, _ in layers]
             biases = [None if b is None else _f32(b) for _, b in layers]
-            self._tables = (_ptr_array(packed), _ptr_array(biases), packed, biases, layers)
+            # the 3x3 / 5x5 layers with 8 / 16 / 32 input channels run on the matrix cores (svs_conv2d_mfma)
+            # (not conv0.1, 8 -> 8 at full resolution: 15.5 us there against 13.4 on the vector kernel -- a quarter-full M tile)
+            frags = [conv2d_mfma_frag(w) if (_FPN_MFMA and i not in _FPN_ADDEND and w.shape[2] > 1 and not (w.shape[1] <= 8 and w.shape[2] == 3)
+                                             and conv2d_mfma_supported(w.shape[1], w.shape[0], w.shape[2], _FPN_STRIDES[i])) else None
+                     for i, (w, _) in enumerate(layers)]
+            self._tables = (_ptr_array(packed), _ptr_array(biases), packed, biases, layers, _ptr_array(frags), frags)
             self._tables_key = key
         return self._tables
 
@@ -340,12 +393,13 @@ class FeatureNetFpn:
         if self._ws_key != (H, W, dev):
             self._ws = torch.empty(L.svs_featurenet_fpn_workspace_bytes(b, H, W) // 4, device=dev)
             self._ws_key = (H, W, dev)
-        wt, bt = self.tables(layers)[:2]
+        tb = self.tables(layers)
+        wt, bt, ft = tb[0], tb[1], tb[5]
         s1 = torch.empty(4 * b, H // 4, W // 4, device=dev)
         s2 = torch.empty(2 * b, H // 2, W // 2, device=dev)
         s3 = torch.empty(b, H, W, device=dev)
-        _lib.check(L.svs_featurenet_fpn(_ptr(image), H, W, b, wt, bt, _ptr(self._ws), _ptr(s1), _ptr(s2), _ptr(s3), _stream()),
-                   "svs_featurenet_fpn")
+        _lib.check(L.svs_featurenet_fpn2(_ptr(image), H, W, b, wt, bt, ft, _ptr(self._ws), _ptr(s1), _ptr(s2), _ptr(s3), _stream()),
+                   "svs_featurenet_fpn2")
         return s1, s2, s3
 
 

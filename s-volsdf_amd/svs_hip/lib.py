@@ -102,6 +102,11 @@ SIGNATURES = {
     "svs_conv2d": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "svs_featurenet_fpn_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "svs_featurenet_fpn": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "svs_featurenet_fpn2": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "svs_conv2d_mfma_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "svs_conv2d_mfma_wfrag_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "svs_conv2d_mfma_pack": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
+    "svs_conv2d_mfma": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "svs_chw_to_hwc": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "svs_fuse_mats_per_src": (c_int, []),
     "svs_cloud_grid_bytes": (c_size_t, [c_int]),

@@ -408,6 +408,38 @@ def test_feature_net_hip(dev, golden_dir, hw):
     assert net(x)["stage1"].requires_grad
 
 
+@pytest.mark.parametrize("k,stride,Cin,Cout,hw", [(3, 1, 16, 16, (37, 70)), (3, 1, 32, 32, (24, 132)), (3, 1, 32, 16, (16, 64)),
+                                                   (3, 1, 32, 8, (9, 33)), (3, 1, 8, 8, (21, 40)), (3, 1, 32, 21, (13, 47)),
+                                                   (5, 2, 16, 32, (38, 70)), (5, 2, 8, 16, (25, 131)), (5, 2, 16, 9, (12, 36)),
+                                                   (3, 1, 32, 8, (262, 530)), (3, 1, 16, 16, (259, 545))])      # (8 x 32 windows)
+def test_conv2d_mfma_single_layer(dev, k, stride, Cin, Cout, hw):
+    """svs_conv2d_mfma (FeatureNet's wide layers on the fp16x2 matrix-core path, csrc/svs_conv2d_mfma.hip) against a float64
+    torch convolution on ragged sizes (windows cut by both image edges, odd sizes under stride 2, Cout not a multiple of 16):
+    3e-6 of the output scale -- the float32 class (two 11-bit pieces per operand, float32 accumulation) -- and against the
+    float32 vector kernel it replaces in the pyramid."""
+    from svs_hip import costvol
+    H, W = hw
+    rs = np.random.default_rng(100 * k + Cin + Cout)
+    x = rs.standard_normal((Cin, H, W)).astype(F32)
+    w = (rs.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(F32)
+    b = rs.standard_normal(Cout).astype(F32)
+    assert costvol.conv2d_mfma_supported(Cin, Cout, k, stride)
+    for relu in (True, False):
+        ref = torch.nn.functional.conv2d(torch.from_numpy(x).double()[None], torch.from_numpy(w).double(), torch.from_numpy(b).double(),
+                                         stride=stride, padding=k // 2)[0]
+        ref = (ref.clamp(min=0) if relu else ref).numpy()
+        got = costvol.conv2d_mfma(G(x, dev), G(w, dev), G(b, dev), stride=stride, relu=relu).cpu().numpy()
+        assert got.shape == ref.shape
+        np.testing.assert_allclose(got, ref, atol=3e-6 * np.abs(ref).max())
+        old = costvol.conv2d(G(x, dev), G(w, dev), G(b, dev), stride=stride, relu=relu).cpu().numpy()
+        np.testing.assert_allclose(got, old, atol=2e-5)
+    got = costvol.conv2d_mfma(G(x, dev), G(w, dev), None, stride=stride, relu=False).cpu().numpy()      # no bias
+    ref = torch.nn.functional.conv2d(torch.from_numpy(x).double()[None], torch.from_numpy(w).double(), None, stride=stride,
+                                     padding=k // 2)[0].numpy()
+    np.testing.assert_allclose(got, ref, atol=3e-6 * np.abs(ref).max())
+    assert not costvol.conv2d_mfma_supported(3, 8, 3, 1) and not costvol.conv2d_mfma_supported(32, 40, 3, 1)
+
+
 @pytest.mark.parametrize("k,stride", [(1, 1), (1, 2), (3, 1), (3, 2), (5, 1), (5, 2)])
 def test_conv2d_single_layer(dev, k, stride):
     """svs_conv2d alone (the entry the fused pyramid call is built from) against torch.nn.functional.conv2d on the CPU:
