@@ -549,6 +549,7 @@ __device__ __forceinline__ void regather(f32x4 (&f)[4][1], const i32x4& o4, unsi
 template <int N>
 __device__ __forceinline__ void wait_loads() {
   if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
@@ -653,13 +654,17 @@ __global__ __launch_bounds__((WarpCfg<C, CPL>::T), (CPL == 4 ? (NS <= 2 ? 4 : 2)
     const int vx = p * VPP + vl, x = xt + vx;
     // waves without a voxel inside the image leave here (x grows with p: they were not active before either)
     if (__builtin_amdgcn_readfirstlane(xt + p * VPP + (tid & ~63) / LPV) >= W) break;
-    // CPL = 8: the lane owns unit g; CPL = 4: half (g & 1) of unit g >> 1
-    unsigned so = (unsigned)(splitvol::unit(d0, y, 0, CPL == 8 ? g : g >> 1, x < W ? x : W - 1, G, Hp, Wp) * 16) +
-                  (CPL == 8 ? 0u : 8u * (g & 1));
+    // CPL = 8: the lane owns unit g; CPL = 4: half (g & 1) of unit g >> 1 (`so` = the unit's hi piece)
+    unsigned so = (unsigned)(splitvol::unit(d0, y, 0, CPL == 8 ? g : g >> 1, x < W ? x : W - 1, G, Hp, Wp) * 16);
 #pragma unroll
     for (int dz = 0; dz < kWarpDz; ++dz) {
       const int d = d0 + dz;
-      if (prev_stored) wait_loads<2>(); else wait_loads<0>();
+#if defined(SVS_WARP_STORE128)
+      constexpr int kStores = CPL == 8 ? 2 : 1;
+#else
+      constexpr int kStores = 2;                         // vector-memory stores an active wave issues per stored plane
+#endif
+      if (prev_stored) wait_loads<kStores>(); else wait_loads<0>();
       f32x4 res[Q];
 #pragma unroll
       for (int hh = 0; hh < Q; ++hh) {
@@ -706,8 +711,20 @@ __global__ __launch_bounds__((WarpCfg<C, CPL>::T), (CPL == 4 ? (NS <= 2 ? 4 : 2)
           gstore128(so, __builtin_bit_cast(i32x4, __builtin_shufflevector(h[0], h[Q - 1], 0, 1, 2, 3, 4, 5, 6, 7)), a.split);
           gstore128(so + mid_b, __builtin_bit_cast(i32x4, __builtin_shufflevector(lo[0], lo[Q - 1], 0, 1, 2, 3, 4, 5, 6, 7)), a.split);
         } else {
-          gstore64(so, __builtin_bit_cast(i32x2, h[0]), a.split);
-          gstore64(so + mid_b, __builtin_bit_cast(i32x2, lo[0]), a.split);
+#ifndef SVS_WARP_STORE128
+          gstore64(so + 8u * (g & 1), __builtin_bit_cast(i32x2, h[0]), a.split);
+          gstore64(so + 8u * (g & 1) + mid_b, __builtin_bit_cast(i32x2, lo[0]), a.split);
+#else
+          // (experiment, -DSVS_WARP_STORE128: the two lanes of a unit swap halves (DPP quad_perm [1,0,3,2]), the even lane stores
+          // the whole hi unit, the odd lane the whole mid unit -- ONE 16-byte store per lane and plane instead of two 8-byte
+          // ones.  Measured on one box, three alternations: 0.228-0.240 against 0.225-0.239 ms at stage 1, 0.090 / 0.088,
+          // 0.063 / 0.062: the number of store instructions is not what the kernel waits for either.)
+          const i32x2 hv = __builtin_bit_cast(i32x2, h[0]), lv = __builtin_bit_cast(i32x2, lo[0]);
+          const i32x2 ph = {__builtin_amdgcn_mov_dpp(hv[0], 0xB1, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(hv[1], 0xB1, 0xF, 0xF, true)};
+          const i32x2 pl = {__builtin_amdgcn_mov_dpp(lv[0], 0xB1, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(lv[1], 0xB1, 0xF, 0xF, true)};
+          const i32x4 u = (g & 1) ? i32x4{pl[0], pl[1], lv[0], lv[1]} : i32x4{hv[0], hv[1], ph[0], ph[1]};
+          gstore128(so + ((g & 1) ? mid_b : 0u), u, a.split);
+#endif
         }
       }
       prev_stored = stored;

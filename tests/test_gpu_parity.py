@@ -514,6 +514,8 @@ def test_model_forward_r1024_train(dev, golden_dir):
     # same bin as the kernels (tests/test_oracle_golden.py::test_forward_r1024_train) -- moves the depth by 4e-3: one ray here
     dd = np.abs(out["depth_values"] - g["depth_values"]).reshape(-1)
     assert (dd > 2e-4).sum() <= 2 and dd.max() < 1e-2, np.sort(dd)[-4:]
+    # ... and ONLY on rays that miss the surface (reference depth = the far bound, 5): every ray that hits it holds 2e-4
+    assert np.all(g["depth_values"].reshape(-1)[dd > 2e-4] > 4.5), g["depth_values"].reshape(-1)[dd > 2e-4]
     np.testing.assert_allclose(out["grad_theta"][:1024], g["grad_theta"][:1024], atol=2e-4)     # the uniform eikonal points
     np.testing.assert_allclose(out["grad_theta"][1024:], g["grad_theta"][1024:], atol=5e-3)     # at the sampler's extra depths
     rays = ~moved.any(1)         # (a moved sample changes its neighbours' interval lengths, hence their weights)

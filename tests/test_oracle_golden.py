@@ -265,6 +265,8 @@ def test_forward_r1024_train(golden_dir):
     assert (np.abs(out["rgb_values"] - g["rgb_values"]).max(-1) > 5e-6).sum() <= 4
     dd = np.abs(out["depth_values"] - g["depth_values"]).reshape(-1)      # (that ray misses the surface: depth 5, 4e-3 off)
     assert (dd > 1e-4).sum() <= 2 and dd.max() < 1e-2, (np.sort(dd)[-4:])
+    # ... and ONLY on rays that miss the surface (the reference's depth there is the far bound, 5): no ray that hits it is excused
+    assert np.all(g["depth_values"].reshape(-1)[dd > 1e-4] > 4.5), g["depth_values"].reshape(-1)[dd > 1e-4]
     np.testing.assert_allclose(out["grad_theta"][:1024], g["grad_theta"][:1024], atol=1e-4)
     np.testing.assert_allclose(out["grad_theta"], g["grad_theta"], atol=2e-3)
     ev = int(g["every"])
