@@ -389,6 +389,13 @@ size_t svs_conv2d_mfma_wfrag_bytes(int Cin, int Cout, int k);
 int svs_conv2d_mfma_pack(const float* weight, int Cin, int Cout, int k, void* wfrag, void* hip_stream);
 int svs_conv2d_mfma(const float* in, const void* wfrag, const float* bias, float* out, int Cin, int Cout, int H, int W, int k,
                     int stride, int relu, void* hip_stream);
+/* The lateral step of the FPN (models/CasMVSNet.py:425-431) fused into the 3x3 layer behind it (out3): the layer's 32-channel
+ * input X[c][y][x] = sum_ci W1[c][ci] lat_in[ci][y][x] + lat_bias[c] + lat_add[c][y / 2][x / 2] (ci < 8) is formed while the
+ * kernel converts its input windows -- the float32 1x1 kernel's operations in its order, bit for bit -- and never exists in
+ * memory.  lat_weight: (32,8,1,1) in svs_conv2d's packed layout; wfrag: (Cout <= 16, 32, 3, 3) packed by svs_conv2d_mfma_pack;
+ * H, W even.  svs_featurenet_fpn2 uses it for inner2 + out3 when base_channels = 8 and wfrags[12] is given. */
+int svs_conv2d_mfma_lateral(const float* lat_in, const float* lat_weight, const float* lat_bias, const float* lat_add,
+                            const void* wfrag, const float* bias, float* out, int Cout, int H, int W, int relu, void* hip_stream);
 int svs_featurenet_fpn2(const float* image, int H, int W, int base_channels, const float* const* weights,
                         const float* const* biases, const void* const* wfrags, float* workspace, float* stage1, float* stage2,
                         float* stage3, void* hip_stream);

@@ -13,6 +13,7 @@
 // That direct kernel now serves the 1x1 lateral convolutions only (memory-bound); 3x3 / 5x5 run on the LDS-tiled kernel
 // below.  svs_featurenet_fpn enqueues the whole pyramid (13 launches) from one call.
 #include "svs_common.h"
+#include <cstdlib>
 
 namespace svs {
 namespace conv2d {
@@ -273,6 +274,8 @@ namespace conv2dmfma {      // csrc/svs_conv2d_mfma.hip
 bool supported(int Cin, int Cout, int k, int stride);
 int run(const float* in, const void* wfrag, const float* bias, float* out, int Cin, int Cout, int H, int W, int k, int stride,
         int relu, hipStream_t s);
+int run_lateral(const float* lat_in, const float* lat_w, const float* lat_b, const float* lat_add, const void* wfrag,
+                const float* bias, float* out, int Cout, int H, int W, int relu, hipStream_t s);
 }  // namespace conv2dmfma
 }  // namespace svs
 
@@ -366,8 +369,17 @@ int svs_featurenet_fpn2(const float* image, int H, int W, int base_channels, con
   SVS_FPN(8, ws + B.c2, nullptr, 0, stage1, 4 * b, 4 * b, H4, W4, 1, 1, 0);               // out1
   SVS_FPN(9, ws + B.c1, ws + B.c2, 1, ws + B.f1, 2 * b, 4 * b, H2, W2, 1, 1, 0);          // inner1 + up(c2)
   SVS_FPN(10, ws + B.f1, nullptr, 0, stage2, 4 * b, 2 * b, H2, W2, 3, 1, 0);              // out2
-  SVS_FPN(11, ws + B.c0, ws + B.f1, 1, ws + B.f2, b, 4 * b, H, W, 1, 1, 0);               // inner2 + up(f1)
-  SVS_FPN(12, ws + B.f2, nullptr, 0, stage3, 4 * b, b, H, W, 3, 1, 0);                    // out3
+  // inner2 + up(f1), then out3.  With out3 on the matrix cores (b = 8) the lateral step is formed while out3 converts its
+  // input window and its 4b-channel full-resolution result never exists in memory (42 MB written and read back at 512 x 640:
+  // 22.7 + 30.8 us as two launches, NOTES/r06.md); SVS_FPN_FUSE_LATERAL=0: two launches
+  static const bool fuse_env = [] { const char* e = getenv("SVS_FPN_FUSE_LATERAL"); return !(e && e[0] == '0'); }();
+  if (fuse_env && b == 8 && wfrags && wfrags[12] && svs::conv2dmfma::supported(4 * b, b, 3, 1)) {
+    if ((rc = svs::conv2dmfma::run_lateral(ws + B.c0, weights[11], biases[11], ws + B.f1, wfrags[12], biases[12], stage3, b, H, W, 0, s)) != SVS_OK)
+      return rc;
+  } else {
+    SVS_FPN(11, ws + B.c0, ws + B.f1, 1, ws + B.f2, b, 4 * b, H, W, 1, 1, 0);             // inner2 + up(f1)
+    SVS_FPN(12, ws + B.f2, nullptr, 0, stage3, 4 * b, b, H, W, 3, 1, 0);                  // out3
+  }
 #undef SVS_FPN
   return SVS_OK;
 }

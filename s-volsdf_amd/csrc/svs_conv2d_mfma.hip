@@ -28,18 +28,28 @@ struct Args {
   float* out;           // (Cout, Ho, Wo)
   int Cout, H, W, Ho, Wo, relu;
   int tiles_x, tiles;   // windows per output row of windows, windows in all
+  // LAT instances: `in` is not read; the layer's input is formed while the halo is converted (the FPN's lateral step, models/
+  // CasMVSNet.py:425-431: intra = inner(conv_k) + nearest-up2(intra_coarser)) and never exists in memory:
+  //   input[c][y][x] = sum_ci lat_w[c][ci] * lat_in[ci][y][x] + lat_b[c] + lat_add[c][y / 2][x / 2]
+  const float* lat_in;  // (8, H, W)
+  const float* lat_w;   // the 1x1 weights in svs_conv2d's packed layout [Cin / 8][8][1][1][8]: W[c][ci] = lat_w[(c / 8) * 64 + ci * 8 + c % 8]
+  const float* lat_b;   // [Cin] or nullptr
+  const float* lat_add; // (Cin, H / 2, W / 2)
 };
 
 template <int CIN, int K, int S> constexpr int k_steps() { return (K * K * CIN + 31) / 32; }
 template <int CIN> constexpr int pitch() { return CIN == 8 ? 16 : (CIN == 16 ? 48 : 80); }
 template <int K, int S, int RW> constexpr int halo_y() { return (kWaves * RW - 1) * S + K; }
 template <int K, int S> constexpr int halo_x() { return (kTX - 1) * S + K; }
-template <int CIN, int K, int S, int RW> constexpr int lds_bytes() { return 2 * halo_y<K, S, RW>() * halo_x<K, S>() * pitch<CIN>(); }
+template <int CIN, int K, int S, int RW> constexpr int lds_bytes() {
+  return 2 * halo_y<K, S, RW>() * halo_x<K, S>() * pitch<CIN>() + (CIN * 8 + CIN) * 4;      // + the lateral weights of LAT instances
+}
 
 // RW: output rows per wave (2: an 8 x 32 window -- 1.33 instead of 1.6 input pixels converted per output pixel at 3x3 --
 // for the layers at full image resolution, where the conversion of the halo is most of the kernel)
-template <int CIN, int K, int S, int MT, int RW>
+template <int CIN, int K, int S, int MT, int RW, bool LAT = false>
 __global__ __launch_bounds__(256, 1) void conv2d_mfma_kernel(Args a) {
+  static_assert(!LAT || CIN == 32, "the fused lateral step feeds a 32-channel layer from 8 channels");
   constexpr int KS = k_steps<CIN, K, S>();
   constexpr int PITCH = pitch<CIN>();
   constexpr int kTY = kWaves * RW;
@@ -59,6 +69,14 @@ __global__ __launch_bounds__(256, 1) void conv2d_mfma_kernel(Args a) {
       wh[mt][s] = __builtin_bit_cast(f16x8, a.wfrag[((mt * KS + s) * 2) * 64 + lane]);
       wm[mt][s] = __builtin_bit_cast(f16x8, a.wfrag[((mt * KS + s) * 2 + 1) * 64 + lane]);
     }
+  // ---- LAT: the lateral step's weights [c][ci] and biases behind the window in LDS (read back as broadcasts: held in registers
+  // they cost the kernel two thirds of its occupancy)
+  float* latw = reinterpret_cast<float*>(smem + 2 * PIECE);
+  if (LAT) {
+    for (int i = tid; i < CIN * 8; i += 256) { const int c = i >> 3, ci = i & 7; latw[i] = a.lat_w[(c >> 3) * 64 + ci * 8 + (c & 7)]; }
+    for (int i = tid; i < CIN; i += 256) latw[CIN * 8 + i] = a.lat_b ? a.lat_b[i] : 0.0f;
+    __syncthreads();
+  }
   // ---- the B-fragment address of k-step s inside the halo window: (tap, channel group) of this lane's 8 elements
   int boff[KS];
 #pragma unroll
@@ -76,26 +94,63 @@ __global__ __launch_bounds__(256, 1) void conv2d_mfma_kernel(Args a) {
     const int xo0 = tx * kTX, yo0 = ty * kTY;
     const int xi0 = xo0 * S - PAD, yi0 = yo0 * S - PAD;
     // ---- the input halo window -> channel-last fp16 hi / mid pieces (zero outside the image)
+#pragma unroll 1
     for (int p = tid; p < HY * HX; p += 256) {
       const int ly = p / HX, lx = p - ly * HX;
       const int gy = yi0 + ly, gx = xi0 + lx;
       const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-      const float* g = a.in + (ok ? (size_t)gy * a.W + gx : 0);
-      float v[CIN];
-#pragma unroll
-      for (int c = 0; c < CIN; ++c) v[c] = ok ? g[(size_t)c * HW] : 0.0f;
       unsigned char* ph = smem + p * PITCH;
-#pragma unroll
-      for (int c8 = 0; c8 < CIN / 8; ++c8) {
+      auto put = [&](int c8, const float (&v)[8]) {
         f16x8 h, m;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const _Float16 hh = (_Float16)v[8 * c8 + j];
+          const _Float16 hh = (_Float16)v[j];
           h[j] = hh;
-          m[j] = (_Float16)(v[8 * c8 + j] - (float)hh);
+          m[j] = (_Float16)(v[j] - (float)hh);
         }
         *reinterpret_cast<f16x8*>(ph + 16 * c8) = h;
         *reinterpret_cast<f16x8*>(ph + PIECE + 16 * c8) = m;
+      };
+      if (LAT) {
+        // the same operations in the same order as the float32 1x1 kernel it replaces (svs_conv2d.hip: fma chain over the
+        // input channels from 0, + bias, + addend): the values are the materialised tensor's bit for bit.  Eight output
+        // channels at a time (their addends requested together), so that a pixel's 40 loads are not all live at once
+        const float* g = a.lat_in + (ok ? (size_t)gy * a.W + gx : 0);
+        const float* ad = a.lat_add + (ok ? (size_t)(gy >> 1) * (a.W >> 1) + (gx >> 1) : 0);
+        const size_t HW4 = (size_t)(a.H >> 1) * (a.W >> 1);
+        float c8[8];
+#pragma unroll
+        for (int ci = 0; ci < 8; ++ci) c8[ci] = ok ? g[(size_t)ci * HW] : 0.0f;
+#pragma unroll 1
+        for (int q = 0; q < CIN / 8; ++q) {
+          float add8[8], v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) add8[j] = ok ? ad[(size_t)(8 * q + j) * HW4] : 0.0f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int c = 8 * q + j;
+            const f32x4v w0 = *reinterpret_cast<const f32x4v*>(latw + 8 * c), w1 = *reinterpret_cast<const f32x4v*>(latw + 8 * c + 4);
+            float acc = 0.0f;
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci) acc = __builtin_fmaf(w0[ci], c8[ci], acc);
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci) acc = __builtin_fmaf(w1[ci], c8[4 + ci], acc);
+            float r = acc + latw[CIN * 8 + c];
+            r += add8[j];
+            v[j] = ok ? r : 0.0f;                    // zero padding outside the image
+          }
+          put(q, v);
+        }
+      } else {
+        const float* g = a.in + (ok ? (size_t)gy * a.W + gx : 0);
+        float v[CIN];
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) v[c] = ok ? g[(size_t)c * HW] : 0.0f;
+#pragma unroll
+        for (int c8 = 0; c8 < CIN / 8; ++c8) {
+          const float w8[8] = {v[8 * c8], v[8 * c8 + 1], v[8 * c8 + 2], v[8 * c8 + 3], v[8 * c8 + 4], v[8 * c8 + 5], v[8 * c8 + 6], v[8 * c8 + 7]};
+          put(c8, w8);
+        }
       }
     }
     __syncthreads();
@@ -186,16 +241,16 @@ __global__ void pack_kernel(const float* __restrict__ w, int Cout, int Cin, int 
   frag[base + 64 * 8] = (_Float16)(v - (float)h);
 }
 
-template <int CIN, int K, int S, int MT, int RW>
+template <int CIN, int K, int S, int MT, int RW, bool LAT = false>
 int launch(Args a, hipStream_t s) {
   constexpr int lds = lds_bytes<CIN, K, S, RW>();
   a.tiles = a.tiles_x * ((a.Ho + kWaves * RW - 1) / (kWaves * RW));
-  static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_mfma_kernel<CIN, K, S, MT, RW>),
+  static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_mfma_kernel<CIN, K, S, MT, RW, LAT>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) { set_error("svs_conv2d_mfma: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
   // two workgroups per CU where the registers allow it; a workgroup walks its windows with the weights in registers
   const int grid = a.tiles < 512 ? a.tiles : 512;
-  conv2d_mfma_kernel<CIN, K, S, MT, RW><<<grid, 256, lds, s>>>(a);
+  conv2d_mfma_kernel<CIN, K, S, MT, RW, LAT><<<grid, 256, lds, s>>>(a);
   return check_launch("svs_conv2d_mfma");
 }
 
@@ -206,9 +261,22 @@ bool supported(int Cin, int Cout, int k, int stride) {
   return false;
 }
 
+// the 3x3 layer (32 -> Cout <= 16) behind a lateral step whose result is formed on the fly (Args::lat_*): H, W even
+int run_lateral(const float* lat_in, const float* lat_w, const float* lat_b, const float* lat_add, const void* wfrag,
+                const float* bias, float* out, int Cout, int H, int W, int relu, hipStream_t s) {
+  if (Cout < 1 || Cout > 16 || (H & 1) || (W & 1)) { set_error("svs_conv2d_mfma: lateral fusion needs Cout <= 16 and even H, W"); return SVS_ESHAPE; }
+  Args a;
+  a.in = nullptr; a.wfrag = reinterpret_cast<const uint4*>(wfrag); a.bias = bias; a.out = out; a.Cout = Cout; a.H = H; a.W = W;
+  a.relu = relu; a.Ho = H; a.Wo = W; a.tiles_x = (W + kTX - 1) / kTX; a.tiles = 0;
+  a.lat_in = lat_in; a.lat_w = lat_w; a.lat_b = lat_b; a.lat_add = lat_add;
+  const bool tall = (long long)a.tiles_x * ((a.Ho + 3) / 4) > 1024;
+  return tall ? launch<32, 3, 1, 1, 2, true>(a, s) : launch<32, 3, 1, 1, 1, true>(a, s);
+}
+
 int run(const float* in, const void* wfrag, const float* bias, float* out, int Cin, int Cout, int H, int W, int k, int stride,
         int relu, hipStream_t s) {
   Args a;
+  a.lat_in = a.lat_w = a.lat_b = a.lat_add = nullptr;
   a.in = in; a.wfrag = reinterpret_cast<const uint4*>(wfrag); a.bias = bias; a.out = out; a.Cout = Cout; a.H = H; a.W = W;
   a.relu = relu;
   const int pad = k / 2;
@@ -261,6 +329,16 @@ int svs_conv2d_mfma(const float* in, const void* wfrag, const float* bias, float
                     int stride, int relu, void* hip_stream) {
   if (!in || !wfrag || !out || H < 1 || W < 1) { set_error("svs_conv2d_mfma: bad argument"); return SVS_EINVAL; }
   return conv2dmfma::run(in, wfrag, bias, out, Cin, Cout, H, W, k, stride, relu, (hipStream_t)hip_stream);
+}
+
+// The FPN's lateral step fused into the 3x3 layer behind it: out (Cout <= 16, H, W) = relu?(conv3x3(X) + bias) with
+// X[c][y][x] = sum_ci W1[c][ci] lat_in[ci][y][x] + lat_bias[c] + lat_add[c][y / 2][x / 2], c < 32, ci < 8 -- X is formed while
+// the kernel converts its input windows and never exists in memory.  lat_weight: the 1x1 weights (32, 8, 1, 1) in svs_conv2d's
+// packed layout; wfrag: the 3x3 weights (Cout, 32, 3, 3) packed by svs_conv2d_mfma_pack.  H and W even.
+int svs_conv2d_mfma_lateral(const float* lat_in, const float* lat_weight, const float* lat_bias, const float* lat_add,
+                            const void* wfrag, const float* bias, float* out, int Cout, int H, int W, int relu, void* hip_stream) {
+  if (!lat_in || !lat_weight || !lat_add || !wfrag || !out || H < 2 || W < 2) { set_error("svs_conv2d_mfma_lateral: bad argument"); return SVS_EINVAL; }
+  return conv2dmfma::run_lateral(lat_in, lat_weight, lat_bias, lat_add, wfrag, bias, out, Cout, H, W, relu, (hipStream_t)hip_stream);
 }
 
 }  // extern "C"

@@ -348,6 +348,21 @@ def conv2d_mfma(x, weight, bias=None, stride=1, relu=False):
     return out
 
 
+def conv2d_mfma_lateral(lat_in, lat_weight, lat_bias, lat_add, weight, bias=None, relu=False):
+    """The FPN's lateral step fused into the 3x3 layer behind it (svs_conv2d_mfma_lateral): lat_in (8,H,W), lat_weight (32,8,1,1),
+    lat_add (32,H/2,W/2), weight (Cout<=16,32,3,3) -> (Cout,H,W) = relu?(conv3x3(conv1x1(lat_in) + lat_bias + up2(lat_add)) + bias)."""
+    L = _lib.load()
+    lat_in, lat_add = _f32(lat_in), _f32(lat_add)
+    _, H, W = lat_in.shape
+    Cout = weight.shape[0]
+    out = torch.empty(Cout, H, W, device=lat_in.device)
+    lb = _f32(lat_bias) if lat_bias is not None else None
+    bb = _f32(bias) if bias is not None else None
+    _lib.check(L.svs_conv2d_mfma_lateral(_ptr(lat_in), _ptr(conv2d_pack(lat_weight)), _ptr(lb), _ptr(lat_add), _ptr(conv2d_mfma_frag(weight)),
+                                         _ptr(bb), _ptr(out), Cout, H, W, int(bool(relu)), _stream()), "svs_conv2d_mfma_lateral")
+    return out
+
+
 _FPN_MFMA = os.environ.get("SVS_FPN_MFMA", "1") != "0"     # A/B: 0 = every layer of the pyramid on the float32 vector kernels
 # (layer index -> stride) of svs_featurenet_fpn's 13 convolutions
 _FPN_STRIDES = (1, 1, 2, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1)

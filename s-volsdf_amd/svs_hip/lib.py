@@ -107,6 +107,7 @@ SIGNATURES = {
     "svs_conv2d_mfma_wfrag_bytes": (c_size_t, [c_int, c_int, c_int]),
     "svs_conv2d_mfma_pack": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "svs_conv2d_mfma": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "svs_conv2d_mfma_lateral": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "svs_chw_to_hwc": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "svs_fuse_mats_per_src": (c_int, []),
     "svs_cloud_grid_bytes": (c_size_t, [c_int]),

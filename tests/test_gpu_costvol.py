@@ -440,6 +440,30 @@ def test_conv2d_mfma_single_layer(dev, k, stride, Cin, Cout, hw):
     assert not costvol.conv2d_mfma_supported(3, 8, 3, 1) and not costvol.conv2d_mfma_supported(32, 40, 3, 1)
 
 
+@pytest.mark.parametrize("hw,Cout", [((38, 70), 8), ((12, 34), 16), ((264, 528), 8)])
+def test_conv2d_mfma_lateral_fusion(dev, hw, Cout):
+    """svs_conv2d_mfma_lateral (the FPN's inner2 + up-sampled addend formed inside out3's window conversion) == the two
+    launches it replaces, bit for bit: the float32 1x1 kernel with the x2 up-sampled addend, then svs_conv2d_mfma -- and both
+    against float64 torch."""
+    from svs_hip import costvol
+    H, W = hw
+    rs = np.random.default_rng(H + Cout)
+    c0 = rs.standard_normal((8, H, W)).astype(F32)
+    f1 = rs.standard_normal((32, H // 2, W // 2)).astype(F32)
+    w1 = (rs.standard_normal((32, 8, 1, 1)) / np.sqrt(8)).astype(F32)
+    b1 = rs.standard_normal(32).astype(F32)
+    w3 = (rs.standard_normal((Cout, 32, 3, 3)) / np.sqrt(288)).astype(F32)
+    b3 = rs.standard_normal(Cout).astype(F32)
+    f2 = costvol.conv2d(G(c0, dev), G(w1, dev), G(b1, dev), add=G(f1, dev), add_upsample2=True, relu=False)
+    two = costvol.conv2d_mfma(f2, G(w3, dev), G(b3, dev), relu=False)
+    one = costvol.conv2d_mfma_lateral(G(c0, dev), G(w1, dev), G(b1, dev), G(f1, dev), G(w3, dev), G(b3, dev), relu=False)
+    assert torch.equal(one, two)
+    x = torch.nn.functional.conv2d(torch.from_numpy(c0).double()[None], torch.from_numpy(w1).double(), torch.from_numpy(b1).double())
+    x = x + torch.nn.functional.interpolate(torch.from_numpy(f1).double()[None], scale_factor=2, mode="nearest")
+    ref = torch.nn.functional.conv2d(x, torch.from_numpy(w3).double(), torch.from_numpy(b3).double(), padding=1)[0].numpy()
+    np.testing.assert_allclose(one.cpu().numpy(), ref, atol=4e-6 * np.abs(ref).max())
+
+
 @pytest.mark.parametrize("k,stride", [(1, 1), (1, 2), (3, 1), (3, 2), (5, 1), (5, 2)])
 def test_conv2d_single_layer(dev, k, stride):
     """svs_conv2d alone (the entry the fused pyramid call is built from) against torch.nn.functional.conv2d on the CPU:
