@@ -49,6 +49,10 @@ struct SdfBwdBArgs {
   float* absmax;              // [3]: [0] = max |abar| (atomic max)
   // the block holding ghat_7 = W8[0,:] s'(a_7) of a tile is w0 + tile * w0_stride (fg: gbuf block 7, stride 8 blocks)
   const float* w0; size_t w0_stride;
+  // experiment (SVS_BWD_B_REVERSE=1): the workgroups walk the point tiles in DESCENDING order -- pass A, which ran just before,
+  // wrote the highest tiles last (they may still sit in the 256 MB Infinity Cache), and the weight-gradient GEMM that follows
+  // starts at tile 0, which this sweep then finishes last
+  int reverse = 0;
 };
 // gp: the launch's scaled-block format (svs_blocks_h2.h): both fp16 pieces (true) or the hi piece only
 int launch_bg_bwd_b_h2(const SdfBwdBArgs& a, bool gp, hipStream_t s);   // background implicit network: no a2, bg splice rows

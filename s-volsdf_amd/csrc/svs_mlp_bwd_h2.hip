@@ -19,6 +19,7 @@
 #include "svs_mlp_h2_trunk.h"
 #include "svs_mlp_bwd_h2_dev.h"
 #include "svs_ticket.h"
+#include <cstdlib>
 
 namespace svs {
 namespace mlp {
@@ -619,7 +620,8 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_h2_kernel(SdfBwdBArgs a
   Stream st;
   st.g = a.stream; st.buf = reinterpret_cast<f32x4*>(smem); st.cur = 1;
   const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
-  const int wtile = blockIdx.x * kWaves + wave;
+  const int bx = a.reverse ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+  const int wtile = bx * kWaves + wave;
   const int p = wtile * kTilePts + (lane & 31);
   const int pc = p < a.P ? p : a.P - 1;
   st.prefetch<kChunkF4>();
@@ -708,7 +710,7 @@ __global__ __launch_bounds__(kThreads, 1) void sdf_bwd_b_h2_kernel(SdfBwdBArgs a
     const uint64_t k1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     __syncthreads();
     if (threadIdx.x == 0 && a.sbar_out) {     // per tile index: MFMA part x8, wait part x8, last epilogue, total, real time
-      float* o = a.sbar_out + (size_t)blockIdx.x * kWaves * kTilePts;
+      float* o = a.sbar_out + (size_t)bx * kWaves * kTilePts;
       for (int i = 0; i < 17; ++i) o[i] = (float)cyc[i];
       o[17] = (float)(k1 - k0); o[18] = (float)(r1 - r0);
     }
@@ -806,10 +808,13 @@ int launch_sdf_bwd_a_h2(const SdfBwdAArgs& a, bool gp, hipStream_t s) {
   else sdf_bwd_a_h2_kernel<false><<<grid, kThreads, lds, s>>>(a);
   return check_launch("svs_sdf_bwd_a");
 }
-int launch_sdf_bwd_b_h2(const SdfBwdBArgs& a, bool gp, hipStream_t s) {
+int launch_sdf_bwd_b_h2(const SdfBwdBArgs& a_in, bool gp, hipStream_t s) {
   static int once = set_lds(sdf_bwd_b_h2_kernel<NetFg, true, true>, kLdsBytes, "svs_sdf_bwd_b") |
                     set_lds(sdf_bwd_b_h2_kernel<NetFg, true, false>, kLdsBytes, "svs_sdf_bwd_b");
   if (once) return once;
+  static const int reverse_env = [] { const char* e = getenv("SVS_BWD_B_REVERSE"); return e ? atoi(e) : 0; }();
+  SdfBwdBArgs a = a_in;
+  a.reverse = reverse_env;
   const int grid = (a.P + kWgPts - 1) / kWgPts;
   if (gp) sdf_bwd_b_h2_kernel<NetFg, true, true><<<grid, kThreads, kLdsBytes, s>>>(a);
   else sdf_bwd_b_h2_kernel<NetFg, true, false><<<grid, kThreads, kLdsBytes, s>>>(a);

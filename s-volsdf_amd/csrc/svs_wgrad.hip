@@ -245,7 +245,7 @@ struct Job {
   det::Ticket ticket;    // deterministic mode: the workgroups that add into this job's dW columns flush in turn (svs_ticket.h)
 };
 constexpr int kMaxJobs = 20;
-struct MultiArgs { Job job[kMaxJobs]; int n_jobs; int touch; };
+struct MultiArgs { Job job[kMaxJobs]; int n_jobs; int touch; int reverse; };
 static_assert(sizeof(MultiArgs) <= 4096, "kernel arguments");
 
 constexpr int kThreadsW = 512;          // 8 waves: wave w owns output tile w (32 rows) x all B tiles
@@ -288,12 +288,20 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
 
   const int my_tiles = a.n_tiles > wg ? (a.n_tiles - 1 - wg) / nwg + 1 : 0;
   const int n_items = my_tiles * a.n_pairs;
+  // the point tile of an item.  ma.reverse (experiment, SVS_WGRAD_REVERSE=1): the tiles in DESCENDING order -- the sweep that ran
+  // just before this launch wrote and read the highest tiles last, so the GEMM would start on what may still sit in the 256 MB
+  // Infinity Cache
+  const bool rev = ma.reverse != 0;
+  auto tile_of = [&](int item) {
+    const int k = item / a.n_pairs;
+    return rev ? wg + (my_tiles - 1 - k) * nwg : wg + k * nwg;
+  };
 
   // ---- issue the LDS-DMA of one item into its ring slot: wave w copies the 1-KiB fragments w, w + 8 of every plane, its
   // own copy of the scaled operand's record, and (narrow job) quarter w & 3 of the float32 B tile.  Everything goes
   // through LDS-DMA: with no register loads in the loop the only vmcnt waits are the counted ones below.
   auto issue = [&](int item) {
-    const int t = wg + (item / a.n_pairs) * nwg, pi = item % a.n_pairs;
+    const int t = tile_of(item), pi = item % a.n_pairs;
     const Pair& p = a.p[pi];
     const float* pa = p.a + (size_t)t * p.stride_a;
     const float* pb = p.b + (size_t)t * p.stride_b;
@@ -324,7 +332,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
   // stay in flight).
   unsigned sink = 0;
   auto touch = [&](int item) {
-    const int t = wg + (item / a.n_pairs) * nwg, pi = item % a.n_pairs;
+    const int t = tile_of(item), pi = item % a.n_pairs;
     const Pair& p = a.p[pi];
     constexpr int kLines = R::kPlanes * (kPlane / 128);          // 128-byte lines per operand block
     const int nb = narrow ? 32 : kLines;
@@ -339,7 +347,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
   // float32 source quarters were copied by waves 0..3, hence after the barrier
   auto stage_factors = [&](int item) {
     unsigned char* slot = ring + (item % kRing) * kSlotAll;
-    const int t = wg + (item / a.n_pairs) * nwg;
+    const int t = tile_of(item);
     const int live = a.n_valid_points - t * 32;
     float f = 1.0f;
     if (a.absmax) {
@@ -557,6 +565,8 @@ int svs_wgrad_multi(const svs_wgrad_job* jobs, int n_jobs, int precision, void* 
     ma.n_jobs = n;
     static const int touch_env = [] { const char* e = getenv("SVS_WGRAD_TOUCH"); return e ? atoi(e) : 0; }();
     ma.touch = touch_env;
+    static const int reverse_env = [] { const char* e = getenv("SVS_WGRAD_REVERSE"); return e ? atoi(e) : 0; }();
+    ma.reverse = reverse_env;
     // One workgroup per CU in total, at least one per job and no more than a job has tiles; the rest are handed out one at a
     // time to the job whose workgroups carry the most work (the launch lasts as long as its longest workgroup: with jobs of
     // very different sizes -- a step's two ray groups in one launch -- rounding each share on its own left a small job's
