@@ -10,9 +10,9 @@
 // A workgroup only ever waits for workgroups with LOWER block indices of its own launch, which the dispatcher has started
 // before it: no deadlock.  Slower (the flushes of a layer are serialised: +10 ... 20 % per step), which is why it is a mode.
 //
-// Turn counters live in a static device array of this translation unit (no allocation behind the C-ABI); a launch takes the
-// next `n` of them round-robin, so launches in flight on different streams do not share counters unless more than
-// kSlots / n launches are in flight.  Launches that add into the SAME accumulator must be stream-ordered by the caller
+// Turn counters live in a static device array of the launching translation unit (no allocation behind the C-ABI); a launch
+// takes the next `n` of them round-robin, so launches in flight on different streams do not share counters unless more than
+// kSlots / n launches of that translation unit are in flight.  Launches that add into the SAME accumulator must be stream-ordered by the caller
 // (the Python side runs a deterministic step on one stream).
 #pragma once
 #include "svs_common.h"
@@ -50,8 +50,9 @@ __device__ __forceinline__ void pass_turn(const Ticket& t, unsigned rank) {
   }
 }
 
-// host: `n` counters for one launch (nullptr when the mode is off)
-inline unsigned* take_slots(unsigned n) {
+// host: `n` counters for one launch (nullptr when the mode is off).  Internal linkage like g_turn itself: every translation unit
+// that launches ticketed kernels has its own counter array and its own cursor into it.
+static inline unsigned* take_slots(unsigned n) {
   if (!deterministic() || n == 0 || n > kSlots) return nullptr;
   static std::mutex mu;
   static unsigned* base = nullptr;
