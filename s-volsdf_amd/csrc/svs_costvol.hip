@@ -604,6 +604,9 @@ __global__ __launch_bounds__((WarpCfg<C, CPL>::T), (CPL == 4 ? (NS <= 2 ? 4 : 2)
 #else
       warp_taps8<C>(a, v, xt + vx, y, d0 + dz, dep[k], hw, rhw, hh, rhh, w4, o4);
 #endif
+#if SVS_WARP_ABL & 4            // diagnostic: constant corner tables (the projection arithmetic is dead code)
+      w4 = f32x4{0.25f, 0.25f, 0.25f, 0.25f}; o4 = i32x4{0, C * 4, C * 4 * W, C * 4 * (W + 1)};
+#endif
       tapw[dz][v][vx] = w4;
       tapo[dz][v][vx] = o4;
     }
@@ -698,14 +701,19 @@ __global__ __launch_bounds__((WarpCfg<C, CPL>::T), (CPL == 4 ? (NS <= 2 ? 4 : 2)
           w4s[v] = tapw[dz + 1][v][vx];
           const i32x4 o4 = tapo[dz + 1][v][vx];
           // (a voxel's LPV lanes decide alike; a corner outside the image has offset 0 and weight 0)
-          const bool moved = o4[0] != held[v][0] || o4[1] != held[v][1] || o4[2] != held[v][2] || o4[3] != held[v][3];
+          const bool moved = !(SVS_WARP_ABL & 2) &&       // (diagnostic 2: a voxel's corners are never fetched again)
+                             (o4[0] != held[v][0] || o4[1] != held[v][1] || o4[2] != held[v][2] || o4[3] != held[v][3]);
           regather(f[v], o4, lane_off, a.src_hwc[v], __builtin_amdgcn_ballot_w64(moved));
           held[v] = o4;
         }
       } else if (p + 1 < P) {
         first_loads((p + 1) * VPP + vl);
       }
+#if SVS_WARP_ABL & 1            // diagnostic: no stores of the volume (the guard keeps the values alive)
+      const int stored = d < a.D && res[0][0] == 1.2345e-30f;
+#else
       const int stored = d < a.D;                                        // uniform
+#endif
       if (stored && x < W) {
         if (CPL == 8) {
           gstore128(so, __builtin_bit_cast(i32x4, __builtin_shufflevector(h[0], h[Q - 1], 0, 1, 2, 3, 4, 5, 6, 7)), a.split);
