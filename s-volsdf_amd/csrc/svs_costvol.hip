@@ -494,7 +494,15 @@ __device__ __forceinline__ void gstore128(unsigned off, const i32x4& v, void* ba
 }
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void gstore64(unsigned off, const i32x2& v, void* base) {
+#if defined(SVS_WARP_NT_STORES) && SVS_WARP_NT_STORES == 1        // experiments: streaming / system-coherent store hints
+  asm volatile("global_store_dwordx2 %0, %1, %2 nt" :: "v"(off), "v"(v), "s"(base) : "memory");
+#elif defined(SVS_WARP_NT_STORES) && SVS_WARP_NT_STORES == 2
+  asm volatile("global_store_dwordx2 %0, %1, %2 sc0 sc1" :: "v"(off), "v"(v), "s"(base) : "memory");
+#elif defined(SVS_WARP_NT_STORES) && SVS_WARP_NT_STORES == 3
+  asm volatile("global_store_dwordx2 %0, %1, %2 sc1 nt" :: "v"(off), "v"(v), "s"(base) : "memory");
+#else
   asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"(off), "v"(v), "s"(base) : "memory");
+#endif
 }
 // The conditional re-gather of one source's four corners (2 x 16 bytes each) for the lanes of `mask`: exec is narrowed INSIDE
 // the statement and the corner registers are tied operands of straight-line code.  (As `if (moved) f = load(...)` in C++ the
