@@ -492,7 +492,7 @@ def compact_line(full):
         top["peak_basis"] = "mfma: 2500/3 TFLOP/s (fp16x2 = 3 fp16 products); hbm: 8 TB/s" if "fp16" in full["dtype"] else "f32 MFMA 157.3 TFLOP/s; hbm 8 TB/s"
         top["kernels"] = [{"kernel": short(r["kernel"]), "what": r["what"][:48], "bound": r["bound"], "launches_per_step": r["launches_per_step"],
                            "kernel_ms": r["kernel_ms"], "ms_per_step": r["ms_per_step"], "achieved": r["achieved"], "unit": r["unit"],
-                           "frac": r["frac"]} for r in rf["kernels"][:6]]
+                           "frac": r["frac"], **({"hbm_frac": r["hbm_frac"]} if "hbm_frac" in r else {})} for r in rf["kernels"][:6]]
         out["roofline"] = top
     else:
         out["roofline"] = None
@@ -521,9 +521,12 @@ def compact_line(full):
     if rf is not None and any("sdf_full" in r["kernel"] for r in rf["kernels"]):
         # north_star asks >= 0.40 of the MFMA peak on the fused SDF MLP; the measured reason it stops below (ablation builds and
         # cycle stamps of rounds 2 and 5: NOTES/design_history_r01-r05.md section 4; `sdf_full_ablation` in the extras file)
-        out["sdf_full_note"] = ("one 512-register wave per SIMD issues in order: 166-173 cycles per k-step against 98.5 for its three "
-                                "MFMAs (weight LDS-DMA, LDS fragment reads, barrier, epilogue, h/g block loads+stores share the "
-                                "stream) at the 1.65-1.75 GHz the chip holds under fp16 MFMA load; sdf_only (no block traffic): 0.45")
+        out["sdf_full_note"] = ("the training launch runs against TWO rooflines at once: beside its MFMAs it writes 17 and reads 8 "
+                                "activation blocks per point (25.6 KB; PMC: 2.53 GB per launch) = hbm_frac of 8 TB/s, 2.7 TB/s of it "
+                                "writes; one 512-register wave per SIMD issues in order: 166-173 cycles per k-step against 98.5 for "
+                                "its three MFMAs (weight LDS-DMA, LDS fragment reads, barrier, epilogue, the block loads+stores share "
+                                "the stream) at the 1.65-1.75 GHz the chip holds under fp16 MFMA load; sdf_only (no block traffic): "
+                                "0.45 in isolation")
     out["extras_file"] = full.get("extras_file")
     return _r(out)
 
@@ -841,6 +844,11 @@ def kernel_roofline(ts, step, R, S, h2, train, n_steps=12, ray_groups=None):
             r.update(achieved=rate / 1e12, peak=peak / 1e12, unit="TFLOP/s", frac=rate / peak)
         else:
             r.update(achieved=rate / 1e9, peak=PEAK_HBM / 1e9, unit="GB/s", frac=rate / PEAK_HBM)
+        if train and r["entry"] == "svs_sdf_outputs" and bpp.get("svs_sdf_outputs") and r["kernel_ms"] > 0:
+            # the training launch of the fused SDF MLP is priced against the MFMA peak, but it also moves 25 activation blocks
+            # per point (h, ghat, features out; h back in): its second roofline, from the same launch time
+            hb = bpp["svs_sdf_outputs"] * r["points_per_launch"] / (r["kernel_ms"] * 1e-3)
+            r.update(hbm_bytes_per_point=bpp["svs_sdf_outputs"], hbm_GBps=hb / 1e9, hbm_frac=hb / PEAK_HBM)
     rows.sort(key=lambda r: -r["ms_per_step"])
     # HBM traffic per launch: PMC counters of the committed profile of this same command (profiles/, see
     # tools/summarize_profiles.py); the bench itself cannot run the counters
@@ -866,7 +874,8 @@ def kernel_roofline(ts, step, R, S, h2, train, n_steps=12, ray_groups=None):
                         "peak = 2500 / 3 TFLOP/s.  hbm rows: algorithmic bytes = every activation block the launch "
                         "reads or writes, once" if h2 else "dense float32 MFMA peak / HBM3E peak")
     top["kernels"] = [{k: r[k] for k in ("kernel", "what", "bound", "launches_per_step", "kernel_ms", "ms_per_step",
-                                         "points_per_launch", "work_per_point", "achieved", "unit", "frac")} for r in rows]
+                                         "points_per_launch", "work_per_point", "achieved", "unit", "frac",
+                                         "hbm_bytes_per_point", "hbm_GBps", "hbm_frac") if k in r} for r in rows]
     return top
 
 

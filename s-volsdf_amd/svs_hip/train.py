@@ -529,7 +529,9 @@ def algorithmic_bytes_per_point(precision=None):
       svs_sdf_bwd_b   float32: reads h_1..h_8, a2_0..a2_7, ghat_7, fbar; writes abar_0..abar_7
                       fp16x2: reads h_1..h_8 (hi planes in the one-piece mode), u_1..u_8, ghat_0..ghat_7, fbar; writes abar_0..abar_7
       wgrad_sdf       per layer abar_l, h_l (hi plane), ghat_l, u_l (l = 0..7) + fbar, h_8 (hi plane) for lin8
-      wgrad_radiance  zbar_0..zbar_4, r_0..r_3 (hi planes), the feature block (hi plane), the 16 extra input rows"""
+      wgrad_radiance  zbar_0..zbar_4, r_0..r_3 (hi planes), the feature block (hi plane), the 16 extra input rows
+      svs_sdf_outputs (training launch; MFMA-bound, listed for its SECOND roofline) writes h_1..h_8, ghat_0..ghat_7, the
+                      feature block; its reverse sweep reads h_1..h_8 back"""
     precision = default_precision() if precision is None else precision
     if is_h2(precision):
         # F16X2: every block with both pieces (1024 B per point and block); F16X2_HALF: scaled blocks and the planes the
@@ -540,7 +542,9 @@ def algorithmic_bytes_per_point(precision=None):
                 "svs_sdf_bwd_b": 8 * half + 8 * half + 8 * half + half + 8 * half,
                 "wgrad_sdf": 8 * (half + half + half + half) + half + half,
                 "wgrad_radiance": 5 * half + 4 * half + half + 128,
-                "svs_lin8_row0_grad": pair + half}
+                "svs_lin8_row0_grad": pair + half,
+                "svs_sdf_outputs": 8 * pair + 8 * pair + 8 * half + pair}
     blk = 1024
     return {"svs_sdf_bwd_a": (8 + 8 + 9 + 8 + 1) * blk, "svs_sdf_bwd_b": (8 + 8 + 1 + 1 + 8) * blk,
-            "wgrad_sdf": (8 * 4 + 2) * blk, "wgrad_radiance": (5 + 4 + 1) * blk + 128, "svs_lin8_row0_grad": 2 * blk}
+            "wgrad_sdf": (8 * 4 + 2) * blk, "wgrad_radiance": (5 + 4 + 1) * blk + 128, "svs_lin8_row0_grad": 2 * blk,
+            "svs_sdf_outputs": (8 + 8 + 8 + 1) * blk}
