@@ -487,12 +487,13 @@ def compact_line(full):
     if rf is not None:
         short = lambda k: k.split("::")[-1]
         top = {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "what",
-                                  "launches_per_step", "kernel_ms", "ms_per_step", "points_per_launch", "work_per_point") if k in rf}
+                                  "launches_per_step", "kernel_ms", "ms_per_step", "points_per_launch", "work_per_point", "mfma_frac", "hbm_frac") if k in rf}
         top["timing"] = "HIP events on the kernel's launch stream, steps after the timed region"
         top["peak_basis"] = "mfma: 2500/3 TFLOP/s (fp16x2 = 3 fp16 products); hbm: 8 TB/s" if "fp16" in full["dtype"] else "f32 MFMA 157.3 TFLOP/s; hbm 8 TB/s"
         top["kernels"] = [{"kernel": short(r["kernel"]), "what": r["what"][:48], "bound": r["bound"], "launches_per_step": r["launches_per_step"],
                            "kernel_ms": r["kernel_ms"], "ms_per_step": r["ms_per_step"], "achieved": r["achieved"], "unit": r["unit"],
-                           "frac": r["frac"], **({"hbm_frac": r["hbm_frac"]} if "hbm_frac" in r else {})} for r in rf["kernels"][:6]]
+                           "frac": r["frac"], **({"hbm_frac": r["hbm_frac"]} if "hbm_frac" in r else {}),
+                           **({"mfma_frac": r["mfma_frac"]} if "mfma_frac" in r else {})} for r in rf["kernels"][:6]]
         out["roofline"] = top
     else:
         out["roofline"] = None
@@ -802,22 +803,24 @@ def kernel_roofline(ts, step, R, S, h2, train, n_steps=12, ray_groups=None):
             for t, a in zip(ms, metas):
                 jobs = ctypes.cast(a[0], ctypes.POINTER(_lib.WGradJob))
                 n_jobs = int(a[1])
-                nbytes, pts = 0, {}
+                nbytes, nflop, pts = 0, 0, {}
                 for j in range(n_jobs):
                     jb = jobs[j]
                     nbytes += jb.n_points * (operand * (2 + (2 if jb.a1 else 0)) + (128 if jb.b_extra else 0))
+                    # the launch's SECOND roofline: dW[256][256] += A B^T per operand pair (+ 16 columns for the extra rows)
+                    nflop += jb.n_points * 2 * 256 * (256 * (2 if jb.a1 else 1) + (16 if jb.b_extra else 0))
                     slot, rem = divmod((jb.dW or 0) - base, 256 * LDW * 4)
                     net = ("sdf" if slot < 9 else "radiance") if (rem == 0 and 0 <= slot < 14) else "background"
                     pts.setdefault(net, {}).setdefault(slot, 0)
                     pts[net][slot] += jb.n_points
                 # points of a network in this launch = those of its first layer's jobs (one job per ray group)
                 n_pts = {net: v[min(v)] for net, v in pts.items()}
-                kinds.setdefault((tuple(sorted(n_pts)), n_jobs, nbytes, sum(n_pts.values())), []).append(t)
-            for (nets, n_jobs, nbytes, n_pts), tg in kinds.items():
+                kinds.setdefault((tuple(sorted(n_pts)), n_jobs, nbytes, sum(n_pts.values()), nflop), []).append(t)
+            for (nets, n_jobs, nbytes, n_pts, nflop), tg in kinds.items():
                 which = " + ".join(nets)
                 rows.append(dict(entry=name, kernel=(k_h2 if h2 else k_f32), what=f"{what} ({which}: {n_jobs} layer jobs)",
                                  bound=bound, launches_per_step=len(tg) / n_steps, kernel_ms=float(np.mean(tg)),
-                                 points_per_launch=float(n_pts), work_per_point=nbytes / max(n_pts, 1)))
+                                 points_per_launch=float(n_pts), work_per_point=nbytes / max(n_pts, 1), flop_per_launch=float(nflop)))
             continue
         if name in ("svs_rgb_bwd", "svs_sdf_bwd_b"):
             pts = [int(a[0]) for a in metas]
@@ -844,6 +847,12 @@ def kernel_roofline(ts, step, R, S, h2, train, n_steps=12, ray_groups=None):
             r.update(achieved=rate / 1e12, peak=peak / 1e12, unit="TFLOP/s", frac=rate / peak)
         else:
             r.update(achieved=rate / 1e9, peak=PEAK_HBM / 1e9, unit="GB/s", frac=rate / PEAK_HBM)
+        if r.get("flop_per_launch") and r["kernel_ms"] > 0:
+            # the weight-gradient GEMM is priced against HBM (every operand block read once), and it multiplies while it reads:
+            # its algorithmic FLOP against the MFMA peak of the arithmetic, from the same launch time (NOTES/r06.md section 3f:
+            # with the MFMAs compiled out the same copies run at 6.0 TB/s -- what bounds the launch is both at once)
+            mf = r["flop_per_launch"] / (r["kernel_ms"] * 1e-3)
+            r.update(mfma_TFLOPs=mf / 1e12, mfma_frac=mf / (PEAK_F16_MFMA / 3 if h2 else PEAK_F32_MFMA))
         if train and r["entry"] == "svs_sdf_outputs" and bpp.get("svs_sdf_outputs") and r["kernel_ms"] > 0:
             # the training launch of the fused SDF MLP is priced against the MFMA peak, but it also moves 25 activation blocks
             # per point (h, ghat, features out; h back in): its second roofline, from the same launch time
@@ -875,7 +884,8 @@ def kernel_roofline(ts, step, R, S, h2, train, n_steps=12, ray_groups=None):
                         "reads or writes, once" if h2 else "dense float32 MFMA peak / HBM3E peak")
     top["kernels"] = [{k: r[k] for k in ("kernel", "what", "bound", "launches_per_step", "kernel_ms", "ms_per_step",
                                          "points_per_launch", "work_per_point", "achieved", "unit", "frac",
-                                         "hbm_bytes_per_point", "hbm_GBps", "hbm_frac") if k in r} for r in rows]
+                                         "hbm_bytes_per_point", "hbm_GBps", "hbm_frac", "flop_per_launch", "mfma_TFLOPs",
+                                         "mfma_frac") if k in r} for r in rows]
     return top
 
 

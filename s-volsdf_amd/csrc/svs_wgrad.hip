@@ -449,10 +449,15 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
           }
         }
       }
-      // the two waves of a SIMD cover each other's LDS latency: no software pipelining of the B fragments
+      // the two waves of a SIMD cover each other's LDS latency: no software pipelining of the B fragments (requesting tile
+      // i + 1's fragments before tile i's MFMAs, two register sets and a counted lgkmcnt: bit-identical, <= 1 % -- NOTES/r06.md 3f)
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         if (i > 0 && narrow) break;
+#if defined(SVS_WGRAD_DIAG) && (SVS_WGRAD_DIAG & 8)   // diagnostic build: the copies and the barriers only (no B fragment reads, no MFMAs)
+        asm volatile("" :: "v"(ah), "v"(am));
+        continue;
+#endif
         Frag fh, fm;
         if (!narrow) {
           const unsigned rd = lb + 2048 * i + 512 * ks + rd0;
@@ -463,9 +468,13 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
           tr_issue(fm, nimg + kExtraPiece + ks * 1024 + rx0, nimg + kExtraPiece + ks * 1024 + rx1);
         }
         lds_wait();
+#if defined(SVS_WGRAD_DIAG) && (SVS_WGRAD_DIAG & 4)   // diagnostic build: the fragments are read, nothing is multiplied
+        asm volatile("" :: "v"(fh.lo), "v"(fh.hi), "v"(fm.lo), "v"(fm.hi));
+#else
         if (two || GP) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, frag_of(fm), acc[i], 0, 0, 0);
         if (GP) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, frag_of(fh), acc[i], 0, 0, 0);
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, frag_of(fh), acc[i], 0, 0, 0);
+#endif
       }
     }
   }
@@ -480,6 +489,8 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
     for (int r = 0; r < 16; ++r) {
       const int row = 32 * wave + rho(r) + 4 * half;
       const int c = a.col0 + 32 * i + col;
+      // (-DSVS_WGRAD_DIAG=<mask>, tools/dev/ab_defs.sh + tools/dev/time_wgrad.py: 1 no flush, 2 plain stores, 4 fragments read but
+      // nothing multiplied, 8 copies and barriers only; never defined in the product build)
 #if defined(SVS_WGRAD_DIAG) && (SVS_WGRAD_DIAG & 1)   // diagnostic build: no flush (the guard keeps the accumulators alive)
       if (c < a.ldw && acc[i][r] == 1.2345e-31f) a.dW[(size_t)row * a.ldw + c] = acc[i][r];
 #elif defined(SVS_WGRAD_DIAG) && (SVS_WGRAD_DIAG & 2) // diagnostic build: plain stores instead of atomics (wrong sums)
@@ -558,7 +569,11 @@ int svs_wgrad_multi(const svs_wgrad_job* jobs, int n_jobs, int precision, void* 
         X = J;
         X.p[0].b = q.b_extra; X.p[0].stride_b = (size_t)q.s_extra; X.n_pairs = 1;
         X.b_tiles = 1; X.col0 = 256; X.db = nullptr;
-        work[n] = (long long)X.n_tiles * 4;
+        // (a narrow item copies 36 of a wide item's 64 KiB and multiplies one B tile of eight, but an item's time is mostly
+        // the latency of its copy: priced at 4 / 10 of a wide item, as until round 6, its workgroups were the radiance launch's
+        // longest -- 0.33 ms alone; 5 ... 7: 0.29-0.30; 8, 10: 0.30-0.31 (profiles/r06_wgrad_what_bounds_it.txt))
+        static const int narrow_work = [] { const char* e = getenv("SVS_WGRAD_NARROW_WORK"); return e ? atoi(e) : 6; }();
+        work[n] = (long long)X.n_tiles * narrow_work;
         total += work[n++];
       }
     }
