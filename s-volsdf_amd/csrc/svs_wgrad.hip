@@ -286,14 +286,24 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
   const int wp = lane & 31, whf = lane >> 5;
   const int wxoff = 64 * wp + 16 * (wave & 3) + 8 * whf;
 
+  const bool two_pairs = a.n_pairs == 2;               // (1 or 2)
   const int my_tiles = a.n_tiles > wg ? (a.n_tiles - 1 - wg) / nwg + 1 : 0;
-  const int n_items = my_tiles * a.n_pairs;
+  const int n_items = two_pairs ? 2 * my_tiles : my_tiles;
+  const int n_valid = a.n_valid_points;
+  const bool has_db = a.db != nullptr;
   // the point tile of an item.  ma.reverse (experiment, SVS_WGRAD_REVERSE=1): the tiles in DESCENDING order -- the sweep that ran
   // just before this launch wrote and read the highest tiles last, so the GEMM would start on what may still sit in the 256 MB
   // Infinity Cache
   const bool rev = ma.reverse != 0;
+  // (the job's operand pointers and strides in registers: read through `a` -- kernel-argument memory -- inside issue() they were
+  // scalar loads per item, each waited for with lgkmcnt(0), in front of the copies)
+  const float* const pa0 = a.p[0].a; const float* const pb0 = a.p[0].b;
+  const float* const pa1 = a.p[1].a; const float* const pb1 = a.p[1].b;
+  const size_t sa0 = a.p[0].stride_a, sb0 = a.p[0].stride_b, sa1 = a.p[1].stride_a, sb1 = a.p[1].stride_b;
+  const float* const rec0 = a.rec[0]; const float* const rec1 = a.rec[1];
+  const bool has_scale = a.absmax != nullptr;
   auto tile_of = [&](int item) {
-    const int k = item / a.n_pairs;
+    const int k = two_pairs ? item >> 1 : item;
     return rev ? wg + (my_tiles - 1 - k) * nwg : wg + k * nwg;
   };
 
@@ -301,10 +311,9 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
   // own copy of the scaled operand's record, and (narrow job) quarter w & 3 of the float32 B tile.  Everything goes
   // through LDS-DMA: with no register loads in the loop the only vmcnt waits are the counted ones below.
   auto issue = [&](int item) {
-    const int t = tile_of(item), pi = item % a.n_pairs;
-    const Pair& p = a.p[pi];
-    const float* pa = p.a + (size_t)t * p.stride_a;
-    const float* pb = p.b + (size_t)t * p.stride_b;
+    const int t = tile_of(item), pi = two_pairs ? item & 1 : 0;
+    const float* pa = (pi ? pa1 : pa0) + (size_t)t * (pi ? sa1 : sa0);
+    const float* pb = (pi ? pb1 : pb0) + (size_t)t * (pi ? sb1 : sb0);
     unsigned char* slot = ring + (item % kRing) * kSlotAll;
     // (the planes of a block are contiguous in memory and in the slot: piece index 16 = the mid plane's first piece)
 #pragma unroll
@@ -320,8 +329,8 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
       __builtin_amdgcn_global_load_lds((gvoid)(reinterpret_cast<const f32x4*>(pb) + (wave & 3) * 64 + lane),
                                        SVS_LDS(void, slot + kB + (wave & 3) * 1024), 16, 0, 0);
     // scale record of the scaled operand: pair 0 scales A (abar-like), pair 1 B (u); applied to A either way
-    if (a.absmax)
-      __builtin_amdgcn_global_load_lds((gvoid)(a.rec[pi] + (size_t)t * 64 + lane),
+    if (has_scale)
+      __builtin_amdgcn_global_load_lds((gvoid)((pi ? rec1 : rec0) + (size_t)t * 64 + lane),
                                        SVS_LDS(void, slot + kSlot + wave * 256), 4, 0, 0);
   };
   // ---- L2 prefetch of the item AFTER the one being copied (GP ring: 2 slots of 64 KiB fill the LDS, so only ONE item can be
@@ -332,7 +341,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
   // stay in flight).
   unsigned sink = 0;
   auto touch = [&](int item) {
-    const int t = tile_of(item), pi = item % a.n_pairs;
+    const int t = tile_of(item), pi = two_pairs ? item & 1 : 0;
     const Pair& p = a.p[pi];
     constexpr int kLines = R::kPlanes * (kPlane / 128);          // 128-byte lines per operand block
     const int nb = narrow ? 32 : kLines;
@@ -341,16 +350,16 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
     if (tid < kLines + nb) asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(q) : "memory");
   };
   // number of vector-memory operations issue() makes per wave and item
-  const int ops = (narrow ? 2 * R::kPlanes + 1 : 4 * R::kPlanes) + (a.absmax ? 1 : 0);
+  const int ops = (narrow ? 2 * R::kPlanes + 1 : 4 * R::kPlanes) + (has_scale ? 1 : 0);
 
   // ---- per-item set-up once the wave's own copies have landed: its factor table; (narrow job) the fp16 B image -- whose
   // float32 source quarters were copied by waves 0..3, hence after the barrier
   auto stage_factors = [&](int item) {
     unsigned char* slot = ring + (item % kRing) * kSlotAll;
     const int t = tile_of(item);
-    const int live = a.n_valid_points - t * 32;
+    const int live = n_valid - t * 32;
     float f = 1.0f;
-    if (a.absmax) {
+    if (has_scale) {
       // s / s_p: the record is a power of two in [2^-107, 2^107] (PointScale::pow2_for); anything else (a block that
       // was never written) leaves the factor at 1
       float rec;
@@ -360,7 +369,8 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
       if (eb >= 20 && eb <= 240) f = __builtin_fminf(s_grad * __uint_as_float((254u << 23) - __float_as_uint(rec)), 32768.0f);
     }
     if (wp >= live) f = 0.0f;
-    if (lane < 32) *SVS_LDS(_Float16, slot + kSlot + kRecBytes + wave * 64 + 2 * lane) = (_Float16)f;
+    // (inline assembly: a store hipcc can see is made to wait for every LDS-DMA in flight)
+    if (lane < 32) asm volatile("ds_write_b16 %0, %1" :: "v"(lds_addr(slot + kSlot + kRecBytes + wave * 64 + 2 * lane)), "v"((_Float16)f) : "memory");
   };
   auto stage_narrow = [&](int item) {
     unsigned char* slot = ring + (item % kRing) * kSlotAll;
@@ -387,47 +397,77 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
   const bool touching = GP && ma.touch;
   bool touched = false;                  // a touch is the youngest outstanding operation of this wave
   if (touching && kAhead < n_items) { touch(kAhead); touched = true; }
+  // ---- what a wave does for item `it` once its own copies of it have landed: its factor table.  The wait names how many
+  // operations of later items (up to kAhead - 1 of them) may stay outstanding.  (Doing this for item + 1 in front of the last two
+  // B tiles of item, so that the table's LDS round trip overlaps the other wave's MFMAs: measured equal or slower, 787-791
+  // against 777-786 us alone -- the copy is barely ahead of the multiply phase and the early wait sometimes stalls.)
+  auto pre_stage = [&](int it) {
+    const int left = n_items - 1 - it;
+    const int later = (left < kAhead - 1 ? left : kAhead - 1) * ops;        // 0, ops or 2 ops: 0, 3, 4, 5, 6, 8, 10 (GP: 0)
+    if (later == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (later == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (later == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (later == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if (later == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (later == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (touched) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");       // (GP: later == 0; the touch stays in flight)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stage_factors(it);
+  };
   for (int item = 0; item < n_items; ++item) {
-    const int pi = item % a.n_pairs;
+    const int pi = two_pairs ? item & 1 : 0;
     const bool p0 = pi == 0;
-    // the item's own operations are the oldest outstanding ones of this wave: wait until only those of the later items
-    // (up to kAhead - 1 of them) remain; then everybody's have landed after the barrier -- which also says that every wave
-    // is done with the slot of item - 1, the one item + kAhead is about to be copied into
-    {
-      const int left = n_items - 1 - item;
-      const int later = (left < kAhead - 1 ? left : kAhead - 1) * ops;        // 0, ops or 2 ops: 0, 3, 4, 5, 6, 8, 10 (GP: 0)
-      if (later == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-      else if (later == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (later == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else if (later == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-      else if (later == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else if (later == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      else if (touched) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");       // (GP: later == 0; the touch stays in flight)
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    // the item's own operations are the oldest outstanding ones of this wave; once every wave has waited for its own, everybody's
+    // have landed behind the barrier -- which also says that every wave is done with the slot of item - 1, the one
+    // item + kAhead is about to be copied into
+    pre_stage(item);
     // (raw s_barrier: __syncthreads() carries a fence that hipcc lowers to vmcnt(0), which would also wait for the
     // next item's copies)
-    stage_factors(item);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (narrow) {
       stage_narrow(item);
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    if (item + kAhead < n_items) issue(item + kAhead);
-    touched = false;
-    if (touching && item + kAhead + 1 < n_items) { touch(item + kAhead + 1); touched = true; }
+    auto issue_next = [&]() {
+      if (item + kAhead < n_items) issue(item + kAhead);
+      touched = false;
+      if (touching && item + kAhead + 1 < n_items) { touch(item + kAhead + 1); touched = true; }
+    };
+#ifdef SVS_WGRAD_A_SERIAL
+    issue_next();
+#endif
     const unsigned la = lds_addr(ring + (item % kRing) * kSlotAll);
     const unsigned lb = la + kB;
     const unsigned ftab = la + kSlot + kRecBytes + wave * 64;
     const unsigned nimg = lb + kNarrowImg;
-    const bool want_bias = a.db && p0;
+    const bool want_bias = has_db && p0;
     const bool two = narrow;             // only the narrow float32 tile is split into two pieces
+#ifndef SVS_WGRAD_A_SERIAL
+    // The A fragments of BOTH contraction k-steps (hi and mid pieces, their factors) are requested together, the next item's
+    // copies are issued behind the requests, and the fragments are waited for once: the item period is the multiply phase plus
+    // what precedes it serially in every wave (section 3f of NOTES/r06.md), and the form before (-DSVS_WGRAD_A_SERIAL: copies
+    // first, then per k-step hi then mid, a full LDS round trip each) put four round trips there.
+    Frag fa2[2], fam2[2];
+    f32x4 fraw2[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
+      tr_issue(fa2[ks], la + 512 * ks + a_rd, la + 512 * ks + (a_rd ^ 128));
+      if (GP) tr_issue(fam2[ks], la + kPlane + 512 * ks + a_rd, la + kPlane + 512 * ks + (a_rd ^ 128));
+      lds_read128(fraw2[ks], ftab + 32 * ks + 16 * rh);   // the factors of the fragment's 8 points (16 ks + 8 half + 0..7)
+    }
+    issue_next();        // (the next item's copies are issued while these reads are on their way)
+    lds_wait();
+#endif
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#ifndef SVS_WGRAD_A_SERIAL
+      const f16x8 ah = frag_of(fa2[ks]) * __builtin_bit_cast(f16x8, fraw2[ks]);
+      const f16x8 am = GP ? frag_of(fam2[ks]) * __builtin_bit_cast(f16x8, fraw2[ks]) : ah;
+#else
       Frag fa;
       f32x4 fraw;
       tr_issue(fa, la + 512 * ks + a_rd, la + 512 * ks + (a_rd ^ 128));
-      lds_read128(fraw, ftab + 32 * ks + 16 * rh);        // the factors of the fragment's 8 points (16 ks + 8 half + 0..7)
+      lds_read128(fraw, ftab + 32 * ks + 16 * rh);
       lds_wait();
       const f16x8 ah = frag_of(fa) * __builtin_bit_cast(f16x8, fraw);
       f16x8 am = ah;
@@ -437,6 +477,7 @@ __global__ __launch_bounds__(kThreadsW, 1) void wgrad_h2_multi_kernel(MultiArgs 
         lds_wait();
         am = frag_of(fam) * __builtin_bit_cast(f16x8, fraw);
       }
+#endif
       if (want_bias) {
         // row sums of A: the fragment holds 8 points of row lane & 31 (the other lane half holds the other 8)
 #pragma unroll
